@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the se2lam hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Metric (BASELINE.json): BA Gauss-Newton/LM iterations per second on the 200-keyframe /
+20k-landmark synthetic SE(2) graph (config 4 formulation = Map::loadLocalGraph applied to a
+whole-map window), plus ORB extract+match frames/s at 640x480 reported in the
+`orb` object of the same JSON line.
+
+A "step" is ONE LM outer iteration (linearise -> Schur reduction -> dense pose solve ->
+back-substitution/update -> chi^2, incl. any retry trials) of the reference's protocol
+optimize(10) (Config::LOCAL_ITER, LocalMapper.cpp:260): K steps = ceil(K/10) optimize() calls on
+the graph resident in HBM, estimates reset (device-to-device) before each call.
+N>1: landmarks are sharded over the ranks (poses replicated), the fused buffer [S | b | scalars]
+is summed with one RCCL all-reduce per LM trial (+ one 4-double all-reduce for the trial cost);
+total work is fixed -> "scaling": "strong".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+ITERS_PER_CALL = 10    # Config::LOCAL_ITER of the synthetic setup
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--kf", type=int, default=200)
+    ap.add_argument("--landmarks", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--orb-batch", type=int, default=64)
+    ap.add_argument("--orb-steps", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    from se2lam_amd import capi, synth
+    from se2lam_amd.optimizer import SlamOptimizer
+
+    if capi.device_count() == 0:
+        raise SystemExit("bench.py needs a GPU: libse2gpu has no CPU fallback")
+
+    dist = None
+    torch = None
+    red_tensor = None
+    if world > 1:
+        import torch  # plumbing only: device selection, RCCL process group, the all-reduced tensor
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    capi.check(capi.lib().se2gpu_set_device(local_rank if world > 1 else 0))
+
+    def sync_all():
+        capi.check(capi.lib().se2gpu_device_synchronize())
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    # ---------------- workload: BA graph resident in HBM ----------------
+    g_full = synth.ba_graph(args.kf, args.landmarks)
+    g = g_full.shard(rank, world)
+    opt = SlamOptimizer()
+    if world > 1:
+        n_red = opt.reduce_buffer_doubles(g.P)
+        red_tensor = torch.zeros(n_red, dtype=torch.float64, device="cuda")
+        base = red_tensor.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+        opt.set_stream(stream)
+        opt.set_shard(rank, world)
+
+        def allreduce(ptr, count, _stream):
+            off = (ptr - base) // 8
+            assert 0 <= off and off + count <= n_red and (ptr - base) % 8 == 0
+            dist.all_reduce(red_tensor[off:off + count], op=dist.ReduceOp.SUM)
+
+        opt.set_allreduce(allreduce, buffer_ptr=base)
+    opt.load(g)
+    opt.initializeOptimization(0)
+
+    def run_steps(k):
+        done = 0
+        trials = 0
+        while done < k:
+            it = min(ITERS_PER_CALL, k - done)
+            opt.reset_estimates()
+            got = opt.optimize(it)
+            if got != it:
+                raise SystemExit(f"LM stopped after {got}/{it} iterations: {opt.stats}")
+            trials += opt.stats["trials"]
+            done += it
+        return trials
+
+    run_steps(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    trials = run_steps(args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    iters_per_s = args.steps / dt
+    chi2_final = opt.stats["chi2_final"]
+
+    # ---------------- per-kernel durations with HIP events on the kernels' stream ----------------
+    # Same K steps again with an event pair around every launch (serialises the stream, so it is a
+    # separate pass and not the timed region above).
+    opt.profile(True)
+    run_steps(min(args.steps, 50))
+    sync_all()
+    prof = opt.profile_report()
+    opt.profile(False)
+    kern = {k: {"avg_us": 1e3 * ms / max(n, 1), "launches": n, "total_ms": ms} for k, (ms, n) in prof.items()}
+    dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+    B_ba = g_full.algorithmic_bytes_per_iter()
+    B_ba_rank = g.algorithmic_bytes_per_iter()
+    roofline = None
+    if dom is not None:
+        avg_s = kern[dom]["avg_us"] * 1e-6
+        achieved = B_ba_rank / avg_s / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": B_ba_rank, "avg_launch_us": kern[dom]["avg_us"],
+            "whole_step_achieved": B_ba * iters_per_s / 1e9,
+            "whole_step_frac": B_ba * iters_per_s / 1e9 / HBM_PEAK_GBS,
+            "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},
+        }
+
+    # ---------------- ORB leg (frames/s) ----------------
+    orb_obj = None
+    if not args.no_orb:
+        try:
+            from se2lam_amd import orb_bench
+            orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch,
+                                    cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        except ImportError:
+            orb_obj = None
+
+    # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        oracle.lib()
+        t1 = time.perf_counter()
+        n_it = 0
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            _, _, st = oracle.ba_optimize(g_full, ITERS_PER_CALL, 0)
+            n_it += st["iterations"]
+        cdt = time.perf_counter() - t1
+        cpu = {"value": n_it / cdt, "unit": "iters/s", "cores": 1, "kind": "port",
+               "sample": f"{n_it} LM iterations ({n_it // ITERS_PER_CALL} x optimize(10)) of the same "
+                         f"{g_full.P} KF / {g_full.L} landmark / {g_full.E} edge graph, oracle/ba_ref.cpp, 1 thread",
+               "host": _host_desc()}
+
+    if rank == 0:
+        out = {
+            "metric": "BA GN-iters/s (200 KF, 20k pts)", "value": iters_per_s, "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"globalBA-window {g_full.P} KF / {g_full.L} landmarks / {g_full.E} EdgeSE2XYZ "
+                                   f"+ {g_full.O} PreEdgeSE2, LM optimize(10) (config 4 formulation, SURVEY D3)",
+                       "parallelism": f"landmark-sharded x{world}, RCCL all-reduce of [S|b]" if world > 1 else "single GPU",
+                       "lm_trials_per_step": trials / args.steps, "chi2_final": chi2_final},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "orb": orb_obj,
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _host_desc():
+    model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu": model}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+/* se2gpu.h - C ABI of the MI355X-native se2lam hot path (libse2gpu.so).
+ *
+ * The reference (izhengfan/se2lam) has no plugin / FFI layer: the boundary of its hot path
+ * is three C++ header surfaces.  This C ABI is what a binding for those
+ * surfaces calls; include/se2lam_amd/{ORBextractor,ORBmatcher,optimizer}.h are header-only C++
+ * adapters over it that keep the reference's names and argument meaning.
+ *
+ * Conventions: every function returns an int status (SE2GPU_OK = 0, negative = error) and never
+ * throws; the caller owns all host buffers; a handle owns its device memory and HIP stream and is
+ * NOT thread-safe (one handle per calling thread, as the reference uses one ORBextractor per
+ * thread and one SlamOptimizer per localBA call).  There is no CPU fallback: without a visible
+ * gfx950 device every compute entry point returns SE2GPU_ERR_NO_DEVICE.
+ */
+#ifndef SE2GPU_H
+#define SE2GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE2GPU_OK 0
+#define SE2GPU_ERR_INVALID (-1)    /* bad argument / handle / id                      */
+#define SE2GPU_ERR_NO_DEVICE (-2)  /* no HIP device (the library has no CPU fallback)  */
+#define SE2GPU_ERR_HIP (-3)        /* a HIP runtime call failed; see se2gpu_last_error */
+#define SE2GPU_ERR_CAPACITY (-4)   /* an internal or caller-supplied capacity overflowed */
+#define SE2GPU_ERR_STATE (-5)      /* call sequence error (e.g. optimize before initialize) */
+
+const char* se2gpu_last_error(void);    /* thread-local message of the last failing call */
+int se2gpu_device_count(void);          /* number of visible HIP devices (0 = none)      */
+const char* se2gpu_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor  -  replaces se2lam::ORBextractor
+ *   ctor          /root/reference/include/se2lam/ORBextractor.h:44, src/ORBextractor.cpp:463-520
+ *   operator()    /root/reference/include/se2lam/ORBextractor.h:49-51, src/ORBextractor.cpp:727-788
+ * ------------------------------------------------------------------------------------------ */
+typedef struct se2gpu_orb se2gpu_orb;
+
+typedef struct se2gpu_orb_params {   /* defaults of ORBextractor.h:44 */
+    int32_t nfeatures;     /* 1000 */
+    float scale_factor;    /* 1.2f */
+    int32_t nlevels;       /* 8    */
+    int32_t score_type;    /* 1 = FAST_SCORE (0 = HARRIS_SCORE is rejected: dormant in the reference) */
+    int32_t fast_th;       /* 20   */
+    int32_t max_rows, max_cols;  /* largest image the handle will see (0,0 -> 480,640) */
+    int32_t max_batch;     /* frames per batched call (0 -> 1) */
+} se2gpu_orb_params;
+
+/* Layout-compatible with cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct se2gpu_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} se2gpu_keypoint;
+
+int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out);
+void se2gpu_orb_destroy(se2gpu_orb* h);
+int se2gpu_orb_levels(const se2gpu_orb* h);            /* GetLevels()      ORBextractor.h:53 */
+float se2gpu_orb_scale_factor(const se2gpu_orb* h);    /* GetScaleFactor() ORBextractor.h:56 */
+
+/* operator()(image, mask, keypoints, descriptors): `img` is a rows x cols CV_8UC1 host image with
+ * row pitch `step`; `mask` must be NULL (the reference always passes an empty mask, Frame.cpp:25).
+ * Writes up to `cap` keypoints / cap*32 descriptor bytes, *n_out = number of keypoints.
+ * An empty image (rows==0 || cols==0) returns OK with *n_out = 0 (ORBextractor.cpp:730-731). */
+int se2gpu_orb_extract(se2gpu_orb* h, const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
+                       se2gpu_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched, device-resident form used for throughput (frames are independent):
+ * d_imgs  = nframes contiguous rows x cols u8 images already in HBM (pitch = cols);
+ * d_kps   = nframes * cap keypoints, d_desc = nframes * cap * 32 bytes, d_counts = nframes ints (device).
+ * Asynchronous on the handle's stream; se2gpu_orb_sync() waits for it. */
+int se2gpu_orb_extract_batch_device(se2gpu_orb* h, const uint8_t* d_imgs, int nframes, int rows, int cols,
+                                    se2gpu_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap);
+int se2gpu_orb_sync(se2gpu_orb* h);
+int se2gpu_orb_set_stream(se2gpu_orb* h, void* hip_stream);  /* NULL -> the handle's own stream */
+
+/* Introspection for the parity tests: copies pyramid level `level` of frame `frame` of the last call
+ * (un-blurred if blurred==0) into `out` (rows*cols of that level, tight pitch); rows and cols are set. */
+int se2gpu_orb_debug_level(se2gpu_orb* h, int frame, int level, int blurred, uint8_t* out, size_t out_cap,
+                           int* rows, int* cols);
+/* FAST score map S of a level of the last call, same geometry as the level. */
+int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, size_t out_cap, int* rows, int* cols);
+
+/* ------------------------------------------------------------------------------------------
+ * ORB matcher  -  replaces se2lam::ORBmatcher
+ *   DescriptorDistance   /root/reference/src/ORBmatcher.cpp:110-126
+ *   MatchByWindow        /root/reference/src/ORBmatcher.cpp:278-381   (+ Frame::GetFeaturesInArea,
+ *                        PosInGrid: /root/reference/src/Frame.cpp:209-286)
+ *   MatchByProjection    /root/reference/src/ORBmatcher.cpp:383-454
+ * ------------------------------------------------------------------------------------------ */
+int se2gpu_hamming(const uint8_t* a, const uint8_t* b);  /* host utility, 256-bit Hamming distance */
+
+typedef struct se2gpu_matcher se2gpu_matcher;
+int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out);
+void se2gpu_matcher_destroy(se2gpu_matcher* h);
+int se2gpu_matcher_set_stream(se2gpu_matcher* h, void* hip_stream);
+int se2gpu_matcher_sync(se2gpu_matcher* h);
+
+/* Image bounds / grid of Frame (Frame.cpp:37-44): minX,minY,maxX,maxY of the undistorted image. */
+typedef struct se2gpu_frame_bounds {
+    float min_x, min_y, max_x, max_y;
+} se2gpu_frame_bounds;
+
+/* MatchByWindow(frame1, frame2, vbPrevMatched, winSize, vnMatches12, levelOffset, minLevel, maxLevel)
+ * with ORBmatcher(nnratio, checkOri=true).  Host buffers.  prev_xy (n1 x 2 floats) is updated in place
+ * as the reference updates vbPrevMatched (ORBmatcher.cpp:375-377).  matches12: n1 ints (-1 = none).
+ * Returns the match count in *n_matches. */
+int se2gpu_match_window(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds,
+                        const se2gpu_keypoint* kps1, const uint8_t* desc1, int n1,
+                        const se2gpu_keypoint* kps2, const uint8_t* desc2, int n2,
+                        float* prev_xy, int win_size, int level_offset, int min_level, int max_level,
+                        float nnratio, int32_t* matches12, int* n_matches);
+
+/* Batched device-resident MatchByWindow over `npairs` independent frame pairs.  Pair p matches
+ * frame a[p] against frame b[p] of the same device arrays the batched extractor wrote
+ * (d_kps: nframes*cap, d_desc: nframes*cap*32, d_counts: nframes).  prev_xy = keypoint positions of
+ * frame a (Track::resetLocalTrack, Track.cpp:194).  d_matches12: npairs*cap ints, d_nmatches: npairs. */
+int se2gpu_match_window_batch_device(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds,
+                                     const se2gpu_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_counts,
+                                     int cap, const int32_t* d_pair_a, const int32_t* d_pair_b, int npairs,
+                                     int win_size, int level_offset, int min_level, int max_level, float nnratio,
+                                     int32_t* d_matches12, int32_t* d_nmatches);
+
+/* MatchByProjection(pNewKF, localMPs, winSize, levelOffset, vMatchesIdxMP) with ORBmatcher(nnratio).
+ *  map points: mp_pos (m x 3 float, world), mp_desc (m x 32), mp_octave (m), mp_skip (m; 1 = the
+ *  reference would `continue` at ORBmatcher.cpp:392-395: null / bad parallax / already observed);
+ *  key frame:  Tcw (3x4 row-major float), K = fx, fy, cx, cy (float), kps/desc (n),
+ *  kf_observed (n; 1 = hasObservation(idx), ORBmatcher.cpp:417).
+ *  match_idx_mp: n ints (index into the map-point array, -1 = none). */
+int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds,
+                            const float* mp_pos, const uint8_t* mp_desc, const int32_t* mp_octave,
+                            const uint8_t* mp_skip, int m,
+                            const float* Tcw, float fx, float fy, float cx, float cy,
+                            const se2gpu_keypoint* kps, const uint8_t* desc, const uint8_t* kf_observed, int n,
+                            int win_size, int level_offset, float nnratio, int32_t* match_idx_mp, int* n_matches);
+
+/* ------------------------------------------------------------------------------------------
+ * SE(2)-XYZ bundle adjustment  -  replaces the g2o::SparseOptimizer built by
+ *   LocalMapper::localBA          /root/reference/src/LocalMapper.cpp:232-302
+ *   Map::loadLocalGraph           /root/reference/src/Map.cpp:891-1053
+ * through the free functions of  /root/reference/include/se2lam/optimizer.h:
+ *   addCamPara (:85) addVertexSE2 (:104) addVertexSBAXYZ (:91) addEdgeSE2XYZ (:100) addEdgeSE2 (:109)
+ *   estimateVertexSE2 (:107) estimateVertexSBAXYZ (:141) initOptimizer (:78)
+ * and SlamOptimizer::{setForceStopFlag, initializeOptimization, optimize, clear}.
+ * Vertex ids are the caller's (Map.cpp:925,966,985); poses and landmarks share one id space.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct se2gpu_ba se2gpu_ba;
+
+typedef struct se2gpu_ba_stats {
+    int32_t iterations;   /* outer iterations executed (SparseOptimizer::optimize return value) */
+    int32_t trials;       /* LM trials = linear solves */
+    int32_t terminated;   /* 1 = algorithm returned Terminate (10 failed trials or rho == 0)   */
+    int32_t stopped;      /* 1 = left early because *stop_flag became true */
+    double chi2_init, chi2_final, lambda_final;
+    double chi2_hist[64], lambda_hist[64];
+    int32_t trials_hist[64];
+} se2gpu_ba_stats;
+
+int se2gpu_ba_create(se2gpu_ba** out);
+void se2gpu_ba_destroy(se2gpu_ba* h);
+int se2gpu_ba_clear(se2gpu_ba* h);                                   /* optimizer.clear(); clearParameters() */
+int se2gpu_ba_set_stream(se2gpu_ba* h, void* hip_stream);
+int se2gpu_ba_add_cam(se2gpu_ba* h, double f, double cx, double cy);  /* addCamPara: single focal length */
+int se2gpu_ba_set_Tbc(se2gpu_ba* h, const double R[9], const double t[3]); /* setExtParameter(Tbc), row-major R */
+int se2gpu_ba_add_vertex_se2(se2gpu_ba* h, int id, double x, double y, double theta, int fixed);
+int se2gpu_ba_add_vertex_xyz(se2gpu_ba* h, int id, const double xyz[3], int marginal, int fixed);
+int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double uv[2], const double info[4],
+                              double huber_delta);
+int se2gpu_ba_add_edge_se2(se2gpu_ba* h, int id0, int id1, const double meas[3], const double info[9]);
+
+/* Bulk form of the same calls (SoA arena filled once per key frame):
+ * vertex ids: poses 0..P-1, landmarks P..P+L-1.  e_info: E x 3 (xx, xy, yy).  o_info: O x 9. */
+int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O,
+                   const double* poses, const uint8_t* fixed, const double* lms,
+                   const int32_t* e_kf, const int32_t* e_lm, const double* e_uv, const double* e_info,
+                   const int32_t* o_i, const int32_t* o_j, const double* o_meas, const double* o_info,
+                   double huber_delta);
+
+/* initializeOptimization(0): freezes the graph, builds the device-side SoA + reduction plans. */
+int se2gpu_ba_initialize(se2gpu_ba* h);
+/* restores every vertex estimate to the value it was added with (device-to-device) */
+int se2gpu_ba_reset_estimates(se2gpu_ba* h);
+
+#define SE2GPU_BA_LM 0  /* OptimizationAlgorithmLevenberg, g2o policy (optimizer.h:32) */
+#define SE2GPU_BA_GN 1  /* plain Gauss-Newton: lambda = 0, every step accepted           */
+/* optimize(iters); stop_flag mirrors setForceStopFlag(bool*) (LocalMapper.cpp:246), may be NULL. */
+int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
+                       se2gpu_ba_stats* stats);
+int se2gpu_ba_get_se2(se2gpu_ba* h, int id, double xyt[3]);   /* estimateVertexSE2   */
+int se2gpu_ba_get_xyz(se2gpu_ba* h, int id, double xyz[3]);   /* estimateVertexSBAXYZ */
+int se2gpu_ba_get_all(se2gpu_ba* h, double* poses /*P*3, in pose-add order*/, double* lms /*L*3*/);
+double se2gpu_ba_chi2(se2gpu_ba* h);                          /* activeRobustChi2() at the current estimate; <0 on error */
+
+/* Parity introspection: reduced (Schur) system at the current estimate and damping `lambda`:
+ * S (3P x 3P row-major, fixed poses -> identity rows), bs (3P).  P counts poses in add order. */
+int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs);
+
+/* Multi-GPU (landmark-sharded) BA, SURVEY.md §8e: every rank holds all poses and a shard of the
+ * landmarks (+ their edges); odometry edges live on one rank.  Once per LM trial the library calls
+ *     allreduce(dev_ptr, count_doubles, hip_stream, user)
+ * which must sum `count_doubles` FP64 values in place over all ranks, ordered on `hip_stream`
+ * (RCCL ncclAllReduce(ncclDouble, ncclSum), or torch.distributed.all_reduce on a tensor that
+ * aliases the buffer).  The fused buffer is [S (3P*3P) | bs (3P) | 4 scalars]; a second call
+ * reduces the 4 trial scalars.  If `buffer` is non-NULL it must be a device allocation of at least
+ * se2gpu_ba_reduce_buffer_doubles(h) doubles, used instead of an internal one (so the caller can
+ * alias it with its own tensor). */
+typedef int (*se2gpu_allreduce_fn)(void* dev_ptr, size_t count_doubles, void* hip_stream, void* user);
+size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba* h, int P);
+int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, void* buffer);
+/* This handle holds landmark shard `rank` of `world` (rank 0 owns the odometry edges and the
+ * lambda*I / fixed-pose identity terms, which must enter the sum exactly once). */
+int se2gpu_ba_set_shard(se2gpu_ba* h, int rank, int world);
+
+/* Host-side landmark partition ("sharded by keyframe window"): owner[l] in [0, world) for the
+ * L landmarks of a graph given by its edge lists.  Pure host code (no device needed). */
+int se2gpu_ba_shard_landmarks(int L, int E, const int32_t* e_kf, const int32_t* e_lm, int world, int32_t* owner);
+
+/* ------------------------------------------------------------------------------------------
+ * Timing helpers for bench.py: HIP events on the stream the kernels are launched on.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct se2gpu_timer se2gpu_timer;
+int se2gpu_timer_create(se2gpu_timer** out);
+void se2gpu_timer_destroy(se2gpu_timer* t);
+int se2gpu_timer_start(se2gpu_timer* t, void* hip_stream);
+int se2gpu_timer_stop(se2gpu_timer* t, void* hip_stream);
+int se2gpu_timer_elapsed_ms(se2gpu_timer* t, float* ms);  /* synchronises on the stop event */
+void* se2gpu_orb_stream(se2gpu_orb* h);
+void* se2gpu_matcher_stream(se2gpu_matcher* h);
+void* se2gpu_ba_stream(se2gpu_ba* h);
+/* Per-kernel accumulated device time (ms) / launch count since the last reset, measured with HIP
+ * events around every launch when profiling is enabled on the handle (adds sync overhead). */
+int se2gpu_ba_profile(se2gpu_ba* h, int enable);
+int se2gpu_ba_profile_get(se2gpu_ba* h, int idx, const char** name, double* ms, int64_t* launches);
+int se2gpu_orb_profile(se2gpu_orb* h, int enable);
+int se2gpu_orb_profile_get(se2gpu_orb* h, int idx, const char** name, double* ms, int64_t* launches);
+
+/* Raw device memory helpers so a non-torch caller (and the tests) can stage device buffers. */
+int se2gpu_malloc(void** dev_ptr, size_t bytes);
+int se2gpu_free(void* dev_ptr);
+int se2gpu_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int se2gpu_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int se2gpu_device_synchronize(void);
+int se2gpu_set_device(int ordinal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE2GPU_H */

@@ -1,0 +1,180 @@
+"""ctypes loader for the CPU oracle (oracle/_build/liboracle.so).
+
+ORACLE - TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from se2lam_amd/ (the product path).
+PARITY UNPINNED - see the headers of oracle/*.cpp and DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _declare(_lib)
+    return _lib
+
+
+def _p(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty))
+
+
+# --------------------------------------------------------------------------------------
+# BA
+# --------------------------------------------------------------------------------------
+class BaProblem(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("L", C.c_int32), ("E", C.c_int32), ("O", C.c_int32),
+        ("poses", C.POINTER(C.c_double)), ("fixed", C.POINTER(C.c_uint8)), ("lms", C.POINTER(C.c_double)),
+        ("e_kf", C.POINTER(C.c_int32)), ("e_lm", C.POINTER(C.c_int32)),
+        ("e_uv", C.POINTER(C.c_double)), ("e_info", C.POINTER(C.c_double)),
+        ("o_i", C.POINTER(C.c_int32)), ("o_j", C.POINTER(C.c_int32)),
+        ("o_meas", C.POINTER(C.c_double)), ("o_info", C.POINTER(C.c_double)),
+        ("fx", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("Rbc", C.c_double * 9), ("tbc", C.c_double * 3), ("huber", C.c_double),
+    ]
+
+
+class BaStats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
+        ("chi2_init", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+        ("chi2_hist", C.c_double * 64), ("lambda_hist", C.c_double * 64), ("trials_hist", C.c_int32 * 64),
+    ]
+
+
+def _declare(l):
+    l.ba_ref_chi2.restype = C.c_double
+    l.ba_ref_chi2.argtypes = [C.POINTER(BaProblem), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    l.ba_ref_optimize.restype = C.c_int
+    l.ba_ref_optimize.argtypes = [C.POINTER(BaProblem), C.c_int, C.c_int, C.POINTER(C.c_uint8),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(BaStats)]
+    l.ba_ref_reduced_system.restype = None
+    l.ba_ref_reduced_system.argtypes = [C.POINTER(BaProblem)] + [C.POINTER(C.c_double)] * 2 + [C.c_double] + \
+        [C.POINTER(C.c_double)] * 5
+    l.ba_ref_edge_se2xyz.restype = None
+    l.ba_ref_edge_se2xyz.argtypes = [C.POINTER(BaProblem)] + [C.POINTER(C.c_double)] * 6
+    l.ba_ref_edge_pre_se2.restype = None
+    l.ba_ref_edge_pre_se2.argtypes = [C.POINTER(C.c_double)] * 6
+    if hasattr(l, "orb_ref_extract"):
+        _declare_orb(l)
+    if hasattr(l, "match_ref_window"):
+        _declare_match(l)
+
+
+class _Keep:
+    """Holds numpy arrays alive for the lifetime of a ctypes problem struct."""
+
+    def __init__(self):
+        self.arrs = []
+
+    def arr(self, a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        self.arrs.append(a)
+        return a
+
+
+def ba_problem(g):
+    """synth.BAGraph -> (BaProblem, keepalive)."""
+    k = _Keep()
+    pr = BaProblem()
+    pr.P, pr.L, pr.E, pr.O = g.P, g.L, g.E, g.O
+    pr.poses = _p(k.arr(g.poses, np.float64), C.c_double)
+    pr.fixed = _p(k.arr(g.fixed, np.uint8), C.c_uint8)
+    pr.lms = _p(k.arr(g.lms, np.float64), C.c_double)
+    pr.e_kf = _p(k.arr(g.e_kf, np.int32), C.c_int32)
+    pr.e_lm = _p(k.arr(g.e_lm, np.int32), C.c_int32)
+    pr.e_uv = _p(k.arr(g.e_uv, np.float64), C.c_double)
+    pr.e_info = _p(k.arr(g.e_info, np.float64), C.c_double)
+    pr.o_i = _p(k.arr(g.o_i, np.int32), C.c_int32)
+    pr.o_j = _p(k.arr(g.o_j, np.int32), C.c_int32)
+    pr.o_meas = _p(k.arr(g.o_meas, np.float64), C.c_double)
+    pr.o_info = _p(k.arr(g.o_info, np.float64), C.c_double)
+    pr.fx, pr.cx, pr.cy = g.fx, g.cx, g.cy
+    pr.Rbc = (C.c_double * 9)(*np.asarray(g.Rbc, dtype=np.float64).reshape(-1))
+    pr.tbc = (C.c_double * 3)(*np.asarray(g.tbc, dtype=np.float64).reshape(-1))
+    pr.huber = g.huber
+    return pr, k
+
+
+def ba_chi2(g, poses=None, lms=None) -> float:
+    pr, k = ba_problem(g)
+    poses = k.arr(g.poses if poses is None else poses, np.float64)
+    lms = k.arr(g.lms if lms is None else lms, np.float64)
+    return float(lib().ba_ref_chi2(C.byref(pr), _p(poses, C.c_double), _p(lms, C.c_double)))
+
+
+def ba_optimize(g, iters=10, mode=0):
+    """-> (poses (P,3), lms (L,3), stats dict)"""
+    pr, k = ba_problem(g)
+    poses = np.zeros((g.P, 3))
+    lms = np.zeros((g.L, 3))
+    st = BaStats()
+    rc = lib().ba_ref_optimize(C.byref(pr), iters, mode, None, _p(poses, C.c_double), _p(lms, C.c_double), C.byref(st))
+    assert rc == 0
+    n = min(st.iterations, 64)
+    stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated),
+                 chi2_init=st.chi2_init, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
+                 chi2_hist=list(st.chi2_hist[:n]), lambda_hist=list(st.lambda_hist[:n]),
+                 trials_hist=list(st.trials_hist[:n]))
+    return poses, lms, stats
+
+
+def ba_reduced_system(g, lam, poses=None, lms=None):
+    """-> dict(S (3P,3P), bs, bp, bl, Hll (L,3,3)) at the given state and damping."""
+    pr, k = ba_problem(g)
+    poses = k.arr(g.poses if poses is None else poses, np.float64)
+    lms = k.arr(g.lms if lms is None else lms, np.float64)
+    n = 3 * g.P
+    S = np.zeros((n, n)); bs = np.zeros(n); bp = np.zeros(n)
+    bl = np.zeros((g.L, 3)); Hll = np.zeros((g.L, 3, 3))
+    lib().ba_ref_reduced_system(C.byref(pr), _p(poses, C.c_double), _p(lms, C.c_double), float(lam),
+                                _p(S, C.c_double), _p(bs, C.c_double), _p(bp, C.c_double),
+                                _p(bl, C.c_double), _p(Hll, C.c_double))
+    return dict(S=S, bs=bs, bp=bp, bl=bl, Hll=Hll)
+
+
+def ba_edge_se2xyz(g, pose, lw, uv):
+    pr, k = ba_problem(g)
+    pose = k.arr(pose, np.float64); lw = k.arr(lw, np.float64); uv = k.arr(uv, np.float64)
+    e = np.zeros(2); Jp = np.zeros((2, 3)); Jl = np.zeros((2, 3))
+    lib().ba_ref_edge_se2xyz(C.byref(pr), _p(pose, C.c_double), _p(lw, C.c_double), _p(uv, C.c_double),
+                             _p(e, C.c_double), _p(Jp, C.c_double), _p(Jl, C.c_double))
+    return e, Jp, Jl
+
+
+def ba_edge_pre_se2(pi, pj, z):
+    pi = np.ascontiguousarray(pi, np.float64); pj = np.ascontiguousarray(pj, np.float64)
+    z = np.ascontiguousarray(z, np.float64)
+    e = np.zeros(3); Ji = np.zeros((3, 3)); Jj = np.zeros((3, 3))
+    lib().ba_ref_edge_pre_se2(_p(pi, C.c_double), _p(pj, C.c_double), _p(z, C.c_double),
+                              _p(e, C.c_double), _p(Ji, C.c_double), _p(Jj, C.c_double))
+    return e, Ji, Jj
+
+
+def _declare_orb(l):  # filled in with orb_ref.cpp
+    pass
+
+
+def _declare_match(l):  # filled in with match_ref.cpp
+    pass

@@ -1,0 +1,1280 @@
+// libse2gpu - SE(2)-XYZ local bundle adjustment on gfx950 (MI355X).
+//
+// Replaces the g2o::SparseOptimizer that LocalMapper::localBA builds and runs
+//   /root/reference/src/LocalMapper.cpp:232-302      (driver: LM(BlockSolverX(Cholmod)), optimize(LOCAL_ITER))
+//   /root/reference/src/Map.cpp:891-1053              (graph: VertexSE2 / VertexSBAPointXYZ / EdgeSE2XYZ / PreEdgeSE2)
+//   /root/reference/src/EdgeSE2XYZ.cpp:61-106         (per-edge residual + 2x3 / 2x3 Jacobians)
+//   /root/reference/include/se2lam/EdgeSE2XYZ.h:62-102 (PreEdgeSE2)
+// with FP64 HIP kernels.  Design:
+//   * SoA arena in HBM; observation edges are sorted by landmark (CSR) once per graph.
+//   * k_linearize      8 lanes per landmark: residual, Jacobians, Huber weight, per-edge Hpl / Hpp_e / bp_e,
+//                      per-landmark Hll / bl via an in-group shuffle reduction (no atomics).
+//   * k_pose_reduce    one wave per pose: Hpp, bp (output-stationary sum over the pose's edges + odometry).
+//   * k_schur_lm       per landmark: Dinv = (Hll + lambda I)^-1, z = Dinv bl, Y_e = Hpl_e Dinv.
+//   * k_reduce         one wave per (pose, pose) block of the reduced system: S_ab = Hpp_ab - sum Y_i Hpl_j^T over a
+//                      PRECOMPUTED contributor list (output-stationary: deterministic, atomic-free), plus b_s.
+//   * dense pose solve LL^T of the (3P)^2 system (host, FP64) - "small dense pose solve on the host".
+//   * k_update         back-substitution, oplus into a trial state, robust chi^2 and the LM gain denominator.
+//   * the LM controller mirrors g2o's OptimizationAlgorithmLevenberg (lambda policy, <= 10 trials, Terminate rule)
+//     and polls the caller's stop flag between trials (SparseOptimizer::setForceStopFlag).
+// Multi-GPU: landmarks are sharded; S|bs is summed over ranks through the caller's all-reduce callback (RCCL).
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <unordered_map>
+
+#include "common.h"
+
+using namespace se2gpu;
+
+namespace {
+
+constexpr int kGroup = 8;       // lanes cooperating on one landmark
+constexpr int kBlock = 256;
+constexpr double kPi = 3.14159265358979323846;
+
+struct CamDev {
+    double fx, cx, cy;
+    double Rcb[9];
+    double tcb[3];
+    double huber;
+};
+
+__host__ __device__ inline double normalize_theta(double theta) {
+    if (theta >= -kPi && theta < kPi) return theta;
+    double multiplier = floor(theta / (2 * kPi));
+    theta = theta - multiplier * 2 * kPi;
+    if (theta >= kPi) theta -= 2 * kPi;
+    if (theta < -kPi) theta += 2 * kPi;
+    return theta;
+}
+
+// Residual (and optionally the 2x3 pose / 2x3 landmark Jacobians) of one EdgeSE2XYZ.
+// lc = Rcb Rz(-theta) (lw - [x,y,0]) + tcb ; e = f (X/Z, Y/Z) + c - z     (EdgeSE2XYZ.cpp:61-106)
+template <bool JAC>
+__device__ inline void se2xyz(const CamDev& cam, double px, double py, double pth, double lx, double ly, double lz,
+                              double u, double v, double& e0, double& e1, double* Jp, double* Jl) {
+    double s, c;
+    sincos(pth, &s, &c);
+    const double dx = lx - px, dy = ly - py;
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        R[i * 3 + 0] = cam.Rcb[i * 3 + 0] * c - cam.Rcb[i * 3 + 1] * s;
+        R[i * 3 + 1] = cam.Rcb[i * 3 + 0] * s + cam.Rcb[i * 3 + 1] * c;
+        R[i * 3 + 2] = cam.Rcb[i * 3 + 2];
+    }
+    const double X = R[0] * dx + R[1] * dy + R[2] * lz + cam.tcb[0];
+    const double Y = R[3] * dx + R[4] * dy + R[5] * lz + cam.tcb[1];
+    const double Z = R[6] * dx + R[7] * dy + R[8] * lz + cam.tcb[2];
+    const double zi = 1.0 / Z;
+    e0 = cam.fx * X * zi + cam.cx - u;
+    e1 = cam.fx * Y * zi + cam.cy - v;
+    if (JAC) {
+        const double zi2 = zi * zi;
+        const double j00 = cam.fx * zi, j02 = -cam.fx * X * zi2, j12 = -cam.fx * Y * zi2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            Jl[k] = j00 * R[k] + j02 * R[6 + k];
+            Jl[3 + k] = j00 * R[3 + k] + j12 * R[6 + k];
+        }
+        Jp[0] = -Jl[0]; Jp[1] = -Jl[1]; Jp[2] = Jl[0] * dy - Jl[1] * dx;
+        Jp[3] = -Jl[3]; Jp[4] = -Jl[4]; Jp[5] = Jl[3] * dy - Jl[4] * dx;
+    }
+}
+
+__device__ inline void huber(double e2, double delta, double& rho0, double& rho1) {  // RobustKernelHuber
+    const double dsqr = delta * delta;
+    if (e2 <= dsqr) {
+        rho0 = e2; rho1 = 1.0;
+    } else {
+        const double sq = sqrt(e2);
+        rho0 = 2 * sq * delta - dsqr;
+        rho1 = delta / sq;
+    }
+}
+
+__device__ inline double group_sum(double v) {  // sum over an aligned group of kGroup lanes
+#pragma unroll
+    for (int m = 1; m < kGroup; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_linearize: per landmark group.  Outputs per edge: Hpl (3x3 row-major), Hpp_e (6 sym), bp_e (3);
+// per landmark: Hll (6 sym: xx xy xz yy yz zz), bl (3).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const int* __restrict__ lm_ptr,
+                                                       const int* __restrict__ e_kf, const double* __restrict__ e_uv,
+                                                       const double* __restrict__ e_info,
+                                                       const double* __restrict__ poses,
+                                                       const uint8_t* __restrict__ fixed,
+                                                       const double* __restrict__ lms, double* __restrict__ Hpl,
+                                                       double* __restrict__ Hpp_e, double* __restrict__ bp_e,
+                                                       double* __restrict__ Hll, double* __restrict__ bl) {
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    if (l < L) {
+        const double lx = lms[3 * l], ly = lms[3 * l + 1], lz = lms[3 * l + 2];
+        const int beg = lm_ptr[l], end = lm_ptr[l + 1];
+        for (int e = beg + sub; e < end; e += kGroup) {
+            const int kf = e_kf[e];
+            double e0, e1, Jp[6], Jl[6];
+            se2xyz<true>(cam, poses[3 * kf], poses[3 * kf + 1], poses[3 * kf + 2], lx, ly, lz, e_uv[2 * e],
+                         e_uv[2 * e + 1], e0, e1, Jp, Jl);
+            const double w0 = e_info[3 * e], w1 = e_info[3 * e + 1], w2 = e_info[3 * e + 2];
+            const double we0 = w0 * e0 + w1 * e1, we1 = w1 * e0 + w2 * e1;
+            double r0, r1;
+            huber(e0 * we0 + e1 * we1, cam.huber, r0, r1);
+            const double W0 = r1 * w0, W1 = r1 * w1, W2 = r1 * w2;  // weightedOmega
+            const double or0 = -r1 * we0, or1 = -r1 * we1;          // omega_r
+            double WJl[6], WJp[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                WJl[c] = W0 * Jl[c] + W1 * Jl[3 + c];
+                WJl[3 + c] = W1 * Jl[c] + W2 * Jl[3 + c];
+                WJp[c] = W0 * Jp[c] + W1 * Jp[3 + c];
+                WJp[3 + c] = W1 * Jp[c] + W2 * Jp[3 + c];
+            }
+            hll[0] += Jl[0] * WJl[0] + Jl[3] * WJl[3];
+            hll[1] += Jl[0] * WJl[1] + Jl[3] * WJl[4];
+            hll[2] += Jl[0] * WJl[2] + Jl[3] * WJl[5];
+            hll[3] += Jl[1] * WJl[1] + Jl[4] * WJl[4];
+            hll[4] += Jl[1] * WJl[2] + Jl[4] * WJl[5];
+            hll[5] += Jl[2] * WJl[2] + Jl[5] * WJl[5];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) b[r] += Jl[r] * or0 + Jl[3 + r] * or1;
+            const bool fr = !fixed[kf];
+            double* hpl = Hpl + (size_t)e * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hpl[r * 3 + c] = fr ? Jp[r] * WJl[c] + Jp[3 + r] * WJl[3 + c] : 0.0;
+            double* hpp = Hpp_e + (size_t)e * 6;
+            hpp[0] = fr ? Jp[0] * WJp[0] + Jp[3] * WJp[3] : 0.0;
+            hpp[1] = fr ? Jp[0] * WJp[1] + Jp[3] * WJp[4] : 0.0;
+            hpp[2] = fr ? Jp[0] * WJp[2] + Jp[3] * WJp[5] : 0.0;
+            hpp[3] = fr ? Jp[1] * WJp[1] + Jp[4] * WJp[4] : 0.0;
+            hpp[4] = fr ? Jp[1] * WJp[2] + Jp[4] * WJp[5] : 0.0;
+            hpp[5] = fr ? Jp[2] * WJp[2] + Jp[5] * WJp[5] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) bp_e[(size_t)e * 3 + r] = fr ? Jp[r] * or0 + Jp[3 + r] * or1 : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hll[i] = group_sum(hll[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = group_sum(b[i]);
+    if (l < L && sub == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Hll[(size_t)l * 6 + i] = hll[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bl[(size_t)l * 3 + i] = b[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_odometry: one thread per PreEdgeSE2 (EdgeSE2XYZ.h:62-102, no robust kernel): blocks Oii, Ojj, Oij (3x3
+// row-major) and gradients obi, obj.  Fixed vertices get zero blocks (constructQuadraticForm skips them).
+// ---------------------------------------------------------------------------------------------
+__device__ inline void pre_se2(const double* pi, const double* pj, const double* z, double e[3], double A[9],
+                               double B[9]) {
+    double s, c;
+    sincos(pi[2], &s, &c);
+    const double rx = pj[0] - pi[0], ry = pj[1] - pi[1];
+    e[0] = c * rx + s * ry - z[0];
+    e[1] = -s * rx + c * ry - z[1];
+    e[2] = pj[2] - pi[2] - z[2];
+    const double qx = -ry, qy = rx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { A[i] = 0; B[i] = 0; }
+    A[0] = -c; A[1] = -s; A[3] = s; A[4] = -c;
+    A[2] = -(c * qx + s * qy);
+    A[5] = -(-s * qx + c * qy);
+    A[8] = -1;
+    B[0] = c; B[1] = s; B[3] = -s; B[4] = c; B[8] = 1;
+}
+
+__global__ void k_odometry(int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
+                           const double* __restrict__ o_meas, const double* __restrict__ o_info,
+                           const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                           double* __restrict__ Oii, double* __restrict__ Ojj, double* __restrict__ Oij,
+                           double* __restrict__ obi, double* __restrict__ obj) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= O) return;
+    const int i = o_i[k], j = o_j[k];
+    double e[3], A[9], B[9];
+    pre_se2(poses + 3 * i, poses + 3 * j, o_meas + 3 * k, e, A, B);
+    const double* W = o_info + 9 * k;
+    double omr[3], WA[9], WB[9];
+    for (int r = 0; r < 3; ++r) {
+        omr[r] = -(W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
+        for (int c = 0; c < 3; ++c) {
+            WA[r * 3 + c] = W[r * 3] * A[c] + W[r * 3 + 1] * A[3 + c] + W[r * 3 + 2] * A[6 + c];
+            WB[r * 3 + c] = W[r * 3] * B[c] + W[r * 3 + 1] * B[3 + c] + W[r * 3 + 2] * B[6 + c];
+        }
+    }
+    const bool fi = !fixed[i], fj = !fixed[j];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) {
+            const double aa = A[r] * WA[c] + A[3 + r] * WA[3 + c] + A[6 + r] * WA[6 + c];
+            const double ab = A[r] * WB[c] + A[3 + r] * WB[3 + c] + A[6 + r] * WB[6 + c];
+            const double bb = B[r] * WB[c] + B[3 + r] * WB[3 + c] + B[6 + r] * WB[6 + c];
+            Oii[k * 9 + r * 3 + c] = fi ? aa : 0.0;
+            Ojj[k * 9 + r * 3 + c] = fj ? bb : 0.0;
+            Oij[k * 9 + r * 3 + c] = (fi && fj) ? ab : 0.0;
+        }
+        obi[k * 3 + r] = fi ? A[r] * omr[0] + A[3 + r] * omr[1] + A[6 + r] * omr[2] : 0.0;
+        obj[k * 3 + r] = fj ? B[r] * omr[0] + B[3 + r] * omr[1] + B[6 + r] * omr[2] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pose_reduce: one wave per pose.  Hpp (3x3 row-major, full) and bp (3) = sum over the pose's observation edges
+// (CSR pose_ptr / pose_edges) + its odometry edges (CSR podo_ptr / podo_item: item = 2*k + (pose is j ? 1 : 0)).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __restrict__ pose_ptr,
+                                                         const int* __restrict__ pose_edges,
+                                                         const double* __restrict__ Hpp_e,
+                                                         const double* __restrict__ bp_e,
+                                                         const int* __restrict__ podo_ptr,
+                                                         const int* __restrict__ podo_item,
+                                                         const double* __restrict__ Oii, const double* __restrict__ Ojj,
+                                                         const double* __restrict__ obi, const double* __restrict__ obj,
+                                                         double* __restrict__ Hpp, double* __restrict__ bp) {
+    const int p = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (p >= P) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int t = pose_ptr[p] + lane; t < pose_ptr[p + 1]; t += 64) {
+        const int e = pose_edges[t];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h[i] += Hpp_e[(size_t)e * 6 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] += bp_e[(size_t)e * 3 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = wave_sum(h[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = wave_sum(b[i]);
+    if (lane == 0) {
+        double H[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
+        for (int t = podo_ptr[p]; t < podo_ptr[p + 1]; ++t) {
+            const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
+            const double* M = (isj ? Ojj : Oii) + (size_t)k * 9;
+            const double* g = (isj ? obj : obi) + (size_t)k * 3;
+            for (int i = 0; i < 9; ++i) H[i] += M[i];
+            for (int i = 0; i < 3; ++i) b[i] += g[i];
+        }
+        for (int i = 0; i < 9; ++i) Hpp[(size_t)p * 9 + i] = H[i];
+        for (int i = 0; i < 3; ++i) bp[(size_t)p * 3 + i] = b[i];
+    }
+}
+
+// max |diag| over a strided array (computeLambdaInit); single block, deterministic.
+__global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const double* __restrict__ Hpp_diag3,
+                          const uint8_t* __restrict__ fixed, double* __restrict__ out) {
+    __shared__ double sm[1024];
+    double m = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        m = fmax(m, fabs(Hll[(size_t)i * 6 + 0]));
+        m = fmax(m, fabs(Hll[(size_t)i * 6 + 3]));
+        m = fmax(m, fabs(Hll[(size_t)i * 6 + 5]));
+    }
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+        if (!fixed[i])
+            for (int r = 0; r < 3; ++r) m = fmax(m, fabs(Hpp_diag3[(size_t)i * 3 + r]));
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sm[0];
+}
+
+__global__ void k_extract_diag(int P, const double* __restrict__ Hpp, double* __restrict__ d3) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P * 3) d3[i] = Hpp[(size_t)(i / 3) * 9 + (i % 3) * 4];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_schur_lm: per landmark group: Dinv = (Hll + lambda I)^-1 (sym 6), z = Dinv bl, Y_e = Hpl_e Dinv.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void inv_sym3(const double h[6], double lambda, double d[6]) {
+    const double a = h[0] + lambda, b = h[1], c = h[2], e = h[3] + lambda, f = h[4], i = h[5] + lambda;
+    const double A = e * i - f * f, B = -(b * i - f * c), C = b * f - e * c;
+    const double id = 1.0 / (a * A + b * B + c * C);
+    d[0] = A * id; d[1] = B * id; d[2] = C * id;
+    d[3] = (a * i - c * c) * id; d[4] = -(a * f - c * b) * id; d[5] = (a * e - b * b) * id;
+}
+
+__global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const int* __restrict__ lm_ptr,
+                                                      const double* __restrict__ Hll, const double* __restrict__ bl,
+                                                      const double* __restrict__ Hpl, double* __restrict__ Dinv,
+                                                      double* __restrict__ z, double* __restrict__ Y) {
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    if (l >= L) return;
+    double h[6], d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = Hll[(size_t)l * 6 + i];
+    inv_sym3(h, lambda, d);
+    if (sub == 0) {
+        const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
+        z[(size_t)l * 3 + 0] = d[0] * b0 + d[1] * b1 + d[2] * b2;
+        z[(size_t)l * 3 + 1] = d[1] * b0 + d[3] * b1 + d[4] * b2;
+        z[(size_t)l * 3 + 2] = d[2] * b0 + d[4] * b1 + d[5] * b2;
+    }
+    for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
+        const double* B = Hpl + (size_t)e * 9;
+        double* y = Y + (size_t)e * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double b0 = B[r * 3], b1 = B[r * 3 + 1], b2 = B[r * 3 + 2];
+            y[r * 3 + 0] = b0 * d[0] + b1 * d[1] + b2 * d[2];
+            y[r * 3 + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
+            y[r * 3 + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reduce: one wave per upper-triangular (a <= b) block of the reduced system.
+//   S_ab = [a==b] (Hpp_a + lambda I * root) - sum_{(i,j) in pairs(a,b)} Y_i Hpl_j^T
+//   bs_a = bp_a - sum_{e in pose a} Hpl_e z_{lm(e)}                      (diagonal-block waves)
+// Fixed poses: zero rows/cols, unit diagonal on the root rank, zero rhs.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_reduce(int P, int nblk, double lambda, int root,
+                                                    const int* __restrict__ blk_a, const int* __restrict__ blk_b,
+                                                    const int* __restrict__ blk_ptr, const int* __restrict__ pair_i,
+                                                    const int* __restrict__ pair_j, const double* __restrict__ Y,
+                                                    const double* __restrict__ Hpl, const double* __restrict__ Hpp,
+                                                    const double* __restrict__ bp, const uint8_t* __restrict__ fixed,
+                                                    const int* __restrict__ pose_ptr,
+                                                    const int* __restrict__ pose_edges,
+                                                    const int* __restrict__ e_lm, const double* __restrict__ z,
+                                                    double* __restrict__ S, double* __restrict__ bs) {
+    const int k = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (k >= nblk) return;
+    const int a = blk_a[k], b = blk_b[k];
+    const int n = 3 * P;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = blk_ptr[k] + lane; t < blk_ptr[k + 1]; t += 64) {
+        const double* y = Y + (size_t)pair_i[t] * 9;
+        const double* h = Hpl + (size_t)pair_j[t] * 9;
+        double yy[9], hh[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { yy[i] = y[i]; hh[i] = h[i]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                acc[r * 3 + c] += yy[r * 3] * hh[c * 3] + yy[r * 3 + 1] * hh[c * 3 + 1] + yy[r * 3 + 2] * hh[c * 3 + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) acc[i] = wave_sum(acc[i]);
+    const bool fa = fixed[a], fb = fixed[b];
+    if (lane < 9) {
+        const int r = lane / 3, c = lane % 3;
+        double v = 0;
+        // pick acc[lane] without dynamic register indexing
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v = (lane == i) ? acc[i] : v;
+        double out;
+        if (fa || fb) {
+            out = (a == b && r == c && root) ? 1.0 : 0.0;
+        } else {
+            out = -v;
+            if (a == b) out += Hpp[(size_t)a * 9 + lane] + ((r == c && root) ? lambda : 0.0);
+        }
+        S[(size_t)(3 * a + r) * n + 3 * b + c] = out;
+        if (a != b) S[(size_t)(3 * b + c) * n + 3 * a + r] = out;
+    }
+    if (a == b) {
+        double g[3] = {0, 0, 0};
+        if (!fa) {
+            for (int t = pose_ptr[a] + lane; t < pose_ptr[a + 1]; t += 64) {
+                const int e = pose_edges[t];
+                const double* h = Hpl + (size_t)e * 9;
+                const double* zz = z + (size_t)e_lm[e] * 3;
+                const double z0 = zz[0], z1 = zz[1], z2 = zz[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) g[r] += h[r * 3] * z0 + h[r * 3 + 1] * z1 + h[r * 3 + 2] * z2;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g[r] = wave_sum(g[r]);
+        if (lane < 3) {
+            double v = lane == 0 ? g[0] : (lane == 1 ? g[1] : g[2]);
+            bs[3 * a + lane] = fa ? 0.0 : bp[(size_t)a * 3 + lane] - v;
+        }
+    }
+}
+
+// odometry pose-pose blocks: S_ij += Oij, S_ji += Oij^T.  One thread per (edge, entry).
+__global__ void k_reduce_odo(int O, int P, const int* __restrict__ o_i, const int* __restrict__ o_j,
+                             const double* __restrict__ Oij, double* __restrict__ S) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= O * 9) return;
+    const int k = t / 9, r = (t % 9) / 3, c = t % 3;
+    const int i = o_i[k], j = o_j[k];
+    const int n = 3 * P;
+    const double v = Oij[t];
+    if (v == 0.0) return;
+    atomicAdd(&S[(size_t)(3 * i + r) * n + 3 * j + c], v);
+    atomicAdd(&S[(size_t)(3 * j + c) * n + 3 * i + r], v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_update: per landmark group: back-substitute x_l = z - sum_e Y_e^T x_p[kf(e)], trial landmark = lw + x_l,
+// robust chi^2 of the landmark's edges at the trial state, and the landmark part of computeScale().
+// With xp == nullptr it evaluates chi^2 at the current state (x = 0).  Per-block partials -> part[2*blockIdx].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lambda, const int* __restrict__ lm_ptr,
+                                                    const int* __restrict__ e_kf, const double* __restrict__ e_uv,
+                                                    const double* __restrict__ e_info,
+                                                    const double* __restrict__ poses,
+                                                    const uint8_t* __restrict__ fixed, const double* __restrict__ lms,
+                                                    const double* __restrict__ xp, const double* __restrict__ z,
+                                                    const double* __restrict__ Y, const double* __restrict__ bl,
+                                                    double* __restrict__ lms_trial, double* __restrict__ part) {
+    __shared__ double sm[2][kBlock / 64];
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    double chi = 0, scale = 0;
+    double x[3] = {0, 0, 0};
+    const bool step = xp != nullptr;
+    int beg = 0, end = 0;
+    if (l < L) {
+        beg = lm_ptr[l];
+        end = lm_ptr[l + 1];
+        if (step) {
+            for (int e = beg + sub; e < end; e += kGroup) {
+                const int kf = e_kf[e];
+                const double* y = Y + (size_t)e * 9;
+                const double p0 = xp[3 * kf], p1 = xp[3 * kf + 1], p2 = xp[3 * kf + 2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x[c] -= y[c] * p0 + y[3 + c] * p1 + y[6 + c] * p2;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = group_sum(x[c]);
+    if (l < L) {
+        double lw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (step) x[c] += z[(size_t)l * 3 + c];
+            lw[c] = lms[(size_t)l * 3 + c] + x[c];
+        }
+        if (sub == 0 && step) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lms_trial[(size_t)l * 3 + c] = lw[c];
+                scale += x[c] * (lambda * x[c] + bl[(size_t)l * 3 + c]);
+            }
+        }
+        for (int e = beg + sub; e < end; e += kGroup) {
+            const int kf = e_kf[e];
+            double px = poses[3 * kf], py = poses[3 * kf + 1], pth = poses[3 * kf + 2];
+            if (step && !fixed[kf]) {
+                px += xp[3 * kf];
+                py += xp[3 * kf + 1];
+                pth = normalize_theta(pth + xp[3 * kf + 2]);
+            }
+            double e0, e1;
+            se2xyz<false>(cam, px, py, pth, lw[0], lw[1], lw[2], e_uv[2 * e], e_uv[2 * e + 1], e0, e1, nullptr, nullptr);
+            const double w0 = e_info[3 * e], w1 = e_info[3 * e + 1], w2 = e_info[3 * e + 2];
+            double r0, r1;
+            huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), cam.huber, r0, r1);
+            chi += r0;
+        }
+    }
+    chi = wave_sum(chi);
+    scale = wave_sum(scale);
+    const int w = threadIdx.x / 64;
+    if ((threadIdx.x & 63) == 0) { sm[0][w] = chi; sm[1][w] = scale; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0, s = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { c += sm[0][i]; s += sm[1][i]; }
+        part[2 * blockIdx.x] = c;
+        part[2 * blockIdx.x + 1] = s;
+    }
+}
+
+// k_finalize: single block.  Sums the k_update partials, applies oplus to the poses (VertexSE2::oplusImpl:
+// additive x,y; theta = normalize_theta(theta + dtheta)), adds the odometry chi^2 at the trial poses and the pose
+// part of computeScale().  out[0] = chi2_trial, out[1] = scale (local to this rank).
+__global__ void k_finalize(int nparts, const double* __restrict__ part, int P, double lambda,
+                           const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                           const double* __restrict__ xp, const double* __restrict__ bp, double* __restrict__ poses_trial,
+                           int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
+                           const double* __restrict__ o_meas, const double* __restrict__ o_info, int root,
+                           double* __restrict__ out) {
+    __shared__ double sm[2][1024];
+    __shared__ double sp[3 * 1024];  // trial poses staged for the odometry pass when P <= 1024
+    const bool step = xp != nullptr;
+    double chi = 0, scale = 0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        chi += part[2 * i];
+        scale += part[2 * i + 1];
+    }
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        double x = poses[3 * p], y = poses[3 * p + 1], th = poses[3 * p + 2];
+        if (step && !fixed[p]) {
+            const double d0 = xp[3 * p], d1 = xp[3 * p + 1], d2 = xp[3 * p + 2];
+            x += d0; y += d1; th = normalize_theta(th + d2);
+            if (root) scale += d0 * (lambda * d0 + bp[3 * p]) + d1 * (lambda * d1 + bp[3 * p + 1]) + d2 * (lambda * d2 + bp[3 * p + 2]);
+        }
+        if (step) { poses_trial[3 * p] = x; poses_trial[3 * p + 1] = y; poses_trial[3 * p + 2] = th; }
+        if (p < 1024) { sp[3 * p] = x; sp[3 * p + 1] = y; sp[3 * p + 2] = th; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < O; k += blockDim.x) {
+        const int i = o_i[k], j = o_j[k];
+        double pi[3], pj[3];
+        for (int c = 0; c < 3; ++c) {
+            pi[c] = (i < 1024) ? sp[3 * i + c] : (step ? poses_trial[3 * i + c] : poses[3 * i + c]);
+            pj[c] = (j < 1024) ? sp[3 * j + c] : (step ? poses_trial[3 * j + c] : poses[3 * j + c]);
+        }
+        double e[3], A[9], B[9];
+        pre_se2(pi, pj, o_meas + 3 * k, e, A, B);
+        const double* W = o_info + 9 * k;
+        for (int r = 0; r < 3; ++r) chi += e[r] * (W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
+    }
+    sm[0][threadIdx.x] = chi;
+    sm[1][threadIdx.x] = scale;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
+            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = sm[0][0]; out[1] = sm[1][0]; out[2] = 0; out[3] = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host: dense SPD solve of the reduced pose system (replaces CHOLMOD on the (3P)^2 matrix).
+// Blocked right-looking LL^T on the lower triangle, row-major, FP64.
+// ---------------------------------------------------------------------------------------------
+bool host_cholesky_solve(double* A, int n, double* x) {
+    constexpr int NB = 48;
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = std::min(NB, n - k0);
+        // factor the diagonal block
+        for (int j = k0; j < k0 + kb; ++j) {
+            double* Aj = A + (size_t)j * n;
+            double d = Aj[j];
+            for (int k = k0; k < j; ++k) d -= Aj[k] * Aj[k];
+            if (!(d > 0.0) || !std::isfinite(d)) return false;
+            d = std::sqrt(d);
+            Aj[j] = d;
+            const double id = 1.0 / d;
+            for (int i = j + 1; i < k0 + kb; ++i) {
+                double* Ai = A + (size_t)i * n;
+                double s = Ai[j];
+                for (int k = k0; k < j; ++k) s -= Ai[k] * Aj[k];
+                Ai[j] = s * id;
+            }
+        }
+        // panel: rows below the block, solve X * L_kk^T = A_ik
+        for (int i = k0 + kb; i < n; ++i) {
+            double* Ai = A + (size_t)i * n;
+            for (int j = k0; j < k0 + kb; ++j) {
+                const double* Aj = A + (size_t)j * n;
+                double s = Ai[j];
+                for (int k = k0; k < j; ++k) s -= Ai[k] * Aj[k];
+                Ai[j] = s / Aj[j];
+            }
+        }
+        // trailing update (lower triangle): A_ij -= sum_k L_ik L_jk
+        for (int i = k0 + kb; i < n; ++i) {
+            double* Ai = A + (size_t)i * n;
+            const double* Li = Ai + k0;
+            for (int j = k0 + kb; j <= i; ++j) {
+                const double* Lj = A + (size_t)j * n + k0;
+                double s = 0;
+
+                for (int k = 0; k < kb; ++k) s += Li[k] * Lj[k];
+                Ai[j] -= s;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const double* Li = A + (size_t)i * n;
+        double s = x[i];
+        for (int k = 0; k < i; ++k) s -= Li[k] * x[k];
+        x[i] = s / Li[i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * x[k];
+        x[i] = s / A[(size_t)i * n + i];
+    }
+    return true;
+}
+
+struct EdgeObs {
+    int kf, lm;   // indices (not ids)
+    double uv[2];
+    double info[3];
+    double huber;
+};
+struct EdgeOdo {
+    int i, j;
+    double meas[3];
+    double info[9];
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct se2gpu_ba {
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    LaunchProfile prof;
+    // graph under construction (host)
+    CamDev cam{};
+    bool have_cam = false, have_tbc = false;
+    double Rbc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tbc[3] = {0, 0, 0};
+    std::unordered_map<int, int> pose_of_id, lm_of_id;
+    std::vector<int> pose_ids, lm_ids;
+    std::vector<double> h_poses, h_lms;
+    std::vector<uint8_t> h_fixed;
+    std::vector<EdgeObs> obs;
+    std::vector<EdgeOdo> odo;
+    bool initialized = false;
+    int P = 0, L = 0, E = 0, O = 0, nblk = 0, nparts = 0;
+    // device SoA
+    DevBuf<double> poses0, lms0, poses_a, poses_b, lms_a, lms_b;
+    double *poses = nullptr, *poses_t = nullptr, *lms = nullptr, *lms_t = nullptr;
+    DevBuf<uint8_t> fixed;
+    DevBuf<int> lm_ptr, e_kf, e_lm, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j;
+    DevBuf<int> blk_a, blk_b, blk_ptr, pair_i, pair_j;
+    DevBuf<double> e_uv, e_info, o_meas, o_info;
+    DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Hpp, bp, Oii, Ojj, Oij, obi, obj;
+    DevBuf<double> red_own, xp, part, scal, diag3;
+    double* red = nullptr;  // [S (n*n) | bs (n) | 4 scalars]
+    PinBuf<double> h_red, h_x, h_scal;
+    // multi-GPU
+    se2gpu_allreduce_fn allreduce = nullptr;
+    void* ar_user = nullptr;
+    void* ar_buffer = nullptr;
+    int root = 1, rank = 0, world = 1;
+
+    ~se2gpu_ba() {
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+};
+
+namespace {
+
+int ba_upload_graph(se2gpu_ba* h) {
+    const int P = (int)h->pose_ids.size(), L = (int)h->lm_ids.size();
+    const int E = (int)h->obs.size(), O = (int)h->odo.size();
+    SE2_REQUIRE(P > 0, SE2GPU_ERR_STATE, "initialize: no pose vertices");
+    SE2_REQUIRE(h->have_cam, SE2GPU_ERR_STATE, "initialize: add_cam was not called");
+    h->P = P; h->L = L; h->E = E; h->O = O;
+    double delta = E ? h->obs[0].huber : 0.0;
+    for (const auto& e : h->obs)
+        SE2_REQUIRE(e.huber == delta, SE2GPU_ERR_INVALID, "all EdgeSE2XYZ must share one Huber delta (Map.cpp:977)");
+    h->cam.huber = delta;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) h->cam.Rcb[i * 3 + j] = h->Rbc[j * 3 + i];
+    for (int i = 0; i < 3; ++i)
+        h->cam.tcb[i] = -(h->cam.Rcb[i * 3] * h->tbc[0] + h->cam.Rcb[i * 3 + 1] * h->tbc[1] + h->cam.Rcb[i * 3 + 2] * h->tbc[2]);
+
+    // --- sort observation edges by landmark (stable counting sort)
+    std::vector<int> lm_ptr(L + 1, 0);
+    for (const auto& e : h->obs) lm_ptr[e.lm + 1]++;
+    for (int l = 0; l < L; ++l) lm_ptr[l + 1] += lm_ptr[l];
+    std::vector<int> fill(lm_ptr.begin(), lm_ptr.end() - 1), e_kf(E), e_lm(E);
+    std::vector<double> e_uv(2 * (size_t)E), e_info(3 * (size_t)E);
+    for (const auto& e : h->obs) {
+        const int s = fill[e.lm]++;
+        e_kf[s] = e.kf; e_lm[s] = e.lm;
+        e_uv[2 * s] = e.uv[0]; e_uv[2 * s + 1] = e.uv[1];
+        e_info[3 * s] = e.info[0]; e_info[3 * s + 1] = e.info[1]; e_info[3 * s + 2] = e.info[2];
+    }
+    // --- pose -> edges CSR
+    std::vector<int> pose_ptr(P + 1, 0), pose_edges(E);
+    for (int s = 0; s < E; ++s) pose_ptr[e_kf[s] + 1]++;
+    for (int p = 0; p < P; ++p) pose_ptr[p + 1] += pose_ptr[p];
+    {
+        std::vector<int> f(pose_ptr.begin(), pose_ptr.end() - 1);
+        for (int s = 0; s < E; ++s) pose_edges[f[e_kf[s]]++] = s;
+    }
+    // --- odometry
+    std::vector<int> o_i(O), o_j(O), podo_ptr(P + 1, 0), podo_item(2 * (size_t)O);
+    std::vector<double> o_meas(3 * (size_t)O), o_info(9 * (size_t)O);
+    for (int k = 0; k < O; ++k) {
+        o_i[k] = h->odo[k].i; o_j[k] = h->odo[k].j;
+        std::memcpy(&o_meas[3 * k], h->odo[k].meas, 24);
+        std::memcpy(&o_info[9 * k], h->odo[k].info, 72);
+        podo_ptr[o_i[k] + 1]++;
+        podo_ptr[o_j[k] + 1]++;
+    }
+    for (int p = 0; p < P; ++p) podo_ptr[p + 1] += podo_ptr[p];
+    {
+        std::vector<int> f(podo_ptr.begin(), podo_ptr.end() - 1);
+        for (int k = 0; k < O; ++k) {
+            podo_item[f[o_i[k]]++] = 2 * k;
+            podo_item[f[o_j[k]]++] = 2 * k + 1;
+        }
+    }
+    // --- reduced-system block plan: upper-triangular (a <= b) blocks, contributor pairs per block
+    const int nblk = P * (P + 1) / 2;
+    auto blk_index = [P](int a, int b) { return a * P - a * (a - 1) / 2 + (b - a); };
+    std::vector<int> blk_a(nblk), blk_b(nblk), blk_ptr(nblk + 1, 0);
+    for (int a = 0; a < P; ++a)
+        for (int b = a; b < P; ++b) {
+            blk_a[blk_index(a, b)] = a;
+            blk_b[blk_index(a, b)] = b;
+        }
+    const std::vector<uint8_t>& fx = h->h_fixed;
+    for (int l = 0; l < L; ++l)
+        for (int s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
+            if (fx[e_kf[s]]) continue;
+            for (int t = lm_ptr[l]; t < lm_ptr[l + 1]; ++t) {
+                if (fx[e_kf[t]]) continue;
+                const int a = e_kf[s], b = e_kf[t];
+                if (a < b || (a == b)) blk_ptr[blk_index(a, b) + 1]++;
+            }
+        }
+    for (int k = 0; k < nblk; ++k) blk_ptr[k + 1] += blk_ptr[k];
+    const size_t npairs = (size_t)blk_ptr[nblk];
+    std::vector<int> pair_i(npairs), pair_j(npairs);
+    {
+        std::vector<int> f(blk_ptr.begin(), blk_ptr.end() - 1);
+        for (int l = 0; l < L; ++l)
+            for (int s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
+                if (fx[e_kf[s]]) continue;
+                for (int t = lm_ptr[l]; t < lm_ptr[l + 1]; ++t) {
+                    if (fx[e_kf[t]]) continue;
+                    const int a = e_kf[s], b = e_kf[t];
+                    if (a < b || (a == b)) {
+                        const int q = f[blk_index(a, b)]++;
+                        pair_i[q] = s;
+                        pair_j[q] = t;
+                    }
+                }
+            }
+    }
+    h->nblk = nblk;
+    hipStream_t st = h->stream;
+    const int n = 3 * P;
+    SE2_CHECK(h->poses0.upload(h->h_poses, st));
+    SE2_CHECK(h->lms0.upload(h->h_lms, st));
+    SE2_CHECK(h->fixed.upload(h->h_fixed, st));
+    SE2_CHECK(h->lm_ptr.upload(lm_ptr, st));
+    SE2_CHECK(h->e_kf.upload(e_kf, st));
+    SE2_CHECK(h->e_lm.upload(e_lm, st));
+    SE2_CHECK(h->e_uv.upload(e_uv, st));
+    SE2_CHECK(h->e_info.upload(e_info, st));
+    SE2_CHECK(h->pose_ptr.upload(pose_ptr, st));
+    SE2_CHECK(h->pose_edges.upload(pose_edges, st));
+    SE2_CHECK(h->podo_ptr.upload(podo_ptr, st));
+    SE2_CHECK(h->podo_item.upload(podo_item, st));
+    SE2_CHECK(h->o_i.upload(o_i, st));
+    SE2_CHECK(h->o_j.upload(o_j, st));
+    SE2_CHECK(h->o_meas.upload(o_meas, st));
+    SE2_CHECK(h->o_info.upload(o_info, st));
+    SE2_CHECK(h->blk_a.upload(blk_a, st));
+    SE2_CHECK(h->blk_b.upload(blk_b, st));
+    SE2_CHECK(h->blk_ptr.upload(blk_ptr, st));
+    SE2_CHECK(h->pair_i.upload(pair_i, st));
+    SE2_CHECK(h->pair_j.upload(pair_j, st));
+    SE2_CHECK(h->poses_a.reserve(3 * (size_t)P));
+    SE2_CHECK(h->poses_b.reserve(3 * (size_t)P));
+    SE2_CHECK(h->lms_a.reserve(3 * (size_t)L + 1));
+    SE2_CHECK(h->lms_b.reserve(3 * (size_t)L + 1));
+    SE2_CHECK(h->Hpl.reserve(9 * (size_t)E + 1));
+    SE2_CHECK(h->Y.reserve(9 * (size_t)E + 1));
+    SE2_CHECK(h->Hpp_e.reserve(6 * (size_t)E + 1));
+    SE2_CHECK(h->bp_e.reserve(3 * (size_t)E + 1));
+    SE2_CHECK(h->Hll.reserve(6 * (size_t)L + 1));
+    SE2_CHECK(h->bl.reserve(3 * (size_t)L + 1));
+    SE2_CHECK(h->Dinv.reserve(6 * (size_t)L + 1));
+    SE2_CHECK(h->z.reserve(3 * (size_t)L + 1));
+    SE2_CHECK(h->Hpp.reserve(9 * (size_t)P));
+    SE2_CHECK(h->bp.reserve(3 * (size_t)P));
+    SE2_CHECK(h->diag3.reserve(3 * (size_t)P));
+    SE2_CHECK(h->Oii.reserve(9 * (size_t)O + 1));
+    SE2_CHECK(h->Ojj.reserve(9 * (size_t)O + 1));
+    SE2_CHECK(h->Oij.reserve(9 * (size_t)O + 1));
+    SE2_CHECK(h->obi.reserve(3 * (size_t)O + 1));
+    SE2_CHECK(h->obj.reserve(3 * (size_t)O + 1));
+    SE2_CHECK(h->xp.reserve(n));
+    h->nparts = (L * kGroup + kBlock - 1) / kBlock;
+    SE2_CHECK(h->part.reserve(2 * (size_t)std::max(h->nparts, 1)));
+    SE2_CHECK(h->scal.reserve(8 + (size_t)h->world));
+    const size_t nred = std::max((size_t)n * n + n + 4, (size_t)h->world);
+    if (h->ar_buffer) {
+        h->red = (double*)h->ar_buffer;
+    } else {
+        SE2_CHECK(h->red_own.reserve(nred));
+        h->red = h->red_own.p;
+    }
+    SE2_CHECK(h->h_red.reserve(nred));
+    SE2_CHECK(h->h_x.reserve(n));
+    SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
+    h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
+    h->lms = h->lms_a.p; h->lms_t = h->lms_b.p;
+    SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+    if (L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    h->initialized = true;
+    return SE2GPU_OK;
+}
+
+inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
+
+// linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl, odometry blocks, Hpp, bp
+int ba_linearize(se2gpu_ba* h) {
+    hipStream_t st = h->stream;
+    SE2_LAUNCH(h->prof, st, "k_linearize", k_linearize, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam,
+               h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
+               h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p);
+    if (h->O)
+        SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
+                   h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
+    SE2_LAUNCH(h->prof, st, "k_pose_reduce", k_pose_reduce, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
+               h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p,
+               h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
+    SE2_HIP(hipGetLastError());
+    return SE2GPU_OK;
+}
+
+// reduced system for damping lambda into h->red = [S | bs | ...] (local contribution of this rank)
+int ba_reduce(se2gpu_ba* h, double lambda) {
+    hipStream_t st = h->stream;
+    const int n = 3 * h->P;
+    double* S = h->red;
+    double* bs = h->red + (size_t)n * n;
+    SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
+               lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Dinv.p, h->z.p, h->Y.p);
+    SE2_LAUNCH(h->prof, st, "k_reduce", k_reduce, grid1((size_t)h->nblk * 64, kBlock), dim3(kBlock), 0, h->P, h->nblk,
+               lambda, h->root, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->pair_i.p, h->pair_j.p, h->Y.p, h->Hpl.p,
+               h->Hpp.p, h->bp.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->e_lm.p, h->z.p, S, bs);
+    if (h->O)
+        SE2_LAUNCH(h->prof, st, "k_reduce_odo", k_reduce_odo, grid1((size_t)h->O * 9, 256), dim3(256), 0, h->O, h->P,
+                   h->o_i.p, h->o_j.p, h->Oij.p, S);
+    SE2_HIP(hipGetLastError());
+    return SE2GPU_OK;
+}
+
+int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count) {
+    if (!h->allreduce) return SE2GPU_OK;
+    const int rc = h->allreduce(ptr, count, (void*)h->stream, h->ar_user);
+    SE2_REQUIRE(rc == 0, SE2GPU_ERR_HIP, "all-reduce callback failed with %d", rc);
+    return SE2GPU_OK;
+}
+
+// chi2 / scale of a (trial) step; xp == nullptr evaluates the current state.  Result in h->h_scal[0..1].
+int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
+    hipStream_t st = h->stream;
+    const int n = 3 * h->P;
+    double* scal = h->red + (size_t)n * n + n;  // 4 trailing scalars of the fused buffer
+    SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
+               lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
+               h->Y.p, h->bl.p, h->lms_t, h->part.p);
+    SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
+               lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
+               h->o_info.p, h->root, scal);
+    SE2_HIP(hipGetLastError());
+    SE2_CHECK(ba_allreduce(h, scal, 4));
+    SE2_HIP(hipMemcpyAsync(h->h_scal.p, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    return SE2GPU_OK;
+}
+
+// dense pose solve: S|bs (device, already all-reduced) -> xp (device).  ok=false on a failed factorisation.
+int ba_solve(se2gpu_ba* h, bool* ok) {
+    hipStream_t st = h->stream;
+    const int n = 3 * h->P;
+    SE2_HIP(hipMemcpyAsync(h->h_red.p, h->red, ((size_t)n * n + n) * sizeof(double), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    std::memcpy(h->h_x.p, h->h_red.p + (size_t)n * n, n * sizeof(double));
+    *ok = host_cholesky_solve(h->h_red.p, n, h->h_x.p);
+    if (!*ok) std::memset(h->h_x.p, 0, n * sizeof(double));
+    SE2_HIP(hipMemcpyAsync(h->xp.p, h->h_x.p, n * sizeof(double), hipMemcpyHostToDevice, st));
+    return SE2GPU_OK;
+}
+
+int ba_lambda_init(se2gpu_ba* h, double* lambda) {
+    hipStream_t st = h->stream;
+    SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
+               h->Hpp.p, h->diag3.p);
+    const bool sharded = h->allreduce && h->world > 1;
+    const size_t nd = 3 * (size_t)h->P;
+    if (sharded) {
+        // global Hpp diagonal when landmark-sharded.  Every all-reduce goes through the fused buffer `red`
+        // (it may alias a caller tensor); at this point of the iteration it holds nothing live.
+        SE2_HIP(hipMemcpyAsync(h->red, h->diag3.p, nd * 8, hipMemcpyDeviceToDevice, st));
+        SE2_CHECK(ba_allreduce(h, h->red, nd));
+        SE2_HIP(hipMemcpyAsync(h->diag3.p, h->red, nd * 8, hipMemcpyDeviceToDevice, st));
+    }
+    SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
+               h->fixed.p, h->scal.p);
+    SE2_HIP(hipGetLastError());
+    SE2_HIP(hipMemcpyAsync(h->h_scal.p + 4, h->scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    double maxd = h->h_scal.p[4];
+    if (sharded) {
+        // max over ranks through the SUM all-reduce: every rank deposits its local max in its own slot
+        double* slots = h->h_scal.p + 8;
+        for (int r = 0; r < h->world; ++r) slots[r] = (r == h->rank) ? maxd : 0.0;
+        SE2_HIP(hipMemcpyAsync(h->red, slots, h->world * sizeof(double), hipMemcpyHostToDevice, st));
+        SE2_CHECK(ba_allreduce(h, h->red, (size_t)h->world));
+        SE2_HIP(hipMemcpyAsync(slots, h->red, h->world * sizeof(double), hipMemcpyDeviceToHost, st));
+        SE2_HIP(hipStreamSynchronize(st));
+        for (int r = 0; r < h->world; ++r) maxd = std::max(maxd, slots[r]);
+    }
+    *lambda = 1e-5 * maxd;
+    return SE2GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int se2gpu_ba_create(se2gpu_ba** out) {
+    SE2_REQUIRE(out, SE2GPU_ERR_INVALID, "ba_create: out is NULL");
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
+    se2gpu_ba* h = new se2gpu_ba;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        set_error("hipStreamCreate failed");
+        return SE2GPU_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return SE2GPU_OK;
+}
+
+void se2gpu_ba_destroy(se2gpu_ba* h) { delete h; }
+
+int se2gpu_ba_clear(se2gpu_ba* h) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    h->pose_of_id.clear(); h->lm_of_id.clear(); h->pose_ids.clear(); h->lm_ids.clear();
+    h->h_poses.clear(); h->h_lms.clear(); h->h_fixed.clear(); h->obs.clear(); h->odo.clear();
+    h->have_cam = false;
+    h->initialized = false;
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_set_stream(se2gpu_ba* h, void* s) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return SE2GPU_OK;
+}
+void* se2gpu_ba_stream(se2gpu_ba* h) { return h ? (void*)h->stream : nullptr; }
+
+int se2gpu_ba_add_cam(se2gpu_ba* h, double f, double cx, double cy) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    h->cam.fx = f; h->cam.cx = cx; h->cam.cy = cy;
+    h->have_cam = true;
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_set_Tbc(se2gpu_ba* h, const double R[9], const double t[3]) {
+    SE2_REQUIRE(h && R && t, SE2GPU_ERR_INVALID, "set_Tbc: NULL argument");
+    std::memcpy(h->Rbc, R, 72);
+    std::memcpy(h->tbc, t, 24);
+    h->have_tbc = true;
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_add_vertex_se2(se2gpu_ba* h, int id, double x, double y, double theta, int fixed) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    SE2_REQUIRE(!h->pose_of_id.count(id) && !h->lm_of_id.count(id), SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    h->pose_of_id[id] = (int)h->pose_ids.size();
+    h->pose_ids.push_back(id);
+    h->h_poses.push_back(x); h->h_poses.push_back(y); h->h_poses.push_back(normalize_theta(theta));  // SE2 ctor
+    h->h_fixed.push_back(fixed ? 1 : 0);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_add_vertex_xyz(se2gpu_ba* h, int id, const double xyz[3], int marginal, int fixed) {
+    SE2_REQUIRE(h && xyz, SE2GPU_ERR_INVALID, "add_vertex_xyz: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    SE2_REQUIRE(marginal && !fixed, SE2GPU_ERR_INVALID,
+                "only marginalised, free landmarks are supported (addVertexSBAXYZ defaults, optimizer.h:91)");
+    SE2_REQUIRE(!h->pose_of_id.count(id) && !h->lm_of_id.count(id), SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    h->lm_of_id[id] = (int)h->lm_ids.size();
+    h->lm_ids.push_back(id);
+    h->h_lms.push_back(xyz[0]); h->h_lms.push_back(xyz[1]); h->h_lms.push_back(xyz[2]);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double uv[2], const double info[4],
+                              double huber_delta) {
+    SE2_REQUIRE(h && uv && info, SE2GPU_ERR_INVALID, "add_edge_se2xyz: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    auto a = h->pose_of_id.find(id_kf);
+    auto b = h->lm_of_id.find(id_mp);
+    SE2_REQUIRE(a != h->pose_of_id.end() && b != h->lm_of_id.end(), SE2GPU_ERR_INVALID,
+                "add_edge_se2xyz: unknown vertex id (%d, %d)", id_kf, id_mp);
+    EdgeObs e;
+    e.kf = a->second; e.lm = b->second;
+    e.uv[0] = uv[0]; e.uv[1] = uv[1];
+    e.info[0] = info[0]; e.info[1] = 0.5 * (info[1] + info[2]); e.info[2] = info[3];
+    e.huber = huber_delta;
+    h->obs.push_back(e);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_add_edge_se2(se2gpu_ba* h, int id0, int id1, const double meas[3], const double info[9]) {
+    SE2_REQUIRE(h && meas && info, SE2GPU_ERR_INVALID, "add_edge_se2: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    auto a = h->pose_of_id.find(id0);
+    auto b = h->pose_of_id.find(id1);
+    SE2_REQUIRE(a != h->pose_of_id.end() && b != h->pose_of_id.end(), SE2GPU_ERR_INVALID,
+                "add_edge_se2: unknown pose id (%d, %d)", id0, id1);
+    EdgeOdo e;
+    e.i = a->second; e.j = b->second;
+    std::memcpy(e.meas, meas, 24);
+    std::memcpy(e.info, info, 72);
+    h->odo.push_back(e);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O, const double* poses, const uint8_t* fixed,
+                   const double* lms, const int32_t* e_kf, const int32_t* e_lm, const double* e_uv,
+                   const double* e_info, const int32_t* o_i, const int32_t* o_j, const double* o_meas,
+                   const double* o_info, double huber_delta) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    SE2_REQUIRE(P >= 0 && L >= 0 && E >= 0 && O >= 0, SE2GPU_ERR_INVALID, "negative size");
+    for (int p = 0; p < P; ++p)
+        SE2_CHECK(se2gpu_ba_add_vertex_se2(h, p, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], fixed[p]));
+    h->lm_of_id.reserve(L);
+    for (int l = 0; l < L; ++l) SE2_CHECK(se2gpu_ba_add_vertex_xyz(h, P + l, lms + 3 * (size_t)l, 1, 0));
+    h->obs.reserve(E);
+    for (int k = 0; k < E; ++k) {
+        SE2_REQUIRE(e_kf[k] >= 0 && e_kf[k] < P && e_lm[k] >= 0 && e_lm[k] < L, SE2GPU_ERR_INVALID,
+                    "edge %d references a vertex out of range", k);
+        EdgeObs e;
+        e.kf = e_kf[k]; e.lm = e_lm[k];
+        e.uv[0] = e_uv[2 * (size_t)k]; e.uv[1] = e_uv[2 * (size_t)k + 1];
+        e.info[0] = e_info[3 * (size_t)k]; e.info[1] = e_info[3 * (size_t)k + 1]; e.info[2] = e_info[3 * (size_t)k + 2];
+        e.huber = huber_delta;
+        h->obs.push_back(e);
+    }
+    for (int k = 0; k < O; ++k) SE2_CHECK(se2gpu_ba_add_edge_se2(h, o_i[k], o_j[k], o_meas + 3 * k, o_info + 9 * k));
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_initialize(se2gpu_ba* h) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    return ba_upload_graph(h);
+}
+
+int se2gpu_ba_reset_estimates(se2gpu_ba* h) {
+    SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "reset_estimates before initialize");
+    SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)h->P * 8, hipMemcpyDeviceToDevice, h->stream));
+    if (h->L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)h->L * 8, hipMemcpyDeviceToDevice, h->stream));
+    return SE2GPU_OK;
+}
+
+size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba*, int P) {
+    const size_t n = 3 * (size_t)P;
+    return n * n + n + 4;
+}
+
+int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, void* buffer) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "set_allreduce must precede initialize");
+    h->allreduce = fn;
+    h->ar_user = user;
+    h->ar_buffer = buffer;
+    return SE2GPU_OK;
+}
+
+// landmark shard `rank` of `world`; rank 0 owns the odometry edges and the lambda*I / identity terms
+int se2gpu_ba_set_shard(se2gpu_ba* h, int rank, int world) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "set_shard must precede initialize");
+    SE2_REQUIRE(world >= 1 && rank >= 0 && rank < world, SE2GPU_ERR_INVALID, "bad rank/world %d/%d", rank, world);
+    h->rank = rank;
+    h->world = world;
+    h->root = rank == 0 ? 1 : 0;
+    return SE2GPU_OK;
+}
+
+double se2gpu_ba_chi2(se2gpu_ba* h) {
+    if (!h || !h->initialized) {
+        set_error("chi2 before initialize");
+        return -1.0;
+    }
+    if (ba_evaluate(h, nullptr, 0.0) != SE2GPU_OK) return -1.0;
+    return h->h_scal.p[0];
+}
+
+int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs) {
+    SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "debug_reduced_system before initialize");
+    const int n = 3 * h->P;
+    SE2_CHECK(ba_linearize(h));
+    SE2_CHECK(ba_reduce(h, lambda));
+    SE2_CHECK(ba_allreduce(h, h->red, (size_t)n * n + n));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    if (S) SE2_HIP(hipMemcpy(S, h->red, (size_t)n * n * 8, hipMemcpyDeviceToHost));
+    if (bs) SE2_HIP(hipMemcpy(bs, h->red + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
+                       se2gpu_ba_stats* stats) {
+    SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "optimize before initialize");
+    SE2_REQUIRE(mode == SE2GPU_BA_LM || mode == SE2GPU_BA_GN, SE2GPU_ERR_INVALID, "unknown mode %d", mode);
+    se2gpu_ba_stats s;
+    std::memset(&s, 0, sizeof(s));
+    const int n = 3 * h->P;
+    auto terminate = [&]() { return stop_flag && *stop_flag; };
+    SE2_CHECK(ba_evaluate(h, nullptr, 0.0));
+    double currentChi = h->h_scal.p[0];
+    s.chi2_init = s.chi2_final = currentChi;
+    double lambda = 0, ni = 2;
+    bool ok = true;
+    for (int it = 0; it < iters && !terminate() && ok; ++it) {
+        SE2_CHECK(ba_linearize(h));
+        if (mode == SE2GPU_BA_LM && it == 0) {
+            SE2_CHECK(ba_lambda_init(h, &lambda));
+            ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const double lam = mode == SE2GPU_BA_LM ? lambda : 0.0;
+            SE2_CHECK(ba_reduce(h, lam));
+            SE2_CHECK(ba_allreduce(h, h->red, (size_t)n * n + n));
+            bool ok2 = true;
+            SE2_CHECK(ba_solve(h, &ok2));
+            SE2_CHECK(ba_evaluate(h, h->xp.p, lam));
+            double tempChi = h->h_scal.p[0];
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            ++s.trials;
+            ++qmax;
+            if (mode == SE2GPU_BA_GN) {
+                std::swap(h->poses, h->poses_t);
+                std::swap(h->lms, h->lms_t);
+                currentChi = tempChi;
+                rho = 1;
+                break;
+            }
+            rho = currentChi - tempChi;
+            const double scale = h->h_scal.p[1] + 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                std::swap(h->poses, h->poses_t);   // discardTop(): the trial state becomes the estimate
+                std::swap(h->lms, h->lms_t);
+            } else {
+                lambda *= ni;                       // pop(): keep the previous estimate
+                ni *= 2;
+            }
+            if (verbose)
+                fprintf(stderr, "se2gpu_ba: it %d trial %d chi2 %.9g -> %.9g rho %.3g lambda %.6g\n", it, qmax,
+                        currentChi, tempChi, rho, lambda);
+        } while (rho < 0 && qmax < 10 && !terminate());
+        if (it < 64) { s.chi2_hist[it] = currentChi; s.lambda_hist[it] = lambda; s.trials_hist[it] = qmax; }
+        s.iterations = it + 1;
+        s.chi2_final = currentChi;
+        if (mode == SE2GPU_BA_LM && (qmax == 10 || rho == 0)) { s.terminated = 1; ok = false; }
+    }
+    s.stopped = terminate() ? 1 : 0;
+    s.lambda_final = lambda;
+    if (stats) *stats = s;
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_get_all(se2gpu_ba* h, double* poses, double* lms) {
+    SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "get before initialize");
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    if (poses) SE2_HIP(hipMemcpy(poses, h->poses, 3 * (size_t)h->P * 8, hipMemcpyDeviceToHost));
+    if (lms && h->L) SE2_HIP(hipMemcpy(lms, h->lms, 3 * (size_t)h->L * 8, hipMemcpyDeviceToHost));
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_get_se2(se2gpu_ba* h, int id, double xyt[3]) {
+    SE2_REQUIRE(h && h->initialized && xyt, SE2GPU_ERR_STATE, "get_se2 before initialize");
+    auto a = h->pose_of_id.find(id);
+    SE2_REQUIRE(a != h->pose_of_id.end(), SE2GPU_ERR_INVALID, "unknown pose id %d", id);
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    SE2_HIP(hipMemcpy(xyt, h->poses + 3 * (size_t)a->second, 24, hipMemcpyDeviceToHost));
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_get_xyz(se2gpu_ba* h, int id, double xyz[3]) {
+    SE2_REQUIRE(h && h->initialized && xyz, SE2GPU_ERR_STATE, "get_xyz before initialize");
+    auto a = h->lm_of_id.find(id);
+    SE2_REQUIRE(a != h->lm_of_id.end(), SE2GPU_ERR_INVALID, "unknown landmark id %d", id);
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    SE2_HIP(hipMemcpy(xyz, h->lms + 3 * (size_t)a->second, 24, hipMemcpyDeviceToHost));
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_shard_landmarks(int L, int E, const int32_t* e_kf, const int32_t* e_lm, int world, int32_t* owner) {
+    SE2_REQUIRE(L >= 0 && E >= 0 && world >= 1 && owner && (E == 0 || (e_kf && e_lm)), SE2GPU_ERR_INVALID,
+                "shard_landmarks: bad argument");
+    std::vector<int64_t> first(L, std::numeric_limits<int64_t>::max());
+    std::vector<int64_t> deg(L, 0);
+    for (int k = 0; k < E; ++k) {
+        SE2_REQUIRE(e_lm[k] >= 0 && e_lm[k] < L, SE2GPU_ERR_INVALID, "edge %d: landmark out of range", k);
+        first[e_lm[k]] = std::min<int64_t>(first[e_lm[k]], e_kf[k]);
+        deg[e_lm[k]]++;
+    }
+    std::vector<int> order(L);
+    for (int l = 0; l < L; ++l) order[l] = l;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+    int64_t total = 0;
+    for (int l = 0; l < L; ++l) total += deg[l];
+    int64_t csum = 0;
+    for (int k = 0; k < L; ++k) {
+        const int l = order[k];
+        csum += deg[l];
+        // first chunk r with bound_r = total*(r+1)/world >= csum
+        int r = 0;
+        while (r < world - 1 && (total * (int64_t)(r + 1)) / world < csum) ++r;
+        owner[l] = r;
+    }
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_profile(se2gpu_ba* h, int enable) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    h->prof.enabled = enable != 0;
+    h->prof.reset();
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_profile_get(se2gpu_ba* h, int idx, const char** name, double* ms, int64_t* launches) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    if (idx < 0 || idx >= (int)h->prof.slots.size()) return SE2GPU_ERR_INVALID;
+    if (name) *name = h->prof.slots[idx].name;
+    if (ms) *ms = h->prof.slots[idx].ms;
+    if (launches) *launches = h->prof.slots[idx].launches;
+    return SE2GPU_OK;
+}
+
+}  // extern "C"

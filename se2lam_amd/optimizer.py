@@ -1,0 +1,218 @@
+"""Python mirror of the reference's optimiser call surface over the C ABI.
+
+Names and argument meaning follow /root/reference/include/se2lam/optimizer.h:78-141 and the
+g2o::SparseOptimizer methods LocalMapper::localBA uses (/root/reference/src/LocalMapper.cpp:239-260)
+so the parity tests read like the reference's own call sites (Map.cpp:891-1053).  The C++ twin of
+this file is include/se2lam_amd/optimizer.h.  All compute happens in libse2gpu.so (HIP).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+LM, GN = 0, 1
+
+
+class SlamOptimizer:
+    """g2o::SparseOptimizer with SlamAlgorithm = Levenberg, BlockSolverX, dense pose solve."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        capi.check(capi.lib().se2gpu_ba_create(C.byref(self._h)))
+        self._stop = None
+        self._verbose = False
+        self._cb = None
+        self._keep = []
+        self.stats = None
+
+    # -- SparseOptimizer methods -----------------------------------------------------------
+    def setVerbose(self, v: bool):
+        self._verbose = bool(v)
+
+    def setForceStopFlag(self, flag: np.ndarray | None):
+        """flag: a 1-element uint8 numpy array polled between LM trials (bool* in the reference)."""
+        self._stop = flag
+
+    def clear(self):
+        capi.check(capi.lib().se2gpu_ba_clear(self._h))
+
+    clearParameters = clear
+
+    def initializeOptimization(self, level: int = 0):
+        assert level == 0
+        capi.check(capi.lib().se2gpu_ba_initialize(self._h))
+
+    def optimize(self, iterations: int, mode: int = LM) -> int:
+        st = capi.BaStats()
+        stop = self._stop.ctypes.data_as(C.POINTER(C.c_uint8)) if self._stop is not None else None
+        capi.check(capi.lib().se2gpu_ba_optimize(self._h, int(iterations), int(mode), stop, int(self._verbose),
+                                                 C.byref(st)))
+        n = min(st.iterations, 64)
+        self.stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated),
+                          stopped=bool(st.stopped), chi2_init=st.chi2_init, chi2_final=st.chi2_final,
+                          lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
+                          lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]))
+        return st.iterations
+
+    def activeRobustChi2(self) -> float:
+        v = capi.lib().se2gpu_ba_chi2(self._h)
+        if v < 0:
+            capi.check(capi.ERR_STATE)
+        return float(v)
+
+    # -- harness extras ----------------------------------------------------------------------
+    def load(self, g):
+        """Bulk se2gpu_ba_load of a synth.BAGraph (ids: poses 0..P-1, landmarks P..P+L-1)."""
+        l = capi.lib()
+        capi.check(l.se2gpu_ba_add_cam(self._h, g.fx, g.cx, g.cy))
+        R = np.ascontiguousarray(g.Rbc, np.float64).reshape(-1)
+        t = np.ascontiguousarray(g.tbc, np.float64).reshape(-1)
+        capi.check(l.se2gpu_ba_set_Tbc(self._h, capi.pd(R), capi.pd(t)))
+        a = [np.ascontiguousarray(g.poses, np.float64), np.ascontiguousarray(g.fixed, np.uint8),
+             np.ascontiguousarray(g.lms, np.float64), np.ascontiguousarray(g.e_kf, np.int32),
+             np.ascontiguousarray(g.e_lm, np.int32), np.ascontiguousarray(g.e_uv, np.float64),
+             np.ascontiguousarray(g.e_info, np.float64), np.ascontiguousarray(g.o_i, np.int32),
+             np.ascontiguousarray(g.o_j, np.int32), np.ascontiguousarray(g.o_meas, np.float64),
+             np.ascontiguousarray(g.o_info, np.float64)]
+        P32, PU8 = C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+        capi.check(l.se2gpu_ba_load(self._h, g.P, g.L, g.E, g.O, capi.pd(a[0]), a[1].ctypes.data_as(PU8),
+                                    capi.pd(a[2]), a[3].ctypes.data_as(P32), a[4].ctypes.data_as(P32),
+                                    capi.pd(a[5]), capi.pd(a[6]), a[7].ctypes.data_as(P32),
+                                    a[8].ctypes.data_as(P32), capi.pd(a[9]), capi.pd(a[10]), float(g.huber)))
+        self._shape = (g.P, g.L)
+
+    def estimates(self):
+        P, L = self._shape
+        poses = np.zeros((P, 3))
+        lms = np.zeros((max(L, 1), 3))
+        capi.check(capi.lib().se2gpu_ba_get_all(self._h, capi.pd(poses), capi.pd(lms)))
+        return poses, lms[:L]
+
+    def reset_estimates(self):
+        capi.check(capi.lib().se2gpu_ba_reset_estimates(self._h))
+
+    def reduced_system(self, lam: float):
+        P, _ = self._shape
+        n = 3 * P
+        S = np.zeros((n, n))
+        bs = np.zeros(n)
+        capi.check(capi.lib().se2gpu_ba_debug_reduced_system(self._h, float(lam), capi.pd(S), capi.pd(bs)))
+        return S, bs
+
+    def set_shard(self, rank: int, world: int):
+        capi.check(capi.lib().se2gpu_ba_set_shard(self._h, rank, world))
+
+    def set_allreduce(self, fn, buffer_ptr=None):
+        """fn(dev_ptr:int, count:int, stream:int) -> None must sum `count` doubles in place over ranks."""
+        def _tramp(ptr, count, stream, user):
+            try:
+                fn(ptr, count, stream)
+                return 0
+            except Exception as exc:  # never unwind through the C ABI
+                print(f"se2lam_amd: all-reduce callback failed: {exc!r}")
+                return 1
+        self._cb = capi.ALLREDUCE_FN(_tramp)
+        capi.check(capi.lib().se2gpu_ba_set_allreduce(self._h, self._cb, None, buffer_ptr))
+
+    def reduce_buffer_doubles(self, P: int) -> int:
+        return int(capi.lib().se2gpu_ba_reduce_buffer_doubles(self._h, P))
+
+    def set_stream(self, stream_ptr):
+        capi.check(capi.lib().se2gpu_ba_set_stream(self._h, stream_ptr))
+
+    def stream(self):
+        return capi.lib().se2gpu_ba_stream(self._h)
+
+    def profile(self, enable: bool):
+        capi.check(capi.lib().se2gpu_ba_profile(self._h, int(enable)))
+
+    def profile_report(self):
+        out = {}
+        i = 0
+        while True:
+            name = C.c_char_p()
+            ms = C.c_double()
+            n = C.c_int64()
+            if capi.lib().se2gpu_ba_profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(n)) != 0:
+                break
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                capi.lib().se2gpu_ba_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+# -- free functions of optimizer.h ------------------------------------------------------------
+def addCamPara(opt: SlamOptimizer, K: np.ndarray, id: int = 0):
+    """optimizer.h:85 / optimizer.cpp:207-215: single focal length K(0,0), principal point K(0,2),K(1,2)."""
+    K = np.asarray(K, dtype=np.float32)
+    capi.check(capi.lib().se2gpu_ba_add_cam(opt._h, float(K[0, 0]), float(K[0, 2]), float(K[1, 2])))
+
+
+def setExtParameter(opt: SlamOptimizer, Rbc, tbc):
+    """EdgeSE2XYZ::setExtParameter(Tbc) (EdgeSE2XYZ.h:53) - one extrinsic for the whole graph."""
+    R = np.ascontiguousarray(Rbc, np.float64).reshape(-1)
+    t = np.ascontiguousarray(tbc, np.float64).reshape(-1)
+    capi.check(capi.lib().se2gpu_ba_set_Tbc(opt._h, capi.pd(R), capi.pd(t)))
+
+
+def addVertexSE2(opt: SlamOptimizer, pose, id: int, fixed: bool = False):
+    """optimizer.h:104"""
+    capi.check(capi.lib().se2gpu_ba_add_vertex_se2(opt._h, int(id), float(pose[0]), float(pose[1]), float(pose[2]),
+                                                   int(bool(fixed))))
+
+
+def addVertexSBAXYZ(opt: SlamOptimizer, xyz, id: int, marginal: bool = True, fixed: bool = False):
+    """optimizer.h:91"""
+    a = np.ascontiguousarray(xyz, np.float64)
+    capi.check(capi.lib().se2gpu_ba_add_vertex_xyz(opt._h, int(id), capi.pd(a), int(marginal), int(fixed)))
+
+
+def addEdgeSE2XYZ(opt: SlamOptimizer, meas, id0: int, id1: int, info, thHuber: float):
+    """optimizer.h:100 (campara / Tbc are graph-wide: addCamPara, setExtParameter)."""
+    m = np.ascontiguousarray(meas, np.float64)
+    w = np.ascontiguousarray(info, np.float64).reshape(-1)
+    assert w.size == 4
+    capi.check(capi.lib().se2gpu_ba_add_edge_se2xyz(opt._h, int(id0), int(id1), capi.pd(m), capi.pd(w), float(thHuber)))
+
+
+def addEdgeSE2(opt: SlamOptimizer, meas, id0: int, id1: int, info):
+    """optimizer.h:109"""
+    m = np.ascontiguousarray(meas, np.float64)
+    w = np.ascontiguousarray(info, np.float64).reshape(-1)
+    assert w.size == 9
+    capi.check(capi.lib().se2gpu_ba_add_edge_se2(opt._h, int(id0), int(id1), capi.pd(m), capi.pd(w)))
+
+
+def estimateVertexSE2(opt: SlamOptimizer, id: int) -> np.ndarray:
+    """optimizer.h:107"""
+    out = np.zeros(3)
+    capi.check(capi.lib().se2gpu_ba_get_se2(opt._h, int(id), capi.pd(out)))
+    return out
+
+
+def estimateVertexSBAXYZ(opt: SlamOptimizer, id: int) -> np.ndarray:
+    """optimizer.h:141"""
+    out = np.zeros(3)
+    capi.check(capi.lib().se2gpu_ba_get_xyz(opt._h, int(id), capi.pd(out)))
+    return out
+
+
+def shard_landmarks(L: int, e_kf: np.ndarray, e_lm: np.ndarray, world: int) -> np.ndarray:
+    """Host-side landmark partition of the library (no device needed)."""
+    e_kf = np.ascontiguousarray(e_kf, np.int32)
+    e_lm = np.ascontiguousarray(e_lm, np.int32)
+    owner = np.zeros(L, np.int32)
+    P32 = C.POINTER(C.c_int32)
+    capi.check(capi.lib().se2gpu_ba_shard_landmarks(int(L), int(e_kf.size), e_kf.ctypes.data_as(P32),
+                                                     e_lm.ctypes.data_as(P32), int(world), owner.ctypes.data_as(P32)))
+    return owner

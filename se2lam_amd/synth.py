@@ -1,0 +1,373 @@
+"""Seeded synthetic inputs for the se2lam hot path.
+
+Nothing here is on the product path: these generators only build inputs that
+the tests, `bench.py` and `__graft_entry__.smoke()` feed to BOTH the oracle
+and the HIP library.
+
+* `texture()/frame()`      - 640x480 u8 crops of a random-rectangle texture
+                             (seed 20190520) for the ORB extractor / matcher.
+* `ba_graph(P, L, ...)`    - circular-trajectory room graph (seed 424242) in the
+                             formulation of `Map::loadLocalGraph`
+                             (/root/reference/src/Map.cpp:891-1053): SE(2) poses,
+                             XYZ landmarks, EdgeSE2XYZ observations with the
+                             plane-motion information of Map.cpp:1024-1049 and
+                             PreEdgeSE2 odometry edges whose measurement and
+                             covariance are pre-integrated exactly as
+                             Track::updateFramePose (src/Track.cpp:162-188).
+"""
+from __future__ import annotations
+
+import dataclasses
+import functools
+
+import numpy as np
+
+ORB_SEED = 20190520
+BA_SEED = 424242
+
+IMG_W, IMG_H = 640, 480
+FX = 400.0
+CX, CY = 320.0, 240.0
+
+# Camera (z fwd, x right, y down) mounted on body (x fwd, y left, z up); mm.
+RBC = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+TBC = np.array([100.0, 0.0, 300.0])
+
+TH_HUBER = float(np.sqrt(5.991))
+PLANEMOTION_XROT_INFO = 1e6  # src/Config.cpp:46
+PLANEMOTION_Z_INFO = 1.0  # src/Config.cpp:48
+SCALE_FACTOR = np.float32(1.2)
+
+
+# --------------------------------------------------------------------------
+# ORB frames
+# --------------------------------------------------------------------------
+@functools.lru_cache(maxsize=2)
+def texture(seed: int = ORB_SEED) -> np.ndarray:
+    """1280x960 u8: 4000 random axis-aligned rectangles over mid-grey + N(0,3^2)."""
+    rng = np.random.default_rng(seed)
+    W, H = 1280, 960
+    tex = np.full((H, W), 128.0, dtype=np.float64)
+    n = 4000
+    xs = rng.integers(0, W, n)
+    ys = rng.integers(0, H, n)
+    ws = rng.integers(4, 41, n)
+    hs = rng.integers(4, 41, n)
+    gs = rng.integers(0, 256, n)
+    for x, y, w, h, g in zip(xs, ys, ws, hs, gs):
+        tex[y:y + h, x:x + w] = g
+    tex += rng.normal(0.0, 3.0, size=tex.shape)
+    return np.clip(np.rint(tex), 0, 255).astype(np.uint8)
+
+
+def frame(t: int, seed: int = ORB_SEED) -> np.ndarray:
+    """Frame t = 640x480 crop at offset (100+3t, 80+t) (wrapped to stay inside)."""
+    tex = texture(seed)
+    ox = 100 + (3 * t) % 540
+    oy = 80 + t % 400
+    return np.ascontiguousarray(tex[oy:oy + IMG_H, ox:ox + IMG_W])
+
+
+def frames(n: int, start: int = 0, seed: int = ORB_SEED) -> np.ndarray:
+    return np.stack([frame(start + i, seed) for i in range(n)], axis=0)
+
+
+# --------------------------------------------------------------------------
+# BA graphs
+# --------------------------------------------------------------------------
+@dataclasses.dataclass
+class BAGraph:
+    """Flat (SoA) description of one local-BA window.
+
+    poses      (P,3) f64  initial (x, y, theta) of each keyframe  [VertexSE2]
+    fixed      (P,)  u8   1 = fixed vertex (Map.cpp:927,969)
+    lms        (L,3) f64  initial landmark positions              [VertexSBAPointXYZ]
+    e_kf,e_lm  (E,)  i32  vertices of each EdgeSE2XYZ
+    e_uv       (E,2) f64  measurement
+    e_info     (E,3) f64  information (xx, xy, yy) = Sigma_all^-1 (Map.cpp:1045-1049)
+    o_i,o_j    (O,)  i32  PreEdgeSE2 vertices (this KF, next KF) (Map.cpp:942-953)
+    o_meas     (O,3) f64
+    o_info     (O,9) f64  row-major 3x3 = cov^-1
+    """
+    poses: np.ndarray
+    fixed: np.ndarray
+    lms: np.ndarray
+    e_kf: np.ndarray
+    e_lm: np.ndarray
+    e_uv: np.ndarray
+    e_info: np.ndarray
+    o_i: np.ndarray
+    o_j: np.ndarray
+    o_meas: np.ndarray
+    o_info: np.ndarray
+    fx: float = FX
+    cx: float = CX
+    cy: float = CY
+    Rbc: np.ndarray = dataclasses.field(default_factory=lambda: RBC.copy())
+    tbc: np.ndarray = dataclasses.field(default_factory=lambda: TBC.copy())
+    huber: float = TH_HUBER
+    poses_true: np.ndarray | None = None
+    lms_true: np.ndarray | None = None
+
+    @property
+    def P(self) -> int:
+        return int(self.poses.shape[0])
+
+    @property
+    def L(self) -> int:
+        return int(self.lms.shape[0])
+
+    @property
+    def E(self) -> int:
+        return int(self.e_kf.shape[0])
+
+    @property
+    def O(self) -> int:
+        return int(self.o_i.shape[0])
+
+    def algorithmic_bytes_per_iter(self) -> int:
+        """B_ba of SURVEY.md §8(d): 48E + 48L + 48P + 4*3P*(3P+1) + 24P."""
+        P, L, E = self.P, self.L, self.E
+        return 48 * E + 48 * L + 48 * P + 4 * 3 * P * (3 * P + 1) + 24 * P
+
+    def shard(self, rank: int, world: int) -> "BAGraph":
+        """Landmark shard `rank` of `world`: landmarks are ordered by the
+        lowest-id observing keyframe and split into `world` contiguous chunks of
+        (nearly) equal EDGE count; poses are replicated; odometry edges go to rank 0."""
+        if world == 1:
+            return self
+        owner = shard_landmarks(self.e_kf, self.e_lm, self.L, world)
+        keep_lm = np.nonzero(owner == rank)[0]
+        remap = -np.ones(self.L, dtype=np.int64)
+        remap[keep_lm] = np.arange(keep_lm.size)
+        keep_e = np.nonzero(owner[self.e_lm] == rank)[0]
+        odo = slice(None) if rank == 0 else slice(0, 0)
+        return dataclasses.replace(
+            self,
+            lms=self.lms[keep_lm].copy(),
+            e_kf=self.e_kf[keep_e].copy(),
+            e_lm=remap[self.e_lm[keep_e]].astype(np.int32),
+            e_uv=self.e_uv[keep_e].copy(),
+            e_info=self.e_info[keep_e].copy(),
+            o_i=self.o_i[odo].copy(), o_j=self.o_j[odo].copy(),
+            o_meas=self.o_meas[odo].copy(), o_info=self.o_info[odo].copy(),
+            lms_true=None if self.lms_true is None else self.lms_true[keep_lm].copy(),
+        )
+
+
+def shard_landmarks(e_kf: np.ndarray, e_lm: np.ndarray, L: int, world: int) -> np.ndarray:
+    """owner[l] in [0, world): contiguous chunks, balanced by edge count, of the landmarks
+    sorted by (lowest observing keyframe id, landmark id) - "sharded by keyframe window"."""
+    first_kf = np.full(L, np.iinfo(np.int64).max, dtype=np.int64)
+    np.minimum.at(first_kf, e_lm, e_kf.astype(np.int64))
+    deg = np.bincount(e_lm, minlength=L)
+    order = np.lexsort((np.arange(L), first_kf))
+    csum = np.cumsum(deg[order])
+    total = int(csum[-1]) if L else 0
+    owner = np.zeros(L, dtype=np.int32)
+    # landmark at sorted position k goes to the chunk its cumulative edge count falls in
+    bounds = [(total * (r + 1)) // world for r in range(world)]
+    chunk = np.searchsorted(np.asarray(bounds), csum, side="left")
+    owner[order] = np.minimum(chunk, world - 1).astype(np.int32)
+    return owner
+
+
+def _rot2(th):
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c, -s], [s, c]])
+
+
+def _norm_angle(a):
+    return (a + np.pi) % (2 * np.pi) - np.pi
+
+
+def _preintegrate(rng, pose_i, pose_j, nsub=10, sx=2.0, sy=2.0, st=0.002):
+    """PreSE2 (meas, cov) between two keyframes, accumulated over `nsub` odometry frames
+    exactly as Track::updateFramePose (src/Track.cpp:170-187), in double."""
+    # true relative motion, split into nsub equal body-frame increments + noise
+    dth = _norm_angle(pose_j[2] - pose_i[2])
+    dxy = _rot2(pose_i[2]).T @ (pose_j[:2] - pose_i[:2])
+    # constant-twist interpolation: recover the per-step increment by sampling the arc
+    ths = pose_i[2] + dth * np.arange(nsub + 1) / nsub
+    # positions along a straight chord in the i frame rotated progressively (good enough
+    # as a *generator*: only consistency between meas and cov matters)
+    pts = np.stack([dxy * k / nsub for k in range(nsub + 1)], axis=0)
+    meas = np.zeros(3)
+    cov = np.zeros((3, 3))
+    Sv = np.diag([sx * sx, sy * sy, st * st])
+    for k in range(nsub):
+        # odometry increment expressed in the frame at step k (relative heading ths[k]-ths[0])
+        Rk = _rot2(ths[k] - ths[0])
+        odo_xy = Rk.T @ (pts[k + 1] - pts[k]) + rng.normal(0.0, [sx, sy])
+        odo_th = (ths[k + 1] - ths[k]) + rng.normal(0.0, st)
+        Phi = _rot2(meas[2])
+        A = np.eye(3)
+        B = np.eye(3)
+        A[:2, 2] = Phi @ np.array([-odo_xy[1], odo_xy[0]])
+        B[:2, :2] = Phi
+        meas[:2] += Phi @ odo_xy
+        meas[2] += odo_th
+        cov = A @ cov @ A.T + B @ Sv @ B.T
+    return meas, cov
+
+
+def _project(poses, lms, kf, lm, Rcb, tcb, fx, cx, cy):
+    """u,v,depth of landmark lm seen from keyframe kf (EdgeSE2XYZ.cpp:61-72 closed form)."""
+    th = poses[kf, 2]
+    c, s = np.cos(th), np.sin(th)
+    d = lms[lm] - np.stack([poses[kf, 0], poses[kf, 1], np.zeros_like(th)], axis=-1)
+    # Rz(-th) * d
+    bx = c * d[..., 0] + s * d[..., 1]
+    by = -s * d[..., 0] + c * d[..., 1]
+    bz = d[..., 2]
+    b = np.stack([bx, by, bz], axis=-1)
+    lc = b @ Rcb.T + tcb
+    z = lc[..., 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = fx * lc[..., 0] / z + cx
+        v = fx * lc[..., 1] / z + cy
+    return u, v, z, lc
+
+
+def edge_information(poses, lms, e_kf, e_lm, level, Rbc, tbc, fx):
+    """Per-observation information of Map::loadLocalGraph (src/Map.cpp:1024-1049):
+    Sigma = s_rot*J_r*J_r^T + s_z*J_z*J_z^T + sigma2_level*I, Omega = Sigma^-1.
+    lc / Rcw go through float32 as in the reference (mViewMPs, Tcw are CV_32F)."""
+    Rcb = Rbc.T
+    tcb = -Rcb @ tbc
+    _, _, _, lc = _project(poses, lms, e_kf, e_lm, Rcb, tcb, fx, 0.0, 0.0)
+    lc = lc.astype(np.float32).astype(np.float64)
+    th = poses[e_kf, 2]
+    c, s = np.cos(th), np.sin(th)
+    E = e_kf.shape[0]
+    Rbw = np.zeros((E, 3, 3))
+    Rbw[:, 0, 0] = c
+    Rbw[:, 0, 1] = s
+    Rbw[:, 1, 0] = -s
+    Rbw[:, 1, 1] = c
+    Rbw[:, 2, 2] = 1.0
+    Rcw = (Rcb[None] @ Rbw).astype(np.float32).astype(np.float64)
+    zi = 1.0 / lc[:, 2]
+    zi2 = zi * zi
+    fxf = float(np.float32(fx))
+    Jpi = np.zeros((E, 2, 3))
+    Jpi[:, 0, 0] = fxf * zi
+    Jpi[:, 0, 2] = -fxf * lc[:, 0] * zi2
+    Jpi[:, 1, 1] = fxf * zi
+    Jpi[:, 1, 2] = -fxf * lc[:, 1] * zi2
+    A = Jpi @ Rcw  # (E,2,3)
+    # lw from float MP position, pi from float Twb
+    lw = lms[e_lm].astype(np.float32).astype(np.float64)
+    pi = np.zeros((E, 3))
+    pi[:, 0] = poses[e_kf, 0].astype(np.float32)
+    pi[:, 1] = poses[e_kf, 1].astype(np.float32)
+    d = lw - pi
+    sk = np.zeros((E, 3, 3))
+    sk[:, 0, 1] = -d[:, 2]
+    sk[:, 0, 2] = d[:, 1]
+    sk[:, 1, 0] = d[:, 2]
+    sk[:, 1, 2] = -d[:, 0]
+    sk[:, 2, 0] = -d[:, 1]
+    sk[:, 2, 1] = d[:, 0]
+    Jr = (A @ sk)[:, :, :2]
+    Jz = -A[:, :, 2:3]
+    s_rot = float(np.float32(1.0 / PLANEMOTION_XROT_INFO))
+    s_z = float(np.float32(1.0 / PLANEMOTION_Z_INFO))
+    # mvLevelSigma2[octave] (float chain, src/Frame.cpp:50-58)
+    sf = np.ones(8, dtype=np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * SCALE_FACTOR
+    sig2 = (sf * sf).astype(np.float32)
+    sig2[0] = 1.0
+    Sigma = s_rot * (Jr @ Jr.transpose(0, 2, 1)) + s_z * (Jz @ Jz.transpose(0, 2, 1))
+    Sigma[:, 0, 0] += sig2[level]
+    Sigma[:, 1, 1] += sig2[level]
+    info = np.linalg.inv(Sigma)
+    return np.stack([info[:, 0, 0], 0.5 * (info[:, 0, 1] + info[:, 1, 0]), info[:, 1, 1]], axis=1)
+
+
+@functools.lru_cache(maxsize=4)
+def ba_graph(P: int = 50, L: int = 5000, obs_per_lm: float = 6.0, seed: int = BA_SEED) -> BAGraph:
+    """Room 20 m x 20 m x 3 m, (almost) closed circle radius 6 m, P keyframes, L landmarks on the
+    walls / ceiling, ~obs_per_lm observations per landmark (config 3: P=50, L=5000;
+    config 4: P=200, L=20000).  Units: mm."""
+    rng = np.random.default_rng(seed + 1000003 * P + L)
+    Rcb = RBC.T
+    tcb = -Rcb @ TBC
+    # --- truth
+    # Headings sweep (-pi+0.1, pi-0.1): an almost-closed circle (348.5 deg).  The gap keeps every
+    # heading away from +-pi, where the reference's PreEdgeSE2 error `aj - ai - z` has no angle
+    # wrap (EdgeSE2XYZ.h:80) and VertexSE2::oplus re-normalises theta - a crossing would inject a
+    # spurious 2*pi odometry residual into the benchmark graph.
+    head = -np.pi + 0.1 + (2 * np.pi - 0.2) * np.arange(P) / max(P - 1, 1)
+    ang = head - np.pi / 2
+    poses_t = np.stack([6000.0 * np.cos(ang), 6000.0 * np.sin(ang), head], axis=1)
+
+    def sample_lms(n):
+        face = rng.integers(0, 5, n)  # 4 walls + ceiling
+        a = rng.uniform(-10000.0, 10000.0, n)
+        b = rng.uniform(-10000.0, 10000.0, n)
+        z = rng.uniform(0.0, 3000.0, n)
+        # faces 0/1: (+-10000, a, z) ; faces 2/3: (a, +-10000, z) ; face 4: (a, b, 3000)
+        x = np.select([face == 0, face == 1], [10000.0, -10000.0], default=a)
+        y = np.select([face == 2, face == 3, face == 4], [10000.0, -10000.0, b], default=a)
+        zz = np.where(face == 4, 3000.0, z)
+        return np.stack([x, y, zz], axis=1)
+
+    lms_list, ekf_list, elm_list = [], [], []
+    nlm = 0
+    guard = 0
+    while nlm < L:
+        guard += 1
+        assert guard < 200, "landmark sampling does not converge"
+        cand = sample_lms(max(2 * (L - nlm), 64))
+        kf = np.repeat(np.arange(P), cand.shape[0])
+        lm = np.tile(np.arange(cand.shape[0]), P)
+        u, v, z, _ = _project(poses_t, cand, kf, lm, Rcb, tcb, FX, CX, CY)
+        vis = (z >= 300.0) & (z <= 12000.0) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H)
+        vis = vis.reshape(P, -1)
+        for j in range(cand.shape[0]):
+            if nlm >= L:
+                break
+            who = np.nonzero(vis[:, j])[0]
+            if who.size < 2:
+                continue
+            k = int(np.clip(rng.poisson(obs_per_lm - 2.0) + 2, 2, who.size))
+            sel = np.sort(rng.choice(who, size=k, replace=False))
+            lms_list.append(cand[j])
+            ekf_list.append(sel)
+            elm_list.append(np.full(k, nlm))
+            nlm += 1
+    lms_t = np.stack(lms_list, axis=0)
+    e_kf = np.concatenate(ekf_list).astype(np.int32)
+    e_lm = np.concatenate(elm_list).astype(np.int32)
+    E = e_kf.shape[0]
+    # --- measurements
+    level = rng.integers(0, 8, E)
+    u, v, _, _ = _project(poses_t, lms_t, e_kf, e_lm, Rcb, tcb, FX, CX, CY)
+    sig = 1.2 ** level
+    e_uv = np.stack([u + rng.normal(0.0, 1.0, E) * sig, v + rng.normal(0.0, 1.0, E) * sig], axis=1)
+    # a few gross outliers so the Huber branch is exercised
+    nout = max(1, E // 200)
+    oidx = rng.choice(E, size=nout, replace=False)
+    e_uv[oidx] += rng.normal(0.0, 25.0, size=(nout, 2))
+    # --- initial estimates
+    poses0 = poses_t + rng.normal(0.0, 1.0, size=(P, 3)) * np.array([20.0, 20.0, 0.01])
+    poses0[0] = poses_t[0]
+    poses0[:, 2] = _norm_angle(poses0[:, 2])
+    lms0 = lms_t + rng.normal(0.0, 50.0, size=(L, 3))
+    fixed = np.zeros(P, dtype=np.uint8)
+    fixed[0] = 1
+    e_info = edge_information(poses0, lms0, e_kf, e_lm, level, RBC, TBC, FX)
+    # --- odometry (consecutive KFs; the loop is NOT closed by odometry)
+    o_i = np.arange(P - 1, dtype=np.int32)
+    o_j = o_i + 1
+    o_meas = np.zeros((P - 1, 3))
+    o_info = np.zeros((P - 1, 9))
+    for i in range(P - 1):
+        m, c = _preintegrate(rng, poses_t[i], poses_t[i + 1])
+        o_meas[i] = m
+        o_info[i] = np.linalg.inv(c).reshape(-1)
+    return BAGraph(poses=poses0, fixed=fixed, lms=lms0, e_kf=e_kf, e_lm=e_lm, e_uv=e_uv,
+                   e_info=e_info, o_i=o_i, o_j=o_j, o_meas=o_meas, o_info=o_info,
+                   poses_true=poses_t, lms_true=lms_t)

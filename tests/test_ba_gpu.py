@@ -1,0 +1,233 @@
+"""GPU parity tests of the HIP bundle adjustment (through the C ABI) against the CPU oracle.
+
+Tolerance (BASELINE.json north_star): BA cost and pose updates within 1e-5 relative.  The kernels
+sum J^T W J in a different order than the oracle, so FP64 results agree to ~1e-12 on one
+linearisation and to ~1e-9 after 10 LM iterations; the asserted bounds are the 1e-5 of the
+north star or tighter.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+
+
+def _opt(g):
+    from se2lam_amd.optimizer import SlamOptimizer
+    o = SlamOptimizer()
+    o.load(g)
+    o.initializeOptimization(0)
+    return o
+
+
+def _pose_update_close(p_gpu, p_ref, p0, rel=REL):
+    """pose UPDATES (estimate - initial) agree within `rel` relative (norm-wise per component)."""
+    d_gpu, d_ref = p_gpu - p0, p_ref - p0
+    for c in range(3):
+        scale = np.abs(d_ref[:, c]).max() + 1e-12
+        assert np.abs(d_gpu[:, c] - d_ref[:, c]).max() <= rel * scale, (c, np.abs(d_gpu[:, c] - d_ref[:, c]).max(), scale)
+
+
+def test_chi2_matches_oracle(oracle, synth):
+    for P, L in ((8, 60), (50, 5000)):
+        g = synth.ba_graph(P, L)
+        o = _opt(g)
+        assert o.activeRobustChi2() == pytest.approx(oracle.ba_chi2(g), rel=1e-12)
+
+
+def test_reduced_system_matches_oracle(oracle, synth):
+    for P, L, lam in ((8, 60, 0.0), (8, 60, 3.0), (50, 5000, 17.5)):
+        g = synth.ba_graph(P, L)
+        o = _opt(g)
+        S, bs = o.reduced_system(lam)
+        ref = oracle.ba_reduced_system(g, lam)
+        scale = np.abs(ref["S"]).max()
+        assert np.abs(S - ref["S"]).max() <= 1e-11 * scale
+        assert np.abs(bs - ref["bs"]).max() <= 1e-11 * np.abs(ref["bs"]).max()
+        assert np.array_equal(S, S.T)
+
+
+@pytest.mark.parametrize("P,L", [(8, 60), (50, 5000)])
+def test_lm_10_iterations_match_oracle(oracle, synth, P, L):
+    """config 3: localBA 50 KF / 5k landmarks / ~30k EdgeSE2XYZ, 10 iterations, cost within 1e-5."""
+    g = synth.ba_graph(P, L)
+    o = _opt(g)
+    assert o.optimize(10) == 10
+    p_ref, l_ref, st = oracle.ba_optimize(g, 10, 0)
+    s = o.stats
+    assert s["trials_hist"] == st["trials_hist"]
+    assert np.allclose(s["chi2_hist"], st["chi2_hist"], rtol=REL, atol=0)
+    assert np.allclose(s["lambda_hist"], st["lambda_hist"], rtol=REL, atol=0)
+    assert s["chi2_init"] == pytest.approx(st["chi2_init"], rel=1e-12)
+    assert s["chi2_final"] == pytest.approx(st["chi2_final"], rel=REL)
+    poses, lms = o.estimates()
+    _pose_update_close(poses, p_ref, g.poses)
+    dl = np.abs((lms - g.lms) - (l_ref - g.lms)).max()
+    assert dl <= REL * np.abs(l_ref - g.lms).max()
+    # the estimate the library holds reproduces its reported cost
+    assert o.activeRobustChi2() == pytest.approx(s["chi2_final"], rel=1e-12)
+
+
+def test_global_window_200kf_20k_landmarks(oracle, synth):
+    """config 4 formulation on one GPU: 200 KF / 20k landmarks / ~120k edges."""
+    g = synth.ba_graph(200, 20000)
+    o = _opt(g)
+    o.optimize(10)
+    p_ref, l_ref, st = oracle.ba_optimize(g, 10, 0)
+    assert o.stats["trials_hist"] == st["trials_hist"]
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=REL, atol=0)
+    poses, _ = o.estimates()
+    _pose_update_close(poses, p_ref, g.poses)
+
+
+def test_gauss_newton_mode(oracle, synth):
+    g = synth.ba_graph(8, 60)
+    o = _opt(g)
+    o.optimize(3, mode=1)
+    p_ref, l_ref, st = oracle.ba_optimize(g, 3, 1)
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=REL)
+
+
+def test_reference_call_surface_equals_bulk_load(oracle, synth):
+    """Graph built call by call as Map::loadLocalGraph does (Map.cpp:891-1053) == bulk load."""
+    from se2lam_amd import optimizer as op
+    g = synth.ba_graph(8, 60)
+    opt = op.SlamOptimizer()
+    K = np.array([[g.fx, 0, g.cx], [0, g.fx, g.cy], [0, 0, 1]], np.float32)
+    op.addCamPara(opt, K, 0)
+    op.setExtParameter(opt, g.Rbc, g.tbc)
+    nLocal = g.P
+    maxKFid = nLocal + 0 + 1                                   # Map.cpp:972
+    for i in range(g.P):
+        op.addVertexSE2(opt, g.poses[i], i, bool(g.fixed[i]))  # Map.cpp:925-930
+    for k in range(g.O):
+        op.addEdgeSE2(opt, g.o_meas[k], int(g.o_i[k]), int(g.o_j[k]), g.o_info[k])
+    for l in range(g.L):
+        op.addVertexSBAXYZ(opt, g.lms[l], maxKFid + l)         # Map.cpp:985-988
+    for k in range(g.E):
+        w = g.e_info[k]
+        op.addEdgeSE2XYZ(opt, g.e_uv[k], int(g.e_kf[k]), maxKFid + int(g.e_lm[k]),
+                         [[w[0], w[1]], [w[1], w[2]]], g.huber)
+    opt.initializeOptimization(0)
+    opt.optimize(5)
+    ref = _opt(g)
+    ref.optimize(5)
+    assert opt.stats["chi2_hist"] == ref.stats["chi2_hist"]
+    for i in range(g.P):
+        assert np.array_equal(op.estimateVertexSE2(opt, i), ref.estimates()[0][i])
+    assert np.array_equal(op.estimateVertexSBAXYZ(opt, maxKFid + 7), ref.estimates()[1][7])
+
+
+def test_force_stop_flag(synth):
+    """setForceStopFlag(&mbAbortBA) (LocalMapper.cpp:246): a raised flag stops before iteration 0."""
+    g = synth.ba_graph(8, 60)
+    o = _opt(g)
+    flag = np.ones(1, np.uint8)
+    o.setForceStopFlag(flag)
+    assert o.optimize(10) == 0
+    assert o.stats["stopped"]
+    poses, _ = o.estimates()
+    assert np.array_equal(poses, g.poses)
+    flag[0] = 0
+    assert o.optimize(2) == 2
+
+
+def test_edge_cases(oracle, synth):
+    import dataclasses
+    g = synth.ba_graph(8, 60)
+    # (a) no odometry edges
+    g0 = dataclasses.replace(g, o_i=g.o_i[:0], o_j=g.o_j[:0], o_meas=g.o_meas[:0], o_info=g.o_info[:0])
+    o = _opt(g0)
+    o.optimize(4)
+    _, _, st = oracle.ba_optimize(g0, 4, 0)
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=REL)
+    # (b) several fixed poses (reference KFs are all fixed, Map.cpp:959-970)
+    fx = g.fixed.copy()
+    fx[[0, 3, 7]] = 1
+    g1 = dataclasses.replace(g, fixed=fx)
+    o = _opt(g1)
+    o.optimize(4)
+    p_ref, _, st = oracle.ba_optimize(g1, 4, 0)
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=REL)
+    poses, _ = o.estimates()
+    assert np.array_equal(poses[[0, 3, 7]], g.poses[[0, 3, 7]])
+    # (c) a landmark nobody observes and a single-observation landmark
+    keep = (g.e_lm != 5) & ~((g.e_lm == 6) & (np.cumsum(g.e_lm == 6) > 1))
+    g2 = dataclasses.replace(g, e_kf=g.e_kf[keep], e_lm=g.e_lm[keep], e_uv=g.e_uv[keep], e_info=g.e_info[keep])
+    o = _opt(g2)
+    o.optimize(3)
+    # an unobserved landmark has Hll = 0: g2o would invert a singular block; LM damping keeps it finite
+    _, l_ref, st = oracle.ba_optimize(g2, 3, 0)
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=REL)
+
+
+def test_error_codes(synth):
+    from se2lam_amd import capi, optimizer as op
+    opt = op.SlamOptimizer()
+    with pytest.raises(capi.Se2GpuError) as e:
+        opt.optimize(1)
+    assert e.value.code == capi.ERR_STATE
+    op.addVertexSE2(opt, [0, 0, 0], 1, True)
+    with pytest.raises(capi.Se2GpuError) as e:
+        op.addVertexSE2(opt, [0, 0, 0], 1, True)
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.Se2GpuError):
+        op.addEdgeSE2XYZ(opt, [0, 0], 1, 99, np.eye(2), 1.0)
+    with pytest.raises(capi.Se2GpuError) as e:
+        opt.initializeOptimization(0)  # no camera parameters
+    assert e.value.code == capi.ERR_STATE
+
+
+def test_landmark_sharded_two_ranks_on_one_gpu(oracle, synth):
+    """The multi-GPU path with world=2 on ONE device: two handles, each holding a
+    landmark shard, run their LM loops in two threads; the all-reduce callback sums the fused buffer
+    [S | bs | scalars] over the two handles through host memory.  Result == single-handle run."""
+    from se2lam_amd import capi
+    from se2lam_amd.optimizer import SlamOptimizer
+    g = synth.ba_graph(8, 60)
+    world = 2
+    single = _opt(g)
+    single.optimize(6)
+    barrier = threading.Barrier(world)
+    stage = [None] * world
+    results = [None] * world
+    errors = []
+
+    def make_cb(rank):
+        def cb(ptr, count, stream):
+            capi.check(capi.lib().se2gpu_device_synchronize())
+            buf = np.empty(count)
+            capi.check(capi.lib().se2gpu_memcpy_d2h(capi.vp(buf), ptr, buf.nbytes))
+            stage[rank] = buf
+            barrier.wait()
+            tot = stage[0] + stage[1]
+            barrier.wait()
+            capi.check(capi.lib().se2gpu_memcpy_h2d(ptr, capi.vp(tot), tot.nbytes))
+        return cb
+
+    def run(rank):
+        try:
+            o = SlamOptimizer()
+            o.set_shard(rank, world)
+            o.set_allreduce(make_cb(rank))
+            o.load(g.shard(rank, world))
+            o.initializeOptimization(0)
+            o.optimize(6)
+            results[rank] = (o.stats, o.estimates())
+        except Exception as exc:  # pragma: no cover
+            errors.append(exc)
+            barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for r in range(world):
+        st, (poses, _) = results[r]
+        assert st["trials_hist"] == single.stats["trials_hist"]
+        assert np.allclose(st["chi2_hist"], single.stats["chi2_hist"], rtol=1e-9)
+        assert np.allclose(poses, single.estimates()[0], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(results[0][1][0], results[1][1][0])  # replicated poses stay identical

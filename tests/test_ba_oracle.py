@@ -1,0 +1,190 @@
+"""CPU tests of the BA oracle (oracle/ba_ref.cpp) and of the host-side sharding logic.
+
+The reference holds no golden vectors for this path (parity unpinned), so the
+oracle is pinned by what CAN be derived from the reference's own source: analytic-vs-numeric
+Jacobians of EdgeSE2XYZ (src/EdgeSE2XYZ.cpp:75-106) and PreEdgeSE2 (EdgeSE2XYZ.h:82-99), the Huber
+weights, g2o's LM policy invariants, and algebraic properties of the Schur reduction.
+"""
+import numpy as np
+import pytest
+
+
+def _num_jac(f, x, h=1e-6):
+    x = np.asarray(x, float)
+    f0 = f(x)
+    J = np.zeros((f0.size, x.size))
+    for k in range(x.size):
+        d = np.zeros_like(x)
+        d[k] = h
+        J[:, k] = (f(x + d) - f(x - d)) / (2 * h)
+    return J
+
+
+def test_edge_se2xyz_jacobians_match_numeric(oracle, synth):
+    g = synth.ba_graph(12, 200)
+    rng = np.random.default_rng(1)
+    for k in rng.choice(g.E, 25, replace=False):
+        pose = g.poses[g.e_kf[k]]
+        lw = g.lms[g.e_lm[k]]
+        uv = g.e_uv[k]
+        e, Jp, Jl = oracle.ba_edge_se2xyz(g, pose, lw, uv)
+        Jpn = _num_jac(lambda p: oracle.ba_edge_se2xyz(g, p, lw, uv)[0], pose, 1e-5)
+        Jln = _num_jac(lambda l: oracle.ba_edge_se2xyz(g, pose, l, uv)[0], lw, 1e-4)
+        assert np.allclose(Jp, Jpn, rtol=1e-6, atol=1e-6)
+        assert np.allclose(Jl, Jln, rtol=1e-6, atol=1e-7)
+        # pose Jacobian structure of EdgeSE2XYZ.cpp:101-104: J_pose[:, :2] = -J_lm[:, :2]
+        assert np.array_equal(Jp[:, :2], -Jl[:, :2])
+
+
+def test_edge_se2xyz_residual_closed_form(oracle, synth):
+    """e = cam_map(Tcb * SE3(Twb^-1) * lw) - z with an independent numpy SE3 evaluation."""
+    g = synth.ba_graph(12, 200)
+    k = 17
+    x, y, th = g.poses[g.e_kf[k]]
+    lw = g.lms[g.e_lm[k]]
+    Twb = np.eye(4)
+    Twb[:2, :2] = [[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]
+    Twb[:2, 3] = [x, y]
+    Tbc = np.eye(4)
+    Tbc[:3, :3] = g.Rbc
+    Tbc[:3, 3] = g.tbc
+    lc = (np.linalg.inv(Tbc) @ np.linalg.inv(Twb) @ np.append(lw, 1.0))[:3]
+    e_ref = np.array([g.fx * lc[0] / lc[2] + g.cx, g.fx * lc[1] / lc[2] + g.cy]) - g.e_uv[k]
+    e, _, _ = oracle.ba_edge_se2xyz(g, g.poses[g.e_kf[k]], lw, g.e_uv[k])
+    assert np.allclose(e, e_ref, rtol=1e-10, atol=1e-9)
+
+
+def test_pre_edge_se2_jacobians_and_no_angle_wrap(oracle):
+    rng = np.random.default_rng(2)
+    for _ in range(10):
+        pi = rng.normal(size=3) * [1000, 1000, 1]
+        pj = pi + rng.normal(size=3) * [500, 500, 0.3]
+        z = rng.normal(size=3) * [500, 500, 0.3]
+        e, Ji, Jj = oracle.ba_edge_pre_se2(pi, pj, z)
+        Jin = _num_jac(lambda p: oracle.ba_edge_pre_se2(p, pj, z)[0], pi, 1e-5)
+        Jjn = _num_jac(lambda p: oracle.ba_edge_pre_se2(pi, p, z)[0], pj, 1e-5)
+        assert np.allclose(Ji, Jin, atol=1e-5)
+        assert np.allclose(Jj, Jjn, atol=1e-5)
+    # EdgeSE2XYZ.h:80: e[2] = aj - ai - z[2] with NO normalisation
+    e, _, _ = oracle.ba_edge_pre_se2([0, 0, 3.0], [0, 0, -3.0], [0, 0, 0.1])
+    assert e[2] == pytest.approx(-6.1)
+
+
+def test_chi2_truth_is_about_two_per_edge(oracle, synth):
+    g = synth.ba_graph(50, 5000)
+    chi = oracle.ba_chi2(g, g.poses_true, g.lms_true)
+    assert 1.5 * g.E < chi < 3.0 * g.E
+    assert oracle.ba_chi2(g) > chi
+
+
+def test_lm_policy_invariants(oracle, synth):
+    """g2o OptimizationAlgorithmLevenberg: chi2 never increases over accepted iterations;
+    lambda0 = 1e-5 * max diag(H); on a good step lambda shrinks by a factor in [1/3, 2/3]."""
+    g = synth.ba_graph(50, 5000)
+    sys0 = oracle.ba_reduced_system(g, 0.0)
+    n = 3 * g.P
+    Hpp_diag_max = 0.0
+    # max diagonal: landmarks from Hll; poses from the UNREDUCED Hpp = S + sum(...) -> use lambda trick:
+    # S(lambda) - S(0) on the diagonal of free poses is lambda + O(lambda) terms, so take Hll only as a
+    # lower bound and check lambda0 >= 1e-5 * max diag(Hll).
+    Hll_max = np.abs(np.diagonal(sys0["Hll"], axis1=1, axis2=2)).max()
+    poses, lms, st = oracle.ba_optimize(g, 10, 0)
+    assert st["iterations"] == 10 and not st["terminated"]
+    hist = [st["chi2_init"]] + st["chi2_hist"]
+    assert all(b <= a for a, b in zip(hist, hist[1:]))
+    lam = st["lambda_hist"]
+    lam0 = lam[0] / (1.0 / 3.0) if st["trials_hist"][0] == 1 else None
+    if lam0 is not None:
+        assert lam0 >= 1e-5 * Hll_max * (1 - 1e-12)
+    for a, b, t in zip(lam, lam[1:], st["trials_hist"][1:]):
+        if t == 1:
+            assert a / 3 * (1 - 1e-12) <= b <= a * 2 / 3 * (1 + 1e-12)
+    assert st["chi2_final"] == pytest.approx(oracle.ba_chi2(g, poses, lms), rel=1e-12)
+
+
+def test_reduced_system_properties(oracle, synth):
+    """S is symmetric, fixed poses are identity rows, S(lambda) grows monotonically on the diagonal,
+    and solving the reduced system equals solving the full (un-reduced) normal equations."""
+    g = synth.ba_graph(8, 60)
+    lam = 3.0
+    r = oracle.ba_reduced_system(g, lam)
+    S, bs = r["S"], r["bs"]
+    assert np.allclose(S, S.T, rtol=1e-12, atol=1e-9)
+    for p in np.nonzero(g.fixed)[0]:
+        for c in range(3):
+            row = S[3 * p + c]
+            assert row[3 * p + c] == 1.0 and np.count_nonzero(row) == 1 and bs[3 * p + c] == 0.0
+    # full system assembled independently in numpy from oracle edge Jacobians
+    P, L = g.P, g.L
+    N = 3 * P + 3 * L
+    H = np.zeros((N, N))
+    b = np.zeros(N)
+    for k in range(g.E):
+        kf, lm = g.e_kf[k], g.e_lm[k]
+        e, Jp, Jl = oracle.ba_edge_se2xyz(g, g.poses[kf], g.lms[lm], g.e_uv[k])
+        W = np.array([[g.e_info[k, 0], g.e_info[k, 1]], [g.e_info[k, 1], g.e_info[k, 2]]])
+        e2 = e @ W @ e
+        rho1 = 1.0 if e2 <= g.huber ** 2 else g.huber / np.sqrt(e2)
+        J = np.zeros((2, N))
+        if not g.fixed[kf]:
+            J[:, 3 * kf:3 * kf + 3] = Jp
+        J[:, 3 * P + 3 * lm:3 * P + 3 * lm + 3] = Jl
+        H += J.T @ (rho1 * W) @ J
+        b += -rho1 * (J.T @ W @ e)
+    for k in range(g.O):
+        i, j = g.o_i[k], g.o_j[k]
+        e, Ji, Jj = oracle.ba_edge_pre_se2(g.poses[i], g.poses[j], g.o_meas[k])
+        W = g.o_info[k].reshape(3, 3)
+        J = np.zeros((3, N))
+        if not g.fixed[i]:
+            J[:, 3 * i:3 * i + 3] = Ji
+        if not g.fixed[j]:
+            J[:, 3 * j:3 * j + 3] = Jj
+        H += J.T @ W @ J
+        b += -(J.T @ W @ e)
+    H += lam * np.eye(N)
+    free = np.ones(N, bool)
+    for p in np.nonzero(g.fixed)[0]:
+        free[3 * p:3 * p + 3] = False
+    x_full = np.zeros(N)
+    x_full[free] = np.linalg.solve(H[np.ix_(free, free)], b[free])
+    x_red = np.linalg.solve(S, bs)
+    assert np.allclose(x_red, x_full[:3 * P], rtol=1e-7, atol=1e-9)
+
+
+def test_landmark_shards_sum_to_full_system(oracle, synth):
+    """the Schur complement is a SUM over landmarks, so the reduced systems of the
+    landmark shards (odometry + lambda*I on rank 0 only) add up to the single-GPU system."""
+    g = synth.ba_graph(10, 120)
+    lam = 2.5
+    full = oracle.ba_reduced_system(g, lam)
+    n = 3 * g.P
+    for world in (2, 3):
+        S = np.zeros((n, n))
+        bs = np.zeros(n)
+        edges = 0
+        for r in range(world):
+            sh = g.shard(r, world)
+            edges += sh.E
+            part = oracle.ba_reduced_system(sh, lam)
+            Sr, br = part["S"].copy(), part["bs"].copy()
+            if r != 0:  # lambda*I and the fixed-pose identity enter once (rank 0)
+                free = np.repeat(~g.fixed.astype(bool), 3)
+                Sr[np.diag_indices(n)] -= np.where(free, lam, 1.0)
+            S += Sr
+            bs += br
+        assert edges == g.E
+        assert np.allclose(S, full["S"], rtol=1e-10, atol=1e-8)
+        assert np.allclose(bs, full["bs"], rtol=1e-10, atol=1e-8)
+
+
+def test_library_shard_partition_matches_generator(synth):
+    """The library's host-side partitioner (C ABI, no device needed) = synth.shard_landmarks."""
+    from se2lam_amd import optimizer
+    g = synth.ba_graph(50, 5000)
+    for world in (1, 2, 4, 8):
+        own = optimizer.shard_landmarks(g.L, g.e_kf, g.e_lm, world)
+        ref = synth.shard_landmarks(g.e_kf, g.e_lm, g.L, world)
+        assert np.array_equal(own, ref)
+        cnt = np.bincount(own[g.e_lm], minlength=world)
+        assert cnt.min() > 0.9 * g.E / world and cnt.max() < 1.1 * g.E / world
