@@ -20,6 +20,7 @@
 // Multi-GPU: landmarks are sharded; S|bs is summed over ranks through the caller's all-reduce callback (RCCL).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <unordered_map>
 
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const
 //   bs_a = bp_a - sum_{e in pose a} Hpl_e z_{lm(e)}                      (diagonal-block waves)
 // Fixed poses: zero rows/cols, unit diagonal on the root rank, zero rhs.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_reduce(int P, int nblk, double lambda, int root,
+__global__ __launch_bounds__(kBlock) void k_reduce(int P, int ld, int npad, int nblk, double lambda, int root,
                                                     const int* __restrict__ blk_a, const int* __restrict__ blk_b,
                                                     const int* __restrict__ blk_ptr, const int* __restrict__ pair_i,
                                                     const int* __restrict__ pair_j, const double* __restrict__ Y,
@@ -363,12 +364,17 @@ __global__ __launch_bounds__(kBlock) void k_reduce(int P, int nblk, double lambd
                                                     const int* __restrict__ pose_ptr,
                                                     const int* __restrict__ pose_edges,
                                                     const int* __restrict__ e_lm, const double* __restrict__ z,
-                                                    double* __restrict__ S, double* __restrict__ bs) {
+                                                    double* __restrict__ S) {
     const int k = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
-    if (k >= nblk) return;
-    const int a = blk_a[k], b = blk_b[k];
     const int n = 3 * P;
+    double* __restrict__ bs = S + (size_t)n * ld;  // rhs = augmented row n
+    if (k == nblk) {  // one extra wave clears the padding of the augmented matrix (rows > n, tail of row n)
+        for (size_t t = (size_t)n * ld + n + lane; t < (size_t)npad * ld; t += 64) S[t] = 0.0;
+        return;
+    }
+    if (k > nblk) return;
+    const int a = blk_a[k], b = blk_b[k];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = blk_ptr[k] + lane; t < blk_ptr[k + 1]; t += 64) {
         const double* y = Y + (size_t)pair_i[t] * 9;
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce(int P, int nblk, double lambd
             out = -v;
             if (a == b) out += Hpp[(size_t)a * 9 + lane] + ((r == c && root) ? lambda : 0.0);
         }
-        S[(size_t)(3 * a + r) * n + 3 * b + c] = out;
-        if (a != b) S[(size_t)(3 * b + c) * n + 3 * a + r] = out;
+        S[(size_t)(3 * a + r) * ld + 3 * b + c] = out;
+        if (a != b) S[(size_t)(3 * b + c) * ld + 3 * a + r] = out;
     }
     if (a == b) {
         double g[3] = {0, 0, 0};
@@ -423,17 +429,153 @@ __global__ __launch_bounds__(kBlock) void k_reduce(int P, int nblk, double lambd
 }
 
 // odometry pose-pose blocks: S_ij += Oij, S_ji += Oij^T.  One thread per (edge, entry).
-__global__ void k_reduce_odo(int O, int P, const int* __restrict__ o_i, const int* __restrict__ o_j,
+__global__ void k_reduce_odo(int O, int ld, const int* __restrict__ o_i, const int* __restrict__ o_j,
                              const double* __restrict__ Oij, double* __restrict__ S) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= O * 9) return;
     const int k = t / 9, r = (t % 9) / 3, c = t % 3;
     const int i = o_i[k], j = o_j[k];
-    const int n = 3 * P;
     const double v = Oij[t];
     if (v == 0.0) return;
-    atomicAdd(&S[(size_t)(3 * i + r) * n + 3 * j + c], v);
-    atomicAdd(&S[(size_t)(3 * j + c) * n + 3 * i + r], v);
+    atomicAdd(&S[(size_t)(3 * i + r) * ld + 3 * j + c], v);
+    atomicAdd(&S[(size_t)(3 * j + c) * ld + 3 * i + r], v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense pose solve on the device: blocked right-looking LL^T (FP64) of the augmented matrix
+//     [ S  . ]      rows 0..n-1 : reduced system (lower triangle is used)
+//     [ b' . ]      row  n      : right-hand side; factorising maps it to y' = (L^-1 b)'
+// so the forward substitution comes for free; k_chol_backsolve then solves L^T x = y.
+// One (panel, update) launch pair per 32-wide block column; replaces CHOLMOD on the (3P)^2 system.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNB = 32;
+
+__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int ld, int n, int k,
+                                                     double* __restrict__ fail) {
+    __shared__ double D[kNB][kNB + 1];
+    __shared__ double T[kNB][kNB + 1];
+    const int tid = threadIdx.x;
+    const int i = k + blockIdx.x;  // tile row handled by this workgroup
+    const int c0 = kNB * k;
+    const int ncol = min(kNB, n - c0);
+    for (int idx = tid; idx < kNB * kNB; idx += 256) {
+        const int r = idx / kNB, c = idx % kNB;
+        D[r][c] = (c <= r) ? A[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
+        if (i != k) T[r][c] = A[(size_t)(kNB * i + r) * ld + c0 + c];
+    }
+    __syncthreads();
+    // factor the diagonal tile (every workgroup redundantly: it is tiny and removes a launch)
+    for (int j = 0; j < ncol; ++j) {
+        if (tid == 0) {
+            double d = D[j][j];
+            if (!(d > 0.0) || !isfinite(d)) {
+                if (blockIdx.x == 0) fail[0] = 1.0;
+                d = 1.0;
+            }
+            D[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        if (tid > j && tid < kNB) D[tid][j] /= D[j][j];
+        __syncthreads();
+        for (int idx = tid; idx < kNB * kNB; idx += 256) {
+            const int r = idx / kNB, c = idx % kNB;
+            if (c > j && c <= r) D[r][c] -= D[r][j] * D[c][j];
+        }
+        __syncthreads();
+    }
+    if (i == k) {
+        for (int idx = tid; idx < kNB * kNB; idx += 256) {
+            const int r = idx / kNB, c = idx % kNB;
+            if (c <= r) A[(size_t)(c0 + r) * ld + c0 + c] = D[r][c];
+        }
+        return;
+    }
+    // panel tile: X L_kk^T = A_ik, one row per thread group of 8 lanes (dot product split + shuffle reduce)
+    {
+        const int r = tid / 8, sub = tid % 8;
+        volatile double(*Tv)[kNB + 1] = T;  // written by lane 0 of the group, re-read by its 7 partners (same wave)
+        for (int c = 0; c < ncol; ++c) {
+            double sacc = 0.0;
+            for (int m = sub; m < c; m += 8) sacc += Tv[r][m] * D[c][m];
+            sacc += __shfl_xor(sacc, 1);
+            sacc += __shfl_xor(sacc, 2);
+            sacc += __shfl_xor(sacc, 4);
+            if (sub == 0) Tv[r][c] = (Tv[r][c] - sacc) / D[c][c];
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < kNB * kNB; idx += 256) {
+        const int r = idx / kNB, c = idx % kNB;
+        if (c < ncol) A[(size_t)(kNB * i + r) * ld + c0 + c] = T[r][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int k) {
+    const int i = k + 1 + blockIdx.y, j = k + 1 + blockIdx.x;
+    if (j > i) return;
+    __shared__ double Li[kNB][kNB + 1];
+    __shared__ double Lj[kNB][kNB + 1];
+    const int tid = threadIdx.x;
+    const int c0 = kNB * k;
+    for (int idx = tid; idx < kNB * kNB; idx += 256) {
+        const int r = idx / kNB, c = idx % kNB;
+        Li[r][c] = A[(size_t)(kNB * i + r) * ld + c0 + c];
+        Lj[r][c] = A[(size_t)(kNB * j + r) * ld + c0 + c];
+    }
+    __syncthreads();
+    const int r = tid / 8, cc = (tid % 8) * 4;
+    double acc[4] = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int m = 0; m < kNB; ++m) {
+        const double a = Li[r][m];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += a * Lj[cc + q][m];
+    }
+    double* out = A + (size_t)(kNB * i + r) * ld + kNB * j + cc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] -= acc[q];
+}
+
+// L^T x = y with y = augmented row n.  Single workgroup; x (n doubles) in dynamic LDS.
+__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ A, int ld, int n,
+                                                         double* __restrict__ xout) {
+    extern __shared__ double xs[];
+    __shared__ double D[kNB][kNB + 1];
+    const int tid = threadIdx.x;
+    for (int j = tid; j < n; j += 256) xs[j] = A[(size_t)n * ld + j];
+    __syncthreads();
+    const int nbc = (n + kNB - 1) / kNB;
+    for (int kb = nbc - 1; kb >= 0; --kb) {
+        const int c0 = kNB * kb;
+        const int ncol = min(kNB, n - c0);
+        for (int idx = tid; idx < kNB * kNB; idx += 256) {
+            const int r = idx / kNB, c = idx % kNB;
+            D[r][c] = (r < ncol && c <= r) ? A[(size_t)(c0 + r) * ld + c0 + c] : (r == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < 64) {  // wave 0: x_kb = L_kk^-T y_kb, register resident, lane m holds x[c0+m]
+            const int lane = tid;
+            double xr = (lane < ncol) ? xs[c0 + lane] : 0.0;
+#pragma unroll
+            for (int c = kNB - 1; c >= 0; --c) {
+                const double xc = __shfl(xr, c) / D[c][c];
+                if (lane == c) xr = xc;
+                if (lane < c) xr -= D[c][lane] * xc;
+            }
+            if (lane < ncol) xs[c0 + lane] = xr;
+        }
+        __syncthreads();
+        // y_j -= sum_c L[c0+c][j] x[c0+c] for j < c0
+        for (int j = tid; j < c0; j += 256) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int c = 0; c < ncol; ++c) acc += A[(size_t)(c0 + c) * ld + j] * xs[c0 + c];
+            xs[j] -= acc;
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < n; j += 256) xout[j] = xs[j];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,7 +706,7 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = sm[0][0]; out[1] = sm[1][0]; out[2] = 0; out[3] = 0; }
+    if (threadIdx.x == 0) { out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -660,6 +802,8 @@ struct se2gpu_ba {
     std::vector<EdgeOdo> odo;
     bool initialized = false;
     int P = 0, L = 0, E = 0, O = 0, nblk = 0, nparts = 0;
+    int ld = 0;              // leading dimension = padded order of the augmented reduced system
+    bool host_solve = false; // SE2GPU_BA_HOST_SOLVE=1: factorise on the host instead (north-star wording)
     // device SoA
     DevBuf<double> poses0, lms0, poses_a, poses_b, lms_a, lms_b;
     double *poses = nullptr, *poses_t = nullptr, *lms = nullptr, *lms_t = nullptr;
@@ -669,7 +813,7 @@ struct se2gpu_ba {
     DevBuf<double> e_uv, e_info, o_meas, o_info;
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Hpp, bp, Oii, Ojj, Oij, obi, obj;
     DevBuf<double> red_own, xp, part, scal, diag3;
-    double* red = nullptr;  // [S (n*n) | bs (n) | 4 scalars]
+    double* red = nullptr;  // [augmented (ld x ld): rows 0..n-1 = S, row n = bs | 4 scalars]
     PinBuf<double> h_red, h_x, h_scal;
     // multi-GPU
     se2gpu_allreduce_fn allreduce = nullptr;
@@ -823,7 +967,12 @@ int ba_upload_graph(se2gpu_ba* h) {
     h->nparts = (L * kGroup + kBlock - 1) / kBlock;
     SE2_CHECK(h->part.reserve(2 * (size_t)std::max(h->nparts, 1)));
     SE2_CHECK(h->scal.reserve(8 + (size_t)h->world));
-    const size_t nred = std::max((size_t)n * n + n + 4, (size_t)h->world);
+    h->ld = ((n + 1 + kNB - 1) / kNB) * kNB;
+    const size_t nred = (size_t)h->ld * h->ld + 4;
+    {
+        const char* env = getenv("SE2GPU_BA_HOST_SOLVE");
+        h->host_solve = env && env[0] == '1';
+    }
     if (h->ar_buffer) {
         h->red = (double*)h->ar_buffer;
     } else {
@@ -863,16 +1012,14 @@ int ba_linearize(se2gpu_ba* h) {
 // reduced system for damping lambda into h->red = [S | bs | ...] (local contribution of this rank)
 int ba_reduce(se2gpu_ba* h, double lambda) {
     hipStream_t st = h->stream;
-    const int n = 3 * h->P;
     double* S = h->red;
-    double* bs = h->red + (size_t)n * n;
     SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
                lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Dinv.p, h->z.p, h->Y.p);
-    SE2_LAUNCH(h->prof, st, "k_reduce", k_reduce, grid1((size_t)h->nblk * 64, kBlock), dim3(kBlock), 0, h->P, h->nblk,
-               lambda, h->root, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->pair_i.p, h->pair_j.p, h->Y.p, h->Hpl.p,
-               h->Hpp.p, h->bp.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->e_lm.p, h->z.p, S, bs);
+    SE2_LAUNCH(h->prof, st, "k_reduce", k_reduce, grid1((size_t)(h->nblk + 1) * 64, kBlock), dim3(kBlock), 0, h->P,
+               h->ld, h->ld, h->nblk, lambda, h->root, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->pair_i.p, h->pair_j.p,
+               h->Y.p, h->Hpl.p, h->Hpp.p, h->bp.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->e_lm.p, h->z.p, S);
     if (h->O)
-        SE2_LAUNCH(h->prof, st, "k_reduce_odo", k_reduce_odo, grid1((size_t)h->O * 9, 256), dim3(256), 0, h->O, h->P,
+        SE2_LAUNCH(h->prof, st, "k_reduce_odo", k_reduce_odo, grid1((size_t)h->O * 9, 256), dim3(256), 0, h->O, h->ld,
                    h->o_i.p, h->o_j.p, h->Oij.p, S);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
@@ -889,7 +1036,8 @@ int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count) {
 int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
     hipStream_t st = h->stream;
     const int n = 3 * h->P;
-    double* scal = h->red + (size_t)n * n + n;  // 4 trailing scalars of the fused buffer
+    (void)n;
+    double* scal = h->red + (size_t)h->ld * h->ld;  // 4 trailing scalars of the fused buffer
     SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
                lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
                h->Y.p, h->bl.p, h->lms_t, h->part.p);
@@ -897,22 +1045,46 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                h->o_info.p, h->root, scal);
     SE2_HIP(hipGetLastError());
+    if (!xp) SE2_HIP(hipMemsetAsync(scal + 2, 0, sizeof(double), st));
     SE2_CHECK(ba_allreduce(h, scal, 4));
-    SE2_HIP(hipMemcpyAsync(h->h_scal.p, scal, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipMemcpyAsync(h->h_scal.p, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipStreamSynchronize(st));
     return SE2GPU_OK;
 }
 
-// dense pose solve: S|bs (device, already all-reduced) -> xp (device).  ok=false on a failed factorisation.
-int ba_solve(se2gpu_ba* h, bool* ok) {
+// dense pose solve: augmented S|bs (device, already all-reduced) -> xp (device).
+// `fail` = scalar slot [2] of the fused buffer: set to 1 by the factorisation on a non-positive pivot.
+int ba_solve(se2gpu_ba* h) {
     hipStream_t st = h->stream;
     const int n = 3 * h->P;
-    SE2_HIP(hipMemcpyAsync(h->h_red.p, h->red, ((size_t)n * n + n) * sizeof(double), hipMemcpyDeviceToHost, st));
-    SE2_HIP(hipStreamSynchronize(st));
-    std::memcpy(h->h_x.p, h->h_red.p + (size_t)n * n, n * sizeof(double));
-    *ok = host_cholesky_solve(h->h_red.p, n, h->h_x.p);
-    if (!*ok) std::memset(h->h_x.p, 0, n * sizeof(double));
-    SE2_HIP(hipMemcpyAsync(h->xp.p, h->h_x.p, n * sizeof(double), hipMemcpyHostToDevice, st));
+    const int ld = h->ld;
+    double* A = h->red;
+    double* fail = h->red + (size_t)ld * ld + 2;
+    if (h->host_solve) {
+        SE2_HIP(hipMemcpyAsync(h->h_red.p, A, (size_t)(n + 1) * ld * sizeof(double), hipMemcpyDeviceToHost, st));
+        SE2_HIP(hipStreamSynchronize(st));
+        std::vector<double> M((size_t)n * n);
+        for (int r = 0; r < n; ++r) std::memcpy(&M[(size_t)r * n], h->h_red.p + (size_t)r * ld, n * sizeof(double));
+        std::memcpy(h->h_x.p, h->h_red.p + (size_t)n * ld, n * sizeof(double));
+        const bool ok = host_cholesky_solve(M.data(), n, h->h_x.p);
+        if (!ok) std::memset(h->h_x.p, 0, n * sizeof(double));
+        const double f = ok ? 0.0 : 1.0;
+        SE2_HIP(hipMemcpyAsync(h->xp.p, h->h_x.p, n * sizeof(double), hipMemcpyHostToDevice, st));
+        SE2_HIP(hipMemcpyAsync(fail, &f, sizeof(double), hipMemcpyHostToDevice, st));
+        SE2_HIP(hipStreamSynchronize(st));
+        return SE2GPU_OK;
+    }
+    SE2_HIP(hipMemsetAsync(fail, 0, sizeof(double), st));
+    const int nt = ld / kNB;                 // tile rows (incl. the rhs / padding tile row)
+    const int nbc = (n + kNB - 1) / kNB;     // block columns to factor
+    for (int k = 0; k < nbc; ++k) {
+        SE2_LAUNCH(h->prof, st, "k_chol_panel", k_chol_panel, dim3(nt - k), dim3(256), 0, A, ld, n, k, fail);
+        const int m = nt - k - 1;
+        if (m > 0) SE2_LAUNCH(h->prof, st, "k_chol_update", k_chol_update, dim3(m, m), dim3(256), 0, A, ld, k);
+    }
+    SE2_LAUNCH(h->prof, st, "k_chol_backsolve", k_chol_backsolve, dim3(1), dim3(256), (size_t)n * sizeof(double), A, ld,
+               n, h->xp.p);
+    SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
 
@@ -1095,7 +1267,8 @@ int se2gpu_ba_reset_estimates(se2gpu_ba* h) {
 
 size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba*, int P) {
     const size_t n = 3 * (size_t)P;
-    return n * n + n + 4;
+    const size_t ld = ((n + 1 + kNB - 1) / kNB) * kNB;
+    return ld * ld + 4;
 }
 
 int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, void* buffer) {
@@ -1132,10 +1305,11 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
     const int n = 3 * h->P;
     SE2_CHECK(ba_linearize(h));
     SE2_CHECK(ba_reduce(h, lambda));
-    SE2_CHECK(ba_allreduce(h, h->red, (size_t)n * n + n));
+    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
     SE2_HIP(hipStreamSynchronize(h->stream));
-    if (S) SE2_HIP(hipMemcpy(S, h->red, (size_t)n * n * 8, hipMemcpyDeviceToHost));
-    if (bs) SE2_HIP(hipMemcpy(bs, h->red + (size_t)n * n, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (S)
+        SE2_HIP(hipMemcpy2D(S, (size_t)n * 8, h->red, (size_t)h->ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
+    if (bs) SE2_HIP(hipMemcpy(bs, h->red + (size_t)n * h->ld, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SE2GPU_OK;
 }
 
@@ -1163,11 +1337,11 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
         do {
             const double lam = mode == SE2GPU_BA_LM ? lambda : 0.0;
             SE2_CHECK(ba_reduce(h, lam));
-            SE2_CHECK(ba_allreduce(h, h->red, (size_t)n * n + n));
-            bool ok2 = true;
-            SE2_CHECK(ba_solve(h, &ok2));
+            SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
+            SE2_CHECK(ba_solve(h));
             SE2_CHECK(ba_evaluate(h, h->xp.p, lam));
             double tempChi = h->h_scal.p[0];
+            const bool ok2 = !(h->h_scal.p[2] > 0.0);  // factorisation flag (summed over ranks: identical on all)
             if (!ok2) tempChi = std::numeric_limits<double>::max();
             ++s.trials;
             ++qmax;
