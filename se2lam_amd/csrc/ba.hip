@@ -443,84 +443,94 @@ __global__ void k_reduce_odo(int O, int ld, const int* __restrict__ o_i, const i
 
 // ---------------------------------------------------------------------------------------------
 // Dense pose solve on the device: blocked right-looking LL^T (FP64) of the augmented matrix
-//     [ S  . ]      rows 0..n-1 : reduced system (lower triangle is used)
-//     [ b' . ]      row  n      : right-hand side; factorising maps it to y' = (L^-1 b)'
-// so the forward substitution comes for free; k_chol_backsolve then solves L^T x = y.
+//     [ S  ]   rows 0..n-1 : reduced system (lower triangle is used)
+//     [ b' ]   row  n      : right-hand side     -> the elimination maps it to y' = (L^-1 b)'
+//     [ I  ]   (kept in R) : identity            -> the elimination maps it to R  = L^-T
+// so neither triangular solve has a sequential phase: x = R y is one GEMV at the end.
 // One (panel, update) launch pair per 32-wide block column; replaces CHOLMOD on the (3P)^2 system.
 // ---------------------------------------------------------------------------------------------
 constexpr int kNB = 32;
 
-__global__ __launch_bounds__(256) void k_chol_panel(double* __restrict__ A, int ld, int n, int k,
-                                                     double* __restrict__ fail) {
-    __shared__ double D[kNB][kNB + 1];
-    __shared__ double T[kNB][kNB + 1];
-    const int tid = threadIdx.x;
-    const int i = k + blockIdx.x;  // tile row handled by this workgroup
-    const int c0 = kNB * k;
-    const int ncol = min(kNB, n - c0);
-    for (int idx = tid; idx < kNB * kNB; idx += 256) {
-        const int r = idx / kNB, c = idx % kNB;
-        D[r][c] = (c <= r) ? A[(size_t)(c0 + r) * ld + c0 + c] : 0.0;
-        if (i != k) T[r][c] = A[(size_t)(kNB * i + r) * ld + c0 + c];
-    }
-    __syncthreads();
-    // factor the diagonal tile (every workgroup redundantly: it is tiny and removes a launch)
-    for (int j = 0; j < ncol; ++j) {
-        if (tid == 0) {
-            double d = D[j][j];
-            if (!(d > 0.0) || !isfinite(d)) {
-                if (blockIdx.x == 0) fail[0] = 1.0;
-                d = 1.0;
-            }
-            D[j][j] = sqrt(d);
-        }
-        __syncthreads();
-        if (tid > j && tid < kNB) D[tid][j] /= D[j][j];
-        __syncthreads();
-        for (int idx = tid; idx < kNB * kNB; idx += 256) {
-            const int r = idx / kNB, c = idx % kNB;
-            if (c > j && c <= r) D[r][c] -= D[r][j] * D[c][j];
-        }
-        __syncthreads();
-    }
-    if (i == k) {
-        for (int idx = tid; idx < kNB * kNB; idx += 256) {
-            const int r = idx / kNB, c = idx % kNB;
-            if (c <= r) A[(size_t)(c0 + r) * ld + c0 + c] = D[r][c];
-        }
-        return;
-    }
-    // panel tile: X L_kk^T = A_ik, one row per thread group of 8 lanes (dot product split + shuffle reduce)
-    {
-        const int r = tid / 8, sub = tid % 8;
-        volatile double(*Tv)[kNB + 1] = T;  // written by lane 0 of the group, re-read by its 7 partners (same wave)
-        for (int c = 0; c < ncol; ++c) {
-            double sacc = 0.0;
-            for (int m = sub; m < c; m += 8) sacc += Tv[r][m] * D[c][m];
-            sacc += __shfl_xor(sacc, 1);
-            sacc += __shfl_xor(sacc, 2);
-            sacc += __shfl_xor(sacc, 4);
-            if (sub == 0) Tv[r][c] = (Tv[r][c] - sacc) / D[c][c];
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < kNB * kNB; idx += 256) {
-        const int r = idx / kNB, c = idx % kNB;
-        if (c < ncol) A[(size_t)(kNB * i + r) * ld + c0 + c] = T[r][c];
-    }
+__device__ inline double bcast_lane(double v, int lane) {  // lane must be a compile-time / wave-uniform constant
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double fast_rcp(double d) {  // v_rcp_f64 + 2 Newton steps (full FP64 accuracy)
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ inline double fast_rsqrt(double d) {  // v_rsq_f64 + 2 Newton steps
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    return y;
 }
 
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int ld, int k) {
-    const int i = k + 1 + blockIdx.y, j = k + 1 + blockIdx.x;
-    if (j > i) return;
+// Panel step k.  ONE WAVE per workgroup eliminates a stacked 64x32 matrix held entirely in registers (lane = row,
+// 32 doubles per lane): lanes 0..31 = diagonal tile A(k,k) (every workgroup repeats it), lanes 32..63 = its own
+// tile: A(i,k) for i > k, the identity for the diagonal workgroup (-> R(k,k)), or R(r,k) for r < k.
+//     M[r][c] -= M[r][j] * M[c][j] / M[j][j]   (c > j),      L[r][j] = M[r][j] / sqrt(M[j][j]) at the end.
+// M[c][j] lives in lane c and is broadcast with v_readlane: no LDS, no barriers, fully unrolled.
+__global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ A, double* __restrict__ R, int ld, int n,
+                                                    int nt, int k, double* __restrict__ fail) {
+    const int lane = threadIdx.x;
+    const int nS = nt - k;
+    const bool isR = (int)blockIdx.x >= nS;
+    const int tr = isR ? (int)blockIdx.x - nS : k + (int)blockIdx.x;
+    const bool isDiag = !isR && tr == k;
+    const int c0 = kNB * k;
+    const int ncol = min(kNB, n - c0);
+    const int r = lane & 31;
+    double* rowp;  // this lane's row (32 contiguous doubles starting at column c0)
+    if (lane < kNB) rowp = A + (size_t)(c0 + r) * ld + c0;
+    else if (!isR) rowp = A + (size_t)(kNB * tr + r) * ld + c0;
+    else rowp = R + (size_t)(kNB * tr + r) * ld + c0;
+    if (isDiag && lane >= kNB) rowp = R + (size_t)(c0 + r) * ld + c0;
+    double m[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) m[c] = (isDiag && lane >= kNB) ? (c == r ? 1.0 : 0.0) : rowp[c];
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {
+        if (j < ncol) {
+            const double inv = fast_rcp(bcast_lane(m[j], j));
+            const double mr = m[j] * inv;
+#pragma unroll
+            for (int c = j + 1; c < kNB; ++c) m[c] = fma(-mr, bcast_lane(m[j], c), m[c]);
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) {
+        if (c < ncol) {
+            const double d = bcast_lane(m[c], c);
+            const bool okd = d > 0.0 && isfinite(d);
+            bad |= !okd;
+            const double v = m[c] * fast_rsqrt(okd ? d : 1.0);
+            if (lane >= kNB || (isDiag && c <= r)) rowp[c] = v;
+        }
+    }
+    if (bad && isDiag && lane == 0) fail[0] = 1.0;
+}
+
+// Trailing update with panel k: A(i,j) -= L(i,k) L(j,k)^T for k < j <= i, and R(r,j) -= R(r,k) L(j,k)^T for r <= k
+// (R(r,j) is first touched at step k == r, where its previous value is known to be zero).
+__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, double* __restrict__ R, int ld, int k,
+                                                      int m_s) {
+    const int j = k + 1 + blockIdx.x;
+    const bool isR = (int)blockIdx.y >= m_s;
+    const int i = isR ? (int)blockIdx.y - m_s : k + 1 + (int)blockIdx.y;  // tile row (in A, or in R)
+    if (!isR && j > i) return;
     __shared__ double Li[kNB][kNB + 1];
     __shared__ double Lj[kNB][kNB + 1];
     const int tid = threadIdx.x;
     const int c0 = kNB * k;
+    const double* src = isR ? R : A;
     for (int idx = tid; idx < kNB * kNB; idx += 256) {
         const int r = idx / kNB, c = idx % kNB;
-        Li[r][c] = A[(size_t)(kNB * i + r) * ld + c0 + c];
+        Li[r][c] = src[(size_t)(kNB * i + r) * ld + c0 + c];
         Lj[r][c] = A[(size_t)(kNB * j + r) * ld + c0 + c];
     }
     __syncthreads();
@@ -532,50 +542,24 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, int
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] += a * Lj[cc + q][m];
     }
-    double* out = A + (size_t)(kNB * i + r) * ld + kNB * j + cc;
+    double* out = (isR ? R : A) + (size_t)(kNB * i + r) * ld + kNB * j + cc;
+    const bool first = isR && i == k;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[q] -= acc[q];
+    for (int q = 0; q < 4; ++q) out[q] = (first ? 0.0 : out[q]) - acc[q];
 }
 
-// L^T x = y with y = augmented row n.  Single workgroup; x (n doubles) in dynamic LDS.
-__global__ __launch_bounds__(256) void k_chol_backsolve(const double* __restrict__ A, int ld, int n,
-                                                         double* __restrict__ xout) {
-    extern __shared__ double xs[];
-    __shared__ double D[kNB][kNB + 1];
-    const int tid = threadIdx.x;
-    for (int j = tid; j < n; j += 256) xs[j] = A[(size_t)n * ld + j];
-    __syncthreads();
-    const int nbc = (n + kNB - 1) / kNB;
-    for (int kb = nbc - 1; kb >= 0; --kb) {
-        const int c0 = kNB * kb;
-        const int ncol = min(kNB, n - c0);
-        for (int idx = tid; idx < kNB * kNB; idx += 256) {
-            const int r = idx / kNB, c = idx % kNB;
-            D[r][c] = (r < ncol && c <= r) ? A[(size_t)(c0 + r) * ld + c0 + c] : (r == c ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        if (tid < 64) {  // wave 0: x_kb = L_kk^-T y_kb, register resident, lane m holds x[c0+m]
-            const int lane = tid;
-            double xr = (lane < ncol) ? xs[c0 + lane] : 0.0;
-#pragma unroll
-            for (int c = kNB - 1; c >= 0; --c) {
-                const double xc = __shfl(xr, c) / D[c][c];
-                if (lane == c) xr = xc;
-                if (lane < c) xr -= D[c][lane] * xc;
-            }
-            if (lane < ncol) xs[c0 + lane] = xr;
-        }
-        __syncthreads();
-        // y_j -= sum_c L[c0+c][j] x[c0+c] for j < c0
-        for (int j = tid; j < c0; j += 256) {
-            double acc = 0.0;
-#pragma unroll 8
-            for (int c = 0; c < ncol; ++c) acc += A[(size_t)(c0 + c) * ld + j] * xs[c0 + c];
-            xs[j] -= acc;
-        }
-        __syncthreads();
-    }
-    for (int j = tid; j < n; j += 256) xout[j] = xs[j];
+// x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
+__global__ __launch_bounds__(256) void k_chol_apply(const double* __restrict__ A, const double* __restrict__ R, int ld,
+                                                     int n, double* __restrict__ x) {
+    const int r = blockIdx.x * 4 + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const double* y = A + (size_t)n * ld;
+    // R(r, c) is defined for c >= kNB * (r / kNB); inside the diagonal tile only c >= r is non-zero
+    double acc = 0.0;
+    for (int c = r + lane; c < n; c += 64) acc += R[(size_t)r * ld + c] * y[c];
+    acc = wave_sum(acc);
+    if (lane == 0) x[r] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -812,7 +796,7 @@ struct se2gpu_ba {
     DevBuf<int> blk_a, blk_b, blk_ptr, pair_i, pair_j;
     DevBuf<double> e_uv, e_info, o_meas, o_info;
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Hpp, bp, Oii, Ojj, Oij, obi, obj;
-    DevBuf<double> red_own, xp, part, scal, diag3;
+    DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
     double* red = nullptr;  // [augmented (ld x ld): rows 0..n-1 = S, row n = bs | 4 scalars]
     PinBuf<double> h_red, h_x, h_scal;
     // multi-GPU
@@ -980,6 +964,7 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->red = h->red_own.p;
     }
     SE2_CHECK(h->h_red.reserve(nred));
+    SE2_CHECK(h->Rinv.reserve((size_t)h->ld * h->ld));
     SE2_CHECK(h->h_x.reserve(n));
     SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
@@ -1075,15 +1060,18 @@ int ba_solve(se2gpu_ba* h) {
         return SE2GPU_OK;
     }
     SE2_HIP(hipMemsetAsync(fail, 0, sizeof(double), st));
-    const int nt = ld / kNB;                 // tile rows (incl. the rhs / padding tile row)
+    const int nt = ld / kNB;                 // tile rows of A (incl. the rhs / padding tile row)
     const int nbc = (n + kNB - 1) / kNB;     // block columns to factor
+    double* Rm = h->Rinv.p;
     for (int k = 0; k < nbc; ++k) {
-        SE2_LAUNCH(h->prof, st, "k_chol_panel", k_chol_panel, dim3(nt - k), dim3(256), 0, A, ld, n, k, fail);
-        const int m = nt - k - 1;
-        if (m > 0) SE2_LAUNCH(h->prof, st, "k_chol_update", k_chol_update, dim3(m, m), dim3(256), 0, A, ld, k);
+        // workgroups: (nt - k) tile rows of A (the diagonal one also produces R(k,k)) + k tile rows of R
+        SE2_LAUNCH(h->prof, st, "k_chol_panel", k_chol_panel, dim3(nt - k + k), dim3(64), 0, A, Rm, ld, n, nt, k, fail);
+        const int mx = nbc - k - 1;          // block columns right of k
+        const int ms = nt - k - 1;           // tile rows of A below k
+        if (mx > 0)
+            SE2_LAUNCH(h->prof, st, "k_chol_update", k_chol_update, dim3(mx, ms + k + 1), dim3(256), 0, A, Rm, ld, k, ms);
     }
-    SE2_LAUNCH(h->prof, st, "k_chol_backsolve", k_chol_backsolve, dim3(1), dim3(256), (size_t)n * sizeof(double), A, ld,
-               n, h->xp.p);
+    SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
