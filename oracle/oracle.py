@@ -172,8 +172,107 @@ def ba_edge_pre_se2(pi, pj, z):
     return e, Ji, Jj
 
 
-def _declare_orb(l):  # filled in with orb_ref.cpp
-    pass
+# --------------------------------------------------------------------------------------
+# ORB extractor
+# --------------------------------------------------------------------------------------
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("fast_th", C.c_int32)]
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def _declare_orb(l):
+    VP = C.c_void_p
+    PI = C.POINTER(C.c_int)
+    l.orb_ref_extract.restype = C.c_int
+    l.orb_ref_extract.argtypes = [C.POINTER(OrbParams), VP, C.c_int, C.c_int, C.c_int, VP, VP, C.c_int, PI]
+    l.orb_ref_tables.restype = None
+    l.orb_ref_tables.argtypes = [C.POINTER(OrbParams), VP, VP, VP, VP]
+    l.orb_ref_geometry.restype = None
+    l.orb_ref_geometry.argtypes = [C.POINTER(OrbParams), C.c_int, C.c_int, VP]
+    l.orb_ref_level.restype = C.c_int
+    l.orb_ref_level.argtypes = [C.POINTER(OrbParams), VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, PI, PI]
+    l.orb_ref_score.restype = C.c_int
+    l.orb_ref_score.argtypes = [C.POINTER(OrbParams), VP, C.c_int, C.c_int, C.c_int, C.c_int, VP]
+    l.orb_ref_pattern.restype = None
+    l.orb_ref_pattern.argtypes = [VP]
+    l.orb_ref_gaussian_taps.restype = None
+    l.orb_ref_gaussian_taps.argtypes = [VP]
+    l.orb_ref_fast_atan2.restype = C.c_float
+    l.orb_ref_fast_atan2.argtypes = [C.c_float, C.c_float]
+    l.orb_ref_cv_round.restype = C.c_int
+    l.orb_ref_cv_round.argtypes = [C.c_float]
+    l.orb_ref_fast_score.restype = C.c_int
+    l.orb_ref_fast_score.argtypes = [VP, C.c_int]
+
+
+def orb_params(nfeatures=1000, scale_factor=1.2, nlevels=8, fast_th=20):
+    return OrbParams(nfeatures, scale_factor, nlevels, fast_th)
+
+
+def orb_extract(img, params=None, cap=4096):
+    """-> (keypoints structured array (n,), descriptors (n,32) u8)"""
+    params = params or orb_params()
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols = (img.shape if img.ndim == 2 else (0, 0))
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    rc = lib().orb_ref_extract(C.byref(params), img.ctypes.data, rows, cols, cols, kps.ctypes.data,
+                               desc.ctypes.data, cap, C.byref(n))
+    assert rc == 0, "orb_ref_extract: capacity exceeded"
+    return kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def orb_tables(params=None):
+    params = params or orb_params()
+    L = params.nlevels
+    scale = np.zeros(L, np.float32); inv = np.zeros(L, np.float32)
+    quota = np.zeros(L, np.int32); umax = np.zeros(16, np.int32)
+    lib().orb_ref_tables(C.byref(params), scale.ctypes.data, inv.ctypes.data, quota.ctypes.data, umax.ctypes.data)
+    return dict(scale=scale, inv_scale=inv, quota=quota, umax=umax)
+
+
+def orb_geometry(rows, cols, params=None):
+    params = params or orb_params()
+    out = np.zeros((params.nlevels, 7), np.int32)
+    lib().orb_ref_geometry(C.byref(params), rows, cols, out.ctypes.data)
+    return out
+
+
+def orb_level(img, level, blurred=False, params=None):
+    params = params or orb_params()
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(img.size, np.uint8)
+    w = C.c_int(); h = C.c_int()
+    lib().orb_ref_level(C.byref(params), img.ctypes.data, img.shape[0], img.shape[1], img.shape[1], level,
+                        int(blurred), out.ctypes.data, C.byref(w), C.byref(h))
+    return out[:w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def orb_score(img, level, params=None):
+    params = params or orb_params()
+    lv = orb_level(img, level, False, params)
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.zeros(lv.shape, np.uint8)
+    lib().orb_ref_score(C.byref(params), img.ctypes.data, img.shape[0], img.shape[1], img.shape[1], level,
+                        out.ctypes.data)
+    return out
+
+
+def orb_pattern():
+    out = np.zeros(1024, np.int32)
+    lib().orb_ref_pattern(out.ctypes.data)
+    return out
+
+
+def orb_gaussian_taps():
+    out = np.zeros(7, np.int32)
+    lib().orb_ref_gaussian_taps(out.ctypes.data)
+    return out
 
 
 def _declare_match(l):  # filled in with match_ref.cpp

@@ -1,0 +1,874 @@
+// libse2gpu - ORB extractor on gfx950 (MI355X), batched over frames.
+//
+// Replaces se2lam::ORBextractor (/root/reference/src/ORBextractor.cpp, include/se2lam/ORBextractor.h:38-83):
+//   ctor :463-520, ComputePyramid :790-831, ComputeKeyPoints :531-716, IC_Angle :130-157,
+//   GaussianBlur call :769, computeOrbDescriptor :161-200, operator() :727-788.
+// The OpenCV primitives it calls are restated with the semantics DESIGN.md / oracle/orb_ref.cpp define
+// (FAST-9/16 + cornerScore + in-cell NMS, 11-bit fixed-point bilinear resize, reflect-101 border, 8-bit
+// fixed-point 7x7 Gaussian, canonical retain-best order, fastAtan2, round-half-even).
+//
+// Pipeline (every kernel covers the whole batch; all stages stay in HBM, no host round trip):
+//   k_level0 / k_resize   pyramid level k from level k-1, border filled in the same pass (4 px per thread)
+//   k_fast_score          S(x,y) = FAST-9/16 score for every level in one launch
+//   k_cell_detect         one workgroup per (frame, level, cell): in-cell NMS, threshold 20 / fallback 7,
+//                         LDS bitonic sort by (response desc, y, x) -> per-cell sorted candidate list
+//   k_level_select        one workgroup per frame: quota redistribution (serial, tiny), per-cell top-n gather,
+//                         level-wide retain-best by rank, keypoint list in level order
+//   k_orientation         16 lanes per keypoint: integer intensity-centroid moments, fastAtan2
+//   k_blur                7x7 fixed-point Gaussian through LDS tiles (interior only; the 16 px frame of the blurred
+//                         pyramid keeps the un-blurred reflect copies, as in the reference's in-place ROI blur)
+//   k_describe            one wave per keypoint: lane l evaluates pattern pairs l, l+64, l+128, l+192 and the four
+//                         64-bit wave ballots ARE the 256-bit descriptor; also writes the final cv::KeyPoint
+// Compiled with -ffp-contract=off (se2lam_amd/build.py): the float index arithmetic must round as the
+// reference's non-FMA build does.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+#include "common.h"
+
+using namespace se2gpu;
+
+namespace {
+
+constexpr int kMaxLevels = 12;
+constexpr int kEdge = 16;          // EDGE_THRESHOLD
+constexpr int kPatch = 31;         // PATCH_SIZE
+constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE
+constexpr int kSortCap = 4096;     // candidates (S > 7, local maxima) one cell can hold in LDS
+constexpr int kLevelCap = 2048;    // keypoints one level can hold before the level-wide retain
+
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern_31.inc"
+};
+
+struct Geom {
+    int nlevels;
+    int rows, cols;
+    int w[kMaxLevels], h[kMaxLevels], stride[kMaxLevels];
+    unsigned off[kMaxLevels];            // byte offset of the level's bordered buffer inside a frame block
+    unsigned frame_bytes;
+    int quota[kMaxLevels], gcols[kMaxLevels], grows[kMaxLevels], cellW[kMaxLevels], cellH[kMaxLevels];
+    int nfc[kMaxLevels];                 // nfeaturesCell
+    int cell_base[kMaxLevels + 1];       // prefix sum of cells per level
+    float scale[kMaxLevels];             // mvScaleFactor
+    float patch[kMaxLevels];             // (float)(int)(PATCH_SIZE * mvScaleFactor[level])
+    int tile_base[kMaxLevels + 1];       // prefix sums of work tiles per level (set per kernel family)
+    int cell_cap;                        // entries kept per cell in the global candidate lists
+    int umax[16];
+    int nfeatures;
+    int fast_th;
+};
+
+// interior pixel (x, y) of level l of frame f
+__device__ __forceinline__ size_t pix(const Geom& g, int f, int l, int y, int x) {
+    return (size_t)f * g.frame_bytes + g.off[l] + (size_t)(y + kEdge) * g.stride[l] + (x + kEdge);
+}
+
+__device__ __forceinline__ int reflect101(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+
+// ---------------------------------------------------------------------------------------------
+// pyramid
+// ---------------------------------------------------------------------------------------------
+// level 0: copyMakeBorder(image, 16 px, BORDER_REFLECT_101); 4 output bytes per thread
+__global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restrict__ imgs, int pitch,
+                                                 uint8_t* __restrict__ pyr) {
+    const int f = blockIdx.z;
+    const int Y = blockIdx.y;                                  // row of the bordered buffer
+    const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;       // first of 4 columns of the bordered buffer
+    const int W = g.w[0], H = g.h[0], stride = g.stride[0];
+    if (X4 >= stride) return;
+    const int sy = reflect101(Y - kEdge, H);
+    const uint8_t* src = imgs + (size_t)f * pitch * H + (size_t)sy * pitch;
+    uint32_t v = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X4 + q;
+        uint32_t b = 0;
+        if (X < W + 2 * kEdge) b = src[reflect101(X - kEdge, W)];
+        v |= b << (8 * q);
+    }
+    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[0] + (size_t)Y * stride + X4) = v;
+}
+
+// level l >= 1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border.
+// xtab[dx] = {sx, a0, a1, use_one}; ytab[dy] = {sy0, sy1, b0, b1}
+struct ResizeTab {
+    const int4* xtab;
+    const int4* ytab;
+};
+
+__global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr) {
+    const int f = blockIdx.z;
+    const int Y = blockIdx.y;
+    const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
+    if (X4 >= stride) return;
+    const int dy = reflect101(Y - kEdge, H);
+    const int4 yt = t.ytab[dy];
+    const uint8_t* S0 = pyr + pix(g, f, l - 1, yt.x, 0);
+    const uint8_t* S1 = pyr + pix(g, f, l - 1, yt.y, 0);
+    uint32_t v = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int X = X4 + q;
+        uint32_t b = 0;
+        if (X < W + 2 * kEdge) {
+            const int4 xt = t.xtab[reflect101(X - kEdge, W)];
+            int r0, r1;
+            if (xt.w) {  // dx >= xmax: S[sx] * ONE
+                r0 = S0[xt.x] * 2048;
+                r1 = S1[xt.x] * 2048;
+            } else {
+                r0 = S0[xt.x] * xt.y + S0[xt.x + 1] * xt.z;
+                r1 = S1[xt.x] * xt.y + S1[xt.x + 1] * xt.z;
+            }
+            b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        }
+        v |= b << (8 * q);
+    }
+    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + X4) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FAST-9/16 score map.  S = max over the 16 arcs of 9 contiguous circle pixels of min(v - p) and of min(p - v),
+// clamped to [0, 255].  Corner at threshold t  <=>  S > t;  cv::FAST's cornerScore  =  S - 1.
+// One thread per pixel of the scan area [16, w-16) x [16, h-16) of every level (tiles of 64 x 4).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ p, int stride) {
+    const int v = p[0];
+    int d[16];
+    d[0] = v - p[3 * stride];        d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];
+    d[3] = v - p[stride + 3];        d[4] = v - p[3];                d[5] = v - p[-stride + 3];
+    d[6] = v - p[-2 * stride + 2];   d[7] = v - p[-3 * stride + 1];  d[8] = v - p[-3 * stride];
+    d[9] = v - p[-3 * stride - 1];   d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
+    d[12] = v - p[-3];               d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];
+    d[15] = v - p[3 * stride - 1];
+    // sliding min / max over 9 consecutive entries of the circular array by doubling: 2, 4, 8, then +1
+    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int mn9 = min(mn8[k], d[(k + 8) & 15]);
+        const int mx9 = max(mx8[k], d[(k + 8) & 15]);
+        best = max(best, max(mn9, -mx9));
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+    const int f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
+    const int t = blockIdx.x - g.tile_base[l];
+    const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;  // scan area size
+    const int tiles_x = (sw + 63) / 64;
+    const int tx = t % tiles_x, ty = t / tiles_x;
+    const int x = kEdge + tx * 64 + (threadIdx.x & 63);
+    const int y = kEdge + ty * 4 + (threadIdx.x >> 6);
+    if (x >= g.w[l] - kEdge || y >= g.h[l] - kEdge || sw <= 0 || sh <= 0) return;
+    const size_t o = pix(g, f, l, y, x);
+    score[o] = (uint8_t)fast_score(pyr + o, g.stride[l]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-cell detection: NMS + threshold selection + sort.
+// Cell (i, j) of level l scans x in [16 + j*cellW, min(16 + (j+1)*cellW, w-16)), same for y: the cells tile the
+// scan area exactly (cell window = cell +- 3 px, cv::FAST skips a 3 px rim, ORBextractor.cpp:569-608).
+// key = (255 - S) << 24 | y << 12 | x  (ascending = response desc, y asc, x asc)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __restrict__ score,
+                                                      uint32_t* __restrict__ cell_keys, int* __restrict__ cell_total,
+                                                      int* __restrict__ overflow) {
+    __shared__ uint32_t keys[kSortCap];
+    __shared__ int s_n, s_n20;
+    const int f = blockIdx.y;
+    const int cell = blockIdx.x;
+    int l = 0;
+    while (l + 1 < g.nlevels && cell >= g.cell_base[l + 1]) ++l;
+    const int ci = (cell - g.cell_base[l]) / g.gcols[l], cj = (cell - g.cell_base[l]) % g.gcols[l];
+    const int xa = kEdge + cj * g.cellW[l], ya = kEdge + ci * g.cellH[l];
+    const int xb = (cj == g.gcols[l] - 1) ? g.w[l] - kEdge : xa + g.cellW[l];
+    const int yb = (ci == g.grows[l] - 1) ? g.h[l] - kEdge : ya + g.cellH[l];
+    if (threadIdx.x == 0) { s_n = 0; s_n20 = 0; }
+    __syncthreads();
+    const int cw = xb - xa, ch = yb - ya;
+    const int stride = g.stride[l];
+    const uint8_t* base = score + pix(g, f, l, 0, 0);
+    if (cw > 0 && ch > 0) {
+        for (int idx = threadIdx.x; idx < cw * ch; idx += 256) {
+            const int x = xa + idx % cw, y = ya + idx / cw;
+            const int s = base[(size_t)y * stride + x];
+            if (s <= 7) continue;
+            bool ismax = true;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dx == 0 && dy == 0) continue;
+                    const int xx = x + dx, yy = y + dy;
+                    if (xx < xa || xx >= xb || yy < ya || yy >= yb) continue;  // outside the FAST call: score 0
+                    if (s <= base[(size_t)yy * stride + xx]) ismax = false;
+                }
+            if (!ismax) continue;
+            const int slot = atomicAdd(&s_n, 1);
+            if (s > g.fast_th) atomicAdd(&s_n20, 1);
+            if (slot < kSortCap) keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+        }
+    }
+    __syncthreads();
+    int n = s_n;
+    if (n > kSortCap) {
+        if (threadIdx.x == 0) atomicOr(overflow, 1);
+        n = kSortCap;
+    }
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    for (int i = n + threadIdx.x; i < npad; i += 256) keys[i] = 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npad; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 keypoints, FAST(7).
+    // The thr-20 corners are exactly the sorted prefix with S > fast_th.
+    const int n20 = s_n20;
+    const int total = (n20 > 3) ? n20 : n;
+    const int keep = min(total, g.cell_cap);
+    uint32_t* out = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
+    for (int i = threadIdx.x; i < keep; i += 256) out[i] = keys[i];
+    if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frame selection: quota redistribution (ORBextractor.cpp:631-679), per-cell retain (:687-705), level-wide
+// retain (:706-710).  Output: kp_list[f][i] = {level, x, y, response} in final order; counts[f].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __restrict__ cell_keys,
+                                                       const int* __restrict__ cell_total, int4* __restrict__ kp_list,
+                                                       int* __restrict__ counts, int cap, int* __restrict__ overflow) {
+    __shared__ uint32_t lst[kLevelCap];
+    __shared__ int keepflag[kLevelCap];
+    __shared__ int n_retain[64 * 4];   // per cell (<= 256 cells per level)
+    __shared__ int cell_off[64 * 4 + 1];
+    __shared__ int s_count, s_scan[256];
+    const int f = blockIdx.x;
+    const int ncells_frame = g.cell_base[g.nlevels];
+    int out_n = 0;  // keypoints written so far (uniform across the block)
+    for (int l = 0; l < g.nlevels; ++l) {
+        const int nCells = g.gcols[l] * g.grows[l];
+        const int* tot = cell_total + (size_t)f * ncells_frame + g.cell_base[l];
+        if (threadIdx.x == 0) {
+            // serial replay of the reference's quota logic
+            const int nfc = g.nfc[l];
+            int nNoMore = 0, nToDistribute = 0;
+            bool noMore[256];
+            for (int c = 0; c < nCells; ++c) {
+                const int nk = tot[c];
+                if (nk > nfc) { n_retain[c] = nfc; noMore[c] = false; }
+                else { n_retain[c] = nk; nToDistribute += nfc - nk; noMore[c] = true; nNoMore++; }
+            }
+            while (nToDistribute > 0 && nNoMore < nCells) {
+                const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
+                nToDistribute = 0;
+                for (int c = 0; c < nCells; ++c)
+                    if (!noMore[c]) {
+                        if (tot[c] > nNew) { n_retain[c] = nNew; }
+                        else { n_retain[c] = tot[c]; nToDistribute += nNew - tot[c]; noMore[c] = true; nNoMore++; }
+                    }
+            }
+            int o = 0;
+            for (int c = 0; c < nCells; ++c) {
+                cell_off[c] = o;
+                if (n_retain[c] > g.cell_cap) { atomicOr(overflow, 2); n_retain[c] = g.cell_cap; }
+                o += n_retain[c];
+            }
+            cell_off[nCells] = o;
+            if (o > kLevelCap) { atomicOr(overflow, 4); o = kLevelCap; }
+            s_count = o;
+        }
+        __syncthreads();
+        const int n = s_count;
+        // gather the per-cell prefixes in cell row-major order
+        for (int c = 0; c < nCells; ++c) {
+            const uint32_t* src = cell_keys + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
+            const int o = cell_off[c];
+            for (int i = threadIdx.x; i < n_retain[c]; i += 256)
+                if (o + i < kLevelCap) lst[o + i] = src[i];
+        }
+        __syncthreads();
+        const int quota = g.quota[l];
+        if (n > quota) {
+            // keep the `quota` best by (response desc, list position asc), preserving list order
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const uint32_t ri = lst[i] >> 24;  // 255 - S: smaller is better
+                int rank = 0;
+                for (int j = 0; j < n; ++j) {
+                    const uint32_t rj = lst[j] >> 24;
+                    rank += (rj < ri) || (rj == ri && j < i);
+                }
+                keepflag[i] = rank < quota;
+            }
+        } else {
+            for (int i = threadIdx.x; i < n; i += 256) keepflag[i] = 1;
+        }
+        __syncthreads();
+        // ordered compaction: chunks of 256 with a block scan
+        int base = 0;
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int i = c0 + threadIdx.x;
+            const int kf = (i < n) ? keepflag[i] : 0;
+            s_scan[threadIdx.x] = kf;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1) {
+                const int v = (threadIdx.x >= (unsigned)d) ? s_scan[threadIdx.x - d] : 0;
+                __syncthreads();
+                s_scan[threadIdx.x] += v;
+                __syncthreads();
+            }
+            const int pos = out_n + base + s_scan[threadIdx.x] - kf;
+            if (kf) {
+                if (pos < cap) {
+                    const uint32_t key = lst[i];
+                    kp_list[(size_t)f * cap + pos] = make_int4(l, (int)(key & 0xfff), (int)((key >> 12) & 0xfff),
+                                                               254 - (int)(key >> 24));
+                } else {
+                    atomicOr(overflow, 8);
+                }
+            }
+            base += s_scan[255];
+            __syncthreads();
+        }
+        out_n += base;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[f] = min(out_n, cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// orientation: intensity centroid over the radius-15 disc (IC_Angle, ORBextractor.cpp:130-157), 16 lanes per keypoint
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __restrict__ pyr,
+                                                      const int4* __restrict__ kp_list, const int* __restrict__ counts,
+                                                      int cap, float* __restrict__ angles) {
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 16 + threadIdx.x / 16;
+    const int v = threadIdx.x & 15;  // row offset handled by this lane: rows +v and -v
+    const int n = counts[f];
+    int m01 = 0, m10 = 0;
+    if (k < n) {
+        const int4 kp = kp_list[(size_t)f * cap + k];
+        const int stride = g.stride[kp.x];
+        const uint8_t* center = pyr + pix(g, f, kp.x, kp.z, kp.y);
+        if (v == 0) {
+            for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m10 += u * center[u];
+        } else {
+            const int d = g.umax[v];
+            int vsum = 0;
+            for (int u = -d; u <= d; ++u) {
+                const int vp = center[u + v * stride], vm = center[u - v * stride];
+                vsum += vp - vm;
+                m10 += u * (vp + vm);
+            }
+            m01 = v * vsum;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        m01 += __shfl_xor(m01, m);
+        m10 += __shfl_xor(m10, m);
+    }
+    if (k < n && v == 0) angles[(size_t)f * cap + k] = fast_atan2_deg((float)m01, (float)m10);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 7x7 Gaussian, sigma 2, 8-bit fixed point: taps {18,34,49,55,49,34,18} per pass, (v + 2^15) >> 16, saturate.
+// Tile = 64 x 16 outputs per workgroup; reads the un-blurred pyramid (whose frame holds reflect-101 copies).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+    __shared__ uint8_t tin[22][72];
+    __shared__ int th[22][64];
+    const int f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
+    const int t = blockIdx.x - g.tile_base[l];
+    const int tiles_x = (g.w[l] + 63) / 64;
+    const int x0 = (t % tiles_x) * 64, y0 = (t / tiles_x) * 16;
+    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
+    const uint8_t* src = pyr + pix(g, f, l, 0, 0);
+    for (int idx = threadIdx.x; idx < 22 * 70; idx += 256) {
+        const int r = idx / 70, c = idx % 70;
+        int x = x0 + c - 3, y = y0 + r - 3;
+        x = min(x, W + kEdge - 1);  // stay inside the bordered buffer for partial tiles
+        y = min(y, H + kEdge - 1);
+        tin[r][c] = src[(ptrdiff_t)y * stride + x];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 22 * 64; idx += 256) {
+        const int r = idx / 64, c = idx % 64;
+        const uint8_t* p = &tin[r][c];
+        th[r][c] = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+    }
+    __syncthreads();
+    uint8_t* dst = blur + pix(g, f, l, 0, 0);
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
+        const int r = idx / 64, c = idx % 64;
+        const int x = x0 + c, y = y0 + r;
+        if (x >= W || y >= H) continue;
+        const int s = 18 * (th[r][c] + th[r + 6][c]) + 34 * (th[r + 1][c] + th[r + 5][c]) +
+                      49 * (th[r + 2][c] + th[r + 4][c]) + 55 * th[r + 3][c];
+        const int v = (s + (1 << 15)) >> 16;
+        dst[(size_t)y * stride + x] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// descriptors + final key points.  One wave per keypoint; lane l evaluates bits l, l+64, l+128, l+192.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restrict__ blur,
+                                                   const int4* __restrict__ kp_list, const int* __restrict__ counts,
+                                                   int cap, const float* __restrict__ angles,
+                                                   se2gpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 4 + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (k >= counts[f]) return;  // wave-uniform
+    const int4 kp = kp_list[(size_t)f * cap + k];
+    const float ang = angles[(size_t)f * cap + k];
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float angle = ang * factorPI;
+    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int stride = g.stride[kp.x];
+    const uint8_t* center = blur + pix(g, f, kp.x, kp.z, kp.y);
+    unsigned long long words[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const signed char* pt = c_pattern + 4 * (64 * q + lane);
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = (int)rintf(x0 * b + y0 * a), c0 = (int)rintf(x0 * a - y0 * b);
+        const int r1 = (int)rintf(x1 * b + y1 * a), c1 = (int)rintf(x1 * a - y1 * b);
+        const int t0 = center[r0 * stride + c0], t1 = center[r1 * stride + c1];
+        words[q] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long w = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
+        *(unsigned long long*)(desc + ((size_t)f * cap + k) * 32 + 8 * lane) = w;
+    }
+    if (lane == 0) {
+        se2gpu_keypoint o;
+        o.x = (float)kp.y;
+        o.y = (float)kp.z;
+        if (kp.x != 0) {
+            const float s = g.scale[kp.x];
+            o.x *= s;
+            o.y *= s;
+        }
+        o.size = g.patch[kp.x];
+        o.angle = ang;
+        o.response = (float)kp.w;
+        o.octave = kp.x;
+        o.class_id = -1;
+        kps[(size_t)f * cap + k] = o;
+    }
+}
+
+inline int cv_round_f(float v) { return (int)std::nearbyintf(v); }
+inline int cv_round_d(double v) { return (int)std::nearbyint(v); }
+inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct se2gpu_orb {
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    LaunchProfile prof;
+    se2gpu_orb_params params{};
+    double scaleFactor = 1.2;
+    std::vector<float> mvScale, mvInvScale;
+    std::vector<int> quota;
+    int umax[16];
+    Geom g{};
+    int max_batch = 1;
+    int last_batch = 0;
+    DevBuf<uint8_t> pyr, blur, score, img;
+    DevBuf<uint32_t> cell_keys;
+    DevBuf<int> cell_total, counts, overflow;
+    DevBuf<int4> kp_list, tabs;
+    DevBuf<float> angles;
+    DevBuf<se2gpu_keypoint> kps;
+    DevBuf<uint8_t> desc;
+    std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
+    int score_tiles = 0, blur_tiles = 0;
+    int score_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
+    ~se2gpu_orb() {
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+};
+
+namespace {
+
+// Geometry for a rows x cols image (ORBextractor.cpp:540-556, 794-795) + resize tables (cv::resize INTER_LINEAR).
+int orb_configure(se2gpu_orb* h, int rows, int cols) {
+    Geom& g = h->g;
+    if (g.rows == rows && g.cols == cols && g.nlevels == h->params.nlevels) return SE2GPU_OK;
+    const int L = h->params.nlevels;
+    g.nlevels = L;
+    g.rows = rows; g.cols = cols;
+    g.nfeatures = h->params.nfeatures;
+    g.fast_th = h->params.fast_th;
+    for (int i = 0; i < 16; ++i) g.umax[i] = h->umax[i];
+    unsigned off = 0;
+    const float imageRatio = (float)cols / rows;
+    g.cell_base[0] = 0;
+    int maxq = 0;
+    for (int l = 0; l < L; ++l) {
+        const float scale = h->mvInvScale[l];
+        g.w[l] = cv_round_f((float)cols * scale);
+        g.h[l] = cv_round_f((float)rows * scale);
+        SE2_REQUIRE(g.w[l] > 2 * kEdge + 6 && g.h[l] > 2 * kEdge + 6 && g.w[l] < 4096 && g.h[l] < 4096,
+                    SE2GPU_ERR_INVALID, "pyramid level %d is %dx%d: unsupported image size", l, g.w[l], g.h[l]);
+        g.stride[l] = ((g.w[l] + 2 * kEdge + 63) / 64) * 64;
+        g.off[l] = off;
+        off += (unsigned)g.stride[l] * (g.h[l] + 2 * kEdge);
+        g.quota[l] = h->quota[l];
+        maxq = std::max(maxq, g.quota[l]);
+        g.gcols[l] = (int)std::sqrt((float)g.quota[l] / (5 * imageRatio));
+        g.grows[l] = (int)(imageRatio * g.gcols[l]);
+        SE2_REQUIRE(g.gcols[l] >= 1 && g.grows[l] >= 1 && g.gcols[l] * g.grows[l] <= 256, SE2GPU_ERR_INVALID,
+                    "level %d: unsupported cell grid %dx%d", l, g.gcols[l], g.grows[l]);
+        const int W = g.w[l] - 2 * kEdge, H = g.h[l] - 2 * kEdge;
+        g.cellW[l] = (int)std::ceil((float)W / g.gcols[l]);
+        g.cellH[l] = (int)std::ceil((float)H / g.grows[l]);
+        g.nfc[l] = (int)std::ceil((float)g.quota[l] / (g.gcols[l] * g.grows[l]));
+        g.cell_base[l + 1] = g.cell_base[l] + g.gcols[l] * g.grows[l];
+        g.scale[l] = h->mvScale[l];
+        g.patch[l] = (float)(int)(kPatch * h->mvScale[l]);
+        // the cells must tile the scan area the way the reference's windows do (no empty last row / column)
+        SE2_REQUIRE(g.cellW[l] * (g.gcols[l] - 1) < W && g.cellH[l] * (g.grows[l] - 1) < H, SE2GPU_ERR_INVALID,
+                    "level %d: degenerate cell grid", l);
+    }
+    g.frame_bytes = (off + 255u) & ~255u;
+    g.cell_cap = std::min(kSortCap, ((2 * maxq + 64 + 63) / 64) * 64);
+    // tiles
+    h->score_tile_base[0] = 0;
+    h->blur_tile_base[0] = 0;
+    for (int l = 0; l < L; ++l) {
+        const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;
+        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 63) / 64) * ((sh + 3) / 4);
+        h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 63) / 64) * ((g.h[l] + 15) / 16);
+    }
+    // resize tables
+    std::vector<int4> tabs;
+    h->xtab_off.assign(L, 0);
+    h->ytab_off.assign(L, 0);
+    for (int l = 1; l < L; ++l) {
+        const int sw = g.w[l - 1], sh = g.h[l - 1], dw = g.w[l], dh = g.h[l];
+        const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+        const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+        int xmax = dw;
+        std::vector<int4> xt(dw), yt(dh);
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = cv_floor_f(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            if (sx + 1 >= sw) {
+                xmax = std::min(xmax, dx);
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+            }
+            const float cb0 = 1.f - fx, cb1 = fx;
+            auto sat = [](int v) { return std::min(std::max(v, -32768), 32767); };
+            xt[dx] = make_int4(sx, sat(cv_round_f(cb0 * 2048)), sat(cv_round_f(cb1 * 2048)), 0);
+        }
+        for (int dx = xmax; dx < dw; dx++) xt[dx].w = 1;
+        auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
+        for (int dy = 0; dy < dh; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = cv_floor_f(fy);
+            fy -= sy;
+            const float cb0 = 1.f - fy, cb1 = fy;
+            auto sat = [](int v) { return std::min(std::max(v, -32768), 32767); };
+            yt[dy] = make_int4(clip(sy, 0, sh), clip(sy + 1, 0, sh), sat(cv_round_f(cb0 * 2048)), sat(cv_round_f(cb1 * 2048)));
+        }
+        h->xtab_off[l] = tabs.size();
+        tabs.insert(tabs.end(), xt.begin(), xt.end());
+        h->ytab_off[l] = tabs.size();
+        tabs.insert(tabs.end(), yt.begin(), yt.end());
+    }
+    if (tabs.empty()) tabs.push_back(make_int4(0, 0, 0, 0));
+    SE2_CHECK(h->tabs.upload(tabs, h->stream));
+    // buffers
+    const size_t B = (size_t)h->max_batch;
+    SE2_CHECK(h->pyr.reserve(B * g.frame_bytes));
+    SE2_CHECK(h->blur.reserve(B * g.frame_bytes));
+    const bool fresh_score = h->score.cap < B * g.frame_bytes;
+    SE2_CHECK(h->score.reserve(B * g.frame_bytes));
+    (void)fresh_score;
+    SE2_HIP(hipMemsetAsync(h->score.p, 0, B * g.frame_bytes, h->stream));
+    SE2_CHECK(h->cell_keys.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
+    SE2_CHECK(h->cell_total.reserve(B * g.cell_base[L]));
+    SE2_CHECK(h->overflow.reserve(1));
+    SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    return SE2GPU_OK;
+}
+
+// the device pipeline for `nframes` frames already in d_imgs (pitch = cols)
+int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu_keypoint* d_kps, uint8_t* d_desc,
+            int32_t* d_counts, int cap) {
+    Geom g = h->g;
+    hipStream_t st = h->stream;
+    const int L = g.nlevels;
+    SE2_CHECK(h->kp_list.reserve((size_t)h->max_batch * cap));
+    SE2_CHECK(h->angles.reserve((size_t)h->max_batch * cap));
+    {
+        dim3 grid((g.stride[0] / 4 + 255) / 256, g.h[0] + 2 * kEdge, nframes);
+        SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
+    }
+    for (int l = 1; l < L; ++l) {
+        ResizeTab t{h->tabs.p + h->xtab_off[l], h->tabs.p + h->ytab_off[l]};
+        dim3 grid((g.stride[l] / 4 + 255) / 256, g.h[l] + 2 * kEdge, nframes);
+        SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
+    }
+    for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
+    SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p,
+               h->score.p);
+    SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect, dim3(g.cell_base[L], nframes), dim3(256), 0, g, h->score.p,
+               h->cell_keys.p, h->cell_total.p, h->overflow.p);
+    SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(nframes), dim3(256), 0, g, h->cell_keys.p,
+               h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
+    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 15) / 16, nframes), dim3(256), 0, g, h->pyr.p,
+               h->kp_list.p, d_counts, cap, h->angles.p);
+    // blurred pyramid: frame = un-blurred reflect copies, interior = blur
+    h->prof.begin(st);
+    SE2_HIP(hipMemcpyAsync(h->blur.p, h->pyr.p, (size_t)nframes * g.frame_bytes, hipMemcpyDeviceToDevice, st));
+    h->prof.end(st, "copy_border");
+    for (int l = 0; l <= L; ++l) g.tile_base[l] = h->blur_tile_base[l];
+    SE2_LAUNCH(h->prof, st, "k_blur", k_blur, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p, h->blur.p);
+    SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->blur.p,
+               h->kp_list.p, d_counts, cap, h->angles.p, d_kps, d_desc);
+    SE2_HIP(hipGetLastError());
+    h->last_batch = nframes;
+    return SE2GPU_OK;
+}
+
+int orb_check_overflow(se2gpu_orb* h) {
+    int ov = 0;
+    SE2_HIP(hipMemcpyAsync(&ov, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    if (ov) {
+        SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
+        set_error("ORB extractor: internal capacity overflow (mask %d): cell candidates / level list / output cap", ov);
+        return SE2GPU_ERR_CAPACITY;
+    }
+    return SE2GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
+    SE2_REQUIRE(params && out, SE2GPU_ERR_INVALID, "orb_create: NULL argument");
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
+    SE2_REQUIRE(params->score_type == 1, SE2GPU_ERR_INVALID,
+                "only FAST_SCORE is supported (HARRIS_SCORE is dormant in the reference, ORBextractor.h:44)");
+    SE2_REQUIRE(params->nlevels >= 1 && params->nlevels <= kMaxLevels && params->nfeatures > 0 &&
+                    params->scale_factor > 1.0f && params->fast_th >= 7 && params->fast_th < 255,
+                SE2GPU_ERR_INVALID, "orb_create: parameter out of range");
+    se2gpu_orb* h = new se2gpu_orb;
+    h->params = *params;
+    if (h->params.max_rows <= 0 || h->params.max_cols <= 0) { h->params.max_rows = 480; h->params.max_cols = 640; }
+    h->max_batch = std::max(1, params->max_batch);
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        set_error("hipStreamCreate failed");
+        return SE2GPU_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+    // ORBextractor::ORBextractor (ORBextractor.cpp:463-520); scaleFactor is a double member built from a float
+    const int L = params->nlevels;
+    h->scaleFactor = (double)params->scale_factor;
+    h->mvScale.resize(L); h->mvInvScale.resize(L); h->quota.resize(L);
+    h->mvScale[0] = 1;
+    for (int i = 1; i < L; i++) h->mvScale[i] = (float)(h->mvScale[i - 1] * h->scaleFactor);
+    const float invScaleFactor = (float)(1.0f / h->scaleFactor);
+    h->mvInvScale[0] = 1;
+    for (int i = 1; i < L; i++) h->mvInvScale[i] = h->mvInvScale[i - 1] * invScaleFactor;
+    const float factor = (float)(1.0 / h->scaleFactor);
+    float nDesired = params->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)L));
+    int sum = 0;
+    for (int level = 0; level < L - 1; level++) {
+        h->quota[level] = cv_round_f(nDesired);
+        sum += h->quota[level];
+        nDesired *= factor;
+    }
+    h->quota[L - 1] = std::max(params->nfeatures - sum, 0);
+    {
+        int um[kHalfPatch + 2] = {0};
+        int v, v0;
+        const int vmax = cv_floor_f(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+        const int vmin = cv_ceil_d(kHalfPatch * std::sqrt(2.f) / 2);
+        const double hp2 = kHalfPatch * kHalfPatch;
+        for (v = 0; v <= vmax; ++v) um[v] = cv_round_d(std::sqrt(hp2 - v * v));
+        for (v = kHalfPatch, v0 = 0; v >= vmin; --v) {
+            while (um[v0] == um[v0 + 1]) ++v0;
+            um[v] = v0;
+            ++v0;
+        }
+        for (int i = 0; i < 16; ++i) h->umax[i] = um[i];
+    }
+    const int rc = orb_configure(h, h->params.max_rows, h->params.max_cols);
+    if (rc != SE2GPU_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SE2GPU_OK;
+}
+
+void se2gpu_orb_destroy(se2gpu_orb* h) { delete h; }
+int se2gpu_orb_levels(const se2gpu_orb* h) { return h ? h->params.nlevels : 0; }
+float se2gpu_orb_scale_factor(const se2gpu_orb* h) { return h ? (float)h->scaleFactor : 0.f; }
+void* se2gpu_orb_stream(se2gpu_orb* h) { return h ? (void*)h->stream : nullptr; }
+
+int se2gpu_orb_set_stream(se2gpu_orb* h, void* s) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "orb handle is NULL");
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return SE2GPU_OK;
+}
+
+int se2gpu_orb_sync(se2gpu_orb* h) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "orb handle is NULL");
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    return orb_check_overflow(h);
+}
+
+int se2gpu_orb_extract_batch_device(se2gpu_orb* h, const uint8_t* d_imgs, int nframes, int rows, int cols,
+                                    se2gpu_keypoint* d_kps, uint8_t* d_desc, int32_t* d_counts, int cap) {
+    SE2_REQUIRE(h && d_imgs && d_kps && d_desc && d_counts, SE2GPU_ERR_INVALID, "extract_batch: NULL argument");
+    SE2_REQUIRE(nframes >= 1 && nframes <= h->max_batch, SE2GPU_ERR_CAPACITY, "nframes %d exceeds max_batch %d", nframes,
+                h->max_batch);
+    SE2_REQUIRE(rows <= h->params.max_rows && cols <= h->params.max_cols && rows > 0 && cols > 0, SE2GPU_ERR_INVALID,
+                "image %dx%d exceeds the handle's maximum %dx%d", rows, cols, h->params.max_rows, h->params.max_cols);
+    SE2_REQUIRE(cap > 0, SE2GPU_ERR_INVALID, "cap must be positive");
+    SE2_CHECK(orb_configure(h, rows, cols));
+    return orb_run(h, d_imgs, cols, nframes, d_kps, d_desc, d_counts, cap);
+}
+
+int se2gpu_orb_extract(se2gpu_orb* h, const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
+                       se2gpu_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
+    SE2_REQUIRE(h && n_out, SE2GPU_ERR_INVALID, "orb_extract: NULL argument");
+    SE2_REQUIRE(mask == nullptr, SE2GPU_ERR_INVALID, "masks are not supported (the reference passes an empty mask, Frame.cpp:25)");
+    *n_out = 0;
+    if (!img || rows == 0 || cols == 0) return SE2GPU_OK;  // _image.empty(): silent return (ORBextractor.cpp:730)
+    SE2_REQUIRE(kps && desc && cap > 0, SE2GPU_ERR_INVALID, "orb_extract: NULL output");
+    SE2_REQUIRE(rows <= h->params.max_rows && cols <= h->params.max_cols && rows > 0 && cols > 0, SE2GPU_ERR_INVALID,
+                "image %dx%d exceeds the handle's maximum %dx%d", rows, cols, h->params.max_rows, h->params.max_cols);
+    SE2_CHECK(orb_configure(h, rows, cols));
+    hipStream_t st = h->stream;
+    SE2_CHECK(h->img.reserve((size_t)h->params.max_rows * h->params.max_cols));
+    SE2_CHECK(h->kps.reserve((size_t)cap));
+    SE2_CHECK(h->desc.reserve((size_t)cap * 32));
+    SE2_CHECK(h->counts.reserve((size_t)h->max_batch));
+    SE2_HIP(hipMemcpy2DAsync(h->img.p, cols, img, step, cols, rows, hipMemcpyHostToDevice, st));
+    SE2_CHECK(orb_run(h, h->img.p, cols, 1, h->kps.p, h->desc.p, h->counts.p, cap));
+    int n = 0;
+    SE2_HIP(hipMemcpyAsync(&n, h->counts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    SE2_CHECK(orb_check_overflow(h));
+    n = std::min(n, cap);
+    if (n) {
+        SE2_HIP(hipMemcpyAsync(kps, h->kps.p, (size_t)n * sizeof(se2gpu_keypoint), hipMemcpyDeviceToHost, st));
+        SE2_HIP(hipMemcpyAsync(desc, h->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
+        SE2_HIP(hipStreamSynchronize(st));
+    }
+    *n_out = n;
+    return SE2GPU_OK;
+}
+
+int se2gpu_orb_debug_level(se2gpu_orb* h, int frame, int level, int blurred, uint8_t* out, size_t out_cap, int* rows,
+                           int* cols) {
+    SE2_REQUIRE(h && out && rows && cols, SE2GPU_ERR_INVALID, "debug_level: NULL argument");
+    SE2_REQUIRE(frame >= 0 && frame < h->last_batch && level >= 0 && level < h->g.nlevels, SE2GPU_ERR_INVALID,
+                "debug_level: frame/level out of range");
+    const Geom& g = h->g;
+    SE2_REQUIRE(out_cap >= (size_t)g.w[level] * g.h[level], SE2GPU_ERR_CAPACITY, "debug_level: buffer too small");
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    const uint8_t* src = (blurred ? h->blur.p : h->pyr.p) + (size_t)frame * g.frame_bytes + g.off[level] +
+                         (size_t)kEdge * g.stride[level] + kEdge;
+    SE2_HIP(hipMemcpy2D(out, g.w[level], src, g.stride[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
+    *rows = g.h[level];
+    *cols = g.w[level];
+    return SE2GPU_OK;
+}
+
+int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, size_t out_cap, int* rows, int* cols) {
+    SE2_REQUIRE(h && out && rows && cols, SE2GPU_ERR_INVALID, "debug_score: NULL argument");
+    SE2_REQUIRE(frame >= 0 && frame < h->last_batch && level >= 0 && level < h->g.nlevels, SE2GPU_ERR_INVALID,
+                "debug_score: frame/level out of range");
+    const Geom& g = h->g;
+    SE2_REQUIRE(out_cap >= (size_t)g.w[level] * g.h[level], SE2GPU_ERR_CAPACITY, "debug_score: buffer too small");
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    const uint8_t* src = h->score.p + (size_t)frame * g.frame_bytes + g.off[level] + (size_t)kEdge * g.stride[level] + kEdge;
+    SE2_HIP(hipMemcpy2D(out, g.w[level], src, g.stride[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
+    *rows = g.h[level];
+    *cols = g.w[level];
+    return SE2GPU_OK;
+}
+
+int se2gpu_orb_profile(se2gpu_orb* h, int enable) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "orb handle is NULL");
+    h->prof.enabled = enable != 0;
+    h->prof.reset();
+    return SE2GPU_OK;
+}
+
+int se2gpu_orb_profile_get(se2gpu_orb* h, int idx, const char** name, double* ms, int64_t* launches) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "orb handle is NULL");
+    if (idx < 0 || idx >= (int)h->prof.slots.size()) return SE2GPU_ERR_INVALID;
+    if (name) *name = h->prof.slots[idx].name;
+    if (ms) *ms = h->prof.slots[idx].ms;
+    if (launches) *launches = h->prof.slots[idx].launches;
+    return SE2GPU_OK;
+}
+
+}  // extern "C"

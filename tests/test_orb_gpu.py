@@ -1,0 +1,99 @@
+"""GPU parity tests of the HIP ORB extractor (through the C ABI) against the CPU oracle: BIT-EXACT
+pyramid, FAST score map, blurred pyramid, key points (all 7 cv::KeyPoint fields) and descriptors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ex():
+    from se2lam_amd.orb import ORBextractor
+    return ORBextractor(max_batch=8)
+
+
+def test_pyramid_score_blur_bit_exact(ex, oracle, synth):
+    img = synth.frame(3)
+    ex(img)
+    for lv in range(8):
+        assert np.array_equal(ex.debug_level(0, lv), oracle.orb_level(img, lv)), f"level {lv}"
+        assert np.array_equal(ex.debug_level(0, lv, blurred=True), oracle.orb_level(img, lv, blurred=True)), f"blur {lv}"
+        s_gpu, s_ref = ex.debug_score(0, lv), oracle.orb_score(img, lv)
+        assert np.array_equal(s_gpu[16:-16, 16:-16], s_ref[16:-16, 16:-16]), f"score {lv}"
+
+
+@pytest.mark.parametrize("t", range(10))
+def test_extract_bit_exact_config1_frames(ex, oracle, synth, t):
+    """config 1/2: the ten 640x480 synthetic frames, 8 levels, 1000 features - every key point field and
+    every descriptor byte equal to the oracle's."""
+    img = synth.frame(t)
+    k, d = ex(img)
+    ko, do = oracle.orb_extract(img)
+    assert len(k) == len(ko) == 1000
+    for field in ("octave", "x", "y", "response", "size", "angle", "class_id"):
+        assert np.array_equal(k[field], ko[field]), field
+    assert np.array_equal(d, do)
+
+
+def test_batch_equals_single(ex, oracle, synth):
+    imgs = synth.frames(8, start=20)
+    out = ex.extract_batch(imgs)
+    for b in range(8):
+        ko, do = oracle.orb_extract(imgs[b])
+        assert np.array_equal(out[b][0], ko) and np.array_equal(out[b][1], do), b
+
+
+def test_other_image_sizes_and_parameters(oracle, synth):
+    from se2lam_amd.orb import ORBextractor
+    tex = synth.texture()
+    for (rows, cols, nf, nl, th) in ((480, 640, 500, 8, 20), (376, 1241 // 2, 1000, 6, 12), (240, 320, 300, 4, 20)):
+        img = np.ascontiguousarray(tex[50:50 + rows, 70:70 + cols])
+        ex = ORBextractor(nfeatures=nf, nlevels=nl, fastTh=th, max_rows=rows, max_cols=cols)
+        k, d = ex(img)
+        ko, do = oracle.orb_extract(img, oracle.orb_params(nf, 1.2, nl, th))
+        assert len(k) == len(ko) > 0
+        assert np.array_equal(k, ko) and np.array_equal(d, do), (rows, cols)
+
+
+def test_edge_cases(ex, oracle, synth):
+    # empty image: silent return (ORBextractor.cpp:730-731)
+    k, d = ex(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0
+    # flat image: no corners at either threshold
+    k, d = ex(np.full((480, 640), 128, np.uint8))
+    assert len(k) == 0
+    # low contrast: only the threshold-7 fallback fires (cells with <= 3 corners at 20)
+    img = (128 + (synth.frame(0).astype(np.int32) - 128) // 8).astype(np.uint8)
+    k, d = ex(img)
+    ko, do = oracle.orb_extract(img)
+    assert len(ko) > 0 and np.array_equal(k, ko) and np.array_equal(d, do)
+    # salt-and-pepper noise: thousands of candidates per cell, many ties at the retain boundary
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (480, 640)).astype(np.uint8)
+    k, d = ex(img)
+    ko, do = oracle.orb_extract(img)
+    assert len(ko) == 1000 and np.array_equal(k, ko) and np.array_equal(d, do)
+    # a textured half and a flat half: quota redistribution between cells (ORBextractor.cpp:653-679)
+    img = synth.frame(2).copy()
+    img[:, 320:] = 90
+    k, d = ex(img)
+    ko, do = oracle.orb_extract(img)
+    assert np.array_equal(k, ko) and np.array_equal(d, do)
+    # strided input (cv::Mat ROI with step > cols)
+    big = synth.texture()
+    view = big[100:580, 200:840]
+    k, d = ex(view)
+    ko, do = oracle.orb_extract(np.ascontiguousarray(view))
+    assert np.array_equal(k, ko) and np.array_equal(d, do)
+
+
+def test_errors(ex):
+    from se2lam_amd import capi
+    from se2lam_amd.orb import ORBextractor
+    with pytest.raises(capi.Se2GpuError) as e:
+        ORBextractor(scoreType=0)                      # HARRIS_SCORE: dormant in the reference, rejected
+    assert e.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.Se2GpuError):
+        ex(np.zeros((480, 640), np.uint8), mask=np.ones((480, 640), np.uint8))
+    with pytest.raises(capi.Se2GpuError):
+        ex(np.zeros((481, 640), np.uint8))             # larger than the handle was created for
