@@ -275,5 +275,77 @@ def orb_gaussian_taps():
     return out
 
 
-def _declare_match(l):  # filled in with match_ref.cpp
-    pass
+# --------------------------------------------------------------------------------------
+# matcher
+# --------------------------------------------------------------------------------------
+class Bounds(C.Structure):
+    _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
+
+
+def _declare_match(l):
+    VP = C.c_void_p
+    l.match_ref_hamming.restype = C.c_int
+    l.match_ref_hamming.argtypes = [VP, VP]
+    l.match_ref_features_in_area.restype = C.c_int
+    l.match_ref_features_in_area.argtypes = [C.POINTER(Bounds), VP, C.c_int, C.c_float, C.c_float, C.c_float,
+                                             C.c_int, C.c_int, VP, C.c_int]
+    l.match_ref_window.restype = C.c_int
+    l.match_ref_window.argtypes = [C.POINTER(Bounds), VP, VP, C.c_int, VP, VP, C.c_int, VP, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_float, VP]
+    l.match_ref_projection.restype = C.c_int
+    l.match_ref_projection.argtypes = [C.POINTER(Bounds), VP, VP, VP, VP, C.c_int, VP, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]
+
+
+def default_bounds(cols=640, rows=480):
+    return Bounds(0.0, 0.0, float(cols), float(rows))
+
+
+def hamming(a, b) -> int:
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().match_ref_hamming(a.ctypes.data, b.ctypes.data))
+
+
+def features_in_area(kps, x, y, r, min_level, max_level, bounds=None):
+    bounds = bounds or default_bounds()
+    kps = np.ascontiguousarray(kps)
+    out = np.zeros(max(len(kps), 1), np.int32)
+    n = lib().match_ref_features_in_area(C.byref(bounds), kps.ctypes.data, len(kps), x, y, r, min_level, max_level,
+                                         out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def match_window(kps1, desc1, kps2, desc2, prev_xy=None, win=20, level_offset=1, min_level=0, max_level=8,
+                 nnratio=0.9, bounds=None):
+    """-> (matches12 (n1,), nmatches, prev_xy updated)"""
+    bounds = bounds or default_bounds()
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    n1, n2 = len(kps1), len(kps2)
+    if prev_xy is None:
+        prev_xy = np.stack([kps1["x"], kps1["y"]], axis=1)
+    prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    nm = lib().match_ref_window(C.byref(bounds), kps1.ctypes.data, desc1.ctypes.data, n1, kps2.ctypes.data,
+                                desc2.ctypes.data, n2, prev.ctypes.data, win, level_offset, min_level, max_level,
+                                nnratio, m12.ctypes.data)
+    return m12[:n1].copy(), int(nm), prev
+
+
+def match_projection(mp_pos, mp_desc, mp_octave, mp_skip, Tcw, K4, kps, desc, kf_observed, win=15, level_offset=2,
+                     nnratio=0.6, bounds=None):
+    """-> (match_idx_mp (n,), nmatches)"""
+    bounds = bounds or default_bounds()
+    mp_pos = np.ascontiguousarray(mp_pos, np.float32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    mp_octave = np.ascontiguousarray(mp_octave, np.int32); mp_skip = np.ascontiguousarray(mp_skip, np.uint8)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy()
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+    kf_observed = np.ascontiguousarray(kf_observed, np.uint8)
+    n, m = len(kps), len(mp_octave)
+    out = np.full(max(n, 1), -1, np.int32)
+    fx, fy, cx, cy = [float(v) for v in K4]
+    nm = lib().match_ref_projection(C.byref(bounds), mp_pos.ctypes.data, mp_desc.ctypes.data, mp_octave.ctypes.data,
+                                    mp_skip.ctypes.data, m, Tcw.ctypes.data, fx, fy, cx, cy, kps.ctypes.data,
+                                    desc.ctypes.data, kf_observed.ctypes.data, n, win, level_offset, nnratio,
+                                    out.ctypes.data)
+    return out[:n].copy(), int(nm)

@@ -1,0 +1,609 @@
+// libse2gpu - ORB matchers on gfx950 (MI355X).
+//
+// Replaces se2lam::ORBmatcher (/root/reference/src/ORBmatcher.cpp, include/se2lam/ORBmatcher.h:42-80):
+//   DescriptorDistance :110-126, ComputeThreeMaxima :64-105, MatchByWindow :278-381, MatchByProjection :383-454
+// and the Frame grid they search (/root/reference/src/Frame.cpp:209-286: PosInGrid uses round(), GetFeaturesInArea
+// returns indices in (cell x, cell y, insertion) order; 64 x 48 cells, include/se2lam/Frame.h:26-27).
+//
+// The reference's matchers are order-dependent greedy passes: query i sees vMatchesDistance as left by queries
+// 0..i-1 and ties go to the earliest candidate.  The split used here keeps that exactly:
+//   k_grid_order     per target frame: features sorted by (cell x, cell y, index) = the order GetFeaturesInArea
+//                    enumerates them (LDS bitonic sort of 28-bit keys)
+//   k_cand_*         one wave per query: window / level / square test over the sorted list, wave-ballot ordered
+//                    compaction, 256-bit Hamming distance (4 x popcll) -> per-query candidate list (idx, dist)
+//                    - the parallel O(N1*N2) part
+//   k_resolve_*      one wave per frame pair: replays the greedy pass in query order on the pre-computed lists
+//                    (wave-ballot arg-min for best / second best, state in LDS), rotation histogram,
+//                    ComputeThreeMaxima, prev-matched update - the sequential part, parallel across pairs
+// Compiled with -ffp-contract=off (float grid / projection arithmetic must round as the reference's).
+#include <algorithm>
+#include <climits>
+#include <cmath>
+
+#include "common.h"
+
+using namespace se2gpu;
+
+namespace {
+
+constexpr int kGridCols = 64, kGridRows = 48;
+constexpr int kThHigh = 100, kThLow = 75, kHisto = 30;
+constexpr int kMaxCand = 128;     // candidates kept per query
+constexpr int kMaxFeat = 8192;    // features per frame the LDS sort can hold
+
+struct Bounds {
+    float min_x, min_y, max_x, max_y, wInv, hInv;
+};
+
+__device__ __forceinline__ int hamming256(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b) {
+    const unsigned long long* pa = (const unsigned long long*)a;
+    const unsigned long long* pb = (const unsigned long long*)b;
+    return __popcll(pa[0] ^ pb[0]) + __popcll(pa[1] ^ pb[1]) + __popcll(pa[2] ^ pb[2]) + __popcll(pa[3] ^ pb[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_grid_order: one workgroup per frame.  sorted[f][i] = (cell << 16) | idx for the features that fall in the grid,
+// ascending (cell = ix * 48 + iy); n_grid[f] = their number.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_order(Bounds bd, const se2gpu_keypoint* __restrict__ kps,
+                                                     const int* __restrict__ counts, const int* __restrict__ frames,
+                                                     int cap, uint32_t* __restrict__ sorted, int* __restrict__ n_grid) {
+    __shared__ uint32_t keys[kMaxFeat];
+    __shared__ int s_n;
+    const int f = frames ? frames[blockIdx.x] : blockIdx.x;
+    const int n = min(counts[f], min(cap, kMaxFeat));
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int npad = 1;
+    while (npad < n) npad <<= 1;
+    for (int i = threadIdx.x; i < npad; i += 256) {
+        uint32_t key = 0xffffffffu;
+        if (i < n) {
+            const se2gpu_keypoint kp = kps[(size_t)f * cap + i];
+            const int px = (int)roundf((kp.x - bd.min_x) * bd.wInv);
+            const int py = (int)roundf((kp.y - bd.min_y) * bd.hInv);
+            if (px >= 0 && px < kGridCols && py >= 0 && py < kGridRows) {
+                key = ((uint32_t)(px * kGridRows + py) << 16) | (uint32_t)i;
+                atomicAdd(&s_n, 1);
+            }
+        }
+        keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npad; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 256) sorted[(size_t)f * cap + i] = keys[i];
+    if (threadIdx.x == 0) n_grid[f] = s_n;
+}
+
+// Candidate scan of one query by one wave (Frame::GetFeaturesInArea + DescriptorDistance).
+// Returns the number of candidates (may exceed kMaxCand: the caller flags overflow); out[s] = (idx << 12) | dist.
+__device__ __forceinline__ int scan_candidates(const Bounds& bd, float x, float y, float r, int minLevel, int maxLevel,
+                                               const uint8_t* __restrict__ d1, const se2gpu_keypoint* __restrict__ kps2,
+                                               const uint8_t* __restrict__ desc2, const uint32_t* __restrict__ sorted2,
+                                               int n_grid2, const uint8_t* __restrict__ excl, uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    int nMinCellX = (int)floorf((x - bd.min_x - r) * bd.wInv);
+    nMinCellX = max(0, nMinCellX);
+    if (nMinCellX >= kGridCols) return 0;
+    int nMaxCellX = (int)ceilf((x - bd.min_x + r) * bd.wInv);
+    nMaxCellX = min(kGridCols - 1, nMaxCellX);
+    if (nMaxCellX < 0) return 0;
+    int nMinCellY = (int)floorf((y - bd.min_y - r) * bd.hInv);
+    nMinCellY = max(0, nMinCellY);
+    if (nMinCellY >= kGridRows) return 0;
+    int nMaxCellY = (int)ceilf((y - bd.min_y + r) * bd.hInv);
+    nMaxCellY = min(kGridRows - 1, nMaxCellY);
+    if (nMaxCellY < 0) return 0;
+    const bool checkLevels = !(minLevel == -1 && maxLevel == -1);
+    int count = 0;
+    for (int c0 = 0; c0 < n_grid2; c0 += 64) {
+        const int pos = c0 + lane;
+        bool ok = false;
+        int idx = 0;
+        if (pos < n_grid2) {
+            const uint32_t pk = sorted2[pos];
+            const int cell = (int)(pk >> 16);
+            idx = (int)(pk & 0xffffu);
+            const int cx = cell / kGridRows, cy = cell % kGridRows;
+            if (cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
+                const se2gpu_keypoint kp = kps2[idx];
+                ok = (!checkLevels || (kp.octave >= minLevel && kp.octave <= maxLevel)) && !(fabsf(kp.x - x) > r) &&
+                     !(fabsf(kp.y - y) > r) && !(excl && excl[idx]);
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+            const int slot = count + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < kMaxCand) out[slot] = ((uint32_t)idx << 12) | (uint32_t)hamming256(d1, desc2 + 32 * (size_t)idx);
+        }
+        count += __popcll(m);
+        // the list is sorted by cell x first: nothing left once the last lane of this chunk is past the window
+        const uint32_t last = sorted2[min(c0 + 63, n_grid2 - 1)];
+        if ((int)(last >> 16) / kGridRows > nMaxCellX) break;
+    }
+    return count;
+}
+
+// MatchByWindow candidates: query i1 of pair p = frame a's key point, searched around prev_xy in frame b.
+__global__ __launch_bounds__(256) void k_cand_window(Bounds bd, const se2gpu_keypoint* __restrict__ kps,
+                                                      const uint8_t* __restrict__ desc, const int* __restrict__ counts,
+                                                      int cap, const int* __restrict__ pair_a,
+                                                      const int* __restrict__ pair_b, const float* __restrict__ prev_xy,
+                                                      const uint32_t* __restrict__ sorted, const int* __restrict__ n_grid,
+                                                      int win, int level_offset, int min_level, int max_level,
+                                                      uint32_t* __restrict__ cand, int* __restrict__ ncand) {
+    const int p = blockIdx.y;
+    const int i1 = blockIdx.x * 4 + threadIdx.x / 64;
+    const int fa = pair_a[p], fb = pair_b[p];
+    if (i1 >= min(counts[fa], cap)) return;
+    const se2gpu_keypoint kp1 = kps[(size_t)fa * cap + i1];
+    const int level1 = kp1.octave;
+    int n = 0;
+    if (!(level1 > max_level || level1 < min_level)) {
+        const int minLevel2 = level1 - level_offset > 0 ? level1 - level_offset : 0;
+        n = scan_candidates(bd, prev_xy[((size_t)p * cap + i1) * 2], prev_xy[((size_t)p * cap + i1) * 2 + 1], (float)win,
+                            minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + i1) * 32, kps + (size_t)fb * cap,
+                            desc + (size_t)fb * cap * 32, sorted + (size_t)fb * cap, n_grid[fb], nullptr,
+                            cand + ((size_t)p * cap + i1) * kMaxCand);
+    }
+    if ((threadIdx.x & 63) == 0) ncand[(size_t)p * cap + i1] = n;
+}
+
+// wave-uniform arg-min over the lanes with `valid`: smallest dist, then lowest lane.  Returns lane or -1.
+__device__ __forceinline__ int wave_argmin(bool valid, int dist) {
+    unsigned long long m = __ballot(valid);
+    if (m == 0) return -1;
+#pragma unroll
+    for (int b = 8; b >= 0; --b) {
+        const unsigned long long z = __ballot(valid && (((dist >> b) & 1) == 0)) & m;
+        if (z) m = z;
+    }
+    return __ffsll((long long)m) - 1;
+}
+
+struct Best2 {
+    int d1, p1, d2, p2;  // best (dist, position), second best; INT_MAX / -1 when absent
+};
+__device__ __forceinline__ void best2_push(Best2& b, int d, int p) {  // (d, p) ordering, p increasing across pushes
+    if (d < b.d1 || (d == b.d1 && p < b.p1)) {
+        b.d2 = b.d1; b.p2 = b.p1;
+        b.d1 = d; b.p1 = p;
+    } else if (d < b.d2 || (d == b.d2 && p < b.p2)) {
+        b.d2 = d; b.p2 = p;
+    }
+}
+
+// best / second best by (dist, list position) among the candidates of one query that pass `vMatchesDistance[idx] > dist`
+__device__ __forceinline__ Best2 resolve_query(const uint32_t* __restrict__ cl, int n, const int* vMatchesDistance) {
+    const int lane = threadIdx.x & 63;
+    Best2 b{INT_MAX, -1, INT_MAX, -1};
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int pos = c0 + lane;
+        bool valid = false;
+        int dist = 0;
+        if (pos < n) {
+            const uint32_t pk = cl[pos];
+            dist = (int)(pk & 0xfffu);
+            valid = !(vMatchesDistance[pk >> 12] <= dist);
+        }
+        const int l1 = wave_argmin(valid, dist);
+        if (l1 < 0) continue;
+        const int dd1 = __shfl(dist, l1);
+        const int l2 = wave_argmin(valid && lane != l1, dist);
+        best2_push(b, dd1, c0 + l1);
+        if (l2 >= 0) best2_push(b, __shfl(dist, l2), c0 + l2);
+    }
+    return b;
+}
+
+__device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    ind1 = ind2 = ind3 = -1;
+    for (int i = 0; i < kHisto; i++) {
+        const int s = hist[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+// MatchByWindow greedy pass (ORBmatcher.cpp:292-377), one wave per pair.  Dynamic LDS: vMatchesDistance[n2],
+// vnMatches21[n2], bin_of[n1].
+__global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __restrict__ kps,
+                                                        const int* __restrict__ counts, int cap,
+                                                        const int* __restrict__ pair_a, const int* __restrict__ pair_b,
+                                                        const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
+                                                        float nnratio, int* __restrict__ matches12,
+                                                        float* __restrict__ prev_xy, int* __restrict__ nmatches,
+                                                        int* __restrict__ overflow) {
+    extern __shared__ int lds[];
+    __shared__ int hist[kHisto];
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int fa = pair_a[p], fb = pair_b[p];
+    const int n1 = min(counts[fa], cap), n2 = min(counts[fb], cap);
+    int* vMatchesDistance = lds;
+    int* vnMatches21 = lds + cap;
+    int* bin_of = lds + 2 * cap;
+    int* m12 = matches12 + (size_t)p * cap;
+    for (int i = lane; i < n2; i += 64) { vMatchesDistance[i] = INT_MAX; vnMatches21[i] = -1; }
+    for (int i = lane; i < n1; i += 64) { bin_of[i] = -1; m12[i] = -1; }
+    if (lane < kHisto) hist[lane] = 0;
+    __syncthreads();
+    const se2gpu_keypoint* k1 = kps + (size_t)fa * cap;
+    const se2gpu_keypoint* k2 = kps + (size_t)fb * cap;
+    const float factor = (float)kHisto / 360.0f;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        int n = ncand[(size_t)p * cap + i1];
+        if (n == 0) continue;
+        if (n > kMaxCand) {
+            if (lane == 0) atomicOr(overflow, 1);
+            n = kMaxCand;
+        }
+        const uint32_t* cl = cand + ((size_t)p * cap + i1) * kMaxCand;
+        const Best2 b = resolve_query(cl, n, vMatchesDistance);
+        if (b.p1 >= 0 && b.d1 <= kThLow && (float)b.d1 < (float)b.d2 * nnratio) {
+            if (lane == 0) {
+                const int bestIdx2 = (int)(cl[b.p1] >> 12);
+                const int prev = vnMatches21[bestIdx2];
+                if (prev >= 0) m12[prev] = -1;
+                m12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchesDistance[bestIdx2] = b.d1;
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0f) rot += 360.f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == kHisto) bin = 0;
+                bin_of[i1] = bin;
+                hist[bin] += 1;
+            }
+        }
+        __syncthreads();
+    }
+    __shared__ int s_ind[3];
+    if (lane == 0) three_maxima(hist, s_ind[0], s_ind[1], s_ind[2]);
+    __syncthreads();
+    int cnt = 0;
+    for (int i = lane; i < n1; i += 64) {
+        const int bin = bin_of[i];
+        int m = m12[i];
+        if (bin >= 0 && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2] && m >= 0) {
+            m = -1;
+            m12[i] = -1;
+        }
+        if (m >= 0) {
+            ++cnt;
+            prev_xy[((size_t)p * cap + i) * 2] = k2[m].x;
+            prev_xy[((size_t)p * cap + i) * 2 + 1] = k2[m].y;
+        }
+    }
+    for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
+    if (lane == 0) nmatches[p] = cnt;
+}
+
+// prev_xy of pair p = key point positions of frame a (Track::resetLocalTrack, Track.cpp:194)
+__global__ void k_init_prev(const se2gpu_keypoint* __restrict__ kps, const int* __restrict__ counts, int cap,
+                            const int* __restrict__ pair_a, float* __restrict__ prev_xy) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int fa = pair_a[p];
+    if (i >= min(counts[fa], cap)) return;
+    prev_xy[((size_t)p * cap + i) * 2] = kps[(size_t)fa * cap + i].x;
+    prev_xy[((size_t)p * cap + i) * 2 + 1] = kps[(size_t)fa * cap + i].y;
+}
+
+// MatchByProjection candidates: query i = map point, projected with cvu::camprjc(K, cvu::se3map(Tcw, pos)).
+struct ProjCam {
+    float T[12];
+    float fx, fy, cx, cy;
+};
+__global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam, const float* __restrict__ mp_pos,
+                                                          const uint8_t* __restrict__ mp_desc,
+                                                          const int* __restrict__ mp_octave,
+                                                          const uint8_t* __restrict__ mp_skip, int m,
+                                                          const se2gpu_keypoint* __restrict__ kps,
+                                                          const uint8_t* __restrict__ desc,
+                                                          const uint8_t* __restrict__ kf_observed,
+                                                          const uint32_t* __restrict__ sorted,
+                                                          const int* __restrict__ n_grid, int win, int level_offset,
+                                                          uint32_t* __restrict__ cand, int* __restrict__ ncand) {
+    const int i = blockIdx.x * 4 + threadIdx.x / 64;
+    if (i >= m) return;
+    int n = 0;
+    if (!mp_skip[i]) {
+        const float X = mp_pos[3 * i], Y = mp_pos[3 * i + 1], Z = mp_pos[3 * i + 2];
+        float pc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            float s = 0;
+            s += cam.T[4 * r + 0] * X;
+            s += cam.T[4 * r + 1] * Y;
+            s += cam.T[4 * r + 2] * Z;
+            pc[r] = s + cam.T[4 * r + 3];
+        }
+        float u = 0, v = 0, w = 0;
+        u += cam.fx * pc[0]; u += 0.f * pc[1]; u += cam.cx * pc[2];
+        v += 0.f * pc[0]; v += cam.fy * pc[1]; v += cam.cy * pc[2];
+        w += 0.f * pc[0]; w += 0.f * pc[1]; w += 1.f * pc[2];
+        const float px = u / w, py = v / w;
+        if (px >= bd.min_x && px <= bd.max_x && py >= bd.min_y && py <= bd.max_y) {
+            const int predictLevel = mp_octave[i];
+            const int levelWinSize = predictLevel * win;
+            const int minLevel = predictLevel > level_offset ? predictLevel - level_offset : 0;
+            n = scan_candidates(bd, px, py, (float)levelWinSize, minLevel, predictLevel + level_offset,
+                                mp_desc + 32 * (size_t)i, kps, desc, sorted, n_grid[0], kf_observed,
+                                cand + (size_t)i * kMaxCand);
+        }
+    }
+    if ((threadIdx.x & 63) == 0) ncand[i] = n;
+}
+
+// MatchByProjection greedy pass (ORBmatcher.cpp:390-451), one wave.
+__global__ __launch_bounds__(64) void k_resolve_projection(const se2gpu_keypoint* __restrict__ kps, int n, int m,
+                                                            const uint32_t* __restrict__ cand,
+                                                            const int* __restrict__ ncand, float nnratio,
+                                                            int* __restrict__ match_idx, int* __restrict__ nmatches,
+                                                            int* __restrict__ overflow) {
+    extern __shared__ int lds[];
+    const int lane = threadIdx.x;
+    int* vMatchesDistance = lds;
+    for (int i = lane; i < n; i += 64) { vMatchesDistance[i] = INT_MAX; match_idx[i] = -1; }
+    __syncthreads();
+    for (int i = 0; i < m; ++i) {
+        int nc = ncand[i];
+        if (nc == 0) continue;
+        if (nc > kMaxCand) {
+            if (lane == 0) atomicOr(overflow, 1);
+            nc = kMaxCand;
+        }
+        const uint32_t* cl = cand + (size_t)i * kMaxCand;
+        const Best2 b = resolve_query(cl, nc, vMatchesDistance);
+        if (b.p1 >= 0 && b.d1 <= kThHigh) {
+            const int bestIdx = (int)(cl[b.p1] >> 12);
+            const int bestLevel = kps[bestIdx].octave;
+            const int bestLevel2 = b.p2 >= 0 ? kps[cl[b.p2] >> 12].octave : -1;
+            const bool reject = bestLevel == bestLevel2 && (float)b.d1 > nnratio * (float)b.d2;
+            if (!reject && lane == 0) {
+                match_idx[bestIdx] = i;
+                vMatchesDistance[bestIdx] = b.d1;
+            }
+        }
+        __syncthreads();
+    }
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) cnt += match_idx[i] >= 0;
+    for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
+    if (lane == 0) nmatches[0] = cnt;
+}
+
+Bounds make_bounds(const se2gpu_frame_bounds& b) {
+    Bounds o;
+    o.min_x = b.min_x; o.min_y = b.min_y; o.max_x = b.max_x; o.max_y = b.max_y;
+    o.wInv = (float)kGridCols / (b.max_x - b.min_x);   // Frame.cpp:40-41
+    o.hInv = (float)kGridRows / (b.max_y - b.min_y);
+    return o;
+}
+
+}  // namespace
+
+struct se2gpu_matcher {
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int max_features = 0, max_batch = 1;
+    // scratch for frame sets of up to `nframes_cap` frames with stride `cap_cur`
+    DevBuf<uint32_t> sorted, cand;
+    DevBuf<int> n_grid, ncand, overflow, pair_a, pair_b, counts, matches, nmatches, mp_octave;
+    DevBuf<float> prev, mp_pos;
+    DevBuf<se2gpu_keypoint> kps;
+    DevBuf<uint8_t> desc, mp_desc, mp_skip, kf_obs;
+    ~se2gpu_matcher() {
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+};
+
+namespace {
+
+int check_overflow(se2gpu_matcher* h) {
+    int ov = 0;
+    SE2_HIP(hipMemcpyAsync(&ov, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    if (ov) {
+        SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
+        set_error("matcher: more than %d candidates in one search window", kMaxCand);
+        return SE2GPU_ERR_CAPACITY;
+    }
+    return SE2GPU_OK;
+}
+
+// MatchByWindow over `npairs` pairs of frames of a device-resident frame set
+int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_kps, const uint8_t* d_desc,
+                 const int32_t* d_counts, int cap, int nframes_hint, const int32_t* d_pair_a, const int32_t* d_pair_b,
+                 int npairs, int win, int level_offset, int min_level, int max_level, float nnratio, float* d_prev,
+                 bool init_prev, int32_t* d_matches12, int32_t* d_nmatches) {
+    hipStream_t st = h->stream;
+    SE2_REQUIRE(cap <= kMaxFeat && cap <= 65536, SE2GPU_ERR_CAPACITY, "cap %d exceeds the matcher limit %d", cap, kMaxFeat);
+    // grid order of every frame that appears as a target (all frames < nframes_hint: cheap)
+    SE2_CHECK(h->sorted.reserve((size_t)nframes_hint * cap));
+    SE2_CHECK(h->n_grid.reserve((size_t)nframes_hint));
+    SE2_CHECK(h->cand.reserve((size_t)npairs * cap * kMaxCand));
+    SE2_CHECK(h->ncand.reserve((size_t)npairs * cap));
+    hipLaunchKernelGGL(k_grid_order, dim3(nframes_hint), dim3(256), 0, st, bd, d_kps, d_counts, (const int*)nullptr, cap,
+                       h->sorted.p, h->n_grid.p);
+    if (init_prev)
+        hipLaunchKernelGGL(k_init_prev, dim3((cap + 255) / 256, npairs), dim3(256), 0, st, d_kps, d_counts, cap, d_pair_a,
+                           d_prev);
+    hipLaunchKernelGGL(k_cand_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, st, bd, d_kps, d_desc, d_counts, cap,
+                       d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win, level_offset, min_level, max_level,
+                       h->cand.p, h->ncand.p);
+    const size_t lds = (size_t)3 * cap * sizeof(int);
+    SE2_REQUIRE(lds <= 64 * 1024, SE2GPU_ERR_CAPACITY, "cap %d needs %zu B of LDS in the resolve pass (limit 64 KiB)", cap, lds);
+    hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(64), lds, st, d_kps, d_counts, cap, d_pair_a, d_pair_b,
+                       h->cand.p, h->ncand.p, nnratio, d_matches12, d_prev, d_nmatches, h->overflow.p);
+    SE2_HIP(hipGetLastError());
+    return SE2GPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out) {
+    SE2_REQUIRE(out, SE2GPU_ERR_INVALID, "matcher_create: out is NULL");
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
+    SE2_REQUIRE(max_features > 0 && max_features <= kMaxFeat, SE2GPU_ERR_INVALID, "max_features must be in 1..%d", kMaxFeat);
+    se2gpu_matcher* h = new se2gpu_matcher;
+    h->max_features = max_features;
+    h->max_batch = std::max(1, max_batch);
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        set_error("hipStreamCreate failed");
+        return SE2GPU_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+    if (h->overflow.reserve(1) != SE2GPU_OK || hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream) != hipSuccess) {
+        delete h;
+        return SE2GPU_ERR_HIP;
+    }
+    *out = h;
+    return SE2GPU_OK;
+}
+
+void se2gpu_matcher_destroy(se2gpu_matcher* h) { delete h; }
+void* se2gpu_matcher_stream(se2gpu_matcher* h) { return h ? (void*)h->stream : nullptr; }
+
+int se2gpu_matcher_set_stream(se2gpu_matcher* h, void* s) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "matcher handle is NULL");
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return SE2GPU_OK;
+}
+
+int se2gpu_matcher_sync(se2gpu_matcher* h) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "matcher handle is NULL");
+    return check_overflow(h);
+}
+
+int se2gpu_match_window_batch_device(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds,
+                                     const se2gpu_keypoint* d_kps, const uint8_t* d_desc, const int32_t* d_counts,
+                                     int cap, const int32_t* d_pair_a, const int32_t* d_pair_b, int npairs, int win_size,
+                                     int level_offset, int min_level, int max_level, float nnratio,
+                                     int32_t* d_matches12, int32_t* d_nmatches) {
+    SE2_REQUIRE(h && bounds && d_kps && d_desc && d_counts && d_pair_a && d_pair_b && d_matches12 && d_nmatches,
+                SE2GPU_ERR_INVALID, "match_window_batch: NULL argument");
+    SE2_REQUIRE(npairs >= 1 && cap >= 1, SE2GPU_ERR_INVALID, "match_window_batch: bad sizes");
+    // frames referenced by the pairs are 0..max_batch-1 of the extractor's output arrays
+    const int nframes = h->max_batch;
+    SE2_CHECK(h->prev.reserve((size_t)npairs * cap * 2));
+    return window_batch(h, make_bounds(*bounds), d_kps, d_desc, d_counts, cap, nframes, d_pair_a, d_pair_b, npairs,
+                        win_size, level_offset, min_level, max_level, nnratio, h->prev.p, true, d_matches12, d_nmatches);
+}
+
+int se2gpu_match_window(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds, const se2gpu_keypoint* kps1,
+                        const uint8_t* desc1, int n1, const se2gpu_keypoint* kps2, const uint8_t* desc2, int n2,
+                        float* prev_xy, int win_size, int level_offset, int min_level, int max_level, float nnratio,
+                        int32_t* matches12, int* n_matches) {
+    SE2_REQUIRE(h && bounds && n_matches, SE2GPU_ERR_INVALID, "match_window: NULL argument");
+    SE2_REQUIRE(n1 >= 0 && n2 >= 0 && n1 <= h->max_features && n2 <= h->max_features, SE2GPU_ERR_CAPACITY,
+                "match_window: %d / %d features exceed max_features %d", n1, n2, h->max_features);
+    *n_matches = 0;
+    if (n1 == 0) return SE2GPU_OK;
+    SE2_REQUIRE(kps1 && desc1 && prev_xy && matches12 && (n2 == 0 || (kps2 && desc2)), SE2GPU_ERR_INVALID,
+                "match_window: NULL buffer");
+    hipStream_t st = h->stream;
+    const int cap = std::max(std::max(n1, n2), 1);
+    SE2_CHECK(h->kps.reserve(2 * (size_t)cap));
+    SE2_CHECK(h->desc.reserve(2 * (size_t)cap * 32));
+    SE2_CHECK(h->counts.reserve(2));
+    SE2_CHECK(h->pair_a.reserve(1));
+    SE2_CHECK(h->pair_b.reserve(1));
+    SE2_CHECK(h->prev.reserve((size_t)cap * 2));
+    SE2_CHECK(h->matches.reserve((size_t)cap));
+    SE2_CHECK(h->nmatches.reserve(1));
+    const int cnt[2] = {n1, n2}, pa = 0, pb = 1;
+    SE2_HIP(hipMemcpyAsync(h->kps.p, kps1, (size_t)n1 * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
+    if (n2) {
+        SE2_HIP(hipMemcpyAsync(h->kps.p + cap, kps2, (size_t)n2 * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
+        SE2_HIP(hipMemcpyAsync(h->desc.p + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+    }
+    SE2_HIP(hipMemcpyAsync(h->counts.p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->pair_a.p, &pa, sizeof(int), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->pair_b.p, &pb, sizeof(int), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->prev.p, prev_xy, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice, st));
+    SE2_CHECK(window_batch(h, make_bounds(*bounds), h->kps.p, h->desc.p, h->counts.p, cap, 2, h->pair_a.p, h->pair_b.p, 1,
+                           win_size, level_offset, min_level, max_level, nnratio, h->prev.p, false, h->matches.p,
+                           h->nmatches.p));
+    SE2_HIP(hipMemcpyAsync(matches12, h->matches.p, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipMemcpyAsync(prev_xy, h->prev.p, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    return check_overflow(h);
+}
+
+int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds, const float* mp_pos,
+                            const uint8_t* mp_desc, const int32_t* mp_octave, const uint8_t* mp_skip, int m,
+                            const float* Tcw, float fx, float fy, float cx, float cy, const se2gpu_keypoint* kps,
+                            const uint8_t* desc, const uint8_t* kf_observed, int n, int win_size, int level_offset,
+                            float nnratio, int32_t* match_idx_mp, int* n_matches) {
+    SE2_REQUIRE(h && bounds && n_matches && Tcw, SE2GPU_ERR_INVALID, "match_projection: NULL argument");
+    SE2_REQUIRE(n >= 0 && n <= h->max_features && m >= 0, SE2GPU_ERR_CAPACITY, "match_projection: %d features exceed %d", n,
+                h->max_features);
+    *n_matches = 0;
+    if (n == 0) return SE2GPU_OK;
+    SE2_REQUIRE(kps && desc && kf_observed && match_idx_mp && (m == 0 || (mp_pos && mp_desc && mp_octave && mp_skip)),
+                SE2GPU_ERR_INVALID, "match_projection: NULL buffer");
+    hipStream_t st = h->stream;
+    const int mm = std::max(m, 1);
+    SE2_CHECK(h->kps.reserve((size_t)n));
+    SE2_CHECK(h->desc.reserve((size_t)n * 32));
+    SE2_CHECK(h->kf_obs.reserve((size_t)n));
+    SE2_CHECK(h->counts.reserve(2));
+    SE2_CHECK(h->mp_pos.reserve(3 * (size_t)mm));
+    SE2_CHECK(h->mp_desc.reserve(32 * (size_t)mm));
+    SE2_CHECK(h->mp_octave.reserve((size_t)mm));
+    SE2_CHECK(h->mp_skip.reserve((size_t)mm));
+    SE2_CHECK(h->sorted.reserve((size_t)n));
+    SE2_CHECK(h->n_grid.reserve(1));
+    SE2_CHECK(h->cand.reserve((size_t)mm * kMaxCand));
+    SE2_CHECK(h->ncand.reserve((size_t)mm));
+    SE2_CHECK(h->matches.reserve((size_t)n));
+    SE2_CHECK(h->nmatches.reserve(1));
+    SE2_HIP(hipMemcpyAsync(h->kps.p, kps, (size_t)n * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->kf_obs.p, kf_observed, (size_t)n, hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->counts.p, &n, sizeof(int), hipMemcpyHostToDevice, st));
+    if (m) {
+        SE2_HIP(hipMemcpyAsync(h->mp_pos.p, mp_pos, 3 * (size_t)m * sizeof(float), hipMemcpyHostToDevice, st));
+        SE2_HIP(hipMemcpyAsync(h->mp_desc.p, mp_desc, 32 * (size_t)m, hipMemcpyHostToDevice, st));
+        SE2_HIP(hipMemcpyAsync(h->mp_octave.p, mp_octave, (size_t)m * sizeof(int), hipMemcpyHostToDevice, st));
+        SE2_HIP(hipMemcpyAsync(h->mp_skip.p, mp_skip, (size_t)m, hipMemcpyHostToDevice, st));
+    }
+    const Bounds bd = make_bounds(*bounds);
+    ProjCam cam;
+    std::memcpy(cam.T, Tcw, sizeof(cam.T));
+    cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy;
+    hipLaunchKernelGGL(k_grid_order, dim3(1), dim3(256), 0, st, bd, h->kps.p, h->counts.p, (const int*)nullptr, n,
+                       h->sorted.p, h->n_grid.p);
+    if (m)
+        hipLaunchKernelGGL(k_cand_projection, dim3((m + 3) / 4), dim3(256), 0, st, bd, cam, h->mp_pos.p, h->mp_desc.p,
+                           h->mp_octave.p, h->mp_skip.p, m, h->kps.p, h->desc.p, h->kf_obs.p, h->sorted.p, h->n_grid.p,
+                           win_size, level_offset, h->cand.p, h->ncand.p);
+    hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(64), (size_t)n * sizeof(int), st, h->kps.p, n, m, h->cand.p,
+                       h->ncand.p, nnratio, h->matches.p, h->nmatches.p, h->overflow.p);
+    SE2_HIP(hipGetLastError());
+    SE2_HIP(hipMemcpyAsync(match_idx_mp, h->matches.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    return check_overflow(h);
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""Python mirror of se2lam::ORBmatcher over the C ABI (harness view; C++ twin: include/se2lam_amd/ORBmatcher.h).
+
+Reference interface: /root/reference/include/se2lam/ORBmatcher.h:46-77
+    ORBmatcher(nnratio=0.6, checkOri=true)
+    static DescriptorDistance(a, b)
+    MatchByWindow(frame1, frame2, vbPrevMatched, winSize, vnMatches12, levelOffset=1, minLevel=0, maxLevel=8)
+    MatchByProjection(pNewKF, localMPs, winSize, levelOffset, vMatchesIdxMP)
+A "frame" here is the POD content the matchers read: key points (cv::KeyPoint layout), descriptors and the
+image bounds that define the 64x48 grid (Frame.cpp:37-44).  All compute happens in libse2gpu.so (HIP).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 75, 30
+
+
+def bounds(cols=640, rows=480):
+    return capi.FrameBounds(0.0, 0.0, float(cols), float(rows))
+
+
+class ORBmatcher:
+    def __init__(self, nnratio=0.6, checkOri=True, max_features=4096, max_batch=1):
+        assert checkOri, "the reference always checks orientation in MatchByWindow (ORBmatcher.cpp:350-372)"
+        self.mfNNratio = float(nnratio)
+        self._h = C.c_void_p()
+        capi.check(capi.lib().se2gpu_matcher_create(max_features, max_batch, C.byref(self._h)))
+
+    @staticmethod
+    def DescriptorDistance(a, b) -> int:
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+        return int(capi.lib().se2gpu_hamming(a.ctypes.data, b.ctypes.data))
+
+    def MatchByWindow(self, kps1, desc1, kps2, desc2, vbPrevMatched, winSize, levelOffset=1, minLevel=0, maxLevel=8,
+                      frame_bounds=None):
+        """-> (nmatches, vnMatches12); vbPrevMatched (n1,2) float32 is updated in place."""
+        fb = frame_bounds or bounds()
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags.c_contiguous
+        n1, n2 = len(kps1), len(kps2)
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        nm = C.c_int(0)
+        capi.check(capi.lib().se2gpu_match_window(self._h, C.byref(fb), kps1.ctypes.data, desc1.ctypes.data, n1,
+                                                  kps2.ctypes.data, desc2.ctypes.data, n2, vbPrevMatched.ctypes.data,
+                                                  winSize, levelOffset, minLevel, maxLevel, self.mfNNratio,
+                                                  m12.ctypes.data, C.byref(nm)))
+        return nm.value, m12[:n1].copy()
+
+    def MatchByProjection(self, mp_pos, mp_desc, mp_octave, mp_skip, Tcw, K4, kps, desc, kf_observed, winSize,
+                          levelOffset, frame_bounds=None):
+        """-> (nmatches, vMatchesIdxMP).  mp_skip[i]=1: the reference skips the map point (null / bad parallax /
+        already observed, ORBmatcher.cpp:392-395); kf_observed[idx]=1: hasObservation(idx) (:417)."""
+        fb = frame_bounds or bounds()
+        mp_pos = np.ascontiguousarray(mp_pos, np.float32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+        mp_octave = np.ascontiguousarray(mp_octave, np.int32); mp_skip = np.ascontiguousarray(mp_skip, np.uint8)
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy()
+        kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+        kf_observed = np.ascontiguousarray(kf_observed, np.uint8)
+        n, m = len(kps), len(mp_octave)
+        out = np.full(max(n, 1), -1, np.int32)
+        nm = C.c_int(0)
+        fx, fy, cx, cy = [float(v) for v in K4]
+        capi.check(capi.lib().se2gpu_match_projection(self._h, C.byref(fb), mp_pos.ctypes.data, mp_desc.ctypes.data,
+                                                      mp_octave.ctypes.data, mp_skip.ctypes.data, m, Tcw.ctypes.data,
+                                                      fx, fy, cx, cy, kps.ctypes.data, desc.ctypes.data,
+                                                      kf_observed.ctypes.data, n, winSize, levelOffset, self.mfNNratio,
+                                                      out.ctypes.data, C.byref(nm)))
+        return nm.value, out[:n].copy()
+
+    # -- batched, device resident -----------------------------------------------------------
+    def match_window_batch_device(self, d_kps, d_desc, d_counts, cap, d_pair_a, d_pair_b, npairs, winSize,
+                                  d_matches12, d_nmatches, levelOffset=1, minLevel=0, maxLevel=8, frame_bounds=None):
+        fb = frame_bounds or bounds()
+        capi.check(capi.lib().se2gpu_match_window_batch_device(self._h, C.byref(fb), d_kps, d_desc, d_counts, cap,
+                                                               d_pair_a, d_pair_b, npairs, winSize, levelOffset,
+                                                               minLevel, maxLevel, self.mfNNratio, d_matches12,
+                                                               d_nmatches))
+
+    def sync(self):
+        capi.check(capi.lib().se2gpu_matcher_sync(self._h))
+
+    def stream(self):
+        return capi.lib().se2gpu_matcher_stream(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                capi.lib().se2gpu_matcher_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -1,0 +1,155 @@
+"""GPU parity tests of the HIP matchers (through the C ABI) against the CPU oracle: match lists,
+match counts and the updated vbPrevMatched are compared EXACTLY."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def feats(oracle, synth):
+    return [oracle.orb_extract(synth.frame(t)) for t in range(6)]
+
+
+@pytest.fixture(scope="module")
+def matcher():
+    from se2lam_amd.matcher import ORBmatcher
+    return ORBmatcher(0.9)
+
+
+def _prev(k):
+    return np.ascontiguousarray(np.stack([k["x"], k["y"]], 1), np.float32)
+
+
+@pytest.mark.parametrize("a,b", [(0, 1), (1, 2), (2, 3), (0, 5), (3, 3)])
+def test_match_by_window_exact(matcher, oracle, feats, a, b):
+    """Track::mTrack call (Track.cpp:131-132): ORBmatcher(0.9).MatchByWindow(ref, cur, prev, 20, ...)"""
+    (k1, d1), (k2, d2) = feats[a], feats[b]
+    prev = _prev(k1)
+    nm, m12 = matcher.MatchByWindow(k1, d1, k2, d2, prev, 20)
+    m_ref, nm_ref, prev_ref = oracle.match_window(k1, d1, k2, d2)
+    assert nm == nm_ref and nm > 100
+    assert np.array_equal(m12, m_ref)
+    assert np.array_equal(prev, prev_ref)
+
+
+def test_match_by_window_parameters_and_chained_prev(matcher, oracle, feats):
+    from se2lam_amd.matcher import ORBmatcher
+    (k1, d1), (k2, d2), (k3, d3) = feats[0], feats[1], feats[2]
+    # vbPrevMatched carried over between calls (Track keeps mPrevMatched across frames)
+    prev = _prev(k1)
+    matcher.MatchByWindow(k1, d1, k2, d2, prev, 20)
+    nm, m12 = matcher.MatchByWindow(k1, d1, k3, d3, prev, 20)
+    _, _, p_ref = oracle.match_window(k1, d1, k2, d2)
+    m_ref, nm_ref, p_ref2 = oracle.match_window(k1, d1, k3, d3, prev_xy=p_ref)
+    assert nm == nm_ref and np.array_equal(m12, m_ref) and np.array_equal(prev, p_ref2)
+    # other window / level / ratio parameters
+    for (win, lo, mn, mx, ratio) in ((8, 1, 0, 8, 0.9), (40, 2, 1, 5, 0.7), (20, 0, 0, 3, 0.6)):
+        mt = ORBmatcher(ratio)
+        prev = _prev(k1)
+        nm, m12 = mt.MatchByWindow(k1, d1, k2, d2, prev, win, lo, mn, mx)
+        m_ref, nm_ref, p_ref = oracle.match_window(k1, d1, k2, d2, None, win, lo, mn, mx, ratio)
+        assert nm == nm_ref and np.array_equal(m12, m_ref) and np.array_equal(prev, p_ref), (win, lo, mn, mx, ratio)
+
+
+def test_match_by_window_edge_cases(matcher, oracle, feats):
+    (k1, d1), (k2, d2) = feats[0], feats[1]
+    e_k = k1[:0]; e_d = d1[:0]
+    nm, m12 = matcher.MatchByWindow(k1, d1, e_k, e_d, _prev(k1), 20)          # empty target frame
+    assert nm == 0 and (m12 == -1).all()
+    nm, m12 = matcher.MatchByWindow(e_k, e_d, k2, d2, np.zeros((0, 2), np.float32), 20)  # empty query frame
+    assert nm == 0 and len(m12) == 0
+    # duplicated descriptors / collisions: many queries compete for the same targets (eviction path)
+    kk = np.concatenate([k1[:200], k1[:200]]); dd = np.concatenate([d1[:200], d1[:200]])
+    prev = _prev(kk)
+    nm, m12 = matcher.MatchByWindow(kk, dd, k1, d1, prev, 20)
+    m_ref, nm_ref, p_ref = oracle.match_window(kk, dd, k1, d1)
+    assert nm == nm_ref and np.array_equal(m12, m_ref) and np.array_equal(prev, p_ref)
+    # ragged sizes
+    nm, m12 = matcher.MatchByWindow(k1[:37], d1[:37], k2[:911], d2[:911], _prev(k1[:37]), 20)
+    m_ref, nm_ref, _ = oracle.match_window(k1[:37], d1[:37], k2[:911], d2[:911])
+    assert nm == nm_ref and np.array_equal(m12, m_ref)
+
+
+def _projection_case(oracle, feats, seed):
+    """Synthetic LocalMapper::findCorrespd input: map points back-projected from frame-0 key points at random
+    depths in a camera frame, seen from a slightly moved key frame (features of frame 1)."""
+    rng = np.random.default_rng(seed)
+    (k0, d0), (k1, d1) = feats[0], feats[1]
+    fx = fy = 400.0; cx, cy = 320.0, 240.0
+    m = 1500
+    src = rng.integers(0, len(k0), m)
+    depth = rng.uniform(800, 6000, m).astype(np.float32)
+    Xc = np.stack([(k0["x"][src] - cx) / fx * depth, (k0["y"][src] - cy) / fy * depth, depth], 1).astype(np.float32)
+    th = 0.01
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    t = np.array([15.0, -4.0, 8.0], np.float32)
+    Tcw = np.concatenate([R, t[:, None]], 1).astype(np.float32)          # 3x4
+    mp_pos = ((Xc - t) @ R).astype(np.float32)                           # world = R^T (Xc - t)
+    mp_desc = d0[src].copy()
+    flip = rng.integers(0, 256, (m, 32)).astype(np.uint8) & (rng.random((m, 32)) < 0.03).astype(np.uint8) * 255
+    mp_desc ^= flip.astype(np.uint8)
+    mp_octave = k0["octave"][src].astype(np.int32)
+    mp_skip = (rng.random(m) < 0.1).astype(np.uint8)
+    kf_obs = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    return mp_pos, mp_desc, mp_octave, mp_skip, Tcw, (fx, fy, cx, cy), k1, d1, kf_obs
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_match_by_projection_exact(oracle, feats, seed):
+    """LocalMapper::findCorrespd call (LocalMapper.cpp:117-118): ORBmatcher().MatchByProjection(newKF, localMPs, 15, 2, ..)"""
+    from se2lam_amd.matcher import ORBmatcher
+    args = _projection_case(oracle, feats, seed)
+    mt = ORBmatcher()  # nnratio 0.6
+    nm, idx = mt.MatchByProjection(*args, 15, 2)
+    idx_ref, nm_ref = oracle.match_projection(*args, 15, 2, 0.6)
+    assert nm == nm_ref and nm > 50
+    assert np.array_equal(idx, idx_ref)
+
+
+def test_match_by_projection_edge_cases(oracle, feats):
+    from se2lam_amd.matcher import ORBmatcher
+    args = list(_projection_case(oracle, feats, 7))
+    mt = ORBmatcher()
+    # all map points skipped
+    a = list(args); a[3] = np.ones_like(args[3])
+    nm, idx = mt.MatchByProjection(*a, 15, 2)
+    assert nm == 0 and (idx == -1).all()
+    # no map points at all
+    a = list(args); a[0] = args[0][:0]; a[1] = args[1][:0]; a[2] = args[2][:0]; a[3] = args[3][:0]
+    nm, idx = mt.MatchByProjection(*a, 15, 2)
+    assert nm == 0 and (idx == -1).all()
+    # everything already observed in the key frame
+    a = list(args); a[8] = np.ones_like(args[8])
+    nm, idx = mt.MatchByProjection(*a, 15, 2)
+    assert nm == 0
+    # points behind the camera / outside the image are rejected by inImgBound
+    a = list(args); p = args[0].copy(); p[:, 2] -= 1e5; a[0] = p
+    nm, idx = mt.MatchByProjection(*a, 15, 2)
+    idx_ref, nm_ref = oracle.match_projection(*a, 15, 2, 0.6)
+    assert nm == nm_ref and np.array_equal(idx, idx_ref)
+
+
+def test_batched_extract_and_match_device_resident(oracle, synth):
+    """The throughput path of bench.py: frames stay in HBM from the extractor to the matcher."""
+    from se2lam_amd import capi
+    from se2lam_amd.matcher import ORBmatcher
+    from se2lam_amd.orb import ORBextractor, KP_DTYPE
+    B, cap = 6, 1024
+    imgs = synth.frames(B)
+    ex = ORBextractor(max_batch=B)
+    mt = ORBmatcher(0.9, max_features=cap, max_batch=B)
+    d_img = capi.DeviceArray.from_numpy(imgs)
+    d_kps = capi.DeviceArray(B * cap * 28); d_desc = capi.DeviceArray(B * cap * 32); d_cnt = capi.DeviceArray(B * 4)
+    ex.extract_batch_device(d_img.ptr, B, 480, 640, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap)
+    ex.sync()
+    pa = np.arange(B - 1, dtype=np.int32); pb = pa + 1
+    d_pa = capi.DeviceArray.from_numpy(pa); d_pb = capi.DeviceArray.from_numpy(pb)
+    d_m = capi.DeviceArray((B - 1) * cap * 4); d_nm = capi.DeviceArray((B - 1) * 4)
+    mt.match_window_batch_device(d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap, d_pa.ptr, d_pb.ptr, B - 1, 20, d_m.ptr, d_nm.ptr)
+    mt.sync()
+    m = d_m.to_numpy(np.int32, (B - 1, cap)); nm = d_nm.to_numpy(np.int32, (B - 1,))
+    for p in range(B - 1):
+        k1, d1 = oracle.orb_extract(imgs[p]); k2, d2 = oracle.orb_extract(imgs[p + 1])
+        m_ref, nm_ref, _ = oracle.match_window(k1, d1, k2, d2)
+        assert nm[p] == nm_ref and np.array_equal(m[p, :len(k1)], m_ref)
