@@ -1,0 +1,100 @@
+"""ORB leg of bench.py: batched extract + MatchByWindow on frames resident in HBM.
+
+A "step" is one batch of B synthetic 640x480 frames through the extractor (8 levels, 1000 features) and the
+window matcher (frame t vs t+1 inside the batch, B pairs with wrap-around), i.e. B frames of extract+match.
+N>1 ranks: frame-parallel replicas, no collective - weak scaling.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from . import capi, synth
+from .matcher import ORBmatcher
+from .orb import ORBextractor
+
+HBM_PEAK_GBS = 8000.0
+B_ORB = 5_742_474      # algorithmic bytes per frame, SURVEY.md §8(d)
+B_MATCH = 132_000      # algorithmic bytes per frame pair
+
+
+def run(rank, world, batch, steps, sync_all, dist, torch, cpu_baseline=False, warmup=2, cap=1024):
+    B = batch
+    imgs = synth.frames(B, start=1000 * rank)
+    ex = ORBextractor(max_batch=B)
+    mt = ORBmatcher(0.9, max_features=cap, max_batch=B)
+    d_img = capi.DeviceArray.from_numpy(imgs)
+    d_kps = capi.DeviceArray(B * cap * 28)
+    d_desc = capi.DeviceArray(B * cap * 32)
+    d_cnt = capi.DeviceArray(B * 4)
+    pa = np.arange(B, dtype=np.int32)
+    pb = (pa + 1) % B
+    d_pa = capi.DeviceArray.from_numpy(pa)
+    d_pb = capi.DeviceArray.from_numpy(pb)
+    d_m = capi.DeviceArray(B * cap * 4)
+    d_nm = capi.DeviceArray(B * 4)
+
+    def step():
+        ex.extract_batch_device(d_img.ptr, B, 480, 640, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap)
+        ex.sync()   # the matcher runs on its own stream: order the two handles
+        mt.match_window_batch_device(d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap, d_pa.ptr, d_pb.ptr, B, 20, d_m.ptr, d_nm.ptr)
+        mt.sync()
+
+    for _ in range(warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fps = world * B * steps / dt
+    cnt = d_cnt.to_numpy(np.int32, (B,))
+    nm = d_nm.to_numpy(np.int32, (B,))
+
+    # per-kernel durations (HIP events around every extractor launch, separate pass)
+    ex.profile(True)
+    for _ in range(min(steps, 5)):
+        ex.extract_batch_device(d_img.ptr, B, 480, 640, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap)
+        ex.sync()
+    prof = ex.profile_report()
+    ex.profile(False)
+    kern = {k: {"avg_us": 1e3 * ms / max(n, 1), "launches": n, "total_ms": ms} for k, (ms, n) in prof.items()}
+    dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
+    roof = None
+    if dom:
+        # one launch of an extractor kernel processes the B frames of the batch (k_resize: one of 7 launches)
+        per_launch_frames = B * (1.0 / 7.0 if dom == "k_resize" else 1.0)
+        ach = B_ORB * per_launch_frames / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": B_ORB * per_launch_frames,
+                "avg_launch_us": kern[dom]["avg_us"],
+                "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,
+                "whole_step_frac": (B_ORB + B_MATCH) * fps / world / 1e9 / HBM_PEAK_GBS,
+                "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()}}
+    cpu = None
+    if cpu_baseline:
+        from oracle import oracle
+        t1 = time.perf_counter()
+        nfr = 0
+        prev = oracle.orb_extract(imgs[0])
+        while time.perf_counter() - t1 < 10.0 and nfr < B - 1:
+            cur = oracle.orb_extract(imgs[nfr + 1])
+            oracle.match_window(prev[0], prev[1], cur[0], cur[1])
+            prev = cur
+            nfr += 1
+        cdt = time.perf_counter() - t1
+        cpu = {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + oracle/match_ref.cpp "
+                         f"MatchByWindow, 1 thread"}
+    return {"metric": "ORB extract+match frames/s @640x480", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "batch": B, "steps": steps, "ms_per_batch": 1e3 * dt / steps, "scaling": "weak",
+            "config": {"workload": "640x480 u8, 8-level pyramid, 1000 features/frame, MatchByWindow(win 20, ratio 0.9), "
+                                   "frames t vs t+1", "features_per_frame": float(cnt.mean()),
+                       "matches_per_pair": float(nm.mean())},
+            "roofline": roof, "cpu_baseline": cpu}
