@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--landmarks", type=int, default=20000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
-    ap.add_argument("--orb-batch", type=int, default=64)
+    ap.add_argument("--orb-batch", type=int, default=256)
     ap.add_argument("--orb-steps", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -158,10 +158,11 @@ def main():
     if not args.no_orb:
         try:
             from se2lam_amd import orb_bench
-            orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch,
-                                    cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+            orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch)
         except ImportError:
             orb_obj = None
+        if orb_obj is not None and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            orb_obj["cpu_baseline"] = _orb_cpu_baseline(synth, args.orb_batch)
 
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores ----------------
     cpu = None
@@ -197,6 +198,24 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _orb_cpu_baseline(synth, nframes, seconds=10.0):
+    """oracle extract + MatchByWindow on a bounded sample of the same synthetic sequence, 1 thread"""
+    from oracle import oracle
+    imgs = synth.frames(min(nframes, 64))
+    t1 = time.perf_counter()
+    nfr = 0
+    prev = oracle.orb_extract(imgs[0])
+    while time.perf_counter() - t1 < seconds and nfr < len(imgs) - 1:
+        cur = oracle.orb_extract(imgs[nfr + 1])
+        oracle.match_window(prev[0], prev[1], cur[0], cur[1])
+        prev = cur
+        nfr += 1
+    cdt = time.perf_counter() - t1
+    return {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
+                      f"oracle/match_ref.cpp MatchByWindow, 1 thread", "host": _host_desc()}
 
 
 def _host_desc():

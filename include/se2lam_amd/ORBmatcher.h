@@ -1,0 +1,80 @@
+// Drop-in mirror of se2lam::ORBmatcher (/root/reference/include/se2lam/ORBmatcher.h:42-80) over libse2gpu.
+//   ORBmatcher(nnratio=0.6, checkOri=true)                                                        (:46)
+//   static int DescriptorDistance(a, b)                                                           (:49)
+//   int MatchByWindow(frame1, frame2, vbPrevMatched, winSize, vnMatches12, levelOffset=1, minLevel=0, maxLevel=8) (:68-71)
+//   int MatchByProjection(pNewKF, localMPs, winSize, levelOffset, vMatchesIdxMP)                  (:73-74)
+// Frame / KeyFrame / MapPoint are pointer-graph classes of the reference's data model (out of scope); the adapters
+// take the POD content the matchers actually read from them (FrameView / MapPointView below) - INTEGRATION.md shows
+// the three-line glue that fills the views from the reference's classes.
+#pragma once
+#include "types.h"
+
+namespace se2lam_amd {
+
+struct FrameView {                       // what MatchByWindow / MatchByProjection read from a (Key)Frame
+    const KeyPoint* keyPointsUn = nullptr;   // Frame::keyPointsUn
+    const uint8_t* descriptors = nullptr;    // Frame::descriptors (N x 32, CV_8U, continuous)
+    int N = 0;
+    float minXUn = 0, minYUn = 0, maxXUn = 640, maxYUn = 480;  // Frame::minXUn.. (Frame.cpp:183-200)
+    const uint8_t* observed = nullptr;       // KeyFrame::hasObservation(idx) per feature (MatchByProjection only)
+    const float* Tcw = nullptr;              // KeyFrame::Tcw rows 0..2 (3x4 row-major float)
+};
+
+struct MapPointView {                    // what MatchByProjection reads from localMPs[i]
+    const float* pos = nullptr;              // M x 3, MapPoint::getPos()
+    const uint8_t* mainDescriptor = nullptr; // M x 32, MapPoint::mMainDescriptor
+    const int32_t* mainOctave = nullptr;     // M, MapPoint::mMainOctave
+    const uint8_t* skip = nullptr;           // M, 1 = isNull() || !isGoodPrl() || pNewKF->hasObservation(pMP)
+    int M = 0;
+};
+
+class ORBmatcher {
+public:
+    static const int TH_HIGH = 100, TH_LOW = 75, HISTO_LENGTH = 30;   // ORBmatcher.cpp:45-47
+
+    explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int maxFeatures = 4096)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
+        check(se2gpu_matcher_create(maxFeatures, 1, &h_), "ORBmatcher");
+    }
+    ~ORBmatcher() { se2gpu_matcher_destroy(h_); }
+    ORBmatcher(const ORBmatcher&) = delete;
+    ORBmatcher& operator=(const ORBmatcher&) = delete;
+
+    static int DescriptorDistance(const uint8_t* a, const uint8_t* b) { return se2gpu_hamming(a, b); }
+
+    int MatchByWindow(const FrameView& frame1, const FrameView& frame2, std::vector<Point2f>& vbPrevMatched,
+                      const int winSize, std::vector<int>& vnMatches12, const int levelOffset = 1,
+                      const int minLevel = 0, const int maxLevel = 8) {
+        vnMatches12.assign(frame1.N, -1);
+        se2gpu_frame_bounds b{frame2.minXUn, frame2.minYUn, frame2.maxXUn, frame2.maxYUn};
+        int nmatches = 0;
+        check(se2gpu_match_window(h_, &b, reinterpret_cast<const se2gpu_keypoint*>(frame1.keyPointsUn), frame1.descriptors,
+                                  frame1.N, reinterpret_cast<const se2gpu_keypoint*>(frame2.keyPointsUn),
+                                  frame2.descriptors, frame2.N, reinterpret_cast<float*>(vbPrevMatched.data()), winSize,
+                                  levelOffset, minLevel, maxLevel, mfNNratio, vnMatches12.data(), &nmatches),
+              "ORBmatcher::MatchByWindow");
+        return nmatches;
+    }
+
+    int MatchByProjection(const FrameView& newKF, const MapPointView& localMPs, const float fx, const float fy,
+                          const float cx, const float cy, const int winSize, const int levelOffset,
+                          std::vector<int>& vMatchesIdxMP) {
+        vMatchesIdxMP.assign(newKF.N, -1);
+        se2gpu_frame_bounds b{newKF.minXUn, newKF.minYUn, newKF.maxXUn, newKF.maxYUn};
+        int nmatches = 0;
+        check(se2gpu_match_projection(h_, &b, localMPs.pos, localMPs.mainDescriptor, localMPs.mainOctave, localMPs.skip,
+                                      localMPs.M, newKF.Tcw, fx, fy, cx, cy,
+                                      reinterpret_cast<const se2gpu_keypoint*>(newKF.keyPointsUn), newKF.descriptors,
+                                      newKF.observed, newKF.N, winSize, levelOffset, mfNNratio, vMatchesIdxMP.data(),
+                                      &nmatches),
+              "ORBmatcher::MatchByProjection");
+        return nmatches;
+    }
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+    se2gpu_matcher* h_ = nullptr;
+};
+
+}  // namespace se2lam_amd

@@ -3,7 +3,7 @@
 // Replaces se2lam::ORBextractor (/root/reference/src/ORBextractor.cpp, include/se2lam/ORBextractor.h:38-83):
 //   ctor :463-520, ComputePyramid :790-831, ComputeKeyPoints :531-716, IC_Angle :130-157,
 //   GaussianBlur call :769, computeOrbDescriptor :161-200, operator() :727-788.
-// The OpenCV primitives it calls are restated with the semantics DESIGN.md / oracle/orb_ref.cpp define
+// The OpenCV primitives it calls are restated with the semantics DESIGN.md defines
 // (FAST-9/16 + cornerScore + in-cell NMS, 11-bit fixed-point bilinear resize, reflect-101 border, 8-bit
 // fixed-point 7x7 Gaussian, canonical retain-best order, fastAtan2, round-half-even).
 //

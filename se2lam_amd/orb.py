@@ -112,14 +112,3 @@ class ORBextractor:
         except Exception:
             pass
 
-
-def smoke():
-    """one small frame through the HIP extractor, checked bit-exactly against the oracle"""
-    from . import synth
-    from oracle import oracle
-    img = synth.frame(0)
-    ex = ORBextractor()
-    k, d = ex(img)
-    ko, do = oracle.orb_extract(img)
-    assert len(k) == len(ko) and np.array_equal(k, ko) and np.array_equal(d, do), "ORB smoke: GPU != oracle"
-    print(f"smoke: ORB {len(k)} keypoints, descriptors bit-exact vs oracle")

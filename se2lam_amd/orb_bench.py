@@ -19,7 +19,7 @@ B_ORB = 5_742_474      # algorithmic bytes per frame, SURVEY.md §8(d)
 B_MATCH = 132_000      # algorithmic bytes per frame pair
 
 
-def run(rank, world, batch, steps, sync_all, dist, torch, cpu_baseline=False, warmup=2, cap=1024):
+def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024):
     B = batch
     imgs = synth.frames(B, start=1000 * rank)
     ex = ORBextractor(max_batch=B)
@@ -77,24 +77,9 @@ def run(rank, world, batch, steps, sync_all, dist, torch, cpu_baseline=False, wa
                 "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,
                 "whole_step_frac": (B_ORB + B_MATCH) * fps / world / 1e9 / HBM_PEAK_GBS,
                 "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()}}
-    cpu = None
-    if cpu_baseline:
-        from oracle import oracle
-        t1 = time.perf_counter()
-        nfr = 0
-        prev = oracle.orb_extract(imgs[0])
-        while time.perf_counter() - t1 < 10.0 and nfr < B - 1:
-            cur = oracle.orb_extract(imgs[nfr + 1])
-            oracle.match_window(prev[0], prev[1], cur[0], cur[1])
-            prev = cur
-            nfr += 1
-        cdt = time.perf_counter() - t1
-        cpu = {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + oracle/match_ref.cpp "
-                         f"MatchByWindow, 1 thread"}
     return {"metric": "ORB extract+match frames/s @640x480", "value": fps, "unit": "frames/s", "n_gpus": world,
             "batch": B, "steps": steps, "ms_per_batch": 1e3 * dt / steps, "scaling": "weak",
             "config": {"workload": "640x480 u8, 8-level pyramid, 1000 features/frame, MatchByWindow(win 20, ratio 0.9), "
                                    "frames t vs t+1", "features_per_frame": float(cnt.mean()),
                        "matches_per_pair": float(nm.mean())},
-            "roofline": roof, "cpu_baseline": cpu}
+            "roofline": roof, "cpu_baseline": None}

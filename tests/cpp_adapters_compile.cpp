@@ -1,0 +1,67 @@
+// Compile-and-link check of the C++ adapters (include/se2lam_amd/*.h) against libse2gpu.so.  Without a GPU it only
+// checks that construction fails loudly with SE2GPU_ERR_NO_DEVICE; on the GPU box it runs a tiny localBA-shaped
+// call sequence through the reference's names.
+#include <cstdio>
+#include <cstring>
+
+#include "se2lam_amd/ORBextractor.h"
+#include "se2lam_amd/ORBmatcher.h"
+#include "se2lam_amd/optimizer.h"
+
+using namespace se2lam_amd;
+
+int main() {
+    if (se2gpu_device_count() == 0) {
+        try {
+            SlamOptimizer opt;
+            std::printf("FAIL: construction succeeded without a device\n");
+            return 1;
+        } catch (const std::exception& e) {
+            std::printf("OK (no device): %s\n", e.what());
+            return 0;
+        }
+    }
+    // LocalMapper::localBA shape: two poses, one landmark, two observations, one odometry edge
+    SlamOptimizer optimizer;
+    bool abortBA = false;
+    initOptimizer(optimizer, false);
+    optimizer.setForceStopFlag(&abortBA);
+    CamPara campr = addCamPara(optimizer, 400.f, 320.f, 240.f, 0);
+    SE3Quat Tbc;
+    const double R[9] = {0, 0, 1, -1, 0, 0, 0, -1, 0};
+    std::memcpy(Tbc.R, R, sizeof(R));
+    Tbc.t[0] = 100; Tbc.t[2] = 300;
+    addVertexSE2(optimizer, SE2{0, 0, 0}, 0, true);
+    addVertexSE2(optimizer, SE2{500, 10, 0.02}, 1, false);
+    Matrix3D oinfo{{1e-2, 0, 0, 0, 1e-2, 0, 0, 0, 1e3}};
+    addEdgeSE2(optimizer, Vector3D{{500, 0, 0}}, 0, 1, oinfo);
+    addVertexSBAXYZ(optimizer, Vector3D{{4000, 300, 500}}, 3);
+    Matrix2D info{{1, 0, 0, 1}};
+    addEdgeSE2XYZ(optimizer, Vector2D{{290.0, 260.0}}, 0, 3, &campr, Tbc, info, 2.4477);
+    addEdgeSE2XYZ(optimizer, Vector2D{{286.0, 262.0}}, 1, 3, &campr, Tbc, info, 2.4477);
+    optimizer.initializeOptimization(0);
+    const double chi0 = optimizer.activeRobustChi2();
+    const int it = optimizer.optimize(5);
+    const double chi1 = optimizer.activeRobustChi2();
+    SE2 p1 = estimateVertexSE2(optimizer, 1);
+    Vector3D l = estimateVertexSBAXYZ(optimizer, 3);
+    std::printf("localBA adapters: %d iterations, chi2 %.6f -> %.6f, pose1 (%.3f %.3f %.5f), lm (%.2f %.2f %.2f)\n", it, chi0,
+                chi1, p1.x, p1.y, p1.theta, l.v[0], l.v[1], l.v[2]);
+    if (!(chi1 <= chi0)) return 1;
+    ORBextractor extractor(1000, 1.2f, 8, ORBextractor::FAST_SCORE, 20);
+    std::vector<uint8_t> img(640 * 480);
+    for (size_t i = 0; i < img.size(); ++i) img[i] = (uint8_t)(((i % 640) / 16 + (i / 640) / 16) % 2 ? 200 : 40);
+    Mat8U im; im.rows = 480; im.cols = 640; im.step = 640; im.data = img.data();
+    std::vector<KeyPoint> kps; Mat8U desc;
+    extractor(im, Mat8U(), kps, desc);
+    std::printf("ORBextractor adapter: %zu keypoints, levels %d, scale %.2f\n", kps.size(), extractor.GetLevels(),
+                extractor.GetScaleFactor());
+    ORBmatcher matcher(0.9f);
+    FrameView f; f.keyPointsUn = kps.data(); f.descriptors = desc.data; f.N = (int)kps.size();
+    std::vector<Point2f> prev(kps.size());
+    for (size_t i = 0; i < kps.size(); ++i) prev[i] = kps[i].pt;
+    std::vector<int> m12;
+    const int nm = matcher.MatchByWindow(f, f, prev, 20, m12);
+    std::printf("ORBmatcher adapter: %d self-matches of %zu\n", nm, kps.size());
+    return kps.empty() ? 1 : 0;
+}

@@ -1,0 +1,85 @@
+"""world_size-2 gloo test of the landmark-sharded BA exchange step on CPU.
+
+There is no GPU here and the library has no CPU fallback, so the per-shard arithmetic comes from the oracle; what is
+exercised is everything around it that the N>1 bench path relies on: the library's host-side partitioner, the fused
+buffer layout [augmented (ld x ld): rows 0..n-1 = S, row n = b | 4 scalars] of se2gpu_ba_reduce_buffer_doubles, the
+"rank 0 owns lambda*I / identity / odometry" rule, one torch.distributed all_reduce(SUM) of the buffer, the redundant
+per-rank solve, and the max-through-sum slot trick used for lambda_0."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from se2lam_amd import capi, optimizer, synth
+    from oracle import oracle
+    g = synth.ba_graph(10, 120)
+    lam = 2.5
+    own = optimizer.shard_landmarks(g.L, g.e_kf, g.e_lm, world)       # library partitioner (host code)
+    assert np.array_equal(own, synth.shard_landmarks(g.e_kf, g.e_lm, g.L, world))
+    sh = g.shard(rank, world)
+    part = oracle.ba_reduced_system(sh, lam)
+    n = 3 * g.P
+    nred = int(capi.lib().se2gpu_ba_reduce_buffer_doubles(None, g.P))
+    ld = int(round((nred - 4) ** 0.5))
+    assert ld * ld + 4 == nred and ld >= n + 1 and ld % 32 == 0
+    buf = np.zeros(nred)
+    A = buf[:ld * ld].reshape(ld, ld)
+    S, bs = part["S"].copy(), part["bs"].copy()
+    if rank != 0:                                                     # lambda*I / identity enter once
+        free = np.repeat(~g.fixed.astype(bool), 3)
+        S[np.diag_indices(n)] -= np.where(free, lam, 1.0)
+    A[:n, :n] = S
+    A[n, :n] = bs
+    buf[ld * ld + 0] = float(rank + 1)                                # trial scalars ride in the tail
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t[:(n + 1) * ld])                                 # the big exchange: rows 0..n
+    dist.all_reduce(t[ld * ld:])                                      # the 4-scalar exchange
+    x = np.linalg.solve(A[:n, :n], A[n, :n])                          # every rank solves redundantly
+    # max over ranks through SUM: each rank deposits its local value in its own slot
+    slots = torch.zeros(world, dtype=torch.float64)
+    slots[rank] = float(np.abs(np.diagonal(part["Hll"], axis1=1, axis2=2)).max())
+    dist.all_reduce(slots)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, S=A[:n, :n], bs=A[n, :n], tail=buf[ld * ld:],
+             maxd=float(slots.max()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_reduction_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from se2lam_amd import synth
+    from oracle import oracle
+    g = synth.ba_graph(10, 120)
+    full = oracle.ba_reduced_system(g, 2.5)
+    x_full = np.linalg.solve(full["S"], full["bs"])
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    for r in (r0, r1):
+        assert np.allclose(r["S"], full["S"], rtol=1e-10, atol=1e-8)
+        assert np.allclose(r["bs"], full["bs"], rtol=1e-10, atol=1e-8)
+        assert np.allclose(r["x"], x_full, rtol=1e-8, atol=1e-10)
+        assert r["tail"][0] == 3.0                                   # 1 + 2
+        assert r["maxd"] == pytest.approx(np.abs(np.diagonal(full["Hll"], axis1=1, axis2=2)).max(), rel=1e-12)
+    assert np.array_equal(r0["x"], r1["x"])                          # identical on every rank
