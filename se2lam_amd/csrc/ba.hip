@@ -111,14 +111,20 @@ __device__ inline double wave_sum(double v) {
 // k_linearize: per landmark group.  Outputs per edge: Hpl (3x3 row-major), Hpp_e (6 sym), bp_e (3);
 // per landmark: Hll (6 sym: xx xy xz yy yz zz), bl (3).
 // ---------------------------------------------------------------------------------------------
+__device__ inline void inv_sym3(const double h[6], double lambda, double d[6]);
+
+// FUSED: also produce the lambda-dependent per-landmark pieces of k_schur_lm (Dinv, z, Y_e) in the same pass.
+template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const int* __restrict__ lm_ptr,
                                                        const int* __restrict__ e_kf, const double* __restrict__ e_uv,
                                                        const double* __restrict__ e_info,
                                                        const double* __restrict__ poses,
                                                        const uint8_t* __restrict__ fixed,
-                                                       const double* __restrict__ lms, double* __restrict__ Hpl,
+                                                       const double* __restrict__ lms, double* Hpl,
                                                        double* __restrict__ Hpp_e, double* __restrict__ bp_e,
-                                                       double* __restrict__ Hll, double* __restrict__ bl) {
+                                                       double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                       double* __restrict__ Dinv, double* __restrict__ z,
+                                                       double* __restrict__ Y) {
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -178,6 +184,28 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
         for (int i = 0; i < 6; ++i) Hll[(size_t)l * 6 + i] = hll[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) bl[(size_t)l * 3 + i] = b[i];
+    }
+    if (FUSED && l < L) {
+        double d[6];
+        inv_sym3(hll, lambda, d);
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
+            z[(size_t)l * 3 + 0] = d[0] * b[0] + d[1] * b[1] + d[2] * b[2];
+            z[(size_t)l * 3 + 1] = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
+            z[(size_t)l * 3 + 2] = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
+        }
+        for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
+            const double* B = Hpl + (size_t)e * 9;  // written by this same lane above
+            double* y = Y + (size_t)e * 9;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double b0 = B[r * 3], b1 = B[r * 3 + 1], b2 = B[r * 3 + 2];
+                y[r * 3 + 0] = b0 * d[0] + b1 * d[1] + b2 * d[2];
+                y[r * 3 + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
+                y[r * 3 + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
+            }
+        }
     }
 }
 
@@ -428,6 +456,170 @@ __global__ __launch_bounds__(kBlock) void k_reduce(int P, int ld, int npad, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_reduce2: the reduced system in ONE launch, output-stationary, atomic-free.
+//   blocks [0, nb_off)        : off-diagonal (a < b) blocks, one THREAD per entry (9 consecutive lanes per block):
+//                               S_ab(r,c) = - sum_{(i,j) in pairs(a,b)} Y_i(r,:) . Hpl_j(c,:)  (+ the PreEdgeSE2 block)
+//   blocks [nb_off, nb_off+nb_diag) : one WAVE per pose: S_aa = Hpp_a + lambda I - sum_e Y_e Hpl_e^T, b_s, b_p
+//                               (absorbs k_pose_reduce, k_odometry and k_reduce_odo; odometry terms are recomputed
+//                               on the fly from the poses: <= 2 edges per pose)
+//   last wave of the diagonal part clears the padding of the augmented matrix.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void odo_terms(const double* poses, const uint8_t* fixed, const int* o_i, const int* o_j,
+                                 const double* o_meas, const double* o_info, int k, double e[3], double A[9], double B[9],
+                                 double WA[9], double WB[9], double omr[3]) {
+    const int i = o_i[k], j = o_j[k];
+    pre_se2(poses + 3 * i, poses + 3 * j, o_meas + 3 * k, e, A, B);
+    const double* W = o_info + 9 * k;
+    for (int r = 0; r < 3; ++r) {
+        omr[r] = -(W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
+        for (int c = 0; c < 3; ++c) {
+            WA[r * 3 + c] = W[r * 3] * A[c] + W[r * 3 + 1] * A[3 + c] + W[r * 3 + 2] * A[6 + c];
+            WB[r * 3 + c] = W[r * 3] * B[c] + W[r * 3 + 1] * B[3 + c] + W[r * 3 + 2] * B[6 + c];
+        }
+    }
+}
+
+constexpr int kGrpPerWG = 28;   // 9-lane groups per 256-thread workgroup (252 lanes used)
+constexpr int kChunk = 16;      // contributor pairs per group
+
+// Off-diagonal part: workgroup w owns the groups [w*28, w*28+28) of the host-built plan.  A group = 9 lanes (one per
+// entry of a 3x3 block) accumulating one chunk of <= kChunk contributor pairs of ONE reduced-system block; blocks
+// with several chunks are packed into the same workgroup and combined in LDS in chunk order (deterministic).
+// grp = {block index or -1, first pair, last pair, (first group of the block in this WG) | (number of groups << 8)}
+__global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, double lambda, int root,
+                                                     const int4* __restrict__ grp, const int* __restrict__ blk_a,
+                                                     const int* __restrict__ blk_b, const int* __restrict__ pair_i,
+                                                     const int* __restrict__ pair_j, const int* __restrict__ blk_odo,
+                                                     const double* __restrict__ Y, const double* __restrict__ Hpl,
+                                                     const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
+                                                     const uint8_t* __restrict__ fixed, const int* __restrict__ pose_ptr,
+                                                     const int* __restrict__ pose_edges, const int* __restrict__ e_lm,
+                                                     const double* __restrict__ z, const int* __restrict__ podo_ptr,
+                                                     const int* __restrict__ podo_item, const int* __restrict__ o_i,
+                                                     const int* __restrict__ o_j, const double* __restrict__ o_meas,
+                                                     const double* __restrict__ o_info, const double* __restrict__ poses,
+                                                     double* __restrict__ S, double* __restrict__ bp) {
+    const int n = 3 * P;
+    __shared__ double part[kGrpPerWG][9];
+    __shared__ double dpart[kBlock / 64][12];
+    if ((int)blockIdx.x < nwg_off) {
+        const int g = threadIdx.x / 9, en = threadIdx.x - 9 * g;
+        int4 d = make_int4(-1, 0, 0, 0);
+        if (g < kGrpPerWG) d = grp[(size_t)blockIdx.x * kGrpPerWG + g];
+        const int r = en / 3, c = en - 3 * r;
+        double acc0 = 0, acc1 = 0;
+        if (d.x >= 0) {
+            int q = d.y;
+            for (; q + 1 < d.z; q += 2) {
+                const double* y0 = Y + (size_t)pair_i[q] * 9 + 3 * r;
+                const double* h0 = Hpl + (size_t)pair_j[q] * 9 + 3 * c;
+                const double* y1 = Y + (size_t)pair_i[q + 1] * 9 + 3 * r;
+                const double* h1 = Hpl + (size_t)pair_j[q + 1] * 9 + 3 * c;
+                acc0 += y0[0] * h0[0] + y0[1] * h0[1] + y0[2] * h0[2];
+                acc1 += y1[0] * h1[0] + y1[1] * h1[1] + y1[2] * h1[2];
+            }
+            if (q < d.z) {
+                const double* y0 = Y + (size_t)pair_i[q] * 9 + 3 * r;
+                const double* h0 = Hpl + (size_t)pair_j[q] * 9 + 3 * c;
+                acc0 += y0[0] * h0[0] + y0[1] * h0[1] + y0[2] * h0[2];
+            }
+            part[g][en] = acc0 + acc1;
+        }
+        __syncthreads();
+        if (d.x >= 0 && (d.w & 0xff) == g) {
+            const int ng = d.w >> 8;
+            double tot = 0;
+            for (int t = 0; t < ng; ++t) tot += part[g + t][en];
+            const int a = blk_a[d.x], b = blk_b[d.x];
+            double out = 0.0;
+            if (!fixed[a] && !fixed[b]) {
+                out = -tot;
+                const int od = blk_odo[d.x];
+                if (od >= 0) {  // PreEdgeSE2 between a and b: A^T W B (transposed when the edge runs b -> a)
+                    double e[3], A[9], B[9], WA[9], WB[9], omr[3];
+                    odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, od >> 1, e, A, B, WA, WB, omr);
+                    const int rr = (od & 1) ? c : r, cc = (od & 1) ? r : c;
+                    out += A[rr] * WB[cc] + A[3 + rr] * WB[3 + cc] + A[6 + rr] * WB[6 + cc];
+                }
+            }
+            S[(size_t)(3 * a + r) * ld + 3 * b + c] = out;
+            S[(size_t)(3 * b + c) * ld + 3 * a + r] = out;
+        }
+        return;
+    }
+    // ---- diagonal part: one workgroup per pose (+ one that clears the padding)
+    const int p = (int)blockIdx.x - nwg_off;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* __restrict__ bs = S + (size_t)n * ld;
+    if (p == P) {
+        for (size_t t = (size_t)n * ld + n + threadIdx.x; t < (size_t)ld * ld; t += kBlock) S[t] = 0.0;
+        return;
+    }
+    double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // S diag (6 sym), bp (3), g (3)
+    const bool fa = fixed[p];
+    if (!fa) {
+        for (int t = pose_ptr[p] + threadIdx.x; t < pose_ptr[p + 1]; t += kBlock) {
+            const int e = pose_edges[t];
+            const double* y = Y + (size_t)e * 9;
+            const double* h = Hpl + (size_t)e * 9;
+            const double* hp = Hpp_e + (size_t)e * 6;
+            const double* zz = z + (size_t)e_lm[e] * 3;
+            double yy[9], hh[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { yy[i] = y[i]; hh[i] = h[i]; }
+            acc[0] += hp[0] - (yy[0] * hh[0] + yy[1] * hh[1] + yy[2] * hh[2]);
+            acc[1] += hp[1] - (yy[0] * hh[3] + yy[1] * hh[4] + yy[2] * hh[5]);
+            acc[2] += hp[2] - (yy[0] * hh[6] + yy[1] * hh[7] + yy[2] * hh[8]);
+            acc[3] += hp[3] - (yy[3] * hh[3] + yy[4] * hh[4] + yy[5] * hh[5]);
+            acc[4] += hp[4] - (yy[3] * hh[6] + yy[4] * hh[7] + yy[5] * hh[8]);
+            acc[5] += hp[5] - (yy[6] * hh[6] + yy[7] * hh[7] + yy[8] * hh[8]);
+            const double z0 = zz[0], z1 = zz[1], z2 = zz[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                acc[6 + r] += bp_e[(size_t)e * 3 + r];
+                acc[9 + r] += hh[r * 3] * z0 + hh[r * 3 + 1] * z1 + hh[r * 3 + 2] * z2;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) dpart[wv][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t12[12];
+        for (int i = 0; i < 12; ++i) t12[i] = dpart[0][i] + dpart[1][i] + dpart[2][i] + dpart[3][i];
+        double H[9] = {t12[0], t12[1], t12[2], t12[1], t12[3], t12[4], t12[2], t12[4], t12[5]};
+        double b[3] = {t12[6], t12[7], t12[8]};
+        if (!fa) {
+            for (int t = podo_ptr[p]; t < podo_ptr[p + 1]; ++t) {
+                const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
+                double e[3], A[9], B[9], WA[9], WB[9], omr[3];
+                odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
+                const double* J = isj ? B : A;
+                const double* WJ = isj ? WB : WA;
+                for (int r = 0; r < 3; ++r) {
+                    for (int c = 0; c < 3; ++c) H[r * 3 + c] += J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
+                    b[r] += J[r] * omr[0] + J[3 + r] * omr[1] + J[6 + r] * omr[2];
+                }
+            }
+        }
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) {
+                double out;
+                if (fa) out = (r == c && root) ? 1.0 : 0.0;
+                else out = H[r * 3 + c] + ((r == c && root) ? lambda : 0.0);
+                S[(size_t)(3 * p + r) * ld + 3 * p + c] = out;
+            }
+            bs[3 * p + r] = fa ? 0.0 : b[r] - t12[9 + r];
+            bp[(size_t)p * 3 + r] = fa ? 0.0 : b[r];
+        }
+    }
+}
+
 // odometry pose-pose blocks: S_ij += Oij, S_ji += Oij^T.  One thread per (edge, entry).
 __global__ void k_reduce_odo(int O, int ld, const int* __restrict__ o_i, const int* __restrict__ o_j,
                              const double* __restrict__ Oij, double* __restrict__ S) {
@@ -473,9 +665,13 @@ __device__ inline double fast_rsqrt(double d) {  // v_rsq_f64 + 2 Newton steps
 // 32 doubles per lane): lanes 0..31 = diagonal tile A(k,k) (every workgroup repeats it), lanes 32..63 = its own
 // tile: A(i,k) for i > k, the identity for the diagonal workgroup (-> R(k,k)), or R(r,k) for r < k.
 //     M[r][c] -= M[r][j] * M[c][j] / M[j][j]   (c > j),      L[r][j] = M[r][j] / sqrt(M[j][j]) at the end.
-// M[c][j] lives in lane c and is broadcast with v_readlane: no LDS, no barriers, fully unrolled.
+// The sequential chain is pivot -> reciprocal -> multiplier -> next pivot (dependent FP64 ops, 48 clk each on
+// gfx950), so the loop is software pipelined: column j first updates column j+1 and starts the reciprocal of the
+// NEXT pivot, then does the bulk rank-1 update of columns j+2.. while that chain is in flight.  M[c][j] of the bulk
+// comes from a 64-entry LDS column (uniform-address ds_read = broadcast); only the pivot path uses v_readlane.
 __global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ A, double* __restrict__ R, int ld, int n,
                                                     int nt, int k, double* __restrict__ fail) {
+    __shared__ double col[64];
     const int lane = threadIdx.x;
     const int nS = nt - k;
     const bool isR = (int)blockIdx.x >= nS;
@@ -490,26 +686,49 @@ __global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ A, doubl
     else rowp = R + (size_t)(kNB * tr + r) * ld + c0;
     if (isDiag && lane >= kNB) rowp = R + (size_t)(c0 + r) * ld + c0;
     double m[kNB];
+    {
+        const double2* rp2 = reinterpret_cast<const double2*>(rowp);
 #pragma unroll
-    for (int c = 0; c < kNB; ++c) m[c] = (isDiag && lane >= kNB) ? (c == r ? 1.0 : 0.0) : rowp[c];
+        for (int c = 0; c < kNB; c += 2) {
+            double2 v = (isDiag && lane >= kNB) ? make_double2(c == r ? 1.0 : 0.0, c + 1 == r ? 1.0 : 0.0) : rp2[c / 2];
+            m[c] = v.x;
+            m[c + 1] = v.y;
+        }
+    }
+    double inv = fast_rcp(bcast_lane(m[0], 0));
 #pragma unroll
     for (int j = 0; j < kNB; ++j) {
         if (j < ncol) {
-            const double inv = fast_rcp(bcast_lane(m[j], j));
             const double mr = m[j] * inv;
+            if (j + 1 < kNB) {
+                m[j + 1] = fma(-mr, bcast_lane(m[j], j + 1), m[j + 1]);
+                inv = fast_rcp(bcast_lane(m[j + 1], j + 1));  // next pivot: in flight during the bulk update
+            }
+            if (j + 2 < kNB) {
+                col[lane] = m[j];
 #pragma unroll
-            for (int c = j + 1; c < kNB; ++c) m[c] = fma(-mr, bcast_lane(m[j], c), m[c]);
+                for (int c = j + 2; c < kNB; ++c) m[c] = fma(-mr, col[c], m[c]);
+            }
         }
     }
     bool bad = false;
+    double out[kNB];
 #pragma unroll
     for (int c = 0; c < kNB; ++c) {
-        if (c < ncol) {
-            const double d = bcast_lane(m[c], c);
-            const bool okd = d > 0.0 && isfinite(d);
-            bad |= !okd;
-            const double v = m[c] * fast_rsqrt(okd ? d : 1.0);
-            if (lane >= kNB || (isDiag && c <= r)) rowp[c] = v;
+        const double d = bcast_lane(m[c], c);
+        const bool okd = !(c < ncol) || (d > 0.0 && isfinite(d));
+        bad |= !okd;
+        out[c] = m[c] * fast_rsqrt((c < ncol && okd) ? d : 1.0);
+    }
+    {
+        double2* wp2 = reinterpret_cast<double2*>(rowp);
+        if (lane >= kNB && ncol == kNB) {
+#pragma unroll
+            for (int c = 0; c < kNB; c += 2) wp2[c / 2] = make_double2(out[c], out[c + 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < kNB; ++c)
+                if (c < ncol && (lane >= kNB || (isDiag && c <= r))) rowp[c] = out[c];
         }
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
@@ -523,29 +742,39 @@ __global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, dou
     const bool isR = (int)blockIdx.y >= m_s;
     const int i = isR ? (int)blockIdx.y - m_s : k + 1 + (int)blockIdx.y;  // tile row (in A, or in R)
     if (!isR && j > i) return;
-    __shared__ double Li[kNB][kNB + 1];
-    __shared__ double Lj[kNB][kNB + 1];
+    __shared__ double Li[kNB][kNB + 2];
+    __shared__ double Lj[kNB][kNB + 2];
     const int tid = threadIdx.x;
     const int c0 = kNB * k;
     const double* src = isR ? R : A;
-    for (int idx = tid; idx < kNB * kNB; idx += 256) {
-        const int r = idx / kNB, c = idx % kNB;
-        Li[r][c] = src[(size_t)(kNB * i + r) * ld + c0 + c];
-        Lj[r][c] = A[(size_t)(kNB * j + r) * ld + c0 + c];
-    }
-    __syncthreads();
     const int r = tid / 8, cc = (tid % 8) * 4;
-    double acc[4] = {0, 0, 0, 0};
-#pragma unroll 8
-    for (int m = 0; m < kNB; ++m) {
-        const double a = Li[r][m];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += a * Lj[cc + q][m];
-    }
-    double* out = (isR ? R : A) + (size_t)(kNB * i + r) * ld + kNB * j + cc;
+    double* outp = (isR ? R : A) + (size_t)(kNB * i + r) * ld + kNB * j + cc;
     const bool first = isR && i == k;
+    // issue every global load up front: two double2 of each operand tile + the 4 outputs this thread updates
+    const double2 li0 = *reinterpret_cast<const double2*>(src + (size_t)(kNB * i + r) * ld + c0 + cc);
+    const double2 li1 = *reinterpret_cast<const double2*>(src + (size_t)(kNB * i + r) * ld + c0 + cc + 2);
+    const double2 lj0 = *reinterpret_cast<const double2*>(A + (size_t)(kNB * j + r) * ld + c0 + cc);
+    const double2 lj1 = *reinterpret_cast<const double2*>(A + (size_t)(kNB * j + r) * ld + c0 + cc + 2);
+    double2 o0 = make_double2(0.0, 0.0), o1 = make_double2(0.0, 0.0);
+    if (!first) {
+        o0 = *reinterpret_cast<const double2*>(outp);
+        o1 = *reinterpret_cast<const double2*>(outp + 2);
+    }
+    Li[r][cc] = li0.x; Li[r][cc + 1] = li0.y; Li[r][cc + 2] = li1.x; Li[r][cc + 3] = li1.y;
+    Lj[r][cc] = lj0.x; Lj[r][cc + 1] = lj0.y; Lj[r][cc + 2] = lj1.x; Lj[r][cc + 3] = lj1.y;
+    __syncthreads();
+    double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[q] = (first ? 0.0 : out[q]) - acc[q];
+    for (int m = 0; m < kNB; m += 2) {
+        const double a0 = Li[r][m], a1 = Li[r][m + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[q][0] = fma(a0, Lj[cc + q][m], acc[q][0]);
+            acc[q][1] = fma(a1, Lj[cc + q][m + 1], acc[q][1]);
+        }
+    }
+    *reinterpret_cast<double2*>(outp) = make_double2(o0.x - (acc[0][0] + acc[0][1]), o0.y - (acc[1][0] + acc[1][1]));
+    *reinterpret_cast<double2*>(outp + 2) = make_double2(o1.x - (acc[2][0] + acc[2][1]), o1.y - (acc[3][0] + acc[3][1]));
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -793,7 +1022,10 @@ struct se2gpu_ba {
     double *poses = nullptr, *poses_t = nullptr, *lms = nullptr, *lms_t = nullptr;
     DevBuf<uint8_t> fixed;
     DevBuf<int> lm_ptr, e_kf, e_lm, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j;
-    DevBuf<int> blk_a, blk_b, blk_ptr, pair_i, pair_j;
+    DevBuf<int> blk_a, blk_b, blk_ptr, pair_i, pair_j, blk_odo;
+    DevBuf<int4> grp;
+    int nwg_off = 0;
+    bool odo_fallback = false;
     DevBuf<double> e_uv, e_info, o_meas, o_info;
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Hpp, bp, Oii, Ojj, Oij, obi, obj;
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
@@ -881,7 +1113,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             for (int t = lm_ptr[l]; t < lm_ptr[l + 1]; ++t) {
                 if (fx[e_kf[t]]) continue;
                 const int a = e_kf[s], b = e_kf[t];
-                if (a < b || (a == b)) blk_ptr[blk_index(a, b) + 1]++;
+                if (a < b) blk_ptr[blk_index(a, b) + 1]++;
             }
         }
     for (int k = 0; k < nblk; ++k) blk_ptr[k + 1] += blk_ptr[k];
@@ -895,7 +1127,7 @@ int ba_upload_graph(se2gpu_ba* h) {
                 for (int t = lm_ptr[l]; t < lm_ptr[l + 1]; ++t) {
                     if (fx[e_kf[t]]) continue;
                     const int a = e_kf[s], b = e_kf[t];
-                    if (a < b || (a == b)) {
+                    if (a < b) {
                         const int q = f[blk_index(a, b)]++;
                         pair_i[q] = s;
                         pair_j[q] = t;
@@ -904,8 +1136,47 @@ int ba_upload_graph(se2gpu_ba* h) {
             }
     }
     h->nblk = nblk;
+    // PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan; duplicates fall back
+    std::vector<int> blk_odo(nblk, -1);
+    h->odo_fallback = false;
+    for (int k = 0; k < O; ++k) {
+        const int i = o_i[k], j = o_j[k];
+        if (i == j) { h->odo_fallback = true; continue; }
+        const int q = blk_index(std::min(i, j), std::max(i, j));
+        if (blk_odo[q] >= 0) h->odo_fallback = true;
+        blk_odo[q] = 2 * k + (i > j ? 1 : 0);
+    }
+    if (h->odo_fallback) std::fill(blk_odo.begin(), blk_odo.end(), -1);
+    // pack 16-pair chunks of the off-diagonal blocks into workgroups of 28 nine-lane groups
+    std::vector<int4> grp;
+    {
+        int used = 0;  // groups used in the current workgroup
+        auto flush = [&]() {
+            while (used % kGrpPerWG) { grp.push_back(make_int4(-1, 0, 0, 0)); ++used; }
+            used = 0;
+        };
+        for (int kb = 0; kb < nblk; ++kb) {
+            if (blk_a[kb] == blk_b[kb]) continue;
+            const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
+            int chunk = kChunk;
+            int ng = std::max(1, (q1 - q0 + chunk - 1) / chunk);
+            if (ng > kGrpPerWG) { chunk = (q1 - q0 + kGrpPerWG - 1) / kGrpPerWG; ng = (q1 - q0 + chunk - 1) / chunk; }
+            if (used + ng > kGrpPerWG) flush();
+            const int first = used;
+            for (int t = 0; t < ng; ++t) {
+                const int a0 = q0 + t * chunk, a1 = std::min(q1, a0 + chunk);
+                grp.push_back(make_int4(kb, a0, std::max(a0, a1), first | (ng << 8)));
+                ++used;
+            }
+            if (used == kGrpPerWG) used = 0;
+        }
+        flush();
+        if (grp.empty()) grp.assign(kGrpPerWG, make_int4(-1, 0, 0, 0));
+    }
+    h->nwg_off = (int)(grp.size() / kGrpPerWG);
     hipStream_t st = h->stream;
     const int n = 3 * P;
+    SE2_CHECK(h->grp.upload(grp, st));
     SE2_CHECK(h->poses0.upload(h->h_poses, st));
     SE2_CHECK(h->lms0.upload(h->h_lms, st));
     SE2_CHECK(h->fixed.upload(h->h_fixed, st));
@@ -925,6 +1196,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_CHECK(h->blk_a.upload(blk_a, st));
     SE2_CHECK(h->blk_b.upload(blk_b, st));
     SE2_CHECK(h->blk_ptr.upload(blk_ptr, st));
+    SE2_CHECK(h->blk_odo.upload(blk_odo, st));
     SE2_CHECK(h->pair_i.upload(pair_i, st));
     SE2_CHECK(h->pair_j.upload(pair_j, st));
     SE2_CHECK(h->poses_a.reserve(3 * (size_t)P));
@@ -978,12 +1250,24 @@ int ba_upload_graph(se2gpu_ba* h) {
 
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
 
-// linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl, odometry blocks, Hpp, bp
-int ba_linearize(se2gpu_ba* h) {
+// linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl; with fuse_lambda >= 0 also Dinv, z, Y for that damping
+int ba_linearize(se2gpu_ba* h, double fuse_lambda) {
     hipStream_t st = h->stream;
-    SE2_LAUNCH(h->prof, st, "k_linearize", k_linearize, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam,
-               h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
-               h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p);
+    if (fuse_lambda >= 0.0)
+        SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
+                   h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p);
+    else
+        SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
+                   h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p);
+    SE2_HIP(hipGetLastError());
+    return SE2GPU_OK;
+}
+
+// un-reduced pose blocks Hpp / bp (only needed for lambda_0 = 1e-5 max diag H and by the odometry fallback)
+int ba_pose_blocks(se2gpu_ba* h) {
+    hipStream_t st = h->stream;
     if (h->O)
         SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
                    h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
@@ -994,18 +1278,24 @@ int ba_linearize(se2gpu_ba* h) {
     return SE2GPU_OK;
 }
 
-// reduced system for damping lambda into h->red = [S | bs | ...] (local contribution of this rank)
-int ba_reduce(se2gpu_ba* h, double lambda) {
+// reduced system for damping lambda into h->red (local contribution of this rank).
+// need_schur: Dinv / z / Y are not current for this lambda (first trial after an un-fused linearisation, or a retry)
+int ba_reduce(se2gpu_ba* h, double lambda, bool need_schur) {
     hipStream_t st = h->stream;
     double* S = h->red;
-    SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
-               lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Dinv.p, h->z.p, h->Y.p);
-    SE2_LAUNCH(h->prof, st, "k_reduce", k_reduce, grid1((size_t)(h->nblk + 1) * 64, kBlock), dim3(kBlock), 0, h->P,
-               h->ld, h->ld, h->nblk, lambda, h->root, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->pair_i.p, h->pair_j.p,
-               h->Y.p, h->Hpl.p, h->Hpp.p, h->bp.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->e_lm.p, h->z.p, S);
-    if (h->O)
+    if (need_schur)
+        SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
+                   lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Dinv.p, h->z.p, h->Y.p);
+    SE2_LAUNCH(h->prof, st, "k_reduce2", k_reduce2, dim3(h->nwg_off + h->P + 1), dim3(kBlock), 0, h->P, h->ld, h->nwg_off,
+               lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
+               h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->e_lm.p, h->z.p,
+               h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, h->poses, S, h->bp.p);
+    if (h->O && h->odo_fallback) {
+        SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
+                   h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
         SE2_LAUNCH(h->prof, st, "k_reduce_odo", k_reduce_odo, grid1((size_t)h->O * 9, 256), dim3(256), 0, h->O, h->ld,
                    h->o_i.p, h->o_j.p, h->Oij.p, S);
+    }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -1078,6 +1368,7 @@ int ba_solve(se2gpu_ba* h) {
 
 int ba_lambda_init(se2gpu_ba* h, double* lambda) {
     hipStream_t st = h->stream;
+    SE2_CHECK(ba_pose_blocks(h));
     SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
                h->Hpp.p, h->diag3.p);
     const bool sharded = h->allreduce && h->world > 1;
@@ -1291,8 +1582,8 @@ double se2gpu_ba_chi2(se2gpu_ba* h) {
 int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "debug_reduced_system before initialize");
     const int n = 3 * h->P;
-    SE2_CHECK(ba_linearize(h));
-    SE2_CHECK(ba_reduce(h, lambda));
+    SE2_CHECK(ba_linearize(h, lambda));
+    SE2_CHECK(ba_reduce(h, lambda, false));
     SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
     SE2_HIP(hipStreamSynchronize(h->stream));
     if (S)
@@ -1315,16 +1606,22 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
     double lambda = 0, ni = 2;
     bool ok = true;
     for (int it = 0; it < iters && !terminate() && ok; ++it) {
-        SE2_CHECK(ba_linearize(h));
+        bool need_schur;
         if (mode == SE2GPU_BA_LM && it == 0) {
+            SE2_CHECK(ba_linearize(h, -1.0));  // lambda_0 needs max diag(H) of this linearisation first
             SE2_CHECK(ba_lambda_init(h, &lambda));
             ni = 2;
+            need_schur = true;
+        } else {
+            SE2_CHECK(ba_linearize(h, mode == SE2GPU_BA_LM ? lambda : 0.0));
+            need_schur = false;
         }
         double rho = 0;
         int qmax = 0;
         do {
             const double lam = mode == SE2GPU_BA_LM ? lambda : 0.0;
-            SE2_CHECK(ba_reduce(h, lam));
+            SE2_CHECK(ba_reduce(h, lam, need_schur));
+            need_schur = true;  // a retry changes lambda
             SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
             SE2_CHECK(ba_solve(h));
             SE2_CHECK(ba_evaluate(h, h->xp.p, lam));
