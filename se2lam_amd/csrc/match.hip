@@ -184,8 +184,48 @@ __device__ __forceinline__ void best2_push(Best2& b, int d, int p) {  // (d, p) 
     }
 }
 
+// Stage the candidate lists of `nq` queries (fixed stride kMaxCand in HBM) into LDS as one compact array so that
+// the sequential greedy pass never waits on HBM.  off[0..nq] = exclusive prefix of min(ncand, kMaxCand); entries that
+// do not fit in `cap_e` stay in HBM (the pass falls back to global reads for those queries).  One wave.
+__device__ __forceinline__ int stage_candidates(const uint32_t* __restrict__ cand, const int* __restrict__ ncand, int nq,
+                                                int* off, uint32_t* ce, int cap_e, int* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int per = (nq + 63) / 64;
+    int local = 0;
+    for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
+        int n = ncand[i];
+        if (n > kMaxCand) { atomicOr(overflow, 1); n = kMaxCand; }
+        local += n;
+    }
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if (lane >= d) incl += v;
+    }
+    int run = incl - local;
+    for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
+        off[i] = run;
+        run += min(ncand[i], kMaxCand);
+    }
+    const int total = __shfl(incl, 63);
+    if (lane == 0) off[nq] = total;
+    __syncthreads();
+    const int tcopy = min(total, cap_e);
+    for (int e = lane; e < tcopy; e += 64) {
+        int lo = 0, hi = nq;  // largest i with off[i] <= e
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (off[mid] <= e) lo = mid; else hi = mid;
+        }
+        ce[e] = cand[(size_t)lo * kMaxCand + (e - off[lo])];
+    }
+    __syncthreads();
+    return total;
+}
+
 // best / second best by (dist, list position) among the candidates of one query that pass `vMatchesDistance[idx] > dist`
-__device__ __forceinline__ Best2 resolve_query(const uint32_t* __restrict__ cl, int n, const int* vMatchesDistance) {
+__device__ __forceinline__ Best2 resolve_query(const uint32_t* cl, int n, const int* vMatchesDistance) {
     const int lane = threadIdx.x & 63;
     Best2 b{INT_MAX, -1, INT_MAX, -1};
     for (int c0 = 0; c0 < n; c0 += 64) {
@@ -200,9 +240,11 @@ __device__ __forceinline__ Best2 resolve_query(const uint32_t* __restrict__ cl, 
         const int l1 = wave_argmin(valid, dist);
         if (l1 < 0) continue;
         const int dd1 = __shfl(dist, l1);
-        const int l2 = wave_argmin(valid && lane != l1, dist);
         best2_push(b, dd1, c0 + l1);
-        if (l2 >= 0) best2_push(b, __shfl(dist, l2), c0 + l2);
+        if (__popcll(__ballot(valid)) > 1) {
+            const int l2 = wave_argmin(valid && lane != l1, dist);
+            if (l2 >= 0) best2_push(b, __shfl(dist, l2), c0 + l2);
+        }
     }
     return b;
 }
@@ -226,7 +268,7 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
                                                         const int* __restrict__ counts, int cap,
                                                         const int* __restrict__ pair_a, const int* __restrict__ pair_b,
                                                         const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
-                                                        float nnratio, int* __restrict__ matches12,
+                                                        float nnratio, int cand_lds, int* __restrict__ matches12,
                                                         float* __restrict__ prev_xy, int* __restrict__ nmatches,
                                                         int* __restrict__ overflow) {
     extern __shared__ int lds[];
@@ -238,22 +280,24 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
     int* vMatchesDistance = lds;
     int* vnMatches21 = lds + cap;
     int* bin_of = lds + 2 * cap;
-    int* m12 = matches12 + (size_t)p * cap;
-    for (int i = lane; i < n2; i += 64) { vMatchesDistance[i] = INT_MAX; vnMatches21[i] = -1; }
-    for (int i = lane; i < n1; i += 64) { bin_of[i] = -1; m12[i] = -1; }
-    if (lane < kHisto) hist[lane] = 0;
-    __syncthreads();
+    int* off = lds + 3 * cap;                       // cap + 1 entries
+    int* m12 = lds + 4 * cap + 1;                   // vnMatches12 (written back at the end)
+    float* ang1 = (float*)(lds + 5 * cap + 1);      // key point angles of both frames: the accept path stays in LDS
+    float* ang2 = (float*)(lds + 6 * cap + 1);
+    uint32_t* ce = (uint32_t*)(lds + 7 * cap + 1);  // cand_lds entries
     const se2gpu_keypoint* k1 = kps + (size_t)fa * cap;
     const se2gpu_keypoint* k2 = kps + (size_t)fb * cap;
+    for (int i = lane; i < n2; i += 64) { vMatchesDistance[i] = INT_MAX; vnMatches21[i] = -1; ang2[i] = k2[i].angle; }
+    for (int i = lane; i < n1; i += 64) { bin_of[i] = -1; m12[i] = -1; ang1[i] = k1[i].angle; }
+    if (lane < kHisto) hist[lane] = 0;
+    const uint32_t* cand_p = cand + (size_t)p * cap * kMaxCand;
+    stage_candidates(cand_p, ncand + (size_t)p * cap, n1, off, ce, cand_lds, overflow);
     const float factor = (float)kHisto / 360.0f;
     for (int i1 = 0; i1 < n1; ++i1) {
-        int n = ncand[(size_t)p * cap + i1];
+        const int o0 = off[i1];
+        const int n = off[i1 + 1] - o0;
         if (n == 0) continue;
-        if (n > kMaxCand) {
-            if (lane == 0) atomicOr(overflow, 1);
-            n = kMaxCand;
-        }
-        const uint32_t* cl = cand + ((size_t)p * cap + i1) * kMaxCand;
+        const uint32_t* cl = (o0 + n <= cand_lds) ? ce + o0 : cand_p + (size_t)i1 * kMaxCand;
         const Best2 b = resolve_query(cl, n, vMatchesDistance);
         if (b.p1 >= 0 && b.d1 <= kThLow && (float)b.d1 < (float)b.d2 * nnratio) {
             if (lane == 0) {
@@ -263,7 +307,7 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
                 m12[i1] = bestIdx2;
                 vnMatches21[bestIdx2] = i1;
                 vMatchesDistance[bestIdx2] = b.d1;
-                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                float rot = ang1[i1] - ang2[bestIdx2];
                 if (rot < 0.0f) rot += 360.f;
                 int bin = (int)roundf(rot * factor);
                 if (bin == kHisto) bin = 0;
@@ -289,6 +333,7 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
             prev_xy[((size_t)p * cap + i) * 2] = k2[m].x;
             prev_xy[((size_t)p * cap + i) * 2 + 1] = k2[m].y;
         }
+        matches12[(size_t)p * cap + i] = m;
     }
     for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
     if (lane == 0) nmatches[p] = cnt;
@@ -355,21 +400,25 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
 __global__ __launch_bounds__(64) void k_resolve_projection(const se2gpu_keypoint* __restrict__ kps, int n, int m,
                                                             const uint32_t* __restrict__ cand,
                                                             const int* __restrict__ ncand, float nnratio,
-                                                            int* __restrict__ match_idx, int* __restrict__ nmatches,
-                                                            int* __restrict__ overflow) {
+                                                            int chunk, int cand_lds, int* __restrict__ match_idx,
+                                                            int* __restrict__ nmatches, int* __restrict__ overflow) {
     extern __shared__ int lds[];
     const int lane = threadIdx.x;
     int* vMatchesDistance = lds;
+    int* off = lds + n;                                  // chunk + 1 entries
+    uint32_t* ce = (uint32_t*)(lds + n + chunk + 1);
     for (int i = lane; i < n; i += 64) { vMatchesDistance[i] = INT_MAX; match_idx[i] = -1; }
     __syncthreads();
-    for (int i = 0; i < m; ++i) {
-        int nc = ncand[i];
+    // map points are processed in chunks whose candidate lists are staged in LDS
+    for (int i0 = 0; i0 < m; i0 += chunk) {
+      const int mq = min(chunk, m - i0);
+      stage_candidates(cand + (size_t)i0 * kMaxCand, ncand + i0, mq, off, ce, cand_lds, overflow);
+      for (int ii = 0; ii < mq; ++ii) {
+        const int i = i0 + ii;
+        const int o0 = off[ii];
+        const int nc = off[ii + 1] - o0;
         if (nc == 0) continue;
-        if (nc > kMaxCand) {
-            if (lane == 0) atomicOr(overflow, 1);
-            nc = kMaxCand;
-        }
-        const uint32_t* cl = cand + (size_t)i * kMaxCand;
+        const uint32_t* cl = (o0 + nc <= cand_lds) ? ce + o0 : cand + (size_t)i * kMaxCand;
         const Best2 b = resolve_query(cl, nc, vMatchesDistance);
         if (b.p1 >= 0 && b.d1 <= kThHigh) {
             const int bestIdx = (int)(cl[b.p1] >> 12);
@@ -382,6 +431,8 @@ __global__ __launch_bounds__(64) void k_resolve_projection(const se2gpu_keypoint
             }
         }
         __syncthreads();
+      }
+      __syncthreads();
     }
     int cnt = 0;
     for (int i = lane; i < n; i += 64) cnt += match_idx[i] >= 0;
@@ -447,10 +498,13 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     hipLaunchKernelGGL(k_cand_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, st, bd, d_kps, d_desc, d_counts, cap,
                        d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win, level_offset, min_level, max_level,
                        h->cand.p, h->ncand.p);
-    const size_t lds = (size_t)3 * cap * sizeof(int);
-    SE2_REQUIRE(lds <= 64 * 1024, SE2GPU_ERR_CAPACITY, "cap %d needs %zu B of LDS in the resolve pass (limit 64 KiB)", cap, lds);
+    const size_t fixed_lds = ((size_t)7 * cap + 1) * sizeof(int);
+    SE2_REQUIRE(fixed_lds + 4096 <= 64 * 1024, SE2GPU_ERR_CAPACITY,
+                "cap %d needs %zu B of LDS in the resolve pass (limit 64 KiB)", cap, fixed_lds);
+    const int cand_lds = (int)((60 * 1024 - fixed_lds) / sizeof(int));  // staged candidate entries
+    const size_t lds = fixed_lds + (size_t)cand_lds * sizeof(int);
     hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(64), lds, st, d_kps, d_counts, cap, d_pair_a, d_pair_b,
-                       h->cand.p, h->ncand.p, nnratio, d_matches12, d_prev, d_nmatches, h->overflow.p);
+                       h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, h->overflow.p);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -598,8 +652,15 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
         hipLaunchKernelGGL(k_cand_projection, dim3((m + 3) / 4), dim3(256), 0, st, bd, cam, h->mp_pos.p, h->mp_desc.p,
                            h->mp_octave.p, h->mp_skip.p, m, h->kps.p, h->desc.p, h->kf_obs.p, h->sorted.p, h->n_grid.p,
                            win_size, level_offset, h->cand.p, h->ncand.p);
-    hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(64), (size_t)n * sizeof(int), st, h->kps.p, n, m, h->cand.p,
-                       h->ncand.p, nnratio, h->matches.p, h->nmatches.p, h->overflow.p);
+    {
+        const int chunk = 1024;
+        const size_t fixed_lds = ((size_t)n + chunk + 1) * sizeof(int);
+        SE2_REQUIRE(fixed_lds + 4096 <= 64 * 1024, SE2GPU_ERR_CAPACITY, "%d key-frame features need %zu B of LDS", n, fixed_lds);
+        const int cand_lds = (int)((60 * 1024 - fixed_lds) / sizeof(int));
+        hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(64), fixed_lds + (size_t)cand_lds * sizeof(int), st, h->kps.p,
+                           n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, h->matches.p, h->nmatches.p,
+                           h->overflow.p);
+    }
     SE2_HIP(hipGetLastError());
     SE2_HIP(hipMemcpyAsync(match_idx_mp, h->matches.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));

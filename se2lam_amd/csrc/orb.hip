@@ -92,10 +92,12 @@ __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restric
 }
 
 // level l >= 1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border.
-// xtab[dx] = {sx, a0, a1, use_one}; ytab[dy] = {sy0, sy1, b0, b1}
+// ytab[dy] = {sy0, sy1, b0, b1} (one entry per row, block-uniform); the x coefficients are evaluated per pixel with
+// exactly cv::resize's arithmetic: fx = (float)((dx + 0.5) * scale_x - 0.5) in double, 11-bit rounding in float.
 struct ResizeTab {
-    const int4* xtab;
     const int4* ytab;
+    double scale_x;   // 1.0 / ((double)dw / sw)
+    int sw;
 };
 
 __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr) {
@@ -114,14 +116,24 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
         const int X = X4 + q;
         uint32_t b = 0;
         if (X < W + 2 * kEdge) {
-            const int4 xt = t.xtab[reflect101(X - kEdge, W)];
+            const int dx = reflect101(X - kEdge, W);
+            float fx = (float)((dx + 0.5) * t.scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0) { fx = 0; sx = 0; }
+            bool one = false;                 // dx >= xmax: S[sx] * ONE (cv::resize's tail loop)
+            if (sx + 1 >= t.sw) {
+                one = true;
+                if (sx >= t.sw - 1) { fx = 0; sx = t.sw - 1; }
+            }
             int r0, r1;
-            if (xt.w) {  // dx >= xmax: S[sx] * ONE
-                r0 = S0[xt.x] * 2048;
-                r1 = S1[xt.x] * 2048;
+            if (one) {
+                r0 = S0[sx] * 2048;
+                r1 = S1[sx] * 2048;
             } else {
-                r0 = S0[xt.x] * xt.y + S0[xt.x + 1] * xt.z;
-                r1 = S1[xt.x] * xt.y + S1[xt.x + 1] * xt.z;
+                const int a0 = (int)rintf((1.f - fx) * 2048.f), a1 = (int)rintf(fx * 2048.f);
+                r0 = S0[sx] * a0 + S0[sx + 1] * a1;
+                r1 = S1[sx] * a0 + S1[sx + 1] * a1;
             }
             b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
         }
@@ -135,31 +147,84 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
 // clamped to [0, 255].  Corner at threshold t  <=>  S > t;  cv::FAST's cornerScore  =  S - 1.
 // One thread per pixel of the scan area [16, w-16) x [16, h-16) of every level (tiles of 64 x 4).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int fast_score(const uint8_t* __restrict__ p, int stride) {
-    const int v = p[0];
-    int d[16];
-    d[0] = v - p[3 * stride];        d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];
-    d[3] = v - p[stride + 3];        d[4] = v - p[3];                d[5] = v - p[-stride + 3];
-    d[6] = v - p[-2 * stride + 2];   d[7] = v - p[-3 * stride + 1];  d[8] = v - p[-3 * stride];
-    d[9] = v - p[-3 * stride - 1];   d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
-    d[12] = v - p[-3];               d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];
-    d[15] = v - p[3 * stride - 1];
-    // sliding min / max over 9 consecutive entries of the circular array by doubling: 2, 4, 8, then +1
-    int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
-    int best = 0;
+typedef short short2v __attribute__((ext_vector_type(2)));
+
+// Two pixels at once in packed int16 lanes (v_pk_min_i16 / v_pk_max_i16): d[k] = v - p_k for the 16 ring pixels.
+__device__ __forceinline__ short2v fast_score_pk(const short2v d[16]) {
+    short2v mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int mn9 = min(mn8[k], d[(k + 8) & 15]);
-        const int mx9 = max(mx8[k], d[(k + 8) & 15]);
-        best = max(best, max(mn9, -mx9));
+        mn2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+        mx2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn4[k] = __builtin_elementwise_min(mn2[k], mn2[(k + 2) & 15]);
+        mx4[k] = __builtin_elementwise_max(mx2[k], mx2[(k + 2) & 15]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        mn8[k] = __builtin_elementwise_min(mn4[k], mn4[(k + 4) & 15]);
+        mx8[k] = __builtin_elementwise_max(mx4[k], mx4[(k + 4) & 15]);
+    }
+    short2v best = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const short2v mn9 = __builtin_elementwise_min(mn8[k], d[(k + 8) & 15]);
+        const short2v mx9 = __builtin_elementwise_max(mx8[k], d[(k + 8) & 15]);
+        best = __builtin_elementwise_max(best, __builtin_elementwise_max(mn9, -mx9));
     }
     return best;
+}
+
+// byte `i` (0..11) of the 12-byte window {w0, w1, w2}
+__device__ __forceinline__ int win_byte(uint32_t w0, uint32_t w1, uint32_t w2, int i) {
+    const uint32_t w = i < 4 ? w0 : (i < 8 ? w1 : w2);
+    return (int)((w >> (8 * (i & 3))) & 0xffu);
+}
+
+// One thread = 4 horizontally adjacent pixels of a vertical strip of kScoreRows rows.  A 7-row x 12-byte sliding
+// window lives in registers (three aligned dwords per row: pixels x0-4 .. x0+7); every input byte is loaded once per
+// thread with 32-bit loads.  Workgroup = 4 waves = 4 strips; a wave spans 64 column groups of which the first and
+// last are halo (their scores feed the neighbours' non-max suppression, they write nothing), and each strip computes
+// one extra row above and below for the same reason.
+//
+// The kernel writes S' = S where S > 7 and S is a strict maximum over the 8-neighbours that lie in the SAME CELL
+// (cv::FAST's non-max suppression inside one FAST call, ORBextractor.cpp:616-623; cells of level l tile the scan area
+// [16, w-16) x [16, h-16) in steps of cellW x cellH), else 0.  k_cell_detect then only collects the non-zero bytes.
+constexpr int kScoreRows = 16;
+constexpr int kScoreGroups = 62;  // useful column groups per wave
+__device__ __forceinline__ uint32_t score_row4(const uint32_t (&w)[7][3]) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp += 2) {
+        short2v d[16];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c = 4 + pp + q;  // centre byte index inside the 12-byte window
+            const int v = win_byte(w[3][0], w[3][1], w[3][2], c);
+            const int ring[16] = {
+                win_byte(w[6][0], w[6][1], w[6][2], c),     win_byte(w[6][0], w[6][1], w[6][2], c + 1),
+                win_byte(w[5][0], w[5][1], w[5][2], c + 2), win_byte(w[4][0], w[4][1], w[4][2], c + 3),
+                win_byte(w[3][0], w[3][1], w[3][2], c + 3), win_byte(w[2][0], w[2][1], w[2][2], c + 3),
+                win_byte(w[1][0], w[1][1], w[1][2], c + 2), win_byte(w[0][0], w[0][1], w[0][2], c + 1),
+                win_byte(w[0][0], w[0][1], w[0][2], c),     win_byte(w[0][0], w[0][1], w[0][2], c - 1),
+                win_byte(w[1][0], w[1][1], w[1][2], c - 2), win_byte(w[2][0], w[2][1], w[2][2], c - 3),
+                win_byte(w[3][0], w[3][1], w[3][2], c - 3), win_byte(w[4][0], w[4][1], w[4][2], c - 3),
+                win_byte(w[5][0], w[5][1], w[5][2], c - 2), win_byte(w[6][0], w[6][1], w[6][2], c - 1)};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k][q] = (short)(v - ring[k]);
+        }
+        const short2v sres = fast_score_pk(d);
+        out |= ((uint32_t)(uint16_t)sres[0] & 0xffu) << (8 * pp);
+        out |= ((uint32_t)(uint16_t)sres[1] & 0xffu) << (8 * (pp + 1));
+    }
+    return out;
+}
+
+// bytes x0-1 .. x0+4 of a score row: own word plus the edge bytes of the neighbouring lanes' words
+__device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t left, uint32_t right) {
+    return (unsigned long long)(left >> 24) | ((unsigned long long)own << 8) | ((unsigned long long)(right & 0xffu) << 40);
 }
 
 __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
@@ -167,14 +232,80 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
     const int t = blockIdx.x - g.tile_base[l];
-    const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;  // scan area size
-    const int tiles_x = (sw + 63) / 64;
-    const int tx = t % tiles_x, ty = t / tiles_x;
-    const int x = kEdge + tx * 64 + (threadIdx.x & 63);
-    const int y = kEdge + ty * 4 + (threadIdx.x >> 6);
-    if (x >= g.w[l] - kEdge || y >= g.h[l] - kEdge || sw <= 0 || sh <= 0) return;
-    const size_t o = pix(g, f, l, y, x);
-    score[o] = (uint8_t)fast_score(pyr + o, g.stride[l]);
+    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
+    const int sw = W - 2 * kEdge;
+    const int tiles_x = (sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups);
+    const int lane = threadIdx.x & 63;
+    const int x0 = kEdge + (t % tiles_x) * (4 * kScoreGroups) + (lane - 1) * 4;  // lane 0 / 63 = halo groups
+    const int y0 = kEdge + ((t / tiles_x) * 4 + (threadIdx.x >> 6)) * kScoreRows;
+    if (y0 >= H - kEdge) return;  // wave-uniform
+    const bool xin = x0 >= kEdge && x0 < W - kEdge;            // this lane's group starts inside the scan area
+    const uint8_t* base = pyr + pix(g, f, l, 0, 0);
+    uint8_t* sbase = score + pix(g, f, l, 0, 0);
+    const int xc = min(max(x0, kEdge), W - kEdge - 1) & ~3;    // clamped (aligned) load position for halo lanes outside
+    uint32_t w[7][3];
+    // window rows y0-4 .. y0+1 so that the first computed score row is y0-1
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)(y0 - 4 + r) * stride + xc - 4);
+        w[r + 1][0] = p[0]; w[r + 1][1] = p[1]; w[r + 1][2] = p[2];
+    }
+    const int yend = min(y0 + kScoreRows, H - kEdge);
+    const int nvalid = xin ? min(4, W - kEdge - x0) : 0;
+    const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
+    // cell-edge flags of the 4 pixels (horizontal): bit q of eL / eR
+    const int cellW = g.cellW[l], cellH = g.cellH[l];
+    unsigned eL = 0, eR = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int xr = x0 + q - kEdge;
+        if (xr >= 0 && xr % cellW == 0) eL |= 1u << q;
+        if (xr >= 0 && (xr % cellW == cellW - 1 || x0 + q == W - kEdge - 1)) eR |= 1u << q;
+    }
+    unsigned long long e_pp = 0, e_p = 0;   // extended score rows y-2, y-1 (relative to the row being computed)
+    for (int y = y0 - 1; y <= yend; ++y) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { w[r][0] = w[r + 1][0]; w[r][1] = w[r + 1][1]; w[r][2] = w[r + 1][2]; }
+        {
+            const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)(y + 3) * stride + xc - 4);
+            w[6][0] = p[0]; w[6][1] = p[1]; w[6][2] = p[2];
+        }
+        uint32_t sw4 = 0;
+        if (y >= kEdge && y < H - kEdge) sw4 = score_row4(w) & vmask;   // rows outside the scan area score 0
+        const uint32_t left = __shfl_up(sw4, 1), right = __shfl_down(sw4, 1);
+        const unsigned long long e_c = ext_row(sw4, lane == 0 ? 0u : left, lane == 63 ? 0u : right);
+        const int yo = y - 1;  // row whose suppression can now be decided
+        if (yo >= y0 && yo < yend && lane >= 1 && lane <= kScoreGroups && nvalid > 0) {
+            uint32_t out = 0;
+            if (((uint32_t)(e_p >> 8) & 0xf8f8f8f8u) != 0) {   // some S > 7 in this dword (rare at fine levels)
+            const int yr = yo - kEdge;
+            const bool eT = yr % cellH == 0, eB = (yr % cellH == cellH - 1) || yo == H - kEdge - 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sc = (int)((e_p >> (8 * (q + 1))) & 0xff);
+                if (sc <= 7) continue;
+                const bool L = !((eL >> q) & 1), R = !((eR >> q) & 1);
+                int m = 0;  // max over the neighbours inside the cell
+                if (L) m = max(m, (int)((e_p >> (8 * q)) & 0xff));
+                if (R) m = max(m, (int)((e_p >> (8 * (q + 2))) & 0xff));
+                if (!eT) {
+                    m = max(m, (int)((e_pp >> (8 * (q + 1))) & 0xff));
+                    if (L) m = max(m, (int)((e_pp >> (8 * q)) & 0xff));
+                    if (R) m = max(m, (int)((e_pp >> (8 * (q + 2))) & 0xff));
+                }
+                if (!eB) {
+                    m = max(m, (int)((e_c >> (8 * (q + 1))) & 0xff));
+                    if (L) m = max(m, (int)((e_c >> (8 * q)) & 0xff));
+                    if (R) m = max(m, (int)((e_c >> (8 * (q + 2))) & 0xff));
+                }
+                if (sc > m) out |= (uint32_t)sc << (8 * q);
+            }
+            }
+            *(uint32_t*)(sbase + (size_t)yo * stride + x0) = out & vmask;
+        }
+        e_pp = e_p;
+        e_p = e_c;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,24 +333,22 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
     const int stride = g.stride[l];
     const uint8_t* base = score + pix(g, f, l, 0, 0);
     if (cw > 0 && ch > 0) {
-        for (int idx = threadIdx.x; idx < cw * ch; idx += 256) {
-            const int x = xa + idx % cw, y = ya + idx / cw;
-            const int s = base[(size_t)y * stride + x];
-            if (s <= 7) continue;
-            bool ismax = true;
+        // scan aligned dwords (4 score bytes); S <= 7 everywhere in a dword is the common case and exits at once
+        const int xs = xa & ~3;
+        const int cw4 = (xb - xs + 3) >> 2;
+        for (int idx = threadIdx.x; idx < cw4 * ch; idx += 256) {
+            const int x4 = xs + 4 * (idx % cw4), y = ya + idx / cw4;
+            const uint32_t word = *(const uint32_t*)(base + (size_t)y * stride + x4);
+            if (word == 0) continue;   // k_fast_score already applied S > 7 and the in-cell non-max suppression
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    if (dx == 0 && dy == 0) continue;
-                    const int xx = x + dx, yy = y + dy;
-                    if (xx < xa || xx >= xb || yy < ya || yy >= yb) continue;  // outside the FAST call: score 0
-                    if (s <= base[(size_t)yy * stride + xx]) ismax = false;
-                }
-            if (!ismax) continue;
-            const int slot = atomicAdd(&s_n, 1);
-            if (s > g.fast_th) atomicAdd(&s_n20, 1);
-            if (slot < kSortCap) keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            for (int q = 0; q < 4; ++q) {
+                const int s = (int)((word >> (8 * q)) & 0xffu);
+                const int x = x4 + q;
+                if (s == 0 || x < xa || x >= xb) continue;
+                const int slot = atomicAdd(&s_n, 1);
+                if (s > g.fast_th) atomicAdd(&s_n20, 1);
+                if (slot < kSortCap) keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            }
         }
     }
     __syncthreads();
@@ -420,40 +549,60 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
 // 7x7 Gaussian, sigma 2, 8-bit fixed point: taps {18,34,49,55,49,34,18} per pass, (v + 2^15) >> 16, saturate.
 // Tile = 64 x 16 outputs per workgroup; reads the un-blurred pyramid (whose frame holds reflect-101 copies).
 // ---------------------------------------------------------------------------------------------
+constexpr int kBlurRows = 32;
+// One thread = 4 adjacent output pixels of a vertical strip of kBlurRows rows; the horizontal 7-tap sums of the last
+// 7 rows stay in registers (sliding window), inputs come in as three aligned dwords per row.  No LDS.
 __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    __shared__ uint8_t tin[22][72];
-    __shared__ int th[22][64];
     const int f = blockIdx.y;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
     const int t = blockIdx.x - g.tile_base[l];
-    const int tiles_x = (g.w[l] + 63) / 64;
-    const int x0 = (t % tiles_x) * 64, y0 = (t / tiles_x) * 16;
     const int W = g.w[l], H = g.h[l], stride = g.stride[l];
+    const int tiles_x = (W + 255) / 256;
+    const int x0 = (t % tiles_x) * 256 + (threadIdx.x & 63) * 4;
+    const int y0 = ((t / tiles_x) * 4 + (threadIdx.x >> 6)) * kBlurRows;
+    if (x0 >= W || y0 >= H) return;
     const uint8_t* src = pyr + pix(g, f, l, 0, 0);
-    for (int idx = threadIdx.x; idx < 22 * 70; idx += 256) {
-        const int r = idx / 70, c = idx % 70;
-        int x = x0 + c - 3, y = y0 + r - 3;
-        x = min(x, W + kEdge - 1);  // stay inside the bordered buffer for partial tiles
-        y = min(y, H + kEdge - 1);
-        tin[r][c] = src[(ptrdiff_t)y * stride + x];
-    }
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < 22 * 64; idx += 256) {
-        const int r = idx / 64, c = idx % 64;
-        const uint8_t* p = &tin[r][c];
-        th[r][c] = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-    }
-    __syncthreads();
     uint8_t* dst = blur + pix(g, f, l, 0, 0);
-    for (int idx = threadIdx.x; idx < 16 * 64; idx += 256) {
-        const int r = idx / 64, c = idx % 64;
-        const int x = x0 + c, y = y0 + r;
-        if (x >= W || y >= H) continue;
-        const int s = 18 * (th[r][c] + th[r + 6][c]) + 34 * (th[r + 1][c] + th[r + 5][c]) +
-                      49 * (th[r + 2][c] + th[r + 4][c]) + 55 * th[r + 3][c];
-        const int v = (s + (1 << 15)) >> 16;
-        dst[(size_t)y * stride + x] = (uint8_t)min(max(v, 0), 255);
+    auto hrow = [&](int y, int h[4]) {
+        const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)y * stride + x0 - 4);
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        int b[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            b[i] = (w0 >> (8 * i)) & 0xff;
+            b[4 + i] = (w1 >> (8 * i)) & 0xff;
+            b[8 + i] = (w2 >> (8 * i)) & 0xff;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)  // output pixel x0+q: bytes b[1+q .. 7+q] = x0+q-3 .. x0+q+3
+            h[q] = 18 * (b[1 + q] + b[7 + q]) + 34 * (b[2 + q] + b[6 + q]) + 49 * (b[3 + q] + b[5 + q]) + 55 * b[4 + q];
+    };
+    int hw[7][4];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) hrow(y0 - 3 + r, hw[r + 1]);
+    const int yend = min(y0 + kBlurRows, H);
+    const int nvalid = min(4, W - x0);
+    for (int y = y0; y < yend; ++y) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hw[r][q] = hw[r + 1][q];
+        hrow(y + 3, hw[6]);
+        uint32_t out = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sacc = 18 * (hw[0][q] + hw[6][q]) + 34 * (hw[1][q] + hw[5][q]) + 49 * (hw[2][q] + hw[4][q]) + 55 * hw[3][q];
+            const int v = min(max((sacc + (1 << 15)) >> 16, 0), 255);
+            out |= (uint32_t)v << (8 * q);
+        }
+        uint32_t* o = (uint32_t*)(dst + (size_t)y * stride + x0);
+        if (nvalid == 4) {
+            *o = out;
+        } else {  // last column group: keep the frame bytes (un-blurred reflect copies) to the right of the interior
+            const uint32_t keep = ~((1u << (8 * nvalid)) - 1u);
+            *o = (*o & keep) | (out & ~keep);
+        }
     }
 }
 
@@ -536,6 +685,7 @@ struct se2gpu_orb {
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
+    double xscale[kMaxLevels] = {0};
     int score_tiles = 0, blur_tiles = 0;
     int score_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
     ~se2gpu_orb() {
@@ -592,8 +742,8 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     h->blur_tile_base[0] = 0;
     for (int l = 0; l < L; ++l) {
         const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;
-        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 63) / 64) * ((sh + 3) / 4);
-        h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 63) / 64) * ((g.h[l] + 15) / 16);
+        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
+        h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 255) / 256) * ((g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows));
     }
     // resize tables
     std::vector<int4> tabs;
@@ -603,22 +753,10 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         const int sw = g.w[l - 1], sh = g.h[l - 1], dw = g.w[l], dh = g.h[l];
         const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
         const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
-        int xmax = dw;
-        std::vector<int4> xt(dw), yt(dh);
-        for (int dx = 0; dx < dw; dx++) {
-            float fx = (float)((dx + 0.5) * scale_x - 0.5);
-            int sx = cv_floor_f(fx);
-            fx -= sx;
-            if (sx < 0) { fx = 0; sx = 0; }
-            if (sx + 1 >= sw) {
-                xmax = std::min(xmax, dx);
-                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
-            }
-            const float cb0 = 1.f - fx, cb1 = fx;
-            auto sat = [](int v) { return std::min(std::max(v, -32768), 32767); };
-            xt[dx] = make_int4(sx, sat(cv_round_f(cb0 * 2048)), sat(cv_round_f(cb1 * 2048)), 0);
-        }
-        for (int dx = xmax; dx < dw; dx++) xt[dx].w = 1;
+        // cv::resize switches to the S[sx]*ONE tail at the first dx whose sx+1 leaves the row and stays there; the
+        // kernel applies the test per pixel, which is identical as long as sx is non-decreasing in dx (it is).
+        (void)dw; (void)scale_x;
+        std::vector<int4> yt(dh);
         auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
         for (int dy = 0; dy < dh; dy++) {
             float fy = (float)((dy + 0.5) * scale_y - 0.5);
@@ -628,8 +766,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
             auto sat = [](int v) { return std::min(std::max(v, -32768), 32767); };
             yt[dy] = make_int4(clip(sy, 0, sh), clip(sy + 1, 0, sh), sat(cv_round_f(cb0 * 2048)), sat(cv_round_f(cb1 * 2048)));
         }
-        h->xtab_off[l] = tabs.size();
-        tabs.insert(tabs.end(), xt.begin(), xt.end());
+        h->xscale[l] = scale_x;
         h->ytab_off[l] = tabs.size();
         tabs.insert(tabs.end(), yt.begin(), yt.end());
     }
@@ -664,7 +801,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
     }
     for (int l = 1; l < L; ++l) {
-        ResizeTab t{h->tabs.p + h->xtab_off[l], h->tabs.p + h->ytab_off[l]};
+        ResizeTab t{h->tabs.p + h->ytab_off[l], h->xscale[l], g.w[l - 1]};
         dim3 grid((g.stride[l] / 4 + 255) / 256, g.h[l] + 2 * kEdge, nframes);
         SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
     }

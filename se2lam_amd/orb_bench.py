@@ -25,28 +25,43 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024):
     ex = ORBextractor(max_batch=B)
     mt = ORBmatcher(0.9, max_features=cap, max_batch=B)
     d_img = capi.DeviceArray.from_numpy(imgs)
-    d_kps = capi.DeviceArray(B * cap * 28)
-    d_desc = capi.DeviceArray(B * cap * 32)
-    d_cnt = capi.DeviceArray(B * 4)
+    # two output sets: the matcher of batch k (its own stream; 1 wave per pair, latency-bound) runs while the
+    # extractor already works on batch k+1
+    bufs = []
+    for _ in range(2):
+        bufs.append(dict(kps=capi.DeviceArray(B * cap * 28), desc=capi.DeviceArray(B * cap * 32),
+                         cnt=capi.DeviceArray(B * 4), m=capi.DeviceArray(B * cap * 4), nm=capi.DeviceArray(B * 4),
+                         done=capi.Timer(), used=False))
     pa = np.arange(B, dtype=np.int32)
     pb = (pa + 1) % B
     d_pa = capi.DeviceArray.from_numpy(pa)
     d_pb = capi.DeviceArray.from_numpy(pb)
-    d_m = capi.DeviceArray(B * cap * 4)
-    d_nm = capi.DeviceArray(B * 4)
+    state = {"k": 0}
 
     def step():
-        ex.extract_batch_device(d_img.ptr, B, 480, 640, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap)
-        ex.sync()   # the matcher runs on its own stream: order the two handles
-        mt.match_window_batch_device(d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap, d_pa.ptr, d_pb.ptr, B, 20, d_m.ptr, d_nm.ptr)
+        b = bufs[state["k"] % 2]
+        state["k"] += 1
+        if b["used"]:
+            b["done"].elapsed_ms()          # host-waits for the match that last read this buffer set (event sync)
+        ex.extract_batch_device(d_img.ptr, B, 480, 640, b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap)
+        ex.sync()                            # extraction of this batch complete (+ capacity check)
+        b["done"].start(mt.stream())
+        mt.match_window_batch_device(b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap, d_pa.ptr, d_pb.ptr, B, 20,
+                                     b["m"].ptr, b["nm"].ptr)
+        b["done"].stop(mt.stream())
+        b["used"] = True
+
+    def drain():
         mt.sync()
 
     for _ in range(warmup):
         step()
+    drain()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    drain()
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -54,8 +69,10 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     fps = world * B * steps / dt
-    cnt = d_cnt.to_numpy(np.int32, (B,))
-    nm = d_nm.to_numpy(np.int32, (B,))
+    last = bufs[(state["k"] - 1) % 2]
+    cnt = last["cnt"].to_numpy(np.int32, (B,))
+    nm = last["nm"].to_numpy(np.int32, (B,))
+    d_kps, d_desc, d_cnt = last["kps"], last["desc"], last["cnt"]
 
     # per-kernel durations (HIP events around every extractor launch, separate pass)
     ex.profile(True)

@@ -18,8 +18,23 @@ def test_pyramid_score_blur_bit_exact(ex, oracle, synth):
     for lv in range(8):
         assert np.array_equal(ex.debug_level(0, lv), oracle.orb_level(img, lv)), f"level {lv}"
         assert np.array_equal(ex.debug_level(0, lv, blurred=True), oracle.orb_level(img, lv, blurred=True)), f"blur {lv}"
-        s_gpu, s_ref = ex.debug_score(0, lv), oracle.orb_score(img, lv)
-        assert np.array_equal(s_gpu[16:-16, 16:-16], s_ref[16:-16, 16:-16]), f"score {lv}"
+        # the device score plane holds S' = S where S > 7 and S is a strict maximum among the 8-neighbours of the
+        # SAME cell (cv::FAST's in-call non-max suppression), else 0
+        s_gpu, s_ref = ex.debug_score(0, lv), oracle.orb_score(img, lv).astype(np.int32)
+        w, h, gcols, grows, cellW, cellH, _ = oracle.orb_geometry(480, 640)[lv]
+        exp = np.zeros_like(s_ref)
+        ys, xs = np.nonzero(s_ref > 7)
+        for y, x in zip(ys, xs):
+            if not (16 <= x < w - 16 and 16 <= y < h - 16):
+                continue
+            cj, ci = min((x - 16) // cellW, gcols - 1), min((y - 16) // cellH, grows - 1)
+            xa, ya = 16 + cj * cellW, 16 + ci * cellH
+            xb = w - 16 if cj == gcols - 1 else xa + cellW
+            yb = h - 16 if ci == grows - 1 else ya + cellH
+            nb = s_ref[max(y - 1, ya):min(y + 2, yb), max(x - 1, xa):min(x + 2, xb)]
+            if (nb >= s_ref[y, x]).sum() == 1:
+                exp[y, x] = s_ref[y, x]
+        assert np.array_equal(s_gpu.astype(np.int32), exp), f"score {lv}"
 
 
 @pytest.mark.parametrize("t", range(10))
