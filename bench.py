@@ -141,12 +141,16 @@ def main():
     B_ba = g_full.algorithmic_bytes_per_iter()
     B_ba_rank = g.algorithmic_bytes_per_iter()
     roofline = None
+    traffic = _pmc_traffic()
     if dom is not None:
         avg_s = kern[dom]["avg_us"] * 1e-6
         achieved = B_ba_rank / avg_s / 1e9
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS,
+            # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, collected with
+            # tools/pmc_summarize.py on this workload; FETCH_SIZE x2 correction) - null when the file has no entry
+            "traffic": (traffic.get(dom, {}).get("traffic_bytes") if world == 1 else None),
             "algorithmic_bytes_per_launch": B_ba_rank, "avg_launch_us": kern[dom]["avg_us"],
             "whole_step_achieved": B_ba * iters_per_s / 1e9,
             "whole_step_frac": B_ba * iters_per_s / 1e9 / HBM_PEAK_GBS,
@@ -158,7 +162,8 @@ def main():
     if not args.no_orb:
         try:
             from se2lam_amd import orb_bench
-            orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch)
+            orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch,
+                                    traffic=traffic if args.orb_batch == 256 else {})
         except ImportError:
             orb_obj = None
         if orb_obj is not None and rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -216,6 +221,14 @@ def _orb_cpu_baseline(synth, nframes, seconds=10.0):
     return {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
                       f"oracle/match_ref.cpp MatchByWindow, 1 thread", "host": _host_desc()}
+
+
+def _pmc_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 def _host_desc():

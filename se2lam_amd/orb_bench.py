@@ -19,7 +19,7 @@ B_ORB = 5_742_474      # algorithmic bytes per frame, SURVEY.md §8(d)
 B_MATCH = 132_000      # algorithmic bytes per frame pair
 
 
-def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024):
+def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, traffic=None):
     B = batch
     imgs = synth.frames(B, start=1000 * rank)
     ex = ORBextractor(max_batch=B)
@@ -89,7 +89,8 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024):
         per_launch_frames = B * (1.0 / 7.0 if dom == "k_resize" else 1.0)
         ach = B_ORB * per_launch_frames / (kern[dom]["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": B_ORB * per_launch_frames,
+                "frac": ach / HBM_PEAK_GBS, "traffic": (traffic or {}).get(dom, {}).get("traffic_bytes"),
+                "algorithmic_bytes_per_launch": B_ORB * per_launch_frames,
                 "avg_launch_us": kern[dom]["avg_us"],
                 "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,
                 "whole_step_frac": (B_ORB + B_MATCH) * fps / world / 1e9 / HBM_PEAK_GBS,
