@@ -262,8 +262,46 @@ __device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& in
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// MatchByWindow greedy pass (ORBmatcher.cpp:292-377), one wave per pair.  Dynamic LDS: vMatchesDistance[n2],
-// vnMatches21[n2], bin_of[n1].
+// Per-lane best / second-best scan of one query's candidate list (ORBmatcher.cpp:308-325; ties go to the earliest
+// list position) against the EFFECTIVE vMatchesDistance the sequential pass would see: the committed value, lowered by
+// the tentative acceptances of EARLIER lanes of the chunk (accMask[idx] bit l' set <=> lane l' currently accepts idx
+// with distance accDist[l']).
+struct LaneBest {
+    int bd, bp, bd2, bp2;
+};
+__device__ __forceinline__ LaneBest lane_scan(const uint32_t* cl, int n, const int* vMatchesDistance,
+                                              const unsigned long long* accMask, const int* accDist, int lane) {
+    LaneBest b{INT_MAX, -1, INT_MAX, -1};
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int t = 0; __any(t < n); ++t) {
+        if (t < n) {
+            const uint32_t pk = cl[t];
+            const int dist = (int)(pk & 0xfffu), idx = (int)(pk >> 12);
+            int eff = vMatchesDistance[idx];
+            unsigned long long m = accMask[idx] & below;
+            while (m) {
+                eff = min(eff, accDist[__ffsll((long long)m) - 1]);
+                m &= m - 1;
+            }
+            if (!(eff <= dist)) {
+                if (dist < b.bd) { b.bd2 = b.bd; b.bp2 = b.bp; b.bd = dist; b.bp = t; }
+                else if (dist < b.bd2) { b.bd2 = dist; b.bp2 = t; }
+            }
+        }
+    }
+    return b;
+}
+
+// MatchByWindow greedy pass (ORBmatcher.cpp:292-377), one wave per pair, parallel over queries.
+// The reference processes queries in index order; query i depends on earlier queries only through
+// vMatchesDistance[idx] of its own candidates.  64 consecutive queries (one per lane) are iterated to a FIXED POINT:
+// in every sweep each lane recomputes (best, second best, accept?) against the committed state plus the tentative
+// acceptances of the lanes below it.  Lane 0 is final after sweep 1, and a lane is final once all lanes below it are,
+// so any fixed point is exactly the sequential result (induction on the lane index); dependency chains are short, so
+// 2-4 sweeps suffice in practice (worst case 64).  The chunk is then committed at once: the highest accepting lane of
+// a target owns it (the sequential eviction chain), every accept feeds the rotation histogram.
+// Dynamic LDS (ints): vMatchesDistance[cap] vnMatches21[cap] bin_of[cap] off[cap+1] m12[cap] ang1[cap] ang2[cap]
+//                     accMask[cap] (64-bit) | staged candidate entries.
 __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __restrict__ kps,
                                                         const int* __restrict__ counts, int cap,
                                                         const int* __restrict__ pair_a, const int* __restrict__ pair_b,
@@ -271,63 +309,87 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
                                                         float nnratio, int cand_lds, int* __restrict__ matches12,
                                                         float* __restrict__ prev_xy, int* __restrict__ nmatches,
                                                         int* __restrict__ overflow) {
-    extern __shared__ int lds[];
-    __shared__ int hist[kHisto];
+    // ALL shared memory is dynamic and the 64-bit array sits at offset 0: with static __shared__ objects in front, the
+    // dynamic base is only 4-byte aligned and 64-bit DS atomics on it misbehave (cdna_hip_programming.md G17)
+    extern __shared__ __attribute__((aligned(16))) int lds[];
     const int p = blockIdx.x;
     const int lane = threadIdx.x;
     const int fa = pair_a[p], fb = pair_b[p];
     const int n1 = min(counts[fa], cap), n2 = min(counts[fb], cap);
-    int* vMatchesDistance = lds;
-    int* vnMatches21 = lds + cap;
-    int* bin_of = lds + 2 * cap;
-    int* off = lds + 3 * cap;                       // cap + 1 entries
-    int* m12 = lds + 4 * cap + 1;                   // vnMatches12 (written back at the end)
-    float* ang1 = (float*)(lds + 5 * cap + 1);      // key point angles of both frames: the accept path stays in LDS
-    float* ang2 = (float*)(lds + 6 * cap + 1);
-    uint32_t* ce = (uint32_t*)(lds + 7 * cap + 1);  // cand_lds entries
+    const int capE = (cap + 3) & ~3;
+    unsigned long long* accMask = (unsigned long long*)lds;                // capE entries = 2*capE ints
+    int* vMatchesDistance = lds + 2 * capE;
+    int* vnMatches21 = lds + 3 * capE;
+    int* bin_of = lds + 4 * capE;
+    int* m12 = lds + 5 * capE;
+    float* ang1 = (float*)(lds + 6 * capE);
+    float* ang2 = (float*)(lds + 7 * capE);
+    int* hist = lds + 8 * capE;                      // 32
+    int* s_ind = lds + 8 * capE + 32;                // 4
+    int* accDist = lds + 8 * capE + 36;              // 64
+    int* off = lds + 8 * capE + 100;                 // cap + 1 entries
+    uint32_t* ce = (uint32_t*)(lds + 9 * capE + 104);
     const se2gpu_keypoint* k1 = kps + (size_t)fa * cap;
     const se2gpu_keypoint* k2 = kps + (size_t)fb * cap;
-    for (int i = lane; i < n2; i += 64) { vMatchesDistance[i] = INT_MAX; vnMatches21[i] = -1; ang2[i] = k2[i].angle; }
+    for (int i = lane; i < n2; i += 64) {
+        vMatchesDistance[i] = INT_MAX; vnMatches21[i] = -1; ang2[i] = k2[i].angle; accMask[i] = 0ull;
+    }
     for (int i = lane; i < n1; i += 64) { bin_of[i] = -1; m12[i] = -1; ang1[i] = k1[i].angle; }
     if (lane < kHisto) hist[lane] = 0;
     const uint32_t* cand_p = cand + (size_t)p * cap * kMaxCand;
     stage_candidates(cand_p, ncand + (size_t)p * cap, n1, off, ce, cand_lds, overflow);
     const float factor = (float)kHisto / 360.0f;
-    for (int i1 = 0; i1 < n1; ++i1) {
-        const int o0 = off[i1];
-        const int n = off[i1 + 1] - o0;
-        if (n == 0) continue;
-        const uint32_t* cl = (o0 + n <= cand_lds) ? ce + o0 : cand_p + (size_t)i1 * kMaxCand;
-        const Best2 b = resolve_query(cl, n, vMatchesDistance);
-        if (b.p1 >= 0 && b.d1 <= kThLow && (float)b.d1 < (float)b.d2 * nnratio) {
-            if (lane == 0) {
-                const int bestIdx2 = (int)(cl[b.p1] >> 12);
-                const int prev = vnMatches21[bestIdx2];
-                if (prev >= 0) m12[prev] = -1;
-                m12[i1] = bestIdx2;
-                vnMatches21[bestIdx2] = i1;
-                vMatchesDistance[bestIdx2] = b.d1;
-                float rot = ang1[i1] - ang2[bestIdx2];
-                if (rot < 0.0f) rot += 360.f;
-                int bin = (int)roundf(rot * factor);
-                if (bin == kHisto) bin = 0;
-                bin_of[i1] = bin;
-                hist[bin] += 1;
+    const unsigned long long bit = 1ull << lane;
+    for (int c0 = 0; c0 < n1; c0 += 64) {
+        const int q = c0 + lane;
+        int n = 0, o0 = 0;
+        if (q < n1) { o0 = off[q]; n = off[q + 1] - o0; }
+        const uint32_t* cl = (o0 + n <= cand_lds) ? ce + o0 : cand_p + (size_t)q * kMaxCand;
+        bool acc = false;
+        int bidx = -1, bd = 0;
+        for (int sweep = 0; sweep < 65; ++sweep) {
+            const LaneBest b = lane_scan(cl, n, vMatchesDistance, accMask, accDist, lane);
+            const bool nacc = b.bp >= 0 && b.bd <= kThLow && (float)b.bd < (float)b.bd2 * nnratio;
+            const int nidx = nacc ? (int)(cl[b.bp] >> 12) : -1;
+            const bool changed = nacc != acc || (nacc && (nidx != bidx || b.bd != bd));
+            const unsigned long long chg = __ballot(changed);
+            __syncthreads();                           // every lane has read the masks of this sweep
+            if (!chg) break;
+            if (changed) {
+                if (acc) atomicAnd(&accMask[bidx], ~bit);
+                if (nacc) { atomicOr(&accMask[nidx], bit); accDist[lane] = b.bd; }
+                acc = nacc; bidx = nidx; bd = b.bd;
             }
+            __syncthreads();
+        }
+        // commit the chunk
+        if (acc) {
+            float rot = ang1[q] - ang2[bidx];
+            if (rot < 0.0f) rot += 360.f;
+            int bin = (int)roundf(rot * factor);
+            if (bin == kHisto) bin = 0;
+            bin_of[q] = bin;
+            atomicAdd(&hist[bin], 1);
+            const unsigned long long am = accMask[bidx];
+            if ((63 - __clzll((long long)am)) == lane) {   // highest accepting lane owns the target
+                const int prev = vnMatches21[bidx];
+                if (prev >= 0) m12[prev] = -1;             // owner from an earlier chunk is evicted
+                vnMatches21[bidx] = q;
+                vMatchesDistance[bidx] = bd;
+                m12[q] = bidx;
+            }                                              // else: evicted by a later lane of this chunk
         }
         __syncthreads();
+        if (acc) accMask[bidx] = 0ull;
+        __syncthreads();
     }
-    __shared__ int s_ind[3];
     if (lane == 0) three_maxima(hist, s_ind[0], s_ind[1], s_ind[2]);
     __syncthreads();
     int cnt = 0;
     for (int i = lane; i < n1; i += 64) {
         const int bin = bin_of[i];
         int m = m12[i];
-        if (bin >= 0 && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2] && m >= 0) {
-            m = -1;
-            m12[i] = -1;
-        }
+        if (bin >= 0 && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2] && m >= 0) m = -1;
         if (m >= 0) {
             ++cnt;
             prev_xy[((size_t)p * cap + i) * 2] = k2[m].x;
@@ -335,7 +397,7 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
         }
         matches12[(size_t)p * cap + i] = m;
     }
-    for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
+    for (int sft = 1; sft < 64; sft <<= 1) cnt += __shfl_xor(cnt, sft);
     if (lane == 0) nmatches[p] = cnt;
 }
 
@@ -498,10 +560,16 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     hipLaunchKernelGGL(k_cand_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, st, bd, d_kps, d_desc, d_counts, cap,
                        d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win, level_offset, min_level, max_level,
                        h->cand.p, h->ncand.p);
-    const size_t fixed_lds = ((size_t)7 * cap + 1) * sizeof(int);
-    SE2_REQUIRE(fixed_lds + 4096 <= 64 * 1024, SE2GPU_ERR_CAPACITY,
-                "cap %d needs %zu B of LDS in the resolve pass (limit 64 KiB)", cap, fixed_lds);
-    const int cand_lds = (int)((60 * 1024 - fixed_lds) / sizeof(int));  // staged candidate entries
+    const size_t fixed_lds = ((size_t)9 * ((cap + 3) & ~3) + 104) * sizeof(int);
+    constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: one wave per pair, occupancy is irrelevant here
+    SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY,
+                "cap %d needs %zu B of LDS in the resolve pass (limit %zu)", cap, fixed_lds, kLdsBudget);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SE2_HIP(hipFuncSetAttribute((const void*)k_resolve_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        attr_set = true;
+    }
+    const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));  // staged candidate entries
     const size_t lds = fixed_lds + (size_t)cand_lds * sizeof(int);
     hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(64), lds, st, d_kps, d_counts, cap, d_pair_a, d_pair_b,
                        h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, h->overflow.p);
