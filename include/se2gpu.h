@@ -89,6 +89,7 @@ int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, si
  *   MatchByWindow        /root/reference/src/ORBmatcher.cpp:278-381   (+ Frame::GetFeaturesInArea,
  *                        PosInGrid: /root/reference/src/Frame.cpp:209-286)
  *   MatchByProjection    /root/reference/src/ORBmatcher.cpp:383-454
+ *   SearchByBoW          /root/reference/src/ORBmatcher.cpp:128-276
  * ------------------------------------------------------------------------------------------ */
 int se2gpu_hamming(const uint8_t* a, const uint8_t* b);  /* host utility, 256-bit Hamming distance */
 
@@ -135,6 +136,20 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
                             const float* Tcw, float fx, float fy, float cx, float cy,
                             const se2gpu_keypoint* kps, const uint8_t* desc, const uint8_t* kf_observed, int n,
                             int win_size, int level_offset, float nnratio, int32_t* match_idx_mp, int* n_matches);
+
+/* SearchByBoW(pKF1, pKF2, mapMatches12, bIfMPOnly) with ORBmatcher(nnratio, checkOri) - ORBmatcher.cpp:128-276.
+ * The DBoW2::FeatureVector of each key frame (std::map<NodeId, std::vector<unsigned>>, computed by the host
+ * vocabulary) is passed as CSR: fv_nodes[nn] ascending node ids, fv_ptr[nn+1], fv_idx[fv_ptr[nn]] feature indices.
+ * has_mp1/2 (n1 / n2 bytes): 1 = the feature has a non-null map point (only read when mp_only != 0).
+ * matches12: n1 ints, index into key frame 2 or -1 (the reference's std::map<int,int> as a dense array). */
+int se2gpu_search_by_bow(se2gpu_matcher* h,
+                         const se2gpu_keypoint* kps1, const uint8_t* desc1, int n1,
+                         const int32_t* fv1_nodes, const int32_t* fv1_ptr, const int32_t* fv1_idx, int nn1,
+                         const uint8_t* has_mp1,
+                         const se2gpu_keypoint* kps2, const uint8_t* desc2, int n2,
+                         const int32_t* fv2_nodes, const int32_t* fv2_ptr, const int32_t* fv2_idx, int nn2,
+                         const uint8_t* has_mp2,
+                         int mp_only, float nnratio, int check_orientation, int32_t* matches12, int* n_matches);
 
 /* ------------------------------------------------------------------------------------------
  * SE(2)-XYZ bundle adjustment  -  replaces the g2o::SparseOptimizer built by

@@ -11,6 +11,7 @@
 //   ComputeThreeMaxima      :64-105
 //   MatchByWindow           :278-381
 //   MatchByProjection       :383-454      (+ cvu::se3map / cvu::camprjc float arithmetic, src/cvutil.cpp:89-106)
+//   SearchByBoW             :128-276      (DBoW2 feature vectors passed as CSR; the vocabulary itself is host code)
 //   Frame::PosInGrid        /root/reference/src/Frame.cpp:209-219   (NOTE: round(), not floor)
 //   Frame::GetFeaturesInArea :222-286     (cell range by floor/ceil, level filter, square |dx|,|dy| <= r test,
 //                                          results in (cell x, cell y, insertion) order)
@@ -270,6 +271,75 @@ int match_ref_projection(const match_ref_bounds* bounds, const float* mp_pos, co
             vMatchesIdxMP[bestIdx] = i;
             vMatchesDistance[bestIdx] = bestDist;
             nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// SearchByBoW (ORBmatcher.cpp:128-276); feature vectors as CSR with ascending node ids
+int match_ref_search_by_bow(const match_ref_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* fv1_nodes,
+                            const int32_t* fv1_ptr, const int32_t* fv1_idx, int nn1, const uint8_t* has_mp1,
+                            const match_ref_keypoint* kps2, const uint8_t* desc2, int n2, const int32_t* fv2_nodes,
+                            const int32_t* fv2_ptr, const int32_t* fv2_idx, int nn2, const uint8_t* has_mp2, int mp_only,
+                            float nnratio, int check_orientation, int32_t* matches12) {
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<char> vbMatched2(n2, 0);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = (float)HISTO_LENGTH / 360.0f;
+    int nmatches = 0;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (fv1_nodes[a] == fv2_nodes[b]) {
+            for (int i1 = fv1_ptr[a]; i1 < fv1_ptr[a + 1]; i1++) {
+                const int idx1 = fv1_idx[i1];
+                if (mp_only && !has_mp1[idx1]) continue;
+                const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+                int bestDist1 = INT_MAX, bestIdx2 = -1, bestDist2 = INT_MAX;
+                for (int i2 = fv2_ptr[b]; i2 < fv2_ptr[b + 1]; i2++) {
+                    const int idx2 = fv2_idx[i2];
+                    if (mp_only && !has_mp2[idx2]) continue;
+                    if (vbMatched2[idx2]) continue;
+                    const int dist = descriptor_distance(d1, desc2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = 1;
+                        if (check_orientation) {
+                            float rot = kps1[idx1].angle - kps2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (fv1_nodes[a] < fv2_nodes[b]) {
+            while (a < nn1 && fv1_nodes[a] < fv2_nodes[b]) a++;   // lower_bound
+        } else {
+            while (b < nn2 && fv2_nodes[b] < fv1_nodes[a]) b++;
+        }
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rotHist[i]) {
+                matches12[idx1] = -1;
+                nmatches--;
+            }
         }
     }
     return nmatches;

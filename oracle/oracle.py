@@ -297,6 +297,24 @@ def _declare_match(l):
                                        C.c_float, C.c_float, VP, VP, VP, C.c_int, C.c_int, C.c_int, C.c_float, VP]
 
 
+def search_by_bow(kps1, desc1, fv1, has_mp1, kps2, desc2, fv2, has_mp2, mp_only=False, nnratio=0.6, check_ori=True):
+    """fv = (nodes, ptr, idx) CSR int32 arrays -> (matches12 (n1,), nmatches)"""
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    a = [np.ascontiguousarray(x, np.int32) for x in fv1]; b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+    h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+    out = np.full(max(len(kps1), 1), -1, np.int32)
+    f = lib().match_ref_search_by_bow
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p] + [C.c_void_p] * 2 + \
+        [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    nm = f(kps1.ctypes.data, desc1.ctypes.data, len(kps1), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+           len(a[0]), h1.ctypes.data, kps2.ctypes.data, desc2.ctypes.data, len(kps2), b[0].ctypes.data,
+           b[1].ctypes.data, b[2].ctypes.data, len(b[0]), h2.ctypes.data, int(mp_only), nnratio, int(check_ori),
+           out.ctypes.data)
+    return out[:len(kps1)].copy(), int(nm)
+
+
 def default_bounds(cols=640, rows=480):
     return Bounds(0.0, 0.0, float(cols), float(rows))
 

@@ -86,6 +86,8 @@ SYMBOLS = {
                                  _VP, C.POINTER(_I)]),
     "se2gpu_match_window_batch_device": (_I, [_VP, C.POINTER(FrameBounds), _VP, _VP, _VP, _I, _VP, _VP, _I, _I, _I,
                                               _I, _I, _F, _VP, _VP]),
+    "se2gpu_search_by_bow": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _I, _F, _I,
+                                  _VP, C.POINTER(_I)]),
     "se2gpu_match_projection": (_I, [_VP, C.POINTER(FrameBounds), _VP, _VP, _VP, _VP, _I, _VP, _F, _F, _F, _F,
                                      _VP, _VP, _VP, _I, _I, _I, _F, _VP, C.POINTER(_I)]),
     # BA

@@ -502,6 +502,91 @@ __global__ __launch_bounds__(64) void k_resolve_projection(const se2gpu_keypoint
     if (lane == 0) nmatches[0] = cnt;
 }
 
+// ---------------------------------------------------------------------------------------------
+// SearchByBoW (ORBmatcher.cpp:128-276).  A feature belongs to exactly one vocabulary node, so the vbMatched2
+// dependency never crosses nodes: one wave per pair of equal nodes replays the reference's loop for that node
+// (idx1 in list order; best / second best over the still unmatched idx2 of the node by wave-ballot arg-min);
+// nodes run in parallel.  The rotation histogram is global (30 atomic counters).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_bow_match(const int2* __restrict__ node_pairs, const int* __restrict__ ptr1,
+                                                   const int* __restrict__ idx1s, const int* __restrict__ ptr2,
+                                                   const int* __restrict__ idx2s, const se2gpu_keypoint* __restrict__ kps1,
+                                                   const uint8_t* __restrict__ desc1, const uint8_t* __restrict__ has1,
+                                                   const se2gpu_keypoint* __restrict__ kps2,
+                                                   const uint8_t* __restrict__ desc2, const uint8_t* __restrict__ has2,
+                                                   int mp_only, float nnratio, int check_ori, int* __restrict__ matches12,
+                                                   int* __restrict__ bin_of, int* __restrict__ hist) {
+    __shared__ unsigned char matched2[2048];
+    const int lane = threadIdx.x;
+    const int2 np = node_pairs[blockIdx.x];
+    const int a0 = ptr1[np.x], a1 = ptr1[np.x + 1], b0 = ptr2[np.y], b1 = ptr2[np.y + 1];
+    const int m2 = min(b1 - b0, 2048);
+    for (int i = lane; i < m2; i += 64) matched2[i] = 0;
+    __syncthreads();
+    const float factor = (float)kHisto / 360.0f;
+    for (int i1 = a0; i1 < a1; ++i1) {
+        const int idx1 = idx1s[i1];
+        if (mp_only && !has1[idx1]) continue;
+        const uint8_t* d1 = desc1 + 32 * (size_t)idx1;
+        Best2 b{INT_MAX, -1, INT_MAX, -1};
+        for (int c0 = 0; c0 < m2; c0 += 64) {
+            const int pos = c0 + lane;
+            bool valid = false;
+            int dist = 0;
+            if (pos < m2) {
+                const int idx2 = idx2s[b0 + pos];
+                valid = !(mp_only && !has2[idx2]) && !matched2[pos];
+                if (valid) dist = hamming256(d1, desc2 + 32 * (size_t)idx2);
+            }
+            const int l1 = wave_argmin(valid, dist);
+            if (l1 < 0) continue;
+            best2_push(b, __shfl(dist, l1), c0 + l1);
+            const int l2 = wave_argmin(valid && lane != l1, dist);
+            if (l2 >= 0) best2_push(b, __shfl(dist, l2), c0 + l2);
+        }
+        if (b.p1 >= 0 && b.d1 < kThLow && (float)b.d1 < nnratio * (float)b.d2) {
+            if (lane == 0) {
+                const int idx2 = idx2s[b0 + b.p1];
+                matches12[idx1] = idx2;
+                matched2[b.p1] = 1;
+                if (check_ori) {
+                    float rot = kps1[idx1].angle - kps2[idx2].angle;
+                    if (rot < 0.0f) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == kHisto) bin = 0;
+                    bin_of[idx1] = bin;
+                    atomicAdd(&hist[bin], 1);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_bow_finish(int n1, int check_ori, const int* __restrict__ bin_of, const int* __restrict__ hist,
+                             int* __restrict__ matches12, int* __restrict__ nmatches) {
+    __shared__ int s_ind[3];
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) {
+        s_cnt = 0;
+        s_ind[0] = s_ind[1] = s_ind[2] = -1;
+        if (check_ori) three_maxima(hist, s_ind[0], s_ind[1], s_ind[2]);
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+        int m = matches12[i];
+        if (check_ori && m >= 0) {
+            const int bin = bin_of[i];
+            if (bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2]) { m = -1; matches12[i] = -1; }
+        }
+        cnt += m >= 0;
+    }
+    atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) nmatches[0] = s_cnt;
+}
+
 Bounds make_bounds(const se2gpu_frame_bounds& b) {
     Bounds o;
     o.min_x = b.min_x; o.min_y = b.min_y; o.max_x = b.max_x; o.max_y = b.max_y;
@@ -520,7 +605,9 @@ struct se2gpu_matcher {
     DevBuf<int> n_grid, ncand, overflow, pair_a, pair_b, counts, matches, nmatches, mp_octave;
     DevBuf<float> prev, mp_pos;
     DevBuf<se2gpu_keypoint> kps;
-    DevBuf<uint8_t> desc, mp_desc, mp_skip, kf_obs;
+    DevBuf<uint8_t> desc, mp_desc, mp_skip, kf_obs, has1, has2;
+    DevBuf<int> fvp1, fvi1, fvp2, fvi2, bin_of, hist;
+    DevBuf<int2> node_pairs;
     ~se2gpu_matcher() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
@@ -733,6 +820,87 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     SE2_HIP(hipMemcpyAsync(match_idx_mp, h->matches.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));
     return check_overflow(h);
+}
+
+int se2gpu_search_by_bow(se2gpu_matcher* h, const se2gpu_keypoint* kps1, const uint8_t* desc1, int n1,
+                         const int32_t* fv1_nodes, const int32_t* fv1_ptr, const int32_t* fv1_idx, int nn1,
+                         const uint8_t* has_mp1, const se2gpu_keypoint* kps2, const uint8_t* desc2, int n2,
+                         const int32_t* fv2_nodes, const int32_t* fv2_ptr, const int32_t* fv2_idx, int nn2,
+                         const uint8_t* has_mp2, int mp_only, float nnratio, int check_orientation, int32_t* matches12,
+                         int* n_matches) {
+    SE2_REQUIRE(h && n_matches, SE2GPU_ERR_INVALID, "search_by_bow: NULL argument");
+    SE2_REQUIRE(n1 >= 0 && n2 >= 0 && n1 <= h->max_features && n2 <= h->max_features && nn1 >= 0 && nn2 >= 0,
+                SE2GPU_ERR_CAPACITY, "search_by_bow: sizes out of range");
+    *n_matches = 0;
+    if (n1 == 0) return SE2GPU_OK;
+    SE2_REQUIRE(kps1 && desc1 && matches12 && (nn1 == 0 || (fv1_nodes && fv1_ptr && fv1_idx)) &&
+                    (n2 == 0 || (kps2 && desc2)) && (nn2 == 0 || (fv2_nodes && fv2_ptr && fv2_idx)) &&
+                    (!mp_only || (has_mp1 && (n2 == 0 || has_mp2))),
+                SE2GPU_ERR_INVALID, "search_by_bow: NULL buffer");
+    // merge walk over the two ascending node lists (host: hundreds of nodes) -> pairs of equal nodes
+    std::vector<int2> pairs;
+    for (int a = 0, b = 0; a < nn1 && b < nn2;) {
+        if (fv1_nodes[a] == fv2_nodes[b]) { pairs.push_back(make_int2(a, b)); ++a; ++b; }
+        else if (fv1_nodes[a] < fv2_nodes[b]) ++a;
+        else ++b;
+    }
+    for (int k = 0; k < nn1; ++k)
+        SE2_REQUIRE(fv1_ptr[k] <= fv1_ptr[k + 1], SE2GPU_ERR_INVALID, "search_by_bow: fv1_ptr is not monotone");
+    for (int k = 0; k < nn2; ++k) {
+        SE2_REQUIRE(fv2_ptr[k] <= fv2_ptr[k + 1], SE2GPU_ERR_INVALID, "search_by_bow: fv2_ptr is not monotone");
+        SE2_REQUIRE(fv2_ptr[k + 1] - fv2_ptr[k] <= 2048, SE2GPU_ERR_CAPACITY, "search_by_bow: more than 2048 features in one node");
+    }
+    hipStream_t st = h->stream;
+    const int t1 = nn1 ? fv1_ptr[nn1] : 0, t2 = nn2 ? fv2_ptr[nn2] : 0;
+    SE2_CHECK(h->kps.reserve((size_t)n1 + n2 + 1));
+    SE2_CHECK(h->desc.reserve(((size_t)n1 + n2 + 1) * 32));
+    SE2_CHECK(h->has1.reserve((size_t)n1 + 1));
+    SE2_CHECK(h->has2.reserve((size_t)n2 + 1));
+    SE2_CHECK(h->fvp1.reserve((size_t)nn1 + 2));
+    SE2_CHECK(h->fvp2.reserve((size_t)nn2 + 2));
+    SE2_CHECK(h->fvi1.reserve((size_t)t1 + 1));
+    SE2_CHECK(h->fvi2.reserve((size_t)t2 + 1));
+    SE2_CHECK(h->matches.reserve((size_t)n1));
+    SE2_CHECK(h->bin_of.reserve((size_t)n1));
+    SE2_CHECK(h->hist.reserve(32));
+    SE2_CHECK(h->nmatches.reserve(1));
+    SE2_CHECK(h->node_pairs.reserve(pairs.size() + 1));
+    se2gpu_keypoint* d_k2 = h->kps.p + n1;
+    uint8_t* d_d2 = h->desc.p + (size_t)n1 * 32;
+    SE2_HIP(hipMemcpyAsync(h->kps.p, kps1, (size_t)n1 * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
+    if (n2) {
+        SE2_HIP(hipMemcpyAsync(d_k2, kps2, (size_t)n2 * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
+        SE2_HIP(hipMemcpyAsync(d_d2, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+    }
+    if (mp_only) {
+        SE2_HIP(hipMemcpyAsync(h->has1.p, has_mp1, (size_t)n1, hipMemcpyHostToDevice, st));
+        if (n2) SE2_HIP(hipMemcpyAsync(h->has2.p, has_mp2, (size_t)n2, hipMemcpyHostToDevice, st));
+    }
+    if (nn1) {
+        SE2_HIP(hipMemcpyAsync(h->fvp1.p, fv1_ptr, ((size_t)nn1 + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        if (t1) SE2_HIP(hipMemcpyAsync(h->fvi1.p, fv1_idx, (size_t)t1 * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    if (nn2) {
+        SE2_HIP(hipMemcpyAsync(h->fvp2.p, fv2_ptr, ((size_t)nn2 + 1) * sizeof(int), hipMemcpyHostToDevice, st));
+        if (t2) SE2_HIP(hipMemcpyAsync(h->fvi2.p, fv2_idx, (size_t)t2 * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    if (!pairs.empty())
+        SE2_HIP(hipMemcpyAsync(h->node_pairs.p, pairs.data(), pairs.size() * sizeof(int2), hipMemcpyHostToDevice, st));
+    SE2_HIP(hipMemsetAsync(h->matches.p, 0xff, (size_t)n1 * sizeof(int), st));
+    SE2_HIP(hipMemsetAsync(h->bin_of.p, 0xff, (size_t)n1 * sizeof(int), st));
+    SE2_HIP(hipMemsetAsync(h->hist.p, 0, 32 * sizeof(int), st));
+    if (!pairs.empty())
+        hipLaunchKernelGGL(k_bow_match, dim3((unsigned)pairs.size()), dim3(64), 0, st, h->node_pairs.p, h->fvp1.p, h->fvi1.p,
+                           h->fvp2.p, h->fvi2.p, h->kps.p, h->desc.p, h->has1.p, d_k2, d_d2, h->has2.p, mp_only, nnratio,
+                           check_orientation, h->matches.p, h->bin_of.p, h->hist.p);
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, n1, check_orientation, h->bin_of.p, h->hist.p, h->matches.p,
+                       h->nmatches.p);
+    SE2_HIP(hipGetLastError());
+    SE2_HIP(hipMemcpyAsync(matches12, h->matches.p, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    return SE2GPU_OK;
 }
 
 }  // extern "C"

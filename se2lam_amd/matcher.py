@@ -72,6 +72,23 @@ class ORBmatcher:
                                                       out.ctypes.data, C.byref(nm)))
         return nm.value, out[:n].copy()
 
+    def SearchByBoW(self, kps1, desc1, fv1, has_mp1, kps2, desc2, fv2, has_mp2, bIfMPOnly=True, checkOri=True):
+        """ORBmatcher.h:55 SearchByBoW(pKF1, pKF2, mapMatches12, bIfMPOnly).  fv = (nodes, ptr, idx) int32 CSR of the
+        key frame's DBoW2::FeatureVector (host vocabulary).  -> (nmatches, matches12 (n1,), -1 = no match)"""
+        kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        a = [np.ascontiguousarray(x, np.int32) for x in fv1]; b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+        h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        out = np.full(max(len(kps1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        capi.check(capi.lib().se2gpu_search_by_bow(self._h, kps1.ctypes.data, desc1.ctypes.data, len(kps1),
+                                                   a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, len(a[0]),
+                                                   h1.ctypes.data, kps2.ctypes.data, desc2.ctypes.data, len(kps2),
+                                                   b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data, len(b[0]),
+                                                   h2.ctypes.data, int(bIfMPOnly), self.mfNNratio, int(checkOri),
+                                                   out.ctypes.data, C.byref(nm)))
+        return nm.value, out[:len(kps1)].copy()
+
     # -- batched, device resident -----------------------------------------------------------
     def match_window_batch_device(self, d_kps, d_desc, d_counts, cap, d_pair_a, d_pair_b, npairs, winSize,
                                   d_matches12, d_nmatches, levelOffset=1, minLevel=0, maxLevel=8, frame_bounds=None):

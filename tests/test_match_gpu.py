@@ -130,6 +130,43 @@ def test_match_by_projection_edge_cases(oracle, feats):
     assert nm == nm_ref and np.array_equal(idx, idx_ref)
 
 
+def _feature_vector(desc, nbits):
+    """Stand-in for DBoW2::FeatureVector: node = the first `nbits` descriptor bits; CSR with ascending node ids."""
+    node = (desc[:, 0].astype(np.int32) | (desc[:, 1].astype(np.int32) << 8)) & ((1 << nbits) - 1)
+    order = np.argsort(node, kind="stable")
+    nodes, counts = np.unique(node[order], return_counts=True)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return nodes.astype(np.int32), ptr, order.astype(np.int32)
+
+
+@pytest.mark.parametrize("nbits,mp_only,ratio", [(5, False, 0.6), (3, True, 0.6), (0, False, 0.9), (7, True, 0.75)])
+def test_search_by_bow_exact(oracle, feats, nbits, mp_only, ratio):
+    """GlobalMapper::VerifyLoopClose / Localizer call (GlobalMapper.cpp:274-276): SearchByBoW(KF1, KF2, map, false)"""
+    from se2lam_amd.matcher import ORBmatcher
+    (k1, d1), (k2, d2) = feats[0], feats[2]
+    rng = np.random.default_rng(nbits)
+    fv1, fv2 = _feature_vector(d1, nbits), _feature_vector(d2, nbits)
+    if nbits >= 5:  # drop a few nodes on each side so that the merge walk has to skip
+        keep1 = rng.random(len(fv1[0])) > 0.2; keep2 = rng.random(len(fv2[0])) > 0.2
+        def sub(fv, keep):
+            nodes, ptr, idx = fv
+            segs = [idx[ptr[i]:ptr[i + 1]] for i in range(len(nodes)) if keep[i]]
+            return nodes[keep], np.concatenate([[0], np.cumsum([len(x) for x in segs])]).astype(np.int32), \
+                (np.concatenate(segs) if segs else np.zeros(0, np.int32)).astype(np.int32)
+        fv1, fv2 = sub(fv1, keep1), sub(fv2, keep2)
+    h1 = (rng.random(len(k1)) < 0.7).astype(np.uint8); h2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    mt = ORBmatcher(ratio)
+    nm, m12 = mt.SearchByBoW(k1, d1, fv1, h1, k2, d2, fv2, h2, bIfMPOnly=mp_only)
+    m_ref, nm_ref = oracle.search_by_bow(k1, d1, fv1, h1, k2, d2, fv2, h2, mp_only, ratio, True)
+    assert nm == nm_ref and np.array_equal(m12, m_ref)
+    if nbits <= 5 and not mp_only:
+        assert nm > 20
+    # without the orientation check
+    nm2, m2 = mt.SearchByBoW(k1, d1, fv1, h1, k2, d2, fv2, h2, bIfMPOnly=mp_only, checkOri=False)
+    m_ref2, nm_ref2 = oracle.search_by_bow(k1, d1, fv1, h1, k2, d2, fv2, h2, mp_only, ratio, False)
+    assert nm2 == nm_ref2 and np.array_equal(m2, m_ref2) and nm2 >= nm
+
+
 def test_batched_extract_and_match_device_resident(oracle, synth):
     """The throughput path of bench.py: frames stay in HBM from the extractor to the matcher."""
     from se2lam_amd import capi
