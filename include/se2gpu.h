@@ -212,6 +212,17 @@ double se2gpu_ba_chi2(se2gpu_ba* h);                          /* activeRobustChi
  * S (3P x 3P row-major, fixed poses -> identity rows), bs (3P).  P counts poses in add order. */
 int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs);
 
+/* Per-observation information matrices of Map::loadLocalGraph (/root/reference/src/Map.cpp:1024-1049), SURVEY §8f.1:
+ *   Sigma = s_rot * J_r J_r^T + s_z * J_z J_z^T + sigma2 * I,   Omega = Sigma^-1       (2x2, FP64)
+ *   J_r = (J_pi Rcw skew(lw - p))[:, 0:2],  J_z = -(J_pi Rcw)[:, 2],  J_pi from the stored camera-frame point lc.
+ * Host buffers: lc, lw (E x 3 float: KeyFrame::mViewMPs[ftrIdx], MapPoint::getPos()), e_kf (E, index into the P
+ * key frames), sigma2 (E float: mvLevelSigma2[octave]), Rcw (P x 9 float, row-major rotation of KeyFrame::Tcw),
+ * twb_xy (P x 2 float: Twb.x, Twb.y), fx = Config::fxCam, xrot_info / z_info = Config::PLANEMOTION_XROT_INFO / _Z_INFO.
+ * info_out: E x 4 doubles (row-major 2x2), ready for se2gpu_ba_add_edge_se2xyz. */
+int se2gpu_ba_edge_information(int E, const float* lc, const float* lw, const int32_t* e_kf, const float* sigma2, int P,
+                               const float* Rcw, const float* twb_xy, float fx, float xrot_info, float z_info,
+                               double* info_out);
+
 /* Multi-GPU (landmark-sharded) BA, SURVEY.md §8e: every rank holds all poses and a shard of the
  * landmarks (+ their edges); odometry edges live on one rank.  Once per LM trial the library calls
  *     allreduce(dev_ptr, count_doubles, hip_stream, user)

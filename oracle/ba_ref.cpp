@@ -450,6 +450,46 @@ void ba_ref_reduced_system(const ba_ref_problem* p, const double* poses, const d
     if (Hll) std::memcpy(Hll, sys.Hll.data(), sys.Hll.size() * sizeof(double));
 }
 
+// Per-observation information of Map::loadLocalGraph (src/Map.cpp:1024-1049), same argument layout as
+// se2gpu_ba_edge_information.  Doubles promoted from the float members exactly where the reference promotes them.
+void ba_ref_edge_information(int E, const float* lc_, const float* lw_, const int32_t* e_kf, const float* sigma2, int P,
+                             const float* Rcw_, const float* twb_xy, float fx, float xrot_info, float z_info, double* out) {
+    (void)P;
+    for (int k = 0; k < E; ++k) {
+        const double lc[3] = {lc_[3 * k], lc_[3 * k + 1], lc_[3 * k + 2]};
+        const double lw[3] = {lw_[3 * k], lw_[3 * k + 1], lw_[3 * k + 2]};
+        const int kf = e_kf[k];
+        double Rcw[9];
+        for (int i = 0; i < 9; ++i) Rcw[i] = Rcw_[9 * kf + i];
+        const double pi[3] = {twb_xy[2 * kf], twb_xy[2 * kf + 1], 0.0};
+        const double zc = lc[2];
+        const double zc_inv = 1. / zc;
+        const double zc_inv2 = zc_inv * zc_inv;
+        const double Jpi[6] = {fx * zc_inv, 0, -fx * lc[0] * zc_inv2, 0, fx * zc_inv, -fx * lc[1] * zc_inv2};
+        double A[6];  // J_pi * Rcw
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c) A[r * 3 + c] = Jpi[r * 3] * Rcw[c] + Jpi[r * 3 + 1] * Rcw[3 + c] + Jpi[r * 3 + 2] * Rcw[6 + c];
+        const double d[3] = {lw[0] - pi[0], lw[1] - pi[1], lw[2] - pi[2]};
+        const double sk[9] = {0, -d[2], d[1], d[2], 0, -d[0], -d[1], d[0], 0};
+        double Jr[4];  // (A * skew(d))[:, 0:2]
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 2; ++c) Jr[r * 2 + c] = A[r * 3] * sk[c] + A[r * 3 + 1] * sk[3 + c] + A[r * 3 + 2] * sk[6 + c];
+        const double Jz[2] = {-A[2], -A[5]};
+        const float Sigma_rotxy = (float)(1. / xrot_info);
+        const float Sigma_z = (float)(1. / z_info);
+        const double s2 = sigma2[k];
+        double S[4];
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 2; ++c)
+                S[r * 2 + c] = Sigma_rotxy * (Jr[r * 2] * Jr[c * 2] + Jr[r * 2 + 1] * Jr[c * 2 + 1]) + Sigma_z * Jz[r] * Jz[c] +
+                               (r == c ? s2 : 0.0);
+        const double det = S[0] * S[3] - S[1] * S[2];
+        const double id = 1.0 / det;
+        out[4 * k + 0] = S[3] * id; out[4 * k + 1] = -S[1] * id;
+        out[4 * k + 2] = -S[2] * id; out[4 * k + 3] = S[0] * id;
+    }
+}
+
 // mode 0 = Levenberg-Marquardt with g2o's policy (the reference behaviour, optimizer.h:32)
 // mode 1 = plain Gauss-Newton (lambda = 0, every step accepted) - "GN iteration" of BASELINE.json
 // stop_flag mirrors SparseOptimizer::setForceStopFlag (LocalMapper.cpp:246); may be NULL.

@@ -163,6 +163,20 @@ def ba_edge_se2xyz(g, pose, lw, uv):
     return e, Jp, Jl
 
 
+def ba_edge_information(lc, lw, e_kf, sigma2, Rcw, twb_xy, fx, xrot_info=1e6, z_info=1.0):
+    lc = np.ascontiguousarray(lc, np.float32); lw = np.ascontiguousarray(lw, np.float32)
+    e_kf = np.ascontiguousarray(e_kf, np.int32); sigma2 = np.ascontiguousarray(sigma2, np.float32)
+    Rcw = np.ascontiguousarray(Rcw, np.float32).reshape(-1, 9); twb_xy = np.ascontiguousarray(twb_xy, np.float32)
+    E = len(e_kf)
+    out = np.zeros((max(E, 1), 2, 2))
+    f = lib().ba_ref_edge_information
+    f.restype = None
+    f.argtypes = [C.c_int] + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 2 + [C.c_float] * 3 + [C.c_void_p]
+    f(E, lc.ctypes.data, lw.ctypes.data, e_kf.ctypes.data, sigma2.ctypes.data, len(Rcw), Rcw.ctypes.data,
+      twb_xy.ctypes.data, fx, xrot_info, z_info, out.ctypes.data)
+    return out[:E]
+
+
 def ba_edge_pre_se2(pi, pj, z):
     pi = np.ascontiguousarray(pi, np.float64); pj = np.ascontiguousarray(pj, np.float64)
     z = np.ascontiguousarray(z, np.float64)

@@ -115,6 +115,7 @@ SYMBOLS = {
     "se2gpu_ba_set_allreduce": (_I, [_VP, ALLREDUCE_FN, _VP, _VP]),
     "se2gpu_ba_set_shard": (_I, [_VP, _I, _I]),
     "se2gpu_ba_shard_landmarks": (_I, [_I, _I, _PI32, _PI32, _I, _PI32]),
+    "se2gpu_ba_edge_information": (_I, [_I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _F, _F, _F, _VP]),
     "se2gpu_ba_profile": (_I, [_VP, _I]),
     "se2gpu_ba_profile_get": (_I, [_VP, _I, C.POINTER(C.c_char_p), _PD, C.POINTER(C.c_int64)]),
     # timers / memory

@@ -997,6 +997,40 @@ struct EdgeOdo {
 
 }  // namespace
 
+// Map::loadLocalGraph's per-observation information (src/Map.cpp:1024-1049), one thread per edge
+__global__ void k_edge_information(int E, const float* __restrict__ lc_, const float* __restrict__ lw_,
+                                   const int* __restrict__ e_kf, const float* __restrict__ sigma2,
+                                   const float* __restrict__ Rcw_, const float* __restrict__ twb, float fx,
+                                   float s_rot, float s_z, double* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= E) return;
+    const double lc0 = lc_[3 * k], lc1 = lc_[3 * k + 1], lc2 = lc_[3 * k + 2];
+    const int kf = e_kf[k];
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rcw_[9 * kf + i];
+    const double zi = 1. / lc2, zi2 = zi * zi;
+    const double j00 = fx * zi, j02 = -fx * lc0 * zi2, j12 = -fx * lc1 * zi2;
+    double A[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        A[c] = j00 * R[c] + j02 * R[6 + c];
+        A[3 + c] = j00 * R[3 + c] + j12 * R[6 + c];
+    }
+    const double d0 = (double)lw_[3 * k] - (double)twb[2 * kf], d1 = (double)lw_[3 * k + 1] - (double)twb[2 * kf + 1];
+    const double d2 = (double)lw_[3 * k + 2];
+    // (A * skew(d))[:, 0] = A[:,1]*d2 - A[:,2]*d1 ; [:, 1] = -A[:,0]*d2 + A[:,2]*d0
+    const double r00 = A[1] * d2 - A[2] * d1, r01 = -A[0] * d2 + A[2] * d0;
+    const double r10 = A[4] * d2 - A[5] * d1, r11 = -A[3] * d2 + A[5] * d0;
+    const double z0 = -A[2], z1 = -A[5];
+    const double s2 = sigma2[k];
+    const double S00 = s_rot * (r00 * r00 + r01 * r01) + s_z * z0 * z0 + s2;
+    const double S01 = s_rot * (r00 * r10 + r01 * r11) + s_z * z0 * z1;
+    const double S11 = s_rot * (r10 * r10 + r11 * r11) + s_z * z1 * z1 + s2;
+    const double id = 1.0 / (S00 * S11 - S01 * S01);
+    out[4 * k] = S11 * id; out[4 * k + 1] = -S01 * id; out[4 * k + 2] = -S01 * id; out[4 * k + 3] = S00 * id;
+}
+
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
@@ -1733,6 +1767,36 @@ int se2gpu_ba_profile_get(se2gpu_ba* h, int idx, const char** name, double* ms, 
     if (name) *name = h->prof.slots[idx].name;
     if (ms) *ms = h->prof.slots[idx].ms;
     if (launches) *launches = h->prof.slots[idx].launches;
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_edge_information(int E, const float* lc, const float* lw, const int32_t* e_kf, const float* sigma2, int P,
+                               const float* Rcw, const float* twb_xy, float fx, float xrot_info, float z_info,
+                               double* info_out) {
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
+    SE2_REQUIRE(E >= 0 && P >= 0, SE2GPU_ERR_INVALID, "edge_information: negative size");
+    if (E == 0) return SE2GPU_OK;
+    SE2_REQUIRE(lc && lw && e_kf && sigma2 && Rcw && twb_xy && info_out && P > 0, SE2GPU_ERR_INVALID,
+                "edge_information: NULL argument");
+    for (int k = 0; k < E; ++k)
+        SE2_REQUIRE(e_kf[k] >= 0 && e_kf[k] < P, SE2GPU_ERR_INVALID, "edge %d references key frame %d of %d", k, e_kf[k], P);
+    DevBuf<float> d_lc, d_lw, d_s2, d_R, d_t;
+    DevBuf<int> d_kf;
+    DevBuf<double> d_out;
+    hipStream_t st = nullptr;
+    SE2_CHECK(d_lc.upload(lc, 3 * (size_t)E, st));
+    SE2_CHECK(d_lw.upload(lw, 3 * (size_t)E, st));
+    SE2_CHECK(d_kf.upload(e_kf, (size_t)E, st));
+    SE2_CHECK(d_s2.upload(sigma2, (size_t)E, st));
+    SE2_CHECK(d_R.upload(Rcw, 9 * (size_t)P, st));
+    SE2_CHECK(d_t.upload(twb_xy, 2 * (size_t)P, st));
+    SE2_CHECK(d_out.reserve(4 * (size_t)E));
+    const float s_rot = (float)(1. / xrot_info), s_z = (float)(1. / z_info);
+    hipLaunchKernelGGL(k_edge_information, grid1(E, 256), dim3(256), 0, st, E, d_lc.p, d_lw.p, d_kf.p, d_s2.p, d_R.p,
+                       d_t.p, fx, s_rot, s_z, d_out.p);
+    SE2_HIP(hipGetLastError());
+    SE2_HIP(hipMemcpyAsync(info_out, d_out.p, 4 * (size_t)E * sizeof(double), hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
     return SE2GPU_OK;
 }
 

@@ -216,3 +216,16 @@ def shard_landmarks(L: int, e_kf: np.ndarray, e_lm: np.ndarray, world: int) -> n
     capi.check(capi.lib().se2gpu_ba_shard_landmarks(int(L), int(e_kf.size), e_kf.ctypes.data_as(P32),
                                                      e_lm.ctypes.data_as(P32), int(world), owner.ctypes.data_as(P32)))
     return owner
+
+
+def edge_information(lc, lw, e_kf, sigma2, Rcw, twb_xy, fx, xrot_info=1e6, z_info=1.0) -> np.ndarray:
+    """Map::loadLocalGraph's per-observation information (Map.cpp:1024-1049) on the device -> (E, 2, 2) float64."""
+    lc = np.ascontiguousarray(lc, np.float32); lw = np.ascontiguousarray(lw, np.float32)
+    e_kf = np.ascontiguousarray(e_kf, np.int32); sigma2 = np.ascontiguousarray(sigma2, np.float32)
+    Rcw = np.ascontiguousarray(Rcw, np.float32).reshape(-1, 9); twb_xy = np.ascontiguousarray(twb_xy, np.float32)
+    E, P = len(e_kf), len(Rcw)
+    out = np.zeros((max(E, 1), 2, 2))
+    capi.check(capi.lib().se2gpu_ba_edge_information(E, lc.ctypes.data, lw.ctypes.data, e_kf.ctypes.data,
+                                                     sigma2.ctypes.data, P, Rcw.ctypes.data, twb_xy.ctypes.data,
+                                                     float(fx), float(xrot_info), float(z_info), out.ctypes.data))
+    return out[:E]

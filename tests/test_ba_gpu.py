@@ -231,3 +231,17 @@ def test_landmark_sharded_two_ranks_on_one_gpu(oracle, synth):
         assert np.allclose(st["chi2_hist"], single.stats["chi2_hist"], rtol=1e-9)
         assert np.allclose(poses, single.estimates()[0], rtol=1e-9, atol=1e-9)
     assert np.array_equal(results[0][1][0], results[1][1][0])  # replicated poses stay identical
+
+
+def test_edge_information_on_device(oracle, synth):
+    """SURVEY §8f.1: Map::loadLocalGraph's per-observation information (Map.cpp:1024-1049) computed on the GPU."""
+    from se2lam_amd import optimizer as op
+    from test_ba_oracle import _info_inputs
+    for P, L in ((12, 200), (50, 5000)):
+        inp, g, _ = _info_inputs(synth, P, L)
+        got = op.edge_information(**inp)
+        ref = oracle.ba_edge_information(**inp)
+        assert got.shape == ref.shape == (g.E, 2, 2)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert op.edge_information(inp["lc"][:0], inp["lw"][:0], inp["e_kf"][:0], inp["sigma2"][:0], inp["Rcw"],
+                               inp["twb_xy"], inp["fx"]).shape == (0, 2, 2)

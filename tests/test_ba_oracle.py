@@ -188,3 +188,36 @@ def test_library_shard_partition_matches_generator(synth):
         assert np.array_equal(own, ref)
         cnt = np.bincount(own[g.e_lm], minlength=world)
         assert cnt.min() > 0.9 * g.E / world and cnt.max() < 1.1 * g.E / world
+
+
+def _info_inputs(synth, P=12, L=200, seed=0):
+    """Inputs of Map::loadLocalGraph's information computation (Map.cpp:1024-1049) for a synthetic window."""
+    g = synth.ba_graph(P, L)
+    rng = np.random.default_rng(seed)
+    Rcb = g.Rbc.T
+    tcb = -Rcb @ g.tbc
+    _, _, _, lc = synth._project(g.poses, g.lms, g.e_kf, g.e_lm, Rcb, tcb, g.fx, 0.0, 0.0)
+    th = g.poses[:, 2]
+    Rbw = np.zeros((g.P, 3, 3))
+    Rbw[:, 0, 0] = np.cos(th); Rbw[:, 0, 1] = np.sin(th); Rbw[:, 1, 0] = -np.sin(th); Rbw[:, 1, 1] = np.cos(th)
+    Rbw[:, 2, 2] = 1
+    Rcw = (Rcb[None] @ Rbw).astype(np.float32)
+    level = rng.integers(0, 8, g.E)
+    sf = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * np.float32(1.2)
+    sig2 = (sf * sf).astype(np.float32)
+    return dict(lc=lc.astype(np.float32), lw=g.lms[g.e_lm].astype(np.float32), e_kf=g.e_kf, sigma2=sig2[level],
+                Rcw=Rcw.reshape(g.P, 9), twb_xy=g.poses[:, :2].astype(np.float32), fx=np.float32(g.fx)), g, level
+
+
+def test_edge_information_oracle_vs_generator(oracle, synth):
+    """oracle/ba_ref.cpp::ba_ref_edge_information (C++ restatement of Map.cpp:1024-1049) against the independent
+    numpy restatement used by the generator; both must give SPD 2x2 information matrices bounded by 1/sigma2."""
+    inp, g, level = _info_inputs(synth)
+    info = oracle.ba_edge_information(**inp)
+    ref = synth.edge_information(g.poses, g.lms, g.e_kf, g.e_lm, level, g.Rbc, g.tbc, g.fx)
+    assert np.allclose(info[:, 0, 0], ref[:, 0], rtol=1e-9) and np.allclose(info[:, 1, 1], ref[:, 2], rtol=1e-9)
+    assert np.allclose(info[:, 0, 1], ref[:, 1], rtol=1e-7, atol=1e-12) and np.array_equal(info[:, 0, 1], info[:, 1, 0])
+    ev = np.linalg.eigvalsh(info)
+    assert (ev > 0).all() and (ev[:, 1] <= 1.0 / inp["sigma2"] * (1 + 1e-9)).all()
