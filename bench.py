@@ -65,40 +65,38 @@ def main():
     if capi.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: libse2gpu has no CPU fallback")
 
-    dist = None
-    torch = None
-    red_tensor = None
-    if world > 1:
-        import torch  # plumbing only: device selection, RCCL process group, the all-reduced tensor
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    capi.check(capi.lib().se2gpu_set_device(local_rank if world > 1 else 0))
+    dist = None      # se2lam_amd.rendezvous.Rendezvous when N > 1
+    torch = None     # never imported: see se2lam_amd/rendezvous.py (two HSA runtimes cannot share a process)
+    comm = None
+    # N>1: the data-path collective is RCCL, called by libse2gpu itself on its own HIP stream (se2gpu_comm_*).  The only
+    # things exchanged outside it are the 128-byte ncclUniqueId, barriers and the max of the timings (TCP, stdlib).
+    # SE2_BENCH_FORCE_DIST=1 runs that code path with a single rank (the only way to exercise it on a 1-GPU box).
+    use_dist = world > 1 or os.environ.get("SE2_BENCH_FORCE_DIST") == "1"
+    capi.check(capi.lib().se2gpu_set_device(local_rank if use_dist else 0))
+    if use_dist:
+        import ctypes as C
+        from se2lam_amd.rendezvous import Rendezvous
+        dist = Rendezvous(rank, world)
+        uid = np.zeros(128, np.uint8)
+        with _stdout_to_stderr():   # RCCL prints a "Librccl path" banner on stdout; stdout carries only the JSON line
+            if rank == 0:
+                capi.check(capi.lib().se2gpu_comm_unique_id(uid.ctypes.data))
+            uid = np.frombuffer(dist.broadcast(uid.tobytes(), 128), np.uint8).copy()
+            comm = C.c_void_p()
+            capi.check(capi.lib().se2gpu_comm_create(uid.ctypes.data, rank, world, C.byref(comm)))
 
     def sync_all():
-        capi.check(capi.lib().se2gpu_device_synchronize())
+        capi.check(capi.lib().se2gpu_device_synchronize())   # hipDeviceSynchronize (= torch.cuda.synchronize())
         if dist is not None:
-            torch.cuda.synchronize()
             dist.barrier()
+            capi.check(capi.lib().se2gpu_device_synchronize())
 
     # ---------------- workload: BA graph resident in HBM ----------------
     g_full = synth.ba_graph(args.kf, args.landmarks)
     g = g_full.shard(rank, world)
     opt = SlamOptimizer()
-    if world > 1:
-        n_red = opt.reduce_buffer_doubles(g.P)
-        red_tensor = torch.zeros(n_red, dtype=torch.float64, device="cuda")
-        base = red_tensor.data_ptr()
-        stream = torch.cuda.current_stream().cuda_stream
-        opt.set_stream(stream)
-        opt.set_shard(rank, world)
-
-        def allreduce(ptr, count, _stream):
-            off = (ptr - base) // 8
-            assert 0 <= off and off + count <= n_red and (ptr - base) % 8 == 0
-            dist.all_reduce(red_tensor[off:off + count], op=dist.ReduceOp.SUM)
-
-        opt.set_allreduce(allreduce, buffer_ptr=base)
+    if use_dist:
+        opt.set_comm(comm)          # landmark shard rank/world + native RCCL all-reduce of [S | b | scalars]
     opt.load(g)
     opt.initializeOptimization(0)
 
@@ -122,9 +120,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = dist.allreduce_max(dt)
     iters_per_s = args.steps / dt
     chi2_final = opt.stats["chi2_final"]
 
@@ -202,7 +198,10 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        del opt
+        with _stdout_to_stderr():
+            capi.lib().se2gpu_comm_destroy(comm)
+        dist.close()
 
 
 def _orb_cpu_baseline(synth, nframes, seconds=10.0):
@@ -221,6 +220,20 @@ def _orb_cpu_baseline(synth, nframes, seconds=10.0):
     return {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
                       f"oracle/match_ref.cpp MatchByWindow, 1 thread", "host": _host_desc()}
+
+
+class _stdout_to_stderr:
+    """temporarily route file descriptor 1 to stderr (C libraries that print banners on stdout)"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
 
 
 def _pmc_traffic():

@@ -239,6 +239,18 @@ int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, vo
  * lambda*I / fixed-pose identity terms, which must enter the sum exactly once). */
 int se2gpu_ba_set_shard(se2gpu_ba* h, int rank, int world);
 
+/* Native RCCL communicator (one process per GPU).  The library dlopen()s the system librccl.so.1 - it is NOT a link
+ * dependency of single-GPU users - and calls ncclAllReduce(ncclDouble, ncclSum) in place on the handle's stream.
+ * Rendezvous of the 128-byte ncclUniqueId is the caller's business (bench.py broadcasts it with torch.distributed
+ * over gloo; a ROS deployment would use its own transport).  se2gpu_ba_set_comm = set_shard(rank, world) + an internal
+ * all-reduce through this communicator. */
+typedef struct se2gpu_comm se2gpu_comm;
+int se2gpu_comm_unique_id(uint8_t id_out[128]);                       /* ncclGetUniqueId (rank 0) */
+int se2gpu_comm_create(const uint8_t id[128], int rank, int world, se2gpu_comm** out);  /* ncclCommInitRank */
+void se2gpu_comm_destroy(se2gpu_comm* c);
+int se2gpu_comm_allreduce_sum_f64(se2gpu_comm* c, void* dev_ptr, size_t count, void* hip_stream);
+int se2gpu_ba_set_comm(se2gpu_ba* h, se2gpu_comm* c);
+
 /* Host-side landmark partition ("sharded by keyframe window"): owner[l] in [0, world) for the
  * L landmarks of a graph given by its edge lists.  Pure host code (no device needed). */
 int se2gpu_ba_shard_landmarks(int L, int E, const int32_t* e_kf, const int32_t* e_lm, int world, int32_t* owner);

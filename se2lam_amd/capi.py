@@ -114,6 +114,11 @@ SYMBOLS = {
     "se2gpu_ba_reduce_buffer_doubles": (_SZ, [_VP, _I]),
     "se2gpu_ba_set_allreduce": (_I, [_VP, ALLREDUCE_FN, _VP, _VP]),
     "se2gpu_ba_set_shard": (_I, [_VP, _I, _I]),
+    "se2gpu_comm_unique_id": (_I, [_VP]),
+    "se2gpu_comm_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
+    "se2gpu_comm_destroy": (None, [_VP]),
+    "se2gpu_comm_allreduce_sum_f64": (_I, [_VP, _VP, _SZ, _VP]),
+    "se2gpu_ba_set_comm": (_I, [_VP, _VP]),
     "se2gpu_ba_shard_landmarks": (_I, [_I, _I, _PI32, _PI32, _I, _PI32]),
     "se2gpu_ba_edge_information": (_I, [_I, _VP, _VP, _VP, _VP, _I, _VP, _VP, _F, _F, _F, _VP]),
     "se2gpu_ba_profile": (_I, [_VP, _I]),

@@ -1068,6 +1068,7 @@ struct se2gpu_ba {
     // multi-GPU
     se2gpu_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
+    se2gpu_comm* comm = nullptr;   // native RCCL path (se2gpu_ba_set_comm)
     void* ar_buffer = nullptr;
     int root = 1, rank = 0, world = 1;
 
@@ -1590,6 +1591,23 @@ int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, vo
     h->allreduce = fn;
     h->ar_user = user;
     h->ar_buffer = buffer;
+    return SE2GPU_OK;
+}
+
+static int ba_comm_trampoline(void* dev_ptr, size_t count, void* stream, void* user) {
+    return comm_allreduce((se2gpu_comm*)user, dev_ptr, count, stream);
+}
+
+int se2gpu_ba_set_comm(se2gpu_ba* h, se2gpu_comm* c) {
+    SE2_REQUIRE(h && c, SE2GPU_ERR_INVALID, "ba_set_comm: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "set_comm must precede initialize");
+    h->comm = c;
+    h->rank = comm_rank(c);
+    h->world = comm_world(c);
+    h->root = h->rank == 0 ? 1 : 0;
+    h->allreduce = ba_comm_trampoline;
+    h->ar_user = c;
+    h->ar_buffer = nullptr;
     return SE2GPU_OK;
 }
 

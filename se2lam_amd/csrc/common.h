@@ -15,6 +15,10 @@ namespace se2gpu {
 
 void set_error(const char* fmt, ...);
 bool have_device();
+// in-place sum all-reduce of `count` doubles through a native RCCL communicator (comm.hip); 0 on success
+int comm_allreduce(se2gpu_comm* c, void* dev_ptr, size_t count, void* hip_stream);
+int comm_rank(const se2gpu_comm* c);
+int comm_world(const se2gpu_comm* c);
 
 #define SE2_HIP(expr)                                                                          \
     do {                                                                                       \

@@ -117,6 +117,10 @@ class SlamOptimizer:
         self._cb = capi.ALLREDUCE_FN(_tramp)
         capi.check(capi.lib().se2gpu_ba_set_allreduce(self._h, self._cb, None, buffer_ptr))
 
+    def set_comm(self, comm):
+        """comm: capi-level se2gpu_comm* (c_void_p) from se2gpu_comm_create - native RCCL all-reduce"""
+        capi.check(capi.lib().se2gpu_ba_set_comm(self._h, comm))
+
     def reduce_buffer_doubles(self, P: int) -> int:
         return int(capi.lib().se2gpu_ba_reduce_buffer_doubles(self._h, P))
 

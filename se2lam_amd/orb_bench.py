@@ -65,9 +65,7 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = dist.allreduce_max(dt)
     fps = world * B * steps / dt
     last = bufs[(state["k"] - 1) % 2]
     cnt = last["cnt"].to_numpy(np.int32, (B,))

@@ -83,3 +83,32 @@ def test_two_rank_sharded_reduction_gloo(tmp_path):
         assert r["tail"][0] == 3.0                                   # 1 + 2
         assert r["maxd"] == pytest.approx(np.abs(np.diagonal(full["Hll"], axis1=1, axis2=2)).max(), rel=1e-12)
     assert np.array_equal(r0["x"], r1["x"])                          # identical on every rank
+
+
+def _rdv_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from se2lam_amd.rendezvous import Rendezvous
+    r = Rendezvous(rank, world, "127.0.0.1", port)
+    uid = bytes(range(128)) if rank == 0 else None
+    got = r.broadcast(uid, 128)
+    r.barrier()
+    m = r.allreduce_max(float(rank) * 1.5 + 0.25)
+    r.close()
+    q.put((rank, got == bytes(range(128)), m))
+
+
+def test_tcp_rendezvous_three_ranks():
+    """bench.py's N>1 rendezvous (ncclUniqueId broadcast, barrier, max of timings) without torch in the workers"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 3
+    ps = [ctx.Process(target=_rdv_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=60) for _ in range(world))
+    [p.join(timeout=30) for p in ps]
+    assert [r[0] for r in res] == [0, 1, 2]
+    assert all(r[1] for r in res)
+    assert all(r[2] == 3.25 for r in res)
