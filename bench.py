@@ -232,6 +232,8 @@ class _stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)   # C stdio buffers of the library (the banner) go to stderr as well
         os.dup2(self._saved, 1)
         os.close(self._saved)
 
