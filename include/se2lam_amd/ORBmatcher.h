@@ -3,6 +3,7 @@
 //   static int DescriptorDistance(a, b)                                                           (:49)
 //   int MatchByWindow(frame1, frame2, vbPrevMatched, winSize, vnMatches12, levelOffset=1, minLevel=0, maxLevel=8) (:68-71)
 //   int MatchByProjection(pNewKF, localMPs, winSize, levelOffset, vMatchesIdxMP)                  (:73-74)
+//   int SearchByBoW(pKF1, pKF2, mapIdxMatches12, bIfMPOnly=true)                                 (:55)
 // Frame / KeyFrame / MapPoint are pointer-graph classes of the reference's data model (out of scope); the adapters
 // take the POD content the matchers actually read from them (FrameView / MapPointView below) - INTEGRATION.md shows
 // the three-line glue that fills the views from the reference's classes.
@@ -18,6 +19,14 @@ struct FrameView {                       // what MatchByWindow / MatchByProjecti
     float minXUn = 0, minYUn = 0, maxXUn = 640, maxYUn = 480;  // Frame::minXUn.. (Frame.cpp:183-200)
     const uint8_t* observed = nullptr;       // KeyFrame::hasObservation(idx) per feature (MatchByProjection only)
     const float* Tcw = nullptr;              // KeyFrame::Tcw rows 0..2 (3x4 row-major float)
+};
+
+struct FeatureVectorView {               // DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened to CSR
+    const int32_t* nodes = nullptr;          // ascending node ids
+    const int32_t* ptr = nullptr;            // numNodes + 1 offsets into idx
+    const int32_t* idx = nullptr;            // feature indices
+    int numNodes = 0;
+    const uint8_t* hasMapPoint = nullptr;    // per feature: GetMapPointMatches()[i] non-null (read only if bIfMPOnly)
 };
 
 struct MapPointView {                    // what MatchByProjection reads from localMPs[i]
@@ -68,6 +77,21 @@ public:
                                       newKF.observed, newKF.N, winSize, levelOffset, mfNNratio, vMatchesIdxMP.data(),
                                       &nmatches),
               "ORBmatcher::MatchByProjection");
+        return nmatches;
+    }
+
+    // SearchByBoW(pKF1, pKF2, mapIdxMatches12, bIfMPOnly) (ORBmatcher.h:55, ORBmatcher.cpp:128-276); matches as a dense
+    // array (index into KF2 or -1) instead of std::map<int,int>
+    int SearchByBoW(const FrameView& kf1, const FeatureVectorView& fv1, const FrameView& kf2, const FeatureVectorView& fv2,
+                    std::vector<int>& matches12, bool bIfMPOnly = true) {
+        matches12.assign(kf1.N, -1);
+        int nmatches = 0;
+        check(se2gpu_search_by_bow(h_, reinterpret_cast<const se2gpu_keypoint*>(kf1.keyPointsUn), kf1.descriptors, kf1.N,
+                                   fv1.nodes, fv1.ptr, fv1.idx, fv1.numNodes, fv1.hasMapPoint,
+                                   reinterpret_cast<const se2gpu_keypoint*>(kf2.keyPointsUn), kf2.descriptors, kf2.N,
+                                   fv2.nodes, fv2.ptr, fv2.idx, fv2.numNodes, fv2.hasMapPoint, bIfMPOnly ? 1 : 0, mfNNratio,
+                                   mbCheckOrientation ? 1 : 0, matches12.data(), &nmatches),
+              "ORBmatcher::SearchByBoW");
         return nmatches;
     }
 

@@ -78,6 +78,17 @@ inline void addEdgeSE2(SlamOptimizer& opt, const Vector3D& meas, int id0, int id
     check(se2gpu_ba_add_edge_se2(opt.handle(), id0, id1, meas.v, info.m), "addEdgeSE2");
 }
 
+// Map::loadLocalGraph's per-observation information Sigma_all.inverse() (src/Map.cpp:1024-1049) for a whole window in
+// one device pass: lc = KeyFrame::mViewMPs[ftrIdx], lw = MapPoint::getPos(), Rcw / twb_xy per key frame, sigma2 =
+// mvLevelSigma2[octave]; info_out[k] is ready for addEdgeSE2XYZ.
+inline void computeEdgeInformation(int E, const float* lc, const float* lw, const int32_t* e_kf, const float* sigma2, int P,
+                                   const float* Rcw, const float* twb_xy, float fx, float xrotInfo, float zInfo,
+                                   std::vector<Matrix2D>& info_out) {
+    info_out.resize(E);
+    check(se2gpu_ba_edge_information(E, lc, lw, e_kf, sigma2, P, Rcw, twb_xy, fx, xrotInfo, zInfo,
+                                     E ? info_out[0].m : nullptr), "computeEdgeInformation");
+}
+
 inline SE2 estimateVertexSE2(SlamOptimizer& opt, int id) {
     double v[3];
     check(se2gpu_ba_get_se2(opt.handle(), id, v), "estimateVertexSE2");
