@@ -136,18 +136,36 @@ def main():
     dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     B_ba = g_full.algorithmic_bytes_per_iter()
     B_ba_rank = g.algorithmic_bytes_per_iter()
+
+    def kernel_bytes(name):
+        """Algorithmic bytes ONE launch of `name` has to move; whole-iteration figure otherwise."""
+        n3 = 3 * g.P
+        if name.startswith("k_chol"):       # dense pose solve: lower triangle of S + rhs in, x out
+            return 8 * (n3 * (n3 + 1) // 2 + n3) + 8 * n3
+        if name == "k_reduce2":             # 152 B per contributor pair + the reduced system written once
+            k = np.bincount(np.asarray(g.e_lm), minlength=g.L).astype(np.int64)
+            return int(152 * (k * (k - 1) // 2).sum() + 8 * n3 * n3)
+        if name == "k_linearize":
+            return 44 * g.E + 24 * g.L + 24 * g.P + 216 * g.E + 144 * g.L
+        if name in ("k_update", "k_finalize"):
+            return 44 * g.E + 72 * g.E + 48 * g.L + 24 * g.L
+        return B_ba_rank
     roofline = None
     traffic = _pmc_traffic()
     if dom is not None:
         avg_s = kern[dom]["avg_us"] * 1e-6
-        achieved = B_ba_rank / avg_s / 1e9
+        B_dom = kernel_bytes(dom)
+        achieved = B_dom / avg_s / 1e9
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, collected with
             # tools/pmc_summarize.py on this workload; FETCH_SIZE x2 correction) - null when the file has no entry
             "traffic": (traffic.get(dom, {}).get("traffic_bytes") if world == 1 else None),
-            "algorithmic_bytes_per_launch": B_ba_rank, "avg_launch_us": kern[dom]["avg_us"],
+            "algorithmic_bytes_per_launch": B_dom, "avg_launch_us": kern[dom]["avg_us"],
+            "note": ("the dominant kernel is the dense pose solve: a 600-column dependency chain, bound by FP64 / LDS "
+                     "latency and inter-workgroup hand-offs, not by bandwidth (DESIGN.md 4.1.1)"
+                     if dom.startswith("k_chol") else None),
             "whole_step_achieved": B_ba * iters_per_s / 1e9,
             "whole_step_frac": B_ba * iters_per_s / 1e9 / HBM_PEAK_GBS,
             "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},

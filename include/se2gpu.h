@@ -211,6 +211,9 @@ double se2gpu_ba_chi2(se2gpu_ba* h);                          /* activeRobustChi
 /* Parity introspection: reduced (Schur) system at the current estimate and damping `lambda`:
  * S (3P x 3P row-major, fixed poses -> identity rows), bs (3P).  P counts poses in add order. */
 int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs);
+/* ... and its dense solve on the device (the LL^T that stands in for CHOLMOD): x (3P) with S x = bs;
+ * *factor_ok = 0 when a pivot was not positive. */
+int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok);
 
 /* Per-observation information matrices of Map::loadLocalGraph (/root/reference/src/Map.cpp:1024-1049), SURVEY §8f.1:
  *   Sigma = s_rot * J_r J_r^T + s_z * J_z J_z^T + sigma2 * I,   Omega = Sigma^-1       (2x2, FP64)

@@ -639,7 +639,7 @@ __global__ void k_reduce_odo(int O, int ld, const int* __restrict__ o_i, const i
 //     [ b' ]   row  n      : right-hand side     -> the elimination maps it to y' = (L^-1 b)'
 //     [ I  ]   (kept in R) : identity            -> the elimination maps it to R  = L^-T
 // so neither triangular solve has a sequential phase: x = R y is one GEMV at the end.
-// One (panel, update) launch pair per 32-wide block column; replaces CHOLMOD on the (3P)^2 system.
+// One launch per 32-wide block column (k_chol_step); replaces CHOLMOD on the (3P)^2 system.
 // ---------------------------------------------------------------------------------------------
 constexpr int kNB = 32;
 
@@ -661,54 +661,140 @@ __device__ inline double fast_rsqrt(double d) {  // v_rsq_f64 + 2 Newton steps
     return y;
 }
 
-// Panel step k.  ONE WAVE per workgroup eliminates a stacked 64x32 matrix held entirely in registers (lane = row,
-// 32 doubles per lane): lanes 0..31 = diagonal tile A(k,k) (every workgroup repeats it), lanes 32..63 = its own
-// tile: A(i,k) for i > k, the identity for the diagonal workgroup (-> R(k,k)), or R(r,k) for r < k.
-//     M[r][c] -= M[r][j] * M[c][j] / M[j][j]   (c > j),      L[r][j] = M[r][j] / sqrt(M[j][j]) at the end.
-// The sequential chain is pivot -> reciprocal -> multiplier -> next pivot (dependent FP64 ops, 48 clk each on
-// gfx950), so the loop is software pipelined: column j first updates column j+1 and starts the reciprocal of the
-// NEXT pivot, then does the bulk rank-1 update of columns j+2.. while that chain is in flight.  M[c][j] of the bulk
-// comes from a 64-entry LDS column (uniform-address ds_read = broadcast); only the pivot path uses v_readlane.
-__global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ A, double* __restrict__ R, int ld, int n,
-                                                    int nt, int k, double* __restrict__ fail) {
-    __shared__ double col[64];
-    const int lane = threadIdx.x;
+// Step k of the factorisation, ONE launch per 32-wide block column: the trailing update with panel k-1 and the
+// elimination of panel k are fused, so a solve is nbc launches instead of 2 nbc (kernel boundaries, not flops, bound
+// this 600-column problem).  Grid (nbc - k, nt): x = block column j = k + x, y = tile row (A rows k.., then R rows).
+//   * every workgroup first applies panel k-1 to its tile:   T(i,j) -= L(i,k-1) L(j,k-1)^T          (256 threads)
+//     (R(r,j) is first touched at step r+1, where its previous value is known to be zero);
+//   * workgroups of columns j > k write T back and are done;
+//   * workgroups of column k also form the updated diagonal tile D = A(k,k) - L(k,k-1) L(k,k-1)^T (every one of
+//     them, redundantly - nothing is exchanged between workgroups) and wave 0 eliminates the stacked 64x32 matrix
+//     [D; T] held entirely in registers (lane = row, 32 doubles per lane): lanes 0..31 = D, lanes 32..63 = T, the
+//     identity for the diagonal workgroup (-> R(k,k)), or the R(r,k) tile.
+//         M[r][c] -= M[r][j] * M[c][j] / M[j][j]   (c > j),      L[r][j] = M[r][j] / sqrt(M[j][j]) at the end.
+//     The loop is software pipelined: column j first updates column j+1 and starts the reciprocal of the NEXT
+//     pivot, then does the bulk rank-1 update of columns j+2.. while that chain is in flight.  M[c][j] of the bulk
+//     comes from a 64-entry LDS column (uniform-address ds_read = broadcast); only the pivot path uses v_readlane.
+//     The loop has no branches (one basic block): columns past n are replaced by a decoupled block.
+// L(k,k) itself is never read again and is not written (so no workgroup writes what another one reads).
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, double* __restrict__ R, int ld, int n, int nt,
+                                                    int k, double* __restrict__ fail) {
+    __shared__ __attribute__((aligned(16))) double Ti[kNB][kNB + 2];  // L(i,k-1), then the updated tile T
+    __shared__ __attribute__((aligned(16))) double Tj[kNB][kNB + 2];  // L(j,k-1), then the updated diagonal D
+    __shared__ __attribute__((aligned(16))) double colA[64];  // two column buffers: column j+1 can be staged while
+    __shared__ __attribute__((aligned(16))) double colB[64];  // the bulk update of column j is still reading
+    const int tid = threadIdx.x;
+    const int j = k + (int)blockIdx.x;
     const int nS = nt - k;
-    const bool isR = (int)blockIdx.x >= nS;
-    const int tr = isR ? (int)blockIdx.x - nS : k + (int)blockIdx.x;
-    const bool isDiag = !isR && tr == k;
+    const bool isR = (int)blockIdx.y >= nS;
+    const int i = isR ? (int)blockIdx.y - nS : k + (int)blockIdx.y;  // tile row (of A, or of R)
+    if (!isR && j > i) return;
+    const bool elim = (j == k);
+    const bool isDiag = elim && !isR && i == k;
+    double* own = isR ? R : A;
+    const int r = tid / 8, cc = (tid % 8) * 4;
+    double* ownp = own + (size_t)(kNB * i + r) * ld + kNB * j + cc;
+    double2 t0, t1, d0 = make_double2(0, 0), d1 = make_double2(0, 0);
+    if (k > 0) {
+        const int cp = kNB * (k - 1);
+        const bool first = isR && i == k - 1;  // R(k-1, j): previous value is zero, never read
+        const double* src = own + (size_t)(kNB * i + r) * ld + cp + cc;
+        const double* srj = A + (size_t)(kNB * j + r) * ld + cp + cc;
+        // issue every global load up front
+        const double2 li0 = *reinterpret_cast<const double2*>(src), li1 = *reinterpret_cast<const double2*>(src + 2);
+        const double2 lj0 = *reinterpret_cast<const double2*>(srj), lj1 = *reinterpret_cast<const double2*>(srj + 2);
+        t0 = make_double2(0, 0);
+        t1 = make_double2(0, 0);
+        if (!first) {
+            t0 = *reinterpret_cast<const double2*>(ownp);
+            t1 = *reinterpret_cast<const double2*>(ownp + 2);
+        }
+        if (elim) {
+            const double* dp = A + (size_t)(kNB * k + r) * ld + kNB * k + cc;
+            d0 = *reinterpret_cast<const double2*>(dp);
+            d1 = *reinterpret_cast<const double2*>(dp + 2);
+        }
+        Ti[r][cc] = li0.x; Ti[r][cc + 1] = li0.y; Ti[r][cc + 2] = li1.x; Ti[r][cc + 3] = li1.y;
+        Tj[r][cc] = lj0.x; Tj[r][cc + 1] = lj0.y; Tj[r][cc + 2] = lj1.x; Tj[r][cc + 3] = lj1.y;
+        __syncthreads();
+        double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        double dcc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+        for (int m = 0; m < kNB; m += 2) {
+            const double a0 = Ti[r][m], a1 = Ti[r][m + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[q][0] = fma(a0, Tj[cc + q][m], acc[q][0]);
+                acc[q][1] = fma(a1, Tj[cc + q][m + 1], acc[q][1]);
+            }
+        }
+        if (elim) {  // D -= L(k,k-1) L(k,k-1)^T  (Tj holds L(k,k-1))
+#pragma unroll
+            for (int m = 0; m < kNB; m += 2) {
+                const double a0 = Tj[r][m], a1 = Tj[r][m + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dcc[q][0] = fma(a0, Tj[cc + q][m], dcc[q][0]);
+                    dcc[q][1] = fma(a1, Tj[cc + q][m + 1], dcc[q][1]);
+                }
+            }
+        }
+        t0 = make_double2(t0.x - (acc[0][0] + acc[0][1]), t0.y - (acc[1][0] + acc[1][1]));
+        t1 = make_double2(t1.x - (acc[2][0] + acc[2][1]), t1.y - (acc[3][0] + acc[3][1]));
+        if (!elim) {
+            *reinterpret_cast<double2*>(ownp) = t0;
+            *reinterpret_cast<double2*>(ownp + 2) = t1;
+            return;
+        }
+        d0 = make_double2(d0.x - (dcc[0][0] + dcc[0][1]), d0.y - (dcc[1][0] + dcc[1][1]));
+        d1 = make_double2(d1.x - (dcc[2][0] + dcc[2][1]), d1.y - (dcc[3][0] + dcc[3][1]));
+        __syncthreads();  // everyone is done reading L(i,k-1), L(k,k-1)
+    } else {
+        // k == 0: every column-0 tile is eliminated as loaded (the grid has one column)
+        t0 = *reinterpret_cast<const double2*>(ownp);
+        t1 = *reinterpret_cast<const double2*>(ownp + 2);
+        const double* dp = A + (size_t)r * ld + cc;
+        d0 = *reinterpret_cast<const double2*>(dp);
+        d1 = *reinterpret_cast<const double2*>(dp + 2);
+        if (!elim) return;  // (cannot happen: j == k == 0)
+    }
+    // stage D and T for wave 0 (row per lane)
+    Ti[r][cc] = t0.x; Ti[r][cc + 1] = t0.y; Ti[r][cc + 2] = t1.x; Ti[r][cc + 3] = t1.y;
+    Tj[r][cc] = d0.x; Tj[r][cc + 1] = d0.y; Tj[r][cc + 2] = d1.x; Tj[r][cc + 3] = d1.y;
+    __syncthreads();
+    if (tid >= 64) return;
+    const int lane = tid;
     const int c0 = kNB * k;
     const int ncol = min(kNB, n - c0);
-    const int r = lane & 31;
-    double* rowp;  // this lane's row (32 contiguous doubles starting at column c0)
-    if (lane < kNB) rowp = A + (size_t)(c0 + r) * ld + c0;
-    else if (!isR) rowp = A + (size_t)(kNB * tr + r) * ld + c0;
-    else rowp = R + (size_t)(kNB * tr + r) * ld + c0;
-    if (isDiag && lane >= kNB) rowp = R + (size_t)(c0 + r) * ld + c0;
+    const int rr = lane & 31;
     double m[kNB];
     {
-        const double2* rp2 = reinterpret_cast<const double2*>(rowp);
+        const double* lp = (lane < kNB) ? &Tj[rr][0] : &Ti[rr][0];
+        const bool ident = isDiag && lane >= kNB;
 #pragma unroll
         for (int c = 0; c < kNB; c += 2) {
-            double2 v = (isDiag && lane >= kNB) ? make_double2(c == r ? 1.0 : 0.0, c + 1 == r ? 1.0 : 0.0) : rp2[c / 2];
-            m[c] = v.x;
-            m[c + 1] = v.y;
+            const double2 v = *reinterpret_cast<const double2*>(lp + c);
+            m[c] = ident ? (c == rr ? 1.0 : 0.0) : v.x;
+            m[c + 1] = ident ? (c + 1 == rr ? 1.0 : 0.0) : v.y;
         }
+        // columns past n (last panel only) become a harmless decoupled block: huge diagonal, zero elsewhere
+#pragma unroll
+        for (int c = 0; c < kNB; ++c)
+            if (c >= ncol) m[c] = (lane < kNB && c == rr) ? 1e300 : 0.0;
     }
     double inv = fast_rcp(bcast_lane(m[0], 0));
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) {
-        if (j < ncol) {
-            const double mr = m[j] * inv;
-            if (j + 1 < kNB) {
-                m[j + 1] = fma(-mr, bcast_lane(m[j], j + 1), m[j + 1]);
-                inv = fast_rcp(bcast_lane(m[j + 1], j + 1));  // next pivot: in flight during the bulk update
-            }
-            if (j + 2 < kNB) {
-                col[lane] = m[j];
+    for (int jj = 0; jj < kNB; ++jj) {
+        const double mr = m[jj] * inv;
+        if (jj + 1 < kNB) {
+            m[jj + 1] = fma(-mr, bcast_lane(m[jj], jj + 1), m[jj + 1]);
+            inv = fast_rcp(bcast_lane(m[jj + 1], jj + 1));  // next pivot: in flight during the bulk update
+        }
+        if (jj + 2 < kNB) {
+            double* col = (jj & 1) ? colB : colA;
+            col[lane] = m[jj];
 #pragma unroll
-                for (int c = j + 2; c < kNB; ++c) m[c] = fma(-mr, col[c], m[c]);
-            }
+            for (int c = jj + 2; c < kNB; ++c) m[c] = fma(-mr, col[c], m[c]);
         }
     }
     bool bad = false;
@@ -716,65 +802,221 @@ __global__ __launch_bounds__(64) void k_chol_panel(double* __restrict__ A, doubl
 #pragma unroll
     for (int c = 0; c < kNB; ++c) {
         const double d = bcast_lane(m[c], c);
-        const bool okd = !(c < ncol) || (d > 0.0 && isfinite(d));
-        bad |= !okd;
-        out[c] = m[c] * fast_rsqrt((c < ncol && okd) ? d : 1.0);
+        const bool pos = (d > 0.0) & (d < __builtin_inf());  // false for NaN; bitwise: no short-circuit branches
+        bad |= (c < ncol) & !pos;
+        out[c] = m[c] * fast_rsqrt(((c < ncol) & pos) ? d : 1.0);
     }
-    {
-        double2* wp2 = reinterpret_cast<double2*>(rowp);
-        if (lane >= kNB && ncol == kNB) {
+    // lanes 32..63 own the output rows: L(i,k), R(r,k) or R(k,k).  Of the diagonal tile only rows >= n (the rhs
+    // row when it lives in the last diagonal tile) are results: y = L^-1 b.
+    double* rowp;
+    if (lane < kNB) rowp = A + (size_t)(c0 + rr) * ld + c0;
+    else if (isDiag) rowp = R + (size_t)(c0 + rr) * ld + c0;
+    else rowp = own + (size_t)(kNB * i + rr) * ld + c0;
+    if (ncol == kNB) {
+        if (lane >= kNB) {
+            double2* wp2 = reinterpret_cast<double2*>(rowp);
 #pragma unroll
             for (int c = 0; c < kNB; c += 2) wp2[c / 2] = make_double2(out[c], out[c + 1]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < kNB; ++c)
-                if (c < ncol && (lane >= kNB || (isDiag && c <= r))) rowp[c] = out[c];
         }
+    } else {
+#pragma unroll
+        for (int c = 0; c < kNB; ++c)
+            if (c < ncol && (lane >= kNB || (isDiag && rr >= ncol))) rowp[c] = out[c];
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
 }
 
-// Trailing update with panel k: A(i,j) -= L(i,k) L(j,k)^T for k < j <= i, and R(r,j) -= R(r,k) L(j,k)^T for r <= k
-// (R(r,j) is first touched at step k == r, where its previous value is known to be zero).
-__global__ __launch_bounds__(256) void k_chol_update(double* __restrict__ A, double* __restrict__ R, int ld, int k,
-                                                      int m_s) {
-    const int j = k + 1 + blockIdx.x;
-    const bool isR = (int)blockIdx.y >= m_s;
-    const int i = isR ? (int)blockIdx.y - m_s : k + 1 + (int)blockIdx.y;  // tile row (in A, or in R)
-    if (!isR && j > i) return;
-    __shared__ double Li[kNB][kNB + 2];
-    __shared__ double Lj[kNB][kNB + 2];
-    const int tid = threadIdx.x;
-    const int c0 = kNB * k;
-    const double* src = isR ? R : A;
-    const int r = tid / 8, cc = (tid % 8) * 4;
-    double* outp = (isR ? R : A) + (size_t)(kNB * i + r) * ld + kNB * j + cc;
-    const bool first = isR && i == k;
-    // issue every global load up front: two double2 of each operand tile + the 4 outputs this thread updates
-    const double2 li0 = *reinterpret_cast<const double2*>(src + (size_t)(kNB * i + r) * ld + c0 + cc);
-    const double2 li1 = *reinterpret_cast<const double2*>(src + (size_t)(kNB * i + r) * ld + c0 + cc + 2);
-    const double2 lj0 = *reinterpret_cast<const double2*>(A + (size_t)(kNB * j + r) * ld + c0 + cc);
-    const double2 lj1 = *reinterpret_cast<const double2*>(A + (size_t)(kNB * j + r) * ld + c0 + cc + 2);
-    double2 o0 = make_double2(0.0, 0.0), o1 = make_double2(0.0, 0.0);
-    if (!first) {
-        o0 = *reinterpret_cast<const double2*>(outp);
-        o1 = *reinterpret_cast<const double2*>(outp + 2);
+// ---------------------------------------------------------------------------------------------
+// k_chol_tiles: the whole factorisation in ONE launch - a dataflow over 32x32 tiles (default path).
+// The 600-column problem is bound by kernel boundaries and dependent memory latency, not by flops, so each tile (i,j)
+// of the lower triangle of A, and each tile (r,j) of R = "L^-T", gets its own persistent workgroup that
+//   1. keeps its tile T and a private copy of the diagonal tile D(j,j) in registers and subtracts the contribution of
+//      block column m = 0..j-1 as soon as that column is published (left-looking; only m = j-1 is on the critical path),
+//   2. eliminates the stacked [D; T] exactly like k_chol_step (wave 0, lane = row),
+//   3. publishes its result and raises flag(i,j) (agent-scope release; consumers poll with a bounded spin).
+// Tasks are ordered by block column, dependencies point to lower workgroup ids only, so the dataflow cannot deadlock
+// even when the grid exceeds what is resident (in-order dispatch); a spin that exceeds 2 s reports a failure instead
+// of hanging.  The factorisation is kept in LDL^T form, which takes the 32 reciprocal square roots off the critical
+// path: with M = the unnormalised elimination result and MR = M * diag(1/pivot),
+//      L L^T = MR M^T,    x = R y = MR_R y_un      (no square root anywhere)
+// both M (in place in A / R) and MR (in AM / RM) are published.  Flags carry the solve's epoch: no clearing needed.
+// ---------------------------------------------------------------------------------------------
+__device__ inline bool spin_until(const unsigned* f, unsigned epoch) {
+    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    const long long t0 = wall_clock64();  // 100 MHz
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > 200000000ll) return false;
     }
-    Li[r][cc] = li0.x; Li[r][cc + 1] = li0.y; Li[r][cc + 2] = li1.x; Li[r][cc + 3] = li1.y;
-    Lj[r][cc] = lj0.x; Lj[r][cc + 1] = lj0.y; Lj[r][cc + 2] = lj1.x; Lj[r][cc + 3] = lj1.y;
-    __syncthreads();
-    double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-#pragma unroll
-    for (int m = 0; m < kNB; m += 2) {
-        const double a0 = Li[r][m], a1 = Li[r][m + 1];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[q][0] = fma(a0, Lj[cc + q][m], acc[q][0]);
-            acc[q][1] = fma(a1, Lj[cc + q][m + 1], acc[q][1]);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
+                                                     double* __restrict__ R, double* __restrict__ RM, int ld, int n,
+                                                     int nbc, const int2* __restrict__ tasks,
+                                                     unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
+                                                     unsigned epoch, double* __restrict__ fail,
+                                                     long long* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) double Ta[kNB][kNB + 2];  // MR(i,m), then the finished tile T
+    __shared__ __attribute__((aligned(16))) double Tb[kNB][kNB + 2];  // M(j,m),  then the finished diagonal D
+    __shared__ __attribute__((aligned(16))) double Tc[kNB][kNB + 2];  // MR(j,m)
+    __shared__ __attribute__((aligned(16))) double colA[64];
+    __shared__ __attribute__((aligned(16))) double colB[64];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x;
+    long long* stamp = dbg ? dbg + (size_t)blockIdx.x * 8 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
+    if (stamp && tid == 0) stamp[0] = wall_clock64();
+    const int2 tk = tasks[blockIdx.x];
+    const bool isR = (tk.x >> 16) != 0;
+    const int i = tk.x & 0xffff, j = tk.y;
+    const bool isDiag = !isR && i == j;
+    double* own = isR ? R : A;
+    double* ownM = isR ? RM : AM;
+    const int r = tid / 8, cc = (tid % 8) * 4;
+    const size_t own_off = (size_t)(kNB * i + r) * ld + kNB * j + cc;
+    double2 t0 = make_double2(0, 0), t1 = make_double2(0, 0), d0, d1;
+    {
+        const double* dp = A + (size_t)(kNB * j + r) * ld + kNB * j + cc;
+        d0 = *reinterpret_cast<const double2*>(dp);
+        d1 = *reinterpret_cast<const double2*>(dp + 2);
+        if (!isR && !isDiag) {
+            t0 = *reinterpret_cast<const double2*>(A + own_off);
+            t1 = *reinterpret_cast<const double2*>(A + own_off + 2);
         }
     }
-    *reinterpret_cast<double2*>(outp) = make_double2(o0.x - (acc[0][0] + acc[0][1]), o0.y - (acc[1][0] + acc[1][1]));
-    *reinterpret_cast<double2*>(outp + 2) = make_double2(o1.x - (acc[2][0] + acc[2][1]), o1.y - (acc[3][0] + acc[3][1]));
+    for (int m = 0; m < j; ++m) {
+        const bool hasT = !isDiag && !(isR && m < i);  // R(r,m) is zero for m < r: only D is updated
+        if (tid == 0) {
+            bool ok = spin_until(flagA + (size_t)j * nbc + m, epoch);
+            if (hasT) ok = ok && spin_until((isR ? flagR : flagA) + (size_t)i * nbc + m, epoch);
+            ok_s = ok ? 1 : 0;
+        }
+        __syncthreads();  // also: everyone is done with the LDS tiles of the previous column
+        if (!ok_s) {
+            if (tid == 0) fail[0] = 1e6;
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (stamp && tid == 0) stamp[1] = wall_clock64();
+        const size_t offj = (size_t)(kNB * j + r) * ld + kNB * m + cc;
+        const size_t offi = (size_t)(kNB * i + r) * ld + kNB * m + cc;
+        const double2 mj0 = *reinterpret_cast<const double2*>(A + offj), mj1 = *reinterpret_cast<const double2*>(A + offj + 2);
+        const double2 rj0 = *reinterpret_cast<const double2*>(AM + offj), rj1 = *reinterpret_cast<const double2*>(AM + offj + 2);
+        double2 ri0 = make_double2(0, 0), ri1 = make_double2(0, 0);
+        if (hasT) {
+            ri0 = *reinterpret_cast<const double2*>(ownM + offi);
+            ri1 = *reinterpret_cast<const double2*>(ownM + offi + 2);
+        }
+        Ta[r][cc] = ri0.x; Ta[r][cc + 1] = ri0.y; Ta[r][cc + 2] = ri1.x; Ta[r][cc + 3] = ri1.y;
+        Tb[r][cc] = mj0.x; Tb[r][cc + 1] = mj0.y; Tb[r][cc + 2] = mj1.x; Tb[r][cc + 3] = mj1.y;
+        Tc[r][cc] = rj0.x; Tc[r][cc + 1] = rj0.y; Tc[r][cc + 2] = rj1.x; Tc[r][cc + 3] = rj1.y;
+        __syncthreads();
+        double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+        double dcc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#pragma unroll
+        for (int q2 = 0; q2 < kNB; q2 += 2) {
+            const double a0 = Ta[r][q2], a1 = Ta[r][q2 + 1];
+            const double c0 = Tc[r][q2], c1 = Tc[r][q2 + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double b0 = Tb[cc + q][q2], b1 = Tb[cc + q][q2 + 1];
+                acc[q][0] = fma(a0, b0, acc[q][0]);
+                acc[q][1] = fma(a1, b1, acc[q][1]);
+                dcc[q][0] = fma(c0, b0, dcc[q][0]);
+                dcc[q][1] = fma(c1, b1, dcc[q][1]);
+            }
+        }
+        t0 = make_double2(t0.x - (acc[0][0] + acc[0][1]), t0.y - (acc[1][0] + acc[1][1]));
+        t1 = make_double2(t1.x - (acc[2][0] + acc[2][1]), t1.y - (acc[3][0] + acc[3][1]));
+        d0 = make_double2(d0.x - (dcc[0][0] + dcc[0][1]), d0.y - (dcc[1][0] + dcc[1][1]));
+        d1 = make_double2(d1.x - (dcc[2][0] + dcc[2][1]), d1.y - (dcc[3][0] + dcc[3][1]));
+    }
+    __syncthreads();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    Ta[r][cc] = t0.x; Ta[r][cc + 1] = t0.y; Ta[r][cc + 2] = t1.x; Ta[r][cc + 3] = t1.y;
+    Tb[r][cc] = d0.x; Tb[r][cc + 1] = d0.y; Tb[r][cc + 2] = d1.x; Tb[r][cc + 3] = d1.y;
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- wave 0: eliminate [D; T]
+    const int lane = tid;
+    const int c0 = kNB * j;
+    const int ncol = min(kNB, n - c0);
+    const int rr = lane & 31;
+    double m[kNB];
+    {
+        const double* lp = (lane < kNB) ? &Tb[rr][0] : &Ta[rr][0];
+        const bool ident = isDiag && lane >= kNB;
+#pragma unroll
+        for (int c = 0; c < kNB; c += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(lp + c);
+            m[c] = ident ? (c == rr ? 1.0 : 0.0) : v.x;
+            m[c + 1] = ident ? (c + 1 == rr ? 1.0 : 0.0) : v.y;
+        }
+        if (ncol < kNB) {  // last panel only (uniform branch: keeps 32 select masks out of the common path)
+#pragma unroll
+            for (int c = 0; c < kNB; ++c)
+                if (c >= ncol) m[c] = (lane < kNB && c == rr) ? 1e300 : 0.0;
+        }
+    }
+    long long clk0 = 0;
+    if (stamp) clk0 = clock64();
+    if (stamp && lane == 0) stamp[3] = wall_clock64();
+    // the multipliers MR = M / pivot of this lane's row are parked in LDS (the staged tiles are in registers now)
+    double* mrrow = (lane < kNB) ? &Tb[rr][0] : &Ta[rr][0];
+    bool bad = false;
+    double piv = bcast_lane(m[0], 0);
+    double inv = fast_rcp(piv);
+#pragma unroll
+    for (int jj = 0; jj < kNB; ++jj) {
+        bad |= !__builtin_amdgcn_class(piv, 0x180);  // not (+normal | +denormal): <= 0, inf or NaN (pad pivots are 1e300)
+        const double mr = m[jj] * inv;
+        mrrow[jj] = mr;
+        if (jj + 1 < kNB) {
+            m[jj + 1] = fma(-mr, bcast_lane(m[jj], jj + 1), m[jj + 1]);
+            piv = bcast_lane(m[jj + 1], jj + 1);
+            inv = fast_rcp(piv);  // next pivot: in flight during the bulk update
+        }
+        if (jj + 2 < kNB) {
+            double* col = (jj & 1) ? colB : colA;
+            col[lane] = m[jj];
+#pragma unroll
+            for (int c = jj + 2; c < kNB; ++c) m[c] = fma(-mr, col[c], m[c]);
+        }
+    }
+    if (stamp && lane == 32) stamp[4] = wall_clock64() + (long long)(m[31] == 1.2345e-300);
+    if (stamp && lane == 32) stamp[6] = clock64() - clk0;
+    // lanes 32..63 own the output rows (diagonal task: R(j,j) from the identity).  Of the diagonal tile only rows
+    // >= n (the rhs row when it lives in the last diagonal tile) are results: y_un.
+    if (lane >= kNB) {
+        const size_t off = (size_t)(kNB * i + rr) * ld + c0;
+        double* pm = (isDiag ? R : own) + off;
+        double* pr = (isDiag ? RM : ownM) + off;
+        if (ncol == kNB) {
+#pragma unroll
+            for (int c = 0; c < kNB; c += 2) {
+                reinterpret_cast<double2*>(pm)[c / 2] = make_double2(m[c], m[c + 1]);
+                reinterpret_cast<double2*>(pr)[c / 2] = *reinterpret_cast<const double2*>(mrrow + c);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < kNB; ++c)
+                if (c < ncol) {
+                    pm[c] = m[c];
+                    pr[c] = mrrow[c];
+                }
+        }
+    } else if (isDiag && rr >= ncol) {
+        double* pm = A + (size_t)(c0 + rr) * ld + c0;
+#pragma unroll
+        for (int c = 0; c < kNB; ++c)
+            if (c < ncol) pm[c] = m[c];
+    }
+    if (bad && isDiag && lane == 0) fail[0] = 1.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0)
+        __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp && lane == 0) stamp[5] = wall_clock64();
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -1063,6 +1305,12 @@ struct se2gpu_ba {
     DevBuf<double> e_uv, e_info, o_meas, o_info;
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Hpp, bp, Oii, Ojj, Oij, obi, obj;
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
+    DevBuf<int2> chol_tasks;      // k_chol_tiles: (tile row | isR << 16, block column), ordered by column
+    DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
+    int chol_ntask = 0;
+    unsigned chol_epoch = 0;
+    DevBuf<long long> chol_trace; // SE2GPU_BA_CHOL_TRACE=1: per-task stamps of the last solve -> stderr (debug_solve)
+    bool chol_steps = false;      // SE2GPU_BA_CHOL=steps: one launch per block column (k_chol_step) instead
     double* red = nullptr;  // [augmented (ld x ld): rows 0..n-1 = S, row n = bs | 4 scalars]
     PinBuf<double> h_red, h_x, h_scal;
     // multi-GPU
@@ -1271,7 +1519,27 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->red = h->red_own.p;
     }
     SE2_CHECK(h->h_red.reserve(nred));
-    SE2_CHECK(h->Rinv.reserve((size_t)h->ld * h->ld));
+    SE2_CHECK(h->Rinv.reserve(3 * (size_t)h->ld * h->ld));  // R | AM | RM (the last two: k_chol_tiles only)
+    {
+        const int nt = h->ld / kNB, nbc = (n + kNB - 1) / kNB;
+        std::vector<int2> tasks;
+        for (int j = 0; j < nbc; ++j) {
+            for (int i = j; i < nt; ++i) tasks.push_back(make_int2(i, j));
+            for (int r = 0; r < j; ++r) tasks.push_back(make_int2(r | (1 << 16), j));
+        }
+        h->chol_ntask = (int)tasks.size();
+        SE2_CHECK(h->chol_tasks.upload(tasks, st));
+        SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
+        SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
+        h->chol_epoch = 0;
+        const char* env = getenv("SE2GPU_BA_CHOL");
+        h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt > 64;
+        const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
+        if (tr && tr[0] == '1') {
+            SE2_CHECK(h->chol_trace.reserve(8 * (size_t)h->chol_ntask));
+            SE2_HIP(hipMemsetAsync(h->chol_trace.p, 0, 8 * (size_t)h->chol_ntask * sizeof(long long), st));
+        }
+    }
     SE2_CHECK(h->h_x.reserve(n));
     SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
@@ -1388,15 +1656,20 @@ int ba_solve(se2gpu_ba* h) {
     const int nt = ld / kNB;                 // tile rows of A (incl. the rhs / padding tile row)
     const int nbc = (n + kNB - 1) / kNB;     // block columns to factor
     double* Rm = h->Rinv.p;
-    for (int k = 0; k < nbc; ++k) {
-        // workgroups: (nt - k) tile rows of A (the diagonal one also produces R(k,k)) + k tile rows of R
-        SE2_LAUNCH(h->prof, st, "k_chol_panel", k_chol_panel, dim3(nt - k + k), dim3(64), 0, A, Rm, ld, n, nt, k, fail);
-        const int mx = nbc - k - 1;          // block columns right of k
-        const int ms = nt - k - 1;           // tile rows of A below k
-        if (mx > 0)
-            SE2_LAUNCH(h->prof, st, "k_chol_update", k_chol_update, dim3(mx, ms + k + 1), dim3(256), 0, A, Rm, ld, k, ms);
+    if (h->chol_steps) {
+        for (int k = 0; k < nbc; ++k)  // update with panel k-1 fused with the elimination of panel k
+            SE2_LAUNCH(h->prof, st, "k_chol_step", k_chol_step, dim3(nbc - k, nt), dim3(256), 0, A, Rm, ld, n, nt, k, fail);
+        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p);
+    } else {
+        double* AM = Rm + (size_t)ld * ld;
+        double* RM = AM + (size_t)ld * ld;
+        unsigned* flagA = h->chol_flags.p;
+        unsigned* flagR = flagA + (size_t)nt * nbc;
+        ++h->chol_epoch;
+        SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
+                   h->chol_tasks.p, flagA, flagR, h->chol_epoch, fail, h->chol_trace.p);
+        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, RM, ld, n, h->xp.p);
     }
-    SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -1644,6 +1917,36 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
     return SE2GPU_OK;
 }
 
+int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok) {
+    SE2_REQUIRE(h && h->initialized && x, SE2GPU_ERR_STATE, "debug_solve before initialize");
+    const int n = 3 * h->P;
+    SE2_CHECK(ba_linearize(h, lambda));
+    SE2_CHECK(ba_reduce(h, lambda, false));
+    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
+    SE2_CHECK(ba_solve(h));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    SE2_HIP(hipMemcpy(x, h->xp.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    double f = 0;
+    SE2_HIP(hipMemcpy(&f, h->red + (size_t)h->ld * h->ld + 2, 8, hipMemcpyDeviceToHost));
+    SE2_REQUIRE(f < 1e5, SE2GPU_ERR_HIP, "k_chol_tiles: a dependency spin timed out (2 s)");
+    if (factor_ok) *factor_ok = !(f > 0.0);
+    if (h->chol_trace.p && !h->chol_steps) {  // task, tile row, R?, column, then stamps relative to the first in 10 ns ticks
+        std::vector<long long> tr(8 * (size_t)h->chol_ntask);
+        std::vector<int2> tk(h->chol_ntask);
+        SE2_HIP(hipMemcpy(tr.data(), h->chol_trace.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        SE2_HIP(hipMemcpy(tk.data(), h->chol_tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        long long t0 = tr[0];
+        for (int t = 0; t < h->chol_ntask; ++t) t0 = std::min(t0, tr[8 * (size_t)t]);
+        for (int t = 0; t < h->chol_ntask; ++t) {
+            std::fprintf(stderr, "choltrace %d %d %d %d", t, tk[t].x & 0xffff, tk[t].x >> 16, tk[t].y);
+            for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %lld", tr[8 * (size_t)t + q] ? tr[8 * (size_t)t + q] - t0 : -1);
+            std::fprintf(stderr, " %lld", tr[8 * (size_t)t + 6]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    return SE2GPU_OK;
+}
+
 int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
                        se2gpu_ba_stats* stats) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "optimize before initialize");
@@ -1679,6 +1982,7 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
             SE2_CHECK(ba_evaluate(h, h->xp.p, lam));
             double tempChi = h->h_scal.p[0];
             const bool ok2 = !(h->h_scal.p[2] > 0.0);  // factorisation flag (summed over ranks: identical on all)
+            SE2_REQUIRE(h->h_scal.p[2] < 1e5, SE2GPU_ERR_HIP, "k_chol_tiles: a dependency spin timed out (2 s)");
             if (!ok2) tempChi = std::numeric_limits<double>::max();
             ++s.trials;
             ++qmax;

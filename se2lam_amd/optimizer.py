@@ -102,6 +102,14 @@ class SlamOptimizer:
         capi.check(capi.lib().se2gpu_ba_debug_reduced_system(self._h, float(lam), capi.pd(S), capi.pd(bs)))
         return S, bs
 
+    def solve(self, lam: float):
+        """x with S(lam) x = bs by the device factorisation; returns (x, factor_ok)."""
+        P, _ = self._shape
+        x = np.zeros(3 * P)
+        ok = C.c_int(0)
+        capi.check(capi.lib().se2gpu_ba_debug_solve(self._h, float(lam), capi.pd(x), C.byref(ok)))
+        return x, bool(ok.value)
+
     def set_shard(self, rank: int, world: int):
         capi.check(capi.lib().se2gpu_ba_set_shard(self._h, rank, world))
 
