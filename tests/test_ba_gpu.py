@@ -245,3 +245,27 @@ def test_edge_information_on_device(oracle, synth):
         assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
     assert op.edge_information(inp["lc"][:0], inp["lw"][:0], inp["e_kf"][:0], inp["sigma2"][:0], inp["Rcw"],
                                inp["twb_xy"], inp["fx"]).shape == (0, 2, 2)
+
+
+@pytest.mark.parametrize("path", ["tiles", "steps"])
+@pytest.mark.parametrize("P,L", [(8, 60), (50, 5000), (200, 20000)])
+def test_device_pose_solve_matches_host_cholesky(synth, monkeypatch, path, P, L):
+    """The device factorisation that stands in for CHOLMOD (k_chol_tiles: one dataflow launch; k_chol_step: one launch
+    per block column) against a host Cholesky refined in extended precision; solved twice (flag epochs)."""
+    if path == "steps":
+        monkeypatch.setenv("SE2GPU_BA_CHOL", "steps")
+    else:
+        monkeypatch.delenv("SE2GPU_BA_CHOL", raising=False)
+    g = synth.ba_graph(P, L)
+    o = _opt(g)
+    for lam in (30.0, 3.0):
+        S, bs = o.reduced_system(lam)
+        c = np.linalg.cholesky(S)
+        solve = lambda r: np.linalg.solve(c.T, np.linalg.solve(c, r))
+        x_ref = solve(bs).astype(np.longdouble)
+        for _ in range(3):
+            x_ref = x_ref + solve((bs.astype(np.longdouble) - S.astype(np.longdouble) @ x_ref).astype(np.float64))
+        for _ in range(2):
+            x, ok = o.solve(lam)
+            assert ok
+            assert np.abs(x - x_ref.astype(np.float64)).max() <= 1e-9 * np.abs(x_ref).max()
