@@ -841,6 +841,25 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
 //      L L^T = MR M^T,    x = R y = MR_R y_un      (no square root anywhere)
 // both M (in place in A / R) and MR (in AM / RM) are published.  Flags carry the solve's epoch: no clearing needed.
 // ---------------------------------------------------------------------------------------------
+// Tile hand-off between workgroups that may sit behind different L2s (one per XCD): agent-scope ("sc1") vector loads
+// and write-through stores, so that neither side has to invalidate / write back a whole L2 (which is what an
+// acquire / release fence costs, and what every other workgroup on that XCD then pays for).  The flag protocol
+// orders them: data stores -> s_waitcnt vmcnt(0) -> flag store;  flag seen -> barrier -> data loads.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ inline d2_t load_agent(const double* p) {
+    d2_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ inline void store_agent(double* p, d2_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ inline void store_agent1(double* p, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
+#define SE2_WAIT_VM6(a, b, c, d, e, f) \
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
+
 __device__ inline bool spin_until(const unsigned* f, unsigned epoch) {
     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
     const long long t0 = wall_clock64();  // 100 MHz
@@ -896,21 +915,19 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
             if (tid == 0) fail[0] = 1e6;
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (stamp && tid == 0) stamp[1] = wall_clock64();
         const size_t offj = (size_t)(kNB * j + r) * ld + kNB * m + cc;
-        const size_t offi = (size_t)(kNB * i + r) * ld + kNB * m + cc;
-        const double2 mj0 = *reinterpret_cast<const double2*>(A + offj), mj1 = *reinterpret_cast<const double2*>(A + offj + 2);
-        const double2 rj0 = *reinterpret_cast<const double2*>(AM + offj), rj1 = *reinterpret_cast<const double2*>(AM + offj + 2);
-        double2 ri0 = make_double2(0, 0), ri1 = make_double2(0, 0);
-        if (hasT) {
-            ri0 = *reinterpret_cast<const double2*>(ownM + offi);
-            ri1 = *reinterpret_cast<const double2*>(ownM + offi + 2);
-        }
+        const size_t offi = hasT ? (size_t)(kNB * i + r) * ld + kNB * m + cc : offj;
+        d2_t mj0 = load_agent(A + offj), mj1 = load_agent(A + offj + 2);
+        d2_t rj0 = load_agent(AM + offj), rj1 = load_agent(AM + offj + 2);
+        d2_t ri0 = load_agent((hasT ? ownM : AM) + offi), ri1 = load_agent((hasT ? ownM : AM) + offi + 2);
+        SE2_WAIT_VM6(mj0, mj1, rj0, rj1, ri0, ri1);
+        if (!hasT) ri0 = ri1 = d2_t{0.0, 0.0};
         Ta[r][cc] = ri0.x; Ta[r][cc + 1] = ri0.y; Ta[r][cc + 2] = ri1.x; Ta[r][cc + 3] = ri1.y;
         Tb[r][cc] = mj0.x; Tb[r][cc + 1] = mj0.y; Tb[r][cc + 2] = mj1.x; Tb[r][cc + 3] = mj1.y;
         Tc[r][cc] = rj0.x; Tc[r][cc + 1] = rj0.y; Tc[r][cc + 2] = rj1.x; Tc[r][cc + 3] = rj1.y;
         __syncthreads();
+        if (stamp && tid == 0) stamp[7] = wall_clock64();
         double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
         double dcc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
@@ -994,27 +1011,28 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         if (ncol == kNB) {
 #pragma unroll
             for (int c = 0; c < kNB; c += 2) {
-                reinterpret_cast<double2*>(pm)[c / 2] = make_double2(m[c], m[c + 1]);
-                reinterpret_cast<double2*>(pr)[c / 2] = *reinterpret_cast<const double2*>(mrrow + c);
+                const double2 mrv = *reinterpret_cast<const double2*>(mrrow + c);
+                store_agent(pm + c, d2_t{m[c], m[c + 1]});
+                store_agent(pr + c, d2_t{mrv.x, mrv.y});
             }
         } else {
 #pragma unroll
             for (int c = 0; c < kNB; ++c)
                 if (c < ncol) {
-                    pm[c] = m[c];
-                    pr[c] = mrrow[c];
+                    store_agent1(pm + c, m[c]);
+                    store_agent1(pr + c, mrrow[c]);
                 }
         }
     } else if (isDiag && rr >= ncol) {
         double* pm = A + (size_t)(c0 + rr) * ld + c0;
 #pragma unroll
         for (int c = 0; c < kNB; ++c)
-            if (c < ncol) pm[c] = m[c];
+            if (c < ncol) pm[c] = m[c];   // y_un: read by k_chol_apply only (next kernel)
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores of the whole wave have landed
     if (lane == 0)
-        __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELEASE,
+        __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (stamp && lane == 0) stamp[5] = wall_clock64();
 }
@@ -1940,7 +1958,7 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
         for (int t = 0; t < h->chol_ntask; ++t) {
             std::fprintf(stderr, "choltrace %d %d %d %d", t, tk[t].x & 0xffff, tk[t].x >> 16, tk[t].y);
             for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %lld", tr[8 * (size_t)t + q] ? tr[8 * (size_t)t + q] - t0 : -1);
-            std::fprintf(stderr, " %lld", tr[8 * (size_t)t + 6]);
+            std::fprintf(stderr, " %lld %lld", tr[8 * (size_t)t + 6], tr[8 * (size_t)t + 7] ? tr[8 * (size_t)t + 7] - t0 : -1);
             std::fprintf(stderr, "\n");
         }
     }
