@@ -1012,15 +1012,15 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
 #pragma unroll
             for (int c = 0; c < kNB; c += 2) {
                 const double2 mrv = *reinterpret_cast<const double2*>(mrrow + c);
-                store_agent(pm + c, d2_t{m[c], m[c + 1]});
-                store_agent(pr + c, d2_t{mrv.x, mrv.y});
+                reinterpret_cast<double2*>(pm)[c / 2] = make_double2(m[c], m[c + 1]);
+                reinterpret_cast<double2*>(pr)[c / 2] = mrv;
             }
         } else {
 #pragma unroll
             for (int c = 0; c < kNB; ++c)
                 if (c < ncol) {
-                    store_agent1(pm + c, m[c]);
-                    store_agent1(pr + c, mrrow[c]);
+                    pm[c] = m[c];
+                    pr[c] = mrrow[c];
                 }
         }
     } else if (isDiag && rr >= ncol) {
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
             if (c < ncol) pm[c] = m[c];   // y_un: read by k_chol_apply only (next kernel)
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores of the whole wave have landed
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // stores of the whole wave written back from this XCD's L2
     if (lane == 0)
         __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
