@@ -19,6 +19,8 @@
 //     and polls the caller's stop flag between trials (SparseOptimizer::setForceStopFlag).
 // Multi-GPU: landmarks are sharded; S|bs is summed over ranks through the caller's all-reduce callback (RCCL).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <limits>
@@ -846,6 +848,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
 // acquire / release fence costs, and what every other workgroup on that XCD then pays for).  The flag protocol
 // orders them: data stores -> s_waitcnt vmcnt(0) -> flag store;  flag seen -> barrier -> data loads.
 typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d4_t __attribute__((ext_vector_type(4)));
 __device__ inline d2_t load_agent(const double* p) {
     d2_t v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
@@ -893,15 +896,18 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     double* ownM = isR ? RM : AM;
     const int r = tid / 8, cc = (tid % 8) * 4;
     const size_t own_off = (size_t)(kNB * i + r) * ld + kNB * j + cc;
-    double2 t0 = make_double2(0, 0), t1 = make_double2(0, 0), d0, d1;
-    {
-        const double* dp = A + (size_t)(kNB * j + r) * ld + kNB * j + cc;
-        d0 = *reinterpret_cast<const double2*>(dp);
-        d1 = *reinterpret_cast<const double2*>(dp + 2);
-        if (!isR && !isDiag) {
-            t0 = *reinterpret_cast<const double2*>(A + own_off);
-            t1 = *reinterpret_cast<const double2*>(A + own_off + 2);
-        }
+    // The 32x32x32 tile products run on the matrix cores: v_mfma_f64_16x16x4_f64, wave w owns the 16x16 quadrant
+    // (w >> 1, w & 1) of T and of D.  Layouts (tools/mfma_probe.hip): A[i][k]: lane = i + 16 k; B[k][j]: lane = j + 16 k;
+    // D[i][j]: lane = j + 16 (i % 4), register = i / 4.
+    const int wv = tid >> 6, ln = tid & 63;
+    const int qi = 16 * (wv >> 1), qj = 16 * (wv & 1);
+    const int orow = qi + (ln >> 4), ocol = qj + (ln & 15);   // output element v: (orow + 4 v, ocol)
+    const int arow = ln & 15, acol = ln >> 4;                 // operand element of k-chunk ks: (arow, 4 ks + acol)
+    d4_t T0 = {0, 0, 0, 0}, D0, accT = {0, 0, 0, 0}, accD = {0, 0, 0, 0};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        D0[v] = A[(size_t)(kNB * j + orow + 4 * v) * ld + kNB * j + ocol];
+        if (!isR && !isDiag) T0[v] = A[(size_t)(kNB * i + orow + 4 * v) * ld + kNB * j + ocol];
     }
     for (int m = 0; m < j; ++m) {
         const bool hasT = !isDiag && !(isR && m < i);  // R(r,m) is zero for m < r: only D is updated
@@ -922,36 +928,25 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         d2_t rj0 = load_agent(AM + offj), rj1 = load_agent(AM + offj + 2);
         d2_t ri0 = load_agent((hasT ? ownM : AM) + offi), ri1 = load_agent((hasT ? ownM : AM) + offi + 2);
         SE2_WAIT_VM6(mj0, mj1, rj0, rj1, ri0, ri1);
-        if (!hasT) ri0 = ri1 = d2_t{0.0, 0.0};
         Ta[r][cc] = ri0.x; Ta[r][cc + 1] = ri0.y; Ta[r][cc + 2] = ri1.x; Ta[r][cc + 3] = ri1.y;
         Tb[r][cc] = mj0.x; Tb[r][cc + 1] = mj0.y; Tb[r][cc + 2] = mj1.x; Tb[r][cc + 3] = mj1.y;
         Tc[r][cc] = rj0.x; Tc[r][cc + 1] = rj0.y; Tc[r][cc + 2] = rj1.x; Tc[r][cc + 3] = rj1.y;
         __syncthreads();
         if (stamp && tid == 0) stamp[7] = wall_clock64();
-        double acc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-        double dcc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 #pragma unroll
-        for (int q2 = 0; q2 < kNB; q2 += 2) {
-            const double a0 = Ta[r][q2], a1 = Ta[r][q2 + 1];
-            const double c0 = Tc[r][q2], c1 = Tc[r][q2 + 1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double b0 = Tb[cc + q][q2], b1 = Tb[cc + q][q2 + 1];
-                acc[q][0] = fma(a0, b0, acc[q][0]);
-                acc[q][1] = fma(a1, b1, acc[q][1]);
-                dcc[q][0] = fma(c0, b0, dcc[q][0]);
-                dcc[q][1] = fma(c1, b1, dcc[q][1]);
-            }
+        for (int ks = 0; ks < kNB / 4; ++ks) {
+            const double bv = Tb[qj + arow][4 * ks + acol];
+            accD = __builtin_amdgcn_mfma_f64_16x16x4f64(Tc[qi + arow][4 * ks + acol], bv, accD, 0, 0, 0);
+            if (hasT) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Ta[qi + arow][4 * ks + acol], bv, accT, 0, 0, 0);
         }
-        t0 = make_double2(t0.x - (acc[0][0] + acc[0][1]), t0.y - (acc[1][0] + acc[1][1]));
-        t1 = make_double2(t1.x - (acc[2][0] + acc[2][1]), t1.y - (acc[3][0] + acc[3][1]));
-        d0 = make_double2(d0.x - (dcc[0][0] + dcc[0][1]), d0.y - (dcc[1][0] + dcc[1][1]));
-        d1 = make_double2(d1.x - (dcc[2][0] + dcc[2][1]), d1.y - (dcc[3][0] + dcc[3][1]));
     }
     __syncthreads();
     if (stamp && tid == 0) stamp[2] = wall_clock64();
-    Ta[r][cc] = t0.x; Ta[r][cc + 1] = t0.y; Ta[r][cc + 2] = t1.x; Ta[r][cc + 3] = t1.y;
-    Tb[r][cc] = d0.x; Tb[r][cc + 1] = d0.y; Tb[r][cc + 2] = d1.x; Tb[r][cc + 3] = d1.y;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        Ta[orow + 4 * v][ocol] = T0[v] - accT[v];
+        Tb[orow + 4 * v][ocol] = D0[v] - accD[v];
+    }
     __syncthreads();
     if (tid >= 64) return;
     // ---- wave 0: eliminate [D; T]
@@ -1137,7 +1132,7 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
                            const double* __restrict__ xp, const double* __restrict__ bp, double* __restrict__ poses_trial,
                            int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
                            const double* __restrict__ o_meas, const double* __restrict__ o_info, int root,
-                           double* __restrict__ out) {
+                           double* __restrict__ out, volatile double* __restrict__ mail, double seq) {
     __shared__ double sm[2][1024];
     __shared__ double sp[3 * 1024];  // trial poses staged for the odometry pass when P <= 1024
     const bool step = xp != nullptr;
@@ -1179,7 +1174,16 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0; }
+    if (threadIdx.x == 0) {
+        out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0;
+        if (mail) {  // single-GPU: the LM controller on the host polls this mapped, coherent host buffer instead of
+            mail[0] = sm[0][0];           // paying a stream synchronise + D2H copy per trial
+            mail[1] = sm[1][0];
+            mail[2] = step ? out[2] : 0.0;  // factorisation flag of the solve that produced xp
+            __threadfence_system();
+            mail[3] = seq;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1331,6 +1335,9 @@ struct se2gpu_ba {
     bool chol_steps = false;      // SE2GPU_BA_CHOL=steps: one launch per block column (k_chol_step) instead
     double* red = nullptr;  // [augmented (ld x ld): rows 0..n-1 = S, row n = bs | 4 scalars]
     PinBuf<double> h_red, h_x, h_scal;
+    double* h_mail = nullptr;      // mapped + coherent host mailbox written by k_finalize: {chi2, scale, fail, seq}
+    double* d_mail = nullptr;
+    uint64_t mail_seq = 0;
     // multi-GPU
     se2gpu_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
@@ -1340,6 +1347,7 @@ struct se2gpu_ba {
 
     ~se2gpu_ba() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (h_mail) (void)hipHostFree(h_mail);
     }
 };
 
@@ -1560,6 +1568,14 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     SE2_CHECK(h->h_x.reserve(n));
     SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
+    if (!h->h_mail) {
+        const char* env = getenv("SE2GPU_BA_MAILBOX");
+        if (!(env && env[0] == '0')) {
+            SE2_HIP(hipHostMalloc((void**)&h->h_mail, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(h->h_mail, 0, 8 * sizeof(double));
+            SE2_HIP(hipHostGetDevicePointer((void**)&h->d_mail, h->h_mail, 0));
+        }
+    }
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
     h->lms = h->lms_a.p; h->lms_t = h->lms_b.p;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));
@@ -1634,13 +1650,30 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
     const int n = 3 * h->P;
     (void)n;
     double* scal = h->red + (size_t)h->ld * h->ld;  // 4 trailing scalars of the fused buffer
+    const bool use_mail = h->d_mail && !(h->allreduce && h->world > 1) && !h->comm;
+    const double seq = (double)(++h->mail_seq);
     SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
                lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
                h->Y.p, h->bl.p, h->lms_t, h->part.p);
     SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
-               h->o_info.p, h->root, scal);
+               h->o_info.p, h->root, scal, use_mail ? h->d_mail : nullptr, seq);
     SE2_HIP(hipGetLastError());
+    if (use_mail) {
+        volatile double* mb = h->h_mail;
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (mb[3] != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                SE2_HIP(hipStreamSynchronize(st));  // surfaces a device fault, if that is what happened
+                SE2_REQUIRE(mb[3] == seq, SE2GPU_ERR_HIP, "k_finalize mailbox was not written");
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h->h_scal.p[0] = mb[0]; h->h_scal.p[1] = mb[1]; h->h_scal.p[2] = mb[2];
+        return SE2GPU_OK;
+    }
     if (!xp) SE2_HIP(hipMemsetAsync(scal + 2, 0, sizeof(double), st));
     SE2_CHECK(ba_allreduce(h, scal, 4));
     SE2_HIP(hipMemcpyAsync(h->h_scal.p, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
