@@ -656,6 +656,10 @@ __device__ inline double fast_rcp(double d) {  // v_rcp_f64 + 2 Newton steps (fu
     r = fma(fma(-d, r, 1.0), r, r);
     return r;
 }
+__device__ inline double fast_rcp1(double d) {  // v_rcp_f64 + 1 Newton step: relative error ~2e-15
+    double r = __builtin_amdgcn_rcp(d);
+    return fma(fma(-d, r, 1.0), r, r);
+}
 __device__ inline double fast_rsqrt(double d) {  // v_rsq_f64 + 2 Newton steps
     double y = __builtin_amdgcn_rsq(d);
     y = y * fma(-0.5 * d * y, y, 1.5);
@@ -882,10 +886,11 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     __shared__ __attribute__((aligned(16))) double Ta[kNB][kNB + 2];  // MR(i,m), then the finished tile T
     __shared__ __attribute__((aligned(16))) double Tb[kNB][kNB + 2];  // M(j,m),  then the finished diagonal D
     __shared__ __attribute__((aligned(16))) double Tc[kNB][kNB + 2];  // MR(j,m)
-    __shared__ __attribute__((aligned(16))) double colA[64];
-    __shared__ __attribute__((aligned(16))) double colB[64];
-    __shared__ int ok_s;
+    __shared__ __attribute__((aligned(16))) double MRC[kNB][64];      // multiplier column of every eliminated column
+    __shared__ __attribute__((aligned(16))) double COLV[kNB][64];     // its values in the D rows (lanes 0..31 are used)
+    __shared__ int ok_s, ready_s;
     const int tid = threadIdx.x;
+    if (tid == 0) ready_s = 0;
     long long* stamp = dbg ? dbg + (size_t)blockIdx.x * 8 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     const int2 tk = tasks[blockIdx.x];
@@ -895,7 +900,6 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     double* own = isR ? R : A;
     double* ownM = isR ? RM : AM;
     const int r = tid / 8, cc = (tid % 8) * 4;
-    const size_t own_off = (size_t)(kNB * i + r) * ld + kNB * j + cc;
     // The 32x32x32 tile products run on the matrix cores: v_mfma_f64_16x16x4_f64, wave w owns the 16x16 quadrant
     // (w >> 1, w & 1) of T and of D.  Layouts (tools/mfma_probe.hip): A[i][k]: lane = i + 16 k; B[k][j]: lane = j + 16 k;
     // D[i][j]: lane = j + 16 (i % 4), register = i / 4.
@@ -948,88 +952,120 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         Tb[orow + 4 * v][ocol] = D0[v] - accD[v];
     }
     __syncthreads();
-    if (tid >= 64) return;
-    // ---- wave 0: eliminate [D; T]
-    const int lane = tid;
+    // ---- eliminate the stacked [D; T] (lane = row): the 32 columns are split over the 4 waves, 8 each.  Wave w first
+    // applies the rank-1 updates of the 8 w columns owned by the waves before it, as their owners publish them in LDS
+    // (multiplier column MRC[jj][row], pivot-row values COLV[jj][c] and a progress counter), then eliminates its own 8
+    // columns (pivot path through v_readlane, reciprocal of the next pivot in flight during the update).  The chain
+    // is still 32 pivots long, but the 465 rank-1 column updates that bounded the single-wave version are spread over
+    // four SIMDs and the early waves publish their part of the tile while the later ones still work.
+    const int lane = ln;
+    const int w = __builtin_amdgcn_readfirstlane(wv);
+    const int cb = 8 * w;
     const int c0 = kNB * j;
     const int ncol = min(kNB, n - c0);
     const int rr = lane & 31;
-    double m[kNB];
+    double m[8], mrs[8];
     {
-        const double* lp = (lane < kNB) ? &Tb[rr][0] : &Ta[rr][0];
+        const double* lp = (lane < kNB) ? &Tb[rr][cb] : &Ta[rr][cb];
         const bool ident = isDiag && lane >= kNB;
 #pragma unroll
-        for (int c = 0; c < kNB; c += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(lp + c);
-            m[c] = ident ? (c == rr ? 1.0 : 0.0) : v.x;
-            m[c + 1] = ident ? (c + 1 == rr ? 1.0 : 0.0) : v.y;
+        for (int q = 0; q < 8; q += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(lp + q);
+            m[q] = ident ? (cb + q == rr ? 1.0 : 0.0) : v.x;
+            m[q + 1] = ident ? (cb + q + 1 == rr ? 1.0 : 0.0) : v.y;
         }
-        if (ncol < kNB) {  // last panel only (uniform branch: keeps 32 select masks out of the common path)
+        if (ncol < kNB) {  // last panel only: columns past n become a decoupled block (huge diagonal, zero elsewhere)
 #pragma unroll
-            for (int c = 0; c < kNB; ++c)
-                if (c >= ncol) m[c] = (lane < kNB && c == rr) ? 1e300 : 0.0;
+            for (int q = 0; q < 8; ++q)
+                if (cb + q >= ncol) m[q] = (lane < kNB && cb + q == rr) ? 1e300 : 0.0;
         }
     }
     long long clk0 = 0;
     if (stamp) clk0 = clock64();
-    if (stamp && lane == 0) stamp[3] = wall_clock64();
-    // the multipliers MR = M / pivot of this lane's row are parked in LDS (the staged tiles are in registers now)
-    double* mrrow = (lane < kNB) ? &Tb[rr][0] : &Ta[rr][0];
-    bool bad = false;
-    double piv = bcast_lane(m[0], 0);
-    double inv = fast_rcp(piv);
-#pragma unroll
-    for (int jj = 0; jj < kNB; ++jj) {
-        bad |= !__builtin_amdgcn_class(piv, 0x180);  // not (+normal | +denormal): <= 0, inf or NaN (pad pivots are 1e300)
-        const double mr = m[jj] * inv;
-        mrrow[jj] = mr;
-        if (jj + 1 < kNB) {
-            m[jj + 1] = fma(-mr, bcast_lane(m[jj], jj + 1), m[jj + 1]);
-            piv = bcast_lane(m[jj + 1], jj + 1);
-            inv = fast_rcp(piv);  // next pivot: in flight during the bulk update
+    if (stamp && tid == 0) stamp[3] = wall_clock64();
+    for (int done = 0; done < cb;) {
+        int avail = __hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        avail = min(avail, cb);
+        if (avail == done) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;
         }
-        if (jj + 2 < kNB) {
-            double* col = (jj & 1) ? colB : colA;
-            col[lane] = m[jj];
+        for (; done < avail; ++done) {
+            const double mr = MRC[done][lane];
+            const double* cv = &COLV[done][cb];
 #pragma unroll
-            for (int c = jj + 2; c < kNB; ++c) m[c] = fma(-mr, col[c], m[c]);
+            for (int q = 0; q < 8; ++q) m[q] = fma(-mr, cv[q], m[q]);
         }
     }
-    if (stamp && lane == 32) stamp[4] = wall_clock64() + (long long)(m[31] == 1.2345e-300);
-    if (stamp && lane == 32) stamp[6] = clock64() - clk0;
+    // Every instruction of this wave is issued in order at ~8 clk, so the cost of a pivot column is its instruction
+    // count: one Newton step on v_rcp_f64 (relative error 2e-15, used consistently for M and MR, i.e. a 2e-15 relative
+    // perturbation of the pivots of an LDL^T whose rounding errors are larger), pivot test folded into one running
+    // minimum, LDS rows addressed with immediate offsets.
+    double* mrc = &MRC[cb][lane];
+    double* colv = &COLV[cb][lane];
+    double pmin = 1e300;
+    double piv = bcast_lane(m[0], cb);
+    double inv = fast_rcp1(piv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int jj = cb + q;
+        pmin = fmin(pmin, piv);  // (ignores NaN: caught below)
+        const double mr = m[q] * inv;
+        mrs[q] = mr;
+        mrc[q * 64] = mr;        // later waves need this column (the last wave's copy is never read)
+        colv[q * 64] = m[q];
+        // LDS operations of one wave execute in issue order, so the counter needs no s_waitcnt in front of it (that
+        // wait would sit on the pivot chain) - only the compiler has to keep the three writes in this order
+        asm volatile("" ::: "memory");
+        __hip_atomic_store(&ready_s, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+        if (q + 1 < 8) {
+            m[q + 1] = fma(-mr, bcast_lane(m[q], jj + 1), m[q + 1]);
+            piv = bcast_lane(m[q + 1], jj + 1);
+            inv = fast_rcp1(piv);  // next pivot: in flight during the rest of the update
+        }
+#pragma unroll
+        for (int q2 = q + 2; q2 < 8; ++q2) m[q2] = fma(-mr, bcast_lane(m[q], cb + q2), m[q2]);
+    }
+    // pivots must be positive and finite (pad pivots are ~1e300)
+    // (the pivot row's own multiplier is pivot * inv: NaN exactly when this or an earlier pivot was NaN)
+    const double chk = bcast_lane(mrs[7], cb + 7);
+    const bool bad = !(pmin > 0.0) | !(pmin < __builtin_inf()) | !(chk == chk);
+    if (stamp && tid == 224) stamp[4] = wall_clock64() + (long long)(m[7] == 1.2345e-300);
+    if (stamp && tid == 224) stamp[6] = clock64() - clk0;
     // lanes 32..63 own the output rows (diagonal task: R(j,j) from the identity).  Of the diagonal tile only rows
     // >= n (the rhs row when it lives in the last diagonal tile) are results: y_un.
     if (lane >= kNB) {
-        const size_t off = (size_t)(kNB * i + rr) * ld + c0;
+        const size_t off = (size_t)(kNB * i + rr) * ld + c0 + cb;
         double* pm = (isDiag ? R : own) + off;
         double* pr = (isDiag ? RM : ownM) + off;
         if (ncol == kNB) {
 #pragma unroll
-            for (int c = 0; c < kNB; c += 2) {
-                const double2 mrv = *reinterpret_cast<const double2*>(mrrow + c);
-                reinterpret_cast<double2*>(pm)[c / 2] = make_double2(m[c], m[c + 1]);
-                reinterpret_cast<double2*>(pr)[c / 2] = mrv;
+            for (int q = 0; q < 8; q += 2) {
+                reinterpret_cast<double2*>(pm)[q / 2] = make_double2(m[q], m[q + 1]);
+                reinterpret_cast<double2*>(pr)[q / 2] = make_double2(mrs[q], mrs[q + 1]);
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < kNB; ++c)
-                if (c < ncol) {
-                    pm[c] = m[c];
-                    pr[c] = mrrow[c];
+            for (int q = 0; q < 8; ++q)
+                if (cb + q < ncol) {
+                    pm[q] = m[q];
+                    pr[q] = mrs[q];
                 }
         }
     } else if (isDiag && rr >= ncol) {
-        double* pm = A + (size_t)(c0 + rr) * ld + c0;
+        double* py = A + (size_t)(c0 + rr) * ld + c0 + cb;
 #pragma unroll
-        for (int c = 0; c < kNB; ++c)
-            if (c < ncol) pm[c] = m[c];   // y_un: read by k_chol_apply only (next kernel)
+        for (int q = 0; q < 8; ++q)
+            if (cb + q < ncol) py[q] = m[q];   // y_un: read by k_chol_apply only (next kernel)
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // stores of the whole wave written back from this XCD's L2
-    if (lane == 0)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores are written back from this XCD's L2
+    __syncthreads();
+    if (tid == 0)
         __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-    if (stamp && lane == 0) stamp[5] = wall_clock64();
+    if (stamp && tid == 0) stamp[5] = wall_clock64();
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
