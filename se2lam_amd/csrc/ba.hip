@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     __shared__ int ok_s, ready_s;
     const int tid = threadIdx.x;
     if (tid == 0) ready_s = 0;
-    long long* stamp = dbg ? dbg + (size_t)blockIdx.x * 8 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
+    long long* stamp = dbg ? dbg + (size_t)blockIdx.x * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     const int2 tk = tasks[blockIdx.x];
     const bool isR = (tk.x >> 16) != 0;
@@ -983,20 +983,27 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     long long clk0 = 0;
     if (stamp) clk0 = clock64();
     if (stamp && tid == 0) stamp[3] = wall_clock64();
-    for (int done = 0; done < cb;) {
-        int avail = __hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        avail = min(avail, cb);
-        if (avail == done) {
+    // published columns are consumed four at a time (cb is a multiple of 8): one poll and one LDS latency per batch, all
+    // 20 reads in flight before the first FMA needs one - a consumer that polled per column could not keep up with
+    // the ~200 clk per column of the producing wave
+    for (int done = 0; done < cb; done += 4) {
+        while (__hip_atomic_load(&ready_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < done + 4)
             __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        for (; done < avail; ++done) {
-            const double mr = MRC[done][lane];
-            const double* cv = &COLV[done][cb];
+        double mrv[4], cv[4][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = fma(-mr, cv[q], m[q]);
+        for (int u = 0; u < 4; ++u) {
+            mrv[u] = MRC[done + u][lane];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cv[u][q] = COLV[done + u][cb + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = fma(-mrv[u], cv[u][q], m[q]);
         }
     }
+    if (stamp && lane == 0) stamp[8 + w] = wall_clock64();
     // Every instruction of this wave is issued in order at ~8 clk, so the cost of a pivot column is its instruction
     // count: one Newton step on v_rcp_f64 (relative error 2e-15, used consistently for M and MR, i.e. a 2e-15 relative
     // perturbation of the pivots of an LDL^T whose rounding errors are larger), pivot test folded into one running
@@ -1027,6 +1034,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
 #pragma unroll
         for (int q2 = q + 2; q2 < 8; ++q2) m[q2] = fma(-mr, bcast_lane(m[q], cb + q2), m[q2]);
     }
+    if (stamp && lane == 0) stamp[12 + w] = wall_clock64() + (long long)(m[7] == 1.2345e-300);
     // pivots must be positive and finite (pad pivots are ~1e300)
     // (the pivot row's own multiplier is pivot * inv: NaN exactly when this or an earlier pivot was NaN)
     const double chk = bcast_lane(mrs[7], cb + 7);
@@ -1598,8 +1606,8 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt > 64;
         const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
         if (tr && tr[0] == '1') {
-            SE2_CHECK(h->chol_trace.reserve(8 * (size_t)h->chol_ntask));
-            SE2_HIP(hipMemsetAsync(h->chol_trace.p, 0, 8 * (size_t)h->chol_ntask * sizeof(long long), st));
+            SE2_CHECK(h->chol_trace.reserve(16 * (size_t)h->chol_ntask));
+            SE2_HIP(hipMemsetAsync(h->chol_trace.p, 0, 16 * (size_t)h->chol_ntask * sizeof(long long), st));
         }
     }
     SE2_CHECK(h->h_x.reserve(n));
@@ -2018,16 +2026,17 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
     SE2_REQUIRE(f < 1e5, SE2GPU_ERR_HIP, "k_chol_tiles: a dependency spin timed out (2 s)");
     if (factor_ok) *factor_ok = !(f > 0.0);
     if (h->chol_trace.p && !h->chol_steps) {  // task, tile row, R?, column, then stamps relative to the first in 10 ns ticks
-        std::vector<long long> tr(8 * (size_t)h->chol_ntask);
+        std::vector<long long> tr(16 * (size_t)h->chol_ntask);
         std::vector<int2> tk(h->chol_ntask);
         SE2_HIP(hipMemcpy(tr.data(), h->chol_trace.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
         SE2_HIP(hipMemcpy(tk.data(), h->chol_tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost));
         long long t0 = tr[0];
-        for (int t = 0; t < h->chol_ntask; ++t) t0 = std::min(t0, tr[8 * (size_t)t]);
+        for (int t = 0; t < h->chol_ntask; ++t) t0 = std::min(t0, tr[16 * (size_t)t]);
         for (int t = 0; t < h->chol_ntask; ++t) {
             std::fprintf(stderr, "choltrace %d %d %d %d", t, tk[t].x & 0xffff, tk[t].x >> 16, tk[t].y);
-            for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %lld", tr[8 * (size_t)t + q] ? tr[8 * (size_t)t + q] - t0 : -1);
-            std::fprintf(stderr, " %lld %lld", tr[8 * (size_t)t + 6], tr[8 * (size_t)t + 7] ? tr[8 * (size_t)t + 7] - t0 : -1);
+            for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %lld", tr[16 * (size_t)t + q] ? tr[16 * (size_t)t + q] - t0 : -1);
+            std::fprintf(stderr, " %lld %lld", tr[16 * (size_t)t + 6], tr[16 * (size_t)t + 7] ? tr[16 * (size_t)t + 7] - t0 : -1);
+            for (int q = 8; q < 16; ++q) std::fprintf(stderr, " %lld", tr[16 * (size_t)t + q] ? tr[16 * (size_t)t + q] - t0 : -1);
             std::fprintf(stderr, "\n");
         }
     }
