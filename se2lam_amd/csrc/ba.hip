@@ -585,27 +585,60 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
     }
     double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // S diag (6 sym), bp (3), g (3)
     const bool fa = fixed[p];
+    __shared__ double odoc[8][12];  // PreEdgeSE2 contributions of this pose, one lane each (sin/cos: kept off thread 0)
+    const int no = fa ? 0 : podo_ptr[p + 1] - podo_ptr[p];
+    if ((int)threadIdx.x >= kBlock - 8 && (int)threadIdx.x - (kBlock - 8) < min(no, 8)) {
+        const int t = podo_ptr[p] + (int)threadIdx.x - (kBlock - 8);
+        const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
+        double e[3], A[9], B[9], WA[9], WB[9], omr[3];
+        odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
+        const double* J = isj ? B : A;
+        const double* WJ = isj ? WB : WA;
+        double* o = odoc[threadIdx.x - (kBlock - 8)];
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) o[r * 3 + c] = J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
+            o[9 + r] = J[r] * omr[0] + J[3 + r] * omr[1] + J[6 + r] * omr[2];
+        }
+    }
     if (!fa) {
-        for (int t = pose_ptr[p] + threadIdx.x; t < pose_ptr[p + 1]; t += kBlock) {
-            const int e = pose_edges[t];
-            const double* y = Y + (size_t)e * 9;
-            const double* h = Hpl + (size_t)e * 9;
-            const double* hp = Hpp_e + (size_t)e * 6;
-            const double* zz = z + (size_t)e_lm[e] * 3;
-            double yy[9], hh[9];
+        // dependent gather (edge list -> edge rows, edge -> landmark -> z): the indices of up to four edges per thread
+        // are fetched first, so a pose with <= 1024 observations pays each level of the chain once
+        const int e0 = pose_ptr[p], ne = pose_ptr[p + 1] - e0;
+        for (int base = 0; base < ne; base += 4 * kBlock) {
+            int ee[4], ll[4];
+            double wgt[4];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) { yy[i] = y[i]; hh[i] = h[i]; }
-            acc[0] += hp[0] - (yy[0] * hh[0] + yy[1] * hh[1] + yy[2] * hh[2]);
-            acc[1] += hp[1] - (yy[0] * hh[3] + yy[1] * hh[4] + yy[2] * hh[5]);
-            acc[2] += hp[2] - (yy[0] * hh[6] + yy[1] * hh[7] + yy[2] * hh[8]);
-            acc[3] += hp[3] - (yy[3] * hh[3] + yy[4] * hh[4] + yy[5] * hh[5]);
-            acc[4] += hp[4] - (yy[3] * hh[6] + yy[4] * hh[7] + yy[5] * hh[8]);
-            acc[5] += hp[5] - (yy[6] * hh[6] + yy[7] * hh[7] + yy[8] * hh[8]);
-            const double z0 = zz[0], z1 = zz[1], z2 = zz[2];
+            for (int u = 0; u < 4; ++u) {
+                const int t = base + u * kBlock + (int)threadIdx.x;
+                wgt[u] = t < ne ? 1.0 : 0.0;
+                ee[u] = pose_edges[e0 + min(t, ne - 1)];
+            }
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                acc[6 + r] += bp_e[(size_t)e * 3 + r];
-                acc[9 + r] += hh[r * 3] * z0 + hh[r * 3 + 1] * z1 + hh[r * 3 + 2] * z2;
+            for (int u = 0; u < 4; ++u) ll[u] = e_lm[ee[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (base + u * kBlock >= ne) break;  // uniform
+                const int e = ee[u];
+                const double* y = Y + (size_t)e * 9;
+                const double* h = Hpl + (size_t)e * 9;
+                const double* hp = Hpp_e + (size_t)e * 6;
+                const double* zz = z + (size_t)ll[u] * 3;
+                const double w = wgt[u];
+                double yy[9], hh[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) { yy[i] = y[i]; hh[i] = h[i]; }
+                acc[0] += w * (hp[0] - (yy[0] * hh[0] + yy[1] * hh[1] + yy[2] * hh[2]));
+                acc[1] += w * (hp[1] - (yy[0] * hh[3] + yy[1] * hh[4] + yy[2] * hh[5]));
+                acc[2] += w * (hp[2] - (yy[0] * hh[6] + yy[1] * hh[7] + yy[2] * hh[8]));
+                acc[3] += w * (hp[3] - (yy[3] * hh[3] + yy[4] * hh[4] + yy[5] * hh[5]));
+                acc[4] += w * (hp[4] - (yy[3] * hh[6] + yy[4] * hh[7] + yy[5] * hh[8]));
+                acc[5] += w * (hp[5] - (yy[6] * hh[6] + yy[7] * hh[7] + yy[8] * hh[8]));
+                const double z0 = zz[0], z1 = zz[1], z2 = zz[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[6 + r] += w * bp_e[(size_t)e * 3 + r];
+                    acc[9 + r] += w * (hh[r * 3] * z0 + hh[r * 3 + 1] * z1 + hh[r * 3 + 2] * z2);
+                }
             }
         }
     }
@@ -616,33 +649,37 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
         for (int i = 0; i < 12; ++i) dpart[wv][i] = acc[i];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double t12[12];
-        for (int i = 0; i < 12; ++i) t12[i] = dpart[0][i] + dpart[1][i] + dpart[2][i] + dpart[3][i];
-        double H[9] = {t12[0], t12[1], t12[2], t12[1], t12[3], t12[4], t12[2], t12[4], t12[5]};
-        double b[3] = {t12[6], t12[7], t12[8]};
-        if (!fa) {
-            for (int t = podo_ptr[p]; t < podo_ptr[p + 1]; ++t) {
-                const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
-                double e[3], A[9], B[9], WA[9], WB[9], omr[3];
-                odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
-                const double* J = isj ? B : A;
-                const double* WJ = isj ? WB : WA;
-                for (int r = 0; r < 3; ++r) {
-                    for (int c = 0; c < 3; ++c) H[r * 3 + c] += J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
-                    b[r] += J[r] * omr[0] + J[3 + r] * omr[1] + J[6 + r] * omr[2];
-                }
+    if (threadIdx.x < 12) {  // entries 0..8 of the 3x3 block (row-major), 9..11 of the right-hand sides
+        const int i = threadIdx.x;
+        const int sym[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+        const int src = i < 9 ? sym[i] : i - 3;  // H entry, or bp component (slots 6..8)
+        double v = dpart[0][src] + dpart[1][src] + dpart[2][src] + dpart[3][src];
+        for (int t = 0; t < min(no, 8); ++t) v += odoc[t][i];
+        for (int t = podo_ptr[p] + 8; t < podo_ptr[p] + no; ++t) {  // more than 8 PreEdgeSE2 at one pose: serial tail
+            const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
+            double e[3], A[9], B[9], WA[9], WB[9], omr[3];
+            odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
+            const double* J = isj ? B : A;
+            const double* WJ = isj ? WB : WA;
+            if (i < 9) {
+                const int r = i / 3, c = i - 3 * r;
+                v += J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
+            } else {
+                const int r = i - 9;
+                v += J[r] * omr[0] + J[3 + r] * omr[1] + J[6 + r] * omr[2];
             }
         }
-        for (int r = 0; r < 3; ++r) {
-            for (int c = 0; c < 3; ++c) {
-                double out;
-                if (fa) out = (r == c && root) ? 1.0 : 0.0;
-                else out = H[r * 3 + c] + ((r == c && root) ? lambda : 0.0);
-                S[(size_t)(3 * p + r) * ld + 3 * p + c] = out;
-            }
-            bs[3 * p + r] = fa ? 0.0 : b[r] - t12[9 + r];
-            bp[(size_t)p * 3 + r] = fa ? 0.0 : b[r];
+        if (i < 9) {
+            const int r = i / 3, c = i - 3 * r;
+            double out;
+            if (fa) out = (r == c && root) ? 1.0 : 0.0;
+            else out = v + ((r == c && root) ? lambda : 0.0);
+            S[(size_t)(3 * p + r) * ld + 3 * p + c] = out;
+        } else {
+            const int r = i - 9;
+            const double gz = dpart[0][9 + r] + dpart[1][9 + r] + dpart[2][9 + r] + dpart[3][9 + r];
+            bs[3 * p + r] = fa ? 0.0 : v - gz;
+            bp[(size_t)p * 3 + r] = fa ? 0.0 : v;
         }
     }
 }
