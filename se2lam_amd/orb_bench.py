@@ -83,12 +83,16 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     dom = max(kern, key=lambda k: kern[k]["total_ms"]) if kern else None
     roof = None
     if dom:
-        # one launch of an extractor kernel processes the B frames of the batch (k_resize: one of 7 launches)
-        per_launch_frames = B * (1.0 / 7.0 if dom == "k_resize" else 1.0)
-        ach = B_ORB * per_launch_frames / (kern[dom]["avg_us"] * 1e-6) / 1e9
+        # one launch of an extractor kernel processes the B frames of the batch; its algorithmic bytes are its stage's
+        # share of SURVEY.md section 8(d)'s pass-per-stage accounting (sum over the 8 pyramid levels = 950,532 px)
+        stage = {"k_level0": 307_200 + 307_200, "k_resize": (926_546 + 643_332 - 307_200) / 7.0,
+                 "k_fast_score": 950_532, "k_cell_detect": 950_532, "k_blur": 1_901_064, "copy_border": 1_901_064,
+                 "k_orientation": 749_000, "k_describe": 512_000 + 60_000, "k_level_select": 60_000}
+        b_launch = stage.get(dom, B_ORB) * B
+        ach = b_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": (traffic or {}).get(dom, {}).get("traffic_bytes"),
-                "algorithmic_bytes_per_launch": B_ORB * per_launch_frames,
+                "algorithmic_bytes_per_launch": b_launch,
                 "avg_launch_us": kern[dom]["avg_us"],
                 "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,
                 "whole_step_frac": (B_ORB + B_MATCH) * fps / world / 1e9 / HBM_PEAK_GBS,
