@@ -150,31 +150,39 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
 typedef short short2v __attribute__((ext_vector_type(2)));
 
 // Two pixels at once in packed int16 lanes (v_pk_min_i16 / v_pk_max_i16): d[k] = v - p_k for the 16 ring pixels.
+// The 16 circular windows of 9 are formed from prefix / suffix extrema of the two halves of the ring (van Herk):
+// window k = d[k..7] u d[8..8+k] = min(sufA[k], preB[k]) for k < 8, and min(sufB[k-8], preA[k-8]) for k >= 8 - 44
+// instead of 64 operations per extremum; S = max(0, max_k min9[k], -min_k max9[k]).
 __device__ __forceinline__ short2v fast_score_pk(const short2v d[16]) {
-    short2v mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+    short2v preA[8], sufA[8], preB[8], sufB[8], PreA[8], SufA[8], PreB[8], SufB[8];   // lower case: min, upper: max
+    preA[0] = PreA[0] = d[0];
+    preB[0] = PreB[0] = d[8];
+    sufA[7] = SufA[7] = d[7];
+    sufB[7] = SufB[7] = d[15];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        mn2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
-        mx2[k] = __builtin_elementwise_max(d[k], d[(k + 1) & 15]);
+    for (int i = 1; i < 8; ++i) {
+        preA[i] = __builtin_elementwise_min(preA[i - 1], d[i]);
+        PreA[i] = __builtin_elementwise_max(PreA[i - 1], d[i]);
+        preB[i] = __builtin_elementwise_min(preB[i - 1], d[8 + i]);
+        PreB[i] = __builtin_elementwise_max(PreB[i - 1], d[8 + i]);
+        sufA[7 - i] = __builtin_elementwise_min(sufA[8 - i], d[7 - i]);
+        SufA[7 - i] = __builtin_elementwise_max(SufA[8 - i], d[7 - i]);
+        sufB[7 - i] = __builtin_elementwise_min(sufB[8 - i], d[15 - i]);
+        SufB[7 - i] = __builtin_elementwise_max(SufB[8 - i], d[15 - i]);
     }
+    short2v bmn = __builtin_elementwise_min(sufA[0], preB[0]);   // max over the windows of their minimum
+    short2v bmx = __builtin_elementwise_max(SufA[0], PreB[0]);   // min over the windows of their maximum
+    bmn = __builtin_elementwise_max(bmn, __builtin_elementwise_min(sufB[0], preA[0]));
+    bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufB[0], PreA[0]));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        mn4[k] = __builtin_elementwise_min(mn2[k], mn2[(k + 2) & 15]);
-        mx4[k] = __builtin_elementwise_max(mx2[k], mx2[(k + 2) & 15]);
+    for (int i = 1; i < 8; ++i) {
+        bmn = __builtin_elementwise_max(bmn, __builtin_elementwise_min(sufA[i], preB[i]));
+        bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufA[i], PreB[i]));
+        bmn = __builtin_elementwise_max(bmn, __builtin_elementwise_min(sufB[i], preA[i]));
+        bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufB[i], PreA[i]));
     }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        mn8[k] = __builtin_elementwise_min(mn4[k], mn4[(k + 4) & 15]);
-        mx8[k] = __builtin_elementwise_max(mx4[k], mx4[(k + 4) & 15]);
-    }
-    short2v best = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const short2v mn9 = __builtin_elementwise_min(mn8[k], d[(k + 8) & 15]);
-        const short2v mx9 = __builtin_elementwise_max(mx8[k], d[(k + 8) & 15]);
-        best = __builtin_elementwise_max(best, __builtin_elementwise_max(mn9, -mx9));
-    }
-    return best;
+    const short2v zero = {0, 0};
+    return __builtin_elementwise_max(zero, __builtin_elementwise_max(bmn, -bmx));
 }
 
 // byte `i` (0..11) of the 12-byte window {w0, w1, w2}
@@ -194,32 +202,34 @@ __device__ __forceinline__ int win_byte(uint32_t w0, uint32_t w1, uint32_t w2, i
 // [16, w-16) x [16, h-16) in steps of cellW x cellH), else 0.  k_cell_detect then only collects the non-zero bytes.
 constexpr int kScoreRows = 16;
 constexpr int kScoreGroups = 62;  // useful column groups per wave
+// bytes b and b+1 (compile-time b, 0..10) of a 12-byte window row as two zero-extended int16 lanes: one v_perm_b32
+template <int B>
+__device__ __forceinline__ short2v win_pair(const uint32_t (&row)[3]) {
+    constexpr int j = B / 4, k0 = B - 4 * j;
+    constexpr uint32_t sel = (uint32_t)k0 | (0x0cu << 8) | ((uint32_t)(k0 + 1) << 16) | (0x0cu << 24);
+    const uint32_t lo = row[j], hi = row[j + 1 < 3 ? j + 1 : 2];
+    const uint32_t r = __builtin_amdgcn_perm(hi, lo, sel);
+    return __builtin_bit_cast(short2v, r);
+}
+template <int C>  // C = centre byte of the first pixel of the pair inside the 12-byte window (4 or 6)
+__device__ __forceinline__ short2v score_pair(const uint32_t (&w)[7][3]) {
+    const short2v v = win_pair<C>(w[3]);
+    short2v d[16];
+    d[0] = v - win_pair<C>(w[6]);      d[1] = v - win_pair<C + 1>(w[6]);
+    d[2] = v - win_pair<C + 2>(w[5]);  d[3] = v - win_pair<C + 3>(w[4]);
+    d[4] = v - win_pair<C + 3>(w[3]);  d[5] = v - win_pair<C + 3>(w[2]);
+    d[6] = v - win_pair<C + 2>(w[1]);  d[7] = v - win_pair<C + 1>(w[0]);
+    d[8] = v - win_pair<C>(w[0]);      d[9] = v - win_pair<C - 1>(w[0]);
+    d[10] = v - win_pair<C - 2>(w[1]); d[11] = v - win_pair<C - 3>(w[2]);
+    d[12] = v - win_pair<C - 3>(w[3]); d[13] = v - win_pair<C - 3>(w[4]);
+    d[14] = v - win_pair<C - 2>(w[5]); d[15] = v - win_pair<C - 1>(w[6]);
+    return fast_score_pk(d);
+}
 __device__ __forceinline__ uint32_t score_row4(const uint32_t (&w)[7][3]) {
-    uint32_t out = 0;
-#pragma unroll
-    for (int pp = 0; pp < 4; pp += 2) {
-        short2v d[16];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int c = 4 + pp + q;  // centre byte index inside the 12-byte window
-            const int v = win_byte(w[3][0], w[3][1], w[3][2], c);
-            const int ring[16] = {
-                win_byte(w[6][0], w[6][1], w[6][2], c),     win_byte(w[6][0], w[6][1], w[6][2], c + 1),
-                win_byte(w[5][0], w[5][1], w[5][2], c + 2), win_byte(w[4][0], w[4][1], w[4][2], c + 3),
-                win_byte(w[3][0], w[3][1], w[3][2], c + 3), win_byte(w[2][0], w[2][1], w[2][2], c + 3),
-                win_byte(w[1][0], w[1][1], w[1][2], c + 2), win_byte(w[0][0], w[0][1], w[0][2], c + 1),
-                win_byte(w[0][0], w[0][1], w[0][2], c),     win_byte(w[0][0], w[0][1], w[0][2], c - 1),
-                win_byte(w[1][0], w[1][1], w[1][2], c - 2), win_byte(w[2][0], w[2][1], w[2][2], c - 3),
-                win_byte(w[3][0], w[3][1], w[3][2], c - 3), win_byte(w[4][0], w[4][1], w[4][2], c - 3),
-                win_byte(w[5][0], w[5][1], w[5][2], c - 2), win_byte(w[6][0], w[6][1], w[6][2], c - 1)};
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k][q] = (short)(v - ring[k]);
-        }
-        const short2v sres = fast_score_pk(d);
-        out |= ((uint32_t)(uint16_t)sres[0] & 0xffu) << (8 * pp);
-        out |= ((uint32_t)(uint16_t)sres[1] & 0xffu) << (8 * (pp + 1));
-    }
-    return out;
+    // scores are 0..255 in int16 lanes: pack the low bytes of the four lanes into one dword
+    const uint32_t a = __builtin_bit_cast(uint32_t, score_pair<4>(w));
+    const uint32_t b = __builtin_bit_cast(uint32_t, score_pair<6>(w));
+    return __builtin_amdgcn_perm(b, a, 0x06040200u);
 }
 
 // bytes x0-1 .. x0+4 of a score row: own word plus the edge bytes of the neighbouring lanes' words
