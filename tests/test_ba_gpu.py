@@ -269,3 +269,20 @@ def test_device_pose_solve_matches_host_cholesky(synth, monkeypatch, path, P, L)
             x, ok = o.solve(lam)
             assert ok
             assert np.abs(x - x_ref.astype(np.float64)).max() <= 1e-9 * np.abs(x_ref).max()
+
+
+@pytest.mark.parametrize("path", ["tiles", "steps"])
+def test_device_pose_solve_reports_indefinite_system(synth, monkeypatch, path):
+    """A non-positive pivot must come back as factor_ok = False (the LM controller then retries with a larger lambda,
+    as g2o does when CHOLMOD fails) - never as a hang or a silent wrong step."""
+    if path == "steps":
+        monkeypatch.setenv("SE2GPU_BA_CHOL", "steps")
+    else:
+        monkeypatch.delenv("SE2GPU_BA_CHOL", raising=False)
+    g = synth.ba_graph(50, 5000)
+    o = _opt(g)
+    S, _ = o.reduced_system(0.0)
+    x, ok = o.solve(-2.0 * float(np.abs(np.diag(S)).max()))   # S - 2 max(diag) I is negative definite
+    assert not ok
+    x, ok = o.solve(10.0)                                      # and the next solve is clean again
+    assert ok and np.isfinite(x).all()
