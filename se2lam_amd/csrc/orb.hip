@@ -65,7 +65,7 @@ __device__ __forceinline__ size_t pix(const Geom& g, int f, int l, int y, int x)
     return (size_t)f * g.frame_bytes + g.off[l] + (size_t)(y + kEdge) * g.stride[l] + (x + kEdge);
 }
 
-__device__ __forceinline__ int reflect101(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
+__host__ __device__ __forceinline__ int reflect101(int p, int n) { return p < 0 ? -p : (p >= n ? 2 * n - 2 - p : p); }
 
 // ---------------------------------------------------------------------------------------------
 // pyramid
@@ -91,55 +91,47 @@ __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restric
     *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[0] + (size_t)Y * stride + X4) = v;
 }
 
-// level l >= 1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border.
-// ytab[dy] = {sy0, sy1, b0, b1} (one entry per row, block-uniform); the x coefficients are evaluated per pixel with
-// exactly cv::resize's arithmetic: fx = (float)((dx + 0.5) * scale_x - 0.5) in double, 11-bit rounding in float.
+// level l >= 1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border, 4 output bytes per thread.
+// ytab[dy] = {sy0, sy1, b0, b1}.  xtab has one entry per column X of the BORDERED destination row (so the reflection
+// costs nothing per pixel), built on the host with exactly cv::resize's arithmetic (fx = (float)((dx + 0.5) * scale_x
+// - 0.5) in double, 11-bit rounding in float, the S[sx] * ONE tail): two int4 per group of 4 columns,
+// {sx | valid << 31} x 4 and {a0 | a1 << 16} x 4.  The two source bytes S[sx], S[sx + 1] of a row come from one
+// (unaligned) 16-bit load.  Threads are laid out over (row, column group) of the whole level, so narrow levels do not
+// leave most of a workgroup idle.
 struct ResizeTab {
     const int4* ytab;
-    double scale_x;   // 1.0 / ((double)dw / sw)
-    int sw;
+    const int4* xtab;
+    int ngroups;   // stride / 4
 };
 
 __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr) {
-    const int f = blockIdx.z;
-    const int Y = blockIdx.y;
-    const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
-    if (X4 >= stride) return;
+    const int f = blockIdx.y;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int H = g.h[l], stride = g.stride[l];
+    const int Y = gid / t.ngroups;
+    if (Y >= H + 2 * kEdge) return;
+    const int xg = gid - Y * t.ngroups;
     const int dy = reflect101(Y - kEdge, H);
     const int4 yt = t.ytab[dy];
+    const int4 xs = t.xtab[2 * xg], xa = t.xtab[2 * xg + 1];
     const uint8_t* S0 = pyr + pix(g, f, l - 1, yt.x, 0);
     const uint8_t* S1 = pyr + pix(g, f, l - 1, yt.y, 0);
+    const int sxv[4] = {xs.x, xs.y, xs.z, xs.w};
+    const int av[4] = {xa.x, xa.y, xa.z, xa.w};
     uint32_t v = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int X = X4 + q;
-        uint32_t b = 0;
-        if (X < W + 2 * kEdge) {
-            const int dx = reflect101(X - kEdge, W);
-            float fx = (float)((dx + 0.5) * t.scale_x - 0.5);
-            int sx = (int)floorf(fx);
-            fx -= sx;
-            if (sx < 0) { fx = 0; sx = 0; }
-            bool one = false;                 // dx >= xmax: S[sx] * ONE (cv::resize's tail loop)
-            if (sx + 1 >= t.sw) {
-                one = true;
-                if (sx >= t.sw - 1) { fx = 0; sx = t.sw - 1; }
-            }
-            int r0, r1;
-            if (one) {
-                r0 = S0[sx] * 2048;
-                r1 = S1[sx] * 2048;
-            } else {
-                const int a0 = (int)rintf((1.f - fx) * 2048.f), a1 = (int)rintf(fx * 2048.f);
-                r0 = S0[sx] * a0 + S0[sx + 1] * a1;
-                r1 = S1[sx] * a0 + S1[sx + 1] * a1;
-            }
-            b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        }
+        const int sx = sxv[q] & 0xffff;
+        const uint32_t p0 = *reinterpret_cast<const uint16_t*>(S0 + sx);   // S0[sx] | S0[sx + 1] << 8
+        const uint32_t p1 = *reinterpret_cast<const uint16_t*>(S1 + sx);
+        const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
+        const int r0 = (int)(p0 & 0xffu) * a0 + (int)(p0 >> 8) * a1;
+        const int r1 = (int)(p1 & 0xffu) * a0 + (int)(p1 >> 8) * a1;
+        uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
         v |= b << (8 * q);
     }
-    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + X4) = v;
+    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 4 * xg) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -695,7 +687,6 @@ struct se2gpu_orb {
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
-    double xscale[kMaxLevels] = {0};
     int score_tiles = 0, blur_tiles = 0;
     int score_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
     ~se2gpu_orb() {
@@ -765,7 +756,6 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
         // cv::resize switches to the S[sx]*ONE tail at the first dx whose sx+1 leaves the row and stays there; the
         // kernel applies the test per pixel, which is identical as long as sx is non-decreasing in dx (it is).
-        (void)dw; (void)scale_x;
         std::vector<int4> yt(dh);
         auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
         for (int dy = 0; dy < dh; dy++) {
@@ -776,9 +766,37 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
             auto sat = [](int v) { return std::min(std::max(v, -32768), 32767); };
             yt[dy] = make_int4(clip(sy, 0, sh), clip(sy + 1, 0, sh), sat(cv_round_f(cb0 * 2048)), sat(cv_round_f(cb1 * 2048)));
         }
-        h->xscale[l] = scale_x;
         h->ytab_off[l] = tabs.size();
         tabs.insert(tabs.end(), yt.begin(), yt.end());
+        // x table over the bordered destination row (stride[l] columns, groups of 4)
+        const int ng = g.stride[l] / 4;
+        std::vector<int4> xt(2 * (size_t)ng, make_int4(0, 0, 0, 0));
+        for (int X = 0; X < g.stride[l]; ++X) {
+            int w0 = 0, w1 = 0;
+            if (X < dw + 2 * kEdge) {
+                const int dx = reflect101(X - kEdge, dw);
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_f(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                int a0, a1;
+                if (sx + 1 >= sw) {            // dx >= xmax: S[sx] * ONE (cv::resize's tail loop)
+                    if (sx >= sw - 1) sx = sw - 1;
+                    a0 = 2048; a1 = 0;
+                } else {
+                    a0 = cv_round_f((1.f - fx) * 2048.f);
+                    a1 = cv_round_f(fx * 2048.f);
+                }
+                w0 = sx | (int)0x80000000u;
+                w1 = a0 | (a1 << 16);
+            }
+            int* e0 = &xt[2 * (size_t)(X / 4)].x;
+            int* e1 = &xt[2 * (size_t)(X / 4) + 1].x;
+            e0[X & 3] = w0;
+            e1[X & 3] = w1;
+        }
+        h->xtab_off[l] = tabs.size();
+        tabs.insert(tabs.end(), xt.begin(), xt.end());
     }
     if (tabs.empty()) tabs.push_back(make_int4(0, 0, 0, 0));
     SE2_CHECK(h->tabs.upload(tabs, h->stream));
@@ -811,8 +829,9 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
     }
     for (int l = 1; l < L; ++l) {
-        ResizeTab t{h->tabs.p + h->ytab_off[l], h->xscale[l], g.w[l - 1]};
-        dim3 grid((g.stride[l] / 4 + 255) / 256, g.h[l] + 2 * kEdge, nframes);
+        const int ng = g.stride[l] / 4;
+        ResizeTab t{h->tabs.p + h->ytab_off[l], h->tabs.p + h->xtab_off[l], ng};
+        dim3 grid((ng * (g.h[l] + 2 * kEdge) + 255) / 256, nframes);
         SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
     }
     for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
