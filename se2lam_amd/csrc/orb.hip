@@ -141,26 +141,28 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
 // ---------------------------------------------------------------------------------------------
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-// Two pixels at once in packed int16 lanes (v_pk_min_i16 / v_pk_max_i16): d[k] = v - p_k for the 16 ring pixels.
+// Two pixels at once in packed int16 lanes (v_pk_min_i16 / v_pk_max_i16).  With p[k] the 16 ring pixels and v the
+// centre,  min_arc(v - p) = v - max_arc(p)  and  min_arc(p - v) = min_arc(p) - v,  so the extrema are taken on the raw
+// ring values and only two subtractions remain:   S = max(0, v - min_k max9[k], max_k min9[k] - v).
 // The 16 circular windows of 9 are formed from prefix / suffix extrema of the two halves of the ring (van Herk):
-// window k = d[k..7] u d[8..8+k] = min(sufA[k], preB[k]) for k < 8, and min(sufB[k-8], preA[k-8]) for k >= 8 - 44
-// instead of 64 operations per extremum; S = max(0, max_k min9[k], -min_k max9[k]).
-__device__ __forceinline__ short2v fast_score_pk(const short2v d[16]) {
+// window k = p[k..7] u p[8..8+k] = min(sufA[k], preB[k]) for k < 8, and min(sufB[k-8], preA[k-8]) for k >= 8 - 44
+// instead of 64 operations per extremum.
+__device__ __forceinline__ short2v fast_score_pk(const short2v p[16], short2v v) {
     short2v preA[8], sufA[8], preB[8], sufB[8], PreA[8], SufA[8], PreB[8], SufB[8];   // lower case: min, upper: max
-    preA[0] = PreA[0] = d[0];
-    preB[0] = PreB[0] = d[8];
-    sufA[7] = SufA[7] = d[7];
-    sufB[7] = SufB[7] = d[15];
+    preA[0] = PreA[0] = p[0];
+    preB[0] = PreB[0] = p[8];
+    sufA[7] = SufA[7] = p[7];
+    sufB[7] = SufB[7] = p[15];
 #pragma unroll
     for (int i = 1; i < 8; ++i) {
-        preA[i] = __builtin_elementwise_min(preA[i - 1], d[i]);
-        PreA[i] = __builtin_elementwise_max(PreA[i - 1], d[i]);
-        preB[i] = __builtin_elementwise_min(preB[i - 1], d[8 + i]);
-        PreB[i] = __builtin_elementwise_max(PreB[i - 1], d[8 + i]);
-        sufA[7 - i] = __builtin_elementwise_min(sufA[8 - i], d[7 - i]);
-        SufA[7 - i] = __builtin_elementwise_max(SufA[8 - i], d[7 - i]);
-        sufB[7 - i] = __builtin_elementwise_min(sufB[8 - i], d[15 - i]);
-        SufB[7 - i] = __builtin_elementwise_max(SufB[8 - i], d[15 - i]);
+        preA[i] = __builtin_elementwise_min(preA[i - 1], p[i]);
+        PreA[i] = __builtin_elementwise_max(PreA[i - 1], p[i]);
+        preB[i] = __builtin_elementwise_min(preB[i - 1], p[8 + i]);
+        PreB[i] = __builtin_elementwise_max(PreB[i - 1], p[8 + i]);
+        sufA[7 - i] = __builtin_elementwise_min(sufA[8 - i], p[7 - i]);
+        SufA[7 - i] = __builtin_elementwise_max(SufA[8 - i], p[7 - i]);
+        sufB[7 - i] = __builtin_elementwise_min(sufB[8 - i], p[15 - i]);
+        SufB[7 - i] = __builtin_elementwise_max(SufB[8 - i], p[15 - i]);
     }
     short2v bmn = __builtin_elementwise_min(sufA[0], preB[0]);   // max over the windows of their minimum
     short2v bmx = __builtin_elementwise_max(SufA[0], PreB[0]);   // min over the windows of their maximum
@@ -174,7 +176,7 @@ __device__ __forceinline__ short2v fast_score_pk(const short2v d[16]) {
         bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufB[i], PreA[i]));
     }
     const short2v zero = {0, 0};
-    return __builtin_elementwise_max(zero, __builtin_elementwise_max(bmn, -bmx));
+    return __builtin_elementwise_max(zero, __builtin_elementwise_max(v - bmx, bmn - v));
 }
 
 // byte `i` (0..11) of the 12-byte window {w0, w1, w2}
@@ -183,46 +185,52 @@ __device__ __forceinline__ int win_byte(uint32_t w0, uint32_t w1, uint32_t w2, i
     return (int)((w >> (8 * (i & 3))) & 0xffu);
 }
 
-// One thread = 4 horizontally adjacent pixels of a vertical strip of kScoreRows rows.  A 7-row x 12-byte sliding
-// window lives in registers (three aligned dwords per row: pixels x0-4 .. x0+7); every input byte is loaded once per
-// thread with 32-bit loads.  Workgroup = 4 waves = 4 strips; a wave spans 64 column groups of which the first and
-// last are halo (their scores feed the neighbours' non-max suppression, they write nothing), and each strip computes
-// one extra row above and below for the same reason.
+// One thread = 4 horizontally adjacent pixels of a vertical strip of kScoreRows rows.  A 7-row sliding window lives
+// in registers; every input byte is loaded once per thread with 32-bit loads (three aligned dwords per row: pixels
+// x0-4 .. x0+7) and EXPANDED once, when its row enters the window, into the nine byte pairs {b, b+1}, b = 1..9, as
+// packed u16 lanes (v_perm_b32) - exactly the operands the two pixel pairs of the thread need from that row at every
+// ring position, for the seven iterations the row stays in the window.  The window is a circular buffer with static
+// slot indices: the row loop is unrolled by 7.  Workgroup = 4 waves = 4 strips; a wave spans 64 column groups of
+// which the first and last are halo (their scores feed the neighbours' non-max suppression, they write nothing), and
+// each strip computes one extra row above and below for the same reason (kScoreRows + 2 = 21 = 3 x 7 iterations).
 //
 // The kernel writes S' = S where S > 7 and S is a strict maximum over the 8-neighbours that lie in the SAME CELL
 // (cv::FAST's non-max suppression inside one FAST call, ORBextractor.cpp:616-623; cells of level l tile the scan area
 // [16, w-16) x [16, h-16) in steps of cellW x cellH), else 0.  k_cell_detect then only collects the non-zero bytes.
-constexpr int kScoreRows = 16;
+constexpr int kScoreRows = 19;
 constexpr int kScoreGroups = 62;  // useful column groups per wave
-// bytes b and b+1 (compile-time b, 0..10) of a 12-byte window row as two zero-extended int16 lanes: one v_perm_b32
-template <int B>
-__device__ __forceinline__ short2v win_pair(const uint32_t (&row)[3]) {
-    constexpr int j = B / 4, k0 = B - 4 * j;
-    constexpr uint32_t sel = (uint32_t)k0 | (0x0cu << 8) | ((uint32_t)(k0 + 1) << 16) | (0x0cu << 24);
-    const uint32_t lo = row[j], hi = row[j + 1 < 3 ? j + 1 : 2];
-    const uint32_t r = __builtin_amdgcn_perm(hi, lo, sel);
-    return __builtin_bit_cast(short2v, r);
+
+// pairs {b, b+1}, b = 1..9, of a 12-byte window row {w0, w1, w2} as zero-extended u16 lanes
+__device__ __forceinline__ void expand_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t (&e)[9]) {
+    e[0] = __builtin_amdgcn_perm(w1, w0, 0x0c020c01u);   // bytes 1, 2
+    e[1] = __builtin_amdgcn_perm(w1, w0, 0x0c030c02u);   // 2, 3
+    e[2] = __builtin_amdgcn_perm(w1, w0, 0x0c040c03u);   // 3, 4
+    e[3] = __builtin_amdgcn_perm(w2, w1, 0x0c010c00u);   // 4, 5
+    e[4] = __builtin_amdgcn_perm(w2, w1, 0x0c020c01u);   // 5, 6
+    e[5] = __builtin_amdgcn_perm(w2, w1, 0x0c030c02u);   // 6, 7
+    e[6] = __builtin_amdgcn_perm(w2, w1, 0x0c040c03u);   // 7, 8
+    e[7] = __builtin_amdgcn_perm(w2, w2, 0x0c010c00u);   // 8, 9
+    e[8] = __builtin_amdgcn_perm(w2, w2, 0x0c020c01u);   // 9, 10
 }
-template <int C>  // C = centre byte of the first pixel of the pair inside the 12-byte window (4 or 6)
-__device__ __forceinline__ short2v score_pair(const uint32_t (&w)[7][3]) {
-    const short2v v = win_pair<C>(w[3]);
-    short2v d[16];
-    d[0] = v - win_pair<C>(w[6]);      d[1] = v - win_pair<C + 1>(w[6]);
-    d[2] = v - win_pair<C + 2>(w[5]);  d[3] = v - win_pair<C + 3>(w[4]);
-    d[4] = v - win_pair<C + 3>(w[3]);  d[5] = v - win_pair<C + 3>(w[2]);
-    d[6] = v - win_pair<C + 2>(w[1]);  d[7] = v - win_pair<C + 1>(w[0]);
-    d[8] = v - win_pair<C>(w[0]);      d[9] = v - win_pair<C - 1>(w[0]);
-    d[10] = v - win_pair<C - 2>(w[1]); d[11] = v - win_pair<C - 3>(w[2]);
-    d[12] = v - win_pair<C - 3>(w[3]); d[13] = v - win_pair<C - 3>(w[4]);
-    d[14] = v - win_pair<C - 2>(w[5]); d[15] = v - win_pair<C - 1>(w[6]);
-    return fast_score_pk(d);
+// window row r of iteration phase PH lives in slot (PH + r) % 7; pair b of that row
+#define SE2_WP(r, b) __builtin_bit_cast(short2v, E[(PH + (r)) % 7][(b) - 1])
+template <int PH, int C>  // C = centre byte of the first pixel of the pair inside the 12-byte window (4 or 6)
+__device__ __forceinline__ short2v score_pair(const uint32_t (&E)[7][9]) {
+    short2v p[16];
+    p[0] = SE2_WP(6, C);      p[1] = SE2_WP(6, C + 1);  p[2] = SE2_WP(5, C + 2);  p[3] = SE2_WP(4, C + 3);
+    p[4] = SE2_WP(3, C + 3);  p[5] = SE2_WP(2, C + 3);  p[6] = SE2_WP(1, C + 2);  p[7] = SE2_WP(0, C + 1);
+    p[8] = SE2_WP(0, C);      p[9] = SE2_WP(0, C - 1);  p[10] = SE2_WP(1, C - 2); p[11] = SE2_WP(2, C - 3);
+    p[12] = SE2_WP(3, C - 3); p[13] = SE2_WP(4, C - 3); p[14] = SE2_WP(5, C - 2); p[15] = SE2_WP(6, C - 1);
+    return fast_score_pk(p, SE2_WP(3, C));
 }
-__device__ __forceinline__ uint32_t score_row4(const uint32_t (&w)[7][3]) {
+template <int PH>
+__device__ __forceinline__ uint32_t score_row4(const uint32_t (&E)[7][9]) {
     // scores are 0..255 in int16 lanes: pack the low bytes of the four lanes into one dword
-    const uint32_t a = __builtin_bit_cast(uint32_t, score_pair<4>(w));
-    const uint32_t b = __builtin_bit_cast(uint32_t, score_pair<6>(w));
+    const uint32_t a = __builtin_bit_cast(uint32_t, score_pair<PH, 4>(E));
+    const uint32_t b = __builtin_bit_cast(uint32_t, score_pair<PH, 6>(E));
     return __builtin_amdgcn_perm(b, a, 0x06040200u);
 }
+#undef SE2_WP
 
 // bytes x0-1 .. x0+4 of a score row: own word plus the edge bytes of the neighbouring lanes' words
 __device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t left, uint32_t right) {
@@ -245,12 +253,13 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     const uint8_t* base = pyr + pix(g, f, l, 0, 0);
     uint8_t* sbase = score + pix(g, f, l, 0, 0);
     const int xc = min(max(x0, kEdge), W - kEdge - 1) & ~3;    // clamped (aligned) load position for halo lanes outside
-    uint32_t w[7][3];
-    // window rows y0-4 .. y0+1 so that the first computed score row is y0-1
+    uint32_t E[7][9];
+    const int ymax = H + kEdge - 1;   // last row of the bordered plane (strips at the bottom clamp their look-ahead)
+    // window rows y0-4 .. y0+1 (slots 0..5) so that the first computed score row is y0-1
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)(y0 - 4 + r) * stride + xc - 4);
-        w[r + 1][0] = p[0]; w[r + 1][1] = p[1]; w[r + 1][2] = p[2];
+        const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)min(y0 - 4 + r, ymax) * stride + xc - 4);
+        expand_row(p[0], p[1], p[2], E[r]);
     }
     const int yend = min(y0 + kScoreRows, H - kEdge);
     const int nvalid = xin ? min(4, W - kEdge - x0) : 0;
@@ -265,15 +274,14 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         if (xr >= 0 && (xr % cellW == cellW - 1 || x0 + q == W - kEdge - 1)) eR |= 1u << q;
     }
     unsigned long long e_pp = 0, e_p = 0;   // extended score rows y-2, y-1 (relative to the row being computed)
-    for (int y = y0 - 1; y <= yend; ++y) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { w[r][0] = w[r + 1][0]; w[r][1] = w[r + 1][1]; w[r][2] = w[r + 1][2]; }
-        {
-            const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)(y + 3) * stride + xc - 4);
-            w[6][0] = p[0]; w[6][1] = p[1]; w[6][2] = p[2];
+    auto step = [&](auto phc, int y) {
+        constexpr int PH = decltype(phc)::value;
+        {   // row y+3 enters the window (slot of window row 6)
+            const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)min(y + 3, ymax) * stride + xc - 4);
+            expand_row(p[0], p[1], p[2], E[(PH + 6) % 7]);
         }
         uint32_t sw4 = 0;
-        if (y >= kEdge && y < H - kEdge) sw4 = score_row4(w) & vmask;   // rows outside the scan area score 0
+        if (y >= kEdge && y < H - kEdge) sw4 = score_row4<PH>(E) & vmask;   // rows outside the scan area score 0
         const uint32_t left = __shfl_up(sw4, 1), right = __shfl_down(sw4, 1);
         const unsigned long long e_c = ext_row(sw4, lane == 0 ? 0u : left, lane == 63 ? 0u : right);
         const int yo = y - 1;  // row whose suppression can now be decided
@@ -307,6 +315,15 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         }
         e_pp = e_p;
         e_p = e_c;
+    };
+    for (int y = y0 - 1; y <= yend; y += 7) {   // rows past yend only feed guarded code
+        step(std::integral_constant<int, 0>{}, y);
+        step(std::integral_constant<int, 1>{}, y + 1);
+        step(std::integral_constant<int, 2>{}, y + 2);
+        step(std::integral_constant<int, 3>{}, y + 3);
+        step(std::integral_constant<int, 4>{}, y + 4);
+        step(std::integral_constant<int, 5>{}, y + 5);
+        step(std::integral_constant<int, 6>{}, y + 6);
     }
 }
 
