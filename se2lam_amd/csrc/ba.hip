@@ -1239,7 +1239,7 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
                            int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
                            const double* __restrict__ o_meas, const double* __restrict__ o_info, int root,
                            double* __restrict__ out, volatile double* __restrict__ mail, double seq) {
-    __shared__ double sm[2][1024];
+    __shared__ double sm[2][16];
     __shared__ double sp[3 * 1024];  // trial poses staged for the odometry pass when P <= 1024
     const bool step = xp != nullptr;
     double chi = 0, scale = 0;
@@ -1270,17 +1270,18 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
         const double* W = o_info + 9 * k;
         for (int r = 0; r < 3; ++r) chi += e[r] * (W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
     }
-    sm[0][threadIdx.x] = chi;
-    sm[1][threadIdx.x] = scale;
-    __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            sm[0][threadIdx.x] += sm[0][threadIdx.x + s];
-            sm[1][threadIdx.x] += sm[1][threadIdx.x + s];
-        }
-        __syncthreads();
+    chi = wave_sum(chi);
+    scale = wave_sum(scale);
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = chi;
+        sm[1][threadIdx.x >> 6] = scale;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {   // fixed order: deterministic
+            sm[0][0] += sm[0][w];
+            sm[1][0] += sm[1][w];
+        }
         out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0;
         if (mail) {  // single-GPU: the LM controller on the host polls this mapped, coherent host buffer instead of
             mail[0] = sm[0][0];           // paying a stream synchronise + D2H copy per trial
