@@ -534,34 +534,47 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
 __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __restrict__ pyr,
                                                       const int4* __restrict__ kp_list, const int* __restrict__ counts,
                                                       int cap, float* __restrict__ angles) {
+    // one wave per key point: lane = (row offset v = 0..15, column octet c = 0..3); a lane reads 8 bytes of row +v and
+    // of row -v with two (unaligned) 32-bit loads each - 749 disc pixels in 4 load instructions instead of 47 byte
+    // loads per lane.  Integer moments: the summation order is irrelevant.
     const int f = blockIdx.y;
-    const int k = blockIdx.x * 16 + threadIdx.x / 16;
-    const int v = threadIdx.x & 15;  // row offset handled by this lane: rows +v and -v
+    const int k = blockIdx.x * 4 + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    const int v = lane & 15, c = lane >> 4;
     const int n = counts[f];
     int m01 = 0, m10 = 0;
     if (k < n) {
         const int4 kp = kp_list[(size_t)f * cap + k];
         const int stride = g.stride[kp.x];
         const uint8_t* center = pyr + pix(g, f, kp.x, kp.z, kp.y);
-        if (v == 0) {
-            for (int u = -kHalfPatch; u <= kHalfPatch; ++u) m10 += u * center[u];
-        } else {
-            const int d = g.umax[v];
-            int vsum = 0;
-            for (int u = -d; u <= d; ++u) {
-                const int vp = center[u + v * stride], vm = center[u - v * stride];
-                vsum += vp - vm;
-                m10 += u * (vp + vm);
+        const int d = g.umax[v];
+        const int u0 = -16 + 8 * c;
+        const uint8_t* pp = center + u0 + v * stride;
+        const uint8_t* pm = center + u0 - v * stride;
+        const uint32_t wp[2] = {*reinterpret_cast<const uint32_t*>(pp), *reinterpret_cast<const uint32_t*>(pp + 4)};
+        const uint32_t wm[2] = {*reinterpret_cast<const uint32_t*>(pm), *reinterpret_cast<const uint32_t*>(pm + 4)};
+        int vsum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int u = u0 + i;
+            const int vp = (int)((wp[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            const int vm = (int)((wm[i >> 2] >> (8 * (i & 3))) & 0xffu);
+            const bool in = u >= -d && u <= d;
+            if (v == 0) {
+                m10 += in ? u * vp : 0;
+            } else {
+                vsum += in ? vp - vm : 0;
+                m10 += in ? u * (vp + vm) : 0;
             }
-            m01 = v * vsum;
         }
+        m01 = v * vsum;
     }
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
+    for (int m = 1; m < 64; m <<= 1) {
         m01 += __shfl_xor(m01, m);
         m10 += __shfl_xor(m10, m);
     }
-    if (k < n && v == 0) angles[(size_t)f * cap + k] = fast_atan2_deg((float)m01, (float)m10);
+    if (k < n && lane == 0) angles[(size_t)f * cap + k] = fast_atan2_deg((float)m01, (float)m10);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -571,6 +584,36 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
 constexpr int kBlurRows = 32;
 // One thread = 4 adjacent output pixels of a vertical strip of kBlurRows rows; the horizontal 7-tap sums of the last
 // 7 rows stay in registers (sliding window), inputs come in as three aligned dwords per row.  No LDS.
+// The blurred pyramid keeps the UN-blurred 16 px reflect frame of every level (the descriptor pattern of a key point
+// 16 px from the edge reaches a few pixels into it).  Only the frame is copied (about 14 % of a pyramid), as a flat list
+// of 16-byte chunks: per level the 2 x 16 full frame rows, then for every interior row its first chunk and the chunks
+// from the one that straddles the right edge of the interior onwards (the interior bytes that chunk carries are
+// overwritten by k_blur afterwards).  tile_base[l] = chunk-list prefix sums.
+__device__ __host__ inline int frame_chunks_right(int W, int stride) { return stride / 16 - (kEdge + W) / 16; }
+__global__ __launch_bounds__(256) void k_copy_frame(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+    const int f = blockIdx.y;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= g.tile_base[g.nlevels]) return;
+    int l = 0;
+    while (l + 1 < g.nlevels && item >= g.tile_base[l + 1]) ++l;
+    int t = item - g.tile_base[l];
+    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
+    const int nch = stride / 16, nr = frame_chunks_right(W, stride);
+    int Y, c;
+    if (t < 2 * kEdge * nch) {            // full frame rows: top 16, bottom 16
+        const int r = t / nch;
+        c = t - r * nch;
+        Y = r < kEdge ? r : H + r;        // r in [16, 32) -> rows H + 16 .. H + 31
+    } else {
+        t -= 2 * kEdge * nch;
+        const int r = t / (1 + nr), q = t - r * (1 + nr);
+        Y = kEdge + r;
+        c = q == 0 ? 0 : nch - nr + (q - 1);
+    }
+    const size_t off = (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 16 * c;
+    *reinterpret_cast<uint4*>(blur + off) = *reinterpret_cast<const uint4*>(pyr + off);
+}
+
 __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     const int f = blockIdx.y;
     int l = 0;
@@ -858,12 +901,19 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
                h->cell_keys.p, h->cell_total.p, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(nframes), dim3(256), 0, g, h->cell_keys.p,
                h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
-    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 15) / 16, nframes), dim3(256), 0, g, h->pyr.p,
+    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p);
     // blurred pyramid: frame = un-blurred reflect copies, interior = blur
-    h->prof.begin(st);
-    SE2_HIP(hipMemcpyAsync(h->blur.p, h->pyr.p, (size_t)nframes * g.frame_bytes, hipMemcpyDeviceToDevice, st));
-    h->prof.end(st, "copy_border");
+    {
+        int items = 0;
+        for (int l = 0; l < L; ++l) {
+            g.tile_base[l] = items;
+            items += 2 * kEdge * (g.stride[l] / 16) + g.h[l] * (1 + frame_chunks_right(g.w[l], g.stride[l]));
+        }
+        g.tile_base[L] = items;
+        SE2_LAUNCH(h->prof, st, "k_copy_frame", k_copy_frame, dim3((items + 255) / 256, nframes), dim3(256), 0, g, h->pyr.p,
+                   h->blur.p);
+    }
     for (int l = 0; l <= L; ++l) g.tile_base[l] = h->blur_tile_base[l];
     SE2_LAUNCH(h->prof, st, "k_blur", k_blur, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p, h->blur.p);
     SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->blur.p,
