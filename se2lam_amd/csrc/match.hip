@@ -35,6 +35,10 @@ struct Bounds {
     float min_x, min_y, max_x, max_y, wInv, hInv;
 };
 
+// per-frame grid record: [0] = number of features in the grid, [1 + cx] = first position of grid column cx in the
+// sorted list (cx = 0 .. kGridCols; the last one = the number again)
+constexpr int kGridRec = kGridCols + 2;
+
 __device__ __forceinline__ int hamming256(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b) {
     const unsigned long long* pa = (const unsigned long long*)a;
     const unsigned long long* pb = (const unsigned long long*)b;
@@ -83,7 +87,17 @@ __global__ __launch_bounds__(256) void k_grid_order(Bounds bd, const se2gpu_keyp
             __syncthreads();
         }
     for (int i = threadIdx.x; i < n; i += 256) sorted[(size_t)f * cap + i] = keys[i];
-    if (threadIdx.x == 0) n_grid[f] = s_n;
+    const int ng = s_n;
+    if (threadIdx.x == 0) n_grid[(size_t)f * kGridRec] = ng;
+    if (threadIdx.x <= kGridCols) {   // lower bound of column cx in the sorted keys (invalid keys 0xffffffff sort last)
+        const uint32_t want = (uint32_t)(threadIdx.x * kGridRows) << 16;
+        int lo = 0, hi = ng;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        n_grid[(size_t)f * kGridRec + 1 + threadIdx.x] = lo;
+    }
 }
 
 // Candidate scan of one query by one wave (Frame::GetFeaturesInArea + DescriptorDistance).
@@ -91,7 +105,8 @@ __global__ __launch_bounds__(256) void k_grid_order(Bounds bd, const se2gpu_keyp
 __device__ __forceinline__ int scan_candidates(const Bounds& bd, float x, float y, float r, int minLevel, int maxLevel,
                                                const uint8_t* __restrict__ d1, const se2gpu_keypoint* __restrict__ kps2,
                                                const uint8_t* __restrict__ desc2, const uint32_t* __restrict__ sorted2,
-                                               int n_grid2, const uint8_t* __restrict__ excl, uint32_t* __restrict__ out) {
+                                               const int* __restrict__ grid2, const uint8_t* __restrict__ excl,
+                                               uint32_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     int nMinCellX = (int)floorf((x - bd.min_x - r) * bd.wInv);
     nMinCellX = max(0, nMinCellX);
@@ -107,11 +122,13 @@ __device__ __forceinline__ int scan_candidates(const Bounds& bd, float x, float 
     if (nMaxCellY < 0) return 0;
     const bool checkLevels = !(minLevel == -1 && maxLevel == -1);
     int count = 0;
-    for (int c0 = 0; c0 < n_grid2; c0 += 64) {
+    // the list is sorted by grid column first: only the slice of columns nMinCellX .. nMaxCellX is visited
+    const int cbeg = grid2[1 + nMinCellX], cend = grid2[2 + nMaxCellX];
+    for (int c0 = cbeg; c0 < cend; c0 += 64) {
         const int pos = c0 + lane;
         bool ok = false;
         int idx = 0;
-        if (pos < n_grid2) {
+        if (pos < cend) {
             const uint32_t pk = sorted2[pos];
             const int cell = (int)(pk >> 16);
             idx = (int)(pk & 0xffffu);
@@ -128,9 +145,6 @@ __device__ __forceinline__ int scan_candidates(const Bounds& bd, float x, float 
             if (slot < kMaxCand) out[slot] = ((uint32_t)idx << 12) | (uint32_t)hamming256(d1, desc2 + 32 * (size_t)idx);
         }
         count += __popcll(m);
-        // the list is sorted by cell x first: nothing left once the last lane of this chunk is past the window
-        const uint32_t last = sorted2[min(c0 + 63, n_grid2 - 1)];
-        if ((int)(last >> 16) / kGridRows > nMaxCellX) break;
     }
     return count;
 }
@@ -154,7 +168,7 @@ __global__ __launch_bounds__(256) void k_cand_window(Bounds bd, const se2gpu_key
         const int minLevel2 = level1 - level_offset > 0 ? level1 - level_offset : 0;
         n = scan_candidates(bd, prev_xy[((size_t)p * cap + i1) * 2], prev_xy[((size_t)p * cap + i1) * 2 + 1], (float)win,
                             minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + i1) * 32, kps + (size_t)fb * cap,
-                            desc + (size_t)fb * cap * 32, sorted + (size_t)fb * cap, n_grid[fb], nullptr,
+                            desc + (size_t)fb * cap * 32, sorted + (size_t)fb * cap, n_grid + (size_t)fb * kGridRec, nullptr,
                             cand + ((size_t)p * cap + i1) * kMaxCand);
     }
     if ((threadIdx.x & 63) == 0) ncand[(size_t)p * cap + i1] = n;
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
             const int levelWinSize = predictLevel * win;
             const int minLevel = predictLevel > level_offset ? predictLevel - level_offset : 0;
             n = scan_candidates(bd, px, py, (float)levelWinSize, minLevel, predictLevel + level_offset,
-                                mp_desc + 32 * (size_t)i, kps, desc, sorted, n_grid[0], kf_observed,
+                                mp_desc + 32 * (size_t)i, kps, desc, sorted, n_grid, kf_observed,
                                 cand + (size_t)i * kMaxCand);
         }
     }
@@ -636,7 +650,7 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     SE2_REQUIRE(cap <= kMaxFeat && cap <= 65536, SE2GPU_ERR_CAPACITY, "cap %d exceeds the matcher limit %d", cap, kMaxFeat);
     // grid order of every frame that appears as a target (all frames < nframes_hint: cheap)
     SE2_CHECK(h->sorted.reserve((size_t)nframes_hint * cap));
-    SE2_CHECK(h->n_grid.reserve((size_t)nframes_hint));
+    SE2_CHECK(h->n_grid.reserve((size_t)nframes_hint * kGridRec));
     SE2_CHECK(h->cand.reserve((size_t)npairs * cap * kMaxCand));
     SE2_CHECK(h->ncand.reserve((size_t)npairs * cap));
     hipLaunchKernelGGL(k_grid_order, dim3(nframes_hint), dim3(256), 0, st, bd, d_kps, d_counts, (const int*)nullptr, cap,
@@ -782,7 +796,7 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     SE2_CHECK(h->mp_octave.reserve((size_t)mm));
     SE2_CHECK(h->mp_skip.reserve((size_t)mm));
     SE2_CHECK(h->sorted.reserve((size_t)n));
-    SE2_CHECK(h->n_grid.reserve(1));
+    SE2_CHECK(h->n_grid.reserve(kGridRec));
     SE2_CHECK(h->cand.reserve((size_t)mm * kMaxCand));
     SE2_CHECK(h->ncand.reserve((size_t)mm));
     SE2_CHECK(h->matches.reserve((size_t)n));
