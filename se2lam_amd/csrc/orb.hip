@@ -730,6 +730,8 @@ inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
 // ---------------------------------------------------------------------------------------------
 struct se2gpu_orb {
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;          // blurred pyramid: independent of the key-point chain, runs beside it
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     LaunchProfile prof;
     se2gpu_orb_params params{};
     double scaleFactor = 1.2;
@@ -751,6 +753,9 @@ struct se2gpu_orb {
     int score_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
     ~se2gpu_orb() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 
@@ -894,6 +899,27 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         dim3 grid((ng * (g.h[l] + 2 * kEdge) + 255) / 256, nframes);
         SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
     }
+    // The blurred pyramid needs only the pyramid: it runs on a side stream next to the key-point chain, whose
+    // k_level_select (one workgroup per frame) and k_cell_detect leave most CUs idle.  (Serial when profiling.)
+    hipStream_t sb = h->prof.enabled ? st : h->side_stream;
+    if (sb != st) {
+        SE2_HIP(hipEventRecord(h->ev_fork, st));
+        SE2_HIP(hipStreamWaitEvent(sb, h->ev_fork, 0));
+    }
+    {
+        Geom gb = g;
+        int items = 0;
+        for (int l = 0; l < L; ++l) {
+            gb.tile_base[l] = items;
+            items += 2 * kEdge * (g.stride[l] / 16) + g.h[l] * (1 + frame_chunks_right(g.w[l], g.stride[l]));
+        }
+        gb.tile_base[L] = items;
+        SE2_LAUNCH(h->prof, sb, "k_copy_frame", k_copy_frame, dim3((items + 255) / 256, nframes), dim3(256), 0, gb, h->pyr.p,
+                   h->blur.p);
+        for (int l = 0; l <= L; ++l) gb.tile_base[l] = h->blur_tile_base[l];
+        SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(gb.tile_base[L], nframes), dim3(256), 0, gb, h->pyr.p, h->blur.p);
+    }
+    if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
     for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
     SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p,
                h->score.p);
@@ -903,19 +929,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
                h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p);
-    // blurred pyramid: frame = un-blurred reflect copies, interior = blur
-    {
-        int items = 0;
-        for (int l = 0; l < L; ++l) {
-            g.tile_base[l] = items;
-            items += 2 * kEdge * (g.stride[l] / 16) + g.h[l] * (1 + frame_chunks_right(g.w[l], g.stride[l]));
-        }
-        g.tile_base[L] = items;
-        SE2_LAUNCH(h->prof, st, "k_copy_frame", k_copy_frame, dim3((items + 255) / 256, nframes), dim3(256), 0, g, h->pyr.p,
-                   h->blur.p);
-    }
-    for (int l = 0; l <= L; ++l) g.tile_base[l] = h->blur_tile_base[l];
-    SE2_LAUNCH(h->prof, st, "k_blur", k_blur, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p, h->blur.p);
+    if (sb != st) SE2_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->blur.p,
                h->kp_list.p, d_counts, cap, h->angles.p, d_kps, d_desc);
     SE2_HIP(hipGetLastError());
@@ -957,6 +971,13 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
         return SE2GPU_ERR_HIP;
     }
     h->stream = h->own_stream;
+    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        set_error("hipStreamCreate / hipEventCreate failed");
+        delete h;
+        return SE2GPU_ERR_HIP;
+    }
     // ORBextractor::ORBextractor (ORBextractor.cpp:463-520); scaleFactor is a double member built from a float
     const int L = params->nlevels;
     h->scaleFactor = (double)params->scale_factor;
