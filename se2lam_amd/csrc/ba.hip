@@ -1112,8 +1112,13 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         if (ncol == kNB) {
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
-                reinterpret_cast<double2*>(pm)[q / 2] = make_double2(m[q], m[q + 1]);
-                reinterpret_cast<double2*>(pr)[q / 2] = make_double2(mrs[q], mrs[q + 1]);
+                if (w == 3) {   // the last wave is on the critical path: write-through stores, no L2 write-back after
+                    store_agent(pm + q, d2_t{m[q], m[q + 1]});
+                    store_agent(pr + q, d2_t{mrs[q], mrs[q + 1]});
+                } else {
+                    reinterpret_cast<double2*>(pm)[q / 2] = make_double2(m[q], m[q + 1]);
+                    reinterpret_cast<double2*>(pr)[q / 2] = make_double2(mrs[q], mrs[q + 1]);
+                }
             }
         } else {
 #pragma unroll
@@ -1130,7 +1135,8 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
             if (cb + q < ncol) py[q] = m[q];   // y_un: read by k_chol_apply only (next kernel)
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores are written back from this XCD's L2
+    if (w == 3 && ncol == kNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores are written back from this XCD's L2
     __syncthreads();
     if (tid == 0)
         __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELAXED,
