@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     // minimum, LDS rows addressed with immediate offsets.
     double* mrc = &MRC[cb][lane];
     double* colv = &COLV[cb][lane];
-    double pmin = 1e300;
+    double pmin = 1e300, mr_prev = 0.0, rvb[2][8];   // rvb: double buffer (static indices: the loop is unrolled)
     double piv = bcast_lane(m[0], cb);
     double inv = fast_rcp1(piv);
 #pragma unroll
@@ -1088,13 +1088,21 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         asm volatile("" ::: "memory");
         __hip_atomic_store(&ready_s, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         asm volatile("" ::: "memory");
+        // This column's pivot-row values for the wave's remaining columns come back from the LDS row just written
+        // (uniform-address reads = broadcast, in order behind the write) and are applied ONE column later, when they
+        // have long arrived: 2 v_readlane per element would otherwise be 40 % of the instructions of this section.
+#pragma unroll
+        for (int q2 = q + 2; q2 < 8; ++q2) rvb[q & 1][q2] = COLV[jj][cb + q2];
+        if (q > 0) {
+#pragma unroll
+            for (int q2 = q + 1; q2 < 8; ++q2) m[q2] = fma(-mr_prev, rvb[(q & 1) ^ 1][q2], m[q2]);
+        }
         if (q + 1 < 8) {
             m[q + 1] = fma(-mr, bcast_lane(m[q], jj + 1), m[q + 1]);
             piv = bcast_lane(m[q + 1], jj + 1);
             inv = fast_rcp1(piv);  // next pivot: in flight during the rest of the update
         }
-#pragma unroll
-        for (int q2 = q + 2; q2 < 8; ++q2) m[q2] = fma(-mr, bcast_lane(m[q], cb + q2), m[q2]);
+        mr_prev = mr;
     }
     if (stamp && lane == 0) stamp[12 + w] = wall_clock64() + (long long)(m[7] == 1.2345e-300);
     // pivots must be positive and finite (pad pivots are ~1e300)
