@@ -7,10 +7,31 @@
 #include "se2lam_amd/ORBextractor.h"
 #include "se2lam_amd/ORBmatcher.h"
 #include "se2lam_amd/optimizer.h"
+#include "se2lam_amd/preintegration.h"
 
 using namespace se2lam_amd;
 
+// Track::updateFramePose pre-integration over a fixed odometry sequence; printed for tests/test_capi.py, which
+// recomputes it with numpy
+static void preintegration_demo() {
+    PreSE2 p;
+    resetPreSE2(p);
+    Se2f last{100.f, -20.f, 0.3f};
+    for (int k = 1; k <= 12; ++k) {
+        Se2f now{100.f + 35.f * k + 3.f * (k % 3), -20.f + 4.f * k - 2.f * (k % 2), 0.3f + 0.021f * k};
+        updatePreSE2(p, se2Minus(now, last), 2.0, 2.0, 0.002);
+        last = now;
+    }
+    Matrix3D info;
+    const bool ok = preSE2Information(p, info);
+    std::printf("PRESE2 %.17g %.17g %.17g", p.meas[0], p.meas[1], p.meas[2]);
+    for (int i = 0; i < 9; ++i) std::printf(" %.17g", p.cov[i]);
+    for (int i = 0; i < 9; ++i) std::printf(" %.17g", ok ? info.m[i] : 0.0);
+    std::printf("\n");
+}
+
 int main() {
+    preintegration_demo();
     if (se2gpu_device_count() == 0) {
         try {
             SlamOptimizer opt;

@@ -82,6 +82,38 @@ def test_cpp_adapters_compile_and_link(tmp_path):
     assert "OK" in r.stdout or "adapters" in r.stdout
 
 
+def test_cpp_preintegration_matches_numpy(tmp_path):
+    """include/se2lam_amd/preintegration.h (Track::updateFramePose, Track.cpp:169-187; Se2::operator-, Config.cpp:215)
+    against a numpy restatement of the same recursion on the same odometry sequence."""
+    import numpy as np
+    exe = _build_adapter_binary(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("PRESE2")][0]
+    v = np.array(line.split()[1:], dtype=np.float64)
+    meas_c, cov_c, info_c = v[:3], v[3:12].reshape(3, 3), v[12:21].reshape(3, 3)
+    f32 = np.float32
+    last = np.array([100, -20, 0.3], f32)
+    meas, cov = np.zeros(3), np.zeros((3, 3))
+    Sv = np.diag([4.0, 4.0, 0.002 ** 2])
+    for k in range(1, 13):
+        now = np.array([100 + 35 * k + 3 * (k % 3), -20 + 4 * k - 2 * (k % 2), f32(0.3) + f32(0.021) * f32(k)], f32)
+        dx, dy = f32(now[0] - last[0]), f32(now[1] - last[1])
+        dth = f32(now[2] - last[2])
+        c, s = f32(np.cos(last[2])), f32(np.sin(last[2]))
+        o = np.array([f32(c * dx + s * dy), f32(-s * dx + c * dy), dth], np.float64)
+        Phi = np.array([[np.cos(meas[2]), -np.sin(meas[2])], [np.sin(meas[2]), np.cos(meas[2])]])
+        A, B = np.eye(3), np.eye(3)
+        A[:2, 2] = Phi @ np.array([-o[1], o[0]])
+        B[:2, :2] = Phi
+        meas[:2] += Phi @ o[:2]
+        meas[2] += o[2]
+        cov = A @ cov @ A.T + B @ Sv @ B.T
+        last = now
+    assert np.allclose(meas_c, meas, rtol=1e-6, atol=1e-6)      # float odometry differences: libm float rounding
+    assert np.allclose(cov_c, cov, rtol=1e-5)
+    assert np.allclose(info_c @ cov_c, np.eye(3), atol=1e-9)
+
+
 @pytest.mark.gpu
 def test_cpp_adapters_run_on_gpu(tmp_path):
     exe = _build_adapter_binary(tmp_path)
