@@ -43,7 +43,7 @@ typedef struct se2gpu_orb_params {   /* defaults of ORBextractor.h:44 */
     int32_t nfeatures;     /* 1000 */
     float scale_factor;    /* 1.2f */
     int32_t nlevels;       /* 8    */
-    int32_t score_type;    /* 1 = FAST_SCORE (0 = HARRIS_SCORE is rejected: dormant in the reference) */
+    int32_t score_type;    /* cv::ORB enum: 1 = FAST_SCORE (the reference's default), 0 = HARRIS_SCORE */
     int32_t fast_th;       /* 20   */
     int32_t max_rows, max_cols;  /* largest image the handle will see (0,0 -> 480,640) */
     int32_t max_batch;     /* frames per batched call (0 -> 1) */

@@ -191,7 +191,7 @@ def ba_edge_pre_se2(pi, pj, z):
 # --------------------------------------------------------------------------------------
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
-                ("fast_th", C.c_int32)]
+                ("fast_th", C.c_int32), ("score_type", C.c_int32)]
 
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -223,8 +223,11 @@ def _declare_orb(l):
     l.orb_ref_fast_score.argtypes = [VP, C.c_int]
 
 
-def orb_params(nfeatures=1000, scale_factor=1.2, nlevels=8, fast_th=20):
-    return OrbParams(nfeatures, scale_factor, nlevels, fast_th)
+FAST_SCORE, HARRIS_SCORE = 1, 0   # cv::ORB enum values the reference's constructor takes (ORBextractor.h:44)
+
+
+def orb_params(nfeatures=1000, scale_factor=1.2, nlevels=8, fast_th=20, score_type=FAST_SCORE):
+    return OrbParams(nfeatures, scale_factor, nlevels, fast_th, score_type)
 
 
 def orb_extract(img, params=None, cap=4096):

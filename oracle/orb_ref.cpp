@@ -40,6 +40,7 @@ struct orb_ref_params {
     float scale_factor;   // 1.2f
     int32_t nlevels;      // 8
     int32_t fast_th;      // 20
+    int32_t score_type;   // 1 = ORB::FAST_SCORE (the reference's default), 0 = ORB::HARRIS_SCORE (ORBextractor.h:44)
 };
 struct orb_ref_keypoint {  // cv::KeyPoint layout
     float x, y, size, angle, response;
@@ -92,14 +93,15 @@ struct Level {
 };
 
 struct Extractor {
-    int nfeatures, nlevels, fastTh;
+    int nfeatures, nlevels, fastTh, scoreType;
     double scaleFactor;  // member is double (ORBextractor.h:68), constructed from a float
     std::vector<float> mvScaleFactor, mvInvScaleFactor;
     std::vector<int> mnFeaturesPerLevel, umax;
     std::vector<Level> pyr;
 
     explicit Extractor(const orb_ref_params& p)
-        : nfeatures(p.nfeatures), nlevels(p.nlevels), fastTh(p.fast_th), scaleFactor(p.scale_factor) {
+        : nfeatures(p.nfeatures), nlevels(p.nlevels), fastTh(p.fast_th), scoreType(p.score_type),
+          scaleFactor(p.scale_factor) {
         mvScaleFactor.resize(nlevels);
         mvScaleFactor[0] = 1;
         for (int i = 1; i < nlevels; i++) mvScaleFactor[i] = (float)(mvScaleFactor[i - 1] * scaleFactor);
@@ -254,9 +256,33 @@ struct Extractor {
     }
 
     struct KP {
-        int x, y;   // level coordinates (interior)
-        int resp;   // cornerScore = S - 1
+        int x, y;     // level coordinates (interior)
+        float resp;   // cornerScore = S - 1 (exact in float), or the Harris response
     };
+
+    // HarrisResponses(cellImage, pts, 7, HARRIS_K) of ORBextractor.cpp:85-126 for one key point: the cell image is a
+    // view into the (un-blurred) level image, so the 7x7 block of 3x3 Sobel windows is read from the level itself.
+    // Float expression evaluated in the reference's order (no contraction: -ffp-contract=off).
+    float harris_response(const Level& L, int x, int y) const {
+        const int blockSize = 7, r = blockSize / 2;
+        const float harris_k = 0.04f;
+        float scale = (1 << 2) * blockSize * 255.0f;
+        scale = 1.0f / scale;
+        const float scale_sq_sq = scale * scale * scale * scale;
+        const int step = L.stride;
+        const uint8_t* ptr0 = L.at(y - r, x - r);
+        int a = 0, b = 0, c = 0;
+        for (int i = 0; i < blockSize; i++)
+            for (int j = 0; j < blockSize; j++) {
+                const uint8_t* ptr = ptr0 + i * step + j;
+                const int Ix = (ptr[1] - ptr[-1]) * 2 + (ptr[-step + 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[step - 1]);
+                const int Iy = (ptr[step] - ptr[-step]) * 2 + (ptr[step - 1] - ptr[-step - 1]) + (ptr[step + 1] - ptr[-step + 1]);
+                a += Ix * Ix;
+                b += Iy * Iy;
+                c += Ix * Iy;
+            }
+        return ((float)a * b - (float)c * c - harris_k * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+    }
 
     // cv::FAST(cell, kps, thr, true) over the cell window [x0, x0+w) x [y0, y0+h): scans rows/cols 3..dim-4.
     static void fast_cell(const std::vector<uint8_t>& S, int W, int x0, int y0, int w, int h, int thr,
@@ -274,7 +300,7 @@ struct Extractor {
                 if (s == 0) continue;
                 if (s > sc(x - 1, y) && s > sc(x + 1, y) && s > sc(x - 1, y - 1) && s > sc(x, y - 1) &&
                     s > sc(x + 1, y - 1) && s > sc(x - 1, y + 1) && s > sc(x, y + 1) && s > sc(x + 1, y + 1))
-                    out.push_back(KP{x, y, s});
+                    out.push_back(KP{x, y, (float)s});
             }
     }
 
@@ -339,6 +365,8 @@ struct Extractor {
                     std::vector<KP>& kps = cellKP[i][j];
                     fast_cell(S, pyr[level].w, x0, y0, x1 - x0, y1 - y0, fastTh, kps);
                     if (kps.size() <= 3) fast_cell(S, pyr[level].w, x0, y0, x1 - x0, y1 - y0, 7, kps);
+                    if (scoreType == 0)   // ORB::HARRIS_SCORE (ORBextractor.cpp:625-629)
+                        for (KP& k : kps) k.resp = harris_response(pyr[level], k.x, k.y);
                     const int nKeys = (int)kps.size();
                     nTotal[i][j] = nKeys;
                     if (nKeys > nfeaturesCell) {
@@ -402,7 +430,7 @@ struct Extractor {
                 kp.y = (float)k.y;
                 kp.size = (float)scaledPatchSize;
                 kp.angle = -1;
-                kp.response = (float)k.resp;
+                kp.response = k.resp;
                 kp.octave = level;
                 kp.class_id = -1;
                 all[level].push_back(kp);

@@ -58,6 +58,7 @@ struct Geom {
     int umax[16];
     int nfeatures;
     int fast_th;
+    int harris;                          // scoreType == ORB::HARRIS_SCORE: retain by Harris response
 };
 
 // interior pixel (x, y) of level l of frame f
@@ -333,10 +334,37 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
 // scan area exactly (cell window = cell +- 3 px, cv::FAST skips a 3 px rim, ORBextractor.cpp:569-608).
 // key = (255 - S) << 24 | y << 12 | x  (ascending = response desc, y asc, x asc)
 // ---------------------------------------------------------------------------------------------
+// HarrisResponses(cellImage, pts, 7, 0.04f) of ORBextractor.cpp:85-126 for one key point (x, y) of the un-blurred level:
+// 7x7 block of 3x3 Sobel windows, integer sums, then the reference's float expression (compiled without contraction).
+__device__ __forceinline__ float harris_response(const uint8_t* __restrict__ lvl, int stride, int x, int y) {
+    const uint8_t* p0 = lvl + (ptrdiff_t)(y - 3) * stride + (x - 3);
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < 7; ++i) {
+        const uint8_t* r0 = p0 + (ptrdiff_t)(i - 1) * stride;
+        const uint8_t* r1 = r0 + stride;
+        const uint8_t* r2 = r1 + stride;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const int Ix = ((int)r1[j + 1] - (int)r1[j - 1]) * 2 + ((int)r0[j + 1] - (int)r0[j - 1]) + ((int)r2[j + 1] - (int)r2[j - 1]);
+            const int Iy = ((int)r2[j] - (int)r0[j]) * 2 + ((int)r2[j - 1] - (int)r0[j - 1]) + ((int)r2[j + 1] - (int)r0[j + 1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            c += Ix * Iy;
+        }
+    }
+    float scale = (1 << 2) * 7 * 255.0f;
+    scale = 1.0f / scale;
+    const float scale_sq_sq = scale * scale * scale * scale;
+    return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
+}
+
+template <bool HARRIS>
 __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __restrict__ score,
-                                                      uint32_t* __restrict__ cell_keys, int* __restrict__ cell_total,
-                                                      int* __restrict__ overflow) {
+                                                      const uint8_t* __restrict__ pyr,
+                                                      uint32_t* __restrict__ cell_keys, float* __restrict__ cell_resp,
+                                                      int* __restrict__ cell_total, int* __restrict__ overflow) {
     __shared__ uint32_t keys[kSortCap];
+    __shared__ unsigned long long keys64[HARRIS ? kSortCap : 1];   // (~ordered(response) << 32) | (y << 12) | x
     __shared__ int s_n, s_n20;
     const int f = blockIdx.y;
     const int cell = blockIdx.x;
@@ -398,8 +426,51 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
     const int total = (n20 > 3) ? n20 : n;
     const int keep = min(total, g.cell_cap);
     uint32_t* out = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-    for (int i = threadIdx.x; i < keep; i += 256) out[i] = keys[i];
+    float* outr = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
     if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = total;
+    if (!HARRIS) {
+        for (int i = threadIdx.x; i < keep; i += 256) {
+            out[i] = keys[i] & 0x00ffffffu;
+            outr[i] = (float)(254 - (int)(keys[i] >> 24));   // cornerScore = S - 1
+        }
+        return;
+    }
+    // HARRIS_SCORE (ORBextractor.cpp:625-629): the key points FAST selected get the Harris response of the level
+    // image and are retained by it: order (response desc, y asc, x asc)
+    const uint8_t* lvl = pyr + pix(g, f, l, 0, 0);
+    int np2 = 1;
+    while (np2 < total) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += 256) {
+        unsigned long long k = ~0ull;
+        if (i < total) {
+            const uint32_t pos = keys[i] & 0x00ffffffu;
+            const float rsp = harris_response(lvl, stride, (int)(pos & 0xfff), (int)(pos >> 12));
+            uint32_t bits = __float_as_uint(rsp);
+            bits ^= (bits >> 31) ? 0xffffffffu : 0x80000000u;   // monotone map float -> uint32
+            k = ((unsigned long long)(~bits) << 32) | pos;
+        }
+        keys64[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = keys64[i], b = keys64[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys64[i] = b; keys64[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < keep; i += 256) {
+        const unsigned long long k = keys64[i];
+        uint32_t bits = ~(uint32_t)(k >> 32);
+        bits ^= (bits >> 31) ? 0x80000000u : 0xffffffffu;       // inverse of the map above
+        out[i] = (uint32_t)k;
+        outr[i] = __uint_as_float(bits);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,9 +478,11 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
 // retain (:706-710).  Output: kp_list[f][i] = {level, x, y, response} in final order; counts[f].
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __restrict__ cell_keys,
+                                                       const float* __restrict__ cell_resp,
                                                        const int* __restrict__ cell_total, int4* __restrict__ kp_list,
                                                        int* __restrict__ counts, int cap, int* __restrict__ overflow) {
     __shared__ uint32_t lst[kLevelCap];
+    __shared__ float lrsp[kLevelCap];
     __shared__ int keepflag[kLevelCap];
     __shared__ int n_retain[64 * 4];   // per cell (<= 256 cells per level)
     __shared__ int cell_off[64 * 4 + 1];
@@ -454,20 +527,24 @@ __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __
         // gather the per-cell prefixes in cell row-major order
         for (int c = 0; c < nCells; ++c) {
             const uint32_t* src = cell_keys + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
+            const float* srcr = cell_resp + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
             const int o = cell_off[c];
             for (int i = threadIdx.x; i < n_retain[c]; i += 256)
-                if (o + i < kLevelCap) lst[o + i] = src[i];
+                if (o + i < kLevelCap) {
+                    lst[o + i] = src[i];
+                    lrsp[o + i] = srcr[i];
+                }
         }
         __syncthreads();
         const int quota = g.quota[l];
         if (n > quota) {
             // keep the `quota` best by (response desc, list position asc), preserving list order
             for (int i = threadIdx.x; i < n; i += 256) {
-                const uint32_t ri = lst[i] >> 24;  // 255 - S: smaller is better
+                const float ri = lrsp[i];
                 int rank = 0;
                 for (int j = 0; j < n; ++j) {
-                    const uint32_t rj = lst[j] >> 24;
-                    rank += (rj < ri) || (rj == ri && j < i);
+                    const float rj = lrsp[j];
+                    rank += (rj > ri) || (rj == ri && j < i);
                 }
                 keepflag[i] = rank < quota;
             }
@@ -493,7 +570,7 @@ __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __
                 if (pos < cap) {
                     const uint32_t key = lst[i];
                     kp_list[(size_t)f * cap + pos] = make_int4(l, (int)(key & 0xfff), (int)((key >> 12) & 0xfff),
-                                                               254 - (int)(key >> 24));
+                                                               __float_as_int(lrsp[i]));
                 } else {
                     atomicOr(overflow, 8);
                 }
@@ -711,7 +788,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
         }
         o.size = g.patch[kp.x];
         o.angle = ang;
-        o.response = (float)kp.w;
+        o.response = __int_as_float(kp.w);
         o.octave = kp.x;
         o.class_id = -1;
         kps[(size_t)f * cap + k] = o;
@@ -745,7 +822,7 @@ struct se2gpu_orb {
     DevBuf<uint32_t> cell_keys;
     DevBuf<int> cell_total, counts, overflow;
     DevBuf<int4> kp_list, tabs;
-    DevBuf<float> angles;
+    DevBuf<float> angles, cell_resp;
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
@@ -770,6 +847,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     g.rows = rows; g.cols = cols;
     g.nfeatures = h->params.nfeatures;
     g.fast_th = h->params.fast_th;
+    g.harris = h->params.score_type == 0;
     for (int i = 0; i < 16; ++i) g.umax[i] = h->umax[i];
     unsigned off = 0;
     const float imageRatio = (float)cols / rows;
@@ -875,6 +953,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     SE2_HIP(hipMemsetAsync(h->score.p, 0, B * g.frame_bytes, h->stream));
     SE2_CHECK(h->cell_keys.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
     SE2_CHECK(h->cell_total.reserve(B * g.cell_base[L]));
+    SE2_CHECK(h->cell_resp.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
     SE2_CHECK(h->overflow.reserve(1));
     SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
     SE2_HIP(hipStreamSynchronize(h->stream));
@@ -923,10 +1002,14 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
     SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p,
                h->score.p);
-    SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect, dim3(g.cell_base[L], nframes), dim3(256), 0, g, h->score.p,
-               h->cell_keys.p, h->cell_total.p, h->overflow.p);
+    if (g.harris)
+        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
+                   h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
+    else
+        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<false>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
+                   h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(nframes), dim3(256), 0, g, h->cell_keys.p,
-               h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
+               h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p);
     if (sb != st) SE2_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -956,8 +1039,8 @@ extern "C" {
 int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
     SE2_REQUIRE(params && out, SE2GPU_ERR_INVALID, "orb_create: NULL argument");
     SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
-    SE2_REQUIRE(params->score_type == 1, SE2GPU_ERR_INVALID,
-                "only FAST_SCORE is supported (HARRIS_SCORE is dormant in the reference, ORBextractor.h:44)");
+    SE2_REQUIRE(params->score_type == 1 || params->score_type == 0, SE2GPU_ERR_INVALID,
+                "score_type must be 1 (ORB::FAST_SCORE) or 0 (ORB::HARRIS_SCORE)");
     SE2_REQUIRE(params->nlevels >= 1 && params->nlevels <= kMaxLevels && params->nfeatures > 0 &&
                     params->scale_factor > 1.0f && params->fast_th >= 7 && params->fast_th < 255,
                 SE2GPU_ERR_INVALID, "orb_create: parameter out of range");

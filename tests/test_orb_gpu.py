@@ -106,9 +106,26 @@ def test_errors(ex):
     from se2lam_amd import capi
     from se2lam_amd.orb import ORBextractor
     with pytest.raises(capi.Se2GpuError) as e:
-        ORBextractor(scoreType=0)                      # HARRIS_SCORE: dormant in the reference, rejected
+        ORBextractor(scoreType=2)                      # neither ORB::HARRIS_SCORE (0) nor ORB::FAST_SCORE (1)
     assert e.value.code == capi.ERR_INVALID
     with pytest.raises(capi.Se2GpuError):
         ex(np.zeros((480, 640), np.uint8), mask=np.ones((480, 640), np.uint8))
     with pytest.raises(capi.Se2GpuError):
         ex(np.zeros((481, 640), np.uint8))             # larger than the handle was created for
+
+
+@pytest.mark.parametrize("t", [0, 4, 9])
+def test_harris_score_bit_exact(oracle, synth, t):
+    """scoreType = ORB::HARRIS_SCORE (ORBextractor.cpp:85-126, 625-629; dormant in the reference's own callers): the FAST
+    key points of every cell are re-scored with the 7x7 Harris response and retained by it - every key point field
+    (response = the float Harris value) and every descriptor byte equal to the oracle's."""
+    from se2lam_amd.orb import ORBextractor, HARRIS_SCORE
+    ex = ORBextractor(scoreType=HARRIS_SCORE)
+    img = synth.frame(t)
+    k, d = ex(img)
+    kr, dr = oracle.orb_extract(img, oracle.orb_params(score_type=oracle.HARRIS_SCORE))
+    assert len(k) == len(kr) > 500
+    for name in k.dtype.names:
+        assert np.array_equal(k[name], kr[name]), name
+    assert np.array_equal(d, dr)
+    assert not np.array_equal(kr["response"], np.round(kr["response"]))   # really Harris floats, not FAST scores
