@@ -248,10 +248,12 @@ def test_edge_information_on_device(oracle, synth):
 
 
 @pytest.mark.parametrize("path", ["tiles", "steps"])
-@pytest.mark.parametrize("P,L", [(8, 60), (50, 5000), (200, 20000)])
+@pytest.mark.parametrize("P,L", [(8, 60), (11, 300), (21, 600), (32, 900), (43, 1200), (50, 5000), (200, 20000)])
 def test_device_pose_solve_matches_host_cholesky(synth, monkeypatch, path, P, L):
     """The device factorisation that stands in for CHOLMOD (k_chol_tiles: one dataflow launch; k_chol_step: one launch
-    per block column) against a host Cholesky refined in extended precision; solved twice (flag epochs)."""
+    per block column) against a host Cholesky refined in extended precision; solved twice (flag epochs).  The sizes
+    cover the layouts of the augmented right-hand-side row: inside the last diagonal tile (3P % 32 != 0), as its last
+    row (3P = 63) and in a tile row of its own (3P = 96)."""
     if path == "steps":
         monkeypatch.setenv("SE2GPU_BA_CHOL", "steps")
     else:
