@@ -288,3 +288,18 @@ def test_device_pose_solve_reports_indefinite_system(synth, monkeypatch, path):
     assert not ok
     x, ok = o.solve(10.0)                                      # and the next solve is clean again
     assert ok and np.isfinite(x).all()
+
+
+def test_dataflow_solve_with_more_tiles_than_resident_workgroups(synth, monkeypatch):
+    """500 key frames: 47 x 48 = 2,256 tile tasks, several times what the GPU keeps resident.  The dataflow launch
+    must still complete (tasks only wait for lower workgroup ids, dispatch is in order) and be exact."""
+    monkeypatch.delenv("SE2GPU_BA_CHOL", raising=False)
+    g = synth.ba_graph(500, 10000)
+    o = _opt(g)
+    S, bs = o.reduced_system(20.0)
+    c = np.linalg.cholesky(S)
+    x_ref = np.linalg.solve(c.T, np.linalg.solve(c, bs))
+    for _ in range(2):
+        x, ok = o.solve(20.0)
+        assert ok
+        assert np.abs(x - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
