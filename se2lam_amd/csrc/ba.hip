@@ -116,6 +116,25 @@ __device__ inline double wave_sum(double v) {
 __device__ inline void inv_sym3(const double h[6], double lambda, double d[6]);
 
 // FUSED: also produce the lambda-dependent per-landmark pieces of k_schur_lm (Dinv, z, Y_e) in the same pass.
+// Per-edge contribution to the DIAGONAL of the reduced system, formed where Y_e, Hpl_e and z_l are already at hand:
+//   Dg_e = { sym(Hpp_e - Y_e Hpl_e^T) (6), bp_e (3), Hpl_e z_l (3) }        (12 doubles, one 96-byte record)
+// k_reduce2's per-pose gather then reads one record per edge instead of five arrays through two levels of indices.
+__device__ inline void write_diag_record(double* __restrict__ dg, const double* __restrict__ yy,
+                                         const double* __restrict__ hh, const double* __restrict__ hp,
+                                         const double* __restrict__ bpe, double z0, double z1, double z2) {
+    dg[0] = hp[0] - (yy[0] * hh[0] + yy[1] * hh[1] + yy[2] * hh[2]);
+    dg[1] = hp[1] - (yy[0] * hh[3] + yy[1] * hh[4] + yy[2] * hh[5]);
+    dg[2] = hp[2] - (yy[0] * hh[6] + yy[1] * hh[7] + yy[2] * hh[8]);
+    dg[3] = hp[3] - (yy[3] * hh[3] + yy[4] * hh[4] + yy[5] * hh[5]);
+    dg[4] = hp[4] - (yy[3] * hh[6] + yy[4] * hh[7] + yy[5] * hh[8]);
+    dg[5] = hp[5] - (yy[6] * hh[6] + yy[7] * hh[7] + yy[8] * hh[8]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        dg[6 + r] = bpe[r];
+        dg[9 + r] = hh[r * 3] * z0 + hh[r * 3 + 1] * z1 + hh[r * 3 + 2] * z2;
+    }
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const int* __restrict__ lm_ptr,
                                                        const int* __restrict__ e_kf, const double* __restrict__ e_uv,
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
                                                        double* __restrict__ Hpp_e, double* __restrict__ bp_e,
                                                        double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                        double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ Y) {
+                                                       double* __restrict__ Y, double* __restrict__ Dg) {
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -197,16 +216,25 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
             z[(size_t)l * 3 + 1] = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
             z[(size_t)l * 3 + 2] = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
         }
+        const double z0 = d[0] * b[0] + d[1] * b[1] + d[2] * b[2];
+        const double z1 = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
+        const double z2 = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
         for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
             const double* B = Hpl + (size_t)e * 9;  // written by this same lane above
             double* y = Y + (size_t)e * 9;
+            double hh[9], yy[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) hh[i] = B[i];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const double b0 = B[r * 3], b1 = B[r * 3 + 1], b2 = B[r * 3 + 2];
-                y[r * 3 + 0] = b0 * d[0] + b1 * d[1] + b2 * d[2];
-                y[r * 3 + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
-                y[r * 3 + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
+                const double b0 = hh[r * 3], b1 = hh[r * 3 + 1], b2 = hh[r * 3 + 2];
+                yy[r * 3 + 0] = b0 * d[0] + b1 * d[1] + b2 * d[2];
+                yy[r * 3 + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
+                yy[r * 3 + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
             }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) y[i] = yy[i];
+            write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
         }
     }
 }
@@ -349,8 +377,11 @@ __device__ inline void inv_sym3(const double h[6], double lambda, double d[6]) {
 
 __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const int* __restrict__ lm_ptr,
                                                       const double* __restrict__ Hll, const double* __restrict__ bl,
-                                                      const double* __restrict__ Hpl, double* __restrict__ Dinv,
-                                                      double* __restrict__ z, double* __restrict__ Y) {
+                                                      const double* __restrict__ Hpl,
+                                                      const double* __restrict__ Hpp_e,
+                                                      const double* __restrict__ bp_e, double* __restrict__ Dinv,
+                                                      double* __restrict__ z, double* __restrict__ Y,
+                                                      double* __restrict__ Dg) {
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     if (l >= L) return;
@@ -358,24 +389,33 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const
 #pragma unroll
     for (int i = 0; i < 6; ++i) h[i] = Hll[(size_t)l * 6 + i];
     inv_sym3(h, lambda, d);
+    const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
+    const double z0 = d[0] * b0 + d[1] * b1 + d[2] * b2;
+    const double z1 = d[1] * b0 + d[3] * b1 + d[4] * b2;
+    const double z2 = d[2] * b0 + d[4] * b1 + d[5] * b2;
     if (sub == 0) {
-        const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
 #pragma unroll
         for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
-        z[(size_t)l * 3 + 0] = d[0] * b0 + d[1] * b1 + d[2] * b2;
-        z[(size_t)l * 3 + 1] = d[1] * b0 + d[3] * b1 + d[4] * b2;
-        z[(size_t)l * 3 + 2] = d[2] * b0 + d[4] * b1 + d[5] * b2;
+        z[(size_t)l * 3 + 0] = z0;
+        z[(size_t)l * 3 + 1] = z1;
+        z[(size_t)l * 3 + 2] = z2;
     }
     for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
         const double* B = Hpl + (size_t)e * 9;
         double* y = Y + (size_t)e * 9;
+        double hh[9], yy[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hh[i] = B[i];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const double b0 = B[r * 3], b1 = B[r * 3 + 1], b2 = B[r * 3 + 2];
-            y[r * 3 + 0] = b0 * d[0] + b1 * d[1] + b2 * d[2];
-            y[r * 3 + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
-            y[r * 3 + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
+            const double c0 = hh[r * 3], c1 = hh[r * 3 + 1], c2 = hh[r * 3 + 2];
+            yy[r * 3 + 0] = c0 * d[0] + c1 * d[1] + c2 * d[2];
+            yy[r * 3 + 1] = c0 * d[1] + c1 * d[3] + c2 * d[4];
+            yy[r * 3 + 2] = c0 * d[2] + c1 * d[4] + c2 * d[5];
         }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) y[i] = yy[i];
+        write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
     }
 }
 
@@ -494,10 +534,9 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                                                      const int* __restrict__ blk_b, const int* __restrict__ pair_i,
                                                      const int* __restrict__ pair_j, const int* __restrict__ blk_odo,
                                                      const double* __restrict__ Y, const double* __restrict__ Hpl,
-                                                     const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
+                                                     const double* __restrict__ Dg,
                                                      const uint8_t* __restrict__ fixed, const int* __restrict__ pose_ptr,
-                                                     const int* __restrict__ pose_edges, const int* __restrict__ e_lm,
-                                                     const double* __restrict__ z, const int* __restrict__ podo_ptr,
+                                                     const int* __restrict__ pose_edges, const int* __restrict__ podo_ptr,
                                                      const int* __restrict__ podo_item, const int* __restrict__ o_i,
                                                      const int* __restrict__ o_j, const double* __restrict__ o_meas,
                                                      const double* __restrict__ o_info, const double* __restrict__ poses,
@@ -601,11 +640,11 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
         }
     }
     if (!fa) {
-        // dependent gather (edge list -> edge rows, edge -> landmark -> z): the indices of up to four edges per thread
-        // are fetched first, so a pose with <= 1024 observations pays each level of the chain once
+        // gather of the per-edge diagonal records (write_diag_record): edge list -> one 96-byte record per edge; the
+        // indices of up to four edges per thread are fetched first, then all the records
         const int e0 = pose_ptr[p], ne = pose_ptr[p + 1] - e0;
         for (int base = 0; base < ne; base += 4 * kBlock) {
-            int ee[4], ll[4];
+            int ee[4];
             double wgt[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -614,30 +653,15 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                 ee[u] = pose_edges[e0 + min(t, ne - 1)];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ll[u] = e_lm[ee[u]];
-#pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (base + u * kBlock >= ne) break;  // uniform
-                const int e = ee[u];
-                const double* y = Y + (size_t)e * 9;
-                const double* h = Hpl + (size_t)e * 9;
-                const double* hp = Hpp_e + (size_t)e * 6;
-                const double* zz = z + (size_t)ll[u] * 3;
+                const double2* rec = reinterpret_cast<const double2*>(Dg + (size_t)ee[u] * 12);
                 const double w = wgt[u];
-                double yy[9], hh[9];
 #pragma unroll
-                for (int i = 0; i < 9; ++i) { yy[i] = y[i]; hh[i] = h[i]; }
-                acc[0] += w * (hp[0] - (yy[0] * hh[0] + yy[1] * hh[1] + yy[2] * hh[2]));
-                acc[1] += w * (hp[1] - (yy[0] * hh[3] + yy[1] * hh[4] + yy[2] * hh[5]));
-                acc[2] += w * (hp[2] - (yy[0] * hh[6] + yy[1] * hh[7] + yy[2] * hh[8]));
-                acc[3] += w * (hp[3] - (yy[3] * hh[3] + yy[4] * hh[4] + yy[5] * hh[5]));
-                acc[4] += w * (hp[4] - (yy[3] * hh[6] + yy[4] * hh[7] + yy[5] * hh[8]));
-                acc[5] += w * (hp[5] - (yy[6] * hh[6] + yy[7] * hh[7] + yy[8] * hh[8]));
-                const double z0 = zz[0], z1 = zz[1], z2 = zz[2];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    acc[6 + r] += w * bp_e[(size_t)e * 3 + r];
-                    acc[9 + r] += w * (hh[r * 3] * z0 + hh[r * 3 + 1] * z1 + hh[r * 3 + 2] * z2);
+                for (int i = 0; i < 6; ++i) {
+                    const double2 v = rec[i];
+                    acc[2 * i] += w * v.x;
+                    acc[2 * i + 1] += w * v.y;
                 }
             }
         }
@@ -1446,7 +1470,7 @@ struct se2gpu_ba {
     int nwg_off = 0;
     bool odo_fallback = false;
     DevBuf<double> e_uv, e_info, o_meas, o_info;
-    DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Hpp, bp, Oii, Ojj, Oij, obi, obj;
+    DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Dg, Hpp, bp, Oii, Ojj, Oij, obi, obj;
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
     DevBuf<int2> chol_tasks;      // k_chol_tiles: (tile row | isR << 16, block column), ordered by column
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
@@ -1637,6 +1661,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_CHECK(h->Y.reserve(9 * (size_t)E + 1));
     SE2_CHECK(h->Hpp_e.reserve(6 * (size_t)E + 1));
     SE2_CHECK(h->bp_e.reserve(3 * (size_t)E + 1));
+    SE2_CHECK(h->Dg.reserve(12 * (size_t)E + 1));
     SE2_CHECK(h->Hll.reserve(6 * (size_t)L + 1));
     SE2_CHECK(h->bl.reserve(3 * (size_t)L + 1));
     SE2_CHECK(h->Dinv.reserve(6 * (size_t)L + 1));
@@ -1714,11 +1739,11 @@ int ba_linearize(se2gpu_ba* h, double fuse_lambda) {
     if (fuse_lambda >= 0.0)
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p);
     else
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -1743,10 +1768,11 @@ int ba_reduce(se2gpu_ba* h, double lambda, bool need_schur) {
     double* S = h->red;
     if (need_schur)
         SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
-                   lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Dinv.p, h->z.p, h->Y.p);
+                   lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->Y.p,
+                   h->Dg.p);
     SE2_LAUNCH(h->prof, st, "k_reduce2", k_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0, h->P, h->ld, h->nwg_off,
                lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
-               h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->e_lm.p, h->z.p,
+               h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p,
                h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, h->poses, S, h->bp.p);
     if (h->O && h->odo_fallback) {
         SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
