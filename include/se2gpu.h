@@ -215,6 +215,19 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
  * *factor_ok = 0 when a pivot was not positive. */
 int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok);
 
+/* Track::doTriangulate (/root/reference/src/Track.cpp:378-419) for every match of a frame pair in one device pass -
+ * SURVEY section 8(f).3.  Per feature i of the reference key frame with match_idx[i] >= 0 and no map point yet:
+ *   pos = cvu::triangulate(kps_ref[i].pt, kps_cur[match_idx[i]].pt, P_ref, P_cur)   (cvutil.cpp:46-59: DLT, smallest
+ *         right singular vector of the 4x4 system; one-sided Jacobi like cv::SVD, FP64 inside, FP32 in / out)
+ *   Config::acceptDepth(pos.z) (Config.cpp:188-190)  ? pos_out[i] = pos, good_parallax[i] = cvu::checkParallax(0, Ocam,
+ *         pos, min_degree) (cvutil.cpp:92-98)        : match_idx[i] = -1
+ * Features with has_observation[i] != 0 are only counted (*n_tracked_old; the caller keeps the key frame's map point).
+ * P_ref = Config::PrjMtrxEye, P_cur = Config::Kcam * Tcr.rowRange(0,3): 3x4 row-major float.  Host buffers. */
+int se2gpu_triangulate(int n, const se2gpu_keypoint* kps_ref, const se2gpu_keypoint* kps_cur, int n_cur,
+                       int32_t* match_idx, const uint8_t* has_observation, const float* P_ref, const float* P_cur,
+                       const float* Ocam, float lower_depth, float upper_depth, int min_degree, float* pos_out,
+                       uint8_t* good_parallax, int* n_good, int* n_tracked_old);
+
 /* Per-observation information matrices of Map::loadLocalGraph (/root/reference/src/Map.cpp:1024-1049), SURVEY §8f.1:
  *   Sigma = s_rot * J_r J_r^T + s_z * J_z J_z^T + sigma2 * I,   Omega = Sigma^-1       (2x2, FP64)
  *   J_r = (J_pi Rcw skew(lw - p))[:, 0:2],  J_z = -(J_pi Rcw)[:, 2],  J_pi from the stored camera-frame point lc.

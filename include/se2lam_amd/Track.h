@@ -1,0 +1,50 @@
+// Front-end geometry of se2lam::Track on the device - header-only mirror over the C ABI (include/se2gpu.h).
+//   Track::doTriangulate   /root/reference/src/Track.cpp:378-419   (cvu::triangulate, Config::acceptDepth, cvu::checkParallax)
+// The reference loops over the matches on the host, one 4x4 SVD each; here all matches of the frame pair go through one
+// kernel.  Map-point bookkeeping (mLocalMPs[i] = mpKF->mViewMPs[i] for features that already have an observation)
+// stays with the caller, exactly where the reference has it.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../se2gpu.h"
+#include "types.h"
+
+namespace se2lam_amd {
+
+struct Point3f {
+    float x, y, z;
+};
+
+struct TriangulationResult {
+    std::vector<Point3f> localMPs;      // mLocalMPs[i] for the features triangulated now (zero elsewhere)
+    std::vector<uint8_t> goodPrl;       // mvbGoodPrl
+    int nGoodPrl = 0;                   // mnGoodPrl
+    int nTrackedOld = 0;                // return value of Track::doTriangulate
+};
+
+// keyPointsUnRef / keyPointsUnCur: undistorted key points of the key frame and of the current frame; matchIdx =
+// Track::mMatchIdx (set to -1 where the depth gate rejects the point); hasObservation[i] = mpKF->hasObservation(i);
+// PrjMtrxEye = Config::PrjMtrxEye, P = Config::Kcam * mFrame.Tcr.rowRange(0,3) (3x4 row-major float);
+// Ocam = translation of cvu::inv(mFrame.Tcr).
+inline TriangulationResult doTriangulate(const std::vector<KeyPoint>& keyPointsUnRef,
+                                         const std::vector<KeyPoint>& keyPointsUnCur, std::vector<int>& matchIdx,
+                                         const std::vector<uint8_t>& hasObservation, const float PrjMtrxEye[12],
+                                         const float P[12], const float Ocam[3], float lowerDepth, float upperDepth,
+                                         int minDegree = 2) {
+    TriangulationResult r;
+    const int n = (int)keyPointsUnRef.size();
+    r.localMPs.assign(n, Point3f{0, 0, 0});
+    r.goodPrl.assign(n, 0);
+    if (n == 0) return r;
+    check(se2gpu_triangulate(n, reinterpret_cast<const se2gpu_keypoint*>(keyPointsUnRef.data()),
+                             reinterpret_cast<const se2gpu_keypoint*>(keyPointsUnCur.data()),
+                             (int)keyPointsUnCur.size(), matchIdx.data(),
+                             hasObservation.empty() ? nullptr : hasObservation.data(), PrjMtrxEye, P, Ocam, lowerDepth,
+                             upperDepth, minDegree, reinterpret_cast<float*>(r.localMPs.data()), r.goodPrl.data(),
+                             &r.nGoodPrl, &r.nTrackedOld),
+          "se2gpu_triangulate");
+    return r;
+}
+
+}  // namespace se2lam_amd

@@ -345,4 +345,108 @@ int match_ref_search_by_bow(const match_ref_keypoint* kps1, const uint8_t* desc1
     return nmatches;
 }
 
+// Track::doTriangulate for all matches of a frame pair (/root/reference/src/Track.cpp:378-419), with
+// cvu::triangulate (src/cvutil.cpp:46-59), Config::acceptDepth (src/Config.cpp:188-190) and cvu::checkParallax
+// (src/cvutil.cpp:92-98).  cv::SVD::compute is OpenCV's one-sided Jacobi in FP32 (third-party, not in the tree); the
+// same Hestenes iteration is run here in FP64 on the FP32 system matrix.  PARITY UNPINNED against OpenCV's own float
+// iteration (expected agreement ~1e-5 relative on well-conditioned points).
+static void smallest_right_singular_vector(const double a_in[16], double v4[4]) {
+    double At[4][4], Vt[4][4], W[4];
+    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < 4; ++k) {
+            At[i][k] = a_in[k * 4 + i];
+            Vt[i][k] = i == k ? 1.0 : 0.0;
+        }
+    for (int i = 0; i < 4; ++i) {
+        double sd = 0;
+        for (int k = 0; k < 4; ++k) sd += At[i][k] * At[i][k];
+        W[i] = sd;
+    }
+    const double eps = 2.220446049250313e-16 * 10;
+    for (int iter = 0; iter < 30; ++iter) {
+        bool changed = false;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i + 1; j < 4; ++j) {
+                double a = W[i], p = 0, b = W[j];
+                for (int k = 0; k < 4; ++k) p += At[i][k] * At[j][k];
+                if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = std::sqrt(p * p + beta * beta);
+                double c, sn;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    sn = std::sqrt(delta / gamma);
+                    c = p / (gamma * sn * 2);
+                } else {
+                    c = std::sqrt((gamma + beta) / (gamma * 2));
+                    sn = p / (gamma * c * 2);
+                }
+                a = 0;
+                b = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const double t0 = c * At[i][k] + sn * At[j][k];
+                    const double t1 = -sn * At[i][k] + c * At[j][k];
+                    At[i][k] = t0;
+                    At[j][k] = t1;
+                    a += t0 * t0;
+                    b += t1 * t1;
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = true;
+                for (int k = 0; k < 4; ++k) {
+                    const double t0 = c * Vt[i][k] + sn * Vt[j][k];
+                    const double t1 = -sn * Vt[i][k] + c * Vt[j][k];
+                    Vt[i][k] = t0;
+                    Vt[j][k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    int m = 0;
+    for (int i = 1; i < 4; ++i)
+        if (W[i] < W[m]) m = i;
+    for (int k = 0; k < 4; ++k) v4[k] = Vt[m][k];
+}
+
+int match_ref_triangulate(int n, const match_ref_keypoint* kps_ref, const match_ref_keypoint* kps_cur, int n_cur,
+                          int32_t* match_idx, const uint8_t* has_obs, const float* P1, const float* P2,
+                          const float* Ocam, float lower, float upper, int min_degree, float* pos, uint8_t* good,
+                          int* n_tracked_old) {
+    const float minCos[4] = {0.9998f, 0.9994f, 0.9986f, 0.9976f};
+    int ngood = 0, nold = 0;
+    for (int i = 0; i < n; ++i) {
+        good[i] = 0;
+        pos[3 * i] = pos[3 * i + 1] = pos[3 * i + 2] = 0.f;
+        const int mi = match_idx[i];
+        if (mi < 0 || mi >= n_cur) continue;
+        if (has_obs && has_obs[i]) { nold++; continue; }
+        const float x1 = kps_ref[i].x, y1 = kps_ref[i].y, x2 = kps_cur[mi].x, y2 = kps_cur[mi].y;
+        double A[16];
+        for (int c = 0; c < 4; ++c) {
+            A[0 + c] = (double)(x1 * P1[8 + c] - P1[0 + c]);
+            A[4 + c] = (double)(y1 * P1[8 + c] - P1[4 + c]);
+            A[8 + c] = (double)(x2 * P2[8 + c] - P2[0 + c]);
+            A[12 + c] = (double)(y2 * P2[8 + c] - P2[4 + c]);
+        }
+        double v[4];
+        smallest_right_singular_vector(A, v);
+        const float w = (float)v[3];
+        const float px = (float)v[0] / w, py = (float)v[1] / w, pz = (float)v[2] / w;
+        pos[3 * i] = px; pos[3 * i + 1] = py; pos[3 * i + 2] = pz;
+        if (pz >= lower && pz <= upper) {
+            const float q0 = px - Ocam[0], q1 = py - Ocam[1], q2 = pz - Ocam[2];
+            const double dot = (double)px * q0 + (double)py * q1 + (double)pz * q2;
+            const double n1 = std::sqrt((double)px * px + (double)py * py + (double)pz * pz);
+            const double n2 = std::sqrt((double)q0 * q0 + (double)q1 * q1 + (double)q2 * q2);
+            const float cosp = (float)(std::fabs(dot) / (n1 * n2));
+            if (cosp < minCos[min_degree - 1]) { good[i] = 1; ngood++; }
+        } else {
+            match_idx[i] = -1;
+        }
+    }
+    if (n_tracked_old) *n_tracked_old = nold;
+    return ngood;
+}
+
 }  // extern "C"

@@ -384,3 +384,24 @@ def match_projection(mp_pos, mp_desc, mp_octave, mp_skip, Tcw, K4, kps, desc, kf
                                     desc.ctypes.data, kf_observed.ctypes.data, n, win, level_offset, nnratio,
                                     out.ctypes.data)
     return out[:n].copy(), int(nm)
+
+
+def triangulate(kps_ref, kps_cur, match_idx, has_obs, P_ref, P_cur, Ocam, lower, upper, min_degree=2):
+    """Track::doTriangulate over all matches -> (pos (n,3) f32, good (n,) u8, match_idx updated, n_good, n_tracked_old)"""
+    kps_ref = np.ascontiguousarray(kps_ref); kps_cur = np.ascontiguousarray(kps_cur)
+    n = len(kps_ref)
+    m = np.ascontiguousarray(match_idx, np.int32).copy()
+    ho = None if has_obs is None else np.ascontiguousarray(has_obs, np.uint8)
+    P1 = np.ascontiguousarray(P_ref, np.float32).reshape(-1); P2 = np.ascontiguousarray(P_cur, np.float32).reshape(-1)
+    oc = np.ascontiguousarray(Ocam, np.float32)
+    pos = np.zeros((max(n, 1), 3), np.float32)
+    good = np.zeros(max(n, 1), np.uint8)
+    nold = C.c_int(0)
+    f = lib().match_ref_triangulate
+    f.restype = C.c_int
+    f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    ng = f(n, kps_ref.ctypes.data, kps_cur.ctypes.data, len(kps_cur), m.ctypes.data,
+           None if ho is None else ho.ctypes.data, P1.ctypes.data, P2.ctypes.data, oc.ctypes.data, lower, upper,
+           min_degree, pos.ctypes.data, good.ctypes.data, C.byref(nold))
+    return pos[:n], good[:n], m, int(ng), int(nold.value)

@@ -27,6 +27,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno
 PER_FILE = {
     "orb.hip": ["-ffp-contract=off"],
     "match.hip": ["-ffp-contract=off"],
+    "triangulate.hip": ["-ffp-contract=off"],
 }
 
 

@@ -111,3 +111,23 @@ class ORBmatcher:
                 self._h = None
         except Exception:
             pass
+
+
+def doTriangulate(kps_ref, kps_cur, match_idx, has_observation, P_ref, P_cur, Ocam, lower_depth, upper_depth,
+                  min_degree=2):
+    """Track::doTriangulate (Track.cpp:378-419) for all matches of a frame pair on the device.
+    -> (pos (n,3) float32, good_parallax (n,) uint8, match_idx updated (n,) int32, n_good, n_tracked_old)"""
+    kps_ref = np.ascontiguousarray(kps_ref); kps_cur = np.ascontiguousarray(kps_cur)
+    n = len(kps_ref)
+    m = np.ascontiguousarray(match_idx, np.int32).copy()
+    ho = None if has_observation is None else np.ascontiguousarray(has_observation, np.uint8)
+    P1 = np.ascontiguousarray(P_ref, np.float32).reshape(-1); P2 = np.ascontiguousarray(P_cur, np.float32).reshape(-1)
+    oc = np.ascontiguousarray(Ocam, np.float32)
+    pos = np.zeros((max(n, 1), 3), np.float32)
+    good = np.zeros(max(n, 1), np.uint8)
+    ng, nold = C.c_int(0), C.c_int(0)
+    capi.check(capi.lib().se2gpu_triangulate(n, kps_ref.ctypes.data, kps_cur.ctypes.data, len(kps_cur), m.ctypes.data,
+                                             None if ho is None else ho.ctypes.data, P1.ctypes.data, P2.ctypes.data,
+                                             oc.ctypes.data, float(lower_depth), float(upper_depth), int(min_degree),
+                                             pos.ctypes.data, good.ctypes.data, C.byref(ng), C.byref(nold)))
+    return pos[:n], good[:n], m, int(ng.value), int(nold.value)

@@ -8,6 +8,7 @@
 #include "se2lam_amd/ORBmatcher.h"
 #include "se2lam_amd/optimizer.h"
 #include "se2lam_amd/preintegration.h"
+#include "se2lam_amd/Track.h"
 
 using namespace se2lam_amd;
 
