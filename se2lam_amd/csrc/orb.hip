@@ -224,12 +224,11 @@ __device__ __forceinline__ short2v score_pair(const uint32_t (&E)[7][9]) {
     p[12] = SE2_WP(3, C - 3); p[13] = SE2_WP(4, C - 3); p[14] = SE2_WP(5, C - 2); p[15] = SE2_WP(6, C - 1);
     return fast_score_pk(p, SE2_WP(3, C));
 }
-template <int PH>
-__device__ __forceinline__ uint32_t score_row4(const uint32_t (&E)[7][9]) {
-    // scores are 0..255 in int16 lanes: pack the low bytes of the four lanes into one dword
-    const uint32_t a = __builtin_bit_cast(uint32_t, score_pair<PH, 4>(E));
-    const uint32_t b = __builtin_bit_cast(uint32_t, score_pair<PH, 6>(E));
-    return __builtin_amdgcn_perm(b, a, 0x06040200u);
+// c > 7 ? c : 0 and, generally, "keep a where a > b" on packed int16 lanes: (b - a) >> 15 (arithmetic) is all ones
+// exactly where a > b
+__device__ __forceinline__ short2v keep_greater(short2v a, short2v b) {
+    const short2v m = (b - a) >> 15;
+    return a & m;
 }
 #undef SE2_WP
 
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     }
     const int yend = min(y0 + kScoreRows, H - kEdge);
     const int nvalid = xin ? min(4, W - kEdge - x0) : 0;
-    const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
     // cell-edge flags of the 4 pixels (horizontal): bit q of eL / eR
     const int cellW = g.cellW[l], cellH = g.cellH[l];
     unsigned eL = 0, eR = 0;
@@ -274,48 +272,55 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         if (xr >= 0 && xr % cellW == 0) eL |= 1u << q;
         if (xr >= 0 && (xr % cellW == cellW - 1 || x0 + q == W - kEdge - 1)) eR |= 1u << q;
     }
-    unsigned long long e_pp = 0, e_p = 0;   // extended score rows y-2, y-1 (relative to the row being computed)
+    // Non-max suppression state, all in packed int16 pairs A = pixels {0,1}, B = pixels {2,3} of this thread:
+    //   c   scores with S <= 7 already zeroed (a score <= 7 can neither win nor beat a winner, so this changes nothing)
+    //   Hc  max over the left / right neighbour that lies in the same cell        (centre-row contribution)
+    //   H3  max(Hc, c)                                                            (contribution of the row above / below)
+    // mLA.. are the per-thread cell-edge masks (all ones where that neighbour is inside the cell), vA / vB the valid-
+    // pixel masks of the last column group.
+    auto pairmask = [](bool lo, bool hi) { return (uint32_t)(lo ? 0xffffu : 0u) | (hi ? 0xffff0000u : 0u); };
+    const uint32_t mLA = pairmask(!(eL & 1), !(eL & 2)), mLB = pairmask(!(eL & 4), !(eL & 8));
+    const uint32_t mRA = pairmask(!(eR & 1), !(eR & 2)), mRB = pairmask(!(eR & 4), !(eR & 8));
+    const uint32_t vA = pairmask(nvalid > 0, nvalid > 1), vB = pairmask(nvalid > 2, nvalid > 3);
+    const short2v seven = {7, 7};
+    uint32_t H3ppA = 0, H3ppB = 0, H3pA = 0, H3pB = 0, HcpA = 0, HcpB = 0, cpA = 0, cpB = 0;
     auto step = [&](auto phc, int y) {
         constexpr int PH = decltype(phc)::value;
         {   // row y+3 enters the window (slot of window row 6)
             const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)min(y + 3, ymax) * stride + xc - 4);
             expand_row(p[0], p[1], p[2], E[(PH + 6) % 7]);
         }
-        uint32_t sw4 = 0;
-        if (y >= kEdge && y < H - kEdge) sw4 = score_row4<PH>(E) & vmask;   // rows outside the scan area score 0
-        const uint32_t left = __shfl_up(sw4, 1), right = __shfl_down(sw4, 1);
-        const unsigned long long e_c = ext_row(sw4, lane == 0 ? 0u : left, lane == 63 ? 0u : right);
+        uint32_t cA = 0, cB = 0;
+        if (y >= kEdge && y < H - kEdge) {   // rows outside the scan area score 0
+            cA = __builtin_bit_cast(uint32_t, keep_greater(score_pair<PH, 4>(E), seven)) & vA;
+            cB = __builtin_bit_cast(uint32_t, keep_greater(score_pair<PH, 6>(E), seven)) & vB;
+        }
+        const uint32_t lB = __shfl_up(cB, 1), rA = __shfl_down(cA, 1);
+        const uint32_t LA = (cA << 16) | (lane == 0 ? 0u : lB >> 16);        // {s-1, s0}
+        const uint32_t MID = (cA >> 16) | (cB << 16);                         // {s1, s2}
+        const uint32_t RB = (cB >> 16) | (lane == 63 ? 0u : rA << 16);        // {s3, s4}
+        const short2v hcA = __builtin_elementwise_max(__builtin_bit_cast(short2v, LA & mLA), __builtin_bit_cast(short2v, MID & mRA));
+        const short2v hcB = __builtin_elementwise_max(__builtin_bit_cast(short2v, MID & mLB), __builtin_bit_cast(short2v, RB & mRB));
+        const uint32_t HcA = __builtin_bit_cast(uint32_t, hcA), HcB = __builtin_bit_cast(uint32_t, hcB);
+        const uint32_t H3A = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hcA, __builtin_bit_cast(short2v, cA)));
+        const uint32_t H3B = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hcB, __builtin_bit_cast(short2v, cB)));
         const int yo = y - 1;  // row whose suppression can now be decided
         if (yo >= y0 && yo < yend && lane >= 1 && lane <= kScoreGroups && nvalid > 0) {
-            uint32_t out = 0;
-            if (((uint32_t)(e_p >> 8) & 0xf8f8f8f8u) != 0) {   // some S > 7 in this dword (rare at fine levels)
             const int yr = yo - kEdge;
-            const bool eT = yr % cellH == 0, eB = (yr % cellH == cellH - 1) || yo == H - kEdge - 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int sc = (int)((e_p >> (8 * (q + 1))) & 0xff);
-                if (sc <= 7) continue;
-                const bool L = !((eL >> q) & 1), R = !((eR >> q) & 1);
-                int m = 0;  // max over the neighbours inside the cell
-                if (L) m = max(m, (int)((e_p >> (8 * q)) & 0xff));
-                if (R) m = max(m, (int)((e_p >> (8 * (q + 2))) & 0xff));
-                if (!eT) {
-                    m = max(m, (int)((e_pp >> (8 * (q + 1))) & 0xff));
-                    if (L) m = max(m, (int)((e_pp >> (8 * q)) & 0xff));
-                    if (R) m = max(m, (int)((e_pp >> (8 * (q + 2))) & 0xff));
-                }
-                if (!eB) {
-                    m = max(m, (int)((e_c >> (8 * (q + 1))) & 0xff));
-                    if (L) m = max(m, (int)((e_c >> (8 * q)) & 0xff));
-                    if (R) m = max(m, (int)((e_c >> (8 * (q + 2))) & 0xff));
-                }
-                if (sc > m) out |= (uint32_t)sc << (8 * q);
-            }
-            }
-            *(uint32_t*)(sbase + (size_t)yo * stride + x0) = out & vmask;
+            const uint32_t tT = (yr % cellH == 0) ? 0u : 0xffffffffu;                                      // row above in the cell?
+            const uint32_t tB = ((yr % cellH == cellH - 1) || yo == H - kEdge - 1) ? 0u : 0xffffffffu;    // row below?
+            const short2v mA = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(short2v, HcpA),
+                                                                                     __builtin_bit_cast(short2v, H3ppA & tT)),
+                                                         __builtin_bit_cast(short2v, H3A & tB));
+            const short2v mB = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(short2v, HcpB),
+                                                                                     __builtin_bit_cast(short2v, H3ppB & tT)),
+                                                         __builtin_bit_cast(short2v, H3B & tB));
+            const uint32_t oA = __builtin_bit_cast(uint32_t, keep_greater(__builtin_bit_cast(short2v, cpA), mA));
+            const uint32_t oB = __builtin_bit_cast(uint32_t, keep_greater(__builtin_bit_cast(short2v, cpB), mB));
+            *(uint32_t*)(sbase + (size_t)yo * stride + x0) = __builtin_amdgcn_perm(oB, oA, 0x06040200u);
         }
-        e_pp = e_p;
-        e_p = e_c;
+        H3ppA = H3pA; H3ppB = H3pB;
+        H3pA = H3A; H3pB = H3B; HcpA = HcA; HcpB = HcB; cpA = cA; cpB = cB;
     };
     for (int y = y0 - 1; y <= yend; y += 7) {   // rows past yend only feed guarded code
         step(std::integral_constant<int, 0>{}, y);
