@@ -388,18 +388,34 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
         // scan aligned dwords (4 score bytes); S <= 7 everywhere in a dword is the common case and exits at once
         const int xs = xa & ~3;
         const int cw4 = (xb - xs + 3) >> 2;
-        for (int idx = threadIdx.x; idx < cw4 * ch; idx += 256) {
-            const int x4 = xs + 4 * (idx % cw4), y = ya + idx / cw4;
-            const uint32_t word = *(const uint32_t*)(base + (size_t)y * stride + x4);
-            if (word == 0) continue;   // k_fast_score already applied S > 7 and the in-cell non-max suppression
+        // four dwords per thread and round are in flight before any is examined (the appends below are rare, but their
+        // control flow would otherwise serialise one global-load latency per dword)
+        const int ndw = cw4 * ch;
+        for (int base4 = threadIdx.x; base4 < ndw; base4 += 4 * 256) {
+            uint32_t wv[4];
+            int xv[4], yv[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int s = (int)((word >> (8 * q)) & 0xffu);
-                const int x = x4 + q;
-                if (s == 0 || x < xa || x >= xb) continue;
-                const int slot = atomicAdd(&s_n, 1);
-                if (s > g.fast_th) atomicAdd(&s_n20, 1);
-                if (slot < kSortCap) keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base4 + u * 256;
+                const int ic = min(idx, ndw - 1);
+                xv[u] = xs + 4 * (ic % cw4);
+                yv[u] = ya + ic / cw4;
+                const uint32_t wd = *(const uint32_t*)(base + (size_t)yv[u] * stride + xv[u]);
+                wv[u] = idx < ndw ? wd : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t word = wv[u];
+                if (word == 0) continue;   // k_fast_score already applied S > 7 and the in-cell non-max suppression
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s = (int)((word >> (8 * q)) & 0xffu);
+                    const int x = xv[u] + q, y = yv[u];
+                    if (s == 0 || x < xa || x >= xb) continue;
+                    const int slot = atomicAdd(&s_n, 1);
+                    if (s > g.fast_th) atomicAdd(&s_n20, 1);
+                    if (slot < kSortCap) keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+                }
             }
         }
     }
