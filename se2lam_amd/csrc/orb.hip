@@ -71,25 +71,40 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) { return p < 0 
 // ---------------------------------------------------------------------------------------------
 // pyramid
 // ---------------------------------------------------------------------------------------------
-// level 0: copyMakeBorder(image, 16 px, BORDER_REFLECT_101); 4 output bytes per thread
+// level 0: copyMakeBorder(image, 16 px, BORDER_REFLECT_101)
+// One thread = one 16-byte chunk of a bordered row; threads are laid out flat over (row, chunk).
 __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restrict__ imgs, int pitch,
                                                  uint8_t* __restrict__ pyr) {
-    const int f = blockIdx.z;
-    const int Y = blockIdx.y;                                  // row of the bordered buffer
-    const int X4 = (blockIdx.x * 256 + threadIdx.x) * 4;       // first of 4 columns of the bordered buffer
+    const int f = blockIdx.y;
     const int W = g.w[0], H = g.h[0], stride = g.stride[0];
-    if (X4 >= stride) return;
+    const int nch = stride / 16;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int Y = item / nch;                                   // row of the bordered buffer
+    if (Y >= H + 2 * kEdge) return;
+    const int X0 = (item - Y * nch) * 16;                       // first of 16 columns of the bordered buffer
     const int sy = reflect101(Y - kEdge, H);
     const uint8_t* src = imgs + (size_t)f * pitch * H + (size_t)sy * pitch;
-    uint32_t v = 0;
+    const uint8_t* p16 = src + (X0 - kEdge);
+    uint4 v;
+    if (X0 >= kEdge && X0 + 15 < W + kEdge && ((uintptr_t)p16 & 15) == 0) {
+        v = *reinterpret_cast<const uint4*>(p16);               // interior chunk: one aligned 128-bit load
+    } else {
+        uint32_t wv[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int X = X4 + q;
-        uint32_t b = 0;
-        if (X < W + 2 * kEdge) b = src[reflect101(X - kEdge, W)];
-        v |= b << (8 * q);
+        for (int k = 0; k < 4; ++k) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int X = X0 + 4 * k + q;
+                uint32_t b = 0;
+                if (X < W + 2 * kEdge) b = src[reflect101(X - kEdge, W)];
+                acc |= b << (8 * q);
+            }
+            wv[k] = acc;
+        }
+        v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
     }
-    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[0] + (size_t)Y * stride + X4) = v;
+    *reinterpret_cast<uint4*>(pyr + (size_t)f * g.frame_bytes + g.off[0] + (size_t)Y * stride + X0) = v;
 }
 
 // level l >= 1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border, 4 output bytes per thread.
@@ -990,7 +1005,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     SE2_CHECK(h->kp_list.reserve((size_t)h->max_batch * cap));
     SE2_CHECK(h->angles.reserve((size_t)h->max_batch * cap));
     {
-        dim3 grid((g.stride[0] / 4 + 255) / 256, g.h[0] + 2 * kEdge, nframes);
+        dim3 grid(((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256, nframes);
         SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
     }
     for (int l = 1; l < L; ++l) {
