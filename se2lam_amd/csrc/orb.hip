@@ -136,16 +136,24 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
     const int av[4] = {xa.x, xa.y, xa.z, xa.w};
     uint32_t v = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int sx = sxv[q] & 0xffff;
-        const uint32_t p0 = *reinterpret_cast<const uint16_t*>(S0 + sx);   // S0[sx] | S0[sx + 1] << 8
-        const uint32_t p1 = *reinterpret_cast<const uint16_t*>(S1 + sx);
-        const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
-        const int r0 = (int)(p0 & 0xffu) * a0 + (int)(p0 >> 8) * a1;
-        const int r1 = (int)(p1 & 0xffu) * a0 + (int)(p1 >> 8) * a1;
-        uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
-        v |= b << (8 * q);
+    for (int q2 = 0; q2 < 4; q2 += 2) {
+        // two neighbouring output pixels: their source columns differ by at most 2 (scale 1.2, also across the
+        // reflection), so the four taps of a source row lie in ONE (unaligned) 32-bit word starting at the smaller one
+        const int sxa = sxv[q2] & 0xffff, sxb = sxv[q2 + 1] & 0xffff;
+        const int sb = min(sxa, sxb);
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(S0 + sb);
+        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(S1 + sb);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = q2 + u;
+            const int o8 = 8 * ((u ? sxb : sxa) - sb);
+            const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
+            const int r0 = (int)((w0 >> o8) & 0xffu) * a0 + (int)((w0 >> (o8 + 8)) & 0xffu) * a1;
+            const int r1 = (int)((w1 >> o8) & 0xffu) * a0 + (int)((w1 >> (o8 + 8)) & 0xffu) * a1;
+            uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+            if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
+            v |= b << (8 * q);
+        }
     }
     *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 4 * xg) = v;
 }
