@@ -77,7 +77,8 @@ int se2gpu_orb_sync(se2gpu_orb* h);
 int se2gpu_orb_set_stream(se2gpu_orb* h, void* hip_stream);  /* NULL -> the handle's own stream */
 
 /* Introspection for the parity tests: copies pyramid level `level` of frame `frame` of the last call
- * (un-blurred if blurred==0) into `out` (rows*cols of that level, tight pitch); rows and cols are set. */
+ * (un-blurred if bit 0 of `blurred` is clear) into `out` (rows*cols of that level, tight pitch); rows and cols are set.
+ * Bit 1 of `blurred` includes the 16 px reflect-101 frame: (rows + 32) x (cols + 32). */
 int se2gpu_orb_debug_level(se2gpu_orb* h, int frame, int level, int blurred, uint8_t* out, size_t out_cap,
                            int* rows, int* cols);
 /* FAST score map S of a level of the last call, same geometry as the level. */

@@ -260,13 +260,13 @@ def orb_geometry(rows, cols, params=None):
     return out
 
 
-def orb_level(img, level, blurred=False, params=None):
+def orb_level(img, level, blurred=False, params=None, bordered=False):
     params = params or orb_params()
     img = np.ascontiguousarray(img, np.uint8)
-    out = np.zeros(img.size, np.uint8)
+    out = np.zeros((img.shape[0] + 32) * (img.shape[1] + 32), np.uint8)
     w = C.c_int(); h = C.c_int()
     lib().orb_ref_level(C.byref(params), img.ctypes.data, img.shape[0], img.shape[1], img.shape[1], level,
-                        int(blurred), out.ctypes.data, C.byref(w), C.byref(h))
+                        int(blurred) | (2 if bordered else 0), out.ctypes.data, C.byref(w), C.byref(h))
     return out[:w.value * h.value].reshape(h.value, w.value).copy()
 
 

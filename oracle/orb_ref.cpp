@@ -587,9 +587,17 @@ int orb_ref_level(const orb_ref_params* p, const uint8_t* img, int rows, int col
     Extractor ex(*p);
     ex.compute_pyramid(img, rows, cols, step);
     Level& L = ex.pyr[level];
-    if (blurred) ex.blur_level(level);
+    if (blurred & 1) ex.blur_level(level);
+    const bool bl = blurred & 1;
+    if (blurred & 2) {   // with the 16 px frame: (h + 32) x (w + 32)
+        const int e = EDGE_THRESHOLD;
+        *w = L.w + 2 * e; *h = L.h + 2 * e;
+        for (int y = -e; y < L.h + e; ++y)
+            std::memcpy(out + (size_t)(y + e) * (L.w + 2 * e), bl ? L.bat(y, -e) : L.at(y, -e), L.w + 2 * e);
+        return 0;
+    }
     *w = L.w; *h = L.h;
-    for (int y = 0; y < L.h; ++y) std::memcpy(out + (size_t)y * L.w, blurred ? L.bat(y, 0) : L.at(y, 0), L.w);
+    for (int y = 0; y < L.h; ++y) std::memcpy(out + (size_t)y * L.w, bl ? L.bat(y, 0) : L.at(y, 0), L.w);
     return 0;
 }
 

@@ -135,25 +135,23 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
     const int sxv[4] = {xs.x, xs.y, xs.z, xs.w};
     const int av[4] = {xa.x, xa.y, xa.z, xa.w};
     uint32_t v = 0;
+    // The source columns of the four output pixels span at most 4 (scale 1.2, also across the reflection), so all
+    // eight taps of a source row lie in ONE (unaligned) 64-bit word starting at the smallest column.
+    const int sx0 = sxv[0] & 0xffff, sx1 = sxv[1] & 0xffff, sx2 = sxv[2] & 0xffff, sx3 = sxv[3] & 0xffff;
+    const int sb = min(min(sx0, sx1), min(sx2, sx3));
+    const unsigned long long w0 = *reinterpret_cast<const unsigned long long*>(S0 + sb);
+    const unsigned long long w1 = *reinterpret_cast<const unsigned long long*>(S1 + sb);
+    const int sxq[4] = {sx0, sx1, sx2, sx3};
 #pragma unroll
-    for (int q2 = 0; q2 < 4; q2 += 2) {
-        // two neighbouring output pixels: their source columns differ by at most 2 (scale 1.2, also across the
-        // reflection), so the four taps of a source row lie in ONE (unaligned) 32-bit word starting at the smaller one
-        const int sxa = sxv[q2] & 0xffff, sxb = sxv[q2 + 1] & 0xffff;
-        const int sb = min(sxa, sxb);
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(S0 + sb);
-        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(S1 + sb);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = q2 + u;
-            const int o8 = 8 * ((u ? sxb : sxa) - sb);
-            const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
-            const int r0 = (int)((w0 >> o8) & 0xffu) * a0 + (int)((w0 >> (o8 + 8)) & 0xffu) * a1;
-            const int r1 = (int)((w1 >> o8) & 0xffu) * a0 + (int)((w1 >> (o8 + 8)) & 0xffu) * a1;
-            uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-            if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
-            v |= b << (8 * q);
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int o8 = 8 * (sxq[q] - sb);
+        const uint32_t t0 = (uint32_t)(w0 >> o8), t1 = (uint32_t)(w1 >> o8);   // tap pair in the low 16 bits
+        const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
+        const int r0 = (int)(t0 & 0xffu) * a0 + (int)((t0 >> 8) & 0xffu) * a1;
+        const int r1 = (int)(t1 & 0xffu) * a0 + (int)((t1 >> 8) & 0xffu) * a1;
+        uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+        if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
+        v |= b << (8 * q);
     }
     *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 4 * xg) = v;
 }
@@ -958,8 +956,10 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         // x table over the bordered destination row (stride[l] columns, groups of 4)
         const int ng = g.stride[l] / 4;
         std::vector<int4> xt(2 * (size_t)ng, make_int4(0, 0, 0, 0));
+        int last_sx = 0;   // padding columns repeat the last valid source column (bit 31 clear = "write 0"), so that
+                           // the smallest column of a group of four is always one of its real taps
         for (int X = 0; X < g.stride[l]; ++X) {
-            int w0 = 0, w1 = 0;
+            int w0 = last_sx, w1 = 0;
             if (X < dw + 2 * kEdge) {
                 const int dx = reflect101(X - kEdge, dw);
                 float fx = (float)((dx + 0.5) * scale_x - 0.5);
@@ -976,6 +976,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
                 }
                 w0 = sx | (int)0x80000000u;
                 w1 = a0 | (a1 << 16);
+                last_sx = sx;
             }
             int* e0 = &xt[2 * (size_t)(X / 4)].x;
             int* e1 = &xt[2 * (size_t)(X / 4) + 1].x;
@@ -1212,13 +1213,16 @@ int se2gpu_orb_debug_level(se2gpu_orb* h, int frame, int level, int blurred, uin
     SE2_REQUIRE(frame >= 0 && frame < h->last_batch && level >= 0 && level < h->g.nlevels, SE2GPU_ERR_INVALID,
                 "debug_level: frame/level out of range");
     const Geom& g = h->g;
-    SE2_REQUIRE(out_cap >= (size_t)g.w[level] * g.h[level], SE2GPU_ERR_CAPACITY, "debug_level: buffer too small");
+    const int e = (blurred & 2) ? kEdge : 0;   // bit 1: include the 16 px frame
+    const int ow = g.w[level] + 2 * e, oh = g.h[level] + 2 * e;
+    SE2_REQUIRE(out_cap >= (size_t)ow * oh, SE2GPU_ERR_CAPACITY, "debug_level: buffer too small");
     SE2_HIP(hipStreamSynchronize(h->stream));
-    const uint8_t* src = (blurred ? h->blur.p : h->pyr.p) + (size_t)frame * g.frame_bytes + g.off[level] +
-                         (size_t)kEdge * g.stride[level] + kEdge;
-    SE2_HIP(hipMemcpy2D(out, g.w[level], src, g.stride[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
-    *rows = g.h[level];
-    *cols = g.w[level];
+    SE2_HIP(hipStreamSynchronize(h->side_stream));
+    const uint8_t* src = ((blurred & 1) ? h->blur.p : h->pyr.p) + (size_t)frame * g.frame_bytes + g.off[level] +
+                         (size_t)(kEdge - e) * g.stride[level] + (kEdge - e);
+    SE2_HIP(hipMemcpy2D(out, ow, src, g.stride[level], ow, oh, hipMemcpyDeviceToHost));
+    *rows = oh;
+    *cols = ow;
     return SE2GPU_OK;
 }
 

@@ -73,10 +73,11 @@ class ORBextractor:
         desc = d_desc.to_numpy(np.uint8, (B, cap, 32))
         return [(kps[b, :cnt[b]].copy(), desc[b, :cnt[b]].copy()) for b in range(B)]
 
-    def debug_level(self, frame, level, blurred=False):
+    def debug_level(self, frame, level, blurred=False, bordered=False):
         out = np.zeros(4096 * 4096 // 4, np.uint8)
         r = C.c_int(); c = C.c_int()
-        capi.check(capi.lib().se2gpu_orb_debug_level(self._h, frame, level, int(blurred), out.ctypes.data, out.size,
+        capi.check(capi.lib().se2gpu_orb_debug_level(self._h, frame, level, int(blurred) | (2 if bordered else 0),
+                                                     out.ctypes.data, out.size,
                                                      C.byref(r), C.byref(c)))
         return out[:r.value * c.value].reshape(r.value, c.value).copy()
 

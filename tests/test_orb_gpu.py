@@ -18,6 +18,10 @@ def test_pyramid_score_blur_bit_exact(ex, oracle, synth):
     for lv in range(8):
         assert np.array_equal(ex.debug_level(0, lv), oracle.orb_level(img, lv)), f"level {lv}"
         assert np.array_equal(ex.debug_level(0, lv, blurred=True), oracle.orb_level(img, lv, blurred=True)), f"blur {lv}"
+        # ... and with the 16 px reflect-101 frame (the blurred pyramid keeps the un-blurred frame)
+        assert np.array_equal(ex.debug_level(0, lv, bordered=True), oracle.orb_level(img, lv, bordered=True)), f"frame {lv}"
+        assert np.array_equal(ex.debug_level(0, lv, blurred=True, bordered=True),
+                              oracle.orb_level(img, lv, blurred=True, bordered=True)), f"blur frame {lv}"
         # the device score plane holds S' = S where S > 7 and S is a strict maximum among the 8-neighbours of the
         # SAME cell (cv::FAST's in-call non-max suppression), else 0
         s_gpu, s_ref = ex.debug_score(0, lv), oracle.orb_score(img, lv).astype(np.int32)
