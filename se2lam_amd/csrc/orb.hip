@@ -790,9 +790,23 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
 // ---------------------------------------------------------------------------------------------
 // descriptors + final key points.  One wave per keypoint; lane l evaluates bits l, l+64, l+128, l+192.
 // ---------------------------------------------------------------------------------------------
+// cos / sin of the key-point angle, in double and rounded once to float as computeOrbDescriptor does
+// (ORBextractor.cpp:166-167).  One THREAD per key point: inside k_describe (one wave per key point) the double-precision
+// sin and cos would be executed once per wave, i.e. 64 times more often.
+__global__ __launch_bounds__(256) void k_angle_trig(const int* __restrict__ counts, int cap,
+                                                     const float* __restrict__ angles, float2* __restrict__ cs) {
+    const int f = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(counts[f], cap)) return;
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    const float angle = angles[(size_t)f * cap + k] * factorPI;
+    cs[(size_t)f * cap + k] = make_float2((float)cos((double)angle), (float)sin((double)angle));
+}
+
 __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restrict__ blur,
                                                    const int4* __restrict__ kp_list, const int* __restrict__ counts,
                                                    int cap, const float* __restrict__ angles,
+                                                   const float2* __restrict__ cs,
                                                    se2gpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
     const int f = blockIdx.y;
     const int k = blockIdx.x * 4 + threadIdx.x / 64;
@@ -800,16 +814,16 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
     if (k >= counts[f]) return;  // wave-uniform
     const int4 kp = kp_list[(size_t)f * cap + k];
     const float ang = angles[(size_t)f * cap + k];
-    const float factorPI = (float)(3.14159265358979323846 / 180.f);
-    const float angle = ang * factorPI;
-    const float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const float2 ab = cs[(size_t)f * cap + k];
+    const float a = ab.x, b = ab.y;
     const int stride = g.stride[kp.x];
     const uint8_t* center = blur + pix(g, f, kp.x, kp.z, kp.y);
     unsigned long long words[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const signed char* pt = c_pattern + 4 * (64 * q + lane);
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int pw = reinterpret_cast<const int*>(c_pattern)[64 * q + lane];   // the 4 pattern bytes in one load
+        const float x0 = (float)(signed char)(pw & 0xff), y0 = (float)(signed char)((pw >> 8) & 0xff);
+        const float x1 = (float)(signed char)((pw >> 16) & 0xff), y1 = (float)(signed char)((pw >> 24) & 0xff);
         const int r0 = (int)rintf(x0 * b + y0 * a), c0 = (int)rintf(x0 * a - y0 * b);
         const int r1 = (int)rintf(x1 * b + y1 * a), c1 = (int)rintf(x1 * a - y1 * b);
         const int t0 = center[r0 * stride + c0], t1 = center[r1 * stride + c1];
@@ -865,6 +879,7 @@ struct se2gpu_orb {
     DevBuf<int> cell_total, counts, overflow;
     DevBuf<int4> kp_list, tabs;
     DevBuf<float> angles, cell_resp;
+    DevBuf<float2> angle_cs;
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
@@ -1013,6 +1028,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     const int L = g.nlevels;
     SE2_CHECK(h->kp_list.reserve((size_t)h->max_batch * cap));
     SE2_CHECK(h->angles.reserve((size_t)h->max_batch * cap));
+    SE2_CHECK(h->angle_cs.reserve((size_t)h->max_batch * cap));
     {
         dim3 grid(((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256, nframes);
         SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
@@ -1057,9 +1073,11 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
                h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p);
+    SE2_LAUNCH(h->prof, st, "k_angle_trig", k_angle_trig, dim3((cap + 255) / 256, nframes), dim3(256), 0, d_counts, cap,
+               h->angles.p, h->angle_cs.p);
     if (sb != st) SE2_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
     SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->blur.p,
-               h->kp_list.p, d_counts, cap, h->angles.p, d_kps, d_desc);
+               h->kp_list.p, d_counts, cap, h->angles.p, h->angle_cs.p, d_kps, d_desc);
     SE2_HIP(hipGetLastError());
     h->last_batch = nframes;
     return SE2GPU_OK;
