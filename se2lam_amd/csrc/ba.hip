@@ -1792,6 +1792,32 @@ int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count) {
 }
 
 // chi2 / scale of a (trial) step; xp == nullptr evaluates the current state.  Result in h->h_scal[0..1].
+// host side of the mailbox: poll the mapped, coherent buffer until the device has written sequence number `seq`
+int ba_wait_mail(se2gpu_ba* h, double seq) {
+    volatile double* mb = h->h_mail;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (mb[3] != seq) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            SE2_HIP(hipStreamSynchronize(h->stream));  // surfaces a device fault, if that is what happened
+            SE2_REQUIRE(mb[3] == seq, SE2GPU_ERR_HIP, "the host mailbox was not written");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    h->h_scal.p[0] = mb[0]; h->h_scal.p[1] = mb[1]; h->h_scal.p[2] = mb[2];
+    return SE2GPU_OK;
+}
+
+// multi-GPU: the all-reduced scalars go to the host mailbox too (instead of a stream synchronise + D2H copy per trial)
+__global__ void k_post_mail(const double* __restrict__ scal, volatile double* __restrict__ mail, double seq) {
+    mail[0] = scal[0];
+    mail[1] = scal[1];
+    mail[2] = scal[2];
+    __threadfence_system();
+    mail[3] = seq;
+}
+
 int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
     hipStream_t st = h->stream;
     const int n = 3 * h->P;
@@ -1806,23 +1832,15 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                h->o_info.p, h->root, scal, use_mail ? h->d_mail : nullptr, seq);
     SE2_HIP(hipGetLastError());
-    if (use_mail) {
-        volatile double* mb = h->h_mail;
-        const auto t0 = std::chrono::steady_clock::now();
-        long spins = 0;
-        while (mb[3] != seq) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                SE2_HIP(hipStreamSynchronize(st));  // surfaces a device fault, if that is what happened
-                SE2_REQUIRE(mb[3] == seq, SE2GPU_ERR_HIP, "k_finalize mailbox was not written");
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        h->h_scal.p[0] = mb[0]; h->h_scal.p[1] = mb[1]; h->h_scal.p[2] = mb[2];
-        return SE2GPU_OK;
-    }
+    if (use_mail) return ba_wait_mail(h, seq);
     if (!xp) SE2_HIP(hipMemsetAsync(scal + 2, 0, sizeof(double), st));
     SE2_CHECK(ba_allreduce(h, scal, 4));
+    if (h->d_mail) {
+        hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(1), 0, st, scal, h->d_mail, seq);
+        SE2_HIP(hipGetLastError());
+        SE2_CHECK(ba_wait_mail(h, seq));
+        return SE2GPU_OK;
+    }
     SE2_HIP(hipMemcpyAsync(h->h_scal.p, scal, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipStreamSynchronize(st));
     return SE2GPU_OK;
