@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
 // 7x7 Gaussian, sigma 2, 8-bit fixed point: taps {18,34,49,55,49,34,18} per pass, (v + 2^15) >> 16, saturate.
 // Tile = 64 x 16 outputs per workgroup; reads the un-blurred pyramid (whose frame holds reflect-101 copies).
 // ---------------------------------------------------------------------------------------------
-constexpr int kBlurRows = 32;
+constexpr int kBlurRows = 35;
 // One thread = 4 adjacent output pixels of a vertical strip of kBlurRows rows; the horizontal 7-tap sums of the last
 // 7 rows stay in registers (sliding window), inputs come in as three aligned dwords per row.  No LDS.
 // The blurred pyramid keeps the UN-blurred 16 px reflect frame of every level (the descriptor pattern of a key point
@@ -745,35 +745,45 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
     if (x0 >= W || y0 >= H) return;
     const uint8_t* src = pyr + pix(g, f, l, 0, 0);
     uint8_t* dst = blur + pix(g, f, l, 0, 0);
-    auto hrow = [&](int y, int h[4]) {
+    // Horizontal 7-tap sums of a row in packed u16 pairs (they fit: 255 * 257 = 65535): the byte pairs {b, b+1} of the
+    // 12-byte window come from v_perm_b32, the taps are v_pk_add_u16 / v_pk_mad_u16 on two output pixels at once.
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    auto hrow = [&](int y, int (&h)[4]) {
         const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)y * stride + x0 - 4);
         const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
-        int b[12];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            b[i] = (w0 >> (8 * i)) & 0xff;
-            b[4 + i] = (w1 >> (8 * i)) & 0xff;
-            b[8 + i] = (w2 >> (8 * i)) & 0xff;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)  // output pixel x0+q: bytes b[1+q .. 7+q] = x0+q-3 .. x0+q+3
-            h[q] = 18 * (b[1 + q] + b[7 + q]) + 34 * (b[2 + q] + b[6 + q]) + 49 * (b[3 + q] + b[5 + q]) + 55 * b[4 + q];
+        uint32_t e[9];   // pairs {b, b+1}, b = 1 .. 9
+        e[0] = __builtin_amdgcn_perm(w1, w0, 0x0c020c01u);
+        e[1] = __builtin_amdgcn_perm(w1, w0, 0x0c030c02u);
+        e[2] = __builtin_amdgcn_perm(w1, w0, 0x0c040c03u);
+        e[3] = __builtin_amdgcn_perm(w2, w1, 0x0c010c00u);
+        e[4] = __builtin_amdgcn_perm(w2, w1, 0x0c020c01u);
+        e[5] = __builtin_amdgcn_perm(w2, w1, 0x0c030c02u);
+        e[6] = __builtin_amdgcn_perm(w2, w1, 0x0c040c03u);
+        e[7] = __builtin_amdgcn_perm(w2, w2, 0x0c010c00u);
+        e[8] = __builtin_amdgcn_perm(w2, w2, 0x0c020c01u);
+        auto P = [&](int b) { return __builtin_bit_cast(ushort2v, e[b - 1]); };
+        const ushort2v k18 = {18, 18}, k34 = {34, 34}, k49 = {49, 49}, k55 = {55, 55};
+        // output pixels {0,1}: bytes 1..7 / 2..8 ; {2,3}: bytes 3..9 / 4..10
+        const ushort2v hA = (P(1) + P(7)) * k18 + (P(2) + P(6)) * k34 + (P(3) + P(5)) * k49 + P(4) * k55;
+        const ushort2v hB = (P(3) + P(9)) * k18 + (P(4) + P(8)) * k34 + (P(5) + P(7)) * k49 + P(6) * k55;
+        h[0] = hA[0]; h[1] = hA[1]; h[2] = hB[0]; h[3] = hB[1];
     };
+    // The window of the last seven rows is a circular buffer with static slots: the row loop is unrolled by 7
+    // (kBlurRows is a multiple of 7).
     int hw[7][4];
 #pragma unroll
-    for (int r = 0; r < 6; ++r) hrow(y0 - 3 + r, hw[r + 1]);
+    for (int r = 0; r < 6; ++r) hrow(y0 - 3 + r, hw[r]);
     const int yend = min(y0 + kBlurRows, H);
     const int nvalid = min(4, W - x0);
-    for (int y = y0; y < yend; ++y) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) hw[r][q] = hw[r + 1][q];
-        hrow(y + 3, hw[6]);
+    auto step = [&](auto phc, int y) {
+        constexpr int PH = decltype(phc)::value;   // window row r of this iteration lives in slot (PH + r) % 7
+        if (y >= yend) return;                     // uniform
+        hrow(y + 3, hw[(PH + 6) % 7]);
         uint32_t out = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int sacc = 18 * (hw[0][q] + hw[6][q]) + 34 * (hw[1][q] + hw[5][q]) + 49 * (hw[2][q] + hw[4][q]) + 55 * hw[3][q];
+            const int sacc = 18 * (hw[PH % 7][q] + hw[(PH + 6) % 7][q]) + 34 * (hw[(PH + 1) % 7][q] + hw[(PH + 5) % 7][q]) +
+                             49 * (hw[(PH + 2) % 7][q] + hw[(PH + 4) % 7][q]) + 55 * hw[(PH + 3) % 7][q];
             const int v = min(max((sacc + (1 << 15)) >> 16, 0), 255);
             out |= (uint32_t)v << (8 * q);
         }
@@ -784,6 +794,15 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
             const uint32_t keep = ~((1u << (8 * nvalid)) - 1u);
             *o = (*o & keep) | (out & ~keep);
         }
+    };
+    for (int y = y0; y < yend; y += 7) {
+        step(std::integral_constant<int, 0>{}, y);
+        step(std::integral_constant<int, 1>{}, y + 1);
+        step(std::integral_constant<int, 2>{}, y + 2);
+        step(std::integral_constant<int, 3>{}, y + 3);
+        step(std::integral_constant<int, 4>{}, y + 4);
+        step(std::integral_constant<int, 5>{}, y + 5);
+        step(std::integral_constant<int, 6>{}, y + 6);
     }
 }
 
