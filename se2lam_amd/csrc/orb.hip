@@ -446,6 +446,28 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
         if (threadIdx.x == 0) atomicOr(overflow, 1);
         n = kSortCap;
     }
+    // FAST_SCORE with a cell of ordinary size (~100 candidates): rank sort.  A key's rank = the number of smaller keys
+    // (keys are unique: they contain the position); every thread reads the same keys[j] (LDS broadcast), no barriers -
+    // the bitonic network below costs ~30 barrier-separated stages for the same job.
+    constexpr int kRankMax = 768;
+    if (!HARRIS && n <= kRankMax) {
+        const int n20r = s_n20;
+        const int totalr = (n20r > 3) ? n20r : n;
+        const int keepr = min(totalr, g.cell_cap);
+        uint32_t* outk = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
+        float* outf = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
+        if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = totalr;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const uint32_t ki = keys[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += keys[j] < ki;
+            if (rank < keepr) {
+                outk[rank] = ki & 0x00ffffffu;
+                outf[rank] = (float)(254 - (int)(ki >> 24));   // cornerScore = S - 1
+            }
+        }
+        return;
+    }
     int npad = 1;
     while (npad < n) npad <<= 1;
     for (int i = n + threadIdx.x; i < npad; i += 256) keys[i] = 0xffffffffu;
