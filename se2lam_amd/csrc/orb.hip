@@ -849,46 +849,69 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
                                                    int cap, const float* __restrict__ angles,
                                                    const float2* __restrict__ cs,
                                                    se2gpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
+    // One wave handles TWO key points: the per-wave work is a short dependent chain (key point -> 8 byte gathers per
+    // lane -> 4 ballots), so the kernel is bound by how many such chains are in flight; two per wave keep 16
+    // independent gathers per lane outstanding with half the waves.
     const int f = blockIdx.y;
-    const int k = blockIdx.x * 4 + threadIdx.x / 64;
+    const int k0 = 2 * (blockIdx.x * 4 + threadIdx.x / 64);
     const int lane = threadIdx.x & 63;
-    if (k >= counts[f]) return;  // wave-uniform
-    const int4 kp = kp_list[(size_t)f * cap + k];
-    const float ang = angles[(size_t)f * cap + k];
-    const float2 ab = cs[(size_t)f * cap + k];
-    const float a = ab.x, b = ab.y;
-    const int stride = g.stride[kp.x];
-    const uint8_t* center = blur + pix(g, f, kp.x, kp.z, kp.y);
-    unsigned long long words[4];
+    const int n = counts[f];
+    if (k0 >= n) return;  // wave-uniform
+    const bool two = k0 + 1 < n;
+    int4 kp[2];
+    float ang[2];
+    float2 ab[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pw = reinterpret_cast<const int*>(c_pattern)[64 * q + lane];   // the 4 pattern bytes in one load
-        const float x0 = (float)(signed char)(pw & 0xff), y0 = (float)(signed char)((pw >> 8) & 0xff);
-        const float x1 = (float)(signed char)((pw >> 16) & 0xff), y1 = (float)(signed char)((pw >> 24) & 0xff);
-        const int r0 = (int)rintf(x0 * b + y0 * a), c0 = (int)rintf(x0 * a - y0 * b);
-        const int r1 = (int)rintf(x1 * b + y1 * a), c1 = (int)rintf(x1 * a - y1 * b);
-        const int t0 = center[r0 * stride + c0], t1 = center[r1 * stride + c1];
-        words[q] = __ballot(t0 < t1);
+    for (int u = 0; u < 2; ++u) {
+        const int k = (u == 0 || two) ? k0 + u : k0;
+        kp[u] = kp_list[(size_t)f * cap + k];
+        ang[u] = angles[(size_t)f * cap + k];
+        ab[u] = cs[(size_t)f * cap + k];
     }
-    if (lane < 4) {
-        unsigned long long w = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
-        *(unsigned long long*)(desc + ((size_t)f * cap + k) * 32 + 8 * lane) = w;
-    }
-    if (lane == 0) {
-        se2gpu_keypoint o;
-        o.x = (float)kp.y;
-        o.y = (float)kp.z;
-        if (kp.x != 0) {
-            const float s = g.scale[kp.x];
-            o.x *= s;
-            o.y *= s;
+    int t0[2][4], t1[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float a = ab[u].x, b = ab[u].y;
+        const int stride = g.stride[kp[u].x];
+        const uint8_t* center = blur + pix(g, f, kp[u].x, kp[u].z, kp[u].y);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pw = reinterpret_cast<const int*>(c_pattern)[64 * q + lane];   // the 4 pattern bytes in one load
+            const float x0 = (float)(signed char)(pw & 0xff), y0 = (float)(signed char)((pw >> 8) & 0xff);
+            const float x1 = (float)(signed char)((pw >> 16) & 0xff), y1 = (float)(signed char)((pw >> 24) & 0xff);
+            const int r0 = (int)rintf(x0 * b + y0 * a), c0 = (int)rintf(x0 * a - y0 * b);
+            const int r1 = (int)rintf(x1 * b + y1 * a), c1 = (int)rintf(x1 * a - y1 * b);
+            t0[u][q] = center[r0 * stride + c0];
+            t1[u][q] = center[r1 * stride + c1];
         }
-        o.size = g.patch[kp.x];
-        o.angle = ang;
-        o.response = __int_as_float(kp.w);
-        o.octave = kp.x;
-        o.class_id = -1;
-        kps[(size_t)f * cap + k] = o;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        const int k = k0 + u;
+        unsigned long long words[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) words[q] = __ballot(t0[u][q] < t1[u][q]);
+        if (lane < 4) {
+            unsigned long long w = lane == 0 ? words[0] : (lane == 1 ? words[1] : (lane == 2 ? words[2] : words[3]));
+            *(unsigned long long*)(desc + ((size_t)f * cap + k) * 32 + 8 * lane) = w;
+        }
+        if (lane == 0) {
+            se2gpu_keypoint o;
+            o.x = (float)kp[u].y;
+            o.y = (float)kp[u].z;
+            if (kp[u].x != 0) {
+                const float sc = g.scale[kp[u].x];
+                o.x *= sc;
+                o.y *= sc;
+            }
+            o.size = g.patch[kp[u].x];
+            o.angle = ang[u];
+            o.response = __int_as_float(kp[u].w);
+            o.octave = kp[u].x;
+            o.class_id = -1;
+            kps[(size_t)f * cap + k] = o;
+        }
     }
 }
 
@@ -1117,7 +1140,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     SE2_LAUNCH(h->prof, st, "k_angle_trig", k_angle_trig, dim3((cap + 255) / 256, nframes), dim3(256), 0, d_counts, cap,
                h->angles.p, h->angle_cs.p);
     if (sb != st) SE2_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
-    SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->blur.p,
+    SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 7) / 8, nframes), dim3(256), 0, g, h->blur.p,
                h->kp_list.p, d_counts, cap, h->angles.p, h->angle_cs.p, d_kps, d_desc);
     SE2_HIP(hipGetLastError());
     h->last_batch = nframes;
