@@ -133,3 +133,18 @@ def test_harris_score_bit_exact(oracle, synth, t):
         assert np.array_equal(k[name], kr[name]), name
     assert np.array_equal(d, dr)
     assert not np.array_equal(kr["response"], np.round(kr["response"]))   # really Harris floats, not FAST scores
+
+
+def test_harris_score_on_noise_and_half_flat(oracle, synth):
+    """HARRIS_SCORE where cells hold thousands of candidates (bitonic 64-bit sort path, negative responses) and where
+    the quota is redistributed between cells."""
+    from se2lam_amd.orb import ORBextractor, HARRIS_SCORE
+    ex = ORBextractor(scoreType=HARRIS_SCORE)
+    par = oracle.orb_params(score_type=oracle.HARRIS_SCORE)
+    rng = np.random.default_rng(11)
+    imgs = [rng.integers(0, 256, (480, 640)).astype(np.uint8), synth.frame(5).copy()]
+    imgs[1][:, :300] = 40
+    for img in imgs:
+        k, d = ex(img)
+        ko, do = oracle.orb_extract(img, par)
+        assert len(ko) > 0 and np.array_equal(k, ko) and np.array_equal(d, do)
