@@ -306,7 +306,8 @@ def test_dataflow_solve_with_more_tiles_than_resident_workgroups(synth, monkeypa
 
 
 def _perturbed(synth, P, L, scale, seed=5):
-    g = synth.ba_graph(P, L)
+    import copy
+    g = copy.copy(synth.ba_graph(P, L))   # the generator caches its graphs: never modify the shared instance
     rng = np.random.default_rng(seed)
     g.poses = g.poses.copy()
     g.lms = g.lms.copy()
