@@ -8,16 +8,18 @@
 // with FP64 HIP kernels.  Design:
 //   * SoA arena in HBM; observation edges are sorted by landmark (CSR) once per graph.
 //   * k_linearize      8 lanes per landmark: residual, Jacobians, Huber weight, per-edge Hpl / Hpp_e / bp_e,
-//                      per-landmark Hll / bl via an in-group shuffle reduction (no atomics).
-//   * k_pose_reduce    one wave per pose: Hpp, bp (output-stationary sum over the pose's edges + odometry).
-//   * k_schur_lm       per landmark: Dinv = (Hll + lambda I)^-1, z = Dinv bl, Y_e = Hpl_e Dinv.
-//   * k_reduce         one wave per (pose, pose) block of the reduced system: S_ab = Hpp_ab - sum Y_i Hpl_j^T over a
-//                      PRECOMPUTED contributor list (output-stationary: deterministic, atomic-free), plus b_s.
-//   * dense pose solve LL^T of the (3P)^2 system (host, FP64) - "small dense pose solve on the host".
-//   * k_update         back-substitution, oplus into a trial state, robust chi^2 and the LM gain denominator.
+//                      per-landmark Hll / bl via an in-group shuffle reduction (no atomics); <FUSED>: also the
+//                      lambda-dependent Dinv, z, Y_e and the per-edge diagonal record Dg_e.
+//   * k_schur_lm       the lambda-dependent part alone: Dinv = (Hll + lambda I)^-1, z = Dinv bl, Y_e = Hpl_e Dinv, Dg_e.
+//   * k_reduce2        the reduced system S|b_s in one launch from a PRECOMPUTED contributor plan (output-stationary:
+//                      deterministic, atomic-free); k_pose_reduce / k_maxdiag only for lambda_0.
+//   * k_chol_tiles     dense pose solve: LDL^T of the augmented (3P)^2 system as one dataflow launch over 32x32 tiles
+//                      (k_chol_step: one launch per block column, second implementation); k_chol_apply: x = R y.
+//   * k_update, k_finalize  back-substitution, oplus into a trial state, robust chi^2, the LM gain denominator; the
+//                      scalars reach the host LM controller through a mapped mailbox.
 //   * the LM controller mirrors g2o's OptimizationAlgorithmLevenberg (lambda policy, <= 10 trials, Terminate rule)
 //     and polls the caller's stop flag between trials (SparseOptimizer::setForceStopFlag).
-// Multi-GPU: landmarks are sharded; S|bs is summed over ranks through the caller's all-reduce callback (RCCL).
+// Multi-GPU: landmarks are sharded; S|bs is summed over ranks by RCCL (se2gpu_comm_*) or the caller's callback.
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -416,85 +418,6 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const
 #pragma unroll
         for (int i = 0; i < 9; ++i) y[i] = yy[i];
         write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_reduce: one wave per upper-triangular (a <= b) block of the reduced system.
-//   S_ab = [a==b] (Hpp_a + lambda I * root) - sum_{(i,j) in pairs(a,b)} Y_i Hpl_j^T
-//   bs_a = bp_a - sum_{e in pose a} Hpl_e z_{lm(e)}                      (diagonal-block waves)
-// Fixed poses: zero rows/cols, unit diagonal on the root rank, zero rhs.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_reduce(int P, int ld, int npad, int nblk, double lambda, int root,
-                                                    const int* __restrict__ blk_a, const int* __restrict__ blk_b,
-                                                    const int* __restrict__ blk_ptr, const int* __restrict__ pair_i,
-                                                    const int* __restrict__ pair_j, const double* __restrict__ Y,
-                                                    const double* __restrict__ Hpl, const double* __restrict__ Hpp,
-                                                    const double* __restrict__ bp, const uint8_t* __restrict__ fixed,
-                                                    const int* __restrict__ pose_ptr,
-                                                    const int* __restrict__ pose_edges,
-                                                    const int* __restrict__ e_lm, const double* __restrict__ z,
-                                                    double* __restrict__ S) {
-    const int k = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
-    const int lane = threadIdx.x & 63;
-    const int n = 3 * P;
-    double* __restrict__ bs = S + (size_t)n * ld;  // rhs = augmented row n
-    if (k == nblk) {  // one extra wave clears the padding of the augmented matrix (rows > n, tail of row n)
-        for (size_t t = (size_t)n * ld + n + lane; t < (size_t)npad * ld; t += 64) S[t] = 0.0;
-        return;
-    }
-    if (k > nblk) return;
-    const int a = blk_a[k], b = blk_b[k];
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = blk_ptr[k] + lane; t < blk_ptr[k + 1]; t += 64) {
-        const double* y = Y + (size_t)pair_i[t] * 9;
-        const double* h = Hpl + (size_t)pair_j[t] * 9;
-        double yy[9], hh[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { yy[i] = y[i]; hh[i] = h[i]; }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                acc[r * 3 + c] += yy[r * 3] * hh[c * 3] + yy[r * 3 + 1] * hh[c * 3 + 1] + yy[r * 3 + 2] * hh[c * 3 + 2];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) acc[i] = wave_sum(acc[i]);
-    const bool fa = fixed[a], fb = fixed[b];
-    if (lane < 9) {
-        const int r = lane / 3, c = lane % 3;
-        double v = 0;
-        // pick acc[lane] without dynamic register indexing
-#pragma unroll
-        for (int i = 0; i < 9; ++i) v = (lane == i) ? acc[i] : v;
-        double out;
-        if (fa || fb) {
-            out = (a == b && r == c && root) ? 1.0 : 0.0;
-        } else {
-            out = -v;
-            if (a == b) out += Hpp[(size_t)a * 9 + lane] + ((r == c && root) ? lambda : 0.0);
-        }
-        S[(size_t)(3 * a + r) * ld + 3 * b + c] = out;
-        if (a != b) S[(size_t)(3 * b + c) * ld + 3 * a + r] = out;
-    }
-    if (a == b) {
-        double g[3] = {0, 0, 0};
-        if (!fa) {
-            for (int t = pose_ptr[a] + lane; t < pose_ptr[a + 1]; t += 64) {
-                const int e = pose_edges[t];
-                const double* h = Hpl + (size_t)e * 9;
-                const double* zz = z + (size_t)e_lm[e] * 3;
-                const double z0 = zz[0], z1 = zz[1], z2 = zz[2];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) g[r] += h[r * 3] * z0 + h[r * 3 + 1] * z1 + h[r * 3 + 2] * z2;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) g[r] = wave_sum(g[r]);
-        if (lane < 3) {
-            double v = lane == 0 ? g[0] : (lane == 1 ? g[1] : g[2]);
-            bs[3 * a + lane] = fa ? 0.0 : bp[(size_t)a * 3 + lane] - v;
-        }
     }
 }
 

@@ -8,13 +8,15 @@
 // The reference's matchers are order-dependent greedy passes: query i sees vMatchesDistance as left by queries
 // 0..i-1 and ties go to the earliest candidate.  The split used here keeps that exactly:
 //   k_grid_order     per target frame: features sorted by (cell x, cell y, index) = the order GetFeaturesInArea
-//                    enumerates them (LDS bitonic sort of 28-bit keys)
-//   k_cand_*         one wave per query: window / level / square test over the sorted list, wave-ballot ordered
+//                    enumerates them (LDS bitonic sort of 28-bit keys) + the start of every grid column in that list
+//   k_cand_*         one wave per query: window / level / square test over the grid-column slice of the sorted list
+//                    that the search window covers, wave-ballot ordered
 //                    compaction, 256-bit Hamming distance (4 x popcll) -> per-query candidate list (idx, dist)
 //                    - the parallel O(N1*N2) part
-//   k_resolve_*      one wave per frame pair: replays the greedy pass in query order on the pre-computed lists
-//                    (wave-ballot arg-min for best / second best, state in LDS), rotation histogram,
-//                    ComputeThreeMaxima, prev-matched update - the sequential part, parallel across pairs
+//   k_resolve_*      one wave per frame pair: reproduces the greedy pass on the pre-computed lists - MatchByWindow as a
+//                    fixed-point iteration over 64 queries at a time (exactly the sequential result), MatchByProjection
+//                    in query order with wave-ballot arg-min; rotation histogram, ComputeThreeMaxima, prev-matched
+//                    update; parallel across pairs
 // Compiled with -ffp-contract=off (float grid / projection arithmetic must round as the reference's).
 #include <algorithm>
 #include <climits>

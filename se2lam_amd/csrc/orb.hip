@@ -8,16 +8,21 @@
 // fixed-point 7x7 Gaussian, canonical retain-best order, fastAtan2, round-half-even).
 //
 // Pipeline (every kernel covers the whole batch; all stages stay in HBM, no host round trip):
-//   k_level0 / k_resize   pyramid level k from level k-1, border filled in the same pass (4 px per thread)
-//   k_fast_score          S(x,y) = FAST-9/16 score for every level in one launch
-//   k_cell_detect         one workgroup per (frame, level, cell): in-cell NMS, threshold 20 / fallback 7,
-//                         LDS bitonic sort by (response desc, y, x) -> per-cell sorted candidate list
+//   k_level0 / k_resize   pyramid level k from level k-1, border filled in the same pass; resize coefficients from host
+//                         tables over the bordered row, the taps of a thread from one 64-bit load per source row
+//   k_fast_score          S(x,y) = FAST-9/16 score for every level in one launch, in-cell non-max suppression fused:
+//                         writes a sparse plane (S where S > 7 and a strict in-cell maximum, else 0)
+//   k_cell_detect         one workgroup per (frame, level, cell): collects the non-zero scores, threshold 20 /
+//                         fallback 7, rank sort by (response desc, y, x) -> per-cell sorted candidate list
+//                         (<true>: HARRIS_SCORE, responses re-scored with the 7x7 Harris measure)
 //   k_level_select        one workgroup per frame: quota redistribution (serial, tiny), per-cell top-n gather,
 //                         level-wide retain-best by rank, keypoint list in level order
-//   k_orientation         16 lanes per keypoint: integer intensity-centroid moments, fastAtan2
-//   k_blur                7x7 fixed-point Gaussian through LDS tiles (interior only; the 16 px frame of the blurred
-//                         pyramid keeps the un-blurred reflect copies, as in the reference's in-place ROI blur)
-//   k_describe            one wave per keypoint: lane l evaluates pattern pairs l, l+64, l+128, l+192 and the four
+//   k_orientation         one wave per keypoint: integer intensity-centroid moments, fastAtan2
+//   k_copy_frame, k_blur  blurred pyramid: the 16 px frame keeps the un-blurred reflect copies (as in the reference's
+//                         in-place ROI blur), the interior gets the 7x7 fixed-point Gaussian (register window, packed
+//                         u16 horizontal taps); both on a side stream beside the key-point chain
+//   k_angle_trig          cos / sin of the key-point angle (double, rounded once), one thread per key point
+//   k_describe            one wave per two keypoints: lane l evaluates pattern pairs l, l+64, l+128, l+192 and the four
 //                         64-bit wave ballots ARE the 256-bit descriptor; also writes the final cv::KeyPoint
 // Compiled with -ffp-contract=off (se2lam_amd/build.py): the float index arithmetic must round as the
 // reference's non-FMA build does.
