@@ -201,7 +201,7 @@ __device__ __forceinline__ void best2_push(Best2& b, int d, int p) {  // (d, p) 
 }
 
 // Stage the candidate lists of `nq` queries (fixed stride kMaxCand in HBM) into LDS as one compact array so that
-// the sequential greedy pass never waits on HBM.  off[0..nq] = exclusive prefix of min(ncand, kMaxCand); entries that
+// the greedy pass never waits on HBM.  off[0..nq] = exclusive prefix of min(ncand, kMaxCand); entries that
 // do not fit in `cap_e` stay in HBM (the pass falls back to global reads for those queries).  One wave.
 __device__ __forceinline__ int stage_candidates(const uint32_t* __restrict__ cand, const int* __restrict__ ncand, int nq,
                                                 int* off, uint32_t* ce, int cap_e, int* __restrict__ overflow) {
@@ -238,31 +238,6 @@ __device__ __forceinline__ int stage_candidates(const uint32_t* __restrict__ can
     }
     __syncthreads();
     return total;
-}
-
-// best / second best by (dist, list position) among the candidates of one query that pass `vMatchesDistance[idx] > dist`
-__device__ __forceinline__ Best2 resolve_query(const uint32_t* cl, int n, const int* vMatchesDistance) {
-    const int lane = threadIdx.x & 63;
-    Best2 b{INT_MAX, -1, INT_MAX, -1};
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int pos = c0 + lane;
-        bool valid = false;
-        int dist = 0;
-        if (pos < n) {
-            const uint32_t pk = cl[pos];
-            dist = (int)(pk & 0xfffu);
-            valid = !(vMatchesDistance[pk >> 12] <= dist);
-        }
-        const int l1 = wave_argmin(valid, dist);
-        if (l1 < 0) continue;
-        const int dd1 = __shfl(dist, l1);
-        best2_push(b, dd1, c0 + l1);
-        if (__popcll(__ballot(valid)) > 1) {
-            const int l2 = wave_argmin(valid && lane != l1, dist);
-            if (l2 >= 0) best2_push(b, __shfl(dist, l2), c0 + l2);
-        }
-    }
-    return b;
 }
 
 __device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& ind2, int& ind3) {
@@ -474,44 +449,78 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
     if ((threadIdx.x & 63) == 0) ncand[i] = n;
 }
 
-// MatchByProjection greedy pass (ORBmatcher.cpp:390-451), one wave.
+// MatchByProjection greedy pass (ORBmatcher.cpp:390-451), one wave, parallel over map points: the same fixed-point
+// scheme as k_resolve_window.  64 consecutive map points (one per lane) are swept until no lane changes its
+// (accept?, target, distance); lane l sees the committed vMatchesDistance lowered by the tentative acceptances of the
+// lanes below it, so the fixed point is the sequential result.  On commit the highest accepting lane of a target owns
+// vMatchesIdxMP[target] (the reference overwrites the earlier owner) and leaves its - smallest - distance behind.
+// Dynamic LDS (ints): accMask[nE] (64-bit, offset 0) | vMatchesDistance[nE] | octave[nE] | accDist[64] |
+//                     off[chunk+1] | staged candidate entries.
 __global__ __launch_bounds__(64) void k_resolve_projection(const se2gpu_keypoint* __restrict__ kps, int n, int m,
                                                             const uint32_t* __restrict__ cand,
                                                             const int* __restrict__ ncand, float nnratio,
                                                             int chunk, int cand_lds, int* __restrict__ match_idx,
                                                             int* __restrict__ nmatches, int* __restrict__ overflow) {
-    extern __shared__ int lds[];
+    extern __shared__ __attribute__((aligned(16))) int lds[];
     const int lane = threadIdx.x;
-    int* vMatchesDistance = lds;
-    int* off = lds + n;                                  // chunk + 1 entries
-    uint32_t* ce = (uint32_t*)(lds + n + chunk + 1);
-    for (int i = lane; i < n; i += 64) { vMatchesDistance[i] = INT_MAX; match_idx[i] = -1; }
+    const int nE = (n + 3) & ~3;
+    unsigned long long* accMask = (unsigned long long*)lds;
+    int* vMatchesDistance = lds + 2 * nE;
+    int* octave = lds + 3 * nE;
+    int* accDist = lds + 4 * nE;                         // 64
+    int* off = lds + 4 * nE + 64;                        // chunk + 1 entries
+    uint32_t* ce = (uint32_t*)(lds + 4 * nE + 64 + chunk + 1);
+    for (int i = lane; i < n; i += 64) {
+        vMatchesDistance[i] = INT_MAX; accMask[i] = 0ull; octave[i] = kps[i].octave; match_idx[i] = -1;
+    }
     __syncthreads();
+    const unsigned long long bit = 1ull << lane;
     // map points are processed in chunks whose candidate lists are staged in LDS
     for (int i0 = 0; i0 < m; i0 += chunk) {
       const int mq = min(chunk, m - i0);
       stage_candidates(cand + (size_t)i0 * kMaxCand, ncand + i0, mq, off, ce, cand_lds, overflow);
-      for (int ii = 0; ii < mq; ++ii) {
-        const int i = i0 + ii;
-        const int o0 = off[ii];
-        const int nc = off[ii + 1] - o0;
-        if (nc == 0) continue;
-        const uint32_t* cl = (o0 + nc <= cand_lds) ? ce + o0 : cand + (size_t)i * kMaxCand;
-        const Best2 b = resolve_query(cl, nc, vMatchesDistance);
-        if (b.p1 >= 0 && b.d1 <= kThHigh) {
-            const int bestIdx = (int)(cl[b.p1] >> 12);
-            const int bestLevel = kps[bestIdx].octave;
-            const int bestLevel2 = b.p2 >= 0 ? kps[cl[b.p2] >> 12].octave : -1;
-            const bool reject = bestLevel == bestLevel2 && (float)b.d1 > nnratio * (float)b.d2;
-            if (!reject && lane == 0) {
-                match_idx[bestIdx] = i;
-                vMatchesDistance[bestIdx] = b.d1;
+      for (int c0 = 0; c0 < mq; c0 += 64) {
+        const int q = c0 + lane;
+        int nc = 0, o0 = 0;
+        if (q < mq) { o0 = off[q]; nc = off[q + 1] - o0; }
+        if (!__any(nc > 0)) continue;
+        const uint32_t* cl = (o0 + nc <= cand_lds) ? ce + o0 : cand + (size_t)(i0 + q) * kMaxCand;
+        bool acc = false;
+        int bidx = -1, bd = 0;
+        for (int sweep = 0; sweep < 65; ++sweep) {
+            const LaneBest b = lane_scan(cl, nc, vMatchesDistance, accMask, accDist, lane);
+            bool nacc = b.bp >= 0 && b.bd <= kThHigh;
+            int nidx = -1;
+            if (nacc) {
+                nidx = (int)(cl[b.bp] >> 12);
+                const int bestLevel2 = b.bp2 >= 0 ? octave[cl[b.bp2] >> 12] : -1;
+                if (octave[nidx] == bestLevel2 && (float)b.bd > nnratio * (float)b.bd2) { nacc = false; nidx = -1; }
+            }
+            const bool changed = nacc != acc || (nacc && (nidx != bidx || b.bd != bd));
+            const unsigned long long chg = __ballot(changed);
+            __syncthreads();                           // every lane has read the masks of this sweep
+            if (!chg) break;
+            if (changed) {
+                if (acc) atomicAnd(&accMask[bidx], ~bit);
+                if (nacc) { atomicOr(&accMask[nidx], bit); accDist[lane] = b.bd; }
+                acc = nacc; bidx = nidx; bd = b.bd;
+            }
+            __syncthreads();
+        }
+        if (acc) {
+            const unsigned long long am = accMask[bidx];
+            if ((63 - __clzll((long long)am)) == lane) {   // the last accepting map point keeps the feature
+                match_idx[bidx] = i0 + q;
+                vMatchesDistance[bidx] = bd;
             }
         }
+        __syncthreads();
+        if (acc) accMask[bidx] = 0ull;
         __syncthreads();
       }
       __syncthreads();
     }
+    __syncthreads();
     int cnt = 0;
     for (int i = lane; i < n; i += 64) cnt += match_idx[i] >= 0;
     for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
@@ -825,9 +834,17 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
                            win_size, level_offset, h->cand.p, h->ncand.p);
     {
         const int chunk = 1024;
-        const size_t fixed_lds = ((size_t)n + chunk + 1) * sizeof(int);
-        SE2_REQUIRE(fixed_lds + 4096 <= 64 * 1024, SE2GPU_ERR_CAPACITY, "%d key-frame features need %zu B of LDS", n, fixed_lds);
-        const int cand_lds = (int)((60 * 1024 - fixed_lds) / sizeof(int));
+        constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: a single wave, occupancy is irrelevant
+        const size_t nE = ((size_t)n + 3) & ~(size_t)3;
+        const size_t fixed_lds = (4 * nE + 64 + chunk + 1) * sizeof(int);
+        SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY, "%d key-frame features need %zu B of LDS", n, fixed_lds);
+        static bool attr_set = false;
+        if (!attr_set) {
+            SE2_HIP(hipFuncSetAttribute((const void*)k_resolve_projection, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kLdsBudget));
+            attr_set = true;
+        }
+        const int cand_lds = (int)((kLdsBudget - fixed_lds) / sizeof(int));
         hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(64), fixed_lds + (size_t)cand_lds * sizeof(int), st, h->kps.p,
                            n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, h->matches.p, h->nmatches.p,
                            h->overflow.p);

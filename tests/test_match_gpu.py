@@ -128,6 +128,17 @@ def test_match_by_projection_edge_cases(oracle, feats):
     nm, idx = mt.MatchByProjection(*a, 15, 2)
     idx_ref, nm_ref = oracle.match_projection(*a, 15, 2, 0.6)
     assert nm == nm_ref and np.array_equal(idx, idx_ref)
+    # every map point three times (adjacent and far apart): long chains of queries competing for one feature
+    rng = np.random.default_rng(5)
+    for order in ("adjacent", "tiled"):
+        a = list(args)
+        for k in range(4):
+            a[k] = np.repeat(args[k], 3, axis=0) if order == "adjacent" else np.concatenate([args[k]] * 3)
+        noise = (rng.random(a[1].shape) < 0.01).astype(np.uint8) * rng.integers(0, 256, a[1].shape).astype(np.uint8)
+        a[1] = a[1] ^ noise
+        nm, idx = mt.MatchByProjection(*a, 15, 2)
+        idx_ref, nm_ref = oracle.match_projection(*a, 15, 2, 0.6)
+        assert nm == nm_ref and np.array_equal(idx, idx_ref), order
 
 
 def _feature_vector(desc, nbits):
