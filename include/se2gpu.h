@@ -229,6 +229,26 @@ int se2gpu_triangulate(int n, const se2gpu_keypoint* kps_ref, const se2gpu_keypo
                        const float* Ocam, float lower_depth, float upper_depth, int min_degree, float* pos_out,
                        uint8_t* good_parallax, int* n_good, int* n_tracked_old);
 
+/* Track::removeOutliers (/root/reference/src/Track.cpp:308-344) - SURVEY section 8(f).3: the epipolar filter applied to
+ * the MatchByWindow result in Track::mTrack (Track.cpp:134).  The handle owns a stream and the staging / device buffers
+ * of the calling thread (Track is single-threaded); it is not thread-safe.
+ *   se2gpu_track_fundamental_mask  = cv::findFundamentalMat(pt1, pt2, mask) with the defaults FM_RANSAC, 3 px, 0.99
+ *       [OpenCV 3.2]: n < 7 no mask (all 0 here, *n_inliers = 0); n == 7 all 1; 8..14 LMedS; >= 15 RANSAC over 7-point
+ *       samples drawn by cv::RNG(-1), at most 1000 iterations, adaptive stop.  pt1 / pt2: n x (x, y) float.
+ *       No model found => mask all 0 (the reference leaves the mask uninitialised in that case).
+ *   se2gpu_track_remove_outliers   = the whole member function: matches[i] (n1 entries, index into kps2 or -1) is set to
+ *       -1 for the outliers; with fewer than 10 inliers every match is dropped and *n_inliers = 0.
+ *   se2gpu_track_last_ransac       = {inliers, winning sample, winning model of that sample, iterations the reference's
+ *       loop would have run} of the last call, for tracing. */
+typedef struct se2gpu_track se2gpu_track;
+int se2gpu_track_create(se2gpu_track** out);
+void se2gpu_track_destroy(se2gpu_track* h);
+int se2gpu_track_fundamental_mask(se2gpu_track* h, const float* pt1, const float* pt2, int n, uint8_t* mask,
+                                  int* n_inliers);
+int se2gpu_track_remove_outliers(se2gpu_track* h, const se2gpu_keypoint* kps1, int n1, const se2gpu_keypoint* kps2,
+                                 int n2, int32_t* matches, int* n_inliers);
+int se2gpu_track_last_ransac(const se2gpu_track* h, int info[4]);
+
 /* Per-observation information matrices of Map::loadLocalGraph (/root/reference/src/Map.cpp:1024-1049), SURVEY §8f.1:
  *   Sigma = s_rot * J_r J_r^T + s_z * J_z J_z^T + sigma2 * I,   Omega = Sigma^-1       (2x2, FP64)
  *   J_r = (J_pi Rcw skew(lw - p))[:, 0:2],  J_z = -(J_pi Rcw)[:, 2],  J_pi from the stored camera-frame point lc.

@@ -1,4 +1,5 @@
 // Front-end geometry of se2lam::Track on the device - header-only mirror over the C ABI (include/se2gpu.h).
+//   Track::removeOutliers  /root/reference/src/Track.cpp:308-344   (cv::findFundamentalMat RANSAC mask, < 10 inliers => none)
 //   Track::doTriangulate   /root/reference/src/Track.cpp:378-419   (cvu::triangulate, Config::acceptDepth, cvu::checkParallax)
 // The reference loops over the matches on the host, one 4x4 SVD each; here all matches of the frame pair go through one
 // kernel.  Map-point bookkeeping (mLocalMPs[i] = mpKF->mViewMPs[i] for features that already have an observation)
@@ -46,5 +47,37 @@ inline TriangulationResult doTriangulate(const std::vector<KeyPoint>& keyPointsU
           "se2gpu_triangulate");
     return r;
 }
+
+// Device workspace of the tracking thread; removeOutliers has the reference's signature and semantics
+// (Track.cpp:134: nMatched = removeOutliers(mRefFrame.keyPointsUn, mFrame.keyPointsUn, mMatchIdx)).
+class TrackGeometry {
+public:
+    TrackGeometry() { check(se2gpu_track_create(&h_), "se2gpu_track_create"); }
+    ~TrackGeometry() { se2gpu_track_destroy(h_); }
+    TrackGeometry(const TrackGeometry&) = delete;
+    TrackGeometry& operator=(const TrackGeometry&) = delete;
+
+    int removeOutliers(const std::vector<KeyPoint>& kp1, const std::vector<KeyPoint>& kp2, std::vector<int>& matches) {
+        int nInlier = 0;
+        check(se2gpu_track_remove_outliers(h_, reinterpret_cast<const se2gpu_keypoint*>(kp1.data()), (int)kp1.size(),
+                                           reinterpret_cast<const se2gpu_keypoint*>(kp2.data()), (int)kp2.size(),
+                                           matches.data(), &nInlier),
+              "se2gpu_track_remove_outliers");
+        return nInlier;
+    }
+
+    // cv::findFundamentalMat(pt1, pt2, mask): pt = (x, y) pairs
+    int findFundamentalMask(const std::vector<float>& pt1, const std::vector<float>& pt2, std::vector<uint8_t>& mask) {
+        const int n = (int)(pt1.size() / 2);
+        mask.assign(n, 0);
+        int nInlier = 0;
+        check(se2gpu_track_fundamental_mask(h_, pt1.data(), pt2.data(), n, mask.data(), &nInlier),
+              "se2gpu_track_fundamental_mask");
+        return nInlier;
+    }
+
+private:
+    se2gpu_track* h_ = nullptr;
+};
 
 }  // namespace se2lam_amd

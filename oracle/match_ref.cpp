@@ -17,6 +17,7 @@
 //                                          results in (cell x, cell y, insertion) order)
 //   grid element sizes      :37-44, FRAME_GRID_COLS = 64, FRAME_GRID_ROWS = 48 (include/se2lam/Frame.h:26-27)
 // Build: g++ -O2 -ffp-contract=off (oracle/Makefile).
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -447,6 +448,335 @@ int match_ref_triangulate(int n, const match_ref_keypoint* kps_ref, const match_
     }
     if (n_tracked_old) *n_tracked_old = nold;
     return ngood;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Track::removeOutliers (src/Track.cpp:308-344) = cv::findFundamentalMat(pt1, pt2, mask) with the defaults
+// FM_RANSAC, param1 = 3, param2 = 0.99 [3P: OpenCV 3.2 modules/calib3d/src/fundam.cpp + ptsetreg.cpp, restated from
+// memory - parity with the real library is UNPINNED]:
+//   npoints < 7          -> no mask                                 (=> every match is discarded, Track.cpp:338-341)
+//   npoints == 7         -> 7-point, mask = all ones
+//   8 <= npoints < 15    -> LMedS  (7-point samples, 0.45 outlier ratio, median of the FP32 errors sorted AS INTS)
+//   npoints >= 15        -> RANSAC (7-point samples, cv::RNG(-1), <= 1000 iterations, adaptive stop)
+// run7Point needs a basis of the 2-d null space of the 7x9 system.  cv::SVD's FULL_UV completes V with seeded random
+// vectors, i.e. an arbitrary basis; the fundamental matrices are the det = 0 members of the pencil and do not depend on
+// the basis, so a Householder QR of A^T supplies it here.  cv::solveCubic's acos/cos/cubeRoot are replaced by Newton
+// iterations built from + - * / sqrt only (same branch structure and root order), so that every platform executing this
+// operation sequence gets the same bits.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct CvRng {  // cv::RNG: multiply-with-carry
+    uint64_t state;
+    explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffull) {}
+    unsigned next() {
+        state = (uint64_t)(unsigned)state * 4164903690u + (unsigned)(state >> 32);
+        return (unsigned)state;
+    }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+// PointSetRegistrator::getSubset with Callback::checkSubset == true: 7 distinct indices by rejection
+void fm_subset(CvRng& rng, int count, int idx[7]) {
+    for (int i = 0; i < 7; ++i) {
+        for (;;) {
+            const int v = idx[i] = rng.uniform(0, count);
+            int j = 0;
+            for (; j < i; ++j)
+                if (v == idx[j]) break;
+            if (j == i) break;
+        }
+    }
+}
+
+double fm_cbrt(double v) {  // v >= 0
+    if (!(v > 0)) return v;
+    uint64_t bits;
+    std::memcpy(&bits, &v, 8);
+    const int ex = (int)((bits >> 52) & 0x7ff) - 1023;
+    const int q = ex >= 0 ? ex / 3 : -((-ex + 2) / 3);
+    const uint64_t yb = (uint64_t)(q + 1023) << 52;
+    double y;
+    std::memcpy(&y, &yb, 8);
+    for (int it = 0; it < 12; ++it) y = (2.0 * y + v / (y * y)) / 3.0;
+    return y;
+}
+
+// cos(acos(r) / 3): the root of 4c^3 - 3c = r in [1/2, 1], Newton from c = 1 (monotone)
+double fm_cos_third(double r) {
+    if (r > 1.0) r = 1.0;
+    if (r < -1.0) r = -1.0;
+    double c = 1.0;
+    for (int it = 0; it < 64; ++it) {
+        const double gp = 12.0 * c * c - 3.0;
+        if (!(gp > 0)) break;
+        const double g = (4.0 * c * c - 3.0) * c - r;
+        const double cn = c - g / gp;
+        if (cn == c) break;
+        c = cn;
+    }
+    return c;
+}
+
+// cv::solveCubic for c[0] x^3 + c[1] x^2 + c[2] x + c[3]
+int fm_solve_cubic(const double c[4], double x[3]) {
+    double a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+    int n = 0;
+    x[0] = x[1] = x[2] = 0;
+    if (a0 == 0) {
+        if (a1 == 0) {
+            if (a2 == 0) n = a3 == 0 ? -1 : 0;
+            else { x[0] = -a3 / a2; n = 1; }
+        } else {
+            double d = a2 * a2 - 4 * a1 * a3;
+            if (d >= 0) {
+                d = std::sqrt(d);
+                const double q1 = (-a2 + d) * 0.5, q2 = (a2 + d) * -0.5;
+                if (std::fabs(q1) > std::fabs(q2)) { x[0] = q1 / a1; x[1] = a3 / q1; }
+                else { x[0] = q2 / a1; x[1] = a3 / q2; }
+                n = d > 0 ? 2 : 1;
+            }
+        }
+    } else {
+        a0 = 1. / a0;
+        a1 *= a0; a2 *= a0; a3 *= a0;
+        const double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+        const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+        const double Qcubed = Q * Q * Q;
+        double d = Qcubed - R * R;
+        if (d >= 0) {
+            // theta = acos(R / sqrt(Q^3)); x_k = -2 sqrt(Q) cos(theta/3 + 2 k pi/3) - a1/3
+            const double ct = fm_cos_third(R / std::sqrt(Qcubed));
+            const double st = std::sqrt(1.0 - ct * ct);
+            const double t0 = -2 * std::sqrt(Q), t2 = a1 * (1. / 3);
+            const double h = 0.8660254037844386;  // sin(2 pi / 3)
+            x[0] = t0 * ct - t2;
+            x[1] = t0 * (-0.5 * ct - h * st) - t2;
+            x[2] = t0 * (-0.5 * ct + h * st) - t2;
+            n = 3;
+        } else {
+            d = std::sqrt(-d);
+            double e = fm_cbrt(std::fabs(R) + d);
+            if (R > 0) e = -e;
+            x[0] = (e + Q / e) - a1 * (1. / 3);
+            n = 1;
+        }
+    }
+    return n;
+}
+
+// basis (f1, f2) of the null space of the 7x9 matrix a: last two columns of Q in the Householder QR of a^T
+void fm_null_space(const double a[7][9], double f1[9], double f2[9]) {
+    double M[9][7], V[7][9], beta[7];
+    for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 7; ++c) M[r][c] = a[c][r];
+    for (int k = 0; k < 7; ++k) {
+        double sigma = 0;
+        for (int r = k; r < 9; ++r) sigma += M[r][k] * M[r][k];
+        const double norm = std::sqrt(sigma);
+        const double alpha = M[k][k] > 0 ? -norm : norm;
+        for (int r = 0; r < 9; ++r) V[k][r] = r < k ? 0.0 : M[r][k];
+        V[k][k] = M[k][k] - alpha;
+        double vn = 0;
+        for (int r = k; r < 9; ++r) vn += V[k][r] * V[k][r];
+        beta[k] = vn > 0 ? 2.0 / vn : 0.0;
+        for (int c = k + 1; c < 7; ++c) {
+            double s = 0;
+            for (int r = k; r < 9; ++r) s += V[k][r] * M[r][c];
+            s *= beta[k];
+            for (int r = k; r < 9; ++r) M[r][c] -= s * V[k][r];
+        }
+    }
+    for (int j = 0; j < 2; ++j) {
+        double q[9];
+        for (int r = 0; r < 9; ++r) q[r] = r == 7 + j ? 1.0 : 0.0;
+        for (int k = 6; k >= 0; --k) {
+            double s = 0;
+            for (int r = k; r < 9; ++r) s += V[k][r] * q[r];
+            s *= beta[k];
+            for (int r = k; r < 9; ++r) q[r] -= s * V[k][r];
+        }
+        for (int r = 0; r < 9; ++r) (j == 0 ? f1 : f2)[r] = q[r];
+    }
+}
+
+// run7Point (fundam.cpp): up to three 3x3 matrices (row-major) from 7 correspondences
+int fm_run7point(const float* m1, const float* m2, const int idx[7], double F[27]) {
+    double a[7][9], f1[9], f2[9], c[4], r[3];
+    for (int i = 0; i < 7; ++i) {
+        const double x0 = m1[2 * idx[i]], y0 = m1[2 * idx[i] + 1];
+        const double x1 = m2[2 * idx[i]], y1 = m2[2 * idx[i] + 1];
+        a[i][0] = x1 * x0; a[i][1] = x1 * y0; a[i][2] = x1;
+        a[i][3] = y1 * x0; a[i][4] = y1 * y0; a[i][5] = y1;
+        a[i][6] = x0; a[i][7] = y0; a[i][8] = 1;
+    }
+    fm_null_space(a, f1, f2);
+    for (int i = 0; i < 9; ++i) f1[i] -= f2[i];
+    double t0 = f2[4] * f2[8] - f2[5] * f2[7];
+    double t1 = f2[3] * f2[8] - f2[5] * f2[6];
+    double t2 = f2[3] * f2[7] - f2[4] * f2[6];
+    c[3] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2;
+    c[2] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2 - f1[3] * (f2[1] * f2[8] - f2[2] * f2[7]) +
+           f1[4] * (f2[0] * f2[8] - f2[2] * f2[6]) - f1[5] * (f2[0] * f2[7] - f2[1] * f2[6]) +
+           f1[6] * (f2[1] * f2[5] - f2[2] * f2[4]) - f1[7] * (f2[0] * f2[5] - f2[2] * f2[3]) +
+           f1[8] * (f2[0] * f2[4] - f2[1] * f2[3]);
+    t0 = f1[4] * f1[8] - f1[5] * f1[7];
+    t1 = f1[3] * f1[8] - f1[5] * f1[6];
+    t2 = f1[3] * f1[7] - f1[4] * f1[6];
+    c[0] = f1[0] * t0 - f1[1] * t1 + f1[2] * t2;
+    c[1] = f2[0] * t0 - f2[1] * t1 + f2[2] * t2 - f2[3] * (f1[1] * f1[8] - f1[2] * f1[7]) +
+           f2[4] * (f1[0] * f1[8] - f1[2] * f1[6]) - f2[5] * (f1[0] * f1[7] - f1[1] * f1[6]) +
+           f2[6] * (f1[1] * f1[5] - f1[2] * f1[4]) - f2[7] * (f1[0] * f1[5] - f1[2] * f1[3]) +
+           f2[8] * (f1[0] * f1[4] - f1[1] * f1[3]);
+    const int n = fm_solve_cubic(c, r);
+    if (n < 1 || n > 3) return n;
+    for (int k = 0; k < n; ++k) {
+        double* f = F + 9 * k;
+        double lambda = r[k], mu = 1.;
+        const double s = f1[8] * r[k] + f2[8];
+        if (std::fabs(s) > 2.220446049250313e-16) {
+            mu = 1. / s;
+            lambda *= mu;
+            f[8] = 1.;
+        } else
+            f[8] = 0.;
+        for (int i = 0; i < 8; ++i) f[i] = f1[i] * lambda + f2[i] * mu;
+    }
+    return n;
+}
+
+// FMEstimatorCallback::computeError: symmetric squared epipolar distance (max of the two), FP32 result
+float fm_error(const double F[9], float x1, float y1, float x2, float y2) {
+    double a = F[0] * x1 + F[1] * y1 + F[2];
+    double b = F[3] * x1 + F[4] * y1 + F[5];
+    double c = F[6] * x1 + F[7] * y1 + F[8];
+    const double s2 = 1. / (a * a + b * b);
+    const double d2 = x2 * a + y2 * b + c;
+    a = F[0] * x2 + F[3] * y2 + F[6];
+    b = F[1] * x2 + F[4] * y2 + F[7];
+    c = F[2] * x2 + F[5] * y2 + F[8];
+    const double s1 = 1. / (a * a + b * b);
+    const double d1 = x1 * a + y1 * b + c;
+    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)((e1 < e2) ? e2 : e1);  // std::max(e1, e2)
+}
+
+int fm_update_num_iters(double p, double ep, int modelPoints, int maxIters) {  // cv::RANSACUpdateNumIters
+    p = std::fmax(p, 0.); p = std::fmin(p, 1.);
+    ep = std::fmax(ep, 0.); ep = std::fmin(ep, 1.);
+    double num = std::fmax(1. - p, 2.2250738585072014e-308);
+    double denom = 1. - std::pow(1. - ep, modelPoints);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)std::nearbyint(num / denom);
+}
+
+int32_t fm_sort_key(float e) {  // LMedS sorts the float errors as ints; an x86 default NaN has the sign bit set
+    int32_t k;
+    if (e != e) return (int32_t)0xffc00000;
+    std::memcpy(&k, &e, 4);
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+// mask[i] (n entries) for the n correspondences m1[i] <-> m2[i] (x, y interleaved); returns the number of inliers,
+// 0 with an all-zero mask when findFundamentalMat leaves the mask empty or finds no model
+int match_ref_fundamental_mask(const float* m1, const float* m2, int n, uint8_t* mask) {
+    for (int i = 0; i < n; ++i) mask[i] = 0;
+    if (n < 7) return 0;
+    if (n == 7) {
+        for (int i = 0; i < n; ++i) mask[i] = 1;
+        return n;
+    }
+    CvRng rng((uint64_t)-1);
+    double F[27], best[9];
+    int idx[7];
+    if (n >= 15) {
+        int niters = 1000, maxGood = 0;
+        const float t = (float)(3.0 * 3.0);
+        std::vector<uint8_t> cur(n);
+        for (int iter = 0; iter < niters; ++iter) {
+            fm_subset(rng, n, idx);
+            const int nm = fm_run7point(m1, m2, idx, F);
+            if (nm <= 0) continue;
+            for (int k = 0; k < nm; ++k) {
+                int good = 0;
+                for (int i = 0; i < n; ++i) {
+                    cur[i] = fm_error(F + 9 * k, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= t;
+                    good += cur[i];
+                }
+                if (good > std::max(maxGood, 6)) {
+                    std::memcpy(mask, cur.data(), n);
+                    maxGood = good;
+                    niters = fm_update_num_iters(0.99, (double)(n - good) / n, 7, niters);
+                }
+            }
+        }
+        return maxGood;
+    }
+    // LMedS
+    int niters = std::max(fm_update_num_iters(0.99, 0.45, 7, 1000), 3);
+    double minMedian = 1.7976931348623157e308;
+    std::vector<int32_t> keys(n);
+    for (int iter = 0; iter < niters; ++iter) {
+        fm_subset(rng, n, idx);
+        const int nm = fm_run7point(m1, m2, idx, F);
+        if (nm <= 0) continue;
+        for (int k = 0; k < nm; ++k) {
+            for (int i = 0; i < n; ++i)
+                keys[i] = fm_sort_key(fm_error(F + 9 * k, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]));
+            std::sort(keys.begin(), keys.end());
+            float lo, hi;
+            std::memcpy(&lo, &keys[n / 2 - 1], 4);
+            std::memcpy(&hi, &keys[n / 2], 4);
+            const double median = n % 2 != 0 ? (double)hi : (double)((lo + hi) * 0.5);
+            if (median < minMedian) {
+                minMedian = median;
+                std::memcpy(best, F + 9 * k, sizeof(best));
+            }
+        }
+    }
+    if (!(minMedian < 1.7976931348623157e308)) return 0;
+    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * std::sqrt(minMedian);
+    sigma = std::fmax(sigma, 0.001);
+    const float t = (float)(sigma * sigma);
+    int good = 0;
+    for (int i = 0; i < n; ++i) {
+        mask[i] = fm_error(best, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= t;
+        good += mask[i];
+    }
+    return good;
+}
+
+// Track::removeOutliers (src/Track.cpp:308-344): matches[i] = -1 for the outliers; fewer than 10 inliers => every
+// match is discarded and 0 is returned
+int match_ref_remove_outliers(const match_ref_keypoint* kp1, int n1, const match_ref_keypoint* kp2, int n2,
+                              int32_t* matches) {
+    std::vector<float> pt1, pt2;
+    std::vector<int> idx;
+    for (int i = 0; i < n1; ++i) {
+        if (matches[i] < 0) continue;
+        idx.push_back(i);
+        pt1.push_back(kp1[i].x); pt1.push_back(kp1[i].y);
+        pt2.push_back(kp2[matches[i]].x); pt2.push_back(kp2[matches[i]].y);
+    }
+    (void)n2;
+    const int n = (int)idx.size();
+    std::vector<uint8_t> mask(std::max(n, 1));
+    int nInlier = n ? match_ref_fundamental_mask(pt1.data(), pt2.data(), n, mask.data()) : 0;
+    for (int i = 0; i < n; ++i)
+        if (!mask[i]) matches[idx[i]] = -1;
+    if (nInlier < 10) {
+        nInlier = 0;
+        for (int i = 0; i < n1; ++i) matches[i] = -1;
+    }
+    return nInlier;
 }
 
 }  // extern "C"

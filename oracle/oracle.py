@@ -405,3 +405,27 @@ def triangulate(kps_ref, kps_cur, match_idx, has_obs, P_ref, P_cur, Ocam, lower,
            None if ho is None else ho.ctypes.data, P1.ctypes.data, P2.ctypes.data, oc.ctypes.data, lower, upper,
            min_degree, pos.ctypes.data, good.ctypes.data, C.byref(nold))
     return pos[:n], good[:n], m, int(ng), int(nold.value)
+
+
+def fundamental_mask(pt1, pt2):
+    """cv::findFundamentalMat(pt1, pt2, mask) with the defaults (FM_RANSAC, 3 px, 0.99) -> (mask (n,) u8, n_inliers)"""
+    p1 = np.ascontiguousarray(pt1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(pt2, np.float32).reshape(-1, 2)
+    n = len(p1)
+    mask = np.zeros(max(n, 1), np.uint8)
+    f = lib().match_ref_fundamental_mask
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    ni = f(p1.ctypes.data, p2.ctypes.data, n, mask.ctypes.data)
+    return mask[:n], int(ni)
+
+
+def remove_outliers(kps1, kps2, matches):
+    """Track::removeOutliers -> (matches with the outliers set to -1, n_inliers)"""
+    k1 = np.ascontiguousarray(kps1); k2 = np.ascontiguousarray(kps2)
+    m = np.ascontiguousarray(matches, np.int32).copy()
+    f = lib().match_ref_remove_outliers
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    ni = f(k1.ctypes.data, len(k1), k2.ctypes.data, len(k2), m.ctypes.data)
+    return m, int(ni)

@@ -28,6 +28,7 @@ PER_FILE = {
     "orb.hip": ["-ffp-contract=off"],
     "match.hip": ["-ffp-contract=off"],
     "triangulate.hip": ["-ffp-contract=off"],
+    "ransac.hip": ["-ffp-contract=off"],
 }
 
 

@@ -85,5 +85,15 @@ int main() {
     std::vector<int> m12;
     const int nm = matcher.MatchByWindow(f, f, prev, 20, m12);
     std::printf("ORBmatcher adapter: %d self-matches of %zu\n", nm, kps.size());
-    return kps.empty() ? 1 : 0;
+    TrackGeometry track;
+    // forward motion with a different depth per point: kp2 = c + (kp - c) * s_i, epipole at c => every match is exact
+    std::vector<KeyPoint> kps2 = kps;
+    for (size_t i = 0; i < kps2.size(); ++i) {
+        const float s = 1.f + 0.05f * (float)(i % 7 + 1) / 7.f;
+        kps2[i].pt.x = 320.f + (kps[i].pt.x - 320.f) * s;
+        kps2[i].pt.y = 240.f + (kps[i].pt.y - 240.f) * s;
+    }
+    const int nInlier = track.removeOutliers(kps, kps2, m12);
+    std::printf("Track::removeOutliers adapter: %d inliers of %d matches\n", nInlier, nm);
+    return kps.empty() || nInlier != nm ? 1 : 0;
 }

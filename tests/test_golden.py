@@ -41,6 +41,23 @@ def test_oracle_match_window_matches_fixture(oracle, synth):
     assert digest(np.asarray(m, np.int32), prev) == GOLD["match_window_0_1"]["sha256"]
 
 
+def _corrupted_matches(m, n2):
+    rng = np.random.default_rng(7)
+    mm = np.asarray(m, np.int32).copy()
+    bad = rng.choice(np.flatnonzero(mm >= 0), 60, replace=False)
+    mm[bad] = rng.integers(0, n2, 60)
+    return mm
+
+
+def test_oracle_remove_outliers_matches_fixture(oracle, synth):
+    k0, d0 = oracle.orb_extract(synth.frame(0))
+    k1, d1 = oracle.orb_extract(synth.frame(1))
+    m, n, prev = oracle.match_window(k0, d0, k1, d1, None, 20, 1, 0, 8, 0.9)
+    kept, ninl = oracle.remove_outliers(k0, k1, _corrupted_matches(m, len(k1)))
+    assert ninl == GOLD["remove_outliers_0_1"]["ninliers"]
+    assert digest(kept) == GOLD["remove_outliers_0_1"]["sha256"]
+
+
 def test_oracle_ba_matches_fixture(oracle, synth):
     g = synth.ba_graph(8, 60)
     p, l, st = oracle.ba_optimize(g, 10, 0)
@@ -68,6 +85,11 @@ def test_hip_orb_and_match_equal_fixture(synth):
     n, m = ORBmatcher(0.9).MatchByWindow(k0, d0, k1, d1, prev, 20)
     assert n == GOLD["match_window_0_1"]["nmatches"]
     assert digest(np.asarray(m, np.int32), prev) == GOLD["match_window_0_1"]["sha256"]
+    from se2lam_amd.track import Track
+    mm = _corrupted_matches(m, len(k1))
+    ninl = Track().removeOutliers(k0, k1, mm)                                       # Track.cpp:134
+    assert ninl == GOLD["remove_outliers_0_1"]["ninliers"]
+    assert digest(mm) == GOLD["remove_outliers_0_1"]["sha256"]
 
 
 @pytest.mark.gpu

@@ -40,6 +40,13 @@ def build():
     k1, d1 = oracle.orb_extract(synth.frame(1))
     m, n, prev = oracle.match_window(k0, d0, k1, d1, None, 20, 1, 0, 8, 0.9)
     out["match_window_0_1"] = {"nmatches": int(n), "sha256": digest(np.asarray(m, np.int32), prev)}
+    # Track::removeOutliers on those matches (Track.cpp:134) with 60 of them corrupted
+    rng = np.random.default_rng(7)
+    mm = np.asarray(m, np.int32).copy()
+    bad = rng.choice(np.flatnonzero(mm >= 0), 60, replace=False)
+    mm[bad] = rng.integers(0, len(k1), 60)
+    kept, ninl = oracle.remove_outliers(k0, k1, mm)
+    out["remove_outliers_0_1"] = {"ninliers": int(ninl), "sha256": digest(kept)}
     # BA: config-3-shaped and tiny graphs, 10 LM iterations
     for P, L in ((8, 60), (50, 5000)):
         g = synth.ba_graph(P, L)
