@@ -248,6 +248,11 @@ int se2gpu_track_fundamental_mask(se2gpu_track* h, const float* pt1, const float
 int se2gpu_track_remove_outliers(se2gpu_track* h, const se2gpu_keypoint* kps1, int n1, const se2gpu_keypoint* kps2,
                                  int n2, int32_t* matches, int* n_inliers);
 int se2gpu_track_last_ransac(const se2gpu_track* h, int info[4]);
+/* se2gpu_triangulate (below) on the workspace of the tracking thread: one packed upload / download, no allocation */
+int se2gpu_track_triangulate(se2gpu_track* h, int n, const se2gpu_keypoint* kps_ref, const se2gpu_keypoint* kps_cur,
+                             int n_cur, int32_t* match_idx, const uint8_t* has_observation, const float* P_ref,
+                             const float* P_cur, const float* Ocam, float lower_depth, float upper_depth,
+                             int min_degree, float* pos_out, uint8_t* good_parallax, int* n_good, int* n_tracked_old);
 
 /* Per-observation information matrices of Map::loadLocalGraph (/root/reference/src/Map.cpp:1024-1049), SURVEY §8f.1:
  *   Sigma = s_rot * J_r J_r^T + s_z * J_z J_z^T + sigma2 * I,   Omega = Sigma^-1       (2x2, FP64)

@@ -66,6 +66,27 @@ public:
         return nInlier;
     }
 
+    // Track::doTriangulate on this workspace (no allocation per call); arguments as the free function above
+    TriangulationResult doTriangulate(const std::vector<KeyPoint>& keyPointsUnRef,
+                                      const std::vector<KeyPoint>& keyPointsUnCur, std::vector<int>& matchIdx,
+                                      const std::vector<uint8_t>& hasObservation, const float PrjMtrxEye[12],
+                                      const float P[12], const float Ocam[3], float lowerDepth, float upperDepth,
+                                      int minDegree = 2) {
+        TriangulationResult r;
+        const int n = (int)keyPointsUnRef.size();
+        r.localMPs.assign(n, Point3f{0, 0, 0});
+        r.goodPrl.assign(n, 0);
+        if (n == 0) return r;
+        check(se2gpu_track_triangulate(h_, n, reinterpret_cast<const se2gpu_keypoint*>(keyPointsUnRef.data()),
+                                       reinterpret_cast<const se2gpu_keypoint*>(keyPointsUnCur.data()),
+                                       (int)keyPointsUnCur.size(), matchIdx.data(),
+                                       hasObservation.empty() ? nullptr : hasObservation.data(), PrjMtrxEye, P, Ocam,
+                                       lowerDepth, upperDepth, minDegree, reinterpret_cast<float*>(r.localMPs.data()),
+                                       r.goodPrl.data(), &r.nGoodPrl, &r.nTrackedOld),
+              "se2gpu_track_triangulate");
+        return r;
+    }
+
     // cv::findFundamentalMat(pt1, pt2, mask): pt = (x, y) pairs
     int findFundamentalMask(const std::vector<float>& pt1, const std::vector<float>& pt2, std::vector<uint8_t>& mask) {
         const int n = (int)(pt1.size() / 2);

@@ -119,6 +119,8 @@ SYMBOLS = {
     "se2gpu_track_fundamental_mask": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(C.c_int)]),
     "se2gpu_track_remove_outliers": (_I, [_VP, _VP, _I, _VP, _I, _VP, C.POINTER(C.c_int)]),
     "se2gpu_track_last_ransac": (_I, [_VP, _VP]),
+    "se2gpu_track_triangulate": (_I, [_VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _I, _VP, _VP,
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se2gpu_ba_reduce_buffer_doubles": (_SZ, [_VP, _I]),
     "se2gpu_ba_set_allreduce": (_I, [_VP, ALLREDUCE_FN, _VP, _VP]),
     "se2gpu_ba_set_shard": (_I, [_VP, _I, _I]),

@@ -22,7 +22,7 @@
 // made of + - * / sqrt, with the same branches and root order, so that the result does not depend on a math library;
 // the CPU test restatement runs the identical operation sequence and the masks agree bit for bit.  Compiled with
 // -ffp-contract=off.  Agreement with OpenCV itself is unpinned (not installed here).
-#include "common.h"
+#include "track_ws.h"
 
 #include <algorithm>
 
@@ -373,20 +373,6 @@ struct CvRng {   // cv::RNG (multiply-with-carry), seeded with (uint64)-1 by bot
 }  // namespace se2gpu
 
 using namespace se2gpu;
-
-struct se2gpu_track {
-    hipStream_t stream = nullptr;
-    PinBuf<uint8_t> h_in, h_out;
-    DevBuf<uint8_t> d_in, d_out;
-    DevBuf<double> d_F, d_score;
-    DevBuf<int> d_nm;
-    std::vector<int> subsets;   // cached: depends on the point count only
-    int subsets_n = -1;
-    std::vector<float> pt1, pt2;
-    std::vector<int> idx;
-    std::vector<uint8_t> mask;
-    int last_info[4] = {0, -1, -1, 0};
-};
 
 extern "C" int se2gpu_track_create(se2gpu_track** out) {
     SE2_REQUIRE(out, SE2GPU_ERR_INVALID, "track_create: NULL argument");

@@ -8,7 +8,7 @@
 // restatement executes the identical operation sequence, so the two agree bit for bit; agreement with OpenCV's own
 // float iteration is unpinned (OpenCV is not installed), expected ~1e-5 relative.
 // Compiled with -ffp-contract=off like the matchers.
-#include "common.h"
+#include "track_ws.h"
 
 namespace se2gpu {
 namespace {
@@ -166,6 +166,67 @@ extern "C" int se2gpu_triangulate(int n, const se2gpu_keypoint* kps_ref, const s
     SE2_HIP(hipMemcpyAsync(match_idx, d_m.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipMemcpyAsync(cnt, d_cnt.p, sizeof(cnt), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipStreamSynchronize(st));
+    if (n_good) *n_good = cnt[0];
+    if (n_tracked_old) *n_tracked_old = cnt[1];
+    return SE2GPU_OK;
+}
+
+// The same pass with the persistent workspace of a tracking thread: one packed upload, one packed download.
+extern "C" int se2gpu_track_triangulate(se2gpu_track* h, int n, const se2gpu_keypoint* kps_ref,
+                                        const se2gpu_keypoint* kps_cur, int n_cur, int32_t* match_idx,
+                                        const uint8_t* has_observation, const float* P_ref, const float* P_cur,
+                                        const float* Ocam, float lower_depth, float upper_depth, int min_degree,
+                                        float* pos_out, uint8_t* good_parallax, int* n_good, int* n_tracked_old) {
+    SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "track_triangulate: NULL handle");
+    SE2_REQUIRE(n >= 0 && n_cur >= 0, SE2GPU_ERR_INVALID, "triangulate: negative size");
+    SE2_REQUIRE(min_degree >= 1 && min_degree <= 4, SE2GPU_ERR_INVALID, "triangulate: minDegree must be 1..4");
+    if (n_good) *n_good = 0;
+    if (n_tracked_old) *n_tracked_old = 0;
+    if (n == 0) return SE2GPU_OK;
+    SE2_REQUIRE(kps_ref && kps_cur && match_idx && P_ref && P_cur && Ocam && pos_out && good_parallax,
+                SE2GPU_ERR_INVALID, "triangulate: NULL argument");
+    const float minCos[4] = {0.9998f, 0.9994f, 0.9986f, 0.9976f};   // cvutil.cpp:96
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    // input  [kps_ref | kps_cur | match_idx | has_obs | P (24 floats)], output [pos | match_idx | counters | good]
+    const size_t o_k1 = 0, o_k2 = up16(o_k1 + (size_t)n * sizeof(se2gpu_keypoint));
+    const size_t o_m = up16(o_k2 + (size_t)std::max(n_cur, 1) * sizeof(se2gpu_keypoint));
+    const size_t o_obs = up16(o_m + (size_t)n * sizeof(int)), o_P = up16(o_obs + (size_t)n);
+    const size_t in_b = o_P + 24 * sizeof(float);
+    const size_t q_pos = 0, q_m = up16(q_pos + 3 * (size_t)n * sizeof(float)), q_cnt = up16(q_m + (size_t)n * sizeof(int));
+    const size_t q_good = q_cnt + 16, out_b = up16(q_good + (size_t)n);
+    SE2_CHECK(h->h_in.reserve(in_b));
+    SE2_CHECK(h->d_in.reserve(in_b));
+    SE2_CHECK(h->h_out.reserve(out_b));
+    SE2_CHECK(h->d_out.reserve(out_b));
+    uint8_t* hi = h->h_in.p;
+    std::memcpy(hi + o_k1, kps_ref, (size_t)n * sizeof(se2gpu_keypoint));
+    if (n_cur) std::memcpy(hi + o_k2, kps_cur, (size_t)n_cur * sizeof(se2gpu_keypoint));
+    std::memcpy(hi + o_m, match_idx, (size_t)n * sizeof(int));
+    if (has_observation) std::memcpy(hi + o_obs, has_observation, (size_t)n);
+    std::memcpy(hi + o_P, P_ref, 12 * sizeof(float));
+    std::memcpy(hi + o_P + 12 * sizeof(float), P_cur, 12 * sizeof(float));
+    hipStream_t st = h->stream;
+    SE2_HIP(hipMemcpyAsync(h->d_in.p, hi, in_b, hipMemcpyHostToDevice, st));
+    uint8_t* di = h->d_in.p;
+    uint8_t* dout = h->d_out.p;
+    SE2_HIP(hipMemsetAsync(dout, 0, q_good, st));   // positions, counters
+    // the kernel updates match_idx in place: work on the copy inside the output block
+    SE2_HIP(hipMemcpyAsync(dout + q_m, di + o_m, (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, st));
+    const float* dP = (const float*)(di + o_P);
+    hipLaunchKernelGGL(k_triangulate, dim3((n + 127) / 128), dim3(128), 0, st, n, (const se2gpu_keypoint*)(di + o_k1),
+                       (const se2gpu_keypoint*)(di + o_k2), n_cur, (int*)(dout + q_m),
+                       has_observation ? (const uint8_t*)(di + o_obs) : (const uint8_t*)nullptr, dP, dP + 12, Ocam[0],
+                       Ocam[1], Ocam[2], lower_depth, upper_depth, minCos[min_degree - 1], (float*)(dout + q_pos),
+                       dout + q_good, (int*)(dout + q_cnt));
+    SE2_HIP(hipGetLastError());
+    SE2_HIP(hipMemcpyAsync(h->h_out.p, dout, out_b, hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    const uint8_t* ho = h->h_out.p;
+    std::memcpy(pos_out, ho + q_pos, 3 * (size_t)n * sizeof(float));
+    std::memcpy(match_idx, ho + q_m, (size_t)n * sizeof(int));
+    std::memcpy(good_parallax, ho + q_good, (size_t)n);
+    int cnt[2];
+    std::memcpy(cnt, ho + q_cnt, sizeof(cnt));
     if (n_good) *n_good = cnt[0];
     if (n_tracked_old) *n_tracked_old = cnt[1];
     return SE2GPU_OK;

@@ -12,7 +12,6 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .matcher import doTriangulate as _do_triangulate
 
 
 class Track:
@@ -55,7 +54,24 @@ class Track:
         capi.check(capi.lib().se2gpu_track_last_ransac(self._h, info.ctypes.data))
         return dict(inliers=int(info[0]), sample=int(info[1]), model=int(info[2]), iterations=int(info[3]))
 
-    doTriangulate = staticmethod(_do_triangulate)
+    def doTriangulate(self, kps_ref, kps_cur, match_idx, has_observation, P_ref, P_cur, Ocam, lower_depth, upper_depth,
+                      min_degree=2):
+        """Track::doTriangulate on this thread's workspace; same results as matcher.doTriangulate.
+        -> (pos (n,3) float32, good_parallax (n,) uint8, match_idx updated (n,) int32, n_good, n_tracked_old)"""
+        kps_ref = np.ascontiguousarray(kps_ref); kps_cur = np.ascontiguousarray(kps_cur)
+        n = len(kps_ref)
+        m = np.ascontiguousarray(match_idx, np.int32).copy()
+        ho = None if has_observation is None else np.ascontiguousarray(has_observation, np.uint8)
+        P1 = np.ascontiguousarray(P_ref, np.float32).reshape(-1); P2 = np.ascontiguousarray(P_cur, np.float32).reshape(-1)
+        oc = np.ascontiguousarray(Ocam, np.float32)
+        pos = np.zeros((max(n, 1), 3), np.float32)
+        good = np.zeros(max(n, 1), np.uint8)
+        ng, nold = C.c_int(0), C.c_int(0)
+        capi.check(capi.lib().se2gpu_track_triangulate(
+            self._h, n, kps_ref.ctypes.data, kps_cur.ctypes.data, len(kps_cur), m.ctypes.data,
+            None if ho is None else ho.ctypes.data, P1.ctypes.data, P2.ctypes.data, oc.ctypes.data, float(lower_depth),
+            float(upper_depth), int(min_degree), pos.ctypes.data, good.ctypes.data, C.byref(ng), C.byref(nold)))
+        return pos[:n], good[:n], m, int(ng.value), int(nold.value)
 
     def __del__(self):
         try:

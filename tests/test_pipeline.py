@@ -56,7 +56,7 @@ class _KF:
 
 @pytest.mark.gpu
 def test_config0_track_localmapper_optimizer(oracle, synth):
-    from se2lam_amd.matcher import ORBmatcher, doTriangulate
+    from se2lam_amd.matcher import ORBmatcher
     from se2lam_amd.optimizer import SlamOptimizer, edge_information
     from se2lam_amd.orb import ORBextractor
     from se2lam_amd.track import Track
@@ -105,7 +105,7 @@ def test_config0_track_localmapper_optimizer(oracle, synth):
         Ocam = np.linalg.inv(Tcr.astype(np.float64))[:3, 3].astype(np.float32)
         has_obs = np.zeros(len(ref.k), np.uint8)
         has_obs[list(ref.obs)] = 1
-        pos, good, m_tri, ngood, nold = doTriangulate(ref.k, k, m12, has_obs, P_eye, P_cur, Ocam, LOWER, UPPER, 2)
+        pos, good, m_tri, ngood, nold = track.doTriangulate(ref.k, k, m12, has_obs, P_eye, P_cur, Ocam, LOWER, UPPER, 2)
         pos_o, good_o, m_tri_o, ngood_o, nold_o = oracle.triangulate(ref.k, k, m12, has_obs, P_eye, P_cur, Ocam, LOWER,
                                                                      UPPER, 2)
         assert (ngood, nold) == (ngood_o, nold_o) and np.array_equal(m_tri, m_tri_o), t

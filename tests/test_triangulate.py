@@ -68,3 +68,20 @@ def test_hip_triangulate_equals_oracle(oracle, seed, n):
         assert got[3:] == ref[3:]
     got = doTriangulate(k1[:0], k2, match[:0], None, P1, P2, Ocam, 500.0, 8000.0)
     assert len(got[0]) == 0 and got[3] == 0
+
+
+@pytest.mark.gpu
+def test_hip_track_workspace_triangulate_equals_oracle(oracle):
+    """the same pass through the tracking thread's persistent workspace (se2gpu_track_triangulate), sizes varying
+    between calls of one handle"""
+    from se2lam_amd.track import Track
+    tr = Track()
+    for seed, n in ((7, 600), (3, 1), (11, 1000), (5, 37)):
+        k1, k2, match, has_obs, P1, P2, Ocam, X = scene(n, seed)
+        for ho in (has_obs, None):
+            ref = oracle.triangulate(k1, k2, match, ho, P1, P2, Ocam, 500.0, 8000.0, 2)
+            got = tr.doTriangulate(k1, k2, match, ho, P1, P2, Ocam, 500.0, 8000.0, 2)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+            assert got[3:] == ref[3:]
+    got = tr.doTriangulate(k1[:0], k2, match[:0], None, P1, P2, Ocam, 500.0, 8000.0)
+    assert len(got[0]) == 0 and got[3] == 0
