@@ -13,10 +13,9 @@
 //                    that the search window covers, wave-ballot ordered
 //                    compaction, 256-bit Hamming distance (4 x popcll) -> per-query candidate list (idx, dist)
 //                    - the parallel O(N1*N2) part
-//   k_resolve_*      one wave per frame pair: reproduces the greedy pass on the pre-computed lists - MatchByWindow as a
-//                    fixed-point iteration over 64 queries at a time (exactly the sequential result), MatchByProjection
-//                    in query order with wave-ballot arg-min; rotation histogram, ComputeThreeMaxima, prev-matched
-//                    update; parallel across pairs
+//   k_resolve_*      one workgroup per frame pair: reproduces the greedy pass on the pre-computed lists as a fixed-point
+//                    iteration over ALL queries at once (exactly the sequential result, see k_resolve_window);
+//                    rotation histogram, ComputeThreeMaxima, prev-matched update; parallel across pairs
 // Compiled with -ffp-contract=off (float grid / projection arithmetic must round as the reference's).
 #include <algorithm>
 #include <climits>
@@ -202,33 +201,36 @@ __device__ __forceinline__ void best2_push(Best2& b, int d, int p) {  // (d, p) 
 
 // Stage the candidate lists of `nq` queries (fixed stride kMaxCand in HBM) into LDS as one compact array so that
 // the greedy pass never waits on HBM.  off[0..nq] = exclusive prefix of min(ncand, kMaxCand); entries that
-// do not fit in `cap_e` stay in HBM (the pass falls back to global reads for those queries).  One wave.
-__device__ __forceinline__ int stage_candidates(const uint32_t* __restrict__ cand, const int* __restrict__ ncand, int nq,
-                                                int* off, uint32_t* ce, int cap_e, int* __restrict__ overflow) {
-    const int lane = threadIdx.x & 63;
-    const int per = (nq + 63) / 64;
-    int local = 0;
-    for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
-        int n = ncand[i];
-        if (n > kMaxCand) { atomicOr(overflow, 1); n = kMaxCand; }
-        local += n;
-    }
-    int incl = local;
+// do not fit in `cap_e` stay in HBM (the pass falls back to global reads for those queries).  Whole workgroup; the
+// prefix is taken by the first wave.
+__device__ __forceinline__ void stage_candidates(const uint32_t* __restrict__ cand, const int* __restrict__ ncand, int nq,
+                                                 int* off, uint32_t* ce, int cap_e, int* __restrict__ overflow) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid < 64) {
+        const int lane = tid;
+        const int per = (nq + 63) / 64;
+        int local = 0;
+        for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
+            int n = ncand[i];
+            if (n > kMaxCand) { atomicOr(overflow, 1); n = kMaxCand; }
+            local += n;
+        }
+        int incl = local;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int v = __shfl_up(incl, d);
-        if (lane >= d) incl += v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        int run = incl - local;
+        for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
+            off[i] = run;
+            run += min(ncand[i], kMaxCand);
+        }
+        if (lane == 63) off[nq] = incl;
     }
-    int run = incl - local;
-    for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
-        off[i] = run;
-        run += min(ncand[i], kMaxCand);
-    }
-    const int total = __shfl(incl, 63);
-    if (lane == 0) off[nq] = total;
     __syncthreads();
-    const int tcopy = min(total, cap_e);
-    for (int e = lane; e < tcopy; e += 64) {
+    const int tcopy = min(off[nq], cap_e);
+    for (int e = tid; e < tcopy; e += nthr) {
         int lo = 0, hi = nq;  // largest i with off[i] <= e
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
@@ -237,7 +239,6 @@ __device__ __forceinline__ int stage_candidates(const uint32_t* __restrict__ can
         ce[e] = cand[(size_t)lo * kMaxCand + (e - off[lo])];
     }
     __syncthreads();
-    return total;
 }
 
 __device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& ind2, int& ind3) {
@@ -253,131 +254,117 @@ __device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& in
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
 }
 
-// Per-lane best / second-best scan of one query's candidate list (ORBmatcher.cpp:308-325; ties go to the earliest
-// list position) against the EFFECTIVE vMatchesDistance the sequential pass would see: the committed value, lowered by
-// the tentative acceptances of EARLIER lanes of the chunk (accMask[idx] bit l' set <=> lane l' currently accepts idx
-// with distance accDist[l']).
+// Best / second-best scan of the candidate list of query q (ORBmatcher.cpp:308-325; ties go to the earliest list
+// position) against the EFFECTIVE vMatchesDistance the sequential pass would see when it reaches q: the committed value
+// (earlier chunks) lowered by the tentative acceptances of the queries below q.  The tentative acceptors of a target
+// form a linked list (head[target] -> next[query] -> ...), rebuilt before every sweep; accD[query] is the distance a
+// query accepts its target with.
 struct LaneBest {
     int bd, bp, bd2, bp2;
 };
-__device__ __forceinline__ LaneBest lane_scan(const uint32_t* cl, int n, const int* vMatchesDistance,
-                                              const unsigned long long* accMask, const int* accDist, int lane) {
+__device__ __forceinline__ LaneBest query_scan(const uint32_t* cl, int n, int q, const int* vMatchesDistance,
+                                               const int* head, const int* next, const int* accD) {
     LaneBest b{INT_MAX, -1, INT_MAX, -1};
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int t = 0; __any(t < n); ++t) {
-        if (t < n) {
-            const uint32_t pk = cl[t];
-            const int dist = (int)(pk & 0xfffu), idx = (int)(pk >> 12);
-            int eff = vMatchesDistance[idx];
-            unsigned long long m = accMask[idx] & below;
-            while (m) {
-                eff = min(eff, accDist[__ffsll((long long)m) - 1]);
-                m &= m - 1;
-            }
-            if (!(eff <= dist)) {
-                if (dist < b.bd) { b.bd2 = b.bd; b.bp2 = b.bp; b.bd = dist; b.bp = t; }
-                else if (dist < b.bd2) { b.bd2 = dist; b.bp2 = t; }
-            }
+    for (int t = 0; t < n; ++t) {
+        const uint32_t pk = cl[t];
+        const int dist = (int)(pk & 0xfffu), idx = (int)(pk >> 12);
+        int eff = vMatchesDistance ? vMatchesDistance[idx] : INT_MAX;
+        for (int a = head[idx]; a >= 0; a = next[a])
+            if (a < q) eff = min(eff, accD[a]);
+        if (!(eff <= dist)) {
+            if (dist < b.bd) { b.bd2 = b.bd; b.bp2 = b.bp; b.bd = dist; b.bp = t; }
+            else if (dist < b.bd2) { b.bd2 = dist; b.bp2 = t; }
         }
     }
     return b;
 }
 
-// MatchByWindow greedy pass (ORBmatcher.cpp:292-377), one wave per pair, parallel over queries.
+// MatchByWindow greedy pass (ORBmatcher.cpp:292-377), one workgroup per pair, parallel over ALL queries.
 // The reference processes queries in index order; query i depends on earlier queries only through
-// vMatchesDistance[idx] of its own candidates.  64 consecutive queries (one per lane) are iterated to a FIXED POINT:
-// in every sweep each lane recomputes (best, second best, accept?) against the committed state plus the tentative
-// acceptances of the lanes below it.  Lane 0 is final after sweep 1, and a lane is final once all lanes below it are,
-// so any fixed point is exactly the sequential result (induction on the lane index); dependency chains are short, so
-// 2-4 sweeps suffice in practice (worst case 64).  The chunk is then committed at once: the highest accepting lane of
-// a target owns it (the sequential eviction chain), every accept feeds the rotation histogram.
-// Dynamic LDS (ints): vMatchesDistance[cap] vnMatches21[cap] bin_of[cap] off[cap+1] m12[cap] ang1[cap] ang2[cap]
-//                     accMask[cap] (64-bit) | staged candidate entries.
-__global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __restrict__ kps,
-                                                        const int* __restrict__ counts, int cap,
-                                                        const int* __restrict__ pair_a, const int* __restrict__ pair_b,
-                                                        const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
-                                                        float nnratio, int cand_lds, int* __restrict__ matches12,
-                                                        float* __restrict__ prev_xy, int* __restrict__ nmatches,
-                                                        int* __restrict__ overflow) {
-    // ALL shared memory is dynamic and the 64-bit array sits at offset 0: with static __shared__ objects in front, the
-    // dynamic base is only 4-byte aligned and 64-bit DS atomics on it misbehave (cdna_hip_programming.md G17)
+// vMatchesDistance[idx] of its own candidates.  The whole pass is iterated to a FIXED POINT: in every sweep each query
+// recomputes (best, second best, accept?) against the tentative acceptances the queries below it held in the previous
+// sweep.  Query 0 is final after sweep 1, and a query is final one sweep after all queries below it are, so any fixed
+// point is exactly the sequential result (induction on the query index); dependency chains are short, a handful of
+// sweeps suffices in practice (worst case n1 + 1).  Afterwards the highest accepting query of a target owns it (the
+// sequential eviction chain), every accept feeds the rotation histogram.
+// Dynamic LDS (ints, capE each): head next accT accD accT2 accD2 bin_of m12 ang1 ang2 | hist[32] ind[4] | off[capE + 4]
+//                                | staged candidate entries.
+__global__ __launch_bounds__(1024) void k_resolve_window(const se2gpu_keypoint* __restrict__ kps,
+                                                          const int* __restrict__ counts, int cap,
+                                                          const int* __restrict__ pair_a, const int* __restrict__ pair_b,
+                                                          const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
+                                                          float nnratio, int cand_lds, int* __restrict__ matches12,
+                                                          float* __restrict__ prev_xy, int* __restrict__ nmatches,
+                                                          int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     const int p = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int fa = pair_a[p], fb = pair_b[p];
     const int n1 = min(counts[fa], cap), n2 = min(counts[fb], cap);
     const int capE = (cap + 3) & ~3;
-    unsigned long long* accMask = (unsigned long long*)lds;                // capE entries = 2*capE ints
-    int* vMatchesDistance = lds + 2 * capE;
-    int* vnMatches21 = lds + 3 * capE;
-    int* bin_of = lds + 4 * capE;
-    int* m12 = lds + 5 * capE;
-    float* ang1 = (float*)(lds + 6 * capE);
-    float* ang2 = (float*)(lds + 7 * capE);
-    int* hist = lds + 8 * capE;                      // 32
-    int* s_ind = lds + 8 * capE + 32;                // 4
-    int* accDist = lds + 8 * capE + 36;              // 64
-    int* off = lds + 8 * capE + 100;                 // cap + 1 entries
-    uint32_t* ce = (uint32_t*)(lds + 9 * capE + 104);
+    int* head = lds;
+    int* next = lds + capE;
+    int* accT = lds + 2 * capE;
+    int* accD = lds + 3 * capE;
+    int* accT2 = lds + 4 * capE;
+    int* accD2 = lds + 5 * capE;
+    int* bin_of = lds + 6 * capE;
+    int* m12 = lds + 7 * capE;
+    float* ang1 = (float*)(lds + 8 * capE);
+    float* ang2 = (float*)(lds + 9 * capE);
+    int* hist = lds + 10 * capE;                     // 32
+    int* s_ind = lds + 10 * capE + 32;               // 4
+    int* off = lds + 10 * capE + 36;                 // cap + 1 entries
+    uint32_t* ce = (uint32_t*)(lds + 11 * capE + 40);
     const se2gpu_keypoint* k1 = kps + (size_t)fa * cap;
     const se2gpu_keypoint* k2 = kps + (size_t)fb * cap;
-    for (int i = lane; i < n2; i += 64) {
-        vMatchesDistance[i] = INT_MAX; vnMatches21[i] = -1; ang2[i] = k2[i].angle; accMask[i] = 0ull;
-    }
-    for (int i = lane; i < n1; i += 64) { bin_of[i] = -1; m12[i] = -1; ang1[i] = k1[i].angle; }
-    if (lane < kHisto) hist[lane] = 0;
+    for (int i = tid; i < n2; i += nthr) ang2[i] = k2[i].angle;
+    for (int i = tid; i < n1; i += nthr) { bin_of[i] = -1; m12[i] = -1; accT[i] = -1; accD[i] = 0; ang1[i] = k1[i].angle; }
+    if (tid < kHisto) hist[tid] = 0;
     const uint32_t* cand_p = cand + (size_t)p * cap * kMaxCand;
     stage_candidates(cand_p, ncand + (size_t)p * cap, n1, off, ce, cand_lds, overflow);
-    const float factor = (float)kHisto / 360.0f;
-    const unsigned long long bit = 1ull << lane;
-    for (int c0 = 0; c0 < n1; c0 += 64) {
-        const int q = c0 + lane;
-        int n = 0, o0 = 0;
-        if (q < n1) { o0 = off[q]; n = off[q + 1] - o0; }
-        const uint32_t* cl = (o0 + n <= cand_lds) ? ce + o0 : cand_p + (size_t)q * kMaxCand;
-        bool acc = false;
-        int bidx = -1, bd = 0;
-        for (int sweep = 0; sweep < 65; ++sweep) {
-            const LaneBest b = lane_scan(cl, n, vMatchesDistance, accMask, accDist, lane);
+    for (int sweep = 0; sweep <= n1 + 1; ++sweep) {
+        for (int t = tid; t < n2; t += nthr) head[t] = -1;
+        __syncthreads();
+        for (int q = tid; q < n1; q += nthr)
+            if (accT[q] >= 0) next[q] = atomicExch(&head[accT[q]], q);
+        __syncthreads();
+        int changed = 0;
+        for (int q = tid; q < n1; q += nthr) {
+            const int o0 = off[q], n = off[q + 1] - o0;
+            const uint32_t* cl = (o0 + n <= cand_lds) ? ce + o0 : cand_p + (size_t)q * kMaxCand;
+            const LaneBest b = query_scan(cl, n, q, nullptr, head, next, accD);
             const bool nacc = b.bp >= 0 && b.bd <= kThLow && (float)b.bd < (float)b.bd2 * nnratio;
             const int nidx = nacc ? (int)(cl[b.bp] >> 12) : -1;
-            const bool changed = nacc != acc || (nacc && (nidx != bidx || b.bd != bd));
-            const unsigned long long chg = __ballot(changed);
-            __syncthreads();                           // every lane has read the masks of this sweep
-            if (!chg) break;
-            if (changed) {
-                if (acc) atomicAnd(&accMask[bidx], ~bit);
-                if (nacc) { atomicOr(&accMask[nidx], bit); accDist[lane] = b.bd; }
-                acc = nacc; bidx = nidx; bd = b.bd;
-            }
-            __syncthreads();
+            const int nd = nacc ? b.bd : 0;
+            changed |= (nidx != accT[q]) | (nd != accD[q]);
+            accT2[q] = nidx;
+            accD2[q] = nd;
         }
-        // commit the chunk
-        if (acc) {
-            float rot = ang1[q] - ang2[bidx];
-            if (rot < 0.0f) rot += 360.f;
-            int bin = (int)roundf(rot * factor);
-            if (bin == kHisto) bin = 0;
-            bin_of[q] = bin;
-            atomicAdd(&hist[bin], 1);
-            const unsigned long long am = accMask[bidx];
-            if ((63 - __clzll((long long)am)) == lane) {   // highest accepting lane owns the target
-                const int prev = vnMatches21[bidx];
-                if (prev >= 0) m12[prev] = -1;             // owner from an earlier chunk is evicted
-                vnMatches21[bidx] = q;
-                vMatchesDistance[bidx] = bd;
-                m12[q] = bidx;
-            }                                              // else: evicted by a later lane of this chunk
-        }
-        __syncthreads();
-        if (acc) accMask[bidx] = 0ull;
-        __syncthreads();
+        if (!__syncthreads_or(changed)) break;       // fixed point: accT / accD and the lists built from them are final
+        int* t0 = accT; accT = accT2; accT2 = t0;
+        int* t1 = accD; accD = accD2; accD2 = t1;
     }
-    if (lane == 0) three_maxima(hist, s_ind[0], s_ind[1], s_ind[2]);
+    // commit
+    const float factor = (float)kHisto / 360.0f;
+    for (int q = tid; q < n1; q += nthr) {
+        const int t = accT[q];
+        if (t < 0) continue;
+        float rot = ang1[q] - ang2[t];
+        if (rot < 0.0f) rot += 360.f;
+        int bin = (int)roundf(rot * factor);
+        if (bin == kHisto) bin = 0;
+        bin_of[q] = bin;
+        atomicAdd(&hist[bin], 1);
+        int owner = -1;
+        for (int a = head[t]; a >= 0; a = next[a]) owner = max(owner, a);
+        if (owner == q) m12[q] = t;                   // the last accepting query keeps the target, the others were evicted
+    }
+    __syncthreads();
+    if (tid == 0) { three_maxima(hist, s_ind[0], s_ind[1], s_ind[2]); s_ind[3] = 0; }
     __syncthreads();
     int cnt = 0;
-    for (int i = lane; i < n1; i += 64) {
+    for (int i = tid; i < n1; i += nthr) {
         const int bin = bin_of[i];
         int m = m12[i];
         if (bin >= 0 && bin != s_ind[0] && bin != s_ind[1] && bin != s_ind[2] && m >= 0) m = -1;
@@ -389,7 +376,9 @@ __global__ __launch_bounds__(64) void k_resolve_window(const se2gpu_keypoint* __
         matches12[(size_t)p * cap + i] = m;
     }
     for (int sft = 1; sft < 64; sft <<= 1) cnt += __shfl_xor(cnt, sft);
-    if (lane == 0) nmatches[p] = cnt;
+    if ((tid & 63) == 0 && cnt) atomicAdd(&s_ind[3], cnt);
+    __syncthreads();
+    if (tid == 0) nmatches[p] = s_ind[3];
 }
 
 // prev_xy of pair p = key point positions of frame a (Track::resetLocalTrack, Track.cpp:194)
@@ -449,82 +438,84 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
     if ((threadIdx.x & 63) == 0) ncand[i] = n;
 }
 
-// MatchByProjection greedy pass (ORBmatcher.cpp:390-451), one wave, parallel over map points: the same fixed-point
-// scheme as k_resolve_window.  64 consecutive map points (one per lane) are swept until no lane changes its
-// (accept?, target, distance); lane l sees the committed vMatchesDistance lowered by the tentative acceptances of the
-// lanes below it, so the fixed point is the sequential result.  On commit the highest accepting lane of a target owns
-// vMatchesIdxMP[target] (the reference overwrites the earlier owner) and leaves its - smallest - distance behind.
-// Dynamic LDS (ints): accMask[nE] (64-bit, offset 0) | vMatchesDistance[nE] | octave[nE] | accDist[64] |
-//                     off[chunk+1] | staged candidate entries.
-__global__ __launch_bounds__(64) void k_resolve_projection(const se2gpu_keypoint* __restrict__ kps, int n, int m,
-                                                            const uint32_t* __restrict__ cand,
-                                                            const int* __restrict__ ncand, float nnratio,
-                                                            int chunk, int cand_lds, int* __restrict__ match_idx,
-                                                            int* __restrict__ nmatches, int* __restrict__ overflow) {
+// MatchByProjection greedy pass (ORBmatcher.cpp:390-451), one workgroup, parallel over map points: the same fixed-point
+// scheme as k_resolve_window, applied to chunks of `chunk` map points (the candidate lists of a chunk are staged in LDS);
+// a chunk starts from the vMatchesDistance the earlier chunks committed.  On commit the highest accepting map point of a
+// feature owns vMatchesIdxMP[feature] (the reference overwrites the earlier owner) and leaves its - smallest - distance.
+// Dynamic LDS (ints): head[nE] vMatchesDistance[nE] octave[nE] | next accT accD accT2 accD2 [chunk each] |
+//                     off[chunk + 4] | staged candidate entries.
+__global__ __launch_bounds__(1024) void k_resolve_projection(const se2gpu_keypoint* __restrict__ kps, int n, int m,
+                                                              const uint32_t* __restrict__ cand,
+                                                              const int* __restrict__ ncand, float nnratio,
+                                                              int chunk, int cand_lds, int* __restrict__ match_idx,
+                                                              int* __restrict__ nmatches, int* __restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    const int lane = threadIdx.x;
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int nE = (n + 3) & ~3;
-    unsigned long long* accMask = (unsigned long long*)lds;
-    int* vMatchesDistance = lds + 2 * nE;
-    int* octave = lds + 3 * nE;
-    int* accDist = lds + 4 * nE;                         // 64
-    int* off = lds + 4 * nE + 64;                        // chunk + 1 entries
-    uint32_t* ce = (uint32_t*)(lds + 4 * nE + 64 + chunk + 1);
-    for (int i = lane; i < n; i += 64) {
-        vMatchesDistance[i] = INT_MAX; accMask[i] = 0ull; octave[i] = kps[i].octave; match_idx[i] = -1;
-    }
+    int* head = lds;
+    int* vMatchesDistance = lds + nE;
+    int* octave = lds + 2 * nE;
+    int* next = lds + 3 * nE;
+    int* accT = next + chunk;
+    int* accD = accT + chunk;
+    int* accT2 = accD + chunk;
+    int* accD2 = accT2 + chunk;
+    int* off = accD2 + chunk;                            // chunk + 1 entries
+    uint32_t* ce = (uint32_t*)(off + chunk + 4);
+    for (int i = tid; i < n; i += nthr) { vMatchesDistance[i] = INT_MAX; octave[i] = kps[i].octave; match_idx[i] = -1; }
+    if (tid == 0) s_cnt = 0;
     __syncthreads();
-    const unsigned long long bit = 1ull << lane;
-    // map points are processed in chunks whose candidate lists are staged in LDS
     for (int i0 = 0; i0 < m; i0 += chunk) {
-      const int mq = min(chunk, m - i0);
-      stage_candidates(cand + (size_t)i0 * kMaxCand, ncand + i0, mq, off, ce, cand_lds, overflow);
-      for (int c0 = 0; c0 < mq; c0 += 64) {
-        const int q = c0 + lane;
-        int nc = 0, o0 = 0;
-        if (q < mq) { o0 = off[q]; nc = off[q + 1] - o0; }
-        if (!__any(nc > 0)) continue;
-        const uint32_t* cl = (o0 + nc <= cand_lds) ? ce + o0 : cand + (size_t)(i0 + q) * kMaxCand;
-        bool acc = false;
-        int bidx = -1, bd = 0;
-        for (int sweep = 0; sweep < 65; ++sweep) {
-            const LaneBest b = lane_scan(cl, nc, vMatchesDistance, accMask, accDist, lane);
-            bool nacc = b.bp >= 0 && b.bd <= kThHigh;
-            int nidx = -1;
-            if (nacc) {
-                nidx = (int)(cl[b.bp] >> 12);
-                const int bestLevel2 = b.bp2 >= 0 ? octave[cl[b.bp2] >> 12] : -1;
-                if (octave[nidx] == bestLevel2 && (float)b.bd > nnratio * (float)b.bd2) { nacc = false; nidx = -1; }
-            }
-            const bool changed = nacc != acc || (nacc && (nidx != bidx || b.bd != bd));
-            const unsigned long long chg = __ballot(changed);
-            __syncthreads();                           // every lane has read the masks of this sweep
-            if (!chg) break;
-            if (changed) {
-                if (acc) atomicAnd(&accMask[bidx], ~bit);
-                if (nacc) { atomicOr(&accMask[nidx], bit); accDist[lane] = b.bd; }
-                acc = nacc; bidx = nidx; bd = b.bd;
-            }
+        const int mq = min(chunk, m - i0);
+        const uint32_t* cand_c = cand + (size_t)i0 * kMaxCand;
+        stage_candidates(cand_c, ncand + i0, mq, off, ce, cand_lds, overflow);
+        for (int q = tid; q < mq; q += nthr) { accT[q] = -1; accD[q] = 0; }
+        for (int sweep = 0; sweep <= mq + 1; ++sweep) {
+            for (int t = tid; t < n; t += nthr) head[t] = -1;
             __syncthreads();
+            for (int q = tid; q < mq; q += nthr)
+                if (accT[q] >= 0) next[q] = atomicExch(&head[accT[q]], q);
+            __syncthreads();
+            int changed = 0;
+            for (int q = tid; q < mq; q += nthr) {
+                const int o0 = off[q], nc = off[q + 1] - o0;
+                const uint32_t* cl = (o0 + nc <= cand_lds) ? ce + o0 : cand_c + (size_t)q * kMaxCand;
+                const LaneBest b = query_scan(cl, nc, q, vMatchesDistance, head, next, accD);
+                bool nacc = b.bp >= 0 && b.bd <= kThHigh;
+                int nidx = -1;
+                if (nacc) {
+                    nidx = (int)(cl[b.bp] >> 12);
+                    const int bestLevel2 = b.bp2 >= 0 ? octave[cl[b.bp2] >> 12] : -1;
+                    if (octave[nidx] == bestLevel2 && (float)b.bd > nnratio * (float)b.bd2) { nacc = false; nidx = -1; }
+                }
+                const int nd = nacc ? b.bd : 0;
+                changed |= (nidx != accT[q]) | (nd != accD[q]);
+                accT2[q] = nidx;
+                accD2[q] = nd;
+            }
+            if (!__syncthreads_or(changed)) break;
+            int* t0 = accT; accT = accT2; accT2 = t0;
+            int* t1 = accD; accD = accD2; accD2 = t1;
         }
-        if (acc) {
-            const unsigned long long am = accMask[bidx];
-            if ((63 - __clzll((long long)am)) == lane) {   // the last accepting map point keeps the feature
-                match_idx[bidx] = i0 + q;
-                vMatchesDistance[bidx] = bd;
+        for (int q = tid; q < mq; q += nthr) {           // commit the chunk
+            const int t = accT[q];
+            if (t < 0) continue;
+            int owner = -1;
+            for (int a = head[t]; a >= 0; a = next[a]) owner = max(owner, a);
+            if (owner == q) {                            // the last accepting map point keeps the feature
+                match_idx[t] = i0 + q;
+                vMatchesDistance[t] = accD[q];
             }
         }
         __syncthreads();
-        if (acc) accMask[bidx] = 0ull;
-        __syncthreads();
-      }
-      __syncthreads();
     }
-    __syncthreads();
     int cnt = 0;
-    for (int i = lane; i < n; i += 64) cnt += match_idx[i] >= 0;
-    for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
-    if (lane == 0) nmatches[0] = cnt;
+    for (int i = tid; i < n; i += nthr) cnt += match_idx[i] >= 0;
+    for (int s2 = 1; s2 < 64; s2 <<= 1) cnt += __shfl_xor(cnt, s2);
+    if ((tid & 63) == 0 && cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0) nmatches[0] = s_cnt;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -633,6 +624,9 @@ struct se2gpu_matcher {
     DevBuf<uint8_t> desc, mp_desc, mp_skip, kf_obs, has1, has2;
     DevBuf<int> fvp1, fvi1, fvp2, fvi2, bin_of, hist;
     DevBuf<int2> node_pairs;
+    // single-call paths (host buffers in, host buffers out): one packed block each way
+    PinBuf<uint8_t> stage_h;
+    DevBuf<uint8_t> stage_d;
     ~se2gpu_matcher() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
@@ -656,7 +650,8 @@ int check_overflow(se2gpu_matcher* h) {
 int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_kps, const uint8_t* d_desc,
                  const int32_t* d_counts, int cap, int nframes_hint, const int32_t* d_pair_a, const int32_t* d_pair_b,
                  int npairs, int win, int level_offset, int min_level, int max_level, float nnratio, float* d_prev,
-                 bool init_prev, int32_t* d_matches12, int32_t* d_nmatches) {
+                 bool init_prev, int32_t* d_matches12, int32_t* d_nmatches, int* d_overflow = nullptr) {
+    if (!d_overflow) d_overflow = h->overflow.p;
     hipStream_t st = h->stream;
     SE2_REQUIRE(cap <= kMaxFeat && cap <= 65536, SE2GPU_ERR_CAPACITY, "cap %d exceeds the matcher limit %d", cap, kMaxFeat);
     // grid order of every frame that appears as a target (all frames < nframes_hint: cheap)
@@ -672,8 +667,8 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     hipLaunchKernelGGL(k_cand_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, st, bd, d_kps, d_desc, d_counts, cap,
                        d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win, level_offset, min_level, max_level,
                        h->cand.p, h->ncand.p);
-    const size_t fixed_lds = ((size_t)9 * ((cap + 3) & ~3) + 104) * sizeof(int);
-    constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: one wave per pair, occupancy is irrelevant here
+    const size_t fixed_lds = ((size_t)11 * ((cap + 3) & ~3) + 48) * sizeof(int);
+    constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: one workgroup per pair and CU
     SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY,
                 "cap %d needs %zu B of LDS in the resolve pass (limit %zu)", cap, fixed_lds, kLdsBudget);
     static bool attr_set = false;
@@ -683,8 +678,9 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     }
     const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));  // staged candidate entries
     const size_t lds = fixed_lds + (size_t)cand_lds * sizeof(int);
-    hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(64), lds, st, d_kps, d_counts, cap, d_pair_a, d_pair_b,
-                       h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, h->overflow.p);
+    const int resolve_threads = std::min(1024, std::max(64, (cap + 63) & ~63));
+    hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(resolve_threads), lds, st, d_kps, d_counts, cap, d_pair_a,
+                       d_pair_b, h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, d_overflow);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -756,32 +752,40 @@ int se2gpu_match_window(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds, co
                 "match_window: NULL buffer");
     hipStream_t st = h->stream;
     const int cap = std::max(std::max(n1, n2), 1);
-    SE2_CHECK(h->kps.reserve(2 * (size_t)cap));
-    SE2_CHECK(h->desc.reserve(2 * (size_t)cap * 32));
-    SE2_CHECK(h->counts.reserve(2));
-    SE2_CHECK(h->pair_a.reserve(1));
-    SE2_CHECK(h->pair_b.reserve(1));
-    SE2_CHECK(h->prev.reserve((size_t)cap * 2));
-    SE2_CHECK(h->matches.reserve((size_t)cap));
-    SE2_CHECK(h->nmatches.reserve(1));
-    const int cnt[2] = {n1, n2}, pa = 0, pb = 1;
-    SE2_HIP(hipMemcpyAsync(h->kps.p, kps1, (size_t)n1 * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->desc.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
+    // one block both ways: [matches12 | prev_xy | nmatches, overflow, counts(2), pair_a, pair_b | kps (2 cap) | desc (2 cap)]
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_m = 0, o_prev = up16(o_m + (size_t)cap * sizeof(int)), o_sc = up16(o_prev + (size_t)cap * 2 * sizeof(float));
+    const size_t o_kps = o_sc + 32, o_desc = up16(o_kps + 2 * (size_t)cap * sizeof(se2gpu_keypoint));
+    const size_t total = o_desc + 2 * (size_t)cap * 32;
+    SE2_CHECK(h->stage_h.reserve(total));
+    SE2_CHECK(h->stage_d.reserve(total));
+    uint8_t* hs = h->stage_h.p;
+    uint8_t* ds = h->stage_d.p;
+    std::memcpy(hs + o_prev, prev_xy, (size_t)n1 * 2 * sizeof(float));
+    const int sc[8] = {0, 0, n1, n2, 0, 1, 0, 0};
+    std::memcpy(hs + o_sc, sc, sizeof(sc));
+    std::memcpy(hs + o_kps, kps1, (size_t)n1 * sizeof(se2gpu_keypoint));
+    std::memcpy(hs + o_desc, desc1, (size_t)n1 * 32);
     if (n2) {
-        SE2_HIP(hipMemcpyAsync(h->kps.p + cap, kps2, (size_t)n2 * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
-        SE2_HIP(hipMemcpyAsync(h->desc.p + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+        std::memcpy(hs + o_kps + (size_t)cap * sizeof(se2gpu_keypoint), kps2, (size_t)n2 * sizeof(se2gpu_keypoint));
+        std::memcpy(hs + o_desc + (size_t)cap * 32, desc2, (size_t)n2 * 32);
     }
-    SE2_HIP(hipMemcpyAsync(h->counts.p, cnt, sizeof(cnt), hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->pair_a.p, &pa, sizeof(int), hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->pair_b.p, &pb, sizeof(int), hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->prev.p, prev_xy, (size_t)n1 * 2 * sizeof(float), hipMemcpyHostToDevice, st));
-    SE2_CHECK(window_batch(h, make_bounds(*bounds), h->kps.p, h->desc.p, h->counts.p, cap, 2, h->pair_a.p, h->pair_b.p, 1,
-                           win_size, level_offset, min_level, max_level, nnratio, h->prev.p, false, h->matches.p,
-                           h->nmatches.p));
-    SE2_HIP(hipMemcpyAsync(matches12, h->matches.p, (size_t)n1 * sizeof(int), hipMemcpyDeviceToHost, st));
-    SE2_HIP(hipMemcpyAsync(prev_xy, h->prev.p, (size_t)n1 * 2 * sizeof(float), hipMemcpyDeviceToHost, st));
-    SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    return check_overflow(h);
+    SE2_HIP(hipMemcpyAsync(ds + o_prev, hs + o_prev, total - o_prev, hipMemcpyHostToDevice, st));
+    int* d_sc = (int*)(ds + o_sc);
+    SE2_CHECK(window_batch(h, make_bounds(*bounds), (const se2gpu_keypoint*)(ds + o_kps), ds + o_desc, d_sc + 2, cap, 2,
+                           d_sc + 4, d_sc + 5, 1, win_size, level_offset, min_level, max_level, nnratio,
+                           (float*)(ds + o_prev), false, (int32_t*)(ds + o_m), d_sc, d_sc + 1));
+    SE2_HIP(hipMemcpyAsync(hs, ds, o_kps, hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    const int* r = (const int*)(hs + o_sc);
+    if (r[1]) {
+        set_error("matcher: more than %d candidates in one search window", kMaxCand);
+        return SE2GPU_ERR_CAPACITY;
+    }
+    std::memcpy(matches12, hs + o_m, (size_t)n1 * sizeof(int));
+    std::memcpy(prev_xy, hs + o_prev, (size_t)n1 * 2 * sizeof(float));
+    *n_matches = r[0];
+    return SE2GPU_OK;
 }
 
 int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds, const float* mp_pos,
@@ -798,45 +802,50 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
                 SE2GPU_ERR_INVALID, "match_projection: NULL buffer");
     hipStream_t st = h->stream;
     const int mm = std::max(m, 1);
-    SE2_CHECK(h->kps.reserve((size_t)n));
-    SE2_CHECK(h->desc.reserve((size_t)n * 32));
-    SE2_CHECK(h->kf_obs.reserve((size_t)n));
-    SE2_CHECK(h->counts.reserve(2));
-    SE2_CHECK(h->mp_pos.reserve(3 * (size_t)mm));
-    SE2_CHECK(h->mp_desc.reserve(32 * (size_t)mm));
-    SE2_CHECK(h->mp_octave.reserve((size_t)mm));
-    SE2_CHECK(h->mp_skip.reserve((size_t)mm));
     SE2_CHECK(h->sorted.reserve((size_t)n));
     SE2_CHECK(h->n_grid.reserve(kGridRec));
     SE2_CHECK(h->cand.reserve((size_t)mm * kMaxCand));
     SE2_CHECK(h->ncand.reserve((size_t)mm));
-    SE2_CHECK(h->matches.reserve((size_t)n));
-    SE2_CHECK(h->nmatches.reserve(1));
-    SE2_HIP(hipMemcpyAsync(h->kps.p, kps, (size_t)n * sizeof(se2gpu_keypoint), hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->kf_obs.p, kf_observed, (size_t)n, hipMemcpyHostToDevice, st));
-    SE2_HIP(hipMemcpyAsync(h->counts.p, &n, sizeof(int), hipMemcpyHostToDevice, st));
+    // one block both ways: [match_idx (n) | nmatches, overflow, count | kps | desc | kf_obs | mp_pos | mp_octave | mp_desc | mp_skip]
+    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_m = 0, o_sc = up16((size_t)n * sizeof(int)), o_kps = o_sc + 16;
+    const size_t o_desc = up16(o_kps + (size_t)n * sizeof(se2gpu_keypoint)), o_obs = o_desc + (size_t)n * 32;
+    const size_t o_pos = up16(o_obs + (size_t)n), o_oct = up16(o_pos + 3 * (size_t)mm * sizeof(float));
+    const size_t o_mdesc = up16(o_oct + (size_t)mm * sizeof(int)), o_skip = o_mdesc + 32 * (size_t)mm;
+    const size_t total = up16(o_skip + (size_t)mm);
+    SE2_CHECK(h->stage_h.reserve(total));
+    SE2_CHECK(h->stage_d.reserve(total));
+    uint8_t* hs = h->stage_h.p;
+    uint8_t* ds = h->stage_d.p;
+    const int sc[4] = {0, 0, n, 0};
+    std::memcpy(hs + o_sc, sc, sizeof(sc));
+    std::memcpy(hs + o_kps, kps, (size_t)n * sizeof(se2gpu_keypoint));
+    std::memcpy(hs + o_desc, desc, (size_t)n * 32);
+    std::memcpy(hs + o_obs, kf_observed, (size_t)n);
     if (m) {
-        SE2_HIP(hipMemcpyAsync(h->mp_pos.p, mp_pos, 3 * (size_t)m * sizeof(float), hipMemcpyHostToDevice, st));
-        SE2_HIP(hipMemcpyAsync(h->mp_desc.p, mp_desc, 32 * (size_t)m, hipMemcpyHostToDevice, st));
-        SE2_HIP(hipMemcpyAsync(h->mp_octave.p, mp_octave, (size_t)m * sizeof(int), hipMemcpyHostToDevice, st));
-        SE2_HIP(hipMemcpyAsync(h->mp_skip.p, mp_skip, (size_t)m, hipMemcpyHostToDevice, st));
+        std::memcpy(hs + o_pos, mp_pos, 3 * (size_t)m * sizeof(float));
+        std::memcpy(hs + o_oct, mp_octave, (size_t)m * sizeof(int));
+        std::memcpy(hs + o_mdesc, mp_desc, 32 * (size_t)m);
+        std::memcpy(hs + o_skip, mp_skip, (size_t)m);
     }
+    SE2_HIP(hipMemcpyAsync(ds + o_sc, hs + o_sc, total - o_sc, hipMemcpyHostToDevice, st));
+    const se2gpu_keypoint* d_kps = (const se2gpu_keypoint*)(ds + o_kps);
+    int* d_sc = (int*)(ds + o_sc);
     const Bounds bd = make_bounds(*bounds);
     ProjCam cam;
     std::memcpy(cam.T, Tcw, sizeof(cam.T));
     cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy;
-    hipLaunchKernelGGL(k_grid_order, dim3(1), dim3(256), 0, st, bd, h->kps.p, h->counts.p, (const int*)nullptr, n,
-                       h->sorted.p, h->n_grid.p);
+    hipLaunchKernelGGL(k_grid_order, dim3(1), dim3(256), 0, st, bd, d_kps, d_sc + 2, (const int*)nullptr, n, h->sorted.p,
+                       h->n_grid.p);
     if (m)
-        hipLaunchKernelGGL(k_cand_projection, dim3((m + 3) / 4), dim3(256), 0, st, bd, cam, h->mp_pos.p, h->mp_desc.p,
-                           h->mp_octave.p, h->mp_skip.p, m, h->kps.p, h->desc.p, h->kf_obs.p, h->sorted.p, h->n_grid.p,
-                           win_size, level_offset, h->cand.p, h->ncand.p);
+        hipLaunchKernelGGL(k_cand_projection, dim3((m + 3) / 4), dim3(256), 0, st, bd, cam, (const float*)(ds + o_pos),
+                           ds + o_mdesc, (const int*)(ds + o_oct), ds + o_skip, m, d_kps, ds + o_desc, ds + o_obs,
+                           h->sorted.p, h->n_grid.p, win_size, level_offset, h->cand.p, h->ncand.p);
     {
         const int chunk = 1024;
-        constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: a single wave, occupancy is irrelevant
+        constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: a single workgroup
         const size_t nE = ((size_t)n + 3) & ~(size_t)3;
-        const size_t fixed_lds = (4 * nE + 64 + chunk + 1) * sizeof(int);
+        const size_t fixed_lds = (3 * nE + 6 * (size_t)chunk + 8) * sizeof(int);
         SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY, "%d key-frame features need %zu B of LDS", n, fixed_lds);
         static bool attr_set = false;
         if (!attr_set) {
@@ -844,15 +853,21 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
                                         (int)kLdsBudget));
             attr_set = true;
         }
-        const int cand_lds = (int)((kLdsBudget - fixed_lds) / sizeof(int));
-        hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(64), fixed_lds + (size_t)cand_lds * sizeof(int), st, h->kps.p,
-                           n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, h->matches.p, h->nmatches.p,
-                           h->overflow.p);
+        const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));
+        hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(1024), fixed_lds + (size_t)cand_lds * sizeof(int), st, d_kps,
+                           n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, (int*)(ds + o_m), d_sc, d_sc + 1);
     }
     SE2_HIP(hipGetLastError());
-    SE2_HIP(hipMemcpyAsync(match_idx_mp, h->matches.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, st));
-    SE2_HIP(hipMemcpyAsync(n_matches, h->nmatches.p, sizeof(int), hipMemcpyDeviceToHost, st));
-    return check_overflow(h);
+    SE2_HIP(hipMemcpyAsync(hs, ds, o_kps, hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    const int* r = (const int*)(hs + o_sc);
+    if (r[1]) {
+        set_error("matcher: more than %d candidates in one search window", kMaxCand);
+        return SE2GPU_ERR_CAPACITY;
+    }
+    std::memcpy(match_idx_mp, hs + o_m, (size_t)n * sizeof(int));
+    *n_matches = r[0];
+    return SE2GPU_OK;
 }
 
 int se2gpu_search_by_bow(se2gpu_matcher* h, const se2gpu_keypoint* kps1, const uint8_t* desc1, int n1,
