@@ -15,7 +15,7 @@
 //   k_cell_detect         one workgroup per (frame, level, cell): collects the non-zero scores, threshold 20 /
 //                         fallback 7, rank sort by (response desc, y, x) -> per-cell sorted candidate list
 //                         (<true>: HARRIS_SCORE, responses re-scored with the 7x7 Harris measure)
-//   k_level_select        one workgroup per frame: quota redistribution (serial, tiny), per-cell top-n gather,
+//   k_level_select        one workgroup per (frame, level): quota redistribution (wave-parallel), per-cell top-n gather,
 //                         level-wide retain-best by rank, keypoint list in level order
 //   k_orientation         one wave per keypoint: integer intensity-centroid moments, fastAtan2
 //   k_copy_frame, k_blur  blurred pyramid: the 16 px frame keeps the un-blurred reflect copies (as in the reference's
@@ -543,9 +543,62 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-frame selection: quota redistribution (ORBextractor.cpp:631-679), per-cell retain (:687-705), level-wide
+// per-(frame, level) selection: quota redistribution (ORBextractor.cpp:631-679), per-cell retain (:687-705), level-wide
 // retain (:706-710).  Output: kp_list[f][i] = {level, x, y, response} in final order; counts[f].
+// A level's place in the output is the number of key points the lower levels keep, which follows from their cell
+// totals alone - every workgroup replays the (cheap, wave-parallel) quota logic of the levels below it instead of
+// waiting for them.
 // ---------------------------------------------------------------------------------------------
+// Quota replay of one level by one wave: lane c + 64 k owns cell c + 64 k (<= 256 cells).  The reference's loop
+// (:640-679) is a fixed-point over passes whose body does not depend on the cell order, so a pass is one wave step.
+// n_ret / c_off (nullable) receive the per-cell retain counts and their exclusive prefix; returns their sum.
+__device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, int cell_cap, int* n_ret, int* c_off,
+                                           int* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    int t[4], r[4];
+    bool nm[4];
+    int dist = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        t[k] = c < nCells ? tot[c] : 0;
+        r[k] = 0;
+        nm[k] = true;
+        if (c < nCells) {
+            if (t[k] > nfc) { r[k] = nfc; nm[k] = false; }
+            else { r[k] = t[k]; dist += nfc - t[k]; ++cnt; }
+        }
+    }
+    for (int s = 1; s < 64; s <<= 1) { dist += __shfl_xor(dist, s); cnt += __shfl_xor(cnt, s); }
+    while (dist > 0 && cnt < nCells) {
+        const int nNew = nfc + (int)ceilf((float)dist / (float)(nCells - cnt));
+        int d2 = 0, c2 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (!nm[k]) {
+                if (t[k] > nNew) { r[k] = nNew; }
+                else { r[k] = t[k]; d2 += nNew - t[k]; nm[k] = true; ++c2; }
+            }
+        for (int s = 1; s < 64; s <<= 1) { d2 += __shfl_xor(d2, s); c2 += __shfl_xor(c2, s); }
+        dist = d2;
+        cnt += c2;
+    }
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        if (r[k] > cell_cap) { atomicOr(overflow, 2); r[k] = cell_cap; }
+        int incl = r[k];
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        if (n_ret && c < nCells) { n_ret[c] = r[k]; c_off[c] = base + incl - r[k]; }
+        base += __shfl(incl, 63);
+    }
+    return base;
+}
+
 __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __restrict__ cell_keys,
                                                        const float* __restrict__ cell_resp,
                                                        const int* __restrict__ cell_total, int4* __restrict__ kp_list,
@@ -555,102 +608,78 @@ __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __
     __shared__ int keepflag[kLevelCap];
     __shared__ int n_retain[64 * 4];   // per cell (<= 256 cells per level)
     __shared__ int cell_off[64 * 4 + 1];
-    __shared__ int s_count, s_scan[256];
-    const int f = blockIdx.x;
+    __shared__ int s_kept[kMaxLevels], s_scan[256];
+    const int f = blockIdx.x, l = blockIdx.y;
     const int ncells_frame = g.cell_base[g.nlevels];
-    int out_n = 0;  // keypoints written so far (uniform across the block)
-    for (int l = 0; l < g.nlevels; ++l) {
-        const int nCells = g.gcols[l] * g.grows[l];
-        const int* tot = cell_total + (size_t)f * ncells_frame + g.cell_base[l];
-        if (threadIdx.x == 0) {
-            // serial replay of the reference's quota logic
-            const int nfc = g.nfc[l];
-            int nNoMore = 0, nToDistribute = 0;
-            bool noMore[256];
-            for (int c = 0; c < nCells; ++c) {
-                const int nk = tot[c];
-                if (nk > nfc) { n_retain[c] = nfc; noMore[c] = false; }
-                else { n_retain[c] = nk; nToDistribute += nfc - nk; noMore[c] = true; nNoMore++; }
+    const int wave = threadIdx.x >> 6;
+    const int* tot_f = cell_total + (size_t)f * ncells_frame;
+    for (int lv = wave; lv <= l; lv += 4) {
+        const int nc = g.gcols[lv] * g.grows[lv];
+        int o = level_quota(tot_f + g.cell_base[lv], nc, g.nfc[lv], g.cell_cap, lv == l ? n_retain : nullptr, cell_off,
+                            overflow);
+        if (o > kLevelCap) { atomicOr(overflow, 4); o = kLevelCap; }
+        if ((threadIdx.x & 63) == 0) s_kept[lv] = o;      // entries before the level-wide retain
+    }
+    __syncthreads();
+    const int nCells = g.gcols[l] * g.grows[l];
+    const int n = s_kept[l];
+    int out_n = 0;                                         // key points of the lower levels
+    for (int lv = 0; lv < l; ++lv) out_n += min(s_kept[lv], g.quota[lv]);
+    // gather the per-cell prefixes in cell row-major order
+    for (int c = 0; c < nCells; ++c) {
+        const uint32_t* src = cell_keys + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
+        const float* srcr = cell_resp + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
+        const int o = cell_off[c];
+        for (int i = threadIdx.x; i < n_retain[c]; i += 256)
+            if (o + i < kLevelCap) {
+                lst[o + i] = src[i];
+                lrsp[o + i] = srcr[i];
             }
-            while (nToDistribute > 0 && nNoMore < nCells) {
-                const int nNew = nfc + (int)ceilf((float)nToDistribute / (float)(nCells - nNoMore));
-                nToDistribute = 0;
-                for (int c = 0; c < nCells; ++c)
-                    if (!noMore[c]) {
-                        if (tot[c] > nNew) { n_retain[c] = nNew; }
-                        else { n_retain[c] = tot[c]; nToDistribute += nNew - tot[c]; noMore[c] = true; nNoMore++; }
-                    }
+    }
+    __syncthreads();
+    const int quota = g.quota[l];
+    if (n > quota) {
+        // keep the `quota` best by (response desc, list position asc), preserving list order
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const float ri = lrsp[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const float rj = lrsp[j];
+                rank += (rj > ri) || (rj == ri && j < i);
             }
-            int o = 0;
-            for (int c = 0; c < nCells; ++c) {
-                cell_off[c] = o;
-                if (n_retain[c] > g.cell_cap) { atomicOr(overflow, 2); n_retain[c] = g.cell_cap; }
-                o += n_retain[c];
-            }
-            cell_off[nCells] = o;
-            if (o > kLevelCap) { atomicOr(overflow, 4); o = kLevelCap; }
-            s_count = o;
+            keepflag[i] = rank < quota;
         }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) keepflag[i] = 1;
+    }
+    __syncthreads();
+    // ordered compaction: chunks of 256 with a block scan
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const int kf = (i < n) ? keepflag[i] : 0;
+        s_scan[threadIdx.x] = kf;
         __syncthreads();
-        const int n = s_count;
-        // gather the per-cell prefixes in cell row-major order
-        for (int c = 0; c < nCells; ++c) {
-            const uint32_t* src = cell_keys + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
-            const float* srcr = cell_resp + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
-            const int o = cell_off[c];
-            for (int i = threadIdx.x; i < n_retain[c]; i += 256)
-                if (o + i < kLevelCap) {
-                    lst[o + i] = src[i];
-                    lrsp[o + i] = srcr[i];
-                }
-        }
-        __syncthreads();
-        const int quota = g.quota[l];
-        if (n > quota) {
-            // keep the `quota` best by (response desc, list position asc), preserving list order
-            for (int i = threadIdx.x; i < n; i += 256) {
-                const float ri = lrsp[i];
-                int rank = 0;
-                for (int j = 0; j < n; ++j) {
-                    const float rj = lrsp[j];
-                    rank += (rj > ri) || (rj == ri && j < i);
-                }
-                keepflag[i] = rank < quota;
-            }
-        } else {
-            for (int i = threadIdx.x; i < n; i += 256) keepflag[i] = 1;
-        }
-        __syncthreads();
-        // ordered compaction: chunks of 256 with a block scan
-        int base = 0;
-        for (int c0 = 0; c0 < n; c0 += 256) {
-            const int i = c0 + threadIdx.x;
-            const int kf = (i < n) ? keepflag[i] : 0;
-            s_scan[threadIdx.x] = kf;
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = (threadIdx.x >= (unsigned)d) ? s_scan[threadIdx.x - d] : 0;
             __syncthreads();
-            for (int d = 1; d < 256; d <<= 1) {
-                const int v = (threadIdx.x >= (unsigned)d) ? s_scan[threadIdx.x - d] : 0;
-                __syncthreads();
-                s_scan[threadIdx.x] += v;
-                __syncthreads();
-            }
-            const int pos = out_n + base + s_scan[threadIdx.x] - kf;
-            if (kf) {
-                if (pos < cap) {
-                    const uint32_t key = lst[i];
-                    kp_list[(size_t)f * cap + pos] = make_int4(l, (int)(key & 0xfff), (int)((key >> 12) & 0xfff),
-                                                               __float_as_int(lrsp[i]));
-                } else {
-                    atomicOr(overflow, 8);
-                }
-            }
-            base += s_scan[255];
+            s_scan[threadIdx.x] += v;
             __syncthreads();
         }
-        out_n += base;
+        const int pos = out_n + base + s_scan[threadIdx.x] - kf;
+        if (kf) {
+            if (pos < cap) {
+                const uint32_t key = lst[i];
+                kp_list[(size_t)f * cap + pos] = make_int4(l, (int)(key & 0xfff), (int)((key >> 12) & 0xfff),
+                                                           __float_as_int(lrsp[i]));
+            } else {
+                atomicOr(overflow, 8);
+            }
+        }
+        base += s_scan[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) counts[f] = min(out_n, cap);
+    if (l == g.nlevels - 1 && threadIdx.x == 0) counts[f] = min(out_n + base, cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -951,6 +980,8 @@ struct se2gpu_orb {
     DevBuf<float2> angle_cs;
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc;
+    PinBuf<uint8_t> stage_h;      // single-frame path: pinned image staging and the packed result block
+    DevBuf<uint8_t> out_d;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
     int score_tiles = 0, blur_tiles = 0;
     int score_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
@@ -1109,7 +1140,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
     }
     // The blurred pyramid needs only the pyramid: it runs on a side stream next to the key-point chain, whose
-    // k_level_select (one workgroup per frame) and k_cell_detect leave most CUs idle.  (Serial when profiling.)
+    // k_level_select and k_cell_detect leave most CUs idle.  (Serial when profiling.)
     hipStream_t sb = h->prof.enabled ? st : h->side_stream;
     if (sb != st) {
         SE2_HIP(hipEventRecord(h->ev_fork, st));
@@ -1138,7 +1169,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     else
         SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<false>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
                    h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
-    SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(nframes), dim3(256), 0, g, h->cell_keys.p,
+    SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(nframes, L), dim3(256), 0, g, h->cell_keys.p,
                h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p);
@@ -1275,20 +1306,28 @@ int se2gpu_orb_extract(se2gpu_orb* h, const uint8_t* img, int rows, int cols, si
     SE2_CHECK(orb_configure(h, rows, cols));
     hipStream_t st = h->stream;
     SE2_CHECK(h->img.reserve((size_t)h->params.max_rows * h->params.max_cols));
-    SE2_CHECK(h->kps.reserve((size_t)cap));
-    SE2_CHECK(h->desc.reserve((size_t)cap * 32));
-    SE2_CHECK(h->counts.reserve((size_t)h->max_batch));
-    SE2_HIP(hipMemcpy2DAsync(h->img.p, cols, img, step, cols, rows, hipMemcpyHostToDevice, st));
-    SE2_CHECK(orb_run(h, h->img.p, cols, 1, h->kps.p, h->desc.p, h->counts.p, cap));
-    int n = 0;
-    SE2_HIP(hipMemcpyAsync(&n, h->counts.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    // result block [count, overflow | key points (cap) | descriptors (cap)]: one download, one synchronisation
+    const size_t o_kps = 16, o_desc = (o_kps + (size_t)cap * sizeof(se2gpu_keypoint) + 15) & ~(size_t)15;
+    const size_t out_b = o_desc + (size_t)cap * 32, img_b = (size_t)rows * cols;
+    SE2_CHECK(h->out_d.reserve(out_b));
+    SE2_CHECK(h->stage_h.reserve(std::max(out_b, img_b)));
+    for (int r = 0; r < rows; ++r) std::memcpy(h->stage_h.p + (size_t)r * cols, img + (size_t)r * step, (size_t)cols);
+    SE2_HIP(hipMemcpyAsync(h->img.p, h->stage_h.p, img_b, hipMemcpyHostToDevice, st));
+    uint8_t* d_out = h->out_d.p;
+    SE2_CHECK(orb_run(h, h->img.p, cols, 1, (se2gpu_keypoint*)(d_out + o_kps), d_out + o_desc, (int*)d_out, cap));
+    SE2_HIP(hipMemcpyAsync(d_out + 4, h->overflow.p, sizeof(int), hipMemcpyDeviceToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->stage_h.p, d_out, out_b, hipMemcpyDeviceToHost, st));   // the upload has completed: stream order
     SE2_HIP(hipStreamSynchronize(st));
-    SE2_CHECK(orb_check_overflow(h));
-    n = std::min(n, cap);
+    const int* hdr = (const int*)h->stage_h.p;
+    if (hdr[1]) {
+        SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), st));
+        set_error("ORB extractor: internal capacity overflow (mask %d): cell candidates / level list / output cap", hdr[1]);
+        return SE2GPU_ERR_CAPACITY;
+    }
+    const int n = std::min(hdr[0], cap);
     if (n) {
-        SE2_HIP(hipMemcpyAsync(kps, h->kps.p, (size_t)n * sizeof(se2gpu_keypoint), hipMemcpyDeviceToHost, st));
-        SE2_HIP(hipMemcpyAsync(desc, h->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, st));
-        SE2_HIP(hipStreamSynchronize(st));
+        std::memcpy(kps, h->stage_h.p + o_kps, (size_t)n * sizeof(se2gpu_keypoint));
+        std::memcpy(desc, h->stage_h.p + o_desc, (size_t)n * 32);
     }
     *n_out = n;
     return SE2GPU_OK;

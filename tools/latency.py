@@ -35,6 +35,30 @@ def main():
     mt = ORBmatcher(0.9)
     prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
     out["match_by_window_ms"] = timeit(lambda: mt.MatchByWindow(k1, d1, k2, d2, prev.copy(), 20))
+    # Track thread: removeOutliers + doTriangulate on the MatchByWindow result of frames 0 -> 5
+    from se2lam_amd.track import Track
+    tr = Track()
+    k5, d5 = ex(synth.frame(5))
+    prev5 = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
+    nm, m12 = mt.MatchByWindow(k1, d1, k5, d5, prev5, 20)
+    out["remove_outliers_ms"] = timeit(lambda: tr.removeOutliers(k1, k5, np.ascontiguousarray(m12, np.int32).copy()))
+    K = np.array([[400, 0, 320], [0, 400, 240], [0, 0, 1.0]], np.float32)
+    Tcr = np.eye(4, dtype=np.float32); Tcr[0, 3] = -112.5; Tcr[1, 3] = -37.5
+    P0 = K @ np.eye(4, dtype=np.float32)[:3]; P1 = (K @ Tcr[:3]).astype(np.float32)
+    oc = np.array([112.5, 37.5, 0], np.float32)
+    out["do_triangulate_ms"] = timeit(lambda: tr.doTriangulate(k1, k5, m12, None, P0, P1, oc, 300, 12000, 2))
+    # LocalMapper thread: MatchByProjection of 1500 local map points into a new key frame
+    rng = np.random.default_rng(0)
+    m = 1500
+    src = rng.integers(0, len(k1), m)
+    depth = rng.uniform(800, 6000, m).astype(np.float32)
+    Xc = np.stack([(k1["x"][src] - 320) / 400 * depth, (k1["y"][src] - 240) / 400 * depth, depth], 1).astype(np.float32)
+    Tcw = np.concatenate([np.eye(3, dtype=np.float32), np.array([[15.0], [-4.0], [8.0]], np.float32)], 1)
+    mp_pos = (Xc - Tcw[:, 3]).astype(np.float32)
+    args = (mp_pos, d1[src].copy(), k1["octave"][src].astype(np.int32), np.zeros(m, np.uint8), Tcw, (400.0, 400.0, 320.0, 240.0),
+            k2, d2, np.zeros(len(k2), np.uint8))
+    mp = ORBmatcher()
+    out["match_by_projection_1500mp_ms"] = timeit(lambda: mp.MatchByProjection(*args, 15, 2))
     for P, L in ((50, 5000), (200, 20000)):
         g = synth.ba_graph(P, L)
         o = SlamOptimizer()
