@@ -10,7 +10,7 @@
 // Pipeline (every kernel covers the whole batch; all stages stay in HBM, no host round trip):
 //   k_level0 / k_resize   pyramid level k from level k-1, border filled in the same pass; resize coefficients from host
 //                         tables over the bordered row, the taps of a thread from one 64-bit load per source row
-//   k_fast_score          S(x,y) = FAST-9/16 score for every level in one launch, in-cell non-max suppression fused:
+//   k_fast_score[_dense]  S(x,y) = FAST-9/16 score for every level in one launch, in-cell non-max suppression fused:
 //                         writes a sparse plane (S where S > 7 and a strict in-cell maximum, else 0)
 //   k_cell_detect         one workgroup per (frame, level, cell): collects the non-zero scores, threshold 20 /
 //                         fallback 7, rank sort by (response desc, y, x) -> per-cell sorted candidate list
@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+
+#include <cstdlib>
 
 #include "common.h"
 
@@ -263,7 +265,7 @@ __device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t lef
     return (unsigned long long)(left >> 24) | ((unsigned long long)own << 8) | ((unsigned long long)(right & 0xffu) << 40);
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score_dense(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
     const int f = blockIdx.y;
     int l = 0;
     while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
@@ -356,6 +358,190 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         step(std::integral_constant<int, 4>{}, y + 4);
         step(std::integral_constant<int, 5>{}, y + 5);
         step(std::integral_constant<int, 6>{}, y + 6);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fast_score: the same plane as k_fast_score_dense (S' = S where S > 7 and a strict in-cell maximum, else 0), computed
+// only where it can be non-zero.  A 9-arc of the 16-ring always contains two ADJACENT compass points (ring positions
+// 0, 4, 8, 12), so S > 7 needs both of them brighter than v + 7 or both darker than v - 7: a 4-pixel test that rejects
+// flat areas, noise and straight edges (typically > 90 % of the pixels).  One workgroup = one 128 x 32 tile staged in
+// LDS with its halo:
+//   1  compass test for every pixel of the tile + 1 px (packed int16 pairs, 4 pixels per thread and step); survivors
+//      are appended to a candidate list in LDS
+//   2  the full FAST-9 score for the candidates only, two per lane in the packed arithmetic of fast_score_pk, ring
+//      bytes gathered from the LDS tile; scores <= 7 dropped; written into a sparse LDS score tile
+//   3  in-cell non-max suppression per surviving candidate against its 8 neighbours in that tile (raw scores, as cv::FAST)
+//   4  the tile is written out as whole dwords
+// Dense corners only cost time, never correctness: the candidate list holds every pixel of the tile if need be.
+// On the benchmark texture (4000 overlapping rectangles: 15 % of the pixels pass the compass test, 6 % have S > 7) the
+// two kernels take 744 us and 783 us per 256 frames; on imagery with fewer corners this one's cost tends to the
+// compass pass alone (about a fifth of the dense kernel's arithmetic).  SE2GPU_ORB_SCORE=dense selects the other one.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFsTW = 128, kFsTH = 32;
+constexpr int kFsLW = kFsTW + 16;          // LDS image tile: columns x0-8 .. x0+TW+8
+constexpr int kFsLH = kFsTH + 8;           //                 rows    y0-4 .. y0+TH+4
+constexpr int kFsSW = kFsTW + 8;           // score tile: columns x0-4 .. x0+TW+4 (whole 4-pixel groups), rows y0-1 .. y0+TH
+constexpr int kFsSH = kFsTH + 2;
+constexpr int kFsMaxCand = kFsSW * kFsSH;
+
+// candidate bits of a pixel pair: bit 15 / bit 31 set where two adjacent compass points are both >= v + 8 or <= v - 8
+__device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e, short2v s, short2v w) {
+    const short2v dn = n - v, de = e - v, ds = s - v, dw = w - v;
+    const short2v mx = __builtin_elementwise_max(
+        __builtin_elementwise_max(__builtin_elementwise_min(dn, de), __builtin_elementwise_min(de, ds)),
+        __builtin_elementwise_max(__builtin_elementwise_min(ds, dw), __builtin_elementwise_min(dw, dn)));
+    const short2v mn = __builtin_elementwise_min(
+        __builtin_elementwise_min(__builtin_elementwise_max(dn, de), __builtin_elementwise_max(de, ds)),
+        __builtin_elementwise_min(__builtin_elementwise_max(ds, dw), __builtin_elementwise_max(dw, dn)));
+    const short2v eight = {8, 8}, zero = {0, 0};
+    const short2v a = mx - eight;               // >= 0: bright candidate
+    const short2v b = zero - mn - eight;        // >= 0: dark candidate
+    return ~(__builtin_bit_cast(uint32_t, a) & __builtin_bit_cast(uint32_t, b)) & 0x80008000u;
+}
+
+__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+    __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
+    __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
+    __shared__ uint32_t s_out[(kFsTW / 4) * kFsTH];
+    __shared__ uint16_t s_cand[kFsMaxCand];
+    __shared__ int s_n;
+    const int f = blockIdx.y;
+    int l = 0;
+    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
+    const int t = blockIdx.x - g.tile_base[l];
+    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
+    const int tiles_x = (W - 2 * kEdge + kFsTW - 1) / kFsTW;
+    const int x0 = kEdge + (t % tiles_x) * kFsTW, y0 = kEdge + (t / tiles_x) * kFsTH;
+    const int tid = threadIdx.x;
+    const uint8_t* plane = pyr + (size_t)f * g.frame_bytes + g.off[l];   // bordered plane: pixel (x, y) at (y+16)*stride + x+16
+    uint8_t* sbase = score + pix(g, f, l, 0, 0);
+    constexpr int LWd = kFsLW / 4, SWd = kFsSW / 4, TWd = kFsTW / 4;
+    // 0. stage the image tile (rows / columns outside the bordered plane are clamped: they only feed pixels that are
+    //    not scored), clear the sparse tiles
+    const int last_row = H + 2 * kEdge - 1, last_dw = stride / 4 - 1;
+    for (int i = tid; i < LWd * kFsLH; i += 256) {
+        const int r = i / LWd, c = i - r * LWd;
+        const int by = min(max(y0 - 4 + r + kEdge, 0), last_row);
+        const int bx = min(max((x0 - 8 + kEdge) / 4 + c, 0), last_dw);
+        s_img[i] = *(const uint32_t*)(plane + (size_t)by * stride + 4 * bx);
+    }
+    for (int i = tid; i < SWd * kFsSH; i += 256) s_sc[i] = 0;
+    for (int i = tid; i < TWd * kFsTH; i += 256) s_out[i] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // 1. compass test.  Thread = (column group gx = tid & 31, row phase tid >> 5): the 128 tile columns, rows -1 .. TH.
+    const int xlo = max(kEdge, x0 - 1), xhi = min(W - kEdge, x0 + kFsTW + 1);   // columns that need a score
+    {
+        const int gx = (tid & 31) + 1;                                   // score-tile group: pixels x0 + 4 (gx - 1) ..
+        const int xg = x0 - 4 + 4 * gx;
+        unsigned colmask = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (xg + q >= xlo && xg + q < xhi) colmask |= 1u << q;
+        for (int gy = tid >> 5; gy < kFsSH; gy += 8) {
+            const int y = y0 + gy - 1;
+            if (y < kEdge || y >= H - kEdge || !colmask) continue;
+            const uint32_t* row = s_img + (gy + 3) * LWd + gx;           // row y, columns xg-4 .. xg+7
+            const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+            const uint32_t n1 = row[1 - 3 * LWd], s1 = row[1 + 3 * LWd];  // rows y-3 / y+3, columns xg .. xg+3
+            const short2v vA = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(w1, w1, 0x0c010c00u));   // pixels 0, 1
+            const short2v vB = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(w1, w1, 0x0c030c02u));   // pixels 2, 3
+            const short2v eA = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(w2, w1, 0x0c040c03u));   // x+3: bytes 7, 8
+            const short2v eB = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(w2, w2, 0x0c020c01u));   //      bytes 9, 10
+            const short2v wA = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(w0, w0, 0x0c020c01u));   // x-3: bytes 1, 2
+            const short2v wB = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(w1, w0, 0x0c040c03u));   //      bytes 3, 4
+            const short2v nA = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(n1, n1, 0x0c010c00u));
+            const short2v nB = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(n1, n1, 0x0c030c02u));
+            const short2v sA = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(s1, s1, 0x0c010c00u));
+            const short2v sB = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(s1, s1, 0x0c030c02u));
+            const uint32_t cA = compass_pair(vA, nA, eA, sA, wA), cB = compass_pair(vB, nB, eB, sB, wB);
+            const unsigned flags = (((cA >> 15) & 1u) | ((cA >> 30) & 2u) | ((cB >> 13) & 4u) | ((cB >> 28) & 8u)) & colmask;
+            if (flags) {
+                int at = atomicAdd(&s_n, __popc(flags));
+                const int code = (gy << 8) | (4 * gx);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (flags & (1u << q)) s_cand[at++] = (uint16_t)(code + q);
+            }
+        }
+    }
+    const uint8_t* img8 = (const uint8_t*)s_img;
+    if (tid < 2 * kFsSH) {   // the two halo columns x0 - 1 and x0 + TW, one pixel per thread
+        const int side = tid >= kFsSH, gy = tid - side * kFsSH;
+        const int sx = side ? kFsTW + 4 : 3;
+        const int x = x0 - 4 + sx, y = y0 + gy - 1;
+        if (y >= kEdge && y < H - kEdge && x >= xlo && x < xhi) {
+            const int c = (gy + 3) * kFsLW + sx + 4;
+            const int v = img8[c];
+            const int dn = img8[c - 3 * kFsLW] - v, ds = img8[c + 3 * kFsLW] - v, de = img8[c + 3] - v, dw = img8[c - 3] - v;
+            const int mx = max(max(min(dn, de), min(de, ds)), max(min(ds, dw), min(dw, dn)));
+            const int mn = min(min(max(dn, de), max(de, ds)), min(max(ds, dw), max(dw, dn)));
+            if (mx >= 8 || mn <= -8) s_cand[atomicAdd(&s_n, 1)] = (uint16_t)((gy << 8) | sx);
+        }
+    }
+    __syncthreads();
+    // 2. FAST-9 score of the candidates, two per lane.  Candidate code = (score-tile row << 8) | score-tile column.
+    const int n = s_n;
+    uint8_t* sc8 = (uint8_t*)s_sc;
+    const short2v seven = {7, 7};
+    for (int b = 2 * tid; b < n; b += 512) {
+        const int k0 = s_cand[b], k1 = (b + 1 < n) ? s_cand[b + 1] : k0;
+        const int c0 = ((k0 >> 8) + 3) * kFsLW + (k0 & 255) + 4;        // byte of the centre pixel in the image tile
+        const int c1 = ((k1 >> 8) + 3) * kFsLW + (k1 & 255) + 4;
+        auto pk = [&](int dy, int dx) {
+            const int o = dy * kFsLW + dx;
+            return __builtin_bit_cast(short2v, (uint32_t)img8[c0 + o] | ((uint32_t)img8[c1 + o] << 16));
+        };
+        short2v p[16];
+        p[0] = pk(3, 0);    p[1] = pk(3, 1);    p[2] = pk(2, 2);    p[3] = pk(1, 3);
+        p[4] = pk(0, 3);    p[5] = pk(-1, 3);   p[6] = pk(-2, 2);   p[7] = pk(-3, 1);
+        p[8] = pk(-3, 0);   p[9] = pk(-3, -1);  p[10] = pk(-2, -2); p[11] = pk(-1, -3);
+        p[12] = pk(0, -3);  p[13] = pk(1, -3);  p[14] = pk(2, -2);  p[15] = pk(3, -1);
+        const short2v sc = keep_greater(fast_score_pk(p, pk(0, 0)), seven);
+        sc8[(k0 >> 8) * kFsSW + (k0 & 255)] = (uint8_t)sc.x;
+        if (b + 1 < n) sc8[(k1 >> 8) * kFsSW + (k1 & 255)] = (uint8_t)sc.y;
+    }
+    __syncthreads();
+    // 3. non-max suppression inside the cell (cv::FAST compares raw scores of the neighbours of one FAST call = one cell)
+    const int cellW = g.cellW[l], cellH = g.cellH[l];
+    const int xr0 = (x0 - kEdge) % cellW, yr0 = (y0 - kEdge) % cellH;    // workgroup-uniform
+    uint8_t* out8 = (uint8_t*)s_out;
+    for (int b = tid; b < n; b += 256) {
+        const int k = s_cand[b];
+        const int sy = k >> 8, sx = k & 255;
+        const int lx = sx - 4, ly = sy - 1;
+        if (lx < 0 || lx >= kFsTW || ly < 0 || ly >= kFsTH) continue;     // halo: another tile's pixel
+        const int i = sy * kFsSW + sx;
+        const int c = sc8[i];
+        if (!c) continue;
+        int xm = xr0 + lx, ym = yr0 + ly;                                  // position inside the cell
+        while (xm >= cellW) xm -= cellW;
+        while (ym >= cellH) ym -= cellH;
+        const bool L = xm != 0, R = !(xm == cellW - 1 || x0 + lx == W - kEdge - 1);
+        const bool T = ym != 0, B = !(ym == cellH - 1 || y0 + ly == H - kEdge - 1);
+        int m = 0;
+        if (L) m = max(m, (int)sc8[i - 1]);
+        if (R) m = max(m, (int)sc8[i + 1]);
+        if (T) {
+            m = max(m, (int)sc8[i - kFsSW]);
+            if (L) m = max(m, (int)sc8[i - kFsSW - 1]);
+            if (R) m = max(m, (int)sc8[i - kFsSW + 1]);
+        }
+        if (B) {
+            m = max(m, (int)sc8[i + kFsSW]);
+            if (L) m = max(m, (int)sc8[i + kFsSW - 1]);
+            if (R) m = max(m, (int)sc8[i + kFsSW + 1]);
+        }
+        if (c > m) out8[ly * kFsTW + lx] = (uint8_t)c;
+    }
+    __syncthreads();
+    // 4. write the tile
+    for (int i = tid; i < TWd * kFsTH; i += 256) {
+        const int ly = i / TWd, gx = i - ly * TWd;
+        const int x = x0 + 4 * gx, y = y0 + ly;
+        if (y >= H - kEdge || x >= W - kEdge) continue;
+        *(uint32_t*)(sbase + (size_t)y * stride + x) = s_out[i];
     }
 }
 
@@ -984,7 +1170,8 @@ struct se2gpu_orb {
     DevBuf<uint8_t> out_d;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
     int score_tiles = 0, blur_tiles = 0;
-    int score_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
+    int score_tile_base[kMaxLevels + 1], dense_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
+    bool dense_score = false;            // SE2GPU_ORB_SCORE=dense: score every pixel (k_fast_score_dense)
     ~se2gpu_orb() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
@@ -1040,10 +1227,12 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     g.cell_cap = std::min(kSortCap, ((2 * maxq + 64 + 63) / 64) * 64);
     // tiles
     h->score_tile_base[0] = 0;
+    h->dense_tile_base[0] = 0;
     h->blur_tile_base[0] = 0;
     for (int l = 0; l < L; ++l) {
         const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;
-        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
+        h->dense_tile_base[l + 1] = h->dense_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
+        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + kFsTW - 1) / kFsTW) * ((sh + kFsTH - 1) / kFsTH);
         h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 255) / 256) * ((g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows));
     }
     // resize tables
@@ -1160,9 +1349,15 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(gb.tile_base[L], nframes), dim3(256), 0, gb, h->pyr.p, h->blur.p);
     }
     if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
-    for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
-    SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p,
-               h->score.p);
+    if (h->dense_score) {
+        for (int l = 0; l <= L; ++l) g.tile_base[l] = h->dense_tile_base[l];
+        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_dense, dim3(g.tile_base[L], nframes), dim3(256), 0, g,
+                   h->pyr.p, h->score.p);
+    } else {
+        for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
+        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p,
+                   h->score.p);
+    }
     if (g.harris)
         SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
                    h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
@@ -1217,6 +1412,7 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
         return SE2GPU_ERR_HIP;
     }
     h->stream = h->own_stream;
+    if (const char* e = std::getenv("SE2GPU_ORB_SCORE")) h->dense_score = std::strcmp(e, "dense") == 0;
     if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {

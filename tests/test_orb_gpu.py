@@ -148,3 +148,22 @@ def test_harris_score_on_noise_and_half_flat(oracle, synth):
         k, d = ex(img)
         ko, do = oracle.orb_extract(img, par)
         assert len(ko) > 0 and np.array_equal(k, ko) and np.array_equal(d, do)
+
+
+def test_dense_and_sparse_score_kernels_agree(synth, monkeypatch):
+    """k_fast_score (compass pre-test + candidates only, the default) and k_fast_score_dense (every pixel,
+    SE2GPU_ORB_SCORE=dense) must produce the same score planes and the same features, also where nearly every pixel is
+    a candidate (noise) and where none is (flat)."""
+    from se2lam_amd.orb import ORBextractor
+    sparse = ORBextractor()
+    monkeypatch.setenv("SE2GPU_ORB_SCORE", "dense")
+    dense = ORBextractor()
+    monkeypatch.delenv("SE2GPU_ORB_SCORE")
+    rng = np.random.default_rng(9)
+    half = synth.frame(1).copy(); half[:240] = 77
+    for img in (synth.frame(4), rng.integers(0, 256, (480, 640)).astype(np.uint8), np.full((480, 640), 31, np.uint8), half):
+        ks, ds = sparse(img)
+        kd, dd = dense(img)
+        assert np.array_equal(ks, kd) and np.array_equal(ds, dd)
+        for lv in range(8):
+            assert np.array_equal(sparse.debug_score(0, lv), dense.debug_score(0, lv)), lv
