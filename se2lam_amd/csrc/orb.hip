@@ -400,16 +400,23 @@ __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e
     return ~(__builtin_bit_cast(uint32_t, a) & __builtin_bit_cast(uint32_t, b)) & 0x80008000u;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score(Geom g, int nframes, const uint8_t* __restrict__ pyr,
+                                                     uint8_t* __restrict__ score) {
     __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
     __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
     __shared__ uint32_t s_out[(kFsTW / 4) * kFsTH];
     __shared__ uint16_t s_cand[kFsMaxCand];
     __shared__ int s_n;
-    const int f = blockIdx.y;
+    // Workgroups are dealt to the 8 XCDs round-robin in launch order: XCD k takes the frames k, k + 8, ... whole, so that
+    // the halos shared by neighbouring tiles meet in one L2 and every XCD gets the same mix of tiles.
+    const int ntiles = g.tile_base[g.nlevels];
+    const int j = (int)(blockIdx.x >> 3);
+    const int f = 8 * (j / ntiles) + (int)(blockIdx.x & 7);
+    const int tlin = j % ntiles;
+    if (f >= nframes) return;
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
-    const int t = blockIdx.x - g.tile_base[l];
+    while (l + 1 < g.nlevels && tlin >= g.tile_base[l + 1]) ++l;
+    const int t = tlin - g.tile_base[l];
     const int W = g.w[l], H = g.h[l], stride = g.stride[l];
     const int tiles_x = (W - 2 * kEdge + kFsTW - 1) / kFsTW;
     const int x0 = kEdge + (t % tiles_x) * kFsTW, y0 = kEdge + (t / tiles_x) * kFsTH;
@@ -1355,8 +1362,8 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
                    h->pyr.p, h->score.p);
     } else {
         for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
-        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(g.tile_base[L], nframes), dim3(256), 0, g, h->pyr.p,
-                   h->score.p);
+        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(8 * ((nframes + 7) / 8) * g.tile_base[L]), dim3(256), 0,
+                   g, nframes, h->pyr.p, h->score.p);
     }
     if (g.harris)
         SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
