@@ -66,7 +66,17 @@ struct Geom {
     int nfeatures;
     int fast_th;
     int harris;                          // scoreType == ORB::HARRIS_SCORE: retain by Harris response
+    int nframes;                         // frames of this launch
 };
+
+// Every batch kernel is launched on a (frames rounded up to 8, blocks per frame) grid.  Workgroups reach the 8 XCDs
+// round-robin in launch order (x fastest), so frame f lives on XCD f % 8 in EVERY kernel: the halos, discs and patches
+// that neighbouring workgroups of a frame share meet in one L2, and all XCDs work on the same block index at the same
+// time (equal load).
+#define SE2_FRAME_GRID(f, bx)          \
+    const int f = (int)blockIdx.x;     \
+    const int bx = (int)blockIdx.y;    \
+    if (f >= g.nframes) return
 
 // interior pixel (x, y) of level l of frame f
 __device__ __forceinline__ size_t pix(const Geom& g, int f, int l, int y, int x) {
@@ -82,10 +92,10 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) { return p < 0 
 // One thread = one 16-byte chunk of a bordered row; threads are laid out flat over (row, chunk).
 __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restrict__ imgs, int pitch,
                                                  uint8_t* __restrict__ pyr) {
-    const int f = blockIdx.y;
+    SE2_FRAME_GRID(f, bx);
     const int W = g.w[0], H = g.h[0], stride = g.stride[0];
     const int nch = stride / 16;
-    const int item = blockIdx.x * 256 + threadIdx.x;
+    const int item = bx * 256 + threadIdx.x;
     const int Y = item / nch;                                   // row of the bordered buffer
     if (Y >= H + 2 * kEdge) return;
     const int X0 = (item - Y * nch) * 16;                       // first of 16 columns of the bordered buffer
@@ -128,8 +138,8 @@ struct ResizeTab {
 };
 
 __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr) {
-    const int f = blockIdx.y;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
+    SE2_FRAME_GRID(f, bx);
+    const int gid = bx * 256 + threadIdx.x;
     const int H = g.h[l], stride = g.stride[l];
     const int Y = gid / t.ngroups;
     if (Y >= H + 2 * kEdge) return;
@@ -266,10 +276,10 @@ __device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t lef
 }
 
 __global__ __launch_bounds__(256) void k_fast_score_dense(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
-    const int f = blockIdx.y;
+    SE2_FRAME_GRID(f, bx);
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
-    const int t = blockIdx.x - g.tile_base[l];
+    while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
+    const int t = bx - g.tile_base[l];
     const int W = g.w[l], H = g.h[l], stride = g.stride[l];
     const int sw = W - 2 * kEdge;
     const int tiles_x = (sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups);
@@ -400,20 +410,13 @@ __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e
     return ~(__builtin_bit_cast(uint32_t, a) & __builtin_bit_cast(uint32_t, b)) & 0x80008000u;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(Geom g, int nframes, const uint8_t* __restrict__ pyr,
-                                                     uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
     __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
     __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
     __shared__ uint32_t s_out[(kFsTW / 4) * kFsTH];
     __shared__ uint16_t s_cand[kFsMaxCand];
     __shared__ int s_n;
-    // Workgroups are dealt to the 8 XCDs round-robin in launch order: XCD k takes the frames k, k + 8, ... whole, so that
-    // the halos shared by neighbouring tiles meet in one L2 and every XCD gets the same mix of tiles.
-    const int ntiles = g.tile_base[g.nlevels];
-    const int j = (int)(blockIdx.x >> 3);
-    const int f = 8 * (j / ntiles) + (int)(blockIdx.x & 7);
-    const int tlin = j % ntiles;
-    if (f >= nframes) return;
+    SE2_FRAME_GRID(f, tlin);
     int l = 0;
     while (l + 1 < g.nlevels && tlin >= g.tile_base[l + 1]) ++l;
     const int t = tlin - g.tile_base[l];
@@ -590,8 +593,7 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
     __shared__ uint32_t keys[kSortCap];
     __shared__ unsigned long long keys64[HARRIS ? kSortCap : 1];   // (~ordered(response) << 32) | (y << 12) | x
     __shared__ int s_n, s_n20;
-    const int f = blockIdx.y;
-    const int cell = blockIdx.x;
+    SE2_FRAME_GRID(f, cell);
     int l = 0;
     while (l + 1 < g.nlevels && cell >= g.cell_base[l + 1]) ++l;
     const int ci = (cell - g.cell_base[l]) / g.gcols[l], cj = (cell - g.cell_base[l]) % g.gcols[l];
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __
     __shared__ int n_retain[64 * 4];   // per cell (<= 256 cells per level)
     __shared__ int cell_off[64 * 4 + 1];
     __shared__ int s_kept[kMaxLevels], s_scan[256];
-    const int f = blockIdx.x, l = blockIdx.y;
+    SE2_FRAME_GRID(f, l);
     const int ncells_frame = g.cell_base[g.nlevels];
     const int wave = threadIdx.x >> 6;
     const int* tot_f = cell_total + (size_t)f * ncells_frame;
@@ -905,8 +907,8 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
     // one wave per key point: lane = (row offset v = 0..15, column octet c = 0..3); a lane reads 8 bytes of row +v and
     // of row -v with two (unaligned) 32-bit loads each - 749 disc pixels in 4 load instructions instead of 47 byte
     // loads per lane.  Integer moments: the summation order is irrelevant.
-    const int f = blockIdx.y;
-    const int k = blockIdx.x * 4 + threadIdx.x / 64;
+    SE2_FRAME_GRID(f, bx);
+    const int k = bx * 4 + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
     const int v = lane & 15, c = lane >> 4;
     const int n = counts[f];
@@ -959,8 +961,8 @@ constexpr int kBlurRows = 35;
 // overwritten by k_blur afterwards).  tile_base[l] = chunk-list prefix sums.
 __device__ __host__ inline int frame_chunks_right(int W, int stride) { return stride / 16 - (kEdge + W) / 16; }
 __global__ __launch_bounds__(256) void k_copy_frame(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    const int f = blockIdx.y;
-    const int item = blockIdx.x * 256 + threadIdx.x;
+    SE2_FRAME_GRID(f, bx);
+    const int item = bx * 256 + threadIdx.x;
     if (item >= g.tile_base[g.nlevels]) return;
     int l = 0;
     while (l + 1 < g.nlevels && item >= g.tile_base[l + 1]) ++l;
@@ -983,10 +985,10 @@ __global__ __launch_bounds__(256) void k_copy_frame(Geom g, const uint8_t* __res
 }
 
 __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    const int f = blockIdx.y;
+    SE2_FRAME_GRID(f, bx);
     int l = 0;
-    while (l + 1 < g.nlevels && (int)blockIdx.x >= g.tile_base[l + 1]) ++l;
-    const int t = blockIdx.x - g.tile_base[l];
+    while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
+    const int t = bx - g.tile_base[l];
     const int W = g.w[l], H = g.h[l], stride = g.stride[l];
     const int tiles_x = (W + 255) / 256;
     const int x0 = (t % tiles_x) * 256 + (threadIdx.x & 63) * 4;
@@ -1079,8 +1081,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
     // One wave handles TWO key points: the per-wave work is a short dependent chain (key point -> 8 byte gathers per
     // lane -> 4 ballots), so the kernel is bound by how many such chains are in flight; two per wave keep 16
     // independent gathers per lane outstanding with half the waves.
-    const int f = blockIdx.y;
-    const int k0 = 2 * (blockIdx.x * 4 + threadIdx.x / 64);
+    SE2_FRAME_GRID(f, bx);
+    const int k0 = 2 * (bx * 4 + threadIdx.x / 64);
     const int lane = threadIdx.x & 63;
     const int n = counts[f];
     if (k0 >= n) return;  // wave-uniform
@@ -1320,19 +1322,21 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
 int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu_keypoint* d_kps, uint8_t* d_desc,
             int32_t* d_counts, int cap) {
     Geom g = h->g;
+    g.nframes = nframes;
     hipStream_t st = h->stream;
     const int L = g.nlevels;
+    const unsigned F8 = 8u * (unsigned)((nframes + 7) / 8);   // grid x: frames (see SE2_FRAME_GRID)
     SE2_CHECK(h->kp_list.reserve((size_t)h->max_batch * cap));
     SE2_CHECK(h->angles.reserve((size_t)h->max_batch * cap));
     SE2_CHECK(h->angle_cs.reserve((size_t)h->max_batch * cap));
     {
-        dim3 grid(((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256, nframes);
+        dim3 grid(F8, ((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256);
         SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
     }
     for (int l = 1; l < L; ++l) {
         const int ng = g.stride[l] / 4;
         ResizeTab t{h->tabs.p + h->ytab_off[l], h->tabs.p + h->xtab_off[l], ng};
-        dim3 grid((ng * (g.h[l] + 2 * kEdge) + 255) / 256, nframes);
+        dim3 grid(F8, (ng * (g.h[l] + 2 * kEdge) + 255) / 256);
         SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
     }
     // The blurred pyramid needs only the pyramid: it runs on a side stream next to the key-point chain, whose
@@ -1350,35 +1354,35 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
             items += 2 * kEdge * (g.stride[l] / 16) + g.h[l] * (1 + frame_chunks_right(g.w[l], g.stride[l]));
         }
         gb.tile_base[L] = items;
-        SE2_LAUNCH(h->prof, sb, "k_copy_frame", k_copy_frame, dim3((items + 255) / 256, nframes), dim3(256), 0, gb, h->pyr.p,
+        SE2_LAUNCH(h->prof, sb, "k_copy_frame", k_copy_frame, dim3(F8, (items + 255) / 256), dim3(256), 0, gb, h->pyr.p,
                    h->blur.p);
         for (int l = 0; l <= L; ++l) gb.tile_base[l] = h->blur_tile_base[l];
-        SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(gb.tile_base[L], nframes), dim3(256), 0, gb, h->pyr.p, h->blur.p);
+        SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(F8, gb.tile_base[L]), dim3(256), 0, gb, h->pyr.p, h->blur.p);
     }
     if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
     if (h->dense_score) {
         for (int l = 0; l <= L; ++l) g.tile_base[l] = h->dense_tile_base[l];
-        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_dense, dim3(g.tile_base[L], nframes), dim3(256), 0, g,
+        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_dense, dim3(F8, g.tile_base[L]), dim3(256), 0, g,
                    h->pyr.p, h->score.p);
     } else {
         for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
-        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(8 * ((nframes + 7) / 8) * g.tile_base[L]), dim3(256), 0,
-                   g, nframes, h->pyr.p, h->score.p);
+        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
+                   h->score.p);
     }
     if (g.harris)
-        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
+        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(F8, g.cell_base[L]), dim3(256), 0, g,
                    h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
     else
-        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<false>, dim3(g.cell_base[L], nframes), dim3(256), 0, g,
+        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<false>, dim3(F8, g.cell_base[L]), dim3(256), 0, g,
                    h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
-    SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(nframes, L), dim3(256), 0, g, h->cell_keys.p,
+    SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
                h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
-    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3((cap + 3) / 4, nframes), dim3(256), 0, g, h->pyr.p,
+    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 3) / 4), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p);
     SE2_LAUNCH(h->prof, st, "k_angle_trig", k_angle_trig, dim3((cap + 255) / 256, nframes), dim3(256), 0, d_counts, cap,
                h->angles.p, h->angle_cs.p);
     if (sb != st) SE2_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
-    SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3((cap + 7) / 8, nframes), dim3(256), 0, g, h->blur.p,
+    SE2_LAUNCH(h->prof, st, "k_describe", k_describe, dim3(F8, (cap + 7) / 8), dim3(256), 0, g, h->blur.p,
                h->kp_list.p, d_counts, cap, h->angles.p, h->angle_cs.p, d_kps, d_desc);
     SE2_HIP(hipGetLastError());
     h->last_batch = nframes;
