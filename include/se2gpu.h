@@ -254,6 +254,22 @@ int se2gpu_track_triangulate(se2gpu_track* h, int n, const se2gpu_keypoint* kps_
                              const float* P_cur, const float* Ocam, float lower_depth, float upper_depth,
                              int min_degree, float* pos_out, uint8_t* good_parallax, int* n_good, int* n_tracked_old);
 
+/* Localizer::DoLocalBA (/root/reference/src/Localizer.cpp:233-302) - SURVEY section 8(f).2: pose-only bundle adjustment of one
+ * key frame against the fixed map points it observes, the whole optimize(iters) in one launch.
+ *   pose12      = rotation row-major (9) then translation (3) of a rigid transform, x_c = R x_w + t (Tcw)
+ *   se2gpu_plane_motion_prior  = addPlaneMotionSE3Expmap (src/optimizer.cpp:236-314): measurement = the pose with the body's
+ *       roll, pitch and height removed (Tbc = Config::bTc), information = adj(Tbc)^T diag(xrot, yrot, 1e-4, 1e-4, 1e-4, z)
+ *       adj(Tbc), vector order (rotation, translation); graph construction, runs on the host
+ *   se2gpu_track_pose_ba       = VertexSE3Expmap + n EdgeProjectXYZ2UV (information inv_sigma2[i] * I, Huber huber_delta,
+ *       single focal length f as addCamPara builds g2o::CameraParameters) + EdgeSE3ExpmapPrior(prior_meas, prior_info),
+ *       Levenberg-Marquardt with g2o's policy; xyz: n x 3 world points, uv: n x 2 key-point positions.
+ *       stats has the meaning it has for se2gpu_ba_optimize. */
+int se2gpu_plane_motion_prior(const double* Tcw12, const double* Tbc12, double xrot_info, double yrot_info, double z_info,
+                              double* meas12, double* info36);
+int se2gpu_track_pose_ba(se2gpu_track* h, const double* Tcw12, const double* prior_meas12, const double* prior_info36, int n,
+                         const double* xyz, const double* uv, const double* inv_sigma2, double f, double cx, double cy,
+                         double huber_delta, int iters, double* Tcw_out12, se2gpu_ba_stats* stats);
+
 /* Per-observation information matrices of Map::loadLocalGraph (/root/reference/src/Map.cpp:1024-1049), SURVEY §8f.1:
  *   Sigma = s_rot * J_r J_r^T + s_z * J_z J_z^T + sigma2 * I,   Omega = Sigma^-1       (2x2, FP64)
  *   J_r = (J_pi Rcw skew(lw - p))[:, 0:2],  J_z = -(J_pi Rcw)[:, 2],  J_pi from the stored camera-frame point lc.

@@ -573,4 +573,317 @@ int ba_ref_optimize(const ba_ref_problem* p, int iters, int mode, const volatile
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Localizer::DoLocalBA (src/Localizer.cpp:233-302): pose-only bundle adjustment - SURVEY.md 8(f).2.
+//   one VertexSE3Expmap (Tcw, free), the observed map points as FIXED non-marginalised VertexSBAPointXYZ,
+//   one EdgeProjectXYZ2UV per observation (information invSigma2 * I, Huber delta = Config::TH_HUBER),
+//   one EdgeSE3ExpmapPrior from addPlaneMotionSE3Expmap (src/optimizer.cpp:236-314, 159-197), LM, optimize(30).
+// [3P g2o 20160424, restated from memory]: types_six_dof_expmap (EdgeProjectXYZ2UV::computeError / linearizeOplus,
+// VertexSE3Expmap::oplusImpl = exp(update) * estimate), se3quat.h (exp, log, adj), the Levenberg policy shared with
+// ba_ref_optimize above.  Rotations are kept as matrices and passed through a unit quaternion after every product /
+// exponential, the way SE3Quat::normalizeRotation does.
+// pose12 = rotation row-major (9) then translation (3): x_c = R x_w + t.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct Se3 {
+    double R[9], t[3];
+};
+Se3 se3_from(const double* p) {
+    Se3 T;
+    std::memcpy(T.R, p, 9 * sizeof(double));
+    std::memcpy(T.t, p + 9, 3 * sizeof(double));
+    return T;
+}
+void se3_to(const Se3& T, double* p) {
+    std::memcpy(p, T.R, 9 * sizeof(double));
+    std::memcpy(p + 9, T.t, 3 * sizeof(double));
+}
+void normalize_rotation(double R[9]) {
+    // SE3Quat keeps a unit quaternion and renormalises it after every product / construction (normalizeRotation):
+    // matrix -> quaternion (Eigen's conversion) -> normalise -> matrix
+    double q[4];   // x, y, z, w
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t;
+        q[1] = (R[2] - R[6]) * t;
+        q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[4 * i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+    }
+    if (q[3] < 0)
+        for (int a = 0; a < 4; ++a) q[a] = -q[a];
+    const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int a = 0; a < 4; ++a) q[a] /= nrm;
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+Se3 se3_mul(const Se3& a, const Se3& b) {
+    Se3 c;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * i] * b.R[j] + a.R[3 * i + 1] * b.R[3 + j] + a.R[3 * i + 2] * b.R[6 + j];
+        c.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
+    }
+    normalize_rotation(c.R);
+    return c;
+}
+Se3 se3_inv(const Se3& a) {
+    Se3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * j + i];
+    for (int i = 0; i < 3; ++i) c.t[i] = -(c.R[3 * i] * a.t[0] + c.R[3 * i + 1] * a.t[1] + c.R[3 * i + 2] * a.t[2]);
+    return c;
+}
+void skew3(const double v[3], double S[9]) {
+    S[0] = 0; S[1] = -v[2]; S[2] = v[1];
+    S[3] = v[2]; S[4] = 0; S[5] = -v[0];
+    S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
+}
+void mat3_mul(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// SE3Quat::exp, update = (omega, upsilon)
+Se3 se3_exp(const double u[6]) {
+    const double theta = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    double Om[9], Om2[9], V[9];
+    skew3(u, Om);
+    mat3_mul(Om, Om, Om2);
+    Se3 T;
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; ++i) T.R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i];
+        std::memcpy(V, T.R, sizeof(V));
+    } else {
+        const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta);
+        const double c = (theta - std::sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 9; ++i) {
+            T.R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
+            V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
+        }
+    }
+    for (int i = 0; i < 3; ++i) T.t[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+    normalize_rotation(T.R);
+    return T;
+}
+// SE3Quat::log -> (omega, upsilon)
+void se3_log(const Se3& T, double out[6]) {
+    const double* R = T.R;
+    const double d = 0.5 * (R[0] + R[4] + R[8] - 1);
+    const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    double om[3], Om[9], Om2[9], Vi[9];
+    if (d > 0.99999) {
+        for (int i = 0; i < 3; ++i) om[i] = 0.5 * dR[i];
+        skew3(om, Om);
+        mat3_mul(Om, Om, Om2);
+        for (int i = 0; i < 9; ++i) Vi[i] = (i % 4 == 0 ? 1.0 : 0.0) - 0.5 * Om[i] + (1. / 12.) * Om2[i];
+    } else {
+        const double theta = std::acos(d);
+        const double k = theta / (2 * std::sqrt(1 - d * d));
+        for (int i = 0; i < 3; ++i) om[i] = k * dR[i];
+        skew3(om, Om);
+        mat3_mul(Om, Om, Om2);
+        const double c = (1 - theta / (2 * std::tan(theta / 2))) / (theta * theta);
+        for (int i = 0; i < 9; ++i) Vi[i] = (i % 4 == 0 ? 1.0 : 0.0) - 0.5 * Om[i] + c * Om2[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        out[i] = om[i];
+        out[3 + i] = Vi[3 * i] * T.t[0] + Vi[3 * i + 1] * T.t[1] + Vi[3 * i + 2] * T.t[2];
+    }
+}
+
+struct PoseProblem {
+    int n;
+    const double *xyz, *uv, *w;
+    double f, cx, cy, delta;
+    Se3 prior;
+    const double* prior_info;   // 6x6 row-major
+};
+
+// robust chi2 of all edges at T; when H / b are given also the normal equations (21 upper entries filled symmetric)
+double pose_system(const PoseProblem& p, const Se3& T, double* H, double* b) {
+    if (H) { std::memset(H, 0, 36 * sizeof(double)); std::memset(b, 0, 6 * sizeof(double)); }
+    double chi = 0;
+    for (int i = 0; i < p.n; ++i) {
+        const double* X = p.xyz + 3 * i;
+        const double x = T.R[0] * X[0] + T.R[1] * X[1] + T.R[2] * X[2] + T.t[0];
+        const double y = T.R[3] * X[0] + T.R[4] * X[1] + T.R[5] * X[2] + T.t[1];
+        const double z = T.R[6] * X[0] + T.R[7] * X[1] + T.R[8] * X[2] + T.t[2];
+        const double e0 = p.uv[2 * i] - (x / z * p.f + p.cx), e1 = p.uv[2 * i + 1] - (y / z * p.f + p.cy);
+        const double w = p.w[i];
+        const double e2 = w * (e0 * e0 + e1 * e1);
+        double rho0, rho1;
+        if (e2 <= p.delta * p.delta) { rho0 = e2; rho1 = 1; }
+        else { const double sq = std::sqrt(e2); rho0 = 2 * sq * p.delta - p.delta * p.delta; rho1 = p.delta / sq; }
+        chi += rho0;
+        if (!H) continue;
+        const double z2 = z * z, f = p.f;
+        const double J[2][6] = {{x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f},
+                                {(1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f}};
+        const double ww = rho1 * w;
+        for (int a = 0; a < 6; ++a) {
+            b[a] += -ww * (J[0][a] * e0 + J[1][a] * e1);
+            for (int c = 0; c < 6; ++c) H[6 * a + c] += ww * (J[0][a] * J[0][c] + J[1][a] * J[1][c]);
+        }
+    }
+    // EdgeSE3ExpmapPrior: error = log(measurement * estimate^-1), Jacobian = -I, no robust kernel
+    double ep[6];
+    se3_log(se3_mul(p.prior, se3_inv(T)), ep);
+    for (int a = 0; a < 6; ++a) {
+        double s = 0;
+        for (int c = 0; c < 6; ++c) s += p.prior_info[6 * a + c] * ep[c];
+        chi += ep[a] * s;
+        if (H) {
+            b[a] += s;
+            for (int c = 0; c < 6; ++c) H[6 * a + c] += p.prior_info[6 * a + c];
+        }
+    }
+    return chi;
+}
+
+bool solve6(const double* H, double lambda, const double* b, double* x) {
+    double L[36];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) L[6 * i + j] = H[6 * i + j] + (i == j ? lambda : 0.0);
+    for (int j = 0; j < 6; ++j) {
+        double d = L[6 * j + j];
+        for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
+        if (!(d > 0)) return false;
+        d = std::sqrt(d);
+        L[6 * j + j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = L[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+            L[6 * i + j] = v / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+        for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+        y[i] = v / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k];
+        x[i] = v / L[6 * i + i];
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// addPlaneMotionSE3Expmap (src/optimizer.cpp:236-314, the non-Euler branch): measurement = the pose with roll, pitch and
+// height of the BODY removed, information = adj(Tbc)^T diag(xrot, yrot, 1e-4, 1e-4, 1e-4, z) adj(Tbc), made symmetric
+// by copying the upper triangle (:296-298)
+void ba_ref_plane_motion_prior(const double* Tcw12, const double* Tbc12, double xrot_info, double yrot_info, double z_info,
+                               double* meas12, double* info36) {
+    const Se3 Tcw = se3_from(Tcw12), Tbc = se3_from(Tbc12);
+    Se3 Tbw = se3_mul(Tbc, Tcw);
+    double lg[6];
+    Se3 Ronly = Tbw;
+    Ronly.t[0] = Ronly.t[1] = Ronly.t[2] = 0;
+    se3_log(Ronly, lg);                       // rotation vector of Rbw (Eigen::AngleAxisd angle * axis)
+    const double yaw = lg[2];
+    const double c = std::cos(yaw), sn = std::sin(yaw);
+    const double Rz[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
+    std::memcpy(Tbw.R, Rz, sizeof(Rz));
+    Tbw.t[2] = 0;
+    se3_to(se3_mul(se3_inv(Tbc), Tbw), meas12);
+    double A[36] = {0}, sk[9], sR[9];         // SE3Quat::adj: [R 0; skew(t) R  R], vector order (rot, trans)
+    skew3(Tbc.t, sk);
+    mat3_mul(sk, Tbc.R, sR);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            A[6 * i + j] = Tbc.R[3 * i + j];
+            A[6 * (i + 3) + (j + 3)] = Tbc.R[3 * i + j];
+            A[6 * (i + 3) + j] = sR[3 * i + j];
+        }
+    const double D[6] = {xrot_info, yrot_info, 1e-4, 1e-4, 1e-4, z_info};
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double s = 0;
+            for (int k = 0; k < 6; ++k) s += A[6 * k + i] * D[k] * A[6 * k + j];
+            info36[6 * i + j] = s;
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < i; ++j) info36[6 * i + j] = info36[6 * j + i];
+}
+
+int ba_ref_pose_only(const double* Tcw12, const double* prior_meas12, const double* prior_info36, int n, const double* xyz,
+                     const double* uv, const double* inv_sigma2, double f, double cx, double cy, double delta, int iters,
+                     double* Tcw_out12, ba_ref_stats* stats) {
+    PoseProblem p{n, xyz, uv, inv_sigma2, f, cx, cy, delta, se3_from(prior_meas12), prior_info36};
+    Se3 est = se3_from(Tcw12);
+    ba_ref_stats s;
+    std::memset(&s, 0, sizeof(s));
+    double lambda = 0, ni = 2, H[36], b[6], x[6];
+    s.chi2_init = pose_system(p, est, nullptr, nullptr);
+    s.chi2_final = s.chi2_init;
+    bool ok = true;
+    for (int it = 0; it < iters && ok; ++it) {
+        double currentChi = pose_system(p, est, H, b);
+        if (it == 0) {
+            double maxd = 0;
+            for (int r = 0; r < 6; ++r) maxd = std::max(std::fabs(H[7 * r]), maxd);
+            lambda = 1e-5 * maxd;
+            ni = 2;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            const bool ok2 = solve6(H, lambda, b, x);
+            if (!ok2) std::memset(x, 0, sizeof(x));
+            const Se3 trial = se3_mul(se3_exp(x), est);
+            double tempChi = pose_system(p, trial, nullptr, nullptr);
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            ++s.trials;
+            ++qmax;
+            rho = currentChi - tempChi;
+            double scale = 1e-3;
+            for (int r = 0; r < 6; ++r) scale += x[r] * (lambda * x[r] + b[r]);
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow(2 * rho - 1, 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha);
+                ni = 2;
+                currentChi = tempChi;
+                est = trial;
+            } else {
+                lambda *= ni;
+                ni *= 2;
+            }
+        } while (rho < 0 && qmax < 10);
+        if (it < 64) { s.chi2_hist[it] = currentChi; s.lambda_hist[it] = lambda; s.trials_hist[it] = qmax; }
+        s.iterations = it + 1;
+        s.chi2_final = currentChi;
+        if (qmax == 10 || rho == 0) { s.terminated = 1; ok = false; }
+    }
+    s.lambda_final = lambda;
+    se3_to(est, Tcw_out12);
+    if (stats) *stats = s;
+    return 0;
+}
+
 }  // extern "C"

@@ -429,3 +429,50 @@ def remove_outliers(kps1, kps2, matches):
     f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     ni = f(k1.ctypes.data, len(k1), k2.ctypes.data, len(k2), m.ctypes.data)
     return m, int(ni)
+
+
+def _pose12(T):
+    T = np.asarray(T, np.float64)
+    if T.shape == (12,):
+        return np.ascontiguousarray(T)
+    return np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+
+
+def pose12_to_matrix(p):
+    T = np.eye(4)
+    T[:3, :3] = np.asarray(p[:9]).reshape(3, 3)
+    T[:3, 3] = p[9:12]
+    return T
+
+
+def plane_motion_prior(Tcw, Tbc, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    """addPlaneMotionSE3Expmap (optimizer.cpp:236-314) -> (measurement 4x4, information 6x6)"""
+    meas = np.zeros(12); info = np.zeros(36)
+    f = lib().ba_ref_plane_motion_prior
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    a, b = _pose12(Tcw), _pose12(Tbc)
+    f(a.ctypes.data, b.ctypes.data, xrot_info, yrot_info, z_info, meas.ctypes.data, info.ctypes.data)
+    return pose12_to_matrix(meas), info.reshape(6, 6)
+
+
+def pose_only_ba(Tcw, prior_meas, prior_info, xyz, uv, inv_sigma2, f, cx, cy, delta, iters=30):
+    """Localizer::DoLocalBA (Localizer.cpp:233-302) -> (Tcw 4x4, stats dict)"""
+    xyz = np.ascontiguousarray(xyz, np.float64); uv = np.ascontiguousarray(uv, np.float64)
+    w = np.ascontiguousarray(inv_sigma2, np.float64)
+    out = np.zeros(12)
+    st = BaStats()
+    fn = lib().ba_ref_pose_only
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                   C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(BaStats)]
+    a, m = _pose12(Tcw), _pose12(prior_meas)
+    pi = np.ascontiguousarray(prior_info, np.float64).reshape(-1)
+    rc = fn(a.ctypes.data, m.ctypes.data, pi.ctypes.data, len(xyz), xyz.ctypes.data, uv.ctypes.data, w.ctypes.data, f, cx, cy,
+            delta, iters, out.ctypes.data, C.byref(st))
+    assert rc == 0
+    n = min(st.iterations, 64)
+    stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated), chi2_init=st.chi2_init,
+                 chi2_final=st.chi2_final, lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
+                 lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]))
+    return pose12_to_matrix(out), stats

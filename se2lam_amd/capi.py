@@ -119,6 +119,8 @@ SYMBOLS = {
     "se2gpu_track_fundamental_mask": (_I, [_VP, _VP, _VP, _I, _VP, C.POINTER(C.c_int)]),
     "se2gpu_track_remove_outliers": (_I, [_VP, _VP, _I, _VP, _I, _VP, C.POINTER(C.c_int)]),
     "se2gpu_track_last_ransac": (_I, [_VP, _VP]),
+    "se2gpu_plane_motion_prior": (_I, [_VP, _VP, _D, _D, _D, _VP, _VP]),
+    "se2gpu_track_pose_ba": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP, _D, _D, _D, _D, _I, _VP, C.POINTER(BaStats)]),
     "se2gpu_track_triangulate": (_I, [_VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _I, _VP, _VP,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se2gpu_ba_reduce_buffer_doubles": (_SZ, [_VP, _I]),

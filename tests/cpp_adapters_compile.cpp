@@ -1,6 +1,7 @@
 // Compile-and-link check of the C++ adapters (include/se2lam_amd/*.h) against libse2gpu.so.  Without a GPU it only
 // checks that construction fails loudly with SE2GPU_ERR_NO_DEVICE; on the GPU box it runs a tiny localBA-shaped
 // call sequence through the reference's names.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -9,6 +10,7 @@
 #include "se2lam_amd/optimizer.h"
 #include "se2lam_amd/preintegration.h"
 #include "se2lam_amd/Track.h"
+#include "se2lam_amd/Localizer.h"
 
 using namespace se2lam_amd;
 
@@ -95,5 +97,27 @@ int main() {
     }
     const int nInlier = track.removeOutliers(kps, kps2, m12);
     std::printf("Track::removeOutliers adapter: %d inliers of %d matches\n", nInlier, nm);
-    return kps.empty() || nInlier != nm ? 1 : 0;
+    // Localizer::DoLocalBA shape: 60 map points in front of a planar pose, exact observations, pose started 30 mm off
+    LocalizerBA localizer;
+    SE3Quat Tcw0;   // camera looking along world x: Tcw = Tbc^-1 for the body at the origin
+    const double Rcb[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
+    std::memcpy(Tcw0.R, Rcb, sizeof(Rcb));
+    Tcw0.t[0] = 0; Tcw0.t[1] = 300; Tcw0.t[2] = -100;
+    std::vector<Vector3D> mps; std::vector<Vector2D> obs; std::vector<double> w;
+    for (int i = 0; i < 60; ++i) {
+        const double X = 3000 + 40 * i, Y = -900 + 31 * i, Z = 100 + 7 * (i % 9);
+        const double xc = Rcb[0] * X + Rcb[1] * Y + Rcb[2] * Z + Tcw0.t[0], yc = Rcb[3] * X + Rcb[4] * Y + Rcb[5] * Z + Tcw0.t[1];
+        const double zc = Rcb[6] * X + Rcb[7] * Y + Rcb[8] * Z + Tcw0.t[2];
+        mps.push_back(Vector3D{{X, Y, Z}});
+        obs.push_back(Vector2D{{400 * xc / zc + 320, 400 * yc / zc + 240}});
+        w.push_back(1.0);
+    }
+    SE3Quat start = Tcw0;
+    start.t[0] += 30;
+    se2gpu_ba_stats pst;
+    const SE3Quat opt = localizer.DoLocalBA(start, Tbc, mps, obs, w, 400, 320, 240, 2.4477, 1e6, 1e6, 1, 30, &pst);
+    std::printf("Localizer::DoLocalBA adapter: chi2 %.3f -> %.6f in %d iterations, t = (%.2f %.2f %.2f)\n", pst.chi2_init,
+                pst.chi2_final, pst.iterations, opt.t[0], opt.t[1], opt.t[2]);
+    const bool pose_ok = std::fabs(opt.t[0] - Tcw0.t[0]) < 5.0 && pst.chi2_final < 1e-3 * pst.chi2_init;   // the weak planar prior keeps ~2 mm
+    return kps.empty() || nInlier != nm || !pose_ok ? 1 : 0;
 }
