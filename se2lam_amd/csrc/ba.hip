@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <limits>
+#include <mutex>
 #include <unordered_map>
 
 #include "common.h"
@@ -1366,6 +1367,30 @@ __global__ void k_edge_information(int E, const float* __restrict__ lc_, const f
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
+// vertex id -> slot.  g2o ids are small dense integers (Map.cpp:925-985 numbers them 0 .. nKF + nMP); a direct table keeps
+// the bulk load of a 20 k-landmark window out of a hash map.  Ids outside [0, kDenseIds) fall back to the map.
+struct IdTable {
+    static constexpr unsigned kDenseIds = 1u << 24;
+    std::vector<int> dense;
+    std::unordered_map<int, int> sparse;
+    int find(int id) const {
+        if ((unsigned)id < dense.size()) return dense[(unsigned)id];
+        if ((unsigned)id < kDenseIds) return -1;
+        const auto it = sparse.find(id);
+        return it == sparse.end() ? -1 : it->second;
+    }
+    void set(int id, int slot) {
+        if ((unsigned)id < kDenseIds) {
+            if ((unsigned)id >= dense.size()) dense.resize(std::max<size_t>((size_t)id + 1, 2 * dense.size()), -1);
+            dense[(unsigned)id] = slot;
+        } else {
+            sparse[id] = slot;
+        }
+    }
+    void clear() { dense.clear(); sparse.clear(); }
+    void reserve(size_t n) { dense.reserve(n); }
+};
+
 struct se2gpu_ba {
     hipStream_t own_stream = nullptr, stream = nullptr;
     LaunchProfile prof;
@@ -1373,7 +1398,7 @@ struct se2gpu_ba {
     CamDev cam{};
     bool have_cam = false, have_tbc = false;
     double Rbc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tbc[3] = {0, 0, 0};
-    std::unordered_map<int, int> pose_of_id, lm_of_id;
+    IdTable pose_of_id, lm_of_id;
     std::vector<int> pose_ids, lm_ids;
     std::vector<double> h_poses, h_lms;
     std::vector<uint8_t> h_fixed;
@@ -1412,6 +1437,12 @@ struct se2gpu_ba {
     se2gpu_comm* comm = nullptr;   // native RCCL path (se2gpu_ba_set_comm)
     void* ar_buffer = nullptr;
     int root = 1, rank = 0, world = 1;
+    int device = 0;                // device the buffers live on (handles are pooled per device, see se2gpu_ba_destroy)
+    PinBuf<uint8_t> h_stage;       // pinned arena the graph arrays pass through on their way to the device
+    // host copy of the estimates: Map::optimizeLocalGraph asks for every vertex separately (Map.cpp:754-783), one
+    // download serves all of those calls until the estimates change again
+    PinBuf<double> est;            // [poses 3P | landmarks 3L]
+    bool est_valid = false;
 
     ~se2gpu_ba() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -1422,6 +1453,13 @@ struct se2gpu_ba {
 namespace {
 
 int ba_upload_graph(se2gpu_ba* h) {
+    static const bool trace = [] { const char* e = getenv("SE2GPU_BA_INIT_TRACE"); return e && e[0] == '1'; }();
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (trace)
+            std::fprintf(stderr, "[ba init] %-28s %8.1f us\n", what,
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     const int P = (int)h->pose_ids.size(), L = (int)h->lm_ids.size();
     const int E = (int)h->obs.size(), O = (int)h->odo.size();
     SE2_REQUIRE(P > 0, SE2GPU_ERR_STATE, "initialize: no pose vertices");
@@ -1474,6 +1512,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             podo_item[f[o_j[k]]++] = 2 * k + 1;
         }
     }
+    lap("edge sort + CSR");
     // --- reduced-system block plan: upper-triangular (a <= b) blocks, contributor pairs per block
     const int nblk = P * (P + 1) / 2;
     auto blk_index = [P](int a, int b) { return a * P - a * (a - 1) / 2 + (b - a); };
@@ -1484,13 +1523,23 @@ int ba_upload_graph(se2gpu_ba* h) {
             blk_b[blk_index(a, b)] = b;
         }
     const std::vector<uint8_t>& fx = h->h_fixed;
+    // every unordered pair of observations of a landmark by two different free poses contributes to one block; the pair
+    // is stored with the lower pose first.  Pass 1 records the block of each pair (in landmark order), pass 2 scatters.
+    std::vector<int> pkey;
+    std::vector<int2> pst;
+    pkey.reserve(4 * (size_t)E);
+    pst.reserve(4 * (size_t)E);
     for (int l = 0; l < L; ++l)
         for (int s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
-            if (fx[e_kf[s]]) continue;
-            for (int t = lm_ptr[l]; t < lm_ptr[l + 1]; ++t) {
-                if (fx[e_kf[t]]) continue;
-                const int a = e_kf[s], b = e_kf[t];
-                if (a < b) blk_ptr[blk_index(a, b) + 1]++;
+            const int a = e_kf[s];
+            if (fx[a]) continue;
+            for (int t = s + 1; t < lm_ptr[l + 1]; ++t) {
+                const int b = e_kf[t];
+                if (fx[b] || a == b) continue;
+                const int q = a < b ? blk_index(a, b) : blk_index(b, a);
+                pkey.push_back(q);
+                pst.push_back(a < b ? make_int2(s, t) : make_int2(t, s));
+                blk_ptr[q + 1]++;
             }
         }
     for (int k = 0; k < nblk; ++k) blk_ptr[k + 1] += blk_ptr[k];
@@ -1498,20 +1547,13 @@ int ba_upload_graph(se2gpu_ba* h) {
     std::vector<int> pair_i(npairs), pair_j(npairs);
     {
         std::vector<int> f(blk_ptr.begin(), blk_ptr.end() - 1);
-        for (int l = 0; l < L; ++l)
-            for (int s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
-                if (fx[e_kf[s]]) continue;
-                for (int t = lm_ptr[l]; t < lm_ptr[l + 1]; ++t) {
-                    if (fx[e_kf[t]]) continue;
-                    const int a = e_kf[s], b = e_kf[t];
-                    if (a < b) {
-                        const int q = f[blk_index(a, b)]++;
-                        pair_i[q] = s;
-                        pair_j[q] = t;
-                    }
-                }
-            }
+        for (size_t k = 0; k < pkey.size(); ++k) {
+            const int q = f[pkey[k]]++;
+            pair_i[q] = pst[k].x;
+            pair_j[q] = pst[k].y;
+        }
     }
+    lap("pair lists");
     h->nblk = nblk;
     // PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan; duplicates fall back
     std::vector<int> blk_odo(nblk, -1);
@@ -1551,31 +1593,46 @@ int ba_upload_graph(se2gpu_ba* h) {
         if (grp.empty()) grp.assign(kGrpPerWG, make_int4(-1, 0, 0, 0));
     }
     h->nwg_off = (int)(grp.size() / kGrpPerWG);
+    lap("workgroup packing");
     hipStream_t st = h->stream;
     const int n = 3 * P;
-    SE2_CHECK(h->grp.upload(grp, st));
-    SE2_CHECK(h->poses0.upload(h->h_poses, st));
-    SE2_CHECK(h->lms0.upload(h->h_lms, st));
-    SE2_CHECK(h->fixed.upload(h->h_fixed, st));
-    SE2_CHECK(h->lm_ptr.upload(lm_ptr, st));
-    SE2_CHECK(h->e_kf.upload(e_kf, st));
-    SE2_CHECK(h->e_lm.upload(e_lm, st));
-    SE2_CHECK(h->e_uv.upload(e_uv, st));
-    SE2_CHECK(h->e_info.upload(e_info, st));
-    SE2_CHECK(h->pose_ptr.upload(pose_ptr, st));
-    SE2_CHECK(h->pose_edges.upload(pose_edges, st));
-    SE2_CHECK(h->podo_ptr.upload(podo_ptr, st));
-    SE2_CHECK(h->podo_item.upload(podo_item, st));
-    SE2_CHECK(h->o_i.upload(o_i, st));
-    SE2_CHECK(h->o_j.upload(o_j, st));
-    SE2_CHECK(h->o_meas.upload(o_meas, st));
-    SE2_CHECK(h->o_info.upload(o_info, st));
-    SE2_CHECK(h->blk_a.upload(blk_a, st));
-    SE2_CHECK(h->blk_b.upload(blk_b, st));
-    SE2_CHECK(h->blk_ptr.upload(blk_ptr, st));
-    SE2_CHECK(h->blk_odo.upload(blk_odo, st));
-    SE2_CHECK(h->pair_i.upload(pair_i, st));
-    SE2_CHECK(h->pair_j.upload(pair_j, st));
+    // All graph arrays go through ONE pinned arena: a copy from pageable memory is staged synchronously by the runtime
+    // (about 20 us each), 23 of them were most of initializeOptimization for a local window.
+    struct Staged { void* dst; const void* src; size_t bytes; };
+    std::vector<Staged> staged;
+    size_t staged_bytes = 0;
+    auto stage = [&](auto& buf, const auto& vec) -> int {
+        SE2_CHECK(buf.reserve(vec.size()));
+        const size_t bytes = vec.size() * sizeof(vec[0]);
+        if (bytes) {
+            staged.push_back(Staged{buf.p, vec.data(), bytes});
+            staged_bytes += (bytes + 63) & ~(size_t)63;
+        }
+        return SE2GPU_OK;
+    };
+    SE2_CHECK(stage(h->grp, grp));
+    SE2_CHECK(stage(h->poses0, h->h_poses));
+    SE2_CHECK(stage(h->lms0, h->h_lms));
+    SE2_CHECK(stage(h->fixed, h->h_fixed));
+    SE2_CHECK(stage(h->lm_ptr, lm_ptr));
+    SE2_CHECK(stage(h->e_kf, e_kf));
+    SE2_CHECK(stage(h->e_lm, e_lm));
+    SE2_CHECK(stage(h->e_uv, e_uv));
+    SE2_CHECK(stage(h->e_info, e_info));
+    SE2_CHECK(stage(h->pose_ptr, pose_ptr));
+    SE2_CHECK(stage(h->pose_edges, pose_edges));
+    SE2_CHECK(stage(h->podo_ptr, podo_ptr));
+    SE2_CHECK(stage(h->podo_item, podo_item));
+    SE2_CHECK(stage(h->o_i, o_i));
+    SE2_CHECK(stage(h->o_j, o_j));
+    SE2_CHECK(stage(h->o_meas, o_meas));
+    SE2_CHECK(stage(h->o_info, o_info));
+    SE2_CHECK(stage(h->blk_a, blk_a));
+    SE2_CHECK(stage(h->blk_b, blk_b));
+    SE2_CHECK(stage(h->blk_ptr, blk_ptr));
+    SE2_CHECK(stage(h->blk_odo, blk_odo));
+    SE2_CHECK(stage(h->pair_i, pair_i));
+    SE2_CHECK(stage(h->pair_j, pair_j));
     SE2_CHECK(h->poses_a.reserve(3 * (size_t)P));
     SE2_CHECK(h->poses_b.reserve(3 * (size_t)P));
     SE2_CHECK(h->lms_a.reserve(3 * (size_t)L + 1));
@@ -1623,7 +1680,16 @@ int ba_upload_graph(se2gpu_ba* h) {
             for (int r = 0; r < j; ++r) tasks.push_back(make_int2(r | (1 << 16), j));
         }
         h->chol_ntask = (int)tasks.size();
-        SE2_CHECK(h->chol_tasks.upload(tasks, st));
+        SE2_CHECK(stage(h->chol_tasks, tasks));
+        lap("reserve");
+        SE2_CHECK(h->h_stage.reserve(staged_bytes));
+        size_t off = 0;
+        for (const Staged& sg : staged) {
+            std::memcpy(h->h_stage.p + off, sg.src, sg.bytes);
+            SE2_HIP(hipMemcpyAsync(sg.dst, h->h_stage.p + off, sg.bytes, hipMemcpyHostToDevice, st));
+            off += (sg.bytes + 63) & ~(size_t)63;
+        }
+        lap("staging + enqueue");
         SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
         SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
         h->chol_epoch = 0;
@@ -1650,7 +1716,9 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));
     if (L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
     SE2_HIP(hipStreamSynchronize(st));
+    lap("synchronise");
     h->initialized = true;
+    h->est_valid = false;
     return SE2GPU_OK;
 }
 
@@ -1850,10 +1918,36 @@ int ba_lambda_init(se2gpu_ba* h, double* lambda) {
 
 extern "C" {
 
+// The reference constructs a SlamOptimizer on the stack of every localBA call (LocalMapper.cpp:239); a handle's streams,
+// mailbox and ~50 device buffers cost milliseconds to create and free, more than the optimisation of a local window.
+// Destroyed handles are therefore parked (per device, at most kPoolMax) with their buffers and handed out again by
+// se2gpu_ba_create, reset to the state of a new one.  SE2GPU_BA_POOL=0 disables this.
+namespace {
+constexpr size_t kPoolMax = 4;
+std::mutex g_pool_mu;
+std::vector<se2gpu_ba*> g_pool;
+bool pool_enabled() {
+    static const bool on = [] { const char* e = getenv("SE2GPU_BA_POOL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+}  // namespace
+
 int se2gpu_ba_create(se2gpu_ba** out) {
     SE2_REQUIRE(out, SE2GPU_ERR_INVALID, "ba_create: out is NULL");
     SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
+    int dev = 0;
+    SE2_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i]->device == dev) {
+                *out = g_pool[i];
+                g_pool.erase(g_pool.begin() + (ptrdiff_t)i);
+                return SE2GPU_OK;
+            }
+    }
     se2gpu_ba* h = new se2gpu_ba;
+    h->device = dev;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         set_error("hipStreamCreate failed");
@@ -1864,7 +1958,30 @@ int se2gpu_ba_create(se2gpu_ba** out) {
     return SE2GPU_OK;
 }
 
-void se2gpu_ba_destroy(se2gpu_ba* h) { delete h; }
+void se2gpu_ba_destroy(se2gpu_ba* h) {
+    if (!h) return;
+    if (pool_enabled()) {
+        (void)hipStreamSynchronize(h->stream);
+        if (h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
+        (void)se2gpu_ba_clear(h);
+        h->have_tbc = false;
+        const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(h->Rbc, I3, sizeof(I3));
+        h->tbc[0] = h->tbc[1] = h->tbc[2] = 0;
+        h->stream = h->own_stream;
+        h->prof.enabled = false;
+        h->prof.reset();
+        h->allreduce = nullptr; h->ar_user = nullptr; h->comm = nullptr; h->ar_buffer = nullptr;
+        h->red = nullptr;
+        h->root = 1; h->rank = 0; h->world = 1;
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool.size() < kPoolMax) {
+            g_pool.push_back(h);
+            return;
+        }
+    }
+    delete h;
+}
 
 int se2gpu_ba_clear(se2gpu_ba* h) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
@@ -1872,6 +1989,7 @@ int se2gpu_ba_clear(se2gpu_ba* h) {
     h->h_poses.clear(); h->h_lms.clear(); h->h_fixed.clear(); h->obs.clear(); h->odo.clear();
     h->have_cam = false;
     h->initialized = false;
+    h->est_valid = false;
     return SE2GPU_OK;
 }
 
@@ -1900,8 +2018,8 @@ int se2gpu_ba_set_Tbc(se2gpu_ba* h, const double R[9], const double t[3]) {
 int se2gpu_ba_add_vertex_se2(se2gpu_ba* h, int id, double x, double y, double theta, int fixed) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
-    SE2_REQUIRE(!h->pose_of_id.count(id) && !h->lm_of_id.count(id), SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
-    h->pose_of_id[id] = (int)h->pose_ids.size();
+    SE2_REQUIRE(h->pose_of_id.find(id) < 0 && h->lm_of_id.find(id) < 0, SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    h->pose_of_id.set(id, (int)h->pose_ids.size());
     h->pose_ids.push_back(id);
     h->h_poses.push_back(x); h->h_poses.push_back(y); h->h_poses.push_back(normalize_theta(theta));  // SE2 ctor
     h->h_fixed.push_back(fixed ? 1 : 0);
@@ -1913,8 +2031,8 @@ int se2gpu_ba_add_vertex_xyz(se2gpu_ba* h, int id, const double xyz[3], int marg
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
     SE2_REQUIRE(marginal && !fixed, SE2GPU_ERR_INVALID,
                 "only marginalised, free landmarks are supported (addVertexSBAXYZ defaults, optimizer.h:91)");
-    SE2_REQUIRE(!h->pose_of_id.count(id) && !h->lm_of_id.count(id), SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
-    h->lm_of_id[id] = (int)h->lm_ids.size();
+    SE2_REQUIRE(h->pose_of_id.find(id) < 0 && h->lm_of_id.find(id) < 0, SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    h->lm_of_id.set(id, (int)h->lm_ids.size());
     h->lm_ids.push_back(id);
     h->h_lms.push_back(xyz[0]); h->h_lms.push_back(xyz[1]); h->h_lms.push_back(xyz[2]);
     return SE2GPU_OK;
@@ -1924,12 +2042,10 @@ int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double u
                               double huber_delta) {
     SE2_REQUIRE(h && uv && info, SE2GPU_ERR_INVALID, "add_edge_se2xyz: NULL argument");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
-    auto a = h->pose_of_id.find(id_kf);
-    auto b = h->lm_of_id.find(id_mp);
-    SE2_REQUIRE(a != h->pose_of_id.end() && b != h->lm_of_id.end(), SE2GPU_ERR_INVALID,
-                "add_edge_se2xyz: unknown vertex id (%d, %d)", id_kf, id_mp);
+    const int a = h->pose_of_id.find(id_kf), b = h->lm_of_id.find(id_mp);
+    SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_se2xyz: unknown vertex id (%d, %d)", id_kf, id_mp);
     EdgeObs e;
-    e.kf = a->second; e.lm = b->second;
+    e.kf = a; e.lm = b;
     e.uv[0] = uv[0]; e.uv[1] = uv[1];
     e.info[0] = info[0]; e.info[1] = 0.5 * (info[1] + info[2]); e.info[2] = info[3];
     e.huber = huber_delta;
@@ -1940,12 +2056,10 @@ int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double u
 int se2gpu_ba_add_edge_se2(se2gpu_ba* h, int id0, int id1, const double meas[3], const double info[9]) {
     SE2_REQUIRE(h && meas && info, SE2GPU_ERR_INVALID, "add_edge_se2: NULL argument");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
-    auto a = h->pose_of_id.find(id0);
-    auto b = h->pose_of_id.find(id1);
-    SE2_REQUIRE(a != h->pose_of_id.end() && b != h->pose_of_id.end(), SE2GPU_ERR_INVALID,
-                "add_edge_se2: unknown pose id (%d, %d)", id0, id1);
+    const int a = h->pose_of_id.find(id0), b = h->pose_of_id.find(id1);
+    SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_se2: unknown pose id (%d, %d)", id0, id1);
     EdgeOdo e;
-    e.i = a->second; e.j = b->second;
+    e.i = a; e.j = b;
     std::memcpy(e.meas, meas, 24);
     std::memcpy(e.info, info, 72);
     h->odo.push_back(e);
@@ -1985,6 +2099,7 @@ int se2gpu_ba_initialize(se2gpu_ba* h) {
 
 int se2gpu_ba_reset_estimates(se2gpu_ba* h) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "reset_estimates before initialize");
+    h->est_valid = false;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)h->P * 8, hipMemcpyDeviceToDevice, h->stream));
     if (h->L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)h->L * 8, hipMemcpyDeviceToDevice, h->stream));
     return SE2GPU_OK;
@@ -2090,6 +2205,7 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
                        se2gpu_ba_stats* stats) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "optimize before initialize");
     SE2_REQUIRE(mode == SE2GPU_BA_LM || mode == SE2GPU_BA_GN, SE2GPU_ERR_INVALID, "unknown mode %d", mode);
+    h->est_valid = false;
     se2gpu_ba_stats s;
     std::memset(&s, 0, sizeof(s));
     const int n = 3 * h->P;
@@ -2162,29 +2278,40 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
     return SE2GPU_OK;
 }
 
+static int ba_fetch_estimates(se2gpu_ba* h) {
+    if (h->est_valid) return SE2GPU_OK;
+    const size_t np = 3 * (size_t)h->P, nl = 3 * (size_t)h->L;
+    SE2_CHECK(h->est.reserve(np + nl + 1));
+    SE2_HIP(hipMemcpyAsync(h->est.p, h->poses, np * 8, hipMemcpyDeviceToHost, h->stream));
+    if (nl) SE2_HIP(hipMemcpyAsync(h->est.p + np, h->lms, nl * 8, hipMemcpyDeviceToHost, h->stream));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    h->est_valid = true;
+    return SE2GPU_OK;
+}
+
 int se2gpu_ba_get_all(se2gpu_ba* h, double* poses, double* lms) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "get before initialize");
-    SE2_HIP(hipStreamSynchronize(h->stream));
-    if (poses) SE2_HIP(hipMemcpy(poses, h->poses, 3 * (size_t)h->P * 8, hipMemcpyDeviceToHost));
-    if (lms && h->L) SE2_HIP(hipMemcpy(lms, h->lms, 3 * (size_t)h->L * 8, hipMemcpyDeviceToHost));
+    SE2_CHECK(ba_fetch_estimates(h));
+    if (poses) std::memcpy(poses, h->est.p, 3 * (size_t)h->P * 8);
+    if (lms && h->L) std::memcpy(lms, h->est.p + 3 * (size_t)h->P, 3 * (size_t)h->L * 8);
     return SE2GPU_OK;
 }
 
 int se2gpu_ba_get_se2(se2gpu_ba* h, int id, double xyt[3]) {
     SE2_REQUIRE(h && h->initialized && xyt, SE2GPU_ERR_STATE, "get_se2 before initialize");
-    auto a = h->pose_of_id.find(id);
-    SE2_REQUIRE(a != h->pose_of_id.end(), SE2GPU_ERR_INVALID, "unknown pose id %d", id);
-    SE2_HIP(hipStreamSynchronize(h->stream));
-    SE2_HIP(hipMemcpy(xyt, h->poses + 3 * (size_t)a->second, 24, hipMemcpyDeviceToHost));
+    const int a = h->pose_of_id.find(id);
+    SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "unknown pose id %d", id);
+    SE2_CHECK(ba_fetch_estimates(h));
+    std::memcpy(xyt, h->est.p + 3 * (size_t)a, 24);
     return SE2GPU_OK;
 }
 
 int se2gpu_ba_get_xyz(se2gpu_ba* h, int id, double xyz[3]) {
     SE2_REQUIRE(h && h->initialized && xyz, SE2GPU_ERR_STATE, "get_xyz before initialize");
-    auto a = h->lm_of_id.find(id);
-    SE2_REQUIRE(a != h->lm_of_id.end(), SE2GPU_ERR_INVALID, "unknown landmark id %d", id);
-    SE2_HIP(hipStreamSynchronize(h->stream));
-    SE2_HIP(hipMemcpy(xyz, h->lms + 3 * (size_t)a->second, 24, hipMemcpyDeviceToHost));
+    const int a = h->lm_of_id.find(id);
+    SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "unknown landmark id %d", id);
+    SE2_CHECK(ba_fetch_estimates(h));
+    std::memcpy(xyz, h->est.p + 3 * (size_t)h->P + 3 * (size_t)a, 24);
     return SE2GPU_OK;
 }
 

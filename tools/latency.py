@@ -11,7 +11,7 @@ import numpy as np  # noqa: E402
 
 from se2lam_amd import synth  # noqa: E402
 from se2lam_amd.matcher import ORBmatcher  # noqa: E402
-from se2lam_amd.optimizer import SlamOptimizer  # noqa: E402
+from se2lam_amd.optimizer import SlamOptimizer, estimateVertexSE2, estimateVertexSBAXYZ  # noqa: E402
 from se2lam_amd.orb import ORBextractor  # noqa: E402
 
 
@@ -71,6 +71,16 @@ def main():
             o.reset_estimates()
             o.optimize(10)
         out[f"ba_{P}kf_optimize10_ms"] = timeit(run, n=10, warm=2)
+
+        def cycle():   # LocalMapper::localBA as the reference runs it: a fresh SlamOptimizer per call
+            q = SlamOptimizer()
+            q.load(g)
+            q.initializeOptimization(0)
+            q.optimize(10)
+            estimateVertexSE2(q, 1); estimateVertexSBAXYZ(q, g.P)   # served from one download of all estimates
+            q.estimates()
+            del q
+        out[f"ba_{P}kf_construct_load_initialize_optimize10_ms"] = timeit(cycle, n=10, warm=2)
     print(json.dumps(out))
 
 
