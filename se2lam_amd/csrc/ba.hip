@@ -1924,9 +1924,9 @@ extern "C" {
 // se2gpu_ba_create, reset to the state of a new one.  SE2GPU_BA_POOL=0 disables this.
 namespace {
 constexpr size_t kPoolMax = 4;
-std::mutex g_pool_mu;
-std::vector<se2gpu_ba*> g_pool;
-bool pool_enabled() {
+static std::mutex g_ba_pool_mu;
+static std::vector<se2gpu_ba*> g_ba_pool;
+static bool ba_pool_enabled() {
     static const bool on = [] { const char* e = getenv("SE2GPU_BA_POOL"); return !(e && e[0] == '0'); }();
     return on;
 }
@@ -1938,11 +1938,11 @@ int se2gpu_ba_create(se2gpu_ba** out) {
     int dev = 0;
     SE2_HIP(hipGetDevice(&dev));
     {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (size_t i = 0; i < g_pool.size(); ++i)
-            if (g_pool[i]->device == dev) {
-                *out = g_pool[i];
-                g_pool.erase(g_pool.begin() + (ptrdiff_t)i);
+        std::lock_guard<std::mutex> lk(g_ba_pool_mu);
+        for (size_t i = 0; i < g_ba_pool.size(); ++i)
+            if (g_ba_pool[i]->device == dev) {
+                *out = g_ba_pool[i];
+                g_ba_pool.erase(g_ba_pool.begin() + (ptrdiff_t)i);
                 return SE2GPU_OK;
             }
     }
@@ -1960,7 +1960,7 @@ int se2gpu_ba_create(se2gpu_ba** out) {
 
 void se2gpu_ba_destroy(se2gpu_ba* h) {
     if (!h) return;
-    if (pool_enabled()) {
+    if (ba_pool_enabled()) {
         (void)hipStreamSynchronize(h->stream);
         if (h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
         (void)se2gpu_ba_clear(h);
@@ -1974,9 +1974,9 @@ void se2gpu_ba_destroy(se2gpu_ba* h) {
         h->allreduce = nullptr; h->ar_user = nullptr; h->comm = nullptr; h->ar_buffer = nullptr;
         h->red = nullptr;
         h->root = 1; h->rank = 0; h->world = 1;
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool.size() < kPoolMax) {
-            g_pool.push_back(h);
+        std::lock_guard<std::mutex> lk(g_ba_pool_mu);
+        if (g_ba_pool.size() < kPoolMax) {
+            g_ba_pool.push_back(h);
             return;
         }
     }

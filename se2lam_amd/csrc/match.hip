@@ -19,6 +19,8 @@
 // Compiled with -ffp-contract=off (float grid / projection arithmetic must round as the reference's).
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
+#include <mutex>
 #include <cmath>
 
 #include "common.h"
@@ -615,7 +617,7 @@ Bounds make_bounds(const se2gpu_frame_bounds& b) {
 
 struct se2gpu_matcher {
     hipStream_t own_stream = nullptr, stream = nullptr;
-    int max_features = 0, max_batch = 1;
+    int max_features = 0, max_batch = 1, device = 0;
     // scratch for frame sets of up to `nframes_cap` frames with stride `cap_cur`
     DevBuf<uint32_t> sorted, cand;
     DevBuf<int> n_grid, ncand, overflow, pair_a, pair_b, counts, matches, nmatches, mp_octave;
@@ -689,11 +691,39 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
 
 extern "C" {
 
+// The reference constructs its ORBmatcher on the stack of every call (Track.cpp:131, LocalMapper.cpp:117).  Destroyed
+// handles are parked with their stream and buffers (per device, at most kPoolMax) and handed out again by
+// se2gpu_matcher_create; SE2GPU_MATCHER_POOL=0 disables this.
+namespace {
+constexpr size_t kPoolMax = 4;
+static std::mutex g_mt_pool_mu;
+static std::vector<se2gpu_matcher*> g_mt_pool;
+static bool mt_pool_enabled() {
+    static const bool on = [] { const char* e = std::getenv("SE2GPU_MATCHER_POOL"); return !(e && e[0] == '0'); }();
+    return on;
+}
+}  // namespace
+
 int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out) {
     SE2_REQUIRE(out, SE2GPU_ERR_INVALID, "matcher_create: out is NULL");
     SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible (libse2gpu has no CPU fallback)");
     SE2_REQUIRE(max_features > 0 && max_features <= kMaxFeat, SE2GPU_ERR_INVALID, "max_features must be in 1..%d", kMaxFeat);
+    int dev = 0;
+    SE2_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lk(g_mt_pool_mu);
+        for (size_t i = 0; i < g_mt_pool.size(); ++i)
+            if (g_mt_pool[i]->device == dev) {
+                se2gpu_matcher* h = g_mt_pool[i];
+                g_mt_pool.erase(g_mt_pool.begin() + (ptrdiff_t)i);
+                h->max_features = max_features;
+                h->max_batch = std::max(1, max_batch);
+                *out = h;
+                return SE2GPU_OK;
+            }
+    }
     se2gpu_matcher* h = new se2gpu_matcher;
+    h->device = dev;
     h->max_features = max_features;
     h->max_batch = std::max(1, max_batch);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -710,7 +740,20 @@ int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out)
     return SE2GPU_OK;
 }
 
-void se2gpu_matcher_destroy(se2gpu_matcher* h) { delete h; }
+void se2gpu_matcher_destroy(se2gpu_matcher* h) {
+    if (!h) return;
+    if (mt_pool_enabled()) {
+        (void)hipStreamSynchronize(h->stream);
+        h->stream = h->own_stream;
+        (void)hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream);
+        std::lock_guard<std::mutex> lk(g_mt_pool_mu);
+        if (g_mt_pool.size() < kPoolMax) {
+            g_mt_pool.push_back(h);
+            return;
+        }
+    }
+    delete h;
+}
 void* se2gpu_matcher_stream(se2gpu_matcher* h) { return h ? (void*)h->stream : nullptr; }
 
 int se2gpu_matcher_set_stream(se2gpu_matcher* h, void* s) {

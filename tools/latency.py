@@ -35,6 +35,12 @@ def main():
     mt = ORBmatcher(0.9)
     prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
     out["match_by_window_ms"] = timeit(lambda: mt.MatchByWindow(k1, d1, k2, d2, prev.copy(), 20))
+
+    def fresh():   # Track.cpp:131: "ORBmatcher matcher(0.9);" on the stack of every frame
+        m = ORBmatcher(0.9)
+        m.MatchByWindow(k1, d1, k2, d2, prev.copy(), 20)
+        del m
+    out["match_by_window_fresh_matcher_ms"] = timeit(fresh)
     # Track thread: removeOutliers + doTriangulate on the MatchByWindow result of frames 0 -> 5
     from se2lam_amd.track import Track
     tr = Track()
