@@ -337,3 +337,53 @@ def test_lm_rejected_trials_follow_the_oracle(oracle, synth, P, L):
     # points close to the camera planes (chi2 ~ 1e8), where the last bits of 1/Z decide - not the regime of the 1e-5 bar,
     # which the unperturbed graphs above are held to.
     assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"][:st["iterations"]], rtol=2e-3, atol=0)
+
+
+def test_pooled_handles_behave_like_new_ones(synth, monkeypatch):
+    """se2gpu_ba_destroy parks handles and se2gpu_ba_create hands them out again (LocalMapper::localBA constructs its
+    SlamOptimizer per call): windows of different sizes through recycled handles give exactly the results of handles
+    that were never used before, cached estimates are refreshed after every optimize, sparse / negative vertex ids
+    still work."""
+    from se2lam_amd import optimizer as op
+    graphs = [synth.ba_graph(50, 5000), synth.ba_graph(8, 60), synth.ba_graph(21, 800), synth.ba_graph(8, 60)]
+    monkeypatch.setenv("SE2GPU_BA_POOL", "1")
+    pooled = []
+    for g in graphs:                         # each optimizer is destroyed before the next one is created
+        o = _opt(g)
+        o.optimize(4)
+        p4, h4 = o.estimates()[0].copy(), list(o.stats["chi2_hist"])
+        o.optimize(3)                        # the host copy of the estimates must follow
+        pooled.append((o.stats["chi2_hist"], p4, o.estimates()[0].copy(), o.estimates()[1].copy(), h4))
+        assert not np.array_equal(p4, pooled[-1][2])
+        del o
+    keep = []                                # handles that are all alive at once: none of them comes from the pool twice
+    for g, ref in zip(graphs, pooled):
+        o = _opt(g)
+        keep.append(o)
+        o.optimize(4)
+        p4 = o.estimates()[0].copy()
+        o.optimize(3)
+        assert o.stats["chi2_hist"] == ref[0]
+        assert np.array_equal(p4, ref[1]) and np.array_equal(o.estimates()[0], ref[2])
+        assert np.array_equal(o.estimates()[1], ref[3])
+    # ids outside the dense table (negative, huge) go through the map
+    g = graphs[1]
+    o = op.SlamOptimizer()
+    K = np.array([[g.fx, 0, g.cx], [0, g.fx, g.cy], [0, 0, 1]], np.float32)
+    op.addCamPara(opt := o, K, 0)
+    op.setExtParameter(opt, g.Rbc, g.tbc)
+    pid = lambda i: -5 - i if i % 2 else (1 << 27) + i
+    lid = lambda l: (1 << 26) + 3 * l
+    for i in range(g.P):
+        op.addVertexSE2(opt, g.poses[i], pid(i), bool(g.fixed[i]))
+    for k in range(g.O):
+        op.addEdgeSE2(opt, g.o_meas[k], pid(int(g.o_i[k])), pid(int(g.o_j[k])), g.o_info[k])
+    for l in range(g.L):
+        op.addVertexSBAXYZ(opt, g.lms[l], lid(l))
+    for k in range(g.E):
+        w = g.e_info[k]
+        op.addEdgeSE2XYZ(opt, g.e_uv[k], pid(int(g.e_kf[k])), lid(int(g.e_lm[k])), [[w[0], w[1]], [w[1], w[2]]], g.huber)
+    opt.initializeOptimization(0)
+    opt.optimize(4)
+    assert opt.stats["chi2_hist"] == pooled[1][4]
+    assert np.array_equal(op.estimateVertexSE2(opt, pid(3)), pooled[1][1][3])
