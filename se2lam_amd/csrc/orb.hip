@@ -18,9 +18,10 @@
 //   k_level_select        one workgroup per (frame, level): quota redistribution (wave-parallel), per-cell top-n gather,
 //                         level-wide retain-best by rank, keypoint list in level order
 //   k_orientation         one wave per keypoint: integer intensity-centroid moments, fastAtan2
-//   k_copy_frame, k_blur  blurred pyramid: the 16 px frame keeps the un-blurred reflect copies (as in the reference's
+//   k_blur                blurred pyramid: the 16 px frame keeps the un-blurred reflect copies (as in the reference's
 //                         in-place ROI blur), the interior gets the 7x7 fixed-point Gaussian (register window, packed
-//                         u16 horizontal taps); both on a side stream beside the key-point chain
+//                         u16 horizontal taps), on a side stream beside the key-point chain; the frame is written by
+//                         k_level0 / k_resize
 //   k_angle_trig          cos / sin of the key-point angle (double, rounded once), one thread per key point
 //   k_describe            one wave per two keypoints: lane l evaluates pattern pairs l, l+64, l+128, l+192 and the four
 //                         64-bit wave ballots ARE the 256-bit descriptor; also writes the final cv::KeyPoint
@@ -89,22 +90,37 @@ __host__ __device__ __forceinline__ int reflect101(int p, int n) { return p < 0 
 // pyramid
 // ---------------------------------------------------------------------------------------------
 // level 0: copyMakeBorder(image, 16 px, BORDER_REFLECT_101)
-// One thread = one 16-byte chunk of a bordered row; threads are laid out flat over (row, chunk).
+// One thread = one 16-byte chunk of a bordered row.  The item space is [interior chunks of all rows | the other chunks]:
+// an interior chunk is one aligned 128-bit load, a chunk that touches the reflected frame or the row padding gathers
+// bytes - keeping the two kinds in separate waves keeps the gather out of 95 % of them.
 __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restrict__ imgs, int pitch,
-                                                 uint8_t* __restrict__ pyr) {
+                                                 uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     SE2_FRAME_GRID(f, bx);
     const int W = g.w[0], H = g.h[0], stride = g.stride[0];
-    const int nch = stride / 16;
+    const int nch = stride / 16, rows = H + 2 * kEdge;
+    const bool aligned = (W % 16 == 0) && (pitch % 16 == 0);    // interior chunks exist only then
+    const int nin = aligned ? W / 16 : 0;                        // interior chunks per row: X0 = 16 .. W
     const int item = bx * 256 + threadIdx.x;
-    const int Y = item / nch;                                   // row of the bordered buffer
-    if (Y >= H + 2 * kEdge) return;
-    const int X0 = (item - Y * nch) * 16;                       // first of 16 columns of the bordered buffer
+    int Y, c;
+    bool interior;
+    if (item < nin * rows) {
+        Y = item / nin;
+        c = item - Y * nin + 1;
+        interior = true;
+    } else {
+        const int j = item - nin * rows, nb = nch - nin;
+        Y = j / nb;
+        if (Y >= rows) return;
+        c = j - Y * nb;
+        if (c >= 1) c += nin;                                    // chunk 0, then the chunks past the interior
+        interior = false;
+    }
+    const int X0 = c * 16;                                       // first of 16 columns of the bordered buffer
     const int sy = reflect101(Y - kEdge, H);
     const uint8_t* src = imgs + (size_t)f * pitch * H + (size_t)sy * pitch;
-    const uint8_t* p16 = src + (X0 - kEdge);
     uint4 v;
-    if (X0 >= kEdge && X0 + 15 < W + kEdge && ((uintptr_t)p16 & 15) == 0) {
-        v = *reinterpret_cast<const uint4*>(p16);               // interior chunk: one aligned 128-bit load
+    if (interior) {
+        v = *reinterpret_cast<const uint4*>(src + (X0 - kEdge));
     } else {
         uint32_t wv[4];
 #pragma unroll
@@ -121,7 +137,10 @@ __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restric
         }
         v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
     }
-    *reinterpret_cast<uint4*>(pyr + (size_t)f * g.frame_bytes + g.off[0] + (size_t)Y * stride + X0) = v;
+    const size_t off = (size_t)f * g.frame_bytes + g.off[0] + (size_t)Y * stride + X0;
+    *reinterpret_cast<uint4*>(pyr + off) = v;
+    // the blurred pyramid keeps the un-blurred frame (see k_blur): frame rows, the left chunk, the chunks from the right edge on
+    if (!interior || Y < kEdge || Y >= H + kEdge) *reinterpret_cast<uint4*>(blur + off) = v;
 }
 
 // level l >= 1: cv::resize(level l-1, INTER_LINEAR) + reflect-101 border, 4 output bytes per thread.
@@ -137,7 +156,8 @@ struct ResizeTab {
     int ngroups;   // stride / 4
 };
 
-__global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr) {
+__global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr,
+                                                 uint8_t* __restrict__ blur) {
     SE2_FRAME_GRID(f, bx);
     const int gid = bx * 256 + threadIdx.x;
     const int H = g.h[l], stride = g.stride[l];
@@ -170,7 +190,11 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
         if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
         v |= b << (8 * q);
     }
-    *(uint32_t*)(pyr + (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 4 * xg) = v;
+    const size_t off = (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 4 * xg;
+    *(uint32_t*)(pyr + off) = v;
+    // un-blurred frame of the blurred pyramid, in whole 16-byte chunks as k_blur expects: frame rows, chunk 0, and
+    // everything from the chunk that holds the first column right of the interior
+    if (Y < kEdge || Y >= H + kEdge || 4 * xg < 16 || 4 * xg >= ((kEdge + g.w[l]) / 16) * 16) *(uint32_t*)(blur + off) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -955,35 +979,10 @@ constexpr int kBlurRows = 35;
 // One thread = 4 adjacent output pixels of a vertical strip of kBlurRows rows; the horizontal 7-tap sums of the last
 // 7 rows stay in registers (sliding window), inputs come in as three aligned dwords per row.  No LDS.
 // The blurred pyramid keeps the UN-blurred 16 px reflect frame of every level (the descriptor pattern of a key point
-// 16 px from the edge reaches a few pixels into it).  Only the frame is copied (about 14 % of a pyramid), as a flat list
-// of 16-byte chunks: per level the 2 x 16 full frame rows, then for every interior row its first chunk and the chunks
-// from the one that straddles the right edge of the interior onwards (the interior bytes that chunk carries are
-// overwritten by k_blur afterwards).  tile_base[l] = chunk-list prefix sums.
-__device__ __host__ inline int frame_chunks_right(int W, int stride) { return stride / 16 - (kEdge + W) / 16; }
-__global__ __launch_bounds__(256) void k_copy_frame(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    SE2_FRAME_GRID(f, bx);
-    const int item = bx * 256 + threadIdx.x;
-    if (item >= g.tile_base[g.nlevels]) return;
-    int l = 0;
-    while (l + 1 < g.nlevels && item >= g.tile_base[l + 1]) ++l;
-    int t = item - g.tile_base[l];
-    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
-    const int nch = stride / 16, nr = frame_chunks_right(W, stride);
-    int Y, c;
-    if (t < 2 * kEdge * nch) {            // full frame rows: top 16, bottom 16
-        const int r = t / nch;
-        c = t - r * nch;
-        Y = r < kEdge ? r : H + r;        // r in [16, 32) -> rows H + 16 .. H + 31
-    } else {
-        t -= 2 * kEdge * nch;
-        const int r = t / (1 + nr), q = t - r * (1 + nr);
-        Y = kEdge + r;
-        c = q == 0 ? 0 : nch - nr + (q - 1);
-    }
-    const size_t off = (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 16 * c;
-    *reinterpret_cast<uint4*>(blur + off) = *reinterpret_cast<const uint4*>(pyr + off);
-}
-
+// 16 px from the edge reaches a few pixels into it).  The frame (about 14 % of a pyramid) is written by k_level0 /
+// k_resize together with the pyramid itself: the 2 x 16 full frame rows, for every interior row its first 16-byte chunk
+// and the chunks from the one that straddles the right edge of the interior onwards (the interior bytes that chunk
+// carries are overwritten here).
 __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
     SE2_FRAME_GRID(f, bx);
     int l = 0;
@@ -1331,13 +1330,13 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     SE2_CHECK(h->angle_cs.reserve((size_t)h->max_batch * cap));
     {
         dim3 grid(F8, ((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256);
-        SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p);
+        SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p, h->blur.p);
     }
     for (int l = 1; l < L; ++l) {
         const int ng = g.stride[l] / 4;
         ResizeTab t{h->tabs.p + h->ytab_off[l], h->tabs.p + h->xtab_off[l], ng};
         dim3 grid(F8, (ng * (g.h[l] + 2 * kEdge) + 255) / 256);
-        SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p);
+        SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p, h->blur.p);
     }
     // The blurred pyramid needs only the pyramid: it runs on a side stream next to the key-point chain, whose
     // k_level_select and k_cell_detect leave most CUs idle.  (Serial when profiling.)
@@ -1348,14 +1347,6 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     }
     {
         Geom gb = g;
-        int items = 0;
-        for (int l = 0; l < L; ++l) {
-            gb.tile_base[l] = items;
-            items += 2 * kEdge * (g.stride[l] / 16) + g.h[l] * (1 + frame_chunks_right(g.w[l], g.stride[l]));
-        }
-        gb.tile_base[L] = items;
-        SE2_LAUNCH(h->prof, sb, "k_copy_frame", k_copy_frame, dim3(F8, (items + 255) / 256), dim3(256), 0, gb, h->pyr.p,
-                   h->blur.p);
         for (int l = 0; l <= L; ++l) gb.tile_base[l] = h->blur_tile_base[l];
         SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(F8, gb.tile_base[L]), dim3(256), 0, gb, h->pyr.p, h->blur.p);
     }
