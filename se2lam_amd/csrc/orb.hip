@@ -998,9 +998,7 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
     // Horizontal 7-tap sums of a row in packed u16 pairs (they fit: 255 * 257 = 65535): the byte pairs {b, b+1} of the
     // 12-byte window come from v_perm_b32, the taps are v_pk_add_u16 / v_pk_mad_u16 on two output pixels at once.
     typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-    auto hrow = [&](int y, int (&h)[4]) {
-        const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)y * stride + x0 - 4);
-        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    auto hrow_w = [&](uint32_t w0, uint32_t w1, uint32_t w2, int (&h)[4]) {
         uint32_t e[9];   // pairs {b, b+1}, b = 1 .. 9
         e[0] = __builtin_amdgcn_perm(w1, w0, 0x0c020c01u);
         e[1] = __builtin_amdgcn_perm(w1, w0, 0x0c030c02u);
@@ -1018,6 +1016,10 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
         const ushort2v hB = (P(3) + P(9)) * k18 + (P(4) + P(8)) * k34 + (P(5) + P(7)) * k49 + P(6) * k55;
         h[0] = hA[0]; h[1] = hA[1]; h[2] = hB[0]; h[3] = hB[1];
     };
+    auto hrow = [&](int y, int (&h)[4]) {
+        const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)y * stride + x0 - 4);
+        hrow_w(p[0], p[1], p[2], h);
+    };
     // The window of the last seven rows is a circular buffer with static slots: the row loop is unrolled by 7
     // (kBlurRows is a multiple of 7).
     int hw[7][4];
@@ -1025,10 +1027,25 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
     for (int r = 0; r < 6; ++r) hrow(y0 - 3 + r, hw[r]);
     const int yend = min(y0 + kBlurRows, H);
     const int nvalid = min(4, W - x0);
+    // the row entering the window is fetched two steps ahead, so that its latency hides behind the steps' arithmetic
+    const int ylast = H + kEdge - 1;               // last row of the bordered plane
+    uint32_t n0, n1, n2, m0, m1, m2;               // rows y + 3 and y + 4 of the coming step
+    {
+        const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)min(y0 + 3, ylast) * stride + x0 - 4);
+        n0 = p[0]; n1 = p[1]; n2 = p[2];
+        const uint32_t* q = (const uint32_t*)(src + (ptrdiff_t)min(y0 + 4, ylast) * stride + x0 - 4);
+        m0 = q[0]; m1 = q[1]; m2 = q[2];
+    }
     auto step = [&](auto phc, int y) {
         constexpr int PH = decltype(phc)::value;   // window row r of this iteration lives in slot (PH + r) % 7
         if (y >= yend) return;                     // uniform
-        hrow(y + 3, hw[(PH + 6) % 7]);
+        const uint32_t c0 = n0, c1 = n1, c2 = n2;
+        n0 = m0; n1 = m1; n2 = m2;
+        {
+            const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)min(y + 5, ylast) * stride + x0 - 4);
+            m0 = p[0]; m1 = p[1]; m2 = p[2];
+        }
+        hrow_w(c0, c1, c2, hw[(PH + 6) % 7]);
         uint32_t out = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
