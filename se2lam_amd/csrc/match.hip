@@ -103,13 +103,39 @@ __global__ __launch_bounds__(256) void k_grid_order(Bounds bd, const se2gpu_keyp
     }
 }
 
+// The target frame's grid-ordered list and the three key-point fields the window test reads, staged in LDS once per
+// workgroup (16 B per feature): a query's scan then waits on LDS instead of on two dependent global loads.
+struct TargetLds {
+    const uint32_t* sorted;
+    const float* x;
+    const float* y;
+    const int* octave;
+};
+// queries per workgroup: 64 (16 per wave) when there are many pairs to fill the chip with, 8 for a single pair
+constexpr int kCandQueriesBatch = 64, kCandQueriesSingle = 8;
+__device__ __forceinline__ TargetLds stage_target(int* lds, int cap, const se2gpu_keypoint* __restrict__ kps2,
+                                                  const uint32_t* __restrict__ sorted2, int n2) {
+    uint32_t* s_sorted = (uint32_t*)lds;
+    float* s_x = (float*)(lds + cap);
+    float* s_y = (float*)(lds + 2 * cap);
+    int* s_oct = lds + 3 * cap;
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+        s_sorted[i] = sorted2[i];
+        const se2gpu_keypoint kp = kps2[i];
+        s_x[i] = kp.x;
+        s_y[i] = kp.y;
+        s_oct[i] = kp.octave;
+    }
+    __syncthreads();
+    return TargetLds{s_sorted, s_x, s_y, s_oct};
+}
+
 // Candidate scan of one query by one wave (Frame::GetFeaturesInArea + DescriptorDistance).
 // Returns the number of candidates (may exceed kMaxCand: the caller flags overflow); out[s] = (idx << 12) | dist.
 __device__ __forceinline__ int scan_candidates(const Bounds& bd, float x, float y, float r, int minLevel, int maxLevel,
-                                               const uint8_t* __restrict__ d1, const se2gpu_keypoint* __restrict__ kps2,
-                                               const uint8_t* __restrict__ desc2, const uint32_t* __restrict__ sorted2,
-                                               const int* __restrict__ grid2, const uint8_t* __restrict__ excl,
-                                               uint32_t* __restrict__ out) {
+                                               const uint8_t* __restrict__ d1, const TargetLds& tg,
+                                               const uint8_t* __restrict__ desc2, const int* __restrict__ grid2,
+                                               const uint8_t* __restrict__ excl, uint32_t* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     int nMinCellX = (int)floorf((x - bd.min_x - r) * bd.wInv);
     nMinCellX = max(0, nMinCellX);
@@ -132,14 +158,14 @@ __device__ __forceinline__ int scan_candidates(const Bounds& bd, float x, float 
         bool ok = false;
         int idx = 0;
         if (pos < cend) {
-            const uint32_t pk = sorted2[pos];
+            const uint32_t pk = tg.sorted[pos];
             const int cell = (int)(pk >> 16);
             idx = (int)(pk & 0xffffu);
             const int cx = cell / kGridRows, cy = cell % kGridRows;
             if (cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY) {
-                const se2gpu_keypoint kp = kps2[idx];
-                ok = (!checkLevels || (kp.octave >= minLevel && kp.octave <= maxLevel)) && !(fabsf(kp.x - x) > r) &&
-                     !(fabsf(kp.y - y) > r) && !(excl && excl[idx]);
+                const int oct = tg.octave[idx];
+                ok = (!checkLevels || (oct >= minLevel && oct <= maxLevel)) && !(fabsf(tg.x[idx] - x) > r) &&
+                     !(fabsf(tg.y[idx] - y) > r) && !(excl && excl[idx]);
             }
         }
         const unsigned long long m = __ballot(ok);
@@ -159,22 +185,29 @@ __global__ __launch_bounds__(256) void k_cand_window(Bounds bd, const se2gpu_key
                                                       const int* __restrict__ pair_b, const float* __restrict__ prev_xy,
                                                       const uint32_t* __restrict__ sorted, const int* __restrict__ n_grid,
                                                       int win, int level_offset, int min_level, int max_level,
-                                                      uint32_t* __restrict__ cand, int* __restrict__ ncand) {
-    const int p = blockIdx.y;
-    const int i1 = blockIdx.x * 4 + threadIdx.x / 64;
+                                                      uint32_t* __restrict__ cand, int* __restrict__ ncand, int npairs, int qpb) {
+    // pairs are the fast grid dimension (padded to a multiple of 8): a pair's workgroups share an XCD and its L2
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    const int p = blockIdx.x;
+    if (p >= npairs) return;
     const int fa = pair_a[p], fb = pair_b[p];
-    if (i1 >= min(counts[fa], cap)) return;
-    const se2gpu_keypoint kp1 = kps[(size_t)fa * cap + i1];
-    const int level1 = kp1.octave;
-    int n = 0;
-    if (!(level1 > max_level || level1 < min_level)) {
-        const int minLevel2 = level1 - level_offset > 0 ? level1 - level_offset : 0;
-        n = scan_candidates(bd, prev_xy[((size_t)p * cap + i1) * 2], prev_xy[((size_t)p * cap + i1) * 2 + 1], (float)win,
-                            minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + i1) * 32, kps + (size_t)fb * cap,
-                            desc + (size_t)fb * cap * 32, sorted + (size_t)fb * cap, n_grid + (size_t)fb * kGridRec, nullptr,
-                            cand + ((size_t)p * cap + i1) * kMaxCand);
+    const int n1 = min(counts[fa], cap), n2 = min(counts[fb], cap);
+    const int q0 = blockIdx.y * qpb;
+    if (q0 >= n1) return;
+    const TargetLds tg = stage_target(lds, cap, kps + (size_t)fb * cap, sorted + (size_t)fb * cap, n2);
+    for (int i1 = q0 + (int)(threadIdx.x / 64); i1 < min(q0 + qpb, n1); i1 += 4) {
+        const se2gpu_keypoint kp1 = kps[(size_t)fa * cap + i1];
+        const int level1 = kp1.octave;
+        int n = 0;
+        if (!(level1 > max_level || level1 < min_level)) {
+            const int minLevel2 = level1 - level_offset > 0 ? level1 - level_offset : 0;
+            n = scan_candidates(bd, prev_xy[((size_t)p * cap + i1) * 2], prev_xy[((size_t)p * cap + i1) * 2 + 1], (float)win,
+                                minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + i1) * 32, tg,
+                                desc + (size_t)fb * cap * 32, n_grid + (size_t)fb * kGridRec, nullptr,
+                                cand + ((size_t)p * cap + i1) * kMaxCand);
+        }
+        if ((threadIdx.x & 63) == 0) ncand[(size_t)p * cap + i1] = n;
     }
-    if ((threadIdx.x & 63) == 0) ncand[(size_t)p * cap + i1] = n;
 }
 
 // wave-uniform arg-min over the lanes with `valid`: smallest dist, then lowest lane.  Returns lane or -1.
@@ -408,36 +441,38 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
                                                           const uint8_t* __restrict__ kf_observed,
                                                           const uint32_t* __restrict__ sorted,
                                                           const int* __restrict__ n_grid, int win, int level_offset,
-                                                          uint32_t* __restrict__ cand, int* __restrict__ ncand) {
-    const int i = blockIdx.x * 4 + threadIdx.x / 64;
-    if (i >= m) return;
-    int n = 0;
-    if (!mp_skip[i]) {
-        const float X = mp_pos[3 * i], Y = mp_pos[3 * i + 1], Z = mp_pos[3 * i + 2];
-        float pc[3];
+                                                          uint32_t* __restrict__ cand, int* __restrict__ ncand, int n_feat, int qpb) {
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    const int q0 = blockIdx.x * qpb;
+    const TargetLds tg = stage_target(lds, n_feat, kps, sorted, n_feat);
+    for (int i = q0 + (int)(threadIdx.x / 64); i < min(q0 + qpb, m); i += 4) {
+        int n = 0;
+        if (!mp_skip[i]) {
+            const float X = mp_pos[3 * i], Y = mp_pos[3 * i + 1], Z = mp_pos[3 * i + 2];
+            float pc[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            float s = 0;
-            s += cam.T[4 * r + 0] * X;
-            s += cam.T[4 * r + 1] * Y;
-            s += cam.T[4 * r + 2] * Z;
-            pc[r] = s + cam.T[4 * r + 3];
+            for (int r = 0; r < 3; ++r) {
+                float s = 0;
+                s += cam.T[4 * r + 0] * X;
+                s += cam.T[4 * r + 1] * Y;
+                s += cam.T[4 * r + 2] * Z;
+                pc[r] = s + cam.T[4 * r + 3];
+            }
+            float u = 0, v = 0, w = 0;
+            u += cam.fx * pc[0]; u += 0.f * pc[1]; u += cam.cx * pc[2];
+            v += 0.f * pc[0]; v += cam.fy * pc[1]; v += cam.cy * pc[2];
+            w += 0.f * pc[0]; w += 0.f * pc[1]; w += 1.f * pc[2];
+            const float px = u / w, py = v / w;
+            if (px >= bd.min_x && px <= bd.max_x && py >= bd.min_y && py <= bd.max_y) {
+                const int predictLevel = mp_octave[i];
+                const int levelWinSize = predictLevel * win;
+                const int minLevel = predictLevel > level_offset ? predictLevel - level_offset : 0;
+                n = scan_candidates(bd, px, py, (float)levelWinSize, minLevel, predictLevel + level_offset,
+                                    mp_desc + 32 * (size_t)i, tg, desc, n_grid, kf_observed, cand + (size_t)i * kMaxCand);
+            }
         }
-        float u = 0, v = 0, w = 0;
-        u += cam.fx * pc[0]; u += 0.f * pc[1]; u += cam.cx * pc[2];
-        v += 0.f * pc[0]; v += cam.fy * pc[1]; v += cam.cy * pc[2];
-        w += 0.f * pc[0]; w += 0.f * pc[1]; w += 1.f * pc[2];
-        const float px = u / w, py = v / w;
-        if (px >= bd.min_x && px <= bd.max_x && py >= bd.min_y && py <= bd.max_y) {
-            const int predictLevel = mp_octave[i];
-            const int levelWinSize = predictLevel * win;
-            const int minLevel = predictLevel > level_offset ? predictLevel - level_offset : 0;
-            n = scan_candidates(bd, px, py, (float)levelWinSize, minLevel, predictLevel + level_offset,
-                                mp_desc + 32 * (size_t)i, kps, desc, sorted, n_grid, kf_observed,
-                                cand + (size_t)i * kMaxCand);
-        }
+        if ((threadIdx.x & 63) == 0) ncand[i] = n;
     }
-    if ((threadIdx.x & 63) == 0) ncand[i] = n;
 }
 
 // MatchByProjection greedy pass (ORBmatcher.cpp:390-451), one workgroup, parallel over map points: the same fixed-point
@@ -648,6 +683,16 @@ int check_overflow(se2gpu_matcher* h) {
     return SE2GPU_OK;
 }
 
+// the candidate kernels stage 16 B per target feature in LDS: up to kMaxFeat features = 128 KiB of dynamic LDS
+int cand_lds_attr() {
+    static bool done = false;
+    if (done) return SE2GPU_OK;
+    SE2_HIP(hipFuncSetAttribute((const void*)k_cand_window, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxFeat * 16));
+    SE2_HIP(hipFuncSetAttribute((const void*)k_cand_projection, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxFeat * 16));
+    done = true;
+    return SE2GPU_OK;
+}
+
 // MatchByWindow over `npairs` pairs of frames of a device-resident frame set
 int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_kps, const uint8_t* d_desc,
                  const int32_t* d_counts, int cap, int nframes_hint, const int32_t* d_pair_a, const int32_t* d_pair_b,
@@ -666,9 +711,11 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     if (init_prev)
         hipLaunchKernelGGL(k_init_prev, dim3((cap + 255) / 256, npairs), dim3(256), 0, st, d_kps, d_counts, cap, d_pair_a,
                            d_prev);
-    hipLaunchKernelGGL(k_cand_window, dim3((cap + 3) / 4, npairs), dim3(256), 0, st, bd, d_kps, d_desc, d_counts, cap,
-                       d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win, level_offset, min_level, max_level,
-                       h->cand.p, h->ncand.p);
+    SE2_CHECK(cand_lds_attr());
+    const int qpb = npairs >= 32 ? kCandQueriesBatch : kCandQueriesSingle;
+    hipLaunchKernelGGL(k_cand_window, dim3((npairs + 7) & ~7, (cap + qpb - 1) / qpb), dim3(256), (size_t)cap * 16, st, bd,
+                       d_kps, d_desc, d_counts, cap, d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win,
+                       level_offset, min_level, max_level, h->cand.p, h->ncand.p, npairs, qpb);
     const size_t fixed_lds = ((size_t)11 * ((cap + 3) & ~3) + 48) * sizeof(int);
     constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: one workgroup per pair and CU
     SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY,
@@ -880,10 +927,14 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy;
     hipLaunchKernelGGL(k_grid_order, dim3(1), dim3(256), 0, st, bd, d_kps, d_sc + 2, (const int*)nullptr, n, h->sorted.p,
                        h->n_grid.p);
-    if (m)
-        hipLaunchKernelGGL(k_cand_projection, dim3((m + 3) / 4), dim3(256), 0, st, bd, cam, (const float*)(ds + o_pos),
-                           ds + o_mdesc, (const int*)(ds + o_oct), ds + o_skip, m, d_kps, ds + o_desc, ds + o_obs,
-                           h->sorted.p, h->n_grid.p, win_size, level_offset, h->cand.p, h->ncand.p);
+    if (m) {
+        SE2_CHECK(cand_lds_attr());
+        const int qpb = kCandQueriesSingle;
+        hipLaunchKernelGGL(k_cand_projection, dim3((m + qpb - 1) / qpb), dim3(256), (size_t)n * 16, st, bd, cam,
+                           (const float*)(ds + o_pos), ds + o_mdesc, (const int*)(ds + o_oct), ds + o_skip, m, d_kps,
+                           ds + o_desc, ds + o_obs, h->sorted.p, h->n_grid.p, win_size, level_offset, h->cand.p, h->ncand.p,
+                           n, qpb);
+    }
     {
         const int chunk = 1024;
         constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: a single workgroup
