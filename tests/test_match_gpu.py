@@ -201,3 +201,47 @@ def test_batched_extract_and_match_device_resident(oracle, synth):
         k1, d1 = oracle.orb_extract(imgs[p]); k2, d2 = oracle.orb_extract(imgs[p + 1])
         m_ref, nm_ref, _ = oracle.match_window(k1, d1, k2, d2)
         assert nm[p] == nm_ref and np.array_equal(m[p, :len(k1)], m_ref)
+
+
+def test_bench_size_batch_parity_and_properties(oracle, synth):
+    """BASELINE config 2 at its full size (256 frames resident in HBM, 255 frame pairs, the launch shapes bench.py
+    times): sampled frames and pairs bit-exact against the oracle, and for EVERY pair the properties any correct
+    MatchByWindow result has - indices in range, no target matched twice, the count equals the number of matches, every
+    matched pair within TH_LOW, the levels of a matched pair at most one apart."""
+    from se2lam_amd import capi
+    from se2lam_amd.matcher import ORBmatcher
+    from se2lam_amd.orb import ORBextractor, KP_DTYPE
+    B, cap = 256, 2000
+    imgs = synth.frames(B)
+    ex = ORBextractor(max_batch=B)
+    mt = ORBmatcher(0.9, max_features=cap, max_batch=B)
+    d_img = capi.DeviceArray.from_numpy(imgs)
+    d_kps = capi.DeviceArray(B * cap * 28); d_desc = capi.DeviceArray(B * cap * 32); d_cnt = capi.DeviceArray(B * 4)
+    ex.extract_batch_device(d_img.ptr, B, 480, 640, d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap)
+    ex.sync()
+    pa = np.arange(B - 1, dtype=np.int32); pb = pa + 1
+    d_pa = capi.DeviceArray.from_numpy(pa); d_pb = capi.DeviceArray.from_numpy(pb)
+    d_m = capi.DeviceArray((B - 1) * cap * 4); d_nm = capi.DeviceArray((B - 1) * 4)
+    mt.match_window_batch_device(d_kps.ptr, d_desc.ptr, d_cnt.ptr, cap, d_pa.ptr, d_pb.ptr, B - 1, 20, d_m.ptr, d_nm.ptr)
+    mt.sync()
+    cnt = d_cnt.to_numpy(np.int32, (B,))
+    kps = d_kps.to_numpy(KP_DTYPE, (B, cap)); desc = d_desc.to_numpy(np.uint8, (B, cap, 32))
+    m = d_m.to_numpy(np.int32, (B - 1, cap)); nm = d_nm.to_numpy(np.int32, (B - 1,))
+    assert (cnt == 1000).all()
+    for p in (0, 101, 254):
+        k1, d1 = oracle.orb_extract(imgs[p]); k2, d2 = oracle.orb_extract(imgs[p + 1])
+        assert np.array_equal(kps[p, :cnt[p]], k1) and np.array_equal(desc[p, :cnt[p]], d1)
+        m_ref, nm_ref, _ = oracle.match_window(k1, d1, k2, d2)
+        assert nm[p] == nm_ref and np.array_equal(m[p, :len(k1)], m_ref)
+    popc = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for p in range(B - 1):
+        n1, n2 = cnt[p], cnt[p + 1]
+        mp = m[p, :n1]
+        hit = mp >= 0
+        assert ((mp >= -1) & (mp < n2)).all() and hit.sum() == nm[p]
+        assert nm[p] > 400 or (3 * (p + 1)) % 540 < 3                          # the crop offset wraps once (synth.frame)
+        tg = mp[hit]
+        assert len(np.unique(tg)) == len(tg)                                   # one-to-one
+        dist = popc[desc[p, :n1][hit] ^ desc[p + 1, tg]].sum(1)
+        assert (dist <= 75).all()                                              # TH_LOW
+        assert (np.abs(kps[p, :n1]["octave"][hit] - kps[p + 1, tg]["octave"]) <= 1).all()   # levelOffset 1
