@@ -613,17 +613,27 @@ void normalize_rotation(double R[9]) {
         q[0] = (R[7] - R[5]) * t;
         q[1] = (R[2] - R[6]) * t;
         q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        q[i] = 0.5 * t;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {   // largest diagonal element first (Eigen), written out per case
+        t = std::sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = 0.5 * t;
         t = 0.5 / t;
-        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        q[3] = (R[7] - R[5]) * t;
+        q[1] = (R[3] + R[1]) * t;
+        q[2] = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && R[4] >= R[8]) {
+        t = std::sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[2] - R[6]) * t;
+        q[2] = (R[7] + R[5]) * t;
+        q[0] = (R[1] + R[3]) * t;
+    } else {
+        t = std::sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3] - R[1]) * t;
+        q[0] = (R[2] + R[6]) * t;
+        q[1] = (R[5] + R[7]) * t;
     }
     if (q[3] < 0)
         for (int a = 0; a < 4; ++a) q[a] = -q[a];

@@ -35,21 +35,33 @@ __host__ __device__ inline void normalize_rotation(double R[9]) {
         q[0] = (R[7] - R[5]) * t;
         q[1] = (R[2] - R[6]) * t;
         q[2] = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
-        q[i] = 0.5 * t;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {   // largest diagonal element first (Eigen), written out per case
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        q[0] = 0.5 * t;
         t = 0.5 / t;
-        q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
-        q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
-        q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+        q[3] = (R[7] - R[5]) * t;
+        q[1] = (R[3] + R[1]) * t;
+        q[2] = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && R[4] >= R[8]) {
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        q[1] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[2] - R[6]) * t;
+        q[2] = (R[7] + R[5]) * t;
+        q[0] = (R[1] + R[3]) * t;
+    } else {
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        q[2] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[3] - R[1]) * t;
+        q[0] = (R[2] + R[6]) * t;
+        q[1] = (R[5] + R[7]) * t;
     }
     if (q[3] < 0)
+        #pragma unroll
         for (int a = 0; a < 4; ++a) q[a] = -q[a];
     const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    #pragma unroll
     for (int a = 0; a < 4; ++a) q[a] /= nrm;
     const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
     const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
@@ -61,7 +73,9 @@ __host__ __device__ inline void normalize_rotation(double R[9]) {
 }
 __host__ __device__ inline Se3 se3_mul(const Se3& a, const Se3& b) {
     Se3 c;
+    #pragma unroll
     for (int i = 0; i < 3; ++i) {
+        #pragma unroll
         for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * i] * b.R[j] + a.R[3 * i + 1] * b.R[3 + j] + a.R[3 * i + 2] * b.R[6 + j];
         c.t[i] = a.R[3 * i] * b.t[0] + a.R[3 * i + 1] * b.t[1] + a.R[3 * i + 2] * b.t[2] + a.t[i];
     }
@@ -70,8 +84,11 @@ __host__ __device__ inline Se3 se3_mul(const Se3& a, const Se3& b) {
 }
 __host__ __device__ inline Se3 se3_inv(const Se3& a) {
     Se3 c;
+    #pragma unroll
     for (int i = 0; i < 3; ++i)
+        #pragma unroll
         for (int j = 0; j < 3; ++j) c.R[3 * i + j] = a.R[3 * j + i];
+    #pragma unroll
     for (int i = 0; i < 3; ++i) c.t[i] = -(c.R[3 * i] * a.t[0] + c.R[3 * i + 1] * a.t[1] + c.R[3 * i + 2] * a.t[2]);
     return c;
 }
@@ -81,7 +98,9 @@ __host__ __device__ inline void skew3(const double v[3], double S[9]) {
     S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
 }
 __host__ __device__ inline void mat3_mul(const double A[9], const double B[9], double C[9]) {
+    #pragma unroll
     for (int i = 0; i < 3; ++i)
+        #pragma unroll
         for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 // SE3Quat::exp, update = (omega, upsilon)
@@ -92,15 +111,18 @@ __host__ __device__ inline Se3 se3_exp(const double u[6]) {
     mat3_mul(Om, Om, Om2);
     Se3 T;
     if (theta < 0.00001) {
+        #pragma unroll
         for (int i = 0; i < 9; ++i) V[i] = T.R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i];
     } else {
         const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta);
         const double c = (theta - sin(theta)) / (theta * theta * theta);
+        #pragma unroll
         for (int i = 0; i < 9; ++i) {
             T.R[i] = (i % 4 == 0 ? 1.0 : 0.0) + a * Om[i] + b * Om2[i];
             V[i] = (i % 4 == 0 ? 1.0 : 0.0) + b * Om[i] + c * Om2[i];
         }
     }
+    #pragma unroll
     for (int i = 0; i < 3; ++i) T.t[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
     normalize_rotation(T.R);
     return T;
@@ -112,19 +134,24 @@ __host__ __device__ inline void se3_log(const Se3& T, double out[6]) {
     const double dR[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
     double om[3], Om[9], Om2[9], Vi[9];
     if (d > 0.99999) {
+        #pragma unroll
         for (int i = 0; i < 3; ++i) om[i] = 0.5 * dR[i];
         skew3(om, Om);
         mat3_mul(Om, Om, Om2);
+        #pragma unroll
         for (int i = 0; i < 9; ++i) Vi[i] = (i % 4 == 0 ? 1.0 : 0.0) - 0.5 * Om[i] + (1. / 12.) * Om2[i];
     } else {
         const double theta = acos(d);
         const double k = theta / (2 * sqrt(1 - d * d));
+        #pragma unroll
         for (int i = 0; i < 3; ++i) om[i] = k * dR[i];
         skew3(om, Om);
         mat3_mul(Om, Om, Om2);
         const double c = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+        #pragma unroll
         for (int i = 0; i < 9; ++i) Vi[i] = (i % 4 == 0 ? 1.0 : 0.0) - 0.5 * Om[i] + c * Om2[i];
     }
+    #pragma unroll
     for (int i = 0; i < 3; ++i) {
         out[i] = om[i];
         out[3 + i] = Vi[3 * i] * T.t[0] + Vi[3 * i + 1] * T.t[1] + Vi[3 * i + 2] * T.t[2];
@@ -187,12 +214,15 @@ __device__ inline double prior_terms(const PoseParams& P, const Se3& T, double* 
     double ep[6];
     se3_log(se3_mul(P.prior, se3_inv(T)), ep);
     double chi = 0;
+    #pragma unroll
     for (int a = 0; a < 6; ++a) {
         double s = 0;
+        #pragma unroll
         for (int c = 0; c < 6; ++c) s += P.info[6 * a + c] * ep[c];
         chi += ep[a] * s;
         if (H) {
             b[a] += s;
+            #pragma unroll
             for (int c = 0; c < 6; ++c) H[6 * a + c] += P.info[6 * a + c];
         }
     }
@@ -201,28 +231,38 @@ __device__ inline double prior_terms(const PoseParams& P, const Se3& T, double* 
 
 __device__ inline bool solve6(const double* H, double lambda, const double* b, double* x) {
     double L[36];
+    #pragma unroll
     for (int i = 0; i < 6; ++i)
+        #pragma unroll
         for (int j = 0; j < 6; ++j) L[6 * i + j] = H[6 * i + j] + (i == j ? lambda : 0.0);
+    #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = L[6 * j + j];
+        #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k];
         if (!(d > 0)) return false;
         d = sqrt(d);
         L[6 * j + j] = d;
+        #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double v = L[6 * i + j];
+            #pragma unroll
             for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
             L[6 * i + j] = v / d;
         }
     }
     double y[6];
+    #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double v = b[i];
+        #pragma unroll
         for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
         y[i] = v / L[6 * i + i];
     }
+    #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double v = y[i];
+        #pragma unroll
         for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * x[k];
         x[i] = v / L[6 * i + i];
     }
@@ -261,25 +301,32 @@ __global__ __launch_bounds__(256) void k_pose_ba(PoseParams P, const double* __r
     }
     for (int it = 0; it < P.iters; ++it) {
         {   // linearise at the estimate
+            #pragma unroll
             for (int k = 0; k < kAcc; ++k) acc[k] = 0;
             const Se3 T = s_est;
             for (int i = tid; i < P.n; i += 256) edge_terms<true>(P, T, xyz, uv, w, i, acc);
             if (tid == kPriorThread) {
+                #pragma unroll
                 for (int a = 0; a < 36; ++a) s_pH[a] = 0;
+                #pragma unroll
                 for (int a = 0; a < 6; ++a) s_pb[a] = 0;
                 s_pchi = prior_terms(P, T, s_pH, s_pb);
             }
             block_sum(acc, kAcc, s_part, s_tot);
             if (tid == 0) {
                 int k = 0;
+                #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     b[a] = s_tot[21 + a] + s_pb[a];
+                    #pragma unroll
                     for (int c = a; c < 6; ++c) { H[6 * a + c] = s_tot[k]; H[6 * c + a] = s_tot[k]; ++k; }
                 }
+                #pragma unroll
                 for (int a = 0; a < 36; ++a) H[a] += s_pH[a];
                 currentChi = s_tot[27] + s_pchi;
                 if (it == 0) {   // computeLambdaInit: tau * max |diag(H)|
                     double maxd = 0;
+                    #pragma unroll
                     for (int r = 0; r < 6; ++r) maxd = fmax(fabs(H[7 * r]), maxd);
                     lambda = 1e-5 * maxd;
                     ni = 2;
@@ -293,6 +340,7 @@ __global__ __launch_bounds__(256) void k_pose_ba(PoseParams P, const double* __r
             if (tid == 0) {
                 ok2 = solve6(H, lambda, b, x);
                 if (!ok2)
+                    #pragma unroll
                     for (int r = 0; r < 6; ++r) x[r] = 0;
                 s_trial = se3_mul(se3_exp(x), s_est);
             }
@@ -309,6 +357,7 @@ __global__ __launch_bounds__(256) void k_pose_ba(PoseParams P, const double* __r
                 ++qmax;
                 rho = currentChi - tempChi;
                 double scale = 1e-3;
+                #pragma unroll
                 for (int r = 0; r < 6; ++r) scale += x[r] * (lambda * x[r] + b[r]);
                 rho /= scale;
                 if (rho > 0 && isfinite(tempChi)) {
@@ -341,7 +390,9 @@ __global__ __launch_bounds__(256) void k_pose_ba(PoseParams P, const double* __r
     if (tid == 0) {
         stats->trials = trials;
         stats->lambda_final = lambda;
+        #pragma unroll
         for (int i = 0; i < 9; ++i) pose_out[i] = s_est.R[i];
+        #pragma unroll
         for (int i = 0; i < 3; ++i) pose_out[9 + i] = s_est.t[i];
     }
 }
@@ -380,21 +431,21 @@ extern "C" int se2gpu_plane_motion_prior(const double* Tcw12, const double* Tbc1
     double A[36] = {0}, sk[9], sR[9];
     skew3(Tbc.t, sk);
     mat3_mul(sk, Tbc.R, sR);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
+        for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
             A[6 * i + j] = Tbc.R[3 * i + j];
             A[6 * (i + 3) + (j + 3)] = Tbc.R[3 * i + j];
             A[6 * (i + 3) + j] = sR[3 * i + j];
         }
     const double D[6] = {xrot_info, yrot_info, 1e-4, 1e-4, 1e-4, z_info};
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j < 6; ++j) {
+        for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
             double s = 0;
-            for (int k = 0; k < 6; ++k) s += A[6 * k + i] * D[k] * A[6 * k + j];
+                        for (int k = 0; k < 6; ++k) s += A[6 * k + i] * D[k] * A[6 * k + j];
             info36[6 * i + j] = s;
         }
-    for (int i = 0; i < 6; ++i)   // "make sure the info matrix is symmetric" (:296-298)
-        for (int j = 0; j < i; ++j) info36[6 * i + j] = info36[6 * j + i];
+        for (int i = 0; i < 6; ++i)   // "make sure the info matrix is symmetric" (:296-298)
+                for (int j = 0; j < i; ++j) info36[6 * i + j] = info36[6 * j + i];
     return SE2GPU_OK;
 }
 
