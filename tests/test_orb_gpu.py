@@ -167,3 +167,20 @@ def test_dense_and_sparse_score_kernels_agree(synth, monkeypatch):
         assert np.array_equal(ks, kd) and np.array_equal(ds, dd)
         for lv in range(8):
             assert np.array_equal(sparse.debug_score(0, lv), dense.debug_score(0, lv)), lv
+
+
+def test_batch_sizes_not_a_multiple_of_eight(oracle, synth):
+    """frames are dealt to the 8 XCDs through the grid's fast axis (rounded up to 8): batches of 1, 3, 19 frames must
+    give the single-frame results, with stale frames of a larger earlier batch left alone"""
+    from se2lam_amd.orb import ORBextractor
+    ex = ORBextractor(max_batch=19)
+    one = ORBextractor()
+    for B, start in ((19, 40), (3, 7), (1, 90)):
+        imgs = synth.frames(B, start=start)
+        out = ex.extract_batch(imgs)
+        assert len(out) == B
+        for b in range(B):
+            k, d = one(imgs[b])
+            assert np.array_equal(out[b][0], k) and np.array_equal(out[b][1], d), (B, b)
+        ko, do = oracle.orb_extract(imgs[B - 1])
+        assert np.array_equal(out[B - 1][0], ko) and np.array_equal(out[B - 1][1], do)
