@@ -896,4 +896,24 @@ int ba_ref_pose_only(const double* Tcw12, const double* prior_meas12, const doub
     return 0;
 }
 
+// test hooks: the building blocks of ba_ref_pose_only, so that tests can check them against their definitions
+// (exp / log round trips, analytic Jacobian of EdgeProjectXYZ2UV against a numeric derivative through exp)
+void ba_ref_se3_exp(const double* update6, double* pose12) { se3_to(se3_exp(update6), pose12); }
+void ba_ref_se3_log(const double* pose12, double* out6) { se3_log(se3_from(pose12), out6); }
+void ba_ref_se3_mul(const double* a12, const double* b12, double* out12) { se3_to(se3_mul(se3_from(a12), se3_from(b12)), out12); }
+// error (2) and the 2x6 Jacobian w.r.t. the pose update (rotation, translation) of one EdgeProjectXYZ2UV
+void ba_ref_project_edge(const double* pose12, const double* X, const double* uv, double f, double cx, double cy,
+                         double* e2, double* J12) {
+    const Se3 T = se3_from(pose12);
+    const double x = T.R[0] * X[0] + T.R[1] * X[1] + T.R[2] * X[2] + T.t[0];
+    const double y = T.R[3] * X[0] + T.R[4] * X[1] + T.R[5] * X[2] + T.t[1];
+    const double z = T.R[6] * X[0] + T.R[7] * X[1] + T.R[8] * X[2] + T.t[2];
+    e2[0] = uv[0] - (x / z * f + cx);
+    e2[1] = uv[1] - (y / z * f + cy);
+    const double z2 = z * z;
+    const double J[12] = {x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f,
+                          (1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f};
+    std::memcpy(J12, J, sizeof(J));
+}
+
 }  // extern "C"

@@ -779,4 +779,16 @@ int match_ref_remove_outliers(const match_ref_keypoint* kp1, int n1, const match
     return nInlier;
 }
 
+// test hook: the 7-point models of one sample (run7Point), for checks against the definition (det F = 0, the seven
+// correspondences on their epipolar lines)
+int match_ref_seven_point(const float* m1, const float* m2, const int* idx7, double* F27) {
+    return fm_run7point(m1, m2, idx7, F27);
+}
+
+// test hook: the first `count` samples PointSetRegistrator::getSubset draws for n points (7 indices each)
+void match_ref_ransac_subsets(int n, int count, int* out) {
+    CvRng rng((uint64_t)-1);
+    for (int k = 0; k < count; ++k) fm_subset(rng, n, out + 7 * k);
+}
+
 }  // extern "C"

@@ -476,3 +476,51 @@ def pose_only_ba(Tcw, prior_meas, prior_info, xyz, uv, inv_sigma2, f, cx, cy, de
                  chi2_final=st.chi2_final, lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
                  lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]))
     return pose12_to_matrix(out), stats
+
+
+def se3_exp(update6):
+    out = np.zeros(12); u = np.ascontiguousarray(update6, np.float64)
+    f = lib().ba_ref_se3_exp; f.restype = None; f.argtypes = [C.c_void_p, C.c_void_p]
+    f(u.ctypes.data, out.ctypes.data)
+    return pose12_to_matrix(out)
+
+
+def se3_log(T):
+    out = np.zeros(6); a = _pose12(T)
+    f = lib().ba_ref_se3_log; f.restype = None; f.argtypes = [C.c_void_p, C.c_void_p]
+    f(a.ctypes.data, out.ctypes.data)
+    return out
+
+
+def se3_mul(A, B):
+    out = np.zeros(12); a, b = _pose12(A), _pose12(B)
+    f = lib().ba_ref_se3_mul; f.restype = None; f.argtypes = [C.c_void_p] * 3
+    f(a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return pose12_to_matrix(out)
+
+
+def project_edge(T, X, uv, f, cx, cy):
+    """EdgeProjectXYZ2UV -> (error (2,), Jacobian (2,6) w.r.t. the pose update)"""
+    e = np.zeros(2); J = np.zeros(12); a = _pose12(T)
+    X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
+    fn = lib().ba_ref_project_edge; fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    fn(a.ctypes.data, X.ctypes.data, uv.ctypes.data, f, cx, cy, e.ctypes.data, J.ctypes.data)
+    return e, J.reshape(2, 6)
+
+
+def seven_point(pt1, pt2, idx7):
+    """run7Point on the correspondences idx7 -> list of 3x3 matrices"""
+    p1 = np.ascontiguousarray(pt1, np.float32).reshape(-1, 2); p2 = np.ascontiguousarray(pt2, np.float32).reshape(-1, 2)
+    idx = np.ascontiguousarray(idx7, np.int32)
+    F = np.zeros(27)
+    fn = lib().match_ref_seven_point; fn.restype = C.c_int; fn.argtypes = [C.c_void_p] * 4
+    n = fn(p1.ctypes.data, p2.ctypes.data, idx.ctypes.data, F.ctypes.data)
+    return [F[9 * k:9 * k + 9].reshape(3, 3).copy() for k in range(max(n, 0))]
+
+
+def ransac_subsets(n, count):
+    out = np.zeros((count, 7), np.int32)
+    fn = lib().match_ref_ransac_subsets; fn.restype = None; fn.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    fn(n, count, out.ctypes.data)
+    return out

@@ -64,6 +64,33 @@ def test_oracle_pose_only_ba_recovers_the_pose(oracle):
         assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12)
 
 
+def test_oracle_se3_exp_log_and_projection_jacobian(oracle):
+    """SE3Quat::exp / log are inverse to each other, exp is a homomorphism along one twist, and the analytic Jacobian
+    of EdgeProjectXYZ2UV (types_six_dof_expmap) is the derivative of the error through exp(update) * estimate."""
+    rng = np.random.default_rng(3)
+    for scale in (1e-7, 1e-3, 0.3, 2.5):
+        u = rng.normal(0, 1, 6) * np.array([scale] * 3 + [300.0] * 3)
+        T = oracle.se3_exp(u)
+        assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-13) and np.isclose(np.linalg.det(T[:3, :3]), 1)
+        # below theta = 1e-5 g2o's exp uses V = R = I + Omega + Omega^2 (its own "TODO: check"), first order only
+        slack = np.linalg.norm(u[:3]) * np.linalg.norm(u[3:]) if scale < 1e-5 else 0.0
+        assert np.allclose(oracle.se3_log(T), u, rtol=1e-7, atol=1e-7 + slack)
+        assert np.allclose(oracle.se3_mul(oracle.se3_exp(0.5 * u), oracle.se3_exp(0.5 * u)), T, atol=1e-8 + slack)
+    T = np.linalg.inv(_Twb(300, -200, 0.7) @ TBC)
+    for _ in range(5):
+        X = (np.linalg.inv(T) @ np.append(rng.uniform([-1500, -1000, 1500], [1500, 1000, 7000]), 1.0))[:3]
+        uv = rng.uniform(0, 640, 2)
+        e0, J = oracle.project_edge(T, X, uv, F, CX, CY)
+        Jn = np.zeros((2, 6))
+        for k in range(6):
+            h = 1e-6 if k < 3 else 1e-3
+            d = np.zeros(6); d[k] = h
+            ep, _ = oracle.project_edge(oracle.se3_mul(oracle.se3_exp(d), T), X, uv, F, CX, CY)
+            em, _ = oracle.project_edge(oracle.se3_mul(oracle.se3_exp(-d), T), X, uv, F, CX, CY)
+            Jn[:, k] = (ep - em) / (2 * h)
+        assert np.allclose(J, Jn, rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------------ device path
 
 def _same_run(st, so):

@@ -60,6 +60,37 @@ def test_oracle_remove_outliers_semantics(oracle, synth):
     assert ni == 0 and (out == -1).all()
 
 
+def test_oracle_seven_point_models_satisfy_their_definition(oracle):
+    """run7Point: every returned matrix is singular, puts the seven sample correspondences on their epipolar lines and
+    has F(3,3) = 1; on exact two-view geometry one of them is the true fundamental matrix (up to scale)."""
+    p1, p2, _ = _two_views(5, 200, outlier_frac=0.0, noise=0.0)
+    rng = np.random.default_rng(1)
+    found_true = 0
+    for _ in range(20):
+        idx = rng.choice(200, 7, replace=False)
+        Fs = oracle.seven_point(p1, p2, idx)
+        assert 1 <= len(Fs) <= 3
+        for Fm in Fs:
+            assert abs(Fm[2, 2] - 1.0) < 1e-12
+            sv = np.linalg.svd(Fm, compute_uv=False)
+            assert sv[2] < 1e-7 * sv[0]                                          # det F = 0
+            x1 = np.c_[p1[idx].astype(np.float64), np.ones(7)]; x2 = np.c_[p2[idx].astype(np.float64), np.ones(7)]
+            r = np.einsum("ij,jk,ik->i", x2, Fm, x1)
+            assert np.abs(r).max() < 1e-6 * np.abs(Fm).max() * 640 * 640         # x2^T F x1 = 0 on the sample
+        a1 = np.c_[p1.astype(np.float64), np.ones(200)]; a2 = np.c_[p2.astype(np.float64), np.ones(200)]
+        res = [np.abs(np.einsum("ij,jk,ik->i", a2, Fm, a1)).max() / (np.abs(Fm).max() * 640 * 640) for Fm in Fs]
+        found_true += min(res) < 1e-4                                           # float32 pixel coordinates
+    assert found_true == 20
+
+
+def test_oracle_ransac_samples_are_distinct_and_reproducible(oracle):
+    a = oracle.ransac_subsets(700, 50); b = oracle.ransac_subsets(700, 50)
+    assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 700
+    assert all(len(set(row)) == 7 for row in a)
+    assert np.array_equal(oracle.ransac_subsets(700, 10), a[:10])
+    assert not np.array_equal(oracle.ransac_subsets(40, 5), a[:5])
+
+
 # ---------------------------------------------------------------- device path
 
 @pytest.mark.gpu
