@@ -148,53 +148,60 @@ __global__ __launch_bounds__(256) void k_level0(Geom g, const uint8_t* __restric
 // costs nothing per pixel), built on the host with exactly cv::resize's arithmetic (fx = (float)((dx + 0.5) * scale_x
 // - 0.5) in double, 11-bit rounding in float, the S[sx] * ONE tail): two int4 per group of 4 columns,
 // {sx | valid << 31} x 4 and {a0 | a1 << 16} x 4.  The two source bytes S[sx], S[sx + 1] of a row come from one
-// (unaligned) 16-bit load.  Threads are laid out over (row, column group) of the whole level, so narrow levels do not
-// leave most of a workgroup idle.
+// (unaligned) 64-bit load per source row and column group.
 struct ResizeTab {
     const int4* ytab;
     const int4* xtab;
     int ngroups;   // stride / 4
 };
 
+// A thread owns one column group (4 output bytes) and walks down kResizeRows rows: the 32 B of x coefficients are
+// fetched once per thread instead of once per 4 output bytes (they were three quarters of this kernel's load traffic),
+// the y entry of a row is one broadcast load per wave.  Workgroup = 4 waves = 4 row bands of one 64-group column tile.
+constexpr int kResizeRows = 8;
 __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint8_t* __restrict__ pyr,
                                                  uint8_t* __restrict__ blur) {
     SE2_FRAME_GRID(f, bx);
-    const int gid = bx * 256 + threadIdx.x;
-    const int H = g.h[l], stride = g.stride[l];
-    const int Y = gid / t.ngroups;
-    if (Y >= H + 2 * kEdge) return;
-    const int xg = gid - Y * t.ngroups;
-    const int dy = reflect101(Y - kEdge, H);
-    const int4 yt = t.ytab[dy];
+    const int H = g.h[l], stride = g.stride[l], rows = H + 2 * kEdge;
+    const int ctiles = (t.ngroups + 63) / 64;
+    const int xg = (bx % ctiles) * 64 + (int)(threadIdx.x & 63);
+    const int Y0 = ((bx / ctiles) * 4 + (int)(threadIdx.x >> 6)) * kResizeRows;
+    if (xg >= t.ngroups || Y0 >= rows) return;
     const int4 xs = t.xtab[2 * xg], xa = t.xtab[2 * xg + 1];
-    const uint8_t* S0 = pyr + pix(g, f, l - 1, yt.x, 0);
-    const uint8_t* S1 = pyr + pix(g, f, l - 1, yt.y, 0);
     const int sxv[4] = {xs.x, xs.y, xs.z, xs.w};
     const int av[4] = {xa.x, xa.y, xa.z, xa.w};
-    uint32_t v = 0;
     // The source columns of the four output pixels span at most 4 (scale 1.2, also across the reflection), so all
     // eight taps of a source row lie in ONE (unaligned) 64-bit word starting at the smallest column.
     const int sx0 = sxv[0] & 0xffff, sx1 = sxv[1] & 0xffff, sx2 = sxv[2] & 0xffff, sx3 = sxv[3] & 0xffff;
     const int sb = min(min(sx0, sx1), min(sx2, sx3));
-    const unsigned long long w0 = *reinterpret_cast<const unsigned long long*>(S0 + sb);
-    const unsigned long long w1 = *reinterpret_cast<const unsigned long long*>(S1 + sb);
-    const int sxq[4] = {sx0, sx1, sx2, sx3};
+    const int o8[4] = {8 * (sx0 - sb), 8 * (sx1 - sb), 8 * (sx2 - sb), 8 * (sx3 - sb)};
+    const uint8_t* src = pyr + pix(g, f, l - 1, 0, 0) + sb;
+    const int sstride = g.stride[l - 1];
+    const size_t obase = (size_t)f * g.frame_bytes + g.off[l] + 4 * xg;
+    const bool frame_col = 4 * xg < 16 || 4 * xg >= ((kEdge + g.w[l]) / 16) * 16;
+    const int Yend = min(Y0 + kResizeRows, rows);
+#pragma unroll 4
+    for (int Y = Y0; Y < Yend; ++Y) {
+        const int4 yt = t.ytab[reflect101(Y - kEdge, H)];
+        const unsigned long long w0 = *reinterpret_cast<const unsigned long long*>(src + (ptrdiff_t)yt.x * sstride);
+        const unsigned long long w1 = *reinterpret_cast<const unsigned long long*>(src + (ptrdiff_t)yt.y * sstride);
+        uint32_t v = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int o8 = 8 * (sxq[q] - sb);
-        const uint32_t t0 = (uint32_t)(w0 >> o8), t1 = (uint32_t)(w1 >> o8);   // tap pair in the low 16 bits
-        const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
-        const int r0 = (int)(t0 & 0xffu) * a0 + (int)((t0 >> 8) & 0xffu) * a1;
-        const int r1 = (int)(t1 & 0xffu) * a0 + (int)((t1 >> 8) & 0xffu) * a1;
-        uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
-        if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
-        v |= b << (8 * q);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t0 = (uint32_t)(w0 >> o8[q]), t1 = (uint32_t)(w1 >> o8[q]);   // tap pair in the low 16 bits
+            const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
+            const int r0 = (int)(t0 & 0xffu) * a0 + (int)((t0 >> 8) & 0xffu) * a1;
+            const int r1 = (int)(t1 & 0xffu) * a0 + (int)((t1 >> 8) & 0xffu) * a1;
+            uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
+            if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
+            v |= b << (8 * q);
+        }
+        const size_t off = obase + (size_t)Y * stride;
+        *(uint32_t*)(pyr + off) = v;
+        // un-blurred frame of the blurred pyramid, in whole 16-byte chunks as k_blur expects: frame rows, chunk 0, and
+        // everything from the chunk that holds the first column right of the interior
+        if (frame_col || Y < kEdge || Y >= H + kEdge) *(uint32_t*)(blur + off) = v;
     }
-    const size_t off = (size_t)f * g.frame_bytes + g.off[l] + (size_t)Y * stride + 4 * xg;
-    *(uint32_t*)(pyr + off) = v;
-    // un-blurred frame of the blurred pyramid, in whole 16-byte chunks as k_blur expects: frame rows, chunk 0, and
-    // everything from the chunk that holds the first column right of the interior
-    if (Y < kEdge || Y >= H + kEdge || 4 * xg < 16 || 4 * xg >= ((kEdge + g.w[l]) / 16) * 16) *(uint32_t*)(blur + off) = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1352,7 +1359,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     for (int l = 1; l < L; ++l) {
         const int ng = g.stride[l] / 4;
         ResizeTab t{h->tabs.p + h->ytab_off[l], h->tabs.p + h->xtab_off[l], ng};
-        dim3 grid(F8, (ng * (g.h[l] + 2 * kEdge) + 255) / 256);
+        dim3 grid(F8, ((ng + 63) / 64) * ((g.h[l] + 2 * kEdge + 4 * kResizeRows - 1) / (4 * kResizeRows)));
         SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p, h->blur.p);
     }
     // The blurred pyramid needs only the pyramid: it runs on a side stream next to the key-point chain, whose
