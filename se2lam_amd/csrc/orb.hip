@@ -10,7 +10,7 @@
 // Pipeline (every kernel covers the whole batch; all stages stay in HBM, no host round trip):
 //   k_level0 / k_resize   pyramid level k from level k-1, border filled in the same pass; resize coefficients from host
 //                         tables over the bordered row, the taps of a thread from one 64-bit load per source row
-//   k_fast_score[_dense]  S(x,y) = FAST-9/16 score for every level in one launch, in-cell non-max suppression fused:
+//   k_fast_score[_sparse] S(x,y) = FAST-9/16 score for every level in one launch, in-cell non-max suppression fused:
 //                         writes a sparse plane (S where S > 7 and a strict in-cell maximum, else 0)
 //   k_cell_detect         one workgroup per (frame, level, cell): collects the non-zero scores, threshold 20 /
 //                         fallback 7, rank sort by (response desc, y, x) -> per-cell sorted candidate list
@@ -214,36 +214,33 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 // Two pixels at once in packed int16 lanes (v_pk_min_i16 / v_pk_max_i16).  With p[k] the 16 ring pixels and v the
 // centre,  min_arc(v - p) = v - max_arc(p)  and  min_arc(p - v) = min_arc(p) - v,  so the extrema are taken on the raw
 // ring values and only two subtractions remain:   S = max(0, v - min_k max9[k], max_k min9[k] - v).
-// The 16 circular windows of 9 are formed from prefix / suffix extrema of the two halves of the ring (van Herk):
-// window k = p[k..7] u p[8..8+k] = min(sufA[k], preB[k]) for k < 8, and min(sufB[k-8], preA[k-8]) for k >= 8 - 44
-// instead of 64 operations per extremum.
+// Every arc of 9 is an arc of 8 plus one end point, and an arc of 8 starting at an odd ring position j serves both the
+// arc of 9 that starts at j - 1 and the one that starts at j:
+//     m8[j] = min(p[j .. j+7])   (j odd, by doubling: 8 + 8 + 8 operations),
+//     max over the two arcs of their minimum = min(m8[j], max(p[j-1], p[j+8]))
+// - 47 packed operations per extremum instead of 64 (59 with prefix / suffix extrema of the ring halves).
 __device__ __forceinline__ short2v fast_score_pk(const short2v p[16], short2v v) {
-    short2v preA[8], sufA[8], preB[8], sufB[8], PreA[8], SufA[8], PreB[8], SufB[8];   // lower case: min, upper: max
-    preA[0] = PreA[0] = p[0];
-    preB[0] = PreB[0] = p[8];
-    sufA[7] = SufA[7] = p[7];
-    sufB[7] = SufB[7] = p[15];
+    short2v a2[8], A2[8], a4[8], A4[8];   // lower case: minima, upper case: maxima; index i <-> odd ring position 2 i + 1
 #pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        preA[i] = __builtin_elementwise_min(preA[i - 1], p[i]);
-        PreA[i] = __builtin_elementwise_max(PreA[i - 1], p[i]);
-        preB[i] = __builtin_elementwise_min(preB[i - 1], p[8 + i]);
-        PreB[i] = __builtin_elementwise_max(PreB[i - 1], p[8 + i]);
-        sufA[7 - i] = __builtin_elementwise_min(sufA[8 - i], p[7 - i]);
-        SufA[7 - i] = __builtin_elementwise_max(SufA[8 - i], p[7 - i]);
-        sufB[7 - i] = __builtin_elementwise_min(sufB[8 - i], p[15 - i]);
-        SufB[7 - i] = __builtin_elementwise_max(SufB[8 - i], p[15 - i]);
+    for (int i = 0; i < 8; ++i) {
+        a2[i] = __builtin_elementwise_min(p[(2 * i + 1) & 15], p[(2 * i + 2) & 15]);
+        A2[i] = __builtin_elementwise_max(p[(2 * i + 1) & 15], p[(2 * i + 2) & 15]);
     }
-    short2v bmn = __builtin_elementwise_min(sufA[0], preB[0]);   // max over the windows of their minimum
-    short2v bmx = __builtin_elementwise_max(SufA[0], PreB[0]);   // min over the windows of their maximum
-    bmn = __builtin_elementwise_max(bmn, __builtin_elementwise_min(sufB[0], preA[0]));
-    bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufB[0], PreA[0]));
 #pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        bmn = __builtin_elementwise_max(bmn, __builtin_elementwise_min(sufA[i], preB[i]));
-        bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufA[i], PreB[i]));
-        bmn = __builtin_elementwise_max(bmn, __builtin_elementwise_min(sufB[i], preA[i]));
-        bmx = __builtin_elementwise_min(bmx, __builtin_elementwise_max(SufB[i], PreA[i]));
+    for (int i = 0; i < 8; ++i) {         // four consecutive ring pixels from position 2 i + 1
+        a4[i] = __builtin_elementwise_min(a2[i], a2[(i + 1) & 7]);
+        A4[i] = __builtin_elementwise_max(A2[i], A2[(i + 1) & 7]);
+    }
+    short2v bmn, bmx;                     // max over the arcs of their minimum / min over the arcs of their maximum
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = 2 * i + 1;
+        const short2v m8 = __builtin_elementwise_min(a4[i], a4[(i + 2) & 7]);   // p[j .. j+7]
+        const short2v M8 = __builtin_elementwise_max(A4[i], A4[(i + 2) & 7]);
+        const short2v lo = __builtin_elementwise_min(m8, __builtin_elementwise_max(p[(j - 1) & 15], p[(j + 8) & 15]));
+        const short2v hi = __builtin_elementwise_max(M8, __builtin_elementwise_min(p[(j - 1) & 15], p[(j + 8) & 15]));
+        bmn = i == 0 ? lo : __builtin_elementwise_max(bmn, lo);
+        bmx = i == 0 ? hi : __builtin_elementwise_min(bmx, hi);
     }
     const short2v zero = {0, 0};
     return __builtin_elementwise_max(zero, __builtin_elementwise_max(v - bmx, bmn - v));
@@ -306,7 +303,7 @@ __device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t lef
     return (unsigned long long)(left >> 24) | ((unsigned long long)own << 8) | ((unsigned long long)(right & 0xffu) << 40);
 }
 
-__global__ __launch_bounds__(256) void k_fast_score_dense(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
     SE2_FRAME_GRID(f, bx);
     int l = 0;
     while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
@@ -403,7 +400,7 @@ __global__ __launch_bounds__(256) void k_fast_score_dense(Geom g, const uint8_t*
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fast_score: the same plane as k_fast_score_dense (S' = S where S > 7 and a strict in-cell maximum, else 0), computed
+// k_fast_score_sparse: the same plane as k_fast_score (S' = S where S > 7 and a strict in-cell maximum, else 0), computed
 // only where it can be non-zero.  A 9-arc of the 16-ring always contains two ADJACENT compass points (ring positions
 // 0, 4, 8, 12), so S > 7 needs both of them brighter than v + 7 or both darker than v - 7: a 4-pixel test that rejects
 // flat areas, noise and straight edges (typically > 90 % of the pixels).  One workgroup = one 128 x 32 tile staged in
@@ -415,9 +412,10 @@ __global__ __launch_bounds__(256) void k_fast_score_dense(Geom g, const uint8_t*
 //   3  in-cell non-max suppression per surviving candidate against its 8 neighbours in that tile (raw scores, as cv::FAST)
 //   4  the tile is written out as whole dwords
 // Dense corners only cost time, never correctness: the candidate list holds every pixel of the tile if need be.
-// On the benchmark texture (4000 overlapping rectangles: 15 % of the pixels pass the compass test, 6 % have S > 7) the
-// two kernels take 744 us and 783 us per 256 frames; on imagery with fewer corners this one's cost tends to the
-// compass pass alone (about a fifth of the dense kernel's arithmetic).  SE2GPU_ORB_SCORE=dense selects the other one.
+// On the benchmark texture (4000 overlapping rectangles: 15 % of the pixels pass the compass test, 6 % have S > 7) this
+// kernel takes 737 us per 256 frames against 631 us for k_fast_score, which is therefore the default; the two meet at
+// about one candidate in ten pixels, and on imagery with fewer corners this one's cost tends to the compass pass alone
+// (about a fifth of the dense kernel's arithmetic).  SE2GPU_ORB_SCORE=sparse selects it.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFsTW = 128, kFsTH = 32;
 constexpr int kFsLW = kFsTW + 16;          // LDS image tile: columns x0-8 .. x0+TW+8
@@ -441,7 +439,7 @@ __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e
     return ~(__builtin_bit_cast(uint32_t, a) & __builtin_bit_cast(uint32_t, b)) & 0x80008000u;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
     __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
     __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
     __shared__ uint32_t s_out[(kFsTW / 4) * kFsTH];
@@ -1202,8 +1200,8 @@ struct se2gpu_orb {
     DevBuf<uint8_t> out_d;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
     int score_tiles = 0, blur_tiles = 0;
-    int score_tile_base[kMaxLevels + 1], dense_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
-    bool dense_score = false;            // SE2GPU_ORB_SCORE=dense: score every pixel (k_fast_score_dense)
+    int score_tile_base[kMaxLevels + 1], sparse_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
+    bool sparse_score = false;           // SE2GPU_ORB_SCORE=sparse: candidates only (k_fast_score_sparse)
     ~se2gpu_orb() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
@@ -1259,12 +1257,12 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     g.cell_cap = std::min(kSortCap, ((2 * maxq + 64 + 63) / 64) * 64);
     // tiles
     h->score_tile_base[0] = 0;
-    h->dense_tile_base[0] = 0;
+    h->sparse_tile_base[0] = 0;
     h->blur_tile_base[0] = 0;
     for (int l = 0; l < L; ++l) {
         const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;
-        h->dense_tile_base[l + 1] = h->dense_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
-        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + kFsTW - 1) / kFsTW) * ((sh + kFsTH - 1) / kFsTH);
+        h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
+        h->sparse_tile_base[l + 1] = h->sparse_tile_base[l] + ((sw + kFsTW - 1) / kFsTW) * ((sh + kFsTH - 1) / kFsTH);
         h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 255) / 256) * ((g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows));
     }
     // resize tables
@@ -1375,10 +1373,10 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(F8, gb.tile_base[L]), dim3(256), 0, gb, h->pyr.p, h->blur.p);
     }
     if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
-    if (h->dense_score) {
-        for (int l = 0; l <= L; ++l) g.tile_base[l] = h->dense_tile_base[l];
-        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_dense, dim3(F8, g.tile_base[L]), dim3(256), 0, g,
-                   h->pyr.p, h->score.p);
+    if (h->sparse_score) {
+        for (int l = 0; l <= L; ++l) g.tile_base[l] = h->sparse_tile_base[l];
+        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_sparse, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
+                   h->score.p);
     } else {
         for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
         SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
@@ -1438,7 +1436,7 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
         return SE2GPU_ERR_HIP;
     }
     h->stream = h->own_stream;
-    if (const char* e = std::getenv("SE2GPU_ORB_SCORE")) h->dense_score = std::strcmp(e, "dense") == 0;
+    if (const char* e = std::getenv("SE2GPU_ORB_SCORE")) h->sparse_score = std::strcmp(e, "sparse") == 0;
     if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -151,13 +151,13 @@ def test_harris_score_on_noise_and_half_flat(oracle, synth):
 
 
 def test_dense_and_sparse_score_kernels_agree(synth, monkeypatch):
-    """k_fast_score (compass pre-test + candidates only, the default) and k_fast_score_dense (every pixel,
-    SE2GPU_ORB_SCORE=dense) must produce the same score planes and the same features, also where nearly every pixel is
+    """k_fast_score (every pixel, the default) and k_fast_score_sparse (compass pre-test + candidates only,
+    SE2GPU_ORB_SCORE=sparse) must produce the same score planes and the same features, also where nearly every pixel is
     a candidate (noise) and where none is (flat)."""
     from se2lam_amd.orb import ORBextractor
-    sparse = ORBextractor()
-    monkeypatch.setenv("SE2GPU_ORB_SCORE", "dense")
     dense = ORBextractor()
+    monkeypatch.setenv("SE2GPU_ORB_SCORE", "sparse")
+    sparse = ORBextractor()
     monkeypatch.delenv("SE2GPU_ORB_SCORE")
     rng = np.random.default_rng(9)
     half = synth.frame(1).copy(); half[:240] = 77
