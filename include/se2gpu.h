@@ -329,6 +329,10 @@ void* se2gpu_ba_stream(se2gpu_ba* h);
  * events around every launch when profiling is enabled on the handle (adds sync overhead). */
 int se2gpu_ba_profile(se2gpu_ba* h, int enable);
 int se2gpu_ba_profile_get(se2gpu_ba* h, int idx, const char** name, double* ms, int64_t* launches);
+/* FAST score kernel selection (SE2GPU_ORB_SCORE = auto | dense | sparse, default auto): info[0] = kernel the next batch
+ * would use (0 = every pixel, 1 = compass pre-test + candidates only), info[1] = last measured candidate density * 1e6, -1
+ * before the first measurement.  Both kernels produce the same plane. */
+int se2gpu_orb_score_kernel(se2gpu_orb* h, int info[2]);
 int se2gpu_orb_profile(se2gpu_orb* h, int enable);
 int se2gpu_orb_profile_get(se2gpu_orb* h, int idx, const char** name, double* ms, int64_t* launches);
 

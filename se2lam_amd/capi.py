@@ -73,6 +73,7 @@ SYMBOLS = {
     "se2gpu_orb_debug_level": (_I, [_VP, _I, _I, _I, _VP, _SZ, C.POINTER(_I), C.POINTER(_I)]),
     "se2gpu_orb_debug_score": (_I, [_VP, _I, _I, _VP, _SZ, C.POINTER(_I), C.POINTER(_I)]),
     "se2gpu_orb_stream": (_VP, [_VP]),
+    "se2gpu_orb_score_kernel": (_I, [_VP, _VP]),
     "se2gpu_orb_profile": (_I, [_VP, _I]),
     "se2gpu_orb_profile_get": (_I, [_VP, _I, C.POINTER(C.c_char_p), _PD, C.POINTER(C.c_int64)]),
     # matcher

@@ -415,7 +415,8 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
 // On the benchmark texture (4000 overlapping rectangles: 15 % of the pixels pass the compass test, 6 % have S > 7) this
 // kernel takes 737 us per 256 frames against 631 us for k_fast_score, which is therefore the default; the two meet at
 // about one candidate in ten pixels, and on imagery with fewer corners this one's cost tends to the compass pass alone
-// (about a fifth of the dense kernel's arithmetic).  SE2GPU_ORB_SCORE=sparse selects it.
+// (about a fifth of the dense kernel's arithmetic).  The extractor picks between the two from the candidate density this
+// kernel measures (se2gpu_orb handle, score_mode); SE2GPU_ORB_SCORE=dense / sparse pins one.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFsTW = 128, kFsTH = 32;
 constexpr int kFsLW = kFsTW + 16;          // LDS image tile: columns x0-8 .. x0+TW+8
@@ -439,7 +440,8 @@ __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e
     return ~(__builtin_bit_cast(uint32_t, a) & __builtin_bit_cast(uint32_t, b)) & 0x80008000u;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+__global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
+                                                           int* __restrict__ cand_count) {
     __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
     __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
     __shared__ uint32_t s_out[(kFsTW / 4) * kFsTH];
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
     __syncthreads();
     // 2. FAST-9 score of the candidates, two per lane.  Candidate code = (score-tile row << 8) | score-tile column.
     const int n = s_n;
+    if (tid == 0 && cand_count) atomicAdd(&cand_count[f], n);   // candidate density of the frame: picks the kernel
     uint8_t* sc8 = (uint8_t*)s_sc;
     const short2v seven = {7, 7};
     for (int b = 2 * tid; b < n; b += 512) {
@@ -1201,12 +1204,25 @@ struct se2gpu_orb {
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
     int score_tiles = 0, blur_tiles = 0;
     int score_tile_base[kMaxLevels + 1], sparse_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
-    bool sparse_score = false;           // SE2GPU_ORB_SCORE=sparse: candidates only (k_fast_score_sparse)
+    // Which FAST kernel: SE2GPU_ORB_SCORE = dense | sparse | auto (default).  In auto mode the candidate kernel counts the
+    // pixels that pass its compass test; it is used while fewer than kSparseBelow of the scanned pixels do, and every
+    // kProbeEvery-th batch scored by the dense kernel goes through it instead to look again.  The count comes back
+    // asynchronously (never waited for), so a decision lags one or two batches behind the imagery.
+    int score_mode = 0;                  // 0 auto, 1 dense, 2 sparse
+    bool use_sparse = false;             // auto: current choice
+    bool fs_pending = false;             // a count download is in flight
+    int fs_frames = 0, since_probe = 1 << 30;
+    double fs_density = -1.0;            // last measured candidates / scanned pixel
+    long long scan_pixels = 0;           // per frame, all levels
+    DevBuf<int> fs_count;
+    PinBuf<int> h_fs_count;
+    hipEvent_t ev_fs = nullptr;
     ~se2gpu_orb() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_fs) (void)hipEventDestroy(ev_fs);
     }
 };
 
@@ -1263,6 +1279,8 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;
         h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
         h->sparse_tile_base[l + 1] = h->sparse_tile_base[l] + ((sw + kFsTW - 1) / kFsTW) * ((sh + kFsTH - 1) / kFsTH);
+        if (l == 0) h->scan_pixels = 0;
+        h->scan_pixels += (long long)std::max(sw, 0) * std::max(sh, 0);
         h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 255) / 256) * ((g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows));
     }
     // resize tables
@@ -1373,10 +1391,37 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(F8, gb.tile_base[L]), dim3(256), 0, gb, h->pyr.p, h->blur.p);
     }
     if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
-    if (h->sparse_score) {
+    constexpr double kSparseBelow = 0.10;   // the two kernels cost the same at about one candidate per ten pixels
+    constexpr int kProbeEvery = 32;
+    bool run_sparse = h->score_mode == 2, count = false;
+    if (h->score_mode == 0) {
+        if (h->fs_pending && hipEventQuery(h->ev_fs) == hipSuccess) {
+            long long tot = 0;
+            for (int i = 0; i < h->fs_frames; ++i) tot += h->h_fs_count.p[i];
+            h->fs_density = (double)tot / ((double)h->fs_frames * (double)std::max(h->scan_pixels, 1ll));
+            h->use_sparse = h->fs_density < kSparseBelow;
+            h->fs_pending = false;
+        }
+        const bool probe = !h->fs_pending && (h->use_sparse || h->since_probe >= kProbeEvery);
+        run_sparse = h->use_sparse || probe;
+        count = probe;
+        h->since_probe = probe ? 0 : h->since_probe + 1;
+    }
+    if (run_sparse) {
+        if (count) {
+            SE2_CHECK(h->fs_count.reserve((size_t)h->max_batch));
+            SE2_CHECK(h->h_fs_count.reserve((size_t)h->max_batch));
+            SE2_HIP(hipMemsetAsync(h->fs_count.p, 0, (size_t)nframes * sizeof(int), st));
+        }
         for (int l = 0; l <= L; ++l) g.tile_base[l] = h->sparse_tile_base[l];
         SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_sparse, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
-                   h->score.p);
+                   h->score.p, count ? h->fs_count.p : (int*)nullptr);
+        if (count) {
+            SE2_HIP(hipMemcpyAsync(h->h_fs_count.p, h->fs_count.p, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, st));
+            SE2_HIP(hipEventRecord(h->ev_fs, st));
+            h->fs_pending = true;
+            h->fs_frames = nframes;
+        }
     } else {
         for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
         SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
@@ -1436,10 +1481,12 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
         return SE2GPU_ERR_HIP;
     }
     h->stream = h->own_stream;
-    if (const char* e = std::getenv("SE2GPU_ORB_SCORE")) h->sparse_score = std::strcmp(e, "sparse") == 0;
+    if (const char* e = std::getenv("SE2GPU_ORB_SCORE"))
+        h->score_mode = std::strcmp(e, "dense") == 0 ? 1 : (std::strcmp(e, "sparse") == 0 ? 2 : 0);
     if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fs, hipEventDisableTiming) != hipSuccess) {
         set_error("hipStreamCreate / hipEventCreate failed");
         delete h;
         return SE2GPU_ERR_HIP;
@@ -1583,6 +1630,14 @@ int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, si
     SE2_HIP(hipMemcpy2D(out, g.w[level], src, g.stride[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
     *rows = g.h[level];
     *cols = g.w[level];
+    return SE2GPU_OK;
+}
+
+// {kernel the next batch would be scored with (0 dense, 1 candidates only), last measured candidate density * 1e6 or -1}
+int se2gpu_orb_score_kernel(se2gpu_orb* h, int info[2]) {
+    SE2_REQUIRE(h && info, SE2GPU_ERR_INVALID, "orb_score_kernel: NULL argument");
+    info[0] = h->score_mode == 2 || (h->score_mode == 0 && h->use_sparse) ? 1 : 0;
+    info[1] = h->fs_density < 0 ? -1 : (int)(h->fs_density * 1e6);
     return SE2GPU_OK;
 }
 

@@ -54,6 +54,12 @@ class ORBextractor:
         capi.check(capi.lib().se2gpu_orb_extract_batch_device(self._h, d_imgs, nframes, rows, cols, d_kps, d_desc,
                                                               d_counts, cap))
 
+    def score_kernel(self):
+        """-> (kernel the next batch would be scored with: 'dense' | 'sparse', last measured FAST candidate density or None)"""
+        info = np.zeros(2, np.int32)
+        capi.check(capi.lib().se2gpu_orb_score_kernel(self._h, info.ctypes.data))
+        return ("sparse" if info[0] else "dense"), (None if info[1] < 0 else info[1] * 1e-6)
+
     def sync(self):
         capi.check(capi.lib().se2gpu_orb_sync(self._h))
 

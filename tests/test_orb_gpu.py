@@ -155,10 +155,12 @@ def test_dense_and_sparse_score_kernels_agree(synth, monkeypatch):
     SE2GPU_ORB_SCORE=sparse) must produce the same score planes and the same features, also where nearly every pixel is
     a candidate (noise) and where none is (flat)."""
     from se2lam_amd.orb import ORBextractor
+    monkeypatch.setenv("SE2GPU_ORB_SCORE", "dense")
     dense = ORBextractor()
     monkeypatch.setenv("SE2GPU_ORB_SCORE", "sparse")
     sparse = ORBextractor()
     monkeypatch.delenv("SE2GPU_ORB_SCORE")
+    assert dense.score_kernel()[0] == "dense" and sparse.score_kernel()[0] == "sparse"
     rng = np.random.default_rng(9)
     half = synth.frame(1).copy(); half[:240] = 77
     for img in (synth.frame(4), rng.integers(0, 256, (480, 640)).astype(np.uint8), np.full((480, 640), 31, np.uint8), half):
@@ -184,3 +186,29 @@ def test_batch_sizes_not_a_multiple_of_eight(oracle, synth):
             assert np.array_equal(out[b][0], k) and np.array_equal(out[b][1], d), (B, b)
         ko, do = oracle.orb_extract(imgs[B - 1])
         assert np.array_equal(out[B - 1][0], ko) and np.array_equal(out[B - 1][1], do)
+
+
+def test_score_kernel_follows_the_candidate_density(oracle, synth):
+    """default (auto) mode: the first frame goes through the candidate kernel, which counts the pixels passing its compass
+    test; busy imagery (the benchmark texture: ~15 % candidates) switches to the dense kernel, quiet imagery back to the
+    candidate kernel - with identical features either way"""
+    from se2lam_amd.orb import ORBextractor
+    ex = ORBextractor()
+    busy = synth.frame(6)
+    quiet = (128 + (synth.frame(6).astype(np.int32) - 128) // 8).astype(np.uint8)
+    ko, do = oracle.orb_extract(busy)
+    kq, dq = oracle.orb_extract(quiet)
+    for _ in range(3):
+        k, d = ex(busy)
+        assert np.array_equal(k, ko) and np.array_equal(d, do)
+    kind, dens = ex.score_kernel()
+    assert kind == "dense" and 0.10 < dens < 0.30, (kind, dens)
+    for _ in range(40):                       # the dense kernel does not count: the next look comes after 32 batches
+        k, d = ex(quiet)
+        assert np.array_equal(k, kq) and np.array_equal(d, dq)
+    kind, dens = ex.score_kernel()
+    assert kind == "sparse" and dens < 0.10, (kind, dens)
+    for _ in range(3):                        # ... and the candidate kernel counts every time
+        k, d = ex(busy)
+        assert np.array_equal(k, ko) and np.array_equal(d, do)
+    assert ex.score_kernel()[0] == "dense"
