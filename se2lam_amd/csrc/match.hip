@@ -683,13 +683,22 @@ int check_overflow(se2gpu_matcher* h) {
     return SE2GPU_OK;
 }
 
-// the candidate kernels stage 16 B per target feature in LDS: up to kMaxFeat features = 128 KiB of dynamic LDS
-int cand_lds_attr() {
-    static bool done = false;
-    if (done) return SE2GPU_OK;
+// Dynamic LDS above 64 KiB has to be allowed per kernel AND per device: the candidate kernels stage 16 B per target
+// feature (up to kMaxFeat features = 128 KiB), the greedy passes keep their state and the staged candidate lists in
+// kResolveLds.
+constexpr size_t kResolveLds = 120 * 1024;   // of the CU's 160 KiB: one workgroup per pair and CU
+int lds_attributes() {
+    static std::mutex mu;
+    static bool done[64] = {};
+    int dev = 0;
+    SE2_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < 64 && done[dev]) return SE2GPU_OK;
     SE2_HIP(hipFuncSetAttribute((const void*)k_cand_window, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxFeat * 16));
     SE2_HIP(hipFuncSetAttribute((const void*)k_cand_projection, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxFeat * 16));
-    done = true;
+    SE2_HIP(hipFuncSetAttribute((const void*)k_resolve_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResolveLds));
+    SE2_HIP(hipFuncSetAttribute((const void*)k_resolve_projection, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kResolveLds));
+    if (dev >= 0 && dev < 64) done[dev] = true;
     return SE2GPU_OK;
 }
 
@@ -711,20 +720,15 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     if (init_prev)
         hipLaunchKernelGGL(k_init_prev, dim3((cap + 255) / 256, npairs), dim3(256), 0, st, d_kps, d_counts, cap, d_pair_a,
                            d_prev);
-    SE2_CHECK(cand_lds_attr());
+    SE2_CHECK(lds_attributes());
     const int qpb = npairs >= 32 ? kCandQueriesBatch : kCandQueriesSingle;
     hipLaunchKernelGGL(k_cand_window, dim3((npairs + 7) & ~7, (cap + qpb - 1) / qpb), dim3(256), (size_t)cap * 16, st, bd,
                        d_kps, d_desc, d_counts, cap, d_pair_a, d_pair_b, d_prev, h->sorted.p, h->n_grid.p, win,
                        level_offset, min_level, max_level, h->cand.p, h->ncand.p, npairs, qpb);
     const size_t fixed_lds = ((size_t)11 * ((cap + 3) & ~3) + 48) * sizeof(int);
-    constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: one workgroup per pair and CU
+    constexpr size_t kLdsBudget = kResolveLds;
     SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY,
                 "cap %d needs %zu B of LDS in the resolve pass (limit %zu)", cap, fixed_lds, kLdsBudget);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SE2_HIP(hipFuncSetAttribute((const void*)k_resolve_window, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        attr_set = true;
-    }
     const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));  // staged candidate entries
     const size_t lds = fixed_lds + (size_t)cand_lds * sizeof(int);
     const int resolve_threads = std::min(1024, std::max(64, (cap + 63) & ~63));
@@ -928,7 +932,7 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     hipLaunchKernelGGL(k_grid_order, dim3(1), dim3(256), 0, st, bd, d_kps, d_sc + 2, (const int*)nullptr, n, h->sorted.p,
                        h->n_grid.p);
     if (m) {
-        SE2_CHECK(cand_lds_attr());
+        SE2_CHECK(lds_attributes());
         const int qpb = kCandQueriesSingle;
         hipLaunchKernelGGL(k_cand_projection, dim3((m + qpb - 1) / qpb), dim3(256), (size_t)n * 16, st, bd, cam,
                            (const float*)(ds + o_pos), ds + o_mdesc, (const int*)(ds + o_oct), ds + o_skip, m, d_kps,
@@ -937,16 +941,11 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     }
     {
         const int chunk = 1024;
-        constexpr size_t kLdsBudget = 120 * 1024;  // of the CU's 160 KiB: a single workgroup
+        constexpr size_t kLdsBudget = kResolveLds;
         const size_t nE = ((size_t)n + 3) & ~(size_t)3;
         const size_t fixed_lds = (3 * nE + 6 * (size_t)chunk + 8) * sizeof(int);
         SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY, "%d key-frame features need %zu B of LDS", n, fixed_lds);
-        static bool attr_set = false;
-        if (!attr_set) {
-            SE2_HIP(hipFuncSetAttribute((const void*)k_resolve_projection, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kLdsBudget));
-            attr_set = true;
-        }
+        SE2_CHECK(lds_attributes());
         const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));
         hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(1024), fixed_lds + (size_t)cand_lds * sizeof(int), st, d_kps,
                            n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, (int*)(ds + o_m), d_sc, d_sc + 1);
