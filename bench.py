@@ -225,7 +225,7 @@ def main():
 def _orb_cpu_baseline(synth, nframes, seconds=10.0):
     """oracle extract + MatchByWindow on a bounded sample of the same synthetic sequence, 1 thread"""
     from oracle import oracle
-    imgs = synth.frames(min(nframes, 64))
+    imgs = synth.frames(min(nframes, 256))   # bounded by `seconds`, not by the number of frames
     t1 = time.perf_counter()
     nfr = 0
     prev = oracle.orb_extract(imgs[0])
