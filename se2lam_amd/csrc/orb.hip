@@ -350,6 +350,8 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     const uint32_t vA = pairmask(nvalid > 0, nvalid > 1), vB = pairmask(nvalid > 2, nvalid > 3);
     const short2v seven = {7, 7};
     uint32_t H3ppA = 0, H3ppB = 0, H3pA = 0, H3pB = 0, HcpA = 0, HcpB = 0, cpA = 0, cpB = 0;
+    // row of the decided output row yo = y - 1 inside its cell, kept incrementally (one modulo here instead of two per row)
+    int ymod = (((y0 - 2 - kEdge) % cellH) + cellH) % cellH;
     auto step = [&](auto phc, int y) {
         constexpr int PH = decltype(phc)::value;
         {   // row y+3 enters the window (slot of window row 6)
@@ -372,9 +374,8 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         const uint32_t H3B = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hcB, __builtin_bit_cast(short2v, cB)));
         const int yo = y - 1;  // row whose suppression can now be decided
         if (yo >= y0 && yo < yend && lane >= 1 && lane <= kScoreGroups && nvalid > 0) {
-            const int yr = yo - kEdge;
-            const uint32_t tT = (yr % cellH == 0) ? 0u : 0xffffffffu;                                      // row above in the cell?
-            const uint32_t tB = ((yr % cellH == cellH - 1) || yo == H - kEdge - 1) ? 0u : 0xffffffffu;    // row below?
+            const uint32_t tT = (ymod == 0) ? 0u : 0xffffffffu;                                            // row above in the cell?
+            const uint32_t tB = ((ymod == cellH - 1) || yo == H - kEdge - 1) ? 0u : 0xffffffffu;          // row below?
             const short2v mA = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(short2v, HcpA),
                                                                                      __builtin_bit_cast(short2v, H3ppA & tT)),
                                                          __builtin_bit_cast(short2v, H3A & tB));
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         }
         H3ppA = H3pA; H3ppB = H3pB;
         H3pA = H3A; H3pB = H3B; HcpA = HcA; HcpB = HcB; cpA = cA; cpB = cB;
+        ymod = (ymod + 1 == cellH) ? 0 : ymod + 1;
     };
     for (int y = y0 - 1; y <= yend; y += 7) {   // rows past yend only feed guarded code
         step(std::integral_constant<int, 0>{}, y);
