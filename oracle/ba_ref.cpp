@@ -62,6 +62,8 @@ struct ba_ref_stats {
     double chi2_hist[64];    // robust chi2 after each outer iteration
     double lambda_hist[64];
     int32_t trials_hist[64];
+    int32_t n_rho;           // gain ratio of every LM trial, in order (first 256): the margin of each accept / reject decision
+    double rho_log[256];
 };
 
 }  // extern "C"
@@ -548,6 +550,7 @@ int ba_ref_optimize(const ba_ref_problem* p, int iters, int mode, const volatile
             for (size_t i = 0; i < xl.size(); ++i) scale += xl[i] * (lambda * xl[i] + sys.bl[i]);
             scale += 1e-3;
             rho /= scale;
+            if (s.n_rho < 256) s.rho_log[s.n_rho++] = rho;
             if (rho > 0 && std::isfinite(tempChi)) {
                 double alpha = 1. - std::pow(2 * rho - 1, 3);
                 alpha = std::min(alpha, 2. / 3.);

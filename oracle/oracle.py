@@ -60,6 +60,7 @@ class BaStats(C.Structure):
         ("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
         ("chi2_init", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
         ("chi2_hist", C.c_double * 64), ("lambda_hist", C.c_double * 64), ("trials_hist", C.c_int32 * 64),
+        ("n_rho", C.c_int32), ("rho_log", C.c_double * 256),
     ]
 
 
@@ -136,7 +137,7 @@ def ba_optimize(g, iters=10, mode=0):
     stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated),
                  chi2_init=st.chi2_init, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
                  chi2_hist=list(st.chi2_hist[:n]), lambda_hist=list(st.lambda_hist[:n]),
-                 trials_hist=list(st.trials_hist[:n]))
+                 trials_hist=list(st.trials_hist[:n]), rho_log=list(st.rho_log[:st.n_rho]))
     return poses, lms, stats
 
 

@@ -1,0 +1,123 @@
+"""Checks that do NOT come from the oracle's restatement ("pin the oracle").
+
+Everything here is written against the *definitions* (the generator's projection model, the textbook bilinear /
+Gaussian formulas, scipy's trust-region least squares), never against oracle/*.cpp or the HIP kernels, so that a
+convention error shared by the restatement and the kernels cannot hide:
+
+* `BAProblemNumpy`   the robust cost  sum_e rho_huber(r_e' Omega_e r_e) + sum_o r_o' Omega_o r_o  of a synth.BAGraph as a
+                     plain numpy residual vector (projection = synth._project, the function that GENERATED the
+                     measurements), suitable for scipy.optimize.least_squares with a finite-difference Jacobian.
+* `bilinear_half_pixel`, `gaussian_float`   float references of cv::resize(INTER_LINEAR) and cv::GaussianBlur(7x7, 2).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from se2lam_amd import synth
+
+
+class BAProblemNumpy:
+    """g2o's cost for Map::loadLocalGraph's graph (src/Map.cpp:891-1053), from the definitions:
+    EdgeSE2XYZ error = project(pose, landmark) - uv with RobustKernelHuber(delta) on e' Omega e
+    (rho = s if s <= delta^2 else 2 delta sqrt(s) - delta^2), PreEdgeSE2 error = (R_i'(t_j - t_i) - z_xy, th_j - th_i - z_th)
+    without a robust kernel.  fun(x) returns a vector f with ||f||^2 = that cost: per observation the whitened residual
+    scaled by sqrt(rho(s)/s)."""
+
+    def __init__(self, g):
+        self.g = g
+        self.Rcb = g.Rbc.T
+        self.tcb = -self.Rcb @ g.tbc
+        self.free = np.nonzero(g.fixed == 0)[0]
+        self.npz = 3 * self.free.size
+        W = np.zeros((g.E, 2, 2))
+        W[:, 0, 0] = g.e_info[:, 0]
+        W[:, 0, 1] = W[:, 1, 0] = g.e_info[:, 1]
+        W[:, 1, 1] = g.e_info[:, 2]
+        self.U = np.linalg.cholesky(W).transpose(0, 2, 1)                       # Omega = U' U
+        self.Uo = np.linalg.cholesky(g.o_info.reshape(g.O, 3, 3)).transpose(0, 2, 1) if g.O else np.zeros((0, 3, 3))
+
+    def pack(self, poses, lms):
+        return np.concatenate([np.asarray(poses)[self.free].reshape(-1), np.asarray(lms).reshape(-1)])
+
+    def unpack(self, x):
+        poses = self.g.poses.copy()
+        poses[self.free] = x[:self.npz].reshape(-1, 3)
+        return poses, x[self.npz:].reshape(self.g.L, 3)
+
+    def fun(self, x):
+        g = self.g
+        poses, lms = self.unpack(x)
+        u, v, _, _ = synth._project(poses, lms, g.e_kf, g.e_lm, self.Rcb, self.tcb, g.fx, g.cx, g.cy)
+        r = np.stack([u - g.e_uv[:, 0], v - g.e_uv[:, 1]], 1)
+        wr = np.einsum("eij,ej->ei", self.U, r)
+        s = (wr * wr).sum(1)
+        d2 = g.huber ** 2
+        rho = np.where(s <= d2, s, 2 * np.sqrt(np.maximum(s, 1e-300)) * g.huber - d2)
+        k = np.sqrt(rho / np.maximum(s, 1e-300))
+        pi, pj = poses[g.o_i], poses[g.o_j]
+        c, sn = np.cos(pi[:, 2]), np.sin(pi[:, 2])
+        dx, dy = pj[:, 0] - pi[:, 0], pj[:, 1] - pi[:, 1]
+        e = np.stack([c * dx + sn * dy - g.o_meas[:, 0], -sn * dx + c * dy - g.o_meas[:, 1],
+                      pj[:, 2] - pi[:, 2] - g.o_meas[:, 2]], 1)          # no angle wrap: EdgeSE2XYZ.h:80
+        return np.concatenate([(wr * k[:, None]).reshape(-1), np.einsum("eij,ej->ei", self.Uo, e).reshape(-1)])
+
+    def cost(self, poses, lms):
+        f = self.fun(self.pack(poses, lms))
+        return float(f @ f)
+
+    def sparsity(self):
+        from scipy.sparse import coo_matrix
+        g = self.g
+        slot = -np.ones(g.P, int)
+        slot[self.free] = np.arange(self.free.size)
+        rows, cols = [], []
+        for k3 in range(3):
+            for rr in range(2):
+                a = slot[g.e_kf]
+                m = a >= 0
+                rows.append((2 * np.arange(g.E) + rr)[m]); cols.append(3 * a[m] + k3)
+                rows.append(2 * np.arange(g.E) + rr); cols.append(self.npz + 3 * g.e_lm + k3)
+            for rr in range(3):
+                for q in (g.o_i, g.o_j):
+                    a = slot[q]
+                    m = a >= 0
+                    rows.append((2 * g.E + 3 * np.arange(g.O) + rr)[m]); cols.append(3 * a[m] + k3)
+        rows = np.concatenate(rows); cols = np.concatenate(cols)
+        return coo_matrix((np.ones(rows.size, np.int8), (rows, cols)),
+                          shape=(2 * g.E + 3 * g.O, self.npz + 3 * g.L)).tocsr()
+
+    def solve(self, x0, max_nfev=200):
+        """scipy's trust-region reflective least squares on fun, finite-difference Jacobian (exact SVD steps for small
+        graphs, LSMR + sparsity pattern otherwise)."""
+        from scipy.optimize import least_squares
+        dense = x0.size <= 600
+        return least_squares(self.fun, x0, jac="3-point", jac_sparsity=None if dense else self.sparsity(), method="trf",
+                             x_scale="jac", ftol=1e-15, xtol=1e-15, gtol=1e-13, max_nfev=max_nfev,
+                             tr_solver="exact" if dense else "lsmr")
+
+
+def bilinear_half_pixel(src: np.ndarray, w: int, h: int) -> np.ndarray:
+    """Float bilinear resize with the half-pixel mapping  sx = (dx + 0.5) * (sw / w) - 0.5  and edge clamping - the
+    definition of cv::resize(..., INTER_LINEAR) (and of torch interpolate(align_corners=False)) - in float64."""
+    sh, sw = src.shape
+    s = src.astype(np.float64)
+    fx = (np.arange(w) + 0.5) * (sw / w) - 0.5
+    fy = (np.arange(h) + 0.5) * (sh / h) - 0.5
+    x0 = np.floor(fx).astype(int); y0 = np.floor(fy).astype(int)
+    ax = fx - x0; ay = fy - y0
+    x0c, x1c = np.clip(x0, 0, sw - 1), np.clip(x0 + 1, 0, sw - 1)
+    y0c, y1c = np.clip(y0, 0, sh - 1), np.clip(y0 + 1, 0, sh - 1)
+    top = s[y0c][:, x0c] * (1 - ax) + s[y0c][:, x1c] * ax
+    bot = s[y1c][:, x0c] * (1 - ax) + s[y1c][:, x1c] * ax
+    return top * (1 - ay)[:, None] + bot * ay[:, None]
+
+
+def gaussian_float(src: np.ndarray, ksize: int = 7, sigma: float = 2.0) -> np.ndarray:
+    """Float separable Gaussian (cv::getGaussianKernel: exp(-(i-c)^2 / 2 sigma^2), normalised) with BORDER_REFLECT_101."""
+    c = (ksize - 1) / 2
+    k = np.exp(-((np.arange(ksize) - c) ** 2) / (2 * sigma * sigma))
+    k /= k.sum()
+    r = ksize // 2
+    p = np.pad(src.astype(np.float64), r, mode="reflect")          # numpy 'reflect' == BORDER_REFLECT_101
+    tmp = sum(k[i] * p[:, i:i + src.shape[1]] for i in range(ksize))
+    return sum(k[i] * tmp[i:i + src.shape[0], :] for i in range(ksize))

@@ -221,3 +221,18 @@ def test_edge_information_oracle_vs_generator(oracle, synth):
     assert np.allclose(info[:, 0, 1], ref[:, 1], rtol=1e-7, atol=1e-12) and np.array_equal(info[:, 0, 1], info[:, 1, 0])
     ev = np.linalg.eigvalsh(info)
     assert (ev > 0).all() and (ev[:, 1] <= 1.0 / inp["sigma2"] * (1 + 1e-9)).all()
+
+
+def test_lm_reject_fixtures_have_wide_decision_margins(oracle, synth):
+    """The fixed starts of tests/test_ba_gpu.py::LM_REJECT_CASES really reject, with the frozen trial counts, and no
+    accept / reject decision is closer than |rho| = 0.2 to its boundary (CPU half of that test)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_ba_gpu", os.path.join(os.path.dirname(__file__), "test_ba_gpu.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for case, trials in m.LM_REJECT_CASES:
+        g = m._kidnapped(synth, *case)
+        _, _, st = oracle.ba_optimize(g, 10, 0)
+        assert st["trials_hist"] == trials, case
+        assert np.abs(st["rho_log"]).min() > 0.2, case
+        assert st["trials"] == sum(trials) and st["terminated"] == (trials == [10])
