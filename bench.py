@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 ITERS_PER_CALL = 10    # Config::LOCAL_ITER of the synthetic setup
+MIN_TIMED_S = 0.1      # floor of the timed region
 
 
 def parse():
@@ -114,21 +115,34 @@ def main():
         return trials
 
     run_steps(args.warmup)
+    # The timed region is K steps, but never less than MIN_TIMED_S of device work: 20 steps of this graph are 4 ms, two
+    # optimize() calls - too short a sample to report from.  K is raised to the next multiple of
+    # itself that fills the floor (every rank computes the same K from the all-reduced time of a first, untimed block).
+    steps = args.steps
     sync_all()
     t0 = time.perf_counter()
-    trials = run_steps(args.steps)
+    run_steps(steps)
+    sync_all()
+    probe = time.perf_counter() - t0
+    if dist is not None:
+        probe = dist.allreduce_max(probe)
+    if probe < MIN_TIMED_S:
+        steps = args.steps * int(np.ceil(1.2 * MIN_TIMED_S / max(probe, 1e-6)))
+    sync_all()
+    t0 = time.perf_counter()
+    trials = run_steps(steps)
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
         dt = dist.allreduce_max(dt)
-    iters_per_s = args.steps / dt
+    iters_per_s = steps / dt
     chi2_final = opt.stats["chi2_final"]
 
     # ---------------- per-kernel durations with HIP events on the kernels' stream ----------------
     # Same K steps again with an event pair around every launch (serialises the stream, so it is a
     # separate pass and not the timed region above).
     opt.profile(True)
-    run_steps(min(args.steps, 50))
+    run_steps(min(steps, 50))
     sync_all()
     prof = opt.profile_report()
     opt.profile(False)
@@ -162,6 +176,9 @@ def main():
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, collected with
             # tools/pmc_summarize.py on this workload; FETCH_SIZE x2 correction) - null when the file has no entry
             "traffic": (traffic.get(dom, {}).get("traffic_bytes") if world == 1 else None),
+            "traffic_commit": traffic.get("_meta", {}).get("commit"),
+            "traffic_source_sha": traffic.get("_meta", {}).get("source_sha"),
+            "traffic_stale": bool(traffic.get("_meta", {}).get("stale", False)),
             "algorithmic_bytes_per_launch": B_dom, "avg_launch_us": kern[dom]["avg_us"],
             "note": ("the dominant kernel is the dense pose solve: a 600-column dependency chain, bound by FP64 / LDS "
                      "latency and inter-workgroup hand-offs, not by bandwidth (DESIGN.md 4.1.1)"
@@ -186,29 +203,19 @@ def main():
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle
-        oracle.lib()
-        t1 = time.perf_counter()
-        n_it = 0
-        while time.perf_counter() - t1 < args.cpu_seconds:
-            _, _, st = oracle.ba_optimize(g_full, ITERS_PER_CALL, 0)
-            n_it += st["iterations"]
-        cdt = time.perf_counter() - t1
-        cpu = {"value": n_it / cdt, "unit": "iters/s", "cores": 1, "kind": "port",
-               "sample": f"{n_it} LM iterations ({n_it // ITERS_PER_CALL} x optimize(10)) of the same "
-                         f"{g_full.P} KF / {g_full.L} landmark / {g_full.E} edge graph, oracle/ba_ref.cpp, 1 thread",
-               "host": _host_desc()}
+        cpu = _ba_cpu_baseline(g_full, args.cpu_seconds)
 
     if rank == 0:
         out = {
             "metric": "BA GN-iters/s (200 KF, 20k pts)", "value": iters_per_s, "unit": "iters/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / steps, "timed_s": dt,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"globalBA-window {g_full.P} KF / {g_full.L} landmarks / {g_full.E} EdgeSE2XYZ "
                                    f"+ {g_full.O} PreEdgeSE2, LM optimize(10) (config 4 formulation, SURVEY D3)",
                        "parallelism": f"landmark-sharded x{world}, RCCL all-reduce of [S|b]" if world > 1 else "single GPU",
-                       "lm_trials_per_step": trials / args.steps, "chi2_final": chi2_final},
+                       "lm_trials_per_step": trials / steps, "chi2_final": chi2_final},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "orb": orb_obj,
@@ -222,22 +229,103 @@ def main():
         dist.close()
 
 
+def _ba_cpu_baseline(g, seconds):
+    """The CPU path timed on this box's host cores: (i) the 1-thread port (the reference's LocalMapper is
+    one thread, g2o is built without OpenMP) and (ii) the all-core variant oracle/ba_ref_mt.cpp (OpenMP over landmarks /
+    pose rows, LAPACK dpotrf for the pose solve when scipy's is reachable) in the best of a few thread counts.  The
+    headline `value` is the faster of the two; both are reported."""
+    from oracle import oracle
+    oracle.lib()
+    what = f"{g.P} KF / {g.L} landmark / {g.E} edge graph"
+
+    def timed(fn, budget):
+        t1 = time.perf_counter()
+        n_it = 0
+        while True:
+            _, _, st = fn()
+            n_it += st["iterations"]
+            if time.perf_counter() - t1 >= budget:
+                break
+        return n_it / (time.perf_counter() - t1), n_it
+
+    v1, n1 = timed(lambda: oracle.ba_optimize(g, ITERS_PER_CALL, 0), 0.4 * seconds)
+    single = {"value": v1, "unit": "iters/s", "cores": 1, "kind": "port",
+              "sample": f"{n1} LM iterations ({n1 // ITERS_PER_CALL} x optimize(10)) of the same {what}, "
+                        f"oracle/ba_ref.cpp, 1 thread"}
+    nproc = os.cpu_count() or 1
+    best = None
+    for thr in sorted({nproc, max(1, nproc // 2), min(nproc, 64), min(nproc, 16)}, reverse=True):
+        for lap in (True, False):
+            try:
+                oracle.ba_optimize_mt(g, 2, thr, lap)                       # warm the thread pools
+                v, _ = timed(lambda: oracle.ba_optimize_mt(g, ITERS_PER_CALL, thr, lap), 0.02 * seconds)
+            except Exception:
+                continue
+            if best is None or v > best[0]:
+                best = (v, thr, lap)
+    out = dict(single)
+    if best is not None:
+        v, thr, lap = best
+        vm, nm = timed(lambda: oracle.ba_optimize_mt(g, ITERS_PER_CALL, thr, lap), 0.3 * seconds)
+        multi = {"value": vm, "unit": "iters/s", "cores": thr, "kind": "port",
+                 "sample": f"{nm} LM iterations of the same {what}, oracle/ba_ref_mt.cpp: OpenMP x{thr} over landmarks / "
+                           f"pose rows, pose solve by {'LAPACK dpotrf (scipy OpenBLAS)' if lap else 'scalar LL^T'}; "
+                           f"best of thread counts up to {nproc}"}
+        if vm > v1:
+            out = dict(multi)
+        out["all_cores"] = multi
+    out["single_thread"] = single
+    out["host"] = _host_desc()
+    return out
+
+
 def _orb_cpu_baseline(synth, nframes, seconds=10.0):
-    """oracle extract + MatchByWindow on a bounded sample of the same synthetic sequence, 1 thread"""
+    """oracle extract + MatchByWindow on a bounded sample of the same synthetic sequence: 1 thread (the reference's Track
+    thread; cv::FAST is serial) and frame-parallel over all host cores (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     imgs = synth.frames(min(nframes, 256))   # bounded by `seconds`, not by the number of frames
     t1 = time.perf_counter()
     nfr = 0
     prev = oracle.orb_extract(imgs[0])
-    while time.perf_counter() - t1 < seconds and nfr < len(imgs) - 1:
+    while time.perf_counter() - t1 < 0.5 * seconds and nfr < len(imgs) - 1:
         cur = oracle.orb_extract(imgs[nfr + 1])
         oracle.match_window(prev[0], prev[1], cur[0], cur[1])
         prev = cur
         nfr += 1
     cdt = time.perf_counter() - t1
-    return {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
-                      f"oracle/match_ref.cpp MatchByWindow, 1 thread", "host": _host_desc()}
+    single = {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+              "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
+                        f"oracle/match_ref.cpp MatchByWindow, 1 thread"}
+    nproc = os.cpu_count() or 1
+    thr = min(nproc, len(imgs))
+
+    def one(t):
+        a = oracle.orb_extract(imgs[t])
+        b = oracle.orb_extract(imgs[(t + 1) % len(imgs)])     # a frame-parallel worker extracts both frames of its pair
+        oracle.match_window(a[0], a[1], b[0], b[1])
+        return 1
+
+    out = dict(single)
+    try:
+        with ThreadPoolExecutor(thr) as ex:
+            list(ex.map(one, range(min(thr, 8))))              # warm-up
+            t1 = time.perf_counter()
+            done = 0
+            while time.perf_counter() - t1 < 0.4 * seconds:
+                done += sum(ex.map(one, range(len(imgs))))
+            cdt = time.perf_counter() - t1
+        multi = {"value": done / cdt, "unit": "frames/s", "cores": thr, "kind": "port",
+                 "sample": f"{done} frame pairs, frame-parallel over {thr} threads (each worker: 2 x extract + MatchByWindow "
+                           f"= one pair; counted as one frame)"}
+        if multi["value"] > single["value"]:
+            out = dict(multi)
+        out["all_cores"] = multi
+    except Exception as exc:   # pragma: no cover
+        out["all_cores_error"] = repr(exc)
+    out["single_thread"] = single
+    out["host"] = _host_desc()
+    return out
 
 
 class _stdout_to_stderr:
@@ -256,12 +344,32 @@ class _stdout_to_stderr:
         os.close(self._saved)
 
 
+def source_sha():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, *.inc): what a PMC capture is valid for.  The GPU box has no
+    .git, so the capture is stamped with this instead of (and next to) the commit hash."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "se2lam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic():
+    """profiles/pmc_traffic.json (tools/pmc_summarize.py) - only if it was captured from THESE kernel sources; a capture
+    of older kernels is a stale constant and is dropped (roofline.traffic = null, traffic_stale = its stamp)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)
+            t = json.load(f)
     except (OSError, ValueError):
         return {}
+    meta = t.get("_meta", {})
+    if meta.get("source_sha") != source_sha():
+        return {"_meta": dict(meta, stale=True)}
+    return t
 
 
 def _host_desc():

@@ -343,6 +343,16 @@ int se2gpu_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int se2gpu_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int se2gpu_device_synchronize(void);
 int se2gpu_set_device(int ordinal);
+/* Streaming helpers (the camera thread's upload path: pinned staging, asynchronous copies on a stream of its own,
+ * cross-stream ordering through the stop event of a timer): what bench.py's `orb.streaming` leg is built from. */
+int se2gpu_host_alloc(void** host_ptr, size_t bytes);   /* pinned */
+int se2gpu_host_free(void* host_ptr);
+int se2gpu_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* hip_stream);
+int se2gpu_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* hip_stream);
+int se2gpu_stream_create(void** hip_stream_out);
+int se2gpu_stream_destroy(void* hip_stream);
+int se2gpu_stream_synchronize(void* hip_stream);
+int se2gpu_timer_stream_wait(se2gpu_timer* t, void* hip_stream);  /* hip_stream waits for the timer's stop event */
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,51 @@ def ba_optimize(g, iters=10, mode=0):
     return poses, lms, stats
 
 
+def _lapack_pointers():
+    """(dpotrf, dpotrs) function pointers of scipy's LAPACK (OpenBLAS, threaded) or (None, None)."""
+    try:
+        import scipy.linalg.cython_lapack as cl
+        C.pythonapi.PyCapsule_GetPointer.restype = C.c_void_p
+        C.pythonapi.PyCapsule_GetPointer.argtypes = [C.py_object, C.c_char_p]
+        C.pythonapi.PyCapsule_GetName.restype = C.c_char_p
+        C.pythonapi.PyCapsule_GetName.argtypes = [C.py_object]
+        out = []
+        for name in ("dpotrf", "dpotrs"):
+            cap = cl.__pyx_capi__[name]
+            out.append(C.pythonapi.PyCapsule_GetPointer(cap, C.pythonapi.PyCapsule_GetName(cap)))
+        return tuple(out)
+    except Exception:
+        return (None, None)
+
+
+def ba_mt_threads() -> int:
+    f = lib().ba_ref_mt_threads
+    f.restype = C.c_int
+    return int(f())
+
+
+def ba_optimize_mt(g, iters=10, threads=0, lapack=True):
+    """ALL-CORE CPU baseline (oracle/ba_ref_mt.cpp: OpenMP over landmarks / pose rows + LAPACK dpotrf for the pose
+    solve) -> (poses, lms, stats); same algorithm and LM policy as ba_optimize."""
+    pr, k = ba_problem(g)
+    poses = np.zeros((g.P, 3))
+    lms = np.zeros((g.L, 3))
+    st = BaStats()
+    f = lib().ba_ref_optimize_mt
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(BaProblem), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                  C.POINTER(C.c_double), C.POINTER(BaStats)]
+    pf, ps = _lapack_pointers() if lapack else (None, None)
+    rc = f(C.byref(pr), iters, threads, pf, ps, _p(poses, C.c_double), _p(lms, C.c_double), C.byref(st))
+    assert rc == 0
+    n = min(st.iterations, 64)
+    stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated),
+                 chi2_init=st.chi2_init, chi2_final=st.chi2_final, lambda_final=st.lambda_final,
+                 chi2_hist=list(st.chi2_hist[:n]), lambda_hist=list(st.lambda_hist[:n]),
+                 trials_hist=list(st.trials_hist[:n]), rho_log=list(st.rho_log[:st.n_rho]), lapack=pf is not None)
+    return poses, lms, stats
+
+
 def ba_reduced_system(g, lam, poses=None, lms=None):
     """-> dict(S (3P,3P), bs, bp, bl, Hll (L,3,3)) at the given state and damping."""
     pr, k = ba_problem(g)

@@ -146,6 +146,14 @@ SYMBOLS = {
     "se2gpu_free": (_I, [_VP]),
     "se2gpu_memcpy_h2d": (_I, [_VP, _VP, _SZ]),
     "se2gpu_memcpy_d2h": (_I, [_VP, _VP, _SZ]),
+    "se2gpu_host_alloc": (_I, [C.POINTER(_VP), _SZ]),
+    "se2gpu_host_free": (_I, [_VP]),
+    "se2gpu_memcpy_h2d_async": (_I, [_VP, _VP, _SZ, _VP]),
+    "se2gpu_memcpy_d2h_async": (_I, [_VP, _VP, _SZ, _VP]),
+    "se2gpu_stream_create": (_I, [C.POINTER(_VP)]),
+    "se2gpu_stream_destroy": (_I, [_VP]),
+    "se2gpu_stream_synchronize": (_I, [_VP]),
+    "se2gpu_timer_stream_wait": (_I, [_VP, _VP]),
     "se2gpu_device_synchronize": (_I, []),
     "se2gpu_set_device": (_I, [_I]),
 }
@@ -222,6 +230,42 @@ class DeviceArray:
             pass
 
 
+class PinnedArray:
+    """Pinned host allocation (se2gpu_host_alloc) viewed as a numpy array; for the streaming bench."""
+
+    def __init__(self, shape, dtype):
+        self.ptr = C.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        check(lib().se2gpu_host_alloc(C.byref(self.ptr), n))
+        buf = (C.c_uint8 * n).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.array = None
+                lib().se2gpu_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+class Stream:
+    def __init__(self):
+        self.h = C.c_void_p()
+        check(lib().se2gpu_stream_create(C.byref(self.h)))
+
+    def sync(self):
+        check(lib().se2gpu_stream_synchronize(self.h))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().se2gpu_stream_destroy(self.h)
+        except Exception:
+            pass
+
+
 class Timer:
     def __init__(self):
         self.h = C.c_void_p()
@@ -232,6 +276,10 @@ class Timer:
 
     def stop(self, stream):
         check(lib().se2gpu_timer_stop(self.h, stream))
+
+    def make_wait(self, stream):
+        """`stream` waits for this timer's stop event (cross-stream ordering without a host sync)"""
+        check(lib().se2gpu_timer_stream_wait(self.h, stream))
 
     def elapsed_ms(self) -> float:
         ms = C.c_float()

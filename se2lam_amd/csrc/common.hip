@@ -111,6 +111,45 @@ int se2gpu_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     SE2_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return SE2GPU_OK;
 }
+int se2gpu_host_alloc(void** p, size_t bytes) {
+    SE2_REQUIRE(p, SE2GPU_ERR_INVALID, "host_alloc: p is NULL");
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible");
+    SE2_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+    return SE2GPU_OK;
+}
+int se2gpu_host_free(void* p) {
+    if (p) SE2_HIP(hipHostFree(p));
+    return SE2GPU_OK;
+}
+int se2gpu_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* s) {
+    SE2_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+    return SE2GPU_OK;
+}
+int se2gpu_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* s) {
+    SE2_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+    return SE2GPU_OK;
+}
+int se2gpu_stream_create(void** out) {
+    SE2_REQUIRE(out, SE2GPU_ERR_INVALID, "stream_create: out is NULL");
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device visible");
+    hipStream_t s = nullptr;
+    SE2_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void*)s;
+    return SE2GPU_OK;
+}
+int se2gpu_stream_destroy(void* s) {
+    if (s) SE2_HIP(hipStreamDestroy((hipStream_t)s));
+    return SE2GPU_OK;
+}
+int se2gpu_stream_synchronize(void* s) {
+    SE2_HIP(hipStreamSynchronize((hipStream_t)s));
+    return SE2GPU_OK;
+}
+int se2gpu_timer_stream_wait(se2gpu_timer* t, void* s) {
+    SE2_REQUIRE(t, SE2GPU_ERR_INVALID, "timer is NULL");
+    SE2_HIP(hipStreamWaitEvent((hipStream_t)s, t->e1, 0));
+    return SE2GPU_OK;
+}
 int se2gpu_device_synchronize(void) {
     SE2_HIP(hipDeviceSynchronize());
     return SE2GPU_OK;

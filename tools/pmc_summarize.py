@@ -15,7 +15,10 @@ import collections
 import csv
 import json
 import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def load(path):
@@ -32,6 +35,11 @@ def main():
     out = {"_meta": {"unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
                      "command": "bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 (BA 200 KF / 20k landmarks)",
                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes"}}
+    # what the capture is valid for: the kernel sources it ran (bench.py nulls `traffic` when they have changed since) and
+    # the commit the caller says it is at (the GPU box has no .git: pass GRAFT_COMMIT=$(git rev-parse --short HEAD))
+    import bench
+    out["_meta"]["source_sha"] = bench.source_sha()
+    out["_meta"]["commit"] = os.environ.get("GRAFT_COMMIT") or None
     for k in sorted(F, key=lambda k: -sum(F[k])):
         f = sum(F[k]) / len(F[k])
         w = sum(W.get(k, [0.0])) / max(len(W.get(k, [0.0])), 1)
