@@ -35,6 +35,23 @@ ITERS_PER_CALL = 10    # Config::LOCAL_ITER of the synthetic setup (SURVEY.md §
 MIN_TIMED_S = 0.1      # floor of the timed region
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line): a hang is then attributable to a section"""
+    print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """cores this process may run on (affinity mask, not the machine's count: a cgroup-limited box oversubscribed with
+    spinning OpenMP threads is slower than one thread)"""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +109,7 @@ def main():
             dist.barrier()
             capi.check(capi.lib().se2gpu_device_synchronize())
 
+    log(f"rank {rank}/{world}: building the BA graph")
     # ---------------- workload: BA graph resident in HBM ----------------
     g_full = synth.ba_graph(args.kf, args.landmarks)
     g = g_full.shard(rank, world)
@@ -114,6 +132,7 @@ def main():
             done += it
         return trials
 
+    log("BA: warm-up")
     run_steps(args.warmup)
     # The timed region is K steps, but never less than MIN_TIMED_S of device work: 20 steps of this graph are 4 ms, two
     # optimize() calls - too short a sample to report from.  K is raised to the next multiple of
@@ -138,6 +157,7 @@ def main():
     iters_per_s = steps / dt
     chi2_final = opt.stats["chi2_final"]
 
+    log(f"BA: {iters_per_s:.1f} it/s over {steps} steps; per-kernel pass")
     # ---------------- per-kernel durations with HIP events on the kernels' stream ----------------
     # Same K steps again with an event pair around every launch (serialises the stream, so it is a
     # separate pass and not the timed region above).
@@ -188,6 +208,7 @@ def main():
             "kernels_us": {k: round(v["avg_us"], 3) for k, v in kern.items()},
         }
 
+    log("ORB leg")
     # ---------------- ORB leg (frames/s) ----------------
     orb_obj = None
     if not args.no_orb:
@@ -197,13 +218,16 @@ def main():
                                     traffic=traffic if args.orb_batch == 256 else {})
         except ImportError:
             orb_obj = None
+        log("ORB leg done; CPU baselines")
         if orb_obj is not None and rank == 0 and world == 1 and not args.no_cpu_baseline:
             orb_obj["cpu_baseline"] = _orb_cpu_baseline(synth, args.orb_batch)
 
     # ---------------- CPU baseline (rank 0, N=1 only): the oracle on the host cores ----------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("BA CPU baseline")
         cpu = _ba_cpu_baseline(g_full, args.cpu_seconds)
+        log("done")
 
     if rank == 0:
         out = {
@@ -252,28 +276,13 @@ def _ba_cpu_baseline(g, seconds):
     single = {"value": v1, "unit": "iters/s", "cores": 1, "kind": "port",
               "sample": f"{n1} LM iterations ({n1 // ITERS_PER_CALL} x optimize(10)) of the same {what}, "
                         f"oracle/ba_ref.cpp, 1 thread"}
-    nproc = os.cpu_count() or 1
-    best = None
-    for thr in sorted({nproc, max(1, nproc // 2), min(nproc, 64), min(nproc, 16)}, reverse=True):
-        for lap in (True, False):
-            try:
-                oracle.ba_optimize_mt(g, 2, thr, lap)                       # warm the thread pools
-                v, _ = timed(lambda: oracle.ba_optimize_mt(g, ITERS_PER_CALL, thr, lap), 0.02 * seconds)
-            except Exception:
-                continue
-            if best is None or v > best[0]:
-                best = (v, thr, lap)
     out = dict(single)
-    if best is not None:
-        v, thr, lap = best
-        vm, nm = timed(lambda: oracle.ba_optimize_mt(g, ITERS_PER_CALL, thr, lap), 0.3 * seconds)
-        multi = {"value": vm, "unit": "iters/s", "cores": thr, "kind": "port",
-                 "sample": f"{nm} LM iterations of the same {what}, oracle/ba_ref_mt.cpp: OpenMP x{thr} over landmarks / "
-                           f"pose rows, pose solve by {'LAPACK dpotrf (scipy OpenBLAS)' if lap else 'scalar LL^T'}; "
-                           f"best of thread counts up to {nproc}"}
-        if vm > v1:
+    multi = _in_subprocess("ba", {"P": g.P, "L": g.L, "seconds": 0.5 * seconds}, timeout=max(60.0, 6 * seconds))
+    if "value" in multi:
+        multi["sample"] = multi["sample"].replace("GRAPH", what)
+        if multi["value"] > v1:
             out = dict(multi)
-        out["all_cores"] = multi
+    out["all_cores"] = multi
     out["single_thread"] = single
     out["host"] = _host_desc()
     return out
@@ -282,7 +291,6 @@ def _ba_cpu_baseline(g, seconds):
 def _orb_cpu_baseline(synth, nframes, seconds=10.0):
     """oracle extract + MatchByWindow on a bounded sample of the same synthetic sequence: 1 thread (the reference's Track
     thread; cv::FAST is serial) and frame-parallel over all host cores (ctypes releases the GIL)."""
-    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
     imgs = synth.frames(min(nframes, 256))   # bounded by `seconds`, not by the number of frames
     t1 = time.perf_counter()
@@ -297,35 +305,86 @@ def _orb_cpu_baseline(synth, nframes, seconds=10.0):
     single = {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
               "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
                         f"oracle/match_ref.cpp MatchByWindow, 1 thread"}
-    nproc = os.cpu_count() or 1
-    thr = min(nproc, len(imgs))
-
-    def one(t):
-        a = oracle.orb_extract(imgs[t])
-        b = oracle.orb_extract(imgs[(t + 1) % len(imgs)])     # a frame-parallel worker extracts both frames of its pair
-        oracle.match_window(a[0], a[1], b[0], b[1])
-        return 1
-
     out = dict(single)
+    multi = _in_subprocess("orb", {"nframes": len(imgs), "seconds": 0.4 * seconds}, timeout=max(60.0, 6 * seconds))
+    if "value" in multi and multi["value"] > single["value"]:
+        out = dict(multi)
+    out["all_cores"] = multi
+    out["single_thread"] = single
+    out["host"] = _host_desc()
+    return out
+
+
+def _in_subprocess(which, cfg, timeout):
+    """The all-core CPU legs run in a child process with a hard timeout: hundreds of OpenMP / OpenBLAS threads on a
+    box whose cgroup grants fewer cores can take minutes, and a C call cannot be interrupted from Python."""
+    import subprocess
+    env = dict(os.environ, OMP_WAIT_POLICY="passive", OMP_PROC_BIND="false")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", which, json.dumps(cfg)]
     try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
+        lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child rc {r.returncode}: {r.stderr.decode(errors='replace')[-300:]}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"all-core leg did not finish within {timeout:.0f} s (killed)"}
+
+
+def _cpu_child(which, cfg):
+    from oracle import oracle
+    from se2lam_amd import synth
+    oracle.lib()
+    ncore = host_cores()
+    if which == "ba":
+        g = synth.ba_graph(cfg["P"], cfg["L"])
+        seconds = cfg["seconds"]
+
+        def timed(fn, budget):
+            t1 = time.perf_counter()
+            n_it = 0
+            while True:
+                _, _, st = fn()
+                n_it += st["iterations"]
+                if time.perf_counter() - t1 >= budget:
+                    break
+            return n_it / (time.perf_counter() - t1), n_it
+
+        best = None
+        for thr in sorted({ncore, max(1, ncore // 2), min(ncore, 64), min(ncore, 16)}, reverse=True):
+            for lap in (True, False):
+                oracle.ba_optimize_mt(g, 2, thr, lap)                       # warm the thread pools
+                v, _ = timed(lambda: oracle.ba_optimize_mt(g, ITERS_PER_CALL, thr, lap), 0.05 * seconds)
+                if best is None or v > best[0]:
+                    best = (v, thr, lap)
+        v, thr, lap = best
+        vm, nm = timed(lambda: oracle.ba_optimize_mt(g, ITERS_PER_CALL, thr, lap), 0.6 * seconds)
+        print(json.dumps({"value": vm, "unit": "iters/s", "cores": thr, "kind": "port",
+                          "sample": f"{nm} LM iterations of the same GRAPH, oracle/ba_ref_mt.cpp: OpenMP x{thr} over "
+                                    f"landmarks / pose rows, pose solve by "
+                                    f"{'LAPACK dpotrf (scipy OpenBLAS)' if lap else 'scalar LL^T'}; best of thread counts "
+                                    f"up to {ncore} usable cores"}), flush=True)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        imgs = synth.frames(cfg["nframes"])
+        thr = min(ncore, len(imgs))
+
+        def one(t):
+            a = oracle.orb_extract(imgs[t])
+            b = oracle.orb_extract(imgs[(t + 1) % len(imgs)])     # a frame-parallel worker extracts both frames of its pair
+            oracle.match_window(a[0], a[1], b[0], b[1])
+            return 1
+
         with ThreadPoolExecutor(thr) as ex:
             list(ex.map(one, range(min(thr, 8))))              # warm-up
             t1 = time.perf_counter()
             done = 0
-            while time.perf_counter() - t1 < 0.4 * seconds:
+            while time.perf_counter() - t1 < cfg["seconds"]:
                 done += sum(ex.map(one, range(len(imgs))))
             cdt = time.perf_counter() - t1
-        multi = {"value": done / cdt, "unit": "frames/s", "cores": thr, "kind": "port",
-                 "sample": f"{done} frame pairs, frame-parallel over {thr} threads (each worker: 2 x extract + MatchByWindow "
-                           f"= one pair; counted as one frame)"}
-        if multi["value"] > single["value"]:
-            out = dict(multi)
-        out["all_cores"] = multi
-    except Exception as exc:   # pragma: no cover
-        out["all_cores_error"] = repr(exc)
-    out["single_thread"] = single
-    out["host"] = _host_desc()
-    return out
+        print(json.dumps({"value": done / cdt, "unit": "frames/s", "cores": thr, "kind": "port",
+                          "sample": f"{done} frame pairs, frame-parallel over {thr} threads (each worker: 2 x extract + "
+                                    f"MatchByWindow = one pair; counted as one frame)"}), flush=True)
 
 
 class _stdout_to_stderr:
@@ -382,8 +441,11 @@ def _host_desc():
                     break
     except OSError:
         pass
-    return {"nproc": os.cpu_count(), "cpu": model}
+    return {"nproc": os.cpu_count(), "usable_cores": host_cores(), "cpu": model}
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-child":
+        _cpu_child(sys.argv[2], json.loads(sys.argv[3]))
+    else:
+        main()

@@ -97,6 +97,8 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
                 "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,
                 "whole_step_frac": (B_ORB + B_MATCH) * fps / world / 1e9 / HBM_PEAK_GBS,
                 "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()}}
+    import sys
+    print(f"[orb_bench] resident {fps:.0f} frames/s; streaming leg", file=sys.stderr, flush=True)
     streaming = None
     try:
         streaming = run_streaming(rank, world, B, steps, sync_all, dist, ex, mt, cap)
