@@ -204,6 +204,13 @@ int se2gpu_ba_reset_estimates(se2gpu_ba* h);
 /* optimize(iters); stop_flag mirrors setForceStopFlag(bool*) (LocalMapper.cpp:246), may be NULL. */
 int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
                        se2gpu_ba_stats* stats);
+/* optimize(iters) of `count` independent windows at once - one initialised handle per window, each on its own stream.
+ * The Levenberg-Marquardt controller of every window runs on the device, so all windows are enqueued before the first
+ * wait and the GPU works on them concurrently (a 50-KF local window occupies a few per cent of an MI355X).  This is the
+ * throughput form for a mapper that keeps several local windows (or several robots' maps) in flight; results are
+ * identical to calling se2gpu_ba_optimize on every handle in turn.  stats: NULL or `count` entries. */
+int se2gpu_ba_optimize_batch(se2gpu_ba** handles, int count, int iters, int mode, const volatile uint8_t* stop_flag,
+                             se2gpu_ba_stats* stats);
 int se2gpu_ba_get_se2(se2gpu_ba* h, int id, double xyt[3]);   /* estimateVertexSE2   */
 int se2gpu_ba_get_xyz(se2gpu_ba* h, int id, double xyz[3]);   /* estimateVertexSBAXYZ */
 int se2gpu_ba_get_all(se2gpu_ba* h, double* poses /*P*3, in pose-add order*/, double* lms /*L*3*/);

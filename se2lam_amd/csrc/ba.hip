@@ -46,6 +46,21 @@ struct CamDev {
     double huber;
 };
 
+// Levenberg-Marquardt controller state, resident on the device: every kernel of an LM trial reads it (which buffer holds
+// the estimate, the damping, whether this trial is a retry on the same linearisation, whether the run is over) and the
+// last kernel of the trial (k_finalize / k_lm_decide) advances it with g2o's policy.  The host only enqueues trial
+// "slots" and reads the block back once per optimize() call - no host round trip between trials.
+struct BaCtl {
+    double lambda, ni, current_chi, rho;
+    double chi2_init, chi2_final;
+    int it, qmax, trials, iters;
+    int done, terminated, stopped, retry;
+    int sel;          // 0: the estimate lives in the "a" buffers (trial state in "b"), 1: the other way round
+    int mode, error, pad;
+    double chi2_hist[64], lambda_hist[64];
+    int trials_hist[64];
+};
+
 __host__ __device__ inline double normalize_theta(double theta) {
     if (theta >= -kPi && theta < kPi) return theta;
     double multiplier = floor(theta / (2 * kPi));
@@ -148,7 +163,14 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
                                                        double* __restrict__ Hpp_e, double* __restrict__ bp_e,
                                                        double* __restrict__ Hll, double* __restrict__ bl, double lambda,
                                                        double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ Y, double* __restrict__ Dg) {
+                                                       double* __restrict__ Y, double* __restrict__ Dg,
+                                                       const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                       const double* __restrict__ lms_b) {
+    if (ctl) {   // device-side LM: nothing to do on a retry (same linearisation) or after the run has ended
+        if (ctl->done | ctl->retry) return;
+        if (ctl->sel) { poses = poses_b; lms = lms_b; }
+        lambda = ctl->lambda;
+    }
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -384,7 +406,12 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const
                                                       const double* __restrict__ Hpp_e,
                                                       const double* __restrict__ bp_e, double* __restrict__ Dinv,
                                                       double* __restrict__ z, double* __restrict__ Y,
-                                                      double* __restrict__ Dg) {
+                                                      double* __restrict__ Dg, const BaCtl* __restrict__ ctl,
+                                                      int force) {
+    if (ctl) {   // needed for the first trial of iteration 0 (lambda_0 comes after the linearisation) and for retries
+        if (ctl->done || !(force | ctl->retry)) return;
+        lambda = ctl->lambda;
+    }
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     if (l >= L) return;
@@ -464,7 +491,13 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                                                      const int* __restrict__ podo_item, const int* __restrict__ o_i,
                                                      const int* __restrict__ o_j, const double* __restrict__ o_meas,
                                                      const double* __restrict__ o_info, const double* __restrict__ poses,
-                                                     double* __restrict__ S, double* __restrict__ bp) {
+                                                     double* __restrict__ S, double* __restrict__ bp,
+                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b) {
+    if (ctl) {
+        if (ctl->done) return;
+        if (ctl->sel) poses = poses_b;
+        lambda = ctl->lambda;
+    }
     const int n = 3 * P;
     __shared__ double part[kGrpPerWG][9];
     __shared__ double dpart[kBlock / 64][12];
@@ -694,7 +727,8 @@ __device__ inline double fast_rsqrt(double d) {  // v_rsq_f64 + 2 Newton steps
 //     The loop has no branches (one basic block): columns past n are replaced by a decoupled block.
 // L(k,k) itself is never read again and is not written (so no workgroup writes what another one reads).
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, double* __restrict__ R, int ld, int n, int nt,
-                                                    int k, double* __restrict__ fail) {
+                                                    int k, double* __restrict__ fail, const BaCtl* __restrict__ ctl) {
+    if (ctl && ctl->done) return;
     __shared__ __attribute__((aligned(16))) double Ti[kNB][kNB + 2];  // L(i,k-1), then the updated tile T
     __shared__ __attribute__((aligned(16))) double Tj[kNB][kNB + 2];  // L(j,k-1), then the updated diagonal D
     __shared__ __attribute__((aligned(16))) double colA[64];  // two column buffers: column j+1 can be staged while
@@ -892,7 +926,8 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
                                                      int nbc, const int2* __restrict__ tasks,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      unsigned epoch, double* __restrict__ fail,
-                                                     long long* __restrict__ dbg) {
+                                                     long long* __restrict__ dbg, const BaCtl* __restrict__ ctl) {
+    if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
     __shared__ __attribute__((aligned(16))) double Ta[kNB][kNB + 2];  // MR(i,m), then the finished tile T
     __shared__ __attribute__((aligned(16))) double Tb[kNB][kNB + 2];  // M(j,m),  then the finished diagonal D
     __shared__ __attribute__((aligned(16))) double Tc[kNB][kNB + 2];  // MR(j,m)
@@ -1102,7 +1137,8 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
 __global__ __launch_bounds__(256) void k_chol_apply(const double* __restrict__ A, const double* __restrict__ R, int ld,
-                                                     int n, double* __restrict__ x) {
+                                                     int n, double* __restrict__ x, const BaCtl* __restrict__ ctl) {
+    if (ctl && ctl->done) return;
     const int r = blockIdx.x * 4 + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
     if (r >= n) return;
@@ -1126,7 +1162,16 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
                                                     const uint8_t* __restrict__ fixed, const double* __restrict__ lms,
                                                     const double* __restrict__ xp, const double* __restrict__ z,
                                                     const double* __restrict__ Y, const double* __restrict__ bl,
-                                                    double* __restrict__ lms_trial, double* __restrict__ part) {
+                                                    double* __restrict__ lms_trial, double* __restrict__ part,
+                                                    const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b) {
+    if (ctl) {   // (poses, lms) / lms_trial are the "a" / "b" buffers: the controller says which holds the estimate
+        if (ctl->done) return;
+        if (ctl->sel) {
+            const double* t = lms; lms = lms_trial; lms_trial = const_cast<double*>(t);
+            poses = poses_b;
+        }
+        lambda = ctl->lambda;
+    }
     __shared__ double sm[2][kBlock / 64];
     const int gid = blockIdx.x * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
@@ -1192,18 +1237,98 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
     }
 }
 
+// One step of g2o's OptimizationAlgorithmLevenberg::solve / OptimizationAlgorithmGaussNewton on the controller block, run
+// by ONE thread after the (all-reduced) scalars of a trial are known:  sc = {chi2 of the trial state, computeScale()
+// denominator, factorisation flag}.  Mirrors, statement for statement, the host loop this replaces
+// (rho = (chi - chi_trial) / (scale + 1e-3); accept: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)), ni = 2, the trial
+// state becomes the estimate (sel flips = discardTop); reject: lambda *= ni, ni *= 2 (pop); at most 10 trials per
+// iteration; Terminate when all 10 failed or rho == 0).  `stop` is the caller's force-stop flag, mirrored by the host
+// into mapped memory (SparseOptimizer::setForceStopFlag).
+__device__ inline void lm_advance(BaCtl* c, const double* sc, const volatile int* stop) {
+    double tempChi = sc[0];
+    const double scale_in = sc[1], fail = sc[2];
+    if (fail >= 1e5) { c->error = 1; c->done = 1; return; }   // a dataflow spin of k_chol_tiles timed out
+    if (fail > 0.0) tempChi = 1.7976931348623157e308;          // factorisation failed: the step is rejected
+    const bool stopped = stop && *stop;
+    c->trials += 1;
+    const int qmax = c->qmax + 1;
+    c->qmax = qmax;
+    double rho;
+    if (c->mode == SE2GPU_BA_GN) {
+        c->sel ^= 1;
+        c->current_chi = tempChi;
+        rho = 1;
+    } else {
+        rho = (c->current_chi - tempChi) / (scale_in + 1e-3);
+        if (rho > 0 && tempChi < 1.7976931348623157e308 && tempChi == tempChi) {
+            const double t = 2 * rho - 1;
+            double alpha = 1. - t * t * t;
+            alpha = fmin(alpha, 2. / 3.);
+            c->lambda *= fmax(1. / 3., alpha);
+            c->ni = 2;
+            c->current_chi = tempChi;
+            c->sel ^= 1;
+        } else {
+            c->lambda *= c->ni;
+            c->ni *= 2;
+        }
+        if (rho < 0 && qmax < 10 && !stopped) {   // do { ... } while (rho < 0 && qmax < 10 && !terminate())
+            c->rho = rho;
+            c->retry = 1;
+            return;
+        }
+    }
+    c->rho = rho;
+    const int it = c->it;
+    if (it < 64) { c->chi2_hist[it] = c->current_chi; c->lambda_hist[it] = c->lambda; c->trials_hist[it] = qmax; }
+    c->it = it + 1;
+    c->chi2_final = c->current_chi;
+    c->qmax = 0;
+    c->retry = 0;
+    if (c->mode == SE2GPU_BA_LM && (qmax == 10 || rho == 0)) { c->terminated = 1; c->done = 1; }
+    if (stopped) { c->stopped = 1; c->done = 1; }
+    if (c->it >= c->iters) c->done = 1;
+}
+
+// The controller block goes to the host through a mapped, coherent mailbox (no stream synchronise + D2H copy):
+// payload first, system-scope fence, sequence number last.
+__device__ inline void post_ctl(const BaCtl* c, volatile double* mail, double seq, int tid, int nthr) {
+    constexpr int kWords = (int)(sizeof(BaCtl) / 8);
+    const double* src = reinterpret_cast<const double*>(c);
+    for (int i = tid; i < kWords; i += nthr) mail[8 + i] = src[i];
+}
+
 // k_finalize: single block.  Sums the k_update partials, applies oplus to the poses (VertexSE2::oplusImpl:
 // additive x,y; theta = normalize_theta(theta + dtheta)), adds the odometry chi^2 at the trial poses and the pose
-// part of computeScale().  out[0] = chi2_trial, out[1] = scale (local to this rank).
+// part of computeScale().  out[0] = chi2_trial, out[1] = scale (local to this rank), out[2] = factorisation flag (already
+// there).  Single GPU with a controller: also advances the LM state (decide != 0) and posts it when the run has ended
+// or the host asked for it (notify).  step == 0 evaluates the current state (x = 0) and seeds the controller's chi^2.
 __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, double lambda,
                            const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
                            const double* __restrict__ xp, const double* __restrict__ bp, double* __restrict__ poses_trial,
                            int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
                            const double* __restrict__ o_meas, const double* __restrict__ o_info, int root,
-                           double* __restrict__ out, volatile double* __restrict__ mail, double seq) {
+                           double* __restrict__ out, volatile double* __restrict__ mail, double seq,
+                           BaCtl* __restrict__ ctl, int step_arg, int decide, int notify,
+                           const volatile int* __restrict__ stop) {
     __shared__ double sm[2][16];
     __shared__ double sp[3 * 1024];  // trial poses staged for the odometry pass when P <= 1024
-    const bool step = xp != nullptr;
+    __shared__ int post_s;
+    bool step = xp != nullptr;
+    if (ctl) {
+        step = step_arg != 0;
+        if (ctl->done) {   // the run is over: only answer a pending notification
+            if (notify && mail) {
+                post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+                __threadfence_system();
+                __syncthreads();
+                if (threadIdx.x == 0) { mail[3] = seq; }
+            }
+            return;
+        }
+        if (ctl->sel) { const double* t = poses; poses = poses_trial; poses_trial = const_cast<double*>(t); }
+        lambda = ctl->lambda;
+    }
     double chi = 0, scale = 0;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
         chi += part[2 * i];
@@ -1214,7 +1339,11 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
         if (step && !fixed[p]) {
             const double d0 = xp[3 * p], d1 = xp[3 * p + 1], d2 = xp[3 * p + 2];
             x += d0; y += d1; th = normalize_theta(th + d2);
+            // computeScale(): sum_j x_j (lambda x_j + b_j).  bp is this rank's LOCAL pose gradient (its landmark shard's
+            // edges, + the odometry edges on the root): every rank contributes x.b_local to the all-reduced sum, the
+            // lambda x.x term enters exactly once (root).
             if (root) scale += d0 * (lambda * d0 + bp[3 * p]) + d1 * (lambda * d1 + bp[3 * p + 1]) + d2 * (lambda * d2 + bp[3 * p + 2]);
+            else scale += d0 * bp[3 * p] + d1 * bp[3 * p + 1] + d2 * bp[3 * p + 2];
         }
         if (step) { poses_trial[3 * p] = x; poses_trial[3 * p + 1] = y; poses_trial[3 * p + 2] = th; }
         if (p < 1024) { sp[3 * p] = x; sp[3 * p + 1] = y; sp[3 * p + 2] = th; }
@@ -1245,14 +1374,89 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
             sm[1][0] += sm[1][w];
         }
         out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0;
-        if (mail) {  // single-GPU: the LM controller on the host polls this mapped, coherent host buffer instead of
-            mail[0] = sm[0][0];           // paying a stream synchronise + D2H copy per trial
+        if (!step) out[2] = 0;
+        post_s = 0;
+        if (ctl && decide) {
+            if (!step) {   // evaluation of the starting state
+                ctl->current_chi = ctl->chi2_init = ctl->chi2_final = sm[0][0];
+                if (stop && *stop) { ctl->stopped = 1; ctl->done = 1; }
+                if (ctl->iters <= 0) ctl->done = 1;
+            } else {
+                const double sc[3] = {sm[0][0], sm[1][0], out[2]};
+                lm_advance(ctl, sc, stop);
+            }
+            post_s = (ctl->done || notify) && mail;
+        } else if (mail && !ctl) {  // synchronous callers (se2gpu_ba_chi2): the three scalars
+            mail[0] = sm[0][0];
             mail[1] = sm[1][0];
-            mail[2] = step ? out[2] : 0.0;  // factorisation flag of the solve that produced xp
+            mail[2] = step ? out[2] : 0.0;
             __threadfence_system();
             mail[3] = seq;
         }
     }
+    if (ctl && decide) {
+        __syncthreads();
+        if (post_s) {
+            __threadfence();
+            post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) mail[3] = seq;
+        }
+    }
+}
+
+// Sharded (multi-GPU) runs: k_finalize leaves this rank's partial scalars in the fused buffer, the all-reduce sums them,
+// and this kernel takes the LM decision - identically on every rank, since the summed scalars are identical.
+__global__ void k_lm_decide(BaCtl* __restrict__ ctl, const double* __restrict__ sc, int step, int notify,
+                            volatile double* __restrict__ mail, double seq, const volatile int* __restrict__ stop) {
+    __shared__ int post_s;
+    if (threadIdx.x == 0) {
+        if (!ctl->done) {
+            if (!step) {
+                ctl->current_chi = ctl->chi2_init = ctl->chi2_final = sc[0];
+                if (stop && *stop) { ctl->stopped = 1; ctl->done = 1; }
+                if (ctl->iters <= 0) ctl->done = 1;
+            } else {
+                lm_advance(ctl, sc, stop);
+            }
+        }
+        post_s = (ctl->done || notify) && mail;
+    }
+    __syncthreads();
+    if (post_s) {
+        __threadfence();
+        post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) mail[3] = seq;
+    }
+}
+
+// start of an optimize() call: fresh controller block
+__global__ void k_ctl_init(BaCtl* __restrict__ ctl, int sel, int iters, int mode) {
+    constexpr int kWords = (int)(sizeof(BaCtl) / 8);
+    double* w = reinterpret_cast<double*>(ctl);
+    for (int i = threadIdx.x; i < kWords; i += blockDim.x) w[i] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl->ni = 2;
+        ctl->sel = sel;
+        ctl->iters = iters;
+        ctl->mode = mode;
+    }
+}
+
+// lambda_0 = 1e-5 * max |diag H| (computeLambdaInit); src holds the maximum (one entry), or one slot per rank
+__global__ void k_set_lambda(BaCtl* __restrict__ ctl, const double* __restrict__ src, int count) {
+    double m = 0;
+    for (int i = 0; i < count; ++i) m = fmax(m, src[i]);
+    ctl->lambda = 1e-5 * m;
+    ctl->ni = 2;
+}
+__global__ void k_fill_slots(double* __restrict__ dst, const double* __restrict__ maxd, int rank, int world) {
+    const int r = threadIdx.x;
+    if (r < world) dst[r] = (r == rank) ? maxd[0] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1391,6 +1595,9 @@ struct IdTable {
     void reserve(size_t n) { dense.reserve(n); }
 };
 
+constexpr int kMailDoubles = 256, kMailStop = 250;
+static_assert(8 + sizeof(BaCtl) / 8 <= kMailStop, "controller block does not fit the mailbox");
+
 struct se2gpu_ba {
     hipStream_t own_stream = nullptr, stream = nullptr;
     LaunchProfile prof;
@@ -1428,9 +1635,18 @@ struct se2gpu_ba {
     bool chol_steps = false;      // SE2GPU_BA_CHOL=steps: one launch per block column (k_chol_step) instead
     double* red = nullptr;  // [augmented (ld x ld): rows 0..n-1 = S, row n = bs | 4 scalars]
     PinBuf<double> h_red, h_x, h_scal;
-    double* h_mail = nullptr;      // mapped + coherent host mailbox written by k_finalize: {chi2, scale, fail, seq}
+    // mapped + coherent host mailbox (kMailDoubles): [0..2] = {chi2, scale, fail} of a synchronous evaluation, [3] = sequence
+    // number (written last), [8 ..] = the controller block posted by k_finalize / k_lm_decide, [kMailStop] = the force-stop
+    // word the device reads (written by the host while it waits)
+    double* h_mail = nullptr;
     double* d_mail = nullptr;
+    volatile int* h_stop = nullptr;
+    int* d_stop = nullptr;
     uint64_t mail_seq = 0;
+    DevBuf<BaCtl> ctl;             // device-side LM controller
+    int run_mode = SE2GPU_BA_LM, run_iters = 0, run_enqueued = 0;
+    bool run_sync = false, run_active = false;
+    double run_seq = 0;
     // multi-GPU
     se2gpu_allreduce_fn allreduce = nullptr;
     void* ar_user = nullptr;
@@ -1658,6 +1874,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     h->nparts = (L * kGroup + kBlock - 1) / kBlock;
     SE2_CHECK(h->part.reserve(2 * (size_t)std::max(h->nparts, 1)));
     SE2_CHECK(h->scal.reserve(8 + (size_t)h->world));
+    SE2_CHECK(h->ctl.reserve(1));
     h->ld = ((n + 1 + kNB - 1) / kNB) * kNB;
     const size_t nred = (size_t)h->ld * h->ld + 4;
     {
@@ -1706,9 +1923,11 @@ int ba_upload_graph(se2gpu_ba* h) {
     if (!h->h_mail) {
         const char* env = getenv("SE2GPU_BA_MAILBOX");
         if (!(env && env[0] == '0')) {
-            SE2_HIP(hipHostMalloc((void**)&h->h_mail, 8 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(h->h_mail, 0, 8 * sizeof(double));
+            SE2_HIP(hipHostMalloc((void**)&h->h_mail, kMailDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(h->h_mail, 0, kMailDoubles * sizeof(double));
             SE2_HIP(hipHostGetDevicePointer((void**)&h->d_mail, h->h_mail, 0));
+            h->h_stop = reinterpret_cast<volatile int*>(h->h_mail + kMailStop);
+            h->d_stop = reinterpret_cast<int*>(h->d_mail + kMailStop);
         }
     }
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
@@ -1724,27 +1943,42 @@ int ba_upload_graph(se2gpu_ba* h) {
 
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
 
-// linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl; with fuse_lambda >= 0 also Dinv, z, Y for that damping
-int ba_linearize(se2gpu_ba* h, double fuse_lambda) {
+// Every launch below exists in two forms: with the device-side controller (`c` = h->ctl.p: the kernel picks the
+// estimate buffer, lambda and whether it has anything to do from the block; "a"/"b" buffers are passed in fixed order)
+// and without (c = nullptr: explicit lambda, h->poses / h->lms are the estimate) for the synchronous entry points
+// (se2gpu_ba_chi2, the debug_* introspection).
+struct Bufs {
+    const BaCtl* c;
+    double *pa, *pb, *la, *lb;   // estimate / trial when c == nullptr, "a" / "b" otherwise
+};
+inline Bufs bufs(se2gpu_ba* h, bool ctl) {
+    if (ctl) return Bufs{h->ctl.p, h->poses_a.p, h->poses_b.p, h->lms_a.p, h->lms_b.p};
+    return Bufs{nullptr, h->poses, h->poses_t, h->lms, h->lms_t};
+}
+
+// linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl; with fuse_lambda >= 0 (or fused && ctl) also Dinv, z, Y
+int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
     hipStream_t st = h->stream;
+    const Bufs B = bufs(h, ctl);
     if (fuse_lambda >= 0.0)
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
-                   h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p);
+                   h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p, B.c, B.pb, B.lb);
     else
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
-                   h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p);
+                   h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p, B.c, B.pb, B.lb);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
 
+// the estimate's pose buffer as a host-known pointer (only valid between optimize() calls / in synchronous mode)
 // un-reduced pose blocks Hpp / bp (only needed for lambda_0 = 1e-5 max diag H and by the odometry fallback)
-int ba_pose_blocks(se2gpu_ba* h) {
+int ba_pose_blocks(se2gpu_ba* h, const double* poses) {
     hipStream_t st = h->stream;
     if (h->O)
         SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
-                   h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
+                   h->o_meas.p, h->o_info.p, poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
     SE2_LAUNCH(h->prof, st, "k_pose_reduce", k_pose_reduce, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
                h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p,
                h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
@@ -1753,19 +1987,22 @@ int ba_pose_blocks(se2gpu_ba* h) {
 }
 
 // reduced system for damping lambda into h->red (local contribution of this rank).
-// need_schur: Dinv / z / Y are not current for this lambda (first trial after an un-fused linearisation, or a retry)
-int ba_reduce(se2gpu_ba* h, double lambda, bool need_schur) {
+// schur: 0 = Dinv / z / Y are current, 1 = recompute them (k_schur_lm), 2 = let the controller decide (retry), 3 = force
+int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
     hipStream_t st = h->stream;
     double* S = h->red;
-    if (need_schur)
+    const Bufs B = bufs(h, ctl);
+    if (schur)
         SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
                    lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->Y.p,
-                   h->Dg.p);
+                   h->Dg.p, B.c, schur == 2 ? 0 : 1);
     SE2_LAUNCH(h->prof, st, "k_reduce2", k_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0, h->P, h->ld, h->nwg_off,
                lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
                h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p,
-               h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, h->poses, S, h->bp.p);
+               h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb);
     if (h->O && h->odo_fallback) {
+        // PreEdgeSE2 edges the plan cannot carry (self loops, duplicates): blocks from the estimate, added atomically.  Only
+        // reachable with a host-known estimate pointer, so such graphs run in synchronous mode (ba_needs_sync).
         SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
                    h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
         SE2_LAUNCH(h->prof, st, "k_reduce_odo", k_reduce_odo, grid1((size_t)h->O * 9, 256), dim3(256), 0, h->O, h->ld,
@@ -1782,14 +2019,15 @@ int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count) {
     return SE2GPU_OK;
 }
 
-// chi2 / scale of a (trial) step; xp == nullptr evaluates the current state.  Result in h->h_scal[0..1].
-// host side of the mailbox: poll the mapped, coherent buffer until the device has written sequence number `seq`
-int ba_wait_mail(se2gpu_ba* h, double seq) {
+// host side of the mailbox: poll the mapped, coherent buffer until the device has written sequence number `seq`;
+// meanwhile the caller's force-stop flag is mirrored into the word the device reads
+int ba_wait_mail(se2gpu_ba* h, double seq, const volatile uint8_t* stop_flag = nullptr) {
     volatile double* mb = h->h_mail;
     const auto t0 = std::chrono::steady_clock::now();
     long spins = 0;
     while (mb[3] != seq) {
         __builtin_ia32_pause();
+        if (stop_flag && *stop_flag) *h->h_stop = 1;
         if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
             SE2_HIP(hipStreamSynchronize(h->stream));  // surfaces a device fault, if that is what happened
             SE2_REQUIRE(mb[3] == seq, SE2GPU_ERR_HIP, "the host mailbox was not written");
@@ -1799,6 +2037,7 @@ int ba_wait_mail(se2gpu_ba* h, double seq) {
     h->h_scal.p[0] = mb[0]; h->h_scal.p[1] = mb[1]; h->h_scal.p[2] = mb[2];
     return SE2GPU_OK;
 }
+inline bool ba_mail_ready(se2gpu_ba* h, double seq) { return ((volatile double*)h->h_mail)[3] == seq; }
 
 // multi-GPU: the all-reduced scalars go to the host mailbox too (instead of a stream synchronise + D2H copy per trial)
 __global__ void k_post_mail(const double* __restrict__ scal, volatile double* __restrict__ mail, double seq) {
@@ -1809,22 +2048,22 @@ __global__ void k_post_mail(const double* __restrict__ scal, volatile double* __
     mail[3] = seq;
 }
 
+// chi2 / scale of a (trial) step, synchronous form (se2gpu_ba_chi2): xp == nullptr evaluates the current state.
+// Result in h->h_scal[0..1].
 int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
     hipStream_t st = h->stream;
-    const int n = 3 * h->P;
-    (void)n;
     double* scal = h->red + (size_t)h->ld * h->ld;  // 4 trailing scalars of the fused buffer
     const bool use_mail = h->d_mail && !(h->allreduce && h->world > 1) && !h->comm;
     const double seq = (double)(++h->mail_seq);
     SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
                lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
-               h->Y.p, h->bl.p, h->lms_t, h->part.p);
+               h->Y.p, h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr);
     SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
-               h->o_info.p, h->root, scal, use_mail ? h->d_mail : nullptr, seq);
+               h->o_info.p, h->root, scal, use_mail ? h->d_mail : nullptr, seq, (BaCtl*)nullptr, xp ? 1 : 0, 0, 0,
+               (const volatile int*)nullptr);
     SE2_HIP(hipGetLastError());
     if (use_mail) return ba_wait_mail(h, seq);
-    if (!xp) SE2_HIP(hipMemsetAsync(scal + 2, 0, sizeof(double), st));
     SE2_CHECK(ba_allreduce(h, scal, 4));
     if (h->d_mail) {
         hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(1), 0, st, scal, h->d_mail, seq);
@@ -1839,12 +2078,13 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
 
 // dense pose solve: augmented S|bs (device, already all-reduced) -> xp (device).
 // `fail` = scalar slot [2] of the fused buffer: set to 1 by the factorisation on a non-positive pivot.
-int ba_solve(se2gpu_ba* h) {
+int ba_solve(se2gpu_ba* h, bool ctl = false) {
     hipStream_t st = h->stream;
     const int n = 3 * h->P;
     const int ld = h->ld;
     double* A = h->red;
     double* fail = h->red + (size_t)ld * ld + 2;
+    const BaCtl* c = ctl ? h->ctl.p : nullptr;
     if (h->host_solve) {
         SE2_HIP(hipMemcpyAsync(h->h_red.p, A, (size_t)(n + 1) * ld * sizeof(double), hipMemcpyDeviceToHost, st));
         SE2_HIP(hipStreamSynchronize(st));
@@ -1864,8 +2104,8 @@ int ba_solve(se2gpu_ba* h) {
     double* Rm = h->Rinv.p;
     if (h->chol_steps) {
         for (int k = 0; k < nbc; ++k)  // update with panel k-1 fused with the elimination of panel k
-            SE2_LAUNCH(h->prof, st, "k_chol_step", k_chol_step, dim3(nbc - k, nt), dim3(256), 0, A, Rm, ld, n, nt, k, fail);
-        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p);
+            SE2_LAUNCH(h->prof, st, "k_chol_step", k_chol_step, dim3(nbc - k, nt), dim3(256), 0, A, Rm, ld, n, nt, k, fail, c);
+        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p, c);
     } else {
         double* AM = Rm + (size_t)ld * ld;
         double* RM = AM + (size_t)ld * ld;
@@ -1873,16 +2113,18 @@ int ba_solve(se2gpu_ba* h) {
         unsigned* flagR = flagA + (size_t)nt * nbc;
         ++h->chol_epoch;
         SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
-                   h->chol_tasks.p, flagA, flagR, h->chol_epoch, fail, h->chol_trace.p);
-        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, RM, ld, n, h->xp.p);
+                   h->chol_tasks.p, flagA, flagR, h->chol_epoch, fail, h->chol_trace.p, c);
+        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, RM, ld, n, h->xp.p, c);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
 
-int ba_lambda_init(se2gpu_ba* h, double* lambda) {
+// lambda_0 = 1e-5 * max |diag H| into the controller block, device to device (no host round trip).  The estimate is in
+// h->poses at this point (first trial of an optimize() call).
+int ba_lambda_init(se2gpu_ba* h) {
     hipStream_t st = h->stream;
-    SE2_CHECK(ba_pose_blocks(h));
+    SE2_CHECK(ba_pose_blocks(h, h->poses));
     SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
                h->Hpp.p, h->diag3.p);
     const bool sharded = h->allreduce && h->world > 1;
@@ -1896,21 +2138,63 @@ int ba_lambda_init(se2gpu_ba* h, double* lambda) {
     }
     SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
                h->fixed.p, h->scal.p);
-    SE2_HIP(hipGetLastError());
-    SE2_HIP(hipMemcpyAsync(h->h_scal.p + 4, h->scal.p, sizeof(double), hipMemcpyDeviceToHost, st));
-    SE2_HIP(hipStreamSynchronize(st));
-    double maxd = h->h_scal.p[4];
     if (sharded) {
         // max over ranks through the SUM all-reduce: every rank deposits its local max in its own slot
-        double* slots = h->h_scal.p + 8;
-        for (int r = 0; r < h->world; ++r) slots[r] = (r == h->rank) ? maxd : 0.0;
-        SE2_HIP(hipMemcpyAsync(h->red, slots, h->world * sizeof(double), hipMemcpyHostToDevice, st));
+        SE2_REQUIRE(h->world <= 1024, SE2GPU_ERR_INVALID, "world size %d > 1024", h->world);
+        hipLaunchKernelGGL(k_fill_slots, dim3(1), dim3(1024), 0, st, h->red, h->scal.p, h->rank, h->world);
         SE2_CHECK(ba_allreduce(h, h->red, (size_t)h->world));
-        SE2_HIP(hipMemcpyAsync(slots, h->red, h->world * sizeof(double), hipMemcpyDeviceToHost, st));
-        SE2_HIP(hipStreamSynchronize(st));
-        for (int r = 0; r < h->world; ++r) maxd = std::max(maxd, slots[r]);
+        hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, st, h->ctl.p, h->red, h->world);
+    } else {
+        hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, st, h->ctl.p, h->scal.p, 1);
     }
-    *lambda = 1e-5 * maxd;
+    SE2_HIP(hipGetLastError());
+    return SE2GPU_OK;
+}
+
+// ---- one LM trial "slot": everything a trial may need, enqueued without knowing what the controller will decide.
+// first: the opening trial of an optimize() call (chi^2 of the start, un-fused linearisation, lambda_0, forced Schur).
+// know_retry: -1 = unknown (asynchronous mode: the kernels look at the controller), 0 / 1 = the host knows (synchronous
+// mode: kernels that would do nothing are not launched, so per-kernel profiles stay clean).
+int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, double seq) {
+    hipStream_t st = h->stream;
+    const int n = 3 * h->P;
+    const bool lm = h->run_mode == SE2GPU_BA_LM;
+    const bool sharded = h->allreduce != nullptr;
+    double* scal = h->red + (size_t)h->ld * h->ld;
+    const Bufs B = bufs(h, true);
+    auto evaluate = [&](bool step, bool note) -> int {
+        SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
+                   0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
+                   step ? h->xp.p : (const double*)nullptr, h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb);
+        SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
+                   0.0, B.pa, h->fixed.p, h->xp.p, h->bp.p, B.pb, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
+                   h->o_info.p, h->root, scal, h->d_mail, seq, h->ctl.p, step ? 1 : 0, sharded ? 0 : 1, note ? 1 : 0,
+                   (const volatile int*)h->d_stop);
+        if (sharded) {
+            SE2_CHECK(ba_allreduce(h, scal, 4));
+            hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, st, h->ctl.p, scal, step ? 1 : 0, note ? 1 : 0,
+                               h->d_mail, seq, (const volatile int*)h->d_stop);
+        }
+        SE2_HIP(hipGetLastError());
+        return SE2GPU_OK;
+    };
+    if (first) {
+        SE2_CHECK(evaluate(false, false));                  // chi^2 of the starting state -> controller
+        if (lm) {
+            SE2_CHECK(ba_linearize(h, -1.0, true));         // lambda_0 needs max diag(H) of this linearisation first
+            SE2_CHECK(ba_lambda_init(h));
+            SE2_CHECK(ba_reduce(h, 0.0, 3, true));
+        } else {
+            SE2_CHECK(ba_linearize(h, 0.0, true));          // Gauss-Newton: lambda = 0 throughout (controller block is zeroed)
+            SE2_CHECK(ba_reduce(h, 0.0, 0, true));
+        }
+    } else {
+        if (know_retry != 1) SE2_CHECK(ba_linearize(h, 0.0, true));
+        SE2_CHECK(ba_reduce(h, 0.0, !lm ? 0 : know_retry == 0 ? 0 : know_retry == 1 ? 3 : 2, true));
+    }
+    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
+    SE2_CHECK(ba_solve(h, true));
+    SE2_CHECK(evaluate(true, notify));
     return SE2GPU_OK;
 }
 
@@ -2201,80 +2485,151 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
     return SE2GPU_OK;
 }
 
-int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
-                       se2gpu_ba_stats* stats) {
+// ---- optimize(): the LM / GN loop runs on the device (BaCtl); the host enqueues trial slots and waits for the posted
+// controller block.  Three phases so that several handles can be driven at once (se2gpu_ba_optimize_batch):
+//   ba_run_begin   resets the controller and enqueues `iters` slots (the common case: no rejected trial)
+//   ba_run_step    is the posted block there?  not finished -> enqueue the missing slots; returns 1 when the run is over
+//   ba_run_finish  stats, estimate pointers
+// Synchronous mode (profiling, verbose, SE2GPU_BA_SYNC=1, host solve, PreEdgeSE2 edges outside the block plan) reads the
+// block back after every trial and only launches the kernels that trial needs.
+namespace {
+
+bool ba_env_sync() {
+    static const bool on = [] { const char* e = getenv("SE2GPU_BA_SYNC"); return e && e[0] == '1'; }();
+    return on;
+}
+
+const BaCtl* ba_posted(se2gpu_ba* h) { return reinterpret_cast<const BaCtl*>(h->h_mail + 8); }
+
+int ba_run_begin(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "optimize before initialize");
     SE2_REQUIRE(mode == SE2GPU_BA_LM || mode == SE2GPU_BA_GN, SE2GPU_ERR_INVALID, "unknown mode %d", mode);
+    SE2_REQUIRE(h->d_mail, SE2GPU_ERR_STATE, "SE2GPU_BA_MAILBOX=0 is no longer supported: the LM controller posts its state "
+                                              "through the mapped mailbox");
     h->est_valid = false;
-    se2gpu_ba_stats s;
-    std::memset(&s, 0, sizeof(s));
-    const int n = 3 * h->P;
-    auto terminate = [&]() { return stop_flag && *stop_flag; };
-    SE2_CHECK(ba_evaluate(h, nullptr, 0.0));
-    double currentChi = h->h_scal.p[0];
-    s.chi2_init = s.chi2_final = currentChi;
-    double lambda = 0, ni = 2;
-    bool ok = true;
-    for (int it = 0; it < iters && !terminate() && ok; ++it) {
-        bool need_schur;
-        if (mode == SE2GPU_BA_LM && it == 0) {
-            SE2_CHECK(ba_linearize(h, -1.0));  // lambda_0 needs max diag(H) of this linearisation first
-            SE2_CHECK(ba_lambda_init(h, &lambda));
-            ni = 2;
-            need_schur = true;
-        } else {
-            SE2_CHECK(ba_linearize(h, mode == SE2GPU_BA_LM ? lambda : 0.0));
-            need_schur = false;
-        }
-        double rho = 0;
-        int qmax = 0;
-        do {
-            const double lam = mode == SE2GPU_BA_LM ? lambda : 0.0;
-            SE2_CHECK(ba_reduce(h, lam, need_schur));
-            need_schur = true;  // a retry changes lambda
-            SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
-            SE2_CHECK(ba_solve(h));
-            SE2_CHECK(ba_evaluate(h, h->xp.p, lam));
-            double tempChi = h->h_scal.p[0];
-            const bool ok2 = !(h->h_scal.p[2] > 0.0);  // factorisation flag (summed over ranks: identical on all)
-            SE2_REQUIRE(h->h_scal.p[2] < 1e5, SE2GPU_ERR_HIP, "k_chol_tiles: a dependency spin timed out (2 s)");
-            if (!ok2) tempChi = std::numeric_limits<double>::max();
-            ++s.trials;
-            ++qmax;
-            if (mode == SE2GPU_BA_GN) {
-                std::swap(h->poses, h->poses_t);
-                std::swap(h->lms, h->lms_t);
-                currentChi = tempChi;
-                rho = 1;
+    h->run_mode = mode;
+    h->run_iters = iters;
+    h->run_enqueued = 0;
+    h->run_sync = ba_env_sync() || h->prof.enabled || verbose || h->odo_fallback || h->host_solve;
+    h->run_active = true;
+    *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
+    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl.p, h->poses == h->poses_b.p ? 1 : 0, iters, mode);
+    SE2_HIP(hipGetLastError());
+    const int n0 = h->run_sync ? 1 : std::max(iters, 1);
+    for (int k = 0; k < n0; ++k) {
+        h->run_seq = (double)(++h->mail_seq);
+        SE2_CHECK(ba_enqueue_trial(h, k == 0, h->run_sync ? 0 : -1, k == n0 - 1, h->run_seq));
+        ++h->run_enqueued;
+    }
+    return SE2GPU_OK;
+}
+
+// returns 1 in *finished when the run is over; wait = block until the pending notification has arrived
+int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int verbose, int* finished) {
+    *finished = 0;
+    if (stop_flag && *stop_flag) *h->h_stop = 1;
+    if (!wait && !ba_mail_ready(h, h->run_seq)) {
+        // an earlier slot may already have posted "done" (Terminate, stop flag): its sequence number is lower
+        const double got = ((volatile double*)h->h_mail)[3];
+        if (!(got > h->run_seq - h->run_enqueued && got <= h->run_seq && ba_posted(h)->done)) return SE2GPU_OK;
+    } else if (wait) {
+        volatile double* mb = h->h_mail;
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        for (;;) {
+            const double got = mb[3];
+            if (got == h->run_seq) break;
+            if (got > h->run_seq - h->run_enqueued && got < h->run_seq) {   // an earlier slot of this run posted: done?
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (ba_posted(h)->done) break;
+            }
+            __builtin_ia32_pause();
+            if (stop_flag && *stop_flag) *h->h_stop = 1;
+            if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                SE2_HIP(hipStreamSynchronize(h->stream));
+                SE2_REQUIRE(mb[3] == h->run_seq || ba_posted(h)->done, SE2GPU_ERR_HIP, "the LM controller never reported back");
                 break;
             }
-            rho = currentChi - tempChi;
-            const double scale = h->h_scal.p[1] + 1e-3;
-            rho /= scale;
-            if (rho > 0 && std::isfinite(tempChi)) {
-                double alpha = 1. - std::pow(2 * rho - 1, 3);
-                alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha);
-                ni = 2;
-                currentChi = tempChi;
-                std::swap(h->poses, h->poses_t);   // discardTop(): the trial state becomes the estimate
-                std::swap(h->lms, h->lms_t);
-            } else {
-                lambda *= ni;                       // pop(): keep the previous estimate
-                ni *= 2;
-            }
-            if (verbose)
-                fprintf(stderr, "se2gpu_ba: it %d trial %d chi2 %.9g -> %.9g rho %.3g lambda %.6g\n", it, qmax,
-                        currentChi, tempChi, rho, lambda);
-        } while (rho < 0 && qmax < 10 && !terminate());
-        if (it < 64) { s.chi2_hist[it] = currentChi; s.lambda_hist[it] = lambda; s.trials_hist[it] = qmax; }
-        s.iterations = it + 1;
-        s.chi2_final = currentChi;
-        if (mode == SE2GPU_BA_LM && (qmax == 10 || rho == 0)) { s.terminated = 1; ok = false; }
+        }
     }
-    s.stopped = terminate() ? 1 : 0;
-    s.lambda_final = lambda;
-    if (stats) *stats = s;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    BaCtl c;
+    std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
+    SE2_REQUIRE(!c.error, SE2GPU_ERR_HIP, "k_chol_tiles: a dependency spin timed out (2 s)");
+    if (verbose)
+        fprintf(stderr, "se2gpu_ba: it %d trial %d chi2 %.9g rho %.3g lambda %.6g%s\n", c.it, c.qmax, c.current_chi, c.rho,
+                c.lambda, c.retry ? " (rejected)" : "");
+    if (h->run_sync)   // the estimate pointer follows the controller (the odometry fallback reads h->poses)
+        if ((h->poses == h->poses_b.p) != (c.sel != 0)) { std::swap(h->poses, h->poses_t); std::swap(h->lms, h->lms_t); }
+    if (c.done) {
+        *finished = 1;
+        return SE2GPU_OK;
+    }
+    const int more = h->run_sync ? 1 : std::max(1, c.iters - c.it);
+    for (int k = 0; k < more; ++k) {
+        h->run_seq = (double)(++h->mail_seq);
+        SE2_CHECK(ba_enqueue_trial(h, false, h->run_sync ? (c.retry ? 1 : 0) : -1, k == more - 1, h->run_seq));
+        ++h->run_enqueued;
+    }
+    return SE2GPU_OK;
+}
+
+int ba_run_finish(se2gpu_ba* h, se2gpu_ba_stats* stats) {
+    BaCtl c;
+    std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
+    h->run_active = false;
+    if ((h->poses == h->poses_b.p) != (c.sel != 0)) { std::swap(h->poses, h->poses_t); std::swap(h->lms, h->lms_t); }
+    if (stats) {
+        se2gpu_ba_stats s;
+        std::memset(&s, 0, sizeof(s));
+        s.iterations = c.it;
+        s.trials = c.trials;
+        s.terminated = c.terminated;
+        s.stopped = c.stopped;
+        s.chi2_init = c.chi2_init;
+        s.chi2_final = c.chi2_final;
+        s.lambda_final = c.lambda;
+        std::memcpy(s.chi2_hist, c.chi2_hist, sizeof(s.chi2_hist));
+        std::memcpy(s.lambda_hist, c.lambda_hist, sizeof(s.lambda_hist));
+        std::memcpy(s.trials_hist, c.trials_hist, sizeof(s.trials_hist));
+        *stats = s;
+    }
+    return SE2GPU_OK;
+}
+
+}  // namespace
+
+int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
+                       se2gpu_ba_stats* stats) {
+    SE2_CHECK(ba_run_begin(h, iters, mode, stop_flag, verbose));
+    for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(h, true, stop_flag, verbose, &fin));
+    return ba_run_finish(h, stats);
+}
+
+// optimize() of `count` independent windows at once (one handle each, every handle on its own stream): all runs are
+// enqueued before the first wait, so the device works on them concurrently - local windows are far too small to fill
+// the chip one at a time.  stats may be NULL or an array of `count`.
+int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
+                             se2gpu_ba_stats* stats) {
+    SE2_REQUIRE(hs && count >= 0, SE2GPU_ERR_INVALID, "optimize_batch: bad argument");
+    for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_begin(hs[i], iters, mode, stop_flag, 0));
+    std::vector<char> fin(count, 0);
+    int left = count;
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (left) {
+        for (int i = 0; i < count; ++i) {
+            if (fin[i]) continue;
+            int f = 0;
+            SE2_CHECK(ba_run_step(hs[i], hs[i]->run_sync, stop_flag, 0, &f));
+            if (f) { fin[i] = 1; --left; }
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+            for (int i = 0; i < count; ++i)
+                if (!fin[i]) { int f = 0; SE2_CHECK(ba_run_step(hs[i], true, stop_flag, 0, &f)); if (f) { fin[i] = 1; --left; } }
+    }
+    for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_finish(hs[i], stats ? stats + i : nullptr));
     return SE2GPU_OK;
 }
 

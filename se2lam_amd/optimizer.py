@@ -16,6 +16,27 @@ from . import capi
 LM, GN = 0, 1
 
 
+def _stats_dict(st):
+    n = min(st.iterations, 64)
+    return dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated),
+                stopped=bool(st.stopped), chi2_init=st.chi2_init, chi2_final=st.chi2_final,
+                lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
+                lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]))
+
+
+def optimize_batch(optimizers, iterations: int, mode: int = 0, stop=None):
+    """se2gpu_ba_optimize_batch: optimize(iterations) of several initialised SlamOptimizers at once (independent
+    windows, concurrently on the device).  Fills every optimizer's .stats; returns the iteration counts."""
+    n = len(optimizers)
+    hs = (C.c_void_p * n)(*[o._h for o in optimizers])
+    st = (capi.BaStats * n)()
+    sp = stop.ctypes.data_as(C.POINTER(C.c_uint8)) if stop is not None else None
+    capi.check(capi.lib().se2gpu_ba_optimize_batch(hs, n, int(iterations), int(mode), sp, st))
+    for o, s in zip(optimizers, st):
+        o.stats = _stats_dict(s)
+    return [s.iterations for s in st]
+
+
 class SlamOptimizer:
     """g2o::SparseOptimizer with SlamAlgorithm = Levenberg, BlockSolverX, dense pose solve."""
 
@@ -50,11 +71,7 @@ class SlamOptimizer:
         stop = self._stop.ctypes.data_as(C.POINTER(C.c_uint8)) if self._stop is not None else None
         capi.check(capi.lib().se2gpu_ba_optimize(self._h, int(iterations), int(mode), stop, int(self._verbose),
                                                  C.byref(st)))
-        n = min(st.iterations, 64)
-        self.stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated),
-                          stopped=bool(st.stopped), chi2_init=st.chi2_init, chi2_final=st.chi2_final,
-                          lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
-                          lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]))
+        self.stats = _stats_dict(st)
         return st.iterations
 
     def activeRobustChi2(self) -> float:

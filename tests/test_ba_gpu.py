@@ -185,12 +185,26 @@ def test_landmark_sharded_two_ranks_on_one_gpu(oracle, synth):
     """The multi-GPU path with world=2 on ONE device: two handles, each holding a
     landmark shard, run their LM loops in two threads; the all-reduce callback sums the fused buffer
     [S | bs | scalars] over the two handles through host memory.  Result == single-handle run."""
+    _sharded_equals_single(synth.ba_graph(8, 60), 6)
+
+
+def test_landmark_sharded_lm_schedule_on_a_start_that_rejects(synth):
+    """computeScale() of the sharded run must include every rank's x.b_p term - on an easy graph
+    every step hits the 1/3 clamp of the lambda schedule and a wrong gain denominator goes unnoticed.  A kidnapped start
+    (rejected trials, gain ratios anywhere in (0, 1)) pins rho, the lambda history and the trial counts to the
+    single-handle run."""
+    case, trials = LM_REJECT_CASES[2]
+    _sharded_equals_single(_kidnapped(synth, *case), 10, trials)
+
+
+def _sharded_equals_single(g, iters, trials=None):
     from se2lam_amd import capi
     from se2lam_amd.optimizer import SlamOptimizer
-    g = synth.ba_graph(8, 60)
     world = 2
     single = _opt(g)
-    single.optimize(6)
+    single.optimize(iters)
+    if trials is not None:
+        assert single.stats["trials_hist"] == trials
     barrier = threading.Barrier(world)
     stage = [None] * world
     results = [None] * world
@@ -215,7 +229,7 @@ def test_landmark_sharded_two_ranks_on_one_gpu(oracle, synth):
             o.set_allreduce(make_cb(rank))
             o.load(g.shard(rank, world))
             o.initializeOptimization(0)
-            o.optimize(6)
+            o.optimize(iters)
             results[rank] = (o.stats, o.estimates())
         except Exception as exc:  # pragma: no cover
             errors.append(exc)
@@ -229,7 +243,8 @@ def test_landmark_sharded_two_ranks_on_one_gpu(oracle, synth):
         st, (poses, _) = results[r]
         assert st["trials_hist"] == single.stats["trials_hist"]
         assert np.allclose(st["chi2_hist"], single.stats["chi2_hist"], rtol=1e-9)
-        assert np.allclose(poses, single.estimates()[0], rtol=1e-9, atol=1e-9)
+        assert np.allclose(st["lambda_hist"], single.stats["lambda_hist"], rtol=1e-9)
+        assert np.allclose(poses, single.estimates()[0], rtol=1e-8, atol=1e-8)
     assert np.array_equal(results[0][1][0], results[1][1][0])  # replicated poses stay identical
 
 
@@ -401,3 +416,48 @@ def test_pooled_handles_behave_like_new_ones(synth, monkeypatch):
     opt.optimize(4)
     assert opt.stats["chi2_hist"] == pooled[1][4]
     assert np.array_equal(op.estimateVertexSE2(opt, pid(3)), pooled[1][1][3])
+
+
+def test_optimize_batch_equals_one_by_one(synth):
+    """se2gpu_ba_optimize_batch: several independent windows (different sizes, one of them a start that rejects trials)
+    driven at once, every controller on the device - bit-identical to optimising them one after the other."""
+    from se2lam_amd.optimizer import optimize_batch
+    graphs = [synth.ba_graph(50, 5000), synth.ba_graph(8, 60), _kidnapped(synth, *LM_REJECT_CASES[3][0]),
+              synth.ba_graph(21, 800), synth.ba_graph(50, 5000)]
+    ref = []
+    for g in graphs:
+        o = _opt(g)
+        o.optimize(10)
+        ref.append((o.stats, o.estimates()))
+    opts = [_opt(g) for g in graphs]
+    its = optimize_batch(opts, 10)
+    for o, (st, (p, l)), n in zip(opts, ref, its):
+        assert n == st["iterations"]
+        assert o.stats == st
+        pp, ll = o.estimates()
+        assert np.array_equal(pp, p) and np.array_equal(ll, l)
+    assert ref[2][0]["trials_hist"] == LM_REJECT_CASES[3][1]
+
+
+def test_force_stop_flag_and_synchronous_controller(synth):
+    """setForceStopFlag (LocalMapper.cpp:246): a flag that is already set leaves the estimate untouched and reports
+    `stopped`; the synchronous controller (SE2GPU_BA_SYNC=1 semantics are the same code path as verbose) agrees with the
+    asynchronous one."""
+    g = synth.ba_graph(21, 800)
+    o = _opt(g)
+    flag = np.ones(1, np.uint8)
+    o.setForceStopFlag(flag)
+    assert o.optimize(10) == 0 and o.stats["stopped"]
+    assert o.stats["chi2_init"] == pytest.approx(o.activeRobustChi2(), rel=1e-14)
+    assert np.array_equal(o.estimates()[0], g.poses)
+    flag[0] = 0
+    assert o.optimize(4) == 4 and not o.stats["stopped"]
+    a = _opt(g)
+    a.optimize(4)
+    assert a.stats["chi2_hist"] == o.stats["chi2_hist"]
+    v = _opt(g)
+    v.setVerbose(True)              # verbose = synchronous controller: one host round trip per trial
+    v.optimize(4)
+    assert v.stats == a.stats and np.array_equal(v.estimates()[0], a.estimates()[0])
+    z = _opt(g)
+    assert z.optimize(0) == 0 and z.stats["chi2_init"] == pytest.approx(a.stats["chi2_init"], rel=1e-14)
