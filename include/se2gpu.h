@@ -194,7 +194,39 @@ int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O,
                    const int32_t* o_i, const int32_t* o_j, const double* o_meas, const double* o_info,
                    double huber_delta);
 
-/* initializeOptimization(0): freezes the graph, builds the device-side SoA + reduction plans. */
+/* Map::loadLocalGraph(SlamOptimizer&) (/root/reference/src/Map.cpp:891-1022) as ONE call on a POD view of the local
+ * window - SURVEY.md section 8f.1.  The caller flattens its pointer graph once per key frame (INTEGRATION.md shows the
+ * 30 lines that do it with one hash map instead of the reference's std::find per observation); the library applies
+ * the reference's vertex numbering (local key frame i -> id i, reference key frame i -> n_local + i, map point i ->
+ * n_local + n_ref + 1 + i), its fixed rule (no reference key frames: the local one with the smallest KeyFrame::id is
+ * fixed; KeyFrame::id == 1 always; reference key frames always), inverts the PreSE2 covariances, and evaluates the
+ * per-observation information matrices (:1024-1049) on the device during se2gpu_ba_initialize.  The optimizer must be
+ * empty; afterwards initialize / optimize / get_* as usual with those ids. */
+typedef struct se2gpu_local_graph {
+    int32_t n_local_kf, n_ref_kf, n_mp, n_obs;
+    /* key frames: mLocalGraphKFs first, then mRefKFs                                    [n_local_kf + n_ref_kf] entries */
+    const int32_t* kf_id;     /* KeyFrame::id */
+    const float* kf_Twb;      /* Se2 Twb: x, y, theta                                      x 3 */
+    const float* kf_Rcw;      /* rotation block of KeyFrame::Tcw (CV_32F), row-major       x 9 */
+    /* odometry of the local key frames (KeyFrame::preOdomFromSelf)                       [n_local_kf] entries, may be NULL */
+    const int32_t* odo_to;    /* position of preOdomFromSelf.first in mLocalGraphKFs, -1 = not in the window / null */
+    const double* odo_meas;   /* PreSE2::meas                                              x 3 */
+    const double* odo_cov;    /* PreSE2::cov, row-major                                    x 9 */
+    /* map points (mLocalGraphMPs) and their observations, grouped by map point            [n_mp] / [n_obs] entries */
+    const float* mp_pos;      /* MapPoint::getPos()                                        x 3 */
+    const int32_t* obs_mp;    /* map point of the observation, nondecreasing */
+    const int32_t* obs_kf;    /* observing key frame: position in the list above, -1 = in neither list (skipped, :1016) */
+    const float* obs_uv;      /* keyPointsUn[ftrIdx].pt                                    x 2 */
+    const float* obs_lc;      /* mViewMPs[ftrIdx]                                          x 3 */
+    const float* obs_sigma2;  /* mvLevelSigma2[octave] */
+    float fx, cx, cy;         /* Config::Kcam (addCamPara uses fx for both axes) */
+    double Rbc[9], tbc[3];    /* Config::bTc, rotation row-major */
+    float huber_delta;        /* Config::TH_HUBER */
+    float xrot_info, z_info;  /* Config::PLANEMOTION_XROT_INFO, PLANEMOTION_Z_INFO */
+} se2gpu_local_graph;
+int se2gpu_ba_load_local_graph(se2gpu_ba* h, const se2gpu_local_graph* graph);
+
+/* initializeOptimization(0): freezes the graph, builds the device-side SoA + reduction plans (on the device). */
 int se2gpu_ba_initialize(se2gpu_ba* h);
 /* restores every vertex estimate to the value it was added with (device-to-device) */
 int se2gpu_ba_reset_estimates(se2gpu_ba* h);

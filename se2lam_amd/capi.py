@@ -44,6 +44,17 @@ class FrameBounds(C.Structure):
     _fields_ = [("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float)]
 
 
+class LocalGraph(C.Structure):
+    _fields_ = [("n_local_kf", C.c_int32), ("n_ref_kf", C.c_int32), ("n_mp", C.c_int32), ("n_obs", C.c_int32),
+                ("kf_id", C.c_void_p), ("kf_Twb", C.c_void_p), ("kf_Rcw", C.c_void_p),
+                ("odo_to", C.c_void_p), ("odo_meas", C.c_void_p), ("odo_cov", C.c_void_p),
+                ("mp_pos", C.c_void_p), ("obs_mp", C.c_void_p), ("obs_kf", C.c_void_p), ("obs_uv", C.c_void_p),
+                ("obs_lc", C.c_void_p), ("obs_sigma2", C.c_void_p),
+                ("fx", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("Rbc", C.c_double * 9), ("tbc", C.c_double * 3),
+                ("huber_delta", C.c_float), ("xrot_info", C.c_float), ("z_info", C.c_float)]
+
+
 class BaStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
                 ("stopped", C.c_int32), ("chi2_init", C.c_double), ("chi2_final", C.c_double),
@@ -104,6 +115,7 @@ SYMBOLS = {
     "se2gpu_ba_add_edge_se2xyz": (_I, [_VP, _I, _I, _PD, _PD, _D]),
     "se2gpu_ba_add_edge_se2": (_I, [_VP, _I, _I, _PD, _PD]),
     "se2gpu_ba_load": (_I, [_VP, _I, _I, _I, _I, _PD, _PU8, _PD, _PI32, _PI32, _PD, _PD, _PI32, _PI32, _PD, _PD, _D]),
+    "se2gpu_ba_load_local_graph": (_I, [_VP, C.POINTER(LocalGraph)]),
     "se2gpu_ba_initialize": (_I, [_VP]),
     "se2gpu_ba_reset_estimates": (_I, [_VP]),
     "se2gpu_ba_optimize": (_I, [_VP, _I, _I, _PU8, _I, C.POINTER(BaStats)]),

@@ -25,6 +25,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <unordered_map>
@@ -1520,12 +1521,6 @@ bool host_cholesky_solve(double* A, int n, double* x) {
     return true;
 }
 
-struct EdgeObs {
-    int kf, lm;   // indices (not ids)
-    double uv[2];
-    double info[3];
-    double huber;
-};
 struct EdgeOdo {
     int i, j;
     double meas[3];
@@ -1538,7 +1533,7 @@ struct EdgeOdo {
 __global__ void k_edge_information(int E, const float* __restrict__ lc_, const float* __restrict__ lw_,
                                    const int* __restrict__ e_kf, const float* __restrict__ sigma2,
                                    const float* __restrict__ Rcw_, const float* __restrict__ twb, float fx,
-                                   float s_rot, float s_z, double* __restrict__ out) {
+                                   float s_rot, float s_z, double* __restrict__ out, int sym3) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= E) return;
     const double lc0 = lc_[3 * k], lc1 = lc_[3 * k + 1], lc2 = lc_[3 * k + 2];
@@ -1565,7 +1560,11 @@ __global__ void k_edge_information(int E, const float* __restrict__ lc_, const f
     const double S01 = s_rot * (r00 * r10 + r01 * r11) + s_z * z0 * z1;
     const double S11 = s_rot * (r10 * r10 + r11 * r11) + s_z * z1 * z1 + s2;
     const double id = 1.0 / (S00 * S11 - S01 * S01);
-    out[4 * k] = S11 * id; out[4 * k + 1] = -S01 * id; out[4 * k + 2] = -S01 * id; out[4 * k + 3] = S00 * id;
+    if (sym3) {   // (xx, xy, yy): the layout of the graph's e_info
+        out[3 * (size_t)k] = S11 * id; out[3 * (size_t)k + 1] = -S01 * id; out[3 * (size_t)k + 2] = S00 * id;
+    } else {
+        out[4 * k] = S11 * id; out[4 * k + 1] = -S01 * id; out[4 * k + 2] = -S01 * id; out[4 * k + 3] = S00 * id;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1609,7 +1608,16 @@ struct se2gpu_ba {
     std::vector<int> pose_ids, lm_ids;
     std::vector<double> h_poses, h_lms;
     std::vector<uint8_t> h_fixed;
-    std::vector<EdgeObs> obs;
+    std::vector<int> he_kf, he_lm;            // observation edges, SoA in insertion order (indices, not ids)
+    std::vector<double> he_uv, he_info;       // 2 / 3 (xx, xy, yy) per edge
+    double huber_delta = 0;
+    bool huber_mixed = false;
+    // se2gpu_ba_load_local_graph: raw inputs of the per-observation information (Map.cpp:1024-1049), evaluated on the
+    // device straight into e_info after the upload
+    bool lg_active = false;
+    std::vector<float> lg_lc, lg_lw, lg_sigma2, lg_Rcw, lg_twb;
+    float lg_fx = 0, lg_srot = 0, lg_sz = 0;
+    DevBuf<float> d_lg_lc, d_lg_lw, d_lg_sigma2, d_lg_Rcw, d_lg_twb;
     std::vector<EdgeOdo> odo;
     bool initialized = false;
     int P = 0, L = 0, E = 0, O = 0, nblk = 0, nparts = 0;
@@ -1622,7 +1630,10 @@ struct se2gpu_ba {
     DevBuf<int> lm_ptr, e_kf, e_lm, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j;
     DevBuf<int> blk_a, blk_b, blk_ptr, pair_i, pair_j, blk_odo;
     DevBuf<int4> grp;
-    int nwg_off = 0;
+    int nwg_off = 0, grp_cap_wg = 0;
+    DevBuf<uint8_t> garena;        // every uploaded graph array lives in this one allocation (one H2D copy)
+    DevBuf<int> plan_np, plan_base, plan_key0, plan_key1, plan_idx, plan_hist, plan_offs, plan_out;  // device plan scratch
+    DevBuf<int2> plan_st0, plan_st1;
     bool odo_fallback = false;
     DevBuf<double> e_uv, e_info, o_meas, o_info;
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Dg, Hpp, bp, Oii, Ojj, Oij, obi, obj;
@@ -1668,6 +1679,345 @@ struct se2gpu_ba {
 
 namespace {
 
+// =============================================================================================
+// Graph plan on the device: everything initializeOptimization used to build on the host - the
+// landmark / pose CSR lists and the contributor plan of k_reduce2 - from the raw edge arrays, in a handful of small
+// launches.  The result is element-for-element what the host builder (ba_plan_host, kept as the reference
+// implementation and fallback: SE2GPU_BA_PLAN=host, or more than 1024 poses) produces, so the LM results are bit-identical
+// (tests/test_ba_gpu.py::test_device_plan_equals_host_plan).
+//   k_plan_lm        lm_ptr by binary search in the landmark-sorted edge list + pairs per landmark
+//   k_scan_i32       exclusive scan (one workgroup)
+//   k_plan_pairs     (block key, edge s, edge t) of every contributor pair, in (landmark, s, t) order
+//   k_radix_*        stable LSD radix sort (hist / scan / scatter), <= 10 bits per pass: pairs by block key, edges by pose
+//   k_lower_bounds   CSR pointers of a sorted key list (blk_ptr, pose_ptr)
+//   k_plan_blocks    blk_a / blk_b / blk_odo
+//   k_plan_pack      first-fit-in-order packing of the 16-pair chunks into workgroups of 28 groups: the sequential rule
+//                    of the host builder evaluated as a scan over transfer functions on the 28 fill states
+// =============================================================================================
+__device__ __host__ inline int blk_index_of(int P, int a, int b) { return a * P - a * (a - 1) / 2 + (b - a); }
+
+__global__ void k_plan_lm(int L, int E, const int* __restrict__ e_lm, const int* __restrict__ e_kf,
+                          const uint8_t* __restrict__ fixed, int* __restrict__ lm_ptr, int* __restrict__ npair) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > L) return;
+    int lo = 0, hi = E;   // first edge with e_lm >= l
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (e_lm[mid] < l) lo = mid + 1; else hi = mid;
+    }
+    lm_ptr[l] = lo;
+    if (l == L) return;
+    int end = lo;
+    while (end < E && e_lm[end] == l) ++end;
+    int np = 0;
+    for (int s = lo; s < end; ++s) {
+        const int a = e_kf[s];
+        if (fixed[a]) continue;
+        for (int t = s + 1; t < end; ++t) {
+            const int b = e_kf[t];
+            np += (!fixed[b] && a != b) ? 1 : 0;
+        }
+    }
+    npair[l] = np;
+}
+
+// exclusive scan of n ints by ONE workgroup of 1024 threads (contiguous chunk per thread); out[n] = total
+__global__ void k_scan_i32(const int* __restrict__ in, int* __restrict__ out, int n) {
+    __shared__ int sums[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = min(t * per, n), e = min(b + per, n);
+    int s = 0;
+    for (int i = b; i < e; ++i) s += in[i];
+    sums[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 chunk sums
+        const int v = t >= off ? sums[t - off] : 0;
+        __syncthreads();
+        sums[t] += v;
+        __syncthreads();
+    }
+    int run = t ? sums[t - 1] : 0;
+    for (int i = b; i < e; ++i) {
+        const int v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (t == 1023) out[n] = sums[1023];
+}
+
+__global__ void k_plan_pairs(int L, int P, const int* __restrict__ lm_ptr, const int* __restrict__ e_kf,
+                             const uint8_t* __restrict__ fixed, const int* __restrict__ pair_base,
+                             int* __restrict__ key, int2* __restrict__ st) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    int o = pair_base[l];
+    const int beg = lm_ptr[l], end = lm_ptr[l + 1];
+    for (int s = beg; s < end; ++s) {
+        const int a = e_kf[s];
+        if (fixed[a]) continue;
+        for (int t = s + 1; t < end; ++t) {
+            const int b = e_kf[t];
+            if (fixed[b] || a == b) continue;
+            key[o] = a < b ? blk_index_of(P, a, b) : blk_index_of(P, b, a);
+            st[o] = a < b ? make_int2(s, t) : make_int2(t, s);
+            ++o;
+        }
+    }
+}
+
+// keys past the real pair count (known only on the device: *count) sort behind every block
+__global__ void k_plan_tail(const int* __restrict__ count, int cap, int big, int* __restrict__ key) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap && i >= *count) key[i] = big;
+}
+
+constexpr int kRadixItems = 256;   // items per workgroup of a radix pass
+
+__global__ __launch_bounds__(kRadixItems) void k_radix_hist(const int* __restrict__ key, int n, int shift, int nbins,
+                                                             int nblk, int* __restrict__ hist) {
+    __shared__ int h[1024];
+    for (int i = threadIdx.x; i < nbins; i += kRadixItems) h[i] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kRadixItems + threadIdx.x;
+    if (i < n) atomicAdd(&h[(key[i] >> shift) & (nbins - 1)], 1);
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += kRadixItems) hist[(size_t)d * nblk + blockIdx.x] = h[d];
+}
+
+// stable: an item's position = start of its digit's run for this workgroup + the number of EARLIER items of the
+// workgroup with the same digit (brute force over the <= 255 predecessors staged in LDS)
+template <typename V>
+__global__ __launch_bounds__(kRadixItems) void k_radix_scatter(const int* __restrict__ key_in, const V* __restrict__ val_in,
+                                                                int n, int shift, int nbins, int nblk,
+                                                                const int* __restrict__ offs, int* __restrict__ key_out,
+                                                                V* __restrict__ val_out) {
+    __shared__ int dg[kRadixItems];
+    const int i = blockIdx.x * kRadixItems + threadIdx.x;
+    int k = 0, d = -1;
+    if (i < n) {
+        k = key_in[i];
+        d = (k >> shift) & (nbins - 1);
+    }
+    dg[threadIdx.x] = d;
+    __syncthreads();
+    if (i >= n) return;
+    int rank = 0;
+    for (int t = 0; t < (int)threadIdx.x; ++t) rank += dg[t] == d ? 1 : 0;
+    const int pos = offs[(size_t)d * nblk + blockIdx.x] + rank;
+    key_out[pos] = k;
+    val_out[pos] = val_in[i];
+}
+
+// out[q] = first position in the sorted key list with key >= q, for q = 0 .. nq (out has nq + 1 entries)
+__global__ void k_lower_bounds(const int* __restrict__ key, int n, int nq, int* __restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q > nq) return;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    out[q] = lo;
+}
+
+__global__ void k_iota(int n, int* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+__global__ void k_split_st(int n, const int2* __restrict__ st, int* __restrict__ pi, int* __restrict__ pj) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { pi[i] = st[i].x; pj[i] = st[i].y; }
+}
+
+__global__ void k_plan_blocks(int P, int* __restrict__ blk_a, int* __restrict__ blk_b, int* __restrict__ blk_odo) {
+    const int a = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P || b < a) return;
+    const int q = blk_index_of(P, a, b);
+    blk_a[q] = a;
+    blk_b[q] = b;
+    blk_odo[q] = -1;
+}
+// PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan (the host checked: no self loops, no
+// duplicates; otherwise the edges take the k_odometry / k_reduce_odo fallback and this kernel is not launched)
+__global__ void k_plan_odo(int P, int O, const int* __restrict__ o_i, const int* __restrict__ o_j, int* __restrict__ blk_odo) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= O) return;
+    const int i = o_i[k], j = o_j[k];
+    blk_odo[blk_index_of(P, min(i, j), max(i, j))] = 2 * k + (i > j ? 1 : 0);
+}
+
+// Packing of the off-diagonal blocks' 16-pair chunks ("groups") into workgroups of kGrpPerWG groups, exactly as the
+// sequential host loop does it (a block never straddles a workgroup; a block that does not fit closes the current
+// workgroup), but as a scan: the blocks are cut into 256 runs; a run's effect on the fill state `used` (0..27) is a
+// function {used -> (used', workgroups closed)}, tabulated by one thread for all 28 start states; one thread composes
+// the 256 tables; every thread then replays its run from its now known start and writes the group descriptors.
+// out_n[0] = number of workgroups.
+__device__ inline void pack_step(int cnt, int& used, int& wg, int& first, int& ng, int& chunk) {
+    chunk = kChunk;
+    ng = max(1, (cnt + chunk - 1) / chunk);
+    if (ng > kGrpPerWG) { chunk = (cnt + kGrpPerWG - 1) / kGrpPerWG; ng = (cnt + chunk - 1) / chunk; }
+    if (used + ng > kGrpPerWG) { ++wg; used = 0; }   // flush(): pad the current workgroup
+    first = used;
+    used += ng;
+}
+__global__ __launch_bounds__(256) void k_plan_pack(int nblk, const int* __restrict__ blk_a, const int* __restrict__ blk_b,
+                                                    const int* __restrict__ blk_ptr, int4* __restrict__ grp,
+                                                    int grp_cap_wg, int* __restrict__ out_n) {
+    __shared__ int tab_used[256][kGrpPerWG], tab_wg[256][kGrpPerWG];
+    __shared__ int start_used[256], start_wg[256];
+    const int t = threadIdx.x;
+    const int per = (nblk + 255) / 256;
+    const int b0 = min(t * per, nblk), b1 = min(b0 + per, nblk);
+    {   // the run's transfer function for all 28 start states in ONE pass over its blocks
+        int used[kGrpPerWG], wgs[kGrpPerWG];
+#pragma unroll
+        for (int u = 0; u < kGrpPerWG; ++u) { used[u] = u; wgs[u] = 0; }
+        for (int kb = b0; kb < b1; ++kb) {
+            if (blk_a[kb] == blk_b[kb]) continue;
+            const int cnt = blk_ptr[kb + 1] - blk_ptr[kb];
+            int ng = max(1, (cnt + kChunk - 1) / kChunk);
+            if (ng > kGrpPerWG) { const int chunk = (cnt + kGrpPerWG - 1) / kGrpPerWG; ng = (cnt + chunk - 1) / chunk; }
+#pragma unroll
+            for (int u = 0; u < kGrpPerWG; ++u) {
+                if (used[u] + ng > kGrpPerWG) { ++wgs[u]; used[u] = 0; }
+                used[u] += ng;
+                if (used[u] == kGrpPerWG) { used[u] = 0; ++wgs[u]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kGrpPerWG; ++u) { tab_used[t][u] = used[u]; tab_wg[t][u] = wgs[u]; }
+    }
+    __syncthreads();
+    if (t == 0) {
+        int used = 0, wg = 0;
+        for (int r = 0; r < 256; ++r) {
+            start_used[r] = used;
+            start_wg[r] = wg;
+            wg += tab_wg[r][used];
+            used = tab_used[r][used];
+        }
+        out_n[0] = wg + (used ? 1 : 0);
+    }
+    __syncthreads();
+    int used = start_used[t], wg = start_wg[t];
+    for (int kb = b0; kb < b1; ++kb) {
+        if (blk_a[kb] == blk_b[kb]) continue;
+        const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
+        int first, ng, chunk;
+        pack_step(q1 - q0, used, wg, first, ng, chunk);
+        if (wg < grp_cap_wg)
+            for (int g = 0; g < ng; ++g) {
+                const int a0 = q0 + g * chunk, a1 = min(q1, a0 + chunk);
+                grp[(size_t)wg * kGrpPerWG + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
+            }
+        if (used == kGrpPerWG) { used = 0; ++wg; }
+    }
+}
+__global__ void k_fill_int4(size_t n, int4 v, int4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
+
+// The host builder of the contributor plan: the reference implementation of the device kernels above and the fallback
+// for graphs they do not take (more than 1024 poses; SE2GPU_BA_PLAN=host).  Edges are already sorted by landmark.
+struct HostPlan {
+    std::vector<int> lm_ptr, pose_ptr, pose_edges, blk_a, blk_b, blk_odo, pair_i, pair_j;
+    std::vector<int4> grp;
+    int nwg_off = 0;
+};
+void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const uint8_t* fx, int O, const int* o_i,
+                  const int* o_j, bool odo_ok, HostPlan& pl) {
+    pl.lm_ptr.assign(L + 1, 0);
+    for (int s = 0; s < E; ++s) pl.lm_ptr[e_lm[s] + 1]++;
+    for (int l = 0; l < L; ++l) pl.lm_ptr[l + 1] += pl.lm_ptr[l];
+    const std::vector<int>& lm_ptr = pl.lm_ptr;
+    // --- pose -> edges CSR
+    pl.pose_ptr.assign(P + 1, 0);
+    pl.pose_edges.resize(E);
+    for (int s = 0; s < E; ++s) pl.pose_ptr[e_kf[s] + 1]++;
+    for (int p = 0; p < P; ++p) pl.pose_ptr[p + 1] += pl.pose_ptr[p];
+    {
+        std::vector<int> f(pl.pose_ptr.begin(), pl.pose_ptr.end() - 1);
+        for (int s = 0; s < E; ++s) pl.pose_edges[f[e_kf[s]]++] = s;
+    }
+    // --- reduced-system block plan: upper-triangular (a <= b) blocks, contributor pairs per block
+    const int nblk = P * (P + 1) / 2;
+    std::vector<int> blk_ptr(nblk + 1, 0);
+    pl.blk_a.resize(nblk);
+    pl.blk_b.resize(nblk);
+    for (int a = 0; a < P; ++a)
+        for (int b = a; b < P; ++b) {
+            pl.blk_a[blk_index_of(P, a, b)] = a;
+            pl.blk_b[blk_index_of(P, a, b)] = b;
+        }
+    // every unordered pair of observations of a landmark by two different free poses contributes to one block; the pair
+    // is stored with the lower pose first.  Pass 1 records the block of each pair (in landmark order), pass 2 scatters.
+    std::vector<int> pkey;
+    std::vector<int2> pst;
+    pkey.reserve(4 * (size_t)E);
+    pst.reserve(4 * (size_t)E);
+    for (int l = 0; l < L; ++l)
+        for (int s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
+            const int a = e_kf[s];
+            if (fx[a]) continue;
+            for (int t = s + 1; t < lm_ptr[l + 1]; ++t) {
+                const int b = e_kf[t];
+                if (fx[b] || a == b) continue;
+                const int q = a < b ? blk_index_of(P, a, b) : blk_index_of(P, b, a);
+                pkey.push_back(q);
+                pst.push_back(a < b ? make_int2(s, t) : make_int2(t, s));
+                blk_ptr[q + 1]++;
+            }
+        }
+    for (int k = 0; k < nblk; ++k) blk_ptr[k + 1] += blk_ptr[k];
+    const size_t npairs = (size_t)blk_ptr[nblk];
+    pl.pair_i.resize(npairs);
+    pl.pair_j.resize(npairs);
+    {
+        std::vector<int> f(blk_ptr.begin(), blk_ptr.end() - 1);
+        for (size_t k = 0; k < pkey.size(); ++k) {
+            const int q = f[pkey[k]]++;
+            pl.pair_i[q] = pst[k].x;
+            pl.pair_j[q] = pst[k].y;
+        }
+    }
+    pl.blk_odo.assign(nblk, -1);
+    if (odo_ok)
+        for (int k = 0; k < O; ++k) {
+            const int i = o_i[k], j = o_j[k];
+            pl.blk_odo[blk_index_of(P, std::min(i, j), std::max(i, j))] = 2 * k + (i > j ? 1 : 0);
+        }
+    // pack 16-pair chunks of the off-diagonal blocks into workgroups of 28 nine-lane groups
+    std::vector<int4>& grp = pl.grp;
+    grp.clear();
+    int used = 0;  // groups used in the current workgroup
+    auto flush = [&]() {
+        while (used % kGrpPerWG) { grp.push_back(make_int4(-1, 0, 0, 0)); ++used; }
+        used = 0;
+    };
+    for (int kb = 0; kb < nblk; ++kb) {
+        if (pl.blk_a[kb] == pl.blk_b[kb]) continue;
+        const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
+        int chunk = kChunk;
+        int ng = std::max(1, (q1 - q0 + chunk - 1) / chunk);
+        if (ng > kGrpPerWG) { chunk = (q1 - q0 + kGrpPerWG - 1) / kGrpPerWG; ng = (q1 - q0 + chunk - 1) / chunk; }
+        if (used + ng > kGrpPerWG) flush();
+        const int first = used;
+        for (int t = 0; t < ng; ++t) {
+            const int a0 = q0 + t * chunk, a1 = std::min(q1, a0 + chunk);
+            grp.push_back(make_int4(kb, a0, std::max(a0, a1), first | (ng << 8)));
+            ++used;
+        }
+        if (used == kGrpPerWG) used = 0;
+    }
+    flush();
+    if (grp.empty()) grp.assign(kGrpPerWG, make_int4(-1, 0, 0, 0));
+    pl.nwg_off = (int)(grp.size() / kGrpPerWG);
+}
+
 int ba_upload_graph(se2gpu_ba* h) {
     static const bool trace = [] { const char* e = getenv("SE2GPU_BA_INIT_TRACE"); return e && e[0] == '1'; }();
     const auto t_begin = std::chrono::steady_clock::now();
@@ -1677,40 +2027,51 @@ int ba_upload_graph(se2gpu_ba* h) {
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
     const int P = (int)h->pose_ids.size(), L = (int)h->lm_ids.size();
-    const int E = (int)h->obs.size(), O = (int)h->odo.size();
+    const int E = (int)h->he_kf.size(), O = (int)h->odo.size();
     SE2_REQUIRE(P > 0, SE2GPU_ERR_STATE, "initialize: no pose vertices");
     SE2_REQUIRE(h->have_cam, SE2GPU_ERR_STATE, "initialize: add_cam was not called");
+    SE2_REQUIRE(!h->huber_mixed, SE2GPU_ERR_INVALID, "all EdgeSE2XYZ must share one Huber delta (Map.cpp:977)");
     h->P = P; h->L = L; h->E = E; h->O = O;
-    double delta = E ? h->obs[0].huber : 0.0;
-    for (const auto& e : h->obs)
-        SE2_REQUIRE(e.huber == delta, SE2GPU_ERR_INVALID, "all EdgeSE2XYZ must share one Huber delta (Map.cpp:977)");
-    h->cam.huber = delta;
+    h->cam.huber = E ? h->huber_delta : 0.0;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) h->cam.Rcb[i * 3 + j] = h->Rbc[j * 3 + i];
     for (int i = 0; i < 3; ++i)
         h->cam.tcb[i] = -(h->cam.Rcb[i * 3] * h->tbc[0] + h->cam.Rcb[i * 3 + 1] * h->tbc[1] + h->cam.Rcb[i * 3 + 2] * h->tbc[2]);
 
-    // --- sort observation edges by landmark (stable counting sort)
-    std::vector<int> lm_ptr(L + 1, 0);
-    for (const auto& e : h->obs) lm_ptr[e.lm + 1]++;
-    for (int l = 0; l < L; ++l) lm_ptr[l + 1] += lm_ptr[l];
-    std::vector<int> fill(lm_ptr.begin(), lm_ptr.end() - 1), e_kf(E), e_lm(E);
-    std::vector<double> e_uv(2 * (size_t)E), e_info(3 * (size_t)E);
-    for (const auto& e : h->obs) {
-        const int s = fill[e.lm]++;
-        e_kf[s] = e.kf; e_lm[s] = e.lm;
-        e_uv[2 * s] = e.uv[0]; e_uv[2 * s + 1] = e.uv[1];
-        e_info[3 * s] = e.info[0]; e_info[3 * s + 1] = e.info[1]; e_info[3 * s + 2] = e.info[2];
+    // --- observation edges sorted by landmark.  Map::loadLocalGraph adds them map point by map point, i.e. already in
+    // order: one pass checks that (and sums the pairs per landmark for the buffer sizes); otherwise a stable counting sort.
+    const int* e_kf = h->he_kf.data();
+    const int* e_lm = h->he_lm.data();
+    const double* e_uv = h->he_uv.data();
+    const double* e_info = h->he_info.data();
+    std::vector<int> s_kf, s_lm;
+    std::vector<double> s_uv, s_info;
+    bool sorted = true;
+    for (int k = 1; k < E; ++k)
+        if (e_lm[k] < e_lm[k - 1]) { sorted = false; break; }
+    if (!sorted) {
+        std::vector<int> ptr(L + 1, 0);
+        for (int k = 0; k < E; ++k) ptr[e_lm[k] + 1]++;
+        for (int l = 0; l < L; ++l) ptr[l + 1] += ptr[l];
+        s_kf.resize(E); s_lm.resize(E); s_uv.resize(2 * (size_t)E); s_info.resize(3 * (size_t)E);
+        for (int k = 0; k < E; ++k) {
+            const int t = ptr[e_lm[k]]++;
+            s_kf[t] = e_kf[k]; s_lm[t] = e_lm[k];
+            s_uv[2 * (size_t)t] = e_uv[2 * (size_t)k]; s_uv[2 * (size_t)t + 1] = e_uv[2 * (size_t)k + 1];
+            for (int c = 0; c < 3; ++c) s_info[3 * (size_t)t + c] = e_info[3 * (size_t)k + c];
+        }
+        e_kf = s_kf.data(); e_lm = s_lm.data(); e_uv = s_uv.data(); e_info = s_info.data();
     }
-    // --- pose -> edges CSR
-    std::vector<int> pose_ptr(P + 1, 0), pose_edges(E);
-    for (int s = 0; s < E; ++s) pose_ptr[e_kf[s] + 1]++;
-    for (int p = 0; p < P; ++p) pose_ptr[p + 1] += pose_ptr[p];
-    {
-        std::vector<int> f(pose_ptr.begin(), pose_ptr.end() - 1);
-        for (int s = 0; s < E; ++s) pose_edges[f[e_kf[s]]++] = s;
+    size_t npairs_max = 0;   // pairs of observations per landmark (an upper bound of the plan's pairs: fixed poses drop out)
+    for (int k = 0; k < E;) {
+        int t = k + 1;
+        while (t < E && e_lm[t] == e_lm[k]) ++t;
+        const size_t d = (size_t)(t - k);
+        npairs_max += d * (d - 1) / 2;
+        k = t;
     }
-    // --- odometry
+    SE2_REQUIRE(npairs_max < (size_t)1 << 30, SE2GPU_ERR_CAPACITY, "the contributor plan would hold %zu pairs", npairs_max);
+    // --- odometry (tiny: host)
     std::vector<int> o_i(O), o_j(O), podo_ptr(P + 1, 0), podo_item(2 * (size_t)O);
     std::vector<double> o_meas(3 * (size_t)O), o_info(9 * (size_t)O);
     for (int k = 0; k < O; ++k) {
@@ -1728,127 +2089,76 @@ int ba_upload_graph(se2gpu_ba* h) {
             podo_item[f[o_j[k]]++] = 2 * k + 1;
         }
     }
-    lap("edge sort + CSR");
-    // --- reduced-system block plan: upper-triangular (a <= b) blocks, contributor pairs per block
-    const int nblk = P * (P + 1) / 2;
-    auto blk_index = [P](int a, int b) { return a * P - a * (a - 1) / 2 + (b - a); };
-    std::vector<int> blk_a(nblk), blk_b(nblk), blk_ptr(nblk + 1, 0);
-    for (int a = 0; a < P; ++a)
-        for (int b = a; b < P; ++b) {
-            blk_a[blk_index(a, b)] = a;
-            blk_b[blk_index(a, b)] = b;
-        }
-    const std::vector<uint8_t>& fx = h->h_fixed;
-    // every unordered pair of observations of a landmark by two different free poses contributes to one block; the pair
-    // is stored with the lower pose first.  Pass 1 records the block of each pair (in landmark order), pass 2 scatters.
-    std::vector<int> pkey;
-    std::vector<int2> pst;
-    pkey.reserve(4 * (size_t)E);
-    pst.reserve(4 * (size_t)E);
-    for (int l = 0; l < L; ++l)
-        for (int s = lm_ptr[l]; s < lm_ptr[l + 1]; ++s) {
-            const int a = e_kf[s];
-            if (fx[a]) continue;
-            for (int t = s + 1; t < lm_ptr[l + 1]; ++t) {
-                const int b = e_kf[t];
-                if (fx[b] || a == b) continue;
-                const int q = a < b ? blk_index(a, b) : blk_index(b, a);
-                pkey.push_back(q);
-                pst.push_back(a < b ? make_int2(s, t) : make_int2(t, s));
-                blk_ptr[q + 1]++;
-            }
-        }
-    for (int k = 0; k < nblk; ++k) blk_ptr[k + 1] += blk_ptr[k];
-    const size_t npairs = (size_t)blk_ptr[nblk];
-    std::vector<int> pair_i(npairs), pair_j(npairs);
-    {
-        std::vector<int> f(blk_ptr.begin(), blk_ptr.end() - 1);
-        for (size_t k = 0; k < pkey.size(); ++k) {
-            const int q = f[pkey[k]]++;
-            pair_i[q] = pst[k].x;
-            pair_j[q] = pst[k].y;
-        }
-    }
-    lap("pair lists");
-    h->nblk = nblk;
-    // PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan; duplicates fall back
-    std::vector<int> blk_odo(nblk, -1);
+    // PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan; self loops / duplicates fall back
     h->odo_fallback = false;
-    for (int k = 0; k < O; ++k) {
-        const int i = o_i[k], j = o_j[k];
-        if (i == j) { h->odo_fallback = true; continue; }
-        const int q = blk_index(std::min(i, j), std::max(i, j));
-        if (blk_odo[q] >= 0) h->odo_fallback = true;
-        blk_odo[q] = 2 * k + (i > j ? 1 : 0);
-    }
-    if (h->odo_fallback) std::fill(blk_odo.begin(), blk_odo.end(), -1);
-    // pack 16-pair chunks of the off-diagonal blocks into workgroups of 28 nine-lane groups
-    std::vector<int4> grp;
     {
-        int used = 0;  // groups used in the current workgroup
-        auto flush = [&]() {
-            while (used % kGrpPerWG) { grp.push_back(make_int4(-1, 0, 0, 0)); ++used; }
-            used = 0;
-        };
-        for (int kb = 0; kb < nblk; ++kb) {
-            if (blk_a[kb] == blk_b[kb]) continue;
-            const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
-            int chunk = kChunk;
-            int ng = std::max(1, (q1 - q0 + chunk - 1) / chunk);
-            if (ng > kGrpPerWG) { chunk = (q1 - q0 + kGrpPerWG - 1) / kGrpPerWG; ng = (q1 - q0 + chunk - 1) / chunk; }
-            if (used + ng > kGrpPerWG) flush();
-            const int first = used;
-            for (int t = 0; t < ng; ++t) {
-                const int a0 = q0 + t * chunk, a1 = std::min(q1, a0 + chunk);
-                grp.push_back(make_int4(kb, a0, std::max(a0, a1), first | (ng << 8)));
-                ++used;
-            }
-            if (used == kGrpPerWG) used = 0;
+        std::vector<std::pair<int, int>> seen(O);
+        for (int k = 0; k < O; ++k) {
+            if (o_i[k] == o_j[k]) h->odo_fallback = true;
+            seen[k] = {std::min(o_i[k], o_j[k]), std::max(o_i[k], o_j[k])};
         }
-        flush();
-        if (grp.empty()) grp.assign(kGrpPerWG, make_int4(-1, 0, 0, 0));
+        std::sort(seen.begin(), seen.end());
+        for (int k = 1; k < O; ++k)
+            if (seen[k] == seen[k - 1]) h->odo_fallback = true;
     }
-    h->nwg_off = (int)(grp.size() / kGrpPerWG);
-    lap("workgroup packing");
+    const int nblk = P * (P + 1) / 2;
+    h->nblk = nblk;
+    const char* plan_env = getenv("SE2GPU_BA_PLAN");
+    const bool device_plan = P <= 1024 && !(plan_env && std::strcmp(plan_env, "host") == 0);
+    lap("edge check + odometry");
+    HostPlan pl;
+    if (!device_plan) {
+        ba_plan_host(P, L, E, e_kf, e_lm, h->h_fixed.data(), O, o_i.data(), o_j.data(), !h->odo_fallback, pl);
+        h->nwg_off = pl.nwg_off;
+        lap("host plan");
+    }
     hipStream_t st = h->stream;
     const int n = 3 * P;
-    // All graph arrays go through ONE pinned arena: a copy from pageable memory is staged synchronously by the runtime
-    // (about 20 us each), 23 of them were most of initializeOptimization for a local window.
-    struct Staged { void* dst; const void* src; size_t bytes; };
+    // All uploads go through ONE pinned arena into ONE device arena with ONE copy (a copy from pageable memory is staged
+    // synchronously by the runtime, about 20 us each; two dozen separate enqueues were a tenth of a local window's cycle).
+    struct Staged { std::function<void(uint8_t*)> bind; const void* src; size_t bytes, off; };
     std::vector<Staged> staged;
     size_t staged_bytes = 0;
-    auto stage = [&](auto& buf, const auto& vec) -> int {
-        SE2_CHECK(buf.reserve(vec.size()));
-        const size_t bytes = vec.size() * sizeof(vec[0]);
-        if (bytes) {
-            staged.push_back(Staged{buf.p, vec.data(), bytes});
-            staged_bytes += (bytes + 63) & ~(size_t)63;
-        }
-        return SE2GPU_OK;
+    auto stage = [&](auto& buf, const auto* src, size_t count) {
+        using T = std::remove_reference_t<decltype(*buf.p)>;
+        const size_t bytes = count * sizeof(T);
+        auto* bp = &buf;
+        staged.push_back(Staged{[bp](uint8_t* base) { bp->alias(reinterpret_cast<T*>(base)); }, src, bytes, staged_bytes});
+        staged_bytes += (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
     };
-    SE2_CHECK(stage(h->grp, grp));
-    SE2_CHECK(stage(h->poses0, h->h_poses));
-    SE2_CHECK(stage(h->lms0, h->h_lms));
-    SE2_CHECK(stage(h->fixed, h->h_fixed));
-    SE2_CHECK(stage(h->lm_ptr, lm_ptr));
-    SE2_CHECK(stage(h->e_kf, e_kf));
-    SE2_CHECK(stage(h->e_lm, e_lm));
-    SE2_CHECK(stage(h->e_uv, e_uv));
-    SE2_CHECK(stage(h->e_info, e_info));
-    SE2_CHECK(stage(h->pose_ptr, pose_ptr));
-    SE2_CHECK(stage(h->pose_edges, pose_edges));
-    SE2_CHECK(stage(h->podo_ptr, podo_ptr));
-    SE2_CHECK(stage(h->podo_item, podo_item));
-    SE2_CHECK(stage(h->o_i, o_i));
-    SE2_CHECK(stage(h->o_j, o_j));
-    SE2_CHECK(stage(h->o_meas, o_meas));
-    SE2_CHECK(stage(h->o_info, o_info));
-    SE2_CHECK(stage(h->blk_a, blk_a));
-    SE2_CHECK(stage(h->blk_b, blk_b));
-    SE2_CHECK(stage(h->blk_ptr, blk_ptr));
-    SE2_CHECK(stage(h->blk_odo, blk_odo));
-    SE2_CHECK(stage(h->pair_i, pair_i));
-    SE2_CHECK(stage(h->pair_j, pair_j));
+    stage(h->poses0, h->h_poses.data(), h->h_poses.size());
+    stage(h->lms0, h->h_lms.data(), h->h_lms.size());
+    stage(h->fixed, h->h_fixed.data(), h->h_fixed.size());
+    stage(h->e_kf, e_kf, (size_t)E);
+    stage(h->e_lm, e_lm, (size_t)E);
+    stage(h->e_uv, e_uv, 2 * (size_t)E);
+    stage(h->e_info, e_info, 3 * (size_t)E);
+    stage(h->podo_ptr, podo_ptr.data(), podo_ptr.size());
+    stage(h->podo_item, podo_item.data(), podo_item.size());
+    stage(h->o_i, o_i.data(), o_i.size());
+    stage(h->o_j, o_j.data(), o_j.size());
+    stage(h->o_meas, o_meas.data(), o_meas.size());
+    stage(h->o_info, o_info.data(), o_info.size());
+    if (h->lg_active) {
+        SE2_REQUIRE(sorted && h->lg_sigma2.size() == (size_t)E, SE2GPU_ERR_STATE,
+                    "load_local_graph must not be mixed with add_edge calls");
+        stage(h->d_lg_lc, h->lg_lc.data(), h->lg_lc.size());
+        stage(h->d_lg_lw, h->lg_lw.data(), h->lg_lw.size());
+        stage(h->d_lg_sigma2, h->lg_sigma2.data(), h->lg_sigma2.size());
+        stage(h->d_lg_Rcw, h->lg_Rcw.data(), h->lg_Rcw.size());
+        stage(h->d_lg_twb, h->lg_twb.data(), h->lg_twb.size());
+    }
+    if (!device_plan) {
+        stage(h->grp, pl.grp.data(), pl.grp.size());
+        stage(h->lm_ptr, pl.lm_ptr.data(), pl.lm_ptr.size());
+        stage(h->pose_ptr, pl.pose_ptr.data(), pl.pose_ptr.size());
+        stage(h->pose_edges, pl.pose_edges.data(), pl.pose_edges.size());
+        stage(h->blk_a, pl.blk_a.data(), pl.blk_a.size());
+        stage(h->blk_b, pl.blk_b.data(), pl.blk_b.size());
+        stage(h->blk_odo, pl.blk_odo.data(), pl.blk_odo.size());
+        stage(h->pair_i, pl.pair_i.data(), pl.pair_i.size());
+        stage(h->pair_j, pl.pair_j.data(), pl.pair_j.size());
+    }
     SE2_CHECK(h->poses_a.reserve(3 * (size_t)P));
     SE2_CHECK(h->poses_b.reserve(3 * (size_t)P));
     SE2_CHECK(h->lms_a.reserve(3 * (size_t)L + 1));
@@ -1887,29 +2197,106 @@ int ba_upload_graph(se2gpu_ba* h) {
         SE2_CHECK(h->red_own.reserve(nred));
         h->red = h->red_own.p;
     }
-    SE2_CHECK(h->h_red.reserve(nred));
+    if (h->host_solve) SE2_CHECK(h->h_red.reserve(nred));
     SE2_CHECK(h->Rinv.reserve(3 * (size_t)h->ld * h->ld));  // R | AM | RM (the last two: k_chol_tiles only)
+    const int nt = h->ld / kNB, nbc = (n + kNB - 1) / kNB;
+    std::vector<int2> tasks;
+    for (int j = 0; j < nbc; ++j) {
+        for (int i = j; i < nt; ++i) tasks.push_back(make_int2(i, j));
+        for (int r = 0; r < j; ++r) tasks.push_back(make_int2(r | (1 << 16), j));
+    }
+    h->chol_ntask = (int)tasks.size();
+    stage(h->chol_tasks, tasks.data(), tasks.size());
+    lap("reserve");
+    SE2_CHECK(h->h_stage.reserve(staged_bytes));
+    SE2_CHECK(h->garena.reserve(staged_bytes));
+    for (const Staged& sg : staged) {
+        if (sg.bytes) std::memcpy(h->h_stage.p + sg.off, sg.src, sg.bytes);
+        sg.bind(h->garena.p + sg.off);
+    }
+    SE2_HIP(hipMemcpyAsync(h->garena.p, h->h_stage.p, staged_bytes, hipMemcpyHostToDevice, st));
+    lap("staging + enqueue");
+    if (h->lg_active && E)
+        hipLaunchKernelGGL(k_edge_information, grid1(E, 256), dim3(256), 0, st, E, h->d_lg_lc.p, h->d_lg_lw.p, h->e_kf.p,
+                           h->d_lg_sigma2.p, h->d_lg_Rcw.p, h->d_lg_twb.p, h->lg_fx, h->lg_srot, h->lg_sz, h->e_info.p, 1);
+    if (device_plan) {
+        // ---- the plan, built where it is used
+        const int Pb = std::max(1, (int)std::ceil(std::log2((double)std::max(P, 2))));          // bits of a pose index
+        const int Qb = std::max(2, (int)std::ceil(std::log2((double)nblk + 2.0)));               // bits of a block key (and of nblk, the tail key)
+        const int qlo = (Qb + 1) / 2, qhi = Qb - qlo;                                            // two passes, <= 10 bits each
+        SE2_REQUIRE(qlo <= 10 && Pb <= 10, SE2GPU_ERR_CAPACITY, "device plan: %d poses", P);
+        const size_t NP = std::max<size_t>(npairs_max, 1);
+        const int nblkE = (int)((E + kRadixItems - 1) / kRadixItems), nblkP = (int)((NP + kRadixItems - 1) / kRadixItems);
+        SE2_CHECK(h->lm_ptr.reserve((size_t)L + 2));
+        SE2_CHECK(h->pose_ptr.reserve((size_t)P + 2));
+        SE2_CHECK(h->pose_edges.reserve((size_t)E + 1));
+        SE2_CHECK(h->blk_a.reserve(nblk));
+        SE2_CHECK(h->blk_b.reserve(nblk));
+        SE2_CHECK(h->blk_odo.reserve(nblk));
+        SE2_CHECK(h->blk_ptr.reserve((size_t)nblk + 2));
+        SE2_CHECK(h->pair_i.reserve(NP));
+        SE2_CHECK(h->pair_j.reserve(NP));
+        SE2_CHECK(h->plan_np.reserve((size_t)L + 2));
+        SE2_CHECK(h->plan_base.reserve((size_t)L + 2));
+        SE2_CHECK(h->plan_key0.reserve(std::max<size_t>(NP, (size_t)E + 1)));
+        SE2_CHECK(h->plan_key1.reserve(std::max<size_t>(NP, (size_t)E + 1)));
+        SE2_CHECK(h->plan_st0.reserve(NP));
+        SE2_CHECK(h->plan_st1.reserve(NP));
+        SE2_CHECK(h->plan_idx.reserve((size_t)E + 1));
+        const size_t nhist = (size_t)1024 * std::max(nblkE, nblkP) + 2;
+        SE2_CHECK(h->plan_hist.reserve(nhist));
+        SE2_CHECK(h->plan_offs.reserve(nhist));
+        SE2_CHECK(h->plan_out.reserve(8));
+        // groups <= pairs / 16 + off-diagonal blocks; two consecutive workgroups hold more than 28 groups together
+        const size_t G = npairs_max / kChunk + (size_t)P * (P - 1) / 2 + 1;
+        const int cap_wg = (int)std::min<size_t>((size_t)P * (P - 1) / 2 + 1, 2 * G / kGrpPerWG + 2) + 1;
+        SE2_CHECK(h->grp.reserve((size_t)cap_wg * kGrpPerWG));
+        h->grp_cap_wg = cap_wg;
+        auto radix = [&](const int* kin, int* kout, auto* vin, auto* vout, size_t cnt, int shift, int bits) -> int {
+            using V = std::remove_pointer_t<decltype(vout)>;
+            const int nb = (int)((cnt + kRadixItems - 1) / kRadixItems), bins = 1 << bits;
+            hipLaunchKernelGGL(k_radix_hist, dim3(std::max(nb, 1)), dim3(kRadixItems), 0, st, kin, (int)cnt, shift, bins, nb,
+                               h->plan_hist.p);
+            hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_hist.p, h->plan_offs.p, bins * nb);
+            hipLaunchKernelGGL((k_radix_scatter<V>), dim3(std::max(nb, 1)), dim3(kRadixItems), 0, st, kin, (const V*)vin,
+                               (int)cnt, shift, bins, nb, h->plan_offs.p, kout, vout);
+            return SE2GPU_OK;
+        };
+        // landmark CSR + pairs per landmark, their prefix sums
+        hipLaunchKernelGGL(k_plan_lm, grid1((size_t)L + 1, 256), dim3(256), 0, st, L, E, h->e_lm.p, h->e_kf.p, h->fixed.p,
+                           h->lm_ptr.p, h->plan_np.p);
+        hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_np.p, h->plan_base.p, L);
+        // pose -> edges CSR: edge indices stably sorted by key frame (one pass)
+        hipLaunchKernelGGL(k_iota, grid1(E, 256), dim3(256), 0, st, E, h->plan_idx.p);
+        if (E) SE2_CHECK(radix(h->e_kf.p, h->plan_key0.p, h->plan_idx.p, h->pose_edges.p, (size_t)E, 0, Pb));
+        hipLaunchKernelGGL(k_lower_bounds, grid1((size_t)P + 1, 256), dim3(256), 0, st, h->plan_key0.p, E, P, h->pose_ptr.p);
+        // contributor pairs, stably sorted by block key (two passes)
+        hipLaunchKernelGGL(k_plan_pairs, grid1(L, 256), dim3(256), 0, st, L, P, h->lm_ptr.p, h->e_kf.p, h->fixed.p,
+                           h->plan_base.p, h->plan_key0.p, h->plan_st0.p);
+        // the number of pairs is plan_base[L] - only the device knows it; the sort runs over the host's upper bound with
+        // the tail keyed past every block, where it stays (stable) and is never referenced
+        hipLaunchKernelGGL(k_plan_tail, grid1(NP, 256), dim3(256), 0, st, h->plan_base.p + L, (int)NP, nblk, h->plan_key0.p);
+        SE2_CHECK(radix(h->plan_key0.p, h->plan_key1.p, h->plan_st0.p, h->plan_st1.p, NP, 0, qlo));
+        SE2_CHECK(radix(h->plan_key1.p, h->plan_key0.p, h->plan_st1.p, h->plan_st0.p, NP, qlo, std::max(qhi, 1)));
+        hipLaunchKernelGGL(k_lower_bounds, grid1((size_t)nblk + 1, 256), dim3(256), 0, st, h->plan_key0.p, (int)NP, nblk,
+                           h->blk_ptr.p);
+        hipLaunchKernelGGL(k_split_st, grid1(NP, 256), dim3(256), 0, st, (int)NP, h->plan_st0.p, h->pair_i.p, h->pair_j.p);
+        hipLaunchKernelGGL(k_plan_blocks, dim3((P + 255) / 256, P), dim3(256), 0, st, P, h->blk_a.p, h->blk_b.p, h->blk_odo.p);
+        if (O && !h->odo_fallback)
+            hipLaunchKernelGGL(k_plan_odo, grid1(O, 64), dim3(64), 0, st, P, O, h->o_i.p, h->o_j.p, h->blk_odo.p);
+        hipLaunchKernelGGL(k_fill_int4, grid1((size_t)cap_wg * kGrpPerWG, 256), dim3(256), 0, st, (size_t)cap_wg * kGrpPerWG,
+                           make_int4(-1, 0, 0, 0), h->grp.p);
+        hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(256), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->grp.p,
+                           cap_wg, h->plan_out.p);
+        SE2_HIP(hipGetLastError());
+        SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
+        SE2_HIP(hipMemcpyAsync(h->h_scal.p, h->plan_out.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        lap("plan kernels enqueued");
+    }
+    SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
+    SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
+    h->chol_epoch = 0;
     {
-        const int nt = h->ld / kNB, nbc = (n + kNB - 1) / kNB;
-        std::vector<int2> tasks;
-        for (int j = 0; j < nbc; ++j) {
-            for (int i = j; i < nt; ++i) tasks.push_back(make_int2(i, j));
-            for (int r = 0; r < j; ++r) tasks.push_back(make_int2(r | (1 << 16), j));
-        }
-        h->chol_ntask = (int)tasks.size();
-        SE2_CHECK(stage(h->chol_tasks, tasks));
-        lap("reserve");
-        SE2_CHECK(h->h_stage.reserve(staged_bytes));
-        size_t off = 0;
-        for (const Staged& sg : staged) {
-            std::memcpy(h->h_stage.p + off, sg.src, sg.bytes);
-            SE2_HIP(hipMemcpyAsync(sg.dst, h->h_stage.p + off, sg.bytes, hipMemcpyHostToDevice, st));
-            off += (sg.bytes + 63) & ~(size_t)63;
-        }
-        lap("staging + enqueue");
-        SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
-        SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
-        h->chol_epoch = 0;
         const char* env = getenv("SE2GPU_BA_CHOL");
         h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt > 64;
         const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
@@ -1921,27 +2308,29 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_CHECK(h->h_x.reserve(n));
     SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
     if (!h->h_mail) {
-        const char* env = getenv("SE2GPU_BA_MAILBOX");
-        if (!(env && env[0] == '0')) {
-            SE2_HIP(hipHostMalloc((void**)&h->h_mail, kMailDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(h->h_mail, 0, kMailDoubles * sizeof(double));
-            SE2_HIP(hipHostGetDevicePointer((void**)&h->d_mail, h->h_mail, 0));
-            h->h_stop = reinterpret_cast<volatile int*>(h->h_mail + kMailStop);
-            h->d_stop = reinterpret_cast<int*>(h->d_mail + kMailStop);
-        }
+        SE2_HIP(hipHostMalloc((void**)&h->h_mail, kMailDoubles * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->h_mail, 0, kMailDoubles * sizeof(double));
+        SE2_HIP(hipHostGetDevicePointer((void**)&h->d_mail, h->h_mail, 0));
+        h->h_stop = reinterpret_cast<volatile int*>(h->h_mail + kMailStop);
+        h->d_stop = reinterpret_cast<int*>(h->d_mail + kMailStop);
     }
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
     h->lms = h->lms_a.p; h->lms_t = h->lms_b.p;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));
     if (L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
     SE2_HIP(hipStreamSynchronize(st));
+    if (device_plan) {
+        int nwg = 0;
+        std::memcpy(&nwg, h->h_scal.p, sizeof(int));
+        SE2_REQUIRE(nwg <= h->grp_cap_wg, SE2GPU_ERR_CAPACITY, "device plan: %d workgroups exceed the bound %d", nwg, h->grp_cap_wg);
+        h->nwg_off = std::max(nwg, 1);
+    }
     lap("synchronise");
     h->initialized = true;
     h->est_valid = false;
     return SE2GPU_OK;
 }
 
-inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
 
 // Every launch below exists in two forms: with the device-side controller (`c` = h->ctl.p: the kernel picks the
 // estimate buffer, lambda and whether it has anything to do from the block; "a"/"b" buffers are passed in fixed order)
@@ -2270,7 +2659,11 @@ void se2gpu_ba_destroy(se2gpu_ba* h) {
 int se2gpu_ba_clear(se2gpu_ba* h) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
     h->pose_of_id.clear(); h->lm_of_id.clear(); h->pose_ids.clear(); h->lm_ids.clear();
-    h->h_poses.clear(); h->h_lms.clear(); h->h_fixed.clear(); h->obs.clear(); h->odo.clear();
+    h->h_poses.clear(); h->h_lms.clear(); h->h_fixed.clear(); h->odo.clear();
+    h->he_kf.clear(); h->he_lm.clear(); h->he_uv.clear(); h->he_info.clear();
+    h->huber_delta = 0; h->huber_mixed = false;
+    h->lg_active = false;
+    h->lg_lc.clear(); h->lg_lw.clear(); h->lg_sigma2.clear(); h->lg_Rcw.clear(); h->lg_twb.clear();
     h->have_cam = false;
     h->initialized = false;
     h->est_valid = false;
@@ -2328,12 +2721,11 @@ int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double u
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
     const int a = h->pose_of_id.find(id_kf), b = h->lm_of_id.find(id_mp);
     SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_se2xyz: unknown vertex id (%d, %d)", id_kf, id_mp);
-    EdgeObs e;
-    e.kf = a; e.lm = b;
-    e.uv[0] = uv[0]; e.uv[1] = uv[1];
-    e.info[0] = info[0]; e.info[1] = 0.5 * (info[1] + info[2]); e.info[2] = info[3];
-    e.huber = huber_delta;
-    h->obs.push_back(e);
+    if (h->he_kf.empty()) h->huber_delta = huber_delta;
+    else if (huber_delta != h->huber_delta) h->huber_mixed = true;
+    h->he_kf.push_back(a); h->he_lm.push_back(b);
+    h->he_uv.push_back(uv[0]); h->he_uv.push_back(uv[1]);
+    h->he_info.push_back(info[0]); h->he_info.push_back(0.5 * (info[1] + info[2])); h->he_info.push_back(info[3]);
     return SE2GPU_OK;
 }
 
@@ -2361,18 +2753,95 @@ int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O, const double* poses
         SE2_CHECK(se2gpu_ba_add_vertex_se2(h, p, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], fixed[p]));
     h->lm_of_id.reserve(L);
     for (int l = 0; l < L; ++l) SE2_CHECK(se2gpu_ba_add_vertex_xyz(h, P + l, lms + 3 * (size_t)l, 1, 0));
-    h->obs.reserve(E);
-    for (int k = 0; k < E; ++k) {
+    for (int k = 0; k < E; ++k)
         SE2_REQUIRE(e_kf[k] >= 0 && e_kf[k] < P && e_lm[k] >= 0 && e_lm[k] < L, SE2GPU_ERR_INVALID,
                     "edge %d references a vertex out of range", k);
-        EdgeObs e;
-        e.kf = e_kf[k]; e.lm = e_lm[k];
-        e.uv[0] = e_uv[2 * (size_t)k]; e.uv[1] = e_uv[2 * (size_t)k + 1];
-        e.info[0] = e_info[3 * (size_t)k]; e.info[1] = e_info[3 * (size_t)k + 1]; e.info[2] = e_info[3 * (size_t)k + 2];
-        e.huber = huber_delta;
-        h->obs.push_back(e);
+    if (E) {   // the bulk arrays ARE the internal layout: four copies
+        if (h->he_kf.empty()) h->huber_delta = huber_delta;
+        else if (huber_delta != h->huber_delta) h->huber_mixed = true;
+        h->he_kf.insert(h->he_kf.end(), e_kf, e_kf + E);
+        h->he_lm.insert(h->he_lm.end(), e_lm, e_lm + E);
+        h->he_uv.insert(h->he_uv.end(), e_uv, e_uv + 2 * (size_t)E);
+        h->he_info.insert(h->he_info.end(), e_info, e_info + 3 * (size_t)E);
     }
     for (int k = 0; k < O; ++k) SE2_CHECK(se2gpu_ba_add_edge_se2(h, o_i[k], o_j[k], o_meas + 3 * k, o_info + 9 * k));
+    return SE2GPU_OK;
+}
+
+// Map::loadLocalGraph (/root/reference/src/Map.cpp:891-1022) through ONE call on a POD view of the local window.
+// What the reference does with ~E std::find calls over the key-frame vectors, E heap-allocated edges and E Eigen 2x2
+// inversions becomes: the vertex ids of Map.cpp:925/966/985, the fixed rule of :927/:969, cov^-1 of the PreSE2 edges
+// (:942-953) on the host (at most one per key frame), and flat copies; the per-observation information (:1024-1049) is
+// evaluated on the device, straight into the edge array, by initialize.
+int se2gpu_ba_load_local_graph(se2gpu_ba* h, const se2gpu_local_graph* g) {
+    SE2_REQUIRE(h && g, SE2GPU_ERR_INVALID, "load_local_graph: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    SE2_REQUIRE(h->pose_ids.empty() && h->lm_ids.empty() && h->he_kf.empty() && h->odo.empty(), SE2GPU_ERR_STATE,
+                "load_local_graph needs an empty optimizer");
+    const int nL = g->n_local_kf, nR = g->n_ref_kf, nK = nL + nR, N = g->n_mp, M = g->n_obs;
+    SE2_REQUIRE(nL > 0 && nR >= 0 && N >= 0 && M >= 0, SE2GPU_ERR_INVALID, "load_local_graph: bad sizes");
+    SE2_REQUIRE(g->kf_id && g->kf_Twb && g->kf_Rcw && (N == 0 || g->mp_pos) &&
+                (M == 0 || (g->obs_mp && g->obs_kf && g->obs_uv && g->obs_lc && g->obs_sigma2)), SE2GPU_ERR_INVALID,
+                "load_local_graph: NULL array");
+    SE2_CHECK(se2gpu_ba_add_cam(h, g->fx, g->cx, g->cy));
+    SE2_CHECK(se2gpu_ba_set_Tbc(h, g->Rbc, g->tbc));
+    // "If no reference KF, the KF with minId should be fixed" (Map.cpp:899-912); KeyFrame id 1 is always fixed (:927)
+    int minKFid = -1;
+    if (nR == 0) {
+        minKFid = g->kf_id[0];
+        for (int i = 0; i < nL; ++i) minKFid = std::min(minKFid, g->kf_id[i]);
+    }
+    for (int i = 0; i < nL; ++i)
+        SE2_CHECK(se2gpu_ba_add_vertex_se2(h, i, g->kf_Twb[3 * i], g->kf_Twb[3 * i + 1], g->kf_Twb[3 * i + 2],
+                                           (g->kf_id[i] == minKFid) || g->kf_id[i] == 1));
+    if (g->odo_to)
+        for (int i = 0; i < nL; ++i) {
+            const int j = g->odo_to[i];
+            if (j < 0) continue;
+            SE2_REQUIRE(j < nL && g->odo_meas && g->odo_cov, SE2GPU_ERR_INVALID, "load_local_graph: odo_to[%d] = %d", i, j);
+            const double* c = g->odo_cov + 9 * (size_t)i;   // info = cov^-1 (Eigen's closed-form 3x3 inverse: cofactors / det)
+            const double A = c[4] * c[8] - c[5] * c[7], B = -(c[3] * c[8] - c[5] * c[6]), C = c[3] * c[7] - c[4] * c[6];
+            const double id = 1.0 / (c[0] * A + c[1] * B + c[2] * C);
+            const double info[9] = {A * id, -(c[1] * c[8] - c[2] * c[7]) * id, (c[1] * c[5] - c[2] * c[4]) * id,
+                                    B * id, (c[0] * c[8] - c[2] * c[6]) * id, -(c[0] * c[5] - c[2] * c[3]) * id,
+                                    C * id, -(c[0] * c[7] - c[1] * c[6]) * id, (c[0] * c[4] - c[1] * c[3]) * id};
+            SE2_CHECK(se2gpu_ba_add_edge_se2(h, i, j, g->odo_meas + 3 * (size_t)i, info));
+        }
+    for (int i = 0; i < nR; ++i)
+        SE2_CHECK(se2gpu_ba_add_vertex_se2(h, nL + i, g->kf_Twb[3 * (nL + i)], g->kf_Twb[3 * (nL + i) + 1],
+                                           g->kf_Twb[3 * (nL + i) + 2], 1));
+    const int maxKFid = nL + nR + 1;
+    h->lm_of_id.reserve((size_t)maxKFid + N);
+    for (int i = 0; i < N; ++i) {
+        const double lw[3] = {g->mp_pos[3 * (size_t)i], g->mp_pos[3 * (size_t)i + 1], g->mp_pos[3 * (size_t)i + 2]};
+        SE2_CHECK(se2gpu_ba_add_vertex_xyz(h, maxKFid + i, lw, 1, 0));
+    }
+    h->he_kf.reserve(M); h->he_lm.reserve(M); h->he_uv.reserve(2 * (size_t)M);
+    h->lg_lc.reserve(3 * (size_t)M); h->lg_lw.reserve(3 * (size_t)M); h->lg_sigma2.reserve(M);
+    int prev = 0;
+    for (int k = 0; k < M; ++k) {
+        const int mp = g->obs_mp[k], kf = g->obs_kf[k];
+        SE2_REQUIRE(mp >= prev && mp < N, SE2GPU_ERR_INVALID, "load_local_graph: obs_mp must be nondecreasing and < n_mp (obs %d)", k);
+        prev = mp;
+        if (kf < 0) continue;   // the observing key frame is in neither list (Map.cpp:1016-1017)
+        SE2_REQUIRE(kf < nK, SE2GPU_ERR_INVALID, "load_local_graph: obs_kf[%d] = %d", k, kf);
+        h->he_kf.push_back(kf); h->he_lm.push_back(mp);
+        h->he_uv.push_back(g->obs_uv[2 * (size_t)k]); h->he_uv.push_back(g->obs_uv[2 * (size_t)k + 1]);
+        for (int c = 0; c < 3; ++c) {
+            h->lg_lc.push_back(g->obs_lc[3 * (size_t)k + c]);
+            h->lg_lw.push_back(g->mp_pos[3 * (size_t)mp + c]);
+        }
+        h->lg_sigma2.push_back(g->obs_sigma2[k]);
+    }
+    h->he_info.assign(3 * h->he_kf.size(), 0.0);
+    h->huber_delta = g->huber_delta;
+    h->lg_Rcw.assign(g->kf_Rcw, g->kf_Rcw + 9 * (size_t)nK);
+    h->lg_twb.resize(2 * (size_t)nK);
+    for (int i = 0; i < nK; ++i) { h->lg_twb[2 * i] = g->kf_Twb[3 * i]; h->lg_twb[2 * i + 1] = g->kf_Twb[3 * i + 1]; }
+    h->lg_fx = g->fx;
+    h->lg_srot = (float)(1. / g->xrot_info);
+    h->lg_sz = (float)(1. / g->z_info);
+    h->lg_active = true;
     return SE2GPU_OK;
 }
 
@@ -2736,7 +3205,7 @@ int se2gpu_ba_edge_information(int E, const float* lc, const float* lw, const in
     SE2_CHECK(d_out.reserve(4 * (size_t)E));
     const float s_rot = (float)(1. / xrot_info), s_z = (float)(1. / z_info);
     hipLaunchKernelGGL(k_edge_information, grid1(E, 256), dim3(256), 0, st, E, d_lc.p, d_lw.p, d_kf.p, d_s2.p, d_R.p,
-                       d_t.p, fx, s_rot, s_z, d_out.p);
+                       d_t.p, fx, s_rot, s_z, d_out.p, 0);
     SE2_HIP(hipGetLastError());
     SE2_HIP(hipMemcpyAsync(info_out, d_out.p, 4 * (size_t)E * sizeof(double), hipMemcpyDeviceToHost, st));
     SE2_HIP(hipStreamSynchronize(st));

@@ -48,14 +48,22 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;  // elements
+    bool owned = true;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        owned = true;
+    }
+    // view into somebody else's allocation (an arena): never freed here, replaced by the next alias() / reserve()
+    void alias(T* q) {
+        release();
+        p = q;
+        owned = false;
     }
     int reserve(size_t n) {
         if (n <= cap) return SE2GPU_OK;

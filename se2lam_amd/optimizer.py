@@ -236,6 +236,30 @@ def estimateVertexSBAXYZ(opt: SlamOptimizer, id: int) -> np.ndarray:
     return out
 
 
+def loadLocalGraph(opt: SlamOptimizer, *, kf_id, kf_Twb, kf_Rcw, n_local, odo_to, odo_meas, odo_cov, mp_pos, obs_mp, obs_kf,
+                   obs_uv, obs_lc, obs_sigma2, K, Rbc, tbc, huber, xrot_info=1e6, z_info=1.0):
+    """Map::loadLocalGraph(optimizer) (Map.cpp:891-1022) through se2gpu_ba_load_local_graph: the POD view of the local
+    window (key frames: local first, then reference; observations grouped by map point)."""
+    keep = [np.ascontiguousarray(kf_id, np.int32), np.ascontiguousarray(kf_Twb, np.float32),
+            np.ascontiguousarray(kf_Rcw, np.float32), np.ascontiguousarray(odo_to, np.int32),
+            np.ascontiguousarray(odo_meas, np.float64), np.ascontiguousarray(odo_cov, np.float64),
+            np.ascontiguousarray(mp_pos, np.float32), np.ascontiguousarray(obs_mp, np.int32),
+            np.ascontiguousarray(obs_kf, np.int32), np.ascontiguousarray(obs_uv, np.float32),
+            np.ascontiguousarray(obs_lc, np.float32), np.ascontiguousarray(obs_sigma2, np.float32)]
+    g = capi.LocalGraph()
+    g.n_local_kf, g.n_ref_kf = int(n_local), int(len(keep[0]) - n_local)
+    g.n_mp, g.n_obs = int(len(keep[6])), int(len(keep[7]))
+    (g.kf_id, g.kf_Twb, g.kf_Rcw, g.odo_to, g.odo_meas, g.odo_cov, g.mp_pos, g.obs_mp, g.obs_kf, g.obs_uv, g.obs_lc,
+     g.obs_sigma2) = [a.ctypes.data for a in keep]
+    K = np.asarray(K, np.float32)
+    g.fx, g.cx, g.cy = float(K[0, 0]), float(K[0, 2]), float(K[1, 2])
+    g.Rbc = (C.c_double * 9)(*np.asarray(Rbc, np.float64).reshape(-1))
+    g.tbc = (C.c_double * 3)(*np.asarray(tbc, np.float64).reshape(-1))
+    g.huber_delta, g.xrot_info, g.z_info = float(huber), float(xrot_info), float(z_info)
+    capi.check(capi.lib().se2gpu_ba_load_local_graph(opt._h, C.byref(g)))
+    opt._shape = (len(keep[0]), len(keep[6]))
+
+
 def shard_landmarks(L: int, e_kf: np.ndarray, e_lm: np.ndarray, world: int) -> np.ndarray:
     """Host-side landmark partition of the library (no device needed)."""
     e_kf = np.ascontiguousarray(e_kf, np.int32)

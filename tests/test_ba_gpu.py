@@ -461,3 +461,116 @@ def test_force_stop_flag_and_synchronous_controller(synth):
     assert v.stats == a.stats and np.array_equal(v.estimates()[0], a.estimates()[0])
     z = _opt(g)
     assert z.optimize(0) == 0 and z.stats["chi2_init"] == pytest.approx(a.stats["chi2_init"], rel=1e-14)
+
+
+def _run_plan(g, plan, monkeypatch, iters=6):
+    if plan:
+        monkeypatch.setenv("SE2GPU_BA_PLAN", plan)
+    else:
+        monkeypatch.delenv("SE2GPU_BA_PLAN", raising=False)
+    o = _opt(g)
+    S, bs = o.reduced_system(3.5)
+    o.optimize(iters)
+    return S, bs, o.stats, o.estimates()
+
+
+def test_device_plan_equals_host_plan(synth, monkeypatch):
+    """initializeOptimization builds the landmark / pose CSR lists and k_reduce2's contributor plan ON THE DEVICE
+    (k_plan_*, stable radix sorts, the packing scan); SE2GPU_BA_PLAN=host keeps the host builder.  Same lists, same
+    summation orders: the reduced system and the whole LM run are bit-identical - on plain windows, with several fixed
+    key frames, with an unobserved and a once-observed landmark, for a single key frame, and at the bench size."""
+    import dataclasses
+    g8 = synth.ba_graph(8, 60)
+    fx = g8.fixed.copy(); fx[[0, 3, 7]] = 1
+    keep = (g8.e_lm != 5) & ~((g8.e_lm == 6) & (np.cumsum(g8.e_lm == 6) > 1))
+    one = dataclasses.replace(g8, poses=g8.poses[:1], fixed=np.zeros(1, np.uint8), e_kf=g8.e_kf[g8.e_kf == 0] * 0,
+                              e_lm=g8.e_lm[g8.e_kf == 0], e_uv=g8.e_uv[g8.e_kf == 0], e_info=g8.e_info[g8.e_kf == 0],
+                              o_i=g8.o_i[:0], o_j=g8.o_j[:0], o_meas=g8.o_meas[:0], o_info=g8.o_info[:0])
+    graphs = [g8, dataclasses.replace(g8, fixed=fx),
+              dataclasses.replace(g8, e_kf=g8.e_kf[keep], e_lm=g8.e_lm[keep], e_uv=g8.e_uv[keep], e_info=g8.e_info[keep]),
+              one, synth.ba_graph(21, 800), synth.ba_graph(50, 5000), synth.ba_graph(200, 20000)]
+    for g in graphs:
+        Sd, bd, sd, (pd_, ld_) = _run_plan(g, None, monkeypatch)
+        Sh, bh, sh, (ph, lh) = _run_plan(g, "host", monkeypatch)
+        assert np.array_equal(Sd, Sh) and np.array_equal(bd, bh), g.P
+        assert sd == sh
+        assert np.array_equal(pd_, ph) and np.array_equal(ld_, lh)
+
+
+def test_edges_in_any_order(synth, oracle):
+    """Edges that do not arrive grouped by landmark (the reference adds them map point by map point, but the call surface
+    does not require it) are stably sorted first; only the summation order inside a landmark changes."""
+    import dataclasses
+    g = synth.ba_graph(21, 800)
+    perm = np.random.default_rng(3).permutation(g.E)
+    gs = dataclasses.replace(g, e_kf=g.e_kf[perm], e_lm=g.e_lm[perm], e_uv=g.e_uv[perm], e_info=g.e_info[perm])
+    a, b = _opt(g), _opt(gs)
+    a.optimize(6); b.optimize(6)
+    assert a.stats["trials_hist"] == b.stats["trials_hist"]
+    assert np.allclose(a.stats["chi2_hist"], b.stats["chi2_hist"], rtol=1e-10)
+    assert np.allclose(a.estimates()[0], b.estimates()[0], rtol=1e-9, atol=1e-9)
+
+
+def test_load_local_graph_pod_call(synth, oracle):
+    """Map::loadLocalGraph through ONE POD call (se2gpu_ba_load_local_graph): vertex ids, the fixed rule, cov^-1 of the
+    PreSE2 edges and the per-observation information are the library's business.  Checked against the reference's call
+    sequence spelled out with the free functions (Map.cpp:891-1053) and the oracle's information matrices - with and
+    without reference key frames, with an observation by a key frame outside both lists."""
+    from se2lam_amd import optimizer as op
+    from test_ba_oracle import _info_inputs
+    inp, g, level = _info_inputs(synth, 12, 200)
+    K = np.array([[g.fx, 0, g.cx], [0, g.fx, g.cy], [0, 0, 1]], np.float32)
+    info = oracle.ba_edge_information(**inp)
+    for n_ref in (0, 3):
+        nL = g.P - n_ref
+        kf_id = np.arange(100, 100 + g.P, dtype=np.int32)      # KeyFrame::id; the smallest one is local key frame 4
+        kf_id[4] = 50
+        if n_ref == 0:
+            fixed = (kf_id == kf_id.min())
+        else:
+            fixed = np.r_[np.zeros(nL, bool), np.ones(n_ref, bool)]
+        odo_to = np.full(nL, -1, np.int32); odo_meas = np.zeros((nL, 3)); odo_cov = np.tile(np.eye(3).reshape(-1), (nL, 1))
+        for k in range(g.O):
+            i, j = int(g.o_i[k]), int(g.o_j[k])
+            if i < nL and j < nL:
+                odo_to[i] = j; odo_meas[i] = g.o_meas[k]; odo_cov[i] = np.linalg.inv(g.o_info[k].reshape(3, 3)).reshape(-1)
+        obs_kf = g.e_kf.astype(np.int32).copy()
+        dropped = np.zeros(g.E, bool); dropped[::37] = True     # observed by a key frame that is in neither list
+        obs_kf[dropped] = -1
+        # the reference's call sequence
+        ref = op.SlamOptimizer()
+        op.addCamPara(ref, K, 0)
+        op.setExtParameter(ref, g.Rbc, g.tbc)
+        twb = np.c_[inp["twb_xy"], g.poses[:, 2].astype(np.float32)].astype(np.float32)
+        for i in range(nL):
+            op.addVertexSE2(ref, twb[i].astype(np.float64), i, bool(fixed[i]))
+        for i in range(nL):
+            if odo_to[i] >= 0:
+                op.addEdgeSE2(ref, odo_meas[i], i, int(odo_to[i]), np.linalg.inv(odo_cov[i].reshape(3, 3)))
+        for i in range(n_ref):
+            op.addVertexSE2(ref, twb[nL + i].astype(np.float64), nL + i, True)
+        maxKFid = g.P + 1
+        for l in range(g.L):
+            op.addVertexSBAXYZ(ref, g.lms[l].astype(np.float32).astype(np.float64), maxKFid + l)
+        uv32 = g.e_uv.astype(np.float32)
+        for k in range(g.E):
+            if not dropped[k]:
+                op.addEdgeSE2XYZ(ref, uv32[k].astype(np.float64), int(g.e_kf[k]), maxKFid + int(g.e_lm[k]), info[k],
+                                 float(np.float32(g.huber)))   # const float delta = Config::TH_HUBER (Map.cpp:977)
+        ref.initializeOptimization(0)
+        ref.optimize(5)
+        # one POD call
+        pod = op.SlamOptimizer()
+        op.loadLocalGraph(pod, kf_id=kf_id, kf_Twb=twb, kf_Rcw=inp["Rcw"], n_local=nL, odo_to=odo_to, odo_meas=odo_meas,
+                          odo_cov=odo_cov, mp_pos=g.lms.astype(np.float32), obs_mp=g.e_lm, obs_kf=obs_kf, obs_uv=uv32,
+                          obs_lc=inp["lc"], obs_sigma2=inp["sigma2"], K=K, Rbc=g.Rbc, tbc=g.tbc, huber=np.float32(g.huber))
+        pod.initializeOptimization(0)
+        pod.optimize(5)
+        assert pod.stats["trials_hist"] == ref.stats["trials_hist"]
+        assert np.allclose(pod.stats["chi2_hist"], ref.stats["chi2_hist"], rtol=1e-9)
+        for i in range(g.P):
+            assert np.allclose(op.estimateVertexSE2(pod, i), op.estimateVertexSE2(ref, i), rtol=1e-9, atol=1e-9)
+        assert np.allclose(op.estimateVertexSBAXYZ(pod, maxKFid + 7), op.estimateVertexSBAXYZ(ref, maxKFid + 7), rtol=1e-9)
+        # fixed vertices did not move
+        for i in np.nonzero(fixed)[0]:
+            assert np.array_equal(op.estimateVertexSE2(pod, int(i)), twb[i].astype(np.float64))
