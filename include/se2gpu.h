@@ -187,7 +187,9 @@ int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double u
 int se2gpu_ba_add_edge_se2(se2gpu_ba* h, int id0, int id1, const double meas[3], const double info[9]);
 
 /* Bulk form of the same calls (SoA arena filled once per key frame):
- * vertex ids: poses 0..P-1, landmarks P..P+L-1.  e_info: E x 3 (xx, xy, yy).  o_info: O x 9. */
+ * vertex ids: poses 0..P-1, landmarks P..P+L-1.  e_info: E x 3 (xx, xy, yy).  o_info: O x 9.
+ * The four edge arrays are BORROWED: they must stay valid and unchanged until se2gpu_ba_initialize returns (which
+ * validates them and copies them once, straight into the pinned upload arena); everything else is copied here. */
 int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O,
                    const double* poses, const uint8_t* fixed, const double* lms,
                    const int32_t* e_kf, const int32_t* e_lm, const double* e_uv, const double* e_info,

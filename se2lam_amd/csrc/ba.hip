@@ -1612,6 +1612,10 @@ struct se2gpu_ba {
     std::vector<double> he_uv, he_info;       // 2 / 3 (xx, xy, yy) per edge
     double huber_delta = 0;
     bool huber_mixed = false;
+    // se2gpu_ba_load: the caller's edge arrays, borrowed until initialize (copied once, straight into the pinned arena)
+    int bulk_E = 0;
+    const int32_t *bulk_kf = nullptr, *bulk_lm = nullptr;
+    const double *bulk_uv = nullptr, *bulk_info = nullptr;
     // se2gpu_ba_load_local_graph: raw inputs of the per-observation information (Map.cpp:1024-1049), evaluated on the
     // device straight into e_info after the upload
     bool lg_active = false;
@@ -1632,7 +1636,7 @@ struct se2gpu_ba {
     DevBuf<int4> grp;
     int nwg_off = 0, grp_cap_wg = 0;
     DevBuf<uint8_t> garena;        // every uploaded graph array lives in this one allocation (one H2D copy)
-    DevBuf<int> plan_np, plan_base, plan_key0, plan_key1, plan_idx, plan_hist, plan_offs, plan_out;  // device plan scratch
+    DevBuf<int> plan_np, plan_base, plan_key0, plan_key1, plan_idx, plan_hist, plan_offs, plan_out, plan_tsum, plan_toff;  // device plan scratch
     DevBuf<int2> plan_st0, plan_st1;
     bool odo_fallback = false;
     DevBuf<double> e_uv, e_info, o_meas, o_info;
@@ -1744,6 +1748,48 @@ __global__ void k_scan_i32(const int* __restrict__ in, int* __restrict__ out, in
         run += v;
     }
     if (t == 1023) out[n] = sums[1023];
+}
+
+// Large scans (the digit histograms of a radix pass: bins x workgroups counters) in three coalesced launches: every
+// workgroup scans a tile of 2048 counters and leaves the tile total, k_scan_i32 scans the totals, k_scan_tile_add adds
+// them back.  (One workgroup walking 10^6 counters with a stride of 10^3 per thread took 0.5 ms per pass.)
+constexpr int kScanTile = 2048;
+__global__ __launch_bounds__(256) void k_scan_tiles(const int* __restrict__ in, int* __restrict__ out, int n,
+                                                     int* __restrict__ tile_sum) {
+    __shared__ int tile[kScanTile + kScanTile / 32];   // padded: thread t walks 8 consecutive entries
+    __shared__ int wsum[256];
+    const int base = blockIdx.x * kScanTile, t = threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = u * 256 + t;
+        tile[i + i / 32] = base + i < n ? in[base + i] : 0;
+    }
+    __syncthreads();
+    int v[8], s = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = 8 * t + u; v[u] = tile[i + i / 32]; s += v[u]; }
+    wsum[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int x = t >= off ? wsum[t - off] : 0;
+        __syncthreads();
+        wsum[t] += x;
+        __syncthreads();
+    }
+    int run = t ? wsum[t - 1] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = 8 * t + u; tile[i + i / 32] = run; run += v[u]; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = u * 256 + t;
+        if (base + i < n) out[base + i] = tile[i + i / 32];
+    }
+    if (t == 255) tile_sum[blockIdx.x] = wsum[255];
+}
+__global__ void k_scan_tile_add(int* __restrict__ out, int n, const int* __restrict__ tile_off) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_off[i / kScanTile];
 }
 
 __global__ void k_plan_pairs(int L, int P, const int* __restrict__ lm_ptr, const int* __restrict__ e_kf,
@@ -2027,7 +2073,7 @@ int ba_upload_graph(se2gpu_ba* h) {
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
     const int P = (int)h->pose_ids.size(), L = (int)h->lm_ids.size();
-    const int E = (int)h->he_kf.size(), O = (int)h->odo.size();
+    const int E = h->bulk_E ? h->bulk_E : (int)h->he_kf.size(), O = (int)h->odo.size();
     SE2_REQUIRE(P > 0, SE2GPU_ERR_STATE, "initialize: no pose vertices");
     SE2_REQUIRE(h->have_cam, SE2GPU_ERR_STATE, "initialize: add_cam was not called");
     SE2_REQUIRE(!h->huber_mixed, SE2GPU_ERR_INVALID, "all EdgeSE2XYZ must share one Huber delta (Map.cpp:977)");
@@ -2040,15 +2086,28 @@ int ba_upload_graph(se2gpu_ba* h) {
 
     // --- observation edges sorted by landmark.  Map::loadLocalGraph adds them map point by map point, i.e. already in
     // order: one pass checks that (and sums the pairs per landmark for the buffer sizes); otherwise a stable counting sort.
-    const int* e_kf = h->he_kf.data();
-    const int* e_lm = h->he_lm.data();
-    const double* e_uv = h->he_uv.data();
-    const double* e_info = h->he_info.data();
+    const int* e_kf = h->bulk_E ? h->bulk_kf : h->he_kf.data();
+    const int* e_lm = h->bulk_E ? h->bulk_lm : h->he_lm.data();
+    const double* e_uv = h->bulk_E ? h->bulk_uv : h->he_uv.data();
+    const double* e_info = h->bulk_E ? h->bulk_info : h->he_info.data();
     std::vector<int> s_kf, s_lm;
     std::vector<double> s_uv, s_info;
-    bool sorted = true;
-    for (int k = 1; k < E; ++k)
-        if (e_lm[k] < e_lm[k - 1]) { sorted = false; break; }
+    bool sorted = true, in_range = true;
+    size_t npairs_max = 0;   // pairs of observations per landmark (an upper bound of the plan's pairs: fixed poses drop out)
+    {   // one pass: index range (borrowed bulk arrays are validated here), order, pairs per landmark
+        size_t run = 0;
+        for (int k = 0; k < E; ++k) {
+            in_range &= (unsigned)e_kf[k] < (unsigned)P && (unsigned)e_lm[k] < (unsigned)L;
+            if (k && e_lm[k] != e_lm[k - 1]) {
+                sorted &= e_lm[k] > e_lm[k - 1];
+                npairs_max += run * (run - 1) / 2;
+                run = 0;
+            }
+            ++run;
+        }
+        npairs_max += run * (run ? run - 1 : 0) / 2;
+    }
+    SE2_REQUIRE(in_range, SE2GPU_ERR_INVALID, "an edge references a vertex out of range");
     if (!sorted) {
         std::vector<int> ptr(L + 1, 0);
         for (int k = 0; k < E; ++k) ptr[e_lm[k] + 1]++;
@@ -2062,13 +2121,15 @@ int ba_upload_graph(se2gpu_ba* h) {
         }
         e_kf = s_kf.data(); e_lm = s_lm.data(); e_uv = s_uv.data(); e_info = s_info.data();
     }
-    size_t npairs_max = 0;   // pairs of observations per landmark (an upper bound of the plan's pairs: fixed poses drop out)
-    for (int k = 0; k < E;) {
-        int t = k + 1;
-        while (t < E && e_lm[t] == e_lm[k]) ++t;
-        const size_t d = (size_t)(t - k);
-        npairs_max += d * (d - 1) / 2;
-        k = t;
+    if (!sorted) {   // recount on the sorted order
+        npairs_max = 0;
+        for (int k = 0; k < E;) {
+            int t = k + 1;
+            while (t < E && e_lm[t] == e_lm[k]) ++t;
+            const size_t d = (size_t)(t - k);
+            npairs_max += d * (d - 1) / 2;
+            k = t;
+        }
     }
     SE2_REQUIRE(npairs_max < (size_t)1 << 30, SE2GPU_ERR_CAPACITY, "the contributor plan would hold %zu pairs", npairs_max);
     // --- odometry (tiny: host)
@@ -2247,6 +2308,8 @@ int ba_upload_graph(se2gpu_ba* h) {
         SE2_CHECK(h->plan_hist.reserve(nhist));
         SE2_CHECK(h->plan_offs.reserve(nhist));
         SE2_CHECK(h->plan_out.reserve(8));
+        SE2_CHECK(h->plan_tsum.reserve(nhist / kScanTile + 4));
+        SE2_CHECK(h->plan_toff.reserve(nhist / kScanTile + 4));
         // groups <= pairs / 16 + off-diagonal blocks; two consecutive workgroups hold more than 28 groups together
         const size_t G = npairs_max / kChunk + (size_t)P * (P - 1) / 2 + 1;
         const int cap_wg = (int)std::min<size_t>((size_t)P * (P - 1) / 2 + 1, 2 * G / kGrpPerWG + 2) + 1;
@@ -2257,7 +2320,15 @@ int ba_upload_graph(se2gpu_ba* h) {
             const int nb = (int)((cnt + kRadixItems - 1) / kRadixItems), bins = 1 << bits;
             hipLaunchKernelGGL(k_radix_hist, dim3(std::max(nb, 1)), dim3(kRadixItems), 0, st, kin, (int)cnt, shift, bins, nb,
                                h->plan_hist.p);
-            hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_hist.p, h->plan_offs.p, bins * nb);
+            const int cnt_h = bins * nb, ntile = (cnt_h + kScanTile - 1) / kScanTile;
+            if (ntile <= 2) {
+                hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_hist.p, h->plan_offs.p, cnt_h);
+            } else {
+                hipLaunchKernelGGL(k_scan_tiles, dim3(ntile), dim3(256), 0, st, h->plan_hist.p, h->plan_offs.p, cnt_h,
+                                   h->plan_tsum.p);
+                hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_tsum.p, h->plan_toff.p, ntile);
+                hipLaunchKernelGGL(k_scan_tile_add, grid1(cnt_h, 256), dim3(256), 0, st, h->plan_offs.p, cnt_h, h->plan_toff.p);
+            }
             hipLaunchKernelGGL((k_radix_scatter<V>), dim3(std::max(nb, 1)), dim3(kRadixItems), 0, st, kin, (const V*)vin,
                                (int)cnt, shift, bins, nb, h->plan_offs.p, kout, vout);
             return SE2GPU_OK;
@@ -2265,7 +2336,7 @@ int ba_upload_graph(se2gpu_ba* h) {
         // landmark CSR + pairs per landmark, their prefix sums
         hipLaunchKernelGGL(k_plan_lm, grid1((size_t)L + 1, 256), dim3(256), 0, st, L, E, h->e_lm.p, h->e_kf.p, h->fixed.p,
                            h->lm_ptr.p, h->plan_np.p);
-        hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_np.p, h->plan_base.p, L);
+        hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_np.p, h->plan_base.p, L);   // 20 per thread
         // pose -> edges CSR: edge indices stably sorted by key frame (one pass)
         hipLaunchKernelGGL(k_iota, grid1(E, 256), dim3(256), 0, st, E, h->plan_idx.p);
         if (E) SE2_CHECK(radix(h->e_kf.p, h->plan_key0.p, h->plan_idx.p, h->pose_edges.p, (size_t)E, 0, Pb));
@@ -2662,6 +2733,7 @@ int se2gpu_ba_clear(se2gpu_ba* h) {
     h->h_poses.clear(); h->h_lms.clear(); h->h_fixed.clear(); h->odo.clear();
     h->he_kf.clear(); h->he_lm.clear(); h->he_uv.clear(); h->he_info.clear();
     h->huber_delta = 0; h->huber_mixed = false;
+    h->bulk_E = 0; h->bulk_kf = h->bulk_lm = nullptr; h->bulk_uv = h->bulk_info = nullptr;
     h->lg_active = false;
     h->lg_lc.clear(); h->lg_lw.clear(); h->lg_sigma2.clear(); h->lg_Rcw.clear(); h->lg_twb.clear();
     h->have_cam = false;
@@ -2715,12 +2787,24 @@ int se2gpu_ba_add_vertex_xyz(se2gpu_ba* h, int id, const double xyz[3], int marg
     return SE2GPU_OK;
 }
 
+// a bulk load followed by single-edge calls: the borrowed arrays become owned ones first
+static void ba_materialize_bulk(se2gpu_ba* h) {
+    if (!h->bulk_E) return;
+    const size_t E = (size_t)h->bulk_E;
+    h->he_kf.insert(h->he_kf.end(), h->bulk_kf, h->bulk_kf + E);
+    h->he_lm.insert(h->he_lm.end(), h->bulk_lm, h->bulk_lm + E);
+    h->he_uv.insert(h->he_uv.end(), h->bulk_uv, h->bulk_uv + 2 * E);
+    h->he_info.insert(h->he_info.end(), h->bulk_info, h->bulk_info + 3 * E);
+    h->bulk_E = 0;
+}
+
 int se2gpu_ba_add_edge_se2xyz(se2gpu_ba* h, int id_kf, int id_mp, const double uv[2], const double info[4],
                               double huber_delta) {
     SE2_REQUIRE(h && uv && info, SE2GPU_ERR_INVALID, "add_edge_se2xyz: NULL argument");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
     const int a = h->pose_of_id.find(id_kf), b = h->lm_of_id.find(id_mp);
     SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_se2xyz: unknown vertex id (%d, %d)", id_kf, id_mp);
+    ba_materialize_bulk(h);
     if (h->he_kf.empty()) h->huber_delta = huber_delta;
     else if (huber_delta != h->huber_delta) h->huber_mixed = true;
     h->he_kf.push_back(a); h->he_lm.push_back(b);
@@ -2751,18 +2835,27 @@ int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O, const double* poses
     SE2_REQUIRE(P >= 0 && L >= 0 && E >= 0 && O >= 0, SE2GPU_ERR_INVALID, "negative size");
     for (int p = 0; p < P; ++p)
         SE2_CHECK(se2gpu_ba_add_vertex_se2(h, p, poses[3 * p], poses[3 * p + 1], poses[3 * p + 2], fixed[p]));
-    h->lm_of_id.reserve(L);
-    for (int l = 0; l < L; ++l) SE2_CHECK(se2gpu_ba_add_vertex_xyz(h, P + l, lms + 3 * (size_t)l, 1, 0));
-    for (int k = 0; k < E; ++k)
-        SE2_REQUIRE(e_kf[k] >= 0 && e_kf[k] < P && e_lm[k] >= 0 && e_lm[k] < L, SE2GPU_ERR_INVALID,
-                    "edge %d references a vertex out of range", k);
-    if (E) {   // the bulk arrays ARE the internal layout: four copies
-        if (h->he_kf.empty()) h->huber_delta = huber_delta;
-        else if (huber_delta != h->huber_delta) h->huber_mixed = true;
-        h->he_kf.insert(h->he_kf.end(), e_kf, e_kf + E);
-        h->he_lm.insert(h->he_lm.end(), e_lm, e_lm + E);
-        h->he_uv.insert(h->he_uv.end(), e_uv, e_uv + 2 * (size_t)E);
-        h->he_info.insert(h->he_info.end(), e_info, e_info + 3 * (size_t)E);
+    if (h->lm_ids.empty() && h->pose_ids.size() == (size_t)P) {   // fresh handle: the landmark block in one go
+        h->lm_ids.resize(L);
+        for (int l = 0; l < L; ++l) { h->lm_ids[l] = P + l; h->lm_of_id.set(P + l, l); }
+        h->h_lms.assign(lms, lms + 3 * (size_t)L);
+    } else {
+        for (int l = 0; l < L; ++l) SE2_CHECK(se2gpu_ba_add_vertex_xyz(h, P + l, lms + 3 * (size_t)l, 1, 0));
+    }
+    if (E) {
+        // the bulk arrays ARE the internal layout (indices, (xx, xy, yy)): they are borrowed until se2gpu_ba_initialize,
+        // which validates them and copies them once, into the pinned upload arena
+        if (h->he_kf.empty() && !h->bulk_E) {
+            h->huber_delta = huber_delta;
+            h->bulk_E = E; h->bulk_kf = e_kf; h->bulk_lm = e_lm; h->bulk_uv = e_uv; h->bulk_info = e_info;
+        } else {
+            ba_materialize_bulk(h);
+            if (huber_delta != h->huber_delta) h->huber_mixed = true;
+            h->he_kf.insert(h->he_kf.end(), e_kf, e_kf + E);
+            h->he_lm.insert(h->he_lm.end(), e_lm, e_lm + E);
+            h->he_uv.insert(h->he_uv.end(), e_uv, e_uv + 2 * (size_t)E);
+            h->he_info.insert(h->he_info.end(), e_info, e_info + 3 * (size_t)E);
+        }
     }
     for (int k = 0; k < O; ++k) SE2_CHECK(se2gpu_ba_add_edge_se2(h, o_i[k], o_j[k], o_meas + 3 * k, o_info + 9 * k));
     return SE2GPU_OK;

@@ -100,6 +100,7 @@ class SlamOptimizer:
                                     capi.pd(a[5]), capi.pd(a[6]), a[7].ctypes.data_as(P32),
                                     a[8].ctypes.data_as(P32), capi.pd(a[9]), capi.pd(a[10]), float(g.huber)))
         self._shape = (g.P, g.L)
+        self._keep = a          # the edge arrays are borrowed by the library until initializeOptimization
 
     def estimates(self):
         P, L = self._shape
