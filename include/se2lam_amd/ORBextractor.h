@@ -5,6 +5,9 @@
 // Callers in the reference: Frame::Frame (src/Frame.cpp:25, empty mask), Track (src/Track.cpp:34), Localizer.
 // One instance per calling thread (the reference's instance is stateful too: mvImagePyramid).
 #pragma once
+#include <algorithm>
+#include <cstring>
+
 #include "types.h"
 
 namespace se2lam_amd {
@@ -13,12 +16,13 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
+    // the reference's five arguments (ORBextractor.h:44); the device buffers follow the image size they meet
     ORBextractor(int nfeatures = 1000, float scaleFactor = 1.2f, int nlevels = 8, int scoreType = FAST_SCORE,
-                 int fastTh = 20, int maxRows = 480, int maxCols = 640)
+                 int fastTh = 20)
         : nfeatures_(nfeatures) {
         se2gpu_orb_params p{};
         p.nfeatures = nfeatures; p.scale_factor = scaleFactor; p.nlevels = nlevels;
-        p.score_type = scoreType; p.fast_th = fastTh; p.max_rows = maxRows; p.max_cols = maxCols; p.max_batch = 1;
+        p.score_type = scoreType; p.fast_th = fastTh; p.max_rows = 0; p.max_cols = 0; p.max_batch = 1;
         check(se2gpu_orb_create(&p, &h_), "ORBextractor");
     }
     ~ORBextractor() { se2gpu_orb_destroy(h_); }
@@ -40,6 +44,21 @@ public:
         descriptors.create(n, 32);                               // _descriptors.create(nkeypoints, 32, CV_8U)
         std::copy(desc.begin(), desc.begin() + (size_t)n * 32, descriptors.owned.begin());
     }
+
+#ifdef SE2LAM_AMD_HAVE_OPENCV
+    // void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>&, cv::OutputArray descriptors)
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints, cv::OutputArray descriptors) {
+        std::vector<KeyPoint> kps;
+        Mat8U d;
+        (*this)(view8U(image.getMat()), mask.empty() ? Mat8U() : view8U(mask.getMat()), kps, d);
+        keypoints.resize(kps.size());
+        if (!kps.empty()) std::memcpy(keypoints.data(), kps.data(), kps.size() * sizeof(KeyPoint));   // layout-identical
+        if (kps.empty()) { descriptors.release(); return; }
+        descriptors.create((int)kps.size(), 32, CV_8U);
+        cv::Mat out = descriptors.getMat();
+        for (int r = 0; r < d.rows; ++r) std::memcpy(out.ptr<uint8_t>(r), d.ptr(r), 32);
+    }
+#endif
 
     int GetLevels() { return se2gpu_orb_levels(h_); }
     float GetScaleFactor() { return se2gpu_orb_scale_factor(h_); }

@@ -8,6 +8,8 @@
 // take the POD content the matchers actually read from them (FrameView / MapPointView below) - INTEGRATION.md shows
 // the three-line glue that fills the views from the reference's classes.
 #pragma once
+#include <map>
+
 #include "types.h"
 
 namespace se2lam_amd {
@@ -19,6 +21,9 @@ struct FrameView {                       // what MatchByWindow / MatchByProjecti
     float minXUn = 0, minYUn = 0, maxXUn = 640, maxYUn = 480;  // Frame::minXUn.. (Frame.cpp:183-200)
     const uint8_t* observed = nullptr;       // KeyFrame::hasObservation(idx) per feature (MatchByProjection only)
     const float* Tcw = nullptr;              // KeyFrame::Tcw rows 0..2 (3x4 row-major float)
+    // Config::fxCam, fyCam, cxCam, cyCam: the reference's matcher reads them from the global Config (ORBmatcher.cpp:400-401)
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    const struct FeatureVectorView* bow = nullptr;   // KeyFrame::GetFeatureVector() (SearchByBoW only)
 };
 
 struct FeatureVectorView {               // DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened to CSR
@@ -41,9 +46,9 @@ class ORBmatcher {
 public:
     static const int TH_HIGH = 100, TH_LOW = 75, HISTO_LENGTH = 30;   // ORBmatcher.cpp:45-47
 
-    explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int maxFeatures = 4096)
-        : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
-        check(se2gpu_matcher_create(maxFeatures, 1, &h_), "ORBmatcher");
+    // ORBmatcher(float nnratio = 0.6, bool checkOri = true)  (ORBmatcher.h:46); the device workspace grows on demand
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {
+        check(se2gpu_matcher_create(4096, 1, &h_), "ORBmatcher");
     }
     ~ORBmatcher() { se2gpu_matcher_destroy(h_); }
     ORBmatcher(const ORBmatcher&) = delete;
@@ -65,9 +70,11 @@ public:
         return nmatches;
     }
 
-    int MatchByProjection(const FrameView& newKF, const MapPointView& localMPs, const float fx, const float fy,
-                          const float cx, const float cy, const int winSize, const int levelOffset,
+    // int MatchByProjection(PtrKeyFrame& pNewKF, std::vector<PtrMapPoint>& localMPs, winSize, levelOffset, vMatchesIdxMP)
+    // (ORBmatcher.h:73-74): the key-frame view carries Tcw and the intrinsics the reference reads from Config
+    int MatchByProjection(const FrameView& newKF, const MapPointView& localMPs, const int winSize, const int levelOffset,
                           std::vector<int>& vMatchesIdxMP) {
+        const float fx = newKF.fx, fy = newKF.fy, cx = newKF.cx, cy = newKF.cy;
         vMatchesIdxMP.assign(newKF.N, -1);
         se2gpu_frame_bounds b{newKF.minXUn, newKF.minYUn, newKF.maxXUn, newKF.maxYUn};
         int nmatches = 0;
@@ -95,9 +102,22 @@ public:
         return nmatches;
     }
 
-protected:
-    float mfNNratio;
+    // int SearchByBoW(PtrKeyFrame pKF1, PtrKeyFrame pKF2, std::map<int, int>& mapIdxMatches12, bool bIfMPOnly = true)
+    // (ORBmatcher.h:55): the key-frame views carry their feature vectors (FrameView::bow)
+    int SearchByBoW(const FrameView& kf1, const FrameView& kf2, std::map<int, int>& mapIdxMatches12, bool bIfMPOnly = true) {
+        if (!kf1.bow || !kf2.bow) throw std::invalid_argument("ORBmatcher::SearchByBoW: FrameView::bow is not set");
+        std::vector<int> dense;
+        const int n = SearchByBoW(kf1, *kf1.bow, kf2, *kf2.bow, dense, bIfMPOnly);
+        mapIdxMatches12.clear();
+        for (int i = 0; i < (int)dense.size(); ++i)
+            if (dense[i] >= 0) mapIdxMatches12[i] = dense[i];
+        return n;
+    }
+
+    float mfNNratio;             // public in the reference (ORBmatcher.h:65-66)
     bool mbCheckOrientation;
+
+protected:
     se2gpu_matcher* h_ = nullptr;
 };
 

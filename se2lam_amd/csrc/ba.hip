@@ -28,6 +28,7 @@
 #include <functional>
 #include <limits>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 #include "common.h"
@@ -3171,9 +3172,8 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
 // optimize() of `count` independent windows at once (one handle each, every handle on its own stream): all runs are
 // enqueued before the first wait, so the device works on them concurrently - local windows are far too small to fill
 // the chip one at a time.  stats may be NULL or an array of `count`.
-int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
+static int ba_optimize_group(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
                              se2gpu_ba_stats* stats) {
-    SE2_REQUIRE(hs && count >= 0, SE2GPU_ERR_INVALID, "optimize_batch: bad argument");
     for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_begin(hs[i], iters, mode, stop_flag, 0));
     std::vector<char> fin(count, 0);
     int left = count;
@@ -3192,6 +3192,36 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
                 if (!fin[i]) { int f = 0; SE2_CHECK(ba_run_step(hs[i], true, stop_flag, 0, &f)); if (f) { fin[i] = 1; --left; } }
     }
     for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_finish(hs[i], stats ? stats + i : nullptr));
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
+                             se2gpu_ba_stats* stats) {
+    SE2_REQUIRE(hs && count >= 0, SE2GPU_ERR_INVALID, "optimize_batch: bad argument");
+    for (int i = 0; i < count; ++i) SE2_REQUIRE(hs[i] && hs[i]->initialized, SE2GPU_ERR_STATE, "optimize_batch: handle %d is not initialised", i);
+    // A local window is a dozen launches per LM iteration; one host thread enqueues ~0.3 M launches per second, which is
+    // what bounds many small windows in flight.  The windows are therefore dealt to a few enqueue threads (each window
+    // stays on one thread: a handle is not thread-safe, its stream is its own).  SE2GPU_BA_BATCH_THREADS overrides.
+    static const int env_threads = [] { const char* e = getenv("SE2GPU_BA_BATCH_THREADS"); return e ? atoi(e) : 0; }();
+    int nthr = env_threads > 0 ? env_threads : 8;
+    nthr = std::max(1, std::min(nthr, count / 4));
+    if (nthr <= 1) return ba_optimize_group(hs, count, iters, mode, stop_flag, stats);
+    int dev = 0;
+    SE2_HIP(hipGetDevice(&dev));
+    std::vector<int> rc(nthr, SE2GPU_OK);
+    std::vector<std::string> err(nthr);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; ++t) {
+        const int b0 = (int)((long long)count * t / nthr), b1 = (int)((long long)count * (t + 1) / nthr);
+        th.emplace_back([=, &rc, &err]() {
+            (void)hipSetDevice(dev);
+            rc[t] = ba_optimize_group(hs + b0, b1 - b0, iters, mode, stop_flag, stats ? stats + b0 : nullptr);
+            if (rc[t] != SE2GPU_OK) err[t] = se2gpu_last_error();
+        });
+    }
+    for (auto& x : th) x.join();
+    for (int t = 0; t < nthr; ++t)
+        if (rc[t] != SE2GPU_OK) { set_error("%s", err[t].c_str()); return rc[t]; }
     return SE2GPU_OK;
 }
 

@@ -1556,8 +1556,10 @@ int se2gpu_orb_extract_batch_device(se2gpu_orb* h, const uint8_t* d_imgs, int nf
     SE2_REQUIRE(h && d_imgs && d_kps && d_desc && d_counts, SE2GPU_ERR_INVALID, "extract_batch: NULL argument");
     SE2_REQUIRE(nframes >= 1 && nframes <= h->max_batch, SE2GPU_ERR_CAPACITY, "nframes %d exceeds max_batch %d", nframes,
                 h->max_batch);
-    SE2_REQUIRE(rows <= h->params.max_rows && cols <= h->params.max_cols && rows > 0 && cols > 0, SE2GPU_ERR_INVALID,
-                "image %dx%d exceeds the handle's maximum %dx%d", rows, cols, h->params.max_rows, h->params.max_cols);
+    SE2_REQUIRE(rows > 0 && cols > 0, SE2GPU_ERR_INVALID, "image %dx%d", rows, cols);
+    // max_rows / max_cols are a sizing hint: a larger image grows the buffers (the reference's extractor takes any size)
+    h->params.max_rows = std::max(h->params.max_rows, rows);
+    h->params.max_cols = std::max(h->params.max_cols, cols);
     SE2_REQUIRE(cap > 0, SE2GPU_ERR_INVALID, "cap must be positive");
     SE2_CHECK(orb_configure(h, rows, cols));
     return orb_run(h, d_imgs, cols, nframes, d_kps, d_desc, d_counts, cap);
@@ -1570,8 +1572,10 @@ int se2gpu_orb_extract(se2gpu_orb* h, const uint8_t* img, int rows, int cols, si
     *n_out = 0;
     if (!img || rows == 0 || cols == 0) return SE2GPU_OK;  // _image.empty(): silent return (ORBextractor.cpp:730)
     SE2_REQUIRE(kps && desc && cap > 0, SE2GPU_ERR_INVALID, "orb_extract: NULL output");
-    SE2_REQUIRE(rows <= h->params.max_rows && cols <= h->params.max_cols && rows > 0 && cols > 0, SE2GPU_ERR_INVALID,
-                "image %dx%d exceeds the handle's maximum %dx%d", rows, cols, h->params.max_rows, h->params.max_cols);
+    SE2_REQUIRE(rows > 0 && cols > 0, SE2GPU_ERR_INVALID, "image %dx%d", rows, cols);
+    // max_rows / max_cols are a sizing hint: a larger image grows the buffers (the reference's extractor takes any size)
+    h->params.max_rows = std::max(h->params.max_rows, rows);
+    h->params.max_cols = std::max(h->params.max_cols, cols);
     SE2_CHECK(orb_configure(h, rows, cols));
     hipStream_t st = h->stream;
     SE2_CHECK(h->img.reserve((size_t)h->params.max_rows * h->params.max_cols));

@@ -50,7 +50,9 @@ int main() {
     bool abortBA = false;
     initOptimizer(optimizer, false);
     optimizer.setForceStopFlag(&abortBA);
-    CamPara campr = addCamPara(optimizer, 400.f, 320.f, 240.f, 0);
+    MatF Kcam = MatF::eye(3);
+    Kcam.at<float>(0, 0) = 400.f; Kcam.at<float>(1, 1) = 400.f; Kcam.at<float>(0, 2) = 320.f; Kcam.at<float>(1, 2) = 240.f;
+    CamPara* campr = addCamPara(optimizer, Kcam, 0);
     SE3Quat Tbc;
     const double R[9] = {0, 0, 1, -1, 0, 0, 0, -1, 0};
     std::memcpy(Tbc.R, R, sizeof(R));
@@ -58,11 +60,11 @@ int main() {
     addVertexSE2(optimizer, SE2{0, 0, 0}, 0, true);
     addVertexSE2(optimizer, SE2{500, 10, 0.02}, 1, false);
     Matrix3D oinfo{{1e-2, 0, 0, 0, 1e-2, 0, 0, 0, 1e3}};
-    addEdgeSE2(optimizer, Vector3D{{500, 0, 0}}, 0, 1, oinfo);
-    addVertexSBAXYZ(optimizer, Vector3D{{4000, 300, 500}}, 3);
-    Matrix2D info{{1, 0, 0, 1}};
-    addEdgeSE2XYZ(optimizer, Vector2D{{290.0, 260.0}}, 0, 3, &campr, Tbc, info, 2.4477);
-    addEdgeSE2XYZ(optimizer, Vector2D{{286.0, 262.0}}, 1, 3, &campr, Tbc, info, 2.4477);
+    addEdgeSE2(optimizer, Vector3D(500, 0, 0), 0, 1, oinfo);
+    addVertexSBAXYZ(optimizer, Vector3D(4000, 300, 500), 3);
+    Matrix2D info = Matrix2D::Identity();
+    addEdgeSE2XYZ(optimizer, Vector2D(290.0, 260.0), 0, 3, campr, Tbc, info, 2.4477);
+    addEdgeSE2XYZ(optimizer, Vector2D(286.0, 262.0), 1, 3, campr, Tbc, info, 2.4477);
     optimizer.initializeOptimization(0);
     const double chi0 = optimizer.activeRobustChi2();
     const int it = optimizer.optimize(5);
@@ -108,8 +110,8 @@ int main() {
         const double X = 3000 + 40 * i, Y = -900 + 31 * i, Z = 100 + 7 * (i % 9);
         const double xc = Rcb[0] * X + Rcb[1] * Y + Rcb[2] * Z + Tcw0.t[0], yc = Rcb[3] * X + Rcb[4] * Y + Rcb[5] * Z + Tcw0.t[1];
         const double zc = Rcb[6] * X + Rcb[7] * Y + Rcb[8] * Z + Tcw0.t[2];
-        mps.push_back(Vector3D{{X, Y, Z}});
-        obs.push_back(Vector2D{{400 * xc / zc + 320, 400 * yc / zc + 240}});
+        mps.push_back(Vector3D(X, Y, Z));
+        obs.push_back(Vector2D(400 * xc / zc + 320, 400 * yc / zc + 240));
         w.push_back(1.0);
     }
     SE3Quat start = Tcw0;

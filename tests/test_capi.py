@@ -75,6 +75,33 @@ def _build_adapter_binary(tmp_path):
     return out
 
 
+def _build_call_lines(tmp_path):
+    cxx = shutil.which("g++")
+    out = str(tmp_path / "cpp_call_lines")
+    libdir = os.path.join(ROOT, "se2lam_amd", "lib")
+    subprocess.check_call([cxx, "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp_reference_call_lines.cpp"), "-o", out, "-L", libdir, "-lse2gpu",
+                           "-Wl,-rpath," + libdir])
+    return out
+
+
+def test_reference_call_lines_compile_against_the_mirrors(tmp_path):
+    """Map.cpp:897, 925-930, 942-953, 985-989, 1045-1049, LocalMapper.cpp:239-260, Map.cpp:760-779, Track.cpp:34,131 pasted
+    against include/se2lam_amd (CamPara* addCamPara(opt, K, id), public mfNNratio, 5-argument ORBextractor, ...)."""
+    exe = _build_call_lines(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_call_lines_run_on_gpu(tmp_path):
+    exe = _build_call_lines(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "reference call lines ran" in r.stdout, r.stdout + r.stderr
+    kf1 = [l for l in r.stdout.splitlines() if l.startswith("KF 1:")][0].split()
+    assert abs(float(kf1[2]) - 500.0) < 50.0       # the free key frame stayed near its odometry prior
+
+
 def test_cpp_adapters_compile_and_link(tmp_path):
     exe = _build_adapter_binary(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
