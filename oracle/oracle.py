@@ -570,3 +570,96 @@ def ransac_subsets(n, count):
     fn = lib().match_ref_ransac_subsets; fn.restype = None; fn.argtypes = [C.c_int, C.c_int, C.c_void_p]
     fn(n, count, out.ctypes.data)
     return out
+
+
+# --------------------------------------------------------------------------------------
+# SE3-expmap bundle adjustment with marginalised points (oracle/ba3_ref.cpp)
+# --------------------------------------------------------------------------------------
+class Ba3Problem(C.Structure):
+    _fields_ = [("P", C.c_int32), ("L", C.c_int32), ("E", C.c_int32), ("O", C.c_int32),
+                ("poses", C.c_void_p), ("fixed", C.c_void_p), ("lms", C.c_void_p), ("e_kf", C.c_void_p),
+                ("e_lm", C.c_void_p), ("e_uv", C.c_void_p), ("e_w", C.c_void_p), ("has_prior", C.c_void_p),
+                ("prior_meas", C.c_void_p), ("prior_info", C.c_void_p), ("o_i", C.c_void_p), ("o_j", C.c_void_p),
+                ("o_meas", C.c_void_p), ("o_info", C.c_void_p),
+                ("f", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("huber", C.c_double)]
+
+
+def poses12(T):
+    """(P,4,4) -> (P,12): rotation row-major then translation"""
+    T = np.asarray(T, np.float64)
+    return np.ascontiguousarray(np.concatenate([T[:, :3, :3].reshape(-1, 9), T[:, :3, 3]], axis=1))
+
+
+def poses44(p12):
+    p12 = np.asarray(p12).reshape(-1, 12)
+    T = np.tile(np.eye(4), (len(p12), 1, 1))
+    T[:, :3, :3] = p12[:, :9].reshape(-1, 3, 3)
+    T[:, :3, 3] = p12[:, 9:]
+    return T
+
+
+def ba3_problem(g):
+    k = _Keep()
+    pr = Ba3Problem()
+    pr.P, pr.L, pr.E, pr.O = g.P, g.L, g.E, g.O
+    arrs = dict(poses=(poses12(g.poses), np.float64), fixed=(g.fixed, np.uint8), lms=(g.lms, np.float64),
+                e_kf=(g.e_kf, np.int32), e_lm=(g.e_lm, np.int32), e_uv=(g.e_uv, np.float64), e_w=(g.e_w, np.float64),
+                has_prior=(g.has_prior, np.uint8), prior_meas=(poses12(g.prior_meas), np.float64),
+                prior_info=(g.prior_info.reshape(g.P, 36), np.float64), o_i=(g.o_i, np.int32), o_j=(g.o_j, np.int32),
+                o_meas=(poses12(g.o_meas) if g.O else np.zeros((0, 12)), np.float64),
+                o_info=(g.o_info.reshape(g.O, 36), np.float64))
+    for name, (a, dt) in arrs.items():
+        setattr(pr, name, k.arr(a, dt).ctypes.data)
+    pr.f, pr.cx, pr.cy, pr.huber = g.fx, g.cx, g.cy, g.huber
+    return pr, k
+
+
+def ba3_chi2(g, poses=None, lms=None):
+    """-> (robust chi2, per-edge chi2 (E,))"""
+    pr, k = ba3_problem(g)
+    p = k.arr(poses12(g.poses if poses is None else poses), np.float64)
+    l = k.arr(g.lms if lms is None else lms, np.float64)
+    ec = np.zeros(max(g.E, 1))
+    f = lib().ba3_ref_chi2
+    f.restype = C.c_double
+    f.argtypes = [C.POINTER(Ba3Problem), C.c_void_p, C.c_void_p, C.c_void_p]
+    return float(f(C.byref(pr), p.ctypes.data, l.ctypes.data, ec.ctypes.data)), ec[:g.E]
+
+
+def ba3_reduced_system(g, lam):
+    pr, k = ba3_problem(g)
+    n = 6 * g.P
+    S = np.zeros((n, n)); bs = np.zeros(n)
+    p = k.arr(poses12(g.poses), np.float64); l = k.arr(g.lms, np.float64)
+    f = lib().ba3_ref_reduced_system
+    f.restype = None
+    f.argtypes = [C.POINTER(Ba3Problem), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    f(C.byref(pr), p.ctypes.data, l.ctypes.data, float(lam), S.ctypes.data, bs.ctypes.data)
+    return S, bs
+
+
+def ba3_optimize(g, iters=10):
+    """-> (poses (P,4,4), lms (L,3), per-edge chi2 (E,), stats)"""
+    pr, k = ba3_problem(g)
+    p = np.zeros((g.P, 12)); l = np.zeros((max(g.L, 1), 3)); ec = np.zeros(max(g.E, 1))
+    st = BaStats()
+    f = lib().ba3_ref_optimize
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(Ba3Problem), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(BaStats)]
+    rc = f(C.byref(pr), iters, p.ctypes.data, l.ctypes.data, ec.ctypes.data, C.byref(st))
+    assert rc == 0
+    n = min(st.iterations, 64)
+    stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated), chi2_init=st.chi2_init,
+                 chi2_final=st.chi2_final, lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
+                 lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]), rho_log=list(st.rho_log[:st.n_rho]))
+    return poses44(p), l[:g.L], ec[:g.E], stats
+
+
+def ba3_odo_edge(Ti, Tj, Cm):
+    e = np.zeros(6); Ji = np.zeros(36); Jj = np.zeros(36)
+    a, b, c = [np.ascontiguousarray(poses12(np.asarray(x)[None])[0]) for x in (Ti, Tj, Cm)]
+    f = lib().ba3_ref_odo_edge
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 6
+    f(a.ctypes.data, b.ctypes.data, c.ctypes.data, e.ctypes.data, Ji.ctypes.data, Jj.ctypes.data)
+    return e, Ji.reshape(6, 6), Jj.reshape(6, 6)

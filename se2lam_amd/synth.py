@@ -108,6 +108,7 @@ class BAGraph:
     huber: float = TH_HUBER
     poses_true: np.ndarray | None = None
     lms_true: np.ndarray | None = None
+    e_level: np.ndarray | None = None      # pyramid level of every observation (octave)
 
     @property
     def P(self) -> int:
@@ -152,6 +153,7 @@ class BAGraph:
             o_i=self.o_i[odo].copy(), o_j=self.o_j[odo].copy(),
             o_meas=self.o_meas[odo].copy(), o_info=self.o_info[odo].copy(),
             lms_true=None if self.lms_true is None else self.lms_true[keep_lm].copy(),
+            e_level=None if self.e_level is None else self.e_level[keep_e].copy(),
         )
 
 
@@ -370,4 +372,150 @@ def ba_graph(P: int = 50, L: int = 5000, obs_per_lm: float = 6.0, seed: int = BA
         o_info[i] = np.linalg.inv(c).reshape(-1)
     return BAGraph(poses=poses0, fixed=fixed, lms=lms0, e_kf=e_kf, e_lm=e_lm, e_uv=e_uv,
                    e_info=e_info, o_i=o_i, o_j=o_j, o_meas=o_meas, o_info=o_info,
-                   poses_true=poses_t, lms_true=lms_t)
+                   poses_true=poses_t, lms_true=lms_t, e_level=level.astype(np.int32))
+
+
+# --------------------------------------------------------------------------
+# SE3-expmap graphs: the same room / trajectory in the formulation of
+# Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx) (/root/reference/src/Map.cpp:414-566)
+# --------------------------------------------------------------------------
+def se2_to_Tcw(pose, Rbc=RBC, tbc=TBC):
+    """Tcw (4x4) of a body at SE(2) pose (x, y, theta) on the plane: Tcw = (Twb Tbc)^-1."""
+    c, s_ = np.cos(pose[2]), np.sin(pose[2])
+    Twb = np.array([[c, -s_, 0, pose[0]], [s_, c, 0, pose[1]], [0, 0, 1, 0], [0, 0, 0, 1.0]])
+    Tbc = np.eye(4)
+    Tbc[:3, :3] = Rbc
+    Tbc[:3, 3] = tbc
+    return np.linalg.inv(Twb @ Tbc)
+
+
+def _so3_exp(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def se3_exp_np(u):
+    """SE3Quat::exp of (omega, upsilon) as a 4x4 matrix (numpy restatement used by the generator and the independent model)."""
+    w, v = np.asarray(u[:3], float), np.asarray(u[3:], float)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+    if th < 1e-9:
+        V = np.eye(3) + 0.5 * K
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+    T = np.eye(4)
+    T[:3, :3] = _so3_exp(w)
+    T[:3, 3] = V @ v
+    return T
+
+
+def se3_log_np(T):
+    """SE3Quat::log -> (omega, upsilon)."""
+    from scipy.spatial.transform import Rotation
+    w = Rotation.from_matrix(T[:3, :3]).as_rotvec()
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0.0]])
+    if th < 1e-9:
+        Vi = np.eye(3) - 0.5 * K
+    else:
+        Vi = np.eye(3) - 0.5 * K + (1 - th / (2 * np.tan(th / 2))) / th ** 2 * K @ K
+    return np.concatenate([w, Vi @ T[:3, 3]])
+
+
+def se3_adj_np(T):
+    R, t = T[:3, :3], T[:3, 3]
+    K = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0.0]])
+    A = np.zeros((6, 6))
+    A[:3, :3] = R
+    A[3:, 3:] = R
+    A[3:, :3] = K @ R
+    return A
+
+
+def plane_motion_prior_np(Tcw, Rbc=RBC, tbc=TBC, xrot=PLANEMOTION_XROT_INFO, yrot=PLANEMOTION_XROT_INFO, zinfo=PLANEMOTION_Z_INFO):
+    """addPlaneMotionSE3Expmap (src/optimizer.cpp:236-314, non-Euler branch): (measurement 4x4, information 6x6)."""
+    from scipy.spatial.transform import Rotation
+    Tbc = np.eye(4)
+    Tbc[:3, :3] = Rbc
+    Tbc[:3, 3] = tbc
+    Tbw = Tbc @ Tcw
+    yaw = Rotation.from_matrix(Tbw[:3, :3]).as_rotvec()[2]
+    Tbw2 = np.eye(4)
+    Tbw2[:3, :3] = _so3_exp(np.array([0, 0, yaw]))
+    Tbw2[:3, 3] = [Tbw[0, 3], Tbw[1, 3], 0.0]
+    A = se3_adj_np(Tbc)
+    info = A.T @ np.diag([xrot, yrot, 1e-4, 1e-4, 1e-4, zinfo]) @ A
+    iu = np.triu_indices(6, 1)
+    info[(iu[1], iu[0])] = info[iu]          # the reference copies the upper triangle down (:296-298)
+    return np.linalg.inv(Tbc) @ Tbw2, info
+
+
+@dataclasses.dataclass
+class BA3Graph:
+    """poses (P,4,4) Tcw, fixed (P,), lms (L,3), e_kf/e_lm (E,), e_uv (E,2), e_w (E,) = invSigma2,
+    has_prior (P,), prior_meas (P,4,4), prior_info (P,6,6), o_i/o_j (O,) (vertex 0 / 1 of EdgeSE3Expmap), o_meas (O,4,4),
+    o_info (O,6,6)."""
+    poses: np.ndarray
+    fixed: np.ndarray
+    lms: np.ndarray
+    e_kf: np.ndarray
+    e_lm: np.ndarray
+    e_uv: np.ndarray
+    e_w: np.ndarray
+    has_prior: np.ndarray
+    prior_meas: np.ndarray
+    prior_info: np.ndarray
+    o_i: np.ndarray
+    o_j: np.ndarray
+    o_meas: np.ndarray
+    o_info: np.ndarray
+    fx: float = FX
+    cx: float = CX
+    cy: float = CY
+    huber: float = TH_HUBER
+    P = property(lambda self: int(self.poses.shape[0]))
+    L = property(lambda self: int(self.lms.shape[0]))
+    E = property(lambda self: int(self.e_kf.shape[0]))
+    O = property(lambda self: int(self.o_i.shape[0]))
+
+
+@functools.lru_cache(maxsize=4)
+def ba3_graph(P: int = 50, L: int = 5000, n_ref: int = 0, seed: int = BA_SEED) -> BA3Graph:
+    """The window of ba_graph(P, L) as an SE3-expmap graph: Tcw vertices (with small out-of-plane errors for the
+    plane-motion priors to pull back), invSigma2-weighted projection edges, one prior per local key frame, SE3 odometry
+    edges between consecutive key frames; the last n_ref key frames are reference key frames (fixed, no prior)."""
+    g = ba_graph(P, L, seed=seed)
+    rng = np.random.default_rng(seed + 77 * P + L + n_ref)
+    poses = np.stack([se2_to_Tcw(p) for p in g.poses])
+    for a in range(1, P):   # roll / pitch / height errors of a few mrad / mm
+        poses[a] = se3_exp_np(rng.normal(0, 1.0, 6) * np.array([2e-3, 2e-3, 2e-3, 3.0, 3.0, 3.0])) @ poses[a]
+    true = np.stack([se2_to_Tcw(p) for p in g.poses_true])
+    fixed = g.fixed.copy()
+    has_prior = np.ones(P, np.uint8)
+    if n_ref:
+        fixed[P - n_ref:] = 1
+        has_prior[P - n_ref:] = 0
+        fixed[0] = 0              # with reference key frames no local one is fixed (Map.cpp:428-438)
+    sf = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * SCALE_FACTOR
+    inv_sig2 = (1.0 / (sf * sf)).astype(np.float32).astype(np.float64)
+    e_w = inv_sig2[g.e_level]
+    pm = [plane_motion_prior_np(poses[a]) for a in range(P)]
+    nL = P - n_ref
+    o_i = np.arange(nL - 1, dtype=np.int32)
+    o_j = o_i + 1
+    o_meas = np.zeros((len(o_i), 4, 4))
+    o_info = np.zeros((len(o_i), 6, 6))
+    for k in range(len(o_i)):
+        noise = se3_exp_np(rng.normal(0, 1.0, 6) * np.array([1e-3, 1e-3, 2e-3, 2.0, 2.0, 2.0]))
+        o_meas[k] = noise @ true[o_j[k]] @ np.linalg.inv(true[o_i[k]])
+        A = np.diag([5e5, 5e5, 2e5, 0.2, 0.2, 0.2]) + 0.05 * np.diag([700, 700, 450, 0.45, 0.45, 0.45]) @ rng.normal(0, 1, (6, 6))
+        o_info[k] = 0.5 * (A + A.T) + np.diag([1e4, 1e4, 1e4, 0.02, 0.02, 0.02])
+        assert np.linalg.eigvalsh(o_info[k]).min() > 0
+    return BA3Graph(poses=poses, fixed=fixed, lms=g.lms.copy(), e_kf=g.e_kf, e_lm=g.e_lm, e_uv=g.e_uv, e_w=e_w,
+                    has_prior=has_prior, prior_meas=np.stack([m for m, _ in pm]), prior_info=np.stack([i for _, i in pm]),
+                    o_i=o_i, o_j=o_j, o_meas=o_meas, o_info=o_info)

@@ -121,3 +121,30 @@ def gaussian_float(src: np.ndarray, ksize: int = 7, sigma: float = 2.0) -> np.nd
     p = np.pad(src.astype(np.float64), r, mode="reflect")          # numpy 'reflect' == BORDER_REFLECT_101
     tmp = sum(k[i] * p[:, i:i + src.shape[1]] for i in range(ksize))
     return sum(k[i] * tmp[i:i + src.shape[0], :] for i in range(ksize))
+
+
+class BA3ProblemNumpy:
+    """The SE3-expmap local BA cost (Map.cpp:414-566) from the definitions, with numpy / scipy.spatial only:
+    sum_e rho_huber(w_e |uv - pi(T X)|^2) + sum_a |log(M_a T_a^-1)|^2_Omega_a + sum_o |log(T_j^-1 C T_i)|^2_Omega_o."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def cost(self, poses, lms):
+        g = self.g
+        T = np.asarray(poses)
+        Xc = np.einsum("eij,ej->ei", T[g.e_kf][:, :3, :3], np.asarray(lms)[g.e_lm]) + T[g.e_kf][:, :3, 3]
+        u = g.fx * Xc[:, 0] / Xc[:, 2] + g.cx
+        v = g.fx * Xc[:, 1] / Xc[:, 2] + g.cy
+        s = g.e_w * ((g.e_uv[:, 0] - u) ** 2 + (g.e_uv[:, 1] - v) ** 2)
+        d2 = g.huber ** 2
+        self.edge_chi2 = s
+        chi = np.where(s <= d2, s, 2 * np.sqrt(s) * g.huber - d2).sum()
+        for a in range(g.P):
+            if g.has_prior[a]:
+                e = synth.se3_log_np(g.prior_meas[a] @ np.linalg.inv(T[a]))
+                chi += e @ g.prior_info[a] @ e
+        for k in range(g.O):
+            e = synth.se3_log_np(np.linalg.inv(T[g.o_j[k]]) @ g.o_meas[k] @ T[g.o_i[k]])
+            chi += e @ g.o_info[k] @ e
+        return float(chi)
