@@ -196,6 +196,27 @@ int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O,
                    const int32_t* o_i, const int32_t* o_j, const double* o_meas, const double* o_info,
                    double huber_delta);
 
+/* ---- SE3-expmap graphs: the marginalising local bundle adjustment of
+ *   Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx)   /root/reference/src/Map.cpp:414-566
+ *   LocalMapper::removeOutlierChi2                          /root/reference/src/LocalMapper.cpp:172-230
+ * on the same handle type: a graph is EITHER SE(2) (add_vertex_se2 ...) OR SE3 (the calls below), decided by its first
+ * pose vertex.  pose12 = rotation row-major (9) then translation (3) of Tcw (x_c = R x_w + t); 6x6 information matrices
+ * row-major in g2o's vector order (rotation, translation).  Replaces, of /root/reference/include/se2lam/optimizer.h:
+ *   addVertexSE3Expmap (:88)                     -> se2gpu_ba_add_vertex_se3
+ *   addPlaneMotionSE3Expmap (:82)                -> se2gpu_plane_motion_prior (host) + se2gpu_ba_add_prior_se3
+ *   addEdgeSE3Expmap (:94)                       -> se2gpu_ba_add_edge_se3   (error = log(T_id1^-1 * measure * T_id0))
+ *   addEdgeXYZ2UV (:97)                          -> se2gpu_ba_add_edge_xyz2uv (information = inv_sigma2 * I, Huber)
+ *   addVertexSBAXYZ / estimateVertexSBAXYZ       -> se2gpu_ba_add_vertex_xyz / se2gpu_ba_get_xyz (shared)
+ *   estimateVertexSE3Expmap (:138)               -> se2gpu_ba_get_se3
+ *   EdgeProjectXYZ2UV::computeError() + chi2()   -> se2gpu_ba_edge_chi2 (all edges, in the order they were added)
+ * initialize / optimize / optimize_batch / chi2 / clear are the common ones.  Single GPU only. */
+int se2gpu_ba_add_vertex_se3(se2gpu_ba* h, int id, const double pose12[12], int fixed);
+int se2gpu_ba_add_prior_se3(se2gpu_ba* h, int id, const double meas12[12], const double info36[36]);
+int se2gpu_ba_add_edge_se3(se2gpu_ba* h, int id0, int id1, const double meas12[12], const double info36[36]);
+int se2gpu_ba_add_edge_xyz2uv(se2gpu_ba* h, int id_mp, int id_kf, const double uv[2], double inv_sigma2, double huber_delta);
+int se2gpu_ba_get_se3(se2gpu_ba* h, int id, double pose12[12]);
+int se2gpu_ba_edge_chi2(se2gpu_ba* h, double* chi2, int cap);
+
 /* Map::loadLocalGraph(SlamOptimizer&) (/root/reference/src/Map.cpp:891-1022) as ONE call on a POD view of the local
  * window - SURVEY.md section 8f.1.  The caller flattens its pointer graph once per key frame (INTEGRATION.md shows the
  * 30 lines that do it with one hash map instead of the reference's std::find per observation); the library applies

@@ -116,6 +116,12 @@ SYMBOLS = {
     "se2gpu_ba_add_edge_se2": (_I, [_VP, _I, _I, _PD, _PD]),
     "se2gpu_ba_load": (_I, [_VP, _I, _I, _I, _I, _PD, _PU8, _PD, _PI32, _PI32, _PD, _PD, _PI32, _PI32, _PD, _PD, _D]),
     "se2gpu_ba_load_local_graph": (_I, [_VP, C.POINTER(LocalGraph)]),
+    "se2gpu_ba_add_vertex_se3": (_I, [_VP, _I, _PD, _I]),
+    "se2gpu_ba_add_prior_se3": (_I, [_VP, _I, _PD, _PD]),
+    "se2gpu_ba_add_edge_se3": (_I, [_VP, _I, _I, _PD, _PD]),
+    "se2gpu_ba_add_edge_xyz2uv": (_I, [_VP, _I, _I, _PD, _D, _D]),
+    "se2gpu_ba_get_se3": (_I, [_VP, _I, _PD]),
+    "se2gpu_ba_edge_chi2": (_I, [_VP, _PD, _I]),
     "se2gpu_ba_initialize": (_I, [_VP]),
     "se2gpu_ba_reset_estimates": (_I, [_VP]),
     "se2gpu_ba_optimize": (_I, [_VP, _I, _I, _PU8, _I, C.POINTER(BaStats)]),

@@ -32,6 +32,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include "se3_math.h"
 
 using namespace se2gpu;
 
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __rest
 
 // max |diag| over a strided array (computeLambdaInit); single block, deterministic.
 __global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const double* __restrict__ Hpp_diag3,
-                          const uint8_t* __restrict__ fixed, double* __restrict__ out) {
+                          const uint8_t* __restrict__ fixed, double* __restrict__ out, int dpp) {
     __shared__ double sm[1024];
     double m = 0;
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
@@ -376,7 +377,7 @@ __global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const do
     }
     for (int i = threadIdx.x; i < P; i += blockDim.x)
         if (!fixed[i])
-            for (int r = 0; r < 3; ++r) m = fmax(m, fabs(Hpp_diag3[(size_t)i * 3 + r]));
+            for (int r = 0; r < dpp; ++r) m = fmax(m, fabs(Hpp_diag3[(size_t)i * dpp + r]));
     sm[threadIdx.x] = m;
     __syncthreads();
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {
@@ -1461,6 +1462,588 @@ __global__ void k_fill_slots(double* __restrict__ dst, const double* __restrict_
     if (r < world) dst[r] = (r == rank) ? maxd[0] : 0.0;
 }
 
+// =============================================================================================
+// SE3-expmap model: the marginalising local bundle adjustment of
+//   Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx)      /root/reference/src/Map.cpp:414-566
+//   EdgeSE3ExpmapPrior / addPlaneMotionSE3Expmap               /root/reference/src/optimizer.cpp:159-197, 236-314
+//   LocalMapper::removeOutlierChi2                             /root/reference/src/LocalMapper.cpp:172-230
+// on the same machinery as the SE(2) model (landmark-sorted edges, device-built contributor plan, dataflow pose solve,
+// device-side LM controller): only the per-edge / per-pose arithmetic differs.  Poses are Tcw as 12 doubles (R row-major,
+// t); a pose has D = 6 unknowns (update = (omega, upsilon), estimate <- exp(update) * estimate); reduced-system blocks
+// are 6x6 (36-lane groups, 7 per workgroup); per-edge blocks: Hpl 6x3, Hpp_e sym 6x6 (21), bp_e 6, Y 6x3 and the
+// diagonal record Dg = {sym(Hpp_e - Y Hpl^T) (21), bp_e (6), Hpl z (6)} (33).
+// [3P g2o 20160424] VertexSE3Expmap, EdgeProjectXYZ2UV, EdgeSE3Expmap, SE3Quat - restated as in oracle/ba3_ref.cpp.
+// =============================================================================================
+constexpr int kD3 = 6, kGrpPerWG3 = 7;
+struct Cam3 { double f, cx, cy, huber; };
+__device__ __host__ inline int sym6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }   // r <= c
+
+template <bool JAC>
+__device__ inline void proj3(const Cam3& cam, const double* __restrict__ T, double X0, double X1, double X2, double u, double v,
+                             double& e0, double& e1, double* Jp, double* Jl) {
+    const double x = T[0] * X0 + T[1] * X1 + T[2] * X2 + T[9];
+    const double y = T[3] * X0 + T[4] * X1 + T[5] * X2 + T[10];
+    const double z = T[6] * X0 + T[7] * X1 + T[8] * X2 + T[11];
+    const double zi = 1.0 / z;
+    e0 = u - (x * zi * cam.f + cam.cx);
+    e1 = v - (y * zi * cam.f + cam.cy);
+    if (JAC) {
+        const double f = cam.f, zi2 = zi * zi;
+        const double t02 = -x * zi * f, t12 = -y * zi * f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Jl[c] = -zi * (f * T[c] + t02 * T[6 + c]);
+            Jl[3 + c] = -zi * (f * T[3 + c] + t12 * T[6 + c]);
+        }
+        Jp[0] = x * y * zi2 * f; Jp[1] = -(1 + (x * x * zi2)) * f; Jp[2] = y * zi * f; Jp[3] = -zi * f; Jp[4] = 0; Jp[5] = x * zi2 * f;
+        Jp[6] = (1 + y * y * zi2) * f; Jp[7] = -x * y * zi2 * f; Jp[8] = -x * zi * f; Jp[9] = 0; Jp[10] = -zi * f; Jp[11] = y * zi2 * f;
+    }
+}
+
+// Dinv-dependent part of one edge: Y = Hpl Dinv and the diagonal record
+__device__ inline void schur_edge3(const double* __restrict__ hh, const double d[6], const double* __restrict__ hp,
+                                   const double* __restrict__ bpe, double z0, double z1, double z2,
+                                   double* __restrict__ y, double* __restrict__ dg) {
+    double yy[18];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const double b0 = hh[3 * r], b1 = hh[3 * r + 1], b2 = hh[3 * r + 2];
+        yy[3 * r] = b0 * d[0] + b1 * d[1] + b2 * d[2];
+        yy[3 * r + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
+        yy[3 * r + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
+    }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) y[i] = yy[i];
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c, ++k)
+            dg[k] = hp[k] - (yy[3 * r] * hh[3 * c] + yy[3 * r + 1] * hh[3 * c + 1] + yy[3 * r + 2] * hh[3 * c + 2]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        dg[21 + r] = bpe[r];
+        dg[27 + r] = hh[3 * r] * z0 + hh[3 * r + 1] * z1 + hh[3 * r + 2] * z2;
+    }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k3_linearize(Cam3 cam, int L, const int* __restrict__ lm_ptr,
+                                                        const int* __restrict__ e_kf, const double* __restrict__ e_uv,
+                                                        const double* __restrict__ e_info, const double* __restrict__ poses,
+                                                        const uint8_t* __restrict__ fixed, const double* __restrict__ lms,
+                                                        double* Hpl, double* __restrict__ Hpp_e, double* __restrict__ bp_e,
+                                                        double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                        double* __restrict__ Dinv, double* __restrict__ z,
+                                                        double* __restrict__ Y, double* __restrict__ Dg,
+                                                        const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                        const double* __restrict__ lms_b) {
+    if (ctl) {
+        if (ctl->done | ctl->retry) return;
+        if (ctl->sel) { poses = poses_b; lms = lms_b; }
+        lambda = ctl->lambda;
+    }
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    if (l < L) {
+        const double X0 = lms[3 * (size_t)l], X1 = lms[3 * (size_t)l + 1], X2 = lms[3 * (size_t)l + 2];
+        for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
+            const int kf = e_kf[e];
+            double e0, e1, Jp[12], Jl[6];
+            proj3<true>(cam, poses + 12 * (size_t)kf, X0, X1, X2, e_uv[2 * (size_t)e], e_uv[2 * (size_t)e + 1], e0, e1, Jp, Jl);
+            const double w = e_info[3 * (size_t)e];   // information = w I
+            double r0, r1;
+            huber(w * (e0 * e0 + e1 * e1), cam.huber, r0, r1);
+            const double W = r1 * w, o0 = -W * e0, o1 = -W * e1;
+            hll[0] += W * (Jl[0] * Jl[0] + Jl[3] * Jl[3]);
+            hll[1] += W * (Jl[0] * Jl[1] + Jl[3] * Jl[4]);
+            hll[2] += W * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
+            hll[3] += W * (Jl[1] * Jl[1] + Jl[4] * Jl[4]);
+            hll[4] += W * (Jl[1] * Jl[2] + Jl[4] * Jl[5]);
+            hll[5] += W * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) b[r] += Jl[r] * o0 + Jl[3 + r] * o1;
+            const bool fr = !fixed[kf];
+            double* hpl = Hpl + (size_t)e * 18;
+            double* hpp = Hpp_e + (size_t)e * 21;
+            int k = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hpl[3 * r + c] = fr ? W * (Jp[r] * Jl[c] + Jp[6 + r] * Jl[3 + c]) : 0.0;
+#pragma unroll
+                for (int c = r; c < 6; ++c, ++k) hpp[k] = fr ? W * (Jp[r] * Jp[c] + Jp[6 + r] * Jp[6 + c]) : 0.0;
+                bp_e[(size_t)e * 6 + r] = fr ? Jp[r] * o0 + Jp[6 + r] * o1 : 0.0;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) hll[i] = group_sum(hll[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = group_sum(b[i]);
+    if (l < L && sub == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Hll[(size_t)l * 6 + i] = hll[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) bl[(size_t)l * 3 + i] = b[i];
+    }
+    if (FUSED && l < L) {
+        double d[6];
+        inv_sym3(hll, lambda, d);
+        const double z0 = d[0] * b[0] + d[1] * b[1] + d[2] * b[2];
+        const double z1 = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
+        const double z2 = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
+            z[(size_t)l * 3] = z0; z[(size_t)l * 3 + 1] = z1; z[(size_t)l * 3 + 2] = z2;
+        }
+        for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup)
+            schur_edge3(Hpl + (size_t)e * 18, d, Hpp_e + (size_t)e * 21, bp_e + (size_t)e * 6, z0, z1, z2, Y + (size_t)e * 18,
+                        Dg + (size_t)e * 33);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k3_schur_lm(int L, double lambda, const int* __restrict__ lm_ptr,
+                                                       const double* __restrict__ Hll, const double* __restrict__ bl,
+                                                       const double* __restrict__ Hpl, const double* __restrict__ Hpp_e,
+                                                       const double* __restrict__ bp_e, double* __restrict__ Dinv,
+                                                       double* __restrict__ z, double* __restrict__ Y, double* __restrict__ Dg,
+                                                       const BaCtl* __restrict__ ctl, int force) {
+    if (ctl) {
+        if (ctl->done || !(force | ctl->retry)) return;
+        lambda = ctl->lambda;
+    }
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    if (l >= L) return;
+    double h[6], d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = Hll[(size_t)l * 6 + i];
+    inv_sym3(h, lambda, d);
+    const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
+    const double z0 = d[0] * b0 + d[1] * b1 + d[2] * b2, z1 = d[1] * b0 + d[3] * b1 + d[4] * b2, z2 = d[2] * b0 + d[4] * b1 + d[5] * b2;
+    if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
+        z[(size_t)l * 3] = z0; z[(size_t)l * 3 + 1] = z1; z[(size_t)l * 3 + 2] = z2;
+    }
+    for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup)
+        schur_edge3(Hpl + (size_t)e * 18, d, Hpp_e + (size_t)e * 21, bp_e + (size_t)e * 6, z0, z1, z2, Y + (size_t)e * 18,
+                    Dg + (size_t)e * 33);
+}
+
+// Per-pose and per-odometry-edge terms that depend on the estimate only (not on lambda): the prior gradient Omega e of
+// EdgeSE3ExpmapPrior (e = log(M T^-1), Jacobian -I: H += Omega, b += Omega e) and the blocks of every EdgeSE3Expmap
+// (e = log(T_j^-1 C T_i), J_i = adj(T_j^-1 C), J_j = -adj(T_i^-1 C^-1)): Oii, Ojj, Oij (6x6), obi, obj (6).
+// One thread per pose, then one thread per odometry edge.
+__global__ void k3_terms(int P, int O, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                         const uint8_t* __restrict__ prior_has, const double* __restrict__ prior_meas,
+                         const double* __restrict__ prior_info, double* __restrict__ pb, const int* __restrict__ o_i,
+                         const int* __restrict__ o_j, const double* __restrict__ o_meas, const double* __restrict__ o_info,
+                         double* __restrict__ Oii, double* __restrict__ Ojj, double* __restrict__ Oij,
+                         double* __restrict__ obi, double* __restrict__ obj, const BaCtl* __restrict__ ctl,
+                         const double* __restrict__ poses_b) {
+    if (ctl) {
+        if (ctl->done | ctl->retry) return;
+        if (ctl->sel) poses = poses_b;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P) {
+        double g[6] = {0, 0, 0, 0, 0, 0};
+        if (prior_has[t] && !fixed[t]) {
+            double e[6];
+            se3_log(se3_mul(se3_load(prior_meas + 12 * (size_t)t), se3_inv(se3_load(poses + 12 * (size_t)t))), e);
+            const double* W = prior_info + 36 * (size_t)t;
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) g[r] += W[6 * r + c] * e[c];
+        }
+        for (int r = 0; r < 6; ++r) pb[6 * (size_t)t + r] = g[r];
+        return;
+    }
+    const int k = t - P;
+    if (k >= O) return;
+    const int i = o_i[k], j = o_j[k];
+    const Se3 Ti = se3_load(poses + 12 * (size_t)i), Tj = se3_load(poses + 12 * (size_t)j), C = se3_load(o_meas + 12 * (size_t)k);
+    const Se3 TjC = se3_mul(se3_inv(Tj), C);
+    double e[6], Ji[36], Jj[36], We[6];
+    se3_log(se3_mul(TjC, Ti), e);
+    se3_adj(TjC, Ji);
+    se3_adj(se3_mul(se3_inv(Ti), se3_inv(C)), Jj);
+    for (int q = 0; q < 36; ++q) Jj[q] = -Jj[q];
+    const double* W = o_info + 36 * (size_t)k;
+    for (int r = 0; r < 6; ++r) {
+        We[r] = 0;
+        for (int c = 0; c < 6; ++c) We[r] += W[6 * r + c] * e[c];
+    }
+    const bool fi = !fixed[i], fj = !fixed[j];
+    for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) {
+            double ii = 0, jj = 0, ij = 0;
+            for (int a = 0; a < 6; ++a) {
+                double wi = 0, wj = 0;
+                for (int q = 0; q < 6; ++q) { wi += W[6 * a + q] * Ji[6 * q + c]; wj += W[6 * a + q] * Jj[6 * q + c]; }
+                ii += Ji[6 * a + r] * wi;
+                jj += Jj[6 * a + r] * wj;
+                ij += Ji[6 * a + r] * wj;
+            }
+            Oii[36 * (size_t)k + 6 * r + c] = fi ? ii : 0.0;
+            Ojj[36 * (size_t)k + 6 * r + c] = fj ? jj : 0.0;
+            Oij[36 * (size_t)k + 6 * r + c] = (fi && fj) ? ij : 0.0;
+        }
+        double bi = 0, bj = 0;
+        for (int q = 0; q < 6; ++q) { bi += Ji[6 * q + r] * We[q]; bj += Jj[6 * q + r] * We[q]; }
+        obi[6 * (size_t)k + r] = fi ? -bi : 0.0;
+        obj[6 * (size_t)k + r] = fj ? -bj : 0.0;
+    }
+}
+
+// The reduced system of the SE3 model in one launch (structure of k_reduce2): off-diagonal 6x6 blocks from the
+// contributor plan (36 lanes per 16-pair chunk, 7 chunks per workgroup), one workgroup per pose for the diagonal
+// block, b_s and b_p (gather of the 33-double records + prior + odometry terms of k3_terms).
+__global__ __launch_bounds__(kBlock) void k3_reduce2(int P, int ld, int nwg_off, double lambda, const int4* __restrict__ grp,
+                                                      const int* __restrict__ blk_a, const int* __restrict__ blk_b,
+                                                      const int* __restrict__ pair_i, const int* __restrict__ pair_j,
+                                                      const int* __restrict__ blk_odo, const double* __restrict__ Y,
+                                                      const double* __restrict__ Hpl, const double* __restrict__ Dg,
+                                                      const uint8_t* __restrict__ fixed, const int* __restrict__ pose_ptr,
+                                                      const int* __restrict__ pose_edges, const int* __restrict__ podo_ptr,
+                                                      const int* __restrict__ podo_item, const uint8_t* __restrict__ prior_has,
+                                                      const double* __restrict__ prior_info, const double* __restrict__ pb,
+                                                      const double* __restrict__ Oii, const double* __restrict__ Ojj,
+                                                      const double* __restrict__ Oij, const double* __restrict__ obi,
+                                                      const double* __restrict__ obj, double* __restrict__ S,
+                                                      double* __restrict__ bp, const BaCtl* __restrict__ ctl) {
+    if (ctl) {
+        if (ctl->done) return;
+        lambda = ctl->lambda;
+    }
+    const int n = 6 * P;
+    __shared__ double part[kGrpPerWG3][36];
+    __shared__ double dpart[kBlock / 64][33];
+    const int ndiag = (P + 1 + 7) & ~7;
+    if ((int)blockIdx.x >= ndiag) {
+        const int bid = (int)blockIdx.x - ndiag;
+        const int nwg_pad = (nwg_off + 7) & ~7;
+        const int wg = (bid & 7) * (nwg_pad >> 3) + (bid >> 3);   // contiguous eighths of the plan per XCD (see k_reduce2)
+        if (wg >= nwg_off) return;
+        const int g = threadIdx.x / 36, en = threadIdx.x - 36 * g;
+        int4 d = make_int4(-1, 0, 0, 0);
+        if (g < kGrpPerWG3) d = grp[(size_t)wg * kGrpPerWG3 + g];
+        const int r = en / 6, c = en - 6 * r;
+        double acc = 0;
+        if (d.x >= 0) {
+            for (int q = d.y; q < d.z; q += 4) {
+                int ia[4], ib[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int qq = min(q + u, d.z - 1);
+                    ia[u] = pair_i[qq];
+                    ib[u] = pair_j[qq];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double* y = Y + (size_t)ia[u] * 18 + 3 * r;
+                    const double* hh = Hpl + (size_t)ib[u] * 18 + 3 * c;
+                    const double w = (q + u < d.z) ? 1.0 : 0.0;
+                    acc += w * (y[0] * hh[0] + y[1] * hh[1] + y[2] * hh[2]);
+                }
+            }
+            part[g][en] = acc;
+        }
+        __syncthreads();
+        if (d.x >= 0 && (d.w & 0xff) == g) {
+            const int ng = d.w >> 8;
+            double tot = 0;
+            for (int t = 0; t < ng; ++t) tot += part[g + t][en];
+            const int a = blk_a[d.x], b = blk_b[d.x];
+            double out = 0.0;
+            if (!fixed[a] && !fixed[b]) {
+                out = -tot;
+                const int od = blk_odo[d.x];
+                if (od >= 0) out += (od & 1) ? Oij[36 * (size_t)(od >> 1) + 6 * c + r] : Oij[36 * (size_t)(od >> 1) + 6 * r + c];
+            }
+            S[(size_t)(6 * a + r) * ld + 6 * b + c] = out;
+            S[(size_t)(6 * b + c) * ld + 6 * a + r] = out;
+        }
+        return;
+    }
+    const int p = (int)blockIdx.x;
+    if (p > P) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* __restrict__ bs = S + (size_t)n * ld;
+    if (p == P) {
+        for (size_t t = (size_t)n * ld + n + threadIdx.x; t < (size_t)ld * ld; t += kBlock) S[t] = 0.0;
+        if (threadIdx.x == 0) S[(size_t)ld * ld + 2] = 0.0;
+        return;
+    }
+    const bool fa = fixed[p];
+    double acc[33];
+#pragma unroll
+    for (int i = 0; i < 33; ++i) acc[i] = 0;
+    if (!fa) {
+        const int e0 = pose_ptr[p], ne = pose_ptr[p + 1] - e0;
+        for (int t = threadIdx.x; t < ne; t += kBlock) {
+            const double* rec = Dg + (size_t)pose_edges[e0 + t] * 33;
+#pragma unroll
+            for (int i = 0; i < 33; ++i) acc[i] += rec[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 33; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 33; ++i) dpart[wv][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 42) {   // 36 entries of the block (row-major), then 6 right-hand-side components
+        const int i = threadIdx.x;
+        if (i < 36) {
+            const int r = i / 6, c = i - 6 * r;
+            double out;
+            if (fa) {
+                out = (r == c) ? 1.0 : 0.0;
+            } else {
+                const int k = r <= c ? sym6(r, c) : sym6(c, r);
+                double v = dpart[0][k] + dpart[1][k] + dpart[2][k] + dpart[3][k];
+                if (prior_has[p]) v += prior_info[36 * (size_t)p + i];
+                for (int t = podo_ptr[p]; t < podo_ptr[p + 1]; ++t) {
+                    const int ko = podo_item[t] >> 1;
+                    v += ((podo_item[t] & 1) ? Ojj : Oii)[36 * (size_t)ko + i];
+                }
+                out = v + (r == c ? lambda : 0.0);
+            }
+            S[(size_t)(6 * p + r) * ld + 6 * p + c] = out;
+        } else {
+            const int r = i - 36;
+            double v = dpart[0][21 + r] + dpart[1][21 + r] + dpart[2][21 + r] + dpart[3][21 + r];
+            const double gz = dpart[0][27 + r] + dpart[1][27 + r] + dpart[2][27 + r] + dpart[3][27 + r];
+            if (!fa) {
+                v += pb[6 * (size_t)p + r];
+                for (int t = podo_ptr[p]; t < podo_ptr[p + 1]; ++t) {
+                    const int ko = podo_item[t] >> 1;
+                    v += ((podo_item[t] & 1) ? obj : obi)[6 * (size_t)ko + r];
+                }
+            }
+            bs[6 * p + r] = fa ? 0.0 : v - gz;
+            bp[6 * (size_t)p + r] = fa ? 0.0 : v;
+        }
+    }
+}
+
+// diagonal of the un-reduced pose blocks (computeLambdaInit): one wave per pose
+__global__ __launch_bounds__(kBlock) void k3_pose_diag(int P, const int* __restrict__ pose_ptr, const int* __restrict__ pose_edges,
+                                                        const double* __restrict__ Hpp_e, const uint8_t* __restrict__ fixed,
+                                                        const uint8_t* __restrict__ prior_has, const double* __restrict__ prior_info,
+                                                        const int* __restrict__ podo_ptr, const int* __restrict__ podo_item,
+                                                        const double* __restrict__ Oii, const double* __restrict__ Ojj,
+                                                        double* __restrict__ diag) {
+    const int p = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    const int lane = threadIdx.x & 63;
+    if (p >= P) return;
+    double d[6] = {0, 0, 0, 0, 0, 0};
+    for (int t = pose_ptr[p] + lane; t < pose_ptr[p + 1]; t += 64) {
+        const double* hp = Hpp_e + (size_t)pose_edges[t] * 21;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) d[r] += hp[sym6(r, r)];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) d[r] = wave_sum(d[r]);
+    if (lane == 0) {
+        for (int r = 0; r < 6; ++r) {
+            double v = d[r];
+            if (!fixed[p]) {
+                if (prior_has[p]) v += prior_info[36 * (size_t)p + 7 * r];
+                for (int t = podo_ptr[p]; t < podo_ptr[p + 1]; ++t)
+                    v += ((podo_item[t] & 1) ? Ojj : Oii)[36 * (size_t)(podo_item[t] >> 1) + 7 * r];
+            }
+            diag[6 * (size_t)p + r] = v;
+        }
+    }
+}
+
+// trial poses: exp(update) * estimate (VertexSE3Expmap::oplusImpl); estimate copied for fixed poses / without a step
+__global__ void k3_oplus(int P, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                         const double* __restrict__ xp, double* __restrict__ poses_trial, const BaCtl* __restrict__ ctl) {
+    if (ctl) {
+        if (ctl->done) return;
+        if (ctl->sel) { const double* t = poses; poses = poses_trial; poses_trial = const_cast<double*>(t); }
+    }
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    Se3 T = se3_load(poses + 12 * (size_t)p);
+    if (!fixed[p]) {
+        double u[6];
+        for (int r = 0; r < 6; ++r) u[r] = xp[6 * (size_t)p + r];
+        T = se3_mul(se3_exp(u), T);
+    }
+    se3_store(T, poses_trial + 12 * (size_t)p);
+}
+
+// back-substitution, trial landmarks, robust chi^2 of the landmark's edges at the trial state (poses from k3_oplus)
+__global__ __launch_bounds__(kBlock) void k3_update(Cam3 cam, int L, double lambda, const int* __restrict__ lm_ptr,
+                                                     const int* __restrict__ e_kf, const double* __restrict__ e_uv,
+                                                     const double* __restrict__ e_info, const double* __restrict__ poses_a,
+                                                     const double* __restrict__ poses_b, const double* __restrict__ lms,
+                                                     const double* __restrict__ xp, const double* __restrict__ z,
+                                                     const double* __restrict__ Y, const double* __restrict__ bl,
+                                                     double* __restrict__ lms_trial, double* __restrict__ part,
+                                                     const BaCtl* __restrict__ ctl, int step, double* __restrict__ edge_chi2) {
+    // poses_a / poses_b: "a" / "b" pose buffers.  With a step the TRIAL poses are read (the buffer that does not hold the
+    // estimate), without one the estimate.
+    const double* poses = poses_a;
+    if (ctl) {
+        if (ctl->done && !edge_chi2) return;
+        const bool est_b = ctl->sel != 0;
+        poses = (est_b != (step != 0)) ? poses_b : poses_a;
+        if (est_b) { const double* t = lms; lms = lms_trial; lms_trial = const_cast<double*>(t); }
+        lambda = ctl->lambda;
+    }
+    __shared__ double sm[2][kBlock / 64];
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    double chi = 0, scale = 0, x[3] = {0, 0, 0};
+    int beg = 0, end = 0;
+    if (l < L) {
+        beg = lm_ptr[l];
+        end = lm_ptr[l + 1];
+        if (step)
+            for (int e = beg + sub; e < end; e += kGroup) {
+                const double* y = Y + (size_t)e * 18;
+                const double* q = xp + 6 * (size_t)e_kf[e];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) x[c] -= y[3 * r + c] * q[r];
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = group_sum(x[c]);
+    if (l < L) {
+        double lw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (step) x[c] += z[(size_t)l * 3 + c];
+            lw[c] = lms[(size_t)l * 3 + c] + x[c];
+        }
+        if (sub == 0 && step) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lms_trial[(size_t)l * 3 + c] = lw[c];
+                scale += x[c] * (lambda * x[c] + bl[(size_t)l * 3 + c]);
+            }
+        }
+        for (int e = beg + sub; e < end; e += kGroup) {
+            double e0, e1, r0, r1;
+            proj3<false>(cam, poses + 12 * (size_t)e_kf[e], lw[0], lw[1], lw[2], e_uv[2 * (size_t)e], e_uv[2 * (size_t)e + 1], e0, e1,
+                         nullptr, nullptr);
+            const double c2 = e_info[3 * (size_t)e] * (e0 * e0 + e1 * e1);
+            if (edge_chi2) edge_chi2[e] = c2;
+            huber(c2, cam.huber, r0, r1);
+            chi += r0;
+        }
+    }
+    chi = wave_sum(chi);
+    scale = wave_sum(scale);
+    const int w = threadIdx.x / 64;
+    if ((threadIdx.x & 63) == 0) { sm[0][w] = chi; sm[1][w] = scale; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0, s2 = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { c += sm[0][i]; s2 += sm[1][i]; }
+        part[2 * blockIdx.x] = c;
+        part[2 * blockIdx.x + 1] = s2;
+    }
+}
+
+// single block: sums the k3_update partials, adds the prior and odometry chi^2 at the trial poses and the pose part of
+// computeScale(), advances the LM controller (structure of k_finalize)
+__global__ void k3_finalize(int nparts, const double* __restrict__ part, int P, const double* __restrict__ poses_a,
+                            const double* __restrict__ poses_b, const uint8_t* __restrict__ fixed, const double* __restrict__ xp,
+                            const double* __restrict__ bp, const uint8_t* __restrict__ prior_has,
+                            const double* __restrict__ prior_meas, const double* __restrict__ prior_info, int O,
+                            const int* __restrict__ o_i, const int* __restrict__ o_j, const double* __restrict__ o_meas,
+                            const double* __restrict__ o_info, double* __restrict__ out, volatile double* __restrict__ mail,
+                            double seq, BaCtl* __restrict__ ctl, int step, int notify, const volatile int* __restrict__ stop) {
+    __shared__ double sm[2][16];
+    __shared__ int post_s;
+    if (ctl->done) {
+        if (notify && mail) {
+            post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) mail[3] = seq;
+        }
+        return;
+    }
+    const bool est_b = ctl->sel != 0;
+    const double* poses = (est_b != (step != 0)) ? poses_b : poses_a;   // trial poses with a step, the estimate without
+    const double lambda = ctl->lambda;
+    double chi = 0, scale = 0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+        chi += part[2 * i];
+        scale += part[2 * i + 1];
+    }
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        if (step && !fixed[p])
+            for (int r = 0; r < 6; ++r) scale += xp[6 * (size_t)p + r] * (lambda * xp[6 * (size_t)p + r] + bp[6 * (size_t)p + r]);
+        if (prior_has[p]) {
+            double e[6];
+            se3_log(se3_mul(se3_load(prior_meas + 12 * (size_t)p), se3_inv(se3_load(poses + 12 * (size_t)p))), e);
+            const double* W = prior_info + 36 * (size_t)p;
+            for (int r = 0; r < 6; ++r) {
+                double v = 0;
+                for (int c = 0; c < 6; ++c) v += W[6 * r + c] * e[c];
+                chi += e[r] * v;
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < O; k += blockDim.x) {
+        const Se3 Ti = se3_load(poses + 12 * (size_t)o_i[k]), Tj = se3_load(poses + 12 * (size_t)o_j[k]);
+        double e[6];
+        se3_log(se3_mul(se3_mul(se3_inv(Tj), se3_load(o_meas + 12 * (size_t)k)), Ti), e);
+        const double* W = o_info + 36 * (size_t)k;
+        for (int r = 0; r < 6; ++r) {
+            double v = 0;
+            for (int c = 0; c < 6; ++c) v += W[6 * r + c] * e[c];
+            chi += e[r] * v;
+        }
+    }
+    chi = wave_sum(chi);
+    scale = wave_sum(scale);
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = chi;
+        sm[1][threadIdx.x >> 6] = scale;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            sm[0][0] += sm[0][w];
+            sm[1][0] += sm[1][w];
+        }
+        out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0;
+        if (!step) {
+            out[2] = 0;
+            ctl->current_chi = ctl->chi2_init = ctl->chi2_final = sm[0][0];
+            if (stop && *stop) { ctl->stopped = 1; ctl->done = 1; }
+            if (ctl->iters <= 0) ctl->done = 1;
+        } else {
+            const double sc[3] = {sm[0][0], sm[1][0], out[2]};
+            lm_advance(ctl, sc, stop);
+        }
+        post_s = (ctl->done || notify) && mail;
+    }
+    __syncthreads();
+    if (post_s) {
+        __threadfence();
+        post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) mail[3] = seq;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host: dense SPD solve of the reduced pose system (replaces CHOLMOD on the (3P)^2 matrix).
 // Blocked right-looking LL^T on the lower triangle, row-major, FP64.
@@ -1613,6 +2196,17 @@ struct se2gpu_ba {
     std::vector<double> he_uv, he_info;       // 2 / 3 (xx, xy, yy) per edge
     double huber_delta = 0;
     bool huber_mixed = false;
+    // pose model: 0 = SE(2) (VertexSE2 / EdgeSE2XYZ / PreEdgeSE2), 1 = SE3-expmap (VertexSE3Expmap / EdgeProjectXYZ2UV /
+    // EdgeSE3ExpmapPrior / EdgeSE3Expmap).  D = unknowns per pose, ps = doubles a pose is stored in.
+    int model = 0, D = 3, ps = 3;
+    Cam3 cam3{};
+    std::vector<uint8_t> h_prior_has;
+    std::vector<double> h_prior_meas, h_prior_info;      // 12 / 36 per pose
+    struct Odo3 { int i, j; double meas[12], info[36]; };
+    std::vector<Odo3> odo3;
+    DevBuf<uint8_t> prior_has;
+    DevBuf<double> prior_meas, prior_info, pb, edge_chi2;
+    std::vector<int> edge_perm;                          // sorted position -> insertion index (empty = identity)
     // se2gpu_ba_load: the caller's edge arrays, borrowed until initialize (copied once, straight into the pinned arena)
     int bulk_E = 0;
     const int32_t *bulk_kf = nullptr, *bulk_lm = nullptr;
@@ -1900,17 +2494,17 @@ __global__ void k_plan_odo(int P, int O, const int* __restrict__ o_i, const int*
 // function {used -> (used', workgroups closed)}, tabulated by one thread for all 28 start states; one thread composes
 // the 256 tables; every thread then replays its run from its now known start and writes the group descriptors.
 // out_n[0] = number of workgroups.
-__device__ inline void pack_step(int cnt, int& used, int& wg, int& first, int& ng, int& chunk) {
+__device__ inline void pack_step(int cnt, int gpw, int& used, int& wg, int& first, int& ng, int& chunk) {
     chunk = kChunk;
     ng = max(1, (cnt + chunk - 1) / chunk);
-    if (ng > kGrpPerWG) { chunk = (cnt + kGrpPerWG - 1) / kGrpPerWG; ng = (cnt + chunk - 1) / chunk; }
-    if (used + ng > kGrpPerWG) { ++wg; used = 0; }   // flush(): pad the current workgroup
+    if (ng > gpw) { chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
+    if (used + ng > gpw) { ++wg; used = 0; }   // flush(): pad the current workgroup
     first = used;
     used += ng;
 }
 __global__ __launch_bounds__(256) void k_plan_pack(int nblk, const int* __restrict__ blk_a, const int* __restrict__ blk_b,
                                                     const int* __restrict__ blk_ptr, int4* __restrict__ grp,
-                                                    int grp_cap_wg, int* __restrict__ out_n) {
+                                                    int grp_cap_wg, int* __restrict__ out_n, int gpw) {
     __shared__ int tab_used[256][kGrpPerWG], tab_wg[256][kGrpPerWG];
     __shared__ int start_used[256], start_wg[256];
     const int t = threadIdx.x;
@@ -1924,12 +2518,12 @@ __global__ __launch_bounds__(256) void k_plan_pack(int nblk, const int* __restri
             if (blk_a[kb] == blk_b[kb]) continue;
             const int cnt = blk_ptr[kb + 1] - blk_ptr[kb];
             int ng = max(1, (cnt + kChunk - 1) / kChunk);
-            if (ng > kGrpPerWG) { const int chunk = (cnt + kGrpPerWG - 1) / kGrpPerWG; ng = (cnt + chunk - 1) / chunk; }
+            if (ng > gpw) { const int chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
 #pragma unroll
-            for (int u = 0; u < kGrpPerWG; ++u) {
-                if (used[u] + ng > kGrpPerWG) { ++wgs[u]; used[u] = 0; }
+            for (int u = 0; u < kGrpPerWG; ++u) {   // (states >= gpw are never reached)
+                if (used[u] + ng > gpw) { ++wgs[u]; used[u] = 0; }
                 used[u] += ng;
-                if (used[u] == kGrpPerWG) { used[u] = 0; ++wgs[u]; }
+                if (used[u] == gpw) { used[u] = 0; ++wgs[u]; }
             }
         }
 #pragma unroll
@@ -1952,13 +2546,13 @@ __global__ __launch_bounds__(256) void k_plan_pack(int nblk, const int* __restri
         if (blk_a[kb] == blk_b[kb]) continue;
         const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
         int first, ng, chunk;
-        pack_step(q1 - q0, used, wg, first, ng, chunk);
+        pack_step(q1 - q0, gpw, used, wg, first, ng, chunk);
         if (wg < grp_cap_wg)
             for (int g = 0; g < ng; ++g) {
                 const int a0 = q0 + g * chunk, a1 = min(q1, a0 + chunk);
-                grp[(size_t)wg * kGrpPerWG + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
+                grp[(size_t)wg * gpw + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
             }
-        if (used == kGrpPerWG) { used = 0; ++wg; }
+        if (used == gpw) { used = 0; ++wg; }
     }
 }
 __global__ void k_fill_int4(size_t n, int4 v, int4* __restrict__ out) {
@@ -1976,7 +2570,7 @@ struct HostPlan {
     int nwg_off = 0;
 };
 void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const uint8_t* fx, int O, const int* o_i,
-                  const int* o_j, bool odo_ok, HostPlan& pl) {
+                  const int* o_j, bool odo_ok, HostPlan& pl, int gpw = kGrpPerWG) {
     pl.lm_ptr.assign(L + 1, 0);
     for (int s = 0; s < E; ++s) pl.lm_ptr[e_lm[s] + 1]++;
     for (int l = 0; l < L; ++l) pl.lm_ptr[l + 1] += pl.lm_ptr[l];
@@ -2042,7 +2636,7 @@ void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const u
     grp.clear();
     int used = 0;  // groups used in the current workgroup
     auto flush = [&]() {
-        while (used % kGrpPerWG) { grp.push_back(make_int4(-1, 0, 0, 0)); ++used; }
+        while (used % gpw) { grp.push_back(make_int4(-1, 0, 0, 0)); ++used; }
         used = 0;
     };
     for (int kb = 0; kb < nblk; ++kb) {
@@ -2050,19 +2644,19 @@ void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const u
         const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
         int chunk = kChunk;
         int ng = std::max(1, (q1 - q0 + chunk - 1) / chunk);
-        if (ng > kGrpPerWG) { chunk = (q1 - q0 + kGrpPerWG - 1) / kGrpPerWG; ng = (q1 - q0 + chunk - 1) / chunk; }
-        if (used + ng > kGrpPerWG) flush();
+        if (ng > gpw) { chunk = (q1 - q0 + gpw - 1) / gpw; ng = (q1 - q0 + chunk - 1) / chunk; }
+        if (used + ng > gpw) flush();
         const int first = used;
         for (int t = 0; t < ng; ++t) {
             const int a0 = q0 + t * chunk, a1 = std::min(q1, a0 + chunk);
             grp.push_back(make_int4(kb, a0, std::max(a0, a1), first | (ng << 8)));
             ++used;
         }
-        if (used == kGrpPerWG) used = 0;
+        if (used == gpw) used = 0;
     }
     flush();
-    if (grp.empty()) grp.assign(kGrpPerWG, make_int4(-1, 0, 0, 0));
-    pl.nwg_off = (int)(grp.size() / kGrpPerWG);
+    if (grp.empty()) grp.assign(gpw, make_int4(-1, 0, 0, 0));
+    pl.nwg_off = (int)(grp.size() / gpw);
 }
 
 int ba_upload_graph(se2gpu_ba* h) {
@@ -2074,12 +2668,16 @@ int ba_upload_graph(se2gpu_ba* h) {
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
     const int P = (int)h->pose_ids.size(), L = (int)h->lm_ids.size();
-    const int E = h->bulk_E ? h->bulk_E : (int)h->he_kf.size(), O = (int)h->odo.size();
+    const int E = h->bulk_E ? h->bulk_E : (int)h->he_kf.size(), O = h->model ? (int)h->odo3.size() : (int)h->odo.size();
+    const int D = h->D, ps = h->ps, gpw = h->model ? kGrpPerWG3 : kGrpPerWG;
+    const int DS = D * (D + 1) / 2;   // entries of a symmetric pose block
     SE2_REQUIRE(P > 0, SE2GPU_ERR_STATE, "initialize: no pose vertices");
+    SE2_REQUIRE(!h->model || (h->world == 1 && !h->allreduce), SE2GPU_ERR_STATE, "the SE3 model is single-GPU");
     SE2_REQUIRE(h->have_cam, SE2GPU_ERR_STATE, "initialize: add_cam was not called");
     SE2_REQUIRE(!h->huber_mixed, SE2GPU_ERR_INVALID, "all EdgeSE2XYZ must share one Huber delta (Map.cpp:977)");
     h->P = P; h->L = L; h->E = E; h->O = O;
     h->cam.huber = E ? h->huber_delta : 0.0;
+    h->cam3 = Cam3{h->cam.fx, h->cam.cx, h->cam.cy, h->cam.huber};
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) h->cam.Rcb[i * 3 + j] = h->Rbc[j * 3 + i];
     for (int i = 0; i < 3; ++i)
@@ -2109,13 +2707,16 @@ int ba_upload_graph(se2gpu_ba* h) {
         npairs_max += run * (run ? run - 1 : 0) / 2;
     }
     SE2_REQUIRE(in_range, SE2GPU_ERR_INVALID, "an edge references a vertex out of range");
+    h->edge_perm.clear();
     if (!sorted) {
         std::vector<int> ptr(L + 1, 0);
         for (int k = 0; k < E; ++k) ptr[e_lm[k] + 1]++;
         for (int l = 0; l < L; ++l) ptr[l + 1] += ptr[l];
         s_kf.resize(E); s_lm.resize(E); s_uv.resize(2 * (size_t)E); s_info.resize(3 * (size_t)E);
+        h->edge_perm.assign(E, 0);
         for (int k = 0; k < E; ++k) {
             const int t = ptr[e_lm[k]]++;
+            h->edge_perm[t] = k;
             s_kf[t] = e_kf[k]; s_lm[t] = e_lm[k];
             s_uv[2 * (size_t)t] = e_uv[2 * (size_t)k]; s_uv[2 * (size_t)t + 1] = e_uv[2 * (size_t)k + 1];
             for (int c = 0; c < 3; ++c) s_info[3 * (size_t)t + c] = e_info[3 * (size_t)k + c];
@@ -2135,11 +2736,18 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_REQUIRE(npairs_max < (size_t)1 << 30, SE2GPU_ERR_CAPACITY, "the contributor plan would hold %zu pairs", npairs_max);
     // --- odometry (tiny: host)
     std::vector<int> o_i(O), o_j(O), podo_ptr(P + 1, 0), podo_item(2 * (size_t)O);
-    std::vector<double> o_meas(3 * (size_t)O), o_info(9 * (size_t)O);
+    const int ms = h->model ? 12 : 3, is = h->model ? 36 : 9;   // doubles per measurement / information
+    std::vector<double> o_meas((size_t)ms * O), o_info((size_t)is * O);
     for (int k = 0; k < O; ++k) {
-        o_i[k] = h->odo[k].i; o_j[k] = h->odo[k].j;
-        std::memcpy(&o_meas[3 * k], h->odo[k].meas, 24);
-        std::memcpy(&o_info[9 * k], h->odo[k].info, 72);
+        if (h->model) {
+            o_i[k] = h->odo3[k].i; o_j[k] = h->odo3[k].j;
+            std::memcpy(&o_meas[12 * (size_t)k], h->odo3[k].meas, 96);
+            std::memcpy(&o_info[36 * (size_t)k], h->odo3[k].info, 288);
+        } else {
+            o_i[k] = h->odo[k].i; o_j[k] = h->odo[k].j;
+            std::memcpy(&o_meas[3 * k], h->odo[k].meas, 24);
+            std::memcpy(&o_info[9 * k], h->odo[k].info, 72);
+        }
         podo_ptr[o_i[k] + 1]++;
         podo_ptr[o_j[k] + 1]++;
     }
@@ -2170,12 +2778,12 @@ int ba_upload_graph(se2gpu_ba* h) {
     lap("edge check + odometry");
     HostPlan pl;
     if (!device_plan) {
-        ba_plan_host(P, L, E, e_kf, e_lm, h->h_fixed.data(), O, o_i.data(), o_j.data(), !h->odo_fallback, pl);
+        ba_plan_host(P, L, E, e_kf, e_lm, h->h_fixed.data(), O, o_i.data(), o_j.data(), !h->odo_fallback, pl, gpw);
         h->nwg_off = pl.nwg_off;
         lap("host plan");
     }
     hipStream_t st = h->stream;
-    const int n = 3 * P;
+    const int n = D * P;
     // All uploads go through ONE pinned arena into ONE device arena with ONE copy (a copy from pageable memory is staged
     // synchronously by the runtime, about 20 us each; two dozen separate enqueues were a tenth of a local window's cycle).
     struct Staged { std::function<void(uint8_t*)> bind; const void* src; size_t bytes, off; };
@@ -2201,6 +2809,11 @@ int ba_upload_graph(se2gpu_ba* h) {
     stage(h->o_j, o_j.data(), o_j.size());
     stage(h->o_meas, o_meas.data(), o_meas.size());
     stage(h->o_info, o_info.data(), o_info.size());
+    if (h->model) {
+        stage(h->prior_has, h->h_prior_has.data(), h->h_prior_has.size());
+        stage(h->prior_meas, h->h_prior_meas.data(), h->h_prior_meas.size());
+        stage(h->prior_info, h->h_prior_info.data(), h->h_prior_info.size());
+    }
     if (h->lg_active) {
         SE2_REQUIRE(sorted && h->lg_sigma2.size() == (size_t)E, SE2GPU_ERR_STATE,
                     "load_local_graph must not be mixed with add_edge calls");
@@ -2221,27 +2834,31 @@ int ba_upload_graph(se2gpu_ba* h) {
         stage(h->pair_i, pl.pair_i.data(), pl.pair_i.size());
         stage(h->pair_j, pl.pair_j.data(), pl.pair_j.size());
     }
-    SE2_CHECK(h->poses_a.reserve(3 * (size_t)P));
-    SE2_CHECK(h->poses_b.reserve(3 * (size_t)P));
+    SE2_CHECK(h->poses_a.reserve((size_t)ps * P));
+    SE2_CHECK(h->poses_b.reserve((size_t)ps * P));
     SE2_CHECK(h->lms_a.reserve(3 * (size_t)L + 1));
     SE2_CHECK(h->lms_b.reserve(3 * (size_t)L + 1));
-    SE2_CHECK(h->Hpl.reserve(9 * (size_t)E + 1));
-    SE2_CHECK(h->Y.reserve(9 * (size_t)E + 1));
-    SE2_CHECK(h->Hpp_e.reserve(6 * (size_t)E + 1));
-    SE2_CHECK(h->bp_e.reserve(3 * (size_t)E + 1));
-    SE2_CHECK(h->Dg.reserve(12 * (size_t)E + 1));
+    SE2_CHECK(h->Hpl.reserve((size_t)D * 3 * E + 1));
+    SE2_CHECK(h->Y.reserve((size_t)D * 3 * E + 1));
+    SE2_CHECK(h->Hpp_e.reserve((size_t)DS * E + 1));
+    SE2_CHECK(h->bp_e.reserve((size_t)D * E + 1));
+    SE2_CHECK(h->Dg.reserve((size_t)(DS + 2 * D) * E + 1));
     SE2_CHECK(h->Hll.reserve(6 * (size_t)L + 1));
     SE2_CHECK(h->bl.reserve(3 * (size_t)L + 1));
     SE2_CHECK(h->Dinv.reserve(6 * (size_t)L + 1));
     SE2_CHECK(h->z.reserve(3 * (size_t)L + 1));
-    SE2_CHECK(h->Hpp.reserve(9 * (size_t)P));
-    SE2_CHECK(h->bp.reserve(3 * (size_t)P));
-    SE2_CHECK(h->diag3.reserve(3 * (size_t)P));
-    SE2_CHECK(h->Oii.reserve(9 * (size_t)O + 1));
-    SE2_CHECK(h->Ojj.reserve(9 * (size_t)O + 1));
-    SE2_CHECK(h->Oij.reserve(9 * (size_t)O + 1));
-    SE2_CHECK(h->obi.reserve(3 * (size_t)O + 1));
-    SE2_CHECK(h->obj.reserve(3 * (size_t)O + 1));
+    SE2_CHECK(h->Hpp.reserve((size_t)D * D * P));
+    SE2_CHECK(h->bp.reserve((size_t)D * P));
+    SE2_CHECK(h->diag3.reserve((size_t)D * P));
+    SE2_CHECK(h->Oii.reserve((size_t)D * D * O + 1));
+    SE2_CHECK(h->Ojj.reserve((size_t)D * D * O + 1));
+    SE2_CHECK(h->Oij.reserve((size_t)D * D * O + 1));
+    SE2_CHECK(h->obi.reserve((size_t)D * O + 1));
+    SE2_CHECK(h->obj.reserve((size_t)D * O + 1));
+    if (h->model) {
+        SE2_CHECK(h->pb.reserve(6 * (size_t)P));
+        SE2_CHECK(h->edge_chi2.reserve((size_t)E + 1));
+    }
     SE2_CHECK(h->xp.reserve(n));
     h->nparts = (L * kGroup + kBlock - 1) / kBlock;
     SE2_CHECK(h->part.reserve(2 * (size_t)std::max(h->nparts, 1)));
@@ -2313,8 +2930,8 @@ int ba_upload_graph(se2gpu_ba* h) {
         SE2_CHECK(h->plan_toff.reserve(nhist / kScanTile + 4));
         // groups <= pairs / 16 + off-diagonal blocks; two consecutive workgroups hold more than 28 groups together
         const size_t G = npairs_max / kChunk + (size_t)P * (P - 1) / 2 + 1;
-        const int cap_wg = (int)std::min<size_t>((size_t)P * (P - 1) / 2 + 1, 2 * G / kGrpPerWG + 2) + 1;
-        SE2_CHECK(h->grp.reserve((size_t)cap_wg * kGrpPerWG));
+        const int cap_wg = (int)std::min<size_t>((size_t)P * (P - 1) / 2 + 1, 2 * G / gpw + 2) + 1;
+        SE2_CHECK(h->grp.reserve((size_t)cap_wg * gpw));
         h->grp_cap_wg = cap_wg;
         auto radix = [&](const int* kin, int* kout, auto* vin, auto* vout, size_t cnt, int shift, int bits) -> int {
             using V = std::remove_pointer_t<decltype(vout)>;
@@ -2356,10 +2973,10 @@ int ba_upload_graph(se2gpu_ba* h) {
         hipLaunchKernelGGL(k_plan_blocks, dim3((P + 255) / 256, P), dim3(256), 0, st, P, h->blk_a.p, h->blk_b.p, h->blk_odo.p);
         if (O && !h->odo_fallback)
             hipLaunchKernelGGL(k_plan_odo, grid1(O, 64), dim3(64), 0, st, P, O, h->o_i.p, h->o_j.p, h->blk_odo.p);
-        hipLaunchKernelGGL(k_fill_int4, grid1((size_t)cap_wg * kGrpPerWG, 256), dim3(256), 0, st, (size_t)cap_wg * kGrpPerWG,
+        hipLaunchKernelGGL(k_fill_int4, grid1((size_t)cap_wg * gpw, 256), dim3(256), 0, st, (size_t)cap_wg * gpw,
                            make_int4(-1, 0, 0, 0), h->grp.p);
         hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(256), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->grp.p,
-                           cap_wg, h->plan_out.p);
+                           cap_wg, h->plan_out.p, gpw);
         SE2_HIP(hipGetLastError());
         SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
         SE2_HIP(hipMemcpyAsync(h->h_scal.p, h->plan_out.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -2388,7 +3005,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
     h->lms = h->lms_a.p; h->lms_t = h->lms_b.p;
-    SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)P * 8, hipMemcpyDeviceToDevice, st));
+    SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, (size_t)ps * P * 8, hipMemcpyDeviceToDevice, st));
     if (L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
     SE2_HIP(hipStreamSynchronize(st));
     if (device_plan) {
@@ -2421,6 +3038,22 @@ inline Bufs bufs(se2gpu_ba* h, bool ctl) {
 int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
     hipStream_t st = h->stream;
     const Bufs B = bufs(h, ctl);
+    if (h->model) {
+        if (fuse_lambda >= 0.0)
+            SE2_LAUNCH(h->prof, st, "k3_linearize", (k3_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
+                       h->cam3, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
+                       h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p, B.c, B.pb, B.lb);
+        else
+            SE2_LAUNCH(h->prof, st, "k3_linearize", (k3_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
+                       h->cam3, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
+                       h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p, B.c, B.pb, B.lb);
+        // the prior gradients and the odometry blocks of this linearisation
+        SE2_LAUNCH(h->prof, st, "k3_terms", k3_terms, grid1((size_t)h->P + h->O, 64), dim3(64), 0, h->P, h->O, B.pa, h->fixed.p,
+                   h->prior_has.p, h->prior_meas.p, h->prior_info.p, h->pb.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p,
+                   h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, B.c, B.pb);
+        SE2_HIP(hipGetLastError());
+        return SE2GPU_OK;
+    }
     if (fuse_lambda >= 0.0)
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
@@ -2453,6 +3086,18 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
     hipStream_t st = h->stream;
     double* S = h->red;
     const Bufs B = bufs(h, ctl);
+    if (h->model) {
+        if (schur)
+            SE2_LAUNCH(h->prof, st, "k3_schur_lm", k3_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
+                       lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->Y.p,
+                       h->Dg.p, B.c, schur == 2 ? 0 : 1);
+        SE2_LAUNCH(h->prof, st, "k3_reduce2", k3_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0,
+                   h->P, h->ld, h->nwg_off, lambda, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p,
+                   h->Y.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->podo_ptr.p, h->podo_item.p,
+                   h->prior_has.p, h->prior_info.p, h->pb.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, S, h->bp.p, B.c);
+        SE2_HIP(hipGetLastError());
+        return SE2GPU_OK;
+    }
     if (schur)
         SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
                    lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->Y.p,
@@ -2541,7 +3186,7 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
 // `fail` = scalar slot [2] of the fused buffer: set to 1 by the factorisation on a non-positive pivot.
 int ba_solve(se2gpu_ba* h, bool ctl = false) {
     hipStream_t st = h->stream;
-    const int n = 3 * h->P;
+    const int n = h->D * h->P;
     const int ld = h->ld;
     double* A = h->red;
     double* fail = h->red + (size_t)ld * ld + 2;
@@ -2585,6 +3230,16 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
 // h->poses at this point (first trial of an optimize() call).
 int ba_lambda_init(se2gpu_ba* h) {
     hipStream_t st = h->stream;
+    if (h->model) {   // diagonal of the pose blocks (observations + prior + odometry), then the common maximum
+        SE2_LAUNCH(h->prof, st, "k3_pose_diag", k3_pose_diag, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
+                   h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->fixed.p, h->prior_has.p, h->prior_info.p, h->podo_ptr.p,
+                   h->podo_item.p, h->Oii.p, h->Ojj.p, h->diag3.p);
+        SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
+                   h->fixed.p, h->scal.p, 6);
+        hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, st, h->ctl.p, h->scal.p, 1);
+        SE2_HIP(hipGetLastError());
+        return SE2GPU_OK;
+    }
     SE2_CHECK(ba_pose_blocks(h, h->poses));
     SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
                h->Hpp.p, h->diag3.p);
@@ -2598,7 +3253,7 @@ int ba_lambda_init(se2gpu_ba* h) {
         SE2_HIP(hipMemcpyAsync(h->diag3.p, h->red, nd * 8, hipMemcpyDeviceToDevice, st));
     }
     SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
-               h->fixed.p, h->scal.p);
+               h->fixed.p, h->scal.p, 3);
     if (sharded) {
         // max over ranks through the SUM all-reduce: every rank deposits its local max in its own slot
         SE2_REQUIRE(h->world <= 1024, SE2GPU_ERR_INVALID, "world size %d > 1024", h->world);
@@ -2618,12 +3273,25 @@ int ba_lambda_init(se2gpu_ba* h) {
 // mode: kernels that would do nothing are not launched, so per-kernel profiles stay clean).
 int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, double seq) {
     hipStream_t st = h->stream;
-    const int n = 3 * h->P;
+    const int n = h->D * h->P;
     const bool lm = h->run_mode == SE2GPU_BA_LM;
     const bool sharded = h->allreduce != nullptr;
     double* scal = h->red + (size_t)h->ld * h->ld;
     const Bufs B = bufs(h, true);
     auto evaluate = [&](bool step, bool note) -> int {
+        if (h->model) {
+            if (step)
+                SE2_LAUNCH(h->prof, st, "k3_oplus", k3_oplus, grid1(h->P, 64), dim3(64), 0, h->P, B.pa, h->fixed.p, h->xp.p, B.pb, B.c);
+            SE2_LAUNCH(h->prof, st, "k3_update", k3_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam3, h->L,
+                       0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, B.pb, B.la, h->xp.p, h->z.p, h->Y.p, h->bl.p,
+                       B.lb, h->part.p, B.c, step ? 1 : 0, (double*)nullptr);
+            SE2_LAUNCH(h->prof, st, "k3_finalize", k3_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
+                       B.pa, B.pb, h->fixed.p, h->xp.p, h->bp.p, h->prior_has.p, h->prior_meas.p, h->prior_info.p, h->O,
+                       h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, scal, h->d_mail, seq, h->ctl.p, step ? 1 : 0, note ? 1 : 0,
+                       (const volatile int*)h->d_stop);
+            SE2_HIP(hipGetLastError());
+            return SE2GPU_OK;
+        }
         SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
                    0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
                    step ? h->xp.p : (const double*)nullptr, h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb);
@@ -2660,6 +3328,8 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
 }
 
 }  // namespace
+
+static int ba_fetch_estimates(se2gpu_ba* h);
 
 extern "C" {
 
@@ -2735,6 +3405,8 @@ int se2gpu_ba_clear(se2gpu_ba* h) {
     h->he_kf.clear(); h->he_lm.clear(); h->he_uv.clear(); h->he_info.clear();
     h->huber_delta = 0; h->huber_mixed = false;
     h->bulk_E = 0; h->bulk_kf = h->bulk_lm = nullptr; h->bulk_uv = h->bulk_info = nullptr;
+    h->model = 0; h->D = 3; h->ps = 3;
+    h->h_prior_has.clear(); h->h_prior_meas.clear(); h->h_prior_info.clear(); h->odo3.clear(); h->edge_perm.clear();
     h->lg_active = false;
     h->lg_lc.clear(); h->lg_lw.clear(); h->lg_sigma2.clear(); h->lg_Rcw.clear(); h->lg_twb.clear();
     h->have_cam = false;
@@ -2769,6 +3441,7 @@ int se2gpu_ba_add_vertex_se2(se2gpu_ba* h, int id, double x, double y, double th
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
     SE2_REQUIRE(h->pose_of_id.find(id) < 0 && h->lm_of_id.find(id) < 0, SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    SE2_REQUIRE(h->model == 0, SE2GPU_ERR_STATE, "VertexSE2 in a graph of VertexSE3Expmap poses");
     h->pose_of_id.set(id, (int)h->pose_ids.size());
     h->pose_ids.push_back(id);
     h->h_poses.push_back(x); h->h_poses.push_back(y); h->h_poses.push_back(normalize_theta(theta));  // SE2 ctor
@@ -2862,6 +3535,99 @@ int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O, const double* poses
     return SE2GPU_OK;
 }
 
+// ---- SE3-expmap graph construction (optimizer.h:82-98): addVertexSE3Expmap, addPlaneMotionSE3Expmap's prior edge,
+// addEdgeSE3Expmap, addEdgeXYZ2UV.  pose12 = rotation row-major (9) then translation (3) of Tcw.
+int se2gpu_ba_add_vertex_se3(se2gpu_ba* h, int id, const double pose12[12], int fixed) {
+    SE2_REQUIRE(h && pose12, SE2GPU_ERR_INVALID, "add_vertex_se3: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    SE2_REQUIRE(h->model == 1 || h->pose_ids.empty(), SE2GPU_ERR_STATE, "VertexSE3Expmap in a graph of VertexSE2 poses");
+    SE2_REQUIRE(h->pose_of_id.find(id) < 0 && h->lm_of_id.find(id) < 0, SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    h->model = 1; h->D = 6; h->ps = 12;
+    h->pose_of_id.set(id, (int)h->pose_ids.size());
+    h->pose_ids.push_back(id);
+    Se3 T = se3_load(pose12);
+    normalize_rotation(T.R);                       // SE3Quat(R, t) normalises its quaternion
+    double q[12];
+    se3_store(T, q);
+    h->h_poses.insert(h->h_poses.end(), q, q + 12);
+    h->h_fixed.push_back(fixed ? 1 : 0);
+    h->h_prior_has.push_back(0);
+    h->h_prior_meas.insert(h->h_prior_meas.end(), q, q + 12);
+    h->h_prior_info.insert(h->h_prior_info.end(), 36, 0.0);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_add_prior_se3(se2gpu_ba* h, int id, const double meas12[12], const double info36[36]) {
+    SE2_REQUIRE(h && meas12 && info36, SE2GPU_ERR_INVALID, "add_prior_se3: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    const int a = h->model == 1 ? h->pose_of_id.find(id) : -1;
+    SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "add_prior_se3: unknown SE3 pose id %d", id);
+    SE2_REQUIRE(!h->h_prior_has[a], SE2GPU_ERR_INVALID, "pose %d already has an EdgeSE3ExpmapPrior", id);
+    h->h_prior_has[a] = 1;
+    std::memcpy(&h->h_prior_meas[12 * (size_t)a], meas12, 96);
+    std::memcpy(&h->h_prior_info[36 * (size_t)a], info36, 288);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_add_edge_se3(se2gpu_ba* h, int id0, int id1, const double meas12[12], const double info36[36]) {
+    SE2_REQUIRE(h && meas12 && info36, SE2GPU_ERR_INVALID, "add_edge_se3: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    const int a = h->model == 1 ? h->pose_of_id.find(id0) : -1, b = h->model == 1 ? h->pose_of_id.find(id1) : -1;
+    SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_se3: unknown SE3 pose id (%d, %d)", id0, id1);
+    SE2_REQUIRE(a != b, SE2GPU_ERR_INVALID, "add_edge_se3: self loop on pose %d", id0);
+    for (const auto& o : h->odo3)
+        SE2_REQUIRE(!((o.i == a && o.j == b) || (o.i == b && o.j == a)), SE2GPU_ERR_INVALID,
+                    "a second EdgeSE3Expmap between poses %d and %d", id0, id1);
+    se2gpu_ba::Odo3 e;
+    e.i = a; e.j = b;
+    std::memcpy(e.meas, meas12, 96);
+    std::memcpy(e.info, info36, 288);
+    h->odo3.push_back(e);
+    return SE2GPU_OK;
+}
+
+// addEdgeXYZ2UV(opt, measure, idMP, idKF, paraId, info, thHuber) (optimizer.h:97): information = inv_sigma2 * I
+int se2gpu_ba_add_edge_xyz2uv(se2gpu_ba* h, int id_mp, int id_kf, const double uv[2], double inv_sigma2, double huber_delta) {
+    SE2_REQUIRE(h && uv, SE2GPU_ERR_INVALID, "add_edge_xyz2uv: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    const int a = h->model == 1 ? h->pose_of_id.find(id_kf) : -1, b = h->lm_of_id.find(id_mp);
+    SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_xyz2uv: unknown vertex id (%d, %d)", id_mp, id_kf);
+    if (h->he_kf.empty()) h->huber_delta = huber_delta;
+    else if (huber_delta != h->huber_delta) h->huber_mixed = true;
+    h->he_kf.push_back(a); h->he_lm.push_back(b);
+    h->he_uv.push_back(uv[0]); h->he_uv.push_back(uv[1]);
+    h->he_info.push_back(inv_sigma2); h->he_info.push_back(0.0); h->he_info.push_back(inv_sigma2);
+    return SE2GPU_OK;
+}
+
+int se2gpu_ba_get_se3(se2gpu_ba* h, int id, double pose12[12]) {
+    SE2_REQUIRE(h && h->initialized && pose12 && h->model == 1, SE2GPU_ERR_STATE, "get_se3 needs an initialised SE3 graph");
+    const int a = h->pose_of_id.find(id);
+    SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "unknown pose id %d", id);
+    SE2_CHECK(ba_fetch_estimates(h));
+    std::memcpy(pose12, h->est.p + 12 * (size_t)a, 96);
+    return SE2GPU_OK;
+}
+
+// EdgeProjectXYZ2UV::chi2() of every projection edge at the current estimate, in the order the edges were added
+// (LocalMapper::removeOutlierChi2 compares it with 25, LocalMapper.cpp:199-214)
+int se2gpu_ba_edge_chi2(se2gpu_ba* h, double* chi2, int cap) {
+    SE2_REQUIRE(h && h->initialized && chi2 && h->model == 1, SE2GPU_ERR_STATE, "edge_chi2 needs an initialised SE3 graph");
+    SE2_REQUIRE(cap >= h->E, SE2GPU_ERR_CAPACITY, "edge_chi2: %d edges, room for %d", h->E, cap);
+    if (!h->E) return SE2GPU_OK;
+    hipStream_t st = h->stream;
+    hipLaunchKernelGGL(k3_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, st, h->cam3, h->L, 0.0, h->lm_ptr.p,
+                       h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->poses_t, h->lms, (const double*)nullptr, h->z.p, h->Y.p,
+                       h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, 0, h->edge_chi2.p);
+    SE2_HIP(hipGetLastError());
+    std::vector<double> tmp(h->E);
+    SE2_HIP(hipMemcpyAsync(tmp.data(), h->edge_chi2.p, (size_t)h->E * 8, hipMemcpyDeviceToHost, st));
+    SE2_HIP(hipStreamSynchronize(st));
+    if (h->edge_perm.empty()) std::memcpy(chi2, tmp.data(), (size_t)h->E * 8);
+    else for (int t = 0; t < h->E; ++t) chi2[h->edge_perm[t]] = tmp[t];
+    return SE2GPU_OK;
+}
+
 // Map::loadLocalGraph (/root/reference/src/Map.cpp:891-1022) through ONE call on a POD view of the local window.
 // What the reference does with ~E std::find calls over the key-frame vectors, E heap-allocated edges and E Eigen 2x2
 // inversions becomes: the vertex ids of Map.cpp:925/966/985, the fixed rule of :927/:969, cov^-1 of the PreSE2 edges
@@ -2947,7 +3713,7 @@ int se2gpu_ba_initialize(se2gpu_ba* h) {
 int se2gpu_ba_reset_estimates(se2gpu_ba* h) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "reset_estimates before initialize");
     h->est_valid = false;
-    SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, 3 * (size_t)h->P * 8, hipMemcpyDeviceToDevice, h->stream));
+    SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, (size_t)h->ps * h->P * 8, hipMemcpyDeviceToDevice, h->stream));
     if (h->L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)h->L * 8, hipMemcpyDeviceToDevice, h->stream));
     return SE2GPU_OK;
 }
@@ -3000,13 +3766,18 @@ double se2gpu_ba_chi2(se2gpu_ba* h) {
         set_error("chi2 before initialize");
         return -1.0;
     }
+    if (h->model) {   // the SE3 kernels are controller-driven: a run of zero iterations evaluates the starting state
+        se2gpu_ba_stats st;
+        if (se2gpu_ba_optimize(h, 0, SE2GPU_BA_LM, nullptr, 0, &st) != SE2GPU_OK) return -1.0;
+        return st.chi2_init;
+    }
     if (ba_evaluate(h, nullptr, 0.0) != SE2GPU_OK) return -1.0;
     return h->h_scal.p[0];
 }
 
 int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "debug_reduced_system before initialize");
-    const int n = 3 * h->P;
+    const int n = h->D * h->P;
     SE2_CHECK(ba_linearize(h, lambda));
     SE2_CHECK(ba_reduce(h, lambda, false));
     SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
@@ -3019,7 +3790,7 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
 
 int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok) {
     SE2_REQUIRE(h && h->initialized && x, SE2GPU_ERR_STATE, "debug_solve before initialize");
-    const int n = 3 * h->P;
+    const int n = h->D * h->P;
     SE2_CHECK(ba_linearize(h, lambda));
     SE2_CHECK(ba_reduce(h, lambda, false));
     SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
@@ -3227,7 +3998,7 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
 
 static int ba_fetch_estimates(se2gpu_ba* h) {
     if (h->est_valid) return SE2GPU_OK;
-    const size_t np = 3 * (size_t)h->P, nl = 3 * (size_t)h->L;
+    const size_t np = (size_t)h->ps * h->P, nl = 3 * (size_t)h->L;
     SE2_CHECK(h->est.reserve(np + nl + 1));
     SE2_HIP(hipMemcpyAsync(h->est.p, h->poses, np * 8, hipMemcpyDeviceToHost, h->stream));
     if (nl) SE2_HIP(hipMemcpyAsync(h->est.p + np, h->lms, nl * 8, hipMemcpyDeviceToHost, h->stream));
@@ -3239,13 +4010,14 @@ static int ba_fetch_estimates(se2gpu_ba* h) {
 int se2gpu_ba_get_all(se2gpu_ba* h, double* poses, double* lms) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "get before initialize");
     SE2_CHECK(ba_fetch_estimates(h));
-    if (poses) std::memcpy(poses, h->est.p, 3 * (size_t)h->P * 8);
-    if (lms && h->L) std::memcpy(lms, h->est.p + 3 * (size_t)h->P, 3 * (size_t)h->L * 8);
+    if (poses) std::memcpy(poses, h->est.p, (size_t)h->ps * h->P * 8);
+    if (lms && h->L) std::memcpy(lms, h->est.p + (size_t)h->ps * h->P, 3 * (size_t)h->L * 8);
     return SE2GPU_OK;
 }
 
 int se2gpu_ba_get_se2(se2gpu_ba* h, int id, double xyt[3]) {
     SE2_REQUIRE(h && h->initialized && xyt, SE2GPU_ERR_STATE, "get_se2 before initialize");
+    SE2_REQUIRE(h->model == 0, SE2GPU_ERR_STATE, "get_se2 on an SE3 graph (use se2gpu_ba_get_se3)");
     const int a = h->pose_of_id.find(id);
     SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "unknown pose id %d", id);
     SE2_CHECK(ba_fetch_estimates(h));
@@ -3258,7 +4030,7 @@ int se2gpu_ba_get_xyz(se2gpu_ba* h, int id, double xyz[3]) {
     const int a = h->lm_of_id.find(id);
     SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "unknown landmark id %d", id);
     SE2_CHECK(ba_fetch_estimates(h));
-    std::memcpy(xyz, h->est.p + 3 * (size_t)h->P + 3 * (size_t)a, 24);
+    std::memcpy(xyz, h->est.p + (size_t)h->ps * h->P + 3 * (size_t)a, 24);
     return SE2GPU_OK;
 }
 

@@ -104,7 +104,7 @@ class SlamOptimizer:
 
     def estimates(self):
         P, L = self._shape
-        poses = np.zeros((P, 3))
+        poses = np.zeros((P, getattr(self, "_pose_dim", 3)))
         lms = np.zeros((max(L, 1), 3))
         capi.check(capi.lib().se2gpu_ba_get_all(self._h, capi.pd(poses), capi.pd(lms)))
         return poses, lms[:L]
@@ -114,7 +114,7 @@ class SlamOptimizer:
 
     def reduced_system(self, lam: float):
         P, _ = self._shape
-        n = 3 * P
+        n = (6 if getattr(self, "_pose_dim", 3) == 12 else 3) * P
         S = np.zeros((n, n))
         bs = np.zeros(n)
         capi.check(capi.lib().se2gpu_ba_debug_reduced_system(self._h, float(lam), capi.pd(S), capi.pd(bs)))
@@ -259,6 +259,86 @@ def loadLocalGraph(opt: SlamOptimizer, *, kf_id, kf_Twb, kf_Rcw, n_local, odo_to
     g.huber_delta, g.xrot_info, g.z_info = float(huber), float(xrot_info), float(z_info)
     capi.check(capi.lib().se2gpu_ba_load_local_graph(opt._h, C.byref(g)))
     opt._shape = (len(keep[0]), len(keep[6]))
+
+
+# -- SE3-expmap graphs (optimizer.h:82-98, 138): Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx) ------------------------
+def _pose12(T):
+    T = np.asarray(T, np.float64)
+    return np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+
+
+def _pose44(p):
+    T = np.eye(4)
+    T[:3, :3] = np.asarray(p[:9]).reshape(3, 3)
+    T[:3, 3] = p[9:12]
+    return T
+
+
+def addVertexSE3Expmap(opt: SlamOptimizer, Tcw, id: int, fixed: bool = False):
+    """optimizer.h:88: Tcw 4x4"""
+    capi.check(capi.lib().se2gpu_ba_add_vertex_se3(opt._h, int(id), capi.pd(_pose12(Tcw)), int(bool(fixed))))
+
+
+def addPlaneMotionSE3Expmap(opt: SlamOptimizer, Tcw, vId: int, extPara, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    """optimizer.h:82 / optimizer.cpp:236-314: the EdgeSE3ExpmapPrior that keeps key frame vId on the plane (extPara = Config::bTc)."""
+    meas = np.zeros(12)
+    info = np.zeros(36)
+    capi.check(capi.lib().se2gpu_plane_motion_prior(_pose12(Tcw).ctypes.data, _pose12(extPara).ctypes.data, float(xrot_info),
+                                                    float(yrot_info), float(z_info), meas.ctypes.data, info.ctypes.data))
+    capi.check(capi.lib().se2gpu_ba_add_prior_se3(opt._h, int(vId), capi.pd(meas), capi.pd(info)))
+
+
+def addPriorSE3Expmap(opt: SlamOptimizer, vId: int, meas, info):
+    capi.check(capi.lib().se2gpu_ba_add_prior_se3(opt._h, int(vId), capi.pd(_pose12(meas)),
+                                                  capi.pd(np.ascontiguousarray(info, np.float64).reshape(-1))))
+
+
+def addEdgeSE3Expmap(opt: SlamOptimizer, measure, id0: int, id1: int, info):
+    """optimizer.h:94"""
+    capi.check(capi.lib().se2gpu_ba_add_edge_se3(opt._h, int(id0), int(id1), capi.pd(_pose12(measure)),
+                                                 capi.pd(np.ascontiguousarray(info, np.float64).reshape(-1))))
+
+
+def addEdgeXYZ2UV(opt: SlamOptimizer, measure, idMP: int, idKF: int, paraId: int, info, thHuber: float):
+    """optimizer.h:97: info = invSigma2 * I (Map.cpp:527)"""
+    w = np.asarray(info, np.float64)
+    inv_sigma2 = float(w.reshape(-1)[0])
+    capi.check(capi.lib().se2gpu_ba_add_edge_xyz2uv(opt._h, int(idMP), int(idKF), capi.pd(np.ascontiguousarray(measure, np.float64)),
+                                                    inv_sigma2, float(thHuber)))
+
+
+def estimateVertexSE3Expmap(opt: SlamOptimizer, id: int) -> np.ndarray:
+    """optimizer.h:138 -> Tcw 4x4"""
+    out = np.zeros(12)
+    capi.check(capi.lib().se2gpu_ba_get_se3(opt._h, int(id), capi.pd(out)))
+    return _pose44(out)
+
+
+def edgeChi2(opt: SlamOptimizer, n_edges: int) -> np.ndarray:
+    """chi2() of every EdgeProjectXYZ2UV at the current estimate, in the order the edges were added"""
+    out = np.zeros(max(n_edges, 1))
+    capi.check(capi.lib().se2gpu_ba_edge_chi2(opt._h, capi.pd(out), int(n_edges)))
+    return out[:n_edges]
+
+
+def load_se3_graph(opt: SlamOptimizer, g, K=None):
+    """A synth.BA3Graph through the reference's call sequence (Map.cpp:414-566): ids as the reference numbers them."""
+    K = np.array([[g.fx, 0, g.cx], [0, g.fx, g.cy], [0, 0, 1]], np.float32) if K is None else K
+    addCamPara(opt, K, 0)
+    for a in range(g.P):
+        addVertexSE3Expmap(opt, g.poses[a], a, bool(g.fixed[a]))
+        if g.has_prior[a]:
+            addPriorSE3Expmap(opt, a, g.prior_meas[a], g.prior_info[a])
+    for k in range(g.O):
+        addEdgeSE3Expmap(opt, g.o_meas[k], int(g.o_i[k]), int(g.o_j[k]), g.o_info[k])
+    maxKFid = g.P + 1
+    for l in range(g.L):
+        addVertexSBAXYZ(opt, g.lms[l], maxKFid + l)
+    for k in range(g.E):
+        addEdgeXYZ2UV(opt, g.e_uv[k], maxKFid + int(g.e_lm[k]), int(g.e_kf[k]), 0, np.eye(2) * g.e_w[k], g.huber)
+    opt._shape = (g.P, g.L)
+    opt._pose_dim = 12
+    return maxKFid
 
 
 def shard_landmarks(L: int, e_kf: np.ndarray, e_lm: np.ndarray, world: int) -> np.ndarray:
