@@ -249,6 +249,23 @@ typedef struct se2gpu_local_graph {
 } se2gpu_local_graph;
 int se2gpu_ba_load_local_graph(se2gpu_ba* h, const se2gpu_local_graph* graph);
 
+/* Map::updateLocalGraph() (/root/reference/src/Map.cpp:285-331) on a CSR view of the map - SURVEY.md section 8 row a25: the
+ * local window of the current key frame = key frames within `search_level` (3 in the reference) covisibility hops, the
+ * map points they observe, and as reference key frames every other observer of those points.  Pure host code (no device
+ * needed); the three outputs are positions in the view's arrays, ordered by KeyFrame::id / MapPoint::id like the
+ * reference's sets, i.e. exactly mLocalGraphKFs, mRefKFs, mLocalGraphMPs - the lists se2gpu_ba_load_local_graph takes.
+ * Output arrays may be NULL (sizes only); capacities n_kf / n_kf / n_mp always suffice. */
+typedef struct se2gpu_map_view {
+    int32_t n_kf, n_mp;
+    const int32_t* kf_id;                        /* KeyFrame::id                                  [n_kf] */
+    const int32_t* covis_ptr; const int32_t* covis_idx;   /* KeyFrame::getAllCovisibleKFs() as CSR        [n_kf + 1] */
+    const int32_t* kf_mp_ptr; const int32_t* kf_mp_idx;   /* KeyFrame::getAllObsMPs(false) as CSR         [n_kf + 1] */
+    const int32_t* mp_id;                        /* MapPoint::id                                  [n_mp] */
+    const int32_t* mp_kf_ptr; const int32_t* mp_kf_idx;   /* MapPoint::getObservations() as CSR           [n_mp + 1] */
+} se2gpu_map_view;
+int se2gpu_map_update_local_graph(const se2gpu_map_view* map, int current_kf, int search_level, int32_t* local_kfs,
+                                  int* n_local, int32_t* ref_kfs, int* n_ref, int32_t* local_mps, int* n_mps);
+
 /* initializeOptimization(0): freezes the graph, builds the device-side SoA + reduction plans (on the device). */
 int se2gpu_ba_initialize(se2gpu_ba* h);
 /* restores every vertex estimate to the value it was added with (device-to-device) */

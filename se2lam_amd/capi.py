@@ -55,6 +55,12 @@ class LocalGraph(C.Structure):
                 ("huber_delta", C.c_float), ("xrot_info", C.c_float), ("z_info", C.c_float)]
 
 
+class MapView(C.Structure):
+    _fields_ = [("n_kf", C.c_int32), ("n_mp", C.c_int32), ("kf_id", C.c_void_p), ("covis_ptr", C.c_void_p),
+                ("covis_idx", C.c_void_p), ("kf_mp_ptr", C.c_void_p), ("kf_mp_idx", C.c_void_p), ("mp_id", C.c_void_p),
+                ("mp_kf_ptr", C.c_void_p), ("mp_kf_idx", C.c_void_p)]
+
+
 class BaStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
                 ("stopped", C.c_int32), ("chi2_init", C.c_double), ("chi2_final", C.c_double),
@@ -122,6 +128,7 @@ SYMBOLS = {
     "se2gpu_ba_add_edge_xyz2uv": (_I, [_VP, _I, _I, _PD, _D, _D]),
     "se2gpu_ba_get_se3": (_I, [_VP, _I, _PD]),
     "se2gpu_ba_edge_chi2": (_I, [_VP, _PD, _I]),
+    "se2gpu_map_update_local_graph": (_I, [C.POINTER(MapView), _I, _I, _VP, C.POINTER(_I), _VP, C.POINTER(_I), _VP, C.POINTER(_I)]),
     "se2gpu_ba_initialize": (_I, [_VP]),
     "se2gpu_ba_reset_estimates": (_I, [_VP]),
     "se2gpu_ba_optimize": (_I, [_VP, _I, _I, _PU8, _I, C.POINTER(BaStats)]),
