@@ -211,6 +211,17 @@ int se2gpu_ba_load(se2gpu_ba* h, int P, int L, int E, int O,
  *   EdgeProjectXYZ2UV::computeError() + chi2()   -> se2gpu_ba_edge_chi2 (all edges, in the order they were added)
  * initialize / optimize / optimize_batch / chi2 / clear are the common ones.  Single GPU only. */
 int se2gpu_ba_add_vertex_se3(se2gpu_ba* h, int id, const double pose12[12], int fixed);
+/* ---- pose graphs: GlobalMapper::GlobalBA (/root/reference/src/GlobalMapper.cpp:328-535).
+ * A graph whose first pose vertex is added with se2gpu_ba_add_vertex_iso3 is a g2o::VertexSE3 pose graph (poses T_w_c,
+ * update estimate * fromVectorMQT(d)); se2gpu_ba_add_prior_se3 then adds an EdgeSE3Prior (what
+ * addVertexSE3PlaneMotion, optimizer.h:123, attaches: build it with se2gpu_plane_motion_prior_iso3), se2gpu_ba_add_edge_se3
+ * an EdgeSE3 (addEdgeSE3, optimizer.h:129: error toVectorMQT(measure^-1 * T_id0^-1 * T_id1); several edges between the
+ * same two key frames are allowed - odometry + feature edge).  Vector order (translation, rotation) for errors and
+ * information matrices.  se2gpu_ba_get_se3 = estimateVertexSE3 (:135), se2gpu_ba_edge_chi2 = EdgeSE3::chi2() of every
+ * edge in insertion order (the feature-edge rejection of GlobalMapper.cpp:415-437, 455-476).  No landmarks. */
+int se2gpu_ba_add_vertex_iso3(se2gpu_ba* h, int id, const double Twc12[12], int fixed);
+int se2gpu_plane_motion_prior_iso3(const double* Twc12, const double* Tbc12, double xrot_info, double yrot_info,
+                                   double z_info, double* meas12, double* info36);
 int se2gpu_ba_add_prior_se3(se2gpu_ba* h, int id, const double meas12[12], const double info36[36]);
 int se2gpu_ba_add_edge_se3(se2gpu_ba* h, int id0, int id1, const double meas12[12], const double info36[36]);
 int se2gpu_ba_add_edge_xyz2uv(se2gpu_ba* h, int id_mp, int id_kf, const double uv[2], double inv_sigma2, double huber_delta);

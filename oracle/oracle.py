@@ -663,3 +663,93 @@ def ba3_odo_edge(Ti, Tj, Cm):
     f.argtypes = [C.c_void_p] * 6
     f(a.ctypes.data, b.ctypes.data, c.ctypes.data, e.ctypes.data, Ji.ctypes.data, Jj.ctypes.data)
     return e, Ji.reshape(6, 6), Jj.reshape(6, 6)
+
+
+# --------------------------------------------------------------------------------------
+# pose graph of GlobalMapper::GlobalBA (oracle/pg_ref.cpp)
+# --------------------------------------------------------------------------------------
+class PgProblem(C.Structure):
+    _fields_ = [("P", C.c_int32), ("O", C.c_int32), ("poses", C.c_void_p), ("fixed", C.c_void_p), ("has_prior", C.c_void_p),
+                ("prior_meas", C.c_void_p), ("prior_info", C.c_void_p), ("o_i", C.c_void_p), ("o_j", C.c_void_p),
+                ("o_meas", C.c_void_p), ("o_info", C.c_void_p)]
+
+
+def pg_problem(g):
+    k = _Keep()
+    pr = PgProblem()
+    pr.P, pr.O = g.P, g.O
+    arrs = dict(poses=(poses12(g.poses), np.float64), fixed=(g.fixed, np.uint8), has_prior=(g.has_prior, np.uint8),
+                prior_meas=(poses12(g.prior_meas), np.float64), prior_info=(g.prior_info.reshape(g.P, 36), np.float64),
+                o_i=(g.o_i, np.int32), o_j=(g.o_j, np.int32), o_meas=(poses12(g.o_meas), np.float64),
+                o_info=(g.o_info.reshape(g.O, 36), np.float64))
+    for name, (a, dt) in arrs.items():
+        setattr(pr, name, k.arr(a, dt).ctypes.data)
+    return pr, k
+
+
+def pg_chi2(g, poses=None):
+    pr, k = pg_problem(g)
+    p = k.arr(poses12(g.poses if poses is None else poses), np.float64)
+    ec = np.zeros(max(g.O, 1))
+    f = lib().pg_ref_chi2
+    f.restype = C.c_double
+    f.argtypes = [C.POINTER(PgProblem), C.c_void_p, C.c_void_p]
+    return float(f(C.byref(pr), p.ctypes.data, ec.ctypes.data)), ec[:g.O]
+
+
+def pg_system(g, lam=0.0):
+    pr, k = pg_problem(g)
+    n = 6 * g.P
+    H = np.zeros((n, n)); b = np.zeros(n)
+    p = k.arr(poses12(g.poses), np.float64)
+    f = lib().pg_ref_system
+    f.restype = None
+    f.argtypes = [C.POINTER(PgProblem), C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    f(C.byref(pr), p.ctypes.data, float(lam), H.ctypes.data, b.ctypes.data)
+    return H, b
+
+
+def pg_optimize(g, iters=10):
+    """-> (poses (P,4,4), per-edge chi2 (O,), stats)"""
+    pr, k = pg_problem(g)
+    p = np.zeros((g.P, 12)); ec = np.zeros(max(g.O, 1))
+    st = BaStats()
+    f = lib().pg_ref_optimize
+    f.restype = C.c_int
+    f.argtypes = [C.POINTER(PgProblem), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BaStats)]
+    assert f(C.byref(pr), iters, p.ctypes.data, ec.ctypes.data, C.byref(st)) == 0
+    n = min(st.iterations, 64)
+    stats = dict(iterations=st.iterations, trials=st.trials, terminated=bool(st.terminated), chi2_init=st.chi2_init,
+                 chi2_final=st.chi2_final, lambda_final=st.lambda_final, chi2_hist=list(st.chi2_hist[:n]),
+                 lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]), rho_log=list(st.rho_log[:st.n_rho]))
+    return poses44(p), ec[:g.O], stats
+
+
+def pg_edge(Xi, Xj, Z):
+    e = np.zeros(6); Ji = np.zeros(36); Jj = np.zeros(36)
+    a, b, c = [np.ascontiguousarray(poses12(np.asarray(x)[None])[0]) for x in (Xi, Xj, Z)]
+    f = lib().pg_ref_edge
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 6
+    f(a.ctypes.data, b.ctypes.data, c.ctypes.data, e.ctypes.data, Ji.ctypes.data, Jj.ctypes.data)
+    return e, Ji.reshape(6, 6), Jj.reshape(6, 6)
+
+
+def pg_oplus(X, upd):
+    out = np.zeros(12)
+    a = np.ascontiguousarray(poses12(np.asarray(X)[None])[0]); u = np.ascontiguousarray(upd, np.float64)
+    f = lib().pg_ref_oplus
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(a.ctypes.data, u.ctypes.data, out.ctypes.data)
+    return poses44(out)[0]
+
+
+def pg_plane_motion_prior(Twc, Tbc, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    meas = np.zeros(12); info = np.zeros(36)
+    a = np.ascontiguousarray(poses12(np.asarray(Twc)[None])[0]); b = np.ascontiguousarray(poses12(np.asarray(Tbc)[None])[0])
+    f = lib().pg_ref_plane_motion_prior
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    f(a.ctypes.data, b.ctypes.data, xrot_info, yrot_info, z_info, meas.ctypes.data, info.ctypes.data)
+    return poses44(meas)[0], info.reshape(6, 6)

@@ -123,6 +123,8 @@ SYMBOLS = {
     "se2gpu_ba_load": (_I, [_VP, _I, _I, _I, _I, _PD, _PU8, _PD, _PI32, _PI32, _PD, _PD, _PI32, _PI32, _PD, _PD, _D]),
     "se2gpu_ba_load_local_graph": (_I, [_VP, C.POINTER(LocalGraph)]),
     "se2gpu_ba_add_vertex_se3": (_I, [_VP, _I, _PD, _I]),
+    "se2gpu_ba_add_vertex_iso3": (_I, [_VP, _I, _PD, _I]),
+    "se2gpu_plane_motion_prior_iso3": (_I, [_VP, _VP, _D, _D, _D, _VP, _VP]),
     "se2gpu_ba_add_prior_se3": (_I, [_VP, _I, _PD, _PD]),
     "se2gpu_ba_add_edge_se3": (_I, [_VP, _I, _I, _PD, _PD]),
     "se2gpu_ba_add_edge_xyz2uv": (_I, [_VP, _I, _I, _PD, _D, _D]),

@@ -2044,6 +2044,202 @@ __global__ void k3_finalize(int nparts, const double* __restrict__ part, int P, 
     }
 }
 
+// =============================================================================================
+// Pose-graph model: GlobalMapper::GlobalBA (/root/reference/src/GlobalMapper.cpp:328-535) -
+// g2o::VertexSE3 (T_w_c), one EdgeSE3Prior per key frame (addVertexSE3PlaneMotion, src/optimizer.cpp:336-470), EdgeSE3
+// odometry and feature edges; no landmarks, so the "reduced" system is the whole system and the SE3 model's
+// k3_reduce2 / dataflow solve / LM controller run unchanged on the blocks this kernel family produces.
+// Several edges may join the same two key frames (odometry + feature edge): the edges are grouped into PAIR SLOTS
+// (canonical orientation a < b), one thread sums a slot's edges into H_aa, H_bb, H_ab, b_a, b_b.
+// [3P g2o 20160424 types/slam3d] restated as in oracle/pg_ref.cpp (se3_math.h: to_mqt / from_mqt / mqt_jac_*).
+// =============================================================================================
+__device__ inline void jtwj6(const double* Ja, const double* W, const double* Jc, double* out, double sgn) {   // out += Ja' W Jc
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            double v = 0;
+            for (int q = 0; q < 6; ++q) {
+                double wj = 0;
+                for (int u = 0; u < 6; ++u) wj += W[6 * q + u] * Jc[6 * u + c];
+                v += Ja[6 * q + r] * wj;
+            }
+            out[6 * r + c] += sgn * v;
+        }
+}
+__device__ inline void jtwe6(const double* Ja, const double* W, const double* e, double* out) {   // out -= Ja' W e
+    double We[6];
+    for (int r = 0; r < 6; ++r) { We[r] = 0; for (int c = 0; c < 6; ++c) We[r] += W[6 * r + c] * e[c]; }
+    for (int r = 0; r < 6; ++r) { double v = 0; for (int q = 0; q < 6; ++q) v += Ja[6 * q + r] * We[q]; out[r] -= v; }
+}
+
+__global__ void k4_terms(int P, int nslot, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                         const uint8_t* __restrict__ prior_has, const double* __restrict__ prior_meas,
+                         const double* __restrict__ prior_info, double* __restrict__ ph, double* __restrict__ pb,
+                         const int* __restrict__ slot_a, const int* __restrict__ slot_ptr, const int* __restrict__ e_i,
+                         const int* __restrict__ e_j, const double* __restrict__ e_meas, const double* __restrict__ e_info,
+                         double* __restrict__ Oii, double* __restrict__ Ojj, double* __restrict__ Oij,
+                         double* __restrict__ obi, double* __restrict__ obj, const BaCtl* __restrict__ ctl,
+                         const double* __restrict__ poses_b) {
+    if (ctl) {
+        if (ctl->done | ctl->retry) return;
+        if (ctl->sel) poses = poses_b;
+    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < P) {
+        double H[36], g[6];
+        for (int i = 0; i < 36; ++i) H[i] = 0;
+        for (int i = 0; i < 6; ++i) g[i] = 0;
+        if (prior_has[t] && !fixed[t]) {
+            const Se3 E = iso_mul(se3_inv(se3_load(prior_meas + 12 * (size_t)t)), se3_load(poses + 12 * (size_t)t));
+            double e[6], J[36];
+            to_mqt(E, e);
+            mqt_jac_right(E, J);
+            jtwj6(J, prior_info + 36 * (size_t)t, J, H, 1.0);
+            jtwe6(J, prior_info + 36 * (size_t)t, e, g);
+        }
+        for (int i = 0; i < 36; ++i) ph[36 * (size_t)t + i] = H[i];
+        for (int i = 0; i < 6; ++i) pb[6 * (size_t)t + i] = g[i];
+        return;
+    }
+    const int sl = t - P;
+    if (sl >= nslot) return;
+    const int a = slot_a[sl];
+    double Haa[36], Hbb[36], Hab[36], ba[6], bb[6];
+    for (int i = 0; i < 36; ++i) Haa[i] = Hbb[i] = Hab[i] = 0;
+    for (int i = 0; i < 6; ++i) ba[i] = bb[i] = 0;
+    for (int k = slot_ptr[sl]; k < slot_ptr[sl + 1]; ++k) {
+        const int i = e_i[k], j = e_j[k];
+        const Se3 A = se3_inv(se3_load(e_meas + 12 * (size_t)k));
+        const Se3 B = iso_mul(se3_inv(se3_load(poses + 12 * (size_t)i)), se3_load(poses + 12 * (size_t)j));
+        const Se3 E = iso_mul(A, B);
+        double e[6], Ji[36], Jj[36];
+        to_mqt(E, e);
+        mqt_jac_left_inv(A, B, Ji);
+        mqt_jac_right(E, Jj);
+        const double* W = e_info + 36 * (size_t)k;
+        const bool fi = !fixed[i], fj = !fixed[j];
+        // vertex 0 (i) is the slot's `a` or its `b`
+        double* Hi = i == a ? Haa : Hbb;
+        double* Hj = i == a ? Hbb : Haa;
+        double* bi = i == a ? ba : bb;
+        double* bj = i == a ? bb : ba;
+        if (fi) { jtwj6(Ji, W, Ji, Hi, 1.0); jtwe6(Ji, W, e, bi); }
+        if (fj) { jtwj6(Jj, W, Jj, Hj, 1.0); jtwe6(Jj, W, e, bj); }
+        if (fi && fj) {
+            if (i == a) jtwj6(Ji, W, Jj, Hab, 1.0);   // H_ab = J_a' W J_b
+            else jtwj6(Jj, W, Ji, Hab, 1.0);
+        }
+    }
+    for (int q = 0; q < 36; ++q) { Oii[36 * (size_t)sl + q] = Haa[q]; Ojj[36 * (size_t)sl + q] = Hbb[q]; Oij[36 * (size_t)sl + q] = Hab[q]; }
+    for (int q = 0; q < 6; ++q) { obi[6 * (size_t)sl + q] = ba[q]; obj[6 * (size_t)sl + q] = bb[q]; }
+}
+
+// trial poses: estimate * fromVectorMQT(update) (VertexSE3::oplusImpl)
+__global__ void k4_oplus(int P, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                         const double* __restrict__ xp, double* __restrict__ poses_trial, const BaCtl* __restrict__ ctl) {
+    if (ctl) {
+        if (ctl->done) return;
+        if (ctl->sel) { const double* t = poses; poses = poses_trial; poses_trial = const_cast<double*>(t); }
+    }
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    Se3 T = se3_load(poses + 12 * (size_t)p);
+    if (!fixed[p]) {
+        double u[6];
+        for (int r = 0; r < 6; ++r) u[r] = xp[6 * (size_t)p + r];
+        T = iso_mul(T, from_mqt(u));
+    }
+    se3_store(T, poses_trial + 12 * (size_t)p);
+}
+
+__device__ inline double quad6(const double* W, const double* e) {
+    double s = 0;
+    for (int r = 0; r < 6; ++r) {
+        double v = 0;
+        for (int c = 0; c < 6; ++c) v += W[6 * r + c] * e[c];
+        s += e[r] * v;
+    }
+    return s;
+}
+
+// chi^2 of the priors and of every EdgeSE3 at the trial poses (the estimate without a step), pose part of computeScale(),
+// LM decision.  edge_chi2 (nullable): chi2() per edge, in slot order.
+__global__ void k4_finalize(int P, int nedge, const double* __restrict__ poses_a, const double* __restrict__ poses_b,
+                            const uint8_t* __restrict__ fixed, const double* __restrict__ xp, const double* __restrict__ bp,
+                            const uint8_t* __restrict__ prior_has, const double* __restrict__ prior_meas,
+                            const double* __restrict__ prior_info, const int* __restrict__ e_i, const int* __restrict__ e_j,
+                            const double* __restrict__ e_meas, const double* __restrict__ e_info, double* __restrict__ out,
+                            volatile double* __restrict__ mail, double seq, BaCtl* __restrict__ ctl, int step, int notify,
+                            const volatile int* __restrict__ stop, double* __restrict__ edge_chi2) {
+    __shared__ double sm[2][16];
+    __shared__ int post_s;
+    const double* poses = poses_a;
+    double lambda = 0;
+    if (ctl) {
+        if (ctl->done) {
+            if (notify && mail) {
+                post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+                __threadfence_system();
+                __syncthreads();
+                if (threadIdx.x == 0) mail[3] = seq;
+            }
+            return;
+        }
+        poses = ((ctl->sel != 0) != (step != 0)) ? poses_b : poses_a;
+        lambda = ctl->lambda;
+    }
+    double chi = 0, scale = 0;
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        if (step && !fixed[p])
+            for (int r = 0; r < 6; ++r) scale += xp[6 * (size_t)p + r] * (lambda * xp[6 * (size_t)p + r] + bp[6 * (size_t)p + r]);
+        if (prior_has[p]) {
+            double e[6];
+            to_mqt(iso_mul(se3_inv(se3_load(prior_meas + 12 * (size_t)p)), se3_load(poses + 12 * (size_t)p)), e);
+            chi += quad6(prior_info + 36 * (size_t)p, e);
+        }
+    }
+    for (int k = threadIdx.x; k < nedge; k += blockDim.x) {
+        double e[6];
+        to_mqt(iso_mul(se3_inv(se3_load(e_meas + 12 * (size_t)k)),
+                       iso_mul(se3_inv(se3_load(poses + 12 * (size_t)e_i[k])), se3_load(poses + 12 * (size_t)e_j[k]))), e);
+        const double c2 = quad6(e_info + 36 * (size_t)k, e);
+        if (edge_chi2) edge_chi2[k] = c2;
+        chi += c2;
+    }
+    if (!ctl) return;
+    chi = wave_sum(chi);
+    scale = wave_sum(scale);
+    if ((threadIdx.x & 63) == 0) {
+        sm[0][threadIdx.x >> 6] = chi;
+        sm[1][threadIdx.x >> 6] = scale;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            sm[0][0] += sm[0][w];
+            sm[1][0] += sm[1][w];
+        }
+        out[0] = sm[0][0]; out[1] = sm[1][0]; out[3] = 0;
+        if (!step) {
+            out[2] = 0;
+            ctl->current_chi = ctl->chi2_init = ctl->chi2_final = sm[0][0];
+            if (stop && *stop) { ctl->stopped = 1; ctl->done = 1; }
+            if (ctl->iters <= 0) ctl->done = 1;
+        } else {
+            const double sc[3] = {sm[0][0], sm[1][0], out[2]};
+            lm_advance(ctl, sc, stop);
+        }
+        post_s = (ctl->done || notify) && mail;
+    }
+    __syncthreads();
+    if (post_s) {
+        __threadfence();
+        post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) mail[3] = seq;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host: dense SPD solve of the reduced pose system (replaces CHOLMOD on the (3P)^2 matrix).
 // Blocked right-looking LL^T on the lower triangle, row-major, FP64.
@@ -2207,6 +2403,11 @@ struct se2gpu_ba {
     DevBuf<uint8_t> prior_has;
     DevBuf<double> prior_meas, prior_info, pb, edge_chi2;
     std::vector<int> edge_perm;                          // sorted position -> insertion index (empty = identity)
+    // model 2 (pose graph: VertexSE3 / EdgeSE3 / EdgeSE3Prior): the EdgeSE3 edges grouped into pair slots
+    int pg_edges = 0;
+    std::vector<int> pg_perm;                            // slot-ordered position -> insertion index
+    DevBuf<int> slot_a, slot_ptr, pe_i, pe_j;
+    DevBuf<double> pe_meas, pe_info, ph;
     // se2gpu_ba_load: the caller's edge arrays, borrowed until initialize (copied once, straight into the pinned arena)
     int bulk_E = 0;
     const int32_t *bulk_kf = nullptr, *bulk_lm = nullptr;
@@ -2668,14 +2869,14 @@ int ba_upload_graph(se2gpu_ba* h) {
                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     };
     const int P = (int)h->pose_ids.size(), L = (int)h->lm_ids.size();
-    const int E = h->bulk_E ? h->bulk_E : (int)h->he_kf.size(), O = h->model ? (int)h->odo3.size() : (int)h->odo.size();
+    const int E = h->bulk_E ? h->bulk_E : (int)h->he_kf.size(), O_in = h->model ? (int)h->odo3.size() : (int)h->odo.size();
     const int D = h->D, ps = h->ps, gpw = h->model ? kGrpPerWG3 : kGrpPerWG;
     const int DS = D * (D + 1) / 2;   // entries of a symmetric pose block
     SE2_REQUIRE(P > 0, SE2GPU_ERR_STATE, "initialize: no pose vertices");
     SE2_REQUIRE(!h->model || (h->world == 1 && !h->allreduce), SE2GPU_ERR_STATE, "the SE3 model is single-GPU");
     SE2_REQUIRE(h->have_cam, SE2GPU_ERR_STATE, "initialize: add_cam was not called");
     SE2_REQUIRE(!h->huber_mixed, SE2GPU_ERR_INVALID, "all EdgeSE2XYZ must share one Huber delta (Map.cpp:977)");
-    h->P = P; h->L = L; h->E = E; h->O = O;
+    h->P = P; h->L = L; h->E = E; h->O = O_in;
     h->cam.huber = E ? h->huber_delta : 0.0;
     h->cam3 = Cam3{h->cam.fx, h->cam.cx, h->cam.cy, h->cam.huber};
     for (int i = 0; i < 3; ++i)
@@ -2735,11 +2936,42 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     SE2_REQUIRE(npairs_max < (size_t)1 << 30, SE2GPU_ERR_CAPACITY, "the contributor plan would hold %zu pairs", npairs_max);
     // --- odometry (tiny: host)
+    // pose graph: the EdgeSE3 edges of one unordered key-frame pair form a slot (a < b); the "odometry" arrays of the
+    // plan are the slots
+    std::vector<int> pg_slot_a, pg_slot_b, pg_slot_ptr, pg_i, pg_j;
+    std::vector<double> pg_meas, pg_info;
+    int O = O_in;
+    if (h->model == 2) {
+        const int NE = (int)h->odo3.size();
+        std::vector<int> order(NE);
+        for (int k = 0; k < NE; ++k) order[k] = k;
+        auto key = [&](int k) { return std::make_pair(std::min(h->odo3[k].i, h->odo3[k].j), std::max(h->odo3[k].i, h->odo3[k].j)); };
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
+        h->pg_perm = order;
+        h->pg_edges = NE;
+        pg_i.resize(NE); pg_j.resize(NE); pg_meas.resize(12 * (size_t)NE); pg_info.resize(36 * (size_t)NE);
+        for (int t = 0; t < NE; ++t) {
+            const auto& e = h->odo3[order[t]];
+            pg_i[t] = e.i; pg_j[t] = e.j;
+            std::memcpy(&pg_meas[12 * (size_t)t], e.meas, 96);
+            std::memcpy(&pg_info[36 * (size_t)t], e.info, 288);
+            if (t == 0 || key(order[t]) != key(order[t - 1])) {
+                pg_slot_a.push_back(key(order[t]).first);
+                pg_slot_b.push_back(key(order[t]).second);
+                pg_slot_ptr.push_back(t);
+            }
+        }
+        pg_slot_ptr.push_back(NE);
+        O = (int)pg_slot_a.size();
+        h->O = O;
+    }
     std::vector<int> o_i(O), o_j(O), podo_ptr(P + 1, 0), podo_item(2 * (size_t)O);
     const int ms = h->model ? 12 : 3, is = h->model ? 36 : 9;   // doubles per measurement / information
-    std::vector<double> o_meas((size_t)ms * O), o_info((size_t)is * O);
+    std::vector<double> o_meas(h->model == 2 ? 0 : (size_t)ms * O), o_info(h->model == 2 ? 0 : (size_t)is * O);
     for (int k = 0; k < O; ++k) {
-        if (h->model) {
+        if (h->model == 2) {
+            o_i[k] = pg_slot_a[k]; o_j[k] = pg_slot_b[k];
+        } else if (h->model) {
             o_i[k] = h->odo3[k].i; o_j[k] = h->odo3[k].j;
             std::memcpy(&o_meas[12 * (size_t)k], h->odo3[k].meas, 96);
             std::memcpy(&o_info[36 * (size_t)k], h->odo3[k].info, 288);
@@ -2809,6 +3041,14 @@ int ba_upload_graph(se2gpu_ba* h) {
     stage(h->o_j, o_j.data(), o_j.size());
     stage(h->o_meas, o_meas.data(), o_meas.size());
     stage(h->o_info, o_info.data(), o_info.size());
+    if (h->model == 2) {
+        stage(h->slot_a, pg_slot_a.data(), pg_slot_a.size());
+        stage(h->slot_ptr, pg_slot_ptr.data(), pg_slot_ptr.size());
+        stage(h->pe_i, pg_i.data(), pg_i.size());
+        stage(h->pe_j, pg_j.data(), pg_j.size());
+        stage(h->pe_meas, pg_meas.data(), pg_meas.size());
+        stage(h->pe_info, pg_info.data(), pg_info.size());
+    }
     if (h->model) {
         stage(h->prior_has, h->h_prior_has.data(), h->h_prior_has.size());
         stage(h->prior_meas, h->h_prior_meas.data(), h->h_prior_meas.size());
@@ -2857,7 +3097,8 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_CHECK(h->obj.reserve((size_t)D * O + 1));
     if (h->model) {
         SE2_CHECK(h->pb.reserve(6 * (size_t)P));
-        SE2_CHECK(h->edge_chi2.reserve((size_t)E + 1));
+        SE2_CHECK(h->edge_chi2.reserve((size_t)std::max(E, h->pg_edges) + 1));
+        if (h->model == 2) SE2_CHECK(h->ph.reserve(36 * (size_t)P));
     }
     SE2_CHECK(h->xp.reserve(n));
     h->nparts = (L * kGroup + kBlock - 1) / kBlock;
@@ -3038,6 +3279,13 @@ inline Bufs bufs(se2gpu_ba* h, bool ctl) {
 int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
     hipStream_t st = h->stream;
     const Bufs B = bufs(h, ctl);
+    if (h->model == 2) {   // pose graph: nothing but the prior and edge blocks
+        SE2_LAUNCH(h->prof, st, "k4_terms", k4_terms, grid1((size_t)h->P + h->O, 64), dim3(64), 0, h->P, h->O, B.pa, h->fixed.p,
+                   h->prior_has.p, h->prior_meas.p, h->prior_info.p, h->ph.p, h->pb.p, h->slot_a.p, h->slot_ptr.p, h->pe_i.p,
+                   h->pe_j.p, h->pe_meas.p, h->pe_info.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, B.c, B.pb);
+        SE2_HIP(hipGetLastError());
+        return SE2GPU_OK;
+    }
     if (h->model) {
         if (fuse_lambda >= 0.0)
             SE2_LAUNCH(h->prof, st, "k3_linearize", (k3_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
@@ -3087,14 +3335,15 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
     double* S = h->red;
     const Bufs B = bufs(h, ctl);
     if (h->model) {
-        if (schur)
+        const double* pinfo = h->model == 2 ? h->ph.p : h->prior_info.p;   // Hessian of the prior: J' Omega J (pose graph) / Omega
+        if (schur && h->model == 1)
             SE2_LAUNCH(h->prof, st, "k3_schur_lm", k3_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
                        lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->Y.p,
                        h->Dg.p, B.c, schur == 2 ? 0 : 1);
         SE2_LAUNCH(h->prof, st, "k3_reduce2", k3_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0,
                    h->P, h->ld, h->nwg_off, lambda, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p,
                    h->Y.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->podo_ptr.p, h->podo_item.p,
-                   h->prior_has.p, h->prior_info.p, h->pb.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, S, h->bp.p, B.c);
+                   h->prior_has.p, pinfo, h->pb.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, S, h->bp.p, B.c);
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
@@ -3232,8 +3481,8 @@ int ba_lambda_init(se2gpu_ba* h) {
     hipStream_t st = h->stream;
     if (h->model) {   // diagonal of the pose blocks (observations + prior + odometry), then the common maximum
         SE2_LAUNCH(h->prof, st, "k3_pose_diag", k3_pose_diag, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
-                   h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->fixed.p, h->prior_has.p, h->prior_info.p, h->podo_ptr.p,
-                   h->podo_item.p, h->Oii.p, h->Ojj.p, h->diag3.p);
+                   h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->fixed.p, h->prior_has.p,
+                   h->model == 2 ? h->ph.p : h->prior_info.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p, h->Ojj.p, h->diag3.p);
         SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
                    h->fixed.p, h->scal.p, 6);
         hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, st, h->ctl.p, h->scal.p, 1);
@@ -3279,6 +3528,16 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
     double* scal = h->red + (size_t)h->ld * h->ld;
     const Bufs B = bufs(h, true);
     auto evaluate = [&](bool step, bool note) -> int {
+        if (h->model == 2) {
+            if (step)
+                SE2_LAUNCH(h->prof, st, "k4_oplus", k4_oplus, grid1(h->P, 64), dim3(64), 0, h->P, B.pa, h->fixed.p, h->xp.p, B.pb, B.c);
+            SE2_LAUNCH(h->prof, st, "k4_finalize", k4_finalize, dim3(1), dim3(1024), 0, h->P, h->pg_edges, B.pa, B.pb, h->fixed.p,
+                       h->xp.p, h->bp.p, h->prior_has.p, h->prior_meas.p, h->prior_info.p, h->pe_i.p, h->pe_j.p, h->pe_meas.p,
+                       h->pe_info.p, scal, h->d_mail, seq, h->ctl.p, step ? 1 : 0, note ? 1 : 0, (const volatile int*)h->d_stop,
+                       (double*)nullptr);
+            SE2_HIP(hipGetLastError());
+            return SE2GPU_OK;
+        }
         if (h->model) {
             if (step)
                 SE2_LAUNCH(h->prof, st, "k3_oplus", k3_oplus, grid1(h->P, 64), dim3(64), 0, h->P, B.pa, h->fixed.p, h->xp.p, B.pb, B.c);
@@ -3407,6 +3666,7 @@ int se2gpu_ba_clear(se2gpu_ba* h) {
     h->bulk_E = 0; h->bulk_kf = h->bulk_lm = nullptr; h->bulk_uv = h->bulk_info = nullptr;
     h->model = 0; h->D = 3; h->ps = 3;
     h->h_prior_has.clear(); h->h_prior_meas.clear(); h->h_prior_info.clear(); h->odo3.clear(); h->edge_perm.clear();
+    h->pg_edges = 0; h->pg_perm.clear();
     h->lg_active = false;
     h->lg_lc.clear(); h->lg_lw.clear(); h->lg_sigma2.clear(); h->lg_Rcw.clear(); h->lg_twb.clear();
     h->have_cam = false;
@@ -3557,10 +3817,67 @@ int se2gpu_ba_add_vertex_se3(se2gpu_ba* h, int id, const double pose12[12], int 
     return SE2GPU_OK;
 }
 
+// g2o::VertexSE3 (pose = T_w_c as an Isometry3D): the pose-graph model of GlobalMapper::GlobalBA.  A prior added with
+// se2gpu_ba_add_prior_se3 is then an EdgeSE3Prior, an edge added with se2gpu_ba_add_edge_se3 an EdgeSE3 - error vectors
+// and information matrices in the order (translation, rotation).
+int se2gpu_ba_add_vertex_iso3(se2gpu_ba* h, int id, const double pose12[12], int fixed) {
+    SE2_REQUIRE(h && pose12, SE2GPU_ERR_INVALID, "add_vertex_iso3: NULL argument");
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
+    SE2_REQUIRE(h->model == 2 || h->pose_ids.empty(), SE2GPU_ERR_STATE, "VertexSE3 in a graph of another pose type");
+    SE2_REQUIRE(h->lm_ids.empty(), SE2GPU_ERR_STATE, "the pose graph has no landmarks");
+    SE2_REQUIRE(h->pose_of_id.find(id) < 0, SE2GPU_ERR_INVALID, "duplicate vertex id %d", id);
+    h->model = 2; h->D = 6; h->ps = 12;
+    h->pose_of_id.set(id, (int)h->pose_ids.size());
+    h->pose_ids.push_back(id);
+    h->h_poses.insert(h->h_poses.end(), pose12, pose12 + 12);
+    h->h_fixed.push_back(fixed ? 1 : 0);
+    h->h_prior_has.push_back(0);
+    h->h_prior_meas.insert(h->h_prior_meas.end(), pose12, pose12 + 12);
+    h->h_prior_info.insert(h->h_prior_info.end(), 36, 0.0);
+    h->have_cam = true;   // no camera in a pose graph
+    return SE2GPU_OK;
+}
+
+// addVertexSE3PlaneMotion's prior (src/optimizer.cpp:336-470, the current branch): measurement = T_w_c with the body's
+// roll, pitch and height removed; information = AdjTR(Tbc)' diag(1e-4, 1e-4, z, xrot, yrot, 1e-4) AdjTR(Tbc) in the
+// order (translation, rotation), AdjTR(T) = [R skew(t) R; 0 R] (:95-104).  Graph construction: host code.
+int se2gpu_plane_motion_prior_iso3(const double* Twc12, const double* Tbc12, double xrot_info, double yrot_info,
+                                   double z_info, double* meas12, double* info36) {
+    SE2_REQUIRE(Twc12 && Tbc12 && meas12 && info36, SE2GPU_ERR_INVALID, "plane_motion_prior_iso3: NULL argument");
+    const Se3 Twc = se3_load(Twc12), Tbc = se3_load(Tbc12);
+    Se3 Twb = iso_mul(Twc, se3_inv(Tbc));
+    double q[4];
+    quat_of(Twb.R, q);
+    const double nv = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double yaw = 0;
+    if (nv > 0) yaw = 2 * std::atan2(nv, q[0]) * q[3] / nv;    // z component of the rotation vector (Eigen::AngleAxisd)
+    const double qz[4] = {std::cos(0.5 * yaw), 0, 0, std::sin(0.5 * yaw)};
+    mat_of_quat(qz, Twb.R);
+    Twb.t[2] = 0;
+    se3_store(iso_mul(Twb, Tbc), meas12);
+    double A[36] = {0}, sk[9], sR[9];
+    skew3(Tbc.t, sk);
+    mat3_mul(sk, Tbc.R, sR);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            A[6 * i + j] = Tbc.R[3 * i + j];
+            A[6 * (i + 3) + (j + 3)] = Tbc.R[3 * i + j];
+            A[6 * i + (j + 3)] = sR[3 * i + j];
+        }
+    const double D[6] = {1e-4, 1e-4, z_info, xrot_info, yrot_info, 1e-4};
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double v = 0;
+            for (int k = 0; k < 6; ++k) v += A[6 * k + i] * D[k] * A[6 * k + j];
+            info36[6 * i + j] = v;
+        }
+    return SE2GPU_OK;
+}
+
 int se2gpu_ba_add_prior_se3(se2gpu_ba* h, int id, const double meas12[12], const double info36[36]) {
     SE2_REQUIRE(h && meas12 && info36, SE2GPU_ERR_INVALID, "add_prior_se3: NULL argument");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
-    const int a = h->model == 1 ? h->pose_of_id.find(id) : -1;
+    const int a = h->model >= 1 ? h->pose_of_id.find(id) : -1;
     SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "add_prior_se3: unknown SE3 pose id %d", id);
     SE2_REQUIRE(!h->h_prior_has[a], SE2GPU_ERR_INVALID, "pose %d already has an EdgeSE3ExpmapPrior", id);
     h->h_prior_has[a] = 1;
@@ -3572,12 +3889,13 @@ int se2gpu_ba_add_prior_se3(se2gpu_ba* h, int id, const double meas12[12], const
 int se2gpu_ba_add_edge_se3(se2gpu_ba* h, int id0, int id1, const double meas12[12], const double info36[36]) {
     SE2_REQUIRE(h && meas12 && info36, SE2GPU_ERR_INVALID, "add_edge_se3: NULL argument");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "graph is frozen; call se2gpu_ba_clear first");
-    const int a = h->model == 1 ? h->pose_of_id.find(id0) : -1, b = h->model == 1 ? h->pose_of_id.find(id1) : -1;
+    const int a = h->model >= 1 ? h->pose_of_id.find(id0) : -1, b = h->model >= 1 ? h->pose_of_id.find(id1) : -1;
     SE2_REQUIRE(a >= 0 && b >= 0, SE2GPU_ERR_INVALID, "add_edge_se3: unknown SE3 pose id (%d, %d)", id0, id1);
     SE2_REQUIRE(a != b, SE2GPU_ERR_INVALID, "add_edge_se3: self loop on pose %d", id0);
-    for (const auto& o : h->odo3)
-        SE2_REQUIRE(!((o.i == a && o.j == b) || (o.i == b && o.j == a)), SE2GPU_ERR_INVALID,
-                    "a second EdgeSE3Expmap between poses %d and %d", id0, id1);
+    if (h->model == 1)   // the pose graph groups parallel edges into slots; the expmap model carries one per pair
+        for (const auto& o : h->odo3)
+            SE2_REQUIRE(!((o.i == a && o.j == b) || (o.i == b && o.j == a)), SE2GPU_ERR_INVALID,
+                        "a second EdgeSE3Expmap between poses %d and %d", id0, id1);
     se2gpu_ba::Odo3 e;
     e.i = a; e.j = b;
     std::memcpy(e.meas, meas12, 96);
@@ -3601,7 +3919,7 @@ int se2gpu_ba_add_edge_xyz2uv(se2gpu_ba* h, int id_mp, int id_kf, const double u
 }
 
 int se2gpu_ba_get_se3(se2gpu_ba* h, int id, double pose12[12]) {
-    SE2_REQUIRE(h && h->initialized && pose12 && h->model == 1, SE2GPU_ERR_STATE, "get_se3 needs an initialised SE3 graph");
+    SE2_REQUIRE(h && h->initialized && pose12 && h->model >= 1, SE2GPU_ERR_STATE, "get_se3 needs an initialised SE3 graph");
     const int a = h->pose_of_id.find(id);
     SE2_REQUIRE(a >= 0, SE2GPU_ERR_INVALID, "unknown pose id %d", id);
     SE2_CHECK(ba_fetch_estimates(h));
@@ -3612,10 +3930,25 @@ int se2gpu_ba_get_se3(se2gpu_ba* h, int id, double pose12[12]) {
 // EdgeProjectXYZ2UV::chi2() of every projection edge at the current estimate, in the order the edges were added
 // (LocalMapper::removeOutlierChi2 compares it with 25, LocalMapper.cpp:199-214)
 int se2gpu_ba_edge_chi2(se2gpu_ba* h, double* chi2, int cap) {
-    SE2_REQUIRE(h && h->initialized && chi2 && h->model == 1, SE2GPU_ERR_STATE, "edge_chi2 needs an initialised SE3 graph");
+    SE2_REQUIRE(h && h->initialized && chi2 && h->model >= 1, SE2GPU_ERR_STATE, "edge_chi2 needs an initialised SE3 graph");
+    hipStream_t st = h->stream;
+    if (h->model == 2) {   // EdgeSE3::chi2() of every edge of the pose graph, in the order the edges were added
+        const int NE = h->pg_edges;
+        SE2_REQUIRE(cap >= NE, SE2GPU_ERR_CAPACITY, "edge_chi2: %d edges, room for %d", NE, cap);
+        if (!NE) return SE2GPU_OK;
+        hipLaunchKernelGGL(k4_finalize, dim3(1), dim3(1024), 0, st, h->P, NE, h->poses, h->poses_t, h->fixed.p, h->xp.p, h->bp.p,
+                           h->prior_has.p, h->prior_meas.p, h->prior_info.p, h->pe_i.p, h->pe_j.p, h->pe_meas.p, h->pe_info.p,
+                           (double*)nullptr, (volatile double*)nullptr, 0.0, (BaCtl*)nullptr, 0, 0, (const volatile int*)nullptr,
+                           h->edge_chi2.p);
+        SE2_HIP(hipGetLastError());
+        std::vector<double> tmp(NE);
+        SE2_HIP(hipMemcpyAsync(tmp.data(), h->edge_chi2.p, (size_t)NE * 8, hipMemcpyDeviceToHost, st));
+        SE2_HIP(hipStreamSynchronize(st));
+        for (int t = 0; t < NE; ++t) chi2[h->pg_perm[t]] = tmp[t];
+        return SE2GPU_OK;
+    }
     SE2_REQUIRE(cap >= h->E, SE2GPU_ERR_CAPACITY, "edge_chi2: %d edges, room for %d", h->E, cap);
     if (!h->E) return SE2GPU_OK;
-    hipStream_t st = h->stream;
     hipLaunchKernelGGL(k3_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, st, h->cam3, h->L, 0.0, h->lm_ptr.p,
                        h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->poses_t, h->lms, (const double*)nullptr, h->z.p, h->Y.p,
                        h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, 0, h->edge_chi2.p);

@@ -341,6 +341,45 @@ def load_se3_graph(opt: SlamOptimizer, g, K=None):
     return maxKFid
 
 
+# -- pose graphs (optimizer.h:117-135): GlobalMapper::GlobalBA -------------------------------------------------------------
+def addVertexSE3(opt: SlamOptimizer, Twc, id: int, fixed: bool = False):
+    """optimizer.h:120: g2o::VertexSE3 with the Isometry3D T_w_c"""
+    capi.check(capi.lib().se2gpu_ba_add_vertex_iso3(opt._h, int(id), capi.pd(_pose12(Twc)), int(bool(fixed))))
+
+
+def addVertexSE3PlaneMotion(opt: SlamOptimizer, Twc, id: int, extPara, paraSE3OffsetId: int = 0, fixed: bool = False,
+                            xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    """optimizer.h:123 / optimizer.cpp:336-470: the vertex plus its EdgeSE3Prior (extPara = Config::bTc)"""
+    addVertexSE3(opt, Twc, id, fixed)
+    meas = np.zeros(12)
+    info = np.zeros(36)
+    capi.check(capi.lib().se2gpu_plane_motion_prior_iso3(_pose12(Twc).ctypes.data, _pose12(extPara).ctypes.data,
+                                                         float(xrot_info), float(yrot_info), float(z_info), meas.ctypes.data,
+                                                         info.ctypes.data))
+    capi.check(capi.lib().se2gpu_ba_add_prior_se3(opt._h, int(id), capi.pd(meas), capi.pd(info)))
+    return _pose44(meas), info.reshape(6, 6)
+
+
+def addEdgeSE3(opt: SlamOptimizer, measure, id0: int, id1: int, info):
+    """optimizer.h:129"""
+    addEdgeSE3Expmap(opt, measure, id0, id1, info)
+
+
+estimateVertexSE3 = estimateVertexSE3Expmap     # optimizer.h:135 (the pose type follows the graph)
+
+
+def load_pose_graph(opt: SlamOptimizer, g):
+    """A synth.PoseGraph through GlobalMapper::GlobalBA's call sequence (GlobalMapper.cpp:352-412)."""
+    for a in range(g.P):
+        addVertexSE3(opt, g.poses[a], a, bool(g.fixed[a]))
+        if g.has_prior[a]:
+            addPriorSE3Expmap(opt, a, g.prior_meas[a], g.prior_info[a])
+    for k in range(g.O):
+        addEdgeSE3(opt, g.o_meas[k], int(g.o_i[k]), int(g.o_j[k]), g.o_info[k])
+    opt._shape = (g.P, 0)
+    opt._pose_dim = 12
+
+
 def shard_landmarks(L: int, e_kf: np.ndarray, e_lm: np.ndarray, world: int) -> np.ndarray:
     """Host-side landmark partition of the library (no device needed)."""
     e_kf = np.ascontiguousarray(e_kf, np.int32)

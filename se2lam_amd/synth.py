@@ -519,3 +519,108 @@ def ba3_graph(P: int = 50, L: int = 5000, n_ref: int = 0, seed: int = BA_SEED) -
     return BA3Graph(poses=poses, fixed=fixed, lms=g.lms.copy(), e_kf=g.e_kf, e_lm=g.e_lm, e_uv=g.e_uv, e_w=e_w,
                     has_prior=has_prior, prior_meas=np.stack([m for m, _ in pm]), prior_info=np.stack([i for _, i in pm]),
                     o_i=o_i, o_j=o_j, o_meas=o_meas, o_info=o_info)
+
+
+# --------------------------------------------------------------------------
+# pose graphs of GlobalMapper::GlobalBA: g2o::VertexSE3 (T_w_c) + EdgeSE3Prior + EdgeSE3
+# --------------------------------------------------------------------------
+def mqt_np(T):
+    """g2o::internal::toVectorMQT: (translation, compact quaternion q_xyz of the rotation, w >= 0)."""
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(T[:3, :3]).as_quat()      # (x, y, z, w)
+    if q[3] < 0:
+        q = -q
+    return np.concatenate([T[:3, 3], q[:3]])
+
+
+def from_mqt_np(v):
+    from scipy.spatial.transform import Rotation
+    w2 = 1 - v[3:] @ v[3:]
+    T = np.eye(4)
+    if w2 >= 0:
+        T[:3, :3] = Rotation.from_quat([v[3], v[4], v[5], np.sqrt(w2)]).as_matrix()
+    T[:3, 3] = v[:3]
+    return T
+
+
+def plane_motion_prior_se3_np(Twc, Rbc=RBC, tbc=TBC, xrot=PLANEMOTION_XROT_INFO, yrot=PLANEMOTION_XROT_INFO, zinfo=PLANEMOTION_Z_INFO):
+    """addVertexSE3PlaneMotion (src/optimizer.cpp:336-470, #else branch): (measurement T_w_c 4x4, information 6x6 in the
+    order (translation, rotation))."""
+    from scipy.spatial.transform import Rotation
+    Tbc = np.eye(4)
+    Tbc[:3, :3] = Rbc
+    Tbc[:3, 3] = tbc
+    Twb = Twc @ np.linalg.inv(Tbc)
+    yaw = Rotation.from_matrix(Twb[:3, :3]).as_rotvec()[2]
+    Twb2 = np.eye(4)
+    Twb2[:3, :3] = _so3_exp(np.array([0, 0, yaw]))
+    Twb2[:3, 3] = [Twb[0, 3], Twb[1, 3], 0.0]
+    R, t = Tbc[:3, :3], Tbc[:3, 3]
+    K = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0.0]])
+    A = np.zeros((6, 6))            # AdjTR (optimizer.cpp:95-104): [R skew(t) R; 0 R]
+    A[:3, :3] = R
+    A[3:, 3:] = R
+    A[:3, 3:] = K @ R
+    return Twb2 @ Tbc, A.T @ np.diag([1e-4, 1e-4, zinfo, xrot, yrot, 1e-4]) @ A
+
+
+@dataclasses.dataclass
+class PoseGraph:
+    """poses (P,4,4) T_w_c, fixed (P,), has_prior (P,), prior_meas (P,4,4), prior_info (P,6,6),
+    o_i / o_j (O,) = vertex 0 / 1 of every EdgeSE3, o_meas (O,4,4), o_info (O,6,6); information order (translation, rotation)."""
+    poses: np.ndarray
+    fixed: np.ndarray
+    has_prior: np.ndarray
+    prior_meas: np.ndarray
+    prior_info: np.ndarray
+    o_i: np.ndarray
+    o_j: np.ndarray
+    o_meas: np.ndarray
+    o_info: np.ndarray
+    poses_true: np.ndarray | None = None
+    P = property(lambda self: int(self.poses.shape[0]))
+    O = property(lambda self: int(self.o_i.shape[0]))
+
+
+@functools.lru_cache(maxsize=4)
+def pose_graph(P: int = 200, seed: int = BA_SEED) -> PoseGraph:
+    """All key frames of a map on the circular trajectory: odometry edges between consecutive key frames, feature edges
+    to the key frames 2 and 3 ahead (both an odometry and a feature edge for some consecutive pairs, as the reference
+    produces), loop-closing feature edges between the two ends; drifted start, key frame 0 fixed."""
+    g = ba_graph(8, 60, seed=seed)           # only for the camera constants
+    del g
+    rng = np.random.default_rng(seed + 5 * P)
+    head = -np.pi + 0.1 + (2 * np.pi - 0.2) * np.arange(P) / max(P - 1, 1)
+    ang = head - np.pi / 2
+    se2 = np.stack([6000.0 * np.cos(ang), 6000.0 * np.sin(ang), head], axis=1)
+    true = np.stack([np.linalg.inv(se2_to_Tcw(p)) for p in se2])            # T_w_c
+    poses = true.copy()
+    drift = np.eye(4)
+    for a in range(1, P):   # accumulated odometry drift + out-of-plane noise
+        drift = drift @ from_mqt_np(rng.normal(0, 1.0, 6) * np.array([4.0, 4.0, 0.5, 2e-4, 2e-4, 8e-4]))
+        poses[a] = true[a] @ drift
+    fixed = np.zeros(P, np.uint8)
+    fixed[0] = 1
+    pm = [plane_motion_prior_se3_np(poses[a]) for a in range(P)]
+    oi, oj, om, ow = [], [], [], []
+
+    def add(i, j, sig_t, sig_r):
+        Z = np.linalg.inv(true[i]) @ true[j] @ from_mqt_np(rng.normal(0, 1.0, 6) * np.array([sig_t] * 3 + [sig_r] * 3))
+        A = np.diag([1 / sig_t ** 2] * 3 + [1 / sig_r ** 2] * 3)
+        B = rng.normal(0, 1, (6, 6)) * 0.05
+        S = np.diag(np.sqrt(np.diag(A)))
+        W = A + S @ (B + B.T) @ S
+        assert np.linalg.eigvalsh(W).min() > 0
+        oi.append(i); oj.append(j); om.append(Z); ow.append(W)
+
+    for a in range(P - 1):
+        add(a + 1, a, 3.0, 1e-3)                 # mOdoMeasureFrom: (this KF, the previous one)  GlobalMapper.cpp:386-388
+    for a in range(P):
+        for d in (1, 2, 3):
+            if a + d < P and (d > 1 or a % 3 == 0):
+                add(a, a + d, 8.0, 2e-3)         # mFtrMeasureFrom
+    for a in range(min(4, P // 8)):
+        add(P - 1 - a, a, 10.0, 3e-3)            # loop closure
+    return PoseGraph(poses=poses, fixed=fixed, has_prior=np.ones(P, np.uint8), prior_meas=np.stack([m for m, _ in pm]),
+                     prior_info=np.stack([w for _, w in pm]), o_i=np.array(oi, np.int32), o_j=np.array(oj, np.int32),
+                     o_meas=np.stack(om), o_info=np.stack(ow), poses_true=true)
