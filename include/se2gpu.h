@@ -228,6 +228,17 @@ int se2gpu_ba_add_edge_xyz2uv(se2gpu_ba* h, int id_mp, int id_kf, const double u
 int se2gpu_ba_get_se3(se2gpu_ba* h, int id, double pose12[12]);
 int se2gpu_ba_edge_chi2(se2gpu_ba* h, double* chi2, int cap);
 
+/* Sparsifier::DoMarginalizeSE3XYZ (/root/reference/src/sparsifier.cpp:105-275) for a batch of key-frame pairs - SURVEY.md
+ * section 8f.4: the feature constraint (relative pose + 6x6 information, order (translation, rotation) of
+ * SE3Quat::toMinimalVector) that GlobalMapper::CreateFeatEdge (src/GlobalMapper.cpp:744-840) stores in mFtrMeasureFrom and
+ * GlobalBA turns into an EdgeSE3.  Pair p: kf12[p] = T_w_c of the two key frames (2 x 12), its map points
+ * mp_xyz[mp_ptr[p] .. mp_ptr[p+1]) and its measurements [m_ptr[p], m_ptr[p+1]): m_kf in {0, 1} (others are ignored, as
+ * :117-119), m_mp = index of the point inside the pair, m_info = 3x3 information (row-major; MeasSE3XYZ::info).
+ * z_out12[p] = pose12 of KF0^-1 * KF1, info_out36[p] row-major.  One wave per pair; host buffers. */
+int se2gpu_sparsify_se3xyz(int npairs, const double* kf12, const int32_t* mp_ptr, const double* mp_xyz,
+                           const int32_t* m_ptr, const int32_t* m_kf, const int32_t* m_mp, const double* m_info,
+                           double* z_out12, double* info_out36);
+
 /* Map::loadLocalGraph(SlamOptimizer&) (/root/reference/src/Map.cpp:891-1022) as ONE call on a POD view of the local
  * window - SURVEY.md section 8f.1.  The caller flattens its pointer graph once per key frame (INTEGRATION.md shows the
  * 30 lines that do it with one hash map instead of the reference's std::find per observation); the library applies

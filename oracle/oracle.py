@@ -753,3 +753,18 @@ def pg_plane_motion_prior(Twc, Tbc, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     f(a.ctypes.data, b.ctypes.data, xrot_info, yrot_info, z_info, meas.ctypes.data, info.ctypes.data)
     return poses44(meas)[0], info.reshape(6, 6)
+
+
+def sparsify(kf, mp, m_kf, m_mp, m_info):
+    """Sparsifier::DoMarginalizeSE3XYZ: kf (2,4,4) T_w_c, mp (N,3), measurements (M,), info (M,3,3)
+    -> (z_out 4x4 = KF0^-1 KF1, info_out 6x6, H_marginal 12x12)"""
+    k12 = poses12(np.asarray(kf))
+    mp = np.ascontiguousarray(mp, np.float64); mk = np.ascontiguousarray(m_kf, np.int32); mm = np.ascontiguousarray(m_mp, np.int32)
+    mi = np.ascontiguousarray(m_info, np.float64).reshape(-1, 9)
+    z = np.zeros(12); info = np.zeros(36); H = np.zeros(144)
+    f = lib().sparsify_ref
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(k12.ctypes.data, len(mp), mp.ctypes.data, len(mk), mk.ctypes.data, mm.ctypes.data, mi.ctypes.data, z.ctypes.data,
+      info.ctypes.data, H.ctypes.data)
+    return poses44(z)[0], info.reshape(6, 6), H.reshape(12, 12)

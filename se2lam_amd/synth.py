@@ -624,3 +624,26 @@ def pose_graph(P: int = 200, seed: int = BA_SEED) -> PoseGraph:
     return PoseGraph(poses=poses, fixed=fixed, has_prior=np.ones(P, np.uint8), prior_meas=np.stack([m for m, _ in pm]),
                      prior_info=np.stack([w for _, w in pm]), o_i=np.array(oi, np.int32), o_j=np.array(oj, np.int32),
                      o_meas=np.stack(om), o_info=np.stack(ow), poses_true=true)
+
+
+def kf_pair(N: int = 80, seed: int = 0, baseline: float = 400.0):
+    """Two key frames (T_w_c) of the circular trajectory `baseline` mm apart and the N map points both see, with the
+    per-observation 3x3 information of KeyFrame::mViewMPsInfo (camera frame: 1/sigma^2 with a depth-dependent z term,
+    randomly rotated a little) - the inputs of GlobalMapper::CreateFeatEdge / Sparsifier::DoMarginalizeSE3XYZ.
+    -> (kf (2,4,4), mp (N,3), m_kf (2N,), m_mp (2N,), m_info (2N,3,3))"""
+    rng = np.random.default_rng(1000 + seed)
+    th0 = rng.uniform(-2.5, 2.5)
+    dth = baseline / 6000.0
+    se2 = [np.array([6000 * np.cos(a - np.pi / 2), 6000 * np.sin(a - np.pi / 2), a]) for a in (th0, th0 + dth)]
+    kf = np.stack([np.linalg.inv(se2_to_Tcw(p)) for p in se2])
+    Xc = np.stack([rng.uniform(-1500, 1500, N), rng.uniform(-900, 900, N), rng.uniform(1500, 7000, N)], 1)   # in camera 0
+    mp = (kf[0][:3, :3] @ Xc.T).T + kf[0][:3, 3]
+    m_kf, m_mp, m_info = [], [], []
+    for j in range(N):
+        for k in (0, 1):
+            z = np.linalg.inv(kf[k]) @ np.r_[mp[j], 1.0]
+            sz = 0.02 * z[2] ** 2 / 400.0 + 5.0
+            Rn = _so3_exp(rng.normal(0, 0.05, 3))
+            m_kf.append(k); m_mp.append(j)
+            m_info.append(Rn @ np.diag([1 / 4.0, 1 / 4.0, 1 / sz ** 2]) @ Rn.T)
+    return kf, mp, np.array(m_kf, np.int32), np.array(m_mp, np.int32), np.stack(m_info)
