@@ -12,6 +12,7 @@
 // the real types are compiled in (conversions.h).
 #pragma once
 #include <deque>
+#include <vector>
 
 #include "types.h"
 
@@ -22,6 +23,23 @@ struct CamPara {   // g2o::CameraParameters (focal_length, principle_point, base
     double principle_point[2] = {0, 0};
     int id = 0;
 };
+
+class SlamOptimizer;
+
+// What the reference keeps of an EdgeProjectXYZ2UV* / EdgeSE3* after adding it (LocalMapper::removeOutlierChi2,
+// LocalMapper.cpp:199-214; GlobalMapper::GlobalBA, GlobalMapper.cpp:415-476): computeError(), chi2(), setLevel(), level().
+// chi2() of all edges comes from ONE device pass after optimize() (se2gpu_ba_edge_chi2), cached by the optimizer.
+struct EdgeHandle {
+    SlamOptimizer* opt = nullptr;
+    int index = -1;
+    int level_ = 0;
+    void computeError() {}
+    double chi2() const;
+    void setLevel(int l) { level_ = l; }
+    int level() const { return level_; }
+};
+typedef EdgeHandle EdgeProjectXYZ2UV;
+typedef EdgeHandle EdgeSE3;
 
 class SlamOptimizer {  // g2o::SparseOptimizer (the subset the hot path uses)
 public:
@@ -41,7 +59,17 @@ public:
         static_assert(sizeof(bool) == 1, "the stop flag is polled as a byte");
         check(se2gpu_ba_optimize(h_, iterations, SE2GPU_BA_LM, reinterpret_cast<const volatile uint8_t*>(stop_),
                                  verbose_ ? 1 : 0, &stats_), "optimize");
+        edge_chi2_.clear();
         return stats_.iterations;
+    }
+    void addEdge(EdgeHandle*) {}                                          // Map.cpp:551: the library added it already
+    EdgeHandle* newEdge() { edges_.emplace_back(); edges_.back().opt = this; edges_.back().index = (int)edges_.size() - 1; return &edges_.back(); }
+    double edgeChi2(int index) {
+        if (edge_chi2_.empty()) {
+            edge_chi2_.assign(edges_.size(), 0.0);
+            check(se2gpu_ba_edge_chi2(h_, edge_chi2_.data(), (int)edge_chi2_.size()), "EdgeProjectXYZ2UV::chi2");
+        }
+        return edge_chi2_.at(index);
     }
     void clear() { check(se2gpu_ba_clear(h_), "clear"); }
     void clearParameters() {}
@@ -53,11 +81,15 @@ public:
 
 private:
     std::deque<CamPara> cams_;
+    std::deque<EdgeHandle> edges_;
+    std::vector<double> edge_chi2_;
     se2gpu_ba* h_ = nullptr;
     bool* stop_ = nullptr;
     bool verbose_ = false;
     se2gpu_ba_stats stats_{};
 };
+
+inline double EdgeHandle::chi2() const { return opt->edgeChi2(index); }
 
 inline void initOptimizer(SlamOptimizer& opt, bool verbose = false) { opt.setVerbose(verbose); }
 
@@ -117,6 +149,87 @@ inline void addEdgeSE2(SlamOptimizer& opt, const Eigen::Vector3d& meas, int id0,
     addEdgeSE2(opt, mirror(meas), id0, id1, mirror(info));
 }
 #endif
+
+// ---- SE3-expmap graphs: Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx) (Map.cpp:414-566) --------------------------
+inline void pose12Of(const SE3Quat& q, double p[12]) {
+    for (int i = 0; i < 9; ++i) p[i] = q.R[i];
+    for (int i = 0; i < 3; ++i) p[9 + i] = q.t[i];
+}
+inline SE3Quat se3QuatOf(const double p[12]) {
+    SE3Quat q;
+    for (int i = 0; i < 9; ++i) q.R[i] = p[i];
+    for (int i = 0; i < 3; ++i) q.t[i] = p[9 + i];
+    return q;
+}
+inline void addVertexSE3Expmap(SlamOptimizer& opt, const SE3Quat& pose, int id, bool fixed = false) {   // optimizer.h:88
+    double p[12];
+    pose12Of(pose, p);
+    check(se2gpu_ba_add_vertex_se3(opt.handle(), id, p, fixed), "addVertexSE3Expmap");
+}
+// EdgeSE3ExpmapPrior* addPlaneMotionSE3Expmap(opt, pose, vId, extPara) (optimizer.h:82): extPara = Config::bTc (4x4 CV_32F);
+// the Config::PLANEMOTION_* weights are arguments here (defaults of src/Config.cpp:46-48)
+template <typename MatT>
+inline void addPlaneMotionSE3Expmap(SlamOptimizer& opt, const SE3Quat& pose, int vId, const MatT& extPara,
+                                    double xrotInfo = 1e6, double yrotInfo = 1e6, double zInfo = 1) {
+    double p[12], b[12], meas[12], info[36];
+    pose12Of(pose, p);
+    pose12Of(toSE3Quat(extPara), b);
+    check(se2gpu_plane_motion_prior(p, b, xrotInfo, yrotInfo, zInfo, meas, info), "addPlaneMotionSE3Expmap");
+    check(se2gpu_ba_add_prior_se3(opt.handle(), vId, meas, info), "addPlaneMotionSE3Expmap");
+}
+// addEdgeSE3Expmap (optimizer.h:94, optimizer.cpp:482-500): "The input info is [trans rot] order, but EdgeSE3Expmap
+// requires [rot trans]" - the four 3x3 blocks are swapped exactly as the reference swaps them
+inline void addEdgeSE3Expmap(SlamOptimizer& opt, const SE3Quat& measure, int id0, int id1, const Matrix6d& info) {
+    Matrix6d n;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            n(r, c) = info(3 + r, 3 + c);
+            n(3 + r, c) = info(r, 3 + c);
+            n(r, 3 + c) = info(3 + r, c);
+            n(3 + r, 3 + c) = info(r, c);
+        }
+    double p[12];
+    pose12Of(measure, p);
+    check(se2gpu_ba_add_edge_se3(opt.handle(), id0, id1, p, n.m), "addEdgeSE3Expmap");
+}
+// EdgeProjectXYZ2UV* addEdgeXYZ2UV(opt, measure, id0 (map point), id1 (key frame), paraId, info, thHuber) (optimizer.h:97)
+inline EdgeProjectXYZ2UV* addEdgeXYZ2UV(SlamOptimizer& opt, const Vector2D& measure, int id0, int id1, int /*paraId*/,
+                                        const Matrix2D& info, double thHuber) {
+    check(se2gpu_ba_add_edge_xyz2uv(opt.handle(), id0, id1, measure.v, info.m[0], thHuber), "addEdgeXYZ2UV");
+    return opt.newEdge();
+}
+inline SE3Quat estimateVertexSE3Expmap(SlamOptimizer& opt, int id) {                                      // optimizer.h:138
+    double p[12];
+    check(se2gpu_ba_get_se3(opt.handle(), id, p), "estimateVertexSE3Expmap");
+    return se3QuatOf(p);
+}
+
+// ---- pose graphs: GlobalMapper::GlobalBA (GlobalMapper.cpp:328-535); Isometry3D is carried as rotation + translation ----
+typedef SE3Quat Isometry3D;
+inline void addParaSE3Offset(SlamOptimizer&, const Isometry3D&, int) {}       // optimizer.h:117: the identity offset GlobalBA uses
+inline void addVertexSE3(SlamOptimizer& opt, const Isometry3D& pose, int id, bool fixed = false) {          // optimizer.h:120
+    double p[12];
+    pose12Of(pose, p);
+    check(se2gpu_ba_add_vertex_iso3(opt.handle(), id, p, fixed), "addVertexSE3");
+}
+template <typename MatT>
+inline void addVertexSE3PlaneMotion(SlamOptimizer& opt, const Isometry3D& pose, int id, const MatT& extPara,
+                                    int /*paraSE3OffsetId*/, bool fixed = false, double xrotInfo = 1e6,
+                                    double yrotInfo = 1e6, double zInfo = 1) {                              // optimizer.h:123
+    addVertexSE3(opt, pose, id, fixed);
+    double p[12], b[12], meas[12], info[36];
+    pose12Of(pose, p);
+    pose12Of(toSE3Quat(extPara), b);
+    check(se2gpu_plane_motion_prior_iso3(p, b, xrotInfo, yrotInfo, zInfo, meas, info), "addVertexSE3PlaneMotion");
+    check(se2gpu_ba_add_prior_se3(opt.handle(), id, meas, info), "addVertexSE3PlaneMotion");
+}
+inline EdgeSE3* addEdgeSE3(SlamOptimizer& opt, const Isometry3D& measure, int id0, int id1, const Matrix6d& info) {   // :129
+    double p[12];
+    pose12Of(measure, p);
+    check(se2gpu_ba_add_edge_se3(opt.handle(), id0, id1, p, info.m), "addEdgeSE3");
+    return opt.newEdge();
+}
+inline Isometry3D estimateVertexSE3(SlamOptimizer& opt, int id) { return estimateVertexSE3Expmap(opt, id); }   // optimizer.h:135
 
 inline SE2 estimateVertexSE2(SlamOptimizer& opt, int id) {
     double v[3];

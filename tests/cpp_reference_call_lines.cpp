@@ -4,6 +4,7 @@
 // classes (KeyFrame, MapPoint, Config) are stubs, and `se2lam` / `g2o` / `cv` / `Eigen` resolve to the mirrors of
 // include/se2lam_amd/types.h (with the real libraries installed they resolve to the real types and the overloads of
 // conversions.h).  The test is that this file COMPILES (-Wall -Werror) and, on a GPU, that the pasted sequence runs.
+#include <cmath>
 #include <cstdio>
 #include <map>
 #include <memory>
@@ -13,6 +14,8 @@
 #include "se2lam_amd/ORBmatcher.h"
 #include "se2lam_amd/Track.h"
 #include "se2lam_amd/optimizer.h"
+#include "se2lam_amd/sparsifier.h"
+#include "se2lam_amd/Map.h"
 
 namespace g2o {
 using SE2 = se2lam_amd::SE2;
@@ -33,7 +36,7 @@ using Eigen_Vector2d = g2o::Vector2D;
 using Matrix2d = g2o::Matrix2D;
 
 struct Se2 { float x = 0, y = 0, theta = 0; };
-struct PreSE2 { double meas[3]; double cov[9]; };
+using se2lam_amd::PreSE2;   // Frame.h:20-24
 struct KeyFrame {
     int id = 0;
     Se2 Twb;
@@ -157,6 +160,183 @@ int main() {
     std::printf("levels %d scale %.2f\n", extractor.GetLevels(), extractor.GetScaleFactor());
     std::map<int, int> mapIdxMatches12;
     (void)mapIdxMatches12;
+    // ---- LocalMapper::removeOutlierChi2 (LocalMapper.cpp:172-214) on Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx)
+    //      (Map.cpp:414-566): two key frames on the plane, one map point, the prior and the projection edges
+    {
+        SlamOptimizer optimizer;
+        initOptimizer(optimizer);
+        std::vector<std::vector<EdgeProjectXYZ2UV*> > vpEdgesAll;
+        std::vector<std::vector<int> > vnAllIdx;
+        int camParaId = 0;
+        addCamPara(optimizer, Config::Kcam, camParaId);
+        cv::Mat Tcw0 = cv::Mat::eye(4), Tcw1 = cv::Mat::eye(4);
+        {   // Tcw = Tbc^-1 for the body at the origin / 500 mm further along x
+            const float Rcb[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Tcw0.at<float>(r, c) = Rcb[3 * r + c]; Tcw1.at<float>(r, c) = Rcb[3 * r + c]; }
+            Tcw0.at<float>(1, 3) = 300; Tcw0.at<float>(2, 3) = -100;
+            Tcw1.at<float>(1, 3) = 300; Tcw1.at<float>(2, 3) = -600;
+        }
+        for (int vertexIdKF = 0; vertexIdKF < 2; ++vertexIdKF) {
+            bool fixed = vertexIdKF == 0;
+            const cv::Mat& pose = vertexIdKF ? Tcw1 : Tcw0;
+            addVertexSE3Expmap(optimizer, toSE3Quat(pose), vertexIdKF, fixed);                       // Map.cpp:444
+            addPlaneMotionSE3Expmap(optimizer, toSE3Quat(pose), vertexIdKF, Config::bTc);            // Map.cpp:445
+        }
+        Matrix6d odoInfo;
+        for (int i = 0; i < 6; ++i) odoInfo(i, i) = i < 3 ? 1e-2 : 1e3;                             // [trans rot] order, as stored
+        SE3Quat Tc1c0;   // T_c1_c0 = Tcw1 * Tcw0^-1: pure translation along the optical axis
+        Tc1c0.t[2] = -500;
+        addEdgeSE3Expmap(optimizer, Tc1c0, 0, 1, odoInfo);                                           // Map.cpp:467
+        int vertexIdMP = 2 + 1;
+        addVertexSBAXYZ(optimizer, Vector3D(4000, 300, 500), vertexIdMP);                            // Map.cpp:500
+        std::vector<EdgeProjectXYZ2UV*> vpEdges;
+        std::vector<int> vnIdx;
+        const float delta = Config::TH_HUBER;
+        const double uvs[2][2] = {{290.0, 260.0}, {286.0, 262.0}};
+        for (int vertexIdKF = 0; vertexIdKF < 2; ++vertexIdKF) {
+            Eigen_Vector2d uv(uvs[vertexIdKF][0], uvs[vertexIdKF][1]);
+            Matrix2d info = Matrix2d::Identity();
+            EdgeProjectXYZ2UV* ei = addEdgeXYZ2UV(optimizer, uv, vertexIdMP, vertexIdKF, camParaId, info, delta);   // Map.cpp:548
+            ei->setLevel(0);
+            optimizer.addEdge(ei);
+            vpEdges.push_back(ei);
+            vnIdx.push_back(vertexIdKF);
+        }
+        vpEdgesAll.push_back(vpEdges);
+        vnAllIdx.push_back(vnIdx);
+        const float chi2 = 25;                                                                        // LocalMapper.cpp:186
+        optimizer.initializeOptimization(0);
+        optimizer.optimize(10);
+        const int nAllMP = vpEdgesAll.size();
+        std::vector<std::vector<int> > vnOutlierIdxAll;
+        for (int i = 0; i < nAllMP; i++) {
+            std::vector<int> vnOutlierIdx;
+            for (int j = 0, jend = vpEdgesAll[i].size(); j < jend; j++) {
+                EdgeProjectXYZ2UV* eij = vpEdgesAll[i][j];
+                if (eij->level() > 0)
+                    continue;
+                eij->computeError();
+                bool chi2Bad = eij->chi2() > chi2;
+                int idKF = vnAllIdx[i][j];
+                if (chi2Bad) {
+                    eij->setLevel(1);
+                    vnOutlierIdx.push_back(idKF);
+                }
+            }
+            vnOutlierIdxAll.push_back(vnOutlierIdx);
+        }
+        SE3Quat T1 = estimateVertexSE3Expmap(optimizer, 1);
+        std::printf("removeOutlierChi2 lines: %zu outliers, KF1 t = %.2f %.2f %.2f\n", vnOutlierIdxAll[0].size(), T1.t[0], T1.t[1], T1.t[2]);
+    }
+    // ---- GlobalMapper::GlobalBA (GlobalMapper.cpp:340-412, 517-524): VertexSE3 + plane-motion prior + EdgeSE3
+    {
+        SlamOptimizer optimizer;
+        int SE3OffsetParaId = 0;
+        addParaSE3Offset(optimizer, Isometry3D(), SE3OffsetParaId);
+        cv::Mat T_w_c0 = cv::Mat::eye(4), T_w_c1 = cv::Mat::eye(4);
+        {
+            const float Rbc[9] = {0, 0, 1, -1, 0, 0, 0, -1, 0};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { T_w_c0.at<float>(r, c) = Rbc[3 * r + c]; T_w_c1.at<float>(r, c) = Rbc[3 * r + c]; }
+            T_w_c0.at<float>(0, 3) = 100; T_w_c0.at<float>(2, 3) = 300;
+            T_w_c1.at<float>(0, 3) = 630; T_w_c1.at<float>(1, 3) = 8; T_w_c1.at<float>(2, 3) = 304;   // drifted by 30 / 8 / 4 mm
+        }
+        std::vector<EdgeSE3*> vpEdgePlane;
+        addVertexSE3PlaneMotion(optimizer, toSE3Quat(T_w_c0), 0, Config::bTc, SE3OffsetParaId, true);
+        addVertexSE3PlaneMotion(optimizer, toSE3Quat(T_w_c1), 1, Config::bTc, SE3OffsetParaId, false);
+        Matrix6d info;
+        for (int i = 0; i < 6; ++i) info(i, i) = i < 3 ? 1e-1 : 1e4;
+        Isometry3D meas;
+        meas.t[2] = 500;                                                   // T_c0_c1 of the true motion: 500 mm along the optical axis
+        EdgeSE3* pEdgeOdoTmp = addEdgeSE3(optimizer, meas, 0, 1, info);    // GlobalMapper.cpp:386
+        optimizer.initializeOptimization();
+        optimizer.optimize(5);
+        Isometry3D Twc = estimateVertexSE3(optimizer, 1);
+        std::printf("GlobalBA lines: KF1 at %.2f %.2f %.2f, odometry edge chi2 %.4f\n", Twc.t[0], Twc.t[1], Twc.t[2], pEdgeOdoTmp->chi2());
+        if (!(std::fabs(Twc.t[0] - 600.0) < 15.0)) return 1;
+    }
+    // ---- GlobalMapper::CreateFeatEdge (GlobalMapper.cpp:795-837): the measurement vector and the Sparsifier call
+    {
+        std::vector<SE3Quat> vSe3KFs(2);
+        vSe3KFs[1].t[0] = 400;
+        std::vector<Vector3D> vPt3MPs;
+        std::vector<MeasSE3XYZ> vMeasSE3XYZ;
+        int count = 0;
+        for (int k = 0; k < 12; ++k) {
+            Vector3D Pw(-800.0 + 170.0 * k, 300.0 * ((k % 3) - 1), 3000.0 + 211.0 * ((k * 5) % 7));
+            vPt3MPs.push_back(Pw);
+            MeasSE3XYZ Meas1;
+            Meas1.idKF = 0;
+            Meas1.idMP = count;
+            Meas1.z = Pw;
+            for (int i = 0; i < 3; ++i) Meas1.info(i, i) = i < 2 ? 1e-2 : 1e-4;
+            MeasSE3XYZ Meas2;
+            Meas2.idKF = 1;
+            Meas2.idMP = count;
+            Meas2.z = Vector3D(Pw(0) - 400, Pw(1), Pw(2));
+            Meas2.info = Meas1.info;
+            vMeasSE3XYZ.push_back(Meas1);
+            vMeasSE3XYZ.push_back(Meas2);
+            count++;
+        }
+        SE3Quat meas_out;
+        Matrix6d info_out;
+        Sparsifier::DoMarginalizeSE3XYZ(vSe3KFs, vPt3MPs, vMeasSE3XYZ, meas_out, info_out);
+        std::printf("CreateFeatEdge lines: z.t = %.1f %.1f %.1f, info(0,0) = %.4g\n", meas_out.t[0], meas_out.t[1], meas_out.t[2], info_out(0, 0));
+        if (!(std::fabs(meas_out.t[0] - 400.0) < 1e-6) || !(info_out(0, 0) > 0)) return 1;
+    }
+    // ---- Map::updateLocalGraph + Map::loadLocalGraph(SlamOptimizer&) + LocalMapper::localBA through the flat views
+    //      (Map.cpp:285-331, 891-1022; LocalMapper.cpp:232-262): three key frames in a row, nine map points
+    {
+        MapView map;
+        for (int k = 0; k < 3; ++k) map.addKeyFrame(k);
+        map.addCovisibility(0, 1); map.addCovisibility(1, 0); map.addCovisibility(1, 2); map.addCovisibility(2, 1);
+        for (int m = 0; m < 9; ++m) {
+            map.addMapPoint(m);
+            for (int k = 0; k < 3; ++k) map.addObservation(k, m);
+        }
+        std::vector<int32_t> localKFs, refKFs, localMPs;
+        map.updateLocalGraph(2, localKFs, refKFs, localMPs);
+        if (localKFs.size() != 3 || !refKFs.empty() || localMPs.size() != 9) return 1;
+
+        LocalGraph graph(Config::Kcam, Config::bTc, Config::TH_HUBER);
+        const float fx = Config::Kcam.at<float>(0, 0), cx = Config::Kcam.at<float>(0, 2), cy = Config::Kcam.at<float>(1, 2);
+        for (int k = 0; k < 3; ++k) {
+            cv::Mat Tcw = cv::Mat::eye(4);
+            const float Rcb[9] = {0, -1, 0, 0, 0, -1, 1, 0, 0};
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Tcw.at<float>(r, c) = Rcb[3 * r + c];
+            graph.addLocalKF(k + 1, Se2f{500.f * k + (k == 2 ? 20.f : 0.f), 0.f, 0.f}, Tcw);   // the last one starts 20 mm off
+        }
+        for (int k = 0; k < 2; ++k) {
+            PreSE2 pre;
+            resetPreSE2(pre);
+            pre.meas[0] = 500;
+            pre.cov[0] = pre.cov[4] = 100; pre.cov[8] = 1e-4;
+            graph.setOdometry(k, k + 1, pre);
+        }
+        for (int m = 0; m < 9; ++m) {
+            const float X = 4000.f + 300.f * (m % 3), Y = -600.f + 600.f * (m / 3), Z = 200.f + 100.f * (m % 4);
+            graph.addMapPoint(X, Y, Z);
+            for (int k = 0; k < 3; ++k) {
+                // camera at the body origin looking along +x (bTc rotation of the test Config, zero lever arm is not assumed:
+                // the measurement is generated with the same Config::bTc the graph evaluates)
+                const float bx = X - 500.f * k, by = Y, bz = Z;
+                const float tx = Config::bTc.at<float>(0, 3), ty = Config::bTc.at<float>(1, 3), tz = Config::bTc.at<float>(2, 3);
+                float pc[3];
+                for (int r = 0; r < 3; ++r)
+                    pc[r] = Config::bTc.at<float>(0, r) * (bx - tx) + Config::bTc.at<float>(1, r) * (by - ty) + Config::bTc.at<float>(2, r) * (bz - tz);
+                graph.addObservation(k, fx * pc[0] / pc[2] + cx, fx * pc[1] / pc[2] + cy, pc[0], pc[1], pc[2], 1.f);
+            }
+        }
+        SlamOptimizer optimizer;
+        initOptimizer(optimizer);
+        graph.load(optimizer);
+        optimizer.initializeOptimization(0);
+        optimizer.optimize(Config::LOCAL_ITER);
+        SE2 last = estimateVertexSE2(optimizer, 2);
+        Vector3D mp0 = estimateVertexSBAXYZ(optimizer, graph.vertexIdMP(0));
+        std::printf("loadLocalGraph lines: KF3 x = %.3f (started at 1020, truth 1000), MP0 x = %.2f\n", last.x, mp0(0));
+        if (!(std::fabs(last.x - 1000.0) < 2.0)) return 1;
+    }
     std::printf("reference call lines ran\n");
     return 0;
 }
