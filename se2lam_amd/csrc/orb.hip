@@ -62,6 +62,10 @@ struct Geom {
     float scale[kMaxLevels];             // mvScaleFactor
     float patch[kMaxLevels];             // (float)(int)(PATCH_SIZE * mvScaleFactor[level])
     int tile_base[kMaxLevels + 1];       // prefix sums of work tiles per level (set per kernel family)
+    // candidate lists written by the score kernel, one per list tile (lst_tw x lst_th pixels of the scan area; a strip of
+    // k_fast_score or a tile of k_fast_score_sparse): list (column tc, row tr) of level l = lst_base[l] + tr * tiles_x + tc
+    int lst_tw, lst_th, lst_cap;
+    int lst_base[kMaxLevels + 1];
     int cell_cap;                        // entries kept per cell in the global candidate lists
     int umax[16];
     int nfeatures;
@@ -211,14 +215,26 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
 // ---------------------------------------------------------------------------------------------
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-// Two pixels at once in packed int16 lanes (v_pk_min_i16 / v_pk_max_i16).  With p[k] the 16 ring pixels and v the
-// centre,  min_arc(v - p) = v - max_arc(p)  and  min_arc(p - v) = min_arc(p) - v,  so the extrema are taken on the raw
-// ring values and only two subtractions remain:   S = max(0, v - min_k max9[k], max_k min9[k] - v).
+// Two pixels at once in packed 16-bit lanes.  With p[k] the 16 ring pixels and v the centre,
+// min_arc(v - p) = v - max_arc(p)  and  min_arc(p - v) = min_arc(p) - v,  so the extrema are taken on the raw ring values
+// and only two subtractions remain:   S = max(0, v - min_k max9[k], max_k min9[k] - v).
 // Every arc of 9 is an arc of 8 plus one end point, and an arc of 8 starting at an odd ring position j serves both the
 // arc of 9 that starts at j - 1 and the one that starts at j:
-//     m8[j] = min(p[j .. j+7])   (j odd, by doubling: 8 + 8 + 8 operations),
-//     max over the two arcs of their minimum = min(m8[j], max(p[j-1], p[j+8]))
-// - 47 packed operations per extremum instead of 64 (59 with prefix / suffix extrema of the ring halves).
+//     m8[j] = min(p[j .. j+7]) = min(a4[j], a4[j+4]),  a4 = minima of 4 consecutive pixels (by doubling: 8 + 8 operations),
+//     max over the two arcs of their minimum = min(m8[j], max(p[j-1], p[j+8])) = min3(a4[j], a4[j+4], max(p[j-1], p[j+8]))
+// The three-input steps are gfx950's v_pk_minimum3_f16 / v_pk_maximum3_f16 (full rate, tools/pkminmax_probe.hip): pixel
+// values 0..255 held in 16-bit lanes are positive f16 denormals, whose order is the integer order of their bit patterns,
+// and minimum / maximum return one operand unchanged (f16 denormals are not flushed: .amdhsa_float_denorm_mode_16_64 3,
+// the code object default) - so they ARE three-input u16 extrema.  36 packed operations per extremum instead of 47.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ short2v min3_pk(short2v a, short2v b, short2v c) {
+    return __builtin_bit_cast(short2v, __builtin_elementwise_minimum(
+        __builtin_elementwise_minimum(__builtin_bit_cast(half2v, a), __builtin_bit_cast(half2v, b)), __builtin_bit_cast(half2v, c)));
+}
+__device__ __forceinline__ short2v max3_pk(short2v a, short2v b, short2v c) {
+    return __builtin_bit_cast(short2v, __builtin_elementwise_maximum(
+        __builtin_elementwise_maximum(__builtin_bit_cast(half2v, a), __builtin_bit_cast(half2v, b)), __builtin_bit_cast(half2v, c)));
+}
 __device__ __forceinline__ short2v fast_score_pk(const short2v p[16], short2v v) {
     short2v a2[8], A2[8], a4[8], A4[8];   // lower case: minima, upper case: maxima; index i <-> odd ring position 2 i + 1
 #pragma unroll
@@ -231,17 +247,15 @@ __device__ __forceinline__ short2v fast_score_pk(const short2v p[16], short2v v)
         a4[i] = __builtin_elementwise_min(a2[i], a2[(i + 1) & 7]);
         A4[i] = __builtin_elementwise_max(A2[i], A2[(i + 1) & 7]);
     }
-    short2v bmn, bmx;                     // max over the arcs of their minimum / min over the arcs of their maximum
+    short2v lo[8], hi[8];                 // per odd position: max over its two arcs of their minimum / min of their maximum
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = 2 * i + 1;
-        const short2v m8 = __builtin_elementwise_min(a4[i], a4[(i + 2) & 7]);   // p[j .. j+7]
-        const short2v M8 = __builtin_elementwise_max(A4[i], A4[(i + 2) & 7]);
-        const short2v lo = __builtin_elementwise_min(m8, __builtin_elementwise_max(p[(j - 1) & 15], p[(j + 8) & 15]));
-        const short2v hi = __builtin_elementwise_max(M8, __builtin_elementwise_min(p[(j - 1) & 15], p[(j + 8) & 15]));
-        bmn = i == 0 ? lo : __builtin_elementwise_max(bmn, lo);
-        bmx = i == 0 ? hi : __builtin_elementwise_min(bmx, hi);
+        lo[i] = min3_pk(a4[i], a4[(i + 2) & 7], __builtin_elementwise_max(p[(j - 1) & 15], p[(j + 8) & 15]));
+        hi[i] = max3_pk(A4[i], A4[(i + 2) & 7], __builtin_elementwise_min(p[(j - 1) & 15], p[(j + 8) & 15]));
     }
+    const short2v bmn = __builtin_elementwise_max(max3_pk(lo[0], lo[1], lo[2]), max3_pk(max3_pk(lo[3], lo[4], lo[5]), lo[6], lo[7]));
+    const short2v bmx = __builtin_elementwise_min(min3_pk(hi[0], hi[1], hi[2]), min3_pk(min3_pk(hi[3], hi[4], hi[5]), hi[6], hi[7]));
     const short2v zero = {0, 0};
     return __builtin_elementwise_max(zero, __builtin_elementwise_max(v - bmx, bmn - v));
 }
@@ -261,9 +275,13 @@ __device__ __forceinline__ int win_byte(uint32_t w0, uint32_t w1, uint32_t w2, i
 // which the first and last are halo (their scores feed the neighbours' non-max suppression, they write nothing), and
 // each strip computes one extra row above and below for the same reason (kScoreRows + 2 = 21 = 3 x 7 iterations).
 //
-// The kernel writes S' = S where S > 7 and S is a strict maximum over the 8-neighbours that lie in the SAME CELL
+// The kernel computes S' = S where S > 7 and S is a strict maximum over the 8-neighbours that lie in the SAME CELL
 // (cv::FAST's non-max suppression inside one FAST call, ORBextractor.cpp:616-623; cells of level l tile the scan area
-// [16, w-16) x [16, h-16) in steps of cellW x cellH), else 0.  k_cell_detect then only collects the non-zero bytes.
+// [16, w-16) x [16, h-16) in steps of cellW x cellH), else 0 - and keeps only the non-zero results: every wave appends
+// the 4-pixel groups that hold a survivor to the candidate list of its strip, {(y << 12) | x of the group, its four S'
+// bytes}, at a slot from a wave ballot (no atomics, no score plane: a strip writes some hundred bytes instead of 4.7 KB
+// and k_cell_detect reads those instead of scanning the plane).  A strip has 62 x 19 groups, which is the capacity of
+// its list: it cannot overflow.
 constexpr int kScoreRows = 19;
 constexpr int kScoreGroups = 62;  // useful column groups per wave
 
@@ -303,7 +321,10 @@ __device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t lef
     return (unsigned long long)(left >> 24) | ((unsigned long long)own << 8) | ((unsigned long long)(right & 0xffu) << 40);
 }
 
-__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score) {
+constexpr int kStripCap = kScoreGroups * kScoreRows;   // 4-pixel groups of one strip
+
+__global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint2* __restrict__ lst_ent,
+                                                     int* __restrict__ lst_cnt) {
     SE2_FRAME_GRID(f, bx);
     int l = 0;
     while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
@@ -317,7 +338,11 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     if (y0 >= H - kEdge) return;  // wave-uniform
     const bool xin = x0 >= kEdge && x0 < W - kEdge;            // this lane's group starts inside the scan area
     const uint8_t* base = pyr + pix(g, f, l, 0, 0);
-    uint8_t* sbase = score + pix(g, f, l, 0, 0);
+    // candidate list of this strip
+    const size_t lst = (size_t)f * g.lst_base[g.nlevels] + g.lst_base[l] +
+                       ((t / tiles_x) * 4 + (threadIdx.x >> 6)) * tiles_x + (t % tiles_x);
+    uint2* ent = lst_ent + lst * kStripCap;
+    int nent = 0;                                              // wave-uniform
     const int xc = min(max(x0, kEdge), W - kEdge - 1) & ~3;    // clamped (aligned) load position for halo lanes outside
     uint32_t E[7][9];
     const int ymax = H + kEdge - 1;   // last row of the bordered plane (strips at the bottom clamp their look-ahead)
@@ -373,6 +398,7 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         const uint32_t H3A = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hcA, __builtin_bit_cast(short2v, cA)));
         const uint32_t H3B = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(hcB, __builtin_bit_cast(short2v, cB)));
         const int yo = y - 1;  // row whose suppression can now be decided
+        uint32_t o4 = 0;   // the four S' bytes of this thread's group in row yo
         if (yo >= y0 && yo < yend && lane >= 1 && lane <= kScoreGroups && nvalid > 0) {
             const uint32_t tT = (ymod == 0) ? 0u : 0xffffffffu;                                            // row above in the cell?
             const uint32_t tB = ((ymod == cellH - 1) || yo == H - kEdge - 1) ? 0u : 0xffffffffu;          // row below?
@@ -384,8 +410,12 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
                                                          __builtin_bit_cast(short2v, H3B & tB));
             const uint32_t oA = __builtin_bit_cast(uint32_t, keep_greater(__builtin_bit_cast(short2v, cpA), mA));
             const uint32_t oB = __builtin_bit_cast(uint32_t, keep_greater(__builtin_bit_cast(short2v, cpB), mB));
-            *(uint32_t*)(sbase + (size_t)yo * stride + x0) = __builtin_amdgcn_perm(oB, oA, 0x06040200u);
+            o4 = __builtin_amdgcn_perm(oB, oA, 0x06040200u);
         }
+        const unsigned long long hit = __ballot(o4 != 0);
+        if (o4 != 0) ent[nent + __builtin_amdgcn_mbcnt_hi((uint32_t)(hit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hit, 0))] =
+            make_uint2(((uint32_t)yo << 12) | (uint32_t)x0, o4);
+        nent += __popcll(hit);
         H3ppA = H3pA; H3ppB = H3pB;
         H3pA = H3A; H3pB = H3B; HcpA = HcA; HcpB = HcB; cpA = cA; cpB = cB;
         ymod = (ymod + 1 == cellH) ? 0 : ymod + 1;
@@ -399,6 +429,7 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         step(std::integral_constant<int, 5>{}, y + 5);
         step(std::integral_constant<int, 6>{}, y + 6);
     }
+    if (lane == 0) lst_cnt[lst] = nent;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -411,8 +442,8 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
 //      are appended to a candidate list in LDS
 //   2  the full FAST-9 score for the candidates only, two per lane in the packed arithmetic of fast_score_pk, ring
 //      bytes gathered from the LDS tile; scores <= 7 dropped; written into a sparse LDS score tile
-//   3  in-cell non-max suppression per surviving candidate against its 8 neighbours in that tile (raw scores, as cv::FAST)
-//   4  the tile is written out as whole dwords
+//   3  in-cell non-max suppression per surviving candidate against its 8 neighbours in that tile (raw scores, as cv::FAST);
+//      survivors go to the candidate list of the tile, in k_fast_score's entry format with one pixel per entry
 // Dense corners only cost time, never correctness: the candidate list holds every pixel of the tile if need be.
 // On the benchmark texture (4000 overlapping rectangles: 15 % of the pixels pass the compass test, 6 % have S > 7) this
 // kernel takes 737 us per 256 frames against 631 us for k_fast_score, which is therefore the default; the two meet at
@@ -426,6 +457,8 @@ constexpr int kFsLH = kFsTH + 8;           //                 rows    y0-4 .. y0
 constexpr int kFsSW = kFsTW + 8;           // score tile: columns x0-4 .. x0+TW+4 (whole 4-pixel groups), rows y0-1 .. y0+TH
 constexpr int kFsSH = kFsTH + 2;
 constexpr int kFsMaxCand = kFsSW * kFsSH;
+constexpr int kFsListCap = 2048;           // survivors one tile can list (in-cell maxima are never adjacent: <= ~1/4 of the
+                                           // 4096 pixels plus cell-boundary effects; more raises the overflow flag)
 
 // candidate bits of a pixel pair: bit 15 / bit 31 set where two adjacent compass points are both >= v + 8 or <= v - 8
 __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e, short2v s, short2v w) {
@@ -442,13 +475,13 @@ __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e
     return ~(__builtin_bit_cast(uint32_t, a) & __builtin_bit_cast(uint32_t, b)) & 0x80008000u;
 }
 
-__global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ score,
-                                                           int* __restrict__ cand_count) {
+__global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t* __restrict__ pyr, uint2* __restrict__ lst_ent,
+                                                           int* __restrict__ lst_cnt, int* __restrict__ cand_count,
+                                                           int* __restrict__ overflow) {
     __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
     __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
-    __shared__ uint32_t s_out[(kFsTW / 4) * kFsTH];
     __shared__ uint16_t s_cand[kFsMaxCand];
-    __shared__ int s_n;
+    __shared__ int s_n, s_nout;
     SE2_FRAME_GRID(f, tlin);
     int l = 0;
     while (l + 1 < g.nlevels && tlin >= g.tile_base[l + 1]) ++l;
@@ -458,8 +491,9 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
     const int x0 = kEdge + (t % tiles_x) * kFsTW, y0 = kEdge + (t / tiles_x) * kFsTH;
     const int tid = threadIdx.x;
     const uint8_t* plane = pyr + (size_t)f * g.frame_bytes + g.off[l];   // bordered plane: pixel (x, y) at (y+16)*stride + x+16
-    uint8_t* sbase = score + pix(g, f, l, 0, 0);
-    constexpr int LWd = kFsLW / 4, SWd = kFsSW / 4, TWd = kFsTW / 4;
+    const size_t lst = (size_t)f * g.lst_base[g.nlevels] + g.lst_base[l] + t;
+    uint2* ent = lst_ent + lst * kFsListCap;
+    constexpr int LWd = kFsLW / 4, SWd = kFsSW / 4;
     // 0. stage the image tile (rows / columns outside the bordered plane are clamped: they only feed pixels that are
     //    not scored), clear the sparse tiles
     const int last_row = H + 2 * kEdge - 1, last_dw = stride / 4 - 1;
@@ -470,8 +504,7 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
         s_img[i] = *(const uint32_t*)(plane + (size_t)by * stride + 4 * bx);
     }
     for (int i = tid; i < SWd * kFsSH; i += 256) s_sc[i] = 0;
-    for (int i = tid; i < TWd * kFsTH; i += 256) s_out[i] = 0;
-    if (tid == 0) s_n = 0;
+    if (tid == 0) { s_n = 0; s_nout = 0; }
     __syncthreads();
     // 1. compass test.  Thread = (column group gx = tid & 31, row phase tid >> 5): the 128 tile columns, rows -1 .. TH.
     const int xlo = max(kEdge, x0 - 1), xhi = min(W - kEdge, x0 + kFsTW + 1);   // columns that need a score
@@ -550,7 +583,6 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
     // 3. non-max suppression inside the cell (cv::FAST compares raw scores of the neighbours of one FAST call = one cell)
     const int cellW = g.cellW[l], cellH = g.cellH[l];
     const int xr0 = (x0 - kEdge) % cellW, yr0 = (y0 - kEdge) % cellH;    // workgroup-uniform
-    uint8_t* out8 = (uint8_t*)s_out;
     for (int b = tid; b < n; b += 256) {
         const int k = s_cand[b];
         const int sy = k >> 8, sx = k & 255;
@@ -577,15 +609,15 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
             if (L) m = max(m, (int)sc8[i + kFsSW - 1]);
             if (R) m = max(m, (int)sc8[i + kFsSW + 1]);
         }
-        if (c > m) out8[ly * kFsTW + lx] = (uint8_t)c;
+        if (c > m && x0 + lx < W - kEdge && y0 + ly < H - kEdge) {
+            const int slot = atomicAdd(&s_nout, 1);
+            if (slot < kFsListCap) ent[slot] = make_uint2(((uint32_t)(y0 + ly) << 12) | (uint32_t)(x0 + lx), (uint32_t)c);
+        }
     }
     __syncthreads();
-    // 4. write the tile
-    for (int i = tid; i < TWd * kFsTH; i += 256) {
-        const int ly = i / TWd, gx = i - ly * TWd;
-        const int x = x0 + 4 * gx, y = y0 + ly;
-        if (y >= H - kEdge || x >= W - kEdge) continue;
-        *(uint32_t*)(sbase + (size_t)y * stride + x) = s_out[i];
+    if (tid == 0) {
+        if (s_nout > kFsListCap) atomicOr(overflow, 1);
+        lst_cnt[lst] = min(s_nout, kFsListCap);
     }
 }
 
@@ -619,14 +651,34 @@ __device__ __forceinline__ float harris_response(const uint8_t* __restrict__ lvl
     return ((float)a * b - (float)c * c - 0.04f * ((float)a + b) * ((float)a + b)) * scale_sq_sq;
 }
 
+// se2gpu_orb_debug_score: the S' plane of one level of one frame, rebuilt from the candidate lists (plane zeroed before)
+__global__ __launch_bounds__(256) void k_scatter_lists(Geom g, int f, int l, const uint2* __restrict__ lst_ent,
+                                                        const int* __restrict__ lst_cnt, uint8_t* __restrict__ plane) {
+    const int id = g.lst_base[l] + (int)blockIdx.x;
+    if (id >= g.lst_base[l + 1]) return;
+    const size_t lst = (size_t)f * g.lst_base[g.nlevels] + id;
+    const int n = lst_cnt[lst];
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const uint2 en = lst_ent[lst * g.lst_cap + e];
+        const int y = (int)(en.x >> 12), x0 = (int)(en.x & 0xfffu);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t sc = (en.y >> (8 * q)) & 0xffu;
+            if (sc) plane[(size_t)y * g.w[l] + x0 + q] = (uint8_t)sc;
+        }
+    }
+}
+
+constexpr int kMaxListsPerCell = 64;
 template <bool HARRIS>
-__global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __restrict__ score,
+__global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __restrict__ lst_ent, const int* __restrict__ lst_cnt,
                                                       const uint8_t* __restrict__ pyr,
                                                       uint32_t* __restrict__ cell_keys, float* __restrict__ cell_resp,
                                                       int* __restrict__ cell_total, int* __restrict__ overflow) {
     __shared__ uint32_t keys[kSortCap];
     __shared__ unsigned long long keys64[HARRIS ? kSortCap : 1];   // (~ordered(response) << 32) | (y << 12) | x
-    __shared__ int s_n, s_n20;
+    __shared__ int s_nw, s_n20;   // candidates with 7 < S <= fast_th (stored from the back of keys[]) / with S > fast_th (front)
+    __shared__ int s_off[kMaxListsPerCell + 1];                    // exclusive prefix of the entry counts of the cell's lists
+    __shared__ unsigned s_lst[kMaxListsPerCell];
     SE2_FRAME_GRID(f, cell);
     int l = 0;
     while (l + 1 < g.nlevels && cell >= g.cell_base[l + 1]) ++l;
@@ -634,59 +686,89 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
     const int xa = kEdge + cj * g.cellW[l], ya = kEdge + ci * g.cellH[l];
     const int xb = (cj == g.gcols[l] - 1) ? g.w[l] - kEdge : xa + g.cellW[l];
     const int yb = (ci == g.grows[l] - 1) ? g.h[l] - kEdge : ya + g.cellH[l];
-    if (threadIdx.x == 0) { s_n = 0; s_n20 = 0; }
-    __syncthreads();
+    if (threadIdx.x == 0) { s_nw = 0; s_n20 = 0; }
     const int cw = xb - xa, ch = yb - ya;
     const int stride = g.stride[l];
-    const uint8_t* base = score + pix(g, f, l, 0, 0);
-    if (cw > 0 && ch > 0) {
-        // scan aligned dwords (4 score bytes); S <= 7 everywhere in a dword is the common case and exits at once
-        const int xs = xa & ~3;
-        const int cw4 = (xb - xs + 3) >> 2;
-        // four dwords per thread and round are in flight before any is examined (the appends below are rare, but their
-        // control flow would otherwise serialise one global-load latency per dword)
-        const int ndw = cw4 * ch;
-        for (int base4 = threadIdx.x; base4 < ndw; base4 += 4 * 256) {
-            uint32_t wv[4];
-            int xv[4], yv[4];
+    // the candidate lists whose tiles meet the cell: columns tc0..tc1 x rows tr0..tr1 of the level's list grid
+    const int ltx = (g.w[l] - 2 * kEdge + g.lst_tw - 1) / g.lst_tw;
+    const int tc0 = (xa - kEdge) / g.lst_tw, tc1 = (xb - 1 - kEdge) / g.lst_tw;
+    const int tr0 = (ya - kEdge) / g.lst_th, tr1 = (yb - 1 - kEdge) / g.lst_th;
+    const int ntc = tc1 - tc0 + 1;
+    const int nl = (cw > 0 && ch > 0) ? min(ntc * (tr1 - tr0 + 1), kMaxListsPerCell) : 0;   // orb_configure checks the bound
+    if ((int)threadIdx.x < 64) {   // wave 0: counts -> exclusive prefix
+        const int k = threadIdx.x;
+        int c = 0;
+        if (k < nl) {
+            const unsigned id = (unsigned)(g.lst_base[l] + (tr0 + k / ntc) * ltx + tc0 + k % ntc);
+            s_lst[k] = id;
+            c = lst_cnt[(size_t)f * g.lst_base[g.nlevels] + id];
+        }
+        int incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (k >= d) incl += v;
+        }
+        s_off[k + 1] = incl;
+        if (k == 0) s_off[0] = 0;
+    }
+    __syncthreads();
+    {
+        const int total = s_off[nl];
+        const uint2* ebase = lst_ent + (size_t)f * g.lst_base[g.nlevels] * g.lst_cap;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            int k = 0;
+            while (s_off[k + 1] <= e) ++k;
+            const uint2 en = ebase[(size_t)s_lst[k] * g.lst_cap + (e - s_off[k])];
+            const int y = (int)(en.x >> 12), x0 = (int)(en.x & 0xfffu);
+            if (y < ya || y >= yb) continue;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = base4 + u * 256;
-                const int ic = min(idx, ndw - 1);
-                xv[u] = xs + 4 * (ic % cw4);
-                yv[u] = ya + ic / cw4;
-                const uint32_t wd = *(const uint32_t*)(base + (size_t)yv[u] * stride + xv[u]);
-                wv[u] = idx < ndw ? wd : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t word = wv[u];
-                if (word == 0) continue;   // k_fast_score already applied S > 7 and the in-cell non-max suppression
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s = (int)((word >> (8 * q)) & 0xffu);
-                    const int x = xv[u] + q, y = yv[u];
-                    if (s == 0 || x < xa || x >= xb) continue;
-                    const int slot = atomicAdd(&s_n, 1);
-                    if (s > g.fast_th) atomicAdd(&s_n20, 1);
-                    if (slot < kSortCap) keys[slot] = ((uint32_t)(255 - s) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+            for (int q = 0; q < 4; ++q) {
+                const int sc = (int)((en.y >> (8 * q)) & 0xffu);
+                const int x = x0 + q;
+                if (sc == 0 || x < xa || x >= xb) continue;
+                const uint32_t key = ((uint32_t)(255 - sc) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
+                if (sc > g.fast_th) {
+                    const int slot = atomicAdd(&s_n20, 1);
+                    if (slot < kSortCap) keys[slot] = key;
+                } else {
+                    const int slot = atomicAdd(&s_nw, 1);
+                    if (slot < kSortCap) keys[kSortCap - 1 - slot] = key;
                 }
             }
         }
     }
     __syncthreads();
-    int n = s_n;
-    if (n > kSortCap) {
+    // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 keypoints, FAST(7).  The thr-20 corners
+    // sort before all others (key = 255 - S first), so when they are taken the others never need sorting at all.
+    const int n20 = s_n20, nw = s_nw;
+    if (n20 + nw > kSortCap) {   // front and back ran into each other
         if (threadIdx.x == 0) atomicOr(overflow, 1);
-        n = kSortCap;
+        if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
+        return;
+    }
+    int n = n20;
+    if (n20 <= 3) {
+        uint32_t mv[kSortCap / 256];   // source and destination ranges may overlap: through registers
+#pragma unroll
+        for (int u = 0; u < kSortCap / 256; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            mv[u] = i < nw ? keys[kSortCap - 1 - i] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kSortCap / 256; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            if (i < nw) keys[n20 + i] = mv[u];
+        }
+        __syncthreads();
+        n = n20 + nw;
     }
     // FAST_SCORE with a cell of ordinary size (~100 candidates): rank sort.  A key's rank = the number of smaller keys
     // (keys are unique: they contain the position); every thread reads the same keys[j] (LDS broadcast), no barriers -
     // the bitonic network below costs ~30 barrier-separated stages for the same job.
     constexpr int kRankMax = 768;
     if (!HARRIS && n <= kRankMax) {
-        const int n20r = s_n20;
-        const int totalr = (n20r > 3) ? n20r : n;
+        const int totalr = n;
         const int keepr = min(totalr, g.cell_cap);
         uint32_t* outk = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
         float* outf = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
@@ -718,10 +800,7 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint8_t* __re
             }
             __syncthreads();
         }
-    // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 keypoints, FAST(7).
-    // The thr-20 corners are exactly the sorted prefix with S > fast_th.
-    const int n20 = s_n20;
-    const int total = (n20 > 3) ? n20 : n;
+    const int total = n;
     const int keep = min(total, g.cell_cap);
     uint32_t* out = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
     float* outr = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
@@ -1193,7 +1272,10 @@ struct se2gpu_orb {
     Geom g{};
     int max_batch = 1;
     int last_batch = 0;
-    DevBuf<uint8_t> pyr, blur, score, img;
+    DevBuf<uint8_t> pyr, blur, score, img;   // score: only se2gpu_orb_debug_score materialises the plane
+    DevBuf<uint2> lst_ent;                   // candidate lists of the score kernel (see Geom::lst_*)
+    DevBuf<int> lst_cnt;
+    int dense_lst_base[kMaxLevels + 1], sparse_lst_base[kMaxLevels + 1];
     DevBuf<uint32_t> cell_keys;
     DevBuf<int> cell_total, counts, overflow;
     DevBuf<int4> kp_list, tabs;
@@ -1205,6 +1287,7 @@ struct se2gpu_orb {
     DevBuf<uint8_t> out_d;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
     int score_tiles = 0, blur_tiles = 0;
+    Geom last_lists{};                       // geometry (with the list layout) of the last score launch
     int score_tile_base[kMaxLevels + 1], sparse_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
     // Which FAST kernel: SE2GPU_ORB_SCORE = dense | sparse | auto (default).  In auto mode the candidate kernel counts the
     // pixels that pass its compass test; it is used while fewer than kSparseBelow of the scanned pixels do, and every
@@ -1284,6 +1367,15 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         if (l == 0) h->scan_pixels = 0;
         h->scan_pixels += (long long)std::max(sw, 0) * std::max(sh, 0);
         h->blur_tile_base[l + 1] = h->blur_tile_base[l] + ((g.w[l] + 255) / 256) * ((g.h[l] + 4 * kBlurRows - 1) / (4 * kBlurRows));
+        // candidate lists: one per strip of k_fast_score (62 groups x 19 rows) / per tile of k_fast_score_sparse
+        if (l == 0) h->dense_lst_base[0] = h->sparse_lst_base[0] = 0;
+        h->dense_lst_base[l + 1] = h->dense_lst_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + kScoreRows - 1) / kScoreRows);
+        h->sparse_lst_base[l + 1] = h->sparse_tile_base[l + 1];
+        // lists one cell can meet (k_cell_detect gathers them through a 64-entry table)
+        const int per_cell = std::max(((g.cellW[l] + 4 * kScoreGroups - 2) / (4 * kScoreGroups) + 1) * ((g.cellH[l] + kScoreRows - 2) / kScoreRows + 1),
+                                      ((g.cellW[l] + kFsTW - 2) / kFsTW + 1) * ((g.cellH[l] + kFsTH - 2) / kFsTH + 1));
+        SE2_REQUIRE(per_cell <= kMaxListsPerCell, SE2GPU_ERR_INVALID, "level %d: a %dx%d cell meets %d candidate lists (max %d)", l,
+                    g.cellW[l], g.cellH[l], per_cell, kMaxListsPerCell);
     }
     // resize tables
     std::vector<int4> tabs;
@@ -1346,10 +1438,8 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     const size_t B = (size_t)h->max_batch;
     SE2_CHECK(h->pyr.reserve(B * g.frame_bytes));
     SE2_CHECK(h->blur.reserve(B * g.frame_bytes));
-    const bool fresh_score = h->score.cap < B * g.frame_bytes;
-    SE2_CHECK(h->score.reserve(B * g.frame_bytes));
-    (void)fresh_score;
-    SE2_HIP(hipMemsetAsync(h->score.p, 0, B * g.frame_bytes, h->stream));
+    SE2_CHECK(h->lst_cnt.reserve(B * (size_t)std::max(h->dense_lst_base[L], h->sparse_lst_base[L])));
+    SE2_CHECK(h->lst_ent.reserve(B * std::max((size_t)h->dense_lst_base[L] * kStripCap, (size_t)h->sparse_lst_base[L] * kFsListCap)));
     SE2_CHECK(h->cell_keys.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
     SE2_CHECK(h->cell_total.reserve(B * g.cell_base[L]));
     SE2_CHECK(h->cell_resp.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
@@ -1415,9 +1505,10 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
             SE2_CHECK(h->h_fs_count.reserve((size_t)h->max_batch));
             SE2_HIP(hipMemsetAsync(h->fs_count.p, 0, (size_t)nframes * sizeof(int), st));
         }
-        for (int l = 0; l <= L; ++l) g.tile_base[l] = h->sparse_tile_base[l];
+        for (int l = 0; l <= L; ++l) { g.tile_base[l] = h->sparse_tile_base[l]; g.lst_base[l] = h->sparse_lst_base[l]; }
+        g.lst_tw = kFsTW; g.lst_th = kFsTH; g.lst_cap = kFsListCap;
         SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_sparse, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
-                   h->score.p, count ? h->fs_count.p : (int*)nullptr);
+                   h->lst_ent.p, h->lst_cnt.p, count ? h->fs_count.p : (int*)nullptr, h->overflow.p);
         if (count) {
             SE2_HIP(hipMemcpyAsync(h->h_fs_count.p, h->fs_count.p, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, st));
             SE2_HIP(hipEventRecord(h->ev_fs, st));
@@ -1425,16 +1516,18 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
             h->fs_frames = nframes;
         }
     } else {
-        for (int l = 0; l <= L; ++l) g.tile_base[l] = h->score_tile_base[l];
+        for (int l = 0; l <= L; ++l) { g.tile_base[l] = h->score_tile_base[l]; g.lst_base[l] = h->dense_lst_base[l]; }
+        g.lst_tw = 4 * kScoreGroups; g.lst_th = kScoreRows; g.lst_cap = kStripCap;
         SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
-                   h->score.p);
+                   h->lst_ent.p, h->lst_cnt.p);
     }
+    h->last_lists = g;
     if (g.harris)
         SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(F8, g.cell_base[L]), dim3(256), 0, g,
-                   h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
+                   h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
     else
         SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<false>, dim3(F8, g.cell_base[L]), dim3(256), 0, g,
-                   h->score.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
+                   h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
                h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 3) / 4), dim3(256), 0, g, h->pyr.p,
@@ -1631,9 +1724,14 @@ int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, si
                 "debug_score: frame/level out of range");
     const Geom& g = h->g;
     SE2_REQUIRE(out_cap >= (size_t)g.w[level] * g.h[level], SE2GPU_ERR_CAPACITY, "debug_score: buffer too small");
+    const Geom& gl = h->last_lists;
+    const size_t bytes = (size_t)g.w[level] * g.h[level];
+    SE2_CHECK(h->score.reserve(bytes));
+    SE2_HIP(hipMemsetAsync(h->score.p, 0, bytes, h->stream));
+    hipLaunchKernelGGL(k_scatter_lists, dim3(gl.lst_base[level + 1] - gl.lst_base[level]), dim3(256), 0, h->stream, gl, frame,
+                       level, h->lst_ent.p, h->lst_cnt.p, h->score.p);
+    SE2_HIP(hipMemcpyAsync(out, h->score.p, bytes, hipMemcpyDeviceToHost, h->stream));
     SE2_HIP(hipStreamSynchronize(h->stream));
-    const uint8_t* src = h->score.p + (size_t)frame * g.frame_bytes + g.off[level] + (size_t)kEdge * g.stride[level] + kEdge;
-    SE2_HIP(hipMemcpy2D(out, g.w[level], src, g.stride[level], g.w[level], g.h[level], hipMemcpyDeviceToHost));
     *rows = g.h[level];
     *cols = g.w[level];
     return SE2GPU_OK;
