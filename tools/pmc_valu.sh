@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 for C in VALUBusy LDSBankConflict; do
   mkdir -p $R/gpurun_out/pmc_$C
-  (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 --no-cpu-baseline > $R/gpurun_out/pmc_$C/stdout.log 2>&1) || true
+  (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 --no-cpu-baseline --ba-windows 0 > $R/gpurun_out/pmc_$C/stdout.log 2>&1) || true
 done
 python - "$R" "$TAG" <<'PY'
 import csv, glob, json, re, sys, collections
