@@ -1153,6 +1153,32 @@ __global__ __launch_bounds__(256) void k_chol_apply(const double* __restrict__ A
     if (lane == 0) x[r] = acc;
 }
 
+// The end of a trial without a kernel boundary (single GPU): k_update gets ONE extra workgroup, launched last, that does
+// what k_finalize does - oplus of the poses, odometry chi^2 at the trial poses, the pose part of computeScale() - while
+// the landmark workgroups run, then waits until their partials have all arrived (an agent-scope counter; it was
+// dispatched after every one of them, so the wait cannot deadlock), sums them in a fixed order and advances the
+// Levenberg-Marquardt controller.  k_finalize stays for the sharded (multi-GPU) runs, whose scalars go through an
+// all-reduce between the two steps.
+struct FinArgs {
+    int enabled, nblk, P, O, root, step, decide, notify;
+    const uint8_t* fixed;
+    const double* xp;
+    const double* bp;
+    const double* poses;      // "a" buffer (the controller's sel bit says which one holds the estimate)
+    double* poses_trial;      // "b" buffer
+    const int* o_i;
+    const int* o_j;
+    const double* o_meas;
+    const double* o_info;
+    double* out;              // {chi2_trial, scale, factorisation flag, 0}
+    volatile double* mail;
+    double seq;
+    BaCtl* ctl;
+    const volatile int* stop;
+    unsigned* counter;        // landmark workgroups that have published their partials (reset by the finisher)
+};
+__device__ void finish_trial(const FinArgs& fin, const double* part, double lambda);
+
 // ---------------------------------------------------------------------------------------------
 // k_update: per landmark group: back-substitute x_l = z - sum_e Y_e^T x_p[kf(e)], trial landmark = lw + x_l,
 // robust chi^2 of the landmark's edges at the trial state, and the landmark part of computeScale().
@@ -1166,7 +1192,24 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
                                                     const double* __restrict__ xp, const double* __restrict__ z,
                                                     const double* __restrict__ Y, const double* __restrict__ bl,
                                                     double* __restrict__ lms_trial, double* __restrict__ part,
-                                                    const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b) {
+                                                    const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                    FinArgs fin) {
+    if (fin.enabled && (int)blockIdx.x == fin.nblk) {
+        finish_trial(fin, part, lambda);
+        return;
+    }
+    // The kernel is a chain of dependent loads (controller / CSR bounds -> edge records -> pose gathers) around very
+    // little arithmetic, so everything that does not depend on the previous link is requested together: the CSR bounds
+    // beside the controller block, and for the first two edges of a lane (a landmark has 6 observations on average, a
+    // lane takes every 8th) ALL operands of both passes - Y_e and x_p for the back-substitution, the pose, measurement and
+    // information for the robust chi^2 - before the first use.  Lanes with more edges take the rest in the old two-pass form.
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    int beg = 0, end = 0;
+    if (l < L) {
+        beg = lm_ptr[l];
+        end = lm_ptr[l + 1];
+    }
     if (ctl) {   // (poses, lms) / lms_trial are the "a" / "b" buffers: the controller says which holds the estimate
         if (ctl->done) return;
         if (ctl->sel) {
@@ -1176,23 +1219,57 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
         lambda = ctl->lambda;
     }
     __shared__ double sm[2][kBlock / 64];
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int l = gid / kGroup, sub = gid % kGroup;
     double chi = 0, scale = 0;
     double x[3] = {0, 0, 0};
     const bool step = xp != nullptr;
-    int beg = 0, end = 0;
-    if (l < L) {
-        beg = lm_ptr[l];
-        end = lm_ptr[l + 1];
-        if (step) {
-            for (int e = beg + sub; e < end; e += kGroup) {
-                const int kf = e_kf[e];
-                const double* y = Y + (size_t)e * 9;
-                const double p0 = xp[3 * kf], p1 = xp[3 * kf + 1], p2 = xp[3 * kf + 2];
+    constexpr int KS = 2;
+    int ekf[KS];
+    bool ev[KS];
+    double ey[KS][9], ep[KS][3], epose[KS][3], euv[KS][2], ew[KS][3];
+    bool efix[KS];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) x[c] -= y[c] * p0 + y[3 + c] * p1 + y[6 + c] * p2;
+    for (int k = 0; k < KS; ++k) {
+        const int e = beg + sub + k * kGroup;
+        ev[k] = e < end;
+        const int ec = ev[k] ? e : max(end - 1, 0);   // (a landmark without edges loads edge 0 of the array: harmless)
+        const bool has = l < L && end > beg;
+        ekf[k] = has ? e_kf[ec] : 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ey[k][i] = (has && step) ? Y[(size_t)ec * 9 + i] : 0.0;
+        euv[k][0] = has ? e_uv[2 * (size_t)ec] : 0.0;
+        euv[k][1] = has ? e_uv[2 * (size_t)ec + 1] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ew[k][i] = has ? e_info[3 * (size_t)ec + i] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        const int kf = ekf[k];
+        epose[k][0] = poses[3 * kf]; epose[k][1] = poses[3 * kf + 1]; epose[k][2] = poses[3 * kf + 2];
+        efix[k] = fixed[kf] != 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ep[k][i] = step ? xp[3 * kf + i] : 0.0;
+    }
+    double lw0[3] = {0, 0, 0}, zz[3] = {0, 0, 0}, blv[3] = {0, 0, 0};
+    if (l < L) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lw0[c] = lms[(size_t)l * 3 + c];
+            if (step) { zz[c] = z[(size_t)l * 3 + c]; blv[c] = bl[(size_t)l * 3 + c]; }
+        }
+    }
+    if (l < L && step) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            if (ev[k]) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) x[c] -= ey[k][c] * ep[k][0] + ey[k][3 + c] * ep[k][1] + ey[k][6 + c] * ep[k][2];
             }
+        for (int e = beg + sub + KS * kGroup; e < end; e += kGroup) {
+            const int kf = e_kf[e];
+            const double* y = Y + (size_t)e * 9;
+            const double p0 = xp[3 * kf], p1 = xp[3 * kf + 1], p2 = xp[3 * kf + 2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) x[c] -= y[c] * p0 + y[3 + c] * p1 + y[6 + c] * p2;
         }
     }
 #pragma unroll
@@ -1201,30 +1278,38 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
         double lw[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if (step) x[c] += z[(size_t)l * 3 + c];
-            lw[c] = lms[(size_t)l * 3 + c] + x[c];
+            if (step) x[c] += zz[c];
+            lw[c] = lw0[c] + x[c];
         }
         if (sub == 0 && step) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 lms_trial[(size_t)l * 3 + c] = lw[c];
-                scale += x[c] * (lambda * x[c] + bl[(size_t)l * 3 + c]);
+                scale += x[c] * (lambda * x[c] + blv[c]);
             }
         }
-        for (int e = beg + sub; e < end; e += kGroup) {
-            const int kf = e_kf[e];
-            double px = poses[3 * kf], py = poses[3 * kf + 1], pth = poses[3 * kf + 2];
-            if (step && !fixed[kf]) {
-                px += xp[3 * kf];
-                py += xp[3 * kf + 1];
-                pth = normalize_theta(pth + xp[3 * kf + 2]);
+        auto edge_chi = [&](double px, double py, double pth, bool fx, const double* dp, double u, double v, double w0,
+                            double w1, double w2) {
+            if (step && !fx) {
+                px += dp[0];
+                py += dp[1];
+                pth = normalize_theta(pth + dp[2]);
             }
             double e0, e1;
-            se2xyz<false>(cam, px, py, pth, lw[0], lw[1], lw[2], e_uv[2 * e], e_uv[2 * e + 1], e0, e1, nullptr, nullptr);
-            const double w0 = e_info[3 * e], w1 = e_info[3 * e + 1], w2 = e_info[3 * e + 2];
+            se2xyz<false>(cam, px, py, pth, lw[0], lw[1], lw[2], u, v, e0, e1, nullptr, nullptr);
             double r0, r1;
             huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), cam.huber, r0, r1);
             chi += r0;
+        };
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            if (ev[k]) edge_chi(epose[k][0], epose[k][1], epose[k][2], efix[k], ep[k], euv[k][0], euv[k][1], ew[k][0], ew[k][1], ew[k][2]);
+        for (int e = beg + sub + KS * kGroup; e < end; e += kGroup) {
+            const int kf = e_kf[e];
+            double dp[3] = {0, 0, 0};
+            if (step) { dp[0] = xp[3 * kf]; dp[1] = xp[3 * kf + 1]; dp[2] = xp[3 * kf + 2]; }
+            edge_chi(poses[3 * kf], poses[3 * kf + 1], poses[3 * kf + 2], fixed[kf] != 0, dp, e_uv[2 * e], e_uv[2 * e + 1],
+                     e_info[3 * e], e_info[3 * e + 1], e_info[3 * e + 2]);
         }
     }
     chi = wave_sum(chi);
@@ -1235,8 +1320,14 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
     if (threadIdx.x == 0) {
         double c = 0, s = 0;
         for (int i = 0; i < kBlock / 64; ++i) { c += sm[0][i]; s += sm[1][i]; }
-        part[2 * blockIdx.x] = c;
-        part[2 * blockIdx.x + 1] = s;
+        if (fin.enabled) {   // write-through stores, landed before the counter moves (the finisher may sit behind another L2)
+            store_agent(part + 2 * blockIdx.x, d2_t{c, s});
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            part[2 * blockIdx.x] = c;
+            part[2 * blockIdx.x + 1] = s;
+        }
     }
 }
 
@@ -1247,12 +1338,11 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
 // state becomes the estimate (sel flips = discardTop); reject: lambda *= ni, ni *= 2 (pop); at most 10 trials per
 // iteration; Terminate when all 10 failed or rho == 0).  `stop` is the caller's force-stop flag, mirrored by the host
 // into mapped memory (SparseOptimizer::setForceStopFlag).
-__device__ inline void lm_advance(BaCtl* c, const double* sc, const volatile int* stop) {
+__device__ inline void lm_advance(BaCtl* c, const double* sc, bool stopped) {
     double tempChi = sc[0];
     const double scale_in = sc[1], fail = sc[2];
     if (fail >= 1e5) { c->error = 1; c->done = 1; return; }   // a dataflow spin of k_chol_tiles timed out
     if (fail > 0.0) tempChi = 1.7976931348623157e308;          // factorisation failed: the step is rejected
-    const bool stopped = stop && *stop;
     c->trials += 1;
     const int qmax = c->qmax + 1;
     c->qmax = qmax;
@@ -1299,6 +1389,129 @@ __device__ inline void post_ctl(const BaCtl* c, volatile double* mail, double se
     constexpr int kWords = (int)(sizeof(BaCtl) / 8);
     const double* src = reinterpret_cast<const double*>(c);
     for (int i = tid; i < kWords; i += nthr) mail[8 + i] = src[i];
+}
+
+// the finisher workgroup of k_update (kBlock threads): see FinArgs
+__device__ void finish_trial(const FinArgs& fin, const double* part, double lambda) {
+    __shared__ double fsm[2][kBlock / 64];
+    __shared__ double fsp[3 * 1024];  // trial poses staged for the odometry pass when P <= 1024
+    __shared__ int fpost;
+    BaCtl* ctl = fin.ctl;
+    const volatile double* cmail = fin.mail;
+    volatile double* mail = fin.mail;
+    (void)cmail;
+    const double* poses = fin.poses;
+    double* poses_trial = fin.poses_trial;
+    const bool step = fin.step != 0;
+    int stopped = 0;
+    double failflag = 0;
+    if (ctl) {
+        if (ctl->done) {   // the run is over: only answer a pending notification
+            if (fin.notify && mail) {
+                post_ctl(ctl, mail, fin.seq, threadIdx.x, blockDim.x);
+                __threadfence_system();
+                __syncthreads();
+                if (threadIdx.x == 0) mail[3] = fin.seq;
+            }
+            return;
+        }
+        if (ctl->sel) { const double* t = poses; poses = poses_trial; poses_trial = const_cast<double*>(t); }
+        lambda = ctl->lambda;
+    }
+    if (threadIdx.x == 0) {   // the two slow reads of the decision (mapped host memory; the solver's flag) start now
+        stopped = (fin.stop && *fin.stop) ? 1 : 0;
+        failflag = step ? fin.out[2] : 0.0;
+    }
+    double chi = 0, scale = 0;
+    for (int p = threadIdx.x; p < fin.P; p += blockDim.x) {
+        double x = poses[3 * p], y = poses[3 * p + 1], th = poses[3 * p + 2];
+        if (step && !fin.fixed[p]) {
+            const double d0 = fin.xp[3 * p], d1 = fin.xp[3 * p + 1], d2 = fin.xp[3 * p + 2];
+            x += d0; y += d1; th = normalize_theta(th + d2);
+            const double* bp = fin.bp;
+            if (fin.root) scale += d0 * (lambda * d0 + bp[3 * p]) + d1 * (lambda * d1 + bp[3 * p + 1]) + d2 * (lambda * d2 + bp[3 * p + 2]);
+            else scale += d0 * bp[3 * p] + d1 * bp[3 * p + 1] + d2 * bp[3 * p + 2];
+        }
+        if (step) { poses_trial[3 * p] = x; poses_trial[3 * p + 1] = y; poses_trial[3 * p + 2] = th; }
+        if (p < 1024) { fsp[3 * p] = x; fsp[3 * p + 1] = y; fsp[3 * p + 2] = th; }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < fin.O; k += blockDim.x) {
+        const int i = fin.o_i[k], j = fin.o_j[k];
+        double pi[3], pj[3];
+        for (int c = 0; c < 3; ++c) {
+            pi[c] = (i < 1024) ? fsp[3 * i + c] : (step ? poses_trial[3 * i + c] : poses[3 * i + c]);
+            pj[c] = (j < 1024) ? fsp[3 * j + c] : (step ? poses_trial[3 * j + c] : poses[3 * j + c]);
+        }
+        double e[3], A[9], B[9];
+        pre_se2(pi, pj, fin.o_meas + 3 * k, e, A, B);
+        const double* W = fin.o_info + 9 * k;
+        for (int r = 0; r < 3; ++r) chi += e[r] * (W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
+    }
+    // the landmark workgroups' partials
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(fin.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)fin.nblk) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wall_clock64() - t0 > 200000000ll) break;   // 2 s: cannot happen (in-order dispatch); never hang
+        }
+        __hip_atomic_store(fin.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int i0 = threadIdx.x; i0 < fin.nblk; i0 += 4 * blockDim.x) {   // four loads in flight per thread and round
+        d2_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load_agent(part + 2 * min(i0 + u * (int)blockDim.x, fin.nblk - 1));
+        // (the asm loads are invisible to the compiler's wait counts)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * (int)blockDim.x < fin.nblk) { chi += v[u].x; scale += v[u].y; }
+    }
+    chi = wave_sum(chi);
+    scale = wave_sum(scale);
+    if ((threadIdx.x & 63) == 0) {
+        fsm[0][threadIdx.x >> 6] = chi;
+        fsm[1][threadIdx.x >> 6] = scale;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {   // fixed order: deterministic
+            fsm[0][0] += fsm[0][w];
+            fsm[1][0] += fsm[1][w];
+        }
+        double* out = fin.out;
+            out[0] = fsm[0][0]; out[1] = fsm[1][0]; out[3] = 0;
+        if (!step) out[2] = 0;
+        fpost = 0;
+        if (ctl && fin.decide) {
+            if (!step) {   // evaluation of the starting state
+                ctl->current_chi = ctl->chi2_init = ctl->chi2_final = fsm[0][0];
+                if (stopped) { ctl->stopped = 1; ctl->done = 1; }
+                if (ctl->iters <= 0) ctl->done = 1;
+            } else {
+                const double sc[3] = {fsm[0][0], fsm[1][0], failflag};
+                lm_advance(ctl, sc, stopped != 0);
+            }
+            fpost = (ctl->done || fin.notify) && mail;
+                } else if (mail && !ctl) {  // synchronous callers (se2gpu_ba_chi2, the host controller): the three scalars
+            mail[0] = fsm[0][0];
+            mail[1] = fsm[1][0];
+            mail[2] = step ? failflag : 0.0;
+            __threadfence_system();
+            mail[3] = fin.seq;
+        }
+    }
+    if (ctl && fin.decide) {
+        __syncthreads();
+        if (fpost) {
+            __threadfence();
+            post_ctl(ctl, mail, fin.seq, threadIdx.x, blockDim.x);
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) mail[3] = fin.seq;
+        }
+    }
 }
 
 // k_finalize: single block.  Sums the k_update partials, applies oplus to the poses (VertexSE2::oplusImpl:
@@ -1386,7 +1599,7 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
                 if (ctl->iters <= 0) ctl->done = 1;
             } else {
                 const double sc[3] = {sm[0][0], sm[1][0], out[2]};
-                lm_advance(ctl, sc, stop);
+                lm_advance(ctl, sc, stop && *stop);
             }
             post_s = (ctl->done || notify) && mail;
         } else if (mail && !ctl) {  // synchronous callers (se2gpu_ba_chi2): the three scalars
@@ -1421,7 +1634,7 @@ __global__ void k_lm_decide(BaCtl* __restrict__ ctl, const double* __restrict__ 
                 if (stop && *stop) { ctl->stopped = 1; ctl->done = 1; }
                 if (ctl->iters <= 0) ctl->done = 1;
             } else {
-                lm_advance(ctl, sc, stop);
+                lm_advance(ctl, sc, stop && *stop);
             }
         }
         post_s = (ctl->done || notify) && mail;
@@ -1474,7 +1687,7 @@ __global__ void k_fill_slots(double* __restrict__ dst, const double* __restrict_
 // diagonal record Dg = {sym(Hpp_e - Y Hpl^T) (21), bp_e (6), Hpl z (6)} (33).
 // [3P g2o 20160424] VertexSE3Expmap, EdgeProjectXYZ2UV, EdgeSE3Expmap, SE3Quat - restated as in oracle/ba3_ref.cpp.
 // =============================================================================================
-constexpr int kD3 = 6, kGrpPerWG3 = 7;
+constexpr int kGrpPerWG3 = 7;
 struct Cam3 { double f, cx, cy, huber; };
 __device__ __host__ inline int sym6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }   // r <= c
 
@@ -2030,7 +2243,7 @@ __global__ void k3_finalize(int nparts, const double* __restrict__ part, int P, 
             if (ctl->iters <= 0) ctl->done = 1;
         } else {
             const double sc[3] = {sm[0][0], sm[1][0], out[2]};
-            lm_advance(ctl, sc, stop);
+            lm_advance(ctl, sc, stop && *stop);
         }
         post_s = (ctl->done || notify) && mail;
     }
@@ -2226,7 +2439,7 @@ __global__ void k4_finalize(int P, int nedge, const double* __restrict__ poses_a
             if (ctl->iters <= 0) ctl->done = 1;
         } else {
             const double sc[3] = {sm[0][0], sm[1][0], out[2]};
-            lm_advance(ctl, sc, stop);
+            lm_advance(ctl, sc, stop && *stop);
         }
         post_s = (ctl->done || notify) && mail;
     }
@@ -2440,6 +2653,7 @@ struct se2gpu_ba {
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
     DevBuf<int2> chol_tasks;      // k_chol_tiles: (tile row | isR << 16, block column), ordered by column
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
+    DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
     int chol_ntask = 0;
     unsigned chol_epoch = 0;
     DevBuf<long long> chol_trace; // SE2GPU_BA_CHOL_TRACE=1: per-task stamps of the last solve -> stderr (debug_solve)
@@ -3223,6 +3437,8 @@ int ba_upload_graph(se2gpu_ba* h) {
         SE2_HIP(hipMemcpyAsync(h->h_scal.p, h->plan_out.p, sizeof(int), hipMemcpyDeviceToHost, st));
         lap("plan kernels enqueued");
     }
+    SE2_CHECK(h->fin_counter.reserve(1));
+    SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
     SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
     SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
     h->chol_epoch = 0;
@@ -3410,15 +3626,25 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
     double* scal = h->red + (size_t)h->ld * h->ld;  // 4 trailing scalars of the fused buffer
     const bool use_mail = h->d_mail && !(h->allreduce && h->world > 1) && !h->comm;
     const double seq = (double)(++h->mail_seq);
-    SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
+    const dim3 ug = grid1((size_t)h->L * kGroup, kBlock);
+    if (use_mail) {   // single GPU: the trial ends inside k_update (FinArgs)
+        FinArgs fin{1, (int)ug.x, h->P, h->O, h->root, xp ? 1 : 0, 0, 0, h->fixed.p, xp, h->bp.p, h->poses, h->poses_t,
+                    h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, scal, h->d_mail, seq, (BaCtl*)nullptr,
+                    (const volatile int*)nullptr, h->fin_counter.p};
+        SE2_LAUNCH(h->prof, st, "k_update", k_update, dim3(ug.x + 1), dim3(kBlock), 0, h->cam, h->L, lambda, h->lm_ptr.p,
+                   h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p, h->Y.p, h->bl.p, h->lms_t,
+                   h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, fin);
+        SE2_HIP(hipGetLastError());
+        return ba_wait_mail(h, seq);
+    }
+    SE2_LAUNCH(h->prof, st, "k_update", k_update, ug, dim3(kBlock), 0, h->cam, h->L,
                lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
-               h->Y.p, h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr);
+               h->Y.p, h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, FinArgs{});
     SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
-               h->o_info.p, h->root, scal, use_mail ? h->d_mail : nullptr, seq, (BaCtl*)nullptr, xp ? 1 : 0, 0, 0,
+               h->o_info.p, h->root, scal, (volatile double*)nullptr, seq, (BaCtl*)nullptr, xp ? 1 : 0, 0, 0,
                (const volatile int*)nullptr);
     SE2_HIP(hipGetLastError());
-    if (use_mail) return ba_wait_mail(h, seq);
     SE2_CHECK(ba_allreduce(h, scal, 4));
     if (h->d_mail) {
         hipLaunchKernelGGL(k_post_mail, dim3(1), dim3(1), 0, st, scal, h->d_mail, seq);
@@ -3551,9 +3777,20 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
             SE2_HIP(hipGetLastError());
             return SE2GPU_OK;
         }
-        SE2_LAUNCH(h->prof, st, "k_update", k_update, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->cam, h->L,
+        const dim3 ug = grid1((size_t)h->L * kGroup, kBlock);
+        if (!sharded) {   // the trial ends inside k_update (FinArgs): no kernel boundary before the controller's decision
+            FinArgs fin{1, (int)ug.x, h->P, h->O, h->root, step ? 1 : 0, 1, note ? 1 : 0, h->fixed.p, h->xp.p, h->bp.p, B.pa,
+                        B.pb, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, scal, h->d_mail, seq, h->ctl.p,
+                        (const volatile int*)h->d_stop, h->fin_counter.p};
+            SE2_LAUNCH(h->prof, st, "k_update", k_update, dim3(ug.x + 1), dim3(kBlock), 0, h->cam, h->L, 0.0, h->lm_ptr.p,
+                       h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, step ? h->xp.p : (const double*)nullptr,
+                       h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, fin);
+            SE2_HIP(hipGetLastError());
+            return SE2GPU_OK;
+        }
+        SE2_LAUNCH(h->prof, st, "k_update", k_update, ug, dim3(kBlock), 0, h->cam, h->L,
                    0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
-                   step ? h->xp.p : (const double*)nullptr, h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb);
+                   step ? h->xp.p : (const double*)nullptr, h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, FinArgs{});
         SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                    0.0, B.pa, h->fixed.p, h->xp.p, h->bp.p, B.pb, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                    h->o_info.p, h->root, scal, h->d_mail, seq, h->ctl.p, step ? 1 : 0, sharded ? 0 : 1, note ? 1 : 0,
