@@ -2653,6 +2653,7 @@ struct se2gpu_ba {
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
     DevBuf<int2> chol_tasks;      // k_chol_tiles: (tile row | isR << 16, block column), ordered by column
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
+    DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
     int chol_ntask = 0;
     unsigned chol_epoch = 0;
@@ -2685,7 +2686,15 @@ struct se2gpu_ba {
     PinBuf<double> est;            // [poses 3P | landmarks 3L]
     bool est_valid = false;
 
+    // the two big edge arrays (measurements, information: 40 of the 48 bytes of an edge) travel on their own stream beside
+    // the plan kernels, which only need the indices
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy0 = nullptr, ev_copy1 = nullptr;
+
     ~se2gpu_ba() {
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (ev_copy0) (void)hipEventDestroy(ev_copy0);
+        if (ev_copy1) (void)hipEventDestroy(ev_copy1);
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (h_mail) (void)hipHostFree(h_mail);
     }
@@ -2970,6 +2979,104 @@ __global__ __launch_bounds__(256) void k_plan_pack(int nblk, const int* __restri
         if (used == gpw) { used = 0; ++wg; }
     }
 }
+// The same packing for graphs whose block count fits the LDS (nblk <= kPackMaxBlk, i.e. up to ~440 key frames; the kernel
+// above stays for the rest), laid out for the machine instead of for one thread per run:
+//   0  groups per block ng (0 = diagonal block, skipped) into LDS bytes, coalesced;
+//   1  the 256 runs' transfer functions with LANE = START STATE (two runs per wave, 16 waves: the 28-fold work of the
+//      tabulation is spread over the lanes and four waves per SIMD hide each other's issue latency);
+//   2  the composition of the 256 tables as a parallel (Hillis-Steele) scan, 8 steps;
+//   3  one thread per run walks it from its now known start state and leaves (workgroup, first group) per block;
+// k_plan_expand then writes the group descriptors with one thread per block.
+constexpr int kPackMaxBlk = 96 * 1024;
+__global__ __launch_bounds__(1024) void k_plan_pack2(int nblk, const int* __restrict__ blk_a, const int* __restrict__ blk_b,
+                                                      const int* __restrict__ blk_ptr, int* __restrict__ place,
+                                                      int* __restrict__ out_n, int gpw) {
+    extern __shared__ unsigned char pack_lds[];
+    int* tab0 = reinterpret_cast<int*>(pack_lds);                 // [256][28]: used | workgroups closed << 8
+    int* tab1 = tab0 + 256 * kGrpPerWG;
+    unsigned char* ng8 = reinterpret_cast<unsigned char*>(tab1 + 256 * kGrpPerWG);
+    const int t = threadIdx.x;
+    for (int kb = t; kb < nblk; kb += 1024) {
+        int ng = 0;
+        if (blk_a[kb] != blk_b[kb]) {
+            const int cnt = blk_ptr[kb + 1] - blk_ptr[kb];
+            ng = max(1, (cnt + kChunk - 1) / kChunk);
+            if (ng > gpw) { const int chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
+        }
+        ng8[kb] = (unsigned char)ng;
+    }
+    __syncthreads();
+    const int per = (nblk + 255) / 256;
+    {   // 1: lane = start state
+        const int half = (t >> 5) & 1, u = t & 31, wave = t >> 6;
+        for (int r = 2 * wave + half; r < 256; r += 32) {
+            const int b0 = min(r * per, nblk), b1 = min(b0 + per, nblk);
+            int used = u, wgs = 0;
+            for (int kb = b0; kb < b1; ++kb) {
+                const int ng = ng8[kb];
+                if (ng == 0) continue;   // (uniform over the half wave)
+                const bool fl = used + ng > gpw;
+                used = (fl ? 0 : used) + ng;
+                wgs += fl;
+                const bool ex = used == gpw;
+                used = ex ? 0 : used;
+                wgs += ex;
+            }
+            if (u < kGrpPerWG) tab0[r * kGrpPerWG + u] = used | (wgs << 8);
+        }
+    }
+    __syncthreads();
+    // 2: inclusive scan of the tables under composition (earlier run first)
+    int* src = tab0;
+    int* dst = tab1;
+    for (int d = 1; d < 256; d <<= 1) {
+        for (int e = t; e < 256 * kGrpPerWG; e += 1024) {
+            const int r = e / kGrpPerWG, u = e - r * kGrpPerWG;
+            int v = src[e];
+            if (r >= d) {
+                const int first = src[(r - d) * kGrpPerWG + u];          // the earlier runs, from state u
+                const int second = src[r * kGrpPerWG + (first & 0xff)];  // this run (and those already folded in) from there
+                v = (second & 0xff) | (((first >> 8) + (second >> 8)) << 8);
+            }
+            dst[e] = v;
+        }
+        __syncthreads();
+        int* tmp = src; src = dst; dst = tmp;
+    }
+    // 3: walk the runs
+    if (t < 256) {
+        int used = 0, wg = 0;
+        if (t > 0) { const int v = src[(t - 1) * kGrpPerWG]; used = v & 0xff; wg = v >> 8; }
+        const int b0 = min(t * per, nblk), b1 = min(b0 + per, nblk);
+        for (int kb = b0; kb < b1; ++kb) {
+            const int ng = ng8[kb];
+            if (ng == 0) { place[kb] = -1; continue; }
+            if (used + ng > gpw) { ++wg; used = 0; }
+            place[kb] = (wg << 8) | used;
+            used += ng;
+            if (used == gpw) { used = 0; ++wg; }
+        }
+        if (t == 255) out_n[0] = wg + (used ? 1 : 0);
+    }
+}
+__global__ void k_plan_expand(int nblk, const int* __restrict__ blk_ptr, const int* __restrict__ place,
+                              int4* __restrict__ grp, int grp_cap_wg, int gpw) {
+    const int kb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kb >= nblk) return;
+    const int pl = place[kb];
+    if (pl < 0) return;
+    const int wg = pl >> 8, first = pl & 0xff;
+    if (wg >= grp_cap_wg) return;
+    const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
+    const int cnt = q1 - q0;
+    int chunk = kChunk;
+    int ng = max(1, (cnt + chunk - 1) / chunk);
+    if (ng > gpw) { chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
+    for (int g = 0; g < ng; ++g) {
+        const int a0 = q0 + g * chunk, a1 = min(q1, a0 + chunk);
+        grp[(size_t)wg * gpw + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
+    }
+}
 __global__ void k_fill_int4(size_t n, int4 v, int4* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = v;
@@ -3108,18 +3215,21 @@ int ba_upload_graph(se2gpu_ba* h) {
     std::vector<double> s_uv, s_info;
     bool sorted = true, in_range = true;
     size_t npairs_max = 0;   // pairs of observations per landmark (an upper bound of the plan's pairs: fixed poses drop out)
-    {   // one pass: index range (borrowed bulk arrays are validated here), order, pairs per landmark
-        size_t run = 0;
-        for (int k = 0; k < E; ++k) {
-            in_range &= (unsigned)e_kf[k] < (unsigned)P && (unsigned)e_lm[k] < (unsigned)L;
-            if (k && e_lm[k] != e_lm[k - 1]) {
-                sorted &= e_lm[k] > e_lm[k - 1];
-                npairs_max += run * (run - 1) / 2;
-                run = 0;
+    {   // index range (borrowed bulk arrays are validated here), order, pairs per landmark: three branch-free loops (the
+        // first two vectorise; the third carries only the start of the current run)
+        unsigned bad = 0;
+        for (int k = 0; k < E; ++k) bad |= (unsigned)((unsigned)e_kf[k] >= (unsigned)P) | (unsigned)((unsigned)e_lm[k] >= (unsigned)L);
+        in_range = !bad;
+        int unsorted = 0;
+        for (int k = 1; k < E; ++k) unsorted |= e_lm[k] < e_lm[k - 1];
+        sorted = !unsorted;
+        if (sorted) {   // pairs = sum over the edges of their position inside their landmark's run
+            int run_start = 0;
+            for (int k = 1; k < E; ++k) {
+                run_start = e_lm[k] != e_lm[k - 1] ? k : run_start;
+                npairs_max += (size_t)(k - run_start);
             }
-            ++run;
         }
-        npairs_max += run * (run ? run - 1 : 0) / 2;
     }
     SE2_REQUIRE(in_range, SE2GPU_ERR_INVALID, "an edge references a vertex out of range");
     h->edge_perm.clear();
@@ -3247,8 +3357,6 @@ int ba_upload_graph(se2gpu_ba* h) {
     stage(h->fixed, h->h_fixed.data(), h->h_fixed.size());
     stage(h->e_kf, e_kf, (size_t)E);
     stage(h->e_lm, e_lm, (size_t)E);
-    stage(h->e_uv, e_uv, 2 * (size_t)E);
-    stage(h->e_info, e_info, 3 * (size_t)E);
     stage(h->podo_ptr, podo_ptr.data(), podo_ptr.size());
     stage(h->podo_item, podo_item.data(), podo_item.size());
     stage(h->o_i, o_i.data(), o_i.size());
@@ -3341,14 +3449,52 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     h->chol_ntask = (int)tasks.size();
     stage(h->chol_tasks, tasks.data(), tasks.size());
+    // last in the arena: the measurements and information matrices (copied on their own stream, see below; with a local
+    // graph loaded through se2gpu_ba_load_local_graph the information is evaluated on the device and not copied at all)
+    const size_t big_off = staged_bytes;
+    stage(h->e_uv, e_uv, 2 * (size_t)E);
+    const size_t info_off = staged_bytes;
+    stage(h->e_info, e_info, 3 * (size_t)E);
+    const size_t big_end = h->lg_active ? info_off : staged_bytes;
     lap("reserve");
     SE2_CHECK(h->h_stage.reserve(staged_bytes));
     SE2_CHECK(h->garena.reserve(staged_bytes));
-    for (const Staged& sg : staged) {
-        if (sg.bytes) std::memcpy(h->h_stage.p + sg.off, sg.src, sg.bytes);
-        sg.bind(h->garena.p + sg.off);
+    {   // the copy into the pinned arena runs ahead of the DMA in pieces of about 1 MB: the engine starts on the first
+        // piece while the host is still copying the rest (5.7 MB at 200 key frames: 130 us of memcpy beside 230 us of DMA)
+        constexpr size_t kPiece = (size_t)1 << 20;
+        size_t sent = 0;   // bytes of the arena already handed to the copy engine
+        if (!h->copy_stream) {
+            SE2_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+            SE2_HIP(hipEventCreateWithFlags(&h->ev_copy0, hipEventDisableTiming));
+            SE2_HIP(hipEventCreateWithFlags(&h->ev_copy1, hipEventDisableTiming));
+        }
+        SE2_HIP(hipEventRecord(h->ev_copy0, st));                      // (the arena may still be read by earlier work)
+        SE2_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_copy0, 0));
+        hipStream_t cur = st;
+        auto flush_on = [&](size_t upto) -> int {
+            if (upto > sent) {
+                SE2_HIP(hipMemcpyAsync(h->garena.p + sent, h->h_stage.p + sent, upto - sent, hipMemcpyHostToDevice, cur));
+                sent = upto;
+            }
+            return SE2GPU_OK;
+        };
+        for (const Staged& sg : staged) {
+            sg.bind(h->garena.p + sg.off);
+            if (sg.off >= big_end) continue;                           // evaluated on the device: nothing to copy
+            if (sg.off == big_off) {                                   // everything before goes out on the main stream now
+                SE2_CHECK(flush_on(big_off));
+                cur = h->copy_stream;
+            }
+            for (size_t done = 0; done < sg.bytes;) {
+                const size_t nb = std::min(sg.bytes - done, kPiece);
+                std::memcpy(h->h_stage.p + sg.off + done, (const uint8_t*)sg.src + done, nb);
+                done += nb;
+                if (sg.off + done - sent >= kPiece) SE2_CHECK(flush_on(sg.off + done));
+            }
+        }
+        SE2_CHECK(flush_on(std::min(big_end, staged_bytes)));
+        SE2_HIP(hipEventRecord(h->ev_copy1, h->copy_stream));
     }
-    SE2_HIP(hipMemcpyAsync(h->garena.p, h->h_stage.p, staged_bytes, hipMemcpyHostToDevice, st));
     lap("staging + enqueue");
     if (h->lg_active && E)
         hipLaunchKernelGGL(k_edge_information, grid1(E, 256), dim3(256), 0, st, E, h->d_lg_lc.p, h->d_lg_lw.p, h->e_kf.p,
@@ -3430,13 +3576,28 @@ int ba_upload_graph(se2gpu_ba* h) {
             hipLaunchKernelGGL(k_plan_odo, grid1(O, 64), dim3(64), 0, st, P, O, h->o_i.p, h->o_j.p, h->blk_odo.p);
         hipLaunchKernelGGL(k_fill_int4, grid1((size_t)cap_wg * gpw, 256), dim3(256), 0, st, (size_t)cap_wg * gpw,
                            make_int4(-1, 0, 0, 0), h->grp.p);
-        hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(256), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->grp.p,
-                           cap_wg, h->plan_out.p, gpw);
+        if (nblk <= kPackMaxBlk) {
+            static const bool lds_ok = [] {
+                return hipFuncSetAttribute((const void*)k_plan_pack2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * 256 * kGrpPerWG * (int)sizeof(int) + kPackMaxBlk) == hipSuccess;
+            }();
+            SE2_REQUIRE(lds_ok, SE2GPU_ERR_HIP, "k_plan_pack2: cannot reserve its LDS");
+            SE2_CHECK(h->plan_place.reserve((size_t)nblk + 1));
+            const size_t lds = 2 * 256 * kGrpPerWG * sizeof(int) + (((size_t)nblk + 15) & ~(size_t)15);
+            hipLaunchKernelGGL(k_plan_pack2, dim3(1), dim3(1024), lds, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p,
+                               h->plan_place.p, h->plan_out.p, gpw);
+            hipLaunchKernelGGL(k_plan_expand, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->blk_ptr.p, h->plan_place.p,
+                               h->grp.p, cap_wg, gpw);
+        } else {
+            hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(256), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->grp.p,
+                               cap_wg, h->plan_out.p, gpw);
+        }
         SE2_HIP(hipGetLastError());
         SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
         SE2_HIP(hipMemcpyAsync(h->h_scal.p, h->plan_out.p, sizeof(int), hipMemcpyDeviceToHost, st));
         lap("plan kernels enqueued");
     }
+    SE2_HIP(hipStreamWaitEvent(st, h->ev_copy1, 0));   // measurements / information are in place before anything later runs
     SE2_CHECK(h->fin_counter.reserve(1));
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
     SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
