@@ -2651,6 +2651,7 @@ struct se2gpu_ba {
     DevBuf<double> e_uv, e_info, o_meas, o_info;
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Dg, Hpp, bp, Oii, Ojj, Oij, obi, obj;
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
+    DevBuf<double> red_packed;    // sharded runs: the lower-triangular tiles of [S; b^T], what the all-reduce ships
     DevBuf<int2> chol_tasks;      // k_chol_tiles: (tile row | isR << 16, block column), ordered by column
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
     DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
@@ -3751,6 +3752,40 @@ int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count) {
     return SE2GPU_OK;
 }
 
+// The exchange of the sharded run ships only what the dense solver reads: of row r of [S; b^T] the columns up to the end of
+// its diagonal tile (the lower-triangular tiles; the rhs row n in full) - 52 % of the rectangle at 200 key frames.  Rows are
+// packed back to back: offset(r) = 32 * (32 q (q + 1) / 2 + (r mod 32) (q + 1)),  q = r / 32.
+__host__ __device__ inline size_t tri_row_off(int r) {
+    const size_t q = (size_t)(r / kNB), rem = (size_t)(r % kNB);
+    return kNB * (kNB * q * (q + 1) / 2 + rem * (q + 1));
+}
+__global__ __launch_bounds__(256) void k_tri_pack(const double* __restrict__ A, int ld, int rows, double* __restrict__ packed,
+                                                   int unpack, double* __restrict__ Aout) {
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    const int len = min(kNB * (r / kNB + 1), ld);
+    const size_t off = tri_row_off(r);
+    if (!unpack) {
+        for (int c = threadIdx.x; c < len; c += 256) packed[off + c] = A[(size_t)r * ld + c];
+    } else {
+        for (int c = threadIdx.x; c < len; c += 256) Aout[(size_t)r * ld + c] = packed[off + c];
+    }
+}
+int ba_allreduce_system(se2gpu_ba* h) {
+    if (!h->allreduce) return SE2GPU_OK;
+    const int n = h->D * h->P, rows = n + 1;
+    // a caller-owned exchange buffer (se2gpu_ba_set_allreduce with `buffer`) can only be reduced where it is, and the host
+    // solve reads whole rows: the rectangle then
+    if (h->ar_buffer || h->host_solve) return ba_allreduce(h, h->red, (size_t)rows * h->ld);
+    const size_t count = tri_row_off(rows);   // (slightly above the exact size when the last row's tile is cut by ld)
+    SE2_CHECK(h->red_packed.reserve(count));
+    hipLaunchKernelGGL(k_tri_pack, dim3(rows), dim3(256), 0, h->stream, h->red, h->ld, rows, h->red_packed.p, 0, (double*)nullptr);
+    SE2_CHECK(ba_allreduce(h, h->red_packed.p, count));
+    hipLaunchKernelGGL(k_tri_pack, dim3(rows), dim3(256), 0, h->stream, (const double*)nullptr, h->ld, rows, h->red_packed.p, 1, h->red);
+    SE2_HIP(hipGetLastError());
+    return SE2GPU_OK;
+}
+
 // host side of the mailbox: poll the mapped, coherent buffer until the device has written sequence number `seq`;
 // meanwhile the caller's force-stop flag is mirrored into the word the device reads
 int ba_wait_mail(se2gpu_ba* h, double seq, const volatile uint8_t* stop_flag = nullptr) {
@@ -3978,7 +4013,7 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
         if (know_retry != 1) SE2_CHECK(ba_linearize(h, 0.0, true));
         SE2_CHECK(ba_reduce(h, 0.0, !lm ? 0 : know_retry == 0 ? 0 : know_retry == 1 ? 3 : 2, true));
     }
-    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
+    SE2_CHECK(ba_allreduce_system(h));
     SE2_CHECK(ba_solve(h, true));
     SE2_CHECK(evaluate(true, notify));
     return SE2GPU_OK;
