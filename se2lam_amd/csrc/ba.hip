@@ -156,6 +156,48 @@ __device__ inline void write_diag_record(double* __restrict__ dg, const double* 
     }
 }
 
+// the lambda-dependent per-landmark pieces alone (a rejected trial keeps its linearisation): Dinv = (Hll + lambda I)^-1,
+// z = Dinv bl, Y_e = Hpl_e Dinv and the diagonal record of every edge
+__device__ inline void schur_lm_body(int L, double lambda, const int* __restrict__ lm_ptr, const double* Hll, const double* bl,
+                                     const double* Hpl, const double* Hpp_e, const double* bp_e, double* Dinv, double* z,
+                                     double* Y, double* Dg) {
+    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int l = gid / kGroup, sub = gid % kGroup;
+    if (l >= L) return;
+    double h[6], d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) h[i] = Hll[(size_t)l * 6 + i];
+    inv_sym3(h, lambda, d);
+    const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
+    const double z0 = d[0] * b0 + d[1] * b1 + d[2] * b2;
+    const double z1 = d[1] * b0 + d[3] * b1 + d[4] * b2;
+    const double z2 = d[2] * b0 + d[4] * b1 + d[5] * b2;
+    if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
+        z[(size_t)l * 3 + 0] = z0;
+        z[(size_t)l * 3 + 1] = z1;
+        z[(size_t)l * 3 + 2] = z2;
+    }
+    for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
+        const double* B = Hpl + (size_t)e * 9;
+        double* y = Y + (size_t)e * 9;
+        double hh[9], yy[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) hh[i] = B[i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double c0 = hh[r * 3], c1 = hh[r * 3 + 1], c2 = hh[r * 3 + 2];
+            yy[r * 3 + 0] = c0 * d[0] + c1 * d[1] + c2 * d[2];
+            yy[r * 3 + 1] = c0 * d[1] + c1 * d[3] + c2 * d[4];
+            yy[r * 3 + 2] = c0 * d[2] + c1 * d[4] + c2 * d[5];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) y[i] = yy[i];
+        write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
+    }
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const int* __restrict__ lm_ptr,
                                                        const int* __restrict__ e_kf, const double* __restrict__ e_uv,
@@ -169,8 +211,13 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
                                                        double* __restrict__ Y, double* __restrict__ Dg,
                                                        const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
                                                        const double* __restrict__ lms_b) {
-    if (ctl) {   // device-side LM: nothing to do on a retry (same linearisation) or after the run has ended
-        if (ctl->done | ctl->retry) return;
+    if (ctl) {   // device-side LM: nothing to do after the run has ended; a retry keeps its linearisation and only redoes the
+                 // lambda-dependent part (what k_schur_lm does - here, so that a trial slot needs no launch of its own for it)
+        if (ctl->done) return;
+        if (ctl->retry) {
+            if (FUSED) schur_lm_body(L, ctl->lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
+            return;
+        }
         if (ctl->sel) { poses = poses_b; lms = lms_b; }
         lambda = ctl->lambda;
     }
@@ -415,41 +462,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const
         if (ctl->done || !(force | ctl->retry)) return;
         lambda = ctl->lambda;
     }
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
-    const int l = gid / kGroup, sub = gid % kGroup;
-    if (l >= L) return;
-    double h[6], d[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) h[i] = Hll[(size_t)l * 6 + i];
-    inv_sym3(h, lambda, d);
-    const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
-    const double z0 = d[0] * b0 + d[1] * b1 + d[2] * b2;
-    const double z1 = d[1] * b0 + d[3] * b1 + d[4] * b2;
-    const double z2 = d[2] * b0 + d[4] * b1 + d[5] * b2;
-    if (sub == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
-        z[(size_t)l * 3 + 0] = z0;
-        z[(size_t)l * 3 + 1] = z1;
-        z[(size_t)l * 3 + 2] = z2;
-    }
-    for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
-        const double* B = Hpl + (size_t)e * 9;
-        double* y = Y + (size_t)e * 9;
-        double hh[9], yy[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) hh[i] = B[i];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double c0 = hh[r * 3], c1 = hh[r * 3 + 1], c2 = hh[r * 3 + 2];
-            yy[r * 3 + 0] = c0 * d[0] + c1 * d[1] + c2 * d[2];
-            yy[r * 3 + 1] = c0 * d[1] + c1 * d[3] + c2 * d[4];
-            yy[r * 3 + 2] = c0 * d[2] + c1 * d[4] + c2 * d[5];
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) y[i] = yy[i];
-        write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
-    }
+    schur_lm_body(L, lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2687,13 +2700,12 @@ struct se2gpu_ba {
     PinBuf<double> est;            // [poses 3P | landmarks 3L]
     bool est_valid = false;
 
-    // the two big edge arrays (measurements, information: 40 of the 48 bytes of an edge) travel on their own stream beside
-    // the plan kernels, which only need the indices
-    hipStream_t copy_stream = nullptr;
+    // the two big edge arrays (measurements, information: 40 of the 48 bytes of an edge) travel on a copy stream beside
+    // the plan kernels, which only need the indices.  The stream is shared by all handles of a device (ba_copy_stream): a
+    // stream per handle would take hardware queues away from the handles' own streams when many windows run at once
     hipEvent_t ev_copy0 = nullptr, ev_copy1 = nullptr;
 
     ~se2gpu_ba() {
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (ev_copy0) (void)hipEventDestroy(ev_copy0);
         if (ev_copy1) (void)hipEventDestroy(ev_copy1);
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -3182,6 +3194,17 @@ void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const u
     pl.nwg_off = (int)(grp.size() / gpw);
 }
 
+// one copy stream per device, shared by all handles, never destroyed
+int ba_copy_stream(int device, hipStream_t* out) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    SE2_REQUIRE(device >= 0 && device < 64, SE2GPU_ERR_INVALID, "device %d", device);
+    if (!streams[device]) SE2_HIP(hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking));
+    *out = streams[device];
+    return SE2GPU_OK;
+}
+
 int ba_upload_graph(se2gpu_ba* h) {
     static const bool trace = [] { const char* e = getenv("SE2GPU_BA_INIT_TRACE"); return e && e[0] == '1'; }();
     const auto t_begin = std::chrono::steady_clock::now();
@@ -3464,13 +3487,14 @@ int ba_upload_graph(se2gpu_ba* h) {
         // piece while the host is still copying the rest (5.7 MB at 200 key frames: 130 us of memcpy beside 230 us of DMA)
         constexpr size_t kPiece = (size_t)1 << 20;
         size_t sent = 0;   // bytes of the arena already handed to the copy engine
-        if (!h->copy_stream) {
-            SE2_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        hipStream_t copy_stream = nullptr;
+        SE2_CHECK(ba_copy_stream(h->device, &copy_stream));
+        if (!h->ev_copy0) {
             SE2_HIP(hipEventCreateWithFlags(&h->ev_copy0, hipEventDisableTiming));
             SE2_HIP(hipEventCreateWithFlags(&h->ev_copy1, hipEventDisableTiming));
         }
         SE2_HIP(hipEventRecord(h->ev_copy0, st));                      // (the arena may still be read by earlier work)
-        SE2_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_copy0, 0));
+        SE2_HIP(hipStreamWaitEvent(copy_stream, h->ev_copy0, 0));
         hipStream_t cur = st;
         auto flush_on = [&](size_t upto) -> int {
             if (upto > sent) {
@@ -3484,7 +3508,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             if (sg.off >= big_end) continue;                           // evaluated on the device: nothing to copy
             if (sg.off == big_off) {                                   // everything before goes out on the main stream now
                 SE2_CHECK(flush_on(big_off));
-                cur = h->copy_stream;
+                cur = copy_stream;
             }
             for (size_t done = 0; done < sg.bytes;) {
                 const size_t nb = std::min(sg.bytes - done, kPiece);
@@ -3494,7 +3518,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             }
         }
         SE2_CHECK(flush_on(std::min(big_end, staged_bytes)));
-        SE2_HIP(hipEventRecord(h->ev_copy1, h->copy_stream));
+        SE2_HIP(hipEventRecord(h->ev_copy1, copy_stream));
     }
     lap("staging + enqueue");
     if (h->lg_active && E)
@@ -4011,7 +4035,8 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
         }
     } else {
         if (know_retry != 1) SE2_CHECK(ba_linearize(h, 0.0, true));
-        SE2_CHECK(ba_reduce(h, 0.0, !lm ? 0 : know_retry == 0 ? 0 : know_retry == 1 ? 3 : 2, true));
+        // (model 0: an undecided slot needs no k_schur_lm of its own, k_linearize<FUSED> redoes the lambda part on a retry)
+        SE2_CHECK(ba_reduce(h, 0.0, !lm ? 0 : know_retry == 0 ? 0 : know_retry == 1 ? 3 : (h->model ? 2 : 0), true));
     }
     SE2_CHECK(ba_allreduce_system(h));
     SE2_CHECK(ba_solve(h, true));
