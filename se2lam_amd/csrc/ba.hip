@@ -3090,6 +3090,97 @@ __global__ void k_plan_expand(int nblk, const int* __restrict__ blk_ptr, const i
         grp[(size_t)wg * gpw + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
     }
 }
+// Independent steps of the plan as ONE launch each (a launch boundary costs about as much as these kernels run: 26 launches
+// were 90 us of host time and as much again on the device for a 50-key-frame window).  Items of the merged kernels are
+// laid out segment after segment, every segment starting on a workgroup boundary.
+//   k_plan_init   = k_plan_lm | k_iota | k_plan_blocks | k_fill_int4        (need nothing but the uploaded graph)
+//   k_plan_pairs2 = k_plan_pairs | k_plan_tail                              (after the scan of the pair counts)
+//   k_plan_bounds = k_lower_bounds (blk_ptr) | k_split_st                   (after the pairs are sorted)
+__global__ __launch_bounds__(256) void k_plan_init(int L, int E, int P, const int* __restrict__ e_lm, const int* __restrict__ e_kf,
+                                                    const uint8_t* __restrict__ fixed, int* __restrict__ lm_ptr,
+                                                    int* __restrict__ npair, int* __restrict__ idx, int* __restrict__ blk_a,
+                                                    int* __restrict__ blk_b, int* __restrict__ blk_odo, size_t ngrp,
+                                                    int4* __restrict__ grp, int b1, int b2, int b3) {
+    const int bx = blockIdx.x;
+    if (bx < b1) {   // landmark CSR + pairs per landmark
+        const int l = bx * 256 + threadIdx.x;
+        if (l > L) return;
+        int lo = 0, hi = E;   // first edge with e_lm >= l
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (e_lm[mid] < l) lo = mid + 1; else hi = mid;
+        }
+        lm_ptr[l] = lo;
+        if (l == L) return;
+        int end = lo;
+        while (end < E && e_lm[end] == l) ++end;
+        int np = 0;
+        for (int s = lo; s < end; ++s) {
+            const int a = e_kf[s];
+            if (fixed[a]) continue;
+            for (int t = s + 1; t < end; ++t) {
+                const int b = e_kf[t];
+                np += (!fixed[b] && a != b) ? 1 : 0;
+            }
+        }
+        npair[l] = np;
+    } else if (bx < b2) {   // edge indices 0 .. E-1 (values of the sort by key frame)
+        const int i = (bx - b1) * 256 + threadIdx.x;
+        if (i < E) idx[i] = i;
+    } else if (bx < b3) {   // blk_a / blk_b / blk_odo
+        const int i = (bx - b2) * 256 + threadIdx.x;
+        const int a = i / P, b = i - a * P;
+        if (a >= P || b < a) return;
+        const int q = blk_index_of(P, a, b);
+        blk_a[q] = a;
+        blk_b[q] = b;
+        blk_odo[q] = -1;
+    } else {   // empty group descriptors
+        const size_t i = (size_t)(bx - b3) * 256 + threadIdx.x;
+        if (i < ngrp) grp[i] = make_int4(-1, 0, 0, 0);
+    }
+}
+__global__ __launch_bounds__(256) void k_plan_pairs2(int L, int P, const int* __restrict__ lm_ptr, const int* __restrict__ e_kf,
+                                                      const uint8_t* __restrict__ fixed, const int* __restrict__ pair_base,
+                                                      int* __restrict__ key, int2* __restrict__ st, int cap, int big, int b1) {
+    if ((int)blockIdx.x < b1) {
+        const int l = blockIdx.x * 256 + threadIdx.x;
+        if (l >= L) return;
+        int o = pair_base[l];
+        const int beg = lm_ptr[l], end = lm_ptr[l + 1];
+        for (int s = beg; s < end; ++s) {
+            const int a = e_kf[s];
+            if (fixed[a]) continue;
+            for (int t = s + 1; t < end; ++t) {
+                const int b = e_kf[t];
+                if (fixed[b] || a == b) continue;
+                key[o] = a < b ? blk_index_of(P, a, b) : blk_index_of(P, b, a);
+                st[o] = a < b ? make_int2(s, t) : make_int2(t, s);
+                ++o;
+            }
+        }
+    } else {   // keys past the real pair count (pair_base[L], known only on the device) sort behind every block
+        const int i = (blockIdx.x - b1) * 256 + threadIdx.x;
+        if (i < cap && i >= pair_base[L]) key[i] = big;
+    }
+}
+__global__ __launch_bounds__(256) void k_plan_bounds(const int* __restrict__ key, int n, int nq, int* __restrict__ out,
+                                                      const int2* __restrict__ st, int* __restrict__ pi, int* __restrict__ pj,
+                                                      int b1) {
+    if ((int)blockIdx.x < b1) {
+        const int q = blockIdx.x * 256 + threadIdx.x;
+        if (q > nq) return;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (key[mid] < q) lo = mid + 1; else hi = mid;
+        }
+        out[q] = lo;
+    } else {
+        const int i = (blockIdx.x - b1) * 256 + threadIdx.x;
+        if (i < n) { pi[i] = st[i].x; pj[i] = st[i].y; }
+    }
+}
 __global__ void k_fill_int4(size_t n, int4 v, int4* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = v;
@@ -3565,7 +3656,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             hipLaunchKernelGGL(k_radix_hist, dim3(std::max(nb, 1)), dim3(kRadixItems), 0, st, kin, (int)cnt, shift, bins, nb,
                                h->plan_hist.p);
             const int cnt_h = bins * nb, ntile = (cnt_h + kScanTile - 1) / kScanTile;
-            if (ntile <= 2) {
+            if (ntile <= 8) {   // up to 16 counters per thread of ONE workgroup: cheaper than three launches
                 hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_hist.p, h->plan_offs.p, cnt_h);
             } else {
                 hipLaunchKernelGGL(k_scan_tiles, dim3(ntile), dim3(256), 0, st, h->plan_hist.p, h->plan_offs.p, cnt_h,
@@ -3577,30 +3668,36 @@ int ba_upload_graph(se2gpu_ba* h) {
                                (int)cnt, shift, bins, nb, h->plan_offs.p, kout, vout);
             return SE2GPU_OK;
         };
-        // landmark CSR + pairs per landmark, their prefix sums
-        hipLaunchKernelGGL(k_plan_lm, grid1((size_t)L + 1, 256), dim3(256), 0, st, L, E, h->e_lm.p, h->e_kf.p, h->fixed.p,
-                           h->lm_ptr.p, h->plan_np.p);
+        // landmark CSR + pairs per landmark | edge indices | block table | empty group descriptors
+        {
+            const int g1 = (int)grid1((size_t)L + 1, 256).x, g2 = (int)grid1(E, 256).x, g3 = (int)grid1((size_t)P * P, 256).x;
+            const size_t ngrp = (size_t)cap_wg * gpw;
+            const int g4 = (int)grid1(ngrp, 256).x;
+            hipLaunchKernelGGL(k_plan_init, dim3(g1 + g2 + g3 + g4), dim3(256), 0, st, L, E, P, h->e_lm.p, h->e_kf.p, h->fixed.p,
+                               h->lm_ptr.p, h->plan_np.p, h->plan_idx.p, h->blk_a.p, h->blk_b.p, h->blk_odo.p, ngrp, h->grp.p,
+                               g1, g1 + g2, g1 + g2 + g3);
+        }
         hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_np.p, h->plan_base.p, L);   // 20 per thread
-        // pose -> edges CSR: edge indices stably sorted by key frame (one pass)
-        hipLaunchKernelGGL(k_iota, grid1(E, 256), dim3(256), 0, st, E, h->plan_idx.p);
-        if (E) SE2_CHECK(radix(h->e_kf.p, h->plan_key0.p, h->plan_idx.p, h->pose_edges.p, (size_t)E, 0, Pb));
-        hipLaunchKernelGGL(k_lower_bounds, grid1((size_t)P + 1, 256), dim3(256), 0, st, h->plan_key0.p, E, P, h->pose_ptr.p);
-        // contributor pairs, stably sorted by block key (two passes)
-        hipLaunchKernelGGL(k_plan_pairs, grid1(L, 256), dim3(256), 0, st, L, P, h->lm_ptr.p, h->e_kf.p, h->fixed.p,
-                           h->plan_base.p, h->plan_key0.p, h->plan_st0.p);
-        // the number of pairs is plan_base[L] - only the device knows it; the sort runs over the host's upper bound with
-        // the tail keyed past every block, where it stays (stable) and is never referenced
-        hipLaunchKernelGGL(k_plan_tail, grid1(NP, 256), dim3(256), 0, st, h->plan_base.p + L, (int)NP, nblk, h->plan_key0.p);
-        SE2_CHECK(radix(h->plan_key0.p, h->plan_key1.p, h->plan_st0.p, h->plan_st1.p, NP, 0, qlo));
-        SE2_CHECK(radix(h->plan_key1.p, h->plan_key0.p, h->plan_st1.p, h->plan_st0.p, NP, qlo, std::max(qhi, 1)));
-        hipLaunchKernelGGL(k_lower_bounds, grid1((size_t)nblk + 1, 256), dim3(256), 0, st, h->plan_key0.p, (int)NP, nblk,
-                           h->blk_ptr.p);
-        hipLaunchKernelGGL(k_split_st, grid1(NP, 256), dim3(256), 0, st, (int)NP, h->plan_st0.p, h->pair_i.p, h->pair_j.p);
-        hipLaunchKernelGGL(k_plan_blocks, dim3((P + 255) / 256, P), dim3(256), 0, st, P, h->blk_a.p, h->blk_b.p, h->blk_odo.p);
         if (O && !h->odo_fallback)
             hipLaunchKernelGGL(k_plan_odo, grid1(O, 64), dim3(64), 0, st, P, O, h->o_i.p, h->o_j.p, h->blk_odo.p);
-        hipLaunchKernelGGL(k_fill_int4, grid1((size_t)cap_wg * gpw, 256), dim3(256), 0, st, (size_t)cap_wg * gpw,
-                           make_int4(-1, 0, 0, 0), h->grp.p);
+        // pose -> edges CSR: edge indices stably sorted by key frame (one pass)
+        if (E) SE2_CHECK(radix(h->e_kf.p, h->plan_key0.p, h->plan_idx.p, h->pose_edges.p, (size_t)E, 0, Pb));
+        hipLaunchKernelGGL(k_lower_bounds, grid1((size_t)P + 1, 256), dim3(256), 0, st, h->plan_key0.p, E, P, h->pose_ptr.p);
+        // contributor pairs, stably sorted by block key (two passes).  The number of pairs is plan_base[L] - only the device
+        // knows it; the sort runs over the host's upper bound with the tail keyed past every block, where it stays (stable)
+        // and is never referenced
+        {
+            const int g1 = (int)grid1(L, 256).x, g2 = (int)grid1(NP, 256).x;
+            hipLaunchKernelGGL(k_plan_pairs2, dim3(g1 + g2), dim3(256), 0, st, L, P, h->lm_ptr.p, h->e_kf.p, h->fixed.p,
+                               h->plan_base.p, h->plan_key0.p, h->plan_st0.p, (int)NP, nblk, g1);
+        }
+        SE2_CHECK(radix(h->plan_key0.p, h->plan_key1.p, h->plan_st0.p, h->plan_st1.p, NP, 0, qlo));
+        SE2_CHECK(radix(h->plan_key1.p, h->plan_key0.p, h->plan_st1.p, h->plan_st0.p, NP, qlo, std::max(qhi, 1)));
+        {
+            const int g1 = (int)grid1((size_t)nblk + 1, 256).x, g2 = (int)grid1(NP, 256).x;
+            hipLaunchKernelGGL(k_plan_bounds, dim3(g1 + g2), dim3(256), 0, st, h->plan_key0.p, (int)NP, nblk, h->blk_ptr.p,
+                               h->plan_st0.p, h->pair_i.p, h->pair_j.p, g1);
+        }
         if (nblk <= kPackMaxBlk) {
             static const bool lds_ok = [] {
                 return hipFuncSetAttribute((const void*)k_plan_pack2, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3968,7 +4065,6 @@ int ba_lambda_init(se2gpu_ba* h) {
 // mode: kernels that would do nothing are not launched, so per-kernel profiles stay clean).
 int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, double seq) {
     hipStream_t st = h->stream;
-    const int n = h->D * h->P;
     const bool lm = h->run_mode == SE2GPU_BA_LM;
     const bool sharded = h->allreduce != nullptr;
     double* scal = h->red + (size_t)h->ld * h->ld;
