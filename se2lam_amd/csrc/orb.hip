@@ -83,6 +83,12 @@ struct Geom {
     const int bx = (int)blockIdx.y;    \
     if (f >= g.nframes) return
 
+// the same with a block offset: a launch that covers only the tiles of some levels (pipelined batches, see orb_run)
+#define SE2_FRAME_GRID_OFF(f, bx, off)       \
+    const int f = (int)blockIdx.x;           \
+    const int bx = (int)blockIdx.y + (off);  \
+    if (f >= g.nframes) return
+
 // interior pixel (x, y) of level l of frame f
 __device__ __forceinline__ size_t pix(const Geom& g, int f, int l, int y, int x) {
     return (size_t)f * g.frame_bytes + g.off[l] + (size_t)(y + kEdge) * g.stride[l] + (x + kEdge);
@@ -324,8 +330,8 @@ __device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t lef
 constexpr int kStripCap = kScoreGroups * kScoreRows;   // 4-pixel groups of one strip
 
 __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __restrict__ pyr, uint2* __restrict__ lst_ent,
-                                                     int* __restrict__ lst_cnt) {
-    SE2_FRAME_GRID(f, bx);
+                                                     int* __restrict__ lst_cnt, int bx0) {
+    SE2_FRAME_GRID_OFF(f, bx, bx0);
     int l = 0;
     while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
     const int t = bx - g.tile_base[l];
@@ -477,12 +483,12 @@ __device__ __forceinline__ uint32_t compass_pair(short2v v, short2v n, short2v e
 
 __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t* __restrict__ pyr, uint2* __restrict__ lst_ent,
                                                            int* __restrict__ lst_cnt, int* __restrict__ cand_count,
-                                                           int* __restrict__ overflow) {
+                                                           int* __restrict__ overflow, int bx0) {
     __shared__ uint32_t s_img[(kFsLW / 4) * kFsLH];
     __shared__ uint32_t s_sc[(kFsSW / 4) * kFsSH];
     __shared__ uint16_t s_cand[kFsMaxCand];
     __shared__ int s_n, s_nout;
-    SE2_FRAME_GRID(f, tlin);
+    SE2_FRAME_GRID_OFF(f, tlin, bx0);
     int l = 0;
     while (l + 1 < g.nlevels && tlin >= g.tile_base[l + 1]) ++l;
     const int t = tlin - g.tile_base[l];
@@ -1072,8 +1078,8 @@ constexpr int kBlurRows = 35;
 // k_resize together with the pyramid itself: the 2 x 16 full frame rows, for every interior row its first 16-byte chunk
 // and the chunks from the one that straddles the right edge of the interior onwards (the interior bytes that chunk
 // carries are overwritten here).
-__global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    SE2_FRAME_GRID(f, bx);
+__global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, int bx0) {
+    SE2_FRAME_GRID_OFF(f, bx, bx0);
     int l = 0;
     while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
     const int t = bx - g.tile_base[l];
@@ -1263,6 +1269,8 @@ struct se2gpu_orb {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;          // blurred pyramid: independent of the key-point chain, runs beside it
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t pyr_stream = nullptr;           // pipelined batches: the pyramid chain; score / blur of level l follow ev_lvl[l]
+    hipEvent_t ev_lvl[kMaxLevels] = {};
     LaunchProfile prof;
     se2gpu_orb_params params{};
     double scaleFactor = 1.2;
@@ -1305,6 +1313,9 @@ struct se2gpu_orb {
     ~se2gpu_orb() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (pyr_stream) (void)hipStreamDestroy(pyr_stream);
+        for (hipEvent_t e : ev_lvl)
+            if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_fs) (void)hipEventDestroy(ev_fs);
@@ -1460,29 +1471,22 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     SE2_CHECK(h->kp_list.reserve((size_t)h->max_batch * cap));
     SE2_CHECK(h->angles.reserve((size_t)h->max_batch * cap));
     SE2_CHECK(h->angle_cs.reserve((size_t)h->max_batch * cap));
-    {
-        dim3 grid(F8, ((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256);
-        SE2_LAUNCH(h->prof, st, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p, h->blur.p);
+    // Batches are pipelined by level: the pyramid chain (k_level0, k_resize x 7: latency-bound, half the VALU idle) runs on
+    // its own stream and the score and blur launches of level l start as soon as level l exists, instead of after the
+    // whole pyramid - the score and blur kernels are VALU-bound and fill the gaps of the resize chain.  A single frame
+    // (the tracking thread's call) keeps the short serial sequence: there the extra launches would cost more than they hide.
+    static const int pipe_min = [] { const char* e = std::getenv("SE2GPU_ORB_PIPELINE_MIN"); return e ? std::atoi(e) : 16; }();
+    const bool piped = !h->prof.enabled && nframes >= pipe_min;
+    if (piped && !h->pyr_stream) {
+        SE2_HIP(hipStreamCreateWithFlags(&h->pyr_stream, hipStreamNonBlocking));
+        for (int l = 0; l < kMaxLevels; ++l) SE2_HIP(hipEventCreateWithFlags(&h->ev_lvl[l], hipEventDisableTiming));
     }
-    for (int l = 1; l < L; ++l) {
-        const int ng = g.stride[l] / 4;
-        ResizeTab t{h->tabs.p + h->ytab_off[l], h->tabs.p + h->xtab_off[l], ng};
-        dim3 grid(F8, ((ng + 63) / 64) * ((g.h[l] + 2 * kEdge + 4 * kResizeRows - 1) / (4 * kResizeRows)));
-        SE2_LAUNCH(h->prof, st, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p, h->blur.p);
-    }
-    // The blurred pyramid needs only the pyramid: it runs on a side stream next to the key-point chain, whose
-    // k_level_select and k_cell_detect leave most CUs idle.  (Serial when profiling.)
-    hipStream_t sb = h->prof.enabled ? st : h->side_stream;
-    if (sb != st) {
-        SE2_HIP(hipEventRecord(h->ev_fork, st));
-        SE2_HIP(hipStreamWaitEvent(sb, h->ev_fork, 0));
-    }
-    {
-        Geom gb = g;
-        for (int l = 0; l <= L; ++l) gb.tile_base[l] = h->blur_tile_base[l];
-        SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(F8, gb.tile_base[L]), dim3(256), 0, gb, h->pyr.p, h->blur.p);
-    }
-    if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
+    hipStream_t sp = piped ? h->pyr_stream : st;
+    hipStream_t sb = h->prof.enabled ? st : h->side_stream;   // blurred pyramid: beside the key-point chain
+    if (piped || sb != st) SE2_HIP(hipEventRecord(h->ev_fork, st));
+    if (piped) SE2_HIP(hipStreamWaitEvent(sp, h->ev_fork, 0));
+    if (sb != st) SE2_HIP(hipStreamWaitEvent(sb, h->ev_fork, 0));
+    // ---- score kernel choice (dense / sparse by the measured candidate density)
     constexpr double kSparseBelow = 0.10;   // the two kernels cost the same at about one candidate per ten pixels
     constexpr int kProbeEvery = 32;
     bool run_sparse = h->score_mode == 2, count = false;
@@ -1499,27 +1503,70 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         count = probe;
         h->since_probe = probe ? 0 : h->since_probe + 1;
     }
+    if (run_sparse && count) {
+        SE2_CHECK(h->fs_count.reserve((size_t)h->max_batch));
+        SE2_CHECK(h->h_fs_count.reserve((size_t)h->max_batch));
+        SE2_HIP(hipMemsetAsync(h->fs_count.p, 0, (size_t)nframes * sizeof(int), st));
+    }
+    Geom gb = g;   // blur tiles
+    for (int l = 0; l <= L; ++l) gb.tile_base[l] = h->blur_tile_base[l];
     if (run_sparse) {
-        if (count) {
-            SE2_CHECK(h->fs_count.reserve((size_t)h->max_batch));
-            SE2_CHECK(h->h_fs_count.reserve((size_t)h->max_batch));
-            SE2_HIP(hipMemsetAsync(h->fs_count.p, 0, (size_t)nframes * sizeof(int), st));
-        }
         for (int l = 0; l <= L; ++l) { g.tile_base[l] = h->sparse_tile_base[l]; g.lst_base[l] = h->sparse_lst_base[l]; }
         g.lst_tw = kFsTW; g.lst_th = kFsTH; g.lst_cap = kFsListCap;
-        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_sparse, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
-                   h->lst_ent.p, h->lst_cnt.p, count ? h->fs_count.p : (int*)nullptr, h->overflow.p);
-        if (count) {
-            SE2_HIP(hipMemcpyAsync(h->h_fs_count.p, h->fs_count.p, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, st));
-            SE2_HIP(hipEventRecord(h->ev_fs, st));
-            h->fs_pending = true;
-            h->fs_frames = nframes;
-        }
     } else {
         for (int l = 0; l <= L; ++l) { g.tile_base[l] = h->score_tile_base[l]; g.lst_base[l] = h->dense_lst_base[l]; }
         g.lst_tw = 4 * kScoreGroups; g.lst_th = kScoreRows; g.lst_cap = kStripCap;
-        SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(F8, g.tile_base[L]), dim3(256), 0, g, h->pyr.p,
-                   h->lst_ent.p, h->lst_cnt.p);
+    }
+    // score / blur of the levels [l0, l1)
+    auto score_levels = [&](int l0, int l1) {
+        const int b0 = g.tile_base[l0], nb = g.tile_base[l1] - b0;
+        if (nb <= 0) return;
+        if (run_sparse)
+            SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score_sparse, dim3(F8, nb), dim3(256), 0, g, h->pyr.p, h->lst_ent.p,
+                       h->lst_cnt.p, count ? h->fs_count.p : (int*)nullptr, h->overflow.p, b0);
+        else
+            SE2_LAUNCH(h->prof, st, "k_fast_score", k_fast_score, dim3(F8, nb), dim3(256), 0, g, h->pyr.p, h->lst_ent.p,
+                       h->lst_cnt.p, b0);
+    };
+    auto blur_levels = [&](int l0, int l1) {
+        const int b0 = gb.tile_base[l0], nb = gb.tile_base[l1] - b0;
+        if (nb > 0) SE2_LAUNCH(h->prof, sb, "k_blur", k_blur, dim3(F8, nb), dim3(256), 0, gb, h->pyr.p, h->blur.p, b0);
+    };
+    // ---- pyramid; in a pipelined batch level l's consumers follow ev_lvl[l].  The small upper levels go out together.
+    const int lgroup = std::min(L, 3);   // levels >= lgroup are scored / blurred by one launch each, after the last resize
+    for (int l = 0; l < L; ++l) {
+        if (l == 0) {
+            dim3 grid(F8, ((g.stride[0] / 16) * (g.h[0] + 2 * kEdge) + 255) / 256);
+            SE2_LAUNCH(h->prof, sp, "k_level0", k_level0, grid, dim3(256), 0, g, d_imgs, pitch, h->pyr.p, h->blur.p);
+        } else {
+            const int ng = g.stride[l] / 4;
+            ResizeTab t{h->tabs.p + h->ytab_off[l], h->tabs.p + h->xtab_off[l], ng};
+            dim3 grid(F8, ((ng + 63) / 64) * ((g.h[l] + 2 * kEdge + 4 * kResizeRows - 1) / (4 * kResizeRows)));
+            SE2_LAUNCH(h->prof, sp, "k_resize", k_resize, grid, dim3(256), 0, g, l, t, h->pyr.p, h->blur.p);
+        }
+        if (!piped) continue;
+        if (l < lgroup || l == L - 1) {
+            SE2_HIP(hipEventRecord(h->ev_lvl[l], sp));
+            SE2_HIP(hipStreamWaitEvent(st, h->ev_lvl[l], 0));
+            SE2_HIP(hipStreamWaitEvent(sb, h->ev_lvl[l], 0));
+            if (l < lgroup) { score_levels(l, l + 1); blur_levels(l, l + 1); }
+            else { score_levels(lgroup, L); blur_levels(lgroup, L); }
+        }
+    }
+    if (!piped) {
+        if (sb != st) {   // (the fork above was recorded before the pyramid: the blur stream must see the pyramid)
+            SE2_HIP(hipEventRecord(h->ev_fork, st));
+            SE2_HIP(hipStreamWaitEvent(sb, h->ev_fork, 0));
+        }
+        blur_levels(0, L);
+        score_levels(0, L);
+    }
+    if (sb != st) SE2_HIP(hipEventRecord(h->ev_join, sb));
+    if (run_sparse && count) {
+        SE2_HIP(hipMemcpyAsync(h->h_fs_count.p, h->fs_count.p, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost, st));
+        SE2_HIP(hipEventRecord(h->ev_fs, st));
+        h->fs_pending = true;
+        h->fs_frames = nframes;
     }
     h->last_lists = g;
     if (g.harris)

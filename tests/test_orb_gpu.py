@@ -188,6 +188,25 @@ def test_batch_sizes_not_a_multiple_of_eight(oracle, synth):
         assert np.array_equal(out[B - 1][0], ko) and np.array_equal(out[B - 1][1], do)
 
 
+def test_pipelined_batches_equal_single_frames(synth, monkeypatch):
+    """batches of 16 frames and more are pipelined by level (pyramid chain on its own stream, score / blur of a level as
+    soon as it exists, orb_run): same features as the serial single-frame sequence, with either score kernel, twice in a
+    row on the same handle (the second batch starts while the first one's key-point chain may still be running)"""
+    from se2lam_amd.orb import ORBextractor
+    one = ORBextractor()
+    for mode in ("dense", "sparse"):
+        monkeypatch.setenv("SE2GPU_ORB_SCORE", mode)
+        ex = ORBextractor(max_batch=20)
+        monkeypatch.delenv("SE2GPU_ORB_SCORE")
+        assert ex.score_kernel()[0] == mode
+        for start in (3, 50):
+            imgs = synth.frames(20, start=start)
+            out = ex.extract_batch(imgs)
+            for b in (0, 7, 8, 19):
+                k, d = one(imgs[b])
+                assert np.array_equal(out[b][0], k) and np.array_equal(out[b][1], d), (mode, start, b)
+
+
 def test_score_kernel_follows_the_candidate_density(oracle, synth):
     """default (auto) mode: the first frame goes through the candidate kernel, which counts the pixels passing its compass
     test; busy imagery (the benchmark texture: ~15 % candidates) switches to the dense kernel, quiet imagery back to the
