@@ -434,10 +434,11 @@ int match_ref_triangulate(int n, const match_ref_keypoint* kps_ref, const match_
         smallest_right_singular_vector(A, v);
         const float w = (float)v[3];
         const float px = (float)v[0] / w, py = (float)v[1] / w, pz = (float)v[2] / w;
-        pos[3 * i] = px; pos[3 * i + 1] = py; pos[3 * i + 2] = pz;
         if (pz >= lower && pz <= upper) {
+            pos[3 * i] = px; pos[3 * i + 1] = py; pos[3 * i + 2] = pz;   // Track.cpp:407-408: only for an accepted depth
             const float q0 = px - Ocam[0], q1 = py - Ocam[1], q2 = pz - Ocam[2];
-            const double dot = (double)px * q0 + (double)py * q1 + (double)pz * q2;
+            const float dotf = px * q0 + py * q1 + pz * q2;   // cv::Point3_<float>::dot: float arithmetic (cvutil.cpp:96)
+            const double dot = (double)dotf;
             const double n1 = std::sqrt((double)px * px + (double)py * py + (double)pz * pz);
             const double n2 = std::sqrt((double)q0 * q0 + (double)q1 * q1 + (double)q2 * q2);
             const float cosp = (float)(std::fabs(dot) / (n1 * n2));

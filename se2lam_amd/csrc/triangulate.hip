@@ -100,13 +100,14 @@ __global__ void k_triangulate(int n, const se2gpu_keypoint* __restrict__ kps_ref
     smallest_right_singular_vector(A, v);
     const float w = (float)v[3];
     const float px = (float)v[0] / w, py = (float)v[1] / w, pz = (float)v[2] / w;
-    pos[3 * i] = px;
-    pos[3 * i + 1] = py;
-    pos[3 * i + 2] = pz;
     if (pz >= lower && pz <= upper) {
+        pos[3 * i] = px;       // mLocalMPs[i] = pos only for an accepted depth (Track.cpp:407-408); zero elsewhere
+        pos[3 * i + 1] = py;
+        pos[3 * i + 2] = pz;
         // checkParallax(o1 = 0, o2 = Ocam, pt3 = pos): |p1 . p2| / (|p1| |p2|) < minCos
         const float q0 = px - ox, q1 = py - oy, q2 = pz - oz;
-        const double dot = (double)px * q0 + (double)py * q1 + (double)pz * q2;           // Point3f::dot accumulates in double
+        const float dotf = px * q0 + py * q1 + pz * q2;                                  // Point3_<float>::dot: float arithmetic
+        const double dot = (double)dotf;                                                 // cv::norm(scalar) = |.| in double
         const double n1 = sqrt((double)px * px + (double)py * py + (double)pz * pz);     // cv::norm(Point3f) in double
         const double n2 = sqrt((double)q0 * q0 + (double)q1 * q1 + (double)q2 * q2);
         const float cosp = (float)(fabs(dot) / (n1 * n2));
@@ -137,6 +138,9 @@ extern "C" int se2gpu_triangulate(int n, const se2gpu_keypoint* kps_ref, const s
     if (n == 0) return SE2GPU_OK;
     SE2_REQUIRE(kps_ref && kps_cur && match_idx && P_ref && P_cur && Ocam && pos_out && good_parallax,
                 SE2GPU_ERR_INVALID, "triangulate: NULL argument");
+    for (int i = 0; i < n; ++i)   // a match that points past the current frame's features is the caller's error, not "no match"
+        SE2_REQUIRE(match_idx[i] < n_cur, SE2GPU_ERR_INVALID, "triangulate: match_idx[%d] = %d but the frame has %d features", i,
+                    match_idx[i], n_cur);
     const float minCos[4] = {0.9998f, 0.9994f, 0.9986f, 0.9976f};   // cvutil.cpp:96
     DevBuf<se2gpu_keypoint> d_k1, d_k2;
     DevBuf<int> d_m, d_cnt;
@@ -185,6 +189,9 @@ extern "C" int se2gpu_track_triangulate(se2gpu_track* h, int n, const se2gpu_key
     if (n == 0) return SE2GPU_OK;
     SE2_REQUIRE(kps_ref && kps_cur && match_idx && P_ref && P_cur && Ocam && pos_out && good_parallax,
                 SE2GPU_ERR_INVALID, "triangulate: NULL argument");
+    for (int i = 0; i < n; ++i)   // a match that points past the current frame's features is the caller's error, not "no match"
+        SE2_REQUIRE(match_idx[i] < n_cur, SE2GPU_ERR_INVALID, "triangulate: match_idx[%d] = %d but the frame has %d features", i,
+                    match_idx[i], n_cur);
     const float minCos[4] = {0.9998f, 0.9994f, 0.9986f, 0.9976f};   // cvutil.cpp:96
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     // input  [kps_ref | kps_cur | match_idx | has_obs | P (24 floats)], output [pos | match_idx | counters | good]

@@ -5,12 +5,14 @@ sum J^T W J in a different order than the oracle, so FP64 results agree to ~1e-1
 linearisation and to ~1e-9 after 10 LM iterations; the asserted bounds are the 1e-5 of the
 north star or tighter.
 """
+import os
 import threading
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 REL = 1e-5
 
@@ -574,3 +576,29 @@ def test_load_local_graph_pod_call(synth, oracle):
         # fixed vertices did not move
         for i in np.nonzero(fixed)[0]:
             assert np.array_equal(op.estimateVertexSE2(pod, int(i)), twb[i].astype(np.float64))
+
+
+def test_dataflow_timeout_falls_back_to_the_column_launches(synth):
+    """k_chol_tiles makes progress only while workgroups are dispatched in task order.  Should that ever
+    fail, a dependency spin times out after 2 s - and the run must go on with k_chol_step instead of ending localBA with
+    an error.  SE2GPU_BA_CHOL_FAULT=1 (read once per process, hence the child) launches the first dataflow solve without
+    its first task; the child's histories must equal an undisturbed run's."""
+    import json
+    import subprocess
+    import sys
+    code = ("import json, sys; sys.path.insert(0, %r)\n"
+            "from se2lam_amd import synth\n"
+            "from se2lam_amd.optimizer import SlamOptimizer\n"
+            "g = synth.ba_graph(20, 600)\n"
+            "o = SlamOptimizer(); o.load(g); o.initializeOptimization(0); o.optimize(6)\n"
+            "print(json.dumps({'chi2': o.stats['chi2_hist'], 'trials': o.stats['trials_hist']}))\n") % ROOT
+    env = dict(os.environ)
+    env["SE2GPU_BA_CHOL_FAULT"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "k_chol_tiles timed out; continuing with k_chol_step" in r.stderr
+    got = json.loads(r.stdout.strip().splitlines()[-1])
+    ref = _opt(synth.ba_graph(20, 600))
+    ref.optimize(6)
+    assert got["trials"] == ref.stats["trials_hist"]
+    assert np.allclose(got["chi2"], ref.stats["chi2_hist"], rtol=1e-9)

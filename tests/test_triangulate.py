@@ -41,12 +41,18 @@ def test_oracle_recovers_points_and_gates(oracle):
     pos, good, m, ng, nold = oracle.triangulate(k1, k2, match, has_obs, P1, P2, Ocam, lower, upper, 2)
     done = (match >= 0) & (has_obs == 0)
     assert nold == int(((match >= 0) & (has_obs == 1)).sum())
-    err = np.abs(pos[done] - X[done]).max(axis=1) / X[done, 2]
+    # Config::acceptDepth: a point is kept (mLocalMPs[i] = pos, Track.cpp:407-408) only inside [lower, upper]; outside, the
+    # match is dropped and the position stays untouched (zero here).  Points within 1 % of a bound may fall either way.
+    clear = (np.abs(X[:, 2] - lower) > 0.01 * lower) & (np.abs(X[:, 2] - upper) > 0.01 * upper)
+    inside = (X[:, 2] >= lower) & (X[:, 2] <= upper)
+    acc = done & (m >= 0)
+    assert np.array_equal(acc[clear & done], inside[clear & done])
+    err = np.abs(pos[acc] - X[acc]).max(axis=1) / X[acc, 2]
     assert err.max() < 2e-3                                     # float pixel coordinates: ~1e-4 of the depth
-    inside = (pos[:, 2] >= lower) & (pos[:, 2] <= upper)
-    assert np.array_equal(m[done & ~inside], np.full((done & ~inside).sum(), -1, np.int32))
-    assert np.array_equal(m[done & inside], match[done & inside])
+    assert not pos[~acc].any()
+    assert np.array_equal(m[acc], match[acc])
     assert np.array_equal(m[~done], match[~done])
+    inside = acc
     # parallax: cos of the angle at the point between the two camera centres < 0.9994 (2 degrees)
     p1, p2 = pos, pos - Ocam
     cosp = np.abs((p1 * p2).sum(1)) / (np.linalg.norm(p1, axis=1) * np.linalg.norm(p2, axis=1) + 1e-30)
@@ -85,3 +91,19 @@ def test_hip_track_workspace_triangulate_equals_oracle(oracle):
             assert got[3:] == ref[3:]
     got = tr.doTriangulate(k1[:0], k2, match[:0], None, P1, P2, Ocam, 500.0, 8000.0)
     assert len(got[0]) == 0 and got[3] == 0
+
+
+@pytest.mark.gpu
+def test_match_past_the_current_frame_is_an_error(oracle):
+    """a match index >= the current frame's feature count is a caller error (ERR_INVALID), not "no match" - both entry
+    points; the reference would read past keyPointsUn there"""
+    from se2lam_amd import capi
+    from se2lam_amd.matcher import doTriangulate
+    from se2lam_amd.track import Track
+    k1, k2, match, has_obs, P1, P2, Ocam, X = scene(50, 2)
+    bad = match.copy()
+    bad[np.nonzero(bad >= 0)[0][3]] = len(k2)
+    for fn in (doTriangulate, Track().doTriangulate):
+        with pytest.raises(capi.Se2GpuError) as e:
+            fn(k1, k2, bad, has_obs, P1, P2, Ocam, 500.0, 8000.0, 2)
+        assert e.value.code == capi.ERR_INVALID
