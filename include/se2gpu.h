@@ -390,9 +390,16 @@ int se2gpu_ba_edge_information(int E, const float* lc, const float* lw, const in
  * aliases the buffer).  The fused buffer is [S (3P*3P) | bs (3P) | 4 scalars]; a second call
  * reduces the 4 trial scalars.  If `buffer` is non-NULL it must be a device allocation of at least
  * se2gpu_ba_reduce_buffer_doubles(h) doubles, used instead of an internal one (so the caller can
- * alias it with its own tensor). */
+ * alias it with its own tensor).
+ * Without a caller buffer the big exchange ships only what the dense solver reads: of row r of [S; bs^T] (r = 0 .. 3P)
+ * the columns [0, 32 (r / 32 + 1)) - the lower-triangular 32 x 32 tiles and the rhs row - packed back to back;
+ * se2gpu_ba_exchange_row gives the offset and length of a row in that packed buffer (host function, no device needed) and
+ * se2gpu_ba_exchange_doubles(P) its total size.  With a caller buffer the rows 0 .. 3P of the rectangle are reduced in
+ * place. */
 typedef int (*se2gpu_allreduce_fn)(void* dev_ptr, size_t count_doubles, void* hip_stream, void* user);
 size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba* h, int P);
+size_t se2gpu_ba_exchange_doubles(int P);
+int se2gpu_ba_exchange_row(int row, size_t* offset, int* length);
 int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, void* buffer);
 /* This handle holds landmark shard `rank` of `world` (rank 0 owns the odometry edges and the
  * lambda*I / fixed-pose identity terms, which must enter the sum exactly once). */

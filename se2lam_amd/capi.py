@@ -154,6 +154,8 @@ SYMBOLS = {
     "se2gpu_track_triangulate": (_I, [_VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _I, _VP, _VP,
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se2gpu_ba_reduce_buffer_doubles": (_SZ, [_VP, _I]),
+    "se2gpu_ba_exchange_doubles": (_SZ, [_I]),
+    "se2gpu_ba_exchange_row": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "se2gpu_ba_set_allreduce": (_I, [_VP, ALLREDUCE_FN, _VP, _VP]),
     "se2gpu_ba_set_shard": (_I, [_VP, _I, _I]),
     "se2gpu_comm_unique_id": (_I, [_VP]),

@@ -4624,6 +4624,15 @@ size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba*, int P) {
     return ld * ld + 4;
 }
 
+size_t se2gpu_ba_exchange_doubles(int P) { return tri_row_off(3 * P + 1); }
+
+int se2gpu_ba_exchange_row(int row, size_t* offset, int* length) {
+    SE2_REQUIRE(row >= 0 && offset && length, SE2GPU_ERR_INVALID, "exchange_row: bad argument");
+    *offset = tri_row_off(row);
+    *length = kNB * (row / kNB + 1);
+    return SE2GPU_OK;
+}
+
 int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, void* buffer) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE, "set_allreduce must precede initialize");

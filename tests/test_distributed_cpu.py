@@ -4,7 +4,9 @@ There is no GPU here and the library has no CPU fallback, so the per-shard arith
 exercised is everything around it that the N>1 bench path relies on: the library's host-side partitioner, the fused
 buffer layout [augmented (ld x ld): rows 0..n-1 = S, row n = b | 4 scalars] of se2gpu_ba_reduce_buffer_doubles, the
 "rank 0 owns lambda*I / identity / odometry" rule, one torch.distributed all_reduce(SUM) of the buffer, the redundant
-per-rank solve, and the max-through-sum slot trick used for lambda_0."""
+per-rank solve, and the max-through-sum slot trick used for lambda_0.  The big exchange goes through the PACKED layout the
+library ships (se2gpu_ba_exchange_row: of row r the columns up to the end of its diagonal 32 x 32 tile); the solve that
+follows reads only the lower triangle, as the device solver does."""
 import os
 import socket
 
@@ -31,7 +33,7 @@ def _worker(rank, world, port, out_dir):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from se2lam_amd import capi, optimizer, synth
     from oracle import oracle
-    g = synth.ba_graph(10, 120)
+    g = synth.ba_graph(25, 300)
     lam = 2.5
     own = optimizer.shard_landmarks(g.L, g.e_kf, g.e_lm, world)       # library partitioner (host code)
     assert np.array_equal(own, synth.shard_landmarks(g.e_kf, g.e_lm, g.L, world))
@@ -51,14 +53,32 @@ def _worker(rank, world, port, out_dir):
     A[n, :n] = bs
     buf[ld * ld + 0] = float(rank + 1)                                # trial scalars ride in the tail
     t = torch.from_numpy(buf)
-    dist.all_reduce(t[:(n + 1) * ld])                                 # the big exchange: rows 0..n
+    # the big exchange, packed as k_tri_pack does it: row r -> [offset(r), offset(r) + 32 (r // 32 + 1))
+    import ctypes as C
+    count = int(capi.lib().se2gpu_ba_exchange_doubles(g.P))
+    packed = np.zeros(count)
+    rows = []
+    for r in range(n + 1):
+        off, ln = C.c_size_t(0), C.c_int(0)
+        capi.check(capi.lib().se2gpu_ba_exchange_row(r, C.byref(off), C.byref(ln)))
+        assert ln.value == 32 * (r // 32 + 1) and (not rows or off.value == rows[-1][0] + rows[-1][1])   # back to back
+        rows.append((off.value, ln.value))
+        packed[off.value:off.value + ln.value] = A[r, :ln.value]
+    assert rows[-1][0] + rows[-1][1] == count and count < 0.75 * (n + 1) * ld   # three tile rows: 2/3 of the rectangle
+    if rank:                                                          # what is not shipped stays local garbage
+        A[np.triu_indices(ld, 32)] = np.nan
+    tp = torch.from_numpy(packed)
+    dist.all_reduce(tp)
+    for r, (off, ln) in enumerate(rows):
+        A[r, :ln] = packed[off:off + ln]
     dist.all_reduce(t[ld * ld:])                                      # the 4-scalar exchange
-    x = np.linalg.solve(A[:n, :n], A[n, :n])                          # every rank solves redundantly
+    Sl = np.tril(A[:n, :n])                                           # the solver reads the lower triangle only
+    x = np.linalg.solve(Sl + np.tril(Sl, -1).T, A[n, :n])             # every rank solves redundantly
     # max over ranks through SUM: each rank deposits its local value in its own slot
     slots = torch.zeros(world, dtype=torch.float64)
     slots[rank] = float(np.abs(np.diagonal(part["Hll"], axis1=1, axis2=2)).max())
     dist.all_reduce(slots)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, S=A[:n, :n], bs=A[n, :n], tail=buf[ld * ld:],
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, S=Sl + np.tril(Sl, -1).T, bs=A[n, :n], tail=buf[ld * ld:],
              maxd=float(slots.max()))
     dist.barrier()
     dist.destroy_process_group()
@@ -71,7 +91,7 @@ def test_two_rank_sharded_reduction_gloo(tmp_path):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     from se2lam_amd import synth
     from oracle import oracle
-    g = synth.ba_graph(10, 120)
+    g = synth.ba_graph(25, 300)
     full = oracle.ba_reduced_system(g, 2.5)
     x_full = np.linalg.solve(full["S"], full["bs"])
     r0 = np.load(tmp_path / "rank0.npz")
