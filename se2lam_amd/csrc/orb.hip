@@ -700,60 +700,123 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
     const int tc0 = (xa - kEdge) / g.lst_tw, tc1 = (xb - 1 - kEdge) / g.lst_tw;
     const int tr0 = (ya - kEdge) / g.lst_th, tr1 = (yb - 1 - kEdge) / g.lst_th;
     const int ntc = tc1 - tc0 + 1;
-    const int nl = (cw > 0 && ch > 0) ? min(ntc * (tr1 - tr0 + 1), kMaxListsPerCell) : 0;   // orb_configure checks the bound
-    if ((int)threadIdx.x < 64) {   // wave 0: counts -> exclusive prefix
-        const int k = threadIdx.x;
-        int c = 0;
-        if (k < nl) {
-            const unsigned id = (unsigned)(g.lst_base[l] + (tr0 + k / ntc) * ltx + tc0 + k % ntc);
-            s_lst[k] = id;
-            c = lst_cnt[(size_t)f * g.lst_base[g.nlevels] + id];
-        }
-        int incl = c;
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d);
-            if (k >= d) incl += v;
-        }
-        s_off[k + 1] = incl;
-        if (k == 0) s_off[0] = 0;
-    }
-    __syncthreads();
-    {
-        const int total = s_off[nl];
-        const uint2* ebase = lst_ent + (size_t)f * g.lst_base[g.nlevels] * g.lst_cap;
-        for (int e = threadIdx.x; e < total; e += 256) {
-            int k = 0;
-            while (s_off[k + 1] <= e) ++k;
-            const uint2 en = ebase[(size_t)s_lst[k] * g.lst_cap + (e - s_off[k])];
-            const int y = (int)(en.x >> 12), x0 = (int)(en.x & 0xfffu);
-            if (y < ya || y >= yb) continue;
+    const int nl_all = (cw > 0 && ch > 0) ? ntc * (tr1 - tr0 + 1) : 0;
+    const uint2* ebase = lst_ent + (size_t)f * g.lst_base[g.nlevels] * g.lst_cap;
+    // every candidate of the cell, kMaxListsPerCell lists at a time (one round for ordinary cells; a 600 x 300 cell of a
+    // 150-feature extractor takes two).  All threads call it together (it contains barriers).
+    auto walk = [&](auto&& visit) {
+        for (int k0 = 0; k0 < nl_all; k0 += kMaxListsPerCell) {
+            const int nl = min(nl_all - k0, kMaxListsPerCell);
+            __syncthreads();   // (the table of the previous round has been consumed; the counters are initialised)
+            if ((int)threadIdx.x < 64) {   // wave 0: counts -> exclusive prefix
+                const int k = threadIdx.x;
+                int c = 0;
+                if (k < nl) {
+                    const int kk = k0 + k;
+                    const unsigned id = (unsigned)(g.lst_base[l] + (tr0 + kk / ntc) * ltx + tc0 + kk % ntc);
+                    s_lst[k] = id;
+                    c = lst_cnt[(size_t)f * g.lst_base[g.nlevels] + id];
+                }
+                int incl = c;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int v = __shfl_up(incl, d);
+                    if (k >= d) incl += v;
+                }
+                s_off[k + 1] = incl;
+                if (k == 0) s_off[0] = 0;
+            }
+            __syncthreads();
+            const int total = s_off[nl];
+            for (int e = threadIdx.x; e < total; e += 256) {
+                int k = 0;
+                while (s_off[k + 1] <= e) ++k;
+                const uint2 en = ebase[(size_t)s_lst[k] * g.lst_cap + (e - s_off[k])];
+                const int y = (int)(en.x >> 12), x0 = (int)(en.x & 0xfffu);
+                if (y < ya || y >= yb) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int sc = (int)((en.y >> (8 * q)) & 0xffu);
-                const int x = x0 + q;
-                if (sc == 0 || x < xa || x >= xb) continue;
-                const uint32_t key = ((uint32_t)(255 - sc) << 24) | ((uint32_t)y << 12) | (uint32_t)x;
-                if (sc > g.fast_th) {
-                    const int slot = atomicAdd(&s_n20, 1);
-                    if (slot < kSortCap) keys[slot] = key;
-                } else {
-                    const int slot = atomicAdd(&s_nw, 1);
-                    if (slot < kSortCap) keys[kSortCap - 1 - slot] = key;
+                for (int q = 0; q < 4; ++q) {
+                    const int sc = (int)((en.y >> (8 * q)) & 0xffu);
+                    const int x = x0 + q;
+                    if (sc == 0 || x < xa || x >= xb) continue;
+                    visit(sc, ((uint32_t)(255 - sc) << 24) | ((uint32_t)y << 12) | (uint32_t)x);
                 }
             }
         }
-    }
+    };
+    walk([&](int sc, uint32_t key) {
+        if (sc > g.fast_th) {
+            const int slot = atomicAdd(&s_n20, 1);
+            if (slot < kSortCap) keys[slot] = key;
+        } else {
+            const int slot = atomicAdd(&s_nw, 1);
+            if (slot < kSortCap) keys[kSortCap - 1 - slot] = key;
+        }
+    });
     __syncthreads();
     // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 keypoints, FAST(7).  The thr-20 corners
     // sort before all others (key = 255 - S first), so when they are taken the others never need sorting at all.
     const int n20 = s_n20, nw = s_nw;
-    if (n20 + nw > kSortCap) {   // front and back ran into each other
-        if (threadIdx.x == 0) atomicOr(overflow, 1);
-        if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
-        return;
-    }
     int n = n20;
-    if (n20 <= 3) {
+    int total = n20 > 3 ? n20 : n20 + nw;   // what cv::FAST returns for the cell: the quota logic needs the true count
+    const bool too_many = n20 + nw > kSortCap;   // front and back ran into each other (a huge cell full of corners)
+    if (too_many) {
+        // Only the min(total, cell_cap) best by score can be retained, so everything below the score that bounds them
+        // drops out before the sort: histogram of the scores, cut, second collection.  (Harris retains by another
+        // response: there the overflow stays an error.)
+        __shared__ int hist[256];
+        __shared__ int s_cut, s_cnt;
+        if (HARRIS) {
+            if (threadIdx.x == 0) atomicOr(overflow, 1);
+            if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
+            return;
+        }
+        hist[threadIdx.x] = 0;
+        walk([&](int sc, uint32_t) { atomicAdd(&hist[sc], 1); });
+        __syncthreads();
+        __shared__ int s_need_ties, s_yc;
+        if (threadIdx.x == 0) {
+            const int lo = n20 > 3 ? g.fast_th + 1 : 8, need = min(total, g.cell_cap);
+            int cut = 255, above = 0;                 // above = candidates with a score > cut
+            while (cut > lo && above + hist[cut] < need) above += hist[cut--];
+            s_cut = cut;
+            s_cnt = above + hist[cut];
+            s_need_ties = need - above;
+            s_yc = 0x7fffffff;
+            s_n20 = 0;
+        }
+        __syncthreads();
+        const int cut = s_cut;
+        if (s_cnt > kSortCap) {
+            // flat imagery: thousands of corners share the bounding score.  Of those only the first few in key order
+            // (row, then column) can be retained: a histogram over the rows of the cell (in keys[], free at this point)
+            // gives the last row that is needed.
+            for (int i = threadIdx.x; i < ch; i += 256) keys[i] = 0;
+            walk([&](int sc, uint32_t key) {
+                if (sc == cut) atomicAdd(&keys[(int)((key >> 12) & 0xfffu) - ya], 1u);
+            });
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int cum = 0, r = 0;
+                while (r < ch && cum + (int)keys[r] < s_need_ties) cum += (int)keys[r++];
+                cum += r < ch ? (int)keys[r] : 0;
+                s_yc = ya + r;
+                s_cnt = s_cnt - hist[cut] + cum;
+            }
+            __syncthreads();
+        }
+        n = s_cnt;
+        const int yc = s_yc;
+        if (n > kSortCap) {   // (a single row of one score beyond the buffer: cannot happen below 8192 columns)
+            if (threadIdx.x == 0) atomicOr(overflow, 1);
+            if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
+            return;
+        }
+        __syncthreads();
+        walk([&](int sc, uint32_t key) {
+            if (sc > cut || (sc == cut && (int)((key >> 12) & 0xfffu) <= yc)) keys[atomicAdd(&s_n20, 1)] = key;
+        });
+        __syncthreads();
+    } else if (n20 <= 3) {
         uint32_t mv[kSortCap / 256];   // source and destination ranges may overlap: through registers
 #pragma unroll
         for (int u = 0; u < kSortCap / 256; ++u) {
@@ -774,7 +837,7 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
     // the bitonic network below costs ~30 barrier-separated stages for the same job.
     constexpr int kRankMax = 768;
     if (!HARRIS && n <= kRankMax) {
-        const int totalr = n;
+        const int totalr = total;
         const int keepr = min(totalr, g.cell_cap);
         uint32_t* outk = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
         float* outf = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
@@ -806,7 +869,6 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
             }
             __syncthreads();
         }
-    const int total = n;
     const int keep = min(total, g.cell_cap);
     uint32_t* out = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
     float* outr = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
@@ -1382,11 +1444,6 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         if (l == 0) h->dense_lst_base[0] = h->sparse_lst_base[0] = 0;
         h->dense_lst_base[l + 1] = h->dense_lst_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + kScoreRows - 1) / kScoreRows);
         h->sparse_lst_base[l + 1] = h->sparse_tile_base[l + 1];
-        // lists one cell can meet (k_cell_detect gathers them through a 64-entry table)
-        const int per_cell = std::max(((g.cellW[l] + 4 * kScoreGroups - 2) / (4 * kScoreGroups) + 1) * ((g.cellH[l] + kScoreRows - 2) / kScoreRows + 1),
-                                      ((g.cellW[l] + kFsTW - 2) / kFsTW + 1) * ((g.cellH[l] + kFsTH - 2) / kFsTH + 1));
-        SE2_REQUIRE(per_cell <= kMaxListsPerCell, SE2GPU_ERR_INVALID, "level %d: a %dx%d cell meets %d candidate lists (max %d)", l,
-                    g.cellW[l], g.cellH[l], per_cell, kMaxListsPerCell);
     }
     // resize tables
     std::vector<int4> tabs;

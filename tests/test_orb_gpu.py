@@ -231,3 +231,19 @@ def test_score_kernel_follows_the_candidate_density(oracle, synth):
         k, d = ex(busy)
         assert np.array_equal(k, ko) and np.array_equal(d, do)
     assert ex.score_kernel()[0] == "dense"
+
+
+def test_huge_cells_full_of_corners(oracle):
+    """few features on a large, busy image: one cell per level (e.g. 768 x 568 pixels at level 0) meets more than 64
+    candidate lists and holds far more FAST corners than its sort buffer (4096) - the cell then keeps only the candidates
+    at or above the score that bounds its quota (histogram cut) instead of failing; results equal the oracle's"""
+    from se2lam_amd.orb import ORBextractor
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (600, 800)).astype(np.uint8)
+    smooth = (0.5 * noise + 0.5 * np.roll(noise, 1, 1)).astype(np.uint8)
+    for img, nf, nl in ((noise, 150, 4), (smooth, 150, 4), (noise[:368, :], 150, 6)):
+        ex = ORBextractor(nfeatures=nf, nlevels=nl, max_rows=img.shape[0], max_cols=img.shape[1])
+        k, d = ex(np.ascontiguousarray(img))
+        ko, do = oracle.orb_extract(np.ascontiguousarray(img), oracle.orb_params(nfeatures=nf, nlevels=nl))
+        assert len(ko) > 0 and np.array_equal(k, ko) and np.array_equal(d, do)
+        assert int((ex.debug_score(0, 0) > 0).sum()) > 4096        # the cell's sort buffer is far too small for all of them
