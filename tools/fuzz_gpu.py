@@ -21,9 +21,96 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 tex = synth.texture()
 ncase = 0
+from se2lam_amd import optimizer as op  # noqa: E402
+from se2lam_amd.matcher import ORBmatcher  # noqa: E402
+from se2lam_amd.track import Track  # noqa: E402
+
+feat_cache = {}
+track = Track()
+
+
+def feats(t):
+    if t not in feat_cache:
+        feat_cache[t] = oracle.orb_extract(synth.frame(t))
+    return feat_cache[t]
+
+
+def fail(msg):
+    print(msg + " MISMATCH")
+    sys.exit(1)
+
+
 while time.time() < t_end:
     ncase += 1
-    if ncase % 2:
+    kind = ncase % 6
+    if kind == 2:   # MatchByWindow on feature subsets / windows / ratios, chained vbPrevMatched
+        a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+        (k1, d1), (k2, d2) = feats(a), feats(b)
+        n1, n2 = int(rng.integers(0, len(k1) + 1)), int(rng.integers(0, len(k2) + 1))
+        s1, s2 = np.sort(rng.choice(len(k1), n1, replace=False)), np.sort(rng.choice(len(k2), n2, replace=False))
+        k1, d1, k2, d2 = k1[s1], np.ascontiguousarray(d1[s1]), k2[s2], np.ascontiguousarray(d2[s2])
+        win, lo = int(rng.choice([5, 12, 20, 45, 90])), int(rng.integers(0, 3))
+        mn = int(rng.integers(0, 3)); mx = int(rng.integers(mn + 1, 9)); ratio = float(rng.choice([0.6, 0.75, 0.9, 1.0]))
+        prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
+        try:
+            nm, m12 = ORBmatcher(ratio).MatchByWindow(k1, d1, k2, d2, prev, win, lo, mn, mx)
+        except Exception as e:   # documented capacity: 128 candidates per search window (the reference's callers use 15 / 20 px)
+            if "more than 128 candidates" in str(e) and win >= 45:
+                print(f"match frames {a}->{b} n {n1}x{n2} win {win}: refused (window capacity)")
+                continue
+            raise
+        m_ref, nm_ref, p_ref = oracle.match_window(k1, d1, k2, d2, None, win, lo, mn, mx, ratio)
+        ok = nm == nm_ref and np.array_equal(m12, m_ref) and np.array_equal(prev, p_ref)
+        print(f"match frames {a}->{b} n {n1}x{n2} win {win} levels {mn}..{mx} ratio {ratio}: {nm} matches {'ok' if ok else ''}")
+        if not ok:
+            fail("match")
+        continue
+    if kind == 3:   # findFundamentalMat masks
+        n = int(rng.choice([0, 5, 7, 8, 12, 15, 16, 40, 300, 1000]))
+        X = np.stack([rng.uniform(-3000, 3000, n), rng.uniform(-2000, 2000, n), rng.uniform(3000, 9000, n)], 1)
+        K = np.array([[400, 0, 320], [0, 400, 240], [0, 0, 1.0]])
+        th = rng.uniform(-0.08, 0.08)
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        tt = rng.uniform(-300, 300, 3)
+        uv1 = X @ K.T; uv2 = (X @ R.T + tt) @ K.T
+        p1 = (uv1[:, :2] / uv1[:, 2:] + rng.normal(0, 0.5, (n, 2))).astype(np.float32) if n else np.zeros((0, 2), np.float32)
+        p2 = (uv2[:, :2] / uv2[:, 2:] + rng.normal(0, 0.5, (n, 2))).astype(np.float32) if n else np.zeros((0, 2), np.float32)
+        out = rng.random(n) < rng.uniform(0, 0.7)
+        p2[out] += rng.uniform(-80, 80, (int(out.sum()), 2)).astype(np.float32)
+        mask, ni = track.findFundamentalMat(p1, p2)
+        mask_ref, ni_ref = oracle.fundamental_mask(p1, p2)
+        ok = ni == ni_ref and np.array_equal(mask, mask_ref)
+        print(f"ransac n {n}: {ni} inliers {'ok' if ok else ''}")
+        if not ok:
+            fail("ransac")
+        continue
+    if kind == 4:   # marginalising SE3-expmap window
+        P = int(rng.integers(3, 40)); L = int(rng.integers(2 * P, 30 * P)); nref = int(rng.integers(0, min(4, P - 2) + 1))
+        g = synth.ba3_graph(P, L, nref, seed=int(rng.integers(1, 10**6)))
+        o = op.SlamOptimizer(); op.load_se3_graph(o, g); o.initializeOptimization(0)
+        iters = int(rng.integers(1, 11))
+        o.optimize(iters)
+        st = oracle.ba3_optimize(g, iters)[3]
+        s_ = o.stats
+        ok = s_["trials_hist"] == st["trials_hist"] and np.allclose(s_["chi2_hist"], st["chi2_hist"], rtol=1e-5, atol=0)
+        print(f"ba3  P {P} L {L} ref {nref} E {g.E} iters {iters}: trials {s_['trials_hist']} {'ok' if ok else ''}")
+        if not ok:
+            fail("ba3")
+        continue
+    if kind == 5:   # pose graph
+        P = int(rng.integers(3, 120))
+        g = synth.pose_graph(P, seed=int(rng.integers(1, 10**6)))
+        o = op.SlamOptimizer(); op.load_pose_graph(o, g); o.initializeOptimization(0)
+        iters = int(rng.integers(1, 11))
+        o.optimize(iters)
+        st = oracle.pg_optimize(g, iters)[2]
+        s_ = o.stats
+        ok = s_["trials_hist"] == st["trials_hist"] and np.allclose(s_["chi2_hist"], st["chi2_hist"], rtol=1e-5, atol=0)
+        print(f"pg   P {P} edges {g.O} iters {iters}: trials {s_['trials_hist']} {'ok' if ok else ''}")
+        if not ok:
+            fail("pg")
+        continue
+    if kind == 1:
         W, H = int(rng.integers(160, 900)), int(rng.integers(120, 700))
         nf = int(rng.choice([150, 500, 1000, 2000]))
         nl = int(rng.integers(1, 9))
