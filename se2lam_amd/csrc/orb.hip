@@ -1251,11 +1251,15 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
                                                    int cap, const float* __restrict__ angles,
                                                    const float2* __restrict__ cs,
                                                    se2gpu_keypoint* __restrict__ kps, uint8_t* __restrict__ desc) {
-    // One wave handles TWO key points: the per-wave work is a short dependent chain (key point -> 8 byte gathers per
-    // lane -> 4 ballots), so the kernel is bound by how many such chains are in flight; two per wave keep 16
-    // independent gathers per lane outstanding with half the waves.
+    // One wave handles TWO key points.  The 512 sample bytes of a key point lie within 18.4 px of it (the farthest pattern
+    // point, whatever the rotation): the wave first copies the 39 x 40 byte patch around the key point from the blurred
+    // level into LDS with dword loads (7 per lane instead of 8 scattered byte gathers, each of which costs the texture
+    // path a pass per lane), then gathers the bytes there.  The patch region is private to the wave: no barrier.
+    constexpr int kPR = 19, kPW = 40, kPH = 2 * kPR + 1;                 // rows -19 .. 19, columns -20 .. 19
+    __shared__ uint32_t patch[8][kPH * (kPW / 4)];
     SE2_FRAME_GRID(f, bx);
-    const int k0 = 2 * (bx * 4 + threadIdx.x / 64);
+    const int wv = threadIdx.x / 64;
+    const int k0 = 2 * (bx * 4 + wv);
     const int lane = threadIdx.x & 63;
     const int n = counts[f];
     if (k0 >= n) return;  // wave-uniform
@@ -1270,12 +1274,30 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
         ang[u] = angles[(size_t)f * cap + k];
         ab[u] = cs[(size_t)f * cap + k];
     }
+    constexpr int kPD = kPH * (kPW / 4);                                   // 390 dwords per patch
+    uint32_t pv[2][(kPD + 63) / 64];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int stride = g.stride[kp[u].x];
+        const uint8_t* center = blur + pix(g, f, kp[u].x, kp[u].z, kp[u].y);
+#pragma unroll
+        for (int i = 0; i < (kPD + 63) / 64; ++i) {
+            const int e = min(lane + 64 * i, kPD - 1);
+            const int row = e / (kPW / 4), col = e - row * (kPW / 4);
+            const uint8_t* p = center + (ptrdiff_t)(row - kPR) * stride + (4 * col - kPW / 2);
+            pv[u][i] = *reinterpret_cast<const uint32_t*>(p);              // (unaligned) dword, as in k_orientation
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < (kPD + 63) / 64; ++i)
+            if (lane + 64 * i < kPD) patch[2 * wv + u][lane + 64 * i] = pv[u][i];
     int t0[2][4], t1[2][4];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const float a = ab[u].x, b = ab[u].y;
-        const int stride = g.stride[kp[u].x];
-        const uint8_t* center = blur + pix(g, f, kp[u].x, kp[u].z, kp[u].y);
+        const uint8_t* pc = reinterpret_cast<const uint8_t*>(patch[2 * wv + u]) + kPR * kPW + kPW / 2;   // the key point
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int pw = reinterpret_cast<const int*>(c_pattern)[64 * q + lane];   // the 4 pattern bytes in one load
@@ -1283,8 +1305,8 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
             const float x1 = (float)(signed char)((pw >> 16) & 0xff), y1 = (float)(signed char)((pw >> 24) & 0xff);
             const int r0 = (int)rintf(x0 * b + y0 * a), c0 = (int)rintf(x0 * a - y0 * b);
             const int r1 = (int)rintf(x1 * b + y1 * a), c1 = (int)rintf(x1 * a - y1 * b);
-            t0[u][q] = center[r0 * stride + c0];
-            t1[u][q] = center[r1 * stride + c1];
+            t0[u][q] = pc[r0 * kPW + c0];
+            t1[u][q] = pc[r1 * kPW + c1];
         }
     }
 #pragma unroll
