@@ -53,6 +53,7 @@ struct CamDev {
 // the estimate, the damping, whether this trial is a retry on the same linearisation, whether the run is over) and the
 // last kernel of the trial (k_finalize / k_lm_decide) advances it with g2o's policy.  The host only enqueues trial
 // "slots" and reads the block back once per optimize() call - no host round trip between trials.
+constexpr int kMailSeq = 4;   // mailbox word of the device-side slot counter (BaCtl::seq)
 struct BaCtl {
     double lambda, ni, current_chi, rho;
     double chi2_init, chi2_final;
@@ -62,6 +63,10 @@ struct BaCtl {
     int mode, error, pad;
     double chi2_hist[64], lambda_hist[64];
     int trials_hist[64];
+    // survive k_ctl_init (and, like sel, say something about the handle rather than about one run):
+    double seq;       // trial slots finished so far; posted next to the block (mail[kMailSeq]) - the host mirrors the count
+    unsigned epoch;   // dense solves so far = the value the tile flags of k_chol_tiles are compared with
+    unsigned pad2;
 };
 
 __host__ __device__ inline double normalize_theta(double theta) {
@@ -340,7 +345,9 @@ __global__ void k_odometry(int O, const int* __restrict__ o_i, const int* __rest
                            const double* __restrict__ o_meas, const double* __restrict__ o_info,
                            const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
                            double* __restrict__ Oii, double* __restrict__ Ojj, double* __restrict__ Oij,
-                           double* __restrict__ obi, double* __restrict__ obj) {
+                           double* __restrict__ obi, double* __restrict__ obj, const BaCtl* __restrict__ ctl,
+                           const double* __restrict__ poses_b) {
+    if (ctl && ctl->sel) poses = poses_b;   // (poses = the "a" buffer then: the controller says which holds the estimate)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= O) return;
     const int i = o_i[k], j = o_j[k];
@@ -508,7 +515,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                                                      const int* __restrict__ o_j, const double* __restrict__ o_meas,
                                                      const double* __restrict__ o_info, const double* __restrict__ poses,
                                                      double* __restrict__ S, double* __restrict__ bp,
-                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b) {
+                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                     unsigned* __restrict__ epoch) {
     if (ctl) {
         if (ctl->done) return;
         if (ctl->sel) poses = poses_b;
@@ -592,7 +600,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
     double* __restrict__ bs = S + (size_t)n * ld;
     if (p == P) {
         for (size_t t = (size_t)n * ld + n + threadIdx.x; t < (size_t)ld * ld; t += kBlock) S[t] = 0.0;
-        if (threadIdx.x == 0) S[(size_t)ld * ld + 2] = 0.0;  // factorisation flag of the solve that follows
+        if (threadIdx.x == 0) {
+            S[(size_t)ld * ld + 2] = 0.0;  // factorisation flag of the solve that follows
+            *epoch += 1u;                   // ... and its epoch (the tile flags of k_chol_tiles are compared with it)
+        }
         return;
     }
     double acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // S diag (6 sym), bp (3), g (3)
@@ -941,9 +952,10 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
                                                      double* __restrict__ R, double* __restrict__ RM, int ld, int n,
                                                      int nbc, const int2* __restrict__ tasks,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
-                                                     unsigned epoch, double* __restrict__ fail,
+                                                     const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl) {
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
+    const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     __shared__ __attribute__((aligned(16))) double Ta[kNB][kNB + 2];  // MR(i,m), then the finished tile T
     __shared__ __attribute__((aligned(16))) double Tb[kNB][kNB + 2];  // M(j,m),  then the finished diagonal D
     __shared__ __attribute__((aligned(16))) double Tc[kNB][kNB + 2];  // MR(j,m)
@@ -1410,6 +1422,25 @@ __device__ inline void post_ctl(const BaCtl* c, volatile double* mail, double se
     for (int i = tid; i < kWords; i += nthr) mail[8 + i] = src[i];
 }
 
+// One trial slot has finished (or was skipped because the run is over): the device-side slot counter moves on and, when
+// asked for, the controller block goes to the host mailbox with the counter as its sequence number.  All threads of the
+// (single) deciding workgroup call it; `post` is uniform.
+// Only the evaluation of a trial STEP ends a slot: the first slot of a run also evaluates the starting state (step == 0),
+// which neither counts nor posts (if that evaluation ends the run - stop flag, zero iterations - the step evaluation of
+// the same slot finds `done` and answers).
+__device__ inline void end_slot(BaCtl* ctl, volatile double* mail, bool post, int tid, int nthr, bool step) {
+    if (!step) return;
+    if (tid == 0) ctl->seq += 1.0;
+    __syncthreads();
+    if (post && mail) {
+        __threadfence();
+        post_ctl(ctl, mail, 0.0, tid, nthr);
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) mail[kMailSeq] = ctl->seq;
+    }
+}
+
 // the finisher workgroup of k_update (kBlock threads): see FinArgs
 __device__ void finish_trial(const FinArgs& fin, const double* part, double lambda) {
     __shared__ double fsm[2][kBlock / 64];
@@ -1426,12 +1457,7 @@ __device__ void finish_trial(const FinArgs& fin, const double* part, double lamb
     double failflag = 0;
     if (ctl) {
         if (ctl->done) {   // the run is over: only answer a pending notification
-            if (fin.notify && mail) {
-                post_ctl(ctl, mail, fin.seq, threadIdx.x, blockDim.x);
-                __threadfence_system();
-                __syncthreads();
-                if (threadIdx.x == 0) mail[3] = fin.seq;
-            }
+            end_slot(ctl, mail, fin.notify != 0, threadIdx.x, blockDim.x, fin.step != 0);
             return;
         }
         if (ctl->sel) { const double* t = poses; poses = poses_trial; poses_trial = const_cast<double*>(t); }
@@ -1500,7 +1526,7 @@ __device__ void finish_trial(const FinArgs& fin, const double* part, double lamb
             fsm[1][0] += fsm[1][w];
         }
         double* out = fin.out;
-            out[0] = fsm[0][0]; out[1] = fsm[1][0]; out[3] = 0;
+        out[0] = fsm[0][0]; out[1] = fsm[1][0]; out[3] = 0;
         if (!step) out[2] = 0;
         fpost = 0;
         if (ctl && fin.decide) {
@@ -1513,7 +1539,7 @@ __device__ void finish_trial(const FinArgs& fin, const double* part, double lamb
                 lm_advance(ctl, sc, stopped != 0);
             }
             fpost = (ctl->done || fin.notify) && mail;
-                } else if (mail && !ctl) {  // synchronous callers (se2gpu_ba_chi2, the host controller): the three scalars
+        } else if (mail && !ctl) {  // synchronous callers (se2gpu_ba_chi2, the host controller): the three scalars
             mail[0] = fsm[0][0];
             mail[1] = fsm[1][0];
             mail[2] = step ? failflag : 0.0;
@@ -1523,13 +1549,7 @@ __device__ void finish_trial(const FinArgs& fin, const double* part, double lamb
     }
     if (ctl && fin.decide) {
         __syncthreads();
-        if (fpost) {
-            __threadfence();
-            post_ctl(ctl, mail, fin.seq, threadIdx.x, blockDim.x);
-            __threadfence_system();
-            __syncthreads();
-            if (threadIdx.x == 0) mail[3] = fin.seq;
-        }
+        end_slot(ctl, mail, fpost != 0, threadIdx.x, blockDim.x, step);
     }
 }
 
@@ -1552,13 +1572,8 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
     bool step = xp != nullptr;
     if (ctl) {
         step = step_arg != 0;
-        if (ctl->done) {   // the run is over: only answer a pending notification
-            if (notify && mail) {
-                post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-                __threadfence_system();
-                __syncthreads();
-                if (threadIdx.x == 0) { mail[3] = seq; }
-            }
+        if (ctl->done) {   // the run is over: only answer a pending notification (sharded runs: k_lm_decide does)
+            if (decide) end_slot(ctl, mail, notify != 0, threadIdx.x, blockDim.x, step);
             return;
         }
         if (ctl->sel) { const double* t = poses; poses = poses_trial; poses_trial = const_cast<double*>(t); }
@@ -1631,13 +1646,7 @@ __global__ void k_finalize(int nparts, const double* __restrict__ part, int P, d
     }
     if (ctl && decide) {
         __syncthreads();
-        if (post_s) {
-            __threadfence();
-            post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-            __threadfence_system();
-            __syncthreads();
-            if (threadIdx.x == 0) mail[3] = seq;
-        }
+        end_slot(ctl, mail, post_s != 0, threadIdx.x, blockDim.x, step != 0);
     }
 }
 
@@ -1659,24 +1668,24 @@ __global__ void k_lm_decide(BaCtl* __restrict__ ctl, const double* __restrict__ 
         post_s = (ctl->done || notify) && mail;
     }
     __syncthreads();
-    if (post_s) {
-        __threadfence();
-        post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) mail[3] = seq;
-    }
+    end_slot(ctl, mail, post_s != 0, threadIdx.x, blockDim.x, step != 0);
 }
 
 // start of an optimize() call: fresh controller block
-__global__ void k_ctl_init(BaCtl* __restrict__ ctl, int sel, int iters, int mode) {
-    constexpr int kWords = (int)(sizeof(BaCtl) / 8);
+// start of an optimize(): everything is reset but the handle's own counters and the sel bit (which of the two estimate
+// buffers is current: it follows from the runs before, the host only mirrors it) - nothing here changes from one run to
+// the next, so the whole optimize() can be replayed as a hipGraph
+__global__ void k_ctl_init(BaCtl* __restrict__ ctl, int iters, int mode) {
+    constexpr int kWords = (int)(offsetof(BaCtl, seq) / 8);
+    __shared__ int sel_s;
+    if (threadIdx.x == 0) sel_s = ctl->sel;
+    __syncthreads();
     double* w = reinterpret_cast<double*>(ctl);
     for (int i = threadIdx.x; i < kWords; i += blockDim.x) w[i] = 0.0;
     __syncthreads();
     if (threadIdx.x == 0) {
         ctl->ni = 2;
-        ctl->sel = sel;
+        ctl->sel = sel_s;
         ctl->iters = iters;
         ctl->mode = mode;
     }
@@ -1946,7 +1955,8 @@ __global__ __launch_bounds__(kBlock) void k3_reduce2(int P, int ld, int nwg_off,
                                                       const double* __restrict__ Oii, const double* __restrict__ Ojj,
                                                       const double* __restrict__ Oij, const double* __restrict__ obi,
                                                       const double* __restrict__ obj, double* __restrict__ S,
-                                                      double* __restrict__ bp, const BaCtl* __restrict__ ctl) {
+                                                      double* __restrict__ bp, const BaCtl* __restrict__ ctl,
+                                                      unsigned* __restrict__ epoch) {
     if (ctl) {
         if (ctl->done) return;
         lambda = ctl->lambda;
@@ -2007,7 +2017,10 @@ __global__ __launch_bounds__(kBlock) void k3_reduce2(int P, int ld, int nwg_off,
     double* __restrict__ bs = S + (size_t)n * ld;
     if (p == P) {
         for (size_t t = (size_t)n * ld + n + threadIdx.x; t < (size_t)ld * ld; t += kBlock) S[t] = 0.0;
-        if (threadIdx.x == 0) S[(size_t)ld * ld + 2] = 0.0;
+        if (threadIdx.x == 0) {
+            S[(size_t)ld * ld + 2] = 0.0;
+            *epoch += 1u;   // see k_reduce2
+        }
         return;
     }
     const bool fa = fixed[p];
@@ -2201,12 +2214,7 @@ __global__ void k3_finalize(int nparts, const double* __restrict__ part, int P, 
     __shared__ double sm[2][16];
     __shared__ int post_s;
     if (ctl->done) {
-        if (notify && mail) {
-            post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-            __threadfence_system();
-            __syncthreads();
-            if (threadIdx.x == 0) mail[3] = seq;
-        }
+        end_slot(ctl, mail, notify != 0, threadIdx.x, blockDim.x, step != 0);
         return;
     }
     const bool est_b = ctl->sel != 0;
@@ -2267,13 +2275,7 @@ __global__ void k3_finalize(int nparts, const double* __restrict__ part, int P, 
         post_s = (ctl->done || notify) && mail;
     }
     __syncthreads();
-    if (post_s) {
-        __threadfence();
-        post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) mail[3] = seq;
-    }
+    end_slot(ctl, mail, post_s != 0, threadIdx.x, blockDim.x, step != 0);
 }
 
 // =============================================================================================
@@ -2408,12 +2410,7 @@ __global__ void k4_finalize(int P, int nedge, const double* __restrict__ poses_a
     double lambda = 0;
     if (ctl) {
         if (ctl->done) {
-            if (notify && mail) {
-                post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-                __threadfence_system();
-                __syncthreads();
-                if (threadIdx.x == 0) mail[3] = seq;
-            }
+            end_slot(ctl, mail, notify != 0, threadIdx.x, blockDim.x, step != 0);
             return;
         }
         poses = ((ctl->sel != 0) != (step != 0)) ? poses_b : poses_a;
@@ -2463,13 +2460,7 @@ __global__ void k4_finalize(int P, int nedge, const double* __restrict__ poses_a
         post_s = (ctl->done || notify) && mail;
     }
     __syncthreads();
-    if (post_s) {
-        __threadfence();
-        post_ctl(ctl, mail, seq, threadIdx.x, blockDim.x);
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) mail[3] = seq;
-    }
+    end_slot(ctl, mail, post_s != 0, threadIdx.x, blockDim.x, step != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2676,7 +2667,12 @@ struct se2gpu_ba {
     DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
     int chol_ntask = 0;
-    unsigned chol_epoch = 0;
+    // optimize(n) as ONE hipGraph launch: captured the second time the same (iterations, mode) is asked of an initialised
+    // handle (a one-shot localBA never pays for the capture), replayed from then on.  Nothing in the slot sequence changes
+    // between runs: the slot counter, the solver's epoch and the estimate's buffer bit live on the device (BaCtl).
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_iters = -1, graph_mode = -1, graph_seen_iters = -1, graph_seen_mode = -1;
+    double dev_seq = 0;           // host mirror of BaCtl::seq
     DevBuf<long long> chol_trace; // SE2GPU_BA_CHOL_TRACE=1: per-task stamps of the last solve -> stderr (debug_solve)
     bool chol_steps = false;      // SE2GPU_BA_CHOL=steps: one launch per block column (k_chol_step) instead
     bool chol_faulted = false;    // SE2GPU_BA_CHOL_FAULT=1: the injected fault has been spent
@@ -2716,6 +2712,7 @@ struct se2gpu_ba {
     ~se2gpu_ba() {
         if (ev_copy0) (void)hipEventDestroy(ev_copy0);
         if (ev_copy1) (void)hipEventDestroy(ev_copy1);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (h_mail) (void)hipHostFree(h_mail);
     }
@@ -3732,7 +3729,11 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
     SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
     SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
-    h->chol_epoch = 0;
+    // the handle's device-side counters start over with the graph (flags = 0 = "no epoch yet")
+    SE2_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(BaCtl), st));
+    h->dev_seq = 0;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    h->graph_iters = h->graph_mode = h->graph_seen_iters = h->graph_seen_mode = -1;
     {
         const char* env = getenv("SE2GPU_BA_CHOL");
         h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt > 64 || h->chol_fallback;
@@ -3751,6 +3752,7 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->h_stop = reinterpret_cast<volatile int*>(h->h_mail + kMailStop);
         h->d_stop = reinterpret_cast<int*>(h->d_mail + kMailStop);
     }
+    ((volatile double*)h->h_mail)[kMailSeq] = 0.0;   // the slot counter starts over with the graph (BaCtl::seq was cleared above)
     h->poses = h->poses_a.p; h->poses_t = h->poses_b.p;
     h->lms = h->lms_a.p; h->lms_t = h->lms_b.p;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, (size_t)ps * P * 8, hipMemcpyDeviceToDevice, st));
@@ -3823,11 +3825,20 @@ int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
 
 // the estimate's pose buffer as a host-known pointer (only valid between optimize() calls / in synchronous mode)
 // un-reduced pose blocks Hpp / bp (only needed for lambda_0 = 1e-5 max diag H and by the odometry fallback)
-int ba_pose_blocks(se2gpu_ba* h, const double* poses) {
+int ba_pose_blocks(se2gpu_ba* h, const double* poses, bool ctl = false) {
     hipStream_t st = h->stream;
-    if (h->O)
-        SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
-                   h->o_meas.p, h->o_info.p, poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
+    if (h->O) {
+        // with the device-side controller the estimate's buffer is the controller's to name (a captured graph must not
+        // carry the host's idea of it)
+        if (ctl)
+            SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
+                       h->o_meas.p, h->o_info.p, h->poses_a.p, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p,
+                       (const BaCtl*)h->ctl.p, (const double*)h->poses_b.p);
+        else
+            SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
+                       h->o_meas.p, h->o_info.p, poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p,
+                       (const BaCtl*)nullptr, (const double*)nullptr);
+    }
     SE2_LAUNCH(h->prof, st, "k_pose_reduce", k_pose_reduce, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
                h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p,
                h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
@@ -3850,7 +3861,8 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
         SE2_LAUNCH(h->prof, st, "k3_reduce2", k3_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0,
                    h->P, h->ld, h->nwg_off, lambda, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p,
                    h->Y.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p, h->podo_ptr.p, h->podo_item.p,
-                   h->prior_has.p, pinfo, h->pb.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, S, h->bp.p, B.c);
+                   h->prior_has.p, pinfo, h->pb.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, S, h->bp.p, B.c,
+                   &h->ctl.p->epoch);
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
@@ -3861,12 +3873,14 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
     SE2_LAUNCH(h->prof, st, "k_reduce2", k_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0, h->P, h->ld, h->nwg_off,
                lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
                h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p,
-               h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb);
+               h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb,
+               &h->ctl.p->epoch);
     if (h->O && h->odo_fallback) {
         // PreEdgeSE2 edges the plan cannot carry (self loops, duplicates): blocks from the estimate, added atomically.  Only
         // reachable with a host-known estimate pointer, so such graphs run in synchronous mode (ba_needs_sync).
         SE2_LAUNCH(h->prof, st, "k_odometry", k_odometry, grid1(h->O, 64), dim3(64), 0, h->O, h->o_i.p, h->o_j.p,
-                   h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p);
+                   h->o_meas.p, h->o_info.p, h->poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p,
+                   (const BaCtl*)nullptr, (const double*)nullptr);
         SE2_LAUNCH(h->prof, st, "k_reduce_odo", k_reduce_odo, grid1((size_t)h->O * 9, 256), dim3(256), 0, h->O, h->ld,
                    h->o_i.p, h->o_j.p, h->Oij.p, S);
     }
@@ -4017,14 +4031,13 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         double* RM = AM + (size_t)ld * ld;
         unsigned* flagA = h->chol_flags.p;
         unsigned* flagR = flagA + (size_t)nt * nbc;
-        ++h->chol_epoch;
         // SE2GPU_BA_CHOL_FAULT=1 (tests): the first dataflow solve of a handle runs without its first task, so that every
         // other task times out - exercises the fallback to k_chol_step in ba_run_step
         static const bool fault = [] { const char* e = getenv("SE2GPU_BA_CHOL_FAULT"); return e && e[0] == '1'; }();
         const int skip = (fault && !h->chol_faulted && h->chol_ntask > 1) ? 1 : 0;
         h->chol_faulted = true;
         SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
-                   h->chol_tasks.p + skip, flagA, flagR, h->chol_epoch, fail, h->chol_trace.p, c);
+                   h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c);
         SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, RM, ld, n, h->xp.p, c);
     }
     SE2_HIP(hipGetLastError());
@@ -4045,7 +4058,7 @@ int ba_lambda_init(se2gpu_ba* h) {
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
-    SE2_CHECK(ba_pose_blocks(h, h->poses));
+    SE2_CHECK(ba_pose_blocks(h, h->poses, true));
     SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
                h->Hpp.p, h->diag3.p);
     const bool sharded = h->allreduce && h->world > 1;
@@ -4756,14 +4769,40 @@ int ba_run_begin(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop
     h->run_sync = ba_env_sync() || h->prof.enabled || verbose || h->odo_fallback || h->host_solve;
     h->run_active = true;
     *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
-    hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl.p, h->poses == h->poses_b.p ? 1 : 0, iters, mode);
-    SE2_HIP(hipGetLastError());
     const int n0 = h->run_sync ? 1 : std::max(iters, 1);
-    for (int k = 0; k < n0; ++k) {
-        h->run_seq = (double)(++h->mail_seq);
-        SE2_CHECK(ba_enqueue_trial(h, k == 0, h->run_sync ? 0 : -1, k == n0 - 1, h->run_seq));
-        ++h->run_enqueued;
+    auto enqueue_all = [&]() -> int {
+        hipLaunchKernelGGL(k_ctl_init, dim3(1), dim3(64), 0, h->stream, h->ctl.p, iters, mode);
+        SE2_HIP(hipGetLastError());
+        for (int k = 0; k < n0; ++k) SE2_CHECK(ba_enqueue_trial(h, k == 0, h->run_sync ? 0 : -1, k == n0 - 1, 0.0));
+        return SE2GPU_OK;
+    };
+    static const bool graphs_on = [] { const char* e = getenv("SE2GPU_BA_GRAPH"); return !(e && e[0] == '0'); }();
+    const bool graphable = graphs_on && !h->run_sync && !h->allreduce && !h->comm;
+    if (graphable && h->graph_exec && h->graph_iters == iters && h->graph_mode == mode) {
+        SE2_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+    } else if (graphable && h->graph_seen_iters == iters && h->graph_seen_mode == mode) {
+        // second run of this shape: capture it (the capture itself does not execute anything), then launch
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        SE2_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue_all();
+        const hipError_t ce = hipStreamEndCapture(h->stream, &g);
+        SE2_CHECK(rc);
+        SE2_HIP(ce);
+        const hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        SE2_HIP(ie);
+        h->graph_iters = iters;
+        h->graph_mode = mode;
+        SE2_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+    } else {
+        h->graph_seen_iters = iters;
+        h->graph_seen_mode = mode;
+        SE2_CHECK(enqueue_all());
     }
+    h->dev_seq += n0;
+    h->run_seq = h->dev_seq;
+    h->run_enqueued = n0;
     return SE2GPU_OK;
 }
 
@@ -4771,16 +4810,16 @@ int ba_run_begin(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop
 int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int verbose, int* finished) {
     *finished = 0;
     if (stop_flag && *stop_flag) *h->h_stop = 1;
-    if (!wait && !ba_mail_ready(h, h->run_seq)) {
+    if (!wait && ((volatile double*)h->h_mail)[kMailSeq] != h->run_seq) {
         // an earlier slot may already have posted "done" (Terminate, stop flag): its sequence number is lower
-        const double got = ((volatile double*)h->h_mail)[3];
+        const double got = ((volatile double*)h->h_mail)[kMailSeq];
         if (!(got > h->run_seq - h->run_enqueued && got <= h->run_seq && ba_posted(h)->done)) return SE2GPU_OK;
     } else if (wait) {
         volatile double* mb = h->h_mail;
         const auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
         for (;;) {
-            const double got = mb[3];
+            const double got = mb[kMailSeq];
             if (got == h->run_seq) break;
             if (got > h->run_seq - h->run_enqueued && got < h->run_seq) {   // an earlier slot of this run posted: done?
                 std::atomic_thread_fence(std::memory_order_acquire);
@@ -4790,7 +4829,7 @@ int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int 
             if (stop_flag && *stop_flag) *h->h_stop = 1;
             if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
                 SE2_HIP(hipStreamSynchronize(h->stream));
-                SE2_REQUIRE(mb[3] == h->run_seq || ba_posted(h)->done, SE2GPU_ERR_HIP, "the LM controller never reported back");
+                SE2_REQUIRE(mb[kMailSeq] == h->run_seq || ba_posted(h)->done, SE2GPU_ERR_HIP, "the LM controller never reported back");
                 break;
             }
         }
@@ -4805,12 +4844,14 @@ int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int 
         // nothing (lm_advance returns before touching the state), so it is simply redone.
         std::fprintf(stderr, "se2gpu_ba: k_chol_tiles timed out; continuing with k_chol_step\n");
         h->chol_steps = h->chol_fallback = true;
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // it launches k_chol_tiles
+        h->graph_iters = h->graph_seen_iters = -1;
         SE2_HIP(hipStreamSynchronize(h->stream));   // the remaining slots of this run have all exited early
         hipLaunchKernelGGL(k_ctl_clear_error, dim3(1), dim3(1), 0, h->stream, h->ctl.p);
         c.error = 0;
         c.done = 0;
         h->run_enqueued = 0;                          // the posted block of the failed slot is no longer part of this run
-        ((volatile double*)h->h_mail)[3] = 0.0;
+        ((volatile double*)h->h_mail)[kMailSeq] = 0.0;
     }
     SE2_REQUIRE(!c.error, SE2GPU_ERR_HIP, "k_chol_step: the factorisation reported a time-out");
     if (verbose)
@@ -4824,8 +4865,9 @@ int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int 
     }
     const int more = h->run_sync ? 1 : std::max(1, c.iters - c.it);
     for (int k = 0; k < more; ++k) {
-        h->run_seq = (double)(++h->mail_seq);
-        SE2_CHECK(ba_enqueue_trial(h, false, h->run_sync ? (c.retry ? 1 : 0) : -1, k == more - 1, h->run_seq));
+        SE2_CHECK(ba_enqueue_trial(h, false, h->run_sync ? (c.retry ? 1 : 0) : -1, k == more - 1, 0.0));
+        h->dev_seq += 1;
+        h->run_seq = h->dev_seq;
         ++h->run_enqueued;
     }
     return SE2GPU_OK;

@@ -602,3 +602,27 @@ def test_dataflow_timeout_falls_back_to_the_column_launches(synth):
     ref.optimize(6)
     assert got["trials"] == ref.stats["trials_hist"]
     assert np.allclose(got["chi2"], ref.stats["chi2_hist"], rtol=1e-9)
+
+
+def test_repeated_optimize_replays_a_graph_with_identical_results(synth):
+    """the same optimize(n) asked again of an initialised handle is captured as a hipGraph the second time and replayed
+    from the third on (ba_run_begin): the first (direct launches), second (capture + launch) and later (replay) runs
+    must give bit-identical histories and estimates - also on a start that rejects trials (the extra slots of a
+    rejected trial are enqueued directly, after the graph) and for the SE3 / pose-graph models"""
+    from se2lam_amd import optimizer as op
+    case, trials = LM_REJECT_CASES[1]
+    for g, loader in ((synth.ba_graph(30, 900), None), (_kidnapped(synth, *case), None),
+                      (synth.ba3_graph(12, 300, 2), op.load_se3_graph), (synth.pose_graph(40), op.load_pose_graph)):
+        o = op.SlamOptimizer()
+        if loader:
+            loader(o, g)
+        else:
+            o.load(g)
+        o.initializeOptimization(0)
+        runs = []
+        for rep in range(5):
+            o.reset_estimates()
+            o.optimize(7 if rep < 4 else 3)              # the last one: another shape, direct again
+            runs.append((o.stats["trials_hist"], o.stats["chi2_hist"], o.stats["lambda_hist"]))
+        assert runs[0] == runs[1] == runs[2] == runs[3]
+        assert runs[4][0] == runs[0][0][:3] and runs[4][1] == runs[0][1][:3]
