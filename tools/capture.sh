@@ -4,6 +4,9 @@
 #   per-kernel HBM traffic json, and the plain default bench line.
 set -e
 export TMPDIR=/tmp
+# one launch per kernel and batch, as bench.py's per-kernel (profiled) pass and its algorithmic bytes per launch assume: the
+# level pipeline of large batches (orb_run) would split k_fast_score / k_blur into four launches each
+export SE2GPU_ORB_PIPELINE_MIN=1000000
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 cd $R
@@ -17,5 +20,5 @@ W=$(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 python tools/pmc_summarize.py $F $W gpurun_out/${TAG}_pmc_traffic.json || true
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json || true
 rm -f $F $W
-timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || true
+SE2GPU_ORB_PIPELINE_MIN=16 timeout 400 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || true
 tail -c 400 gpurun_out/${TAG}_bench.json

@@ -4,6 +4,9 @@
 # the bench workloads: separate rocprofv3 --pmc passes (derived metrics, never combined with the trace domains gpurun refuses)
 set -e
 export TMPDIR=/tmp
+# one launch per kernel and batch, as bench.py's per-kernel (profiled) pass and its algorithmic bytes per launch assume: the
+# level pipeline of large batches (orb_run) would split k_fast_score / k_blur into four launches each
+export SE2GPU_ORB_PIPELINE_MIN=1000000
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 for C in VALUBusy LDSBankConflict; do
