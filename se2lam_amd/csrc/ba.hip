@@ -953,7 +953,8 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
                                                      int nbc, const int2* __restrict__ tasks,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
-                                                     long long* __restrict__ dbg, const BaCtl* __restrict__ ctl) {
+                                                     long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
+                                                     double* __restrict__ xout) {
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     __shared__ __attribute__((aligned(16))) double Ta[kNB][kNB + 2];  // MR(i,m), then the finished tile T
@@ -967,6 +968,43 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     long long* stamp = dbg ? dbg + (size_t)blockIdx.x * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     const int2 tk = tasks[blockIdx.x];
+    if ((tk.x >> 16) == 2) {
+        // ---- x = R y for the 32 rows of tile row r (what k_chol_apply did as a kernel of its own): the last tasks of the
+        // list.  x(r) = sum_{j >= r} MR_R(r,j) y_un(j); the terms are taken as their tiles are published, so that only the last
+        // block column is left when the factorisation ends.  y_un(j) = row n of A in the columns of tile j: written by the
+        // task of tile (n / 32, j) - the diagonal task when the rhs row lives in the last diagonal tile.
+        const int r = tk.x & 0xffff;
+        const int it = n / kNB;                       // tile row of the rhs row
+        const int row = tid / 8, c4 = (tid % 8) * 4;  // 8 lanes per row, 4 columns each
+        double acc = 0.0;
+        for (int j = r; j < nbc; ++j) {
+            if (tid == 0) {
+                bool ok = spin_until(flagR + (size_t)r * nbc + j, epoch);
+                ok = ok && spin_until((it == j ? flagR : flagA) + (size_t)it * nbc + j, epoch);
+                ok_s = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!ok_s) {
+                if (tid == 0) fail[0] = 1e6;
+                return;
+            }
+            const int c0 = kNB * j + c4;
+            d2_t m0 = load_agent(RM + (size_t)(kNB * r + row) * ld + c0), m1 = load_agent(RM + (size_t)(kNB * r + row) * ld + c0 + 2);
+            d2_t y0 = load_agent(A + (size_t)n * ld + c0), y1 = load_agent(A + (size_t)n * ld + c0 + 2);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(y0), "+v"(y1) : : "memory");
+            // (columns past n of the last tile: R is zero there by construction of the padded elimination, y is not read)
+            if (c0 + 0 < n) acc += m0.x * y0.x;
+            if (c0 + 1 < n) acc += m0.y * y0.y;
+            if (c0 + 2 < n) acc += m1.x * y1.x;
+            if (c0 + 3 < n) acc += m1.y * y1.y;
+            __syncthreads();   // ok_s is rewritten in the next round
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        if ((tid & 7) == 0 && kNB * r + row < n) xout[kNB * r + row] = acc;
+        return;
+    }
     const bool isR = (tk.x >> 16) != 0;
     const int i = tk.x & 0xffff, j = tk.y;
     const bool isDiag = !isR && i == j;
@@ -1151,7 +1189,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         double* py = A + (size_t)(c0 + rr) * ld + c0 + cb;
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-            if (cb + q < ncol) py[q] = m[q];   // y_un: read by k_chol_apply only (next kernel)
+            if (cb + q < ncol) store_agent1(py + q, m[q]);   // y_un: read by the x tasks of this launch
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
     if (w == 3 && ncol == kNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
@@ -3567,6 +3605,7 @@ int ba_upload_graph(se2gpu_ba* h) {
         for (int i = j; i < nt; ++i) tasks.push_back(make_int2(i, j));
         for (int r = 0; r < j; ++r) tasks.push_back(make_int2(r | (1 << 16), j));
     }
+    for (int r = 0; r < nbc; ++r) tasks.push_back(make_int2(r | (2 << 16), 0));   // x = R y, one task per tile row
     h->chol_ntask = (int)tasks.size();
     stage(h->chol_tasks, tasks.data(), tasks.size());
     // last in the arena: the measurements and information matrices (copied on their own stream, see below; with a local
@@ -4037,8 +4076,7 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         const int skip = (fault && !h->chol_faulted && h->chol_ntask > 1) ? 1 : 0;
         h->chol_faulted = true;
         SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
-                   h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c);
-        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, RM, ld, n, h->xp.p, c);
+                   h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
