@@ -420,25 +420,40 @@ __global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __rest
 }
 
 // max |diag| over a strided array (computeLambdaInit); single block, deterministic.
+// max |diag H| over the landmark blocks and the free poses' blocks (computeLambdaInit).  The pose diagonals come either as
+// `dpp` values per pose (Hpp_diag3) or, with stride9 set, straight from the 3 x 3 row-major blocks of k_pose_reduce; with
+// `ctl` the kernel also sets lambda_0 = 1e-5 * max itself (single GPU: no k_extract_diag / k_set_lambda launches).
 __global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const double* __restrict__ Hpp_diag3,
-                          const uint8_t* __restrict__ fixed, double* __restrict__ out, int dpp) {
-    __shared__ double sm[1024];
+                          const uint8_t* __restrict__ fixed, double* __restrict__ out, int dpp, int stride9,
+                          BaCtl* __restrict__ ctl) {
+    __shared__ double sm[16];
     double m = 0;
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        m = fmax(m, fabs(Hll[(size_t)i * 6 + 0]));
-        m = fmax(m, fabs(Hll[(size_t)i * 6 + 3]));
-        m = fmax(m, fabs(Hll[(size_t)i * 6 + 5]));
+    for (int i0 = threadIdx.x; i0 < L; i0 += 4 * blockDim.x) {   // four landmarks' diagonals in flight per thread
+        double v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t i = (size_t)min(i0 + u * (int)blockDim.x, L - 1);
+            v[u][0] = Hll[i * 6 + 0]; v[u][1] = Hll[i * 6 + 3]; v[u][2] = Hll[i * 6 + 5];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m = fmax(m, fmax(fabs(v[u][0]), fmax(fabs(v[u][1]), fabs(v[u][2]))));
     }
     for (int i = threadIdx.x; i < P; i += blockDim.x)
         if (!fixed[i])
-            for (int r = 0; r < dpp; ++r) m = fmax(m, fabs(Hpp_diag3[(size_t)i * dpp + r]));
-    sm[threadIdx.x] = m;
+            for (int r = 0; r < dpp; ++r)
+                m = fmax(m, fabs(stride9 ? Hpp_diag3[(size_t)i * 9 + r * 4] : Hpp_diag3[(size_t)i * dpp + r]));
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmax(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, sm[w]);
+        out[0] = m;
+        if (ctl) {
+            ctl->lambda = 1e-5 * m;
+            ctl->ni = 2;
+        }
     }
-    if (threadIdx.x == 0) out[0] = sm[0];
 }
 
 __global__ void k_extract_diag(int P, const double* __restrict__ Hpp, double* __restrict__ d3) {
@@ -4091,16 +4106,21 @@ int ba_lambda_init(se2gpu_ba* h) {
                    h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->fixed.p, h->prior_has.p,
                    h->model == 2 ? h->ph.p : h->prior_info.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p, h->Ojj.p, h->diag3.p);
         SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
-                   h->fixed.p, h->scal.p, 6);
-        hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(1), 0, st, h->ctl.p, h->scal.p, 1);
+                   h->fixed.p, h->scal.p, 6, 0, h->ctl.p);
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
     SE2_CHECK(ba_pose_blocks(h, h->poses, true));
-    SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
-               h->Hpp.p, h->diag3.p);
     const bool sharded = h->allreduce && h->world > 1;
     const size_t nd = 3 * (size_t)h->P;
+    if (!sharded) {   // one launch: pose diagonals straight from the blocks, lambda_0 set by the same kernel
+        SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->Hpp.p, h->fixed.p,
+                   h->scal.p, 3, 1, h->ctl.p);
+        SE2_HIP(hipGetLastError());
+        return SE2GPU_OK;
+    }
+    SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
+               h->Hpp.p, h->diag3.p);
     if (sharded) {
         // global Hpp diagonal when landmark-sharded.  Every all-reduce goes through the fused buffer `red`
         // (it may alias a caller tensor); at this point of the iteration it holds nothing live.
@@ -4109,7 +4129,7 @@ int ba_lambda_init(se2gpu_ba* h) {
         SE2_HIP(hipMemcpyAsync(h->diag3.p, h->red, nd * 8, hipMemcpyDeviceToDevice, st));
     }
     SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->diag3.p,
-               h->fixed.p, h->scal.p, 3);
+               h->fixed.p, h->scal.p, 3, 0, (BaCtl*)nullptr);
     if (sharded) {
         // max over ranks through the SUM all-reduce: every rank deposits its local max in its own slot
         SE2_REQUIRE(h->world <= 1024, SE2GPU_ERR_INVALID, "world size %d > 1024", h->world);
