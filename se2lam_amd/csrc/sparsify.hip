@@ -192,7 +192,8 @@ __device__ void clamp_spectrum6(double* I) {
 }
 
 // mp_ptr: points of pair p = [mp_ptr[p], mp_ptr[p+1]); mm_ptr: measurements of point j = [mm_ptr[j], mm_ptr[j+1]) in the
-// order they were given; m_kf in {0, 1}; scratch: 144 doubles per (pair, lane) for the ordered sum.
+// order they were given; m_kf in {0, 1}; scratch: 288 doubles per POINT (its key-frame blocks and its Schur term), so that
+// the sums can be taken in exactly the reference's order whatever lane computed a point.
 __global__ __launch_bounds__(64) void k_sparsify(int npairs, const double* __restrict__ kf12, const int* __restrict__ mp_ptr,
                                                  const double* __restrict__ mp_xyz, const int* __restrict__ mm_ptr,
                                                  const int* __restrict__ m_kf, const double* __restrict__ m_info,
@@ -202,10 +203,11 @@ __global__ __launch_bounds__(64) void k_sparsify(int npairs, const double* __res
     if (p >= npairs) return;
     const int lane = threadIdx.x;
     const Q3 KF0 = from_pose12(kf12 + 24 * (size_t)p), KF1 = from_pose12(kf12 + 24 * (size_t)p + 12);
-    // this lane's part of H11 (12 x 12, before the regulariser): direct 6x6 diagonal terms minus the Schur terms
-    double* acc = scratch + ((size_t)p * 64 + lane) * 288;   // [0,144): sum of J' W J key-frame blocks; [144,288): Schur terms
-    for (int i = 0; i < 288; ++i) acc[i] = 0.0;
+    __shared__ double h11s[144];
     for (int j = mp_ptr[p] + lane; j < mp_ptr[p + 1]; j += 64) {
+        // this point's part of H11 (12 x 12): [0,144) its J' W J key-frame blocks, [144,288) its Schur term
+        double* acc = scratch + (size_t)j * 288;
+        for (int i = 0; i < 288; ++i) acc[i] = 0.0;
         double Hmm[9], Hkm[36];
         for (int i = 0; i < 9; ++i) Hmm[i] = 0.0;
         for (int i = 0; i < 36; ++i) Hkm[i] = 0.0;
@@ -236,20 +238,23 @@ __global__ __launch_bounds__(64) void k_sparsify(int npairs, const double* __res
             for (int c = 0; c < 12; ++c)
                 acc[144 + 12 * r + c] += BD[3 * r] * Hkm[3 * c] + BD[3 * r + 1] * Hkm[3 * c + 1] + BD[3 * r + 2] * Hkm[3 * c + 2];
     }
+    __threadfence_block();
+    __syncthreads();
+    // Order of the sums: the reference (and the oracle) add the key-frame blocks measurement by measurement (= point by
+    // point: the measurements are grouped by point), then the regulariser, then subtract the Schur terms point by point.
+    // H11 is kept regular only by that 1e-6 I, so the order is part of the result (a pre-summed H11 moved the clamped
+    // spectrum by up to 100 % at 220 points): every entry is summed by one lane over the points in exactly that order.
+    for (int i = lane; i < 144; i += 64) {
+        double hsum = 0.0;
+        for (int j = mp_ptr[p]; j < mp_ptr[p + 1]; ++j) hsum += scratch[(size_t)j * 288 + i];
+        if (i % 13 == 0) hsum += 1e-6;
+        for (int j = mp_ptr[p]; j < mp_ptr[p + 1]; ++j) hsum -= scratch[(size_t)j * 288 + 144 + i];
+        h11s[i] = hsum;
+    }
     __syncthreads();
     if (lane != 0) return;
-    // Order of the sums: the reference (and the oracle) add the key-frame blocks measurement by measurement, then the
-    // regulariser, then subtract the Schur terms point by point.  Lane sums combined in lane order give exactly that order
-    // while every lane holds at most one point (N <= 64, measurements grouped by point); beyond that the points of a lane
-    // are pre-summed - a rounding-level difference in H11, documented and far inside the tolerance.
     double H11[144];
-    for (int i = 0; i < 144; ++i) H11[i] = 0.0;
-    const double* base = scratch + (size_t)p * 64 * 288;
-    for (int l = 0; l < 64; ++l)
-        for (int i = 0; i < 144; ++i) H11[i] += base[(size_t)l * 288 + i];
-    for (int i = 0; i < 12; ++i) H11[13 * i] += 1e-6;
-    for (int l = 0; l < 64; ++l)
-        for (int i = 0; i < 144; ++i) H11[i] -= base[(size_t)l * 288 + 144 + i];
+    for (int i = 0; i < 144; ++i) H11[i] = h11s[i];
     const Q3 zref_q = mul(inverse(KF0), KF1);
     double zref[6], v1[6], v2[6], J[72];
     to_min(zref_q, zref);
@@ -335,7 +340,7 @@ int se2gpu_sparsify_se3xyz(int npairs, const double* kf12, const int32_t* mp_ptr
     if (!kf_s.empty()) SE2_HIP(hipMemcpyAsync(d_mkf.p, kf_s.data(), kf_s.size() * 4, hipMemcpyHostToDevice, st));
     SE2_CHECK(d_info.reserve(std::max<size_t>(info_s.size(), 1)));
     if (!info_s.empty()) SE2_HIP(hipMemcpyAsync(d_info.p, info_s.data(), info_s.size() * 8, hipMemcpyHostToDevice, st));
-    SE2_CHECK(d_scratch.reserve((size_t)npairs * 64 * 288));
+    SE2_CHECK(d_scratch.reserve((size_t)std::max(NP, 1) * 288));
     SE2_CHECK(d_z.reserve(12 * (size_t)npairs));
     SE2_CHECK(d_out.reserve(36 * (size_t)npairs));
     hipLaunchKernelGGL(k_sparsify, dim3(npairs), dim3(64), 0, st, npairs, d_kf.p, d_mpp.p, d_mp.p, d_mmp.p, d_mkf.p, d_info.p,

@@ -85,7 +85,10 @@ def test_degenerate_inputs(oracle, synth):
 @pytest.mark.gpu
 def test_hip_batch_matches_oracle(oracle, synth):
     from se2lam_amd.sparsifier import DoMarginalizeSE3XYZ_batch
-    pairs = [synth.kf_pair(N, s, b) for N, s, b in ((12, 0, 400.0), (80, 1, 250.0), (200, 2, 800.0), (10, 4, 100.0), (150, 5, 600.0))]
+    # (the 220-point pair: found by tools/fuzz_gpu.py - with the points of a lane pre-summed, i.e. H11 added up in another
+    # order than the reference's, its clamped spectrum came out 99 % off; H11 is regular only through the 1e-6 I)
+    pairs = [synth.kf_pair(N, s, b) for N, s, b in ((12, 0, 400.0), (80, 1, 250.0), (200, 2, 800.0), (10, 4, 100.0), (150, 5, 600.0),
+                                                     (220, 196366, 484.40666147511246), (249, 77, 120.0))]
     got = DoMarginalizeSE3XYZ_batch(pairs)
     for (kf, mp, m_kf, m_mp, m_info), (z, info) in zip(pairs, got):
         zr, ir, _ = oracle.sparsify(kf, mp, m_kf, m_mp, m_info)

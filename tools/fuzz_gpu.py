@@ -42,7 +42,7 @@ def fail(msg):
 
 while time.time() < t_end:
     ncase += 1
-    kind = ncase % 6
+    kind = ncase % 9
     if kind == 2:   # MatchByWindow on feature subsets / windows / ratios, chained vbPrevMatched
         a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
         (k1, d1), (k2, d2) = feats(a), feats(b)
@@ -109,6 +109,85 @@ while time.time() < t_end:
         print(f"pg   P {P} edges {g.O} iters {iters}: trials {s_['trials_hist']} {'ok' if ok else ''}")
         if not ok:
             fail("pg")
+        continue
+    if kind == 6:   # MatchByProjection: map points back-projected from one frame's key points, seen from a moved key frame
+        a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+        (k0, d0), (k1, d1) = feats(a), feats(b)
+        m = int(rng.choice([0, 1, 40, 700, 1500, 3000]))
+        src = rng.integers(0, len(k0), m)
+        depth = rng.uniform(800, 6000, m).astype(np.float32)
+        Xc = np.stack([(k0["x"][src] - 320.0) / 400.0 * depth, (k0["y"][src] - 240.0) / 400.0 * depth, depth], 1).astype(np.float32)
+        th = float(rng.uniform(-0.03, 0.03))
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+        tt = rng.uniform(-30, 30, 3).astype(np.float32)
+        Tcw = np.concatenate([R, tt[:, None]], 1).astype(np.float32)
+        mp_pos = ((Xc - tt) @ R).astype(np.float32)
+        mp_desc = np.ascontiguousarray(d0[src].copy())
+        flip = rng.integers(0, 256, (m, 32)).astype(np.uint8) & ((rng.random((m, 32)) < 0.03).astype(np.uint8) * 255)
+        mp_desc ^= flip.astype(np.uint8)
+        args = (mp_pos, mp_desc, k0["octave"][src].astype(np.int32), (rng.random(m) < 0.1).astype(np.uint8), Tcw,
+                (400.0, 400.0, 320.0, 240.0), k1, d1, (rng.random(len(k1)) < 0.2).astype(np.uint8))
+        win, lo = int(rng.choice([8, 15, 25])), int(rng.integers(0, 4))
+        try:
+            nm, idx = ORBmatcher().MatchByProjection(*args, win, lo)
+        except Exception as e:   # the window grows with the octave (win x 3.6 at level 7): 128 candidates per window, see above
+            if "more than 128 candidates" in str(e) and win > 15:
+                print(f"proj frames {a}->{b} map points {m} win {win}: refused (window capacity)")
+                continue
+            raise
+        idx_ref, nm_ref = oracle.match_projection(*args, win, lo, 0.6)
+        ok = nm == nm_ref and np.array_equal(idx, idx_ref)
+        print(f"proj frames {a}->{b} map points {m} win {win} level offset {lo}: {nm} matches {'ok' if ok else ''}")
+        if not ok:
+            fail("proj")
+        continue
+    if kind == 7:   # doTriangulate
+        n = int(rng.choice([0, 1, 30, 600, 1000]))
+        K = np.array([[400.0, 0, 320.0], [0, 400.0, 240.0], [0, 0, 1]], np.float32)
+        th = float(rng.uniform(-0.05, 0.05))
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+        tt = np.array([rng.uniform(-300, -50), rng.uniform(-20, 20), rng.uniform(-50, 50)], np.float32)
+        Tcr = np.eye(4, dtype=np.float32); Tcr[:3, :3] = R; Tcr[:3, 3] = tt
+        P1 = (K @ np.eye(3, 4, dtype=np.float32)).astype(np.float32); P2 = (K @ Tcr[:3]).astype(np.float32)
+        X = np.stack([rng.uniform(-1500, 1500, n), rng.uniform(-800, 800, n), rng.uniform(200, 14000, n)], 1).astype(np.float32)
+        Xh = np.concatenate([X, np.ones((n, 1), np.float32)], 1)
+        u1 = (P1 @ Xh.T).T; u2 = (P2 @ Xh.T).T
+        KPd = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+        k1 = np.zeros(n, KPd); k2 = np.zeros(n, KPd)
+        if n:
+            k1["x"], k1["y"] = (u1[:, 0] / u1[:, 2]), (u1[:, 1] / u1[:, 2])
+            perm = rng.permutation(n)
+            k2["x"][perm], k2["y"][perm] = (u2[:, 0] / u2[:, 2]) + rng.normal(0, 0.3, n), (u2[:, 1] / u2[:, 2]) + rng.normal(0, 0.3, n)
+            match = perm.astype(np.int32); match[rng.random(n) < 0.1] = -1
+        else:
+            match = np.zeros(0, np.int32)
+        has_obs = (rng.random(n) < 0.15).astype(np.uint8)
+        Ocam = np.linalg.inv(Tcr)[:3, 3].astype(np.float32)
+        mind = int(rng.integers(1, 5))
+        ref = oracle.triangulate(k1, k2, match, has_obs, P1, P2, Ocam, 500.0, 8000.0, mind)
+        got = track.doTriangulate(k1, k2, match, has_obs, P1, P2, Ocam, 500.0, 8000.0, mind)
+        ok = np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and got[3:] == ref[3:]
+        print(f"tri  n {n} minDegree {mind}: {got[3]} good {'ok' if ok else ''}")
+        if not ok:
+            fail("tri")
+        continue
+    if kind == 8:   # Sparsifier::DoMarginalizeSE3XYZ, a batch of key-frame pairs
+        from se2lam_amd.sparsifier import DoMarginalizeSE3XYZ_batch
+        spec = [(int(rng.integers(8, 250)), int(rng.integers(0, 10**6)), float(rng.uniform(80, 900))) for _ in range(int(rng.integers(1, 9)))]
+        pairs = [synth.kf_pair(*sp) for sp in spec]
+        got = DoMarginalizeSE3XYZ_batch(pairs)
+        ok = True
+        for sp, (kf, mp, m_kf, m_mp, m_info), (z, info) in zip(spec, pairs, got):
+            zr, ir, _ = oracle.sparsify(kf, mp, m_kf, m_mp, m_info)
+            good = np.allclose(z, zr, atol=1e-12) and np.abs(info - ir).max() <= 1e-5 * np.abs(ir).max()
+            if not good:
+                w = np.linalg.eigvalsh(0.5 * (ir + ir.T))
+                print(f"spars pair {sp}: rel diff {np.abs(info - ir).max() / np.abs(ir).max():.3e}, z diff {np.abs(z - zr).max():.3e}, "
+                      f"eig(info_ref) {w.min():.3e} .. {w.max():.3e}")
+            ok = ok and good
+        print(f"spars {len(pairs)} pairs: {'ok' if ok else ''}")
+        if not ok:
+            fail("spars")
         continue
     if kind == 1:
         W, H = int(rng.integers(160, 900)), int(rng.integers(120, 700))
