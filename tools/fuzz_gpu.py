@@ -42,7 +42,7 @@ def fail(msg):
 
 while time.time() < t_end:
     ncase += 1
-    kind = ncase % 9
+    kind = ncase % 11
     if kind == 2:   # MatchByWindow on feature subsets / windows / ratios, chained vbPrevMatched
         a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
         (k1, d1), (k2, d2) = feats(a), feats(b)
@@ -188,6 +188,69 @@ while time.time() < t_end:
         print(f"spars {len(pairs)} pairs: {'ok' if ok else ''}")
         if not ok:
             fail("spars")
+        continue
+    if kind == 9:   # Localizer::DoLocalBA (pose-only BA with the plane-motion prior)
+        from se2lam_amd.localizer import Localizer
+        RBC = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0.0]])
+        TBC = np.eye(4); TBC[:3, :3] = RBC; TBC[:3, 3] = [100.0, 0.0, 300.0]
+
+        def Twb(x, y, th):
+            T = np.eye(4); c_, s_ = np.cos(th), np.sin(th)
+            T[:3, :3] = [[c_, -s_, 0], [s_, c_, 0], [0, 0, 1.0]]; T[:3, 3] = [x, y, 0]
+            return T
+        n = int(rng.choice([0, 3, 6, 40, 400, 1500]))
+        pose = (rng.uniform(-2000, 2000), rng.uniform(-2000, 2000), rng.uniform(-3, 3))
+        Tcw_true = np.linalg.inv(Twb(*pose) @ TBC)
+        Xc = np.stack([rng.uniform(-2000, 2000, n), rng.uniform(-1500, 1500, n), rng.uniform(1500, 8000, n)], 1)
+        Xw = (np.linalg.inv(Tcw_true) @ np.c_[Xc, np.ones(n)].T).T[:, :3]
+        uv = 400.0 * Xc[:, :2] / Xc[:, 2:] + [320.0, 240.0] + rng.normal(0, 0.7, (n, 2))
+        out = rng.random(n) < rng.uniform(0, 0.3)
+        uv[out] += rng.uniform(-50, 50, (int(out.sum()), 2))
+        w = 1.0 / 1.2 ** (2 * rng.integers(0, 8, n))
+        Tcw0 = np.linalg.inv(Twb(pose[0] + rng.normal(0, 40), pose[1] + rng.normal(0, 40), pose[2] + rng.normal(0, 0.03)) @ TBC)
+        delta = float(np.sqrt(5.991))
+        loc = Localizer()
+        T = loc.DoLocalBA(Tcw0, TBC, Xw, uv, w, 400.0, 320.0, 240.0, delta, 30)
+        st = loc.stats
+        meas, info = oracle.plane_motion_prior(Tcw0, TBC)
+        To, so = oracle.pose_only_ba(Tcw0, meas, info, Xw, uv, w, 400.0, 320.0, 240.0, delta, 30)
+        # identical trial counts and costs while the steps still change the cost (tests/test_pose_ba.py::_same_run)
+        h = np.asarray(so["chi2_hist"]); prev = np.concatenate([[so["chi2_init"]], h[:-1]])
+        flat = (prev - h) < 1e-9 * np.maximum(h, 1e-300)
+        live = min(int(np.argmax(flat)) if flat.any() else len(h), st["iterations"])
+        nn = min(st["iterations"], so["iterations"])
+        noise = so["chi2_init"] < 1e-18      # only the prior edge, already at its minimum: the cost is rounding noise
+        ok = (noise or np.isclose(st["chi2_init"], so["chi2_init"], rtol=1e-12) and list(st["trials_hist"][:live]) == list(so["trials_hist"][:live])
+              and np.allclose(st["chi2_hist"][:nn], so["chi2_hist"][:nn], rtol=1e-5, atol=1e-12)) and (
+              np.allclose(T[:3, :3], To[:3, :3], atol=1e-6) and np.allclose(T[:3, 3], To[:3, 3], rtol=1e-5, atol=1e-2))
+        print(f"pose n {n}: {st['iterations']} iterations {'ok' if ok else ''}")
+        if not ok:
+            print(st, so)
+            fail("pose")
+        continue
+    if kind == 10:   # SearchByBoW with a stand-in vocabulary (node = the first bits of the descriptor)
+        a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
+        (k1, d1), (k2, d2) = feats(a), feats(b)
+        nbits = int(rng.integers(1, 9))
+
+        def fvec(desc, keep_p):
+            node = (desc[:, 0].astype(np.int32) | (desc[:, 1].astype(np.int32) << 8)) & ((1 << nbits) - 1)
+            order = np.argsort(node, kind="stable")
+            nodes, counts = np.unique(node[order], return_counts=True)
+            ptr = np.concatenate([[0], np.cumsum(counts)])
+            keep = rng.random(len(nodes)) < keep_p
+            segs = [order[ptr[i]:ptr[i + 1]] for i in range(len(nodes)) if keep[i]]
+            return (nodes[keep].astype(np.int32), np.concatenate([[0], np.cumsum([len(x) for x in segs])]).astype(np.int32),
+                    (np.concatenate(segs) if segs else np.zeros(0, np.int64)).astype(np.int32))
+        fv1, fv2 = fvec(d1, rng.uniform(0.5, 1.0)), fvec(d2, rng.uniform(0.5, 1.0))
+        h1 = (rng.random(len(k1)) < 0.7).astype(np.uint8); h2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+        ratio = float(rng.choice([0.6, 0.75, 0.9])); mp_only = bool(rng.integers(0, 2)); ori = bool(rng.integers(0, 2))
+        nm, m12 = ORBmatcher(ratio).SearchByBoW(k1, d1, fv1, h1, k2, d2, fv2, h2, bIfMPOnly=mp_only, checkOri=ori)
+        m_ref, nm_ref = oracle.search_by_bow(k1, d1, fv1, h1, k2, d2, fv2, h2, mp_only, ratio, ori)
+        ok = nm == nm_ref and np.array_equal(m12, m_ref)
+        print(f"bow  frames {a},{b} bits {nbits} mpOnly {mp_only} ori {ori} ratio {ratio}: {nm} matches {'ok' if ok else ''}")
+        if not ok:
+            fail("bow")
         continue
     if kind == 1:
         W, H = int(rng.integers(160, 900)), int(rng.integers(120, 700))
