@@ -316,6 +316,11 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
 /* ... and its dense solve on the device (the LL^T that stands in for CHOLMOD): x (3P) with S x = bs;
  * *factor_ok = 0 when a pivot was not positive. */
 int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok);
+/* Which dense solver an initialised handle runs: 0 = the dataflow launch (k_chol_tiles), 1 = one launch per block column
+ * by configuration (SE2GPU_BA_CHOL=steps, more than 64 tile rows), 2 = one launch per block column because a dataflow
+ * dependency timed out earlier in the handle's life (reported once on stderr), 3 = host solve (SE2GPU_BA_HOST_SOLVE=1).
+ * Tests use it to make sure that results were not produced by the fallback. */
+int se2gpu_ba_debug_solver_path(const se2gpu_ba* h);
 
 /* Track::doTriangulate (/root/reference/src/Track.cpp:378-419) for every match of a frame pair in one device pass -
  * SURVEY section 8(f).3.  Per feature i of the reference key frame with match_idx[i] >= 0 and no map point yet:

@@ -944,8 +944,12 @@ __device__ inline d2_t load_agent(const double* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
+// (s_nop: a VMEM store of more than 64 bits reads its data a few cycles after issue, and a VALU write to those VGPRs in
+// the next instruction would change what is stored.  The compiler's hazard recogniser does not see through inline asm, so
+// the wait states are part of the instruction here - found with a temporary in the upper half of the operand, see the
+// express-copy experiment in DESIGN.md 4.1.1.)
 __device__ inline void store_agent(double* p, d2_t v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ inline void store_agent1(double* p, double v) {
     asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
@@ -4766,6 +4770,11 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
         SE2_HIP(hipMemcpy2D(S, (size_t)n * 8, h->red, (size_t)h->ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
     if (bs) SE2_HIP(hipMemcpy(bs, h->red + (size_t)n * h->ld, (size_t)n * 8, hipMemcpyDeviceToHost));
     return SE2GPU_OK;
+}
+
+int se2gpu_ba_debug_solver_path(const se2gpu_ba* h) {
+    if (!h || !h->initialized) return -1;
+    return h->host_solve ? 3 : h->chol_fallback ? 2 : h->chol_steps ? 1 : 0;
 }
 
 int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok) {

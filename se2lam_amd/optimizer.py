@@ -8,6 +8,7 @@ this file is include/se2lam_amd/optimizer.h.  All compute happens in libse2gpu.s
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -24,6 +25,13 @@ def _stats_dict(st):
                 lambda_hist=list(st.lambda_hist[:n]), trials_hist=list(st.trials_hist[:n]))
 
 
+def _no_fallback(h):
+    """This harness (tests, bench) treats the library's solver fallback as a failure: results would still be right, but a
+    dataflow time-out outside the fault-injection test is a bug that the fallback must not hide."""
+    if capi.lib().se2gpu_ba_debug_solver_path(h) == 2 and os.environ.get("SE2GPU_BA_CHOL_FAULT") != "1":
+        raise RuntimeError("se2gpu_ba: k_chol_tiles timed out and the handle fell back to k_chol_step")
+
+
 def optimize_batch(optimizers, iterations: int, mode: int = 0, stop=None):
     """se2gpu_ba_optimize_batch: optimize(iterations) of several initialised SlamOptimizers at once (independent
     windows, concurrently on the device).  Fills every optimizer's .stats; returns the iteration counts."""
@@ -34,6 +42,7 @@ def optimize_batch(optimizers, iterations: int, mode: int = 0, stop=None):
     capi.check(capi.lib().se2gpu_ba_optimize_batch(hs, n, int(iterations), int(mode), sp, st))
     for o, s in zip(optimizers, st):
         o.stats = _stats_dict(s)
+        _no_fallback(o._h)
     return [s.iterations for s in st]
 
 
@@ -72,7 +81,12 @@ class SlamOptimizer:
         capi.check(capi.lib().se2gpu_ba_optimize(self._h, int(iterations), int(mode), stop, int(self._verbose),
                                                  C.byref(st)))
         self.stats = _stats_dict(st)
+        _no_fallback(self._h)
         return st.iterations
+
+    def solver_path(self) -> int:
+        """se2gpu_ba_debug_solver_path: 0 dataflow, 1 column launches (configured), 2 column launches (fallback), 3 host"""
+        return int(capi.lib().se2gpu_ba_debug_solver_path(self._h))
 
     def activeRobustChi2(self) -> float:
         v = capi.lib().se2gpu_ba_chi2(self._h)

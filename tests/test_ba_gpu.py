@@ -591,15 +591,17 @@ def test_dataflow_timeout_falls_back_to_the_column_launches(synth):
             "from se2lam_amd.optimizer import SlamOptimizer\n"
             "g = synth.ba_graph(20, 600)\n"
             "o = SlamOptimizer(); o.load(g); o.initializeOptimization(0); o.optimize(6)\n"
-            "print(json.dumps({'chi2': o.stats['chi2_hist'], 'trials': o.stats['trials_hist']}))\n") % ROOT
+            "print(json.dumps({'chi2': o.stats['chi2_hist'], 'trials': o.stats['trials_hist'], 'path': o.solver_path()}))\n") % ROOT
     env = dict(os.environ)
     env["SE2GPU_BA_CHOL_FAULT"] = "1"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "k_chol_tiles timed out; continuing with k_chol_step" in r.stderr
     got = json.loads(r.stdout.strip().splitlines()[-1])
+    assert got["path"] == 2                      # se2gpu_ba_debug_solver_path: column launches after a time-out
     ref = _opt(synth.ba_graph(20, 600))
     ref.optimize(6)
+    assert ref.solver_path() == 0                # (everywhere else the harness raises if a handle fell back)
     assert got["trials"] == ref.stats["trials_hist"]
     assert np.allclose(got["chi2"], ref.stats["chi2_hist"], rtol=1e-9)
 
