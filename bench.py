@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--orb-batch", type=int, default=256)
     ap.add_argument("--orb-steps", type=int, default=10)
+    ap.add_argument("--orb-inflight", type=int, default=2,
+                    help="ORB batches in flight (extractor handles on their own streams, alternating); 1 = one handle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ba-windows", type=int, default=-1,
                     help="independent 50-KF local windows optimised concurrently per GPU (se2gpu_ba_optimize_batch); "
@@ -250,7 +252,7 @@ def main():
         try:
             from se2lam_amd import orb_bench
             orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch,
-                                    traffic=traffic if args.orb_batch == 256 else {})
+                                    traffic=traffic if args.orb_batch == 256 else {}, inflight=args.orb_inflight)
         except ImportError:
             orb_obj = None
         log("ORB leg done; CPU baselines")

@@ -1561,7 +1561,8 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         for (int l = 0; l < kMaxLevels; ++l) SE2_HIP(hipEventCreateWithFlags(&h->ev_lvl[l], hipEventDisableTiming));
     }
     hipStream_t sp = piped ? h->pyr_stream : st;
-    hipStream_t sb = h->prof.enabled ? st : h->side_stream;   // blurred pyramid: beside the key-point chain
+    // blurred pyramid: beside the key-point chain, on the handle's side stream (none with SE2GPU_ORB_SIDE_STREAM=0)
+    hipStream_t sb = (h->prof.enabled || !h->side_stream) ? st : h->side_stream;
     if (piped || sb != st) SE2_HIP(hipEventRecord(h->ev_fork, st));
     if (piped) SE2_HIP(hipStreamWaitEvent(sp, h->ev_fork, 0));
     if (sb != st) SE2_HIP(hipStreamWaitEvent(sb, h->ev_fork, 0));
@@ -1704,7 +1705,12 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
     h->stream = h->own_stream;
     if (const char* e = std::getenv("SE2GPU_ORB_SCORE"))
         h->score_mode = std::strcmp(e, "dense") == 0 ? 1 : (std::strcmp(e, "sparse") == 0 ? 2 : 0);
-    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+    // The side stream is created here, right after the handle's own stream, and not on first use: streams land on the
+    // device's few hardware queues in creation order, and a side stream that ends up on the queue of its own handle's main
+    // stream (or of another handle's) overlaps nothing - measured: 154k instead of 165k frames/s with two handles in flight.
+    // SE2GPU_ORB_SIDE_STREAM=0: no side stream (callers that keep three or more batches in flight, one queue per handle).
+    static const bool side_on = [] { const char* e = std::getenv("SE2GPU_ORB_SIDE_STREAM"); return !(e && e[0] == '0'); }();
+    if ((side_on && hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fs, hipEventDisableTiming) != hipSuccess) {
@@ -1835,7 +1841,7 @@ int se2gpu_orb_debug_level(se2gpu_orb* h, int frame, int level, int blurred, uin
     const int ow = g.w[level] + 2 * e, oh = g.h[level] + 2 * e;
     SE2_REQUIRE(out_cap >= (size_t)ow * oh, SE2GPU_ERR_CAPACITY, "debug_level: buffer too small");
     SE2_HIP(hipStreamSynchronize(h->stream));
-    SE2_HIP(hipStreamSynchronize(h->side_stream));
+    if (h->side_stream) SE2_HIP(hipStreamSynchronize(h->side_stream));
     const uint8_t* src = ((blurred & 1) ? h->blur.p : h->pyr.p) + (size_t)frame * g.frame_bytes + g.off[level] +
                          (size_t)(kEdge - e) * g.stride[level] + (kEdge - e);
     SE2_HIP(hipMemcpy2D(out, ow, src, g.stride[level], ow, oh, hipMemcpyDeviceToHost));

@@ -19,16 +19,21 @@ B_ORB = 5_742_474      # algorithmic bytes per frame, SURVEY.md §8(d)
 B_MATCH = 132_000      # algorithmic bytes per frame pair
 
 
-def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, traffic=None):
+def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, traffic=None, inflight=2):
     B = batch
     imgs = synth.frames(B, start=1000 * rank)
-    ex = ORBextractor(max_batch=B)
+    # Two extractor handles (own streams, own pyramids) alternate, so that batch k+1 is already queued while batch k runs:
+    # the device never waits for the host's sync / launch turnaround between batches, and the latency-bound tail of one
+    # batch (cell lists, level selection, orientation) overlaps the VALU-bound head of the next (pyramid, FAST score).
+    nex = max(1, int(inflight))
+    exs = [ORBextractor(max_batch=B) for _ in range(nex)]
+    ex = exs[0]
     mt = ORBmatcher(0.9, max_features=cap, max_batch=B)
     d_img = capi.DeviceArray.from_numpy(imgs)
-    # two output sets: the matcher of batch k (its own stream; 1 wave per pair, latency-bound) runs while the
-    # extractor already works on batch k+1
+    # three output sets: the matcher of batch k (its own stream; 1 wave per pair, latency-bound) runs while the
+    # extractors already work on batches k+1 and k+2
     bufs = []
-    for _ in range(2):
+    for _ in range(nex + 1):
         bufs.append(dict(kps=capi.DeviceArray(B * cap * 28), desc=capi.DeviceArray(B * cap * 32),
                          cnt=capi.DeviceArray(B * 4), m=capi.DeviceArray(B * cap * 4), nm=capi.DeviceArray(B * 4),
                          done=capi.Timer(), used=False))
@@ -36,22 +41,31 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     pb = (pa + 1) % B
     d_pa = capi.DeviceArray.from_numpy(pa)
     d_pb = capi.DeviceArray.from_numpy(pb)
-    state = {"k": 0}
+    state = {"k": 0, "pending": []}     # pending: batches whose extraction is queued but not yet matched
 
-    def step():
-        b = bufs[state["k"] % 2]
-        state["k"] += 1
-        if b["used"]:
-            b["done"].elapsed_ms()          # host-waits for the match that last read this buffer set (event sync)
-        ex.extract_batch_device(d_img.ptr, B, 480, 640, b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap)
-        ex.sync()                            # extraction of this batch complete (+ capacity check)
+    def finish(k):
+        b = bufs[k % len(bufs)]
+        exs[k % nex].sync()                  # extraction of batch k complete (+ capacity check)
         b["done"].start(mt.stream())
         mt.match_window_batch_device(b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap, d_pa.ptr, d_pb.ptr, B, 20,
                                      b["m"].ptr, b["nm"].ptr)
         b["done"].stop(mt.stream())
         b["used"] = True
 
+    def step():
+        k = state["k"]
+        state["k"] += 1
+        b = bufs[k % len(bufs)]
+        if b["used"]:
+            b["done"].elapsed_ms()          # host-waits for the match that last read this buffer set (event sync)
+        exs[k % nex].extract_batch_device(d_img.ptr, B, 480, 640, b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap)
+        state["pending"].append(k)
+        while len(state["pending"]) >= nex:  # (one handle: finish this batch now; two: the previous one)
+            finish(state["pending"].pop(0))
+
     def drain():
+        while state["pending"]:
+            finish(state["pending"].pop(0))
         mt.sync()
 
     for _ in range(warmup):
@@ -67,7 +81,7 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     if dist is not None:
         dt = dist.allreduce_max(dt)
     fps = world * B * steps / dt
-    last = bufs[(state["k"] - 1) % 2]
+    last = bufs[(state["k"] - 1) % len(bufs)]
     cnt = last["cnt"].to_numpy(np.int32, (B,))
     nm = last["nm"].to_numpy(np.int32, (B,))
     d_kps, d_desc, d_cnt = last["kps"], last["desc"], last["cnt"]
@@ -101,96 +115,107 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     print(f"[orb_bench] resident {fps:.0f} frames/s; streaming leg", file=sys.stderr, flush=True)
     streaming = None
     try:
-        streaming = run_streaming(rank, world, B, steps, sync_all, dist, ex, mt, cap)
+        streaming = run_streaming(rank, world, B, steps, sync_all, dist, exs, mt, cap)
     except Exception as exc:   # the streaming leg must never take the headline numbers down with it
         streaming = {"error": repr(exc)}
     return {"metric": "ORB extract+match frames/s @640x480", "value": fps, "unit": "frames/s", "n_gpus": world,
-            "batch": B, "steps": steps, "ms_per_batch": 1e3 * dt / steps, "scaling": "weak",
+            "batch": B, "steps": steps, "ms_per_batch": 1e3 * dt / steps, "scaling": "weak", "batches_in_flight": nex,
             "config": {"workload": "640x480 u8, 8-level pyramid, 1000 features/frame, MatchByWindow(win 20, ratio 0.9), "
                                    "frames t vs t+1", "features_per_frame": float(cnt.mean()),
                        "matches_per_pair": float(nm.mean())},
             "roofline": roof, "cpu_baseline": None, "streaming": streaming}
 
 
-def run_streaming(rank, world, B, steps, sync_all, dist, ex, mt, cap, nhost=4, warmup=2):
+def run_streaming(rank, world, B, steps, sync_all, dist, exs, mt, cap, nhost=4, warmup=2):
     """The same extract + match step with the camera-side transfers IN the loop ("GPU numbers
     include H2D/D2H"): every batch is a FRESH set of B frames uploaded from pinned host memory (nhost distinct batches,
-    round-robin) into one of two device image buffers on a copy stream of its own, and the key points, descriptors and
-    match lists of every batch are downloaded to pinned memory on a third stream.  Ordering is by events only (the
-    timers' stop events): upload k+1 and download k-1 overlap extraction k; the host waits only where the library
-    does (se2gpu_orb_sync)."""
+    round-robin) on a copy stream of its own, and the key points, descriptors and match lists of every batch are
+    downloaded to pinned memory behind the match, on the matcher's stream.  The extractor handles alternate as in run();
+    ordering is by events only (the timers' stop events): upload k+1 and match / download k-1 overlap extraction k; the
+    host waits only where the library does (se2gpu_orb_sync).  Streams: one per extractor handle, the matcher's, the upload
+    stream - one hardware queue each on a device with four."""
     frame_bytes = 480 * 640
     host = capi.PinnedArray((nhost, B, 480, 640), np.uint8)
     for i in range(nhost):
         host.array[i] = synth.frames(B, start=1000 * rank + 37 * i)
-    up, down = capi.Stream(), capi.Stream()
+    up = capi.Stream()
     L = capi.lib()
+    nex = len(exs)
     sets = []
-    for _ in range(2):
+    for _ in range(nex + 1):
         sets.append(dict(img=capi.DeviceArray(B * frame_bytes), kps=capi.DeviceArray(B * cap * 28),
                          desc=capi.DeviceArray(B * cap * 32), cnt=capi.DeviceArray(B * 4), m=capi.DeviceArray(B * cap * 4),
                          nm=capi.DeviceArray(B * 4),
                          h_kps=capi.PinnedArray((B * cap * 28,), np.uint8), h_desc=capi.PinnedArray((B * cap * 32,), np.uint8),
                          h_cnt=capi.PinnedArray((B,), np.int32), h_m=capi.PinnedArray((B * cap,), np.int32),
                          h_nm=capi.PinnedArray((B,), np.int32),
-                         uploaded=capi.Timer(), extracted=capi.Timer(), matched=capi.Timer(), downloaded=capi.Timer(),
-                         used=False))
+                         uploaded=capi.Timer(), extracted=capi.Timer(), downloaded=capi.Timer(), used=False))
     pa = np.arange(B, dtype=np.int32)
     d_pa = capi.DeviceArray.from_numpy(pa)
     d_pb = capi.DeviceArray.from_numpy((pa + 1) % B)
-    state = {"k": 0}
+    state = {"k": 0, "pending": []}
 
     def upload(k):
-        b = sets[k % 2]
+        b = sets[k % len(sets)]
         if b["used"]:
             b["extracted"].make_wait(up.h)       # the extraction that last read this image buffer
         b["uploaded"].start(up.h)
         capi.check(L.se2gpu_memcpy_h2d_async(b["img"].ptr, host.array[k % nhost].ctypes.data, B * frame_bytes, up.h))
         b["uploaded"].stop(up.h)
 
+    def finish(k):
+        b = sets[k % len(sets)]
+        exs[k % nex].sync()
+        mt.match_window_batch_device(b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap, d_pa.ptr, d_pb.ptr, B, 20,
+                                     b["m"].ptr, b["nm"].ptr)
+        b["downloaded"].start(mt.stream())
+        for dst, src, n in ((b["h_kps"], b["kps"], B * cap * 28), (b["h_desc"], b["desc"], B * cap * 32),
+                            (b["h_cnt"], b["cnt"], B * 4), (b["h_m"], b["m"], B * cap * 4), (b["h_nm"], b["nm"], B * 4)):
+            capi.check(L.se2gpu_memcpy_d2h_async(dst.array.ctypes.data, src.ptr, n, mt.stream()))
+        b["downloaded"].stop(mt.stream())
+        b["used"] = True
+
     def step():
         k = state["k"]
         state["k"] += 1
-        b = sets[k % 2]
+        b = sets[k % len(sets)]
+        ex = exs[k % nex]
         upload(k + 1)                            # next batch's frames travel while this one is extracted
         b["uploaded"].make_wait(ex.stream())
         if b["used"]:
-            b["downloaded"].make_wait(ex.stream())   # results of batch k-2 have left the output buffers
+            b["downloaded"].make_wait(ex.stream())   # the results of the batch that last used these buffers have left
         b["extracted"].start(ex.stream())
         ex.extract_batch_device(b["img"].ptr, B, 480, 640, b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap)
         b["extracted"].stop(ex.stream())
-        ex.sync()
-        b["matched"].start(mt.stream())
-        mt.match_window_batch_device(b["kps"].ptr, b["desc"].ptr, b["cnt"].ptr, cap, d_pa.ptr, d_pb.ptr, B, 20,
-                                     b["m"].ptr, b["nm"].ptr)
-        b["matched"].stop(mt.stream())
-        b["matched"].make_wait(down.h)
-        b["downloaded"].start(down.h)
-        for dst, src, n in ((b["h_kps"], b["kps"], B * cap * 28), (b["h_desc"], b["desc"], B * cap * 32),
-                            (b["h_cnt"], b["cnt"], B * 4), (b["h_m"], b["m"], B * cap * 4), (b["h_nm"], b["nm"], B * 4)):
-            capi.check(L.se2gpu_memcpy_d2h_async(dst.array.ctypes.data, src.ptr, n, down.h))
-        b["downloaded"].stop(down.h)
-        b["used"] = True
+        state["pending"].append(k)
+        while len(state["pending"]) >= nex:
+            finish(state["pending"].pop(0))
+
+    def drain():
+        while state["pending"]:
+            finish(state["pending"].pop(0))
+        mt.sync()
 
     upload(0)
     for _ in range(warmup):
         step()
-    down.sync()
+    drain()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    down.sync()
+    drain()
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
         dt = dist.allreduce_max(dt)
-    last = sets[(state["k"] - 1) % 2]
+    last = sets[(state["k"] - 1) % len(sets)]
     per_batch_up = B * frame_bytes
     per_batch_down = B * cap * (28 + 32 + 4) + 8 * B
     return {"value": world * B * steps / dt, "unit": "frames/s", "ms_per_batch": 1e3 * dt / steps,
             "h2d_bytes_per_batch": per_batch_up, "d2h_bytes_per_batch": per_batch_down,
             "h2d_gbs": per_batch_up * steps / dt / 1e9, "d2h_gbs": per_batch_down * steps / dt / 1e9,
             "features_per_frame": float(last["h_cnt"].array.mean()), "matches_per_pair": float(last["h_nm"].array.mean()),
-            "note": "fresh frames uploaded from pinned memory every batch (double-buffered, own stream), key points + "
-                    "descriptors + match lists downloaded every batch; PCIe-inclusive, never the headline `value`"}
+            "batches_in_flight": nex,
+            "note": "fresh frames uploaded from pinned memory every batch (own stream), key points + descriptors + match "
+                    "lists downloaded every batch behind the match; PCIe-inclusive, never the headline `value`"}
