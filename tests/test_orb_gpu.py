@@ -207,6 +207,28 @@ def test_pipelined_batches_equal_single_frames(synth, monkeypatch):
                 assert np.array_equal(out[b][0], k) and np.array_equal(out[b][1], d), (mode, start, b)
 
 
+def test_large_batch_pyramids_equal_the_single_frame_pyramids(oracle, synth):
+    """every pyramid level (with its 16 px frame) and every blurred level of frames 0, 9 and B-1 of a batch of 43 and of 32
+    frames equals the single-frame extractor's bit for bit, and so do the features - batch sizes the other tests do not
+    reach (written for a fused upper-level kernel that was measured slower and dropped)"""
+    from se2lam_amd.orb import ORBextractor
+    one = ORBextractor()
+    ex = ORBextractor(max_batch=43)
+    for B, start in ((43, 11), (32, 70)):
+        imgs = synth.frames(B, start=start)
+        out = ex.extract_batch(imgs)
+        levels = {b: [ex.debug_level(b, lv, bordered=True) for lv in range(8)] + [ex.debug_level(b, lv, blurred=True) for lv in range(8)]
+                  for b in (0, 9, B - 1)}
+        for b in (0, 9, B - 1):
+            k, d = one(imgs[b])
+            assert np.array_equal(out[b][0], k) and np.array_equal(out[b][1], d), (B, b)
+            ref = [one.debug_level(0, lv, bordered=True) for lv in range(8)] + [one.debug_level(0, lv, blurred=True) for lv in range(8)]
+            for q in range(16):
+                assert np.array_equal(levels[b][q], ref[q]), (B, b, q)
+        ko, do = oracle.orb_extract(imgs[B - 1])
+        assert np.array_equal(out[B - 1][0], ko) and np.array_equal(out[B - 1][1], do)
+
+
 def test_score_kernel_follows_the_candidate_density(oracle, synth):
     """default (auto) mode: the first frame goes through the candidate kernel, which counts the pixels passing its compass
     test; busy imagery (the benchmark texture: ~15 % candidates) switches to the dense kernel, quiet imagery back to the
