@@ -5,15 +5,16 @@
 set -e
 export TMPDIR=/tmp
 # one launch per kernel and batch, as bench.py's per-kernel (profiled) pass and its algorithmic bytes per launch assume: the
-# level pipeline of large batches (orb_run) would split k_fast_score / k_blur into four launches each
+# level pipeline of large batches (orb_run) would split k_fast_score / k_blur into four launches each, and two batches in
+# flight (--orb-inflight 2, the default) would stretch the kernels that overlap
 export SE2GPU_ORB_PIPELINE_MIN=1000000
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 cd $R
-timeout 300 tools/prof.sh $TAG --steps 50 --warmup 10 --orb-steps 5 --no-cpu-baseline --ba-windows 0 > gpurun_out/${TAG}_prof_stdout.log 2>&1 || true
+timeout 300 tools/prof.sh $TAG --steps 50 --warmup 10 --orb-steps 5 --orb-inflight 1 --no-cpu-baseline --ba-windows 0 > gpurun_out/${TAG}_prof_stdout.log 2>&1 || true
 for C in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $R/gpurun_out/pmc_$C
-  (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 --no-cpu-baseline --ba-windows 0 > $R/gpurun_out/pmc_$C/stdout.log 2>&1) || true
+  (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 --orb-inflight 1 --no-cpu-baseline --ba-windows 0 > $R/gpurun_out/pmc_$C/stdout.log 2>&1) || true
 done
 F=$(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 W=$(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)

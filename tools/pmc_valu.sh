@@ -5,13 +5,14 @@
 set -e
 export TMPDIR=/tmp
 # one launch per kernel and batch, as bench.py's per-kernel (profiled) pass and its algorithmic bytes per launch assume: the
-# level pipeline of large batches (orb_run) would split k_fast_score / k_blur into four launches each
+# level pipeline of large batches (orb_run) would split k_fast_score / k_blur into four launches each, and two batches in
+# flight (--orb-inflight 2, the default) would stretch the kernels that overlap
 export SE2GPU_ORB_PIPELINE_MIN=1000000
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1
 for C in VALUBusy LDSBankConflict; do
   mkdir -p $R/gpurun_out/pmc_$C
-  (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 --no-cpu-baseline --ba-windows 0 > $R/gpurun_out/pmc_$C/stdout.log 2>&1) || true
+  (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -f csv -d $R/gpurun_out/pmc_$C -o pmc -- python $R/bench.py --steps 10 --warmup 10 --orb-batch 256 --orb-steps 2 --orb-inflight 1 --no-cpu-baseline --ba-windows 0 > $R/gpurun_out/pmc_$C/stdout.log 2>&1) || true
 done
 python - "$R" "$TAG" <<'PY'
 import csv, glob, json, re, sys, collections
