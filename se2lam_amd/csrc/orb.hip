@@ -184,7 +184,18 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
     // eight taps of a source row lie in ONE (unaligned) 64-bit word starting at the smallest column.
     const int sx0 = sxv[0] & 0xffff, sx1 = sxv[1] & 0xffff, sx2 = sxv[2] & 0xffff, sx3 = sxv[3] & 0xffff;
     const int sb = min(min(sx0, sx1), min(sx2, sx3));
-    const int o8[4] = {8 * (sx0 - sb), 8 * (sx1 - sb), 8 * (sx2 - sb), 8 * (sx3 - sb)};
+    // tap pair {S[sx], S[sx + 1]} of output pixel q as two u16 lanes: one v_perm_b32 out of the 64-bit word (selector bytes
+    // i, zero, i + 1, zero with i = sx - sb), and the horizontal interpolation S[sx] * a0 + S[sx + 1] * a1 is one
+    // v_dot2_u32_u16 with the table's {a0 | a1 << 16} word - two instructions per pixel and source row instead of seven
+    typedef unsigned short ushort2r __attribute__((ext_vector_type(2)));
+    uint32_t sel[4];
+    ushort2r aw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t i = (uint32_t)((sxv[q] & 0xffff) - sb);
+        sel[q] = i | 0x0c000c00u | ((i + 1u) << 16);
+        aw[q] = __builtin_bit_cast(ushort2r, (uint32_t)av[q]);
+    }
     const uint8_t* src = pyr + pix(g, f, l - 1, 0, 0) + sb;
     const int sstride = g.stride[l - 1];
     const size_t obase = (size_t)f * g.frame_bytes + g.off[l] + 4 * xg;
@@ -198,10 +209,10 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
         uint32_t v = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const uint32_t t0 = (uint32_t)(w0 >> o8[q]), t1 = (uint32_t)(w1 >> o8[q]);   // tap pair in the low 16 bits
-            const int a0 = av[q] & 0xffff, a1 = (int)((uint32_t)av[q] >> 16);
-            const int r0 = (int)(t0 & 0xffu) * a0 + (int)((t0 >> 8) & 0xffu) * a1;
-            const int r1 = (int)(t1 & 0xffu) * a0 + (int)((t1 >> 8) & 0xffu) * a1;
+            const ushort2r p0 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm((uint32_t)(w0 >> 32), (uint32_t)w0, sel[q]));
+            const ushort2r p1 = __builtin_bit_cast(ushort2r, __builtin_amdgcn_perm((uint32_t)(w1 >> 32), (uint32_t)w1, sel[q]));
+            const int r0 = (int)__builtin_amdgcn_udot2(p0, aw[q], 0u, false);
+            const int r1 = (int)__builtin_amdgcn_udot2(p1, aw[q], 0u, false);
             uint32_t b = (uint32_t)((((yt.z * (r0 >> 4)) >> 16) + ((yt.w * (r1 >> 4)) >> 16) + 2) >> 2) & 0xffu;
             if (sxv[q] >= 0) b = 0;   // bit 31 = valid; the padding of the row stride stays 0
             v |= b << (8 * q);
@@ -1152,26 +1163,18 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
     if (x0 >= W || y0 >= H) return;
     const uint8_t* src = pyr + pix(g, f, l, 0, 0);
     uint8_t* dst = blur + pix(g, f, l, 0, 0);
-    // Horizontal 7-tap sums of a row in packed u16 pairs (they fit: 255 * 257 = 65535): the byte pairs {b, b+1} of the
-    // 12-byte window come from v_perm_b32, the taps are v_pk_add_u16 / v_pk_mad_u16 on two output pixels at once.
-    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    // Horizontal 7-tap sums of a row (they fit 16 bits: 255 * 257 = 65535): output pixel j needs the bytes j + 1 .. j + 7 of
+    // the 12-byte window; v_alignbyte_b32 brings them to the front of two dwords and two v_dot4_u32_u8 with the taps
+    // {18,34,49,55} and {49,34,18,0} add them up - 14 instructions per four pixels (27 as packed 16-bit multiply-adds).
     auto hrow_w = [&](uint32_t w0, uint32_t w1, uint32_t w2, int (&h)[4]) {
-        uint32_t e[9];   // pairs {b, b+1}, b = 1 .. 9
-        e[0] = __builtin_amdgcn_perm(w1, w0, 0x0c020c01u);
-        e[1] = __builtin_amdgcn_perm(w1, w0, 0x0c030c02u);
-        e[2] = __builtin_amdgcn_perm(w1, w0, 0x0c040c03u);
-        e[3] = __builtin_amdgcn_perm(w2, w1, 0x0c010c00u);
-        e[4] = __builtin_amdgcn_perm(w2, w1, 0x0c020c01u);
-        e[5] = __builtin_amdgcn_perm(w2, w1, 0x0c030c02u);
-        e[6] = __builtin_amdgcn_perm(w2, w1, 0x0c040c03u);
-        e[7] = __builtin_amdgcn_perm(w2, w2, 0x0c010c00u);
-        e[8] = __builtin_amdgcn_perm(w2, w2, 0x0c020c01u);
-        auto P = [&](int b) { return __builtin_bit_cast(ushort2v, e[b - 1]); };
-        const ushort2v k18 = {18, 18}, k34 = {34, 34}, k49 = {49, 49}, k55 = {55, 55};
-        // output pixels {0,1}: bytes 1..7 / 2..8 ; {2,3}: bytes 3..9 / 4..10
-        const ushort2v hA = (P(1) + P(7)) * k18 + (P(2) + P(6)) * k34 + (P(3) + P(5)) * k49 + P(4) * k55;
-        const ushort2v hB = (P(3) + P(9)) * k18 + (P(4) + P(8)) * k34 + (P(5) + P(7)) * k49 + P(6) * k55;
-        h[0] = hA[0]; h[1] = hA[1]; h[2] = hB[0]; h[3] = hB[1];
+        constexpr uint32_t K0 = 18u | 34u << 8 | 49u << 16 | 55u << 24, K1 = 49u | 34u << 8 | 18u << 16;
+        h[0] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), K1,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), K0, 0u, false), false);
+        h[1] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), K1,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), K0, 0u, false), false);
+        h[2] = (int)__builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), K1,
+                                           __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), K0, 0u, false), false);
+        h[3] = (int)__builtin_amdgcn_udot4(w2, K1, __builtin_amdgcn_udot4(w1, K0, 0u, false), false);
     };
     auto hrow = [&](int y, int (&h)[4]) {
         const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)y * stride + x0 - 4);
@@ -1203,14 +1206,19 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
             m0 = p[0]; m1 = p[1]; m2 = p[2];
         }
         hrow_w(c0, c1, c2, hw[(PH + 6) % 7]);
-        uint32_t out = 0;
+        int sacc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int sacc = 18 * (hw[PH % 7][q] + hw[(PH + 6) % 7][q]) + 34 * (hw[(PH + 1) % 7][q] + hw[(PH + 5) % 7][q]) +
-                             49 * (hw[(PH + 2) % 7][q] + hw[(PH + 4) % 7][q]) + 55 * hw[(PH + 3) % 7][q];
-            const int v = min(max((sacc + (1 << 15)) >> 16, 0), 255);
-            out |= (uint32_t)v << (8 * q);
-        }
+        for (int q = 0; q < 4; ++q)
+            sacc[q] = 18 * (hw[PH % 7][q] + hw[(PH + 6) % 7][q]) + 34 * (hw[(PH + 1) % 7][q] + hw[(PH + 5) % 7][q]) +
+                      49 * (hw[(PH + 2) % 7][q] + hw[(PH + 4) % 7][q]) + 55 * hw[(PH + 3) % 7][q] + (1 << 15);
+        // (v + 2^15) >> 16, saturated to a byte, two pixels per instruction (gfx950's v_ashr_pk_u8_i32: the low half of the
+        // result holds the two bytes, the upper half is NOT cleared - v_perm_b32 takes only the low halves).  Written with
+        // the builtin on purpose: the plain form min(max(x >> 16, 0), 255) is matched to the same instruction by ROCm 7.2's
+        // compiler, which then ORs the third pixel into the uncleared upper half (tools/dot_probe.hip reproduces that;
+        // every third pixel of a group came out as q2 | q0).
+        const uint32_t p01 = __builtin_amdgcn_ashr_pk_u8_i32(sacc[0], sacc[1], 16);
+        const uint32_t p23 = __builtin_amdgcn_ashr_pk_u8_i32(sacc[2], sacc[3], 16);
+        const uint32_t out = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
         uint32_t* o = (uint32_t*)(dst + (size_t)y * stride + x0);
         if (nvalid == 4) {
             *o = out;
