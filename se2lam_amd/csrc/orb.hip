@@ -1095,7 +1095,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
 
 __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __restrict__ pyr,
                                                       const int4* __restrict__ kp_list, const int* __restrict__ counts,
-                                                      int cap, float* __restrict__ angles) {
+                                                      int cap, float* __restrict__ angles, const int4* __restrict__ wtab) {
     // one wave per key point: lane = (row offset v = 0..15, column octet c = 0..3); a lane reads 8 bytes of row +v and
     // of row -v with two (unaligned) 32-bit loads each - 749 disc pixels in 4 load instructions instead of 47 byte
     // loads per lane.  Integer moments: the summation order is irrelevant.
@@ -1109,27 +1109,21 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
         const int4 kp = kp_list[(size_t)f * cap + k];
         const int stride = g.stride[kp.x];
         const uint8_t* center = pyr + pix(g, f, kp.x, kp.z, kp.y);
-        const int d = g.umax[v];
         const int u0 = -16 + 8 * c;
         const uint8_t* pp = center + u0 + v * stride;
         const uint8_t* pm = center + u0 - v * stride;
-        const uint32_t wp[2] = {*reinterpret_cast<const uint32_t*>(pp), *reinterpret_cast<const uint32_t*>(pp + 4)};
-        const uint32_t wm[2] = {*reinterpret_cast<const uint32_t*>(pm), *reinterpret_cast<const uint32_t*>(pm + 4)};
-        int vsum = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int u = u0 + i;
-            const int vp = (int)((wp[i >> 2] >> (8 * (i & 3))) & 0xffu);
-            const int vm = (int)((wm[i >> 2] >> (8 * (i & 3))) & 0xffu);
-            const bool in = u >= -d && u <= d;
-            if (v == 0) {
-                m10 += in ? u * vp : 0;
-            } else {
-                vsum += in ? vp - vm : 0;
-                m10 += in ? u * (vp + vm) : 0;
-            }
-        }
-        m01 = v * vsum;
+        const uint32_t p0 = *reinterpret_cast<const uint32_t*>(pp), p1 = *reinterpret_cast<const uint32_t*>(pp + 4);
+        uint32_t q0 = *reinterpret_cast<const uint32_t*>(pm), q1 = *reinterpret_cast<const uint32_t*>(pm + 4);
+        if (v == 0) q0 = q1 = 0;   // the centre row counts once
+        // m10 = sum u (I(u, v) + I(u, -v)), m01 = v sum (I(u, v) - I(u, -v)) over the disc row: with the byte weights
+        // {u + 16} and {1} of the lane's eight columns (zero outside the disc) these are eight v_dot4_u32_u8
+        const int4 w = wtab[lane];
+        const uint32_t su = __builtin_amdgcn_udot4(p0, (uint32_t)w.x, __builtin_amdgcn_udot4(p1, (uint32_t)w.y,
+                            __builtin_amdgcn_udot4(q0, (uint32_t)w.x, __builtin_amdgcn_udot4(q1, (uint32_t)w.y, 0u, false), false), false), false);
+        const uint32_t sp = __builtin_amdgcn_udot4(p0, (uint32_t)w.z, __builtin_amdgcn_udot4(p1, (uint32_t)w.w, 0u, false), false);
+        const uint32_t sm = __builtin_amdgcn_udot4(q0, (uint32_t)w.z, __builtin_amdgcn_udot4(q1, (uint32_t)w.w, 0u, false), false);
+        m10 = (int)su - 16 * (int)(sp + sm);
+        m01 = v * ((int)sp - (int)sm);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -1386,6 +1380,7 @@ struct se2gpu_orb {
     PinBuf<uint8_t> stage_h;      // single-frame path: pinned image staging and the packed result block
     DevBuf<uint8_t> out_d;
     std::vector<size_t> xtab_off, ytab_off;  // offsets (in int4) into tabs, per level
+    size_t orient_off = 0;                   // ... and of k_orientation's 64 weight entries
     int score_tiles = 0, blur_tiles = 0;
     Geom last_lists{};                       // geometry (with the list layout) of the last score launch
     int score_tile_base[kMaxLevels + 1], sparse_tile_base[kMaxLevels + 1], blur_tile_base[kMaxLevels + 1];
@@ -1530,7 +1525,20 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         h->xtab_off[l] = tabs.size();
         tabs.insert(tabs.end(), xt.begin(), xt.end());
     }
-    if (tabs.empty()) tabs.push_back(make_int4(0, 0, 0, 0));
+    // k_orientation's weights: lane = (row offset v, column octet c) of the radius-15 disc; for its eight columns u the
+    // bytes {u + 16 | 0} (x, y) and {1 | 0} (z, w), zero outside the disc row (|u| > umax[v])
+    h->orient_off = tabs.size();
+    for (int lane = 0; lane < 64; ++lane) {
+        const int v = lane & 15, c = lane >> 4, d = h->umax[v], u0 = -16 + 8 * c;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 8; ++i) {
+            const int u = u0 + i;
+            if (u < -d || u > d) continue;
+            w[i >> 2] |= (uint32_t)(u + 16) << (8 * (i & 3));
+            w[2 + (i >> 2)] |= 1u << (8 * (i & 3));
+        }
+        tabs.push_back(make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]));
+    }
     SE2_CHECK(h->tabs.upload(tabs, h->stream));
     // buffers
     const size_t B = (size_t)h->max_batch;
@@ -1666,7 +1674,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
                h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 3) / 4), dim3(256), 0, g, h->pyr.p,
-               h->kp_list.p, d_counts, cap, h->angles.p);
+               h->kp_list.p, d_counts, cap, h->angles.p, h->tabs.p + h->orient_off);
     SE2_LAUNCH(h->prof, st, "k_angle_trig", k_angle_trig, dim3((cap + 255) / 256, nframes), dim3(256), 0, d_counts, cap,
                h->angles.p, h->angle_cs.p);
     if (sb != st) SE2_HIP(hipStreamWaitEvent(st, h->ev_join, 0));
