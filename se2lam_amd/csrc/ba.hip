@@ -2783,41 +2783,16 @@ namespace {
 // launches.  The result is element-for-element what the host builder (ba_plan_host, kept as the reference
 // implementation and fallback: SE2GPU_BA_PLAN=host, or more than 1024 poses) produces, so the LM results are bit-identical
 // (tests/test_ba_gpu.py::test_device_plan_equals_host_plan).
-//   k_plan_lm        lm_ptr by binary search in the landmark-sorted edge list + pairs per landmark
+//   k_plan_init      lm_ptr by binary search in the landmark-sorted edge list + pairs per landmark | identity permutation |
+//                    blk_a / blk_b / blk_odo | cleared group descriptors         (one launch, segment after segment)
 //   k_scan_i32       exclusive scan (one workgroup)
-//   k_plan_pairs     (block key, edge s, edge t) of every contributor pair, in (landmark, s, t) order
+//   k_plan_pairs2    (block key, edge s, edge t) of every contributor pair, in (landmark, s, t) order | tail keys
 //   k_radix_*        stable LSD radix sort (hist / scan / scatter), <= 10 bits per pass: pairs by block key, edges by pose
-//   k_lower_bounds   CSR pointers of a sorted key list (blk_ptr, pose_ptr)
-//   k_plan_blocks    blk_a / blk_b / blk_odo
-//   k_plan_pack      first-fit-in-order packing of the 16-pair chunks into workgroups of 28 groups: the sequential rule
+//   k_lower_bounds   CSR pointers of a sorted key list (pose_ptr); k_plan_bounds: blk_ptr | split of the (s, t) pairs
+//   k_plan_pack(2)   first-fit-in-order packing of the 16-pair chunks into workgroups of 28 groups: the sequential rule
 //                    of the host builder evaluated as a scan over transfer functions on the 28 fill states
 // =============================================================================================
 __device__ __host__ inline int blk_index_of(int P, int a, int b) { return a * P - a * (a - 1) / 2 + (b - a); }
-
-__global__ void k_plan_lm(int L, int E, const int* __restrict__ e_lm, const int* __restrict__ e_kf,
-                          const uint8_t* __restrict__ fixed, int* __restrict__ lm_ptr, int* __restrict__ npair) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l > L) return;
-    int lo = 0, hi = E;   // first edge with e_lm >= l
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (e_lm[mid] < l) lo = mid + 1; else hi = mid;
-    }
-    lm_ptr[l] = lo;
-    if (l == L) return;
-    int end = lo;
-    while (end < E && e_lm[end] == l) ++end;
-    int np = 0;
-    for (int s = lo; s < end; ++s) {
-        const int a = e_kf[s];
-        if (fixed[a]) continue;
-        for (int t = s + 1; t < end; ++t) {
-            const int b = e_kf[t];
-            np += (!fixed[b] && a != b) ? 1 : 0;
-        }
-    }
-    npair[l] = np;
-}
 
 // exclusive scan of n ints by ONE workgroup of 1024 threads (contiguous chunk per thread); out[n] = total
 __global__ void k_scan_i32(const int* __restrict__ in, int* __restrict__ out, int n) {
@@ -2886,32 +2861,7 @@ __global__ void k_scan_tile_add(int* __restrict__ out, int n, const int* __restr
     if (i < n) out[i] += tile_off[i / kScanTile];
 }
 
-__global__ void k_plan_pairs(int L, int P, const int* __restrict__ lm_ptr, const int* __restrict__ e_kf,
-                             const uint8_t* __restrict__ fixed, const int* __restrict__ pair_base,
-                             int* __restrict__ key, int2* __restrict__ st) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= L) return;
-    int o = pair_base[l];
-    const int beg = lm_ptr[l], end = lm_ptr[l + 1];
-    for (int s = beg; s < end; ++s) {
-        const int a = e_kf[s];
-        if (fixed[a]) continue;
-        for (int t = s + 1; t < end; ++t) {
-            const int b = e_kf[t];
-            if (fixed[b] || a == b) continue;
-            key[o] = a < b ? blk_index_of(P, a, b) : blk_index_of(P, b, a);
-            st[o] = a < b ? make_int2(s, t) : make_int2(t, s);
-            ++o;
-        }
-    }
-}
-
 // keys past the real pair count (known only on the device: *count) sort behind every block
-__global__ void k_plan_tail(const int* __restrict__ count, int cap, int big, int* __restrict__ key) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap && i >= *count) key[i] = big;
-}
-
 constexpr int kRadixItems = 256;   // items per workgroup of a radix pass
 
 __global__ __launch_bounds__(kRadixItems) void k_radix_hist(const int* __restrict__ key, int n, int shift, int nbins,
@@ -2961,23 +2911,6 @@ __global__ void k_lower_bounds(const int* __restrict__ key, int n, int nq, int* 
     out[q] = lo;
 }
 
-__global__ void k_iota(int n, int* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = i;
-}
-__global__ void k_split_st(int n, const int2* __restrict__ st, int* __restrict__ pi, int* __restrict__ pj) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { pi[i] = st[i].x; pj[i] = st[i].y; }
-}
-
-__global__ void k_plan_blocks(int P, int* __restrict__ blk_a, int* __restrict__ blk_b, int* __restrict__ blk_odo) {
-    const int a = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= P || b < a) return;
-    const int q = blk_index_of(P, a, b);
-    blk_a[q] = a;
-    blk_b[q] = b;
-    blk_odo[q] = -1;
-}
 // PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan (the host checked: no self loops, no
 // duplicates; otherwise the edges take the k_odometry / k_reduce_odo fallback and this kernel is not launched)
 __global__ void k_plan_odo(int P, int O, const int* __restrict__ o_i, const int* __restrict__ o_j, int* __restrict__ blk_odo) {
@@ -3155,9 +3088,9 @@ __global__ void k_plan_expand(int nblk, const int* __restrict__ blk_ptr, const i
 // Independent steps of the plan as ONE launch each (a launch boundary costs about as much as these kernels run: 26 launches
 // were 90 us of host time and as much again on the device for a 50-key-frame window).  Items of the merged kernels are
 // laid out segment after segment, every segment starting on a workgroup boundary.
-//   k_plan_init   = k_plan_lm | k_iota | k_plan_blocks | k_fill_int4        (need nothing but the uploaded graph)
-//   k_plan_pairs2 = k_plan_pairs | k_plan_tail                              (after the scan of the pair counts)
-//   k_plan_bounds = k_lower_bounds (blk_ptr) | k_split_st                   (after the pairs are sorted)
+//   k_plan_init   = landmark CSR | identity permutation | block tables | cleared descriptors   (need nothing but the graph)
+//   k_plan_pairs2 = pair enumeration | tail keys                                             (after the scan of the pair counts)
+//   k_plan_bounds = lower bounds (blk_ptr) | split of the sorted (s, t) pairs                (after the pairs are sorted)
 __global__ __launch_bounds__(256) void k_plan_init(int L, int E, int P, const int* __restrict__ e_lm, const int* __restrict__ e_kf,
                                                     const uint8_t* __restrict__ fixed, int* __restrict__ lm_ptr,
                                                     int* __restrict__ npair, int* __restrict__ idx, int* __restrict__ blk_a,
@@ -3243,11 +3176,6 @@ __global__ __launch_bounds__(256) void k_plan_bounds(const int* __restrict__ key
         if (i < n) { pi[i] = st[i].x; pj[i] = st[i].y; }
     }
 }
-__global__ void k_fill_int4(size_t n, int4 v, int4* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = v;
-}
-
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
 
 // The host builder of the contributor plan: the reference implementation of the device kernels above and the fallback
