@@ -3876,7 +3876,12 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
 
 int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count) {
     if (!h->allreduce) return SE2GPU_OK;
+    // in the per-kernel pass (se2gpu_ba_profile) the exchange is timed like a launch: "allreduce_system" is the reduced
+    // system [S | b | scalars] of a trial, "allreduce_small" the scalar / diagonal exchanges (SURVEY.md section 8e asks for the
+    // all-reduce time of the 1/2/4/8 curve to be broken out)
+    h->prof.begin(h->stream);
     const int rc = h->allreduce(ptr, count, (void*)h->stream, h->ar_user);
+    h->prof.end(h->stream, count > 4096 ? "allreduce_system" : "allreduce_small");
     SE2_REQUIRE(rc == 0, SE2GPU_ERR_HIP, "all-reduce callback failed with %d", rc);
     return SE2GPU_OK;
 }
@@ -3908,9 +3913,11 @@ int ba_allreduce_system(se2gpu_ba* h) {
     if (h->ar_buffer || h->host_solve) return ba_allreduce(h, h->red, (size_t)rows * h->ld);
     const size_t count = tri_row_off(rows);   // (slightly above the exact size when the last row's tile is cut by ld)
     SE2_CHECK(h->red_packed.reserve(count));
-    hipLaunchKernelGGL(k_tri_pack, dim3(rows), dim3(256), 0, h->stream, h->red, h->ld, rows, h->red_packed.p, 0, (double*)nullptr);
+    SE2_LAUNCH(h->prof, h->stream, "k_tri_pack", k_tri_pack, dim3(rows), dim3(256), 0, h->red, h->ld, rows, h->red_packed.p, 0,
+               (double*)nullptr);
     SE2_CHECK(ba_allreduce(h, h->red_packed.p, count));
-    hipLaunchKernelGGL(k_tri_pack, dim3(rows), dim3(256), 0, h->stream, (const double*)nullptr, h->ld, rows, h->red_packed.p, 1, h->red);
+    SE2_LAUNCH(h->prof, h->stream, "k_tri_pack", k_tri_pack, dim3(rows), dim3(256), 0, (const double*)nullptr, h->ld, rows,
+               h->red_packed.p, 1, h->red);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }

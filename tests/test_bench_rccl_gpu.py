@@ -28,6 +28,11 @@ def test_bench_sharded_path_with_a_one_rank_rccl_communicator(synth):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["unit"] == "iters/s" and d["value"] > 0 and d["steps"] >= 20
     assert "RCCL" in d["config"]["parallelism"] or "single" in d["config"]["parallelism"]
+    # the exchange is broken out: the packed lower triangle, timed in the per-kernel pass
+    ex = d["exchange"]
+    from se2lam_amd import capi
+    assert ex["doubles_per_trial"] == capi.lib().se2gpu_ba_exchange_doubles(50) < (3 * 50 + 1) * 160
+    assert ex["allreduce_system_us"] > 0 and ex["pack_unpack_us"] > 0 and ex["allreduce_us_per_iteration"] > 0
     # the same window without the communicator: identical LM run (one rank: the all-reduce is the identity)
     o = SlamOptimizer()
     o.load(synth.ba_graph(50, 5000))
