@@ -76,3 +76,73 @@ def test_descriptor_is_steered_brief_on_the_blurred_level(oracle, synth):
                 wrong_unblurred += int(not np.array_equal(bits_u, bits))
     assert total > 900
     assert wrong_unblurred > 0.9 * total      # (the test can tell the blurred level from the un-blurred one)
+
+
+def test_key_points_are_the_best_cell_local_fast_maxima(oracle, synth):
+    """ComputeKeyPoints (:531-716) as properties that do not depend on the order of its loops: with S the FAST score map of
+    a level (checked against a brute-force segment test in test_independent_pin.py),
+    * every key point is a corner (S > 20, or S > 7 in a cell without any S > 20) and a strict maximum of S among its
+      eight neighbours inside its own cell (cv::FAST runs per cell with non-max suppression), response = S - 1;
+    * no candidate of a cell that was dropped beats a kept one of the same cell (both retainBest cuts - per cell and per
+      level - keep the larger responses), and a cell uses the low threshold only if it has no corner at the high one."""
+    t = oracle.orb_tables()
+    img = synth.frame(5)
+    kps, _ = oracle.orb_extract(img)
+    geo = oracle.orb_geometry(480, 640)
+    for lv in range(8):
+        S = oracle.orb_score(img, lv).astype(np.int32)
+        w, h, gcols, grows, cellW, cellH = (int(v) for v in geo[lv][:6])
+        sel = kps[kps["octave"] == lv]
+        xs, ys = _level_xy(sel, float(t["scale"][lv]))
+        kept = set(zip(ys.tolist(), xs.tolist()))
+        assert len(kept) == len(sel)
+        assert np.array_equal(sel["response"], (S[ys, xs] - 1).astype(np.float32))
+        # candidates per cell: strict 8-neighbour maxima inside the cell's window of the scan area [16, w-16) x [16, h-16)
+        cand = {}
+        yy, xx = np.nonzero(S[16:h - 16, 16:w - 16] > 7)
+        for y, x in zip((yy + 16).tolist(), (xx + 16).tolist()):
+            cj, ci = min((x - 16) // cellW, gcols - 1), min((y - 16) // cellH, grows - 1)
+            xa, ya = 16 + cj * cellW, 16 + ci * cellH
+            xb = w - 16 if cj == gcols - 1 else xa + cellW
+            yb = h - 16 if ci == grows - 1 else ya + cellH
+            nb = S[max(y - 1, ya):min(y + 2, yb), max(x - 1, xa):min(x + 2, xb)]
+            if (nb >= S[y, x]).sum() == 1:
+                cand.setdefault((ci, cj), []).append((y, x, int(S[y, x])))
+        allc = {(y, x) for c in cand.values() for (y, x, _) in c}
+        assert kept <= allc, lv                                            # corners, maxima of their cell
+        for cell, c in cand.items():
+            high = [p for p in c if p[2] > 20]
+            pool = high if high else c                                     # iniThFAST, else minThFAST for this cell
+            k_in = [p for p in pool if (p[0], p[1]) in kept]
+            assert all((p[0], p[1]) not in kept for p in c if p not in pool), (lv, cell)
+            if k_in:
+                worst_kept = min(p[2] for p in k_in)
+                assert all(p[2] <= worst_kept for p in pool if (p[0], p[1]) not in kept), (lv, cell)
+
+
+def test_window_matches_satisfy_the_constraints_of_the_search(oracle, synth):
+    """ORBmatcher::MatchByWindow (/root/reference/src/ORBmatcher.cpp:278-381) as order-independent properties of its
+    result: every accepted pair lies inside the search window around the previous position (Frame::GetFeaturesInArea,
+    Frame.cpp:222-286), within the level band, at a Hamming distance (independent popcount) of at most TH_LOW = 75; the
+    assignment is one to one; the rotation differences of the survivors fall into at most three bins of the 30-bin
+    histogram (ComputeThreeMaxima keeps three); and the previous positions were moved onto the partners."""
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for f0, f1, win, off in ((0, 1, 20, 1), (3, 5, 25, 2), (10, 10, 10, 0)):
+        k0, d0 = oracle.orb_extract(synth.frame(f0))
+        k1, d1 = oracle.orb_extract(synth.frame(f1))
+        m12, nm, prev = oracle.match_window(k0, d0, k1, d1, win=win, level_offset=off)
+        i1 = np.nonzero(m12 >= 0)[0]
+        i2 = m12[i1]
+        assert nm == len(i1) > 100
+        assert len(set(i2.tolist())) == len(i2)
+        dx = k1["x"][i2] - k0["x"][i1]; dy = k1["y"][i2] - k0["y"][i1]
+        assert (np.abs(dx) < win + 1).all() and (np.abs(dy) < win + 1).all()
+        l1, l2 = k0["octave"][i1], k1["octave"][i2]
+        assert (l2 >= np.maximum(l1 - off, 0)).all() and (l2 <= l1 + off).all()
+        dist = pop[d0[i1] ^ d1[i2]].sum(1)
+        assert (dist <= 75).all()
+        rot = k0["angle"][i1] - k1["angle"][i2]
+        rot = np.where(rot < 0, rot + np.float32(360), rot)
+        bins = np.floor(rot * np.float32(30.0 / 360.0) + 0.5).astype(int) % 30          # round(); bin 30 wraps to 0
+        assert len(np.unique(bins)) <= 3
+        assert np.array_equal(prev[i1], np.stack([k1["x"][i2], k1["y"][i2]], 1))
