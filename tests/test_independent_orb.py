@@ -146,3 +146,33 @@ def test_window_matches_satisfy_the_constraints_of_the_search(oracle, synth):
         bins = np.floor(rot * np.float32(30.0 / 360.0) + 0.5).astype(int) % 30          # round(); bin 30 wraps to 0
         assert len(np.unique(bins)) <= 3
         assert np.array_equal(prev[i1], np.stack([k1["x"][i2], k1["y"][i2]], 1))
+
+
+def test_harris_responses_equal_a_vectorised_sobel_structure_tensor(oracle, synth):
+    """scoreType == HARRIS_SCORE: the responses of the key points are the Harris measure of the 7 x 7 block of integer Sobel
+    gradients around the key point on the UN-blurred level (HarrisResponses, ORBextractor.cpp:85-126) - recomputed here
+    with whole-image numpy convolutions instead of the per-point pointer walk."""
+    t = oracle.orb_tables()
+    img = synth.frame(4)
+    params = oracle.orb_params(score_type=oracle.HARRIS_SCORE)
+    kps, _ = oracle.orb_extract(img, params)
+    assert len(kps) > 500
+    scale = np.float32(1.0) / (np.float32(4 * 7) * np.float32(255.0))
+    s4 = scale * scale * scale * scale
+    worst = 0.0
+    for lv in range(8):
+        I = oracle.orb_level(img, lv, params=params, bordered=True).astype(np.int64)
+        Ix = np.zeros_like(I); Iy = np.zeros_like(I)
+        Ix[1:-1, 1:-1] = 2 * (I[1:-1, 2:] - I[1:-1, :-2]) + (I[:-2, 2:] - I[:-2, :-2]) + (I[2:, 2:] - I[2:, :-2])
+        Iy[1:-1, 1:-1] = 2 * (I[2:, 1:-1] - I[:-2, 1:-1]) + (I[2:, :-2] - I[:-2, :-2]) + (I[2:, 2:] - I[:-2, 2:])
+        sel = kps[kps["octave"] == lv]
+        xs, ys = _level_xy(sel, float(t["scale"][lv]))
+        for k in range(len(sel)):
+            cy, cx = ys[k] + 16, xs[k] + 16
+            wx = Ix[cy - 3:cy + 4, cx - 3:cx + 4]; wy = Iy[cy - 3:cy + 4, cx - 3:cx + 4]
+            a, b, c = int((wx * wx).sum()), int((wy * wy).sum()), int((wx * wy).sum())
+            ref = (np.float32(a) * np.float32(b) - np.float32(c) * np.float32(c)
+                   - np.float32(0.04) * (np.float32(a) + np.float32(b)) * (np.float32(a) + np.float32(b))) * s4
+            got = float(sel["response"][k])
+            worst = max(worst, abs(got - float(ref)) / max(abs(float(ref)), 1e-12))
+    assert worst < 1e-5, worst
