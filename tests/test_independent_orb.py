@@ -176,3 +176,46 @@ def test_harris_responses_equal_a_vectorised_sobel_structure_tensor(oracle, synt
             got = float(sel["response"][k])
             worst = max(worst, abs(got - float(ref)) / max(abs(float(ref)), 1e-12))
     assert worst < 1e-5, worst
+
+
+def test_projection_matches_satisfy_the_constraints_of_the_search(oracle, synth):
+    """ORBmatcher::MatchByProjection (ORBmatcher.cpp:383-454) as properties of its result, with the projection done here in
+    float64 numpy: a matched map point is good (not skipped), projects into the image, lies within
+    mMainOctave * winSize pixels of its key point (both axes) and within the level band, at a popcount distance of at most
+    TH_HIGH = 100; the key point was not observed before; no map point is used twice."""
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    k0, d0 = oracle.orb_extract(synth.frame(0))
+    k1, d1 = oracle.orb_extract(synth.frame(1))
+    for seed in (0, 1, 2):
+        rng = np.random.default_rng(100 + seed)
+        fx = fy = 400.0; cx, cy = 320.0, 240.0
+        m = 1500
+        src = rng.integers(0, len(k0), m)
+        depth = rng.uniform(800, 6000, m)
+        Xc = np.stack([(k0["x"][src] - cx) / fx * depth, (k0["y"][src] - cy) / fy * depth, depth], 1)
+        th = 0.01
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        tt = np.array([15.0, -4.0, 8.0])
+        Tcw = np.concatenate([R, tt[:, None]], 1).astype(np.float32)
+        mp_pos = ((Xc - tt) @ R).astype(np.float32)
+        mp_desc = d0[src].copy()
+        mp_desc ^= (rng.integers(0, 256, (m, 32)).astype(np.uint8) & ((rng.random((m, 32)) < 0.03) * 255).astype(np.uint8))
+        mp_oct = k0["octave"][src].astype(np.int32)
+        skip = (rng.random(m) < 0.1).astype(np.uint8)
+        seen = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+        win, off = 15, 2
+        idx, nm = oracle.match_projection(mp_pos, mp_desc, mp_oct, skip, Tcw, (fx, fy, cx, cy), k1, d1, seen, win, off, 0.6)
+        kp = np.nonzero(idx >= 0)[0]
+        mp = idx[kp]
+        assert nm == len(kp) > 50
+        assert len(set(mp.tolist())) == len(mp)
+        assert not skip[mp].any() and not seen[kp].any()
+        Xw = mp_pos[mp].astype(np.float64)
+        Xcam = Xw @ Tcw[:, :3].astype(np.float64).T + Tcw[:, 3].astype(np.float64)
+        u = fx * Xcam[:, 0] / Xcam[:, 2] + cx; v = fy * Xcam[:, 1] / Xcam[:, 2] + cy
+        assert (Xcam[:, 2] > 0).all() and (u >= 0).all() and (u < 640).all() and (v >= 0).all() and (v < 480).all()
+        r = mp_oct[mp] * win
+        assert (np.abs(k1["x"][kp] - u) <= r + 1e-2).all() and (np.abs(k1["y"][kp] - v) <= r + 1e-2).all()
+        lv = k1["octave"][kp]
+        assert (lv >= np.maximum(mp_oct[mp] - off, 0)).all() and (lv <= mp_oct[mp] + off).all()
+        assert (pop[mp_desc[mp] ^ d1[kp]].sum(1) <= 100).all()
