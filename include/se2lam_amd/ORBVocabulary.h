@@ -221,6 +221,16 @@ public:
         for (int i = 0; i < n; ++i) if (node_of[i] >= 0) fv.idx[start[node_of[i]]++] = i;
     }
 
+    // the reference's call line unchanged - `_pVoc->transform(vCurrentDesc, mBowVec, mFeatVec, 4)` (KeyFrame.cpp:248-251) with
+    // vCurrentDesc = toDescriptorVector(descriptors), a std::vector<cv::Mat> of 1 x 32 rows: any row type with a `data`
+    // member pointing at the 32 descriptor bytes
+    template <class Row>
+    void transform(const std::vector<Row>& features, BowVector& v, FeatureVectorCSR& fv, int levelsup) const {
+        std::vector<uint8_t> rows(features.size() * (size_t)kDescBytes);
+        for (size_t i = 0; i < features.size(); ++i) std::memcpy(&rows[i * kDescBytes], features[i].data, kDescBytes);
+        transform(rows.data(), (int)features.size(), v, fv, levelsup);
+    }
+
     // score(a, b): the vectors are sorted and normalised as transform() leaves them   (ScoringObject.cpp)
     double score(const BowVector& a, const BowVector& b) const {
         double s = 0.0;

@@ -27,7 +27,17 @@ int main(int argc, char** argv) {
         const std::vector<uint8_t> d = slurp(argv[2 + s]);
         const int n = (int)(d.size() / 32);
         se2lam_amd::FeatureVectorCSR fv;
-        voc.transform(d.data(), n, bow[s], fv, levelsup);   // mpVoc->transform(vCurrentDesc, mBowVec, mFeatVec, 4)
+        voc.transform(d.data(), n, bow[s], fv, levelsup);
+        {   // the reference's call line with a vector of row objects (cv::Mat rows of toDescriptorVector, KeyFrame.cpp:248-251)
+            struct Row { const uint8_t* data; };
+            std::vector<Row> vCurrentDesc;
+            for (int i = 0; i < n; ++i) vCurrentDesc.push_back(Row{d.data() + 32 * (size_t)i});
+            se2lam_amd::BowVector mBowVec; se2lam_amd::FeatureVectorCSR mFeatVec;
+            const se2lam_amd::ORBVocabulary* _pVoc = &voc;
+            _pVoc->transform(vCurrentDesc, mBowVec, mFeatVec, levelsup);
+            if (mBowVec.word != bow[s].word || mBowVec.value != bow[s].value || mFeatVec.nodes != fv.nodes ||
+                mFeatVec.ptr != fv.ptr || mFeatVec.idx != fv.idx) { std::printf("ROWS differ\n"); return 4; }
+        }
         std::printf("BOW%d", s);
         for (size_t i = 0; i < bow[s].size(); ++i) std::printf(" %u:%.17g", bow[s].word[i], bow[s].value[i]);
         std::printf("\nFV%d", s);
