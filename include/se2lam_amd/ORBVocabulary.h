@@ -170,7 +170,7 @@ public:
                 if (d < best) { best = d; final_id = id; }
             }
             if (nid && current_level == nid_level) { *nid = (NodeId)final_id; nid_set = true; }
-        } while (!m_leaf[final_id]);
+        } while (m_child_ptr[final_id + 1] > m_child_ptr[final_id]);   // Node::isLeaf() = children.empty()
         if (nid && !nid_set) *nid = (NodeId)final_id;
         word_id = (WordId)m_word[final_id];
         weight = m_weight[final_id];
