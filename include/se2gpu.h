@@ -93,6 +93,9 @@ int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, si
  *   SearchByBoW          /root/reference/src/ORBmatcher.cpp:128-276
  * ------------------------------------------------------------------------------------------ */
 int se2gpu_hamming(const uint8_t* a, const uint8_t* b);  /* host utility, 256-bit Hamming distance */
+/* ORBmatcher::ComputeThreeMaxima (/root/reference/include/se2lam/ORBmatcher.h:57, src/ORBmatcher.cpp:64-105): host utility
+ * over the bin COUNTS (histo[i].size()); ind1..3 in/out, the reference's callers start them at -1 */
+int se2gpu_three_maxima(const int32_t* counts, int L, int* ind1, int* ind2, int* ind3);
 
 typedef struct se2gpu_matcher se2gpu_matcher;
 int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out);

@@ -29,7 +29,8 @@ public:
     ORBextractor(const ORBextractor&) = delete;
     ORBextractor& operator=(const ORBextractor&) = delete;
 
-    // Compute the ORB features and descriptors on an image (mask must be empty, as at every reference call site)
+    // Compute the ORB features and descriptors on an image.  A non-empty mask is accepted and ignored, as in the reference
+    // (ORBextractor.cpp:797-828 builds a mask pyramid that cv::FAST at :616 / :622 is never given)
     void operator()(const Mat8U& image, const Mat8U& mask, std::vector<KeyPoint>& keypoints, Mat8U& descriptors) {
         if (image.empty()) return;                               // ORBextractor.cpp:730-731
         const int cap = 2 * nfeatures_;

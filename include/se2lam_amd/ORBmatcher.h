@@ -4,11 +4,13 @@
 //   int MatchByWindow(frame1, frame2, vbPrevMatched, winSize, vnMatches12, levelOffset=1, minLevel=0, maxLevel=8) (:68-71)
 //   int MatchByProjection(pNewKF, localMPs, winSize, levelOffset, vMatchesIdxMP)                  (:73-74)
 //   int SearchByBoW(pKF1, pKF2, mapIdxMatches12, bIfMPOnly=true)                                 (:55)
+//   void ComputeThreeMaxima(histo, L, ind1, ind2, ind3)                                          (:57)
 // Frame / KeyFrame / MapPoint are pointer-graph classes of the reference's data model (out of scope); the adapters
 // take the POD content the matchers actually read from them (FrameView / MapPointView below) - INTEGRATION.md shows
 // the three-line glue that fills the views from the reference's classes.
 #pragma once
 #include <map>
+#include <vector>
 
 #include "types.h"
 
@@ -112,6 +114,14 @@ public:
         for (int i = 0; i < (int)dense.size(); ++i)
             if (dense[i] >= 0) mapIdxMatches12[i] = dense[i];
         return n;
+    }
+
+    // void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) (ORBmatcher.h:57): a
+    // public member in the reference; the device resolve kernels run the same function (se2gpu_three_maxima)
+    void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+        std::vector<int32_t> counts(L > 0 ? L : 0);
+        for (int i = 0; i < L; ++i) counts[i] = (int32_t)histo[i].size();
+        check(se2gpu_three_maxima(counts.data(), L, &ind1, &ind2, &ind3), "ORBmatcher::ComputeThreeMaxima");
     }
 
     float mfNNratio;             // public in the reference (ORBmatcher.h:65-66)

@@ -6,12 +6,15 @@
 // and the g2o::SparseOptimizer methods LocalMapper::localBA / Map::loadLocalGraph call
 //   (/root/reference/src/LocalMapper.cpp:239-260, src/Map.cpp:891-1053).
 // Signatures follow the reference's: tests/cpp_reference_call_lines.cpp pastes the call lines of Map.cpp:897, 928-929,
-// 951, 966-970, 989, 1048-1049 and LocalMapper.cpp:239-260 against this header.  The free functions that return raw
-// g2o vertex / edge pointers in the reference (never used by its hot path) return void here; addCamPara returns a
-// stable CamPara* as the reference does (Map.cpp:897).  With g2o / Eigen / OpenCV headers present, overloads taking
-// the real types are compiled in (conversions.h).
+// 951, 966-970, 989, 1048-1049, LocalMapper.cpp:239-260, GlobalMapper.cpp:340-345 and Localizer.cpp:235-240 against this
+// header - including the solver construction (SlamLinearSolver / SlamBlockSolver / SlamAlgorithm + setAlgorithm, tag
+// types here: the dense pose solve and the Levenberg controller live in the library).  The free functions that return
+// g2o vertex / edge pointers in the reference return address-stable handles owned by the optimizer (VertexSE2*,
+// EdgeSE2XYZ*, PreEdgeSE2*); addCamPara returns a stable CamPara* as the reference does (Map.cpp:897).  With g2o / Eigen /
+// OpenCV headers present, overloads taking the real types are compiled in (conversions.h).
 #pragma once
 #include <deque>
+#include <stdexcept>
 #include <vector>
 
 #include "types.h"
@@ -29,9 +32,12 @@ class SlamOptimizer;
 // What the reference keeps of an EdgeProjectXYZ2UV* / EdgeSE3* after adding it (LocalMapper::removeOutlierChi2,
 // LocalMapper.cpp:199-214; GlobalMapper::GlobalBA, GlobalMapper.cpp:415-476): computeError(), chi2(), setLevel(), level().
 // chi2() of all edges comes from ONE device pass after optimize() (se2gpu_ba_edge_chi2), cached by the optimizer.
+// setLevel() is bookkeeping for the caller's own loops (level() > 0 -> skip): the device graph is frozen by
+// initializeOptimization, and a SECOND initializeOptimization on the same optimizer - g2o's way of re-optimising over the
+// edges of one level - is refused by the library (SE2GPU_ERR_STATE -> std::runtime_error), never silently run over all edges.
 struct EdgeHandle {
     SlamOptimizer* opt = nullptr;
-    int index = -1;
+    int index = -1;      // position among the edges whose chi2 the library reports; -1: an edge without per-edge chi2
     int level_ = 0;
     void computeError() {}
     double chi2() const;
@@ -40,14 +46,58 @@ struct EdgeHandle {
 };
 typedef EdgeHandle EdgeProjectXYZ2UV;
 typedef EdgeHandle EdgeSE3;
+typedef EdgeHandle EdgeSE2XYZ;    // what addEdgeSE2XYZ returns (optimizer.h:100)
+typedef EdgeHandle PreEdgeSE2;    // what addEdgeSE2 returns (optimizer.h:109)
+
+struct VertexSE2 {                // what addVertexSE2 returns (optimizer.h:104): id() and estimate() of the g2o vertex
+    SlamOptimizer* opt = nullptr;
+    int id_ = -1;
+    int id() const { return id_; }
+    SE2 estimate() const;
+};
+
+// The reference builds its solver stack by hand in front of every optimisation (LocalMapper.cpp:240-243,
+// GlobalMapper.cpp:341-344, Localizer.cpp:236-239, optimizer.cpp:200-203):
+//     SlamLinearSolver* linearSolver = new SlamLinearSolver();
+//     SlamBlockSolver*  blockSolver  = new SlamBlockSolver(linearSolver);
+//     SlamAlgorithm*    solver       = new SlamAlgorithm(blockSolver);
+//     optimizer.setAlgorithm(solver);
+// Here the Schur complement, the dense pose solve and the Levenberg policy are fixed parts of libse2gpu, so the three
+// types are tags with g2o's ownership chain (the optimizer deletes the algorithm, which deletes the block solver, which
+// deletes the linear solver) - the lines above compile and run unchanged and leak nothing.
+struct SlamLinearSolver {};
+struct SlamBlockSolver {
+    explicit SlamBlockSolver(SlamLinearSolver* ls) : ls_(ls) {}
+    ~SlamBlockSolver() { delete ls_; }
+    SlamBlockSolver(const SlamBlockSolver&) = delete;
+    SlamBlockSolver& operator=(const SlamBlockSolver&) = delete;
+private:
+    SlamLinearSolver* ls_;
+};
+struct SlamAlgorithm {
+    explicit SlamAlgorithm(SlamBlockSolver* bs) : bs_(bs) {}
+    ~SlamAlgorithm() { delete bs_; }
+    SlamAlgorithm(const SlamAlgorithm&) = delete;
+    SlamAlgorithm& operator=(const SlamAlgorithm&) = delete;
+    double currentLambda() const;                                         // REJECT_IF_LARGE_LAMBDA, LocalMapper.cpp:285-292
+private:
+    friend class SlamOptimizer;
+    SlamBlockSolver* bs_;
+    const SlamOptimizer* opt_ = nullptr;
+};
 
 class SlamOptimizer {  // g2o::SparseOptimizer (the subset the hot path uses)
 public:
     SlamOptimizer() { check(se2gpu_ba_create(&h_), "SlamOptimizer"); }
-    ~SlamOptimizer() { se2gpu_ba_destroy(h_); }
+    ~SlamOptimizer() { se2gpu_ba_destroy(h_); delete algorithm_; }
     SlamOptimizer(const SlamOptimizer&) = delete;
     SlamOptimizer& operator=(const SlamOptimizer&) = delete;
 
+    void setAlgorithm(SlamAlgorithm* a) {                                 // LocalMapper.cpp:243: takes ownership, as g2o does
+        if (a != algorithm_) delete algorithm_;
+        algorithm_ = a;
+        if (a) a->opt_ = this;
+    }
     void setVerbose(bool v) { verbose_ = v; }
     void setForceStopFlag(bool* flag) { stop_ = flag; }                   // LocalMapper.cpp:246
     bool initializeOptimization(int level = 0) {                          // LocalMapper.cpp:259
@@ -64,14 +114,21 @@ public:
     }
     void addEdge(EdgeHandle*) {}                                          // Map.cpp:551: the library added it already
     EdgeHandle* newEdge() { edges_.emplace_back(); edges_.back().opt = this; edges_.back().index = (int)edges_.size() - 1; return &edges_.back(); }
+    EdgeHandle* newPlainEdge() { plain_edges_.emplace_back(); plain_edges_.back().opt = this; return &plain_edges_.back(); }
+    VertexSE2* newVertexSE2(int id) { vertices_.emplace_back(); vertices_.back().opt = this; vertices_.back().id_ = id; return &vertices_.back(); }
     double edgeChi2(int index) {
+        if (index < 0) throw std::runtime_error("chi2(): the library reports per-edge chi2 for EdgeProjectXYZ2UV / EdgeSE3 only");
         if (edge_chi2_.empty()) {
             edge_chi2_.assign(edges_.size(), 0.0);
             check(se2gpu_ba_edge_chi2(h_, edge_chi2_.data(), (int)edge_chi2_.size()), "EdgeProjectXYZ2UV::chi2");
         }
         return edge_chi2_.at(index);
     }
-    void clear() { check(se2gpu_ba_clear(h_), "clear"); }
+    // g2o::SparseOptimizer::clear(): vertices and edges are gone, every handle handed out so far is invalid
+    void clear() {
+        check(se2gpu_ba_clear(h_), "clear");
+        edges_.clear(); plain_edges_.clear(); vertices_.clear(); edge_chi2_.clear(); cams_.clear();
+    }
     void clearParameters() {}
     double activeRobustChi2() { return se2gpu_ba_chi2(h_); }
     double currentLambda() const { return stats_.lambda_final; }          // REJECT_IF_LARGE_LAMBDA, LocalMapper.cpp:285-292
@@ -81,7 +138,9 @@ public:
 
 private:
     std::deque<CamPara> cams_;
-    std::deque<EdgeHandle> edges_;
+    std::deque<EdgeHandle> edges_, plain_edges_;
+    std::deque<VertexSE2> vertices_;
+    SlamAlgorithm* algorithm_ = nullptr;
     std::vector<double> edge_chi2_;
     se2gpu_ba* h_ = nullptr;
     bool* stop_ = nullptr;
@@ -90,6 +149,7 @@ private:
 };
 
 inline double EdgeHandle::chi2() const { return opt->edgeChi2(index); }
+inline double SlamAlgorithm::currentLambda() const { return opt_ ? opt_->currentLambda() : 0.0; }
 
 inline void initOptimizer(SlamOptimizer& opt, bool verbose = false) { opt.setVerbose(verbose); }
 
@@ -105,8 +165,9 @@ inline CamPara* addCamPara(SlamOptimizer& opt, const MatT& K, int id) {
     return c;
 }
 
-inline void addVertexSE2(SlamOptimizer& opt, const SE2& pose, int id, bool fixed = false) {
+inline VertexSE2* addVertexSE2(SlamOptimizer& opt, const SE2& pose, int id, bool fixed = false) {
     check(se2gpu_ba_add_vertex_se2(opt.handle(), id, pose.x, pose.y, pose.theta, fixed), "addVertexSE2");
+    return opt.newVertexSE2(id);
 }
 
 inline void addVertexSBAXYZ(SlamOptimizer& opt, const Vector3D& xyz, int id, bool marginal = true, bool fixed = false) {
@@ -114,14 +175,16 @@ inline void addVertexSBAXYZ(SlamOptimizer& opt, const Vector3D& xyz, int id, boo
 }
 
 // campara and _Tbc are graph-wide in the reference (one CamPara, Config::bTc on every edge, Map.cpp:1048-1049)
-inline void addEdgeSE2XYZ(SlamOptimizer& opt, const Vector2D& meas, int id0, int id1, CamPara* /*campara*/,
-                          const SE3Quat& _Tbc, const Matrix2D& info, double thHuber) {
+inline EdgeSE2XYZ* addEdgeSE2XYZ(SlamOptimizer& opt, const Vector2D& meas, int id0, int id1, CamPara* /*campara*/,
+                                 const SE3Quat& _Tbc, const Matrix2D& info, double thHuber) {
     check(se2gpu_ba_set_Tbc(opt.handle(), _Tbc.R, _Tbc.t), "addEdgeSE2XYZ(Tbc)");
     check(se2gpu_ba_add_edge_se2xyz(opt.handle(), id0, id1, meas.v, info.m, thHuber), "addEdgeSE2XYZ");
+    return opt.newPlainEdge();
 }
 
-inline void addEdgeSE2(SlamOptimizer& opt, const Vector3D& meas, int id0, int id1, const Matrix3D& info) {
+inline PreEdgeSE2* addEdgeSE2(SlamOptimizer& opt, const Vector3D& meas, int id0, int id1, const Matrix3D& info) {
     check(se2gpu_ba_add_edge_se2(opt.handle(), id0, id1, meas.v, info.m), "addEdgeSE2");
+    return opt.newPlainEdge();
 }
 
 // Map::loadLocalGraph's per-observation information Sigma_all.inverse() (src/Map.cpp:1024-1049) for a whole window in
@@ -137,16 +200,16 @@ inline void computeEdgeInformation(int E, const float* lc, const float* lw, cons
 
 #if defined(SE2LAM_AMD_HAVE_G2O) && defined(SE2LAM_AMD_HAVE_EIGEN)
 // the reference's own argument types, converted explicitly (conversions.h)
-inline void addVertexSE2(SlamOptimizer& opt, const g2o::SE2& pose, int id, bool fixed = false) { addVertexSE2(opt, mirror(pose), id, fixed); }
+inline VertexSE2* addVertexSE2(SlamOptimizer& opt, const g2o::SE2& pose, int id, bool fixed = false) { return addVertexSE2(opt, mirror(pose), id, fixed); }
 inline void addVertexSBAXYZ(SlamOptimizer& opt, const Eigen::Vector3d& xyz, int id, bool marginal = true, bool fixed = false) {
     addVertexSBAXYZ(opt, mirror(xyz), id, marginal, fixed);
 }
-inline void addEdgeSE2XYZ(SlamOptimizer& opt, const Eigen::Vector2d& meas, int id0, int id1, CamPara* campara,
-                          const g2o::SE3Quat& _Tbc, const Eigen::Matrix2d& info, double thHuber) {
-    addEdgeSE2XYZ(opt, mirror(meas), id0, id1, campara, mirror(_Tbc), mirror(info), thHuber);
+inline EdgeSE2XYZ* addEdgeSE2XYZ(SlamOptimizer& opt, const Eigen::Vector2d& meas, int id0, int id1, CamPara* campara,
+                                 const g2o::SE3Quat& _Tbc, const Eigen::Matrix2d& info, double thHuber) {
+    return addEdgeSE2XYZ(opt, mirror(meas), id0, id1, campara, mirror(_Tbc), mirror(info), thHuber);
 }
-inline void addEdgeSE2(SlamOptimizer& opt, const Eigen::Vector3d& meas, int id0, int id1, const Eigen::Matrix3d& info) {
-    addEdgeSE2(opt, mirror(meas), id0, id1, mirror(info));
+inline PreEdgeSE2* addEdgeSE2(SlamOptimizer& opt, const Eigen::Vector3d& meas, int id0, int id1, const Eigen::Matrix3d& info) {
+    return addEdgeSE2(opt, mirror(meas), id0, id1, mirror(info));
 }
 #endif
 
@@ -237,6 +300,8 @@ inline SE2 estimateVertexSE2(SlamOptimizer& opt, int id) {
     SE2 s; s.x = v[0]; s.y = v[1]; s.theta = v[2];
     return s;
 }
+
+inline SE2 VertexSE2::estimate() const { return estimateVertexSE2(*opt, id_); }
 
 inline Vector3D estimateVertexSBAXYZ(SlamOptimizer& opt, int id) {
     Vector3D v;

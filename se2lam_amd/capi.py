@@ -95,6 +95,7 @@ SYMBOLS = {
     "se2gpu_orb_profile_get": (_I, [_VP, _I, C.POINTER(C.c_char_p), _PD, C.POINTER(C.c_int64)]),
     # matcher
     "se2gpu_hamming": (_I, [_VP, _VP]),
+    "se2gpu_three_maxima": (_I, [_VP, _I, _VP, _VP, _VP]),
     "se2gpu_matcher_create": (_I, [_I, _I, C.POINTER(_VP)]),
     "se2gpu_matcher_destroy": (None, [_VP]),
     "se2gpu_matcher_set_stream": (_I, [_VP, _VP]),

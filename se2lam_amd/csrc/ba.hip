@@ -2727,8 +2727,18 @@ struct se2gpu_ba {
     // optimize(n) as ONE hipGraph launch: captured the second time the same (iterations, mode) is asked of an initialised
     // handle (a one-shot localBA never pays for the capture), replayed from then on.  Nothing in the slot sequence changes
     // between runs: the slot counter, the solver's epoch and the estimate's buffer bit live on the device (BaCtl).
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_iters = -1, graph_mode = -1, graph_seen_iters = -1, graph_seen_mode = -1;
+    // A small cache keyed by (iterations, mode): optimize(n) -> chi2 (= a run of zero iterations for the SE3 models) ->
+    // optimize(n) keeps replaying, and a caller that alternates two iteration counts does not re-capture every time.
+    struct GraphSlot { int iters = -1, mode = -1; hipGraphExec_t exec = nullptr; unsigned long stamp = 0; };
+    static constexpr int kGraphSlots = 3;
+    GraphSlot graphs[kGraphSlots];
+    unsigned long graph_clock = 0;
+    void drop_graphs() {
+        for (auto& g : graphs) {
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            g = GraphSlot{};
+        }
+    }
     double dev_seq = 0;           // host mirror of BaCtl::seq
     DevBuf<long long> chol_trace; // SE2GPU_BA_CHOL_TRACE=1: per-task stamps of the last solve -> stderr (debug_solve)
     bool chol_steps = false;      // SE2GPU_BA_CHOL=steps: one launch per block column (k_chol_step) instead
@@ -2769,7 +2779,7 @@ struct se2gpu_ba {
     ~se2gpu_ba() {
         if (ev_copy0) (void)hipEventDestroy(ev_copy0);
         if (ev_copy1) (void)hipEventDestroy(ev_copy1);
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        drop_graphs();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (h_mail) (void)hipHostFree(h_mail);
     }
@@ -3718,8 +3728,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     // the handle's device-side counters start over with the graph (flags = 0 = "no epoch yet")
     SE2_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(BaCtl), st));
     h->dev_seq = 0;
-    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-    h->graph_iters = h->graph_mode = h->graph_seen_iters = h->graph_seen_mode = -1;
+    h->drop_graphs();
     {
         const char* env = getenv("SE2GPU_BA_CHOL");
         h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt > 64 || h->chol_fallback;
@@ -3751,6 +3760,10 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->nwg_off = std::max(nwg, 1);
     }
     lap("synchronise");
+    // the borrow of se2gpu_ba_load ends here: everything has been copied into the pinned arena and uploaded
+    h->bulk_E = 0;
+    h->bulk_kf = h->bulk_lm = nullptr;
+    h->bulk_uv = h->bulk_info = nullptr;
     h->initialized = true;
     h->est_valid = false;
     return SE2GPU_OK;
@@ -4617,6 +4630,12 @@ int se2gpu_ba_load_local_graph(se2gpu_ba* h, const se2gpu_local_graph* g) {
 
 int se2gpu_ba_initialize(se2gpu_ba* h) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
+    // The graph is frozen by the first call (the arrays borrowed by se2gpu_ba_load are released there).  g2o allows a
+    // second initializeOptimization(level) over the edges of that level; here that is an error, not a silent re-run over all
+    // edges: rebuild the graph after se2gpu_ba_clear, or start over with se2gpu_ba_reset_estimates.
+    SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE,
+                "initialize: the graph is already initialised (se2gpu_ba_clear and rebuild it; re-optimising a subset "
+                "of the edges after setLevel is not supported)");
     return ba_upload_graph(h);
 }
 
@@ -4779,27 +4798,41 @@ int ba_run_begin(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop
         return SE2GPU_OK;
     };
     static const bool graphs_on = [] { const char* e = getenv("SE2GPU_BA_GRAPH"); return !(e && e[0] == '0'); }();
-    const bool graphable = graphs_on && !h->run_sync && !h->allreduce && !h->comm;
-    if (graphable && h->graph_exec && h->graph_iters == iters && h->graph_mode == mode) {
-        SE2_HIP(hipGraphLaunch(h->graph_exec, h->stream));
-    } else if (graphable && h->graph_seen_iters == iters && h->graph_seen_mode == mode) {
-        // second run of this shape: capture it (the capture itself does not execute anything), then launch
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        hipGraph_t g = nullptr;
-        SE2_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue_all();
-        const hipError_t ce = hipStreamEndCapture(h->stream, &g);
-        SE2_CHECK(rc);
-        SE2_HIP(ce);
-        const hipError_t ie = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        SE2_HIP(ie);
-        h->graph_iters = iters;
-        h->graph_mode = mode;
-        SE2_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+    // (a run of zero iterations is an evaluation - se2gpu_ba_chi2 of the SE3 models: one slot, never worth a graph and never
+    // allowed to push a real shape out of the cache)
+    const bool graphable = graphs_on && !h->run_sync && !h->allreduce && !h->comm && iters > 0;
+    se2gpu_ba::GraphSlot* slot = nullptr;
+    if (graphable) {
+        for (auto& g : h->graphs)
+            if (g.iters == iters && g.mode == mode) slot = &g;
+        if (!slot) {   // first run of this shape: remember it (least recently used slot), enqueue directly
+            slot = &h->graphs[0];
+            for (auto& g : h->graphs)
+                if (g.stamp < slot->stamp) slot = &g;
+            if (slot->exec) (void)hipGraphExecDestroy(slot->exec);
+            *slot = se2gpu_ba::GraphSlot{};
+            slot->iters = iters;
+            slot->mode = mode;
+            slot->stamp = ++h->graph_clock;
+            SE2_CHECK(enqueue_all());
+        } else if (slot->exec) {
+            slot->stamp = ++h->graph_clock;
+            SE2_HIP(hipGraphLaunch(slot->exec, h->stream));
+        } else {
+            // second run of this shape: capture it (the capture itself does not execute anything), then launch
+            slot->stamp = ++h->graph_clock;
+            hipGraph_t g = nullptr;
+            SE2_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc = enqueue_all();
+            const hipError_t ce = hipStreamEndCapture(h->stream, &g);
+            SE2_CHECK(rc);
+            SE2_HIP(ce);
+            const hipError_t ie = hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            SE2_HIP(ie);
+            SE2_HIP(hipGraphLaunch(slot->exec, h->stream));
+        }
     } else {
-        h->graph_seen_iters = iters;
-        h->graph_seen_mode = mode;
         SE2_CHECK(enqueue_all());
     }
     h->dev_seq += n0;
@@ -4846,8 +4879,7 @@ int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int 
         // nothing (lm_advance returns before touching the state), so it is simply redone.
         std::fprintf(stderr, "se2gpu_ba: k_chol_tiles timed out; continuing with k_chol_step\n");
         h->chol_steps = h->chol_fallback = true;
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // it launches k_chol_tiles
-        h->graph_iters = h->graph_seen_iters = -1;
+        h->drop_graphs();   // they launch k_chol_tiles
         SE2_HIP(hipStreamSynchronize(h->stream));   // the remaining slots of this run have all exited early
         hipLaunchKernelGGL(k_ctl_clear_error, dim3(1), dim3(1), 0, h->stream, h->ctl.p);
         c.error = 0;

@@ -21,6 +21,14 @@ int se2gpu_map_update_local_graph(const se2gpu_map_view* m, int current_kf, int 
                 "update_local_graph: current key frame %d of %d", current_kf, K);
     SE2_REQUIRE(m->kf_id && m->covis_ptr && m->kf_mp_ptr && (M == 0 || (m->mp_id && m->mp_kf_ptr)), SE2GPU_ERR_INVALID,
                 "update_local_graph: NULL array");
+    auto csr_ok = [](const int32_t* ptr, int n) {   // starts at 0, never decreases
+        if (ptr[0] != 0) return false;
+        for (int i = 0; i < n; ++i)
+            if (ptr[i + 1] < ptr[i]) return false;
+        return true;
+    };
+    SE2_REQUIRE(csr_ok(m->covis_ptr, K) && csr_ok(m->kf_mp_ptr, K) && (M == 0 || csr_ok(m->mp_kf_ptr, M)), SE2GPU_ERR_INVALID,
+                "update_local_graph: a CSR pointer array does not start at 0 or decreases");
     SE2_REQUIRE((m->covis_ptr[K] == 0 || m->covis_idx) && (m->kf_mp_ptr[K] == 0 || m->kf_mp_idx) &&
                 (M == 0 || m->mp_kf_ptr[M] == 0 || m->mp_kf_idx), SE2GPU_ERR_INVALID, "update_local_graph: NULL index array");
     // setLocalKFs: mCurrentKF and everything within `searchLevel` covisibility hops (Map.cpp:298-308); a pass expands

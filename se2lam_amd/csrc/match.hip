@@ -276,10 +276,10 @@ __device__ __forceinline__ void stage_candidates(const uint32_t* __restrict__ ca
     __syncthreads();
 }
 
-__device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& ind2, int& ind3) {
+// (L bins; the indices keep the caller's values where no bin qualifies, as ORBmatcher::ComputeThreeMaxima leaves them)
+__host__ __device__ __forceinline__ void three_maxima_n(const int* hist, int L, int& ind1, int& ind2, int& ind3) {
     int max1 = 0, max2 = 0, max3 = 0;
-    ind1 = ind2 = ind3 = -1;
-    for (int i = 0; i < kHisto; i++) {
+    for (int i = 0; i < L; i++) {
         const int s = hist[i];
         if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
         else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
@@ -287,6 +287,10 @@ __device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& in
     }
     if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+__device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& ind2, int& ind3) {
+    ind1 = ind2 = ind3 = -1;
+    three_maxima_n(hist, kHisto, ind1, ind2, ind3);
 }
 
 // Best / second-best scan of the candidate list of query q (ORBmatcher.cpp:308-325; ties go to the earliest list
@@ -741,6 +745,16 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
 }  // namespace
 
 extern "C" {
+
+// ORBmatcher::ComputeThreeMaxima (ORBmatcher.h:57, ORBmatcher.cpp:64-105) as the public member it is in the reference: the
+// three fullest of L histogram bins, the second / third dropped below a tenth of the first.  Host utility - the same
+// function the resolve kernels run on the device.  ind1..3 are in/out (the reference leaves them untouched where no bin
+// qualifies; its callers start from -1).
+int se2gpu_three_maxima(const int32_t* counts, int L, int* ind1, int* ind2, int* ind3) {
+    SE2_REQUIRE(L >= 0 && (L == 0 || counts) && ind1 && ind2 && ind3, SE2GPU_ERR_INVALID, "three_maxima: bad argument");
+    three_maxima_n(counts, L, *ind1, *ind2, *ind3);
+    return SE2GPU_OK;
+}
 
 // The reference constructs its ORBmatcher on the stack of every call (Track.cpp:131, LocalMapper.cpp:117).  Destroyed
 // handles are parked with their stream and buffers (per device, at most kPoolMax) and handed out again by

@@ -1809,7 +1809,9 @@ int se2gpu_orb_extract_batch_device(se2gpu_orb* h, const uint8_t* d_imgs, int nf
 int se2gpu_orb_extract(se2gpu_orb* h, const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
                        se2gpu_keypoint* kps, uint8_t* desc, int cap, int* n_out) {
     SE2_REQUIRE(h && n_out, SE2GPU_ERR_INVALID, "orb_extract: NULL argument");
-    SE2_REQUIRE(mask == nullptr, SE2GPU_ERR_INVALID, "masks are not supported (the reference passes an empty mask, Frame.cpp:25)");
+    // A mask is accepted and has no effect, exactly as in the reference: ComputePyramid builds mvMaskPyramid from it
+    // (ORBextractor.cpp:797-828) but ComputeKeyPoints calls cv::FAST without it (:616, :622) - no key point is ever masked.
+    (void)mask;
     *n_out = 0;
     if (!img || rows == 0 || cols == 0) return SE2GPU_OK;  // _image.empty(): silent return (ORBextractor.cpp:730)
     SE2_REQUIRE(kps && desc && cap > 0, SE2GPU_ERR_INVALID, "orb_extract: NULL output");

@@ -300,6 +300,11 @@ int se2gpu_sparsify_se3xyz(int npairs, const double* kf12, const int32_t* mp_ptr
     SE2_REQUIRE(npairs >= 0, SE2GPU_ERR_INVALID, "sparsify: negative pair count");
     if (npairs == 0) return SE2GPU_OK;
     SE2_REQUIRE(kf12 && mp_ptr && m_ptr && z_out12 && info_out36, SE2GPU_ERR_INVALID, "sparsify: NULL argument");
+    // the CSR pointers index host and device arrays: start at 0, never decrease
+    SE2_REQUIRE(mp_ptr[0] == 0 && m_ptr[0] == 0, SE2GPU_ERR_INVALID, "sparsify: mp_ptr / m_ptr must start at 0");
+    for (int p = 0; p < npairs; ++p)
+        SE2_REQUIRE(mp_ptr[p + 1] >= mp_ptr[p] && m_ptr[p + 1] >= m_ptr[p], SE2GPU_ERR_INVALID,
+                    "sparsify: mp_ptr / m_ptr decrease at pair %d", p);
     const int NP = mp_ptr[npairs], NM = m_ptr[npairs];
     SE2_REQUIRE(NP >= 0 && NM >= 0 && (NP == 0 || mp_xyz) && (NM == 0 || (m_kf && m_mp && m_info)), SE2GPU_ERR_INVALID,
                 "sparsify: NULL array");
@@ -334,7 +339,9 @@ int se2gpu_sparsify_se3xyz(int npairs, const double* kf12, const int32_t* mp_ptr
     hipStream_t st = nullptr;
     SE2_CHECK(d_kf.upload(kf12, 24 * (size_t)npairs, st));
     SE2_CHECK(d_mpp.upload(mp_ptr, (size_t)npairs + 1, st));
-    SE2_CHECK(d_mp.upload(mp_xyz, 3 * (size_t)std::max(NP, 1), st));
+    // (no pair has points: mp_xyz may be NULL - Sparsifier::DoMarginalizeSE3XYZBatch passes xyz.data() of an empty vector)
+    SE2_CHECK(d_mp.reserve(3 * (size_t)std::max(NP, 1)));
+    if (NP) SE2_HIP(hipMemcpyAsync(d_mp.p, mp_xyz, 3 * (size_t)NP * 8, hipMemcpyHostToDevice, st));
     SE2_CHECK(d_mmp.upload(mm_ptr.data(), mm_ptr.size(), st));
     SE2_CHECK(d_mkf.reserve(std::max<size_t>(kf_s.size(), 1)));
     if (!kf_s.empty()) SE2_HIP(hipMemcpyAsync(d_mkf.p, kf_s.data(), kf_s.size() * 4, hipMemcpyHostToDevice, st));

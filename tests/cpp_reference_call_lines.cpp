@@ -85,9 +85,13 @@ int main() {
     mLocalGraphKFs[0]->preOdomFromSelf.second = PreSE2{{500, 0, 0.02}, {100, 0, 0, 0, 100, 0, 0, 0, 1e-3}};
     bool mbAbortBA = false, mbGlobalBABegin = false;
 
-    // ---- LocalMapper::localBA, LocalMapper.cpp:239-246
+    // ---- LocalMapper::localBA, LocalMapper.cpp:239-246 (the solver construction lines as they stand in the reference)
     SlamOptimizer optimizer;
-    initOptimizer(optimizer, Config::LOCAL_VERBOSE);
+    SlamLinearSolver* linearSolver = new SlamLinearSolver();
+    SlamBlockSolver* blockSolver = new SlamBlockSolver(linearSolver);
+    SlamAlgorithm* solver = new SlamAlgorithm(blockSolver);
+    optimizer.setAlgorithm(solver);
+    optimizer.setVerbose(Config::LOCAL_VERBOSE);
     optimizer.setForceStopFlag(&mbAbortBA);
 
     // ---- Map::loadLocalGraph, Map.cpp:896-897
@@ -104,7 +108,8 @@ int main() {
         int vertexIdKF = i;
         bool fixed = (pKF->id == minKFid) || pKF->id == 1;
         g2o::SE2 pose(pKF->Twb.x, pKF->Twb.y, pKF->Twb.theta);
-        addVertexSE2(optimizer, pose, vertexIdKF, fixed);
+        VertexSE2* v = addVertexSE2(optimizer, pose, vertexIdKF, fixed);   // g2o::VertexSE2* in the reference (optimizer.h:104)
+        if (v->id() != vertexIdKF) return 1;
     }
     // Map.cpp:934-955
     for (int i = 0; i < nLocalKFs; i++) {
@@ -144,6 +149,11 @@ int main() {
     }
     optimizer.initializeOptimization(0);
     optimizer.optimize(Config::LOCAL_ITER);
+    // REJECT_IF_LARGE_LAMBDA, LocalMapper.cpp:285-292
+    if (solver->currentLambda() > 100.0) {
+        std::printf("-- DEBUG LM: current lambda too large %f , reject optimized result\n", solver->currentLambda());
+        return 1;
+    }
     // ---- Map::optimizeLocalGraph, Map.cpp:760-763, 776-779
     for (int i = 0; i < nLocalKFs; i++) {
         g2o::SE2 pose = estimateVertexSE2(optimizer, i);
@@ -160,6 +170,19 @@ int main() {
     std::printf("levels %d scale %.2f\n", extractor.GetLevels(), extractor.GetScaleFactor());
     std::map<int, int> mapIdxMatches12;
     (void)mapIdxMatches12;
+    {   // ORBmatcher.cpp:349-377: the rotation-consistency lines around ComputeThreeMaxima, a public member (ORBmatcher.h:57)
+        const int HISTO_LENGTH = ORBmatcher::HISTO_LENGTH;
+        std::vector<int> rotHist[HISTO_LENGTH];
+        for (int i = 0; i < 40; ++i) rotHist[3].push_back(i);
+        for (int i = 0; i < 12; ++i) rotHist[17].push_back(i);
+        for (int i = 0; i < 3; ++i) rotHist[29].push_back(i);
+        int ind1 = -1;
+        int ind2 = -1;
+        int ind3 = -1;
+        matcher.ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        std::printf("ComputeThreeMaxima: %d %d %d\n", ind1, ind2, ind3);
+        if (ind1 != 3 || ind2 != 17 || ind3 != -1) return 1;
+    }
     // ---- LocalMapper::removeOutlierChi2 (LocalMapper.cpp:172-214) on Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx)
     //      (Map.cpp:414-566): two key frames on the plane, one map point, the prior and the projection edges
     {
@@ -227,10 +250,46 @@ int main() {
         }
         SE3Quat T1 = estimateVertexSE3Expmap(optimizer, 1);
         std::printf("removeOutlierChi2 lines: %zu outliers, KF1 t = %.2f %.2f %.2f\n", vnOutlierIdxAll[0].size(), T1.t[0], T1.t[1], T1.t[2]);
+        const double chi2_first = vpEdgesAll[0][1]->chi2();
+        // g2o's second initializeOptimization() (re-optimising the level-0 edges after setLevel) is refused, not silently run
+        // over all edges
+        bool refused = false;
+        try { optimizer.initializeOptimization(0); } catch (const std::runtime_error&) { refused = true; }
+        if (!refused) return 1;
+        // ---- the optimizer reused across clear(): handles start over with the new graph - the chi2 of the rebuilt
+        // graph's edge 0 is its own, not a stale entry of the first graph's edge list
+        optimizer.clear();
+        addCamPara(optimizer, Config::Kcam, camParaId);
+        // Localizer::DoLocalBA, Localizer.cpp:235-240: the solver lines once more, on the reused optimizer
+        SlamLinearSolver* linearSolver = new SlamLinearSolver();
+        SlamBlockSolver* blockSolver = new SlamBlockSolver(linearSolver);
+        SlamAlgorithm* solver = new SlamAlgorithm(blockSolver);
+        optimizer.setAlgorithm(solver);
+        optimizer.setVerbose(false);
+        for (int vertexIdKF = 0; vertexIdKF < 2; ++vertexIdKF) {
+            const cv::Mat& pose = vertexIdKF ? Tcw1 : Tcw0;
+            addVertexSE3Expmap(optimizer, toSE3Quat(pose), vertexIdKF, vertexIdKF == 0);
+            addPlaneMotionSE3Expmap(optimizer, toSE3Quat(pose), vertexIdKF, Config::bTc);
+        }
+        addEdgeSE3Expmap(optimizer, Tc1c0, 0, 1, odoInfo);
+        addVertexSBAXYZ(optimizer, Vector3D(4000, 300, 500), vertexIdMP);
+        Eigen_Vector2d uvb(286.0 + 40.0, 262.0);   // a gross outlier as the ONLY second observation
+        EdgeProjectXYZ2UV* e0 = addEdgeXYZ2UV(optimizer, Eigen_Vector2d(290.0, 260.0), vertexIdMP, 0, camParaId, Matrix2d::Identity(), delta);
+        EdgeProjectXYZ2UV* e1 = addEdgeXYZ2UV(optimizer, uvb, vertexIdMP, 1, camParaId, Matrix2d::Identity(), delta);
+        if (e0->index != 0 || e1->index != 1) return 1;      // numbering restarted with the graph
+        optimizer.initializeOptimization(0);
+        optimizer.optimize(10);
+        std::printf("reused optimizer: edge chi2 %.4f %.4f (first graph: %.4f)\n", e0->chi2(), e1->chi2(), chi2_first);
+        if (!(e0->chi2() >= 0.0) || !(e1->chi2() >= 0.0) || !std::isfinite(e1->chi2())) return 1;
     }
     // ---- GlobalMapper::GlobalBA (GlobalMapper.cpp:340-412, 517-524): VertexSE3 + plane-motion prior + EdgeSE3
     {
         SlamOptimizer optimizer;
+        //initOptimizer(optimizer);
+        SlamLinearSolver* linearSolver = new SlamLinearSolver();                                     // GlobalMapper.cpp:341-344
+        SlamBlockSolver* blockSolver = new SlamBlockSolver(linearSolver);
+        SlamAlgorithm* solver = new SlamAlgorithm(blockSolver);
+        optimizer.setAlgorithm(solver);
         int SE3OffsetParaId = 0;
         addParaSE3Offset(optimizer, Isometry3D(), SE3OffsetParaId);
         cv::Mat T_w_c0 = cv::Mat::eye(4), T_w_c1 = cv::Mat::eye(4);

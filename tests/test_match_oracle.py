@@ -82,3 +82,34 @@ def test_match_window_on_consecutive_frames(oracle, synth):
     # matching a frame against itself: every key point in the grid matches itself unless a duplicate descriptor
     m, n, _ = oracle.match_window(k0, d0, k0, d0)
     assert (m[m >= 0] == np.nonzero(m >= 0)[0]).mean() > 0.95
+
+
+def test_compute_three_maxima_host_utility():
+    """ORBmatcher::ComputeThreeMaxima (ORBmatcher.h:57, ORBmatcher.cpp:64-105) as the public member it is in the reference:
+    se2gpu_three_maxima is the function the resolve kernels run, callable on the host (no device needed).  Against a
+    sort-based restatement on random histograms with ties, and the 10 % rule."""
+    import ctypes as C
+    from se2lam_amd import capi
+    rng = np.random.default_rng(5)
+
+    def ref(h):
+        order = sorted(range(len(h)), key=lambda i: (-h[i], i))      # strict '>' keeps the earliest of equal bins first
+        top = [i for i in order[:3] if h[i] > 0] + [-1] * 3
+        i1, i2, i3 = top[:3]
+        m1 = h[i1] if i1 >= 0 else 0
+        m2 = h[i2] if i2 >= 0 else 0
+        m3 = h[i3] if i3 >= 0 else 0
+        if m2 < np.float32(0.1) * np.float32(m1):
+            i2 = i3 = -1
+        elif m3 < np.float32(0.1) * np.float32(m1):
+            i3 = -1
+        return i1, i2, i3
+
+    for trial in range(300):
+        L = int(rng.integers(1, 31))
+        h = rng.integers(0, 4 if trial % 3 else 60, L).astype(np.int32)
+        if trial % 5 == 0:
+            h[rng.integers(0, L)] = 500
+        ind = [C.c_int(-1), C.c_int(-1), C.c_int(-1)]
+        capi.check(capi.lib().se2gpu_three_maxima(h.ctypes.data, L, C.byref(ind[0]), C.byref(ind[1]), C.byref(ind[2])))
+        assert tuple(i.value for i in ind) == ref(list(map(int, h))), (h, [i.value for i in ind])
