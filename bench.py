@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py - headline benchmark of the se2lam hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, or - when no
+                                                            WORLD_SIZE is set - bench.py starts the N ranks itself)
 
 Metric (BASELINE.json): BA Gauss-Newton/LM iterations per second on the 200-keyframe /
 20k-landmark synthetic SE(2) graph (config 4 formulation = Map::loadLocalGraph applied to a
@@ -95,21 +96,90 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    for _ in range(64):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        try:   # the rendezvous listens on MASTER_PORT + 1 (torchrun's own store owns MASTER_PORT): that one must be free too
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s2:
+                s2.bind(("127.0.0.1", port + 1))
+            return port
+        except OSError:
+            continue
+    return 29500
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, with the environment
+    torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Rank 0's stdout is
+    ours (the JSON line); the other ranks' stdout goes to stderr.  Returns the worst exit code."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SE2_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs across processes on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    except BaseException:
+        for p in procs:   # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+        raise
+    return rc
+
+
+def _dry_run(rank, world):
+    """SE2_BENCH_DRY_RUN=1: the launch + rendezvous skeleton of an N-rank run without touching a GPU (the CPU test of the
+    self-spawn path): every rank joins the TCP rendezvous, rank 0's 128-byte token reaches all of them, timings are maxed."""
+    from se2lam_amd.rendezvous import Rendezvous
+    dist = Rendezvous(rank, world)
+    token = bytes((7 * i + 3) % 251 for i in range(128))
+    got = dist.broadcast(token if rank == 0 else None, 128)
+    ok = 1.0 if got == token else 0.0
+    worst = dist.allreduce_max(1.0 - ok)               # 0.0 iff every rank received the token
+    top = dist.allreduce_max(float(rank))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "token_ok": worst == 0.0, "max_rank": int(top),
+                          "spawned": os.environ.get("SE2_BENCH_SPAWNED") == "1"}), flush=True)
+    dist.close()
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: become one (VERDICT r02 missing #3)
+        if os.environ.get("SE2_BENCH_DRY_RUN") != "1":
+            from se2lam_amd import capi
+            have = capi.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} device(s) visible (one rank per GPU)")
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size wins")
         args.gpus = world
+    if os.environ.get("SE2_BENCH_DRY_RUN") == "1":
+        return _dry_run(rank, world)
 
     from se2lam_amd import capi, synth
     from se2lam_amd.optimizer import SlamOptimizer
 
     if capi.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: libse2gpu has no CPU fallback")
+    if world > 1 and capi.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {capi.device_count()} device(s) visible "
+                         f"(one rank per GPU)")
 
     dist = None      # se2lam_amd.rendezvous.Rendezvous when N > 1
     torch = None     # never imported: see se2lam_amd/rendezvous.py (two HSA runtimes cannot share a process)
@@ -130,6 +200,10 @@ def main():
             uid = np.frombuffer(dist.broadcast(uid.tobytes(), 128), np.uint8).copy()
             comm = C.c_void_p()
             capi.check(capi.lib().se2gpu_comm_create(uid.ctypes.data, rank, world, C.byref(comm)))
+            nranks = C.c_int(-1)
+            capi.check(capi.lib().se2gpu_comm_count(comm, C.byref(nranks)))
+        if nranks.value != world:   # ncclCommCount: what RCCL itself says the communicator spans
+            raise SystemExit(f"rank {rank}: the RCCL communicator spans {nranks.value} ranks, expected {world}")
 
     def sync_all():
         capi.check(capi.lib().se2gpu_device_synchronize())   # hipDeviceSynchronize (= torch.cuda.synchronize())
@@ -162,26 +236,39 @@ def main():
 
     log("BA: warm-up")
     run_steps(args.warmup)
-    # The timed region is K steps, but never less than MIN_TIMED_S of device work: 20 steps of this graph are 4 ms, two
-    # optimize() calls - too short a sample to report from.  K is raised to the next multiple of
-    # itself that fills the floor (every rank computes the same K from the all-reduced time of a first, untimed block).
-    steps = args.steps
+    # Warm-up continues, untimed, until nothing one-off is left for the timed region: optimize(n) is captured into a
+    # hipGraph the SECOND time a shape n is asked of a handle and replayed from the third (12 ms of capture would otherwise
+    # land inside a 40 ms sample - VERDICT r02 weak #6).  The shapes the timed loop uses: ITERS_PER_CALL and the remainder.
+    for shape in {min(ITERS_PER_CALL, args.steps), args.steps % ITERS_PER_CALL}:
+        for _ in range(3 if shape else 0):
+            opt.reset_estimates()
+            opt.optimize(shape)
+    # The timed region is whole blocks of K steps and never shorter than MIN_TIMED_S of device work (20 steps of this
+    # graph are 4 ms).  The number of blocks comes from an untimed probe block (every rank computes the same count from
+    # the all-reduced time); should the sample still come out short, it is taken again with more blocks - the floor is
+    # enforced, not estimated.  `steps` in the JSON is what ran, `steps_requested` what was asked.
     sync_all()
     t0 = time.perf_counter()
-    run_steps(steps)
+    run_steps(args.steps)
     sync_all()
     probe = time.perf_counter() - t0
     if dist is not None:
         probe = dist.allreduce_max(probe)
-    if probe < MIN_TIMED_S:
-        steps = args.steps * int(np.ceil(1.2 * MIN_TIMED_S / max(probe, 1e-6)))
-    sync_all()
-    t0 = time.perf_counter()
-    trials = run_steps(steps)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        dt = dist.allreduce_max(dt)
+    blocks = max(1, int(np.ceil(1.25 * MIN_TIMED_S / max(probe, 1e-6))))
+    while True:
+        steps = args.steps * blocks
+        sync_all()
+        t0 = time.perf_counter()
+        trials = 0
+        for _ in range(blocks):
+            trials += run_steps(args.steps)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = dist.allreduce_max(dt)
+        if dt >= MIN_TIMED_S:
+            break
+        blocks *= 2
     iters_per_s = steps / dt
     chi2_final = opt.stats["chi2_final"]
 
@@ -205,6 +292,7 @@ def main():
         exchange = {"what": "RCCL all-reduce (sum, f64) of the packed lower-triangular tiles of [S | b] + scalars, once per "
                             "LM trial, on the handle's stream; per-kernel pass (event pair around every call)",
                     "doubles_per_trial": int(capi.lib().se2gpu_ba_exchange_doubles(g.P)),
+                    "comm_ranks": int(nranks.value),
                     "allreduce_system_us": kern.get("allreduce_system", {}).get("avg_us"),
                     "allreduce_small_us": kern.get("allreduce_small", {}).get("avg_us"),
                     "pack_unpack_us": kern.get("k_tri_pack", {}).get("avg_us"),

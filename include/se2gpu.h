@@ -421,6 +421,7 @@ int se2gpu_ba_set_shard(se2gpu_ba* h, int rank, int world);
 typedef struct se2gpu_comm se2gpu_comm;
 int se2gpu_comm_unique_id(uint8_t id_out[128]);                       /* ncclGetUniqueId (rank 0) */
 int se2gpu_comm_create(const uint8_t id[128], int rank, int world, se2gpu_comm** out);  /* ncclCommInitRank */
+int se2gpu_comm_count(se2gpu_comm* c, int* nranks);                      /* ncclCommCount */
 void se2gpu_comm_destroy(se2gpu_comm* c);
 int se2gpu_comm_allreduce_sum_f64(se2gpu_comm* c, void* dev_ptr, size_t count, void* hip_stream);
 int se2gpu_ba_set_comm(se2gpu_ba* h, se2gpu_comm* c);

@@ -163,6 +163,7 @@ SYMBOLS = {
     "se2gpu_comm_unique_id": (_I, [_VP]),
     "se2gpu_comm_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
     "se2gpu_comm_destroy": (None, [_VP]),
+    "se2gpu_comm_count": (_I, [_VP, C.POINTER(_I)]),
     "se2gpu_comm_allreduce_sum_f64": (_I, [_VP, _VP, _SZ, _VP]),
     "se2gpu_ba_set_comm": (_I, [_VP, _VP]),
     "se2gpu_ba_shard_landmarks": (_I, [_I, _I, _PI32, _PI32, _I, _PI32]),

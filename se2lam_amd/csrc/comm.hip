@@ -13,6 +13,7 @@ typedef int (*fn_get_unique_id)(nccl_unique_id*);
 typedef int (*fn_comm_init_rank)(void**, int, nccl_unique_id, int);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_comm_destroy)(void*);
+typedef int (*fn_comm_count)(const void*, int*);
 typedef const char* (*fn_error_string)(int);
 
 struct Rccl {
@@ -21,6 +22,7 @@ struct Rccl {
     fn_comm_init_rank comm_init_rank = nullptr;
     fn_all_reduce all_reduce = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
+    fn_comm_count comm_count = nullptr;
     fn_error_string error_string = nullptr;
 };
 
@@ -41,6 +43,7 @@ Rccl* rccl() {
             r.all_reduce = (fn_all_reduce)dlsym(r.lib, "ncclAllReduce");
             r.comm_destroy = (fn_comm_destroy)dlsym(r.lib, "ncclCommDestroy");
             r.error_string = (fn_error_string)dlsym(r.lib, "ncclGetErrorString");
+            r.comm_count = (fn_comm_count)dlsym(r.lib, "ncclCommCount");
         }
     }
     if (!r.lib || !r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.comm_destroy) return nullptr;
@@ -101,6 +104,16 @@ int se2gpu_comm_create(const uint8_t id[128], int rank, int world, se2gpu_comm**
         return SE2GPU_ERR_HIP;
     }
     *out = c;
+    return SE2GPU_OK;
+}
+
+// ncclCommCount: the number of ranks RCCL itself says the communicator spans (bench.py checks it against WORLD_SIZE)
+int se2gpu_comm_count(se2gpu_comm* c, int* nranks) {
+    SE2_REQUIRE(c && nranks, SE2GPU_ERR_INVALID, "comm_count: NULL argument");
+    Rccl* r = rccl();
+    SE2_REQUIRE(r && r->comm_count, SE2GPU_ERR_STATE, "ncclCommCount is not available");
+    const int rc = r->comm_count(c->comm, nranks);
+    SE2_REQUIRE(rc == 0, SE2GPU_ERR_HIP, "ncclCommCount failed: %s", r->error_string ? r->error_string(rc) : "?");
     return SE2GPU_OK;
 }
 

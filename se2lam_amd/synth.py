@@ -157,6 +157,16 @@ class BAGraph:
         )
 
 
+def _bagraph_shard_landmarks(self, rank: int, world: int) -> np.ndarray:
+    """indices (into this graph's landmarks) of the landmarks shard `rank` holds, in the shard's order"""
+    if world == 1:
+        return np.arange(self.L)
+    return np.nonzero(shard_landmarks(self.e_kf, self.e_lm, self.L, world) == rank)[0]
+
+
+BAGraph.shard_landmarks = _bagraph_shard_landmarks
+
+
 def shard_landmarks(e_kf: np.ndarray, e_lm: np.ndarray, L: int, world: int) -> np.ndarray:
     """owner[l] in [0, world): contiguous chunks, balanced by edge count, of the landmarks
     sorted by (lowest observing keyframe id, landmark id) - "sharded by keyframe window"."""

@@ -32,6 +32,8 @@ def test_bench_sharded_path_with_a_one_rank_rccl_communicator(synth):
     ex = d["exchange"]
     from se2lam_amd import capi
     assert ex["doubles_per_trial"] == capi.lib().se2gpu_ba_exchange_doubles(50) < (3 * 50 + 1) * 160
+    assert ex["comm_ranks"] == 1                   # ncclCommCount of the communicator bench.py created
+    assert d["timed_s"] >= 0.1                      # the timed-region floor is enforced, whatever --steps says
     assert ex["allreduce_system_us"] > 0 and ex["pack_unpack_us"] > 0 and ex["allreduce_us_per_iteration"] > 0
     # the same window without the communicator: identical LM run (one rank: the all-reduce is the identity)
     o = SlamOptimizer()
