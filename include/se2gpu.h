@@ -179,6 +179,10 @@ typedef struct se2gpu_ba_stats {
 
 int se2gpu_ba_create(se2gpu_ba** out);
 void se2gpu_ba_destroy(se2gpu_ba* h);
+/* Start-up pre-warm: runs one throw-away window of P key frames / L landmarks / E observations and parks its handle (code
+ * objects loaded, stream + mailbox + every device buffer allocated at that size), so that the FIRST localBA of the process
+ * (a SlamOptimizer constructed on the stack, LocalMapper.cpp:239) costs what the later ones do.  Off the tracking thread. */
+int se2gpu_ba_reserve(int P, int L, int E);
 int se2gpu_ba_clear(se2gpu_ba* h);                                   /* optimizer.clear(); clearParameters() */
 int se2gpu_ba_set_stream(se2gpu_ba* h, void* hip_stream);
 int se2gpu_ba_add_cam(se2gpu_ba* h, double f, double cx, double cy);  /* addCamPara: single focal length */

@@ -111,6 +111,7 @@ SYMBOLS = {
                                      _VP, _VP, _VP, _I, _I, _I, _F, _VP, C.POINTER(_I)]),
     # BA
     "se2gpu_ba_create": (_I, [C.POINTER(_VP)]),
+    "se2gpu_ba_reserve": (_I, [_I, _I, _I]),
     "se2gpu_ba_destroy": (None, [_VP]),
     "se2gpu_ba_clear": (_I, [_VP]),
     "se2gpu_ba_set_stream": (_I, [_VP, _VP]),

@@ -285,6 +285,21 @@ def test_landmark_sharded_rejecting_start_many_ranks(synth, world):
     _sharded_equals_single(_kidnapped(synth, *case), 10, trials, world=world)
 
 
+def test_reserve_parks_a_warm_handle(oracle, synth):
+    """se2gpu_ba_reserve(P, L, E) (start-up pre-warm): a throw-away window of that size is run and its handle parked; the
+    optimizer constructed next gets it - and behaves like a new one (results equal the oracle's, nothing of the synthetic
+    window left)."""
+    from se2lam_amd import capi
+    g = synth.ba_graph(8, 60)
+    capi.check(capi.lib().se2gpu_ba_reserve(g.P, g.L, g.E))
+    o = _opt(g)
+    o.optimize(6)
+    _, _, st = oracle.ba_optimize(g, 6, 0)
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=1e-9)
+    with pytest.raises(capi.Se2GpuError):
+        capi.check(capi.lib().se2gpu_ba_reserve(1, 0, 0))
+
+
 def test_edge_information_on_device(oracle, synth):
     """SURVEY §8f.1: Map::loadLocalGraph's per-observation information (Map.cpp:1024-1049) computed on the GPU."""
     from se2lam_amd import optimizer as op

@@ -4,6 +4,7 @@ LocalMapper threads would call them one frame / one key frame at a time.  Printe
 import json
 import os
 import sys
+import subprocess
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -87,8 +88,48 @@ def main():
             q.estimates()
             del q
         out[f"ba_{P}kf_construct_load_initialize_optimize10_ms"] = timeit(cycle, n=10, warm=2)
+    # the FIRST localBA of a process (cold: code objects, stream, mailbox, ~50 allocations) against the first one after
+    # se2gpu_ba_reserve(P, L, E) at start-up - each measured in a fresh process
+    for tag, reserve in (("cold", False), ("after_reserve", True)):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--first-cycle", "1" if reserve else "0"],
+                           capture_output=True, text=True, timeout=300)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            out[f"ba_50kf_first_cycle_{tag}_ms"] = d["first_cycle_ms"]
+            out[f"ba_50kf_first_initialize_{tag}_ms"] = d["first_initialize_ms"]
+            if reserve:
+                out["ba_reserve_50kf_ms"] = d["reserve_ms"]
+        else:
+            out[f"ba_50kf_first_cycle_{tag}_ms"] = None
+            print(r.stderr[-500:], file=sys.stderr)
     print(json.dumps(out))
 
 
+def first_cycle(reserve):
+    from se2lam_amd import capi, synth
+    from se2lam_amd.optimizer import SlamOptimizer, estimateVertexSE2, estimateVertexSBAXYZ
+    g = synth.ba_graph(50, 5000)
+    capi.device_count()
+    t0 = time.perf_counter()
+    if reserve:
+        capi.check(capi.lib().se2gpu_ba_reserve(g.P, g.L, g.E))
+    t1 = time.perf_counter()
+    q = SlamOptimizer()
+    q.load(g)
+    ti = time.perf_counter()
+    q.initializeOptimization(0)
+    tj = time.perf_counter()
+    q.optimize(10)
+    estimateVertexSE2(q, 1); estimateVertexSBAXYZ(q, g.P)
+    q.estimates()
+    del q
+    t2 = time.perf_counter()
+    print(json.dumps({"reserve_ms": 1e3 * (t1 - t0), "first_cycle_ms": 1e3 * (t2 - t1), "first_initialize_ms": 1e3 * (tj - ti)}))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 3 and sys.argv[1] == "--first-cycle":
+        first_cycle(sys.argv[2] == "1")
+    else:
+        main()
