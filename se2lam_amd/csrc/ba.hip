@@ -967,6 +967,7 @@ __device__ inline bool spin_until(const unsigned* f, unsigned epoch) {
     return true;
 }
 
+template <bool SEED>
 __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
                                                      double* __restrict__ R, double* __restrict__ RM, int ld, int n,
                                                      int nbc, const int2* __restrict__ tasks,
@@ -1141,13 +1142,21 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     double* mrc = &MRC[cb][lane];
     double* colv = &COLV[cb][lane];
     double pmin = 1e300, mr_prev = 0.0, rvb[2][8];   // rvb: double buffer (static indices: the loop is unrolled)
+    // SEED: the multiplier comes straight from the reciprocal seed x0 and the Newton residual e = 1 - piv x0,
+    //     mr = m x0 (1 + e)        (= m / piv up to e^2 ~ 2e-15, like one Newton step on x0 first)
+    // which takes the refined reciprocal - one dependent FP64 operation of 44 clk - off the pivot chain
+    // (tools/fp64_issue_probe.hip).  SE2GPU_BA_CHOL_SEED=0 keeps the refined reciprocal (A/B).
     double piv = bcast_lane(m[0], cb);
-    double inv = fast_rcp1(piv);
+    double inv = 0.0, x0 = 0.0, e = 0.0;
+    if (SEED) { x0 = __builtin_amdgcn_rcp(piv); e = fma(-piv, x0, 1.0); }
+    else inv = fast_rcp1(piv);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int jj = cb + q;
         pmin = fmin(pmin, piv);  // (ignores NaN: caught below)
-        const double mr = m[q] * inv;
+        double mr;
+        if (SEED) { const double mr0 = m[q] * x0; mr = fma(mr0, e, mr0); }
+        else mr = m[q] * inv;
         mrs[q] = mr;
         mrc[q * 64] = mr;        // later waves need this column (the last wave's copy is never read)
         colv[q * 64] = m[q];
@@ -1168,7 +1177,9 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         if (q + 1 < 8) {
             m[q + 1] = fma(-mr, bcast_lane(m[q], jj + 1), m[q + 1]);
             piv = bcast_lane(m[q + 1], jj + 1);
-            inv = fast_rcp1(piv);  // next pivot: in flight during the rest of the update
+            // next pivot: in flight during the rest of the update
+            if (SEED) { x0 = __builtin_amdgcn_rcp(piv); e = fma(-piv, x0, 1.0); }
+            else inv = fast_rcp1(piv);
         }
         mr_prev = mr;
     }
@@ -4042,8 +4053,13 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         static const bool fault = [] { const char* e = getenv("SE2GPU_BA_CHOL_FAULT"); return e && e[0] == '1'; }();
         const int skip = (fault && !h->chol_faulted && h->chol_ntask > 1) ? 1 : 0;
         h->chol_faulted = true;
-        SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
-                   h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
+        static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
+        if (seed)
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
+                       h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
+        else
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
+                       h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
