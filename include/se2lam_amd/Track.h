@@ -13,10 +13,6 @@
 
 namespace se2lam_amd {
 
-struct Point3f {
-    float x, y, z;
-};
-
 struct TriangulationResult {
     std::vector<Point3f> localMPs;      // mLocalMPs[i] for the features triangulated now (zero elsewhere)
     std::vector<uint8_t> goodPrl;       // mvbGoodPrl

@@ -26,6 +26,10 @@ struct Point2f {          // cv::Point2f
     float x = 0, y = 0;
 };
 
+struct Point3f {          // cv::Point3f
+    float x, y, z;
+};
+
 struct KeyPoint {         // cv::KeyPoint (28 bytes; layout == se2gpu_keypoint)
     Point2f pt;
     float size = 0, angle = -1, response = 0;
