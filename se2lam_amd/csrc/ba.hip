@@ -29,6 +29,8 @@
 #include <limits>
 #include <mutex>
 #include <thread>
+#include <tuple>
+#include <memory>
 #include <unordered_map>
 
 #include "common.h"
@@ -163,10 +165,10 @@ __device__ inline void write_diag_record(double* __restrict__ dg, const double* 
 
 // the lambda-dependent per-landmark pieces alone (a rejected trial keeps its linearisation): Dinv = (Hll + lambda I)^-1,
 // z = Dinv bl, Y_e = Hpl_e Dinv and the diagonal record of every edge
-__device__ inline void schur_lm_body(int L, double lambda, const int* __restrict__ lm_ptr, const double* Hll, const double* bl,
+__device__ inline void schur_lm_body(const unsigned bx, int L, double lambda, const int* __restrict__ lm_ptr, const double* Hll, const double* bl,
                                      const double* Hpl, const double* Hpp_e, const double* bp_e, double* Dinv, double* z,
                                      double* Y, double* Dg) {
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int gid = bx * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     if (l >= L) return;
     double h[6], d[6];
@@ -184,6 +186,7 @@ __device__ inline void schur_lm_body(int L, double lambda, const int* __restrict
         z[(size_t)l * 3 + 1] = z1;
         z[(size_t)l * 3 + 2] = z2;
     }
+    if (!Y) return;   // slim layout (k_reduce_rows): nothing per edge depends on lambda
     for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
         const double* B = Hpl + (size_t)e * 9;
         double* y = Y + (size_t)e * 9;
@@ -204,7 +207,7 @@ __device__ inline void schur_lm_body(int L, double lambda, const int* __restrict
 }
 
 template <bool FUSED>
-__global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const int* __restrict__ lm_ptr,
+__device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L, const int* __restrict__ lm_ptr,
                                                        const int* __restrict__ e_kf, const double* __restrict__ e_uv,
                                                        const double* __restrict__ e_info,
                                                        const double* __restrict__ poses,
@@ -220,13 +223,13 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
                  // lambda-dependent part (what k_schur_lm does - here, so that a trial slot needs no launch of its own for it)
         if (ctl->done) return;
         if (ctl->retry) {
-            if (FUSED) schur_lm_body(L, ctl->lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
+            if (FUSED) schur_lm_body(bx, L, ctl->lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
             return;
         }
         if (ctl->sel) { poses = poses_b; lms = lms_b; }
         lambda = ctl->lambda;
     }
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int gid = bx * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     if (l < L) {
@@ -299,6 +302,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
         const double z0 = d[0] * b[0] + d[1] * b[1] + d[2] * b[2];
         const double z1 = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
         const double z2 = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
+        if (Y)   // (slim layout: k_reduce_rows and k_update form Y_e = Hpl_e Dinv_l themselves - 144 bytes per edge written, not 312)
         for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
             const double* B = Hpl + (size_t)e * 9;  // written by this same lane above
             double* y = Y + (size_t)e * 9;
@@ -317,6 +321,21 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
             write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
         }
     }
+}
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const int* __restrict__ lm_ptr,
+                                                       const int* __restrict__ e_kf, const double* __restrict__ e_uv,
+                                                       const double* __restrict__ e_info,
+                                                       const double* __restrict__ poses,
+                                                       const uint8_t* __restrict__ fixed,
+                                                       const double* __restrict__ lms, double* Hpl,
+                                                       double* __restrict__ Hpp_e, double* __restrict__ bp_e,
+                                                       double* __restrict__ Hll, double* __restrict__ bl, double lambda,
+                                                       double* __restrict__ Dinv, double* __restrict__ z,
+                                                       double* __restrict__ Y, double* __restrict__ Dg,
+                                                       const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                       const double* __restrict__ lms_b) {
+    d_linearize<FUSED>(blockIdx.x, cam, L, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, Hpl, Hpp_e, bp_e, Hll, bl, lambda, Dinv, z, Y, Dg, ctl, poses_b, lms_b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,14 +360,14 @@ __device__ inline void pre_se2(const double* pi, const double* pj, const double*
     B[0] = c; B[1] = s; B[3] = -s; B[4] = c; B[8] = 1;
 }
 
-__global__ void k_odometry(int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
+__device__ __forceinline__ void d_odometry(const unsigned bx, int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
                            const double* __restrict__ o_meas, const double* __restrict__ o_info,
                            const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
                            double* __restrict__ Oii, double* __restrict__ Ojj, double* __restrict__ Oij,
                            double* __restrict__ obi, double* __restrict__ obj, const BaCtl* __restrict__ ctl,
                            const double* __restrict__ poses_b) {
     if (ctl && ctl->sel) poses = poses_b;   // (poses = the "a" buffer then: the controller says which holds the estimate)
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = bx * blockDim.x + threadIdx.x;
     if (k >= O) return;
     const int i = o_i[k], j = o_j[k];
     double e[3], A[9], B[9];
@@ -376,12 +395,20 @@ __global__ void k_odometry(int O, const int* __restrict__ o_i, const int* __rest
         obj[k * 3 + r] = fj ? B[r] * omr[0] + B[3 + r] * omr[1] + B[6 + r] * omr[2] : 0.0;
     }
 }
+__global__ void k_odometry(int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
+                           const double* __restrict__ o_meas, const double* __restrict__ o_info,
+                           const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+                           double* __restrict__ Oii, double* __restrict__ Ojj, double* __restrict__ Oij,
+                           double* __restrict__ obi, double* __restrict__ obj, const BaCtl* __restrict__ ctl,
+                           const double* __restrict__ poses_b) {
+    d_odometry(blockIdx.x, O, o_i, o_j, o_meas, o_info, poses, fixed, Oii, Ojj, Oij, obi, obj, ctl, poses_b);
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_pose_reduce: one wave per pose.  Hpp (3x3 row-major, full) and bp (3) = sum over the pose's observation edges
 // (CSR pose_ptr / pose_edges) + its odometry edges (CSR podo_ptr / podo_item: item = 2*k + (pose is j ? 1 : 0)).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __restrict__ pose_ptr,
+__device__ __forceinline__ void d_pose_reduce(const unsigned bx, int P, const int* __restrict__ pose_ptr,
                                                          const int* __restrict__ pose_edges,
                                                          const double* __restrict__ Hpp_e,
                                                          const double* __restrict__ bp_e,
@@ -390,7 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __rest
                                                          const double* __restrict__ Oii, const double* __restrict__ Ojj,
                                                          const double* __restrict__ obi, const double* __restrict__ obj,
                                                          double* __restrict__ Hpp, double* __restrict__ bp) {
-    const int p = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+    const int p = bx * (kBlock / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
@@ -418,12 +445,23 @@ __global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __rest
         for (int i = 0; i < 3; ++i) bp[(size_t)p * 3 + i] = b[i];
     }
 }
+__global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __restrict__ pose_ptr,
+                                                         const int* __restrict__ pose_edges,
+                                                         const double* __restrict__ Hpp_e,
+                                                         const double* __restrict__ bp_e,
+                                                         const int* __restrict__ podo_ptr,
+                                                         const int* __restrict__ podo_item,
+                                                         const double* __restrict__ Oii, const double* __restrict__ Ojj,
+                                                         const double* __restrict__ obi, const double* __restrict__ obj,
+                                                         double* __restrict__ Hpp, double* __restrict__ bp) {
+    d_pose_reduce(blockIdx.x, P, pose_ptr, pose_edges, Hpp_e, bp_e, podo_ptr, podo_item, Oii, Ojj, obi, obj, Hpp, bp);
+}
 
 // max |diag| over a strided array (computeLambdaInit); single block, deterministic.
 // max |diag H| over the landmark blocks and the free poses' blocks (computeLambdaInit).  The pose diagonals come either as
 // `dpp` values per pose (Hpp_diag3) or, with stride9 set, straight from the 3 x 3 row-major blocks of k_pose_reduce; with
 // `ctl` the kernel also sets lambda_0 = 1e-5 * max itself (single GPU: no k_extract_diag / k_set_lambda launches).
-__global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const double* __restrict__ Hpp_diag3,
+__device__ __forceinline__ void d_maxdiag(const unsigned bx, int L, const double* __restrict__ Hll, int P, const double* __restrict__ Hpp_diag3,
                           const uint8_t* __restrict__ fixed, double* __restrict__ out, int dpp, int stride9,
                           BaCtl* __restrict__ ctl) {
     __shared__ double sm[16];
@@ -455,6 +493,11 @@ __global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const do
         }
     }
 }
+__global__ void k_maxdiag(int L, const double* __restrict__ Hll, int P, const double* __restrict__ Hpp_diag3,
+                          const uint8_t* __restrict__ fixed, double* __restrict__ out, int dpp, int stride9,
+                          BaCtl* __restrict__ ctl) {
+    d_maxdiag(blockIdx.x, L, Hll, P, Hpp_diag3, fixed, out, dpp, stride9, ctl);
+}
 
 __global__ void k_extract_diag(int P, const double* __restrict__ Hpp, double* __restrict__ d3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -472,7 +515,7 @@ __device__ inline void inv_sym3(const double h[6], double lambda, double d[6]) {
     d[3] = (a * i - c * c) * id; d[4] = -(a * f - c * b) * id; d[5] = (a * e - b * b) * id;
 }
 
-__global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const int* __restrict__ lm_ptr,
+__device__ __forceinline__ void d_schur_lm(const unsigned bx, int L, double lambda, const int* __restrict__ lm_ptr,
                                                       const double* __restrict__ Hll, const double* __restrict__ bl,
                                                       const double* __restrict__ Hpl,
                                                       const double* __restrict__ Hpp_e,
@@ -484,7 +527,17 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const
         if (ctl->done || !(force | ctl->retry)) return;
         lambda = ctl->lambda;
     }
-    schur_lm_body(L, lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
+    schur_lm_body(bx, L, lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
+}
+__global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const int* __restrict__ lm_ptr,
+                                                      const double* __restrict__ Hll, const double* __restrict__ bl,
+                                                      const double* __restrict__ Hpl,
+                                                      const double* __restrict__ Hpp_e,
+                                                      const double* __restrict__ bp_e, double* __restrict__ Dinv,
+                                                      double* __restrict__ z, double* __restrict__ Y,
+                                                      double* __restrict__ Dg, const BaCtl* __restrict__ ctl,
+                                                      int force) {
+    d_schur_lm(blockIdx.x, L, lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg, ctl, force);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,7 +571,7 @@ constexpr int kChunk = 16;      // contributor pairs per group
 // entry of a 3x3 block) accumulating one chunk of <= kChunk contributor pairs of ONE reduced-system block; blocks
 // with several chunks are packed into the same workgroup and combined in LDS in chunk order (deterministic).
 // grp = {block index or -1, first pair, last pair, (first group of the block in this WG) | (number of groups << 8)}
-__global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, double lambda, int root,
+__device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int nwg_off, double lambda, int root,
                                                      const int4* __restrict__ grp, const int* __restrict__ blk_a,
                                                      const int* __restrict__ blk_b, const int* __restrict__ pair_i,
                                                      const int* __restrict__ pair_j, const int* __restrict__ blk_odo,
@@ -544,8 +597,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
     // ones have the longest dependent chain (edge list -> edge rows -> landmark z, then the PreEdgeSE2 terms) and must
     // not queue behind the others for a CU slot, so they come FIRST.
     const int ndiag = (P + 1 + 7) & ~7;
-    if ((int)blockIdx.x >= ndiag) {
-        const int bid = (int)blockIdx.x - ndiag;
+    if ((int)bx >= ndiag) {
+        const int bid = (int)bx - ndiag;
         const int nwg_pad = (nwg_off + 7) & ~7;
         // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  The plan is ordered
         // by pose block row, so XCD x takes the x-th CONTIGUOUS eighth of it: the Y / Hpl rows of its pose range are
@@ -609,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
         return;
     }
     // ---- diagonal part: one workgroup per pose (+ one that clears the padding)
-    const int p = (int)blockIdx.x;
+    const int p = (int)bx;
     if (p > P) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* __restrict__ bs = S + (size_t)n * ld;
@@ -705,6 +758,275 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
             bp[(size_t)p * 3 + r] = fa ? 0.0 : v;
         }
     }
+}
+__global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, double lambda, int root,
+                                                     const int4* __restrict__ grp, const int* __restrict__ blk_a,
+                                                     const int* __restrict__ blk_b, const int* __restrict__ pair_i,
+                                                     const int* __restrict__ pair_j, const int* __restrict__ blk_odo,
+                                                     const double* __restrict__ Y, const double* __restrict__ Hpl,
+                                                     const double* __restrict__ Dg,
+                                                     const uint8_t* __restrict__ fixed, const int* __restrict__ pose_ptr,
+                                                     const int* __restrict__ pose_edges, const int* __restrict__ podo_ptr,
+                                                     const int* __restrict__ podo_item, const int* __restrict__ o_i,
+                                                     const int* __restrict__ o_j, const double* __restrict__ o_meas,
+                                                     const double* __restrict__ o_info, const double* __restrict__ poses,
+                                                     double* __restrict__ S, double* __restrict__ bp,
+                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                     unsigned* __restrict__ epoch) {
+    d_reduce2(blockIdx.x, P, ld, nwg_off, lambda, root, grp, blk_a, blk_b, pair_i, pair_j, blk_odo, Y, Hpl, Dg, fixed, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reduce_rows (round 3): the reduced system WITHOUT per-pair operands and without the per-edge Y / Dg records.
+//   S_ab = - sum_{l seen by a and b} Hpl_{a,l} Dinv_l Hpl_{b,l}^T,   S_aa = sum_{e in a} (Hpp_e - Hpl_e Dinv_l Hpl_e^T) + ...
+// One workgroup per pose a (row-stationary): it walks the pose's own edges ("visits"); a visit reads the landmark's
+// inverse block Dinv_l and the landmark's CONTIGUOUS run of edge blocks Hpl (edges are sorted by landmark) - one lane per
+// (observer b of the landmark, entry of the 3x3 block) forms Y_e row x Hpl_b row on the fly and adds it to the block
+// (a, b), b > a, of the pose's row with an LDS add.  Every wave owns a private copy of the row (LDS operations of a wave
+// execute in issue order: its sums are taken in visit order), the copies are combined in wave order: deterministic,
+// atomic-free across workgroups, and block (b, a) is written as the transpose of (a, b), the diagonal block from one
+// expression per symmetric pair of entries - S is symmetric to the bit.
+// Against the pair plan of k_reduce2 this reads runs of 72-byte blocks instead of two scattered 72-byte rows per pair,
+// needs neither Y_e nor the diagonal records (k_linearize writes 144 instead of 312 bytes per edge, a rejected trial
+// only recomputes Dinv and z per landmark), and no pair lists at all.
+//   visit = {edge, first edge of its landmark, observers of the landmark, landmark}           (k_plan_visits, per pose slot)
+// Dynamic LDS: nwaves x (P - a) x 9 doubles (row copies, allocated for a = 0) + the odometry scratch.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_plan_visits(int E, const int* __restrict__ pose_edges, const int* __restrict__ e_lm,
+                              const int* __restrict__ lm_ptr, int4* __restrict__ visit) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E) return;
+    const int e = pose_edges[t], l = e_lm[e];
+    const int s0 = lm_ptr[l];
+    visit[t] = make_int4(e, s0, lm_ptr[l + 1] - s0, l);
+}
+
+__device__ __forceinline__ void d_reduce_rows(const unsigned bx, int P, int ld, double lambda, int root, int odo_offdiag,
+                                              int NW, const int* __restrict__ pose_ptr, const int4* __restrict__ visit,
+                                              const int* __restrict__ e_kf, const double* __restrict__ Hpl,
+                                              const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
+                                              const double* __restrict__ Dinv, const double* __restrict__ z,
+                                              const uint8_t* __restrict__ fixed, const int* __restrict__ podo_ptr,
+                                              const int* __restrict__ podo_item, const int* __restrict__ o_i,
+                                              const int* __restrict__ o_j, const double* __restrict__ o_meas,
+                                              const double* __restrict__ o_info, const double* __restrict__ poses,
+                                              double* __restrict__ S, double* __restrict__ bp,
+                                              const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                              unsigned* __restrict__ epoch) {
+    if (ctl) {
+        if (ctl->done) return;
+        if (ctl->sel) poses = poses_b;
+        lambda = ctl->lambda;
+    }
+    extern __shared__ __attribute__((aligned(16))) double rows_lds[];
+    const int n = 3 * P;
+    const int a = (int)bx;
+    const int nthr = (int)blockDim.x, tid = (int)threadIdx.x;
+    double* __restrict__ bs = S + (size_t)n * ld;
+    if (a == P) {   // the padding of the augmented matrix, the solver's flag and its epoch (as k_reduce2's last diagonal workgroup)
+        for (size_t t = (size_t)n * ld + n + tid; t < (size_t)ld * ld; t += nthr) S[t] = 0.0;
+        if (tid == 0) {
+            S[(size_t)ld * ld + 2] = 0.0;
+            *epoch += 1u;
+        }
+        return;
+    }
+    if (a > P) return;
+    // NW waves take visits and own a copy of the row (the graph's own choice: a batch launches every window with the
+    // widest workgroup of the batch, and a window's sums must not depend on its neighbours); the other waves only help
+    // with the zeroing and the combination
+    const int W = NW, wv = tid >> 6, ln = tid & 63;
+    const int nb = P - a;                        // blocks of this row: b = a .. P-1
+    const int rowlen = nb * 9;
+    double* acc = rows_lds + (size_t)wv * rowlen;          // this wave's copy of the row
+    double* misc = rows_lds + (size_t)W * (size_t)(P * 9); // [W][8]: rhs (3), bp sum (3) per wave | then odometry scratch
+    double* odoc = misc + (size_t)W * 8;                   // [8][24]: diag 9, rhs 3, off-diagonal block 9, target, spare
+    const bool fa = fixed[a] != 0;
+    for (int t = tid; t < W * rowlen; t += nthr) rows_lds[(size_t)(t / rowlen) * rowlen + (t % rowlen)] = 0.0;
+    if (tid < W * 8) misc[tid] = 0.0;
+    __syncthreads();
+    const int v0 = pose_ptr[a], nvis = fa ? 0 : pose_ptr[a + 1] - v0;
+    const int no = fa ? 0 : podo_ptr[a + 1] - podo_ptr[a];
+    // ---- the visits of this wave, in order.  A visit is a chain of dependent loads (record -> landmark / edge blocks), so
+    // the records of up to 64 visits are fetched at once (one per lane) and the visits then go in batches of kU: all loads
+    // of a batch are requested before the first one is used.
+    const int j_of = ln / 9, en = ln - 9 * j_of, r = en / 3, c = en - 3 * r;
+    const bool lane_on = ln < 63;
+    const bool swp_lane = r > c;                 // (for the pose's own edge: entries (r, c) and (c, r) share one expression)
+    const int lo = min(r, c), hi = max(r, c);
+    const int symidx = lo == 0 ? hi : lo == 1 ? hi + 2 : 5;   // Hpp_e is stored as (xx xy xz yy yz zz)
+    constexpr int kU = 4;
+    const int nvis_w = wv < NW && nvis > wv ? (nvis - wv + NW - 1) / NW : 0;
+    for (int vbase = 0; vbase < nvis_w; vbase += 64) {
+        const int mine = vbase + ln;
+        int4 vrec = make_int4(0, 0, 0, 0);
+        if (mine < nvis_w) vrec = visit[v0 + wv + NW * mine];
+        const int cnt = min(64, nvis_w - vbase);
+        for (int u0 = 0; u0 < cnt; u0 += kU) {
+            int ve[kU], vs[kU], vk[kU], vl[kU], vb[kU];
+            double ra[kU][3], rb[kU][3], dd[kU][6], hppv[kU], bpv[kU], zv[kU][3];
+            bool vown[kU], vact[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int idx = min(u0 + u, cnt - 1);          // (a clamped slot repeats the last visit; it is not added)
+                ve[u] = __builtin_amdgcn_readlane(vrec.x, idx);
+                vs[u] = __builtin_amdgcn_readlane(vrec.y, idx);
+                vk[u] = __builtin_amdgcn_readlane(vrec.z, idx);
+                vl[u] = __builtin_amdgcn_readlane(vrec.w, idx);
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const int e = ve[u], l = vl[u];
+                vact[u] = lane_on && j_of < vk[u] && u0 + u < cnt;
+                const int t = vs[u] + ((lane_on && j_of < vk[u]) ? j_of : 0);
+                vown[u] = t == e;
+                vb[u] = e_kf[t];
+                const double* he = Hpl + (size_t)e * 9;
+                const bool swp = vown[u] && swp_lane;
+                const double* pa = swp ? he + 3 * c : he + 3 * r;
+                const double* pb = swp ? he + 3 * r : Hpl + (size_t)t * 9 + 3 * c;
+                ra[u][0] = pa[0]; ra[u][1] = pa[1]; ra[u][2] = pa[2];
+                rb[u][0] = pb[0]; rb[u][1] = pb[1]; rb[u][2] = pb[2];
+                const double* dl = Dinv + (size_t)l * 6;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dd[u][i] = dl[i];
+                hppv[u] = Hpp_e[(size_t)e * 6 + symidx];
+                bpv[u] = bp_e[(size_t)e * 3 + r];
+                const double* zl = z + (size_t)l * 3;
+                zv[u][0] = zl[0]; zv[u][1] = zl[1]; zv[u][2] = zl[2];
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const double a0 = ra[u][0], a1 = ra[u][1], a2 = ra[u][2];
+                const double b0 = rb[u][0], b1 = rb[u][1], b2 = rb[u][2];
+                const double y0 = a0 * dd[u][0] + a1 * dd[u][1] + a2 * dd[u][2];
+                const double y1 = a0 * dd[u][1] + a1 * dd[u][3] + a2 * dd[u][4];
+                const double y2 = a0 * dd[u][2] + a1 * dd[u][4] + a2 * dd[u][5];
+                double val = -(y0 * b0 + y1 * b1 + y2 * b2);
+                const bool own = vown[u], active = vact[u];
+                if (own) val += hppv[u];
+                const int b = vb[u];
+                const bool use = active && (own || b > a);   // (a fixed observer's Hpl_b is zero: k_linearize writes it so)
+                if (use) __hip_atomic_fetch_add(acc + (b - a) * 9 + en, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (own && active && c == 0) {   // right-hand side: bp_e - Hpl_e z_l (row r of Hpl_e is rowB when swapped, rowA else)
+                    const bool swp = swp_lane;
+                    const double h0 = swp ? b0 : a0, h1 = swp ? b1 : a1, h2 = swp ? b2 : a2;
+                    const double g = h0 * zv[u][0] + h1 * zv[u][1] + h2 * zv[u][2];
+                    __hip_atomic_fetch_add(misc + wv * 8 + r, bpv[u] - g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(misc + wv * 8 + 3 + r, bpv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            // landmarks with more than seven observers: the remaining observer groups of these visits, one at a time
+#pragma unroll 1
+            for (int u = 0; u < kU; ++u) {
+                if (u0 + u >= cnt || vk[u] <= 7) continue;
+                const int e = ve[u], l = vl[u], k = vk[u];
+                const double* he = Hpl + (size_t)e * 9;
+                const double* dl = Dinv + (size_t)l * 6;
+                for (int j0 = 7; j0 < k; j0 += 7) {
+                    const int j = j0 + j_of;
+                    const bool active = lane_on && j < k;
+                    const int t = vs[u] + (active ? j : 0);
+                    const int b = e_kf[t];
+                    const bool own = t == e;
+                    const bool swp = own && swp_lane;
+                    const double* pa = swp ? he + 3 * c : he + 3 * r;
+                    const double* pb = swp ? he + 3 * r : Hpl + (size_t)t * 9 + 3 * c;
+                    const double a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+                    const double y0 = a0 * dl[0] + a1 * dl[1] + a2 * dl[2];
+                    const double y1 = a0 * dl[1] + a1 * dl[3] + a2 * dl[4];
+                    const double y2 = a0 * dl[2] + a1 * dl[4] + a2 * dl[5];
+                    double val = -(y0 * b0 + y1 * b1 + y2 * b2);
+                    if (own) val += hppv[u];
+                    const bool use = active && (own || b > a);   // (a fixed observer's Hpl_b is zero: k_linearize writes it so)
+                    if (use) __hip_atomic_fetch_add(acc + (b - a) * 9 + en, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (own && active && c == 0) {
+                        const double h0 = swp ? b0 : a0, h1 = swp ? b1 : a1, h2 = swp ? b2 : a2;
+                        const double g = h0 * zv[u][0] + h1 * zv[u][1] + h2 * zv[u][2];
+                        __hip_atomic_fetch_add(misc + wv * 8 + r, bpv[u] - g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(misc + wv * 8 + 3 + r, bpv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- PreEdgeSE2 terms of this pose, eight at a time: one lane each evaluates an edge (sin / cos), then twelve threads fold
+    // them into wave 0's copy in edge order
+    for (int t0 = 0; t0 < no; t0 += 8) {
+        if (tid >= nthr - 8 && t0 + tid - (nthr - 8) < no) {
+            const int t = tid - (nthr - 8);
+            const int item = podo_item[podo_ptr[a] + t0 + t];
+            const int k = item >> 1, isj = item & 1;
+            double e[3], A[9], B[9], WA[9], WB[9], omr[3];
+            odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
+            const double* J = isj ? B : A;
+            const double* WJ = isj ? WB : WA;
+            double* o = odoc + 24 * t;
+            for (int r2 = 0; r2 < 3; ++r2) {
+                for (int c2 = 0; c2 < 3; ++c2) o[r2 * 3 + c2] = J[r2] * WJ[c2] + J[3 + r2] * WJ[3 + c2] + J[6 + r2] * WJ[6 + c2];
+                o[9 + r2] = J[r2] * omr[0] + J[3 + r2] * omr[1] + J[6 + r2] * omr[2];
+            }
+            // block (a, other), other > a: A^T W B with rows of the i-pose, transposed when this pose is the edge's j end
+            const int other = isj ? o_i[k] : o_j[k];
+            const bool off = odo_offdiag && other > a && !fixed[other];
+            o[21] = off ? (double)other : -1.0;
+            for (int r2 = 0; r2 < 3; ++r2)
+                for (int c2 = 0; c2 < 3; ++c2) {
+                    const int rr = isj ? c2 : r2, cc = isj ? r2 : c2;
+                    o[12 + r2 * 3 + c2] = off ? A[rr] * WB[cc] + A[3 + rr] * WB[3 + cc] + A[6 + rr] * WB[6 + cc] : 0.0;
+                }
+        }
+        __syncthreads();
+        if (tid < 12) {
+            const int cnt = min(8, no - t0);
+            for (int t = 0; t < cnt; ++t) {
+                const double* o = odoc + 24 * t;
+                if (tid < 9) {
+                    rows_lds[tid] += o[tid];                                  // diagonal block (b = a) of wave 0's copy
+                    if (o[21] >= 0.0) rows_lds[((int)o[21] - a) * 9 + tid] += o[12 + tid];
+                } else {
+                    misc[tid - 9] += o[tid];                                  // both the reduced rhs and the pose gradient
+                    misc[3 + tid - 9] += o[tid];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- combine the waves' copies in wave order, write row a and column a
+    for (int idx = tid; idx < rowlen; idx += nthr) {
+        double tot = 0;
+        for (int w = 0; w < W; ++w) tot += rows_lds[(size_t)w * rowlen + idx];
+        const int bb = a + idx / 9, q = idx % 9, rr = q / 3, cc = q - 3 * rr;
+        double out;
+        if (bb == a) {
+            if (fa) out = (rr == cc && root) ? 1.0 : 0.0;
+            else out = tot + ((rr == cc && root) ? lambda : 0.0);
+            S[(size_t)(3 * a + rr) * ld + 3 * a + cc] = out;
+        } else {
+            out = fa ? 0.0 : tot;
+            S[(size_t)(3 * a + rr) * ld + 3 * bb + cc] = out;
+            S[(size_t)(3 * bb + cc) * ld + 3 * a + rr] = out;
+        }
+    }
+    if (tid < 3) {
+        double v = 0, gsum = 0;
+        for (int w = 0; w < W; ++w) { gsum += misc[w * 8 + tid]; v += misc[w * 8 + 3 + tid]; }
+        bs[3 * a + tid] = fa ? 0.0 : gsum;
+        bp[(size_t)a * 3 + tid] = fa ? 0.0 : v;
+    }
+}
+__global__ __launch_bounds__(512) void k_reduce_rows(int P, int ld, double lambda, int root, int odo_offdiag, int NW, const int* __restrict__ pose_ptr,
+                              const int4* __restrict__ visit, const int* __restrict__ e_kf, const double* __restrict__ Hpl,
+                              const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
+                              const double* __restrict__ Dinv, const double* __restrict__ z,
+                              const uint8_t* __restrict__ fixed, const int* __restrict__ podo_ptr,
+                              const int* __restrict__ podo_item, const int* __restrict__ o_i, const int* __restrict__ o_j,
+                              const double* __restrict__ o_meas, const double* __restrict__ o_info,
+                              const double* __restrict__ poses, double* __restrict__ S, double* __restrict__ bp,
+                              const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b, unsigned* __restrict__ epoch) {
+    d_reduce_rows(blockIdx.x, P, ld, lambda, root, odo_offdiag, NW, pose_ptr, visit, e_kf, Hpl, Hpp_e, bp_e, Dinv, z, fixed, podo_ptr,
+                  podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch);
 }
 
 // odometry pose-pose blocks: S_ij += Oij, S_ji += Oij^T.  One thread per (edge, entry).
@@ -957,18 +1279,24 @@ __device__ inline void store_agent1(double* p, double v) {
 #define SE2_WAIT_VM6(a, b, c, d, e, f) \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
 
-__device__ inline bool spin_until(const unsigned* f, unsigned epoch) {
+// `lazy`: the tile is not the one this task needs next on the critical path (it belongs to a block column further back
+// than the previous one) - poll every ~1.3 us instead of every ~50 ns.  Every waiting task of a solve polls the same few
+// flag words with agent-scope loads that go to memory; with 361 tasks (200 key frames) or 64 windows x 35 tasks doing so
+// flat out, the polls queue in front of the publishers' stores (measured: a batch of windows solved side by side scaled at
+// 3.6 us per window instead of overlapping).
+__device__ inline bool spin_until(const unsigned* f, unsigned epoch, bool lazy = false) {
     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
     const long long t0 = wall_clock64();  // 100 MHz
     while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        __builtin_amdgcn_s_sleep(2);
+        if (lazy) __builtin_amdgcn_s_sleep(48);
+        else __builtin_amdgcn_s_sleep(2);
         if (wall_clock64() - t0 > 200000000ll) return false;
     }
     return true;
 }
 
 template <bool SEED>
-__global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
+__device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restrict__ A, double* __restrict__ AM,
                                                      double* __restrict__ R, double* __restrict__ RM, int ld, int n,
                                                      int nbc, const int2* __restrict__ tasks,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
@@ -977,17 +1305,29 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
                                                      double* __restrict__ xout) {
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
-    __shared__ __attribute__((aligned(16))) double Ta[kNB][kNB + 2];  // MR(i,m), then the finished tile T
-    __shared__ __attribute__((aligned(16))) double Tb[kNB][kNB + 2];  // M(j,m),  then the finished diagonal D
-    __shared__ __attribute__((aligned(16))) double Tc[kNB][kNB + 2];  // MR(j,m)
-    __shared__ __attribute__((aligned(16))) double MRC[kNB][64];      // multiplier column of every eliminated column
-    __shared__ __attribute__((aligned(16))) double COLV[kNB][64];     // its values in the D rows (lanes 0..31 are used)
-    __shared__ int ok_s, ready_s;
+    const bool lazy_on = n < 0 ? false : true;   // (SE2GPU_BA_CHOL_LAZY=0 passes -n: A/B of the lazy polls)
+    if (n < 0) n = -n;
+    const bool wt_all = nbc > 0;                  // (SE2GPU_BA_CHOL_WT=0 passes -nbc: early waves plain stores + fence, as before)
+    if (nbc < 0) nbc = -nbc;
+    // LDS: 36 KB per task (was 59), so that four tasks share a CU - what bounds a batch of windows solved side by side
+    // (k_batched) is how many tile tasks are resident.  The multiplier columns of the elimination re-use the operand tiles
+    // of the update phase: rows 0..15 (waves 0, 1) lie over Tc, which nobody reads after the last tile product; rows 16..31
+    // (waves 2, 3) over Ta, which every wave reads once more - its share of the finished tile - and reports in `loaded_s`.
+    constexpr int kTile = kNB * (kNB + 2);
+    __shared__ __attribute__((aligned(16))) double LD[3 * kTile + kNB * kNB + 8 * kNB];
+    double (*Ta)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD);              // MR(i,m), then the finished tile T
+    double (*Tb)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD + kTile);      // M(j,m),  then the finished diagonal D
+    double (*Tc)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD + 2 * kTile);  // MR(j,m)
+    double (*COLV)[kNB] = reinterpret_cast<double (*)[kNB]>(LD + 3 * kTile);        // an eliminated column's values in the D rows
+    double* const DUMMY = LD + 3 * kTile + kNB * kNB;                               // where the T rows' lanes write instead
+    auto mrc_row = [&](int r) -> double* { return r < 16 ? LD + 2 * kTile + r * 64 : LD + (r - 16) * 64; };   // MRC[r][0..63]
+    static_assert(16 * 64 <= kTile, "sixteen multiplier columns fit one operand tile");
+    __shared__ int ok_s, ready_s, loaded_s;
     const int tid = threadIdx.x;
-    if (tid == 0) ready_s = 0;
-    long long* stamp = dbg ? dbg + (size_t)blockIdx.x * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
+    if (tid == 0) { ready_s = 0; loaded_s = 0; }
+    long long* stamp = dbg ? dbg + (size_t)bx * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
-    const int2 tk = tasks[blockIdx.x];
+    const int2 tk = tasks[bx];
     if ((tk.x >> 16) == 2) {
         // ---- x = R y for the 32 rows of tile row r (what k_chol_apply did as a kernel of its own): the last tasks of the
         // list.  x(r) = sum_{j >= r} MR_R(r,j) y_un(j); the terms are taken as their tiles are published, so that only the last
@@ -999,8 +1339,9 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         double acc = 0.0;
         for (int j = r; j < nbc; ++j) {
             if (tid == 0) {
-                bool ok = spin_until(flagR + (size_t)r * nbc + j, epoch);
-                ok = ok && spin_until((it == j ? flagR : flagA) + (size_t)it * nbc + j, epoch);
+                const bool lazy = lazy_on && j + 1 < nbc;     // only the last block column's term is waited for in earnest
+                bool ok = spin_until(flagR + (size_t)r * nbc + j, epoch, lazy);
+                ok = ok && spin_until((it == j ? flagR : flagA) + (size_t)it * nbc + j, epoch, lazy);
                 ok_s = ok ? 1 : 0;
             }
             __syncthreads();
@@ -1047,8 +1388,9 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     for (int m = 0; m < j; ++m) {
         const bool hasT = !isDiag && !(isR && m < i);  // R(r,m) is zero for m < r: only D is updated
         if (tid == 0) {
-            bool ok = spin_until(flagA + (size_t)j * nbc + m, epoch);
-            if (hasT) ok = ok && spin_until((isR ? flagR : flagA) + (size_t)i * nbc + m, epoch);
+            const bool lazy = lazy_on && m + 1 < j;           // block column m is not the one this task's elimination waits for
+            bool ok = spin_until(flagA + (size_t)j * nbc + m, epoch, lazy);
+            if (hasT) ok = ok && spin_until((isR ? flagR : flagA) + (size_t)i * nbc + m, epoch, lazy);
             ok_s = ok ? 1 : 0;
         }
         __syncthreads();  // also: everyone is done with the LDS tiles of the previous column
@@ -1110,6 +1452,9 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
             for (int q = 0; q < 8; ++q)
                 if (cb + q >= ncol) m[q] = (lane < kNB && cb + q == rr) ? 1e300 : 0.0;
         }
+        // this wave has read its share of Ta / Tb (LDS operations of a wave execute in issue order: the reads above are
+        // ahead of this add) - waves 2 and 3 wait for all four before their multiplier columns overwrite Ta
+        if (lane == 0) __hip_atomic_fetch_add(&loaded_s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     long long clk0 = 0;
     if (stamp) clk0 = clock64();
@@ -1123,7 +1468,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         double mrv[4], cv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            mrv[u] = MRC[done + u][lane];
+            mrv[u] = mrc_row(done + u)[lane];
 #pragma unroll
             for (int q = 0; q < 8; ++q) cv[u][q] = COLV[done + u][cb + q];
         }
@@ -1139,8 +1484,10 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
     // count: one Newton step on v_rcp_f64 (relative error 2e-15, used consistently for M and MR, i.e. a 2e-15 relative
     // perturbation of the pivots of an LDL^T whose rounding errors are larger), pivot test folded into one running
     // minimum, LDS rows addressed with immediate offsets.
-    double* mrc = &MRC[cb][lane];
-    double* colv = &COLV[cb][lane];
+    if (w >= 2)
+        while (__hip_atomic_load(&loaded_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+    double* mrc = mrc_row(cb) + lane;
+    double* colv = lane < kNB ? &COLV[cb][lane] : DUMMY + (lane - kNB);   // (same row stride: immediate offsets below)
     double pmin = 1e300, mr_prev = 0.0, rvb[2][8];   // rvb: double buffer (static indices: the loop is unrolled)
     // SEED: the multiplier comes straight from the reciprocal seed x0 and the Newton residual e = 1 - piv x0,
     //     mr = m x0 (1 + e)        (= m / piv up to e^2 ~ 2e-15, like one Newton step on x0 first)
@@ -1159,7 +1506,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         else mr = m[q] * inv;
         mrs[q] = mr;
         mrc[q * 64] = mr;        // later waves need this column (the last wave's copy is never read)
-        colv[q * 64] = m[q];
+        colv[q * kNB] = m[q];
         // LDS operations of one wave execute in issue order, so the counter needs no s_waitcnt in front of it (that
         // wait would sit on the pivot chain) - only the compiler has to keep the three writes in this order
         asm volatile("" ::: "memory");
@@ -1199,7 +1546,11 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
         if (ncol == kNB) {
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
-                if (w == 3) {   // the last wave is on the critical path: write-through stores, no L2 write-back after
+                // write-through stores for every wave: no L2 write-back (release fence) anywhere in the solve.  The early
+                // waves used plain stores + a fence once - hidden behind the later waves in one solve, but a fence walks
+                // the whole L2 of its XCD, and with 64 windows' tasks fencing side by side (three fences per task) the L2s
+                // did little else: the batch scaled at 3.6 us per window instead of overlapping
+                if (wt_all || w == 3) {
                     store_agent(pm + q, d2_t{m[q], m[q + 1]});
                     store_agent(pr + q, d2_t{mrs[q], mrs[q + 1]});
                 } else {
@@ -1222,13 +1573,23 @@ __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, doub
             if (cb + q < ncol) store_agent1(py + q, m[q]);   // y_un: read by the x tasks of this launch
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    if (w == 3 && ncol == kNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
+    if ((wt_all || w == 3) && ncol == kNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores are written back from this XCD's L2
     __syncthreads();
     if (tid == 0)
         __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (stamp && tid == 0) stamp[5] = wall_clock64();
+}
+template <bool SEED>
+__global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
+                                                     double* __restrict__ R, double* __restrict__ RM, int ld, int n,
+                                                     int nbc, const int2* __restrict__ tasks,
+                                                     unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
+                                                     const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
+                                                     long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
+                                                     double* __restrict__ xout) {
+    d_chol_tiles<SEED>(blockIdx.x, A, AM, R, RM, ld, n, nbc, tasks, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -1277,7 +1638,7 @@ __device__ void finish_trial(const FinArgs& fin, const double* part, double lamb
 // robust chi^2 of the landmark's edges at the trial state, and the landmark part of computeScale().
 // With xp == nullptr it evaluates chi^2 at the current state (x = 0).  Per-block partials -> part[2*blockIdx].
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lambda, const int* __restrict__ lm_ptr,
+__device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, double lambda, const int* __restrict__ lm_ptr,
                                                     const int* __restrict__ e_kf, const double* __restrict__ e_uv,
                                                     const double* __restrict__ e_info,
                                                     const double* __restrict__ poses,
@@ -1286,8 +1647,10 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
                                                     const double* __restrict__ Y, const double* __restrict__ bl,
                                                     double* __restrict__ lms_trial, double* __restrict__ part,
                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
-                                                    FinArgs fin) {
-    if (fin.enabled && (int)blockIdx.x == fin.nblk) {
+                                                    FinArgs fin, const double* __restrict__ Dinv) {
+    // Dinv != nullptr: slim layout - `Y` holds the edge blocks Hpl_e and the landmark step is
+    //   x_l = z_l - Dinv_l sum_e Hpl_e^T dp_e      (instead of z_l - sum_e Y_e^T dp_e with Y_e = Hpl_e Dinv_l stored per edge)
+    if (fin.enabled && (int)bx == fin.nblk) {
         finish_trial(fin, part, lambda);
         return;
     }
@@ -1296,7 +1659,7 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
     // beside the controller block, and for the first two edges of a lane (a landmark has 6 observations on average, a
     // lane takes every 8th) ALL operands of both passes - Y_e and x_p for the back-substitution, the pose, measurement and
     // information for the robust chi^2 - before the first use.  Lanes with more edges take the rest in the old two-pass form.
-    const int gid = blockIdx.x * kBlock + threadIdx.x;
+    const int gid = bx * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     int beg = 0, end = 0;
     if (l < L) {
@@ -1367,6 +1730,13 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) x[c] = group_sum(x[c]);
+    if (Dinv && l < L && step) {   // x holds -sum_e Hpl_e^T dp_e
+        const double* dl = Dinv + (size_t)l * 6;
+        const double t0 = x[0], t1 = x[1], t2 = x[2];
+        x[0] = dl[0] * t0 + dl[1] * t1 + dl[2] * t2;
+        x[1] = dl[1] * t0 + dl[3] * t1 + dl[4] * t2;
+        x[2] = dl[2] * t0 + dl[4] * t1 + dl[5] * t2;
+    }
     if (l < L) {
         double lw[3];
 #pragma unroll
@@ -1414,14 +1784,26 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
         double c = 0, s = 0;
         for (int i = 0; i < kBlock / 64; ++i) { c += sm[0][i]; s += sm[1][i]; }
         if (fin.enabled) {   // write-through stores, landed before the counter moves (the finisher may sit behind another L2)
-            store_agent(part + 2 * blockIdx.x, d2_t{c, s});
+            store_agent(part + 2 * bx, d2_t{c, s});
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            part[2 * blockIdx.x] = c;
-            part[2 * blockIdx.x + 1] = s;
+            part[2 * bx] = c;
+            part[2 * bx + 1] = s;
         }
     }
+}
+__global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lambda, const int* __restrict__ lm_ptr,
+                                                    const int* __restrict__ e_kf, const double* __restrict__ e_uv,
+                                                    const double* __restrict__ e_info,
+                                                    const double* __restrict__ poses,
+                                                    const uint8_t* __restrict__ fixed, const double* __restrict__ lms,
+                                                    const double* __restrict__ xp, const double* __restrict__ z,
+                                                    const double* __restrict__ Y, const double* __restrict__ bl,
+                                                    double* __restrict__ lms_trial, double* __restrict__ part,
+                                                    const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
+                                                    FinArgs fin, const double* __restrict__ Dinv) {
+    d_update(blockIdx.x, cam, L, lambda, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, xp, z, Y, bl, lms_trial, part, ctl, poses_b, fin, Dinv);
 }
 
 // One step of g2o's OptimizationAlgorithmLevenberg::solve / OptimizationAlgorithmGaussNewton on the controller block, run
@@ -1743,7 +2125,7 @@ __global__ void k_lm_decide(BaCtl* __restrict__ ctl, const double* __restrict__ 
 // start of an optimize(): everything is reset but the handle's own counters and the sel bit (which of the two estimate
 // buffers is current: it follows from the runs before, the host only mirrors it) - nothing here changes from one run to
 // the next, so the whole optimize() can be replayed as a hipGraph
-__global__ void k_ctl_init(BaCtl* __restrict__ ctl, int iters, int mode) {
+__device__ __forceinline__ void d_ctl_init(const unsigned bx, BaCtl* __restrict__ ctl, int iters, int mode) {
     constexpr int kWords = (int)(offsetof(BaCtl, seq) / 8);
     __shared__ int sel_s;
     if (threadIdx.x == 0) sel_s = ctl->sel;
@@ -1757,6 +2139,9 @@ __global__ void k_ctl_init(BaCtl* __restrict__ ctl, int iters, int mode) {
         ctl->iters = iters;
         ctl->mode = mode;
     }
+}
+__global__ void k_ctl_init(BaCtl* __restrict__ ctl, int iters, int mode) {
+    d_ctl_init(blockIdx.x, ctl, iters, mode);
 }
 
 // lambda_0 = 1e-5 * max |diag H| (computeLambdaInit); src holds the maximum (one entry), or one slot per rank
@@ -2711,6 +3096,12 @@ struct se2gpu_ba {
     DevBuf<float> d_lg_lc, d_lg_lw, d_lg_sigma2, d_lg_Rcw, d_lg_twb;
     std::vector<EdgeOdo> odo;
     bool initialized = false;
+    unsigned long init_serial = 0;   // unique per initialize(): what a cached batch plan (ba_lockstep) was built for
+    // slim layout (model 0): k_reduce_rows instead of the pair plan's k_reduce2; no per-edge Y / Dg records
+    bool slim = false;
+    int rows_waves = 4;            // waves per workgroup of k_reduce_rows
+    size_t rows_lds = 0;           // its dynamic LDS bytes
+    DevBuf<int4> pose_visit;       // per pose slot: {edge, first edge of its landmark, observers, landmark}
     int P = 0, L = 0, E = 0, O = 0, nblk = 0, nparts = 0;
     int ld = 0;              // leading dimension = padded order of the augmented reduced system
     bool host_solve = false; // SE2GPU_BA_HOST_SOLVE=1: factorise on the host instead (north-star wording)
@@ -3732,6 +4123,33 @@ int ba_upload_graph(se2gpu_ba* h) {
         lap("plan kernels enqueued");
     }
     SE2_HIP(hipStreamWaitEvent(st, h->ev_copy1, 0));   // measurements / information are in place before anything later runs
+    // ---- slim layout of the SE(2) model: k_reduce_rows walks every pose's edges and, per edge, the landmark's run of edge
+    // blocks; the visit records spare it two levels of indices.  Built from the plan's pose -> edge list (on the device).
+    {
+        // Measured (profiles/r03_slim_reduce_rows_experiment.txt): correct (all parity tests, bit-identical batches) but SLOWER
+        // than the pair plan - k_linearize 22 -> 16 us, k_schur_lm 16 -> 7 us, but k_reduce_rows 122 us against k_reduce2's
+        // 29 us at 200 key frames (1007 against 294 us for 64 windows): forming Y_e row x Hpl_b row per (visit, observer)
+        // costs ~190 instructions per visit for ~50 useful lanes, and the kernel is bound by instruction issue, not by the
+        // gathers it was designed around.  Kept behind SE2GPU_BA_SLIM=1 as the measured alternative; off by default.
+        static const bool slim_on = [] { const char* e = getenv("SE2GPU_BA_SLIM"); return e && e[0] == '1'; }();
+        const size_t per_wave = (size_t)P * 72;
+        h->slim = slim_on && h->model == 0 && E > 0 && per_wave + 2048 <= 120 * 1024;
+        if (h->slim) {
+            int W = (int)std::min<size_t>(8, std::max<size_t>(1, (120 * 1024 - 2048) / per_wave));
+            // (no more waves than a pose has visits to deal out: a local window's poses have a few hundred edges each)
+            while (W > 1 && (size_t)E / (size_t)std::max(P, 1) < (size_t)4 * W) W >>= 1;
+            h->rows_waves = W;
+            h->rows_lds = ((size_t)W * P * 9 + (size_t)W * 8 + 8 * 24) * sizeof(double);
+            static std::once_flag once;
+            std::call_once(once, [] {
+                (void)hipFuncSetAttribute((const void*)k_reduce_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            });
+            SE2_CHECK(h->pose_visit.reserve((size_t)E));
+            hipLaunchKernelGGL(k_plan_visits, grid1(E, 256), dim3(256), 0, st, E, h->pose_edges.p, h->e_lm.p, h->lm_ptr.p,
+                               h->pose_visit.p);
+            SE2_HIP(hipGetLastError());
+        }
+    }
     SE2_CHECK(h->fin_counter.reserve(1));
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
     SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
@@ -3777,6 +4195,8 @@ int ba_upload_graph(se2gpu_ba* h) {
     h->bulk_uv = h->bulk_info = nullptr;
     h->initialized = true;
     h->est_valid = false;
+    static std::atomic<unsigned long> serial{0};
+    h->init_serial = ++serial;
     return SE2GPU_OK;
 }
 
@@ -3793,6 +4213,10 @@ inline Bufs bufs(se2gpu_ba* h, bool ctl) {
     if (ctl) return Bufs{h->ctl.p, h->poses_a.p, h->poses_b.p, h->lms_a.p, h->lms_b.p};
     return Bufs{nullptr, h->poses, h->poses_t, h->lms, h->lms_t};
 }
+
+// slim layout: k_update reads the edge blocks Hpl_e where it read Y_e, and applies Dinv_l after the sum
+inline const double* ba_y(const se2gpu_ba* h) { return h->slim ? h->Hpl.p : h->Y.p; }
+inline const double* ba_dinv_slim(const se2gpu_ba* h) { return h->slim ? h->Dinv.p : nullptr; }
 
 // linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl; with fuse_lambda >= 0 (or fused && ctl) also Dinv, z, Y
 int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
@@ -3821,14 +4245,16 @@ int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
+    double* const Yw = h->slim ? nullptr : h->Y.p;     // slim layout: no per-edge Y / Dg records
+    double* const Dgw = h->slim ? nullptr : h->Dg.p;
     if (fuse_lambda >= 0.0)
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p, B.c, B.pb, B.lb);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
     else
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Y.p, h->Dg.p, B.c, B.pb, B.lb);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -3878,8 +4304,14 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
     }
     if (schur)
         SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
-                   lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->Y.p,
-                   h->Dg.p, B.c, schur == 2 ? 0 : 1);
+                   lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p,
+                   h->slim ? (double*)nullptr : h->Y.p, h->slim ? (double*)nullptr : h->Dg.p, B.c, schur == 2 ? 0 : 1);
+    if (h->slim)
+        SE2_LAUNCH(h->prof, st, "k_reduce_rows", k_reduce_rows, dim3(h->P + 1), dim3(64 * h->rows_waves), h->rows_lds, h->P, h->ld,
+                   lambda, h->root, h->odo_fallback ? 0 : 1, h->rows_waves, h->pose_ptr.p, h->pose_visit.p, h->e_kf.p, h->Hpl.p, h->Hpp_e.p,
+                   h->bp_e.p, h->Dinv.p, h->z.p, h->fixed.p, h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p,
+                   h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb, &h->ctl.p->epoch);
+    else
     SE2_LAUNCH(h->prof, st, "k_reduce2", k_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0, h->P, h->ld, h->nwg_off,
                lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
                h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p,
@@ -3988,14 +4420,14 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
                     h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, scal, h->d_mail, seq, (BaCtl*)nullptr,
                     (const volatile int*)nullptr, h->fin_counter.p};
         SE2_LAUNCH(h->prof, st, "k_update", k_update, dim3(ug.x + 1), dim3(kBlock), 0, h->cam, h->L, lambda, h->lm_ptr.p,
-                   h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p, h->Y.p, h->bl.p, h->lms_t,
-                   h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, fin);
+                   h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p, ba_y(h), h->bl.p, h->lms_t,
+                   h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, fin, ba_dinv_slim(h));
         SE2_HIP(hipGetLastError());
         return ba_wait_mail(h, seq);
     }
     SE2_LAUNCH(h->prof, st, "k_update", k_update, ug, dim3(kBlock), 0, h->cam, h->L,
                lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
-               h->Y.p, h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, FinArgs{});
+               ba_y(h), h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, FinArgs{}, ba_dinv_slim(h));
     SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                h->o_info.p, h->root, scal, (volatile double*)nullptr, seq, (BaCtl*)nullptr, xp ? 1 : 0, 0, 0,
@@ -4015,6 +4447,14 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
 
 // dense pose solve: augmented S|bs (device, already all-reduced) -> xp (device).
 // `fail` = scalar slot [2] of the fused buffer: set to 1 by the factorisation on a non-positive pivot.
+inline bool chol_write_through() {
+    static const bool on = [] { const char* e = getenv("SE2GPU_BA_CHOL_WT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+inline bool chol_lazy_polls() {
+    static const bool on = [] { const char* e = getenv("SE2GPU_BA_CHOL_LAZY"); return !(e && e[0] == '0'); }();
+    return on;
+}
 int ba_solve(se2gpu_ba* h, bool ctl = false) {
     hipStream_t st = h->stream;
     const int n = h->D * h->P;
@@ -4054,11 +4494,13 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         const int skip = (fault && !h->chol_faulted && h->chol_ntask > 1) ? 1 : 0;
         h->chol_faulted = true;
         static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
+        const int nk = chol_lazy_polls() ? n : -n;
+        const int nbck = chol_write_through() ? nbc : -nbc;
         if (seed)
-            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
                        h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
         else
-            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, n, nbc,
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
                        h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
     }
     SE2_HIP(hipGetLastError());
@@ -4152,13 +4594,14 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
                         (const volatile int*)h->d_stop, h->fin_counter.p};
             SE2_LAUNCH(h->prof, st, "k_update", k_update, dim3(ug.x + 1), dim3(kBlock), 0, h->cam, h->L, 0.0, h->lm_ptr.p,
                        h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, step ? h->xp.p : (const double*)nullptr,
-                       h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, fin);
+                       h->z.p, ba_y(h), h->bl.p, B.lb, h->part.p, B.c, B.pb, fin, ba_dinv_slim(h));
             SE2_HIP(hipGetLastError());
             return SE2GPU_OK;
         }
         SE2_LAUNCH(h->prof, st, "k_update", k_update, ug, dim3(kBlock), 0, h->cam, h->L,
                    0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
-                   step ? h->xp.p : (const double*)nullptr, h->z.p, h->Y.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, FinArgs{});
+                   step ? h->xp.p : (const double*)nullptr, h->z.p, ba_y(h), h->bl.p, B.lb, h->part.p, B.c, B.pb, FinArgs{},
+                   ba_dinv_slim(h));
         SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                    0.0, B.pa, h->fixed.p, h->xp.p, h->bp.p, B.pb, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                    h->o_info.p, h->root, scal, h->d_mail, seq, h->ctl.p, step ? 1 : 0, sharded ? 0 : 1, note ? 1 : 0,
@@ -4189,6 +4632,224 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
     SE2_CHECK(ba_allreduce_system(h));
     SE2_CHECK(ba_solve(h, true));
     SE2_CHECK(evaluate(true, notify));
+    return SE2GPU_OK;
+}
+
+
+// =============================================================================================
+// Lock-step batches: ONE launch per stage for ALL windows of se2gpu_ba_optimize_batch.
+// N windows on N streams are 4 N dependent launches per LM iteration and saturate the command processor at ~157 k
+// launches / s (39 k it/s at 64 windows, > 99 % of the chip idle).  Every model-0 kernel body is a __device__ function
+// of (block index, arguments); k_batched runs it for a whole batch from per-window argument packs in device memory:
+// blockIdx.y = window, blockIdx.x = the window's block.  The windows keep their own controller (BaCtl), mailbox, solver
+// flags and buffers - a window whose trial was rejected redoes its lambda part in the next slot while its neighbours
+// linearise, a finished window's blocks return at once - so the results are bit-identical to one-by-one runs.  Within a
+// window the dispatch order of the 2-D grid (x fastest) is the order the dataflow solve and the finisher of k_update rely on.
+// =============================================================================================
+template <typename... A>
+struct Packed {
+    int nblk;
+    std::tuple<A...> args;
+};
+template <auto Body, int BS, typename... A>
+__global__ __launch_bounds__(BS) void k_batched(const Packed<A...>* __restrict__ p) {
+    const Packed<A...>& x = p[blockIdx.y];
+    if ((int)blockIdx.x >= x.nblk) return;
+    std::apply([&](const A&... a) { Body(blockIdx.x, a...); }, x.args);
+}
+
+// the argument packs of one kernel for all windows of a batch; they live in the plan's arena (one upload per plan)
+struct BatchArena {
+    std::vector<uint8_t> host;
+    DevBuf<uint8_t> dev;
+    size_t add(const void* src, size_t bytes) {
+        const size_t off = (host.size() + 255) & ~(size_t)255;
+        host.resize(off + bytes);
+        std::memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+};
+template <auto Body, int BS>
+struct BatchKernel;
+template <typename... A, void (*Body)(unsigned, A...), int BS>
+struct BatchKernel<Body, BS> {
+    using P = Packed<std::remove_cv_t<A>...>;
+    std::vector<P> packs;
+    size_t off = 0;
+    int maxblk = 0;
+    void add(int nblk, A... a) {
+        packs.push_back(P{nblk, std::tuple<std::remove_cv_t<A>...>(a...)});
+        maxblk = std::max(maxblk, nblk);
+    }
+    void commit(BatchArena& ar) { off = ar.add(packs.data(), packs.size() * sizeof(P)); }
+    void launch(const BatchArena& ar, hipStream_t st, int block = BS, size_t shmem = 0) const {
+        if (packs.empty() || maxblk <= 0) return;
+        hipLaunchKernelGGL((k_batched<Body, BS, std::remove_cv_t<A>...>), dim3((unsigned)maxblk, (unsigned)packs.size()), dim3(block),
+                           shmem, st, reinterpret_cast<const P*>(ar.dev.p + off));
+    }
+    static const void* kernel() { return (const void*)k_batched<Body, BS, std::remove_cv_t<A>...>; }
+};
+
+struct BatchPlan {
+    std::vector<se2gpu_ba*> hs;
+    std::vector<unsigned long> serials;
+    int iters = -1, mode = -1;
+    bool seed = true;
+    BatchArena arena;
+    hipStream_t stream = nullptr;
+    BatchKernel<d_ctl_init, 64> ctl_init;
+    BatchKernel<d_update, kBlock> eval0, step, step_notify;
+    BatchKernel<d_linearize<false>, kBlock> lin0;
+    BatchKernel<d_linearize<true>, kBlock> lin;
+    BatchKernel<d_odometry, 64> odo;
+    BatchKernel<d_pose_reduce, kBlock> pose_reduce;
+    BatchKernel<d_maxdiag, 1024> maxdiag;
+    BatchKernel<d_schur_lm, kBlock> schur;
+    BatchKernel<d_reduce2, kBlock> reduce2;
+    BatchKernel<d_reduce_rows, 512> reduce_rows;    // launched with 64 x rows_waves threads and dynamic LDS
+    bool slim = false;
+    int rows_waves = 16;
+    size_t rows_lds = 0;
+    BatchKernel<d_chol_tiles<true>, 256> chol_seed;
+    BatchKernel<d_chol_tiles<false>, 256> chol_plain;
+    std::vector<hipEvent_t> events;
+    ~BatchPlan() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    bool matches(se2gpu_ba** h, int count, int it, int md) const {
+        if ((int)hs.size() != count || it != iters || md != mode) return false;
+        for (int i = 0; i < count; ++i)
+            if (hs[i] != h[i] || serials[i] != h[i]->init_serial) return false;
+        return true;
+    }
+};
+
+// a window the lock-step path can take: SE(2) model, one GPU, device controller, dataflow solve, no per-kernel profile
+bool ba_lockstep_ok(const se2gpu_ba* h) {
+    return h->initialized && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->chol_steps && !h->odo_fallback &&
+           !h->prof.enabled && h->d_mail && h->L > 0;
+}
+
+int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int mode) {
+    bp.hs.assign(hs, hs + count);
+    bp.serials.resize(count);
+    bp.iters = iters;
+    bp.mode = mode;
+    bp.stream = hs[0]->stream;
+    static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
+    bp.seed = seed;
+    bp.slim = hs[0]->slim;
+    bp.rows_waves = 1;
+    bp.rows_lds = 0;
+    for (int w = 0; w < count; ++w) bp.rows_waves = std::max(bp.rows_waves, hs[w]->rows_waves);
+    for (int w = 0; w < count; ++w) {
+        se2gpu_ba* h = hs[w];
+        bp.rows_lds = std::max(bp.rows_lds, h->rows_lds);
+        bp.serials[w] = h->init_serial;
+        const Bufs B = bufs(h, true);
+        double* scal = h->red + (size_t)h->ld * h->ld;
+        const dim3 ug = grid1((size_t)h->L * kGroup, kBlock);
+        bp.ctl_init.add(1, h->ctl.p, iters, mode);
+        auto fin = [&](int step, int notify) {
+            return FinArgs{1, (int)ug.x, h->P, h->O, h->root, step, 1, notify, h->fixed.p, h->xp.p, h->bp.p, B.pa, B.pb, h->o_i.p,
+                           h->o_j.p, h->o_meas.p, h->o_info.p, scal, h->d_mail, 0.0, h->ctl.p, (const volatile int*)h->d_stop,
+                           h->fin_counter.p};
+        };
+        auto upd = [&](auto& k, int step, int notify) {
+            k.add((int)ug.x + 1, h->cam, h->L, 0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
+                  step ? h->xp.p : (const double*)nullptr, h->z.p, ba_y(h), h->bl.p, B.lb, h->part.p, B.c, B.pb, fin(step, notify),
+                  ba_dinv_slim(h));
+        };
+        upd(bp.eval0, 0, 0);
+        upd(bp.step, 1, 0);
+        upd(bp.step_notify, 1, 1);
+        double* const Yw = h->slim ? nullptr : h->Y.p;
+        double* const Dgw = h->slim ? nullptr : h->Dg.p;
+        bp.lin0.add((int)ug.x, h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
+                    h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
+        bp.lin.add((int)ug.x, h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
+        bp.odo.add(h->O ? (int)grid1(h->O, 64).x : 0, h->O, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, h->poses_a.p, h->fixed.p,
+                   h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, (const BaCtl*)h->ctl.p, (const double*)h->poses_b.p);
+        bp.pose_reduce.add((int)grid1((size_t)h->P * 64, kBlock).x, h->P, h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p,
+                           h->podo_ptr.p, h->podo_item.p, h->Oii.p, h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
+        bp.maxdiag.add(1, h->L, h->Hll.p, h->P, h->Hpp.p, h->fixed.p, h->scal.p, 3, 1, h->ctl.p);
+        bp.schur.add((int)ug.x, h->L, 0.0, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p,
+                     Yw, Dgw, B.c, 1);
+        if (bp.slim)
+            bp.reduce_rows.add(h->P + 1, h->P, h->ld, 0.0, h->root, h->odo_fallback ? 0 : 1, h->rows_waves, h->pose_ptr.p, h->pose_visit.p,
+                               h->e_kf.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->fixed.p, h->podo_ptr.p,
+                               h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, h->red, h->bp.p, B.c, B.pb,
+                               &h->ctl.p->epoch);
+        else
+        bp.reduce2.add(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7), h->P, h->ld, h->nwg_off, 0.0, h->root, h->grp.p, h->blk_a.p,
+                       h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p,
+                       h->pose_edges.p, h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, h->red,
+                       h->bp.p, B.c, B.pb, &h->ctl.p->epoch);
+        {
+            const int n = h->D * h->P, ld = h->ld;
+            const int nt = ld / kNB, nbc = (n + kNB - 1) / kNB;
+            double* Rm = h->Rinv.p;
+            double* AM = Rm + (size_t)ld * ld;
+            double* RM = AM + (size_t)ld * ld;
+            unsigned* flagA = h->chol_flags.p;
+            unsigned* flagR = flagA + (size_t)nt * nbc;
+            double* fail = h->red + (size_t)ld * ld + 2;
+            const int nk = chol_lazy_polls() ? n : -n;
+            const int nbck = chol_write_through() ? nbc : -nbc;
+            if (bp.seed)
+                bp.chol_seed.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, flagA, flagR, &h->ctl.p->epoch,
+                                 fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
+            else
+                bp.chol_plain.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, flagA, flagR, &h->ctl.p->epoch,
+                                  fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
+        }
+    }
+    bp.ctl_init.commit(bp.arena); bp.eval0.commit(bp.arena); bp.step.commit(bp.arena); bp.step_notify.commit(bp.arena);
+    bp.lin0.commit(bp.arena); bp.lin.commit(bp.arena); bp.odo.commit(bp.arena); bp.pose_reduce.commit(bp.arena);
+    bp.maxdiag.commit(bp.arena); bp.schur.commit(bp.arena); bp.reduce2.commit(bp.arena); bp.reduce_rows.commit(bp.arena);
+    if (bp.slim) {
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute(decltype(bp.reduce_rows)::kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        });
+    }
+    bp.chol_seed.commit(bp.arena); bp.chol_plain.commit(bp.arena);
+    SE2_CHECK(bp.arena.dev.reserve(bp.arena.host.size()));
+    SE2_HIP(hipMemcpyAsync(bp.arena.dev.p, bp.arena.host.data(), bp.arena.host.size(), hipMemcpyHostToDevice, bp.stream));
+    while ((int)bp.events.size() < count) {
+        hipEvent_t e = nullptr;
+        SE2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        bp.events.push_back(e);
+    }
+    return SE2GPU_OK;
+}
+
+// one trial slot of every window (ba_enqueue_trial, model 0, one GPU, asynchronous controller)
+int ba_batch_slot(const BatchPlan& bp, bool first, bool notify) {
+    hipStream_t st = bp.stream;
+    const BatchArena& ar = bp.arena;
+    const bool lm = bp.mode == SE2GPU_BA_LM;
+    if (first) {
+        bp.eval0.launch(ar, st);
+        if (lm) {
+            bp.lin0.launch(ar, st);
+            bp.odo.launch(ar, st);
+            bp.pose_reduce.launch(ar, st);
+            bp.maxdiag.launch(ar, st);
+            bp.schur.launch(ar, st);
+        } else {
+            bp.lin.launch(ar, st);
+        }
+    } else {
+        bp.lin.launch(ar, st);
+    }
+    if (bp.slim) bp.reduce_rows.launch(ar, st, 64 * bp.rows_waves, bp.rows_lds);
+    else bp.reduce2.launch(ar, st);
+    if (bp.seed) bp.chol_seed.launch(ar, st);
+    else bp.chol_plain.launch(ar, st);
+    (notify ? bp.step_notify : bp.step).launch(ar, st);
+    SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
 
@@ -4994,6 +5655,108 @@ int ba_run_finish(se2gpu_ba* h, se2gpu_ba_stats* stats) {
     return SE2GPU_OK;
 }
 
+// optimize() of `count` windows in lock step.  *handled = 0 when the windows are not all eligible (the caller falls back
+// to one stream per window).
+int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
+                         se2gpu_ba_stats* stats, int* handled) {
+    *handled = 0;
+    static const bool on = [] { const char* e = getenv("SE2GPU_BA_LOCKSTEP"); return !(e && e[0] == '0'); }();
+    static const bool graphs_on = [] { const char* e = getenv("SE2GPU_BA_GRAPH"); return !(e && e[0] == '0'); }();
+    (void)graphs_on;
+    if (!on || count < 2 || ba_env_sync() || iters < 0) return SE2GPU_OK;
+    if (mode != SE2GPU_BA_LM && mode != SE2GPU_BA_GN) return SE2GPU_OK;
+    for (int i = 0; i < count; ++i)
+        if (!ba_lockstep_ok(hs[i]) || hs[i]->device != hs[0]->device || hs[i]->slim != hs[0]->slim) return SE2GPU_OK;
+    for (int i = 0; i < count; ++i)
+        for (int j = 0; j < i; ++j)
+            if (hs[i] == hs[j]) return SE2GPU_OK;
+    *handled = 1;
+    // the plan of the last batch of this thread is kept: a mapper (or the bench) that optimises the same windows again
+    // re-uses the argument packs on the device
+    // (a plain pointer, replaced on a miss and never destroyed at thread / process exit: its device memory must not be
+    // freed after the HIP runtime has shut down)
+    static thread_local BatchPlan* cache = nullptr;
+    auto drop = [&]() { delete cache; cache = nullptr; };
+    if (!cache || !cache->matches(hs, count, iters, mode)) {
+        if (cache) { SE2_HIP(hipStreamSynchronize(cache->stream)); drop(); }
+        cache = new BatchPlan;
+        const int rc = ba_build_batch_plan(*cache, hs, count, iters, mode);
+        if (rc != SE2GPU_OK) { drop(); return rc; }
+    }
+    BatchPlan& bp = *cache;
+    hipStream_t st = bp.stream;
+    for (int i = 0; i < count; ++i) {
+        se2gpu_ba* h = hs[i];
+        h->est_valid = false;
+        h->run_mode = mode;
+        h->run_iters = iters;
+        h->run_enqueued = 0;
+        h->run_sync = false;
+        h->run_active = true;
+        *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
+        // whatever the caller enqueued on the window's own stream (se2gpu_ba_reset_estimates) comes first
+        if (h->stream != st && hipStreamQuery(h->stream) != hipSuccess) {
+            SE2_HIP(hipEventRecord(bp.events[i], h->stream));
+            SE2_HIP(hipStreamWaitEvent(st, bp.events[i], 0));
+        }
+    }
+    (void)hipGetLastError();   // hipStreamQuery's hipErrorNotReady is not an error
+    const int n0 = std::max(iters, 1);
+    bp.ctl_init.launch(bp.arena, st);
+    for (int k = 0; k < n0; ++k) SE2_CHECK(ba_batch_slot(bp, k == 0, k == n0 - 1));
+    for (int i = 0; i < count; ++i) {
+        hs[i]->dev_seq += n0;
+        hs[i]->run_seq = hs[i]->dev_seq;
+        hs[i]->run_enqueued = n0;
+    }
+    for (;;) {
+        // every window answers the notification of the round's last slot (a finished one from end_slot's early path)
+        int more = 0;
+        for (int i = 0; i < count; ++i) {
+            se2gpu_ba* h = hs[i];
+            volatile double* mb = h->h_mail;
+            const auto t0 = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (mb[kMailSeq] != h->run_seq) {
+                __builtin_ia32_pause();
+                if (stop_flag && *stop_flag)
+                    for (int j = 0; j < count; ++j) *hs[j]->h_stop = 1;
+                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                    SE2_HIP(hipStreamSynchronize(st));
+                    SE2_REQUIRE(mb[kMailSeq] == h->run_seq, SE2GPU_ERR_HIP, "window %d of the batch never reported back", i);
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            BaCtl c;
+            std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
+            if (c.error) {
+                // a dataflow solve timed out in this window: it leaves the batch and finishes on its own stream with the
+                // per-column solver (ba_run_step does the switch); the other windows are unaffected
+                SE2_HIP(hipStreamSynchronize(st));
+                drop();
+                for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(h, true, stop_flag, 0, &fin));
+                for (int j = 0; j < count; ++j) {
+                    if (j == i) continue;
+                    // (the rest of the batch goes on one by one from where it stands: all their slots have been consumed)
+                    for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(hs[j], true, stop_flag, 0, &fin));
+                }
+                for (int j = 0; j < count; ++j) SE2_CHECK(ba_run_finish(hs[j], stats ? stats + j : nullptr));
+                return SE2GPU_OK;
+            }
+            if (!c.done) more = std::max(more, std::max(1, c.iters - c.it));
+        }
+        if (!more) break;
+        for (int k = 0; k < more; ++k) SE2_CHECK(ba_batch_slot(bp, false, k == more - 1));
+        for (int i = 0; i < count; ++i) {
+            hs[i]->dev_seq += more;
+            hs[i]->run_seq = hs[i]->dev_seq;
+            hs[i]->run_enqueued += more;
+        }
+    }
+    for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_finish(hs[i], stats ? stats + i : nullptr));
+    return SE2GPU_OK;
+}
+
 }  // namespace
 
 int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop_flag, int verbose,
@@ -5036,6 +5799,11 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
     // A local window is a dozen launches per LM iteration; one host thread enqueues ~0.3 M launches per second, which is
     // what bounds many small windows in flight.  The windows are therefore dealt to a few enqueue threads (each window
     // stays on one thread: a handle is not thread-safe, its stream is its own).  SE2GPU_BA_BATCH_THREADS overrides.
+    {   // one launch per stage for all windows, when every window qualifies (model 0, one GPU, dataflow solve)
+        int handled = 0;
+        const int rc = ba_optimize_lockstep(hs, count, iters, mode, stop_flag, stats, &handled);
+        if (handled || rc != SE2GPU_OK) return rc;
+    }
     static const int env_threads = [] { const char* e = getenv("SE2GPU_BA_BATCH_THREADS"); return e ? atoi(e) : 0; }();
     int nthr = env_threads > 0 ? env_threads : 8;
     nthr = std::max(1, std::min(nthr, count / 4));

@@ -492,6 +492,47 @@ def test_optimize_batch_equals_one_by_one(synth):
     assert ref[2][0]["trials_hist"] == LM_REJECT_CASES[3][1]
 
 
+def test_lockstep_batch_mixed_rejections_repeats_and_gauss_newton(synth):
+    """the windows of a batch share ONE launch per stage (k_batched: blockIdx.y = window) and still decide
+    for themselves - five starts that reject trials at different iterations next to windows that never do, run twice (the
+    second call re-uses the argument packs on the device) and once in Gauss-Newton mode: every window bit-identical to its
+    own one-by-one run."""
+    from se2lam_amd.optimizer import optimize_batch
+    graphs = [_kidnapped(synth, *c[0]) for c in LM_REJECT_CASES] + [synth.ba_graph(8, 60), synth.ba_graph(30, 2000), synth.ba_graph(50, 5000)]
+    for mode in (0, 1):
+        ref = []
+        for g in graphs:
+            o = _opt(g)
+            o.optimize(10, mode) if mode else o.optimize(10)
+            ref.append((o.stats, o.estimates()))
+        if mode == 0:
+            assert [r[0]["trials_hist"] for r in ref[:len(LM_REJECT_CASES)]] == [c[1] for c in LM_REJECT_CASES]
+        opts = [_opt(g) for g in graphs]
+        for rep in range(2):
+            for o in opts:
+                o.reset_estimates()
+            its = optimize_batch(opts, 10, mode)
+            for o, (st, (p, l)), n in zip(opts, ref, its):
+                assert n == st["iterations"] and o.stats == st
+                pp, ll = o.estimates()
+                assert np.array_equal(pp, p) and np.array_equal(ll, l)
+    # a shorter run on the same handles (another plan), and a stop flag raised from the start
+    ref4 = []
+    for g in graphs:
+        o = _opt(g)
+        o.optimize(4)
+        ref4.append(o.stats)
+    for o in opts:
+        o.reset_estimates()
+    optimize_batch(opts, 4)
+    assert [o.stats for o in opts] == ref4
+    stop = np.ones(1, np.uint8)
+    for o in opts:
+        o.reset_estimates()
+    its = optimize_batch(opts, 10, 0, stop)
+    assert its == [0] * len(opts) and all(o.stats["stopped"] for o in opts)
+
+
 def test_force_stop_flag_and_synchronous_controller(synth):
     """setForceStopFlag (LocalMapper.cpp:246): a flag that is already set leaves the estimate untouched and reports
     `stopped`; the synchronous controller (SE2GPU_BA_SYNC=1 semantics are the same code path as verbose) agrees with the
