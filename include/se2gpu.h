@@ -328,6 +328,11 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
  * dependency timed out earlier in the handle's life (reported once on stderr), 3 = host solve (SE2GPU_BA_HOST_SOLVE=1).
  * Tests use it to make sure that results were not produced by the fallback. */
 int se2gpu_ba_debug_solver_path(const se2gpu_ba* h);
+/* The plan of the dense pose solve (tile tasks, their dependency lists, the fill-reducing order of the poses) for a P x P
+ * block pattern, computed on the host without a device - what stands in for CHOLMOD's symbolic analysis behind
+ * /root/reference/include/se2lam/optimizer.h:31.  Test introspection (tests/test_solve_plan.py). */
+int se2gpu_ba_debug_solve_plan(int P, int D, const uint8_t* pattern, int allow_nd, int* nsys, int* nbc, int* depth, int* ntask,
+                               int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap);
 
 /* Track::doTriangulate (/root/reference/src/Track.cpp:378-419) for every match of a frame pair in one device pass -
  * SURVEY section 8(f).3.  Per feature i of the reference key frame with match_idx[i] >= 0 and no map point yet:

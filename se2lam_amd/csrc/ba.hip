@@ -584,13 +584,15 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                                                      const double* __restrict__ o_info, const double* __restrict__ poses,
                                                      double* __restrict__ S, double* __restrict__ bp,
                                                      const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
-                                                     unsigned* __restrict__ epoch) {
+                                                     unsigned* __restrict__ epoch, const int* __restrict__ pose_off, int nsys) {
     if (ctl) {
         if (ctl->done) return;
         if (ctl->sel) poses = poses_b;
         lambda = ctl->lambda;
     }
-    const int n = 3 * P;
+    // pose p's three unknowns live in the columns pose_off[p] .. + 2 of the system (the solver's fill-reducing order, with
+    // identity padding between its partitions: solve_plan_build); nullptr = natural order, 3 p
+    const int n = pose_off ? nsys : 3 * P;
     __shared__ double part[kGrpPerWG][9];
     __shared__ double dpart[kBlock / 64][12];
     // grid = [P + 1 diagonal workgroups | off-diagonal workgroups, rounded up to a multiple of the 8 XCDs].  The diagonal
@@ -656,8 +658,9 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                     out += A[rr] * WB[cc] + A[3 + rr] * WB[3 + cc] + A[6 + rr] * WB[6 + cc];
                 }
             }
-            S[(size_t)(3 * a + r) * ld + 3 * b + c] = out;
-            S[(size_t)(3 * b + c) * ld + 3 * a + r] = out;
+            const int ca = pose_off ? pose_off[a] : 3 * a, cb = pose_off ? pose_off[b] : 3 * b;
+            S[(size_t)(ca + r) * ld + cb + c] = out;
+            S[(size_t)(cb + c) * ld + ca + r] = out;
         }
         return;
     }
@@ -750,11 +753,12 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
             double out;
             if (fa) out = (r == c && root) ? 1.0 : 0.0;
             else out = v + ((r == c && root) ? lambda : 0.0);
-            S[(size_t)(3 * p + r) * ld + 3 * p + c] = out;
+            const int cp = pose_off ? pose_off[p] : 3 * p;
+            S[(size_t)(cp + r) * ld + cp + c] = out;
         } else {
             const int r = i - 9;
             const double gz = dpart[0][9 + r] + dpart[1][9 + r] + dpart[2][9 + r] + dpart[3][9 + r];
-            bs[3 * p + r] = fa ? 0.0 : v - gz;
+            bs[(pose_off ? pose_off[p] : 3 * p) + r] = fa ? 0.0 : v - gz;
             bp[(size_t)p * 3 + r] = fa ? 0.0 : v;
         }
     }
@@ -772,8 +776,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                                                      const double* __restrict__ o_info, const double* __restrict__ poses,
                                                      double* __restrict__ S, double* __restrict__ bp,
                                                      const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
-                                                     unsigned* __restrict__ epoch) {
-    d_reduce2(blockIdx.x, P, ld, nwg_off, lambda, root, grp, blk_a, blk_b, pair_i, pair_j, blk_odo, Y, Hpl, Dg, fixed, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch);
+                                                     unsigned* __restrict__ epoch, const int* __restrict__ pose_off, int nsys) {
+    d_reduce2(blockIdx.x, P, ld, nwg_off, lambda, root, grp, blk_a, blk_b, pair_i, pair_j, blk_odo, Y, Hpl, Dg, fixed, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch, pose_off, nsys);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1298,7 +1302,8 @@ __device__ inline bool spin_until(const unsigned* f, unsigned epoch, bool lazy =
 template <bool SEED>
 __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restrict__ A, double* __restrict__ AM,
                                                      double* __restrict__ R, double* __restrict__ RM, int ld, int n,
-                                                     int nbc, const int2* __restrict__ tasks,
+                                                     int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
+                                                     const int* __restrict__ col_src,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
@@ -1327,7 +1332,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     if (tid == 0) { ready_s = 0; loaded_s = 0; }
     long long* stamp = dbg ? dbg + (size_t)bx * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
-    const int2 tk = tasks[bx];
+    const int4 tk = tasks[bx];   // {tile row | kind << 16, block column, first, one past the last entry of its dependency list}
     if ((tk.x >> 16) == 2) {
         // ---- x = R y for the 32 rows of tile row r (what k_chol_apply did as a kernel of its own): the last tasks of the
         // list.  x(r) = sum_{j >= r} MR_R(r,j) y_un(j); the terms are taken as their tiles are published, so that only the last
@@ -1337,9 +1342,10 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
         const int it = n / kNB;                       // tile row of the rhs row
         const int row = tid / 8, c4 = (tid % 8) * 4;  // 8 lanes per row, 4 columns each
         double acc = 0.0;
-        for (int j = r; j < nbc; ++j) {
+        for (int dq = tk.z; dq < tk.w; ++dq) {   // the block columns j >= r with a non-zero R(r, j), ascending
+            const int j = deps[dq];
             if (tid == 0) {
-                const bool lazy = lazy_on && j + 1 < nbc;     // only the last block column's term is waited for in earnest
+                const bool lazy = lazy_on && dq + 1 < tk.w;   // only the last term is waited for in earnest
                 bool ok = spin_until(flagR + (size_t)r * nbc + j, epoch, lazy);
                 ok = ok && spin_until((it == j ? flagR : flagA) + (size_t)it * nbc + j, epoch, lazy);
                 ok_s = ok ? 1 : 0;
@@ -1363,7 +1369,10 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
         acc += __shfl_xor(acc, 1);
         acc += __shfl_xor(acc, 2);
         acc += __shfl_xor(acc, 4);
-        if ((tid & 7) == 0 && kNB * r + row < n) xout[kNB * r + row] = acc;
+        if ((tid & 7) == 0 && kNB * r + row < n) {
+            const int dst = col_src ? col_src[kNB * r + row] : kNB * r + row;   // system column -> 3 * pose + component (< 0: padding)
+            if (dst >= 0) xout[dst] = acc;
+        }
         return;
     }
     const bool isR = (tk.x >> 16) != 0;
@@ -1385,10 +1394,14 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
         D0[v] = A[(size_t)(kNB * j + orow + 4 * v) * ld + kNB * j + ocol];
         if (!isR && !isDiag) T0[v] = A[(size_t)(kNB * i + orow + 4 * v) * ld + kNB * j + ocol];
     }
-    for (int m = 0; m < j; ++m) {
-        const bool hasT = !isDiag && !(isR && m < i);  // R(r,m) is zero for m < r: only D is updated
+    // the block columns m < j with a non-zero L(j, m), ascending (all of them for a dense system); bit 15 of an entry: the
+    // task's own tile row has a non-zero tile in that column too (L(i, m) / R(r, m)), otherwise only D is updated
+    for (int dq = tk.z; dq < tk.w; ++dq) {
+        const int dep = deps[dq];
+        const int m = dep & 0x7fff;
+        const bool hasT = (dep >> 15) != 0;
         if (tid == 0) {
-            const bool lazy = lazy_on && m + 1 < j;           // block column m is not the one this task's elimination waits for
+            const bool lazy = lazy_on && dq + 1 < tk.w;       // not the block column this task's elimination waits for
             bool ok = spin_until(flagA + (size_t)j * nbc + m, epoch, lazy);
             if (hasT) ok = ok && spin_until((isR ? flagR : flagA) + (size_t)i * nbc + m, epoch, lazy);
             ok_s = ok ? 1 : 0;
@@ -1584,17 +1597,19 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
 template <bool SEED>
 __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
                                                      double* __restrict__ R, double* __restrict__ RM, int ld, int n,
-                                                     int nbc, const int2* __restrict__ tasks,
+                                                     int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
+                                                     const int* __restrict__ col_src,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
                                                      double* __restrict__ xout) {
-    d_chol_tiles<SEED>(blockIdx.x, A, AM, R, RM, ld, n, nbc, tasks, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
+    d_chol_tiles<SEED>(blockIdx.x, A, AM, R, RM, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
 __global__ __launch_bounds__(256) void k_chol_apply(const double* __restrict__ A, const double* __restrict__ R, int ld,
-                                                     int n, double* __restrict__ x, const BaCtl* __restrict__ ctl) {
+                                                     int n, double* __restrict__ x, const BaCtl* __restrict__ ctl,
+                                                     const int* __restrict__ col_src) {
     if (ctl && ctl->done) return;
     const int r = blockIdx.x * 4 + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
@@ -1604,7 +1619,8 @@ __global__ __launch_bounds__(256) void k_chol_apply(const double* __restrict__ A
     double acc = 0.0;
     for (int c = r + lane; c < n; c += 64) acc += R[(size_t)r * ld + c] * y[c];
     acc = wave_sum(acc);
-    if (lane == 0) x[r] = acc;
+    const int dst = col_src ? col_src[r] : r;   // permuted system: column -> 3 * pose + component, < 0 = padding
+    if (lane == 0 && dst >= 0) x[dst] = acc;
 }
 
 // The end of a trial without a kernel boundary (single GPU): k_update gets ONE extra workgroup, launched last, that does
@@ -3121,7 +3137,16 @@ struct se2gpu_ba {
     DevBuf<double> Hpl, Hpp_e, bp_e, Hll, bl, Dinv, z, Y, Dg, Hpp, bp, Oii, Ojj, Oij, obi, obj;
     DevBuf<double> red_own, xp, part, scal, diag3, Rinv;
     DevBuf<double> red_packed;    // sharded runs: the lower-triangular tiles of [S; b^T], what the all-reduce ships
-    DevBuf<int2> chol_tasks;      // k_chol_tiles: (tile row | isR << 16, block column), ordered by column
+    DevBuf<int4> chol_tasks;      // k_chol_tiles: {tile row | kind << 16, block column, dependency list [first, last)}, by column
+    DevBuf<int> chol_deps;        // the dependency lists: block column | (own tile row non-zero there) << 15
+    DevBuf<int> pose_off;         // fill-reducing order of the pose solve: first system column of pose p (nullptr = 3 p)
+    DevBuf<int> col_src;          // system column -> 3 * pose + component, -1 = padding (nullptr = identity)
+    std::vector<int> h_pose_off;  // host copy (debug_reduced_system gathers S back into pose order)
+    DevBuf<uint8_t> plan_nz;      // per block of the upper triangle: structurally non-zero (k_plan_pattern)
+    PinBuf<uint8_t> h_plan_nz;
+    DevBuf<uint8_t> solver_arena; // chol_tasks | chol_deps | pose_off | col_src
+    int nsys = 0;                 // order of the (padded) system the solver factorises; D * P in natural order
+    int solve_depth = 0;          // block columns on the longest dependency chain of the plan (debug)
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
     DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
@@ -3590,10 +3615,24 @@ __global__ __launch_bounds__(256) void k_plan_bounds(const int* __restrict__ key
 }
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
 
+// which blocks of the reduced system are structurally non-zero (a contributor pair or an odometry edge): what the solver's
+// fill-reducing order is chosen from (solve_plan_choose)
+__global__ void k_plan_pattern(int nblk, const int* __restrict__ blk_ptr, const int* __restrict__ blk_odo, uint8_t* __restrict__ nz) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nblk) nz[q] = (blk_ptr[q + 1] > blk_ptr[q] || blk_odo[q] >= 0) ? 1 : 0;
+}
+// identity on the diagonal of the padding columns of a permuted system (set once: neither k_reduce2 nor the in-place
+// factorisation ever writes anything but zero into padding rows / columns)
+__global__ void k_solver_pads(double* __restrict__ S, int ld, int nsys, const int* __restrict__ col_src) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nsys && col_src[c] < 0) S[(size_t)c * ld + c] = 1.0;
+}
+
 // The host builder of the contributor plan: the reference implementation of the device kernels above and the fallback
 // for graphs they do not take (more than 1024 poses; SE2GPU_BA_PLAN=host).  Edges are already sorted by landmark.
 struct HostPlan {
     std::vector<int> lm_ptr, pose_ptr, pose_edges, blk_a, blk_b, blk_odo, pair_i, pair_j;
+    std::vector<uint8_t> blk_nz;   // per block of the upper triangle: any contributor pair or an odometry edge (solve_plan_choose)
     std::vector<int4> grp;
     int nwg_off = 0;
 };
@@ -3659,6 +3698,9 @@ void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const u
             const int i = o_i[k], j = o_j[k];
             pl.blk_odo[blk_index_of(P, std::min(i, j), std::max(i, j))] = 2 * k + (i > j ? 1 : 0);
         }
+    pl.blk_nz.resize(nblk);
+    for (int q = 0; q < nblk; ++q) pl.blk_nz[q] = (blk_ptr[q + 1] > blk_ptr[q] || pl.blk_odo[q] >= 0) ? 1 : 0;
+    for (int k = 0; k < O; ++k) pl.blk_nz[blk_index_of(P, std::min(o_i[k], o_j[k]), std::max(o_i[k], o_j[k]))] = 1;
     // pack 16-pair chunks of the off-diagonal blocks into workgroups of 28 nine-lane groups
     std::vector<int4>& grp = pl.grp;
     grp.clear();
@@ -3685,6 +3727,172 @@ void ba_plan_host(int P, int L, int E, const int* e_kf, const int* e_lm, const u
     flush();
     if (grp.empty()) grp.assign(gpw, make_int4(-1, 0, 0, 0));
     pl.nwg_off = (int)(grp.size() / gpw);
+}
+
+// =============================================================================================
+// Plan of the dense pose solve (round 3): which tiles exist, what every tile task waits for, and - for the SE(2) model on
+// one GPU - a fill-reducing ORDER of the poses.  The reference hands the reduced system to CHOLMOD, whose ordering
+// exploits that key frames far apart share no landmarks; the dataflow solve gets the same from a nested-dissection
+// order: the tile tasks of two interiors that no landmark couples depend on disjoint block columns and run side by side,
+// so the chain of block columns (7 us each) is the separator's plus ONE interior's instead of all of them (200 key frames
+// on a loop: 19 -> 15).  Everything here is host code on the P x P block pattern; correctness never depends on the
+// heuristics that propose an order - the tile structure of whatever order wins is derived from the pattern itself by a
+// symbolic factorisation (fill included), and an order only wins by a shorter chain.
+//   layout     partitions of poses; a partition starts on a tile boundary (identity padding behind it)
+//   tile L     symbolic Cholesky on the 32-wide tiles of the permuted pattern; the rhs row is a tile row of its own
+//   tile R     R = L^-T restricted to what x = R y needs: R(r,r), R(r,j) <- any m in [r, j): R(r,m) and L(j,m)
+//   tasks      per block column: its L tiles (diagonal first), its R tiles; the x tasks last.  A task lists the block
+//              columns m < j with L(j,m) != 0 (bit 15: its own tile row is non-zero in m as well)
+// =============================================================================================
+struct SolvePlan {
+    int nsys = 0, nbc = 0, nt = 0, depth = 0, ntile = 0;
+    bool permuted = false;
+    std::vector<int> pose_off, col_src;
+    std::vector<int4> tasks;
+    std::vector<int> deps;
+};
+
+// parts: the poses of every partition in order; pad: partitions (and therefore the rhs row) start on tile boundaries
+void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::vector<int>>& parts, bool pad, SolvePlan& sp) {
+    sp.pose_off.assign(P, 0);
+    int c = 0;
+    for (const auto& part : parts) {
+        for (int p : part) { sp.pose_off[p] = c; c += D; }
+        if (pad) c = (c + kNB - 1) / kNB * kNB;
+    }
+    sp.nsys = c;
+    sp.permuted = pad;
+    sp.col_src.assign(sp.nsys, -1);
+    for (int p = 0; p < P; ++p)
+        for (int k = 0; k < D; ++k) sp.col_src[sp.pose_off[p] + k] = D * p + k;
+    const int nbc = (sp.nsys + kNB - 1) / kNB;
+    const int ld = ((sp.nsys + 1 + kNB - 1) / kNB) * kNB, nt = ld / kNB;
+    const int it = sp.nsys / kNB;                     // tile row of the rhs row (== nbc when the system is padded)
+    sp.nbc = nbc;
+    sp.nt = nt;
+    // tile pattern of the lower triangle (rows 0 .. nt-1: the rhs tile row is dense)
+    std::vector<uint8_t> Lt((size_t)nt * nbc, 0);
+    auto L = [&](int i, int j) -> uint8_t& { return Lt[(size_t)i * nbc + j]; };
+    for (int j = 0; j < nbc; ++j) L(j, j) = 1;
+    std::vector<int> t0(P), t1(P);
+    for (int p = 0; p < P; ++p) { t0[p] = sp.pose_off[p] / kNB; t1[p] = (sp.pose_off[p] + D - 1) / kNB; }
+    for (int a = 0; a < P; ++a)
+        for (int b = 0; b <= a; ++b) {
+            if (pat && !pat[(size_t)a * P + b] && !pat[(size_t)b * P + a]) continue;
+            for (int ta = t0[a]; ta <= t1[a]; ++ta)
+                for (int tb = t0[b]; tb <= t1[b]; ++tb) {
+                    if (ta >= tb) L(ta, tb) = 1; else L(tb, ta) = 1;
+                }
+        }
+    for (int j = 0; j < nbc; ++j) L(it, j) = 1;        // y = L^-1 b
+    for (int j = 0; j < nbc; ++j)                      // symbolic factorisation: fill between the rows of a column
+        for (int i = j + 1; i < nt; ++i) {
+            if (!L(i, j)) continue;
+            for (int k = i; k < nt; ++k)
+                if (L(k, j) && k < nt && i < nbc) L(k, i) = 1;
+        }
+    std::vector<uint8_t> Rt((size_t)nbc * nbc, 0);
+    auto R = [&](int r, int j) -> uint8_t& { return Rt[(size_t)r * nbc + j]; };
+    for (int r = 0; r < nbc; ++r) {
+        R(r, r) = 1;
+        for (int j = r + 1; j < nbc; ++j)
+            for (int m = r; m < j; ++m)
+                if (R(r, m) && L(j, m)) { R(r, j) = 1; break; }
+    }
+    sp.tasks.clear();
+    sp.deps.clear();
+    sp.ntile = 0;
+    std::vector<int> depth(nbc, 0);
+    sp.depth = 0;
+    for (int j = 0; j < nbc; ++j) {
+        int dj = 0;
+        for (int m = 0; m < j; ++m)
+            if (L(j, m)) dj = std::max(dj, depth[m]);
+        depth[j] = dj + 1;
+        sp.depth = std::max(sp.depth, depth[j]);
+        for (int i = j; i < nt; ++i) {
+            if (!L(i, j)) continue;
+            const int first = (int)sp.deps.size();
+            for (int m = 0; m < j; ++m)
+                if (L(j, m)) sp.deps.push_back(m | ((i != j && L(i, m)) ? 0x8000 : 0));
+            sp.tasks.push_back(make_int4(i, j, first, (int)sp.deps.size()));
+            ++sp.ntile;
+        }
+        for (int r = 0; r < j; ++r) {
+            if (!R(r, j)) continue;
+            const int first = (int)sp.deps.size();
+            for (int m = 0; m < j; ++m)
+                if (L(j, m)) sp.deps.push_back(m | ((m >= r && R(r, m)) ? 0x8000 : 0));
+            sp.tasks.push_back(make_int4(r | (1 << 16), j, first, (int)sp.deps.size()));
+            ++sp.ntile;
+        }
+    }
+    for (int r = 0; r < nbc; ++r) {   // x = R y, one task per tile row
+        const int first = (int)sp.deps.size();
+        for (int j = r; j < nbc; ++j)
+            if (R(r, j)) sp.deps.push_back(j);
+        sp.tasks.push_back(make_int4(r | (2 << 16), 0, first, (int)sp.deps.size()));
+    }
+}
+
+// candidate orders for a pattern whose natural order is a band - open or closed to a ring (key frames in sequence, a loop
+// closure at most between the ends) - and the choice by chain length
+void solve_plan_choose(int P, int D, const uint8_t* pat, bool allow_nd, SolvePlan& best) {
+    std::vector<int> all(P);
+    for (int p = 0; p < P; ++p) all[p] = p;
+    solve_plan_build(P, D, pat, {all}, false, best);
+    if (!allow_nd || !pat || D * P < 4 * kNB) return;
+    int w_lin = 0, w_cyc = 0;
+    for (int a = 0; a < P; ++a)
+        for (int b = 0; b < a; ++b)
+            if (pat[(size_t)a * P + b] || pat[(size_t)b * P + a]) {
+                w_lin = std::max(w_lin, a - b);
+                w_cyc = std::max(w_cyc, std::min(a - b, P - (a - b)));
+            }
+    const int min_interior = (kNB + D - 1) / D;       // an interior below one tile of poses is not worth a partition
+    std::function<void(int, int, int, int, std::vector<std::vector<int>>&)> linear = [&](int lo, int hi, int w, int levels,
+                                                                                         std::vector<std::vector<int>>& out) {
+        const int n = hi - lo;
+        if (n <= 0) return;
+        if (levels == 0 || n < 2 * min_interior + w) {
+            std::vector<int> v;
+            for (int p = lo; p < hi; ++p) v.push_back(p);
+            out.push_back(v);
+            return;
+        }
+        const int s0 = lo + (n - w) / 2, s1 = s0 + w;
+        linear(lo, s0, w, levels - 1, out);
+        linear(s1, hi, w, levels - 1, out);
+        std::vector<int> sep;
+        for (int p = s0; p < s1; ++p) sep.push_back(p);
+        out.push_back(sep);
+    };
+    auto consider = [&](const std::vector<std::vector<int>>& parts) {
+        SolvePlan cand;
+        solve_plan_build(P, D, pat, parts, true, cand);
+        // a shorter chain of block columns wins; the natural order keeps ties (no padding, fewer tiles)
+        if (cand.depth < best.depth && cand.nt <= 64) best = std::move(cand);
+    };
+    if (w_lin >= 1 && 3 * w_lin <= P)                 // open band: separators of the band's width, up to three levels
+        for (int lv = 1; lv <= 3; ++lv) {
+            std::vector<std::vector<int>> parts;
+            linear(0, P, w_lin, lv, parts);
+            if (parts.size() > 1) consider(parts);
+        }
+    if (w_cyc < w_lin && w_cyc >= 1 && 2 * w_cyc + 2 * min_interior <= P) {   // ring: two separators, joined into the last partition
+        const int w = w_cyc;
+        for (int lv = 0; lv <= 2; ++lv) {
+            const int h = (P + 1) / 2;
+            std::vector<std::vector<int>> parts;
+            linear(w, h, w, lv, parts);
+            linear(h + w, P, w, lv, parts);
+            std::vector<int> sep;
+            for (int p = 0; p < w; ++p) sep.push_back(p);
+            for (int p = h; p < std::min(h + w, P); ++p) sep.push_back(p);
+            parts.push_back(sep);
+            consider(parts);
+        }
+    }
 }
 
 // one copy stream per device, shared by all handles, never destroyed
@@ -3958,15 +4166,10 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     if (h->host_solve) SE2_CHECK(h->h_red.reserve(nred));
     SE2_CHECK(h->Rinv.reserve(3 * (size_t)h->ld * h->ld));  // R | AM | RM (the last two: k_chol_tiles only)
-    const int nt = h->ld / kNB, nbc = (n + kNB - 1) / kNB;
-    std::vector<int2> tasks;
-    for (int j = 0; j < nbc; ++j) {
-        for (int i = j; i < nt; ++i) tasks.push_back(make_int2(i, j));
-        for (int r = 0; r < j; ++r) tasks.push_back(make_int2(r | (1 << 16), j));
-    }
-    for (int r = 0; r < nbc; ++r) tasks.push_back(make_int2(r | (2 << 16), 0));   // x = R y, one task per tile row
-    h->chol_ntask = (int)tasks.size();
-    stage(h->chol_tasks, tasks.data(), tasks.size());
+    // (the tile tasks of the solve are planned after the block pattern is known: ba_setup_solver, below)
+    static const bool nd_env = [] { const char* e = getenv("SE2GPU_BA_ND"); return !(e && e[0] == '0'); }();
+    const bool nd_possible = nd_env && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->ar_buffer &&
+                             D * P >= 4 * kNB && P <= 1024;
     // last in the arena: the measurements and information matrices (copied on their own stream, see below; with a local
     // graph loaded through se2gpu_ba_load_local_graph the information is evaluated on the device and not copied at all)
     const size_t big_off = staged_bytes;
@@ -4120,6 +4323,13 @@ int ba_upload_graph(se2gpu_ba* h) {
         SE2_HIP(hipGetLastError());
         SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
         SE2_HIP(hipMemcpyAsync(h->h_scal.p, h->plan_out.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        if (nd_possible) {   // the block pattern for the solver's order comes back with the same synchronisation
+            SE2_CHECK(h->plan_nz.reserve((size_t)nblk));
+            SE2_CHECK(h->h_plan_nz.reserve((size_t)nblk));
+            hipLaunchKernelGGL(k_plan_pattern, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->blk_ptr.p, h->blk_odo.p,
+                               h->plan_nz.p);
+            SE2_HIP(hipMemcpyAsync(h->h_plan_nz.p, h->plan_nz.p, (size_t)nblk, hipMemcpyDeviceToHost, st));
+        }
         lap("plan kernels enqueued");
     }
     SE2_HIP(hipStreamWaitEvent(st, h->ev_copy1, 0));   // measurements / information are in place before anything later runs
@@ -4152,21 +4362,10 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     SE2_CHECK(h->fin_counter.reserve(1));
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
-    SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt * nbc));
-    SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt * nbc * sizeof(unsigned), st));
-    // the handle's device-side counters start over with the graph (flags = 0 = "no epoch yet")
+    // the handle's device-side counters start over with the graph
     SE2_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(BaCtl), st));
     h->dev_seq = 0;
     h->drop_graphs();
-    {
-        const char* env = getenv("SE2GPU_BA_CHOL");
-        h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt > 64 || h->chol_fallback;
-        const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
-        if (tr && tr[0] == '1') {
-            SE2_CHECK(h->chol_trace.reserve(16 * (size_t)h->chol_ntask));
-            SE2_HIP(hipMemsetAsync(h->chol_trace.p, 0, 16 * (size_t)h->chol_ntask * sizeof(long long), st));
-        }
-    }
     SE2_CHECK(h->h_x.reserve(n));
     SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
     if (!h->h_mail) {
@@ -4189,6 +4388,72 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->nwg_off = std::max(nwg, 1);
     }
     lap("synchronise");
+    // ---- the dense pose solve: order of the poses, tile tasks, dependency lists (solve_plan_choose), then its buffers
+    {
+        std::vector<uint8_t> pat;
+        if (nd_possible && !h->slim) {
+            const uint8_t* nz = device_plan ? h->h_plan_nz.p : pl.blk_nz.data();
+            pat.assign((size_t)P * P, 0);
+            for (int a = 0; a < P; ++a) {
+                pat[(size_t)a * P + a] = 1;
+                for (int b = a + 1; b < P; ++b)
+                    if (nz[blk_index_of(P, a, b)]) pat[(size_t)a * P + b] = pat[(size_t)b * P + a] = 1;
+            }
+        }
+        SolvePlan sp;
+        solve_plan_choose(P, D, pat.empty() ? nullptr : pat.data(), !pat.empty(), sp);
+        h->nsys = sp.nsys;
+        h->solve_depth = sp.depth;
+        h->chol_ntask = (int)sp.tasks.size();
+        {   // tasks | dependency lists | pose_off | col_src: through the (now idle) pinned arena, one copy
+            auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+            const size_t b0 = up(sp.tasks.size() * sizeof(int4)), b1 = up(std::max<size_t>(sp.deps.size(), 1) * 4);
+            const size_t b2 = sp.permuted ? up(sp.pose_off.size() * 4) : 0, b3 = sp.permuted ? up(sp.col_src.size() * 4) : 0;
+            SE2_CHECK(h->h_stage.reserve(b0 + b1 + b2 + b3));
+            SE2_CHECK(h->solver_arena.reserve(b0 + b1 + b2 + b3));
+            uint8_t* hp = h->h_stage.p;
+            std::memcpy(hp, sp.tasks.data(), sp.tasks.size() * sizeof(int4));
+            std::memcpy(hp + b0, sp.deps.data(), sp.deps.size() * 4);
+            if (sp.permuted) {
+                std::memcpy(hp + b0 + b1, sp.pose_off.data(), sp.pose_off.size() * 4);
+                std::memcpy(hp + b0 + b1 + b2, sp.col_src.data(), sp.col_src.size() * 4);
+            }
+            SE2_HIP(hipMemcpyAsync(h->solver_arena.p, hp, b0 + b1 + b2 + b3, hipMemcpyHostToDevice, st));
+            h->chol_tasks.alias(reinterpret_cast<int4*>(h->solver_arena.p));
+            h->chol_deps.alias(reinterpret_cast<int*>(h->solver_arena.p + b0));
+            if (sp.permuted) {
+                h->pose_off.alias(reinterpret_cast<int*>(h->solver_arena.p + b0 + b1));
+                h->col_src.alias(reinterpret_cast<int*>(h->solver_arena.p + b0 + b1 + b2));
+            }
+        }
+        if (sp.permuted) {
+            h->h_pose_off = sp.pose_off;
+            h->ld = ((sp.nsys + 1 + kNB - 1) / kNB) * kNB;
+            const size_t nred2 = (size_t)h->ld * h->ld + 4;
+            SE2_CHECK(h->red_own.reserve(nred2));
+            h->red = h->red_own.p;
+            SE2_CHECK(h->Rinv.reserve(3 * (size_t)h->ld * h->ld));
+            SE2_CHECK(h->xp.reserve((size_t)std::max(n, sp.nsys)));
+            SE2_HIP(hipMemsetAsync(h->red, 0, nred2 * sizeof(double), st));
+            hipLaunchKernelGGL(k_solver_pads, grid1((size_t)sp.nsys, 256), dim3(256), 0, st, h->red, h->ld, sp.nsys, h->col_src.p);
+            SE2_HIP(hipGetLastError());
+        } else {
+            h->h_pose_off.clear();
+            h->pose_off.release();
+            h->col_src.release();
+        }
+        const int nt2 = h->ld / kNB, nbc2 = (h->nsys + kNB - 1) / kNB;
+        SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt2 * nbc2));
+        SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt2 * nbc2 * sizeof(unsigned), st));   // flags = 0 = "no epoch yet"
+        const char* env = getenv("SE2GPU_BA_CHOL");
+        h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt2 > 64 || h->chol_fallback;
+        const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
+        if (tr && tr[0] == '1') {
+            SE2_CHECK(h->chol_trace.reserve(16 * (size_t)h->chol_ntask));
+            SE2_HIP(hipMemsetAsync(h->chol_trace.p, 0, 16 * (size_t)h->chol_ntask * sizeof(long long), st));
+        }
+        lap("solve plan");
+    }
     // the borrow of se2gpu_ba_load ends here: everything has been copied into the pinned arena and uploaded
     h->bulk_E = 0;
     h->bulk_kf = h->bulk_lm = nullptr;
@@ -4316,7 +4581,7 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
                lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
                h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p,
                h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb,
-               &h->ctl.p->epoch);
+               &h->ctl.p->epoch, (const int*)h->pose_off.p, h->nsys);
     if (h->O && h->odo_fallback) {
         // PreEdgeSE2 edges the plan cannot carry (self loops, duplicates): blocks from the estimate, added atomically.  Only
         // reachable with a host-known estimate pointer, so such graphs run in synchronous mode (ba_needs_sync).
@@ -4457,7 +4722,7 @@ inline bool chol_lazy_polls() {
 }
 int ba_solve(se2gpu_ba* h, bool ctl = false) {
     hipStream_t st = h->stream;
-    const int n = h->D * h->P;
+    const int n = h->nsys;   // D * P, or the padded order of the permuted system (solve_plan_choose)
     const int ld = h->ld;
     double* A = h->red;
     double* fail = h->red + (size_t)ld * ld + 2;
@@ -4482,7 +4747,8 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
     if (h->chol_steps) {
         for (int k = 0; k < nbc; ++k)  // update with panel k-1 fused with the elimination of panel k
             SE2_LAUNCH(h->prof, st, "k_chol_step", k_chol_step, dim3(nbc - k, nt), dim3(256), 0, A, Rm, ld, n, nt, k, fail, c);
-        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p, c);
+        SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p, c,
+                   (const int*)h->col_src.p);
     } else {
         double* AM = Rm + (size_t)ld * ld;
         double* RM = AM + (size_t)ld * ld;
@@ -4498,10 +4764,12 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         const int nbck = chol_write_through() ? nbc : -nbc;
         if (seed)
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
-                       h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
+                       h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                       fail, h->chol_trace.p, c, h->xp.p);
         else
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
-                       h->chol_tasks.p + skip, flagA, flagR, &h->ctl.p->epoch, fail, h->chol_trace.p, c, h->xp.p);
+                       h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                       fail, h->chol_trace.p, c, h->xp.p);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
@@ -4785,9 +5053,9 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
         bp.reduce2.add(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7), h->P, h->ld, h->nwg_off, 0.0, h->root, h->grp.p, h->blk_a.p,
                        h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p,
                        h->pose_edges.p, h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, h->red,
-                       h->bp.p, B.c, B.pb, &h->ctl.p->epoch);
+                       h->bp.p, B.c, B.pb, &h->ctl.p->epoch, (const int*)h->pose_off.p, h->nsys);
         {
-            const int n = h->D * h->P, ld = h->ld;
+            const int n = h->nsys, ld = h->ld;
             const int nt = ld / kNB, nbc = (n + kNB - 1) / kNB;
             double* Rm = h->Rinv.p;
             double* AM = Rm + (size_t)ld * ld;
@@ -4798,10 +5066,12 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
             const int nk = chol_lazy_polls() ? n : -n;
             const int nbck = chol_write_through() ? nbc : -nbc;
             if (bp.seed)
-                bp.chol_seed.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, flagA, flagR, &h->ctl.p->epoch,
+                bp.chol_seed.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                                 (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
                                  fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
             else
-                bp.chol_plain.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, flagA, flagR, &h->ctl.p->epoch,
+                bp.chol_plain.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                                  (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
                                   fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
         }
     }
@@ -5445,9 +5715,44 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
     SE2_CHECK(ba_reduce(h, lambda, false));
     SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
     SE2_HIP(hipStreamSynchronize(h->stream));
+    if (!h->h_pose_off.empty()) {   // the solver's fill-reducing order: gather the system back into pose order
+        const int ns = h->nsys, ld = h->ld, D = h->D;
+        std::vector<double> full((size_t)(ns + 1) * ld);
+        SE2_HIP(hipMemcpy(full.data(), h->red, full.size() * 8, hipMemcpyDeviceToHost));
+        for (int a = 0; a < h->P; ++a)
+            for (int r = 0; r < D; ++r) {
+                const int ra = h->h_pose_off[a] + r;
+                if (bs) bs[D * a + r] = full[(size_t)ns * ld + ra];
+                if (S)
+                    for (int b = 0; b < h->P; ++b)
+                        for (int c = 0; c < D; ++c) S[(size_t)(D * a + r) * n + D * b + c] = full[(size_t)ra * ld + h->h_pose_off[b] + c];
+            }
+        return SE2GPU_OK;
+    }
     if (S)
         SE2_HIP(hipMemcpy2D(S, (size_t)n * 8, h->red, (size_t)h->ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost));
     if (bs) SE2_HIP(hipMemcpy(bs, h->red + (size_t)n * h->ld, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return SE2GPU_OK;
+}
+
+// The plan of the dense pose solve for a P x P block pattern (row-major bytes, != 0 where two poses share a landmark or an
+// odometry edge; NULL = dense), without a device: tests/test_solve_plan.py runs the tile algorithm of k_chol_tiles in numpy
+// from these lists.  Arrays may be NULL (sizes only); tasks: {tile row | kind << 16, block column, first dep, end dep}.
+int se2gpu_ba_debug_solve_plan(int P, int D, const uint8_t* pattern, int allow_nd, int* nsys, int* nbc, int* depth, int* ntask,
+                               int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap) {
+    SE2_REQUIRE(P > 0 && (D == 3 || D == 6) && nsys && nbc && depth && ntask && ndep, SE2GPU_ERR_INVALID, "debug_solve_plan: bad argument");
+    SolvePlan sp;
+    solve_plan_choose(P, D, pattern, allow_nd != 0, sp);
+    *nsys = sp.nsys; *nbc = sp.nbc; *depth = sp.depth; *ntask = (int)sp.tasks.size(); *ndep = (int)sp.deps.size();
+    if (pose_off) std::memcpy(pose_off, sp.pose_off.data(), (size_t)P * 4);
+    if (tasks4) {
+        SE2_REQUIRE(task_cap >= (int)sp.tasks.size(), SE2GPU_ERR_CAPACITY, "debug_solve_plan: %zu tasks", sp.tasks.size());
+        std::memcpy(tasks4, sp.tasks.data(), sp.tasks.size() * sizeof(int4));
+    }
+    if (deps) {
+        SE2_REQUIRE(dep_cap >= (int)sp.deps.size(), SE2GPU_ERR_CAPACITY, "debug_solve_plan: %zu dependency entries", sp.deps.size());
+        std::memcpy(deps, sp.deps.data(), sp.deps.size() * 4);
+    }
     return SE2GPU_OK;
 }
 

@@ -90,7 +90,8 @@ def test_reference_call_lines_compile_against_the_mirrors(tmp_path):
     against include/se2lam_amd (CamPara* addCamPara(opt, K, id), public mfNNratio, 5-argument ORBextractor, ...)."""
     exe = _build_call_lines(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout + r.stderr
+    # (without a device the binary stops after the compile-level checks and says OK; on a GPU box it runs the pasted lines)
+    assert r.returncode == 0 and ("OK" in r.stdout or "reference call lines ran" in r.stdout), r.stdout + r.stderr
 
 
 @pytest.mark.gpu
