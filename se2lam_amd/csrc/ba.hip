@@ -1314,25 +1314,30 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     if (n < 0) n = -n;
     const bool wt_all = nbc > 0;                  // (SE2GPU_BA_CHOL_WT=0 passes -nbc: early waves plain stores + fence, as before)
     if (nbc < 0) nbc = -nbc;
-    // LDS: 36 KB per task (was 59), so that four tasks share a CU - what bounds a batch of windows solved side by side
-    // (k_batched) is how many tile tasks are resident.  The multiplier columns of the elimination re-use the operand tiles
-    // of the update phase: rows 0..15 (waves 0, 1) lie over Tc, which nobody reads after the last tile product; rows 16..31
-    // (waves 2, 3) over Ta, which every wave reads once more - its share of the finished tile - and reports in `loaded_s`.
+    // LDS: 36 KB per task (was 59), so that more tasks share a CU when a batch of windows is solved side by side
+    // (k_batched).  The multiplier columns of the elimination re-use the operand tiles of the update phase: rows 0..15
+    // (waves 0, 1) lie over Tc, which nobody reads after the last tile product; rows 16..31 (waves 2, 3) reach into Ta,
+    // which every wave reads once more - its share of the finished tile - and reports in `loaded_s`.
     constexpr int kTile = kNB * (kNB + 2);
     __shared__ __attribute__((aligned(16))) double LD[3 * kTile + kNB * kNB + 8 * kNB];
-    double (*Ta)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD);              // MR(i,m), then the finished tile T
-    double (*Tb)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD + kTile);      // M(j,m),  then the finished diagonal D
-    double (*Tc)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD + 2 * kTile);  // MR(j,m)
+    // order in LDS: Tb | Tc | Ta | COLV | dummy row.  The 32 multiplier columns (32 x 64 doubles, contiguous: immediate
+    // offsets in the pivot loop) start where Tc starts and run on into Ta
+    double (*Tb)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD);              // M(j,m),  then the finished diagonal D
+    double (*Tc)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD + kTile);      // MR(j,m)
+    double (*Ta)[kNB + 2] = reinterpret_cast<double (*)[kNB + 2]>(LD + 2 * kTile);  // MR(i,m), then the finished tile T
     double (*COLV)[kNB] = reinterpret_cast<double (*)[kNB]>(LD + 3 * kTile);        // an eliminated column's values in the D rows
     double* const DUMMY = LD + 3 * kTile + kNB * kNB;                               // where the T rows' lanes write instead
-    auto mrc_row = [&](int r) -> double* { return r < 16 ? LD + 2 * kTile + r * 64 : LD + (r - 16) * 64; };   // MRC[r][0..63]
-    static_assert(16 * 64 <= kTile, "sixteen multiplier columns fit one operand tile");
+    double (*MRC)[64] = reinterpret_cast<double (*)[64]>(LD + kTile);               // multiplier column of every eliminated column
+    static_assert(16 * 64 <= kTile && 32 * 64 <= 2 * kTile, "rows 0..15 of MRC lie inside Tc, all of it inside Tc | Ta");
     __shared__ int ok_s, ready_s, loaded_s;
+    __shared__ int deps_s[64];   // this task's dependency list (at most 64 tile rows): fetched once, not one global load per column
     const int tid = threadIdx.x;
     if (tid == 0) { ready_s = 0; loaded_s = 0; }
     long long* stamp = dbg ? dbg + (size_t)bx * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     const int4 tk = tasks[bx];   // {tile row | kind << 16, block column, first, one past the last entry of its dependency list}
+    if (tid < tk.w - tk.z && tid < 64) deps_s[tid] = deps[tk.z + tid];
+    __syncthreads();
     if ((tk.x >> 16) == 2) {
         // ---- x = R y for the 32 rows of tile row r (what k_chol_apply did as a kernel of its own): the last tasks of the
         // list.  x(r) = sum_{j >= r} MR_R(r,j) y_un(j); the terms are taken as their tiles are published, so that only the last
@@ -1343,7 +1348,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
         const int row = tid / 8, c4 = (tid % 8) * 4;  // 8 lanes per row, 4 columns each
         double acc = 0.0;
         for (int dq = tk.z; dq < tk.w; ++dq) {   // the block columns j >= r with a non-zero R(r, j), ascending
-            const int j = deps[dq];
+            const int j = deps_s[dq - tk.z];
             if (tid == 0) {
                 const bool lazy = lazy_on && dq + 1 < tk.w;   // only the last term is waited for in earnest
                 bool ok = spin_until(flagR + (size_t)r * nbc + j, epoch, lazy);
@@ -1397,7 +1402,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     // the block columns m < j with a non-zero L(j, m), ascending (all of them for a dense system); bit 15 of an entry: the
     // task's own tile row has a non-zero tile in that column too (L(i, m) / R(r, m)), otherwise only D is updated
     for (int dq = tk.z; dq < tk.w; ++dq) {
-        const int dep = deps[dq];
+        const int dep = deps_s[dq - tk.z];
         const int m = dep & 0x7fff;
         const bool hasT = (dep >> 15) != 0;
         if (tid == 0) {
@@ -1481,7 +1486,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
         double mrv[4], cv[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            mrv[u] = mrc_row(done + u)[lane];
+            mrv[u] = MRC[done + u][lane];
 #pragma unroll
             for (int q = 0; q < 8; ++q) cv[u][q] = COLV[done + u][cb + q];
         }
@@ -1499,7 +1504,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     // minimum, LDS rows addressed with immediate offsets.
     if (w >= 2)
         while (__hip_atomic_load(&loaded_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
-    double* mrc = mrc_row(cb) + lane;
+    double* mrc = &MRC[cb][lane];
     double* colv = lane < kNB ? &COLV[cb][lane] : DUMMY + (lane - kNB);   // (same row stride: immediate offsets below)
     double pmin = 1e300, mr_prev = 0.0, rvb[2][8];   // rvb: double buffer (static indices: the loop is unrolled)
     // SEED: the multiplier comes straight from the reciprocal seed x0 and the Newton residual e = 1 - piv x0,

@@ -247,7 +247,7 @@ __device__ __forceinline__ void stage_candidates(const uint32_t* __restrict__ ca
         int local = 0;
         for (int i = lane * per; i < min(nq, (lane + 1) * per); ++i) {
             int n = ncand[i];
-            if (n > kMaxCand) { atomicOr(overflow, 1); n = kMaxCand; }
+            if (n > kMaxCand) { atomicOr(overflow, 1); n = kMaxCand; }   // (informational: such queries take the spill scan)
             local += n;
         }
         int incl = local;
@@ -299,21 +299,75 @@ __device__ __forceinline__ void three_maxima(const int* hist, int& ind1, int& in
 // form a linked list (head[target] -> next[query] -> ...), rebuilt before every sweep; accD[query] is the distance a
 // query accepts its target with.
 struct LaneBest {
-    int bd, bp, bd2, bp2;
+    int bd, bp, bd2, bp2;   // best / second-best distance and list position (-1: none)
+    int bi, bi2;            // ... and the target features they belong to
 };
+__device__ __forceinline__ void lane_best_push(LaneBest& b, int dist, int t, int idx) {
+    if (dist < b.bd) { b.bd2 = b.bd; b.bp2 = b.bp; b.bi2 = b.bi; b.bd = dist; b.bp = t; b.bi = idx; }
+    else if (dist < b.bd2) { b.bd2 = dist; b.bp2 = t; b.bi2 = idx; }
+}
 __device__ __forceinline__ LaneBest query_scan(const uint32_t* cl, int n, int q, const int* vMatchesDistance,
                                                const int* head, const int* next, const int* accD) {
-    LaneBest b{INT_MAX, -1, INT_MAX, -1};
+    LaneBest b{INT_MAX, -1, INT_MAX, -1, -1, -1};
     for (int t = 0; t < n; ++t) {
         const uint32_t pk = cl[t];
         const int dist = (int)(pk & 0xfffu), idx = (int)(pk >> 12);
         int eff = vMatchesDistance ? vMatchesDistance[idx] : INT_MAX;
         for (int a = head[idx]; a >= 0; a = next[a])
             if (a < q) eff = min(eff, accD[a]);
-        if (!(eff <= dist)) {
-            if (dist < b.bd) { b.bd2 = b.bd; b.bp2 = b.bp; b.bd = dist; b.bp = t; }
-            else if (dist < b.bd2) { b.bd2 = dist; b.bp2 = t; }
-        }
+        if (!(eff <= dist)) lane_best_push(b, dist, t, idx);
+    }
+    return b;
+}
+
+// The same scan for a query whose search window holds more candidates than a list keeps (kMaxCand): the candidates are
+// enumerated again from the target frame's grid order - the cells, the level band, the square test and the Hamming
+// distance exactly as scan_candidates takes them, in the same order - by the query's own thread, every sweep.  Slow (a
+// clustered frame: hundreds of key points inside one 40 x 40 window) but exact: the reference has no such limit
+// (ORBmatcher.cpp:298-325 walks whatever GetFeaturesInArea returns), and a tracker must not lose the frame over it.
+struct SpillTarget {
+    Bounds bd;
+    const uint32_t* sorted;          // the target frame's grid order (cell << 16 | feature)
+    const int* grid;                 // its column offsets (kGridRec ints)
+    const se2gpu_keypoint* kps;      // target key points
+    const uint8_t* desc;             // target descriptors
+    const uint8_t* excl;             // features to skip (KeyFrame::hasObservation), or nullptr
+};
+__device__ inline LaneBest query_scan_spill(const SpillTarget& tg, float x, float y, float r, int minLevel, int maxLevel,
+                                            const uint8_t* __restrict__ d1, int q, const int* vMatchesDistance,
+                                            const int* head, const int* next, const int* accD) {
+    LaneBest b{INT_MAX, -1, INT_MAX, -1, -1, -1};
+    const Bounds& bd = tg.bd;
+    int nMinCellX = (int)floorf((x - bd.min_x - r) * bd.wInv);
+    nMinCellX = max(0, nMinCellX);
+    if (nMinCellX >= kGridCols) return b;
+    int nMaxCellX = (int)ceilf((x - bd.min_x + r) * bd.wInv);
+    nMaxCellX = min(kGridCols - 1, nMaxCellX);
+    if (nMaxCellX < 0) return b;
+    int nMinCellY = (int)floorf((y - bd.min_y - r) * bd.hInv);
+    nMinCellY = max(0, nMinCellY);
+    if (nMinCellY >= kGridRows) return b;
+    int nMaxCellY = (int)ceilf((y - bd.min_y + r) * bd.hInv);
+    nMaxCellY = min(kGridRows - 1, nMaxCellY);
+    if (nMaxCellY < 0) return b;
+    const bool checkLevels = !(minLevel == -1 && maxLevel == -1);
+    const int cbeg = tg.grid[1 + nMinCellX], cend = tg.grid[2 + nMaxCellX];
+    int t = 0;
+    for (int pos = cbeg; pos < cend; ++pos) {
+        const uint32_t pk = tg.sorted[pos];
+        const int cell = (int)(pk >> 16), idx = (int)(pk & 0xffffu);
+        const int cx = cell / kGridRows, cy = cell % kGridRows;
+        if (!(cx >= nMinCellX && cx <= nMaxCellX && cy >= nMinCellY && cy <= nMaxCellY)) continue;
+        const se2gpu_keypoint kp = tg.kps[idx];
+        const bool ok = (!checkLevels || (kp.octave >= minLevel && kp.octave <= maxLevel)) && !(fabsf(kp.x - x) > r) &&
+                        !(fabsf(kp.y - y) > r) && !(tg.excl && tg.excl[idx]);
+        if (!ok) continue;
+        const int dist = hamming256(d1, tg.desc + 32 * (size_t)idx);
+        int eff = vMatchesDistance ? vMatchesDistance[idx] : INT_MAX;
+        for (int a = head[idx]; a >= 0; a = next[a])
+            if (a < q) eff = min(eff, accD[a]);
+        if (!(eff <= dist)) lane_best_push(b, dist, t, idx);
+        ++t;
     }
     return b;
 }
@@ -334,7 +388,10 @@ __global__ __launch_bounds__(1024) void k_resolve_window(const se2gpu_keypoint* 
                                                           const uint32_t* __restrict__ cand, const int* __restrict__ ncand,
                                                           float nnratio, int cand_lds, int* __restrict__ matches12,
                                                           float* __restrict__ prev_xy, int* __restrict__ nmatches,
-                                                          int* __restrict__ overflow) {
+                                                          int* __restrict__ overflow, Bounds bd,
+                                                          const uint8_t* __restrict__ desc, const uint32_t* __restrict__ sorted,
+                                                          const int* __restrict__ n_grid, int win, int level_offset,
+                                                          int min_level, int max_level) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     const int p = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -372,9 +429,18 @@ __global__ __launch_bounds__(1024) void k_resolve_window(const se2gpu_keypoint* 
         for (int q = tid; q < n1; q += nthr) {
             const int o0 = off[q], n = off[q + 1] - o0;
             const uint32_t* cl = (o0 + n <= cand_lds) ? ce + o0 : cand_p + (size_t)q * kMaxCand;
-            const LaneBest b = query_scan(cl, n, q, nullptr, head, next, accD);
+            LaneBest b;
+            if (ncand[(size_t)p * cap + q] > kMaxCand) {   // more candidates than the list keeps: exact scan of the grid
+                const int level1 = k1[q].octave;
+                const int minLevel2 = level1 - level_offset > 0 ? level1 - level_offset : 0;
+                const SpillTarget tg{bd, sorted + (size_t)fb * cap, n_grid + (size_t)fb * kGridRec, k2, desc + (size_t)fb * cap * 32, nullptr};
+                b = query_scan_spill(tg, prev_xy[((size_t)p * cap + q) * 2], prev_xy[((size_t)p * cap + q) * 2 + 1], (float)win,
+                                     minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + q) * 32, q, nullptr, head, next, accD);
+            } else {
+                b = query_scan(cl, n, q, nullptr, head, next, accD);
+            }
             const bool nacc = b.bp >= 0 && b.bd <= kThLow && (float)b.bd < (float)b.bd2 * nnratio;
-            const int nidx = nacc ? (int)(cl[b.bp] >> 12) : -1;
+            const int nidx = nacc ? b.bi : -1;
             const int nd = nacc ? b.bd : 0;
             changed |= (nidx != accT[q]) | (nd != accD[q]);
             accT2[q] = nidx;
@@ -445,7 +511,8 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
                                                           const uint8_t* __restrict__ kf_observed,
                                                           const uint32_t* __restrict__ sorted,
                                                           const int* __restrict__ n_grid, int win, int level_offset,
-                                                          uint32_t* __restrict__ cand, int* __restrict__ ncand, int n_feat, int qpb) {
+                                                          uint32_t* __restrict__ cand, int* __restrict__ ncand, int n_feat, int qpb,
+                                                          float* __restrict__ proj_xy) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     const int q0 = blockIdx.x * qpb;
     const TargetLds tg = stage_target(lds, n_feat, kps, sorted, n_feat);
@@ -467,6 +534,7 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
             v += 0.f * pc[0]; v += cam.fy * pc[1]; v += cam.cy * pc[2];
             w += 0.f * pc[0]; w += 0.f * pc[1]; w += 1.f * pc[2];
             const float px = u / w, py = v / w;
+            if ((threadIdx.x & 63) == 0) { proj_xy[2 * (size_t)i] = px; proj_xy[2 * (size_t)i + 1] = py; }   // (for the spill scan)
             if (px >= bd.min_x && px <= bd.max_x && py >= bd.min_y && py <= bd.max_y) {
                 const int predictLevel = mp_octave[i];
                 const int levelWinSize = predictLevel * win;
@@ -489,7 +557,13 @@ __global__ __launch_bounds__(1024) void k_resolve_projection(const se2gpu_keypoi
                                                               const uint32_t* __restrict__ cand,
                                                               const int* __restrict__ ncand, float nnratio,
                                                               int chunk, int cand_lds, int* __restrict__ match_idx,
-                                                              int* __restrict__ nmatches, int* __restrict__ overflow) {
+                                                              int* __restrict__ nmatches, int* __restrict__ overflow, Bounds bd,
+                                                              const uint8_t* __restrict__ desc,
+                                                              const uint8_t* __restrict__ kf_observed,
+                                                              const uint32_t* __restrict__ sorted,
+                                                              const int* __restrict__ n_grid, const float* __restrict__ proj_xy,
+                                                              const uint8_t* __restrict__ mp_desc,
+                                                              const int* __restrict__ mp_octave, int win, int level_offset) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     __shared__ int s_cnt;
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -522,12 +596,22 @@ __global__ __launch_bounds__(1024) void k_resolve_projection(const se2gpu_keypoi
             for (int q = tid; q < mq; q += nthr) {
                 const int o0 = off[q], nc = off[q + 1] - o0;
                 const uint32_t* cl = (o0 + nc <= cand_lds) ? ce + o0 : cand_c + (size_t)q * kMaxCand;
-                const LaneBest b = query_scan(cl, nc, q, vMatchesDistance, head, next, accD);
+                LaneBest b;
+                if (ncand[i0 + q] > kMaxCand) {   // more candidates than the list keeps: exact scan of the key frame's grid
+                    const int predictLevel = mp_octave[i0 + q];
+                    const int minLevel = predictLevel > level_offset ? predictLevel - level_offset : 0;
+                    const SpillTarget tg{bd, sorted, n_grid, kps, desc, kf_observed};
+                    b = query_scan_spill(tg, proj_xy[2 * (size_t)(i0 + q)], proj_xy[2 * (size_t)(i0 + q) + 1],
+                                         (float)(predictLevel * win), minLevel, predictLevel + level_offset,
+                                         mp_desc + 32 * (size_t)(i0 + q), q, vMatchesDistance, head, next, accD);
+                } else {
+                    b = query_scan(cl, nc, q, vMatchesDistance, head, next, accD);
+                }
                 bool nacc = b.bp >= 0 && b.bd <= kThHigh;
                 int nidx = -1;
                 if (nacc) {
-                    nidx = (int)(cl[b.bp] >> 12);
-                    const int bestLevel2 = b.bp2 >= 0 ? octave[cl[b.bp2] >> 12] : -1;
+                    nidx = b.bi;
+                    const int bestLevel2 = b.bp2 >= 0 ? octave[b.bi2] : -1;
                     if (octave[nidx] == bestLevel2 && (float)b.bd > nnratio * (float)b.bd2) { nacc = false; nidx = -1; }
                 }
                 const int nd = nacc ? b.bd : 0;
@@ -573,11 +657,11 @@ __global__ __launch_bounds__(64) void k_bow_match(const int2* __restrict__ node_
                                                    const uint8_t* __restrict__ desc2, const uint8_t* __restrict__ has2,
                                                    int mp_only, float nnratio, int check_ori, int* __restrict__ matches12,
                                                    int* __restrict__ bin_of, int* __restrict__ hist) {
-    __shared__ unsigned char matched2[2048];
+    extern __shared__ unsigned char matched2[];   // vbMatched2 of this node's features: sized by the host to the largest node
     const int lane = threadIdx.x;
     const int2 np = node_pairs[blockIdx.x];
     const int a0 = ptr1[np.x], a1 = ptr1[np.x + 1], b0 = ptr2[np.y], b1 = ptr2[np.y + 1];
-    const int m2 = min(b1 - b0, 2048);
+    const int m2 = b1 - b0;
     for (int i = lane; i < m2; i += 64) matched2[i] = 0;
     __syncthreads();
     const float factor = (float)kHisto / 360.0f;
@@ -660,7 +744,7 @@ struct se2gpu_matcher {
     // scratch for frame sets of up to `nframes_cap` frames with stride `cap_cur`
     DevBuf<uint32_t> sorted, cand;
     DevBuf<int> n_grid, ncand, overflow, pair_a, pair_b, counts, matches, nmatches, mp_octave;
-    DevBuf<float> prev, mp_pos;
+    DevBuf<float> prev, mp_pos, proj_xy;
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc, mp_desc, mp_skip, kf_obs, has1, has2;
     DevBuf<int> fvp1, fvi1, fvp2, fvi2, bin_of, hist;
@@ -679,11 +763,9 @@ int check_overflow(se2gpu_matcher* h) {
     int ov = 0;
     SE2_HIP(hipMemcpyAsync(&ov, h->overflow.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     SE2_HIP(hipStreamSynchronize(h->stream));
-    if (ov) {
-        SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
-        set_error("matcher: more than %d candidates in one search window", kMaxCand);
-        return SE2GPU_ERR_CAPACITY;
-    }
+    // (a search window with more than kMaxCand candidates is no error any more: those queries were resolved by the exact
+    // spill scan; the flag only says that it happened)
+    if (ov) SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
     return SE2GPU_OK;
 }
 
@@ -737,7 +819,8 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     const size_t lds = fixed_lds + (size_t)cand_lds * sizeof(int);
     const int resolve_threads = std::min(1024, std::max(64, (cap + 63) & ~63));
     hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(resolve_threads), lds, st, d_kps, d_counts, cap, d_pair_a,
-                       d_pair_b, h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, d_overflow);
+                       d_pair_b, h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, d_overflow, bd, d_desc,
+                       (const uint32_t*)h->sorted.p, (const int*)h->n_grid.p, win, level_offset, min_level, max_level);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -886,10 +969,6 @@ int se2gpu_match_window(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds, co
     SE2_HIP(hipMemcpyAsync(hs, ds, o_kps, hipMemcpyDeviceToHost, st));
     SE2_HIP(hipStreamSynchronize(st));
     const int* r = (const int*)(hs + o_sc);
-    if (r[1]) {
-        set_error("matcher: more than %d candidates in one search window", kMaxCand);
-        return SE2GPU_ERR_CAPACITY;
-    }
     std::memcpy(matches12, hs + o_m, (size_t)n1 * sizeof(int));
     std::memcpy(prev_xy, hs + o_prev, (size_t)n1 * 2 * sizeof(float));
     *n_matches = r[0];
@@ -914,6 +993,7 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     SE2_CHECK(h->n_grid.reserve(kGridRec));
     SE2_CHECK(h->cand.reserve((size_t)mm * kMaxCand));
     SE2_CHECK(h->ncand.reserve((size_t)mm));
+    SE2_CHECK(h->proj_xy.reserve(2 * (size_t)mm));
     // one block both ways: [match_idx (n) | nmatches, overflow, count | kps | desc | kf_obs | mp_pos | mp_octave | mp_desc | mp_skip]
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_m = 0, o_sc = up16((size_t)n * sizeof(int)), o_kps = o_sc + 16;
@@ -951,7 +1031,7 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
         hipLaunchKernelGGL(k_cand_projection, dim3((m + qpb - 1) / qpb), dim3(256), (size_t)n * 16, st, bd, cam,
                            (const float*)(ds + o_pos), ds + o_mdesc, (const int*)(ds + o_oct), ds + o_skip, m, d_kps,
                            ds + o_desc, ds + o_obs, h->sorted.p, h->n_grid.p, win_size, level_offset, h->cand.p, h->ncand.p,
-                           n, qpb);
+                           n, qpb, h->proj_xy.p);
     }
     {
         const int chunk = 1024;
@@ -962,16 +1042,15 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
         SE2_CHECK(lds_attributes());
         const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));
         hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(1024), fixed_lds + (size_t)cand_lds * sizeof(int), st, d_kps,
-                           n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, (int*)(ds + o_m), d_sc, d_sc + 1);
+                           n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, (int*)(ds + o_m), d_sc, d_sc + 1, bd,
+                           (const uint8_t*)(ds + o_desc), (const uint8_t*)(ds + o_obs), (const uint32_t*)h->sorted.p,
+                           (const int*)h->n_grid.p, (const float*)h->proj_xy.p, (const uint8_t*)(ds + o_mdesc),
+                           (const int*)(ds + o_oct), win_size, level_offset);
     }
     SE2_HIP(hipGetLastError());
     SE2_HIP(hipMemcpyAsync(hs, ds, o_kps, hipMemcpyDeviceToHost, st));
     SE2_HIP(hipStreamSynchronize(st));
     const int* r = (const int*)(hs + o_sc);
-    if (r[1]) {
-        set_error("matcher: more than %d candidates in one search window", kMaxCand);
-        return SE2GPU_ERR_CAPACITY;
-    }
     std::memcpy(match_idx_mp, hs + o_m, (size_t)n * sizeof(int));
     *n_matches = r[0];
     return SE2GPU_OK;
@@ -1003,8 +1082,10 @@ int se2gpu_search_by_bow(se2gpu_matcher* h, const se2gpu_keypoint* kps1, const u
         SE2_REQUIRE(fv1_ptr[k] <= fv1_ptr[k + 1], SE2GPU_ERR_INVALID, "search_by_bow: fv1_ptr is not monotone");
     for (int k = 0; k < nn2; ++k) {
         SE2_REQUIRE(fv2_ptr[k] <= fv2_ptr[k + 1], SE2GPU_ERR_INVALID, "search_by_bow: fv2_ptr is not monotone");
-        SE2_REQUIRE(fv2_ptr[k + 1] - fv2_ptr[k] <= 2048, SE2GPU_ERR_CAPACITY, "search_by_bow: more than 2048 features in one node");
     }
+    int max_node2 = 64;   // LDS bytes of k_bow_match: one flag per feature of the largest node (a key frame has <= max_features)
+    for (int k = 0; k < nn2; ++k) max_node2 = std::max(max_node2, fv2_ptr[k + 1] - fv2_ptr[k]);
+    SE2_REQUIRE(max_node2 <= 64 * 1024, SE2GPU_ERR_CAPACITY, "search_by_bow: %d features in one vocabulary node", max_node2);
     hipStream_t st = h->stream;
     const int t1 = nn1 ? fv1_ptr[nn1] : 0, t2 = nn2 ? fv2_ptr[nn2] : 0;
     SE2_CHECK(h->kps.reserve((size_t)n1 + n2 + 1));
@@ -1046,7 +1127,7 @@ int se2gpu_search_by_bow(se2gpu_matcher* h, const se2gpu_keypoint* kps1, const u
     SE2_HIP(hipMemsetAsync(h->bin_of.p, 0xff, (size_t)n1 * sizeof(int), st));
     SE2_HIP(hipMemsetAsync(h->hist.p, 0, 32 * sizeof(int), st));
     if (!pairs.empty())
-        hipLaunchKernelGGL(k_bow_match, dim3((unsigned)pairs.size()), dim3(64), 0, st, h->node_pairs.p, h->fvp1.p, h->fvi1.p,
+        hipLaunchKernelGGL(k_bow_match, dim3((unsigned)pairs.size()), dim3(64), (size_t)((max_node2 + 63) & ~63), st, h->node_pairs.p, h->fvp1.p, h->fvi1.p,
                            h->fvp2.p, h->fvi2.p, h->kps.p, h->desc.p, h->has1.p, d_k2, d_d2, h->has2.p, mp_only, nnratio,
                            check_orientation, h->matches.p, h->bin_of.p, h->hist.p);
     hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st, n1, check_orientation, h->bin_of.p, h->hist.p, h->matches.p,

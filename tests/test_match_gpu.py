@@ -141,6 +141,67 @@ def test_match_by_projection_edge_cases(oracle, feats):
         assert nm == nm_ref and np.array_equal(idx, idx_ref), order
 
 
+def _clustered(feats, rng, ncluster, nspread, jitter):
+    """key points of frame 0 re-positioned: `ncluster` of them inside a 30 x 30 pixel patch (hundreds of candidates in
+    every 40 x 40 search window there - far beyond the 128 a candidate list keeps), the rest where they were"""
+    (k0, d0) = feats[0]
+    pick = rng.choice(len(k0), ncluster + nspread, replace=False)
+    k = k0[pick].copy(); d = d0[pick].copy()
+    k["x"][:ncluster] = 320 + rng.uniform(-15, 15, ncluster).astype(np.float32)
+    k["y"][:ncluster] = 240 + rng.uniform(-15, 15, ncluster).astype(np.float32)
+    k["octave"][:ncluster] = rng.integers(0, 3, ncluster)
+    k2 = k.copy(); d2 = d.copy()
+    k2["x"] += rng.normal(0, jitter, len(k)).astype(np.float32)
+    k2["y"] += rng.normal(0, jitter, len(k)).astype(np.float32)
+    flip = (rng.random(d.shape) < 0.02).astype(np.uint8) * rng.integers(0, 256, d.shape).astype(np.uint8)
+    d2 ^= flip
+    perm = rng.permutation(len(k))
+    return (k, d), (k2[perm].copy(), d2[perm].copy())
+
+
+@pytest.mark.parametrize("ncluster", [200, 450])
+def test_clustered_features_beyond_the_candidate_lists(oracle, feats, ncluster):
+    """the reference has no limit on what GetFeaturesInArea returns (ORBmatcher.cpp:298-325, 404-427); a
+    search window with more candidates than a device list keeps (128) used to be SE2GPU_ERR_CAPACITY - a clustered frame
+    lost.  Those queries now take an exact scan of the grid inside the resolve pass: results equal the oracle's."""
+    from se2lam_amd.matcher import ORBmatcher
+    rng = np.random.default_rng(ncluster)
+    (k1, d1), (k2, d2) = _clustered(feats, rng, ncluster, 300, 1.5)
+    prev = _prev(k1)
+    nm, m12 = ORBmatcher(0.9).MatchByWindow(k1, d1, k2, d2, prev, 20)
+    m_ref, nm_ref, prev_ref = oracle.match_window(k1, d1, k2, d2)
+    assert nm == nm_ref and nm > 30 and np.array_equal(m12, m_ref) and np.array_equal(prev, prev_ref)
+    # MatchByProjection: map points that all project into the cluster of the key frame
+    fx = fy = 400.0; cx, cy = 320.0, 240.0
+    m = 600
+    src = rng.integers(0, ncluster, m)
+    depth = rng.uniform(1000, 5000, m).astype(np.float32)
+    pos = np.stack([(k1["x"][src] - cx) / fx * depth, (k1["y"][src] - cy) / fy * depth, depth], 1).astype(np.float32)
+    Tcw = np.concatenate([np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32)], 1)
+    mp_desc = d1[src].copy()
+    mp_desc ^= (rng.random(mp_desc.shape) < 0.02).astype(np.uint8) * rng.integers(0, 256, mp_desc.shape).astype(np.uint8)
+    mp_oct = np.clip(k1["octave"][src], 1, 7).astype(np.int32)          # level window = octave * 15 px
+    args = (pos, mp_desc, mp_oct, np.zeros(m, np.uint8), Tcw, (fx, fy, cx, cy), k2, d2, (rng.random(len(k2)) < 0.1).astype(np.uint8))
+    nm, idx = ORBmatcher().MatchByProjection(*args, 15, 2)
+    idx_ref, nm_ref = oracle.match_projection(*args, 15, 2, 0.6)
+    assert nm == nm_ref and nm > 20 and np.array_equal(idx, idx_ref)
+
+
+def test_search_by_bow_with_a_node_of_thousands(oracle, feats):
+    """a vocabulary node that holds more features than the old 2048-entry LDS table: one node for the whole key frame"""
+    from se2lam_amd.matcher import ORBmatcher
+    rng = np.random.default_rng(11)
+    ks = [np.concatenate([feats[t][0] for t in (0, 1, 2)]), np.concatenate([feats[t][0] for t in (3, 4, 5)])]
+    ds = [np.concatenate([feats[t][1] for t in (0, 1, 2)]), np.concatenate([feats[t][1] for t in (3, 4, 5)])]
+    assert len(ks[1]) > 2048
+    fvs = [(np.zeros(1, np.int32), np.array([0, len(k)], np.int32), rng.permutation(len(k)).astype(np.int32)) for k in ks]
+    hs = [np.ones(len(k), np.uint8) for k in ks]
+    mt = ORBmatcher(0.9)
+    nm, m12 = mt.SearchByBoW(ks[0], ds[0], fvs[0], hs[0], ks[1], ds[1], fvs[1], hs[1], bIfMPOnly=False)
+    m_ref, nm_ref = oracle.search_by_bow(ks[0], ds[0], fvs[0], hs[0], ks[1], ds[1], fvs[1], hs[1], False, 0.9, True)
+    assert nm == nm_ref and np.array_equal(m12, m_ref)
+
+
 def _feature_vector(desc, nbits):
     """Stand-in for DBoW2::FeatureVector: node = the first `nbits` descriptor bits; CSR with ascending node ids."""
     node = (desc[:, 0].astype(np.int32) | (desc[:, 1].astype(np.int32) << 8)) & ((1 << nbits) - 1)
