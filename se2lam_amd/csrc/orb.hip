@@ -773,12 +773,80 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
     if (too_many) {
         // Only the min(total, cell_cap) best by score can be retained, so everything below the score that bounds them
         // drops out before the sort: histogram of the scores, cut, second collection.  (Harris retains by another
-        // response: there the overflow stays an error.)
+        // response: a streaming selection, below.)
         __shared__ int hist[256];
         __shared__ int s_cut, s_cnt;
         if (HARRIS) {
-            if (threadIdx.x == 0) atomicOr(overflow, 1);
-            if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
+            // HARRIS_SCORE retains by another response than the one the lists are ordered by, so no score cut can thin
+            // the cell out beforehand.  Streaming selection instead: the cell's corners are taken in bands of rows that
+            // fit the sort buffer beside the K best so far (K = what the cell may retain), every band is scored with the
+            // Harris measure, merged by a sort, and the best K stay.  Exact; a cell full of corners costs a few rounds.
+            __shared__ int s_y1, s_band, s_slot, s_bad;
+            const int lo = n20 > 3 ? g.fast_th : 7;                 // the corners cv::FAST returns for the cell: S > lo
+            const int K = min(total, g.cell_cap);
+            const int budget = kSortCap - K;
+            const uint8_t* lvl = pyr + pix(g, f, l, 0, 0);
+            for (int i = threadIdx.x; i < ch; i += 256) keys[i] = 0;   // corners per row (keys[] is free in this path)
+            walk([&](int sc, uint32_t key) {
+                if (sc > lo) atomicAdd(&keys[(int)((key >> 12) & 0xfffu) - ya], 1u);
+            });
+            __syncthreads();
+            int have = 0;
+            for (int y0 = 0; y0 < ch;) {
+                if (threadIdx.x == 0) {
+                    int y1 = y0, cnt = 0;
+                    while (y1 < ch && cnt + (int)keys[y1] <= budget) cnt += (int)keys[y1++];
+                    s_y1 = y1; s_band = cnt; s_slot = 0;
+                    s_bad = (y1 == y0) ? 1 : 0;                     // one row beyond the buffer (K > 2048 and a row of > 2000 corners)
+                }
+                __syncthreads();
+                if (s_bad) {
+                    if (threadIdx.x == 0) atomicOr(overflow, 1);
+                    if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
+                    return;
+                }
+                const int y1 = s_y1, band = s_band;
+                walk([&](int sc, uint32_t key) {
+                    const int yy = (int)((key >> 12) & 0xfffu) - ya;
+                    if (sc > lo && yy >= y0 && yy < y1) {
+                        const uint32_t pos = key & 0x00ffffffu;
+                        const float rsp = harris_response(lvl, stride, (int)(pos & 0xfff), (int)(pos >> 12));
+                        uint32_t bits = __float_as_uint(rsp);
+                        bits ^= (bits >> 31) ? 0xffffffffu : 0x80000000u;   // monotone map float -> uint32
+                        keys64[have + atomicAdd(&s_slot, 1)] = ((unsigned long long)(~bits) << 32) | pos;
+                    }
+                });
+                __syncthreads();
+                const int m = have + band;
+                int np2 = 1;
+                while (np2 < m) np2 <<= 1;
+                for (int i = m + threadIdx.x; i < np2; i += 256) keys64[i] = ~0ull;
+                __syncthreads();
+                for (int k = 2; k <= np2; k <<= 1)
+                    for (int j = k >> 1; j > 0; j >>= 1) {
+                        for (int i = threadIdx.x; i < np2; i += 256) {
+                            const int ixj = i ^ j;
+                            if (ixj > i) {
+                                const unsigned long long a = keys64[i], b = keys64[ixj];
+                                const bool up = (i & k) == 0;
+                                if ((a > b) == up) { keys64[i] = b; keys64[ixj] = a; }
+                            }
+                        }
+                        __syncthreads();
+                    }
+                have = min(K, m);
+                y0 = y1;
+            }
+            uint32_t* outh = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
+            float* outhr = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
+            if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = total;
+            for (int i = threadIdx.x; i < have; i += 256) {
+                const unsigned long long k = keys64[i];
+                uint32_t bits = ~(uint32_t)(k >> 32);
+                bits ^= (bits >> 31) ? 0x80000000u : 0xffffffffu;       // inverse of the map above
+                outh[i] = (uint32_t)k;
+                outhr[i] = __uint_as_float(bits);
+            }
             return;
         }
         hist[threadIdx.x] = 0;
