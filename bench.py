@@ -401,7 +401,7 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
     across the GPUs" describes - no collective, weak scaling over ranks.  Reports aggregate LM iterations/s and the
     whole-step HBM fraction per window count."""
     from se2lam_amd import synth
-    from se2lam_amd.optimizer import SlamOptimizer, optimize_batch
+    from se2lam_amd.optimizer import SlamOptimizer, optimize_batch, reset_estimates_batch
     g = synth.ba_graph(P, L)
     B = g.algorithmic_bytes_per_iter()
     counts = [args.ba_windows] if args.ba_windows > 0 else [1, 8, 32, 64]
@@ -416,8 +416,7 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
         cur = opts[:n]
 
         def run():
-            for o in cur:
-                o.reset_estimates()
+            reset_estimates_batch(cur)      # one launch (128 one-by-one copies cost the host more than the batch costs the device)
             its = optimize_batch(cur, ITERS_PER_CALL)
             return sum(its)
 

@@ -299,6 +299,9 @@ int se2gpu_map_update_local_graph(const se2gpu_map_view* map, int current_kf, in
 int se2gpu_ba_initialize(se2gpu_ba* h);
 /* restores every vertex estimate to the value it was added with (device-to-device) */
 int se2gpu_ba_reset_estimates(se2gpu_ba* h);
+/* ... of `count` windows with one launch (the companion of se2gpu_ba_optimize_batch for a mapper that re-optimises the same
+ * windows): ordered before any later operation on each of the windows */
+int se2gpu_ba_reset_estimates_batch(se2gpu_ba** handles, int count);
 
 #define SE2GPU_BA_LM 0  /* OptimizationAlgorithmLevenberg, g2o policy (optimizer.h:32) */
 #define SE2GPU_BA_GN 1  /* plain Gauss-Newton: lambda = 0, every step accepted           */

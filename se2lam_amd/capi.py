@@ -136,6 +136,7 @@ SYMBOLS = {
     "se2gpu_sparsify_se3xyz": (_I, [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "se2gpu_ba_initialize": (_I, [_VP]),
     "se2gpu_ba_reset_estimates": (_I, [_VP]),
+    "se2gpu_ba_reset_estimates_batch": (_I, [_VP, _I]),
     "se2gpu_ba_optimize": (_I, [_VP, _I, _I, _PU8, _I, C.POINTER(BaStats)]),
     "se2gpu_ba_optimize_batch": (_I, [C.POINTER(_VP), _I, _I, _I, _PU8, C.POINTER(BaStats)]),
     "se2gpu_ba_get_se2": (_I, [_VP, _I, _PD]),

@@ -3118,6 +3118,10 @@ struct se2gpu_ba {
     std::vector<EdgeOdo> odo;
     bool initialized = false;
     unsigned long init_serial = 0;   // unique per initialize(): what a cached batch plan (ba_lockstep) was built for
+    // se2gpu_ba_reset_estimates_batch wrote this handle's estimate on ANOTHER stream: the event to wait for before the next
+    // operation on the handle's own stream (ba_join), and the stream it was recorded on
+    hipEvent_t join_event = nullptr;
+    hipStream_t join_stream = nullptr;
     // slim layout (model 0): k_reduce_rows instead of the pair plan's k_reduce2; no per-edge Y / Dg records
     bool slim = false;
     int rows_waves = 4;            // waves per workgroup of k_reduce_rows
@@ -4475,6 +4479,26 @@ int ba_upload_graph(se2gpu_ba* h) {
 // estimate buffer, lambda and whether it has anything to do from the block; "a"/"b" buffers are passed in fixed order)
 // and without (c = nullptr: explicit lambda, h->poses / h->lms are the estimate) for the synchronous entry points
 // (se2gpu_ba_chi2, the debug_* introspection).
+// work enqueued for this handle on a batch stream (se2gpu_ba_reset_estimates_batch) comes first
+inline int ba_join(se2gpu_ba* h) {
+    if (h->join_event) {
+        if (h->join_stream != h->stream) SE2_HIP(hipStreamWaitEvent(h->stream, h->join_event, 0));
+        h->join_event = nullptr;
+        h->join_stream = nullptr;
+    }
+    return SE2GPU_OK;
+}
+struct ResetItem {
+    double* dst_p; const double* src_p; unsigned np;
+    double* dst_l; const double* src_l; unsigned nl;
+};
+__global__ __launch_bounds__(256) void k_reset_batch(const ResetItem* __restrict__ items) {
+    const ResetItem it = items[blockIdx.y];
+    const unsigned stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    for (unsigned i = t0; i < it.np; i += stride) it.dst_p[i] = it.src_p[i];
+    for (unsigned i = t0; i < it.nl; i += stride) it.dst_l[i] = it.src_l[i];
+}
+
 struct Bufs {
     const BaCtl* c;
     double *pa, *pb, *la, *lb;   // estimate / trial when c == nullptr, "a" / "b" otherwise
@@ -4680,6 +4704,7 @@ __global__ void k_post_mail(const double* __restrict__ scal, volatile double* __
 // chi2 / scale of a (trial) step, synchronous form (se2gpu_ba_chi2): xp == nullptr evaluates the current state.
 // Result in h->h_scal[0..1].
 int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
+    SE2_CHECK(ba_join(h));
     hipStream_t st = h->stream;
     double* scal = h->red + (size_t)h->ld * h->ld;  // 4 trailing scalars of the fused buffer
     const bool use_mail = h->d_mail && !(h->allreduce && h->world > 1) && !h->comm;
@@ -5176,6 +5201,7 @@ int se2gpu_ba_create(se2gpu_ba** out) {
 
 void se2gpu_ba_destroy(se2gpu_ba* h) {
     if (!h) return;
+    if (h->join_event) { (void)hipEventSynchronize(h->join_event); h->join_event = nullptr; h->join_stream = nullptr; }
     if (ba_pool_enabled()) {
         (void)hipStreamSynchronize(h->stream);
         if (h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
@@ -5521,6 +5547,7 @@ int se2gpu_ba_get_se3(se2gpu_ba* h, int id, double pose12[12]) {
 // (LocalMapper::removeOutlierChi2 compares it with 25, LocalMapper.cpp:199-214)
 int se2gpu_ba_edge_chi2(se2gpu_ba* h, double* chi2, int cap) {
     SE2_REQUIRE(h && h->initialized && chi2 && h->model >= 1, SE2GPU_ERR_STATE, "edge_chi2 needs an initialised SE3 graph");
+    SE2_CHECK(ba_join(h));
     hipStream_t st = h->stream;
     if (h->model == 2) {   // EdgeSE3::chi2() of every edge of the pose graph, in the order the edges were added
         const int NE = h->pg_edges;
@@ -5641,9 +5668,66 @@ int se2gpu_ba_initialize(se2gpu_ba* h) {
 
 int se2gpu_ba_reset_estimates(se2gpu_ba* h) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "reset_estimates before initialize");
+    SE2_CHECK(ba_join(h));
     h->est_valid = false;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, (size_t)h->ps * h->P * 8, hipMemcpyDeviceToDevice, h->stream));
     if (h->L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)h->L * 8, hipMemcpyDeviceToDevice, h->stream));
+    return SE2GPU_OK;
+}
+
+// se2gpu_ba_reset_estimates of `count` windows with ONE launch (on the first window's stream - the stream a lock-step
+// se2gpu_ba_optimize_batch of the same windows runs on): 2 x count device-to-device copies enqueued one by one cost a mapper
+// that re-optimises many windows more host time than the lock-step optimisation costs the device.  Any later operation on
+// one of the windows alone is ordered behind it (ba_join).
+int se2gpu_ba_reset_estimates_batch(se2gpu_ba** hs, int count) {
+    SE2_REQUIRE(hs && count >= 0, SE2GPU_ERR_INVALID, "reset_estimates_batch: bad argument");
+    if (count == 0) return SE2GPU_OK;
+    for (int i = 0; i < count; ++i)
+        SE2_REQUIRE(hs[i] && hs[i]->initialized && hs[i]->device == hs[0]->device, SE2GPU_ERR_STATE,
+                    "reset_estimates_batch: window %d is not initialised (or lives on another device)", i);
+    struct Scratch {
+        PinBuf<ResetItem> host;
+        DevBuf<ResetItem> dev;
+        hipEvent_t ring[64] = {};
+        unsigned next = 0;
+    };
+    static thread_local Scratch* sc = nullptr;   // (never destroyed: device memory must not be freed after the runtime has shut down)
+    if (!sc) sc = new Scratch;
+    hipStream_t st = hs[0]->stream;
+    SE2_CHECK(ba_join(hs[0]));
+    // the staging buffer of the previous call may still be read by its copy: the ring's event of that call says when not
+    if (sc->next) SE2_HIP(hipEventSynchronize(sc->ring[(sc->next - 1) % 64]));
+    SE2_CHECK(sc->host.reserve((size_t)count));
+    SE2_CHECK(sc->dev.reserve((size_t)count));
+    unsigned most = 1;
+    for (int i = 0; i < count; ++i) {
+        se2gpu_ba* h = hs[i];
+        h->est_valid = false;
+        ResetItem it{h->poses, h->poses0.p, (unsigned)((size_t)h->ps * h->P), h->lms, h->lms0.p, (unsigned)(3 * (size_t)h->L)};
+        sc->host.p[i] = it;
+        most = std::max(most, std::max(it.np, it.nl));
+        // a window whose own stream still has work in flight (an optimize that has not been waited for cannot happen: the
+        // optimize entry points return after the controller has posted) is ordered first
+        if (i > 0 && h->stream != st && hipStreamQuery(h->stream) != hipSuccess) {
+            if (h->join_event) SE2_CHECK(ba_join(h));
+            hipEvent_t& e = sc->ring[sc->next++ % 64];
+            if (!e) SE2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            SE2_HIP(hipEventRecord(e, h->stream));
+            SE2_HIP(hipStreamWaitEvent(st, e, 0));
+        }
+    }
+    (void)hipGetLastError();
+    SE2_HIP(hipMemcpyAsync(sc->dev.p, sc->host.p, (size_t)count * sizeof(ResetItem), hipMemcpyHostToDevice, st));
+    const unsigned gx = std::min(64u, (most + 255) / 256);
+    hipLaunchKernelGGL(k_reset_batch, dim3(gx, (unsigned)count), dim3(256), 0, st, (const ResetItem*)sc->dev.p);
+    SE2_HIP(hipGetLastError());
+    hipEvent_t& e = sc->ring[sc->next++ % 64];
+    if (!e) SE2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SE2_HIP(hipEventRecord(e, st));
+    for (int i = 0; i < count; ++i) {
+        hs[i]->join_event = e;
+        hs[i]->join_stream = st;
+    }
     return SE2GPU_OK;
 }
 
@@ -5715,6 +5799,7 @@ double se2gpu_ba_chi2(se2gpu_ba* h) {
 
 int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, double* bs) {
     SE2_REQUIRE(h && h->initialized, SE2GPU_ERR_STATE, "debug_reduced_system before initialize");
+    SE2_CHECK(ba_join(h));
     const int n = h->D * h->P;
     SE2_CHECK(ba_linearize(h, lambda));
     SE2_CHECK(ba_reduce(h, lambda, false));
@@ -5768,6 +5853,7 @@ int se2gpu_ba_debug_solver_path(const se2gpu_ba* h) {
 
 int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok) {
     SE2_REQUIRE(h && h->initialized && x, SE2GPU_ERR_STATE, "debug_solve before initialize");
+    SE2_CHECK(ba_join(h));
     const int n = h->D * h->P;
     SE2_CHECK(ba_linearize(h, lambda));
     SE2_CHECK(ba_reduce(h, lambda, false));
@@ -5818,6 +5904,7 @@ int ba_run_begin(se2gpu_ba* h, int iters, int mode, const volatile uint8_t* stop
     SE2_REQUIRE(mode == SE2GPU_BA_LM || mode == SE2GPU_BA_GN, SE2GPU_ERR_INVALID, "unknown mode %d", mode);
     SE2_REQUIRE(h->d_mail, SE2GPU_ERR_STATE, "SE2GPU_BA_MAILBOX=0 is no longer supported: the LM controller posts its state "
                                               "through the mapped mailbox");
+    SE2_CHECK(ba_join(h));
     h->est_valid = false;
     h->run_mode = mode;
     h->run_iters = iters;
@@ -6004,7 +6091,13 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
         h->run_sync = false;
         h->run_active = true;
         *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
-        // whatever the caller enqueued on the window's own stream (se2gpu_ba_reset_estimates) comes first
+        // whatever the caller enqueued for the window comes first: a batched reset on another stream ...
+        if (h->join_event) {
+            if (h->join_stream != st) SE2_HIP(hipStreamWaitEvent(st, h->join_event, 0));
+            h->join_event = nullptr;
+            h->join_stream = nullptr;
+        }
+        // ... or work on the window's own stream (se2gpu_ba_reset_estimates)
         if (h->stream != st && hipStreamQuery(h->stream) != hipSuccess) {
             SE2_HIP(hipEventRecord(bp.events[i], h->stream));
             SE2_HIP(hipStreamWaitEvent(st, bp.events[i], 0));
@@ -6139,6 +6232,7 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
 
 static int ba_fetch_estimates(se2gpu_ba* h) {
     if (h->est_valid) return SE2GPU_OK;
+    SE2_CHECK(ba_join(h));
     const size_t np = (size_t)h->ps * h->P, nl = 3 * (size_t)h->L;
     SE2_CHECK(h->est.reserve(np + nl + 1));
     SE2_HIP(hipMemcpyAsync(h->est.p, h->poses, np * 8, hipMemcpyDeviceToHost, h->stream));

@@ -32,6 +32,13 @@ def _no_fallback(h):
         raise RuntimeError("se2gpu_ba: k_chol_tiles timed out and the handle fell back to k_chol_step")
 
 
+def reset_estimates_batch(optimizers):
+    """se2gpu_ba_reset_estimates_batch: every optimizer back to the estimates it was initialised with, one launch"""
+    n = len(optimizers)
+    hs = (C.c_void_p * n)(*[o._h for o in optimizers])
+    capi.check(capi.lib().se2gpu_ba_reset_estimates_batch(hs, n))
+
+
 def optimize_batch(optimizers, iterations: int, mode: int = 0, stop=None):
     """se2gpu_ba_optimize_batch: optimize(iterations) of several initialised SlamOptimizers at once (independent
     windows, concurrently on the device).  Fills every optimizer's .stats; returns the iteration counts."""

@@ -492,6 +492,12 @@ def test_optimize_batch_equals_one_by_one(synth):
     assert ref[2][0]["trials_hist"] == LM_REJECT_CASES[3][1]
 
 
+def _opt_initial(o):
+    """the estimates the optimizer was initialised with (reset + download on its own stream)"""
+    o.reset_estimates()
+    return o.estimates()
+
+
 def test_lockstep_batch_mixed_rejections_repeats_and_gauss_newton(synth):
     """the windows of a batch share ONE launch per stage (k_batched: blockIdx.y = window) and still decide
     for themselves - five starts that reject trials at different iterations next to windows that never do, run twice (the
@@ -516,6 +522,20 @@ def test_lockstep_batch_mixed_rejections_repeats_and_gauss_newton(synth):
                 assert n == st["iterations"] and o.stats == st
                 pp, ll = o.estimates()
                 assert np.array_equal(pp, p) and np.array_equal(ll, l)
+    # se2gpu_ba_reset_estimates_batch: one launch for all windows, ordered before whatever follows on any of them - the next
+    # batch (same stream), or a single window optimised on its own stream
+    from se2lam_amd.optimizer import reset_estimates_batch
+    reset_estimates_batch(opts)
+    optimize_batch(opts, 10, 1)
+    assert [o.stats for o in opts] == [r[0] for r in ref]       # (ref holds the Gauss-Newton runs at this point)
+    reset_estimates_batch(opts)
+    o3 = opts[3]
+    o3.optimize(10, 1)
+    assert o3.stats == ref[3][0] and np.array_equal(o3.estimates()[0], ref[3][1][0])
+    reset_estimates_batch(opts)
+    for o, (st, (p, l)) in zip(opts, ref):
+        e0 = o.estimates()                      # (joins the batch stream before the download)
+        assert np.array_equal(e0[0], _opt_initial(o)[0])
     # a shorter run on the same handles (another plan), and a stop flag raised from the start
     ref4 = []
     for g in graphs:

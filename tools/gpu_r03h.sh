@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r03h; mkdir -p $O
-timeout 900 python -m pytest tests/test_ba_gpu.py tests/test_golden.py tests/test_pipeline.py tests/test_independent_pin.py tests/test_ba3_gpu.py tests/test_pg_gpu.py tests/test_capi.py -q -x > $O/pytest_ba.log 2>&1; echo "pytest rc=$?"; tail -30 $O/pytest_ba.log
+timeout 900 python -m pytest tests/test_ba_gpu.py tests/test_concurrency.py -q -x > $O/pytest_ba.log 2>&1; echo "pytest rc=$?"; tail -30 $O/pytest_ba.log
 for nd in 1 0; do
   SE2GPU_BA_ND=$nd timeout 300 python bench.py --steps 100 --warmup 20 --no-orb --no-cpu-baseline > $O/bench_nd$nd.json 2> $O/bench_nd$nd.err
   python - <<PY
