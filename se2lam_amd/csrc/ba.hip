@@ -3122,6 +3122,7 @@ struct se2gpu_ba {
     // operation on the handle's own stream (ba_join), and the stream it was recorded on
     hipEvent_t join_event = nullptr;
     hipStream_t join_stream = nullptr;
+    bool own_pending = false;      // se2gpu_ba_reset_estimates enqueued copies on the handle's own stream that nobody has waited for
     // slim layout (model 0): k_reduce_rows instead of the pair plan's k_reduce2; no per-edge Y / Dg records
     bool slim = false;
     int rows_waves = 4;            // waves per workgroup of k_reduce_rows
@@ -5206,6 +5207,7 @@ void se2gpu_ba_destroy(se2gpu_ba* h) {
         (void)hipStreamSynchronize(h->stream);
         if (h->own_stream != h->stream) (void)hipStreamSynchronize(h->own_stream);
         (void)se2gpu_ba_clear(h);
+        h->own_pending = false;
         h->have_tbc = false;
         const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         std::memcpy(h->Rbc, I3, sizeof(I3));
@@ -5672,6 +5674,7 @@ int se2gpu_ba_reset_estimates(se2gpu_ba* h) {
     h->est_valid = false;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, (size_t)h->ps * h->P * 8, hipMemcpyDeviceToDevice, h->stream));
     if (h->L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)h->L * 8, hipMemcpyDeviceToDevice, h->stream));
+    h->own_pending = true;   // (a batch on another stream orders itself behind these copies)
     return SE2GPU_OK;
 }
 
@@ -5708,15 +5711,15 @@ int se2gpu_ba_reset_estimates_batch(se2gpu_ba** hs, int count) {
         most = std::max(most, std::max(it.np, it.nl));
         // a window whose own stream still has work in flight (an optimize that has not been waited for cannot happen: the
         // optimize entry points return after the controller has posted) is ordered first
-        if (i > 0 && h->stream != st && hipStreamQuery(h->stream) != hipSuccess) {
+        if (i > 0 && h->stream != st && h->own_pending) {
             if (h->join_event) SE2_CHECK(ba_join(h));
             hipEvent_t& e = sc->ring[sc->next++ % 64];
             if (!e) SE2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             SE2_HIP(hipEventRecord(e, h->stream));
             SE2_HIP(hipStreamWaitEvent(st, e, 0));
         }
+        h->own_pending = false;
     }
-    (void)hipGetLastError();
     SE2_HIP(hipMemcpyAsync(sc->dev.p, sc->host.p, (size_t)count * sizeof(ResetItem), hipMemcpyHostToDevice, st));
     const unsigned gx = std::min(64u, (most + 255) / 256);
     hipLaunchKernelGGL(k_reset_batch, dim3(gx, (unsigned)count), dim3(256), 0, st, (const ResetItem*)sc->dev.p);
@@ -6030,6 +6033,7 @@ int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int 
 }
 
 int ba_run_finish(se2gpu_ba* h, se2gpu_ba_stats* stats) {
+    h->own_pending = false;   // (the run was enqueued behind whatever the stream held, and it has reported back)
     BaCtl c;
     std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
     h->run_active = false;
@@ -6068,92 +6072,126 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
         for (int j = 0; j < i; ++j)
             if (hs[i] == hs[j]) return SE2GPU_OK;
     *handled = 1;
-    // the plan of the last batch of this thread is kept: a mapper (or the bench) that optimises the same windows again
-    // re-uses the argument packs on the device
-    // (a plain pointer, replaced on a miss and never destroyed at thread / process exit: its device memory must not be
-    // freed after the HIP runtime has shut down)
-    static thread_local BatchPlan* cache = nullptr;
-    auto drop = [&]() { delete cache; cache = nullptr; };
-    if (!cache || !cache->matches(hs, count, iters, mode)) {
-        if (cache) { SE2_HIP(hipStreamSynchronize(cache->stream)); drop(); }
-        cache = new BatchPlan;
-        const int rc = ba_build_batch_plan(*cache, hs, count, iters, mode);
-        if (rc != SE2GPU_OK) { drop(); return rc; }
-    }
-    BatchPlan& bp = *cache;
-    hipStream_t st = bp.stream;
-    for (int i = 0; i < count; ++i) {
-        se2gpu_ba* h = hs[i];
-        h->est_valid = false;
-        h->run_mode = mode;
-        h->run_iters = iters;
-        h->run_enqueued = 0;
-        h->run_sync = false;
-        h->run_active = true;
-        *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
-        // whatever the caller enqueued for the window comes first: a batched reset on another stream ...
-        if (h->join_event) {
-            if (h->join_stream != st) SE2_HIP(hipStreamWaitEvent(st, h->join_event, 0));
-            h->join_event = nullptr;
-            h->join_stream = nullptr;
+    // Groups: the windows are dealt to a few groups, each in lock step on a stream of its own, slot by slot in turn - while
+    // one group's dataflow solves wait on their chains (latency: the chip is nearly idle) the other groups' linearisation
+    // and reduction (bandwidth / issue bound) run beside them.  SE2GPU_BA_BATCH_GROUPS overrides (1 = one stream).
+    static const int env_groups = [] { const char* e = getenv("SE2GPU_BA_BATCH_GROUPS"); return e ? atoi(e) : 0; }();
+    int G = env_groups > 0 ? env_groups : (count >= 16 ? 2 : 1);
+    G = std::max(1, std::min(G, std::min(count, 4)));
+    // the plans of the last batches of this thread are kept: a mapper (or the bench) that optimises the same windows again
+    // re-uses the argument packs on the device (plain pointers, replaced on a miss and never destroyed at thread / process
+    // exit: their device memory must not be freed after the HIP runtime has shut down)
+    constexpr int kPlans = 4;
+    static thread_local BatchPlan* cache[kPlans] = {};
+    static thread_local unsigned long stamp[kPlans] = {}, clock = 0;
+    struct Group { BatchPlan* bp; se2gpu_ba** hs; int count; bool finished; int slot; };
+    std::vector<Group> groups(G);
+    auto acquire = [&](se2gpu_ba** ghs, int gcount, BatchPlan** out, int* slot_out, const std::vector<Group>& taken) -> int {
+        for (int k = 0; k < kPlans; ++k)
+            if (cache[k] && cache[k]->matches(ghs, gcount, iters, mode)) { stamp[k] = ++clock; *out = cache[k]; *slot_out = k; return SE2GPU_OK; }
+        int victim = -1;
+        for (int k = 0; k < kPlans; ++k) {
+            bool busy = false;
+            for (const Group& g : taken) busy |= (g.bp && g.bp == cache[k]);
+            if (busy) continue;
+            if (victim < 0 || !cache[k] || (cache[victim] && stamp[k] < stamp[victim])) victim = k;
+            if (!cache[k]) break;
         }
-        // ... or work on the window's own stream (se2gpu_ba_reset_estimates)
-        if (h->stream != st && hipStreamQuery(h->stream) != hipSuccess) {
-            SE2_HIP(hipEventRecord(bp.events[i], h->stream));
-            SE2_HIP(hipStreamWaitEvent(st, bp.events[i], 0));
-        }
+        SE2_REQUIRE(victim >= 0, SE2GPU_ERR_STATE, "optimize_batch: no plan slot");
+        if (cache[victim]) { SE2_HIP(hipStreamSynchronize(cache[victim]->stream)); delete cache[victim]; cache[victim] = nullptr; }
+        cache[victim] = new BatchPlan;
+        const int rc = ba_build_batch_plan(*cache[victim], ghs, gcount, iters, mode);
+        if (rc != SE2GPU_OK) { delete cache[victim]; cache[victim] = nullptr; return rc; }
+        stamp[victim] = ++clock;
+        *out = cache[victim];
+        *slot_out = victim;
+        return SE2GPU_OK;
+    };
+    for (int g = 0; g < G; ++g) {
+        const int b0 = (int)((long long)count * g / G), b1 = (int)((long long)count * (g + 1) / G);
+        groups[g] = Group{nullptr, hs + b0, b1 - b0, false, -1};
+        SE2_CHECK(acquire(hs + b0, b1 - b0, &groups[g].bp, &groups[g].slot, groups));
     }
-    (void)hipGetLastError();   // hipStreamQuery's hipErrorNotReady is not an error
+    // ---- prologue of every window (ba_run_begin) and the order behind whatever was enqueued for it before
+    for (Group& g : groups) {
+        hipStream_t st = g.bp->stream;
+        for (int i = 0; i < g.count; ++i) {
+            se2gpu_ba* h = g.hs[i];
+            h->est_valid = false;
+            h->run_mode = mode;
+            h->run_iters = iters;
+            h->run_enqueued = 0;
+            h->run_sync = false;
+            h->run_active = true;
+            *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
+            if (h->join_event) {   // a batched reset on another stream ...
+                if (h->join_stream != st) SE2_HIP(hipStreamWaitEvent(st, h->join_event, 0));
+                h->join_event = nullptr;
+                h->join_stream = nullptr;
+            }
+            if (h->stream != st && h->own_pending) {   // ... or copies of se2gpu_ba_reset_estimates on the window's own stream
+                SE2_HIP(hipEventRecord(g.bp->events[i], h->stream));
+                SE2_HIP(hipStreamWaitEvent(st, g.bp->events[i], 0));
+            }
+            h->own_pending = false;
+        }
+        g.bp->ctl_init.launch(g.bp->arena, st);
+    }
     const int n0 = std::max(iters, 1);
-    bp.ctl_init.launch(bp.arena, st);
-    for (int k = 0; k < n0; ++k) SE2_CHECK(ba_batch_slot(bp, k == 0, k == n0 - 1));
+    for (int k = 0; k < n0; ++k)
+        for (Group& g : groups) SE2_CHECK(ba_batch_slot(*g.bp, k == 0, k == n0 - 1));
     for (int i = 0; i < count; ++i) {
         hs[i]->dev_seq += n0;
         hs[i]->run_seq = hs[i]->dev_seq;
         hs[i]->run_enqueued = n0;
     }
-    for (;;) {
-        // every window answers the notification of the round's last slot (a finished one from end_slot's early path)
-        int more = 0;
-        for (int i = 0; i < count; ++i) {
-            se2gpu_ba* h = hs[i];
-            volatile double* mb = h->h_mail;
-            const auto t0 = std::chrono::steady_clock::now();
-            long spins = 0;
-            while (mb[kMailSeq] != h->run_seq) {
-                __builtin_ia32_pause();
-                if (stop_flag && *stop_flag)
-                    for (int j = 0; j < count; ++j) *hs[j]->h_stop = 1;
-                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+    for (int left = G; left > 0;) {
+        for (Group& g : groups) {
+            if (g.finished) continue;
+            hipStream_t st = g.bp->stream;
+            // every window answers the notification of the round's last slot (a finished one from end_slot's early path)
+            int more = 0;
+            for (int i = 0; i < g.count; ++i) {
+                se2gpu_ba* h = g.hs[i];
+                volatile double* mb = h->h_mail;
+                const auto t0 = std::chrono::steady_clock::now();
+                long spins = 0;
+                while (mb[kMailSeq] != h->run_seq) {
+                    __builtin_ia32_pause();
+                    if (stop_flag && *stop_flag)
+                        for (int j = 0; j < count; ++j) *hs[j]->h_stop = 1;
+                    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                        SE2_HIP(hipStreamSynchronize(st));
+                        SE2_REQUIRE(mb[kMailSeq] == h->run_seq, SE2GPU_ERR_HIP, "window %d of the batch never reported back", i);
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                BaCtl c;
+                std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
+                if (c.error) {
+                    // a dataflow solve timed out in this window: its group leaves the lock step and finishes window by window
+                    // on the windows' own streams with the per-column solver (ba_run_step does the switch for the failed
+                    // one; the others go on from where they stand - all their slots have been consumed)
                     SE2_HIP(hipStreamSynchronize(st));
-                    SE2_REQUIRE(mb[kMailSeq] == h->run_seq, SE2GPU_ERR_HIP, "window %d of the batch never reported back", i);
+                    delete cache[g.slot];
+                    cache[g.slot] = nullptr;
+                    g.bp = nullptr;
+                    for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(h, true, stop_flag, 0, &fin));
+                    for (int j = 0; j < g.count; ++j)
+                        if (j != i)
+                            for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(g.hs[j], true, stop_flag, 0, &fin));
+                    more = 0;
+                    break;
                 }
+                if (!c.done) more = std::max(more, std::max(1, c.iters - c.it));
             }
-            std::atomic_thread_fence(std::memory_order_acquire);
-            BaCtl c;
-            std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
-            if (c.error) {
-                // a dataflow solve timed out in this window: it leaves the batch and finishes on its own stream with the
-                // per-column solver (ba_run_step does the switch); the other windows are unaffected
-                SE2_HIP(hipStreamSynchronize(st));
-                drop();
-                for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(h, true, stop_flag, 0, &fin));
-                for (int j = 0; j < count; ++j) {
-                    if (j == i) continue;
-                    // (the rest of the batch goes on one by one from where it stands: all their slots have been consumed)
-                    for (int fin = 0; !fin;) SE2_CHECK(ba_run_step(hs[j], true, stop_flag, 0, &fin));
-                }
-                for (int j = 0; j < count; ++j) SE2_CHECK(ba_run_finish(hs[j], stats ? stats + j : nullptr));
-                return SE2GPU_OK;
+            if (!more) { g.finished = true; --left; continue; }
+            for (int k = 0; k < more; ++k) SE2_CHECK(ba_batch_slot(*g.bp, false, k == more - 1));
+            for (int i = 0; i < g.count; ++i) {
+                g.hs[i]->dev_seq += more;
+                g.hs[i]->run_seq = g.hs[i]->dev_seq;
+                g.hs[i]->run_enqueued += more;
             }
-            if (!c.done) more = std::max(more, std::max(1, c.iters - c.it));
-        }
-        if (!more) break;
-        for (int k = 0; k < more; ++k) SE2_CHECK(ba_batch_slot(bp, false, k == more - 1));
-        for (int i = 0; i < count; ++i) {
-            hs[i]->dev_seq += more;
-            hs[i]->run_seq = hs[i]->dev_seq;
-            hs[i]->run_enqueued += more;
         }
     }
     for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_finish(hs[i], stats ? stats + i : nullptr));
