@@ -1055,6 +1055,7 @@ __global__ void k_reduce_odo(int O, int ld, const int* __restrict__ o_i, const i
 // One launch per 32-wide block column (k_chol_step); replaces CHOLMOD on the (3P)^2 system.
 // ---------------------------------------------------------------------------------------------
 constexpr int kNB = 32;
+constexpr int kSlabs = 4;   // k_chol_tiles: a tile is handed on in the four 8-column slabs its waves eliminate
 
 __device__ inline double bcast_lane(double v, int lane) {  // lane must be a compile-time / wave-uniform constant
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -1288,6 +1289,12 @@ __device__ inline void store_agent1(double* p, double v) {
 // flag words with agent-scope loads that go to memory; with 361 tasks (200 key frames) or 64 windows x 35 tasks doing so
 // flat out, the polls queue in front of the publishers' stores (measured: a batch of windows solved side by side scaled at
 // 3.6 us per window instead of overlapping).
+// a flag poll that stays in flight: the caller waits for it (s_waitcnt vmcnt(0) on the result) when it has nothing better to do
+__device__ inline unsigned poll_agent(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 __device__ inline bool spin_until(const unsigned* f, unsigned epoch, bool lazy = false) {
     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
     const long long t0 = wall_clock64();  // 100 MHz
@@ -1312,8 +1319,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     const bool lazy_on = n < 0 ? false : true;   // (SE2GPU_BA_CHOL_LAZY=0 passes -n: A/B of the lazy polls)
     if (n < 0) n = -n;
-    const bool wt_all = nbc > 0;                  // (SE2GPU_BA_CHOL_WT=0 passes -nbc: early waves plain stores + fence, as before)
-    if (nbc < 0) nbc = -nbc;
     // LDS: 36 KB per task (was 59), so that more tasks share a CU when a batch of windows is solved side by side
     // (k_batched).  The multiplier columns of the elimination re-use the operand tiles of the update phase: rows 0..15
     // (waves 0, 1) lie over Tc, which nobody reads after the last tile product; rows 16..31 (waves 2, 3) reach into Ta,
@@ -1329,10 +1334,11 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     double* const DUMMY = LD + 3 * kTile + kNB * kNB;                               // where the T rows' lanes write instead
     double (*MRC)[64] = reinterpret_cast<double (*)[64]>(LD + kTile);               // multiplier column of every eliminated column
     static_assert(16 * 64 <= kTile && 32 * 64 <= 2 * kTile, "rows 0..15 of MRC lie inside Tc, all of it inside Tc | Ta");
-    __shared__ int ok_s, ready_s, loaded_s;
+    __shared__ int ok_s, ready_s, loaded_s, slab_s[kSlabs];
     __shared__ int deps_s[64];   // this task's dependency list (at most 64 tile rows): fetched once, not one global load per column
     const int tid = threadIdx.x;
-    if (tid == 0) { ready_s = 0; loaded_s = 0; }
+    if (tid == 0) { ready_s = 0; loaded_s = 0; ok_s = 1; }
+    if (tid < kSlabs) slab_s[tid] = 0;
     long long* stamp = dbg ? dbg + (size_t)bx * 16 : nullptr;  // SE2GPU_BA_CHOL_TRACE=1: 100 MHz stamps
     if (stamp && tid == 0) stamp[0] = wall_clock64();
     const int4 tk = tasks[bx];   // {tile row | kind << 16, block column, first, one past the last entry of its dependency list}
@@ -1351,8 +1357,11 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
             const int j = deps_s[dq - tk.z];
             if (tid == 0) {
                 const bool lazy = lazy_on && dq + 1 < tk.w;   // only the last term is waited for in earnest
-                bool ok = spin_until(flagR + (size_t)r * nbc + j, epoch, lazy);
-                ok = ok && spin_until((it == j ? flagR : flagA) + (size_t)it * nbc + j, epoch, lazy);
+                bool ok = true;
+                for (int sl = 0; sl < kSlabs; ++sl) {
+                    ok = ok && spin_until(flagR + ((size_t)r * nbc + j) * kSlabs + sl, epoch, lazy);
+                    ok = ok && spin_until((it == j ? flagR : flagA) + ((size_t)it * nbc + j) * kSlabs + sl, epoch, lazy);
+                }
                 ok_s = ok ? 1 : 0;
             }
             __syncthreads();
@@ -1385,7 +1394,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     const bool isDiag = !isR && i == j;
     double* own = isR ? R : A;
     double* ownM = isR ? RM : AM;
-    const int r = tid / 8, cc = (tid % 8) * 4;
     // The 32x32x32 tile products run on the matrix cores: v_mfma_f64_16x16x4_f64, wave w owns the 16x16 quadrant
     // (w >> 1, w & 1) of T and of D.  Layouts (tools/mfma_probe.hip): A[i][k]: lane = i + 16 k; B[k][j]: lane = j + 16 k;
     // D[i][j]: lane = j + 16 (i % 4), register = i / 4.
@@ -1401,41 +1409,90 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     }
     // the block columns m < j with a non-zero L(j, m), ascending (all of them for a dense system); bit 15 of an entry: the
     // task's own tile row has a non-zero tile in that column too (L(i, m) / R(r, m)), otherwise only D is updated
+    // A tile travels in the four 8-column slabs its producer's waves finish in (wave w eliminates columns 8 w .. 8 w + 7 and
+    // publishes them with a flag of their own while the later waves still work).  Wave w of this task fetches slab w of
+    // the operand tiles and stages it in LDS; every wave multiplies the slabs in ascending order as they appear there
+    // (the k-chunks in the order of the one-piece version: bit-identical sums).  A wave must not sit in a poll loop for
+    // its own slab while earlier slabs wait to be multiplied - the wave of the LAST slab would then do all eight
+    // k-chunks after the producer's last pivot -, so fetching and multiplying are two halves of one loop: the flag poll
+    // is issued, a ready slab is multiplied while the poll is in flight, then the poll is looked at.  What is left between
+    // the producer's last pivot and this task's elimination is the last slab's flag, its loads and two k-chunks.
+    const int sr = ln >> 1, sc = 8 * wv + 4 * (ln & 1);   // staging: lane = (row, half of the slab's 8 columns)
     for (int dq = tk.z; dq < tk.w; ++dq) {
         const int dep = deps_s[dq - tk.z];
         const int m = dep & 0x7fff;
         const bool hasT = (dep >> 15) != 0;
-        if (tid == 0) {
-            const bool lazy = lazy_on && dq + 1 < tk.w;       // not the block column this task's elimination waits for
-            bool ok = spin_until(flagA + (size_t)j * nbc + m, epoch, lazy);
-            if (hasT) ok = ok && spin_until((isR ? flagR : flagA) + (size_t)i * nbc + m, epoch, lazy);
-            ok_s = ok ? 1 : 0;
-        }
-        __syncthreads();  // also: everyone is done with the LDS tiles of the previous column
+        __syncthreads();  // everyone is done with the LDS tiles of the previous column
         if (!ok_s) {
             if (tid == 0) fail[0] = 1e6;
             return;
         }
-        if (stamp && tid == 0) stamp[1] = wall_clock64();
-        const size_t offj = (size_t)(kNB * j + r) * ld + kNB * m + cc;
-        const size_t offi = hasT ? (size_t)(kNB * i + r) * ld + kNB * m + cc : offj;
-        d2_t mj0 = load_agent(A + offj), mj1 = load_agent(A + offj + 2);
-        d2_t rj0 = load_agent(AM + offj), rj1 = load_agent(AM + offj + 2);
-        d2_t ri0 = load_agent((hasT ? ownM : AM) + offi), ri1 = load_agent((hasT ? ownM : AM) + offi + 2);
-        SE2_WAIT_VM6(mj0, mj1, rj0, rj1, ri0, ri1);
-        Ta[r][cc] = ri0.x; Ta[r][cc + 1] = ri0.y; Ta[r][cc + 2] = ri1.x; Ta[r][cc + 3] = ri1.y;
-        Tb[r][cc] = mj0.x; Tb[r][cc + 1] = mj0.y; Tb[r][cc + 2] = mj1.x; Tb[r][cc + 3] = mj1.y;
-        Tc[r][cc] = rj0.x; Tc[r][cc + 1] = rj0.y; Tc[r][cc + 2] = rj1.x; Tc[r][cc + 3] = rj1.y;
-        __syncthreads();
-        if (stamp && tid == 0) stamp[7] = wall_clock64();
-#pragma unroll
-        for (int ks = 0; ks < kNB / 4; ++ks) {
-            const double bv = Tb[qj + arow][4 * ks + acol];
-            accD = __builtin_amdgcn_mfma_f64_16x16x4f64(Tc[qi + arow][4 * ks + acol], bv, accD, 0, 0, 0);
-            if (hasT) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(Ta[qi + arow][4 * ks + acol], bv, accT, 0, 0, 0);
+        const bool lazy = lazy_on && dq + 1 < tk.w;       // not the block column this task's elimination waits for
+        const unsigned* f0 = flagA + ((size_t)j * nbc + m) * kSlabs + wv;
+        const unsigned* f1 = hasT ? (isR ? flagR : flagA) + ((size_t)i * nbc + m) * kSlabs + wv : f0;
+        const int need = dq - tk.z + 1;
+        bool staged = false;
+        int mult = 0;          // slabs multiplied so far
+        long long t0 = 0;
+        while (mult < kSlabs) {
+            unsigned v0 = 0, v1 = 0;
+            if (!staged) { v0 = poll_agent(f0); v1 = poll_agent(f1); }   // in flight during the products below
+            bool progress = false;
+            if (__hip_atomic_load(&slab_s[mult], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) {
+                // the slab's two k-chunks: all six operand reads in flight before the first product
+                const int k0 = 8 * mult + acol;
+                const double b0 = Tb[qj + arow][k0], b1 = Tb[qj + arow][k0 + 4];
+                const double c0 = Tc[qi + arow][k0], c1 = Tc[qi + arow][k0 + 4];
+                const double a0 = Ta[qi + arow][k0], a1 = Ta[qi + arow][k0 + 4];
+                __builtin_amdgcn_sched_barrier(0);
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(c0, b0, accD, 0, 0, 0);
+                if (hasT) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, accT, 0, 0, 0);
+                accD = __builtin_amdgcn_mfma_f64_16x16x4f64(c1, b1, accD, 0, 0, 0);
+                if (hasT) accT = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, accT, 0, 0, 0);
+                ++mult;
+                progress = true;
+            }
+            if (!staged) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) : : "memory");
+                bool here = __builtin_amdgcn_readfirstlane(v0) == epoch && __builtin_amdgcn_readfirstlane(v1) == epoch;
+                if (!here && !progress) {   // 2 s without the flag: report, and stage whatever is there so that nobody waits for this slab
+                    if (t0 == 0) t0 = wall_clock64();
+                    else if (wall_clock64() - t0 > 200000000ll) {
+                        if (ln == 0) ok_s = 0;
+                        here = true;
+                    }
+                }
+                if (here) {
+                    if (stamp && tid == 192) stamp[1] = wall_clock64();
+                    const size_t offj = (size_t)(kNB * j + sr) * ld + kNB * m + sc;
+                    const size_t offi = hasT ? (size_t)(kNB * i + sr) * ld + kNB * m + sc : offj;
+                    d2_t mj0 = load_agent(A + offj), mj1 = load_agent(A + offj + 2);
+                    d2_t rj0 = load_agent(AM + offj), rj1 = load_agent(AM + offj + 2);
+                    d2_t ri0 = load_agent((hasT ? ownM : AM) + offi), ri1 = load_agent((hasT ? ownM : AM) + offi + 2);
+                    SE2_WAIT_VM6(mj0, mj1, rj0, rj1, ri0, ri1);
+                    Ta[sr][sc] = ri0.x; Ta[sr][sc + 1] = ri0.y; Ta[sr][sc + 2] = ri1.x; Ta[sr][sc + 3] = ri1.y;
+                    Tb[sr][sc] = mj0.x; Tb[sr][sc + 1] = mj0.y; Tb[sr][sc + 2] = mj1.x; Tb[sr][sc + 3] = mj1.y;
+                    Tc[sr][sc] = rj0.x; Tc[sr][sc + 1] = rj0.y; Tc[sr][sc + 2] = rj1.x; Tc[sr][sc + 3] = rj1.y;
+                    // (LDS operations of a wave execute in issue order: the count is behind the writes)
+                    asm volatile("" ::: "memory");
+                    if (ln == 0) __hip_atomic_fetch_add(&slab_s[wv], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (stamp && tid == 192) stamp[7] = wall_clock64();
+                    staged = true;
+                    progress = true;
+                }
+            }
+            if (!progress) {
+                if (staged) __builtin_amdgcn_s_sleep(1);
+                else if (lazy) __builtin_amdgcn_s_sleep(48);
+                else __builtin_amdgcn_s_sleep(2);
+            }
         }
     }
     __syncthreads();
+    if (!ok_s) {
+        if (tid == 0) fail[0] = 1e6;
+        return;
+    }
     if (stamp && tid == 0) stamp[2] = wall_clock64();
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -1497,7 +1554,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
             for (int q = 0; q < 8; ++q) m[q] = fma(-mrv[u], cv[u][q], m[q]);
         }
     }
-    if (stamp && lane == 0) stamp[8 + w] = wall_clock64();
     // Every instruction of this wave is issued in order at ~8 clk, so the cost of a pivot column is its instruction
     // count: one Newton step on v_rcp_f64 (relative error 2e-15, used consistently for M and MR, i.e. a 2e-15 relative
     // perturbation of the pivots of an LDL^T whose rounding errors are larger), pivot test folded into one running
@@ -1548,7 +1604,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
         }
         mr_prev = mr;
     }
-    if (stamp && lane == 0) stamp[12 + w] = wall_clock64() + (long long)(m[7] == 1.2345e-300);
     // pivots must be positive and finite (pad pivots are ~1e300)
     // (the pivot row's own multiplier is pivot * inv: NaN exactly when this or an earlier pivot was NaN)
     const double chk = bcast_lane(mrs[7], cb + 7);
@@ -1568,13 +1623,8 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
                 // waves used plain stores + a fence once - hidden behind the later waves in one solve, but a fence walks
                 // the whole L2 of its XCD, and with 64 windows' tasks fencing side by side (three fences per task) the L2s
                 // did little else: the batch scaled at 3.6 us per window instead of overlapping
-                if (wt_all || w == 3) {
-                    store_agent(pm + q, d2_t{m[q], m[q + 1]});
-                    store_agent(pr + q, d2_t{mrs[q], mrs[q + 1]});
-                } else {
-                    reinterpret_cast<double2*>(pm)[q / 2] = make_double2(m[q], m[q + 1]);
-                    reinterpret_cast<double2*>(pr)[q / 2] = make_double2(mrs[q], mrs[q + 1]);
-                }
+                store_agent(pm + q, d2_t{m[q], m[q + 1]});
+                store_agent(pr + q, d2_t{mrs[q], mrs[q + 1]});
             }
         } else {
 #pragma unroll
@@ -1591,13 +1641,20 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
             if (cb + q < ncol) store_agent1(py + q, m[q]);   // y_un: read by the x tasks of this launch
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    if ((wt_all || w == 3) && ncol == kNB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have landed
-    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this wave's stores are written back from this XCD's L2
-    __syncthreads();
-    if (tid == 0)
-        __hip_atomic_store((isR || isDiag ? flagR : flagA) + (size_t)i * nbc + j, epoch, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    if (stamp && tid == 0) stamp[5] = wall_clock64();
+    unsigned* const myflag = (isR || isDiag ? flagR : flagA) + ((size_t)i * nbc + j) * kSlabs;
+    if (ncol == kNB) {
+        // slab w is this wave's alone: its write-through stores have landed -> its flag, no workgroup barrier in between
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(myflag + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (stamp && lane == 0) stamp[12 + w] = wall_clock64();
+    } else {
+        // last panel of a system that does not end on a tile boundary (plain masked stores): written back from this XCD's
+        // L2 by a release fence, all slabs flagged together
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (tid < kSlabs) __hip_atomic_store(myflag + tid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (stamp && tid == 192) stamp[5] = wall_clock64();
 }
 template <bool SEED>
 __global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
@@ -3157,7 +3214,7 @@ struct se2gpu_ba {
     DevBuf<uint8_t> solver_arena; // chol_tasks | chol_deps | pose_off | col_src
     int nsys = 0;                 // order of the (padded) system the solver factorises; D * P in natural order
     int solve_depth = 0;          // block columns on the longest dependency chain of the plan (debug)
-    DevBuf<unsigned> chol_flags;  // [2][nt][nbc] epochs
+    DevBuf<unsigned> chol_flags;  // [2][nt][nbc][kSlabs] epochs
     DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
     int chol_ntask = 0;
@@ -4453,8 +4510,8 @@ int ba_upload_graph(se2gpu_ba* h) {
             h->col_src.release();
         }
         const int nt2 = h->ld / kNB, nbc2 = (h->nsys + kNB - 1) / kNB;
-        SE2_CHECK(h->chol_flags.reserve(2 * (size_t)nt2 * nbc2));
-        SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * (size_t)nt2 * nbc2 * sizeof(unsigned), st));   // flags = 0 = "no epoch yet"
+        SE2_CHECK(h->chol_flags.reserve(2 * kSlabs * (size_t)nt2 * nbc2));
+        SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * kSlabs * (size_t)nt2 * nbc2 * sizeof(unsigned), st));   // flags = 0 = "no epoch yet"
         const char* env = getenv("SE2GPU_BA_CHOL");
         h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt2 > 64 || h->chol_fallback;
         const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
@@ -4743,10 +4800,6 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
 
 // dense pose solve: augmented S|bs (device, already all-reduced) -> xp (device).
 // `fail` = scalar slot [2] of the fused buffer: set to 1 by the factorisation on a non-positive pivot.
-inline bool chol_write_through() {
-    static const bool on = [] { const char* e = getenv("SE2GPU_BA_CHOL_WT"); return !(e && e[0] == '0'); }();
-    return on;
-}
 inline bool chol_lazy_polls() {
     static const bool on = [] { const char* e = getenv("SE2GPU_BA_CHOL_LAZY"); return !(e && e[0] == '0'); }();
     return on;
@@ -4784,7 +4837,7 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         double* AM = Rm + (size_t)ld * ld;
         double* RM = AM + (size_t)ld * ld;
         unsigned* flagA = h->chol_flags.p;
-        unsigned* flagR = flagA + (size_t)nt * nbc;
+        unsigned* flagR = flagA + kSlabs * (size_t)nt * nbc;
         // SE2GPU_BA_CHOL_FAULT=1 (tests): the first dataflow solve of a handle runs without its first task, so that every
         // other task times out - exercises the fallback to k_chol_step in ba_run_step
         static const bool fault = [] { const char* e = getenv("SE2GPU_BA_CHOL_FAULT"); return e && e[0] == '1'; }();
@@ -4792,7 +4845,7 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         h->chol_faulted = true;
         static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
         const int nk = chol_lazy_polls() ? n : -n;
-        const int nbck = chol_write_through() ? nbc : -nbc;
+        const int nbck = nbc;
         if (seed)
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
@@ -5092,10 +5145,10 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
             double* AM = Rm + (size_t)ld * ld;
             double* RM = AM + (size_t)ld * ld;
             unsigned* flagA = h->chol_flags.p;
-            unsigned* flagR = flagA + (size_t)nt * nbc;
+            unsigned* flagR = flagA + kSlabs * (size_t)nt * nbc;
             double* fail = h->red + (size_t)ld * ld + 2;
             const int nk = chol_lazy_polls() ? n : -n;
-            const int nbck = chol_write_through() ? nbc : -nbc;
+            const int nbck = nbc;
             if (bp.seed)
                 bp.chol_seed.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
                                  (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
@@ -5868,15 +5921,20 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
     SE2_HIP(hipMemcpy(&f, h->red + (size_t)h->ld * h->ld + 2, 8, hipMemcpyDeviceToHost));
     SE2_REQUIRE(f < 1e5, SE2GPU_ERR_HIP, "k_chol_tiles: a dependency spin timed out (2 s)");
     if (factor_ok) *factor_ok = !(f > 0.0);
-    if (h->chol_trace.p && !h->chol_steps) {  // task, tile row, R?, column, then stamps relative to the first in 10 ns ticks
+    if (h->chol_trace.p && !h->chol_steps) {  // task, tile row, kind, column, last dependency (-1: none), then stamps relative to the first in 10 ns ticks
         std::vector<long long> tr(16 * (size_t)h->chol_ntask);
-        std::vector<int2> tk(h->chol_ntask);
+        std::vector<int4> tk(h->chol_ntask);
         SE2_HIP(hipMemcpy(tr.data(), h->chol_trace.p, tr.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        SE2_HIP(hipMemcpy(tk.data(), h->chol_tasks.p, tk.size() * sizeof(int2), hipMemcpyDeviceToHost));
+        SE2_HIP(hipMemcpy(tk.data(), h->chol_tasks.p, tk.size() * sizeof(int4), hipMemcpyDeviceToHost));
+        int ndep = 0;
+        for (const int4& t : tk) ndep = std::max(ndep, t.w);
+        std::vector<int> dp((size_t)std::max(ndep, 1));
+        if (ndep) SE2_HIP(hipMemcpy(dp.data(), h->chol_deps.p, (size_t)ndep * sizeof(int), hipMemcpyDeviceToHost));
         long long t0 = tr[0];
         for (int t = 0; t < h->chol_ntask; ++t) t0 = std::min(t0, tr[16 * (size_t)t]);
         for (int t = 0; t < h->chol_ntask; ++t) {
-            std::fprintf(stderr, "choltrace %d %d %d %d", t, tk[t].x & 0xffff, tk[t].x >> 16, tk[t].y);
+            std::fprintf(stderr, "choltrace %d %d %d %d %d", t, tk[t].x & 0xffff, tk[t].x >> 16, tk[t].y,
+                         tk[t].w > tk[t].z ? dp[tk[t].w - 1] : -1);
             for (int q = 0; q < 6; ++q) std::fprintf(stderr, " %lld", tr[16 * (size_t)t + q] ? tr[16 * (size_t)t + q] - t0 : -1);
             std::fprintf(stderr, " %lld %lld", tr[16 * (size_t)t + 6], tr[16 * (size_t)t + 7] ? tr[16 * (size_t)t + 7] - t0 : -1);
             for (int q = 8; q < 16; ++q) std::fprintf(stderr, " %lld", tr[16 * (size_t)t + q] ? tr[16 * (size_t)t + q] - t0 : -1);

@@ -5,7 +5,6 @@ run() { timeout 120 env "$@" python bench.py --steps 200 --warmup 20 --no-orb --
 import json,sys; d=json.loads(sys.stdin.read()); print('   ', round(d['value'],1), 'it/s  chol', d['roofline']['kernels_us']['k_chol_tiles'])"; }
 for nd in 0 1; do
   echo "ND=$nd default"; run SE2GPU_BA_ND=$nd
-  echo "ND=$nd WT=0"; run SE2GPU_BA_ND=$nd SE2GPU_BA_CHOL_WT=0
   echo "ND=$nd LAZY=0"; run SE2GPU_BA_ND=$nd SE2GPU_BA_CHOL_LAZY=0
   echo "ND=$nd SEED=0"; run SE2GPU_BA_ND=$nd SE2GPU_BA_CHOL_SEED=0
   echo "ND=$nd default again"; run SE2GPU_BA_ND=$nd
