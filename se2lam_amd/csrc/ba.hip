@@ -1055,7 +1055,18 @@ __global__ void k_reduce_odo(int O, int ld, const int* __restrict__ o_i, const i
 // One launch per 32-wide block column (k_chol_step); replaces CHOLMOD on the (3P)^2 system.
 // ---------------------------------------------------------------------------------------------
 constexpr int kNB = 32;
-constexpr int kSlabs = 4;   // k_chol_tiles: a tile is handed on in the four 8-column slabs its waves eliminate
+constexpr int kSlabs = 4;
+constexpr int kSlabDoubles = 2 * kNB * 8;   // a published slab: M then MR, each 4 column pairs x 32 rows x 2 doubles
+// publish buffer of the dataflow solve: tile (kind, i, j) -> 4 slabs; kind 0 = L tiles below the diagonal, 1 = R = L^-T tiles
+__host__ __device__ inline size_t pub_tile(int kind, int i, int j, int nt, int nbc) {
+    return ((size_t)(kind * nt + i) * nbc + j) * (kSlabs * kSlabDoubles);
+}
+// the solver's work buffer: R of the column-launch solver (ld^2), or the publish buffer of the dataflow solve (nbc <= nt
+// block columns) followed by y_un (ld)
+inline size_t chol_work_doubles(int ld) {
+    const size_t nt = (size_t)ld / kNB;
+    return std::max((size_t)ld * ld, 2 * nt * nt * kSlabs * kSlabDoubles + (size_t)ld);
+}   // k_chol_tiles: a tile is handed on in the four 8-column slabs its waves eliminate
 
 __device__ inline double bcast_lane(double v, int lane) {  // lane must be a compile-time / wave-uniform constant
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -1307,8 +1318,8 @@ __device__ inline bool spin_until(const unsigned* f, unsigned epoch, bool lazy =
 }
 
 template <bool SEED>
-__device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restrict__ A, double* __restrict__ AM,
-                                                     double* __restrict__ R, double* __restrict__ RM, int ld, int n,
+__device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __restrict__ A, double* __restrict__ PUB,
+                                                     double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
                                                      const int* __restrict__ col_src,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
@@ -1319,6 +1330,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     const bool lazy_on = n < 0 ? false : true;   // (SE2GPU_BA_CHOL_LAZY=0 passes -n: A/B of the lazy polls)
     if (n < 0) n = -n;
+    const int nt = ld / kNB;
     // LDS: 36 KB per task (was 59), so that more tasks share a CU when a batch of windows is solved side by side
     // (k_batched).  The multiplier columns of the elimination re-use the operand tiles of the update phase: rows 0..15
     // (waves 0, 1) lie over Tc, which nobody reads after the last tile product; rows 16..31 (waves 2, 3) reach into Ta,
@@ -1370,8 +1382,10 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
                 return;
             }
             const int c0 = kNB * j + c4;
-            d2_t m0 = load_agent(RM + (size_t)(kNB * r + row) * ld + c0), m1 = load_agent(RM + (size_t)(kNB * r + row) * ld + c0 + 2);
-            d2_t y0 = load_agent(A + (size_t)n * ld + c0), y1 = load_agent(A + (size_t)n * ld + c0 + 2);
+            const double* rt = PUB + pub_tile(1, r, j, nt, nbc) + (c4 >> 3) * kSlabDoubles + kSlabDoubles / 2;   // MR_R(r, j), the slab of these 4 columns
+            const int p0 = (c4 & 7) >> 1;
+            d2_t m0 = load_agent(rt + (p0 * kNB + row) * 2), m1 = load_agent(rt + ((p0 + 1) * kNB + row) * 2);
+            d2_t y0 = load_agent(YU + c0), y1 = load_agent(YU + c0 + 2);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(m0), "+v"(m1), "+v"(y0), "+v"(y1) : : "memory");
             // (columns past n of the last tile: R is zero there by construction of the padded elimination, y is not read)
             if (c0 + 0 < n) acc += m0.x * y0.x;
@@ -1392,8 +1406,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     const bool isR = (tk.x >> 16) != 0;
     const int i = tk.x & 0xffff, j = tk.y;
     const bool isDiag = !isR && i == j;
-    double* own = isR ? R : A;
-    double* ownM = isR ? RM : AM;
     // The 32x32x32 tile products run on the matrix cores: v_mfma_f64_16x16x4_f64, wave w owns the 16x16 quadrant
     // (w >> 1, w & 1) of T and of D.  Layouts (tools/mfma_probe.hip): A[i][k]: lane = i + 16 k; B[k][j]: lane = j + 16 k;
     // D[i][j]: lane = j + 16 (i % 4), register = i / 4.
@@ -1464,11 +1476,13 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
                 }
                 if (here) {
                     if (stamp && tid == 192) stamp[1] = wall_clock64();
-                    const size_t offj = (size_t)(kNB * j + sr) * ld + kNB * m + sc;
-                    const size_t offi = hasT ? (size_t)(kNB * i + sr) * ld + kNB * m + sc : offj;
-                    d2_t mj0 = load_agent(A + offj), mj1 = load_agent(A + offj + 2);
-                    d2_t rj0 = load_agent(AM + offj), rj1 = load_agent(AM + offj + 2);
-                    d2_t ri0 = load_agent((hasT ? ownM : AM) + offi), ri1 = load_agent((hasT ? ownM : AM) + offi + 2);
+                    // slab wv of L(j, m) - M and MR - and of this task's own tile row in that column (MR); every load instruction
+                    // covers two runs of 512 contiguous bytes (column pair, 32 rows)
+                    const double* tj = PUB + pub_tile(0, j, m, nt, nbc) + wv * kSlabDoubles + ((2 * (ln & 1)) * kNB + sr) * 2;
+                    const double* ti = hasT ? PUB + pub_tile(isR ? 1 : 0, i, m, nt, nbc) + wv * kSlabDoubles + ((2 * (ln & 1)) * kNB + sr) * 2 : tj;
+                    d2_t mj0 = load_agent(tj), mj1 = load_agent(tj + 2 * kNB);
+                    d2_t rj0 = load_agent(tj + kSlabDoubles / 2), rj1 = load_agent(tj + kSlabDoubles / 2 + 2 * kNB);
+                    d2_t ri0 = load_agent(ti + kSlabDoubles / 2), ri1 = load_agent(ti + kSlabDoubles / 2 + 2 * kNB);
                     SE2_WAIT_VM6(mj0, mj1, rj0, rj1, ri0, ri1);
                     Ta[sr][sc] = ri0.x; Ta[sr][sc + 1] = ri0.y; Ta[sr][sc + 2] = ri1.x; Ta[sr][sc + 3] = ri1.y;
                     Tb[sr][sc] = mj0.x; Tb[sr][sc + 1] = mj0.y; Tb[sr][sc + 2] = mj1.x; Tb[sr][sc + 3] = mj1.y;
@@ -1610,62 +1624,46 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, double* __restri
     const bool bad = !(pmin > 0.0) | !(pmin < __builtin_inf()) | !(chk == chk);
     if (stamp && tid == 224) stamp[4] = wall_clock64() + (long long)(m[7] == 1.2345e-300);
     if (stamp && tid == 224) stamp[6] = clock64() - clk0;
-    // lanes 32..63 own the output rows (diagonal task: R(j,j) from the identity).  Of the diagonal tile only rows
-    // >= n (the rhs row when it lives in the last diagonal tile) are results: y_un.
+    // lanes 32..63 own the output rows (diagonal task: R(j,j) from the identity).  The tile is not written back into the
+    // matrix but into the publish buffer, slab by slab: slab w = this wave's 8 columns of M, then of MR, each as four
+    // column pairs x 32 rows x 16 bytes - one store instruction fills 512 contiguous bytes (four whole lines).  In the
+    // row-major matrix the same instruction touched 32 lines with 16 bytes each; partial-line write-through stores take
+    // longer to land, and the hand-off is a store latency, a flag latency and a load latency (tools/xcd_probe.hip: 1.7-1.9 us
+    // per hand-off with the strided pattern, 1.2-1.3 us with whole lines).
     if (lane >= kNB) {
-        const size_t off = (size_t)(kNB * i + rr) * ld + c0 + cb;
-        double* pm = (isDiag ? R : own) + off;
-        double* pr = (isDiag ? RM : ownM) + off;
-        if (ncol == kNB) {
+        double* pb = PUB + pub_tile(isR || isDiag ? 1 : 0, i, j, nt, nbc) + w * kSlabDoubles + rr * 2;
 #pragma unroll
-            for (int q = 0; q < 8; q += 2) {
-                // write-through stores for every wave: no L2 write-back (release fence) anywhere in the solve.  The early
-                // waves used plain stores + a fence once - hidden behind the later waves in one solve, but a fence walks
-                // the whole L2 of its XCD, and with 64 windows' tasks fencing side by side (three fences per task) the L2s
-                // did little else: the batch scaled at 3.6 us per window instead of overlapping
-                store_agent(pm + q, d2_t{m[q], m[q + 1]});
-                store_agent(pr + q, d2_t{mrs[q], mrs[q + 1]});
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (cb + q < ncol) {
-                    pm[q] = m[q];
-                    pr[q] = mrs[q];
-                }
+        for (int q = 0; q < 8; q += 2) {
+            // write-through stores for every wave: no L2 write-back (release fence) anywhere in the solve - a fence walks
+            // the whole L2 of its XCD, and with 64 windows' tasks fencing side by side the L2s did little else
+            store_agent(pb + q * kNB, d2_t{m[q], m[q + 1]});
+            store_agent(pb + kSlabDoubles / 2 + q * kNB, d2_t{mrs[q], mrs[q + 1]});
         }
-    } else if (isDiag && rr >= ncol) {
-        double* py = A + (size_t)(c0 + rr) * ld + c0 + cb;
+    }
+    // y_un = the rhs row after the elimination of this block column: a T row of the task in its tile row, or a row of the
+    // diagonal tile itself when the system does not end on a tile boundary; read by the x tasks of this launch
+    if (!isR && i == n / kNB && lane == (isDiag ? 0 : kNB) + n % kNB) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (cb + q < ncol) store_agent1(py + q, m[q]);   // y_un: read by the x tasks of this launch
+        for (int q = 0; q < 8; q += 2) store_agent(YU + c0 + cb + q, d2_t{m[q], m[q + 1]});
     }
     if (bad && isDiag && lane == 0) fail[0] = 1.0;
-    unsigned* const myflag = (isR || isDiag ? flagR : flagA) + ((size_t)i * nbc + j) * kSlabs;
-    if (ncol == kNB) {
-        // slab w is this wave's alone: its write-through stores have landed -> its flag, no workgroup barrier in between
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(myflag + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (stamp && lane == 0) stamp[12 + w] = wall_clock64();
-    } else {
-        // last panel of a system that does not end on a tile boundary (plain masked stores): written back from this XCD's
-        // L2 by a release fence, all slabs flagged together
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid < kSlabs) __hip_atomic_store(myflag + tid, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // slab w is this wave's alone: its write-through stores have landed -> its flag, no workgroup barrier in between
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        __hip_atomic_store((isR || isDiag ? flagR : flagA) + ((size_t)i * nbc + j) * kSlabs + w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamp && lane == 0) stamp[12 + w] = wall_clock64();
     if (stamp && tid == 192) stamp[5] = wall_clock64();
 }
 template <bool SEED>
-__global__ __launch_bounds__(256) void k_chol_tiles(double* __restrict__ A, double* __restrict__ AM,
-                                                     double* __restrict__ R, double* __restrict__ RM, int ld, int n,
+__global__ __launch_bounds__(256) void k_chol_tiles(const double* __restrict__ A, double* __restrict__ PUB,
+                                                     double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
                                                      const int* __restrict__ col_src,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
                                                      double* __restrict__ xout) {
-    d_chol_tiles<SEED>(blockIdx.x, A, AM, R, RM, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
+    d_chol_tiles<SEED>(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -4232,7 +4230,7 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->red = h->red_own.p;
     }
     if (h->host_solve) SE2_CHECK(h->h_red.reserve(nred));
-    SE2_CHECK(h->Rinv.reserve(3 * (size_t)h->ld * h->ld));  // R | AM | RM (the last two: k_chol_tiles only)
+    SE2_CHECK(h->Rinv.reserve(chol_work_doubles(h->ld)));
     // (the tile tasks of the solve are planned after the block pattern is known: ba_setup_solver, below)
     static const bool nd_env = [] { const char* e = getenv("SE2GPU_BA_ND"); return !(e && e[0] == '0'); }();
     const bool nd_possible = nd_env && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->ar_buffer &&
@@ -4499,7 +4497,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             const size_t nred2 = (size_t)h->ld * h->ld + 4;
             SE2_CHECK(h->red_own.reserve(nred2));
             h->red = h->red_own.p;
-            SE2_CHECK(h->Rinv.reserve(3 * (size_t)h->ld * h->ld));
+            SE2_CHECK(h->Rinv.reserve(chol_work_doubles(h->ld)));
             SE2_CHECK(h->xp.reserve((size_t)std::max(n, sp.nsys)));
             SE2_HIP(hipMemsetAsync(h->red, 0, nred2 * sizeof(double), st));
             hipLaunchKernelGGL(k_solver_pads, grid1((size_t)sp.nsys, 256), dim3(256), 0, st, h->red, h->ld, sp.nsys, h->col_src.p);
@@ -4834,8 +4832,7 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         SE2_LAUNCH(h->prof, st, "k_chol_apply", k_chol_apply, dim3((n + 3) / 4), dim3(256), 0, A, Rm, ld, n, h->xp.p, c,
                    (const int*)h->col_src.p);
     } else {
-        double* AM = Rm + (size_t)ld * ld;
-        double* RM = AM + (size_t)ld * ld;
+        double* YU = Rm + 2 * (size_t)nt * nbc * kSlabs * kSlabDoubles;   // behind the publish buffer
         unsigned* flagA = h->chol_flags.p;
         unsigned* flagR = flagA + kSlabs * (size_t)nt * nbc;
         // SE2GPU_BA_CHOL_FAULT=1 (tests): the first dataflow solve of a handle runs without its first task, so that every
@@ -4847,11 +4844,11 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         const int nk = chol_lazy_polls() ? n : -n;
         const int nbck = nbc;
         if (seed)
-            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, nk, nbck,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
                        fail, h->chol_trace.p, c, h->xp.p);
         else
-            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, AM, Rm, RM, ld, nk, nbck,
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, nk, nbck,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
                        fail, h->chol_trace.p, c, h->xp.p);
     }
@@ -5142,19 +5139,18 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
             const int n = h->nsys, ld = h->ld;
             const int nt = ld / kNB, nbc = (n + kNB - 1) / kNB;
             double* Rm = h->Rinv.p;
-            double* AM = Rm + (size_t)ld * ld;
-            double* RM = AM + (size_t)ld * ld;
+            double* YU = Rm + 2 * (size_t)nt * nbc * kSlabs * kSlabDoubles;
             unsigned* flagA = h->chol_flags.p;
             unsigned* flagR = flagA + kSlabs * (size_t)nt * nbc;
             double* fail = h->red + (size_t)ld * ld + 2;
             const int nk = chol_lazy_polls() ? n : -n;
             const int nbck = nbc;
             if (bp.seed)
-                bp.chol_seed.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                bp.chol_seed.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
                                  (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
                                  fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
             else
-                bp.chol_plain.add(h->chol_ntask, h->red, AM, Rm, RM, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                bp.chol_plain.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
                                   (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
                                   fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
         }
