@@ -3945,18 +3945,29 @@ void solve_plan_choose(int P, int D, const uint8_t* pat, bool allow_nd, SolvePla
             if (parts.size() > 1) consider(parts);
         }
     if (w_cyc < w_lin && w_cyc >= 1 && 2 * w_cyc + 2 * min_interior <= P) {   // ring: two separators, joined into the last partition
-        const int w = w_cyc;
-        for (int lv = 0; lv <= 2; ++lv) {
-            const int h = (P + 1) / 2;
+        const int h = (P + 1) / 2;
+        auto ring = [&](int w, int sw, int lv) {   // separators of sw >= w poses each; inner levels use the band's width
             std::vector<std::vector<int>> parts;
-            linear(w, h, w, lv, parts);
-            linear(h + w, P, w, lv, parts);
+            linear(sw, h, w, lv, parts);
+            linear(h + sw, P, w, lv, parts);
             std::vector<int> sep;
-            for (int p = 0; p < w; ++p) sep.push_back(p);
-            for (int p = h; p < std::min(h + w, P); ++p) sep.push_back(p);
+            for (int p = 0; p < sw; ++p) sep.push_back(p);
+            for (int p = h; p < std::min(h + sw, P); ++p) sep.push_back(p);
             parts.push_back(sep);
             consider(parts);
+        };
+        const int w = w_cyc;
+        for (int lv = 0; lv <= 2; ++lv) ring(w, w, lv);
+        // partitions are padded to tile boundaries, so the chain is ceil(arc / tile) + ceil(separators / tile) block columns: a few
+        // poses moved from the arcs into the separators can take a tile off the arcs without adding one to the separators
+        // (200 key frames, band 43: arcs 57 -> 52 poses = 6 -> 5 tiles, separators 86 -> 96 poses = 9 tiles either way)
+        auto tiles = [&](int poses) { return (D * poses + kNB - 1) / kNB; };
+        int sw_best = w, est_best = tiles(std::max(h - w, P - h - w)) + tiles(2 * w);
+        for (int sw = w + 1; sw <= w + kNB && 2 * sw + 2 * min_interior <= P; ++sw) {
+            const int est = tiles(std::max(h - sw, P - h - sw)) + tiles(2 * sw);
+            if (est < est_best) { est_best = est; sw_best = sw; }
         }
+        if (sw_best != w) ring(w, sw_best, 0);
     }
 }
 

@@ -111,6 +111,7 @@ def _band(P, w, ring):
     ("dense 40", 40, None),
     ("dense 11 (one tile + rhs inside it)", 10, None),
     ("ring 200 / 41", 200, _band(200, 41, True)),
+    ("ring 200 / 43 (widened separators)", 200, _band(200, 43, True)),
     ("ring 50 / 10", 50, _band(50, 10, True)),
     ("open band 120 / 12", 120, _band(120, 12, False)),
     ("open band 64 / 30 (too wide to cut)", 64, _band(64, 30, False)),
@@ -137,6 +138,10 @@ def test_nested_dissection_shortens_the_chain_of_block_columns():
     """the point of the order: fewer block columns on the longest dependency chain (7 us each on the device)"""
     nat, nd = _plan(200, 3, _band(200, 41, True), False), _plan(200, 3, _band(200, 41, True), True)
     assert nat["depth"] == nat["nbc"] == 19 and nd["depth"] <= 15 and nd["nsys"] % NB == 0
+    # the bench loop (band 43): separators widened from 43 to 48 key frames so that the arcs end on a tile boundary -
+    # 5 + 9 block columns on the chain instead of 6 + 9
+    nd = _plan(200, 3, _band(200, 43, True), True)
+    assert nd["depth"] <= 14 and nd["nsys"] == 608
     nat, nd = _plan(50, 3, _band(50, 10, True), False), _plan(50, 3, _band(50, 10, True), True)
     assert nat["depth"] == 5 and nd["depth"] <= 4
     nat, nd = _plan(120, 3, _band(120, 12, False), False), _plan(120, 3, _band(120, 12, False), True)
