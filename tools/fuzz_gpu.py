@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (not part of the test suite: it runs for as long as it is given).
-   python tools/fuzz_gpu.py [seconds] [seed]
+   python tools/fuzz_gpu.py [seconds] [seed] [kinds, comma separated]
 ORB: random image sizes / feature counts / level counts / score types, single frames and batches against the oracle.
 BA : random SE(2) windows (sizes, fixed patterns, kidnapped starts) - LM histories against the oracle.
 Prints one line per case and exits non-zero at the first mismatch."""
@@ -17,6 +17,7 @@ from se2lam_amd.optimizer import SlamOptimizer  # noqa: E402
 from se2lam_amd.orb import ORBextractor  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+KINDS = [int(k) for k in sys.argv[3].split(',')] if len(sys.argv) > 3 else list(range(11))   # e.g. 0,4,5: the three BA models only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 tex = synth.texture()
@@ -42,7 +43,7 @@ def fail(msg):
 
 while time.time() < t_end:
     ncase += 1
-    kind = ncase % 11
+    kind = KINDS[ncase % len(KINDS)]
     if kind == 2:   # MatchByWindow on feature subsets / windows / ratios, chained vbPrevMatched
         a, b = int(rng.integers(0, 30)), int(rng.integers(0, 30))
         (k1, d1), (k2, d2) = feats(a), feats(b)
@@ -273,8 +274,9 @@ while time.time() < t_end:
             if not ok:
                 sys.exit(1)
     else:
-        P = int(rng.integers(2, 70))
-        L = int(rng.integers(max(8, P), 40 * P))
+        big = rng.random() < 0.25    # loops long enough for the nested-dissection orders of the pose solve (several levels)
+        P = int(rng.integers(70, 190)) if big else int(rng.integers(2, 70))
+        L = int(rng.integers(max(8, P), (12 if big else 40) * P))
         g = synth.ba_graph(P, L, obs_per_lm=float(rng.uniform(2.5, 9.0)), seed=int(rng.integers(1, 10**6)))
         if rng.random() < 0.4:   # a start far from the optimum: rejected trials
             k = int(rng.integers(1, P))
