@@ -291,7 +291,7 @@ def main():
                                  if name in kern and "k_chol_tiles" in kern else None)   # noqa: E731
         exchange = {"what": "RCCL all-reduce (sum, f64) of the packed lower-triangular tiles of [S | b] + scalars, once per "
                             "LM trial, on the handle's stream; per-kernel pass (event pair around every call)",
-                    "doubles_per_trial": int(capi.lib().se2gpu_ba_exchange_doubles(g.P)),
+                    "doubles_per_trial": opt.exchange_doubles(),   # of the (possibly re-ordered, padded) system this handle factorises
                     "comm_ranks": int(nranks.value),
                     "allreduce_system_us": kern.get("allreduce_system", {}).get("avg_us"),
                     "allreduce_small_us": kern.get("allreduce_small", {}).get("avg_us"),

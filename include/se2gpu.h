@@ -419,6 +419,11 @@ int se2gpu_ba_edge_information(int E, const float* lc, const float* lw, const in
 typedef int (*se2gpu_allreduce_fn)(void* dev_ptr, size_t count_doubles, void* hip_stream, void* user);
 size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba* h, int P);
 size_t se2gpu_ba_exchange_doubles(int P);
+/* The same for an initialised handle: when the library re-orders the poses for the dense solve (nested dissection, padded
+ * partitions - every rank of a sharded run chooses the same order from the merged block pattern, one extra small
+ * all-reduce inside initialize) the packed exchange has the rows of THAT system; equal to se2gpu_ba_exchange_doubles(P)
+ * in the natural order.  0 before initialize. */
+size_t se2gpu_ba_exchange_doubles_h(const se2gpu_ba* h);
 int se2gpu_ba_exchange_row(int row, size_t* offset, int* length);
 int se2gpu_ba_set_allreduce(se2gpu_ba* h, se2gpu_allreduce_fn fn, void* user, void* buffer);
 /* This handle holds landmark shard `rank` of `world` (rank 0 owns the odometry edges and the

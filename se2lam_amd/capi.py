@@ -160,6 +160,7 @@ SYMBOLS = {
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se2gpu_ba_reduce_buffer_doubles": (_SZ, [_VP, _I]),
     "se2gpu_ba_exchange_doubles": (_SZ, [_I]),
+    "se2gpu_ba_exchange_doubles_h": (_SZ, [_VP]),
     "se2gpu_ba_exchange_row": (_I, [_I, C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "se2gpu_ba_set_allreduce": (_I, [_VP, ALLREDUCE_FN, _VP, _VP]),
     "se2gpu_ba_set_shard": (_I, [_VP, _I, _I]),

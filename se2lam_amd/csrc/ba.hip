@@ -3208,6 +3208,7 @@ struct se2gpu_ba {
     DevBuf<int> col_src;          // system column -> 3 * pose + component, -1 = padding (nullptr = identity)
     std::vector<int> h_pose_off;  // host copy (debug_reduced_system gathers S back into pose order)
     DevBuf<uint8_t> plan_nz;      // per block of the upper triangle: structurally non-zero (k_plan_pattern)
+    DevBuf<double> plan_nzd;      // the same as doubles: what a sharded run's all-reduce can merge
     PinBuf<uint8_t> h_plan_nz;
     DevBuf<uint8_t> solver_arena; // chol_tasks | chol_deps | pose_off | col_src
     int nsys = 0;                 // order of the (padded) system the solver factorises; D * P in natural order
@@ -3688,6 +3689,13 @@ __global__ void k_plan_pattern(int nblk, const int* __restrict__ blk_ptr, const 
 }
 // identity on the diagonal of the padding columns of a permuted system (set once: neither k_reduce2 nor the in-place
 // factorisation ever writes anything but zero into padding rows / columns)
+// block pattern <-> doubles (dir 0: widen, 1: narrow "any rank has it")
+__global__ void k_pattern_widen(int n, uint8_t* __restrict__ nz, double* __restrict__ d, int dir) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (dir == 0) d[i] = nz[i] ? 1.0 : 0.0;
+    else nz[i] = d[i] > 0.5 ? 1 : 0;
+}
 __global__ void k_solver_pads(double* __restrict__ S, int ld, int nsys, const int* __restrict__ col_src) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < nsys && col_src[c] < 0) S[(size_t)c * ld + c] = 1.0;
@@ -3982,6 +3990,8 @@ int ba_copy_stream(int device, hipStream_t* out) {
     return SE2GPU_OK;
 }
 
+int ba_allreduce(se2gpu_ba* h, double* ptr, size_t count);
+
 int ba_upload_graph(se2gpu_ba* h) {
     static const bool trace = [] { const char* e = getenv("SE2GPU_BA_INIT_TRACE"); return e && e[0] == '1'; }();
     const auto t_begin = std::chrono::steady_clock::now();
@@ -4244,8 +4254,12 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_CHECK(h->Rinv.reserve(chol_work_doubles(h->ld)));
     // (the tile tasks of the solve are planned after the block pattern is known: ba_setup_solver, below)
     static const bool nd_env = [] { const char* e = getenv("SE2GPU_BA_ND"); return !(e && e[0] == '0'); }();
-    const bool nd_possible = nd_env && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->ar_buffer &&
-                             D * P >= 4 * kNB && P <= 1024;
+    // (a sharded run can re-order too: every rank must choose the SAME order, so the ranks' block patterns - each sees its own
+    // landmarks' pairs only - are merged by one small all-reduce below; a caller-owned exchange buffer keeps the natural
+    // layout it was sized for)
+    const bool nd_sharded = h->allreduce && h->world > 1;
+    const bool nd_possible = nd_env && h->model == 0 && !h->host_solve && !h->ar_buffer && D * P >= 4 * kNB && P <= 1024 &&
+                             (!nd_sharded || device_plan);
     // last in the arena: the measurements and information matrices (copied on their own stream, see below; with a local
     // graph loaded through se2gpu_ba_load_local_graph the information is evaluated on the device and not copied at all)
     const size_t big_off = staged_bytes;
@@ -4404,6 +4418,13 @@ int ba_upload_graph(se2gpu_ba* h) {
             SE2_CHECK(h->h_plan_nz.reserve((size_t)nblk));
             hipLaunchKernelGGL(k_plan_pattern, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->blk_ptr.p, h->blk_odo.p,
                                h->plan_nz.p);
+            if (nd_sharded) {   // the union of the ranks' patterns: widen to doubles, the run's all-reduce, narrow again
+                SE2_CHECK(h->plan_nzd.reserve((size_t)nblk));
+                hipLaunchKernelGGL(k_pattern_widen, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->plan_nz.p, h->plan_nzd.p, 0);
+                SE2_HIP(hipGetLastError());
+                SE2_CHECK(ba_allreduce(h, h->plan_nzd.p, (size_t)nblk));
+                hipLaunchKernelGGL(k_pattern_widen, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->plan_nz.p, h->plan_nzd.p, 1);
+            }
             SE2_HIP(hipMemcpyAsync(h->h_plan_nz.p, h->plan_nz.p, (size_t)nblk, hipMemcpyDeviceToHost, st));
         }
         lap("plan kernels enqueued");
@@ -4724,7 +4745,7 @@ __global__ __launch_bounds__(256) void k_tri_pack(const double* __restrict__ A, 
 }
 int ba_allreduce_system(se2gpu_ba* h) {
     if (!h->allreduce) return SE2GPU_OK;
-    const int n = h->D * h->P, rows = n + 1;
+    const int n = h->nsys, rows = n + 1;   // (nsys > D * P when the poses were re-ordered into padded partitions)
     // a caller-owned exchange buffer (se2gpu_ba_set_allreduce with `buffer`) can only be reduced where it is, and the host
     // solve reads whole rows: the rectangle then
     if (h->ar_buffer || h->host_solve) return ba_allreduce(h, h->red, (size_t)rows * h->ld);
@@ -5801,6 +5822,7 @@ size_t se2gpu_ba_reduce_buffer_doubles(se2gpu_ba*, int P) {
 }
 
 size_t se2gpu_ba_exchange_doubles(int P) { return tri_row_off(3 * P + 1); }
+size_t se2gpu_ba_exchange_doubles_h(const se2gpu_ba* h) { return (h && h->initialized) ? tri_row_off(h->nsys + 1) : 0; }
 
 int se2gpu_ba_exchange_row(int row, size_t* offset, int* length) {
     SE2_REQUIRE(row >= 0 && offset && length, SE2GPU_ERR_INVALID, "exchange_row: bad argument");

@@ -91,6 +91,10 @@ class SlamOptimizer:
         _no_fallback(self._h)
         return st.iterations
 
+    def exchange_doubles(self) -> int:
+        """se2gpu_ba_exchange_doubles_h: size of the packed system exchange of this (initialised) handle"""
+        return int(capi.lib().se2gpu_ba_exchange_doubles_h(self._h))
+
     def solver_path(self) -> int:
         """se2gpu_ba_debug_solver_path: 0 dataflow, 1 column launches (configured), 2 column launches (fallback), 3 host"""
         return int(capi.lib().se2gpu_ba_debug_solver_path(self._h))

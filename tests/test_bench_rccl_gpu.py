@@ -31,7 +31,9 @@ def test_bench_sharded_path_with_a_one_rank_rccl_communicator(synth):
     # the exchange is broken out: the packed lower triangle, timed in the per-kernel pass
     ex = d["exchange"]
     from se2lam_amd import capi
-    assert ex["doubles_per_trial"] == capi.lib().se2gpu_ba_exchange_doubles(50) < (3 * 50 + 1) * 160
+    # (the packed triangle of the system the handle factorises: the natural order's size, or a little more when the poses
+    # were re-ordered into padded partitions - always less than the rectangle [S; b^T])
+    assert capi.lib().se2gpu_ba_exchange_doubles(50) <= ex["doubles_per_trial"] < (3 * 50 + 1) * 160
     assert ex["comm_ranks"] == 1                   # ncclCommCount of the communicator bench.py created
     assert d["timed_s"] >= 0.1                      # the timed-region floor is enforced, whatever --steps says
     assert ex["allreduce_system_us"] > 0 and ex["pack_unpack_us"] > 0 and ex["allreduce_us_per_iteration"] > 0
