@@ -654,8 +654,13 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                 if (od >= 0) {  // PreEdgeSE2 between a and b: A^T W B (transposed when the edge runs b -> a)
                     double e[3], A[9], B[9], WA[9], WB[9], omr[3];
                     odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, od >> 1, e, A, B, WA, WB, omr);
+                    // (no dynamic index into the private arrays: that would put them - and a scratch segment - into memory)
                     const int rr = (od & 1) ? c : r, cc = (od & 1) ? r : c;
-                    out += A[rr] * WB[cc] + A[3 + rr] * WB[3 + cc] + A[6 + rr] * WB[6 + cc];
+                    const double a0 = rr == 0 ? A[0] : (rr == 1 ? A[1] : A[2]), a1 = rr == 0 ? A[3] : (rr == 1 ? A[4] : A[5]),
+                                 a2 = rr == 0 ? A[6] : (rr == 1 ? A[7] : A[8]);
+                    const double b0 = cc == 0 ? WB[0] : (cc == 1 ? WB[1] : WB[2]), b1 = cc == 0 ? WB[3] : (cc == 1 ? WB[4] : WB[5]),
+                                 b2 = cc == 0 ? WB[6] : (cc == 1 ? WB[7] : WB[8]);
+                    out += a0 * b0 + a1 * b1 + a2 * b2;
                 }
             }
             const int ca = pose_off ? pose_off[a] : 3 * a, cb = pose_off ? pose_off[b] : 3 * b;
@@ -686,10 +691,13 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
         const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
         double e[3], A[9], B[9], WA[9], WB[9], omr[3];
         odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
-        const double* J = isj ? B : A;
-        const double* WJ = isj ? WB : WA;
+        double J[9], WJ[9];   // (element-wise selects: a pointer to one of two private arrays would put both into scratch memory)
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) { J[t9] = isj ? B[t9] : A[t9]; WJ[t9] = isj ? WB[t9] : WA[t9]; }
         double* o = odoc[threadIdx.x - (kBlock - 8)];
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
+#pragma unroll
             for (int c = 0; c < 3; ++c) o[r * 3 + c] = J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
             o[9 + r] = J[r] * omr[0] + J[3 + r] * omr[1] + J[6 + r] * omr[2];
         }
@@ -738,15 +746,18 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
             const int k = podo_item[t] >> 1, isj = podo_item[t] & 1;
             double e[3], A[9], B[9], WA[9], WB[9], omr[3];
             odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
-            const double* J = isj ? B : A;
-            const double* WJ = isj ? WB : WA;
-            if (i < 9) {
-                const int r = i / 3, c = i - 3 * r;
-                v += J[r] * WJ[c] + J[3 + r] * WJ[3 + c] + J[6 + r] * WJ[6 + c];
-            } else {
-                const int r = i - 9;
-                v += J[r] * omr[0] + J[3 + r] * omr[1] + J[6 + r] * omr[2];
+            // (selects, no pointers or dynamic indices into the private arrays: they would live in scratch memory, and the
+            // kernel would need a scratch segment for a tail that practically never runs)
+            const int r = i < 9 ? i / 3 : i - 9, c = i < 9 ? i - 3 * (i / 3) : 0;
+            double jr[3], wc[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const double j0 = isj ? B[3 * q] : A[3 * q], j1 = isj ? B[3 * q + 1] : A[3 * q + 1], j2 = isj ? B[3 * q + 2] : A[3 * q + 2];
+                const double w0 = isj ? WB[3 * q] : WA[3 * q], w1 = isj ? WB[3 * q + 1] : WA[3 * q + 1], w2 = isj ? WB[3 * q + 2] : WA[3 * q + 2];
+                jr[q] = r == 0 ? j0 : (r == 1 ? j1 : j2);
+                wc[q] = i < 9 ? (c == 0 ? w0 : (c == 1 ? w1 : w2)) : omr[q];
             }
+            v += jr[0] * wc[0] + jr[1] * wc[1] + jr[2] * wc[2];
         }
         if (i < 9) {
             const int r = i / 3, c = i - 3 * r;
