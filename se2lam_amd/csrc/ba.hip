@@ -2419,7 +2419,7 @@ __global__ __launch_bounds__(kBlock) void k3_schur_lm(int L, double lambda, cons
 // EdgeSE3ExpmapPrior (e = log(M T^-1), Jacobian -I: H += Omega, b += Omega e) and the blocks of every EdgeSE3Expmap
 // (e = log(T_j^-1 C T_i), J_i = adj(T_j^-1 C), J_j = -adj(T_i^-1 C^-1)): Oii, Ojj, Oij (6x6), obi, obj (6).
 // One thread per pose, then one thread per odometry edge.
-__global__ void k3_terms(int P, int O, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+__global__ __launch_bounds__(64) void k3_terms(int P, int O, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
                          const uint8_t* __restrict__ prior_has, const double* __restrict__ prior_meas,
                          const double* __restrict__ prior_info, double* __restrict__ pb, const int* __restrict__ o_i,
                          const int* __restrict__ o_j, const double* __restrict__ o_meas, const double* __restrict__ o_info,
@@ -2845,7 +2845,7 @@ __device__ inline void jtwe6(const double* Ja, const double* W, const double* e,
     for (int r = 0; r < 6; ++r) { double v = 0; for (int q = 0; q < 6; ++q) v += Ja[6 * q + r] * We[q]; out[r] -= v; }
 }
 
-__global__ void k4_terms(int P, int nslot, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
+__global__ __launch_bounds__(64) void k4_terms(int P, int nslot, const double* __restrict__ poses, const uint8_t* __restrict__ fixed,
                          const uint8_t* __restrict__ prior_has, const double* __restrict__ prior_meas,
                          const double* __restrict__ prior_info, double* __restrict__ ph, double* __restrict__ pb,
                          const int* __restrict__ slot_a, const int* __restrict__ slot_ptr, const int* __restrict__ e_i,
