@@ -408,7 +408,7 @@ __global__ void k_odometry(int O, const int* __restrict__ o_i, const int* __rest
 // k_pose_reduce: one wave per pose.  Hpp (3x3 row-major, full) and bp (3) = sum over the pose's observation edges
 // (CSR pose_ptr / pose_edges) + its odometry edges (CSR podo_ptr / podo_item: item = 2*k + (pose is j ? 1 : 0)).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void d_pose_reduce(const unsigned bx, int P, const int* __restrict__ pose_ptr,
+__device__ __forceinline__ double d_pose_reduce_max(const unsigned bx, int P, const int* __restrict__ pose_ptr,
                                                          const int* __restrict__ pose_edges,
                                                          const double* __restrict__ Hpp_e,
                                                          const double* __restrict__ bp_e,
@@ -419,7 +419,7 @@ __device__ __forceinline__ void d_pose_reduce(const unsigned bx, int P, const in
                                                          double* __restrict__ Hpp, double* __restrict__ bp) {
     const int p = bx * (kBlock / 64) + threadIdx.x / 64;
     const int lane = threadIdx.x & 63;
-    if (p >= P) return;
+    if (p >= P) return 0.0;
     double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     for (int t = pose_ptr[p] + lane; t < pose_ptr[p + 1]; t += 64) {
         const int e = pose_edges[t];
@@ -443,7 +443,17 @@ __device__ __forceinline__ void d_pose_reduce(const unsigned bx, int P, const in
         }
         for (int i = 0; i < 9; ++i) Hpp[(size_t)p * 9 + i] = H[i];
         for (int i = 0; i < 3; ++i) bp[(size_t)p * 3 + i] = b[i];
+        return fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));   // lane 0: the block's largest diagonal entry (lambda_0)
     }
+    return 0.0;
+}
+__device__ __forceinline__ void d_pose_reduce(const unsigned bx, int P, const int* __restrict__ pose_ptr,
+                                              const int* __restrict__ pose_edges, const double* __restrict__ Hpp_e,
+                                              const double* __restrict__ bp_e, const int* __restrict__ podo_ptr,
+                                              const int* __restrict__ podo_item, const double* __restrict__ Oii,
+                                              const double* __restrict__ Ojj, const double* __restrict__ obi,
+                                              const double* __restrict__ obj, double* __restrict__ Hpp, double* __restrict__ bp) {
+    (void)d_pose_reduce_max(bx, P, pose_ptr, pose_edges, Hpp_e, bp_e, podo_ptr, podo_item, Oii, Ojj, obi, obj, Hpp, bp);
 }
 __global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __restrict__ pose_ptr,
                                                          const int* __restrict__ pose_edges,
@@ -455,6 +465,59 @@ __global__ __launch_bounds__(kBlock) void k_pose_reduce(int P, const int* __rest
                                                          const double* __restrict__ obi, const double* __restrict__ obj,
                                                          double* __restrict__ Hpp, double* __restrict__ bp) {
     d_pose_reduce(blockIdx.x, P, pose_ptr, pose_edges, Hpp_e, bp_e, podo_ptr, podo_item, Oii, Ojj, obi, obj, Hpp, bp);
+}
+
+// k_pose_reduce and k_maxdiag in one launch (single GPU, first trial of an optimize()): the pose blocks by the first
+// workgroups, the landmark diagonals by the others, every workgroup folds its maximum into one word with an atomic
+// maximum on the bit pattern (non-negative doubles order like their bits; a maximum is exact whatever the order), and the
+// workgroup that arrives last sets lambda_0 = 1e-5 * max.  One launch and 13 us less in front of the first Schur step.
+constexpr int kL0PerBlock = 8 * kBlock;   // landmarks per workgroup of the landmark part
+__global__ __launch_bounds__(kBlock) void k_lambda0(int P, const int* __restrict__ pose_ptr, const int* __restrict__ pose_edges,
+                                                     const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
+                                                     const int* __restrict__ podo_ptr, const int* __restrict__ podo_item,
+                                                     const double* __restrict__ Oii, const double* __restrict__ Ojj,
+                                                     const double* __restrict__ obi, const double* __restrict__ obj,
+                                                     double* __restrict__ Hpp, double* __restrict__ bp,
+                                                     const uint8_t* __restrict__ fixed, int L, const double* __restrict__ Hll,
+                                                     unsigned long long* __restrict__ acc, double* __restrict__ out,
+                                                     BaCtl* __restrict__ ctl) {
+    __shared__ double sm[kBlock / 64];
+    const int nP = (P + kBlock / 64 - 1) / (kBlock / 64), nL = (L + kL0PerBlock - 1) / kL0PerBlock;
+    double m = 0.0;
+    if ((int)blockIdx.x < nP) {
+        const double dm = d_pose_reduce_max(blockIdx.x, P, pose_ptr, pose_edges, Hpp_e, bp_e, podo_ptr, podo_item, Oii, Ojj, obi, obj, Hpp, bp);
+        const int p = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+        if ((threadIdx.x & 63) == 0 && p < P && !fixed[p]) m = dm;
+    } else {
+        const int i0 = ((int)blockIdx.x - nP) * kL0PerBlock + (int)threadIdx.x;
+        double v[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {   // eight landmarks' diagonals in flight per thread
+            const size_t i = (size_t)min(i0 + u * kBlock, L - 1);
+            v[u][0] = Hll[i * 6 + 0]; v[u][1] = Hll[i * 6 + 3]; v[u][2] = Hll[i * 6 + 5];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * kBlock < L) m = fmax(m, fmax(fabs(v[u][0]), fmax(fabs(v[u][1]), fabs(v[u][2]))));
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmax(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = fmax(m, sm[w]);
+        if (m > 0.0) atomicMax(acc, (unsigned long long)__double_as_longlong(m));
+        __threadfence();
+        const unsigned long long arrived = atomicAdd(acc + 1, 1ull);
+        if (arrived == (unsigned long long)(nP + nL) - 1ull) {   // the last workgroup: everybody's maximum is in
+            __threadfence();
+            const double mm = __longlong_as_double((long long)atomicExch(acc, 0ull));   // (and the words are clear for the next run)
+            atomicExch(acc + 1, 0ull);
+            out[0] = mm;
+            ctl->lambda = 1e-5 * mm;
+            ctl->ni = 2;
+        }
+    }
 }
 
 // max |diag| over a strided array (computeLambdaInit); single block, deterministic.
@@ -3227,6 +3290,7 @@ struct se2gpu_ba {
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc][kSlabs] epochs
     DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
+    DevBuf<unsigned long long> l0_acc;   // k_lambda0: {max |diag H| as bits, workgroups arrived}; left at zero by every run
     int chol_ntask = 0;
     // optimize(n) as ONE hipGraph launch: captured the second time the same (iterations, mode) is asked of an initialised
     // handle (a one-shot localBA never pays for the capture), replayed from then on.  Nothing in the slot sequence changes
@@ -4470,6 +4534,8 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     SE2_CHECK(h->fin_counter.reserve(1));
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
+    SE2_CHECK(h->l0_acc.reserve(2));
+    SE2_HIP(hipMemsetAsync(h->l0_acc.p, 0, 2 * sizeof(unsigned long long), st));
     // the handle's device-side counters start over with the graph
     SE2_HIP(hipMemsetAsync(h->ctl.p, 0, sizeof(BaCtl), st));
     h->dev_seq = 0;
@@ -4660,7 +4726,7 @@ int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
 
 // the estimate's pose buffer as a host-known pointer (only valid between optimize() calls / in synchronous mode)
 // un-reduced pose blocks Hpp / bp (only needed for lambda_0 = 1e-5 max diag H and by the odometry fallback)
-int ba_pose_blocks(se2gpu_ba* h, const double* poses, bool ctl = false) {
+int ba_pose_blocks(se2gpu_ba* h, const double* poses, bool ctl = false, bool odometry_only = false) {
     hipStream_t st = h->stream;
     if (h->O) {
         // with the device-side controller the estimate's buffer is the controller's to name (a captured graph must not
@@ -4674,9 +4740,10 @@ int ba_pose_blocks(se2gpu_ba* h, const double* poses, bool ctl = false) {
                        h->o_meas.p, h->o_info.p, poses, h->fixed.p, h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p,
                        (const BaCtl*)nullptr, (const double*)nullptr);
     }
-    SE2_LAUNCH(h->prof, st, "k_pose_reduce", k_pose_reduce, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
-               h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p,
-               h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
+    if (!odometry_only)   // (k_lambda0 does the pose blocks itself)
+        SE2_LAUNCH(h->prof, st, "k_pose_reduce", k_pose_reduce, grid1((size_t)h->P * 64, kBlock), dim3(kBlock), 0, h->P,
+                   h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p,
+                   h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -4918,15 +4985,18 @@ int ba_lambda_init(se2gpu_ba* h) {
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
-    SE2_CHECK(ba_pose_blocks(h, h->poses, true));
     const bool sharded = h->allreduce && h->world > 1;
     const size_t nd = 3 * (size_t)h->P;
-    if (!sharded) {   // one launch: pose diagonals straight from the blocks, lambda_0 set by the same kernel
-        SE2_LAUNCH(h->prof, st, "k_maxdiag", k_maxdiag, dim3(1), dim3(1024), 0, h->L, h->Hll.p, h->P, h->Hpp.p, h->fixed.p,
-                   h->scal.p, 3, 1, h->ctl.p);
+    if (!sharded) {   // the pose blocks and the maximum over their and the landmarks' diagonals in one launch, lambda_0 set by it
+        SE2_CHECK(ba_pose_blocks(h, h->poses, true, /*odometry_only=*/true));
+        const int nP = (h->P + kBlock / 64 - 1) / (kBlock / 64), nL = (h->L + kL0PerBlock - 1) / kL0PerBlock;
+        SE2_LAUNCH(h->prof, st, "k_lambda0", k_lambda0, dim3(nP + nL), dim3(kBlock), 0, h->P, h->pose_ptr.p, h->pose_edges.p,
+                   h->Hpp_e.p, h->bp_e.p, h->podo_ptr.p, h->podo_item.p, h->Oii.p, h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p,
+                   h->bp.p, h->fixed.p, h->L, h->Hll.p, h->l0_acc.p, h->scal.p, h->ctl.p);
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
+    SE2_CHECK(ba_pose_blocks(h, h->poses, true));
     SE2_LAUNCH(h->prof, st, "k_extract_diag", k_extract_diag, grid1((size_t)h->P * 3, 256), dim3(256), 0, h->P,
                h->Hpp.p, h->diag3.p);
     if (sharded) {
