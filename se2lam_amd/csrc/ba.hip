@@ -6276,7 +6276,10 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
             if (!cache[k]) break;
         }
         SE2_REQUIRE(victim >= 0, SE2GPU_ERR_STATE, "optimize_batch: no plan slot");
-        if (cache[victim]) { SE2_HIP(hipStreamSynchronize(cache[victim]->stream)); delete cache[victim]; cache[victim] = nullptr; }
+        // (no stream call on the evicted plan: its stream is its first window's, and that window may have been destroyed - with
+        // its stream - since the plan was used; a stale hipStream_t handed to the runtime is a rare segmentation fault.  The plan
+        // is idle anyway: every batch waits for the last slot of all of its windows before it returns.)
+        if (cache[victim]) { delete cache[victim]; cache[victim] = nullptr; }
         cache[victim] = new BatchPlan;
         const int rc = ba_build_batch_plan(*cache[victim], ghs, gcount, iters, mode);
         if (rc != SE2GPU_OK) { delete cache[victim]; cache[victim] = nullptr; return rc; }
