@@ -558,6 +558,27 @@ def test_lockstep_batch_mixed_rejections_repeats_and_gauss_newton(synth):
     assert its == [0] * len(opts) and all(o.stats["stopped"] for o in opts)
 
 
+def test_batch_plans_outlive_their_windows(synth):
+    """the lock-step driver keeps the argument packs of its last four batches per thread; a plan is evicted long after the
+    windows it was built for - and their streams - have been destroyed (more windows than the handle pool parks).  Seven
+    batches of six fresh windows each, with different shapes, run through that eviction; every batch still equals the
+    one-by-one runs.  (The eviction used to synchronise the evicted plan's stream - the stream of a destroyed window.)"""
+    import gc
+    from se2lam_amd.optimizer import optimize_batch
+    for round_, iters in enumerate((3, 5, 2, 4, 6, 3, 2)):
+        graphs = [synth.ba_graph(9 + round_ + k, 70 + 10 * k, seed=50 + 7 * round_ + k) for k in range(6)]
+        ref = []
+        for g in graphs:
+            o = _opt(g)
+            o.optimize(iters)
+            ref.append(o.stats)
+        opts = [_opt(g) for g in graphs]
+        optimize_batch(opts, iters)
+        assert [o.stats for o in opts] == ref
+        del opts, o
+        gc.collect()           # six destroys: four handles are parked, two (the batch's first windows) really freed
+
+
 def test_force_stop_flag_and_synchronous_controller(synth):
     """setForceStopFlag (LocalMapper.cpp:246): a flag that is already set leaves the estimate untouched and reports
     `stopped`; the synchronous controller (SE2GPU_BA_SYNC=1 semantics are the same code path as verbose) agrees with the
