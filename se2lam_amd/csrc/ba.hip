@@ -6254,7 +6254,7 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
     // one group's dataflow solves wait on their chains (latency: the chip is nearly idle) the other groups' linearisation
     // and reduction (bandwidth / issue bound) run beside them.  SE2GPU_BA_BATCH_GROUPS overrides (1 = one stream).
     static const int env_groups = [] { const char* e = getenv("SE2GPU_BA_BATCH_GROUPS"); return e ? atoi(e) : 0; }();
-    int G = env_groups > 0 ? env_groups : (count >= 16 ? 2 : 1);
+    int G = env_groups > 0 ? env_groups : (count >= 4 ? 2 : 1);   // (two groups pay from four windows on: 4 / 8 / 12 windows +4 / +12 / +9 %)
     G = std::max(1, std::min(G, std::min(count, 4)));
     // the plans of the last batches of this thread are kept: a mapper (or the bench) that optimises the same windows again
     // re-uses the argument packs on the device (plain pointers, replaced on a miss and never destroyed at thread / process
