@@ -175,7 +175,9 @@ __global__ __launch_bounds__(256) void k_resize(Geom g, int l, ResizeTab t, uint
     const int H = g.h[l], stride = g.stride[l], rows = H + 2 * kEdge;
     const int ctiles = (t.ngroups + 63) / 64;
     const int xg = (bx % ctiles) * 64 + (int)(threadIdx.x & 63);
-    const int Y0 = ((bx / ctiles) * 4 + (int)(threadIdx.x >> 6)) * kResizeRows;
+    // (the row band is the wave's: told to the compiler, the y table entries become scalar loads - one level less in the
+    // table -> source row -> pixel chain of dependent loads, and the row addresses live in scalar registers)
+    const int Y0 = __builtin_amdgcn_readfirstlane(((bx / ctiles) * 4 + (int)(threadIdx.x >> 6)) * kResizeRows);
     if (xg >= t.ngroups || Y0 >= rows) return;
     const int4 xs = t.xtab[2 * xg], xa = t.xtab[2 * xg + 1];
     const int sxv[4] = {xs.x, xs.y, xs.z, xs.w};
@@ -351,13 +353,15 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     const int tiles_x = (sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups);
     const int lane = threadIdx.x & 63;
     const int x0 = kEdge + (t % tiles_x) * (4 * kScoreGroups) + (lane - 1) * 4;  // lane 0 / 63 = halo groups
-    const int y0 = kEdge + ((t / tiles_x) * 4 + (threadIdx.x >> 6)) * kScoreRows;
+    // (the strip is the wave's: said so, its rows, the row addresses and the scan-area tests stay in scalar registers - this
+    // kernel is bound by VALU issue, and every address computed per lane is VALU work)
+    const int strip = __builtin_amdgcn_readfirstlane((t / tiles_x) * 4 + (int)(threadIdx.x >> 6));
+    const int y0 = kEdge + strip * kScoreRows;
     if (y0 >= H - kEdge) return;  // wave-uniform
     const bool xin = x0 >= kEdge && x0 < W - kEdge;            // this lane's group starts inside the scan area
     const uint8_t* base = pyr + pix(g, f, l, 0, 0);
     // candidate list of this strip
-    const size_t lst = (size_t)f * g.lst_base[g.nlevels] + g.lst_base[l] +
-                       ((t / tiles_x) * 4 + (threadIdx.x >> 6)) * tiles_x + (t % tiles_x);
+    const size_t lst = (size_t)f * g.lst_base[g.nlevels] + g.lst_base[l] + strip * tiles_x + (t % tiles_x);
     uint2* ent = lst_ent + lst * kStripCap;
     int nent = 0;                                              // wave-uniform
     const int xc = min(max(x0, kEdge), W - kEdge - 1) & ~3;    // clamped (aligned) load position for halo lanes outside
@@ -1168,7 +1172,7 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
     // of row -v with two (unaligned) 32-bit loads each - 749 disc pixels in 4 load instructions instead of 47 byte
     // loads per lane.  Integer moments: the summation order is irrelevant.
     SE2_FRAME_GRID(f, bx);
-    const int k = bx * 4 + threadIdx.x / 64;
+    const int k = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x / 64));   // the wave's key point: its record is a scalar load
     const int lane = threadIdx.x & 63;
     const int v = lane & 15, c = lane >> 4;
     const int n = counts[f];
@@ -1221,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
     const int W = g.w[l], H = g.h[l], stride = g.stride[l];
     const int tiles_x = (W + 255) / 256;
     const int x0 = (t % tiles_x) * 256 + (threadIdx.x & 63) * 4;
-    const int y0 = ((t / tiles_x) * 4 + (threadIdx.x >> 6)) * kBlurRows;
+    const int y0 = __builtin_amdgcn_readfirstlane(((t / tiles_x) * 4 + (int)(threadIdx.x >> 6)) * kBlurRows);   // the wave's band: scalar rows
     if (x0 >= W || y0 >= H) return;
     const uint8_t* src = pyr + pix(g, f, l, 0, 0);
     uint8_t* dst = blur + pix(g, f, l, 0, 0);
@@ -1328,7 +1332,7 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
     constexpr int kPR = 19, kPW = 40, kPH = 2 * kPR + 1;                 // rows -19 .. 19, columns -20 .. 19
     __shared__ uint32_t patch[8][kPH * (kPW / 4)];
     SE2_FRAME_GRID(f, bx);
-    const int wv = threadIdx.x / 64;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64));   // (wave-uniform, said so: key-point records by scalar loads)
     const int k0 = 2 * (bx * 4 + wv);
     const int lane = threadIdx.x & 63;
     const int n = counts[f];
