@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void k_cand_window(Bounds bd, const se2gpu_key
     const int q0 = blockIdx.y * qpb;
     if (q0 >= n1) return;
     const TargetLds tg = stage_target(lds, cap, kps + (size_t)fb * cap, sorted + (size_t)fb * cap, n2);
-    for (int i1 = q0 + (int)(threadIdx.x / 64); i1 < min(q0 + qpb, n1); i1 += 4) {
+    // (one wave per query: the query index is wave-uniform - said so, its key point, previous position and descriptor address are scalar)
+    for (int i1 = q0 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)); i1 < min(q0 + qpb, n1); i1 += 4) {
         const se2gpu_keypoint kp1 = kps[(size_t)fa * cap + i1];
         const int level1 = kp1.octave;
         int n = 0;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void k_cand_projection(Bounds bd, ProjCam cam,
     extern __shared__ __attribute__((aligned(16))) int lds[];
     const int q0 = blockIdx.x * qpb;
     const TargetLds tg = stage_target(lds, n_feat, kps, sorted, n_feat);
-    for (int i = q0 + (int)(threadIdx.x / 64); i < min(q0 + qpb, m); i += 4) {
+    for (int i = q0 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)); i < min(q0 + qpb, m); i += 4) {   // wave-uniform map point
         int n = 0;
         if (!mp_skip[i]) {
             const float X = mp_pos[3 * i], Y = mp_pos[3 * i + 1], Z = mp_pos[3 * i + 2];

@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __
     __shared__ int s_kept[kMaxLevels], s_scan[256];
     SE2_FRAME_GRID(f, l);
     const int ncells_frame = g.cell_base[g.nlevels];
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int* tot_f = cell_total + (size_t)f * ncells_frame;
     for (int lv = wave; lv <= l; lv += 4) {
         const int nc = g.gcols[lv] * g.grows[lv];
