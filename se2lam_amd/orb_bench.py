@@ -19,6 +19,9 @@ B_ORB = 5_742_474      # algorithmic bytes per frame, SURVEY.md §8(d)
 B_MATCH = 132_000      # algorithmic bytes per frame pair
 
 
+MIN_TIMED_S = 0.1      # floor of the timed region (as bench.py's BA leg)
+
+
 def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, traffic=None, inflight=2):
     B = batch
     imgs = synth.frames(B, start=1000 * rank)
@@ -71,15 +74,23 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     for _ in range(warmup):
         step()
     drain()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    drain()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        dt = dist.allreduce_max(dt)
+    # The timed region is never shorter than MIN_TIMED_S: `steps` batches are a probe when they take less (10 batches are
+    # 15 ms, a quarter of which is the pipeline of two batches in flight filling and draining), and the sample is taken
+    # again with as many batches as the floor needs.  `steps` in the result is what ran, `steps_requested` what was asked.
+    steps_requested = steps
+    while True:
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = dist.allreduce_max(dt)
+        if dt >= MIN_TIMED_S:
+            break
+        steps = max(steps + 1, int(np.ceil(1.25 * steps * MIN_TIMED_S / max(dt, 1e-6))))
     fps = world * B * steps / dt
     last = bufs[(state["k"] - 1) % len(bufs)]
     cnt = last["cnt"].to_numpy(np.int32, (B,))
@@ -115,11 +126,12 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
     print(f"[orb_bench] resident {fps:.0f} frames/s; streaming leg", file=sys.stderr, flush=True)
     streaming = None
     try:
-        streaming = run_streaming(rank, world, B, steps, sync_all, dist, exs, mt, cap)
+        streaming = run_streaming(rank, world, B, min(steps, 40), sync_all, dist, exs, mt, cap)
     except Exception as exc:   # the streaming leg must never take the headline numbers down with it
         streaming = {"error": repr(exc)}
     return {"metric": "ORB extract+match frames/s @640x480", "value": fps, "unit": "frames/s", "n_gpus": world,
-            "batch": B, "steps": steps, "ms_per_batch": 1e3 * dt / steps, "scaling": "weak", "batches_in_flight": nex,
+            "batch": B, "steps": steps, "steps_requested": steps_requested, "timed_s": dt, "ms_per_batch": 1e3 * dt / steps,
+            "scaling": "weak", "batches_in_flight": nex,
             "config": {"workload": "640x480 u8, 8-level pyramid, 1000 features/frame, MatchByWindow(win 20, ratio 0.9), "
                                    "frames t vs t+1", "features_per_frame": float(cnt.mean()),
                        "matches_per_pair": float(nm.mean())},
