@@ -7,10 +7,9 @@
 //   /root/reference/include/se2lam/EdgeSE2XYZ.h:62-102 (PreEdgeSE2)
 // with FP64 HIP kernels.  Design:
 //   * SoA arena in HBM; observation edges are sorted by landmark (CSR) once per graph.
-//   * k_linearize      8 lanes per landmark: residual, Jacobians, Huber weight, per-edge Hpl / Hpp_e / bp_e,
-//                      per-landmark Hll / bl via an in-group shuffle reduction (no atomics); <FUSED>: also the
-//                      lambda-dependent Dinv, z, Y_e and the per-edge diagonal record Dg_e.
-//   * k_schur_lm       the lambda-dependent part alone: Dinv = (Hll + lambda I)^-1, z = Dinv bl, Y_e = Hpl_e Dinv, Dg_e.
+//   * k_linearize      8 lanes per landmark: residual, Jacobians, Huber weight, per-landmark Hll / bl via an in-group
+//                      shuffle reduction (no atomics), then the whitened per-edge records W_e = Hpl_e G^-T and
+//                      Dg_e = {Hpp_e - W_e W_e^T, bp_e, W_e zeta} with Hll + lambda I = G G^T (a retry runs it again).
 //   * k_reduce2        the reduced system S|b_s in one launch from a PRECOMPUTED contributor plan (output-stationary:
 //                      deterministic, atomic-free); k_pose_reduce / k_maxdiag only for lambda_0.
 //   * k_chol_tiles     dense pose solve: LDL^T of the augmented (3P)^2 system as one dataflow launch over 32x32 tiles
@@ -138,71 +137,65 @@ __device__ inline double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_linearize: per landmark group.  Outputs per edge: Hpl (3x3 row-major), Hpp_e (6 sym), bp_e (3);
-// per landmark: Hll (6 sym: xx xy xz yy yz zz), bl (3).
+// k_linearize: per landmark group (8 lanes per landmark, a lane takes every 8th edge of the landmark).
+//
+// Per-edge records in "whitened landmark coordinates" (round 4).  With M_l = Hll_l + lambda I = G G^T (3x3 Cholesky) and
+// A = G^-1 (lower triangular), every product the Schur complement needs factors through W_e = Hpl_e A^T:
+//     Y_e Hpl_j^T = Hpl_e M^-1 Hpl_j^T = W_e W_j^T,      Hpl_e z_l = W_e zeta_l  with  zeta_l = A bl_l,
+//     x_l = z_l - sum_e Y_e^T dp_e = A^T (zeta_l - sum_e W_e^T dp_e).
+// So ONE 72-byte operand per edge (W_e) replaces the two (Hpl_e and Y_e = Hpl_e M^-1) the pair products used to gather, and
+// the un-reduced pose blocks Hpp_e / bp_e never reach memory on the common path: the first edge of a lane stays in
+// registers between the landmark sum and the second pass (a landmark has ~6 observations, a lane almost never a second edge).
+//   per edge:      W_e (3x3 row-major, 9)   and   Dg_e = { sym(Hpp_e - W_e W_e^T) (6), bp_e (3), W_e zeta_l (3) }   (12)
+//   per landmark:  Hll (6 sym: xx xy xz yy yz zz), bl (3), A (6: a00 a10 a11 a20 a21 a22), zeta (3)
+// 168 bytes written per edge instead of 312.  A rejected LM trial keeps its estimate, so its retry simply runs this kernel
+// again with the new lambda (same inputs, same code: the linearisation comes out identical to the bit) - there is no
+// lambda-only kernel and nothing lambda-independent has to be kept per edge.
+// <FUSED = false> is the opening pass of an optimize() call only: lambda_0 = 1e-5 max diag H needs the diagonals first, so
+// it writes Hll, bl and the un-reduced pose terms Hpp_e (6 sym), bp_e (3) for k_lambda0 / k_pose_reduce and no records.
 // ---------------------------------------------------------------------------------------------
-__device__ inline void inv_sym3(const double h[6], double lambda, double d[6]);
+// A = G^-1 for M = h + lambda I = G G^T
+__device__ inline void chol_inv3(const double h[6], double lambda, double a[6]) {
+    const double m00 = h[0] + lambda, m10 = h[1], m20 = h[2], m11 = h[3] + lambda, m21 = h[4], m22 = h[5] + lambda;
+    // M is positive definite whenever lambda > 0; in Gauss-Newton mode (lambda = 0) a landmark without parallax makes it
+    // singular to rounding, and a pivot that comes out at -1e-17 must give a huge finite step (as a cofactor inverse, and
+    // g2o's, would), not a NaN: pivots are floored 30 orders of magnitude below the block's trace
+    const double floor_ = 1e-30 * (m00 + m11 + m22);
+    const double a00 = 1.0 / sqrt(fmax(m00, floor_));
+    const double g10 = m10 * a00, g20 = m20 * a00;
+    const double a11 = 1.0 / sqrt(fmax(m11 - g10 * g10, floor_));
+    const double g21 = (m21 - g20 * g10) * a11;
+    const double a22 = 1.0 / sqrt(fmax(m22 - g20 * g20 - g21 * g21, floor_));
+    const double a10 = -(a11 * g10) * a00;             // rows of A G = I
+    const double a21 = -(a22 * g21) * a11;
+    const double a20 = -(a21 * g10 + a22 * g20) * a00;
+    a[0] = a00; a[1] = a10; a[2] = a11; a[3] = a20; a[4] = a21; a[5] = a22;
+}
 
-// FUSED: also produce the lambda-dependent per-landmark pieces of k_schur_lm (Dinv, z, Y_e) in the same pass.
-// Per-edge contribution to the DIAGONAL of the reduced system, formed where Y_e, Hpl_e and z_l are already at hand:
-//   Dg_e = { sym(Hpp_e - Y_e Hpl_e^T) (6), bp_e (3), Hpl_e z_l (3) }        (12 doubles, one 96-byte record)
-// k_reduce2's per-pose gather then reads one record per edge instead of five arrays through two levels of indices.
-__device__ inline void write_diag_record(double* __restrict__ dg, const double* __restrict__ yy,
-                                         const double* __restrict__ hh, const double* __restrict__ hp,
-                                         const double* __restrict__ bpe, double z0, double z1, double z2) {
-    dg[0] = hp[0] - (yy[0] * hh[0] + yy[1] * hh[1] + yy[2] * hh[2]);
-    dg[1] = hp[1] - (yy[0] * hh[3] + yy[1] * hh[4] + yy[2] * hh[5]);
-    dg[2] = hp[2] - (yy[0] * hh[6] + yy[1] * hh[7] + yy[2] * hh[8]);
-    dg[3] = hp[3] - (yy[3] * hh[3] + yy[4] * hh[4] + yy[5] * hh[5]);
-    dg[4] = hp[4] - (yy[3] * hh[6] + yy[4] * hh[7] + yy[5] * hh[8]);
-    dg[5] = hp[5] - (yy[6] * hh[6] + yy[7] * hh[7] + yy[8] * hh[8]);
+// one edge's whitened record from its un-reduced blocks: hh = Hpl_e (9), hp = Hpp_e (6 sym), bpe = bp_e (3)
+__device__ inline void write_edge_record(double* __restrict__ w_out, double* __restrict__ dg, const double* __restrict__ hh,
+                                         const double* __restrict__ hp, const double* __restrict__ bpe,
+                                         const double a[6], const double zeta[3]) {
+    double w[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const double h0 = hh[r * 3], h1 = hh[r * 3 + 1], h2 = hh[r * 3 + 2];
+        w[r * 3 + 0] = h0 * a[0];
+        w[r * 3 + 1] = h0 * a[1] + h1 * a[2];
+        w[r * 3 + 2] = h0 * a[3] + h1 * a[4] + h2 * a[5];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) w_out[i] = w[i];
+    dg[0] = hp[0] - (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    dg[1] = hp[1] - (w[0] * w[3] + w[1] * w[4] + w[2] * w[5]);
+    dg[2] = hp[2] - (w[0] * w[6] + w[1] * w[7] + w[2] * w[8]);
+    dg[3] = hp[3] - (w[3] * w[3] + w[4] * w[4] + w[5] * w[5]);
+    dg[4] = hp[4] - (w[3] * w[6] + w[4] * w[7] + w[5] * w[8]);
+    dg[5] = hp[5] - (w[6] * w[6] + w[7] * w[7] + w[8] * w[8]);
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         dg[6 + r] = bpe[r];
-        dg[9 + r] = hh[r * 3] * z0 + hh[r * 3 + 1] * z1 + hh[r * 3 + 2] * z2;
-    }
-}
-
-// the lambda-dependent per-landmark pieces alone (a rejected trial keeps its linearisation): Dinv = (Hll + lambda I)^-1,
-// z = Dinv bl, Y_e = Hpl_e Dinv and the diagonal record of every edge
-__device__ inline void schur_lm_body(const unsigned bx, int L, double lambda, const int* __restrict__ lm_ptr, const double* Hll, const double* bl,
-                                     const double* Hpl, const double* Hpp_e, const double* bp_e, double* Dinv, double* z,
-                                     double* Y, double* Dg) {
-    const int gid = bx * kBlock + threadIdx.x;
-    const int l = gid / kGroup, sub = gid % kGroup;
-    if (l >= L) return;
-    double h[6], d[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) h[i] = Hll[(size_t)l * 6 + i];
-    inv_sym3(h, lambda, d);
-    const double b0 = bl[(size_t)l * 3], b1 = bl[(size_t)l * 3 + 1], b2 = bl[(size_t)l * 3 + 2];
-    const double z0 = d[0] * b0 + d[1] * b1 + d[2] * b2;
-    const double z1 = d[1] * b0 + d[3] * b1 + d[4] * b2;
-    const double z2 = d[2] * b0 + d[4] * b1 + d[5] * b2;
-    if (sub == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
-        z[(size_t)l * 3 + 0] = z0;
-        z[(size_t)l * 3 + 1] = z1;
-        z[(size_t)l * 3 + 2] = z2;
-    }
-    if (!Y) return;   // slim layout (k_reduce_rows): nothing per edge depends on lambda
-    for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
-        const double* B = Hpl + (size_t)e * 9;
-        double* y = Y + (size_t)e * 9;
-        double hh[9], yy[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) hh[i] = B[i];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double c0 = hh[r * 3], c1 = hh[r * 3 + 1], c2 = hh[r * 3 + 2];
-            yy[r * 3 + 0] = c0 * d[0] + c1 * d[1] + c2 * d[2];
-            yy[r * 3 + 1] = c0 * d[1] + c1 * d[3] + c2 * d[4];
-            yy[r * 3 + 2] = c0 * d[2] + c1 * d[4] + c2 * d[5];
-        }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) y[i] = yy[i];
-        write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
+        dg[9 + r] = w[r * 3] * zeta[0] + w[r * 3 + 1] * zeta[1] + w[r * 3 + 2] * zeta[2];
     }
 }
 
@@ -212,29 +205,28 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
                                                        const double* __restrict__ e_info,
                                                        const double* __restrict__ poses,
                                                        const uint8_t* __restrict__ fixed,
-                                                       const double* __restrict__ lms, double* Hpl,
-                                                       double* __restrict__ Hpp_e, double* __restrict__ bp_e,
+                                                       const double* __restrict__ lms, double* W,
+                                                       double* Hpp_e, double* bp_e,
                                                        double* __restrict__ Hll, double* __restrict__ bl, double lambda,
-                                                       double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ Y, double* __restrict__ Dg,
+                                                       double* __restrict__ Ainv, double* __restrict__ zeta,
+                                                       double* __restrict__ Dg,
                                                        const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
                                                        const double* __restrict__ lms_b) {
-    if (ctl) {   // device-side LM: nothing to do after the run has ended; a retry keeps its linearisation and only redoes the
-                 // lambda-dependent part (what k_schur_lm does - here, so that a trial slot needs no launch of its own for it)
+    if (ctl) {   // device-side LM: nothing to do after the run has ended; a retry runs like any other trial (the estimate
+                 // did not move, only lambda did)
         if (ctl->done) return;
-        if (ctl->retry) {
-            if (FUSED) schur_lm_body(bx, L, ctl->lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
-            return;
-        }
         if (ctl->sel) { poses = poses_b; lms = lms_b; }
         lambda = ctl->lambda;
     }
     const int gid = bx * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    double k_hpl[9], k_hpp[6], k_bp[3];   // the lane's first edge, kept for the second pass
+    int beg = 0, end = 0;
     if (l < L) {
         const double lx = lms[3 * l], ly = lms[3 * l + 1], lz = lms[3 * l + 2];
-        const int beg = lm_ptr[l], end = lm_ptr[l + 1];
+        beg = lm_ptr[l];
+        end = lm_ptr[l + 1];
         for (int e = beg + sub; e < end; e += kGroup) {
             const int kf = e_kf[e];
             double e0, e1, Jp[6], Jl[6];
@@ -263,12 +255,11 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
 #pragma unroll
             for (int r = 0; r < 3; ++r) b[r] += Jl[r] * or0 + Jl[3 + r] * or1;
             const bool fr = !fixed[kf];
-            double* hpl = Hpl + (size_t)e * 9;
+            double hpl[9], hpp[6], bpe[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) hpl[r * 3 + c] = fr ? Jp[r] * WJl[c] + Jp[3 + r] * WJl[3 + c] : 0.0;
-            double* hpp = Hpp_e + (size_t)e * 6;
             hpp[0] = fr ? Jp[0] * WJp[0] + Jp[3] * WJp[3] : 0.0;
             hpp[1] = fr ? Jp[0] * WJp[1] + Jp[3] * WJp[4] : 0.0;
             hpp[2] = fr ? Jp[0] * WJp[2] + Jp[3] * WJp[5] : 0.0;
@@ -276,7 +267,26 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
             hpp[4] = fr ? Jp[1] * WJp[2] + Jp[4] * WJp[5] : 0.0;
             hpp[5] = fr ? Jp[2] * WJp[2] + Jp[5] * WJp[5] : 0.0;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) bp_e[(size_t)e * 3 + r] = fr ? Jp[r] * or0 + Jp[3 + r] * or1 : 0.0;
+            for (int r = 0; r < 3; ++r) bpe[r] = fr ? Jp[r] * or0 + Jp[3 + r] * or1 : 0.0;
+            if (FUSED && e == beg + sub) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) k_hpl[i] = hpl[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) k_hpp[i] = hpp[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) k_bp[i] = bpe[i];
+            } else {
+                // un-fused pass: the pose terms of every edge (lambda_0); fused pass: a lane's further edges wait in memory
+                // (landmarks with more than 8 observations) - the W slot holds the raw block until the second pass
+                if (FUSED) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) W[(size_t)e * 9 + i] = hpl[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) Hpp_e[(size_t)e * 6 + i] = hpp[i];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) bp_e[(size_t)e * 3 + i] = bpe[i];
+            }
         }
     }
 #pragma unroll
@@ -290,35 +300,27 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
         for (int i = 0; i < 3; ++i) bl[(size_t)l * 3 + i] = b[i];
     }
     if (FUSED && l < L) {
-        double d[6];
-        inv_sym3(hll, lambda, d);
+        double a[6], zt[3];
+        chol_inv3(hll, lambda, a);
+        zt[0] = a[0] * b[0];
+        zt[1] = a[1] * b[0] + a[2] * b[1];
+        zt[2] = a[3] * b[0] + a[4] * b[1] + a[5] * b[2];
         if (sub == 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) Dinv[(size_t)l * 6 + i] = d[i];
-            z[(size_t)l * 3 + 0] = d[0] * b[0] + d[1] * b[1] + d[2] * b[2];
-            z[(size_t)l * 3 + 1] = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
-            z[(size_t)l * 3 + 2] = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
+            for (int i = 0; i < 6; ++i) Ainv[(size_t)l * 6 + i] = a[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) zeta[(size_t)l * 3 + i] = zt[i];
         }
-        const double z0 = d[0] * b[0] + d[1] * b[1] + d[2] * b[2];
-        const double z1 = d[1] * b[0] + d[3] * b[1] + d[4] * b[2];
-        const double z2 = d[2] * b[0] + d[4] * b[1] + d[5] * b[2];
-        if (Y)   // (slim layout: k_reduce_rows and k_update form Y_e = Hpl_e Dinv_l themselves - 144 bytes per edge written, not 312)
-        for (int e = lm_ptr[l] + sub; e < lm_ptr[l + 1]; e += kGroup) {
-            const double* B = Hpl + (size_t)e * 9;  // written by this same lane above
-            double* y = Y + (size_t)e * 9;
-            double hh[9], yy[9];
+        if (beg + sub < end) write_edge_record(W + (size_t)(beg + sub) * 9, Dg + (size_t)(beg + sub) * 12, k_hpl, k_hpp, k_bp, a, zt);
+        for (int e = beg + sub + kGroup; e < end; e += kGroup) {   // written by this same lane above
+            double hh[9], hp[6], bpe[3];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) hh[i] = B[i];
+            for (int i = 0; i < 9; ++i) hh[i] = W[(size_t)e * 9 + i];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double b0 = hh[r * 3], b1 = hh[r * 3 + 1], b2 = hh[r * 3 + 2];
-                yy[r * 3 + 0] = b0 * d[0] + b1 * d[1] + b2 * d[2];
-                yy[r * 3 + 1] = b0 * d[1] + b1 * d[3] + b2 * d[4];
-                yy[r * 3 + 2] = b0 * d[2] + b1 * d[4] + b2 * d[5];
-            }
+            for (int i = 0; i < 6; ++i) hp[i] = Hpp_e[(size_t)e * 6 + i];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) y[i] = yy[i];
-            write_diag_record(Dg + (size_t)e * 12, yy, hh, Hpp_e + (size_t)e * 6, bp_e + (size_t)e * 3, z0, z1, z2);
+            for (int i = 0; i < 3; ++i) bpe[i] = bp_e[(size_t)e * 3 + i];
+            write_edge_record(W + (size_t)e * 9, Dg + (size_t)e * 12, hh, hp, bpe, a, zt);
         }
     }
 }
@@ -328,14 +330,14 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
                                                        const double* __restrict__ e_info,
                                                        const double* __restrict__ poses,
                                                        const uint8_t* __restrict__ fixed,
-                                                       const double* __restrict__ lms, double* Hpl,
-                                                       double* __restrict__ Hpp_e, double* __restrict__ bp_e,
+                                                       const double* __restrict__ lms, double* W,
+                                                       double* Hpp_e, double* bp_e,
                                                        double* __restrict__ Hll, double* __restrict__ bl, double lambda,
-                                                       double* __restrict__ Dinv, double* __restrict__ z,
-                                                       double* __restrict__ Y, double* __restrict__ Dg,
+                                                       double* __restrict__ Ainv, double* __restrict__ zeta,
+                                                       double* __restrict__ Dg,
                                                        const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
                                                        const double* __restrict__ lms_b) {
-    d_linearize<FUSED>(blockIdx.x, cam, L, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, Hpl, Hpp_e, bp_e, Hll, bl, lambda, Dinv, z, Y, Dg, ctl, poses_b, lms_b);
+    d_linearize<FUSED>(blockIdx.x, cam, L, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, W, Hpp_e, bp_e, Hll, bl, lambda, Ainv, zeta, Dg, ctl, poses_b, lms_b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -567,9 +569,7 @@ __global__ void k_extract_diag(int P, const double* __restrict__ Hpp, double* __
     if (i < P * 3) d3[i] = Hpp[(size_t)(i / 3) * 9 + (i % 3) * 4];
 }
 
-// ---------------------------------------------------------------------------------------------
-// k_schur_lm: per landmark group: Dinv = (Hll + lambda I)^-1 (sym 6), z = Dinv bl, Y_e = Hpl_e Dinv.
-// ---------------------------------------------------------------------------------------------
+// (Hll + lambda I)^-1 as 6 symmetric entries (the SE3-expmap model's k3_schur_lm)
 __device__ inline void inv_sym3(const double h[6], double lambda, double d[6]) {
     const double a = h[0] + lambda, b = h[1], c = h[2], e = h[3] + lambda, f = h[4], i = h[5] + lambda;
     const double A = e * i - f * f, B = -(b * i - f * c), C = b * f - e * c;
@@ -578,36 +578,11 @@ __device__ inline void inv_sym3(const double h[6], double lambda, double d[6]) {
     d[3] = (a * i - c * c) * id; d[4] = -(a * f - c * b) * id; d[5] = (a * e - b * b) * id;
 }
 
-__device__ __forceinline__ void d_schur_lm(const unsigned bx, int L, double lambda, const int* __restrict__ lm_ptr,
-                                                      const double* __restrict__ Hll, const double* __restrict__ bl,
-                                                      const double* __restrict__ Hpl,
-                                                      const double* __restrict__ Hpp_e,
-                                                      const double* __restrict__ bp_e, double* __restrict__ Dinv,
-                                                      double* __restrict__ z, double* __restrict__ Y,
-                                                      double* __restrict__ Dg, const BaCtl* __restrict__ ctl,
-                                                      int force) {
-    if (ctl) {   // needed for the first trial of iteration 0 (lambda_0 comes after the linearisation) and for retries
-        if (ctl->done || !(force | ctl->retry)) return;
-        lambda = ctl->lambda;
-    }
-    schur_lm_body(bx, L, lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg);
-}
-__global__ __launch_bounds__(kBlock) void k_schur_lm(int L, double lambda, const int* __restrict__ lm_ptr,
-                                                      const double* __restrict__ Hll, const double* __restrict__ bl,
-                                                      const double* __restrict__ Hpl,
-                                                      const double* __restrict__ Hpp_e,
-                                                      const double* __restrict__ bp_e, double* __restrict__ Dinv,
-                                                      double* __restrict__ z, double* __restrict__ Y,
-                                                      double* __restrict__ Dg, const BaCtl* __restrict__ ctl,
-                                                      int force) {
-    d_schur_lm(blockIdx.x, L, lambda, lm_ptr, Hll, bl, Hpl, Hpp_e, bp_e, Dinv, z, Y, Dg, ctl, force);
-}
-
 // ---------------------------------------------------------------------------------------------
 // k_reduce2: the reduced system in ONE launch, output-stationary, atomic-free.
 //   blocks [0, nb_off)        : off-diagonal (a < b) blocks, one THREAD per entry (9 consecutive lanes per block):
-//                               S_ab(r,c) = - sum_{(i,j) in pairs(a,b)} Y_i(r,:) . Hpl_j(c,:)  (+ the PreEdgeSE2 block)
-//   blocks [nb_off, nb_off+nb_diag) : one WAVE per pose: S_aa = Hpp_a + lambda I - sum_e Y_e Hpl_e^T, b_s, b_p
+//                               S_ab(r,c) = - sum_{(i,j) in pairs(a,b)} W_i(r,:) . W_j(c,:)  (+ the PreEdgeSE2 block)
+//   blocks [nb_off, nb_off+nb_diag) : one WAVE per pose: S_aa = Hpp_a + lambda I - sum_e W_e W_e^T, b_s, b_p
 //                               (absorbs k_pose_reduce, k_odometry and k_reduce_odo; odometry terms are recomputed
 //                               on the fly from the poses: <= 2 edges per pose)
 //   last wave of the diagonal part clears the padding of the augmented matrix.
@@ -638,7 +613,7 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                                                      const int4* __restrict__ grp, const int* __restrict__ blk_a,
                                                      const int* __restrict__ blk_b, const int* __restrict__ pair_i,
                                                      const int* __restrict__ pair_j, const int* __restrict__ blk_odo,
-                                                     const double* __restrict__ Y, const double* __restrict__ Hpl,
+                                                     const double* __restrict__ W,
                                                      const double* __restrict__ Dg,
                                                      const uint8_t* __restrict__ fixed, const int* __restrict__ pose_ptr,
                                                      const int* __restrict__ pose_edges, const int* __restrict__ podo_ptr,
@@ -690,8 +665,8 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                 double yv[8][3], hv[8][3];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const double* y = Y + (size_t)ia[u] * 9 + 3 * r;
-                    const double* hh = Hpl + (size_t)ib[u] * 9 + 3 * c;
+                    const double* y = W + (size_t)ia[u] * 9 + 3 * r;
+                    const double* hh = W + (size_t)ib[u] * 9 + 3 * c;
                     yv[u][0] = y[0]; yv[u][1] = y[1]; yv[u][2] = y[2];
                     hv[u][0] = hh[0]; hv[u][1] = hh[1]; hv[u][2] = hh[2];
                 }
@@ -841,7 +816,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                                                      const int4* __restrict__ grp, const int* __restrict__ blk_a,
                                                      const int* __restrict__ blk_b, const int* __restrict__ pair_i,
                                                      const int* __restrict__ pair_j, const int* __restrict__ blk_odo,
-                                                     const double* __restrict__ Y, const double* __restrict__ Hpl,
+                                                     const double* __restrict__ W,
                                                      const double* __restrict__ Dg,
                                                      const uint8_t* __restrict__ fixed, const int* __restrict__ pose_ptr,
                                                      const int* __restrict__ pose_edges, const int* __restrict__ podo_ptr,
@@ -851,260 +826,7 @@ __global__ __launch_bounds__(kBlock) void k_reduce2(int P, int ld, int nwg_off, 
                                                      double* __restrict__ S, double* __restrict__ bp,
                                                      const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
                                                      unsigned* __restrict__ epoch, const int* __restrict__ pose_off, int nsys) {
-    d_reduce2(blockIdx.x, P, ld, nwg_off, lambda, root, grp, blk_a, blk_b, pair_i, pair_j, blk_odo, Y, Hpl, Dg, fixed, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch, pose_off, nsys);
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_reduce_rows (round 3): the reduced system WITHOUT per-pair operands and without the per-edge Y / Dg records.
-//   S_ab = - sum_{l seen by a and b} Hpl_{a,l} Dinv_l Hpl_{b,l}^T,   S_aa = sum_{e in a} (Hpp_e - Hpl_e Dinv_l Hpl_e^T) + ...
-// One workgroup per pose a (row-stationary): it walks the pose's own edges ("visits"); a visit reads the landmark's
-// inverse block Dinv_l and the landmark's CONTIGUOUS run of edge blocks Hpl (edges are sorted by landmark) - one lane per
-// (observer b of the landmark, entry of the 3x3 block) forms Y_e row x Hpl_b row on the fly and adds it to the block
-// (a, b), b > a, of the pose's row with an LDS add.  Every wave owns a private copy of the row (LDS operations of a wave
-// execute in issue order: its sums are taken in visit order), the copies are combined in wave order: deterministic,
-// atomic-free across workgroups, and block (b, a) is written as the transpose of (a, b), the diagonal block from one
-// expression per symmetric pair of entries - S is symmetric to the bit.
-// Against the pair plan of k_reduce2 this reads runs of 72-byte blocks instead of two scattered 72-byte rows per pair,
-// needs neither Y_e nor the diagonal records (k_linearize writes 144 instead of 312 bytes per edge, a rejected trial
-// only recomputes Dinv and z per landmark), and no pair lists at all.
-//   visit = {edge, first edge of its landmark, observers of the landmark, landmark}           (k_plan_visits, per pose slot)
-// Dynamic LDS: nwaves x (P - a) x 9 doubles (row copies, allocated for a = 0) + the odometry scratch.
-// ---------------------------------------------------------------------------------------------
-__global__ void k_plan_visits(int E, const int* __restrict__ pose_edges, const int* __restrict__ e_lm,
-                              const int* __restrict__ lm_ptr, int4* __restrict__ visit) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= E) return;
-    const int e = pose_edges[t], l = e_lm[e];
-    const int s0 = lm_ptr[l];
-    visit[t] = make_int4(e, s0, lm_ptr[l + 1] - s0, l);
-}
-
-__device__ __forceinline__ void d_reduce_rows(const unsigned bx, int P, int ld, double lambda, int root, int odo_offdiag,
-                                              int NW, const int* __restrict__ pose_ptr, const int4* __restrict__ visit,
-                                              const int* __restrict__ e_kf, const double* __restrict__ Hpl,
-                                              const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
-                                              const double* __restrict__ Dinv, const double* __restrict__ z,
-                                              const uint8_t* __restrict__ fixed, const int* __restrict__ podo_ptr,
-                                              const int* __restrict__ podo_item, const int* __restrict__ o_i,
-                                              const int* __restrict__ o_j, const double* __restrict__ o_meas,
-                                              const double* __restrict__ o_info, const double* __restrict__ poses,
-                                              double* __restrict__ S, double* __restrict__ bp,
-                                              const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
-                                              unsigned* __restrict__ epoch) {
-    if (ctl) {
-        if (ctl->done) return;
-        if (ctl->sel) poses = poses_b;
-        lambda = ctl->lambda;
-    }
-    extern __shared__ __attribute__((aligned(16))) double rows_lds[];
-    const int n = 3 * P;
-    const int a = (int)bx;
-    const int nthr = (int)blockDim.x, tid = (int)threadIdx.x;
-    double* __restrict__ bs = S + (size_t)n * ld;
-    if (a == P) {   // the padding of the augmented matrix, the solver's flag and its epoch (as k_reduce2's last diagonal workgroup)
-        for (size_t t = (size_t)n * ld + n + tid; t < (size_t)ld * ld; t += nthr) S[t] = 0.0;
-        if (tid == 0) {
-            S[(size_t)ld * ld + 2] = 0.0;
-            *epoch += 1u;
-        }
-        return;
-    }
-    if (a > P) return;
-    // NW waves take visits and own a copy of the row (the graph's own choice: a batch launches every window with the
-    // widest workgroup of the batch, and a window's sums must not depend on its neighbours); the other waves only help
-    // with the zeroing and the combination
-    const int W = NW, wv = tid >> 6, ln = tid & 63;
-    const int nb = P - a;                        // blocks of this row: b = a .. P-1
-    const int rowlen = nb * 9;
-    double* acc = rows_lds + (size_t)wv * rowlen;          // this wave's copy of the row
-    double* misc = rows_lds + (size_t)W * (size_t)(P * 9); // [W][8]: rhs (3), bp sum (3) per wave | then odometry scratch
-    double* odoc = misc + (size_t)W * 8;                   // [8][24]: diag 9, rhs 3, off-diagonal block 9, target, spare
-    const bool fa = fixed[a] != 0;
-    for (int t = tid; t < W * rowlen; t += nthr) rows_lds[(size_t)(t / rowlen) * rowlen + (t % rowlen)] = 0.0;
-    if (tid < W * 8) misc[tid] = 0.0;
-    __syncthreads();
-    const int v0 = pose_ptr[a], nvis = fa ? 0 : pose_ptr[a + 1] - v0;
-    const int no = fa ? 0 : podo_ptr[a + 1] - podo_ptr[a];
-    // ---- the visits of this wave, in order.  A visit is a chain of dependent loads (record -> landmark / edge blocks), so
-    // the records of up to 64 visits are fetched at once (one per lane) and the visits then go in batches of kU: all loads
-    // of a batch are requested before the first one is used.
-    const int j_of = ln / 9, en = ln - 9 * j_of, r = en / 3, c = en - 3 * r;
-    const bool lane_on = ln < 63;
-    const bool swp_lane = r > c;                 // (for the pose's own edge: entries (r, c) and (c, r) share one expression)
-    const int lo = min(r, c), hi = max(r, c);
-    const int symidx = lo == 0 ? hi : lo == 1 ? hi + 2 : 5;   // Hpp_e is stored as (xx xy xz yy yz zz)
-    constexpr int kU = 4;
-    const int nvis_w = wv < NW && nvis > wv ? (nvis - wv + NW - 1) / NW : 0;
-    for (int vbase = 0; vbase < nvis_w; vbase += 64) {
-        const int mine = vbase + ln;
-        int4 vrec = make_int4(0, 0, 0, 0);
-        if (mine < nvis_w) vrec = visit[v0 + wv + NW * mine];
-        const int cnt = min(64, nvis_w - vbase);
-        for (int u0 = 0; u0 < cnt; u0 += kU) {
-            int ve[kU], vs[kU], vk[kU], vl[kU], vb[kU];
-            double ra[kU][3], rb[kU][3], dd[kU][6], hppv[kU], bpv[kU], zv[kU][3];
-            bool vown[kU], vact[kU];
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int idx = min(u0 + u, cnt - 1);          // (a clamped slot repeats the last visit; it is not added)
-                ve[u] = __builtin_amdgcn_readlane(vrec.x, idx);
-                vs[u] = __builtin_amdgcn_readlane(vrec.y, idx);
-                vk[u] = __builtin_amdgcn_readlane(vrec.z, idx);
-                vl[u] = __builtin_amdgcn_readlane(vrec.w, idx);
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const int e = ve[u], l = vl[u];
-                vact[u] = lane_on && j_of < vk[u] && u0 + u < cnt;
-                const int t = vs[u] + ((lane_on && j_of < vk[u]) ? j_of : 0);
-                vown[u] = t == e;
-                vb[u] = e_kf[t];
-                const double* he = Hpl + (size_t)e * 9;
-                const bool swp = vown[u] && swp_lane;
-                const double* pa = swp ? he + 3 * c : he + 3 * r;
-                const double* pb = swp ? he + 3 * r : Hpl + (size_t)t * 9 + 3 * c;
-                ra[u][0] = pa[0]; ra[u][1] = pa[1]; ra[u][2] = pa[2];
-                rb[u][0] = pb[0]; rb[u][1] = pb[1]; rb[u][2] = pb[2];
-                const double* dl = Dinv + (size_t)l * 6;
-#pragma unroll
-                for (int i = 0; i < 6; ++i) dd[u][i] = dl[i];
-                hppv[u] = Hpp_e[(size_t)e * 6 + symidx];
-                bpv[u] = bp_e[(size_t)e * 3 + r];
-                const double* zl = z + (size_t)l * 3;
-                zv[u][0] = zl[0]; zv[u][1] = zl[1]; zv[u][2] = zl[2];
-            }
-#pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                const double a0 = ra[u][0], a1 = ra[u][1], a2 = ra[u][2];
-                const double b0 = rb[u][0], b1 = rb[u][1], b2 = rb[u][2];
-                const double y0 = a0 * dd[u][0] + a1 * dd[u][1] + a2 * dd[u][2];
-                const double y1 = a0 * dd[u][1] + a1 * dd[u][3] + a2 * dd[u][4];
-                const double y2 = a0 * dd[u][2] + a1 * dd[u][4] + a2 * dd[u][5];
-                double val = -(y0 * b0 + y1 * b1 + y2 * b2);
-                const bool own = vown[u], active = vact[u];
-                if (own) val += hppv[u];
-                const int b = vb[u];
-                const bool use = active && (own || b > a);   // (a fixed observer's Hpl_b is zero: k_linearize writes it so)
-                if (use) __hip_atomic_fetch_add(acc + (b - a) * 9 + en, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (own && active && c == 0) {   // right-hand side: bp_e - Hpl_e z_l (row r of Hpl_e is rowB when swapped, rowA else)
-                    const bool swp = swp_lane;
-                    const double h0 = swp ? b0 : a0, h1 = swp ? b1 : a1, h2 = swp ? b2 : a2;
-                    const double g = h0 * zv[u][0] + h1 * zv[u][1] + h2 * zv[u][2];
-                    __hip_atomic_fetch_add(misc + wv * 8 + r, bpv[u] - g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(misc + wv * 8 + 3 + r, bpv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            // landmarks with more than seven observers: the remaining observer groups of these visits, one at a time
-#pragma unroll 1
-            for (int u = 0; u < kU; ++u) {
-                if (u0 + u >= cnt || vk[u] <= 7) continue;
-                const int e = ve[u], l = vl[u], k = vk[u];
-                const double* he = Hpl + (size_t)e * 9;
-                const double* dl = Dinv + (size_t)l * 6;
-                for (int j0 = 7; j0 < k; j0 += 7) {
-                    const int j = j0 + j_of;
-                    const bool active = lane_on && j < k;
-                    const int t = vs[u] + (active ? j : 0);
-                    const int b = e_kf[t];
-                    const bool own = t == e;
-                    const bool swp = own && swp_lane;
-                    const double* pa = swp ? he + 3 * c : he + 3 * r;
-                    const double* pb = swp ? he + 3 * r : Hpl + (size_t)t * 9 + 3 * c;
-                    const double a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-                    const double y0 = a0 * dl[0] + a1 * dl[1] + a2 * dl[2];
-                    const double y1 = a0 * dl[1] + a1 * dl[3] + a2 * dl[4];
-                    const double y2 = a0 * dl[2] + a1 * dl[4] + a2 * dl[5];
-                    double val = -(y0 * b0 + y1 * b1 + y2 * b2);
-                    if (own) val += hppv[u];
-                    const bool use = active && (own || b > a);   // (a fixed observer's Hpl_b is zero: k_linearize writes it so)
-                    if (use) __hip_atomic_fetch_add(acc + (b - a) * 9 + en, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (own && active && c == 0) {
-                        const double h0 = swp ? b0 : a0, h1 = swp ? b1 : a1, h2 = swp ? b2 : a2;
-                        const double g = h0 * zv[u][0] + h1 * zv[u][1] + h2 * zv[u][2];
-                        __hip_atomic_fetch_add(misc + wv * 8 + r, bpv[u] - g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(misc + wv * 8 + 3 + r, bpv[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // ---- PreEdgeSE2 terms of this pose, eight at a time: one lane each evaluates an edge (sin / cos), then twelve threads fold
-    // them into wave 0's copy in edge order
-    for (int t0 = 0; t0 < no; t0 += 8) {
-        if (tid >= nthr - 8 && t0 + tid - (nthr - 8) < no) {
-            const int t = tid - (nthr - 8);
-            const int item = podo_item[podo_ptr[a] + t0 + t];
-            const int k = item >> 1, isj = item & 1;
-            double e[3], A[9], B[9], WA[9], WB[9], omr[3];
-            odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, k, e, A, B, WA, WB, omr);
-            const double* J = isj ? B : A;
-            const double* WJ = isj ? WB : WA;
-            double* o = odoc + 24 * t;
-            for (int r2 = 0; r2 < 3; ++r2) {
-                for (int c2 = 0; c2 < 3; ++c2) o[r2 * 3 + c2] = J[r2] * WJ[c2] + J[3 + r2] * WJ[3 + c2] + J[6 + r2] * WJ[6 + c2];
-                o[9 + r2] = J[r2] * omr[0] + J[3 + r2] * omr[1] + J[6 + r2] * omr[2];
-            }
-            // block (a, other), other > a: A^T W B with rows of the i-pose, transposed when this pose is the edge's j end
-            const int other = isj ? o_i[k] : o_j[k];
-            const bool off = odo_offdiag && other > a && !fixed[other];
-            o[21] = off ? (double)other : -1.0;
-            for (int r2 = 0; r2 < 3; ++r2)
-                for (int c2 = 0; c2 < 3; ++c2) {
-                    const int rr = isj ? c2 : r2, cc = isj ? r2 : c2;
-                    o[12 + r2 * 3 + c2] = off ? A[rr] * WB[cc] + A[3 + rr] * WB[3 + cc] + A[6 + rr] * WB[6 + cc] : 0.0;
-                }
-        }
-        __syncthreads();
-        if (tid < 12) {
-            const int cnt = min(8, no - t0);
-            for (int t = 0; t < cnt; ++t) {
-                const double* o = odoc + 24 * t;
-                if (tid < 9) {
-                    rows_lds[tid] += o[tid];                                  // diagonal block (b = a) of wave 0's copy
-                    if (o[21] >= 0.0) rows_lds[((int)o[21] - a) * 9 + tid] += o[12 + tid];
-                } else {
-                    misc[tid - 9] += o[tid];                                  // both the reduced rhs and the pose gradient
-                    misc[3 + tid - 9] += o[tid];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- combine the waves' copies in wave order, write row a and column a
-    for (int idx = tid; idx < rowlen; idx += nthr) {
-        double tot = 0;
-        for (int w = 0; w < W; ++w) tot += rows_lds[(size_t)w * rowlen + idx];
-        const int bb = a + idx / 9, q = idx % 9, rr = q / 3, cc = q - 3 * rr;
-        double out;
-        if (bb == a) {
-            if (fa) out = (rr == cc && root) ? 1.0 : 0.0;
-            else out = tot + ((rr == cc && root) ? lambda : 0.0);
-            S[(size_t)(3 * a + rr) * ld + 3 * a + cc] = out;
-        } else {
-            out = fa ? 0.0 : tot;
-            S[(size_t)(3 * a + rr) * ld + 3 * bb + cc] = out;
-            S[(size_t)(3 * bb + cc) * ld + 3 * a + rr] = out;
-        }
-    }
-    if (tid < 3) {
-        double v = 0, gsum = 0;
-        for (int w = 0; w < W; ++w) { gsum += misc[w * 8 + tid]; v += misc[w * 8 + 3 + tid]; }
-        bs[3 * a + tid] = fa ? 0.0 : gsum;
-        bp[(size_t)a * 3 + tid] = fa ? 0.0 : v;
-    }
-}
-__global__ __launch_bounds__(512) void k_reduce_rows(int P, int ld, double lambda, int root, int odo_offdiag, int NW, const int* __restrict__ pose_ptr,
-                              const int4* __restrict__ visit, const int* __restrict__ e_kf, const double* __restrict__ Hpl,
-                              const double* __restrict__ Hpp_e, const double* __restrict__ bp_e,
-                              const double* __restrict__ Dinv, const double* __restrict__ z,
-                              const uint8_t* __restrict__ fixed, const int* __restrict__ podo_ptr,
-                              const int* __restrict__ podo_item, const int* __restrict__ o_i, const int* __restrict__ o_j,
-                              const double* __restrict__ o_meas, const double* __restrict__ o_info,
-                              const double* __restrict__ poses, double* __restrict__ S, double* __restrict__ bp,
-                              const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b, unsigned* __restrict__ epoch) {
-    d_reduce_rows(blockIdx.x, P, ld, lambda, root, odo_offdiag, NW, pose_ptr, visit, e_kf, Hpl, Hpp_e, bp_e, Dinv, z, fixed, podo_ptr,
-                  podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch);
+    d_reduce2(blockIdx.x, P, ld, nwg_off, lambda, root, grp, blk_a, blk_b, pair_i, pair_j, blk_odo, W, Dg, fixed, pose_ptr, pose_edges, podo_ptr, podo_item, o_i, o_j, o_meas, o_info, poses, S, bp, ctl, poses_b, epoch, pose_off, nsys);
 }
 
 // odometry pose-pose blocks: S_ij += Oij, S_ji += Oij^T.  One thread per (edge, entry).
@@ -1784,7 +1506,8 @@ struct FinArgs {
 __device__ void finish_trial(const FinArgs& fin, const double* part, double lambda);
 
 // ---------------------------------------------------------------------------------------------
-// k_update: per landmark group: back-substitute x_l = z - sum_e Y_e^T x_p[kf(e)], trial landmark = lw + x_l,
+// k_update: per landmark group: back-substitute x_l = A^T (zeta_l - sum_e W_e^T x_p[kf(e)]) (the whitened records of
+// k_linearize: = z_l - sum_e Y_e^T x_p), trial landmark = lw + x_l,
 // robust chi^2 of the landmark's edges at the trial state, and the landmark part of computeScale().
 // With xp == nullptr it evaluates chi^2 at the current state (x = 0).  Per-block partials -> part[2*blockIdx].
 // ---------------------------------------------------------------------------------------------
@@ -1793,13 +1516,11 @@ __device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, d
                                                     const double* __restrict__ e_info,
                                                     const double* __restrict__ poses,
                                                     const uint8_t* __restrict__ fixed, const double* __restrict__ lms,
-                                                    const double* __restrict__ xp, const double* __restrict__ z,
-                                                    const double* __restrict__ Y, const double* __restrict__ bl,
+                                                    const double* __restrict__ xp, const double* __restrict__ zeta,
+                                                    const double* __restrict__ W, const double* __restrict__ bl,
                                                     double* __restrict__ lms_trial, double* __restrict__ part,
                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
-                                                    FinArgs fin, const double* __restrict__ Dinv) {
-    // Dinv != nullptr: slim layout - `Y` holds the edge blocks Hpl_e and the landmark step is
-    //   x_l = z_l - Dinv_l sum_e Hpl_e^T dp_e      (instead of z_l - sum_e Y_e^T dp_e with Y_e = Hpl_e Dinv_l stored per edge)
+                                                    FinArgs fin, const double* __restrict__ Ainv) {
     if (fin.enabled && (int)bx == fin.nblk) {
         finish_trial(fin, part, lambda);
         return;
@@ -1807,7 +1528,7 @@ __device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, d
     // The kernel is a chain of dependent loads (controller / CSR bounds -> edge records -> pose gathers) around very
     // little arithmetic, so everything that does not depend on the previous link is requested together: the CSR bounds
     // beside the controller block, and for the first two edges of a lane (a landmark has 6 observations on average, a
-    // lane takes every 8th) ALL operands of both passes - Y_e and x_p for the back-substitution, the pose, measurement and
+    // lane takes every 8th) ALL operands of both passes - W_e and x_p for the back-substitution, the pose, measurement and
     // information for the robust chi^2 - before the first use.  Lanes with more edges take the rest in the old two-pass form.
     const int gid = bx * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
@@ -1841,7 +1562,7 @@ __device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, d
         const bool has = l < L && end > beg;
         ekf[k] = has ? e_kf[ec] : 0;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) ey[k][i] = (has && step) ? Y[(size_t)ec * 9 + i] : 0.0;
+        for (int i = 0; i < 9; ++i) ey[k][i] = (has && step) ? W[(size_t)ec * 9 + i] : 0.0;
         euv[k][0] = has ? e_uv[2 * (size_t)ec] : 0.0;
         euv[k][1] = has ? e_uv[2 * (size_t)ec + 1] : 0.0;
 #pragma unroll
@@ -1855,12 +1576,16 @@ __device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, d
 #pragma unroll
         for (int i = 0; i < 3; ++i) ep[k][i] = step ? xp[3 * kf + i] : 0.0;
     }
-    double lw0[3] = {0, 0, 0}, zz[3] = {0, 0, 0}, blv[3] = {0, 0, 0};
+    double lw0[3] = {0, 0, 0}, zz[3] = {0, 0, 0}, blv[3] = {0, 0, 0}, av[6] = {0, 0, 0, 0, 0, 0};
     if (l < L) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             lw0[c] = lms[(size_t)l * 3 + c];
-            if (step) { zz[c] = z[(size_t)l * 3 + c]; blv[c] = bl[(size_t)l * 3 + c]; }
+            if (step) { zz[c] = zeta[(size_t)l * 3 + c]; blv[c] = bl[(size_t)l * 3 + c]; }
+        }
+        if (step) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) av[c] = Ainv[(size_t)l * 6 + c];
         }
     }
     if (l < L && step) {
@@ -1872,7 +1597,7 @@ __device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, d
             }
         for (int e = beg + sub + KS * kGroup; e < end; e += kGroup) {
             const int kf = e_kf[e];
-            const double* y = Y + (size_t)e * 9;
+            const double* y = W + (size_t)e * 9;
             const double p0 = xp[3 * kf], p1 = xp[3 * kf + 1], p2 = xp[3 * kf + 2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) x[c] -= y[c] * p0 + y[3 + c] * p1 + y[6 + c] * p2;
@@ -1880,20 +1605,16 @@ __device__ __forceinline__ void d_update(const unsigned bx, CamDev cam, int L, d
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) x[c] = group_sum(x[c]);
-    if (Dinv && l < L && step) {   // x holds -sum_e Hpl_e^T dp_e
-        const double* dl = Dinv + (size_t)l * 6;
-        const double t0 = x[0], t1 = x[1], t2 = x[2];
-        x[0] = dl[0] * t0 + dl[1] * t1 + dl[2] * t2;
-        x[1] = dl[1] * t0 + dl[3] * t1 + dl[4] * t2;
-        x[2] = dl[2] * t0 + dl[4] * t1 + dl[5] * t2;
+    if (l < L && step) {   // x holds -sum_e W_e^T dp_e:  x_l = A^T (zeta + x)
+        const double t0 = zz[0] + x[0], t1 = zz[1] + x[1], t2 = zz[2] + x[2];
+        x[0] = av[0] * t0 + av[1] * t1 + av[3] * t2;
+        x[1] = av[2] * t1 + av[4] * t2;
+        x[2] = av[5] * t2;
     }
     if (l < L) {
         double lw[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            if (step) x[c] += zz[c];
-            lw[c] = lw0[c] + x[c];
-        }
+        for (int c = 0; c < 3; ++c) lw[c] = lw0[c] + x[c];
         if (sub == 0 && step) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -1948,12 +1669,12 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
                                                     const double* __restrict__ e_info,
                                                     const double* __restrict__ poses,
                                                     const uint8_t* __restrict__ fixed, const double* __restrict__ lms,
-                                                    const double* __restrict__ xp, const double* __restrict__ z,
-                                                    const double* __restrict__ Y, const double* __restrict__ bl,
+                                                    const double* __restrict__ xp, const double* __restrict__ zeta,
+                                                    const double* __restrict__ W, const double* __restrict__ bl,
                                                     double* __restrict__ lms_trial, double* __restrict__ part,
                                                     const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
-                                                    FinArgs fin, const double* __restrict__ Dinv) {
-    d_update(blockIdx.x, cam, L, lambda, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, xp, z, Y, bl, lms_trial, part, ctl, poses_b, fin, Dinv);
+                                                    FinArgs fin, const double* __restrict__ Ainv) {
+    d_update(blockIdx.x, cam, L, lambda, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, xp, zeta, W, bl, lms_trial, part, ctl, poses_b, fin, Ainv);
 }
 
 // One step of g2o's OptimizationAlgorithmLevenberg::solve / OptimizationAlgorithmGaussNewton on the controller block, run
@@ -3252,11 +2973,6 @@ struct se2gpu_ba {
     hipEvent_t join_event = nullptr;
     hipStream_t join_stream = nullptr;
     bool own_pending = false;      // se2gpu_ba_reset_estimates enqueued copies on the handle's own stream that nobody has waited for
-    // slim layout (model 0): k_reduce_rows instead of the pair plan's k_reduce2; no per-edge Y / Dg records
-    bool slim = false;
-    int rows_waves = 4;            // waves per workgroup of k_reduce_rows
-    size_t rows_lds = 0;           // its dynamic LDS bytes
-    DevBuf<int4> pose_visit;       // per pose slot: {edge, first edge of its landmark, observers, landmark}
     int P = 0, L = 0, E = 0, O = 0, nblk = 0, nparts = 0;
     int ld = 0;              // leading dimension = padded order of the augmented reduced system
     bool host_solve = false; // SE2GPU_BA_HOST_SOLVE=1: factorise on the host instead (north-star wording)
@@ -4287,7 +4003,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     SE2_CHECK(h->lms_a.reserve(3 * (size_t)L + 1));
     SE2_CHECK(h->lms_b.reserve(3 * (size_t)L + 1));
     SE2_CHECK(h->Hpl.reserve((size_t)D * 3 * E + 1));
-    SE2_CHECK(h->Y.reserve((size_t)D * 3 * E + 1));
+    if (h->model) SE2_CHECK(h->Y.reserve((size_t)D * 3 * E + 1));   // (the SE(2) model's whitened records need no Y_e)
     SE2_CHECK(h->Hpp_e.reserve((size_t)DS * E + 1));
     SE2_CHECK(h->bp_e.reserve((size_t)D * E + 1));
     SE2_CHECK(h->Dg.reserve((size_t)(DS + 2 * D) * E + 1));
@@ -4505,33 +4221,6 @@ int ba_upload_graph(se2gpu_ba* h) {
         lap("plan kernels enqueued");
     }
     SE2_HIP(hipStreamWaitEvent(st, h->ev_copy1, 0));   // measurements / information are in place before anything later runs
-    // ---- slim layout of the SE(2) model: k_reduce_rows walks every pose's edges and, per edge, the landmark's run of edge
-    // blocks; the visit records spare it two levels of indices.  Built from the plan's pose -> edge list (on the device).
-    {
-        // Measured (profiles/r03_slim_reduce_rows_experiment.txt): correct (all parity tests, bit-identical batches) but SLOWER
-        // than the pair plan - k_linearize 22 -> 16 us, k_schur_lm 16 -> 7 us, but k_reduce_rows 122 us against k_reduce2's
-        // 29 us at 200 key frames (1007 against 294 us for 64 windows): forming Y_e row x Hpl_b row per (visit, observer)
-        // costs ~190 instructions per visit for ~50 useful lanes, and the kernel is bound by instruction issue, not by the
-        // gathers it was designed around.  Kept behind SE2GPU_BA_SLIM=1 as the measured alternative; off by default.
-        static const bool slim_on = [] { const char* e = getenv("SE2GPU_BA_SLIM"); return e && e[0] == '1'; }();
-        const size_t per_wave = (size_t)P * 72;
-        h->slim = slim_on && h->model == 0 && E > 0 && per_wave + 2048 <= 120 * 1024;
-        if (h->slim) {
-            int W = (int)std::min<size_t>(8, std::max<size_t>(1, (120 * 1024 - 2048) / per_wave));
-            // (no more waves than a pose has visits to deal out: a local window's poses have a few hundred edges each)
-            while (W > 1 && (size_t)E / (size_t)std::max(P, 1) < (size_t)4 * W) W >>= 1;
-            h->rows_waves = W;
-            h->rows_lds = ((size_t)W * P * 9 + (size_t)W * 8 + 8 * 24) * sizeof(double);
-            static std::once_flag once;
-            std::call_once(once, [] {
-                (void)hipFuncSetAttribute((const void*)k_reduce_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-            });
-            SE2_CHECK(h->pose_visit.reserve((size_t)E));
-            hipLaunchKernelGGL(k_plan_visits, grid1(E, 256), dim3(256), 0, st, E, h->pose_edges.p, h->e_lm.p, h->lm_ptr.p,
-                               h->pose_visit.p);
-            SE2_HIP(hipGetLastError());
-        }
-    }
     SE2_CHECK(h->fin_counter.reserve(1));
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
     SE2_CHECK(h->l0_acc.reserve(2));
@@ -4565,7 +4254,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     // ---- the dense pose solve: order of the poses, tile tasks, dependency lists (solve_plan_choose), then its buffers
     {
         std::vector<uint8_t> pat;
-        if (nd_possible && !h->slim) {
+        if (nd_possible) {
             const uint8_t* nz = device_plan ? h->h_plan_nz.p : pl.blk_nz.data();
             pat.assign((size_t)P * P, 0);
             for (int a = 0; a < P; ++a) {
@@ -4679,9 +4368,8 @@ inline Bufs bufs(se2gpu_ba* h, bool ctl) {
     return Bufs{nullptr, h->poses, h->poses_t, h->lms, h->lms_t};
 }
 
-// slim layout: k_update reads the edge blocks Hpl_e where it read Y_e, and applies Dinv_l after the sum
-inline const double* ba_y(const se2gpu_ba* h) { return h->slim ? h->Hpl.p : h->Y.p; }
-inline const double* ba_dinv_slim(const se2gpu_ba* h) { return h->slim ? h->Dinv.p : nullptr; }
+// SE(2) model (whitened records, k_linearize): h->Hpl holds W_e, h->Dinv the inverse Cholesky factors A_l, h->z the zeta_l;
+// h->Y is not used.  The SE3-expmap model keeps Hpl / Y / Dinv / z as named.
 
 // linearise at the current state: Hpl, Hpp_e, bp_e, Hll, bl; with fuse_lambda >= 0 (or fused && ctl) also Dinv, z, Y
 int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
@@ -4710,16 +4398,14 @@ int ba_linearize(se2gpu_ba* h, double fuse_lambda, bool ctl = false) {
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
-    double* const Yw = h->slim ? nullptr : h->Y.p;     // slim layout: no per-edge Y / Dg records
-    double* const Dgw = h->slim ? nullptr : h->Dg.p;
     if (fuse_lambda >= 0.0)
         SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<true>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, fuse_lambda, h->Dinv.p, h->z.p, h->Dg.p, B.c, B.pb, B.lb);
     else
-        SE2_LAUNCH(h->prof, st, "k_linearize", (k_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
+        SE2_LAUNCH(h->prof, st, "k_linearize0", (k_linearize<false>), grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0,
                    h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Dg.p, B.c, B.pb, B.lb);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -4749,7 +4435,7 @@ int ba_pose_blocks(se2gpu_ba* h, const double* poses, bool ctl = false, bool odo
 }
 
 // reduced system for damping lambda into h->red (local contribution of this rank).
-// schur: 0 = Dinv / z / Y are current, 1 = recompute them (k_schur_lm), 2 = let the controller decide (retry), 3 = force
+// schur: 0 = the lambda-dependent records are current, 1 = recompute them, 2 = let the controller decide (retry; SE3 model), 3 = force
 int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
     hipStream_t st = h->stream;
     double* S = h->red;
@@ -4768,18 +4454,11 @@ int ba_reduce(se2gpu_ba* h, double lambda, int schur, bool ctl = false) {
         SE2_HIP(hipGetLastError());
         return SE2GPU_OK;
     }
-    if (schur)
-        SE2_LAUNCH(h->prof, st, "k_schur_lm", k_schur_lm, grid1((size_t)h->L * kGroup, kBlock), dim3(kBlock), 0, h->L,
-                   lambda, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p,
-                   h->slim ? (double*)nullptr : h->Y.p, h->slim ? (double*)nullptr : h->Dg.p, B.c, schur == 2 ? 0 : 1);
-    if (h->slim)
-        SE2_LAUNCH(h->prof, st, "k_reduce_rows", k_reduce_rows, dim3(h->P + 1), dim3(64 * h->rows_waves), h->rows_lds, h->P, h->ld,
-                   lambda, h->root, h->odo_fallback ? 0 : 1, h->rows_waves, h->pose_ptr.p, h->pose_visit.p, h->e_kf.p, h->Hpl.p, h->Hpp_e.p,
-                   h->bp_e.p, h->Dinv.p, h->z.p, h->fixed.p, h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p,
-                   h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb, &h->ctl.p->epoch);
-    else
+    // the per-edge records depend on lambda: a new damping on the same linearisation (first trial after lambda_0, a retry
+    // the host knows about) runs the fused linearisation again - same estimate, same code, identical blocks
+    if (schur) SE2_CHECK(ba_linearize(h, lambda, ctl));
     SE2_LAUNCH(h->prof, st, "k_reduce2", k_reduce2, dim3(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7)), dim3(kBlock), 0, h->P, h->ld, h->nwg_off,
-               lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p,
+               lambda, h->root, h->grp.p, h->blk_a.p, h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p,
                h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p, h->pose_edges.p,
                h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, S, h->bp.p, B.c, B.pb,
                &h->ctl.p->epoch, (const int*)h->pose_off.p, h->nsys);
@@ -4887,14 +4566,14 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
                     h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, scal, h->d_mail, seq, (BaCtl*)nullptr,
                     (const volatile int*)nullptr, h->fin_counter.p};
         SE2_LAUNCH(h->prof, st, "k_update", k_update, dim3(ug.x + 1), dim3(kBlock), 0, h->cam, h->L, lambda, h->lm_ptr.p,
-                   h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p, ba_y(h), h->bl.p, h->lms_t,
-                   h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, fin, ba_dinv_slim(h));
+                   h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p, (const double*)h->Hpl.p, h->bl.p, h->lms_t,
+                   h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, fin, (const double*)h->Dinv.p);
         SE2_HIP(hipGetLastError());
         return ba_wait_mail(h, seq);
     }
     SE2_LAUNCH(h->prof, st, "k_update", k_update, ug, dim3(kBlock), 0, h->cam, h->L,
                lambda, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, h->poses, h->fixed.p, h->lms, xp, h->z.p,
-               ba_y(h), h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, FinArgs{}, ba_dinv_slim(h));
+               (const double*)h->Hpl.p, h->bl.p, h->lms_t, h->part.p, (const BaCtl*)nullptr, (const double*)nullptr, FinArgs{}, (const double*)h->Dinv.p);
     SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                lambda, h->poses, h->fixed.p, xp, h->bp.p, h->poses_t, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                h->o_info.p, h->root, scal, (volatile double*)nullptr, seq, (BaCtl*)nullptr, xp ? 1 : 0, 0, 0,
@@ -5062,14 +4741,14 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
                         (const volatile int*)h->d_stop, h->fin_counter.p};
             SE2_LAUNCH(h->prof, st, "k_update", k_update, dim3(ug.x + 1), dim3(kBlock), 0, h->cam, h->L, 0.0, h->lm_ptr.p,
                        h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, step ? h->xp.p : (const double*)nullptr,
-                       h->z.p, ba_y(h), h->bl.p, B.lb, h->part.p, B.c, B.pb, fin, ba_dinv_slim(h));
+                       h->z.p, (const double*)h->Hpl.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, fin, (const double*)h->Dinv.p);
             SE2_HIP(hipGetLastError());
             return SE2GPU_OK;
         }
         SE2_LAUNCH(h->prof, st, "k_update", k_update, ug, dim3(kBlock), 0, h->cam, h->L,
                    0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
-                   step ? h->xp.p : (const double*)nullptr, h->z.p, ba_y(h), h->bl.p, B.lb, h->part.p, B.c, B.pb, FinArgs{},
-                   ba_dinv_slim(h));
+                   step ? h->xp.p : (const double*)nullptr, h->z.p, (const double*)h->Hpl.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, FinArgs{},
+                   (const double*)h->Dinv.p);
         SE2_LAUNCH(h->prof, st, "k_finalize", k_finalize, dim3(1), dim3(1024), 0, h->L ? h->nparts : 0, h->part.p, h->P,
                    0.0, B.pa, h->fixed.p, h->xp.p, h->bp.p, B.pb, h->O, h->o_i.p, h->o_j.p, h->o_meas.p,
                    h->o_info.p, h->root, scal, h->d_mail, seq, h->ctl.p, step ? 1 : 0, sharded ? 0 : 1, note ? 1 : 0,
@@ -5094,7 +4773,7 @@ int ba_enqueue_trial(se2gpu_ba* h, bool first, int know_retry, bool notify, doub
         }
     } else {
         if (know_retry != 1) SE2_CHECK(ba_linearize(h, 0.0, true));
-        // (model 0: an undecided slot needs no k_schur_lm of its own, k_linearize<FUSED> redoes the lambda part on a retry)
+        // (model 0: an undecided slot needs nothing of its own for a retry - k_linearize<FUSED> runs again with the new lambda)
         SE2_CHECK(ba_reduce(h, 0.0, !lm ? 0 : know_retry == 0 ? 0 : know_retry == 1 ? 3 : (h->model ? 2 : 0), true));
     }
     SE2_CHECK(ba_allreduce_system(h));
@@ -5172,12 +4851,7 @@ struct BatchPlan {
     BatchKernel<d_odometry, 64> odo;
     BatchKernel<d_pose_reduce, kBlock> pose_reduce;
     BatchKernel<d_maxdiag, 1024> maxdiag;
-    BatchKernel<d_schur_lm, kBlock> schur;
     BatchKernel<d_reduce2, kBlock> reduce2;
-    BatchKernel<d_reduce_rows, 512> reduce_rows;    // launched with 64 x rows_waves threads and dynamic LDS
-    bool slim = false;
-    int rows_waves = 16;
-    size_t rows_lds = 0;
     BatchKernel<d_chol_tiles<true>, 256> chol_seed;
     BatchKernel<d_chol_tiles<false>, 256> chol_plain;
     std::vector<hipEvent_t> events;
@@ -5206,13 +4880,8 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
     bp.stream = hs[0]->stream;
     static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
     bp.seed = seed;
-    bp.slim = hs[0]->slim;
-    bp.rows_waves = 1;
-    bp.rows_lds = 0;
-    for (int w = 0; w < count; ++w) bp.rows_waves = std::max(bp.rows_waves, hs[w]->rows_waves);
     for (int w = 0; w < count; ++w) {
         se2gpu_ba* h = hs[w];
-        bp.rows_lds = std::max(bp.rows_lds, h->rows_lds);
         bp.serials[w] = h->init_serial;
         const Bufs B = bufs(h, true);
         double* scal = h->red + (size_t)h->ld * h->ld;
@@ -5225,33 +4894,23 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
         };
         auto upd = [&](auto& k, int step, int notify) {
             k.add((int)ug.x + 1, h->cam, h->L, 0.0, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la,
-                  step ? h->xp.p : (const double*)nullptr, h->z.p, ba_y(h), h->bl.p, B.lb, h->part.p, B.c, B.pb, fin(step, notify),
-                  ba_dinv_slim(h));
+                  step ? h->xp.p : (const double*)nullptr, h->z.p, (const double*)h->Hpl.p, h->bl.p, B.lb, h->part.p, B.c, B.pb, fin(step, notify),
+                  (const double*)h->Dinv.p);
         };
         upd(bp.eval0, 0, 0);
         upd(bp.step, 1, 0);
         upd(bp.step_notify, 1, 1);
-        double* const Yw = h->slim ? nullptr : h->Y.p;
-        double* const Dgw = h->slim ? nullptr : h->Dg.p;
         bp.lin0.add((int)ug.x, h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
-                    h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
+                    h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Dg.p, B.c, B.pb, B.lb);
         bp.lin.add((int)ug.x, h->cam, h->L, h->lm_ptr.p, h->e_kf.p, h->e_uv.p, h->e_info.p, B.pa, h->fixed.p, B.la, h->Hpl.p,
-                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, Yw, Dgw, B.c, B.pb, B.lb);
+                   h->Hpp_e.p, h->bp_e.p, h->Hll.p, h->bl.p, 0.0, h->Dinv.p, h->z.p, h->Dg.p, B.c, B.pb, B.lb);
         bp.odo.add(h->O ? (int)grid1(h->O, 64).x : 0, h->O, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, h->poses_a.p, h->fixed.p,
                    h->Oii.p, h->Ojj.p, h->Oij.p, h->obi.p, h->obj.p, (const BaCtl*)h->ctl.p, (const double*)h->poses_b.p);
         bp.pose_reduce.add((int)grid1((size_t)h->P * 64, kBlock).x, h->P, h->pose_ptr.p, h->pose_edges.p, h->Hpp_e.p, h->bp_e.p,
                            h->podo_ptr.p, h->podo_item.p, h->Oii.p, h->Ojj.p, h->obi.p, h->obj.p, h->Hpp.p, h->bp.p);
         bp.maxdiag.add(1, h->L, h->Hll.p, h->P, h->Hpp.p, h->fixed.p, h->scal.p, 3, 1, h->ctl.p);
-        bp.schur.add((int)ug.x, h->L, 0.0, h->lm_ptr.p, h->Hll.p, h->bl.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p,
-                     Yw, Dgw, B.c, 1);
-        if (bp.slim)
-            bp.reduce_rows.add(h->P + 1, h->P, h->ld, 0.0, h->root, h->odo_fallback ? 0 : 1, h->rows_waves, h->pose_ptr.p, h->pose_visit.p,
-                               h->e_kf.p, h->Hpl.p, h->Hpp_e.p, h->bp_e.p, h->Dinv.p, h->z.p, h->fixed.p, h->podo_ptr.p,
-                               h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, h->red, h->bp.p, B.c, B.pb,
-                               &h->ctl.p->epoch);
-        else
         bp.reduce2.add(((h->P + 1 + 7) & ~7) + ((h->nwg_off + 7) & ~7), h->P, h->ld, h->nwg_off, 0.0, h->root, h->grp.p, h->blk_a.p,
-                       h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Y.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p,
+                       h->blk_b.p, h->pair_i.p, h->pair_j.p, h->blk_odo.p, h->Hpl.p, h->Dg.p, h->fixed.p, h->pose_ptr.p,
                        h->pose_edges.p, h->podo_ptr.p, h->podo_item.p, h->o_i.p, h->o_j.p, h->o_meas.p, h->o_info.p, B.pa, h->red,
                        h->bp.p, B.c, B.pb, &h->ctl.p->epoch, (const int*)h->pose_off.p, h->nsys);
         {
@@ -5276,13 +4935,7 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
     }
     bp.ctl_init.commit(bp.arena); bp.eval0.commit(bp.arena); bp.step.commit(bp.arena); bp.step_notify.commit(bp.arena);
     bp.lin0.commit(bp.arena); bp.lin.commit(bp.arena); bp.odo.commit(bp.arena); bp.pose_reduce.commit(bp.arena);
-    bp.maxdiag.commit(bp.arena); bp.schur.commit(bp.arena); bp.reduce2.commit(bp.arena); bp.reduce_rows.commit(bp.arena);
-    if (bp.slim) {
-        static std::once_flag once;
-        std::call_once(once, [] {
-            (void)hipFuncSetAttribute(decltype(bp.reduce_rows)::kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        });
-    }
+    bp.maxdiag.commit(bp.arena); bp.reduce2.commit(bp.arena);
     bp.chol_seed.commit(bp.arena); bp.chol_plain.commit(bp.arena);
     SE2_CHECK(bp.arena.dev.reserve(bp.arena.host.size()));
     SE2_HIP(hipMemcpyAsync(bp.arena.dev.p, bp.arena.host.data(), bp.arena.host.size(), hipMemcpyHostToDevice, bp.stream));
@@ -5306,15 +4959,14 @@ int ba_batch_slot(const BatchPlan& bp, bool first, bool notify) {
             bp.odo.launch(ar, st);
             bp.pose_reduce.launch(ar, st);
             bp.maxdiag.launch(ar, st);
-            bp.schur.launch(ar, st);
+            bp.lin.launch(ar, st);     // the records at lambda_0 (the fused pass again: same estimate, identical blocks)
         } else {
             bp.lin.launch(ar, st);
         }
     } else {
         bp.lin.launch(ar, st);
     }
-    if (bp.slim) bp.reduce_rows.launch(ar, st, 64 * bp.rows_waves, bp.rows_lds);
-    else bp.reduce2.launch(ar, st);
+    bp.reduce2.launch(ar, st);
     if (bp.seed) bp.chol_seed.launch(ar, st);
     else bp.chol_plain.launch(ar, st);
     (notify ? bp.step_notify : bp.step).launch(ar, st);
@@ -6245,7 +5897,7 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
     if (!on || count < 2 || ba_env_sync() || iters < 0) return SE2GPU_OK;
     if (mode != SE2GPU_BA_LM && mode != SE2GPU_BA_GN) return SE2GPU_OK;
     for (int i = 0; i < count; ++i)
-        if (!ba_lockstep_ok(hs[i]) || hs[i]->device != hs[0]->device || hs[i]->slim != hs[0]->slim) return SE2GPU_OK;
+        if (!ba_lockstep_ok(hs[i]) || hs[i]->device != hs[0]->device) return SE2GPU_OK;
     for (int i = 0; i < count; ++i)
         for (int j = 0; j < i; ++j)
             if (hs[i] == hs[j]) return SE2GPU_OK;
