@@ -645,36 +645,45 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
         // fetched into one L2 instead of all eight (measured: 178 MB of HBM traffic per launch for 51 MB of operands).
         const int wg = (bid & 7) * (nwg_pad >> 3) + (bid >> 3);
         if (wg >= nwg_off) return;
-        const int g = threadIdx.x / 9, en = threadIdx.x - 9 * g;
+        // 7 groups of 9 lanes per wave (lane 63 idles), 4 waves: the 9 lanes of a group share their loads through
+        // ds_bpermute, so a group must not straddle two waves
+        const int lane = threadIdx.x & 63, gw = lane / 9, en = lane - 9 * gw;
+        const int g = gw < 7 ? (int)(threadIdx.x >> 6) * 7 + gw : kGrpPerWG;
         int4 d = make_int4(-1, 0, 0, 0);
         if (g < kGrpPerWG) d = grp[(size_t)wg * kGrpPerWG + g];
         const int r = en / 3, c = en - 3 * r;
         double acc0 = 0, acc1 = 0;
         if (d.x >= 0) {
-            // The gather is a dependent chain (pair index -> edge row), i.e. latency bound: eight pairs per round, all
-            // sixteen index loads in flight first, then all 48 operand loads.  Slots past the chunk are clamped to its
-            // last pair and weighted 0 (no branches inside the round).
+            // The gather is a dependent chain (pair index -> edge block), i.e. latency bound, and what it costs is L1 accesses
+            // (counters, round 4: 21 cache-line accesses per load instruction, the L1 tag rate is the kernel's bound).  So the
+            // group loads every word ONCE: lane t < 8 fetches the indices of pair t of the round, lane t the t-th word of both
+            // 72-byte blocks of every pair (18 load instructions per round of 8 pairs instead of 64), and the row of W_i /
+            // row of W_j an entry needs comes from the neighbours' registers (ds_bpermute).  Slots past the chunk are
+            // clamped to its last pair and weighted 0 (no branches inside the round).  Same products, same order of the sums.
+            const int gb = 9 * gw;
             for (int q = d.y; q < d.z; q += 8) {
-                int ia[8], ib[8];
+                const int qq = min(q + min(en, 7), d.z - 1);
+                const int my_i = pair_i[qq], my_j = pair_j[qq];
+                double wi[8], wj[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int qq = min(q + u, d.z - 1);
-                    ia[u] = pair_i[qq];
-                    ib[u] = pair_j[qq];
-                }
-                double yv[8][3], hv[8][3];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double* y = W + (size_t)ia[u] * 9 + 3 * r;
-                    const double* hh = W + (size_t)ib[u] * 9 + 3 * c;
-                    yv[u][0] = y[0]; yv[u][1] = y[1]; yv[u][2] = y[2];
-                    hv[u][0] = hh[0]; hv[u][1] = hh[1]; hv[u][2] = hh[2];
+                    const int ia = __shfl(my_i, gb + u), ib = __shfl(my_j, gb + u);
+                    wi[u] = W[(size_t)ia * 9 + en];
+                    wj[u] = W[(size_t)ib * 9 + en];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u += 2) {
                     const double w0 = (q + u < d.z) ? 1.0 : 0.0, w1 = (q + u + 1 < d.z) ? 1.0 : 0.0;
-                    acc0 += w0 * (yv[u][0] * hv[u][0] + yv[u][1] * hv[u][1] + yv[u][2] * hv[u][2]);
-                    acc1 += w1 * (yv[u + 1][0] * hv[u + 1][0] + yv[u + 1][1] * hv[u + 1][1] + yv[u + 1][2] * hv[u + 1][2]);
+                    double y[2][3], hh[2][3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        y[0][k] = __shfl(wi[u], gb + 3 * r + k);
+                        hh[0][k] = __shfl(wj[u], gb + 3 * c + k);
+                        y[1][k] = __shfl(wi[u + 1], gb + 3 * r + k);
+                        hh[1][k] = __shfl(wj[u + 1], gb + 3 * c + k);
+                    }
+                    acc0 += w0 * (y[0][0] * hh[0][0] + y[0][1] * hh[0][1] + y[0][2] * hh[0][2]);
+                    acc1 += w1 * (y[1][0] * hh[1][0] + y[1][1] * hh[1][1] + y[1][2] * hh[1][2]);
                 }
             }
             part[g][en] = acc0 + acc1;
