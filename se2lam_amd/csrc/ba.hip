@@ -603,7 +603,7 @@ __device__ inline void odo_terms(const double* poses, const uint8_t* fixed, cons
 }
 
 constexpr int kGrpPerWG = 28;   // 9-lane groups per 256-thread workgroup (252 lanes used)
-constexpr int kChunk = 16;      // contributor pairs per group
+constexpr int kChunk = 16;      // contributor pairs per group (d_reduce2 keeps the indices of two rounds of 8 per lane)
 
 // Off-diagonal part: workgroup w owns the groups [w*28, w*28+28) of the host-built plan.  A group = 9 lanes (one per
 // entry of a 3x3 block) accumulating one chunk of <= kChunk contributor pairs of ONE reduced-system block; blocks
@@ -623,11 +623,6 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                                                      double* __restrict__ S, double* __restrict__ bp,
                                                      const BaCtl* __restrict__ ctl, const double* __restrict__ poses_b,
                                                      unsigned* __restrict__ epoch, const int* __restrict__ pose_off, int nsys) {
-    if (ctl) {
-        if (ctl->done) return;
-        if (ctl->sel) poses = poses_b;
-        lambda = ctl->lambda;
-    }
     // pose p's three unknowns live in the columns pose_off[p] .. + 2 of the system (the solver's fill-reducing order, with
     // identity padding between its partitions: solve_plan_build); nullptr = natural order, 3 p
     const int n = pose_off ? nsys : 3 * P;
@@ -641,7 +636,7 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
         const int bid = (int)bx - ndiag;
         const int nwg_pad = (nwg_off + 7) & ~7;
         // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2).  The plan is ordered
-        // by pose block row, so XCD x takes the x-th CONTIGUOUS eighth of it: the Y / Hpl rows of its pose range are
+        // by pose block row, so XCD x takes the x-th CONTIGUOUS eighth of it: the W rows of its pose range are
         // fetched into one L2 instead of all eight (measured: 178 MB of HBM traffic per launch for 51 MB of operands).
         const int wg = (bid & 7) * (nwg_pad >> 3) + (bid >> 3);
         if (wg >= nwg_off) return;
@@ -649,21 +644,46 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
         // ds_bpermute, so a group must not straddle two waves
         const int lane = threadIdx.x & 63, gw = lane / 9, en = lane - 9 * gw;
         const int g = gw < 7 ? (int)(threadIdx.x >> 6) * 7 + gw : kGrpPerWG;
+        // A workgroup is one chain of dependent loads (controller -> group -> pair indices -> edge blocks -> block descriptor
+        // -> fixed flags / columns -> store) around a few dozen multiply-adds; with ~9 us per wave and 16 waves per CU the
+        // chain, not a bandwidth, is what a window batch pays for (counters, round 4).  So every link is requested as early
+        // as its address is known: the group descriptor beside the controller block, the block descriptor and the indices of
+        // ALL pairs of the chunk beside each other, the fixed flags and columns beside the edge blocks.
         int4 d = make_int4(-1, 0, 0, 0);
         if (g < kGrpPerWG) d = grp[(size_t)wg * kGrpPerWG + g];
+        if (ctl) {
+            if (ctl->done) return;
+            if (ctl->sel) poses = poses_b;
+        }
         const int r = en / 3, c = en - 3 * r;
         double acc0 = 0, acc1 = 0;
+        int a = 0, b = 0, od = -1, ca = 0, cb = 0;
+        bool free_ab = false;
         if (d.x >= 0) {
-            // The gather is a dependent chain (pair index -> edge block), i.e. latency bound, and what it costs is L1 accesses
-            // (counters, round 4: 21 cache-line accesses per load instruction, the L1 tag rate is the kernel's bound).  So the
-            // group loads every word ONCE: lane t < 8 fetches the indices of pair t of the round, lane t the t-th word of both
-            // 72-byte blocks of every pair (18 load instructions per round of 8 pairs instead of 64), and the row of W_i /
-            // row of W_j an entry needs comes from the neighbours' registers (ds_bpermute).  Slots past the chunk are
-            // clamped to its last pair and weighted 0 (no branches inside the round).  Same products, same order of the sums.
-            const int gb = 9 * gw;
+            // lane t < 8 of the group holds the indices of pairs t and 8 + t of sixteen pairs (a chunk is kChunk = 16 pairs unless
+            // its block has more than 28 chunks' worth); slots past the chunk are clamped to its last pair and weighted 0 (no
+            // branches inside a round)
+            const int gb = 9 * gw, t8 = min(en, 7);
+            int q0 = min(d.y + t8, d.z - 1), q1 = min(d.y + 8 + t8, d.z - 1);
+            int my_i0 = 0, my_j0 = 0, my_i1 = 0, my_j1 = 0;
+            if (d.z > d.y) { my_i0 = pair_i[q0]; my_j0 = pair_j[q0]; my_i1 = pair_i[q1]; my_j1 = pair_j[q1]; }
+            a = blk_a[d.x];
+            b = blk_b[d.x];
+            od = blk_odo[d.x];
+            free_ab = !fixed[a] && !fixed[b];      // (a block may have no pairs at all - an odometry edge only)
+            ca = pose_off ? pose_off[a] : 3 * a;
+            cb = pose_off ? pose_off[b] : 3 * b;
+            // The group loads every word ONCE (counters: 21 L1 accesses per load instruction with one row per lane): lane t
+            // the t-th word of both 72-byte blocks of every pair (16 load instructions per round of 8 pairs instead of 48),
+            // and the row of W_i / row of W_j an entry needs comes from the neighbours' registers (ds_bpermute).
+            // Same products, same order of the sums as one row per lane.
             for (int q = d.y; q < d.z; q += 8) {
-                const int qq = min(q + min(en, 7), d.z - 1);
-                const int my_i = pair_i[qq], my_j = pair_j[qq];
+                const bool second = ((q - d.y) & 8) != 0;
+                if (!second && q != d.y) {   // a long chunk: the indices of its next sixteen pairs
+                    q0 = min(q + t8, d.z - 1); q1 = min(q + 8 + t8, d.z - 1);
+                    my_i0 = pair_i[q0]; my_j0 = pair_j[q0]; my_i1 = pair_i[q1]; my_j1 = pair_j[q1];
+                }
+                const int my_i = second ? my_i1 : my_i0, my_j = second ? my_j1 : my_j0;
                 double wi[8], wj[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -693,11 +713,9 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
             const int ng = d.w >> 8;
             double tot = 0;
             for (int t = 0; t < ng; ++t) tot += part[g + t][en];
-            const int a = blk_a[d.x], b = blk_b[d.x];
             double out = 0.0;
-            if (!fixed[a] && !fixed[b]) {
+            if (free_ab) {
                 out = -tot;
-                const int od = blk_odo[d.x];
                 if (od >= 0) {  // PreEdgeSE2 between a and b: A^T W B (transposed when the edge runs b -> a)
                     double e[3], A[9], B[9], WA[9], WB[9], omr[3];
                     odo_terms(poses, fixed, o_i, o_j, o_meas, o_info, od >> 1, e, A, B, WA, WB, omr);
@@ -710,11 +728,15 @@ __device__ __forceinline__ void d_reduce2(const unsigned bx, int P, int ld, int 
                     out += a0 * b0 + a1 * b1 + a2 * b2;
                 }
             }
-            const int ca = pose_off ? pose_off[a] : 3 * a, cb = pose_off ? pose_off[b] : 3 * b;
             S[(size_t)(ca + r) * ld + cb + c] = out;
             S[(size_t)(cb + c) * ld + ca + r] = out;
         }
         return;
+    }
+    if (ctl) {
+        if (ctl->done) return;
+        if (ctl->sel) poses = poses_b;
+        lambda = ctl->lambda;
     }
     // ---- diagonal part: one workgroup per pose (+ one that clears the padding)
     const int p = (int)bx;
@@ -4813,6 +4835,26 @@ __global__ __launch_bounds__(BS) void k_batched(const Packed<A...>* __restrict__
     if ((int)blockIdx.x >= x.nblk) return;
     std::apply([&](const A&... a) { Body(blockIdx.x, a...); }, x.args);
 }
+// The same with every window pinned to ONE XCD (round 4).  Workgroups are dealt to the 8 XCDs round-robin in dispatch order
+// (linear id mod 8), each XCD has its own 4 MB L2, and a kernel that re-reads a window's records (k_reduce2: every W_e is an
+// operand of ~5 pairs in different blocks) thrashes them when four windows' blocks pass through every L2 at once (counters:
+// 35 % L2 misses, twice the batch's footprint fetched from HBM).  Here XCD x takes the windows x, x + 8, ... one after the
+// other: the k-th workgroup of XCD x (k = linear id / 8) is block k mod nb of window 8 (k / nb) + x.  gridDim.x = nb is a
+// multiple of 8; windows beyond the last full eight take the plain mapping.  Inside a window the blocks are still
+// dispatched in increasing order.
+template <auto Body, int BS, typename... A>
+__global__ __launch_bounds__(BS) void k_batched_xcd(const Packed<A...>* __restrict__ p) {
+    const unsigned nb = gridDim.x, nw8 = gridDim.y & ~7u;
+    unsigned w = blockIdx.y, bx = blockIdx.x;
+    if (w < nw8) {
+        const unsigned lin = w * nb + bx, k = lin >> 3;
+        w = 8 * (k / nb) + (lin & 7);
+        bx = k % nb;
+    }
+    const Packed<A...>& x = p[w];
+    if ((int)bx >= x.nblk) return;
+    std::apply([&](const A&... a) { Body(bx, a...); }, x.args);
+}
 
 // the argument packs of one kernel for all windows of a batch; they live in the plan's arena (one upload per plan)
 struct BatchArena {
@@ -4842,6 +4884,11 @@ struct BatchKernel<Body, BS> {
         if (packs.empty() || maxblk <= 0) return;
         hipLaunchKernelGGL((k_batched<Body, BS, std::remove_cv_t<A>...>), dim3((unsigned)maxblk, (unsigned)packs.size()), dim3(block),
                            shmem, st, reinterpret_cast<const P*>(ar.dev.p + off));
+    }
+    void launch_xcd(const BatchArena& ar, hipStream_t st) const {   // every window on one XCD (k_batched_xcd)
+        if (packs.empty() || maxblk <= 0) return;
+        hipLaunchKernelGGL((k_batched_xcd<Body, BS, std::remove_cv_t<A>...>), dim3((unsigned)((maxblk + 7) & ~7), (unsigned)packs.size()),
+                           dim3(BS), 0, st, reinterpret_cast<const P*>(ar.dev.p + off));
     }
     static const void* kernel() { return (const void*)k_batched<Body, BS, std::remove_cv_t<A>...>; }
 };
@@ -4975,7 +5022,9 @@ int ba_batch_slot(const BatchPlan& bp, bool first, bool notify) {
     } else {
         bp.lin.launch(ar, st);
     }
-    bp.reduce2.launch(ar, st);
+    static const bool pin = [] { const char* e = getenv("SE2GPU_BA_XCD_PIN"); return !(e && e[0] == '0'); }();
+    if (pin) bp.reduce2.launch_xcd(ar, st);
+    else bp.reduce2.launch(ar, st);
     if (bp.seed) bp.chol_seed.launch(ar, st);
     else bp.chol_plain.launch(ar, st);
     (notify ? bp.step_notify : bp.step).launch(ar, st);
