@@ -221,7 +221,9 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
     const int gid = bx * kBlock + threadIdx.x;
     const int l = gid / kGroup, sub = gid % kGroup;
     double hll[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-    double k_hpl[9], k_hpp[6], k_bp[3];   // the lane's first edge, kept for the second pass
+    // the lane's first edge waits for the second pass in LDS (18 doubles per lane, column = thread: conflict-free, no barrier -
+    // a lane reads back its own words); in registers they cost the kernel a wave of occupancy (186 VGPRs)
+    __shared__ double keep[18][kBlock];
     int beg = 0, end = 0;
     if (l < L) {
         const double lx = lms[3 * l], ly = lms[3 * l + 1], lz = lms[3 * l + 2];
@@ -270,11 +272,11 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
             for (int r = 0; r < 3; ++r) bpe[r] = fr ? Jp[r] * or0 + Jp[3 + r] * or1 : 0.0;
             if (FUSED && e == beg + sub) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) k_hpl[i] = hpl[i];
+                for (int i = 0; i < 9; ++i) keep[i][threadIdx.x] = hpl[i];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) k_hpp[i] = hpp[i];
+                for (int i = 0; i < 6; ++i) keep[9 + i][threadIdx.x] = hpp[i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) k_bp[i] = bpe[i];
+                for (int i = 0; i < 3; ++i) keep[15 + i][threadIdx.x] = bpe[i];
             } else {
                 // un-fused pass: the pose terms of every edge (lambda_0); fused pass: a lane's further edges wait in memory
                 // (landmarks with more than 8 observations) - the W slot holds the raw block until the second pass
@@ -311,7 +313,16 @@ __device__ __forceinline__ void d_linearize(const unsigned bx, CamDev cam, int L
 #pragma unroll
             for (int i = 0; i < 3; ++i) zeta[(size_t)l * 3 + i] = zt[i];
         }
-        if (beg + sub < end) write_edge_record(W + (size_t)(beg + sub) * 9, Dg + (size_t)(beg + sub) * 12, k_hpl, k_hpp, k_bp, a, zt);
+        if (beg + sub < end) {
+            double k_hpl[9], k_hpp[6], k_bp[3];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) k_hpl[i] = keep[i][threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) k_hpp[i] = keep[9 + i][threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) k_bp[i] = keep[15 + i][threadIdx.x];
+            write_edge_record(W + (size_t)(beg + sub) * 9, Dg + (size_t)(beg + sub) * 12, k_hpl, k_hpp, k_bp, a, zt);
+        }
         for (int e = beg + sub + kGroup; e < end; e += kGroup) {   // written by this same lane above
             double hh[9], hp[6], bpe[3];
 #pragma unroll
