@@ -1,0 +1,399 @@
+// ORACLE - TEST INFRASTRUCTURE ONLY (oracle/_ref).  Never compiled into, linked with or loaded by the product path.
+//
+// A stand-in for the OpenCV 3.2 headers that /root/reference's hot-path sources include, just large enough for
+//   src/ORBextractor.cpp  src/ORBmatcher.cpp  src/Frame.cpp  src/Config.cpp  src/cvutil.cpp
+// to compile UNMODIFIED from where they lie (oracle/Makefile, target `ref`).  OpenCV itself is not installed in this image,
+// so what oracle/_ref pins is everything se2lam wrote - cell grid, quota redistribution, level loop, orientation,
+// descriptor sampling, the frame grid and GetFeaturesInArea, the three greedy matchers, ComputeThreeMaxima,
+// DescriptorDistance, the Se2 algebra - while the OpenCV functions those files call (FAST, resize, copyMakeBorder,
+// GaussianBlur, KeyPointsFilter::retainBest, fastAtan2, cvRound, undistort, SVD) are re-implemented in cv_shim.cpp from
+// the published OpenCV 3.2 algorithms: written independently of oracle/orb_ref.cpp (generic over cv::Mat views with a
+// step and a parent matrix, as the originals are), so that agreement between the two is a second opinion on the
+// restatement - but it is still not the real library: the third-party arithmetic stays formally unpinned.
+//
+// Semantics kept because the reference relies on them:
+//   * Mat is a reference-counted header over shared storage; row / rowRange / colRange / operator()(Rect) are views and
+//     remember the matrix they were cut from (datastart / dataend, locateROI), which GaussianBlur uses for its border.
+//   * `m = expression` (MatExpr: Mat::zeros, eye, t(), products, sums) evaluates INTO m when size and type already match -
+//     ORBextractor.cpp's computeDescriptors() zero-fills a row range of the output through that rule, cvutil.cpp's
+//     triangulate() fills rows of A through it - whereas `m = otherMat` re-binds the header.
+//   * OutputArray::create() is a no-op on a matrix of the right size and type (resize / copyMakeBorder / GaussianBlur write
+//     through views into the pyramid's bordered buffers).
+#pragma once
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#define CV_PI 3.1415926535897932384626433832795
+
+#define CV_CN_SHIFT 3
+#define CV_MAT_DEPTH(t) ((t) & 7)
+#define CV_MAT_CN(t) ((((t) >> CV_CN_SHIFT) & 63) + 1)
+#define CV_MAKETYPE(depth, cn) (CV_MAT_DEPTH(depth) + (((cn) - 1) << CV_CN_SHIFT))
+#define CV_8U 0
+#define CV_8S 1
+#define CV_16U 2
+#define CV_16S 3
+#define CV_32S 4
+#define CV_32F 5
+#define CV_64F 6
+#define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
+#define CV_32SC1 CV_MAKETYPE(CV_32S, 1)
+#define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_32FC2 CV_MAKETYPE(CV_32F, 2)
+#define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
+#define CV_Assert(expr) do { if (!(expr)) throw std::runtime_error(std::string("CV_Assert failed: ") + #expr); } while (0)
+
+typedef unsigned char uchar;
+typedef int64_t int64;
+
+inline int cvRound(double v) { return (int)std::nearbyint(v); }   // SSE2 cvtsd2si: round half to even
+inline int cvRound(float v) { return (int)std::nearbyintf(v); }
+inline int cvRound(int v) { return v; }
+inline int cvFloor(double v) { int i = (int)v; return i - (i > v); }
+inline int cvFloor(float v) { int i = (int)v; return i - (i > v); }
+inline int cvCeil(double v) { int i = (int)v; return i + (i < v); }
+inline int cvCeil(float v) { int i = (int)v; return i + (i < v); }
+
+namespace cv {
+
+using ::uchar;
+using ::int64;
+
+template <typename T> inline T saturate_cast(double v) { return (T)v; }
+template <> inline uchar saturate_cast<uchar>(double v) { int i = cvRound(v); return (uchar)(i < 0 ? 0 : i > 255 ? 255 : i); }
+inline uchar saturate_u8(int i) { return (uchar)(i < 0 ? 0 : i > 255 ? 255 : i); }
+
+template <typename T> struct Size_ {
+    T width, height;
+    Size_() : width(0), height(0) {}
+    Size_(T w, T h) : width(w), height(h) {}
+    bool operator==(const Size_& o) const { return width == o.width && height == o.height; }
+    bool operator!=(const Size_& o) const { return !(*this == o); }
+};
+typedef Size_<int> Size;
+
+template <typename T> struct Point_ {
+    T x, y;
+    Point_() : x(0), y(0) {}
+    Point_(T x_, T y_) : x(x_), y(y_) {}
+    template <typename U> Point_(const Point_<U>& p) : x((T)p.x), y((T)p.y) {}
+    Point_& operator*=(double s) { x = saturate_cast<T>(x * s); y = saturate_cast<T>(y * s); return *this; }
+    Point_& operator*=(float s) { x = (T)(x * s); y = (T)(y * s); return *this; }
+    T dot(const Point_& p) const { return (T)(x * p.x + y * p.y); }
+};
+template <> template <> inline Point_<int>::Point_(const Point_<float>& p) : x(cvRound(p.x)), y(cvRound(p.y)) {}
+typedef Point_<int> Point;
+typedef Point_<int> Point2i;
+typedef Point_<float> Point2f;
+typedef Point_<double> Point2d;
+template <typename T> inline Point_<T> operator+(const Point_<T>& a, const Point_<T>& b) { return Point_<T>(a.x + b.x, a.y + b.y); }
+template <typename T> inline Point_<T> operator-(const Point_<T>& a, const Point_<T>& b) { return Point_<T>(a.x - b.x, a.y - b.y); }
+
+template <typename T> struct Point3_ {
+    T x, y, z;
+    Point3_() : x(0), y(0), z(0) {}
+    Point3_(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
+    T dot(const Point3_& p) const { return (T)(x * p.x + y * p.y + z * p.z); }
+};
+typedef Point3_<float> Point3f;
+typedef Point3_<double> Point3d;
+template <typename T> inline Point3_<T> operator+(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> inline Point3_<T> operator-(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+
+template <typename T> struct Rect_ {
+    T x, y, width, height;
+    Rect_() : x(0), y(0), width(0), height(0) {}
+    Rect_(T x_, T y_, T w, T h) : x(x_), y(y_), width(w), height(h) {}
+};
+typedef Rect_<int> Rect;
+
+struct Scalar {
+    double val[4];
+    Scalar(double v0 = 0, double v1 = 0, double v2 = 0, double v3 = 0) { val[0] = v0; val[1] = v1; val[2] = v2; val[3] = v3; }
+    double operator[](int i) const { return val[i]; }
+};
+
+struct Range {
+    int start, end;
+    Range(int s, int e) : start(s), end(e) {}
+};
+
+class KeyPoint {
+public:
+    Point2f pt;
+    float size, angle, response;
+    int octave, class_id;
+    KeyPoint() : pt(0, 0), size(0), angle(-1), response(0), octave(0), class_id(-1) {}
+    KeyPoint(Point2f p, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(p), size(s), angle(a), response(r), octave(o), class_id(c) {}
+    KeyPoint(float x, float y, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(x, y), size(s), angle(a), response(r), octave(o), class_id(c) {}
+};
+
+template <typename T> struct DataType;
+template <> struct DataType<uchar> { enum { type = CV_8UC1 }; };
+template <> struct DataType<int> { enum { type = CV_32SC1 }; };
+template <> struct DataType<float> { enum { type = CV_32FC1 }; };
+template <> struct DataType<double> { enum { type = CV_64FC1 }; };
+template <> struct DataType<Point2f> { enum { type = CV_32FC2 }; };
+
+template <typename T> class AutoBuffer {
+    std::vector<T> v;
+public:
+    AutoBuffer() {}
+    explicit AutoBuffer(size_t n) : v(n) {}
+    operator T*() { return v.data(); }
+    operator const T*() const { return v.data(); }
+};
+
+class MatExpr;
+class Mat {
+public:
+    enum { AUTO_STEP = 0 };
+    int flags;                 // the type (depth + channels)
+    int rows, cols;
+    size_t step;               // bytes per row
+    uchar* data;
+    uchar* datastart;          // the matrix this header was cut from (whole allocation)
+    uchar* dataend;
+    std::shared_ptr<uchar> owner;
+
+    Mat() : flags(0), rows(0), cols(0), step(0), data(nullptr), datastart(nullptr), dataend(nullptr) {}
+    Mat(int r, int c, int type) : Mat() { create(r, c, type); }
+    Mat(Size s, int type) : Mat() { create(s.height, s.width, type); }
+    Mat(int r, int c, int type, const Scalar& s) : Mat() { create(r, c, type); setTo(s); }
+    Mat(int r, int c, int type, void* ext, size_t st = AUTO_STEP) : flags(type), rows(r), cols(c), data((uchar*)ext) {
+        step = st == AUTO_STEP ? (size_t)c * elemSize() : st;
+        datastart = data;
+        dataend = data + (r > 0 ? (size_t)(r - 1) * step + (size_t)c * elemSize() : 0);
+    }
+    Mat(const Mat& m, const Rect& roi);
+    Mat(const MatExpr& e);
+    Mat& operator=(const MatExpr& e);    // evaluates into *this when size and type match (see the header comment)
+
+    int type() const { return flags; }
+    int depth() const { return CV_MAT_DEPTH(flags); }
+    int channels() const { return CV_MAT_CN(flags); }
+    size_t elemSize1() const { static const int sz[8] = {1, 1, 2, 2, 4, 4, 8, 0}; return sz[depth()]; }
+    size_t elemSize() const { return elemSize1() * channels(); }
+    size_t step1() const { return step / elemSize1(); }
+    bool empty() const { return data == nullptr || rows * cols == 0; }
+    Size size() const { return Size(cols, rows); }
+    size_t total() const { return (size_t)rows * cols; }
+    bool isContinuous() const { return rows <= 1 || step == (size_t)cols * elemSize(); }
+    bool isSubmatrix() const { return datastart && (data != datastart || dataend != data + (size_t)(rows - 1) * step + (size_t)cols * elemSize()); }
+
+    void create(int r, int c, int type) {
+        if (data && rows == r && cols == c && flags == type) return;
+        flags = type; rows = r; cols = c;
+        step = (size_t)c * elemSize();
+        const size_t bytes = (size_t)r * step;
+        owner.reset(new uchar[bytes ? bytes : 1], std::default_delete<uchar[]>());
+        data = datastart = owner.get();
+        dataend = data + bytes;
+    }
+    void create(Size s, int type) { create(s.height, s.width, type); }
+    void release() { *this = Mat(); }
+
+    uchar* ptr(int r = 0) { return data + (size_t)r * step; }
+    const uchar* ptr(int r = 0) const { return data + (size_t)r * step; }
+    template <typename T> T* ptr(int r = 0) { return (T*)(data + (size_t)r * step); }
+    template <typename T> const T* ptr(int r = 0) const { return (const T*)(data + (size_t)r * step); }
+    template <typename T> T& at(int r, int c) { return ((T*)(data + (size_t)r * step))[c]; }
+    template <typename T> const T& at(int r, int c) const { return ((const T*)(data + (size_t)r * step))[c]; }
+    template <typename T> T& at(int i) { return rows == 1 ? at<T>(0, i) : (cols == 1 ? at<T>(i, 0) : at<T>(i / cols, i % cols)); }
+    template <typename T> const T& at(int i) const { return rows == 1 ? at<T>(0, i) : (cols == 1 ? at<T>(i, 0) : at<T>(i / cols, i % cols)); }
+
+    Mat row(int r) const { return Mat(*this, Rect(0, r, cols, 1)); }
+    Mat col(int c) const { return Mat(*this, Rect(c, 0, 1, rows)); }
+    Mat rowRange(int a, int b) const { return Mat(*this, Rect(0, a, cols, b - a)); }
+    Mat colRange(int a, int b) const { return Mat(*this, Rect(a, 0, b - a, rows)); }
+    Mat operator()(const Rect& roi) const { return Mat(*this, roi); }
+    void locateROI(Size& whole, Point& ofs) const;
+
+    void copyTo(Mat& dst) const;          // dst keeps its storage when size and type match (OutputArray::create)
+    void copyTo(Mat&& dst) const { Mat& d = dst; copyTo(d); }
+    Mat clone() const { Mat m; copyTo(m); return m; }
+    void convertTo(Mat& dst, int type) const;
+    Mat& setTo(const Scalar& s);
+    Mat& operator=(const Scalar& s) { return setTo(s); }
+    MatExpr t() const;
+    static MatExpr zeros(int r, int c, int type);
+    static MatExpr eye(int r, int c, int type);
+
+    double getd(int r, int c) const;      // element as double (8U / 32S / 32F / 64F, single channel)
+    void setd(int r, int c, double v);
+    template <typename T> operator Point3_<T>() const {
+        if (total() != 3) throw std::runtime_error("cv shim: Mat -> Point3_ needs 3 elements");
+        const int n = rows == 3 ? 1 : 0;
+        return Point3_<T>((T)getd(0, 0), (T)getd(n ? 1 : 0, n ? 0 : 1), (T)getd(n ? 2 : 0, n ? 0 : 2));
+    }
+};
+
+// the value of an expression, evaluated eagerly; what makes it an "expression" is only how assignment treats it
+class MatExpr {
+public:
+    Mat m;
+    MatExpr() {}
+    MatExpr(const Mat& x) : m(x) {}
+    MatExpr t() const { return m.t(); }
+    Mat row(int r) const { return m.row(r); }
+    Mat col(int c) const { return m.col(c); }
+};
+inline Mat::Mat(const MatExpr& e) : Mat(e.m) {}
+inline Mat& Mat::operator=(const MatExpr& e) {
+    if (data && rows == e.m.rows && cols == e.m.cols && flags == e.m.flags) { Mat& self = *this; e.m.copyTo(self); }
+    else { const Mat tmp = e.m; flags = tmp.flags; rows = tmp.rows; cols = tmp.cols; step = tmp.step; data = tmp.data;
+           datastart = tmp.datastart; dataend = tmp.dataend; owner = tmp.owner; }
+    return *this;
+}
+MatExpr operator*(const MatExpr& a, const MatExpr& b);     // matrix product (32F / 64F)
+MatExpr operator*(double s, const MatExpr& a);
+MatExpr operator*(const MatExpr& a, double s);
+MatExpr operator/(const MatExpr& a, double s);
+MatExpr operator+(const MatExpr& a, const MatExpr& b);
+MatExpr operator-(const MatExpr& a, const MatExpr& b);
+MatExpr operator-(const MatExpr& a);
+inline MatExpr operator*(const Mat& a, const Mat& b) { return MatExpr(a) * MatExpr(b); }
+inline MatExpr operator*(const Mat& a, const MatExpr& b) { return MatExpr(a) * b; }
+inline MatExpr operator*(const MatExpr& a, const Mat& b) { return a * MatExpr(b); }
+inline MatExpr operator*(double s, const Mat& a) { return s * MatExpr(a); }
+inline MatExpr operator*(const Mat& a, double s) { return MatExpr(a) * s; }
+inline MatExpr operator/(const Mat& a, double s) { return MatExpr(a) / s; }
+inline MatExpr operator+(const Mat& a, const Mat& b) { return MatExpr(a) + MatExpr(b); }
+inline MatExpr operator-(const Mat& a, const Mat& b) { return MatExpr(a) - MatExpr(b); }
+inline MatExpr operator-(const MatExpr& a, const Mat& b) { return a - MatExpr(b); }
+inline MatExpr operator-(const Mat& a, const MatExpr& b) { return MatExpr(a) - b; }
+inline MatExpr operator-(const Mat& a) { return -MatExpr(a); }
+std::ostream& operator<<(std::ostream& os, const Mat& m);
+template <typename T> inline std::ostream& operator<<(std::ostream& os, const Size_<T>& s) { return os << "[" << s.width << " x " << s.height << "]"; }
+
+template <typename T> class MatCommaInitializer_;
+template <typename T> class Mat_ : public Mat {
+public:
+    Mat_() : Mat() { flags = DataType<T>::type; }
+    Mat_(int r, int c) : Mat(r, c, DataType<T>::type) {}
+    Mat_(const Mat& m) : Mat(m) { if (!m.empty() && m.type() != DataType<T>::type) throw std::runtime_error("cv shim: Mat_ of another type"); }
+    T& operator()(int r, int c) { return at<T>(r, c); }
+    const T& operator()(int r, int c) const { return at<T>(r, c); }
+    T& operator()(int i) { return at<T>(i); }
+    const T& operator()(int i) const { return at<T>(i); }
+};
+template <typename T> class MatCommaInitializer_ {
+    Mat_<T> m;
+    int i;
+public:
+    MatCommaInitializer_(const Mat_<T>& m_, int first) : m(m_), i(first) {}
+    template <typename T2> MatCommaInitializer_& operator,(T2 v) {
+        if (i >= (int)m.total()) throw std::runtime_error("cv shim: too many comma-initialiser values");
+        m(i++) = T(v);
+        return *this;
+    }
+    operator Mat_<T>() const { return m; }
+    operator Mat() const { return m; }
+};
+template <typename T, typename T2> inline MatCommaInitializer_<T> operator<<(const Mat_<T>& m, T2 v) {
+    Mat_<T> mm(m);
+    mm(0) = T(v);
+    return MatCommaInitializer_<T>(mm, 1);
+}
+
+struct Matx33f {
+    float val[9];
+    Matx33f() { for (float& v : val) v = 0; }
+    Matx33f(const Mat& m) {
+        if (m.rows != 3 || m.cols != 3) throw std::runtime_error("cv shim: Matx33f from a matrix that is not 3 x 3");
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) val[r * 3 + c] = (float)m.getd(r, c);
+    }
+    float operator()(int r, int c) const { return val[r * 3 + c]; }
+};
+// Matx * Point3_: OpenCV multiplies through Matx<float,3,1> - float accumulation, left to right
+inline Point3f operator*(const Matx33f& a, const Point3f& b) {
+    return Point3f(a.val[0] * b.x + a.val[1] * b.y + a.val[2] * b.z, a.val[3] * b.x + a.val[4] * b.y + a.val[5] * b.z,
+                   a.val[6] * b.x + a.val[7] * b.y + a.val[8] * b.z);
+}
+
+class _InputArray {
+protected:
+    Mat* obj;
+public:
+    _InputArray() : obj(nullptr) {}
+    _InputArray(const Mat& m) : obj(const_cast<Mat*>(&m)) {}
+    Mat getMat() const { return obj ? *obj : Mat(); }
+    bool empty() const { return !obj || obj->empty(); }
+};
+class _OutputArray : public _InputArray {
+public:
+    _OutputArray() {}
+    _OutputArray(Mat& m) : _InputArray(m) {}
+    void create(int r, int c, int type) const { obj->create(r, c, type); }
+    void create(Size s, int type) const { obj->create(s, type); }
+    void release() const { if (obj) obj->release(); }
+    Mat& getMatRef() const { return *obj; }
+};
+typedef const _InputArray& InputArray;
+typedef const _OutputArray& OutputArray;
+inline _InputArray noArray() { return _InputArray(); }
+
+inline int64 getTickCount() { return 0; }
+inline double getTickFrequency() { return 1e9; }
+float fastAtan2(float y, float x);
+inline double norm(double v) { return std::fabs(v); }
+template <typename T> inline double norm(const Point3_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z); }
+
+enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
+enum { BORDER_CONSTANT = 0, BORDER_REPLICATE = 1, BORDER_REFLECT = 2, BORDER_WRAP = 3, BORDER_REFLECT_101 = 4,
+       BORDER_REFLECT101 = 4, BORDER_DEFAULT = 4, BORDER_ISOLATED = 16 };
+
+void FAST(InputArray image, std::vector<KeyPoint>& keypoints, int threshold, bool nonmaxSuppression = true);
+void resize(InputArray src, OutputArray dst, Size dsize, double fx = 0, double fy = 0, int interpolation = INTER_LINEAR);
+void copyMakeBorder(InputArray src, OutputArray dst, int top, int bottom, int left, int right, int borderType,
+                    const Scalar& value = Scalar());
+void GaussianBlur(InputArray src, OutputArray dst, Size ksize, double sigmaX, double sigmaY = 0, int borderType = BORDER_DEFAULT);
+void undistort(InputArray src, OutputArray dst, InputArray K, InputArray D, InputArray newK = _InputArray());
+void undistortPoints(InputArray src, OutputArray dst, InputArray K, InputArray D, InputArray R = _InputArray(), InputArray P = _InputArray());
+void Rodrigues(InputArray src, OutputArray dst);
+
+class KeyPointsFilter {
+public:
+    static void retainBest(std::vector<KeyPoint>& keypoints, int npoints);
+};
+class ORB {
+public:
+    enum { kBytes = 32, HARRIS_SCORE = 0, FAST_SCORE = 1 };
+};
+class SVD {
+public:
+    enum { MODIFY_A = 1, NO_UV = 2, FULL_UV = 4 };
+    static void compute(InputArray src, OutputArray w, OutputArray u, OutputArray vt, int flags = 0);
+};
+
+// cv::FileStorage: only Config::readConfig() (never called by the oracle) touches it - declared so that Config.cpp compiles
+class FileNode {
+public:
+    bool empty() const { return true; }
+    operator int() const { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
+    operator float() const { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
+    operator double() const { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
+};
+template <typename T> inline void operator>>(const FileNode&, T&) { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
+class FileStorage {
+public:
+    enum { READ = 0, WRITE = 1 };
+    FileStorage(const std::string&, int) {}
+    bool isOpened() const { return false; }
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+    void release() {}
+};
+
+}  // namespace cv

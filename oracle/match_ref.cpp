@@ -2,9 +2,14 @@
 // (se2lam_amd/, include/).  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
 // leg may use it, and only as the checker / reported CPU baseline.
 //
-// PARITY UNPINNED for end-to-end match lists (the reference ships no fixtures); the integer parts
-// ARE pinned from the tree: TH_LOW = 75, TH_HIGH = 100, HISTO_LENGTH = 30 (ORBmatcher.cpp:45-47), the 64x48 grid
-// (Frame.h:26-27) and DescriptorDistance against a naive bit count (tests/test_match_oracle.py).
+// PARITY: the matchers and the frame grid are pinned against the REFERENCE'S OWN CODE - oracle/_ref compiles
+// /root/reference/src/ORBmatcher.cpp, Frame.cpp and cvutil.cpp unmodified (`make -C oracle ref`), and
+// tests/test_ref_compiled.py + tools/fuzz_ref.py compare match lists, counts and the updated vbPrevMatched exactly
+// (MatchByWindow, MatchByProjection incl. cvu::se3map / camprjc, SearchByBoW over the reference's DBoW2::FeatureVector,
+// GetFeaturesInArea, ComputeThreeMaxima, DescriptorDistance).  The reference ships no fixtures; also pinned
+// from the tree: TH_LOW = 75, TH_HIGH = 100, HISTO_LENGTH = 30 (ORBmatcher.cpp:45-47), the 64x48 grid (Frame.h:26-27),
+// DescriptorDistance against a naive bit count (tests/test_match_oracle.py).  findFundamentalMat and the SVD of
+// cvu::triangulate are OpenCV arithmetic and stay unpinned.
 //
 // CPU restatement (single thread, no dependencies) of se2lam::ORBmatcher and the Frame grid it searches:
 //   DescriptorDistance      /root/reference/src/ORBmatcher.cpp:110-126   (SWAR popcount over 8 x 32 bit)

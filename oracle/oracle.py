@@ -2,7 +2,8 @@
 
 ORACLE - TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg; never from se2lam_amd/ (the product path).
-PARITY UNPINNED - see the headers of oracle/*.cpp and DESIGN.md.
+PARITY: front end pinned against the reference's own compiled sources (oracle/ref.py, oracle/_ref), third-party arithmetic
+(OpenCV, g2o) and the bundle adjustments unpinned - see the headers of oracle/*.cpp and DESIGN.md section 3.
 """
 from __future__ import annotations
 

@@ -2,11 +2,16 @@
 // (se2lam_amd/, include/).  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
 // leg may use it, and only as the checker / reported CPU baseline.
 //
-// PARITY UNPINNED: /root/reference holds no golden vectors for this path and OpenCV is not
-// installed in this image, so this restatement of the OpenCV primitives the extractor calls
-// (FAST, resize, copyMakeBorder, GaussianBlur, retainBest, fastAtan2, cvRound) could not be checked
-// against the real library.  What CAN be pinned from the tree itself is pinned in
-// tests/test_orb_oracle.py: the 256x4 pattern table (sha256), umax, per-level quotas / sizes / cell
+// PARITY: pinned against the REFERENCE'S OWN CODE for everything se2lam wrote, unpinned for the OpenCV arithmetic under it.
+// /root/reference holds no golden vectors for this path and OpenCV is not installed in this image - but its extractor
+// compiles: oracle/_ref (`make -C oracle ref`) builds /root/reference/src/ORBextractor.cpp unmodified against a stand-in for
+// the OpenCV headers (oracle/_shim), and tests/test_ref_compiled.py + tools/fuzz_ref.py hold this restatement to it, key point
+// for key point and descriptor byte for byte (ten config-1 frames, both score types, odd sizes, noise, 700 random cases).
+// That pins the constructor's tables, the pyramid loop, the cell grid / quota redistribution / 20-7 threshold rule, the
+// level cut, IC_Angle, computeOrbDescriptor, HarrisResponses and operator().  The OpenCV functions those call (FAST, resize,
+// copyMakeBorder, GaussianBlur, retainBest, fastAtan2, cvRound) are restated here and, independently, in
+// oracle/_shim/cv_shim.cpp; the two agree bit for bit, the real library could not be run.  Pinned
+// from the tree itself in tests/test_orb_oracle.py: the 256x4 pattern table (sha256), umax, per-level quotas / sizes / cell
 // grids, EDGE_THRESHOLD / PATCH_SIZE, the Gaussian taps.
 //
 // CPU restatement (single thread, no dependencies) of se2lam::ORBextractor:

@@ -1,0 +1,208 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  ctypes loader of oracle/_ref/libse2lam_ref.so: the reference's OWN hot-path sources
+(/root/reference/src/ORBextractor.cpp, ORBmatcher.cpp, Frame.cpp, Config.cpp, cvutil.cpp, DBoW2's FeatureVector) compiled
+unmodified against oracle/_shim by `make -C oracle ref`.  The library can only be BUILT where /root/reference exists (this
+container); it is git-ignored but travels to the GPU box with the snapshot, where the tests load the prebuilt file.  Same
+call signatures as the restatement's wrappers in oracle/oracle.py, so a test runs either through one code path.
+
+Only tests/ may import this module (and __graft_entry__.build() to compile it): never the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .oracle import KP_DTYPE, Bounds, OrbParams, default_bounds, orb_params  # noqa: F401  (same PODs as the restatement)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_ref", "libse2lam_ref.so")
+REFERENCE = os.environ.get("SE2LAM_REFERENCE", "/root/reference")
+_lib = None
+
+
+def can_build() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE, "src"))
+
+
+def build(force: bool = False) -> str | None:
+    """Compile the reference's sources where they lie; returns the path, or None when /root/reference is absent (GPU box)."""
+    if not can_build():
+        return LIB if os.path.exists(LIB) else None
+    if force and os.path.exists(LIB):
+        os.remove(LIB)
+    subprocess.check_call(["make", "-C", HERE, "ref", "REF=" + REFERENCE], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def available() -> bool:
+    return os.path.exists(LIB) or can_build()
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if build() is None:
+            raise FileNotFoundError("oracle/_ref/libse2lam_ref.so is absent and /root/reference is not here to build it from")
+        _lib = C.CDLL(LIB)
+    return _lib
+
+
+def orb_extract(img, params=None, cap=8192):
+    """se2lam::ORBextractor::operator() -> (keypoints structured array (n,), descriptors (n,32) u8)"""
+    params = params or orb_params()
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols = img.shape
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    f = lib().ref_orb_extract
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    rc = f(C.byref(params), img.ctypes.data, rows, cols, cols, kps.ctypes.data, desc.ctypes.data, cap, C.byref(n))
+    if rc == -2:
+        raise ValueError("the reference raises here (an OpenCV assertion: a cell rectangle outside its pyramid level)")
+    assert rc == 0, "ref_orb_extract: capacity exceeded"
+    return kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def hamming(a, b) -> int:
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    f = lib().ref_hamming
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    return int(f(a.ctypes.data, b.ctypes.data))
+
+
+def three_maxima(counts):
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(3, np.int32)
+    f = lib().ref_three_maxima
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    f(counts.ctypes.data, len(counts), out.ctypes.data)
+    return tuple(int(v) for v in out)
+
+
+def features_in_area(kps, x, y, r, min_level, max_level, bounds=None):
+    bounds = bounds or default_bounds()
+    kps = np.ascontiguousarray(kps)
+    out = np.zeros(max(len(kps), 1), np.int32)
+    f = lib().ref_features_in_area
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = f(C.byref(bounds), kps.ctypes.data, len(kps), x, y, r, min_level, max_level, out.ctypes.data, out.size)
+    return out[:n].copy()
+
+
+def match_window(kps1, desc1, kps2, desc2, prev_xy=None, win=20, level_offset=1, min_level=0, max_level=8,
+                 nnratio=0.9, bounds=None):
+    """ORBmatcher::MatchByWindow -> (matches12 (n1,), nmatches, prev_xy updated)"""
+    bounds = bounds or default_bounds()
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    n1, n2 = len(kps1), len(kps2)
+    if prev_xy is None:
+        prev_xy = np.stack([kps1["x"], kps1["y"]], axis=1)
+    prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+    m12 = np.full(max(n1, 1), -1, np.int32)
+    f = lib().ref_match_window
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                  C.c_int, C.c_int, C.c_float, C.c_void_p]
+    nm = f(C.byref(bounds), kps1.ctypes.data, desc1.ctypes.data, n1, kps2.ctypes.data, desc2.ctypes.data, n2,
+           prev.ctypes.data, win, level_offset, min_level, max_level, nnratio, m12.ctypes.data)
+    return m12[:n1].copy(), int(nm), prev
+
+
+def match_projection(mp_pos, mp_desc, mp_octave, mp_skip, Tcw, K4, kps, desc, kf_observed, win=15, level_offset=2,
+                     nnratio=0.6, bounds=None):
+    """ORBmatcher::MatchByProjection -> (match_idx_mp (n,), nmatches)"""
+    bounds = bounds or default_bounds()
+    mp_pos = np.ascontiguousarray(mp_pos, np.float32); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    mp_octave = np.ascontiguousarray(mp_octave, np.int32); mp_skip = np.ascontiguousarray(mp_skip, np.uint8)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy()
+    kps = np.ascontiguousarray(kps); desc = np.ascontiguousarray(desc, np.uint8)
+    kf_observed = np.ascontiguousarray(kf_observed, np.uint8)
+    n, m = len(kps), len(mp_octave)
+    out = np.full(max(n, 1), -1, np.int32)
+    fx, fy, cx, cy = [float(v) for v in K4]
+    f = lib().ref_match_projection
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    nm = f(C.byref(bounds), mp_pos.ctypes.data, mp_desc.ctypes.data, mp_octave.ctypes.data, mp_skip.ctypes.data, m,
+           Tcw.ctypes.data, fx, fy, cx, cy, kps.ctypes.data, desc.ctypes.data, kf_observed.ctypes.data, n, win, level_offset,
+           nnratio, out.ctypes.data)
+    return out[:n].copy(), int(nm)
+
+
+def search_by_bow(kps1, desc1, fv1, has_mp1, kps2, desc2, fv2, has_mp2, mp_only=False, nnratio=0.6, check_ori=True):
+    """ORBmatcher::SearchByBoW; fv = (nodes, ptr, idx) CSR int32 arrays -> (matches12 (n1,), nmatches)"""
+    kps1 = np.ascontiguousarray(kps1); kps2 = np.ascontiguousarray(kps2)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    a = [np.ascontiguousarray(x, np.int32) for x in fv1]; b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+    h1 = np.ascontiguousarray(has_mp1, np.uint8); h2 = np.ascontiguousarray(has_mp2, np.uint8)
+    out = np.full(max(len(kps1), 1), -1, np.int32)
+    f = lib().ref_search_by_bow
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p] + [C.c_void_p] * 2 + \
+        [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    nm = f(kps1.ctypes.data, desc1.ctypes.data, len(kps1), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+           len(a[0]), h1.ctypes.data, kps2.ctypes.data, desc2.ctypes.data, len(kps2), b[0].ctypes.data,
+           b[1].ctypes.data, b[2].ctypes.data, len(b[0]), h2.ctypes.data, int(mp_only), nnratio, int(check_ori),
+           out.ctypes.data)
+    return out[:len(kps1)].copy(), int(nm)
+
+
+def track_two_frames(img1, img2, params=None, K4=(400.0, 400.0, 320.0, 240.0), win=20, nnratio=0.9, cap=8192):
+    """Frame::Frame on both images (undistort with D = 0, ORBextractor, grid), then MatchByWindow with the first frame's key
+    points as vbPrevMatched -> ((kps1, desc1), (kps2, desc2), matches12, nmatches, prev_xy)"""
+    params = params or orb_params()
+    img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8)
+    rows, cols = img1.shape
+    k1 = np.zeros(cap, KP_DTYPE); k2 = np.zeros(cap, KP_DTYPE)
+    d1 = np.zeros((cap, 32), np.uint8); d2 = np.zeros((cap, 32), np.uint8)
+    n1 = C.c_int(0); n2 = C.c_int(0)
+    m12 = np.full(cap, -1, np.int32)
+    prev = np.zeros((cap, 2), np.float32)
+    f = lib().ref_track_two_frames
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                  C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int,
+                  C.c_void_p, C.c_void_p]
+    nm = f(C.byref(params), img1.ctypes.data, img2.ctypes.data, rows, cols, *[float(v) for v in K4], win, nnratio,
+           k1.ctypes.data, d1.ctypes.data, C.byref(n1), k2.ctypes.data, d2.ctypes.data, C.byref(n2), cap, m12.ctypes.data,
+           prev.ctypes.data)
+    assert nm >= 0, "ref_track_two_frames: capacity exceeded"
+    a, b = n1.value, n2.value
+    return (k1[:a].copy(), d1[:a].copy()), (k2[:b].copy(), d2[:b].copy()), m12[:a].copy(), int(nm), prev[:a].copy()
+
+
+def triangulate_point(pt1, pt2, P1, P2):
+    out = np.zeros(3, np.float32)
+    a = np.ascontiguousarray(pt1, np.float32); b = np.ascontiguousarray(pt2, np.float32)
+    p1 = np.ascontiguousarray(P1, np.float32).reshape(-1); p2 = np.ascontiguousarray(P2, np.float32).reshape(-1)
+    f = lib().ref_triangulate_point
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 5
+    f(a.ctypes.data, b.ctypes.data, p1.ctypes.data, p2.ctypes.data, out.ctypes.data)
+    return out
+
+
+def check_parallax(o1, o2, p, min_degree=1) -> bool:
+    a, b, c = [np.ascontiguousarray(v, np.float32) for v in (o1, o2, p)]
+    f = lib().ref_check_parallax
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int]
+    return bool(f(a.ctypes.data, b.ctypes.data, c.ctypes.data, min_degree))
+
+
+def se2_compose(a, b, minus=False):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    out = np.zeros(3, np.float32)
+    f = lib().ref_se2_compose
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    f(a.ctypes.data, b.ctypes.data, int(minus), out.ctypes.data)
+    return out

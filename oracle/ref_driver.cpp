@@ -1,0 +1,241 @@
+// ORACLE - TEST INFRASTRUCTURE ONLY (oracle/_ref).  Never linked, imported or called by the product path.
+//
+// C entry points over the REFERENCE's own classes, compiled from /root/reference where the sources lie (oracle/Makefile,
+// target `ref`; nothing of the reference is copied into this repository):
+//   se2lam::ORBextractor::operator()      src/ORBextractor.cpp:727-788 (with ComputePyramid, ComputeKeyPoints, IC_Angle,
+//                                         computeOrbDescriptor, HarrisResponses and the constructor's tables)
+//   se2lam::Frame::Frame / PosInGrid / GetFeaturesInArea      src/Frame.cpp:19-83, 209-286
+//   se2lam::ORBmatcher::MatchByWindow / MatchByProjection / SearchByBoW / ComputeThreeMaxima / DescriptorDistance
+//                                         src/ORBmatcher.cpp:64-454
+//   cvu::camprjc / se3map / triangulate / checkParallax       src/cvutil.cpp
+// against oracle/_shim (a stand-in for the OpenCV / ROS headers, and stubs of KeyFrame / MapPoint with the members the
+// matcher reads).  What this library pins is the se2lam-owned logic; the OpenCV arithmetic underneath is the shim's.
+// The signatures mirror oracle/orb_ref.cpp and oracle/match_ref.cpp so that tests call either through the same wrapper.
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "ORBmatcher.h"
+#include "cvutil.h"
+
+using namespace se2lam;
+
+extern "C" {
+struct ref_orb_params {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels, fast_th, score_type;
+};
+struct ref_keypoint {  // cv::KeyPoint layout
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+};
+struct ref_bounds { float min_x, min_y, max_x, max_y; };
+}
+
+namespace {
+
+std::vector<cv::KeyPoint> to_cv(const ref_keypoint* k, int n) {
+    std::vector<cv::KeyPoint> v(n);
+    for (int i = 0; i < n; ++i) v[i] = cv::KeyPoint(k[i].x, k[i].y, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id);
+    return v;
+}
+void from_cv(const std::vector<cv::KeyPoint>& v, ref_keypoint* k) {
+    for (size_t i = 0; i < v.size(); ++i)
+        k[i] = ref_keypoint{v[i].pt.x, v[i].pt.y, v[i].size, v[i].angle, v[i].response, v[i].octave, v[i].class_id};
+}
+
+// A Frame with given key points: what Frame::Frame (src/Frame.cpp:19-83) leaves behind, without the image.  The statics are
+// the ones its first call computes (computeBoundUn with D = 0: the image rectangle; :38-44), the grid loop is :64-76 with the
+// reference's own PosInGrid.
+void set_bounds(const ref_bounds& b) {
+    Frame::minXUn = b.min_x; Frame::minYUn = b.min_y; Frame::maxXUn = b.max_x; Frame::maxYUn = b.max_y;
+    Frame::mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (Frame::maxXUn - Frame::minXUn);
+    Frame::mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (Frame::maxYUn - Frame::minYUn);
+    Frame::mbInitialComputations = false;
+}
+void fill_frame(Frame& f, const ref_keypoint* kps, const uint8_t* desc, int n) {
+    f.keyPoints = to_cv(kps, n);
+    f.keyPointsUn = f.keyPoints;
+    f.N = n;
+    f.descriptors = cv::Mat(n, 32, CV_8UC1);
+    for (int i = 0; i < n; ++i) std::memcpy(f.descriptors.ptr(i), desc + 32 * (size_t)i, 32);
+    for (size_t i = 0; i < f.keyPointsUn.size(); i++) {
+        cv::KeyPoint& kp = f.keyPointsUn[i];
+        int gx, gy;
+        if (f.PosInGrid(kp, gx, gy)) f.mGrid[gx][gy].push_back(i);
+    }
+}
+
+DBoW2::FeatureVector to_fv(const int32_t* nodes, const int32_t* ptr, const int32_t* idx, int nn) {
+    DBoW2::FeatureVector fv;
+    for (int k = 0; k < nn; ++k)
+        for (int t = ptr[k]; t < ptr[k + 1]; ++t) fv.addFeature((DBoW2::NodeId)nodes[k], (unsigned)idx[t]);
+    return fv;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_orb_extract(const ref_orb_params* p, const uint8_t* img, int rows, int cols, int step, ref_keypoint* kps, uint8_t* desc,
+                    int cap, int* n_out) {
+    ORBextractor ex(p->nfeatures, p->scale_factor, p->nlevels, p->score_type, p->fast_th);
+    cv::Mat im(rows, cols, CV_8UC1, (void*)img, (size_t)step);
+    std::vector<cv::KeyPoint> v;
+    cv::Mat d;
+    try {
+        ex(im, cv::Mat(), v, d);
+    } catch (const std::exception& e) {   // where OpenCV would raise cv::Exception (a cell rectangle outside its level, ...)
+        *n_out = 0;
+        return -2;
+    }
+    *n_out = (int)v.size();
+    if ((int)v.size() > cap) return -1;
+    from_cv(v, kps);
+    for (size_t i = 0; i < v.size(); ++i) std::memcpy(desc + 32 * i, d.ptr((int)i), 32);
+    return 0;
+}
+
+int ref_hamming(const uint8_t* a, const uint8_t* b) {
+    cv::Mat A(1, 32, CV_8UC1, (void*)a), B(1, 32, CV_8UC1, (void*)b);
+    return ORBmatcher::DescriptorDistance(A, B);
+}
+
+void ref_three_maxima(const int32_t* counts, int L, int32_t* out3) {
+    std::vector<std::vector<int>> histo(L);
+    for (int i = 0; i < L; ++i) histo[i].assign(counts[i], 0);
+    int i1 = -1, i2 = -1, i3 = -1;
+    ORBmatcher m;
+    m.ComputeThreeMaxima(histo.data(), L, i1, i2, i3);
+    out3[0] = i1; out3[1] = i2; out3[2] = i3;
+}
+
+int ref_features_in_area(const ref_bounds* b, const ref_keypoint* kps, int n, float x, float y, float r, int min_level, int max_level,
+                         int32_t* out, int cap) {
+    set_bounds(*b);
+    Frame f;
+    std::vector<uint8_t> zero(32 * (size_t)(n > 0 ? n : 1), 0);
+    fill_frame(f, kps, zero.data(), n);
+    const std::vector<size_t> v = f.GetFeaturesInArea(x, y, r, min_level, max_level);
+    if ((int)v.size() > cap) return -1;
+    for (size_t i = 0; i < v.size(); ++i) out[i] = (int32_t)v[i];
+    return (int)v.size();
+}
+
+int ref_match_window(const ref_bounds* b, const ref_keypoint* kps1, const uint8_t* desc1, int n1, const ref_keypoint* kps2,
+                     const uint8_t* desc2, int n2, float* prev_xy, int win, int level_offset, int min_level, int max_level,
+                     float nnratio, int32_t* m12) {
+    set_bounds(*b);
+    Frame f1, f2;
+    fill_frame(f1, kps1, desc1, n1);
+    fill_frame(f2, kps2, desc2, n2);
+    std::vector<cv::Point2f> prev(n1);
+    for (int i = 0; i < n1; ++i) prev[i] = cv::Point2f(prev_xy[2 * i], prev_xy[2 * i + 1]);
+    std::vector<int> matches;
+    ORBmatcher matcher(nnratio);
+    const int nm = matcher.MatchByWindow(f1, f2, prev, win, matches, level_offset, min_level, max_level);
+    for (int i = 0; i < n1; ++i) { m12[i] = matches[i]; prev_xy[2 * i] = prev[i].x; prev_xy[2 * i + 1] = prev[i].y; }
+    return nm;
+}
+
+// mp_skip bits: 1 = isNull, 2 = bad parallax, 4 = already observed by the key frame (ORBmatcher.cpp:392-395)
+int ref_match_projection(const ref_bounds* b, const float* mp_pos, const uint8_t* mp_desc, const int32_t* mp_octave,
+                         const uint8_t* mp_skip, int m, const float* Tcw12, float fx, float fy, float cx, float cy,
+                         const ref_keypoint* kps, const uint8_t* desc, const uint8_t* kf_observed, int n, int win, int level_offset,
+                         float nnratio, int32_t* out) {
+    set_bounds(*b);
+    Config::Kcam = (cv::Mat_<float>(3, 3) << fx, 0, cx, 0, fy, cy, 0, 0, 1);
+    PtrKeyFrame kf = std::make_shared<KeyFrame>();
+    fill_frame(*kf, kps, desc, n);
+    kf->Tcw = cv::Mat::eye(4, 4, CV_32FC1);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) kf->Tcw.at<float>(r, c) = Tcw12[4 * r + c];
+    PtrMapPoint dummy = std::make_shared<MapPoint>();
+    for (int i = 0; i < n; ++i) if (kf_observed[i]) kf->mDualObservations[i] = dummy;
+    std::vector<PtrMapPoint> mps(m);
+    std::vector<cv::Mat> keep(m);
+    for (int i = 0; i < m; ++i) {
+        mps[i] = std::make_shared<MapPoint>();
+        mps[i]->mPos = cv::Point3f(mp_pos[3 * i], mp_pos[3 * i + 1], mp_pos[3 * i + 2]);
+        mps[i]->mMainOctave = mp_octave[i];
+        mps[i]->mMainDescriptor = cv::Mat(1, 32, CV_8UC1);
+        std::memcpy(mps[i]->mMainDescriptor.ptr(0), mp_desc + 32 * (size_t)i, 32);
+        // the oracle's mp_skip is one flag for "the reference continues at :392-395": spread it over the three tests in turn
+        const int s = mp_skip[i] ? 1 + (i % 3) : 0;
+        mps[i]->mbNull = s == 1;
+        mps[i]->mbGoodParallax = s != 2;
+        if (s == 3) kf->mObservations[mps[i]] = -1;
+    }
+    std::vector<int> idx;
+    ORBmatcher matcher(nnratio);
+    const int nm = matcher.MatchByProjection(kf, mps, win, level_offset, idx);
+    for (int i = 0; i < n; ++i) out[i] = idx[i];
+    return nm;
+}
+
+int ref_search_by_bow(const ref_keypoint* kps1, const uint8_t* desc1, int n1, const int32_t* nodes1, const int32_t* ptr1,
+                      const int32_t* idx1, int nn1, const uint8_t* has_mp1, const ref_keypoint* kps2, const uint8_t* desc2, int n2,
+                      const int32_t* nodes2, const int32_t* ptr2, const int32_t* idx2, int nn2, const uint8_t* has_mp2, int mp_only,
+                      float nnratio, int check_ori, int32_t* m12) {
+    ref_bounds b{0.f, 0.f, 640.f, 480.f};
+    set_bounds(b);
+    PtrKeyFrame k1 = std::make_shared<KeyFrame>(), k2 = std::make_shared<KeyFrame>();
+    fill_frame(*k1, kps1, desc1, n1);
+    fill_frame(*k2, kps2, desc2, n2);
+    k1->mFeatVec = to_fv(nodes1, ptr1, idx1, nn1);
+    k2->mFeatVec = to_fv(nodes2, ptr2, idx2, nn2);
+    for (int i = 0; i < n1; ++i) if (has_mp1[i]) k1->mDualObservations[i] = std::make_shared<MapPoint>();
+    for (int i = 0; i < n2; ++i) if (has_mp2[i]) k2->mDualObservations[i] = std::make_shared<MapPoint>();
+    std::map<int, int> matches;
+    ORBmatcher matcher(nnratio, check_ori != 0);
+    const int nm = matcher.SearchByBoW(k1, k2, matches, mp_only != 0);
+    for (int i = 0; i < n1; ++i) m12[i] = -1;
+    for (auto& kv : matches) m12[kv.first] = kv.second;
+    return nm;
+}
+
+// Track's per-frame front end exactly as the reference runs it: Frame::Frame (undistort with D = 0, ORBextractor, grid) on both
+// images, then MatchByWindow with vbPrevMatched = the first frame's key points (Track::resetLocalTrack, src/Track.cpp:194)
+int ref_track_two_frames(const ref_orb_params* p, const uint8_t* img1, const uint8_t* img2, int rows, int cols, float fx, float fy,
+                         float cx, float cy, int win, float nnratio, ref_keypoint* kps1, uint8_t* desc1, int* n1, ref_keypoint* kps2,
+                         uint8_t* desc2, int* n2, int cap, int32_t* m12, float* prev_xy) {
+    Config::Kcam = (cv::Mat_<float>(3, 3) << fx, 0, cx, 0, fy, cy, 0, 0, 1);
+    Config::Dcam = cv::Mat::zeros(4, 1, CV_32FC1);
+    Frame::mbInitialComputations = true;
+    ORBextractor ex(p->nfeatures, p->scale_factor, p->nlevels, p->score_type, p->fast_th);
+    cv::Mat im1(rows, cols, CV_8UC1, (void*)img1), im2(rows, cols, CV_8UC1, (void*)img2);
+    Frame f1(im1, Se2(0, 0, 0), &ex, Config::Kcam, Config::Dcam), f2(im2, Se2(0, 0, 0), &ex, Config::Kcam, Config::Dcam);
+    *n1 = f1.N; *n2 = f2.N;
+    if (f1.N > cap || f2.N > cap) return -1;
+    from_cv(f1.keyPoints, kps1);
+    from_cv(f2.keyPoints, kps2);
+    for (int i = 0; i < f1.N; ++i) std::memcpy(desc1 + 32 * (size_t)i, f1.descriptors.ptr(i), 32);
+    for (int i = 0; i < f2.N; ++i) std::memcpy(desc2 + 32 * (size_t)i, f2.descriptors.ptr(i), 32);
+    std::vector<cv::Point2f> prev(f1.N);
+    for (int i = 0; i < f1.N; ++i) prev[i] = f1.keyPoints[i].pt;
+    std::vector<int> matches;
+    ORBmatcher matcher(nnratio);
+    const int nm = matcher.MatchByWindow(f1, f2, prev, win, matches);
+    for (int i = 0; i < f1.N; ++i) { m12[i] = matches[i]; prev_xy[2 * i] = prev[i].x; prev_xy[2 * i + 1] = prev[i].y; }
+    return nm;
+}
+
+// cvu::triangulate + the depth / parallax tests around it (src/cvutil.cpp:46-98); P 3x4 row-major float
+void ref_triangulate_point(const float* pt1, const float* pt2, const float* P1, const float* P2, float* out3) {
+    cv::Mat A(3, 4, CV_32FC1, (void*)P1), B(3, 4, CV_32FC1, (void*)P2);
+    const cv::Point3f x = cvu::triangulate(cv::Point2f(pt1[0], pt1[1]), cv::Point2f(pt2[0], pt2[1]), A, B);
+    out3[0] = x.x; out3[1] = x.y; out3[2] = x.z;
+}
+int ref_check_parallax(const float* o1, const float* o2, const float* p, int min_degree) {
+    return cvu::checkParallax(cv::Point3f(o1[0], o1[1], o1[2]), cv::Point3f(o2[0], o2[1], o2[2]), cv::Point3f(p[0], p[1], p[2]), min_degree) ? 1 : 0;
+}
+void ref_se2_compose(const float* a, const float* b, int minus, float* out3) {   // Se2::operator+ / operator- (src/Config.cpp:200-223)
+    const Se2 A(a[0], a[1], a[2]), B(b[0], b[1], b[2]);
+    const Se2 r = minus ? (A - B) : (A + B);
+    out3[0] = r.x; out3[1] = r.y; out3[2] = r.theta;
+}
+
+}  // extern "C"

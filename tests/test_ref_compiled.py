@@ -1,0 +1,298 @@
+"""oracle/_ref: the REFERENCE'S OWN hot-path sources - /root/reference/src/ORBextractor.cpp, ORBmatcher.cpp, Frame.cpp,
+Config.cpp, cvutil.cpp, compiled unmodified from where they lie against oracle/_shim (`make -C oracle ref`) - against the
+CPU restatement (oracle/orb_ref.cpp, match_ref.cpp) and, with -m gpu, against the HIP path through the C ABI.
+
+What this pins (VERDICT r03 "what's missing" #1): everything se2lam WROTE on the front-end path - the constructor's tables,
+the pyramid loop, the cell grid with its quota redistribution and 20 / 7 threshold rule, the level loop, IC_Angle,
+computeOrbDescriptor, HarrisResponses, the frame grid (PosInGrid's round()) and GetFeaturesInArea, the greedy passes of
+MatchByWindow / MatchByProjection / SearchByBoW, ComputeThreeMaxima, DescriptorDistance, cvu::camprjc / se3map, the Se2
+algebra - runs here as the reference compiled it.  What it does NOT pin: the OpenCV functions underneath (FAST, resize,
+copyMakeBorder, GaussianBlur, retainBest's tie order, fastAtan2) are oracle/_shim/cv_shim.cpp, a second, independently
+written reading of OpenCV 3.2 - agreement between shim and restatement is two readings agreeing, not the library.
+
+Order of the key points inside a level: the reference cuts a level's list with KeyPointsFilter::retainBest, whose order
+is libstdc++'s nth_element - implementation-defined.  Extractor outputs are therefore compared level by level as SETS
+(sorted by position: positions are unique inside a level), with all seven cv::KeyPoint fields and the 32 descriptor bytes;
+the matchers are order-dependent greedy passes and are compared on identical input arrays.
+
+The library is built in this container (where /root/reference is) and travels to the GPU box prebuilt."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ref
+
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref is not built and /root/reference is not here")
+
+
+def _canon(k, d):
+    o = np.lexsort((k["x"], k["y"], k["octave"]))
+    return k[o], d[o]
+
+
+def _same_features(a, b):
+    (ka, da), (kb, db) = _canon(*a), _canon(*b)
+    return len(ka) == len(kb) and np.array_equal(ka, kb) and np.array_equal(da, db)
+
+
+def _prev(k):
+    return np.ascontiguousarray(np.stack([k["x"], k["y"]], 1), np.float32)
+
+
+@pytest.fixture(scope="module")
+def ref_feats(synth):
+    return [ref.orb_extract(synth.frame(t)) for t in range(10)]
+
+
+# ------------------------------------------------------------------------------------------------------------------ CPU
+def test_library_is_the_reference_compiled_where_it_lies():
+    """The recipe compiles the reference's files by path; nothing of them is in this repository (no copy to drift)."""
+    mk = open(os.path.join(os.path.dirname(ref.HERE), "oracle", "Makefile")).read()
+    for f in ("src/ORBextractor.cpp", "src/ORBmatcher.cpp", "src/Frame.cpp", "src/Config.cpp", "src/cvutil.cpp"):
+        assert "$(REF)/" + f in mk
+    ref.lib()
+    for root, _, files in os.walk(os.path.dirname(ref.HERE)):
+        if any(s in root for s in ("/.git", "/gpurun_out", "/_ref", "/_build")):
+            continue
+        assert "bit_pattern_31_" not in files and "ORBextractor.cpp" not in files and "ORBmatcher.cpp" not in files, root
+
+
+def test_extractor_config1_frames_equal_the_restatement(oracle, synth, ref_feats):
+    """BASELINE configs[0] / [1]: the ten seeded 640x480 frames, 1000 features, 8 levels, FAST score."""
+    for t in range(10):
+        ko, do = oracle.orb_extract(synth.frame(t))
+        kr, dr = ref_feats[t]
+        assert len(kr) == 1000
+        assert _same_features((ko, do), (kr, dr)), t
+        # level by level the two lists hold the same points; inside a level the reference's order is retainBest's
+        assert np.array_equal(np.bincount(ko["octave"], minlength=8), np.bincount(kr["octave"], minlength=8))
+        assert np.all(np.diff(kr["octave"]) >= 0) and np.all(np.diff(ko["octave"]) >= 0)
+
+
+@pytest.mark.parametrize("nfeat,scale,levels,th,score", [(1000, 1.2, 8, 20, 0), (500, 1.2, 8, 20, 1), (300, 1.5, 4, 12, 1),
+                                                         (2000, 1.1, 6, 30, 0), (1500, 1.2, 8, 7, 0)])
+def test_extractor_other_parameters_and_harris_score(oracle, synth, nfeat, scale, levels, th, score):
+    p = oracle.orb_params(nfeat, scale, levels, th, score)
+    for t in (0, 3):
+        assert _same_features(oracle.orb_extract(synth.frame(t), p, cap=8192), ref.orb_extract(synth.frame(t), p)), (t, score)
+
+
+def test_extractor_odd_sizes_noise_and_flat_images(oracle, synth):
+    rng = np.random.default_rng(11)
+    base = synth.frame(2)
+    cases = [base[:301, :433], base[37:400, 100:511], np.ascontiguousarray(base[::2, ::2]), base[:160, :200],
+             rng.integers(0, 256, (240, 320)).astype(np.uint8),                               # noise: every cell full of corners
+             np.full((200, 300), 90, np.uint8),                                                # flat: no key point at all
+             np.concatenate([np.full((240, 160), 40, np.uint8), rng.integers(0, 256, (240, 160)).astype(np.uint8)], 1)]
+    for i, img in enumerate(cases):
+        img = np.ascontiguousarray(img)
+        p = oracle.orb_params(400 + 150 * i, 1.2, 8 if min(img.shape) > 220 else 5)
+        a, b = oracle.orb_extract(img, p, cap=8192), ref.orb_extract(img, p)
+        assert _same_features(a, b), (i, img.shape, len(a[0]), len(b[0]))
+    assert len(ref.orb_extract(cases[5])[0]) == 0
+
+
+def test_retain_best_as_the_library_text_differs_only_in_ties(oracle, synth):
+    """SE2_REF_RETAIN=std runs KeyPointsFilter::retainBest as OpenCV writes it (std::nth_element + std::partition, whatever
+    this libstdc++ does with equal responses).  Against the canonical tie rule: the same number of key points per level, the
+    same multiset of responses per level (only WHICH of several equal-response corners survive may differ), and the points
+    that differ are few."""
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from oracle import ref; from se2lam_amd import synth;"
+            "k, d = ref.orb_extract(synth.frame(1)); np.save(sys.argv[1], k)") % os.path.dirname(ref.HERE)
+    out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ref_retain_std.npy")
+    subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, SE2_REF_RETAIN="std"))
+    ks = np.load(out)
+    kc, _ = ref.orb_extract(synth.frame(1))
+    assert len(ks) == len(kc)
+    for lv in range(8):
+        a, b = ks[ks["octave"] == lv], kc[kc["octave"] == lv]
+        assert len(a) == len(b) and np.array_equal(np.sort(a["response"]), np.sort(b["response"])), lv
+    key = lambda k: set(zip(k["octave"].tolist(), k["x"].tolist(), k["y"].tolist()))
+    assert len(key(ks) ^ key(kc)) <= 0.1 * len(kc)
+
+
+def test_descriptor_distance_and_three_maxima(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        a = rng.integers(0, 256, 32).astype(np.uint8); b = rng.integers(0, 256, 32).astype(np.uint8)
+        assert ref.hamming(a, b) == oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+    import ctypes as C
+    from se2lam_amd import capi
+    for trial in range(300):
+        L = int(rng.integers(1, 31))
+        h = rng.integers(0, 4 if trial % 3 else 60, L).astype(np.int32)
+        if trial % 5 == 0:
+            h[rng.integers(0, L)] = 500
+        ind = [C.c_int(-1), C.c_int(-1), C.c_int(-1)]
+        capi.check(capi.lib().se2gpu_three_maxima(h.ctypes.data, L, C.byref(ind[0]), C.byref(ind[1]), C.byref(ind[2])))
+        assert tuple(i.value for i in ind) == ref.three_maxima(h), h      # the product's host function = the reference's member
+
+
+def test_features_in_area_equal_the_restatement(oracle, ref_feats):
+    rng = np.random.default_rng(4)
+    k = ref_feats[0][0]
+    for _ in range(300):
+        x, y = float(rng.uniform(-30, 670)), float(rng.uniform(-30, 510))
+        r = float(rng.choice([5, 20, 45, 120]))
+        lo = int(rng.integers(-1, 7)); hi = lo if rng.random() < 0.3 else (lo + int(rng.integers(0, 4)) if lo >= 0 else -1)
+        assert np.array_equal(ref.features_in_area(k, x, y, r, lo, hi), oracle.features_in_area(k, x, y, r, lo, hi)), (x, y, r, lo, hi)
+
+
+@pytest.mark.parametrize("a,b", [(0, 1), (1, 2), (0, 5), (3, 3), (9, 2)])
+def test_match_by_window_equals_the_restatement(oracle, ref_feats, a, b):
+    (k1, d1), (k2, d2) = ref_feats[a], ref_feats[b]
+    m_r, n_r, p_r = ref.match_window(k1, d1, k2, d2)
+    m_o, n_o, p_o = oracle.match_window(k1, d1, k2, d2)
+    assert n_r == n_o and np.array_equal(m_r, m_o) and np.array_equal(p_r, p_o)
+    assert n_r > (100 if a != 9 else 0)
+    for (win, lo, mn, mx, ratio) in ((8, 1, 0, 8, 0.9), (40, 2, 1, 5, 0.7), (20, 0, 0, 3, 0.6)):
+        m_r, n_r, p_r = ref.match_window(k1, d1, k2, d2, None, win, lo, mn, mx, ratio)
+        m_o, n_o, p_o = oracle.match_window(k1, d1, k2, d2, None, win, lo, mn, mx, ratio)
+        assert n_r == n_o and np.array_equal(m_r, m_o) and np.array_equal(p_r, p_o), (win, lo, mn, mx, ratio)
+    # duplicated queries: the eviction chain (vnMatches21) at work; chained vbPrevMatched
+    kk = np.concatenate([k1[:200], k1[:200]]); dd = np.concatenate([d1[:200], d1[:200]])
+    m_r, n_r, p_r = ref.match_window(kk, dd, k2, d2)
+    m_o, n_o, p_o = oracle.match_window(kk, dd, k2, d2)
+    assert n_r == n_o and np.array_equal(m_r, m_o) and np.array_equal(p_r, p_o)
+    m_r2, n_r2, _ = ref.match_window(kk, dd, k1, d1, prev_xy=p_r)
+    m_o2, n_o2, _ = oracle.match_window(kk, dd, k1, d1, prev_xy=p_o)
+    assert n_r2 == n_o2 and np.array_equal(m_r2, m_o2)
+
+
+def _projection_case(feats, seed, m=1500):
+    rng = np.random.default_rng(seed)
+    (k0, d0), (k1, d1) = feats[0], feats[1]
+    fx = fy = 400.0; cx, cy = 320.0, 240.0
+    src = rng.integers(0, len(k0), m)
+    depth = rng.uniform(800, 6000, m).astype(np.float32)
+    Xc = np.stack([(k0["x"][src] - cx) / fx * depth, (k0["y"][src] - cy) / fy * depth, depth], 1).astype(np.float32)
+    th = 0.01
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    t = np.array([15.0, -4.0, 8.0], np.float32)
+    Tcw = np.concatenate([R, t[:, None]], 1).astype(np.float32)
+    mp_pos = ((Xc - t) @ R).astype(np.float32)
+    mp_desc = d0[src].copy()
+    flip = rng.integers(0, 256, (m, 32)).astype(np.uint8) & ((rng.random((m, 32)) < 0.03).astype(np.uint8) * 255)
+    mp_desc ^= flip.astype(np.uint8)
+    mp_octave = k0["octave"][src].astype(np.int32)
+    mp_skip = (rng.random(m) < 0.1).astype(np.uint8)
+    kf_obs = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    return mp_pos, mp_desc, mp_octave, mp_skip, Tcw, (fx, fy, cx, cy), k1, d1, kf_obs
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_match_by_projection_equals_the_restatement(oracle, ref_feats, seed):
+    """cvu::se3map / camprjc, Frame::inImgBound, GetFeaturesInArea and the greedy pass, all the reference's own code."""
+    args = _projection_case(ref_feats, seed)
+    i_r, n_r = ref.match_projection(*args, 15, 2, 0.6)
+    i_o, n_o = oracle.match_projection(*args, 15, 2, 0.6)
+    assert n_r == n_o and n_r > 50 and np.array_equal(i_r, i_o)
+    a = list(args); a[0] = args[0].copy(); a[0][::4, 2] -= 1e5       # some points behind the camera
+    i_r, n_r = ref.match_projection(*a, 15, 2, 0.6)
+    i_o, n_o = oracle.match_projection(*a, 15, 2, 0.6)
+    assert n_r == n_o and np.array_equal(i_r, i_o)
+    a = list(args)
+    for k in range(4):
+        a[k] = np.repeat(args[k], 3, axis=0)                          # chains of map points competing for one feature
+    i_r, n_r = ref.match_projection(*a, 25, 1, 0.75)
+    i_o, n_o = oracle.match_projection(*a, 25, 1, 0.75)
+    assert n_r == n_o and np.array_equal(i_r, i_o)
+
+
+def _feature_vector(desc, nbits):
+    node = (desc[:, 0].astype(np.int32) | (desc[:, 1].astype(np.int32) << 8)) & ((1 << nbits) - 1)
+    order = np.argsort(node, kind="stable")
+    nodes, counts = np.unique(node[order], return_counts=True)
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    return nodes.astype(np.int32), ptr, order.astype(np.int32)
+
+
+@pytest.mark.parametrize("nbits,mp_only,ratio,ori", [(5, False, 0.6, True), (3, True, 0.6, True), (0, False, 0.9, False), (7, True, 0.75, True)])
+def test_search_by_bow_equals_the_restatement(oracle, ref_feats, nbits, mp_only, ratio, ori):
+    """DBoW2::FeatureVector is the reference's own class here (a std::map walked with lower_bound, ORBmatcher.cpp:128-276)."""
+    (k1, d1), (k2, d2) = ref_feats[0], ref_feats[2]
+    rng = np.random.default_rng(nbits)
+    fv1, fv2 = _feature_vector(d1, nbits), _feature_vector(d2, nbits)
+    h1 = (rng.random(len(k1)) < 0.7).astype(np.uint8); h2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    m_r, n_r = ref.search_by_bow(k1, d1, fv1, h1, k2, d2, fv2, h2, mp_only, ratio, ori)
+    m_o, n_o = oracle.search_by_bow(k1, d1, fv1, h1, k2, d2, fv2, h2, mp_only, ratio, ori)
+    assert n_r == n_o and np.array_equal(m_r, m_o)
+
+
+def test_frame_constructor_pipeline(oracle, synth):
+    """Track's per-frame front end as the reference runs it: Frame::Frame (undistort with D = 0, extractor, grid assignment in
+    the constructor itself) on two images, then MatchByWindow with the first frame's key points as vbPrevMatched."""
+    (a, b, m12, nm, prev) = ref.track_two_frames(synth.frame(4), synth.frame(5))
+    assert _same_features(a, oracle.orb_extract(synth.frame(4))) and _same_features(b, oracle.orb_extract(synth.frame(5)))
+    m_o, n_o, p_o = oracle.match_window(a[0], a[1], b[0], b[1])        # the restatement on the reference's own arrays
+    assert nm == n_o and nm > 300 and np.array_equal(m12, m_o) and np.array_equal(prev, p_o)
+
+
+def test_se2_algebra_and_triangulation_helpers():
+    """Se2::operator+ / - (src/Config.cpp:200-223) against the formulas the generator uses; cvu::triangulate recovers a point
+    from two exact projections; cvu::checkParallax's thresholds."""
+    from se2lam_amd import synth
+    rng = np.random.default_rng(8)
+    for _ in range(100):
+        a = np.array([rng.uniform(-5e3, 5e3), rng.uniform(-5e3, 5e3), rng.uniform(-3.1, 3.1)], np.float32)
+        b = np.array([rng.uniform(-500, 500), rng.uniform(-500, 500), rng.uniform(-3.1, 3.1)], np.float32)
+        s = ref.se2_compose(a, b)
+        c, sn = np.cos(np.float32(a[2])), np.sin(np.float32(a[2]))
+        assert np.allclose(s[:2], [a[0] + b[0] * c - b[1] * sn, a[1] + b[0] * sn + b[1] * c], rtol=1e-5, atol=1e-2)
+        assert abs(((s[2] - (a[2] + b[2]) + np.pi) % (2 * np.pi)) - np.pi) < 1e-5
+        d = ref.se2_compose(s, a, minus=True)                         # (a + b) - a = b
+        assert np.allclose(d[:2], b[:2], atol=2e-2) and abs(((d[2] - b[2] + np.pi) % (2 * np.pi)) - np.pi) < 1e-5
+    K = np.array([[400, 0, 320], [0, 400, 240], [0, 0, 1]], np.float32)
+    P1 = K @ np.eye(3, 4, dtype=np.float32)
+    T2 = np.eye(4, dtype=np.float32); T2[0, 3] = -150.0
+    P2 = K @ T2[:3]
+    for _ in range(50):
+        X = np.array([rng.uniform(-1500, 1500), rng.uniform(-800, 800), rng.uniform(1500, 6000), 1.0], np.float32)
+        u1 = P1 @ X; u2 = P2 @ X
+        got = ref.triangulate_point(u1[:2] / u1[2], u2[:2] / u2[2], P1, P2)
+        assert np.allclose(got, X[:3], rtol=2e-2), (got, X)
+    o1 = np.zeros(3, np.float32); o2 = np.array([150.0, 0, 0], np.float32)
+    assert ref.check_parallax(o1, o2, np.array([75.0, 0, 500.0], np.float32), 2)          # 17 degrees
+    assert not ref.check_parallax(o1, o2, np.array([75.0, 0, 50000.0], np.float32), 2)   # 0.17 degrees
+
+
+# ------------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
+    """_ref == HIP on the ten config-1 frames, key points and descriptors bit-exact."""
+    from se2lam_amd import orb
+    ex = orb.ORBextractor()
+    for t in range(10):
+        assert _same_features(ex(synth.frame(t)), ref_feats[t]), t
+    ex2 = orb.ORBextractor(500, 1.2, 8, orb.HARRIS_SCORE, 20)
+    from oracle import oracle
+    p = oracle.orb_params(500, 1.2, 8, 20, oracle.HARRIS_SCORE)
+    for t in (0, 7):
+        assert _same_features(ex2(synth.frame(t)), ref.orb_extract(synth.frame(t), p)), t
+
+
+@pytest.mark.gpu
+def test_hip_matchers_equal_the_compiled_reference(ref_feats):
+    from se2lam_amd.matcher import ORBmatcher
+    mt = ORBmatcher(0.9)
+    for a, b in ((0, 1), (1, 2), (0, 5), (3, 3)):
+        (k1, d1), (k2, d2) = ref_feats[a], ref_feats[b]
+        prev = _prev(k1)
+        nm, m12 = mt.MatchByWindow(k1, d1, k2, d2, prev, 20)
+        m_r, n_r, p_r = ref.match_window(k1, d1, k2, d2)
+        assert nm == n_r and np.array_equal(m12, m_r) and np.array_equal(prev, p_r), (a, b)
+    for seed in (0, 1):
+        args = _projection_case(ref_feats, seed)
+        nm, idx = ORBmatcher().MatchByProjection(*args, 15, 2)
+        i_r, n_r = ref.match_projection(*args, 15, 2, 0.6)
+        assert nm == n_r and np.array_equal(idx, i_r), seed
+    (k1, d1), (k2, d2) = ref_feats[0], ref_feats[2]
+    rng = np.random.default_rng(5)
+    fv1, fv2 = _feature_vector(d1, 5), _feature_vector(d2, 5)
+    h1 = (rng.random(len(k1)) < 0.7).astype(np.uint8); h2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    nm, m12 = ORBmatcher(0.6).SearchByBoW(k1, d1, fv1, h1, k2, d2, fv2, h2, bIfMPOnly=False)
+    m_r, n_r = ref.search_by_bow(k1, d1, fv1, h1, k2, d2, fv2, h2, False, 0.6, True)
+    assert nm == n_r and np.array_equal(m12, m_r)
