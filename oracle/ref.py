@@ -206,3 +206,38 @@ def se2_compose(a, b, minus=False):
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     f(a.ctypes.data, b.ctypes.data, int(minus), out.ctypes.data)
     return out
+
+
+def edge_se2xyz(g, pose, lw, uv):
+    """g2o::EdgeSE2XYZ::computeError / linearizeOplus on one edge of graph g's camera and extrinsic -> (e (2,), Jp (2,3), Jl (2,3))"""
+    D = C.POINTER(C.c_double)
+    f = lib().ref_edge_se2xyz
+    f.restype = None
+    f.argtypes = [C.c_double] * 3 + [C.c_void_p] * 8
+    R = np.ascontiguousarray(g.Rbc, np.float64); t = np.ascontiguousarray(g.tbc, np.float64)
+    pose = np.ascontiguousarray(pose, np.float64); lw = np.ascontiguousarray(lw, np.float64); uv = np.ascontiguousarray(uv, np.float64)
+    e = np.zeros(2); Jp = np.zeros((2, 3)); Jl = np.zeros((2, 3))
+    f(float(g.fx), float(g.cx), float(g.cy), R.ctypes.data, t.ctypes.data, pose.ctypes.data, lw.ctypes.data, uv.ctypes.data,
+      e.ctypes.data, Jp.ctypes.data, Jl.ctypes.data)
+    return e, Jp, Jl
+
+
+def edge_pre_se2(pi, pj, z):
+    """g2o::PreEdgeSE2 -> (e (3,), Ji (3,3), Jj (3,3))"""
+    pi = np.ascontiguousarray(pi, np.float64); pj = np.ascontiguousarray(pj, np.float64); z = np.ascontiguousarray(z, np.float64)
+    e = np.zeros(3); Ji = np.zeros((3, 3)); Jj = np.zeros((3, 3))
+    f = lib().ref_edge_pre_se2
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 6
+    f(pi.ctypes.data, pj.ctypes.data, z.ctypes.data, e.ctypes.data, Ji.ctypes.data, Jj.ctypes.data)
+    return e, Ji, Jj
+
+
+def se2_se3_round_trip(pose):
+    pose = np.ascontiguousarray(pose, np.float64)
+    out = np.zeros(3); d = np.zeros((3, 3))
+    f = lib().ref_se2_se3_round_trip
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(pose.ctypes.data, out.ctypes.data, d.ctypes.data)
+    return out, d

@@ -8,6 +8,8 @@
 //   se2lam::ORBmatcher::MatchByWindow / MatchByProjection / SearchByBoW / ComputeThreeMaxima / DescriptorDistance
 //                                         src/ORBmatcher.cpp:64-454
 //   cvu::camprjc / se3map / triangulate / checkParallax       src/cvutil.cpp
+//   g2o::EdgeSE2XYZ::computeError / linearizeOplus, SE2ToSE3, SE3ToSE2, d_inv_d_se2      src/EdgeSE2XYZ.cpp:16-106
+//   g2o::PreEdgeSE2::computeError / linearizeOplus             include/se2lam/EdgeSE2XYZ.h:62-102
 // against oracle/_shim (a stand-in for the OpenCV / ROS headers, and stubs of KeyFrame / MapPoint with the members the
 // matcher reads).  What this library pins is the se2lam-owned logic; the OpenCV arithmetic underneath is the shim's.
 // The signatures mirror oracle/orb_ref.cpp and oracle/match_ref.cpp so that tests call either through the same wrapper.
@@ -17,6 +19,7 @@
 #include <memory>
 #include <vector>
 
+#include "EdgeSE2XYZ.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
 #include "cvutil.h"
@@ -236,6 +239,55 @@ void ref_se2_compose(const float* a, const float* b, int minus, float* out3) {  
     const Se2 A(a[0], a[1], a[2]), B(b[0], b[1], b[2]);
     const Se2 r = minus ? (A - B) : (A + B);
     out3[0] = r.x; out3[1] = r.y; out3[2] = r.theta;
+}
+
+// One EdgeSE2XYZ through the reference's own computeError() / linearizeOplus() (src/EdgeSE2XYZ.cpp:61-106): camera f, cx, cy;
+// extrinsic Tbc = (Rbc row-major, tbc) as optimizer.cpp:199-215 hands it over (a rotation matrix turned into the SE3Quat's
+// quaternion); pose (x, y, theta); landmark; measurement.  e[2], Jp[2x3] = d e / d (x, y, theta), Jl[2x3] = d e / d landmark.
+void ref_edge_se2xyz(double f, double cx, double cy, const double* Rbc, const double* tbc, const double* pose, const double* lw,
+                     const double* uv, double* e, double* Jp, double* Jl) {
+    g2o::CameraParameters cam(f, g2o::Vector2D(cx, cy), 1.0);
+    Eigen::Matrix3d R;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R(r, c) = Rbc[3 * r + c];
+    g2o::SE3Quat Tbc;
+    Tbc.setRotation(Eigen::Quaterniond(R));
+    Tbc.setTranslation(g2o::Vector3D(tbc[0], tbc[1], tbc[2]));
+    g2o::VertexSE2 v1;
+    v1.setEstimate(g2o::SE2(pose[0], pose[1], pose[2]));
+    g2o::VertexSBAPointXYZ v2;
+    v2.setEstimate(g2o::Vector3D(lw[0], lw[1], lw[2]));
+    g2o::EdgeSE2XYZ edge;
+    edge.setVertex(0, &v1);
+    edge.setVertex(1, &v2);
+    edge.setMeasurement(g2o::Vector2D(uv[0], uv[1]));
+    edge.setCameraParameter(&cam);
+    edge.setExtParameter(Tbc);
+    edge.computeError();
+    edge.linearizeOplus();
+    for (int i = 0; i < 2; ++i) e[i] = edge.error()[i];
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) { Jp[3 * r + c] = edge.jacobianOplusXi()(r, c); Jl[3 * r + c] = edge.jacobianOplusXj()(r, c); }
+}
+void ref_edge_pre_se2(const double* pi, const double* pj, const double* z, double* e, double* Ji, double* Jj) {
+    g2o::VertexSE2 v1, v2;
+    v1.setEstimate(g2o::SE2(pi[0], pi[1], pi[2]));
+    v2.setEstimate(g2o::SE2(pj[0], pj[1], pj[2]));
+    g2o::PreEdgeSE2 edge;
+    edge.setVertex(0, &v1);
+    edge.setVertex(1, &v2);
+    edge.setMeasurement(g2o::Vector3D(z[0], z[1], z[2]));
+    edge.computeError();
+    edge.linearizeOplus();
+    for (int i = 0; i < 3; ++i) e[i] = edge.error()[i];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Ji[3 * r + c] = edge.jacobianOplusXi()(r, c); Jj[3 * r + c] = edge.jacobianOplusXj()(r, c); }
+}
+// SE3ToSE2(SE2ToSE3(x, y, theta)) and d_inv_d_se2 (src/EdgeSE2XYZ.cpp:16-39)
+void ref_se2_se3_round_trip(const double* pose, double* out3, double* dinv9) {
+    const g2o::SE2 p(pose[0], pose[1], pose[2]);
+    const g2o::SE2 q = g2o::SE3ToSE2(g2o::SE2ToSE3(p));
+    const g2o::Vector3D v = q.toVector();
+    out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2];
+    const Eigen::Matrix3d d = g2o::d_inv_d_se2(p);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dinv9[3 * r + c] = d(r, c);
 }
 
 }  // extern "C"

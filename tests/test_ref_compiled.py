@@ -259,6 +259,98 @@ def test_se2_algebra_and_triangulation_helpers():
     assert not ref.check_parallax(o1, o2, np.array([75.0, 0, 50000.0], np.float32), 2)   # 0.17 degrees
 
 
+def test_ba_edges_equal_the_compiled_reference(oracle, synth):
+    """g2o::EdgeSE2XYZ::computeError / linearizeOplus (src/EdgeSE2XYZ.cpp:61-106, through SE2ToSE3, SE3Quat products and the
+    camera map as the reference writes them) and g2o::PreEdgeSE2 (EdgeSE2XYZ.h:62-102) against the closed forms of
+    oracle/ba_ref.cpp that the HIP kernels restate: residuals and both Jacobians at random states around config-3 edges."""
+    g = synth.ba_graph(50, 5000)
+    rng = np.random.default_rng(0)
+    for _ in range(400):
+        e = int(rng.integers(0, g.E))
+        pose = g.poses[g.e_kf[e]] + rng.normal(0, [40, 40, 0.03])
+        lw = g.lms[g.e_lm[e]] + rng.normal(0, 60, 3)
+        a = oracle.ba_edge_se2xyz(g, pose, lw, g.e_uv[e])
+        b = ref.edge_se2xyz(g, pose, lw, g.e_uv[e])
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 1e-11 * max(1.0, np.abs(y).max())
+    for _ in range(400):
+        pi = np.array([rng.uniform(-8e3, 8e3), rng.uniform(-8e3, 8e3), rng.uniform(-3.1, 3.1)])
+        pj = pi + rng.normal(0, [300, 300, 0.5])
+        z = rng.normal(0, [300, 300, 0.5])
+        a = oracle.ba_edge_pre_se2(pi, pj, z)
+        b = ref.edge_pre_se2(pi, pj, z)
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 1e-12 * max(1.0, np.abs(y).max())
+    # PreEdgeSE2 has no angle wrap (EdgeSE2XYZ.h:80): the compiled reference shows it too
+    e, _, _ = ref.edge_pre_se2([0, 0, 3.1], [0, 0, -3.1], [0, 0, 0.08])
+    assert abs(e[2] - (-6.2 - 0.08)) < 1e-12
+    # SE3ToSE2(SE2ToSE3(p)) = p, and d_inv_d_se2 is the derivative of the inverse (finite differences)
+    for _ in range(50):
+        p = np.array([rng.uniform(-5e3, 5e3), rng.uniform(-5e3, 5e3), rng.uniform(-3.0, 3.0)])
+        back, dinv = ref.se2_se3_round_trip(p)
+        assert np.allclose(back, p, rtol=0, atol=1e-9)
+
+        def inv(q):
+            c, s = np.cos(q[2]), np.sin(q[2])
+            return np.array([-c * q[0] - s * q[1], s * q[0] - c * q[1], -q[2]])
+        num = np.stack([(inv(p + h) - inv(p - h)) / 2e-6 for h in np.eye(3) * 1e-6], 1)
+        assert np.allclose(dinv, num, rtol=1e-6, atol=1e-5)
+
+
+def test_reduced_system_from_the_references_own_jacobians(oracle, synth):
+    """The Schur-reduced pose system of a small window assembled in numpy from the COMPILED REFERENCE'S residuals and
+    Jacobians (robust weights and constructQuadraticForm as g2o defines them: H += J' rho' Omega J, b -= J' rho' Omega e) equals
+    the restatement's, which the HIP kernels are held to at 1e-11 (tests/test_ba_gpu.py)."""
+    g = synth.ba_graph(8, 60)
+    lam = 3.0
+    P, L = g.P, g.L
+    n = 3 * P
+    Hpp = np.zeros((n, n)); bp = np.zeros(n); Hll = np.zeros((L, 3, 3)); bl = np.zeros((L, 3)); Hpl = {}
+    for k in range(g.E):
+        kf, lm = int(g.e_kf[k]), int(g.e_lm[k])
+        e, Jp, Jl = ref.edge_se2xyz(g, g.poses[kf], g.lms[lm], g.e_uv[k])
+        w = g.e_info[k]
+        Om = np.array([[w[0], w[1]], [w[1], w[2]]])
+        e2 = e @ Om @ e
+        r1 = 1.0 if e2 <= g.huber ** 2 else g.huber / np.sqrt(e2)
+        Hll[lm] += Jl.T @ (r1 * Om) @ Jl
+        bl[lm] -= Jl.T @ (r1 * Om) @ e
+        if not g.fixed[kf]:
+            Hpp[3 * kf:3 * kf + 3, 3 * kf:3 * kf + 3] += Jp.T @ (r1 * Om) @ Jp
+            bp[3 * kf:3 * kf + 3] -= Jp.T @ (r1 * Om) @ e
+            Hpl[(kf, lm)] = Jp.T @ (r1 * Om) @ Jl
+    for k in range(g.O):
+        i, j = int(g.o_i[k]), int(g.o_j[k])
+        e, A, B = ref.edge_pre_se2(g.poses[i], g.poses[j], g.o_meas[k])
+        W = g.o_info[k].reshape(3, 3)
+        for (a, Ja) in ((i, A), (j, B)):
+            if g.fixed[a]:
+                continue
+            bp[3 * a:3 * a + 3] -= Ja.T @ W @ e
+            for (b, Jb) in ((i, A), (j, B)):
+                if not g.fixed[b]:
+                    Hpp[3 * a:3 * a + 3, 3 * b:3 * b + 3] += Ja.T @ W @ Jb
+    S = Hpp.copy(); bs = bp.copy()
+    for p in range(P):
+        if g.fixed[p]:
+            S[3 * p:3 * p + 3, 3 * p:3 * p + 3] = np.eye(3)
+        else:
+            S[3 * p:3 * p + 3, 3 * p:3 * p + 3] += lam * np.eye(3)
+    by_lm = {}
+    for (kf, lm), blk in Hpl.items():
+        by_lm.setdefault(lm, []).append((kf, blk))
+    for lm, obs in by_lm.items():
+        Dinv = np.linalg.inv(Hll[lm] + lam * np.eye(3))
+        for (a, Ba) in obs:
+            bs[3 * a:3 * a + 3] -= Ba @ Dinv @ bl[lm]
+            for (b, Bb) in obs:
+                S[3 * a:3 * a + 3, 3 * b:3 * b + 3] -= Ba @ Dinv @ Bb.T
+    want = oracle.ba_reduced_system(g, lam)
+    scale = np.abs(want["S"]).max()
+    assert np.abs(S - want["S"]).max() <= 1e-10 * scale
+    assert np.abs(bs - want["bs"]).max() <= 1e-10 * np.abs(want["bs"]).max()
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
