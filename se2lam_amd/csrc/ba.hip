@@ -5700,7 +5700,8 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
     const int n = h->D * h->P;
     SE2_CHECK(ba_linearize(h, lambda));
     SE2_CHECK(ba_reduce(h, lambda, false));
-    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
+    // (nsys > D * P when the poses were re-ordered into padded partitions: the rhs row is row nsys, not D * P)
+    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(h->nsys + 1) * h->ld));
     SE2_HIP(hipStreamSynchronize(h->stream));
     if (!h->h_pose_off.empty()) {   // the solver's fill-reducing order: gather the system back into pose order
         const int ns = h->nsys, ld = h->ld, D = h->D;
@@ -5754,7 +5755,7 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
     const int n = h->D * h->P;
     SE2_CHECK(ba_linearize(h, lambda));
     SE2_CHECK(ba_reduce(h, lambda, false));
-    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(n + 1) * h->ld));
+    SE2_CHECK(ba_allreduce(h, h->red, (size_t)(h->nsys + 1) * h->ld));   // all rows of the (possibly re-ordered, padded) system
     SE2_CHECK(ba_solve(h));
     SE2_HIP(hipStreamSynchronize(h->stream));
     SE2_HIP(hipMemcpy(x, h->xp.p, (size_t)n * 8, hipMemcpyDeviceToHost));

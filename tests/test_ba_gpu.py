@@ -199,7 +199,7 @@ def test_landmark_sharded_lm_schedule_on_a_start_that_rejects(synth):
     _sharded_equals_single(_kidnapped(synth, *case), 10, trials)
 
 
-def _sharded_equals_single(g, iters, trials=None, world=2):
+def _sharded_equals_single(g, iters, trials=None, world=2, debug_lam=None):
     """`world` landmark shards as `world` handles on `world` threads of ONE GPU; the all-reduce callback (no caller-owned
     buffer, so the library hands it the PACKED exchange: the lower-triangular tiles of [S; b^T], se2gpu_ba_exchange_doubles)
     sums the ranks' buffers on the host.  Same collective pattern as the RCCL path, which takes this buffer too."""
@@ -220,6 +220,7 @@ def _sharded_equals_single(g, iters, trials=None, world=2):
     barrier = threading.Barrier(world)
     stage = [None] * world
     results = [None] * world
+    dbg = [None] * world
     counts = [set() for _ in range(world)]
     errors = []
 
@@ -246,6 +247,8 @@ def _sharded_equals_single(g, iters, trials=None, world=2):
             o.load(g.shard(rank, world))
             o.initializeOptimization(0)
             assert o.exchange_doubles() == packed     # every rank chose the single handle's order
+            if debug_lam is not None:                 # the debug entry points are collectives too
+                dbg[rank] = (o.reduced_system(debug_lam), o.solve(debug_lam))
             o.optimize(iters)
             assert o.solver_path() == 0
             results[rank] = (o.stats, o.estimates())
@@ -265,7 +268,16 @@ def _sharded_equals_single(g, iters, trials=None, world=2):
         assert np.allclose(poses, single.estimates()[0], rtol=1e-8, atol=1e-8)
         assert np.array_equal(poses, results[0][1][0])  # replicated poses stay bit-identical across the ranks
         # the system exchange went through the packed triangle (the other exchanges are 4 scalars / world slots / 3P diagonals)
-        assert packed in counts[r] and (packed >= rect or not any(c >= rect for c in counts[r])), sorted(counts[r])
+        assert packed in counts[r] and (packed >= rect or debug_lam is not None or not any(c >= rect for c in counts[r])), sorted(counts[r])
+    if debug_lam is not None:   # se2gpu_ba_debug_reduced_system / _solve on a sharded handle whose poses were re-ordered
+        fresh = _opt(g)
+        S0, b0 = fresh.reduced_system(debug_lam)
+        x0, ok0 = fresh.solve(debug_lam)
+        assert ok0
+        for r in range(world):
+            (S, b), (x, ok) = dbg[r]
+            assert ok and np.abs(S - S0).max() <= 1e-10 * np.abs(S0).max() and np.abs(b - b0).max() <= 1e-10 * np.abs(b0).max()
+            assert np.abs(x - x0).max() <= 1e-8 * np.abs(x0).max()
     # every landmark lives on exactly one rank: the shards' landmark estimates together are the single run's
     lms = np.full_like(single.estimates()[1], np.nan)
     for r in range(world):
@@ -281,6 +293,18 @@ def test_landmark_sharded_config4_packed_exchange(synth, world):
     device, through the PACKED exchange (k_tri_pack -> all-reduce -> unpack): trial counts equal, chi^2 / lambda histories
     within 1e-9 of the single-GPU run, replicated poses bit-identical across ranks (Map.cpp:891-1053)."""
     _sharded_equals_single(synth.ba_graph(200, 20000), 4, world=world)
+
+
+@pytest.mark.gpu
+def test_sharded_debug_entry_points_reduce_the_reordered_system(synth):
+    """with the nested-dissection order the system has nsys > 3 P rows and its right-hand side sits in
+    row nsys; se2gpu_ba_debug_reduced_system / _solve summed only (3 P + 1) rows over the ranks.  A loop of 120 key frames
+    (re-ordered: the packed exchange is larger than the natural one) over 2 shards against the single handle."""
+    from se2lam_amd import capi
+    g = synth.ba_graph(120, 6000)
+    o = _opt(g)
+    assert o.exchange_doubles() > int(capi.lib().se2gpu_ba_exchange_doubles(g.P)), "expected a re-ordered (padded) system"
+    _sharded_equals_single(g, 3, world=2, debug_lam=7.0)
 
 
 @pytest.mark.gpu
