@@ -1155,7 +1155,6 @@ __device__ inline bool spin_until(const unsigned* f, unsigned epoch, bool lazy =
     return true;
 }
 
-template <bool SEED>
 __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __restrict__ A, double* __restrict__ PUB,
                                                      double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
@@ -1166,8 +1165,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
                                                      double* __restrict__ xout) {
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
-    const bool lazy_on = n < 0 ? false : true;   // (SE2GPU_BA_CHOL_LAZY=0 passes -n: A/B of the lazy polls)
-    if (n < 0) n = -n;
     const int nt = ld / kNB;
     // LDS: 36 KB per task (was 59), so that more tasks share a CU when a batch of windows is solved side by side
     // (k_batched).  The multiplier columns of the elimination re-use the operand tiles of the update phase: rows 0..15
@@ -1206,7 +1203,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
         for (int dq = tk.z; dq < tk.w; ++dq) {   // the block columns j >= r with a non-zero R(r, j), ascending
             const int j = deps_s[dq - tk.z];
             if (tid == 0) {
-                const bool lazy = lazy_on && dq + 1 < tk.w;   // only the last term is waited for in earnest
+                const bool lazy = dq + 1 < tk.w;   // only the last term is waited for in earnest
                 bool ok = true;
                 for (int sl = 0; sl < kSlabs; ++sl) {
                     ok = ok && spin_until(flagR + ((size_t)r * nbc + j) * kSlabs + sl, epoch, lazy);
@@ -1277,7 +1274,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
             if (tid == 0) fail[0] = 1e6;
             return;
         }
-        const bool lazy = lazy_on && dq + 1 < tk.w;       // not the block column this task's elimination waits for
+        const bool lazy = dq + 1 < tk.w;       // not the block column this task's elimination waits for
         const unsigned* f0 = flagA + ((size_t)j * nbc + m) * kSlabs + wv;
         const unsigned* f1 = hasT ? (isR ? flagR : flagA) + ((size_t)i * nbc + m) * kSlabs + wv : f0;
         const int need = dq - tk.z + 1;
@@ -1415,21 +1412,18 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
     double* mrc = &MRC[cb][lane];
     double* colv = lane < kNB ? &COLV[cb][lane] : DUMMY + (lane - kNB);   // (same row stride: immediate offsets below)
     double pmin = 1e300, mr_prev = 0.0, rvb[2][8];   // rvb: double buffer (static indices: the loop is unrolled)
-    // SEED: the multiplier comes straight from the reciprocal seed x0 and the Newton residual e = 1 - piv x0,
+    // The multiplier comes straight from the reciprocal seed x0 and the Newton residual e = 1 - piv x0,
     //     mr = m x0 (1 + e)        (= m / piv up to e^2 ~ 2e-15, like one Newton step on x0 first)
     // which takes the refined reciprocal - one dependent FP64 operation of 44 clk - off the pivot chain
-    // (tools/fp64_issue_probe.hip).  SE2GPU_BA_CHOL_SEED=0 keeps the refined reciprocal (A/B).
+    // (tools/fp64_issue_probe.hip; the refined-reciprocal variant measured the same and was removed in round 4).
     double piv = bcast_lane(m[0], cb);
-    double inv = 0.0, x0 = 0.0, e = 0.0;
-    if (SEED) { x0 = __builtin_amdgcn_rcp(piv); e = fma(-piv, x0, 1.0); }
-    else inv = fast_rcp1(piv);
+    double x0 = __builtin_amdgcn_rcp(piv), e = fma(-piv, x0, 1.0);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int jj = cb + q;
         pmin = fmin(pmin, piv);  // (ignores NaN: caught below)
-        double mr;
-        if (SEED) { const double mr0 = m[q] * x0; mr = fma(mr0, e, mr0); }
-        else mr = m[q] * inv;
+        const double mr0 = m[q] * x0;
+        const double mr = fma(mr0, e, mr0);
         mrs[q] = mr;
         mrc[q * 64] = mr;        // later waves need this column (the last wave's copy is never read)
         colv[q * kNB] = m[q];
@@ -1451,8 +1445,8 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
             m[q + 1] = fma(-mr, bcast_lane(m[q], jj + 1), m[q + 1]);
             piv = bcast_lane(m[q + 1], jj + 1);
             // next pivot: in flight during the rest of the update
-            if (SEED) { x0 = __builtin_amdgcn_rcp(piv); e = fma(-piv, x0, 1.0); }
-            else inv = fast_rcp1(piv);
+            x0 = __builtin_amdgcn_rcp(piv);
+            e = fma(-piv, x0, 1.0);
         }
         mr_prev = mr;
     }
@@ -1492,7 +1486,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
     if (stamp && lane == 0) stamp[12 + w] = wall_clock64();
     if (stamp && tid == 192) stamp[5] = wall_clock64();
 }
-template <bool SEED>
 __global__ __launch_bounds__(256) void k_chol_tiles(const double* __restrict__ A, double* __restrict__ PUB,
                                                      double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
@@ -1501,7 +1494,7 @@ __global__ __launch_bounds__(256) void k_chol_tiles(const double* __restrict__ A
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
                                                      double* __restrict__ xout) {
-    d_chol_tiles<SEED>(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
+    d_chol_tiles(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -4635,10 +4628,6 @@ int ba_evaluate(se2gpu_ba* h, const double* xp, double lambda) {
 
 // dense pose solve: augmented S|bs (device, already all-reduced) -> xp (device).
 // `fail` = scalar slot [2] of the fused buffer: set to 1 by the factorisation on a non-positive pivot.
-inline bool chol_lazy_polls() {
-    static const bool on = [] { const char* e = getenv("SE2GPU_BA_CHOL_LAZY"); return !(e && e[0] == '0'); }();
-    return on;
-}
 int ba_solve(se2gpu_ba* h, bool ctl = false) {
     hipStream_t st = h->stream;
     const int n = h->nsys;   // D * P, or the padded order of the permuted system (solve_plan_choose)
@@ -4677,17 +4666,9 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         static const bool fault = [] { const char* e = getenv("SE2GPU_BA_CHOL_FAULT"); return e && e[0] == '1'; }();
         const int skip = (fault && !h->chol_faulted && h->chol_ntask > 1) ? 1 : 0;
         h->chol_faulted = true;
-        static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
-        const int nk = chol_lazy_polls() ? n : -n;
-        const int nbck = nbc;
-        if (seed)
-            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, nk, nbck,
-                       h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                       fail, h->chol_trace.p, c, h->xp.p);
-        else
-            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, nk, nbck,
-                       h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                       fail, h->chol_trace.p, c, h->xp.p);
+        SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
+                   h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                   fail, h->chol_trace.p, c, h->xp.p);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
@@ -4908,7 +4889,6 @@ struct BatchPlan {
     std::vector<se2gpu_ba*> hs;
     std::vector<unsigned long> serials;
     int iters = -1, mode = -1;
-    bool seed = true;
     BatchArena arena;
     hipStream_t stream = nullptr;
     BatchKernel<d_ctl_init, 64> ctl_init;
@@ -4919,8 +4899,7 @@ struct BatchPlan {
     BatchKernel<d_pose_reduce, kBlock> pose_reduce;
     BatchKernel<d_maxdiag, 1024> maxdiag;
     BatchKernel<d_reduce2, kBlock> reduce2;
-    BatchKernel<d_chol_tiles<true>, 256> chol_seed;
-    BatchKernel<d_chol_tiles<false>, 256> chol_plain;
+    BatchKernel<d_chol_tiles, 256> chol;
     std::vector<hipEvent_t> events;
     ~BatchPlan() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -4945,8 +4924,6 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
     bp.iters = iters;
     bp.mode = mode;
     bp.stream = hs[0]->stream;
-    static const bool seed = [] { const char* e = getenv("SE2GPU_BA_CHOL_SEED"); return !(e && e[0] == '0'); }();
-    bp.seed = seed;
     for (int w = 0; w < count; ++w) {
         se2gpu_ba* h = hs[w];
         bp.serials[w] = h->init_serial;
@@ -4988,22 +4965,15 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
             unsigned* flagA = h->chol_flags.p;
             unsigned* flagR = flagA + kSlabs * (size_t)nt * nbc;
             double* fail = h->red + (size_t)ld * ld + 2;
-            const int nk = chol_lazy_polls() ? n : -n;
-            const int nbck = nbc;
-            if (bp.seed)
-                bp.chol_seed.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
-                                 (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                                 fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
-            else
-                bp.chol_plain.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, nk, nbck, h->chol_tasks.p, (const int*)h->chol_deps.p,
-                                  (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                                  fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
+            bp.chol.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, n, nbc, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                        (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                        fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
         }
     }
     bp.ctl_init.commit(bp.arena); bp.eval0.commit(bp.arena); bp.step.commit(bp.arena); bp.step_notify.commit(bp.arena);
     bp.lin0.commit(bp.arena); bp.lin.commit(bp.arena); bp.odo.commit(bp.arena); bp.pose_reduce.commit(bp.arena);
     bp.maxdiag.commit(bp.arena); bp.reduce2.commit(bp.arena);
-    bp.chol_seed.commit(bp.arena); bp.chol_plain.commit(bp.arena);
+    bp.chol.commit(bp.arena);
     SE2_CHECK(bp.arena.dev.reserve(bp.arena.host.size()));
     SE2_HIP(hipMemcpyAsync(bp.arena.dev.p, bp.arena.host.data(), bp.arena.host.size(), hipMemcpyHostToDevice, bp.stream));
     while ((int)bp.events.size() < count) {
@@ -5033,11 +5003,8 @@ int ba_batch_slot(const BatchPlan& bp, bool first, bool notify) {
     } else {
         bp.lin.launch(ar, st);
     }
-    static const bool pin = [] { const char* e = getenv("SE2GPU_BA_XCD_PIN"); return !(e && e[0] == '0'); }();
-    if (pin) bp.reduce2.launch_xcd(ar, st);
-    else bp.reduce2.launch(ar, st);
-    if (bp.seed) bp.chol_seed.launch(ar, st);
-    else bp.chol_plain.launch(ar, st);
+    bp.reduce2.launch_xcd(ar, st);   // every window on one XCD: its W rows stay in that L2 (k_batched_xcd)
+    bp.chol.launch(ar, st);
     (notify ? bp.step_notify : bp.step).launch(ar, st);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;

@@ -1,0 +1,74 @@
+"""Every environment switch of the library that selects another code path is exercised here ("no
+getenv-gated kernel without a test that sets it").  The switches are read once per process, so each case runs the same
+small parity script in a fresh interpreter: an LM history against the oracle (config 3), a lock-step window batch against
+one-by-one runs, one extract + MatchByWindow against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import oracle
+from se2lam_amd import synth, orb
+from se2lam_amd.matcher import ORBmatcher
+from se2lam_amd.optimizer import SlamOptimizer, optimize_batch
+
+def opt(g):
+    o = SlamOptimizer(); o.load(g); o.initializeOptimization(0); return o
+
+g = synth.ba_graph(50, 5000)
+o = opt(g); o.optimize(6)
+_, _, st = oracle.ba_optimize(g, 6, 0)
+assert o.stats["trials_hist"] == st["trials_hist"], (o.stats["trials_hist"], st["trials_hist"])
+assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=1e-7) and np.allclose(o.stats["lambda_hist"], st["lambda_hist"], rtol=1e-7)
+graphs = [synth.ba_graph(8, 60), synth.ba_graph(30, 2000), synth.ba_graph(50, 5000), synth.ba_graph(21, 600), synth.ba_graph(12, 200)]
+ref = []
+for gg in graphs:
+    a = opt(gg); a.optimize(5); ref.append((a.stats, a.estimates()))
+opts = [opt(gg) for gg in graphs]
+for rep in range(2):
+    for a in opts: a.reset_estimates()
+    optimize_batch(opts, 5)
+    for a, (s, (p, l)) in zip(opts, ref):
+        assert a.stats == s and np.array_equal(a.estimates()[0], p) and np.array_equal(a.estimates()[1], l)
+ex = orb.ORBextractor()
+(k1, d1), (k2, d2) = ex(synth.frame(0)), ex(synth.frame(1))
+ko, do = oracle.orb_extract(synth.frame(0))
+assert np.array_equal(k1, ko) and np.array_equal(d1, do)
+prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], 1), np.float32)
+nm, m12 = ORBmatcher(0.9).MatchByWindow(k1, d1, k2, d2, prev, 20)
+m_ref, nm_ref, _ = oracle.match_window(k1, d1, k2, d2)
+assert nm == nm_ref and np.array_equal(m12, m_ref)
+print("OK")
+""" % ROOT
+
+CASES = [
+    {},                                         # the defaults, as the reference point of this file
+    {"SE2GPU_BA_ND": "0"},                      # natural pose order in the dense solve
+    {"SE2GPU_BA_GRAPH": "0"},                   # no hipGraph capture / replay
+    {"SE2GPU_BA_LOCKSTEP": "0"},                # window batches on per-window streams
+    {"SE2GPU_BA_LOCKSTEP": "0", "SE2GPU_BA_BATCH_THREADS": "3"},
+    {"SE2GPU_BA_BATCH_GROUPS": "1"},
+    {"SE2GPU_BA_BATCH_GROUPS": "3"},
+    {"SE2GPU_BA_SYNC": "1"},                    # host-side LM controller
+    {"SE2GPU_BA_HOST_SOLVE": "1"},              # dense solve on the host (A/B path of DESIGN 4.1.1)
+    {"SE2GPU_BA_CHOL": "steps"},                # one launch per block column
+    {"SE2GPU_BA_PLAN": "host"},                 # graph plan built on the host
+    {"SE2GPU_BA_POOL": "0", "SE2GPU_MATCHER_POOL": "0"},
+    {"SE2GPU_ORB_SIDE_STREAM": "0", "SE2GPU_ORB_PIPELINE_MIN": "1"},
+    {"SE2GPU_ORB_SCORE": "sparse"},
+]
+
+
+@pytest.mark.parametrize("env", CASES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "defaults")
+def test_switch_keeps_results(env):
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (env, r.stdout[-500:], r.stderr[-1500:])
