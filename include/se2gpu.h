@@ -331,6 +331,11 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
  * dependency timed out earlier in the handle's life (reported once on stderr), 3 = host solve (SE2GPU_BA_HOST_SOLVE=1).
  * Tests use it to make sure that results were not produced by the fallback. */
 int se2gpu_ba_debug_solver_path(const se2gpu_ba* h);
+/* Soak-test introspection of the dataflow solve's tile hand-offs.  With SE2GPU_BA_CHOL_VERIFY=1 in the environment every
+ * published half-slab carries a checksum and every consumer checks its loads against it: counts2 = {mismatches, half-slabs
+ * checked}; records (cap x 8 words, may be NULL): {epoch, consumer task, kind << 32 | tile row << 16 | column, slab << 8 |
+ * part, consumer XCC, got, want, 100 MHz time stamp}.  SE2GPU_ERR_STATE when the handle does not run in that mode. */
+int se2gpu_ba_debug_chol_verify(se2gpu_ba* h, unsigned long long* counts2, unsigned long long* records, int cap);
 /* The plan of the dense pose solve (tile tasks, their dependency lists, the fill-reducing order of the poses) for a P x P
  * block pattern, computed on the host without a device - what stands in for CHOLMOD's symbolic analysis behind
  * /root/reference/include/se2lam/optimizer.h:31.  Test introspection (tests/test_solve_plan.py). */

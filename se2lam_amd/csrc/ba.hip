@@ -1155,6 +1155,24 @@ __device__ inline bool spin_until(const unsigned* f, unsigned epoch, bool lazy =
     return true;
 }
 
+// VERIFY (SE2GPU_BA_CHOL_VERIFY=1, the soak tool's mode): every published half-slab (M or MR: 8 columns x 32 rows) travels with
+// the XOR of its 256 bit patterns, and every consumer checks what it loaded against it.  A hand-off that delivered a stale
+// or torn payload - the flag seen before the payload stores had landed, a line served from a cache that should have been
+// bypassed - shows up as a record {epoch, consumer task, kind / tile row / column of the tile, slab, part, consumer XCC,
+// got, want} in `vfy` instead of as a last-bit difference in some chi^2 a few hundred operations later.
+//   vfy[0] = mismatches, vfy[1] = half-slabs checked, records of 8 words from vfy[8] (the first 64), checksums from vfy[520]:
+//   [(kind nt + i) nbc + j][slab][part]
+constexpr int kVfyRecords = 64, kVfyChk = 8 + 8 * kVfyRecords;
+__device__ inline unsigned long long wave_xor64(unsigned long long v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v ^= (unsigned long long)__shfl_xor((long long)v, m);
+    return v;
+}
+__device__ inline unsigned long long bits4(d2_t a, d2_t b) {
+    return (unsigned long long)__double_as_longlong(a.x) ^ (unsigned long long)__double_as_longlong(a.y) ^
+           (unsigned long long)__double_as_longlong(b.x) ^ (unsigned long long)__double_as_longlong(b.y);
+}
+template <bool VERIFY>
 __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __restrict__ A, double* __restrict__ PUB,
                                                      double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
@@ -1162,7 +1180,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
-                                                     double* __restrict__ xout) {
+                                                     double* __restrict__ xout, unsigned long long* __restrict__ vfy) {
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     const int nt = ld / kNB;
@@ -1319,6 +1337,30 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
                     d2_t rj0 = load_agent(tj + kSlabDoubles / 2), rj1 = load_agent(tj + kSlabDoubles / 2 + 2 * kNB);
                     d2_t ri0 = load_agent(ti + kSlabDoubles / 2), ri1 = load_agent(ti + kSlabDoubles / 2 + 2 * kNB);
                     SE2_WAIT_VM6(mj0, mj1, rj0, rj1, ri0, ri1);
+                    if constexpr (VERIFY) {
+                        const unsigned long long got[3] = {wave_xor64(bits4(mj0, mj1)), wave_xor64(bits4(rj0, rj1)), wave_xor64(bits4(ri0, ri1))};
+                        const size_t tjx = ((size_t)(0 * nt + j) * nbc + m) * kSlabs + wv;
+                        const size_t tix = ((size_t)((hasT && isR ? 1 : 0) * nt + (hasT ? i : j)) * nbc + m) * kSlabs + wv;
+                        const unsigned long long* want_p[3] = {vfy + kVfyChk + 2 * tjx, vfy + kVfyChk + 2 * tjx + 1, vfy + kVfyChk + 2 * tix + 1};
+                        if (ln == 0) {
+                            for (int part = 0; part < 3; ++part) {
+                                const unsigned long long want = __hip_atomic_load(want_p[part], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                atomicAdd(vfy + 1, 1ull);
+                                if (want != got[part]) {
+                                    const unsigned long long k = atomicAdd(vfy, 1ull);
+                                    if (k < (unsigned long long)kVfyRecords) {
+                                        unsigned long long* r = vfy + 8 + 8 * k;
+                                        unsigned xcc;
+                                        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                                        r[0] = epoch; r[1] = bx;
+                                        r[2] = ((unsigned long long)(part == 2 ? (isR ? 1 : 0) : 0) << 32) | ((unsigned long long)(part == 2 ? i : j) << 16) | (unsigned)m;
+                                        r[3] = ((unsigned long long)wv << 8) | (unsigned)part;
+                                        r[4] = xcc & 0xf; r[5] = got[part]; r[6] = want; r[7] = (unsigned long long)wall_clock64();
+                                    }
+                                }
+                            }
+                        }
+                    }
                     Ta[sr][sc] = ri0.x; Ta[sr][sc + 1] = ri0.y; Ta[sr][sc + 2] = ri1.x; Ta[sr][sc + 3] = ri1.y;
                     Tb[sr][sc] = mj0.x; Tb[sr][sc + 1] = mj0.y; Tb[sr][sc + 2] = mj1.x; Tb[sr][sc + 3] = mj1.y;
                     Tc[sr][sc] = rj0.x; Tc[sr][sc + 1] = rj0.y; Tc[sr][sc + 2] = rj1.x; Tc[sr][sc + 3] = rj1.y;
@@ -1472,6 +1514,23 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
             store_agent(pb + kSlabDoubles / 2 + q * kNB, d2_t{mrs[q], mrs[q + 1]});
         }
     }
+    if constexpr (VERIFY) {   // the checksums of this slab's two halves, in front of the flag like the payload
+        unsigned long long xm = 0, xr = 0;
+        if (lane >= kNB) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                xm ^= (unsigned long long)__double_as_longlong(m[q]);
+                xr ^= (unsigned long long)__double_as_longlong(mrs[q]);
+            }
+        }
+        xm = wave_xor64(xm);
+        xr = wave_xor64(xr);
+        if (lane == 0) {
+            const size_t tx = ((size_t)((isR || isDiag ? 1 : 0) * nt + i) * nbc + j) * kSlabs + w;
+            __hip_atomic_store(vfy + kVfyChk + 2 * tx, xm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(vfy + kVfyChk + 2 * tx + 1, xr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // y_un = the rhs row after the elimination of this block column: a T row of the task in its tile row, or a row of the
     // diagonal tile itself when the system does not end on a tile boundary; read by the x tasks of this launch
     if (!isR && i == n / kNB && lane == (isDiag ? 0 : kNB) + n % kNB) {
@@ -1486,6 +1545,7 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __
     if (stamp && lane == 0) stamp[12 + w] = wall_clock64();
     if (stamp && tid == 192) stamp[5] = wall_clock64();
 }
+template <bool VERIFY>
 __global__ __launch_bounds__(256) void k_chol_tiles(const double* __restrict__ A, double* __restrict__ PUB,
                                                      double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
@@ -1493,8 +1553,8 @@ __global__ __launch_bounds__(256) void k_chol_tiles(const double* __restrict__ A
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
-                                                     double* __restrict__ xout) {
-    d_chol_tiles(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout);
+                                                     double* __restrict__ xout, unsigned long long* __restrict__ vfy) {
+    d_chol_tiles<VERIFY>(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout, vfy);
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -3039,6 +3099,7 @@ struct se2gpu_ba {
     int nsys = 0;                 // order of the (padded) system the solver factorises; D * P in natural order
     int solve_depth = 0;          // block columns on the longest dependency chain of the plan (debug)
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc][kSlabs] epochs
+    DevBuf<unsigned long long> chol_vfy;   // SE2GPU_BA_CHOL_VERIFY=1: mismatch records + half-slab checksums (d_chol_tiles<true>)
     DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
     DevBuf<unsigned long long> l0_acc;   // k_lambda0: {max |diag H| as bits, workgroups arrived}; left at zero by every run
@@ -4343,6 +4404,14 @@ int ba_upload_graph(se2gpu_ba* h) {
         const int nt2 = h->ld / kNB, nbc2 = (h->nsys + kNB - 1) / kNB;
         SE2_CHECK(h->chol_flags.reserve(2 * kSlabs * (size_t)nt2 * nbc2));
         SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * kSlabs * (size_t)nt2 * nbc2 * sizeof(unsigned), st));   // flags = 0 = "no epoch yet"
+        static const bool verify = [] { const char* e = getenv("SE2GPU_BA_CHOL_VERIFY"); return e && e[0] == '1'; }();
+        if (verify) {
+            const size_t words = kVfyChk + 2 * 2 * kSlabs * (size_t)nt2 * nbc2;
+            SE2_CHECK(h->chol_vfy.reserve(words));
+            SE2_HIP(hipMemsetAsync(h->chol_vfy.p, 0, words * sizeof(unsigned long long), st));
+        } else {
+            h->chol_vfy.release();
+        }
         const char* env = getenv("SE2GPU_BA_CHOL");
         h->chol_steps = (env && std::strcmp(env, "steps") == 0) || nt2 > 64 || h->chol_fallback;
         const char* tr = getenv("SE2GPU_BA_CHOL_TRACE");
@@ -4666,9 +4735,14 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         static const bool fault = [] { const char* e = getenv("SE2GPU_BA_CHOL_FAULT"); return e && e[0] == '1'; }();
         const int skip = (fault && !h->chol_faulted && h->chol_ntask > 1) ? 1 : 0;
         h->chol_faulted = true;
-        SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
-                   h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                   fail, h->chol_trace.p, c, h->xp.p);
+        if (h->chol_vfy.p)
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
+                       h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                       fail, h->chol_trace.p, c, h->xp.p, h->chol_vfy.p);
+        else
+            SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
+                       h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                       fail, h->chol_trace.p, c, h->xp.p, (unsigned long long*)nullptr);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
@@ -4899,7 +4973,9 @@ struct BatchPlan {
     BatchKernel<d_pose_reduce, kBlock> pose_reduce;
     BatchKernel<d_maxdiag, 1024> maxdiag;
     BatchKernel<d_reduce2, kBlock> reduce2;
-    BatchKernel<d_chol_tiles, 256> chol;
+    BatchKernel<d_chol_tiles<false>, 256> chol;
+    BatchKernel<d_chol_tiles<true>, 256> chol_v;     // SE2GPU_BA_CHOL_VERIFY=1
+    bool verify = false;
     std::vector<hipEvent_t> events;
     ~BatchPlan() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -4965,15 +5041,21 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
             unsigned* flagA = h->chol_flags.p;
             unsigned* flagR = flagA + kSlabs * (size_t)nt * nbc;
             double* fail = h->red + (size_t)ld * ld + 2;
-            bp.chol.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, n, nbc, h->chol_tasks.p, (const int*)h->chol_deps.p,
-                        (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                        fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p);
+            bp.verify = hs[0]->chol_vfy.p != nullptr;
+            if (bp.verify)
+                bp.chol_v.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, n, nbc, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                              (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                              fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p, h->chol_vfy.p);
+            else
+                bp.chol.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, n, nbc, h->chol_tasks.p, (const int*)h->chol_deps.p,
+                            (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
+                            fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p, (unsigned long long*)nullptr);
         }
     }
     bp.ctl_init.commit(bp.arena); bp.eval0.commit(bp.arena); bp.step.commit(bp.arena); bp.step_notify.commit(bp.arena);
     bp.lin0.commit(bp.arena); bp.lin.commit(bp.arena); bp.odo.commit(bp.arena); bp.pose_reduce.commit(bp.arena);
     bp.maxdiag.commit(bp.arena); bp.reduce2.commit(bp.arena);
-    bp.chol.commit(bp.arena);
+    bp.chol.commit(bp.arena); bp.chol_v.commit(bp.arena);
     SE2_CHECK(bp.arena.dev.reserve(bp.arena.host.size()));
     SE2_HIP(hipMemcpyAsync(bp.arena.dev.p, bp.arena.host.data(), bp.arena.host.size(), hipMemcpyHostToDevice, bp.stream));
     while ((int)bp.events.size() < count) {
@@ -5004,7 +5086,8 @@ int ba_batch_slot(const BatchPlan& bp, bool first, bool notify) {
         bp.lin.launch(ar, st);
     }
     bp.reduce2.launch_xcd(ar, st);   // every window on one XCD: its W rows stay in that L2 (k_batched_xcd)
-    bp.chol.launch(ar, st);
+    if (bp.verify) bp.chol_v.launch(ar, st);
+    else bp.chol.launch(ar, st);
     (notify ? bp.step_notify : bp.step).launch(ar, st);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
@@ -5708,6 +5791,20 @@ int se2gpu_ba_debug_solve_plan(int P, int D, const uint8_t* pattern, int allow_n
         SE2_REQUIRE(dep_cap >= (int)sp.deps.size(), SE2GPU_ERR_CAPACITY, "debug_solve_plan: %zu dependency entries", sp.deps.size());
         std::memcpy(deps, sp.deps.data(), sp.deps.size() * 4);
     }
+    return SE2GPU_OK;
+}
+
+// SE2GPU_BA_CHOL_VERIFY=1: {mismatches, half-slabs checked} and up to `cap` records of 8 words (see d_chol_tiles); returns
+// SE2GPU_ERR_STATE when the handle does not run in verify mode
+int se2gpu_ba_debug_chol_verify(se2gpu_ba* h, unsigned long long* counts2, unsigned long long* records, int cap) {
+    SE2_REQUIRE(h && h->initialized && h->chol_vfy.p, SE2GPU_ERR_STATE, "the handle does not verify its hand-offs (SE2GPU_BA_CHOL_VERIFY=1)");
+    SE2_CHECK(ba_join(h));
+    SE2_HIP(hipStreamSynchronize(h->stream));
+    unsigned long long head[8];
+    SE2_HIP(hipMemcpy(head, h->chol_vfy.p, sizeof(head), hipMemcpyDeviceToHost));
+    counts2[0] = head[0]; counts2[1] = head[1];
+    const int nrec = (int)std::min<unsigned long long>(std::min<unsigned long long>(head[0], kVfyRecords), (unsigned long long)std::max(cap, 0));
+    if (nrec && records) SE2_HIP(hipMemcpy(records, h->chol_vfy.p + 8, (size_t)nrec * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return SE2GPU_OK;
 }
 

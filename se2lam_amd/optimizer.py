@@ -95,6 +95,13 @@ class SlamOptimizer:
         """se2gpu_ba_exchange_doubles_h: size of the packed system exchange of this (initialised) handle"""
         return int(capi.lib().se2gpu_ba_exchange_doubles_h(self._h))
 
+    def chol_verify(self):
+        """se2gpu_ba_debug_chol_verify (SE2GPU_BA_CHOL_VERIFY=1): (mismatches, half-slabs checked, records (k, 8) uint64)"""
+        counts = np.zeros(2, np.uint64)
+        rec = np.zeros((64, 8), np.uint64)
+        capi.check(capi.lib().se2gpu_ba_debug_chol_verify(self._h, counts.ctypes.data, rec.ctypes.data, 64))
+        return int(counts[0]), int(counts[1]), rec[:min(int(counts[0]), 64)]
+
     def solver_path(self) -> int:
         """se2gpu_ba_debug_solver_path: 0 dataflow, 1 column launches (configured), 2 column launches (fallback), 3 host"""
         return int(capi.lib().se2gpu_ba_debug_solver_path(self._h))
