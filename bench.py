@@ -375,6 +375,11 @@ def main():
             "ms_per_step": 1e3 * dt / steps, "timed_s": dt,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
+            # the figure that CAN scale with N: every rank optimises its own independent windows, no collective (north_star:
+            # "independent keyframe windows shard across the GPUs"); `value` above is the strong-scaling form of ONE window,
+            # whose replicated dense solve caps it
+            "value_weak": (windows_obj or {}).get("value"), "scaling_weak": "weak",
+            "metric_weak": (windows_obj or {}).get("metric"),
             "config": {"workload": f"globalBA-window {g_full.P} KF / {g_full.L} landmarks / {g_full.E} EdgeSE2XYZ "
                                    f"+ {g_full.O} PreEdgeSE2, LM optimize(10) (config 4 formulation, SURVEY D3)",
                        "parallelism": f"landmark-sharded x{world}, RCCL all-reduce of [S|b]" if world > 1 else "single GPU",
@@ -438,12 +443,48 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
                      "whole_step_frac": B * rate / world / 1e9 / HBM_PEAK_GBS})
         log(f"BA windows x{n}: {rate:.0f} it/s aggregate")
     best = max(rows, key=lambda r: r["iters_per_s"])
+    mixed = None
+    if args.ba_windows <= 0 or args.ba_windows >= 16:
+        # the same batch size with DISTINCT windows (30-60 key frames, 3-6 k landmarks, different seeds, a few starts that
+        # reject trials): sizes, solve plans and accept / reject patterns differ per window - the honest form of the number above
+        nmix = args.ba_windows if args.ba_windows > 0 else 64
+        gs = synth.mixed_windows(nmix)
+        mopts = []
+        for gm in gs:
+            o = SlamOptimizer()
+            o.load(gm)
+            o.initializeOptimization(0)
+            mopts.append(o)
+
+        def run_mixed():
+            reset_estimates_batch(mopts)
+            its = optimize_batch(mopts, ITERS_PER_CALL)
+            return sum(its), sum(i * gm.algorithmic_bytes_per_iter() for i, gm in zip(its, gs)), sum(o.stats["trials"] for o in mopts)
+
+        run_mixed()
+        sync_all()
+        t0 = time.perf_counter()
+        done = byts = trials = reps = 0
+        while reps < calls or time.perf_counter() - t0 < MIN_TIMED_S:
+            a, b, c = run_mixed()
+            done += a; byts += b; trials += c; reps += 1
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            dt = dist.allreduce_max(dt)
+        mixed = {"windows_per_gpu": nmix, "iters_per_s": world * done / dt, "lm_trials_per_iter": trials / max(done, 1),
+                 "ms_per_optimize10": 1e3 * dt / reps, "whole_step_achieved_gbs": byts / dt / 1e9,
+                 "whole_step_frac": byts / dt / 1e9 / HBM_PEAK_GBS,
+                 "key_frames": [min(gm.P for gm in gs), max(gm.P for gm in gs)], "landmarks": [min(gm.L for gm in gs), max(gm.L for gm in gs)],
+                 "edges_total": int(sum(gm.E for gm in gs)), "windows_with_rejected_trials": int(sum(1 for o in mopts if max(o.stats["trials_hist"]) > 1))}
+        log(f"BA windows x{nmix} (distinct windows): {mixed['iters_per_s']:.0f} it/s aggregate, {mixed['lm_trials_per_iter']:.2f} trials per iteration")
+        del mopts
     return {"metric": "BA LM-iters/s, independent 50-KF windows in flight", "value": best["iters_per_s"],
             "unit": "iters/s", "n_gpus": world, "scaling": "weak",
             "config": {"workload": f"localBA window {g.P} KF / {g.L} landmarks / {g.E} EdgeSE2XYZ + {g.O} PreEdgeSE2, "
                                    f"LM optimize(10), N windows concurrently per GPU (no collective)",
                        "algorithmic_bytes_per_iter": B},
-            "best": best, "sweep": rows}
+            "best": best, "sweep": rows, "mixed": mixed}
 
 
 def _ba_cpu_baseline(g, seconds):

@@ -101,7 +101,10 @@ public:
     void setVerbose(bool v) { verbose_ = v; }
     void setForceStopFlag(bool* flag) { stop_ = flag; }                   // LocalMapper.cpp:246
     bool initializeOptimization(int level = 0) {                          // LocalMapper.cpp:259
-        (void)level;
+        // g2o optimises over the edges of ONE level; the device graph holds every edge that was added.  An edge moved to
+        // another level (setLevel) before this call would be optimised over all the same - refuse instead of doing so silently
+        for (const EdgeHandle& e : edges_) if (e.level_ != level) throw std::runtime_error("initializeOptimization: an edge has been moved to another level (setLevel); the device graph optimises over all added edges");
+        for (const EdgeHandle& e : plain_edges_) if (e.level_ != level) throw std::runtime_error("initializeOptimization: an edge has been moved to another level (setLevel); the device graph optimises over all added edges");
         check(se2gpu_ba_initialize(h_), "initializeOptimization");
         return true;
     }
@@ -124,12 +127,15 @@ public:
         }
         return edge_chi2_.at(index);
     }
-    // g2o::SparseOptimizer::clear(): vertices and edges are gone, every handle handed out so far is invalid
+    // g2o::SparseOptimizer::clear(): vertices and edges are gone, every vertex / edge handle handed out so far is invalid.
+    // Parameters survive it, as in g2o (OptimizableGraph::clear() keeps _parameters; clearParameters() drops them): a CamPara*
+    // from addCamPara stays valid across clear() and is re-registered with the library's handle, which forgets its camera.
     void clear() {
         check(se2gpu_ba_clear(h_), "clear");
-        edges_.clear(); plain_edges_.clear(); vertices_.clear(); edge_chi2_.clear(); cams_.clear();
+        edges_.clear(); plain_edges_.clear(); vertices_.clear(); edge_chi2_.clear();
+        for (const CamPara& c : cams_) check(se2gpu_ba_add_cam(h_, c.focal_length, c.principle_point[0], c.principle_point[1]), "clear: camera");
     }
-    void clearParameters() {}
+    void clearParameters() { cams_.clear(); }
     double activeRobustChi2() { return se2gpu_ba_chi2(h_); }
     double currentLambda() const { return stats_.lambda_final; }          // REJECT_IF_LARGE_LAMBDA, LocalMapper.cpp:285-292
     const se2gpu_ba_stats& stats() const { return stats_; }

@@ -4962,6 +4962,7 @@ struct BatchKernel<Body, BS> {
 struct BatchPlan {
     std::vector<se2gpu_ba*> hs;
     std::vector<unsigned long> serials;
+    std::vector<hipStream_t> streams;   // every window's stream at build time (se2gpu_ba_set_stream between two batches: rebuild)
     int iters = -1, mode = -1;
     BatchArena arena;
     hipStream_t stream = nullptr;
@@ -4983,7 +4984,7 @@ struct BatchPlan {
     bool matches(se2gpu_ba** h, int count, int it, int md) const {
         if ((int)hs.size() != count || it != iters || md != mode) return false;
         for (int i = 0; i < count; ++i)
-            if (hs[i] != h[i] || serials[i] != h[i]->init_serial) return false;
+            if (hs[i] != h[i] || serials[i] != h[i]->init_serial || streams[i] != h[i]->stream) return false;
         return true;
     }
 };
@@ -4997,12 +4998,14 @@ bool ba_lockstep_ok(const se2gpu_ba* h) {
 int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int mode) {
     bp.hs.assign(hs, hs + count);
     bp.serials.resize(count);
+    bp.streams.resize(count);
     bp.iters = iters;
     bp.mode = mode;
     bp.stream = hs[0]->stream;
     for (int w = 0; w < count; ++w) {
         se2gpu_ba* h = hs[w];
         bp.serials[w] = h->init_serial;
+        bp.streams[w] = h->stream;
         const Bufs B = bufs(h, true);
         double* scal = h->red + (size_t)h->ld * h->ld;
         const dim3 ug = grid1((size_t)h->L * kGroup, kBlock);
@@ -6212,6 +6215,12 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
         const int rc = ba_optimize_lockstep(hs, count, iters, mode, stop_flag, stats, &handled);
         if (handled || rc != SE2GPU_OK) return rc;
     }
+    // Cross-stream orderings left by se2gpu_ba_reset_estimates_batch are resolved HERE, by the calling thread, before any
+    // enqueue thread starts: a window's second optimize() of a shape is captured into a hipGraph, and while one thread
+    // captures the stream the batched reset ran on, the runtime refuses another thread's hipStreamWaitEvent on that reset's
+    // event ("dependency created on uncaptured work in another stream" - found by tools/soak_fresh.sh, round 4: 91 of 130
+    // per-stream batches after a batched reset).
+    for (int i = 0; i < count; ++i) SE2_CHECK(ba_join(hs[i]));
     static const int env_threads = [] { const char* e = getenv("SE2GPU_BA_BATCH_THREADS"); return e ? atoi(e) : 0; }();
     int nthr = env_threads > 0 ? env_threads : 8;
     nthr = std::max(1, std::min(nthr, count / 4));

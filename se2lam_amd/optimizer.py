@@ -76,7 +76,8 @@ class SlamOptimizer:
     def clear(self):
         capi.check(capi.lib().se2gpu_ba_clear(self._h))
 
-    clearParameters = clear
+    def clearParameters(self):
+        """g2o drops the camera parameters here, not in clear(); this harness re-adds the camera with every load()"""
 
     def initializeOptimization(self, level: int = 0):
         assert level == 0

@@ -657,3 +657,40 @@ def kf_pair(N: int = 80, seed: int = 0, baseline: float = 400.0):
             m_kf.append(k); m_mp.append(j)
             m_info.append(Rn @ np.diag([1 / 4.0, 1 / 4.0, 1 / sz ** 2]) @ Rn.T)
     return kf, mp, np.array(m_kf, np.int32), np.array(m_mp, np.int32), np.stack(m_info)
+
+
+def kidnapped(g: "BAGraph", dxy: float, dth: float, nbad: int, seed: int) -> "BAGraph":
+    """A copy of g with `nbad` key frames displaced by N(0, dxy) mm / N(0, dth) rad (landmarks untouched): the first steps
+    overshoot and Levenberg-Marquardt has to reject trials.  Headings stay in [-pi, pi) (the reference's Se2 normalises on
+    construction, and PreEdgeSE2 has no angle wrap)."""
+    import copy
+    k = copy.copy(g)          # the generator caches its graphs: never modify the shared instance
+    rng = np.random.default_rng(seed)
+    k.poses = g.poses.copy()
+    idx = rng.choice(np.arange(1, g.P), min(nbad, g.P - 1), replace=False)
+    k.poses[idx, :2] += rng.normal(0, dxy, (len(idx), 2))
+    k.poses[idx, 2] += rng.normal(0, dth, len(idx))
+    k.poses[:, 2] = (k.poses[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    return k
+
+
+def mixed_windows(count: int = 64, p_range=(30, 60), l_range=(3000, 6000), kidnapped_every: int = 11, seed: int = 4242):
+    """`count` DISTINCT local windows: key-frame counts, landmark counts and seeds all differ, and every
+    `kidnapped_every`-th window starts from displaced key frames so that its LM run rejects trials.  What a mapper's batch of
+    windows looks like - as opposed to `count` copies of one graph, where every window has the same sizes, the same solve
+    plan and the same accept / reject pattern."""
+    out = []
+    for k in range(count):
+        P = p_range[0] + (7 * k + 3) % (p_range[1] - p_range[0] + 1)
+        L = l_range[0] + (997 * k + 131) % (l_range[1] - l_range[0] + 1)
+        g = ba_graph(P, L, seed=seed + k)
+        if kidnapped_every and k % kidnapped_every == kidnapped_every // 2:
+            # Huber-weighted windows of this size shrug most displacements off; the displacement seeds below were picked (with
+            # the CPU oracle, once) so that the default batch's kidnapped windows really make g2o's policy reject trials
+            g = kidnapped(g, 3000.0, 0.8, 2, _KIDNAP_SEEDS.get((count, seed, k), seed + 100 + k))
+        out.append(g)
+    return out
+
+
+# (count, seed, window) -> displacement seed whose start rejects trials (oracle trial histories e.g. [1,1,1,1,6,1,...])
+_KIDNAP_SEEDS = {(64, 4242, 5): 13, (64, 4242, 16): 4, (64, 4242, 27): 8, (64, 4242, 38): 2, (64, 4242, 49): 1, (64, 4242, 60): 3}
