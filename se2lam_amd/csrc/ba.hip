@@ -614,7 +614,7 @@ __device__ inline void odo_terms(const double* poses, const uint8_t* fixed, cons
 }
 
 constexpr int kGrpPerWG = 28;   // 9-lane groups per 256-thread workgroup (252 lanes used)
-constexpr int kChunk = 32;      // contributor pairs per group (d_reduce2 keeps the indices of two rounds of 8 per lane)
+constexpr int kChunk = 16;      // contributor pairs per group (d_reduce2 keeps the indices of two rounds of 8 per lane)
 
 // Off-diagonal part: workgroup w owns the groups [w*28, w*28+28) of the host-built plan.  A group = 9 lanes (one per
 // entry of a 3x3 block) accumulating one chunk of <= kChunk contributor pairs of ONE reduced-system block; blocks
