@@ -331,6 +331,9 @@ int se2gpu_ba_debug_solve(se2gpu_ba* h, double lambda, double* x, int* factor_ok
  * dependency timed out earlier in the handle's life (reported once on stderr), 3 = host solve (SE2GPU_BA_HOST_SOLVE=1).
  * Tests use it to make sure that results were not produced by the fallback. */
 int se2gpu_ba_debug_solver_path(const se2gpu_ba* h);
+/* Test introspection: idle sets in the library's two process-wide lease pools - {plan caches of the lock-step batch driver,
+ * staging buffers of se2gpu_ba_reset_estimates_batch}.  A set is leased per call and returned, whichever thread calls. */
+int se2gpu_ba_debug_pool_sizes(int out2[2]);
 /* Soak-test introspection of the dataflow solve's tile hand-offs.  With SE2GPU_BA_CHOL_VERIFY=1 in the environment every
  * published half-slab carries a checksum and every consumer checks its loads against it: counts2 = {mismatches, half-slabs
  * checked}; records (cap x 8 words, may be NULL): {epoch, consumer task, kind << 32 | tile row << 16 | column, slab << 8 |

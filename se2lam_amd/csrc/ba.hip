@@ -4989,6 +4989,47 @@ struct BatchPlan {
     }
 };
 
+// Per-call scratch objects that own device memory, pinned memory or events (the plan caches of the lock-step driver, the
+// staging of the batched reset) are LEASED from a process-wide pool for the duration of a call instead of living in
+// thread_local storage: a host that runs its mapper on short-lived threads would otherwise leave a set behind
+// with every thread that exits.  The pool is LIFO - a single calling thread gets its own set back, cached plans included -
+// and holds as many sets as calls ever overlapped.  Nothing in it is destroyed at process exit (device memory must not be
+// freed after the HIP runtime has shut down), and events handed out from a set (se2gpu_ba::join_event) stay valid for good.
+template <typename T>
+struct LeasePool {
+    std::mutex mu;
+    std::vector<T*> idle;
+    static LeasePool& get() { static LeasePool* p = new LeasePool; return *p; }
+};
+template <typename T>
+struct Lease {
+    T* obj;
+    Lease() {
+        LeasePool<T>& p = LeasePool<T>::get();
+        std::lock_guard<std::mutex> g(p.mu);
+        if (p.idle.empty()) obj = new T;
+        else { obj = p.idle.back(); p.idle.pop_back(); }
+    }
+    ~Lease() {
+        LeasePool<T>& p = LeasePool<T>::get();
+        std::lock_guard<std::mutex> g(p.mu);
+        p.idle.push_back(obj);
+    }
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
+};
+constexpr int kPlanSlots = 4;
+struct PlanSet {
+    BatchPlan* cache[kPlanSlots] = {};
+    unsigned long stamp[kPlanSlots] = {}, clock = 0;
+};
+struct ResetScratch {
+    PinBuf<ResetItem> host;
+    DevBuf<ResetItem> dev;
+    hipEvent_t ring[64] = {};
+    unsigned next = 0;
+};
+
 // a window the lock-step path can take: SE(2) model, one GPU, device controller, dataflow solve, no per-kernel profile
 bool ba_lockstep_ok(const se2gpu_ba* h) {
     return h->initialized && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->chol_steps && !h->odo_fallback &&
@@ -5634,14 +5675,8 @@ int se2gpu_ba_reset_estimates_batch(se2gpu_ba** hs, int count) {
     for (int i = 0; i < count; ++i)
         SE2_REQUIRE(hs[i] && hs[i]->initialized && hs[i]->device == hs[0]->device, SE2GPU_ERR_STATE,
                     "reset_estimates_batch: window %d is not initialised (or lives on another device)", i);
-    struct Scratch {
-        PinBuf<ResetItem> host;
-        DevBuf<ResetItem> dev;
-        hipEvent_t ring[64] = {};
-        unsigned next = 0;
-    };
-    static thread_local Scratch* sc = nullptr;   // (never destroyed: device memory must not be freed after the runtime has shut down)
-    if (!sc) sc = new Scratch;
+    Lease<ResetScratch> lease;   // (process-wide pool, never destroyed: see LeasePool)
+    ResetScratch* sc = lease.obj;
     hipStream_t st = hs[0]->stream;
     SE2_CHECK(ba_join(hs[0]));
     // the staging buffer of the previous call may still be read by its copy: the ring's event of that call says when not
@@ -5808,6 +5843,15 @@ int se2gpu_ba_debug_chol_verify(se2gpu_ba* h, unsigned long long* counts2, unsig
     counts2[0] = head[0]; counts2[1] = head[1];
     const int nrec = (int)std::min<unsigned long long>(std::min<unsigned long long>(head[0], kVfyRecords), (unsigned long long)std::max(cap, 0));
     if (nrec && records) SE2_HIP(hipMemcpy(records, h->chol_vfy.p + 8, (size_t)nrec * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return SE2GPU_OK;
+}
+
+// idle sets in the two lease pools (plan caches of the lock-step driver, staging of the batched reset): tests check that
+// short-lived calling threads do not grow them
+int se2gpu_ba_debug_pool_sizes(int out2[2]) {
+    SE2_REQUIRE(out2, SE2GPU_ERR_INVALID, "debug_pool_sizes: NULL argument");
+    { LeasePool<PlanSet>& p = LeasePool<PlanSet>::get(); std::lock_guard<std::mutex> g(p.mu); out2[0] = (int)p.idle.size(); }
+    { LeasePool<ResetScratch>& p = LeasePool<ResetScratch>::get(); std::lock_guard<std::mutex> g(p.mu); out2[1] = (int)p.idle.size(); }
     return SE2GPU_OK;
 }
 
@@ -6045,12 +6089,13 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
     static const int env_groups = [] { const char* e = getenv("SE2GPU_BA_BATCH_GROUPS"); return e ? atoi(e) : 0; }();
     int G = env_groups > 0 ? env_groups : (count >= 4 ? 2 : 1);   // (two groups pay from four windows on: 4 / 8 / 12 windows +4 / +12 / +9 %)
     G = std::max(1, std::min(G, std::min(count, 4)));
-    // the plans of the last batches of this thread are kept: a mapper (or the bench) that optimises the same windows again
-    // re-uses the argument packs on the device (plain pointers, replaced on a miss and never destroyed at thread / process
-    // exit: their device memory must not be freed after the HIP runtime has shut down)
-    constexpr int kPlans = 4;
-    static thread_local BatchPlan* cache[kPlans] = {};
-    static thread_local unsigned long stamp[kPlans] = {}, clock = 0;
+    // the plans of the last batches are kept: a mapper (or the bench) that optimises the same windows again re-uses the
+    // argument packs on the device (plain pointers, replaced on a miss; leased from the process-wide pool for this call)
+    constexpr int kPlans = kPlanSlots;
+    Lease<PlanSet> plan_lease;
+    BatchPlan** cache = plan_lease.obj->cache;
+    unsigned long* stamp = plan_lease.obj->stamp;
+    unsigned long& clock = plan_lease.obj->clock;
     struct Group { BatchPlan* bp; se2gpu_ba** hs; int count; bool finished; int slot; };
     std::vector<Group> groups(G);
     auto acquire = [&](se2gpu_ba** ghs, int gcount, BatchPlan** out, int* slot_out, const std::vector<Group>& taken) -> int {

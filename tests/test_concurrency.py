@@ -71,3 +71,45 @@ def test_track_and_local_mapper_threads_share_the_gpu(synth):
     for (sa, pa, la), (sb, pb, lb) in zip(ser_b, con_b):
         assert sa == sb
         assert np.array_equal(pa, pb) and np.array_equal(la, lb)
+
+
+def test_short_lived_threads_do_not_grow_the_lease_pools(synth):
+    """the plan caches of the lock-step driver and the staging of the batched reset used to be thread_local and
+    never freed - a mapper on short-lived threads left a set of device buffers, pinned memory and events behind with every
+    thread that exited.  They are leased from process-wide pools now: twelve threads, one after the other, each running a
+    batched reset + a window batch, leave exactly one idle set in each pool, and their results equal the main thread's."""
+    import ctypes as C
+    from se2lam_amd import capi
+    from se2lam_amd.optimizer import SlamOptimizer, optimize_batch, reset_estimates_batch
+    graphs = [synth.ba_graph(9 + k, 80 + 20 * k, seed=900 + k) for k in range(5)]
+
+    def run(out):
+        opts = []
+        for g in graphs:
+            o = SlamOptimizer(); o.load(g); o.initializeOptimization(0); opts.append(o)
+        optimize_batch(opts, 4)
+        reset_estimates_batch(opts)
+        optimize_batch(opts, 4)
+        out.append([(o.stats, o.estimates()[0].copy()) for o in opts])
+
+    ref = []
+    run(ref)
+    sizes = (C.c_int * 2)()
+    capi.check(capi.lib().se2gpu_ba_debug_pool_sizes(sizes))
+    base = (sizes[0], sizes[1])
+    assert base[0] >= 1 and base[1] >= 1
+    for _ in range(12):
+        got, errors = [], []
+
+        def guard():
+            try:
+                run(got)
+            except Exception as exc:   # pragma: no cover
+                errors.append(exc)
+        t = threading.Thread(target=guard)
+        t.start(); t.join()
+        assert not errors, errors
+        for (sa, pa), (sb, pb) in zip(ref[0], got[0]):
+            assert sa == sb and np.array_equal(pa, pb)
+    capi.check(capi.lib().se2gpu_ba_debug_pool_sizes(sizes))
+    assert (sizes[0], sizes[1]) == base, ((sizes[0], sizes[1]), base)
