@@ -102,6 +102,10 @@ int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out)
 void se2gpu_matcher_destroy(se2gpu_matcher* h);
 int se2gpu_matcher_set_stream(se2gpu_matcher* h, void* hip_stream);
 int se2gpu_matcher_sync(se2gpu_matcher* h);
+/* Number of calls of this handle in which some query's search window held more than the 128 candidates the fast path lists
+ * and was resolved by the exact grid scan instead (same result, a latency cliff on clustered features): lets the tracking
+ * thread see the slow path, which is otherwise silent. */
+int se2gpu_matcher_spill_calls(const se2gpu_matcher* h, long long* calls);
 
 /* Image bounds / grid of Frame (Frame.cpp:37-44): minX,minY,maxX,maxY of the undistorted image. */
 typedef struct se2gpu_frame_bounds {

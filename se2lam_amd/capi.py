@@ -100,6 +100,7 @@ SYMBOLS = {
     "se2gpu_matcher_destroy": (None, [_VP]),
     "se2gpu_matcher_set_stream": (_I, [_VP, _VP]),
     "se2gpu_matcher_sync": (_I, [_VP]),
+    "se2gpu_matcher_spill_calls": (_I, [_VP, _VP]),
     "se2gpu_matcher_stream": (_VP, [_VP]),
     "se2gpu_match_window": (_I, [_VP, C.POINTER(FrameBounds), _VP, _VP, _I, _VP, _VP, _I, _VP, _I, _I, _I, _I, _F,
                                  _VP, C.POINTER(_I)]),

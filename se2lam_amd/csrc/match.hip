@@ -753,6 +753,7 @@ struct se2gpu_matcher {
     // single-call paths (host buffers in, host buffers out): one packed block each way
     PinBuf<uint8_t> stage_h;
     DevBuf<uint8_t> stage_d;
+    long long spill_calls = 0;   // host-buffer / batch calls in which some query took the exact spill scan (se2gpu_matcher_spill_calls)
     ~se2gpu_matcher() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
@@ -766,7 +767,10 @@ int check_overflow(se2gpu_matcher* h) {
     SE2_HIP(hipStreamSynchronize(h->stream));
     // (a search window with more than kMaxCand candidates is no error any more: those queries were resolved by the exact
     // spill scan; the flag only says that it happened)
-    if (ov) SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
+    if (ov) {
+        ++h->spill_calls;
+        SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
+    }
     return SE2GPU_OK;
 }
 
@@ -867,6 +871,7 @@ int se2gpu_matcher_create(int max_features, int max_batch, se2gpu_matcher** out)
                 g_mt_pool.erase(g_mt_pool.begin() + (ptrdiff_t)i);
                 h->max_features = max_features;
                 h->max_batch = std::max(1, max_batch);
+                h->spill_calls = 0;   // a matcher handed out again starts like a new one
                 *out = h;
                 return SE2GPU_OK;
             }
@@ -908,6 +913,15 @@ void* se2gpu_matcher_stream(se2gpu_matcher* h) { return h ? (void*)h->stream : n
 int se2gpu_matcher_set_stream(se2gpu_matcher* h, void* s) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "matcher handle is NULL");
     h->stream = s ? (hipStream_t)s : h->own_stream;
+    return SE2GPU_OK;
+}
+
+// Calls of this handle so far in which at least one query had more than 128 candidates in its search window and was
+// resolved by the exact - and much slower: one wave re-scans the grid per sweep of the fixed point - spill scan.  A caller on
+// the tracking thread can watch the counter: a frame pair that moves it pays a latency the usual pair does not.
+int se2gpu_matcher_spill_calls(const se2gpu_matcher* h, long long* calls) {
+    SE2_REQUIRE(h && calls, SE2GPU_ERR_INVALID, "matcher_spill_calls: NULL argument");
+    *calls = h->spill_calls;
     return SE2GPU_OK;
 }
 
@@ -973,6 +987,7 @@ int se2gpu_match_window(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds, co
     std::memcpy(matches12, hs + o_m, (size_t)n1 * sizeof(int));
     std::memcpy(prev_xy, hs + o_prev, (size_t)n1 * 2 * sizeof(float));
     *n_matches = r[0];
+    if (r[1]) ++h->spill_calls;
     return SE2GPU_OK;
 }
 
@@ -1054,6 +1069,7 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
     const int* r = (const int*)(hs + o_sc);
     std::memcpy(match_idx_mp, hs + o_m, (size_t)n * sizeof(int));
     *n_matches = r[0];
+    if (r[1]) ++h->spill_calls;
     return SE2GPU_OK;
 }
 

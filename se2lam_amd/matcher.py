@@ -30,6 +30,12 @@ class ORBmatcher:
         self._h = C.c_void_p()
         capi.check(capi.lib().se2gpu_matcher_create(max_features, max_batch, C.byref(self._h)))
 
+    def spill_calls(self) -> int:
+        """se2gpu_matcher_spill_calls: calls of this matcher in which a query took the exact spill scan (> 128 candidates)"""
+        v = C.c_longlong(0)
+        capi.check(capi.lib().se2gpu_matcher_spill_calls(self._h, C.byref(v)))
+        return int(v.value)
+
     @staticmethod
     def DescriptorDistance(a, b) -> int:
         a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)

@@ -168,9 +168,15 @@ def test_clustered_features_beyond_the_candidate_lists(oracle, feats, ncluster):
     rng = np.random.default_rng(ncluster)
     (k1, d1), (k2, d2) = _clustered(feats, rng, ncluster, 300, 1.5)
     prev = _prev(k1)
-    nm, m12 = ORBmatcher(0.9).MatchByWindow(k1, d1, k2, d2, prev, 20)
+    mw = ORBmatcher(0.9)
+    nm, m12 = mw.MatchByWindow(k1, d1, k2, d2, prev, 20)
     m_ref, nm_ref, prev_ref = oracle.match_window(k1, d1, k2, d2)
     assert nm == nm_ref and nm > 30 and np.array_equal(m12, m_ref) and np.array_equal(prev, prev_ref)
+    # the slow path is visible to the caller: this pair moved the counter, an ordinary pair does not
+    assert mw.spill_calls() == 1
+    (ka, da), (kb, db) = feats[0], feats[1]
+    mw.MatchByWindow(ka, da, kb, db, _prev(ka), 20)
+    assert mw.spill_calls() == 1
     # MatchByProjection: map points that all project into the cluster of the key frame
     fx = fy = 400.0; cx, cy = 320.0, 240.0
     m = 600
