@@ -299,8 +299,15 @@ typedef struct se2gpu_map_view {
 int se2gpu_map_update_local_graph(const se2gpu_map_view* map, int current_kf, int search_level, int32_t* local_kfs,
                                   int* n_local, int32_t* ref_kfs, int* n_ref, int32_t* local_mps, int* n_mps);
 
-/* initializeOptimization(0): freezes the graph, builds the device-side SoA + reduction plans (on the device). */
+/* initializeOptimization(0): freezes the graph, builds the device-side SoA + reduction plans (on the device).
+ * A second call on an initialised handle is g2o's "initialise again over the edges of level 0": supported for the pose graph
+ * (VertexSE3 / EdgeSE3, the graph of GlobalMapper::GlobalBA, /root/reference/src/GlobalMapper.cpp:421-483): the vertices keep
+ * their current estimates, edges moved to another level by se2gpu_ba_set_edge_level are left out.  For the landmark models
+ * it returns SE2GPU_ERR_STATE. */
 int se2gpu_ba_initialize(se2gpu_ba* h);
+/* g2o::OptimizableGraph::Edge::setLevel(level) of the `edge`-th EdgeSE3 added to a pose graph (the index
+ * se2gpu_ba_edge_chi2 reports it under); takes effect at the next se2gpu_ba_initialize. */
+int se2gpu_ba_set_edge_level(se2gpu_ba* h, int edge, int level);
 /* restores every vertex estimate to the value it was added with (device-to-device) */
 int se2gpu_ba_reset_estimates(se2gpu_ba* h);
 /* ... of `count` windows with one launch (the companion of se2gpu_ba_optimize_batch for a mapper that re-optimises the same

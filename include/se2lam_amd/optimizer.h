@@ -32,16 +32,18 @@ class SlamOptimizer;
 // What the reference keeps of an EdgeProjectXYZ2UV* / EdgeSE3* after adding it (LocalMapper::removeOutlierChi2,
 // LocalMapper.cpp:199-214; GlobalMapper::GlobalBA, GlobalMapper.cpp:415-476): computeError(), chi2(), setLevel(), level().
 // chi2() of all edges comes from ONE device pass after optimize() (se2gpu_ba_edge_chi2), cached by the optimizer.
-// setLevel() is bookkeeping for the caller's own loops (level() > 0 -> skip): the device graph is frozen by
-// initializeOptimization, and a SECOND initializeOptimization on the same optimizer - g2o's way of re-optimising over the
-// edges of one level - is refused by the library (SE2GPU_ERR_STATE -> std::runtime_error), never silently run over all edges.
+// setLevel(): for the EdgeSE3 edges of a pose graph it is g2o's - initializeOptimization() hands the levels to the library and a
+// SECOND initializeOptimization on the same optimizer re-optimises over the level-0 edges from the current estimates
+// (GlobalMapper.cpp:421-483, se2gpu_ba_set_edge_level).  For the landmark models it is bookkeeping for the caller's own loops
+// (level() > 0 -> skip, LocalMapper.cpp:199-214): there an edge moved to another level makes initializeOptimization throw,
+// and a second initializeOptimization is refused by the library - never a silent run over all edges.
 struct EdgeHandle {
     SlamOptimizer* opt = nullptr;
     int index = -1;      // position among the edges whose chi2 the library reports; -1: an edge without per-edge chi2
     int level_ = 0;
     void computeError() {}
     double chi2() const;
-    void setLevel(int l) { level_ = l; }
+    void setLevel(int l);
     int level() const { return level_; }
 };
 typedef EdgeHandle EdgeProjectXYZ2UV;
@@ -101,11 +103,16 @@ public:
     void setVerbose(bool v) { verbose_ = v; }
     void setForceStopFlag(bool* flag) { stop_ = flag; }                   // LocalMapper.cpp:246
     bool initializeOptimization(int level = 0) {                          // LocalMapper.cpp:259
-        // g2o optimises over the edges of ONE level; the device graph holds every edge that was added.  An edge moved to
-        // another level (setLevel) before this call would be optimised over all the same - refuse instead of doing so silently
-        for (const EdgeHandle& e : edges_) if (e.level_ != level) throw std::runtime_error("initializeOptimization: an edge has been moved to another level (setLevel); the device graph optimises over all added edges");
-        for (const EdgeHandle& e : plain_edges_) if (e.level_ != level) throw std::runtime_error("initializeOptimization: an edge has been moved to another level (setLevel); the device graph optimises over all added edges");
+        // g2o optimises over the edges of ONE level.  The pose graph's EdgeSE3 levels go to the library (which leaves the
+        // others out); anywhere else an edge moved to another level would be optimised over all the same - refuse instead
+        if (level != 0) throw std::runtime_error("initializeOptimization: only level 0 can be optimised");
+        for (const EdgeHandle& e : plain_edges_) if (e.level_ != 0) throw std::runtime_error("initializeOptimization: an edge without a library index has been moved to another level (setLevel)");
+        if (levels_touched_)
+            for (const EdgeHandle& e : edges_)
+                if (se2gpu_ba_set_edge_level(h_, e.index, e.level_) != SE2GPU_OK && e.level_ != 0)
+                    throw std::runtime_error("initializeOptimization: an edge has been moved to another level (setLevel); only the pose graph's EdgeSE3 have levels on the device");
         check(se2gpu_ba_initialize(h_), "initializeOptimization");
+        edge_chi2_.clear();
         return true;
     }
     int optimize(int iterations) {                                        // LocalMapper.cpp:260
@@ -132,7 +139,7 @@ public:
     // from addCamPara stays valid across clear() and is re-registered with the library's handle, which forgets its camera.
     void clear() {
         check(se2gpu_ba_clear(h_), "clear");
-        edges_.clear(); plain_edges_.clear(); vertices_.clear(); edge_chi2_.clear();
+        edges_.clear(); plain_edges_.clear(); vertices_.clear(); edge_chi2_.clear(); levels_touched_ = false;
         for (const CamPara& c : cams_) check(se2gpu_ba_add_cam(h_, c.focal_length, c.principle_point[0], c.principle_point[1]), "clear: camera");
     }
     void clearParameters() { cams_.clear(); }
@@ -142,7 +149,10 @@ public:
     se2gpu_ba* handle() { return h_; }
     CamPara* newCamPara() { cams_.emplace_back(); return &cams_.back(); }   // owned by the optimizer, address-stable
 
+    void noteLevelChange() { levels_touched_ = true; }
+
 private:
+    bool levels_touched_ = false;
     std::deque<CamPara> cams_;
     std::deque<EdgeHandle> edges_, plain_edges_;
     std::deque<VertexSE2> vertices_;
@@ -155,6 +165,7 @@ private:
 };
 
 inline double EdgeHandle::chi2() const { return opt->edgeChi2(index); }
+inline void EdgeHandle::setLevel(int l) { level_ = l; if (opt) opt->noteLevelChange(); }
 inline double SlamAlgorithm::currentLambda() const { return opt_ ? opt_->currentLambda() : 0.0; }
 
 inline void initOptimizer(SlamOptimizer& opt, bool verbose = false) { opt.setVerbose(verbose); }

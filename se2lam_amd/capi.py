@@ -136,6 +136,7 @@ SYMBOLS = {
     "se2gpu_map_update_local_graph": (_I, [C.POINTER(MapView), _I, _I, _VP, C.POINTER(_I), _VP, C.POINTER(_I), _VP, C.POINTER(_I)]),
     "se2gpu_sparsify_se3xyz": (_I, [_I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "se2gpu_ba_initialize": (_I, [_VP]),
+    "se2gpu_ba_set_edge_level": (_I, [_VP, _I, _I]),
     "se2gpu_ba_reset_estimates": (_I, [_VP]),
     "se2gpu_ba_reset_estimates_batch": (_I, [_VP, _I]),
     "se2gpu_ba_optimize": (_I, [_VP, _I, _I, _PU8, _I, C.POINTER(BaStats)]),

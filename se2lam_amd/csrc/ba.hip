@@ -3040,7 +3040,7 @@ struct se2gpu_ba {
     Cam3 cam3{};
     std::vector<uint8_t> h_prior_has;
     std::vector<double> h_prior_meas, h_prior_info;      // 12 / 36 per pose
-    struct Odo3 { int i, j; double meas[12], info[36]; };
+    struct Odo3 { int i, j; double meas[12], info[36]; int level = 0; };   // level: g2o's OptimizableGraph::Edge::setLevel (pose graph only)
     std::vector<Odo3> odo3;
     DevBuf<uint8_t> prior_has;
     DevBuf<double> prior_meas, prior_info, pb, edge_chi2;
@@ -3964,9 +3964,12 @@ int ba_upload_graph(se2gpu_ba* h) {
     std::vector<double> pg_meas, pg_info;
     int O = O_in;
     if (h->model == 2) {
-        const int NE = (int)h->odo3.size();
-        std::vector<int> order(NE);
-        for (int k = 0; k < NE; ++k) order[k] = k;
+        // (g2o's initializeOptimization(0) takes the edges of level 0: an EdgeSE3 moved to another level by
+        // se2gpu_ba_set_edge_level - GlobalMapper.cpp:437,466 - stays in the handle and out of the device graph)
+        std::vector<int> order;
+        for (int k = 0; k < (int)h->odo3.size(); ++k)
+            if (h->odo3[k].level == 0) order.push_back(k);
+        const int NE = (int)order.size();
         auto key = [&](int k) { return std::make_pair(std::min(h->odo3[k].i, h->odo3[k].j), std::max(h->odo3[k].i, h->odo3[k].j)); };
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
         h->pg_perm = order;
@@ -5535,8 +5538,9 @@ int se2gpu_ba_edge_chi2(se2gpu_ba* h, double* chi2, int cap) {
     SE2_CHECK(ba_join(h));
     hipStream_t st = h->stream;
     if (h->model == 2) {   // EdgeSE3::chi2() of every edge of the pose graph, in the order the edges were added
-        const int NE = h->pg_edges;
-        SE2_REQUIRE(cap >= NE, SE2GPU_ERR_CAPACITY, "edge_chi2: %d edges, room for %d", NE, cap);
+        const int NE = h->pg_edges, NT = (int)h->odo3.size();   // active (level 0 at the last initialize) / all edges
+        SE2_REQUIRE(cap >= NT, SE2GPU_ERR_CAPACITY, "edge_chi2: %d edges, room for %d", NT, cap);
+        for (int k = 0; k < NT; ++k) chi2[k] = 0.0;   // an edge outside the optimised level reports 0
         if (!NE) return SE2GPU_OK;
         hipLaunchKernelGGL(k4_finalize, dim3(1), dim3(1024), 0, st, h->P, NE, h->poses, h->poses_t, h->fixed.p, h->xp.p, h->bp.p,
                            h->prior_has.p, h->prior_meas.p, h->prior_info.p, h->pe_i.p, h->pe_j.p, h->pe_meas.p, h->pe_info.p,
@@ -5643,12 +5647,33 @@ int se2gpu_ba_load_local_graph(se2gpu_ba* h, const se2gpu_local_graph* g) {
 int se2gpu_ba_initialize(se2gpu_ba* h) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "ba handle is NULL");
     // The graph is frozen by the first call (the arrays borrowed by se2gpu_ba_load are released there).  g2o allows a
-    // second initializeOptimization(level) over the edges of that level; here that is an error, not a silent re-run over all
-    // edges: rebuild the graph after se2gpu_ba_clear, or start over with se2gpu_ba_reset_estimates.
+    // second initializeOptimization(level) over the edges of that level.  The pose graph - where the reference does that:
+    // GlobalMapper::GlobalBA moves rejected feature edges to level 1 and initialises again, GlobalMapper.cpp:421-483 - supports
+    // it: the vertices keep their CURRENT estimates, as g2o's do, and the device graph is rebuilt from the level-0 edges
+    // (se2gpu_ba_set_edge_level).  For the landmark models it stays an error, not a silent re-run over all edges: rebuild the
+    // graph after se2gpu_ba_clear, or start over with se2gpu_ba_reset_estimates.
+    if (h->initialized && h->model == 2 && !h->bulk_E) {
+        SE2_CHECK(ba_fetch_estimates(h));
+        const size_t np = 12 * (size_t)h->P;
+        SE2_REQUIRE(h->h_poses.size() == np, SE2GPU_ERR_STATE, "initialize: the pose graph's host vertices are gone");
+        std::memcpy(h->h_poses.data(), h->est.p, np * sizeof(double));
+        h->initialized = false;
+        h->est_valid = false;
+        return ba_upload_graph(h);
+    }
     SE2_REQUIRE(!h->initialized, SE2GPU_ERR_STATE,
                 "initialize: the graph is already initialised (se2gpu_ba_clear and rebuild it; re-optimising a subset "
-                "of the edges after setLevel is not supported)");
+                "of the edges after setLevel is supported for the pose graph only)");
     return ba_upload_graph(h);
+}
+
+// g2o::OptimizableGraph::Edge::setLevel for the EdgeSE3 edges of the pose graph (`edge` = position in the order the edges were
+// added, the index se2gpu_ba_edge_chi2 reports them under): takes effect at the next se2gpu_ba_initialize.
+int se2gpu_ba_set_edge_level(se2gpu_ba* h, int edge, int level) {
+    SE2_REQUIRE(h && h->model == 2, SE2GPU_ERR_STATE, "set_edge_level: only the pose graph (VertexSE3 / EdgeSE3) has edge levels");
+    SE2_REQUIRE(edge >= 0 && edge < (int)h->odo3.size(), SE2GPU_ERR_INVALID, "set_edge_level: no EdgeSE3 number %d", edge);
+    h->odo3[edge].level = level;
+    return SE2GPU_OK;
 }
 
 int se2gpu_ba_reset_estimates(se2gpu_ba* h) {

@@ -24,6 +24,7 @@ using Vector2D = se2lam_amd::Vector2D;
 using Vector3D = se2lam_amd::Vector3D;
 using Matrix2D = se2lam_amd::Matrix2D;
 using Matrix3D = se2lam_amd::Matrix3D;
+using EdgeSE3 = se2lam_amd::EdgeSE3;
 }  // namespace g2o
 namespace cv {
 using Mat = se2lam_amd::MatF;
@@ -312,6 +313,65 @@ int main() {
         Isometry3D Twc = estimateVertexSE3(optimizer, 1);
         std::printf("GlobalBA lines: KF1 at %.2f %.2f %.2f, odometry edge chi2 %.4f\n", Twc.t[0], Twc.t[1], Twc.t[2], pEdgeOdoTmp->chi2());
         if (!(std::fabs(Twc.t[0] - 600.0) < 15.0)) return 1;
+    }
+    // ---- GlobalMapper::GlobalBA with PRE_REJECT_FTR_OUTLIER (GlobalMapper.cpp:421-483): the feature edges whose chi2 exceeds the
+    // threshold go to level 1 and the SAME optimizer is initialised and optimised again over the others.
+    // Four key frames on a line 500 mm apart, odometry edges between neighbours, consistent feature edges 0-1, 1-2, 2-3, 0-2, 1-3
+    // and a feature edge 0-3 that claims 1.8 m instead of 1.5 m: the loop must reject exactly that one.
+    {
+        SlamOptimizer optimizer;
+        SlamLinearSolver* linearSolver = new SlamLinearSolver();
+        SlamBlockSolver* blockSolver = new SlamBlockSolver(linearSolver);
+        SlamAlgorithm* solver = new SlamAlgorithm(blockSolver);
+        optimizer.setAlgorithm(solver);
+        int SE3OffsetParaId = 0;
+        addParaSE3Offset(optimizer, Isometry3D(), SE3OffsetParaId);
+        const float Rbc[9] = {0, 0, 1, -1, 0, 0, 0, -1, 0};
+        for (int k = 0; k < 4; ++k) {
+            cv::Mat T = cv::Mat::eye(4);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) T.at<float>(r, c) = Rbc[3 * r + c];
+            T.at<float>(0, 3) = 100 + 500.0f * k + (k ? 12.0f : 0.0f); T.at<float>(1, 3) = k ? -5.0f : 0.0f; T.at<float>(2, 3) = 300;
+            addVertexSE3PlaneMotion(optimizer, toSE3Quat(T), k, Config::bTc, SE3OffsetParaId, k == 0);
+        }
+        Matrix6d info;
+        for (int i = 0; i < 6; ++i) info(i, i) = i < 3 ? 1e-3 : 1e4;      // sigma = 32 mm: nine consistent edges outvote the wrong one
+        auto along = [](double mm) { Isometry3D m; m.t[2] = mm; return m; };
+        std::vector<g2o::EdgeSE3*> vpEdgeOdo, vpEdgeFeat;
+        for (int k = 0; k < 3; ++k) vpEdgeOdo.push_back(addEdgeSE3(optimizer, along(500), k, k + 1, info));
+        for (int k = 0; k < 3; ++k) vpEdgeFeat.push_back(addEdgeSE3(optimizer, along(500), k, k + 1, info));
+        vpEdgeFeat.push_back(addEdgeSE3(optimizer, along(1000), 0, 2, info));
+        vpEdgeFeat.push_back(addEdgeSE3(optimizer, along(1000), 1, 3, info));
+        vpEdgeFeat.push_back(addEdgeSE3(optimizer, along(1800), 0, 3, info));
+        const double threshFeatEdgeChi2 = 30.0;
+        int rounds = 0;
+        while (true) {
+            optimizer.initializeOptimization();                            // GlobalMapper.cpp:448-450
+            optimizer.optimize(15);
+            ++rounds;
+            // Reject outliers in feature edges                               GlobalMapper.cpp:459-483
+            bool bFindOutlier = false;
+            std::vector<g2o::EdgeSE3*> vpEdgeFeatGood;
+            for (auto iter = vpEdgeFeat.begin(); iter != vpEdgeFeat.end(); iter++) {
+                g2o::EdgeSE3* pEdge = *iter;
+                double chi2 = pEdge->chi2();
+                if (chi2 > threshFeatEdgeChi2) {
+                    pEdge->setLevel(1);
+                    bFindOutlier = true;
+                }
+                else {
+                    vpEdgeFeatGood.push_back(pEdge);
+                }
+            }
+            vpEdgeFeat.swap(vpEdgeFeatGood);
+
+            if (!bFindOutlier) {
+                break;
+            }
+            if (rounds > 4) return 1;
+        }
+        Isometry3D T3 = estimateVertexSE3(optimizer, 3);
+        std::printf("GlobalBA outlier loop: %d rounds, %zu feature edges kept, KF3 at %.2f %.2f %.2f\n", rounds, vpEdgeFeat.size(), T3.t[0], T3.t[1], T3.t[2]);
+        if (rounds != 2 || vpEdgeFeat.size() != 5 || !(std::fabs(T3.t[0] - 1600.0) < 3.0)) return 1;
     }
     // ---- GlobalMapper::CreateFeatEdge (GlobalMapper.cpp:795-837): the measurement vector and the Sparsifier call
     {

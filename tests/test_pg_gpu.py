@@ -65,3 +65,45 @@ def test_parallel_edges_and_graph_type_errors(synth):
         op.addVertexSE3Expmap(o, np.eye(4), 1)               # one pose type per graph
     with pytest.raises(capi.Se2GpuError):
         op.addVertexSBAXYZ(o, [0, 0, 1.0], 5) or op.addVertexSE3(o, np.eye(4), 6)   # no landmarks in a pose graph
+
+
+def test_reinitialise_over_the_level_0_edges(oracle, synth):
+    """GlobalMapper::GlobalBA with PRE_REJECT_FTR_OUTLIER (GlobalMapper.cpp:421-483): feature edges above the chi2 threshold are
+    moved to level 1 and the same optimizer is initialised and optimised AGAIN - from the estimates of the first run, over the
+    remaining edges.  Against the oracle run on the graph without those edges, started from the first run's poses."""
+    import copy
+    from se2lam_amd import capi, optimizer as op
+    g = copy.copy(synth.pose_graph(60))
+    g.o_meas = g.o_meas.copy()
+    bad = [7, 40, 111]                                  # three EdgeSE3 that claim another 0.8 m along the optical axis
+    for k in bad:
+        g.o_meas[k] = g.o_meas[k].copy()
+        g.o_meas[k][2, 3] += 800.0
+    o = _pg(g)
+    o.optimize(8)
+    ec = op.edgeChi2(o, g.O)
+    out = np.nonzero(ec > 30.0)[0]
+    assert set(bad) <= set(out.tolist())
+    first = np.stack([op.estimateVertexSE3(o, a) for a in range(g.P)])
+    for k in out:
+        capi.check(capi.lib().se2gpu_ba_set_edge_level(o._h, int(k), 1))
+    o.initializeOptimization(0)                          # second initialise: allowed for the pose graph
+    o.optimize(8)
+    keep = np.setdiff1d(np.arange(g.O), out)
+    g2 = copy.copy(g)
+    g2.o_i, g2.o_j, g2.o_meas, g2.o_info = g.o_i[keep], g.o_j[keep], g.o_meas[keep], g.o_info[keep]
+    g2.poses = first
+    X, ec2, st = oracle.pg_optimize(g2, 8)
+    assert o.stats["trials_hist"] == st["trials_hist"]
+    assert np.allclose(o.stats["chi2_hist"], st["chi2_hist"], rtol=REL)
+    upd = max(np.abs(X - first).max(), 1e-9)
+    for a in range(g.P):
+        assert np.abs(op.estimateVertexSE3(o, a) - X[a]).max() <= REL * max(upd, 1.0)
+    got = op.edgeChi2(o, g.O)
+    assert np.all(got[out] == 0.0) and np.allclose(got[keep], ec2, rtol=1e-4, atol=1e-7)
+    # the landmark models still refuse a second initialise instead of silently optimising over everything
+    s = op.SlamOptimizer()
+    s.load(synth.ba_graph(8, 60))
+    s.initializeOptimization(0)
+    with pytest.raises(capi.Se2GpuError):
+        s.initializeOptimization(0)
