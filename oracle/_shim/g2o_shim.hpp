@@ -1,20 +1,28 @@
 // ORACLE - TEST INFRASTRUCTURE ONLY (oracle/_ref).  Never compiled into, linked with or loaded by the product path.
 //
-// A stand-in for the Eigen 3 and g2o (tag 20160424_git) headers that /root/reference/src/EdgeSE2XYZ.cpp and
-// include/se2lam/EdgeSE2XYZ.h include, just large enough for those two files to compile UNMODIFIED (oracle/Makefile, target
-// `ref`): fixed-size matrices with comma initialisers, blocks, transposes and products; AngleAxis / Quaternion / Rotation2D;
-// g2o's SE2, SE3Quat, CameraParameters::cam_map, internal::toEuler, skew, the two vertex types and BaseBinaryEdge's data
-// members.  Neither library is installed in this image.  What oracle/_ref pins with it is what se2lam WROTE - the residual
-// and the analytic Jacobians of EdgeSE2XYZ (src/EdgeSE2XYZ.cpp:61-106), SE2ToSE3 / SE3ToSE2 / d_inv_d_se2 (:16-39) and
-// PreEdgeSE2 (include/se2lam/EdgeSE2XYZ.h:62-102) - evaluated through the reference's own statements.  The library
-// formulas underneath (quaternion from angle-axis, q * v, SE3Quat's product / inverse / map, cam_map, toEuler) are written
-// here from the published Eigen / g2o sources; g2o's block solver, Levenberg-Marquardt and CHOLMOD are not part of this at all.
+// A stand-in for the Eigen 3 and g2o (tag 20160424_git) headers that /root/reference/src/EdgeSE2XYZ.cpp, src/optimizer.cpp,
+// src/converter.cpp and include/se2lam/{EdgeSE2XYZ,optimizer,converter}.h include, just large enough for those files to compile
+// UNMODIFIED (oracle/Makefile, target `ref`): fixed-size matrices with comma initialisers, blocks, transposes and products;
+// AngleAxis / Quaternion / Rotation2D / Isometry3d; g2o's SE2, SE3Quat (product, inverse, map, log, adj), CameraParameters::cam_map,
+// internal::toEuler / toSE3Quat / fromSE3Quat, skew, Huber's rho, and a RECORDING graph - vertices with id / fixed /
+// marginalized, edges with vertices / measurement / information / robust kernel / parameter ids / level, a SparseOptimizer
+// that stores what addVertex / addEdge / addParameter hand it.  Neither library is installed in this image.  What oracle/_ref
+// pins with it is what se2lam WROTE - the residual and the analytic Jacobians of EdgeSE2XYZ (src/EdgeSE2XYZ.cpp:61-106),
+// SE2ToSE3 / SE3ToSE2 / d_inv_d_se2 (:16-39), PreEdgeSE2 (include/se2lam/EdgeSE2XYZ.h:62-102), and all of src/optimizer.cpp:
+// what each add* call puts into the graph, the plane-motion priors, EdgeSE3ExpmapPrior, the information reordering of
+// addEdgeSE3Expmap, Jl / invJl / invJJl - evaluated through the reference's own statements.  The library formulas
+// underneath (quaternion from angle-axis / matrix, q * v, SE3Quat's product / inverse / map / log / adj, cam_map, toEuler) are
+// written here from the published Eigen / g2o sources; g2o's own edge types (EdgeSE3Expmap, EdgeProjectXYZ2UV, EdgeSE3,
+// EdgeSE3Prior, EdgeSE3PointXYZ) are recorded, not evaluated; the block solver, Levenberg-Marquardt and CHOLMOD are empty
+// types: nothing is ever optimised here.
 #pragma once
 #include <cmath>
 #include <iostream>
+#include <map>
 #include <vector>
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#define G2O_TYPES_SBA_API
 
 namespace Eigen {
 
@@ -33,6 +41,19 @@ public:
     template <typename M2> BlockRef& operator=(const BlockRef<M2, T, BR, BC>& o) { return *this = Matrix<T, BR, BC>(o); }
     void setZero() { for (int r = 0; r < BR; ++r) for (int c = 0; c < BC; ++c) m(r0 + r, c0 + c) = T(0); }
     Matrix<T, BR, BC> operator-() const { return -Matrix<T, BR, BC>(*this); }   // (Matrix has the converting constructor)
+};
+
+// view of a run-time sized block (m.block(r, c, nr, nc)); M may be const
+template <typename M> class DynBlock {
+    M& m;
+    int r0, c0, nr, nc;
+public:
+    DynBlock(M& m_, int r, int c, int nr_, int nc_) : m(m_), r0(r), c0(c), nr(nr_), nc(nc_) {}
+    double operator()(int r, int c) const { return m(r0 + r, c0 + c); }
+    template <typename Src> DynBlock& assign(const Src& s) { for (int r = 0; r < nr; ++r) for (int c = 0; c < nc; ++c) m(r0 + r, c0 + c) = s(r, c); return *this; }
+    template <typename T, int R, int C> DynBlock& operator=(const Matrix<T, R, C>& v) { return assign(v); }
+    template <typename M2> DynBlock& operator=(const DynBlock<M2>& o) { return assign(o); }
+    DynBlock& operator=(const DynBlock& o) { return assign(o); }
 };
 
 template <typename T, int R, int C> class CommaInit {
@@ -62,6 +83,10 @@ public:
     void setZero() { for (T& v : d) v = T(0); }
     void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = T(1); }
     static Matrix Zero() { return Matrix(); }
+    static Matrix Zero(int, int) { return Matrix(); }
+    DynBlock<Matrix> block(int r, int c, int nr, int nc) { return DynBlock<Matrix>(*this, r, c, nr, nc); }
+    DynBlock<const Matrix> block(int r, int c, int nr, int nc) const { return DynBlock<const Matrix>(*this, r, c, nr, nc); }
+    Matrix normalized() const { Matrix m(*this); const T n = norm(); for (int i = 0; i < R * C; ++i) m.d[i] /= n; return m; }
     static Matrix Identity() { Matrix m; m.setIdentity(); return m; }
     static Matrix UnitX() { Matrix m; m[0] = T(1); return m; }
     static Matrix UnitY() { Matrix m; m[1] = T(1); return m; }
@@ -97,12 +122,17 @@ typedef Matrix<double, 2, 1> Vector2d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 2, 2> Matrix2d;
 typedef Matrix<double, 3, 3> Matrix3d;
+typedef Matrix<double, 4, 4> Matrix4d;
 
+class Quaterniond;
 class AngleAxisd {
 public:
     double angle_;
     Vector3d axis_;
     AngleAxisd(double a, const Vector3d& ax) : angle_(a), axis_(ax) {}
+    explicit AngleAxisd(const Quaterniond& q);      // below
+    double angle() const { return angle_; }
+    const Vector3d& axis() const { return axis_; }
 };
 
 class Quaterniond {   // Eigen/src/Geometry/Quaternion.h
@@ -165,6 +195,40 @@ public:
     Matrix3d matrix() const { return toRotationMatrix(); }
 };
 
+// Eigen/src/Geometry/AngleAxis.h, operator=(QuaternionBase) of 3.3: angle = 2 atan2(|vec|, |w|), axis = vec / (+-|vec|)
+// (3.2 takes 2 acos(w); the two agree to rounding for the unit quaternions with w >= 0 that SE3Quat hands out)
+inline AngleAxisd::AngleAxisd(const Quaterniond& q) : angle_(0), axis_(1, 0, 0) {
+    double n = q.vec().norm();
+    if (n != 0) {
+        angle_ = 2 * std::atan2(n, std::fabs(q.w()));
+        if (q.w() < 0) n = -n;
+        axis_ = q.vec() * (1.0 / n);
+    }
+}
+
+// Eigen::Transform<double, 3, Isometry>: rotation matrix + translation
+class Isometry3d {
+    Matrix3d R_;
+    Vector3d t_;
+public:
+    Isometry3d() { R_.setIdentity(); }
+    explicit Isometry3d(const Quaterniond& q) : R_(q.toRotationMatrix()) {}
+    Isometry3d& operator=(const Quaterniond& q) { R_ = q.toRotationMatrix(); t_.setZero(); return *this; }
+    Vector3d& translation() { return t_; }
+    const Vector3d& translation() const { return t_; }
+    Matrix3d& linear() { return R_; }
+    const Matrix3d& linear() const { return R_; }
+    const Matrix3d& rotation() const { return R_; }
+    Matrix4d matrix() const {
+        Matrix4d m;
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) m(r, c) = R_(r, c); m(r, 3) = t_[r]; }
+        m(3, 3) = 1;
+        return m;
+    }
+    Isometry3d operator*(const Isometry3d& o) const { Isometry3d r; r.R_ = R_ * o.R_; r.t_ = R_ * o.t_ + t_; return r; }
+    Isometry3d inverse() const { Isometry3d r; r.R_ = R_.transpose(); r.t_ = -(r.R_ * t_); return r; }
+};
+
 class Rotation2Dd {
     double a;
 public:
@@ -213,11 +277,27 @@ public:
     Vector3D toVector() const { return Vector3D(_t(0), _t(1), _R.angle()); }
 };
 
+inline Matrix3D skew(const Vector3D& v) {   // g2o/types/sba/types_six_dof_expmap.h (se3_ops)
+    Matrix3D m;
+    m(0, 1) = -v(2); m(0, 2) = v(1); m(1, 2) = -v(0);
+    m(1, 0) = v(2); m(2, 0) = -v(1); m(2, 1) = v(0);
+    return m;
+}
+inline Vector3D deltaR(const Matrix3D& R) {   // se3_ops.hpp
+    return Vector3D(R(2, 1) - R(1, 2), R(0, 2) - R(2, 0), R(1, 0) - R(0, 1));
+}
+
+typedef Eigen::Matrix<double, 6, 6> Matrix6d;
+typedef Eigen::Matrix<double, 6, 1> Vector6d;
+typedef Eigen::Isometry3d Isometry3D;
+
 class SE3Quat {   // g2o/types/slam3d/se3quat.h
     Eigen::Quaterniond _r;
     Vector3D _t;
 public:
     SE3Quat() : _t(0, 0, 0) {}
+    SE3Quat(const Matrix3D& R, const Vector3D& t) : _r(Eigen::Quaterniond(R)), _t(t) { normalizeRotation(); }
+    SE3Quat(const Eigen::Quaterniond& q, const Vector3D& t) : _r(q), _t(t) { normalizeRotation(); }
     const Vector3D& translation() const { return _t; }
     const Eigen::Quaterniond& rotation() const { return _r; }
     void setTranslation(const Vector3D& t) { _t = t; }
@@ -237,14 +317,48 @@ public:
         return ret;
     }
     Vector3D map(const Vector3D& xyz) const { return _r * xyz + _t; }
+    Vector6d log() const {   // (rotation, translation)
+        Vector6d res;
+        const Matrix3D _R = _r.toRotationMatrix();
+        const double d = 0.5 * (_R(0, 0) + _R(1, 1) + _R(2, 2) - 1);
+        Vector3D omega;
+        const Vector3D dR = deltaR(_R);
+        Matrix3D V_inv;
+        if (d > 0.99999) {
+            omega = 0.5 * dR;
+            const Matrix3D Omega = skew(omega);
+            V_inv = Matrix3D::Identity() - 0.5 * Omega + (1. / 12.) * (Omega * Omega);
+        } else {
+            const double theta = std::acos(d);
+            omega = theta / (2 * std::sqrt(1 - d * d)) * dR;
+            const Matrix3D Omega = skew(omega);
+            V_inv = Matrix3D::Identity() - 0.5 * Omega + ((1 - theta / (2 * std::tan(theta / 2))) / (theta * theta)) * (Omega * Omega);
+        }
+        const Vector3D upsilon = V_inv * _t;
+        for (int i = 0; i < 3; i++) { res[i] = omega[i]; res[i + 3] = upsilon[i]; }
+        return res;
+    }
+    Matrix6d adj() const {   // (rotation, translation) order: [R 0; skew(t) R  R]
+        const Matrix3D R = _r.toRotationMatrix();
+        Matrix6d res;
+        res.block(0, 0, 3, 3) = R;
+        res.block(3, 3, 3, 3) = R;
+        res.block(3, 0, 3, 3) = skew(_t) * R;
+        return res;
+    }
+    Eigen::Matrix4d to_homogeneous_matrix() const {
+        Eigen::Matrix4d m;
+        const Matrix3D R = _r.toRotationMatrix();
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) m(r, c) = R(r, c); m(r, 3) = _t[r]; }
+        m(3, 3) = 1;
+        return m;
+    }
+    operator Isometry3D() const {
+        Isometry3D result(_r);
+        result.translation() = _t;
+        return result;
+    }
 };
-
-inline Matrix3D skew(const Vector3D& v) {   // g2o/types/sba/types_six_dof_expmap.h (se3_ops)
-    Matrix3D m;
-    m(0, 1) = -v(2); m(0, 2) = v(1); m(1, 2) = -v(0);
-    m(1, 0) = v(2); m(2, 0) = -v(1); m(2, 1) = v(0);
-    return m;
-}
 
 namespace internal {
 inline Vector3D toEuler(const Matrix3D& R) {   // g2o/types/slam3d/isometry3d_mappings.cpp
@@ -255,9 +369,24 @@ inline Vector3D toEuler(const Matrix3D& R) {   // g2o/types/slam3d/isometry3d_ma
     const double yaw = std::atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
     return Vector3D(roll, pitch, yaw);
 }
+inline SE3Quat toSE3Quat(const Isometry3D& t) { return SE3Quat(t.linear(), t.translation()); }
+inline Isometry3D fromSE3Quat(const SE3Quat& t) {
+    Isometry3D result(t.rotation());
+    result.translation() = t.translation();
+    return result;
+}
 }  // namespace internal
 
-class CameraParameters {   // g2o/types/sba/types_six_dof_expmap.{h,cpp}
+// ---- the graph: only what records what the reference's add* functions (src/optimizer.cpp) put into it.  No solver.
+class Parameter {
+    int _id = -1;
+public:
+    virtual ~Parameter() {}
+    void setId(int id) { _id = id; }
+    int id() const { return _id; }
+};
+
+class CameraParameters : public Parameter {   // g2o/types/sba/types_six_dof_expmap.{h,cpp}
 public:
     double focal_length;
     Vector2D principle_point;
@@ -273,9 +402,84 @@ public:
     }
 };
 
-namespace HyperGraph { class Vertex { public: virtual ~Vertex() {} }; }
+class ParameterSE3Offset : public Parameter {
+    Isometry3D _offset;
+public:
+    void setOffset(const Isometry3D& o) { _offset = o; }
+    const Isometry3D& offset() const { return _offset; }
+};
 
-template <int D, typename T> class BaseVertex : public HyperGraph::Vertex {
+class RobustKernel {
+protected:
+    double _delta = 1.;
+public:
+    virtual ~RobustKernel() {}
+    virtual void setDelta(double d) { _delta = d; }
+    double delta() const { return _delta; }
+    virtual double rho(double e2) const = 0;
+};
+class RobustKernelHuber : public RobustKernel {   // g2o/core/robust_kernel_impl.cpp: rho[0]
+public:
+    double rho(double e2) const override {
+        const double dsqr = _delta * _delta;
+        if (e2 <= dsqr) return e2;
+        return 2 * std::sqrt(e2) * _delta - dsqr;
+    }
+};
+
+namespace HyperGraph {
+class Vertex {
+protected:
+    int _id = -1;
+public:
+    virtual ~Vertex() {}
+    int id() const { return _id; }
+    void setId(int id) { _id = id; }
+};
+class Edge {
+protected:
+    std::vector<Vertex*> _vertices;
+public:
+    explicit Edge(int n) : _vertices(n, nullptr) {}
+    virtual ~Edge() {}
+    std::vector<Vertex*>& vertices() { return _vertices; }
+    void setVertex(size_t i, Vertex* v) { _vertices[i] = v; }
+};
+}  // namespace HyperGraph
+
+namespace OptimizableGraph {
+class Vertex : public HyperGraph::Vertex {
+    bool _fixed = false, _marginalized = false;
+public:
+    void setFixed(bool f) { _fixed = f; }
+    bool fixed() const { return _fixed; }
+    void setMarginalized(bool m) { _marginalized = m; }
+    bool marginalized() const { return _marginalized; }
+};
+class Edge : public HyperGraph::Edge {
+    RobustKernel* _rk = nullptr;
+    int _level = 0;
+    std::vector<int> _parameterIds;
+public:
+    explicit Edge(int n) : HyperGraph::Edge(n) {}
+    ~Edge() override { delete _rk; }
+    void setRobustKernel(RobustKernel* rk) { delete _rk; _rk = rk; }
+    RobustKernel* robustKernel() const { return _rk; }
+    void setLevel(int l) { _level = l; }
+    int level() const { return _level; }
+    bool setParameterId(int argNum, int paramId) {
+        if ((int)_parameterIds.size() <= argNum) _parameterIds.resize(argNum + 1, -1);
+        _parameterIds[argNum] = paramId;
+        return true;
+    }
+    int parameterId(int argNum) const { return argNum < (int)_parameterIds.size() ? _parameterIds[argNum] : -1; }
+    virtual void computeError() = 0;
+    virtual void linearizeOplus() = 0;
+    virtual double chi2() const = 0;
+};
+}  // namespace OptimizableGraph
+
+template <int D, typename T> class BaseVertex : public OptimizableGraph::Vertex {
 protected:
     T _estimate;
 public:
@@ -285,26 +489,97 @@ public:
 };
 class VertexSE2 : public BaseVertex<3, SE2> {};
 class VertexSBAPointXYZ : public BaseVertex<3, Vector3D> {};
+class VertexSE3Expmap : public BaseVertex<6, SE3Quat> {};
+class VertexSE3 : public BaseVertex<6, Isometry3D> {};
+class VertexPointXYZ : public BaseVertex<3, Vector3D> {};
 
-template <int D, typename E, typename VertexXi, typename VertexXj> class BaseBinaryEdge {
+template <int D, typename E> class BaseEdge : public OptimizableGraph::Edge {
 protected:
-    std::vector<HyperGraph::Vertex*> _vertices;
     E _measurement;
+    Eigen::Matrix<double, D, D> _information;
     Eigen::Matrix<double, D, 1> _error;
+public:
+    explicit BaseEdge(int n) : OptimizableGraph::Edge(n) {}
+    void setMeasurement(const E& m) { _measurement = m; }
+    const E& measurement() const { return _measurement; }
+    const Eigen::Matrix<double, D, D>& information() const { return _information; }
+    Eigen::Matrix<double, D, D>& information() { return _information; }
+    void setInformation(const Eigen::Matrix<double, D, D>& i) { _information = i; }
+    const Eigen::Matrix<double, D, 1>& error() const { return _error; }
+    double chi2() const override { return _error.dot(_information * _error); }
+    virtual bool read(std::istream& is) = 0;
+    virtual bool write(std::ostream& os) const = 0;
+};
+
+template <int D, typename E, typename VertexXi> class BaseUnaryEdge : public BaseEdge<D, E> {
+protected:
+    Eigen::Matrix<double, D, VertexXi::Dimension> _jacobianOplusXi;
+public:
+    BaseUnaryEdge() : BaseEdge<D, E>(1) {}
+    const Eigen::Matrix<double, D, VertexXi::Dimension>& jacobianOplusXi() const { return _jacobianOplusXi; }
+};
+
+template <int D, typename E, typename VertexXi, typename VertexXj> class BaseBinaryEdge : public BaseEdge<D, E> {
+protected:
     Eigen::Matrix<double, D, VertexXi::Dimension> _jacobianOplusXi;
     Eigen::Matrix<double, D, VertexXj::Dimension> _jacobianOplusXj;
 public:
-    BaseBinaryEdge() : _vertices(2, nullptr) {}
-    virtual ~BaseBinaryEdge() {}
-    void setVertex(size_t i, HyperGraph::Vertex* v) { _vertices[i] = v; }
-    void setMeasurement(const E& m) { _measurement = m; }
-    const Eigen::Matrix<double, D, 1>& error() const { return _error; }
+    BaseBinaryEdge() : BaseEdge<D, E>(2) {}
     const Eigen::Matrix<double, D, VertexXi::Dimension>& jacobianOplusXi() const { return _jacobianOplusXi; }
     const Eigen::Matrix<double, D, VertexXj::Dimension>& jacobianOplusXj() const { return _jacobianOplusXj; }
-    virtual void computeError() = 0;
-    virtual void linearizeOplus() = 0;
-    virtual bool read(std::istream& is) = 0;
-    virtual bool write(std::ostream& os) const = 0;
+};
+
+// g2o's own edge types that src/optimizer.cpp only constructs and fills in: recorded, not evaluated (their residuals belong to
+// g2o, not to se2lam; the oracle restates them from the published sources)
+#define SE2_SHIM_RECORD_ONLY                                               \
+    void computeError() override {}                                        \
+    void linearizeOplus() override {}                                      \
+    bool read(std::istream&) override { return false; }                    \
+    bool write(std::ostream&) const override { return false; }
+class EdgeSE3Expmap : public BaseBinaryEdge<6, SE3Quat, VertexSE3Expmap, VertexSE3Expmap> { public: SE2_SHIM_RECORD_ONLY };
+class EdgeProjectXYZ2UV : public BaseBinaryEdge<2, Vector2D, VertexSBAPointXYZ, VertexSE3Expmap> { public: SE2_SHIM_RECORD_ONLY };
+class EdgeSE3 : public BaseBinaryEdge<6, Isometry3D, VertexSE3, VertexSE3> { public: SE2_SHIM_RECORD_ONLY };
+class EdgeSE3Prior : public BaseUnaryEdge<6, Isometry3D, VertexSE3> { public: SE2_SHIM_RECORD_ONLY };
+class EdgeSE3PointXYZ : public BaseBinaryEdge<3, Vector3D, VertexSE3, VertexPointXYZ> { public: SE2_SHIM_RECORD_ONLY };
+#undef SE2_SHIM_RECORD_ONLY
+
+template <typename M> class LinearSolverCholmod {};
+template <typename M> class LinearSolverEigen {};
+class BlockSolverX {
+public:
+    typedef int PoseMatrixType;
+    template <typename LS> explicit BlockSolverX(LS* ls) { delete ls; }
+};
+class OptimizationAlgorithmLevenberg {
+public:
+    explicit OptimizationAlgorithmLevenberg(BlockSolverX* bs) { delete bs; }
+};
+
+class SparseOptimizer {
+    std::map<int, OptimizableGraph::Vertex*> _vertices;
+    std::vector<OptimizableGraph::Edge*> _edges;
+    std::vector<Parameter*> _parameters;
+    OptimizationAlgorithmLevenberg* _algorithm = nullptr;
+    bool _verbose = false;
+public:
+    SparseOptimizer() {}
+    SparseOptimizer(const SparseOptimizer&) = delete;
+    ~SparseOptimizer() {
+        for (auto& kv : _vertices) delete kv.second;
+        for (auto* e : _edges) delete e;
+        for (auto* p : _parameters) delete p;
+        delete _algorithm;
+    }
+    bool addVertex(OptimizableGraph::Vertex* v) { return _vertices.emplace(v->id(), v).second; }
+    bool addEdge(OptimizableGraph::Edge* e) { _edges.push_back(e); return true; }
+    bool addParameter(Parameter* p) { _parameters.push_back(p); return true; }
+    OptimizableGraph::Vertex* vertex(int id) { auto it = _vertices.find(id); return it == _vertices.end() ? nullptr : it->second; }
+    void setAlgorithm(OptimizationAlgorithmLevenberg* a) { delete _algorithm; _algorithm = a; }
+    void setVerbose(bool v) { _verbose = v; }
+    bool verbose() const { return _verbose; }
+    bool hasAlgorithm() const { return _algorithm != nullptr; }
+    const std::vector<OptimizableGraph::Edge*>& edges() const { return _edges; }
+    const std::vector<Parameter*>& parameters() const { return _parameters; }
 };
 
 }  // namespace g2o

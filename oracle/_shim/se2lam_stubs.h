@@ -1,7 +1,8 @@
 // ORACLE - TEST INFRASTRUCTURE ONLY (oracle/_ref).  Pre-included (-include) in front of every reference source file.
 //
-// src/ORBmatcher.cpp and src/Frame.cpp reach KeyFrame.h, MapPoint.h, converter.h and Track.h through their includes; those
-// headers need g2o, Eigen and the rest of the map data model, none of which is installed or on the hot path.  This file
+// src/ORBmatcher.cpp, src/Frame.cpp and include/se2lam/optimizer.h reach KeyFrame.h, MapPoint.h and Track.h through their
+// includes; those headers need the rest of the map data model, which is not on the hot path (converter.h is the reference's
+// own: it compiles against g2o_shim.hpp).  This file
 // defines their include guards, so the reference's own files are skipped where they are included, and puts in their
 // place the few members the two sources actually read - PtrKeyFrame / PtrMapPoint, KeyFrame : Frame with the observation
 // queries and the DBoW2 feature vector, MapPoint with position, main descriptor and main octave.  Frame.h, Config.h,
@@ -20,7 +21,6 @@
 
 #define MAPPOINT_H
 #define KEYFRAME_H
-#define CONVERTER_H
 #define TRACK_H
 
 namespace se2lam {

@@ -2,11 +2,13 @@
 // (se2lam_amd/, include/).  Only tests/, __graft_entry__.smoke() and bench.py's
 // `cpu_baseline` leg may use it, and only as the checker / reported CPU baseline.
 //
-// PARITY: the two EDGES - what se2lam itself wrote of this path - are pinned against the reference's own code: oracle/_ref
-// compiles /root/reference/src/EdgeSE2XYZ.cpp and include/se2lam/EdgeSE2XYZ.h unmodified against a stand-in for the Eigen /
-// g2o headers (oracle/_shim/g2o_shim.hpp), and tests/test_ref_compiled.py holds edge_se2xyz / edge_pre_se2 below to their
-// computeError() / linearizeOplus() (1e-11 relative) and the reduced system assembled from the reference's Jacobians to
-// schur() below (1e-10).  The SOLVER stays UNPINNED: /root/reference holds no golden vectors, known-answer tests or fixtures
+// PARITY: the two EDGES and the GRAPH CONSTRUCTION - what se2lam itself wrote of this path - are pinned against the
+// reference's own code: oracle/_ref compiles /root/reference/src/EdgeSE2XYZ.cpp, src/optimizer.cpp, src/converter.cpp and
+// their headers unmodified against a stand-in for the Eigen / g2o headers (oracle/_shim/g2o_shim.hpp), and
+// tests/test_ref_compiled.py holds edge_se2xyz / edge_pre_se2 below to their computeError() / linearizeOplus() (1e-11
+// relative), the reduced system assembled from the reference's Jacobians to schur() below (1e-10), robust_chi2() to the cost
+// of a window built with the reference's add* calls (1e-13), and ba_ref_plane_motion_prior to addPlaneMotionSE3Expmap (1e-9).
+// The SOLVER stays UNPINNED: /root/reference holds no golden vectors, known-answer tests or fixtures
 // for this path, and g2o / Eigen / CHOLMOD are not available in this image, so the Levenberg-Marquardt histories could
 // not be checked against a run of the real reference; they are pinned against scipy instead.
 //

@@ -1,5 +1,7 @@
-// ORACLE - TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline leg).  PARITY UNPINNED: g2o cannot be built
-// here; a restatement, checked against a numpy / scipy model (tests/test_pg_oracle.py).
+// ORACLE - TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline leg).  PARITY UNPINNED for g2o's part (its
+// EdgeSE3 / EdgeSE3Prior / solver cannot be built here): a restatement, checked against a numpy / scipy
+// model (tests/test_pg_oracle.py).  What se2lam wrote of it - pg_ref_plane_motion_prior = addVertexSE3PlaneMotion - is held to
+// the reference's own src/optimizer.cpp compiled in oracle/_ref (tests/test_ref_compiled.py, 1e-9).
 //
 // pg_ref: the pose graph of GlobalMapper::GlobalBA - SURVEY.md section 8(f).4:
 //   /root/reference/src/GlobalMapper.cpp:328-535: one g2o::VertexSE3 per key frame (T_w_c; KF 0 fixed), one EdgeSE3Prior per

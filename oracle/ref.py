@@ -241,3 +241,106 @@ def se2_se3_round_trip(pose):
     f.argtypes = [C.c_void_p] * 3
     f(pose.ctypes.data, out.ctypes.data, d.ctypes.data)
     return out, d
+
+
+# ---- src/optimizer.cpp + src/converter.cpp (whole files) against the recording graph of oracle/_shim/g2o_shim.hpp
+def _pose12(T):
+    T = np.asarray(T, np.float64)
+    return np.ascontiguousarray(np.concatenate([T[:3, :3].reshape(-1), T[:3, 3]]))
+
+
+def _mat44(p12):
+    T = np.eye(4)
+    T[:3, :3] = p12[:9].reshape(3, 3); T[:3, 3] = p12[9:]
+    return T
+
+
+def _plane(fname, T, Tbc, xrot, yrot, z):
+    f = getattr(lib(), fname)
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    a, b = _pose12(T), _pose12(Tbc)
+    meas = np.zeros(12); info = np.zeros(36)
+    rc = f(a.ctypes.data, b.ctypes.data, xrot, yrot, z, meas.ctypes.data, info.ctypes.data)
+    return _mat44(meas), info.reshape(6, 6), rc
+
+
+def plane_motion_prior(Tcw, Tbc, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    """addVertexSE3Expmap + addPlaneMotionSE3Expmap (optimizer.cpp:226-314) -> (measurement 4x4, information 6x6 in
+    (rotation, translation) order, number of edges the graph then holds).  Tbc is rounded to float32 like Config::bTc."""
+    return _plane("ref_plane_motion_expmap", Tcw, Tbc, xrot_info, yrot_info, z_info)
+
+
+def pg_plane_motion_prior(Twc, Tbc, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    """addVertexSE3PlaneMotion (optimizer.cpp:336-470) -> (measurement 4x4, information 6x6 in (translation, rotation)
+    order, the SE3-offset parameter id handed to the prior edge)"""
+    return _plane("ref_plane_motion_iso3", Twc, Tbc, xrot_info, yrot_info, z_info)
+
+
+def prior_expmap_edge(meas, est):
+    """EdgeSE3ExpmapPrior::computeError / linearizeOplus -> (err (6,), J (6,6))"""
+    a, b = _pose12(meas), _pose12(est)
+    e = np.zeros(6); J = np.zeros(36)
+    f = lib().ref_prior_expmap_edge
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 4
+    f(a.ctypes.data, b.ctypes.data, e.ctypes.data, J.ctypes.data)
+    return e, J.reshape(6, 6)
+
+
+def edge_se3expmap_info(info_tr):
+    """addEdgeSE3Expmap's information as the edge holds it ((rotation, translation) order); None when verifyInfo rejects it"""
+    a = np.ascontiguousarray(info_tr, np.float64); out = np.zeros(36)
+    f = lib().ref_edge_se3expmap_info
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p] * 2
+    return out.reshape(6, 6) if f(a.ctypes.data, out.ctypes.data) == 0 else None
+
+
+def so3_jacobians(v):
+    v = np.ascontiguousarray(v, np.float64); a = np.zeros(9); b = np.zeros(9)
+    f = lib().ref_so3_jacobians
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(v.ctypes.data, a.ctypes.data, b.ctypes.data)
+    return a.reshape(3, 3), b.reshape(3, 3)
+
+
+def inv_jjl(v6):
+    v = np.ascontiguousarray(v6, np.float64); out = np.zeros(36)
+    f = lib().ref_inv_jjl
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 2
+    f(v.ctypes.data, out.ctypes.data)
+    return out.reshape(6, 6)
+
+
+def converter_round_trip(T):
+    a = _pose12(T); q = np.zeros(16, np.float32); i = np.zeros(16, np.float32)
+    f = lib().ref_converter_round_trip
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(a.ctypes.data, q.ctypes.data, i.ctypes.data)
+    return q.reshape(4, 4), i.reshape(4, 4)
+
+
+def window_chi2(g, K=None):
+    """synth.BAGraph built with addCamPara / addVertexSE2 / addEdgeSE2 / addVertexSBAXYZ / addEdgeSE2XYZ, every edge's own
+    computeError() -> (sum rho(chi2), chi2 per observation (E,), chi2 per odometry edge (O,), (edges, fixed, marginalised))"""
+    def arr(a, ty):
+        return np.ascontiguousarray(a, ty)
+    poses = arr(g.poses, np.float64); fixed = arr(g.fixed, np.uint8); lms = arr(g.lms, np.float64)
+    e_kf = arr(g.e_kf, np.int32); e_lm = arr(g.e_lm, np.int32); e_uv = arr(g.e_uv, np.float64); e_info = arr(g.e_info, np.float64)
+    o_i = arr(g.o_i, np.int32); o_j = arr(g.o_j, np.int32); o_meas = arr(g.o_meas, np.float64); o_info = arr(g.o_info, np.float64)
+    K = np.ascontiguousarray([g.fx, 0, g.cx, 0, g.fx, g.cy, 0, 0, 1] if K is None else np.asarray(K).reshape(-1), np.float32)
+    Tbc = np.eye(4); Tbc[:3, :3] = g.Rbc; Tbc[:3, 3] = g.tbc
+    tb = _pose12(Tbc)
+    chi_e = np.zeros(max(g.E, 1)); chi_o = np.zeros(max(g.O, 1)); counts = np.zeros(3, np.int32)
+    f = lib().ref_window_chi2
+    f.restype = C.c_double
+    VP = C.c_void_p
+    f.argtypes = [C.c_int, VP, VP, C.c_int, VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, C.c_double, VP, VP, VP]
+    total = f(g.P, poses.ctypes.data, fixed.ctypes.data, g.L, lms.ctypes.data, g.E, e_kf.ctypes.data, e_lm.ctypes.data,
+              e_uv.ctypes.data, e_info.ctypes.data, g.O, o_i.ctypes.data, o_j.ctypes.data, o_meas.ctypes.data, o_info.ctypes.data,
+              K.ctypes.data, tb.ctypes.data, float(g.huber), chi_e.ctypes.data, chi_o.ctypes.data, counts.ctypes.data)
+    return float(total), chi_e[:g.E], chi_o[:g.O], tuple(int(c) for c in counts)

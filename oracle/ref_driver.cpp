@@ -10,6 +10,9 @@
 //   cvu::camprjc / se3map / triangulate / checkParallax       src/cvutil.cpp
 //   g2o::EdgeSE2XYZ::computeError / linearizeOplus, SE2ToSE3, SE3ToSE2, d_inv_d_se2      src/EdgeSE2XYZ.cpp:16-106
 //   g2o::PreEdgeSE2::computeError / linearizeOplus             include/se2lam/EdgeSE2XYZ.h:62-102
+//   se2lam::addCamPara / addVertexSE2 / addVertexSBAXYZ / addEdgeSE2 / addEdgeSE2XYZ / addVertexSE3Expmap / addEdgeSE3Expmap /
+//   addPlaneMotionSE3Expmap / addVertexSE3PlaneMotion / EdgeSE3ExpmapPrior / Jl / invJl / invJJl / verifyInfo and
+//   toSE3Quat / toIsometry3D / toCvMat                         src/optimizer.cpp, src/converter.cpp (whole files)
 // against oracle/_shim (a stand-in for the OpenCV / ROS headers, and stubs of KeyFrame / MapPoint with the members the
 // matcher reads).  What this library pins is the se2lam-owned logic; the OpenCV arithmetic underneath is the shim's.
 // The signatures mirror oracle/orb_ref.cpp and oracle/match_ref.cpp so that tests call either through the same wrapper.
@@ -22,7 +25,9 @@
 #include "EdgeSE2XYZ.h"
 #include "ORBextractor.h"
 #include "ORBmatcher.h"
+#include "converter.h"
 #include "cvutil.h"
+#include "optimizer.h"
 
 using namespace se2lam;
 
@@ -288,6 +293,147 @@ void ref_se2_se3_round_trip(const double* pose, double* out3, double* dinv9) {
     out3[0] = v[0]; out3[1] = v[1]; out3[2] = v[2];
     const Eigen::Matrix3d d = g2o::d_inv_d_se2(p);
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) dinv9[3 * r + c] = d(r, c);
+}
+
+}  // extern "C"
+
+// ---- src/optimizer.cpp: the graph construction surface, against the recording SparseOptimizer of oracle/_shim/g2o_shim.hpp
+namespace {
+cv::Mat mat4f(const double* pose12) {   // (R row-major, t) -> the 4x4 CV_32F that Config::bTc / KeyFrame::Tcw are
+    cv::Mat T = cv::Mat::eye(4, 4, CV_32FC1);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) T.at<float>(r, c) = (float)pose12[3 * r + c];
+        T.at<float>(r, 3) = (float)pose12[9 + r];
+    }
+    return T;
+}
+g2o::SE3Quat quat12(const double* pose12) {
+    Eigen::Matrix3d R;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R(r, c) = pose12[3 * r + c];
+    return g2o::SE3Quat(R, Eigen::Vector3d(pose12[9], pose12[10], pose12[11]));
+}
+void put12(const Eigen::Matrix3d& R, const Eigen::Vector3d& t, double* out12) {
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) out12[3 * r + c] = R(r, c); out12[9 + r] = t[r]; }
+}
+template <typename M> void put36(const M& m, double* out36) { for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) out36[6 * r + c] = m(r, c); }
+void set_plane_config(double xrot, double yrot, double z) {
+    Config::PLANEMOTION_XROT_INFO = (float)xrot;
+    Config::PLANEMOTION_YROT_INFO = (float)yrot;
+    Config::PLANEMOTION_Z_INFO = (float)z;
+}
+}  // namespace
+
+extern "C" {
+
+// addVertexSE3Expmap + addPlaneMotionSE3Expmap (src/optimizer.cpp:226-314) -> measurement (R, t) and information of the
+// EdgeSE3ExpmapPrior it attaches; Tbc goes in as the CV_32F matrix Config::bTc is.  Returns the number of edges in the graph.
+int ref_plane_motion_expmap(const double* Tcw12, const double* Tbc12, double xrot, double yrot, double z, double* meas12, double* info36) {
+    set_plane_config(xrot, yrot, z);
+    SlamOptimizer opt;
+    initOptimizer(opt);
+    const g2o::SE3Quat pose = quat12(Tcw12);
+    addVertexSE3Expmap(opt, pose, 0, false);
+    EdgeSE3ExpmapPrior* e = addPlaneMotionSE3Expmap(opt, pose, 0, mat4f(Tbc12));
+    put12(e->measurement().rotation().toRotationMatrix(), e->measurement().translation(), meas12);
+    put36(e->information(), info36);
+    return (int)opt.edges().size() * (e->vertices()[0] == opt.vertex(0) ? 1 : -1);
+}
+// addVertexSE3PlaneMotion (src/optimizer.cpp:336-470) -> measurement and information of the g2o::EdgeSE3Prior, and the
+// SE3-offset parameter id the edge was given
+int ref_plane_motion_iso3(const double* Twc12, const double* Tbc12, double xrot, double yrot, double z, double* meas12, double* info36) {
+    set_plane_config(xrot, yrot, z);
+    SlamOptimizer opt;
+    initOptimizer(opt);
+    addParaSE3Offset(opt, g2o::Isometry3D(), 7);
+    g2o::EdgeSE3Prior* e = addVertexSE3PlaneMotion(opt, (g2o::Isometry3D)quat12(Twc12), 3, mat4f(Tbc12), 7, false);
+    put12(e->measurement().linear(), e->measurement().translation(), meas12);
+    put36(e->information(), info36);
+    return (opt.vertex(3) && e->vertices()[0] == opt.vertex(3)) ? e->parameterId(0) : -1;
+}
+// EdgeSE3ExpmapPrior::computeError / linearizeOplus (src/optimizer.cpp:159-191): err (rotation, translation), J 6x6
+void ref_prior_expmap_edge(const double* meas12, const double* est12, double* err6, double* J36) {
+    g2o::VertexSE3Expmap v;
+    v.setEstimate(quat12(est12));
+    EdgeSE3ExpmapPrior e;
+    e.vertices()[0] = &v;
+    e.setMeasurement(quat12(meas12));
+    e.computeError();
+    e.linearizeOplus();
+    for (int i = 0; i < 6; ++i) err6[i] = e.error()[i];
+    put36(e.jacobianOplusXi(), J36);
+}
+// addEdgeSE3Expmap (src/optimizer.cpp:482-500): the (translation, rotation) -> (rotation, translation) reordering of the information
+int ref_edge_se3expmap_info(const double* info36_tr, double* info36_rt) {
+    SlamOptimizer opt;
+    addVertexSE3Expmap(opt, g2o::SE3Quat(), 0, true);
+    addVertexSE3Expmap(opt, g2o::SE3Quat(), 1, false);
+    g2o::Matrix6d info;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) info(r, c) = info36_tr[6 * r + c];
+    if (!verifyInfo(info)) return -1;
+    addEdgeSE3Expmap(opt, g2o::SE3Quat(), 0, 1, info);
+    const g2o::EdgeSE3Expmap* e = static_cast<const g2o::EdgeSE3Expmap*>(opt.edges().at(0));
+    put36(e->information(), info36_rt);
+    return 0;
+}
+// Jl / invJl (src/optimizer.cpp:64-93) and invJJl (:109-157)
+void ref_so3_jacobians(const double* v3, double* Jl9, double* invJl9) {
+    const g2o::Vector3D v(v3[0], v3[1], v3[2]);
+    const g2o::Matrix3D a = Jl(v), b = invJl(v);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Jl9[3 * r + c] = a(r, c); invJl9[3 * r + c] = b(r, c); }
+}
+void ref_inv_jjl(const double* v6, double* out36) {
+    g2o::Vector6d v;
+    for (int i = 0; i < 6; ++i) v[i] = v6[i];
+    put36(invJJl(v), out36);
+}
+// converter.cpp: toSE3Quat(cv::Mat) -> toCvMat(SE3Quat) and toIsometry3D(cv::Mat) -> toCvMat(Isometry3D) round trips of a CV_32F pose
+void ref_converter_round_trip(const double* pose12, float* via_quat16, float* via_iso16) {
+    const cv::Mat T = mat4f(pose12);
+    const cv::Mat a = toCvMat(toSE3Quat(T)), b = toCvMat(toIsometry3D(T));
+    for (int i = 0; i < 16; ++i) { via_quat16[i] = a.at<float>(i / 4, i % 4); via_iso16[i] = b.at<float>(i / 4, i % 4); }
+}
+
+// One SE(2)-XYZ window built with the reference's own calls, in the order of Map::loadLocalGraph's consumer
+// (src/LocalMapper.cpp:355-424 / src/GlobalMapper.cpp:328-388): addCamPara(K), addVertexSE2 per key frame, addEdgeSE2 per
+// odometry pair, addVertexSBAXYZ per landmark (ids after the key frames), addEdgeSE2XYZ per observation with Tbc =
+// toSE3Quat(Config::bTc) and Huber delta.  Every edge then runs its own computeError(); chi_e / chi_o = e' Omega e per edge,
+// returns sum rho(chi) as g2o's activeRobustChi2 does.  K and bTc go in as CV_32F like Config::Kcam / Config::bTc.
+double ref_window_chi2(int P, const double* poses, const uint8_t* fixed, int L, const double* lms, int E, const int32_t* e_kf,
+                       const int32_t* e_lm, const double* e_uv, const double* e_info3, int O, const int32_t* o_i, const int32_t* o_j,
+                       const double* o_meas, const double* o_info9, const float* K9, const double* Tbc12, double huber,
+                       double* chi_e, double* chi_o, int32_t* counts3) {
+    SlamOptimizer opt;
+    initOptimizer(opt);
+    cv::Mat K(3, 3, CV_32FC1);
+    for (int i = 0; i < 9; ++i) K.at<float>(i / 3, i % 3) = K9[i];
+    CamPara* cam = addCamPara(opt, K, 0);
+    const g2o::SE3Quat Tbc = toSE3Quat(mat4f(Tbc12));
+    for (int i = 0; i < P; ++i) addVertexSE2(opt, g2o::SE2(poses[3 * i], poses[3 * i + 1], poses[3 * i + 2]), i, fixed[i] != 0);
+    std::vector<g2o::PreEdgeSE2*> odo;
+    for (int k = 0; k < O; ++k) {
+        g2o::Matrix3D info;
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) info(r, c) = o_info9[9 * k + 3 * r + c];
+        odo.push_back(addEdgeSE2(opt, g2o::Vector3D(o_meas[3 * k], o_meas[3 * k + 1], o_meas[3 * k + 2]), o_i[k], o_j[k], info));
+    }
+    for (int l = 0; l < L; ++l) addVertexSBAXYZ(opt, Eigen::Vector3d(lms[3 * l], lms[3 * l + 1], lms[3 * l + 2]), P + l, true, false);
+    std::vector<g2o::EdgeSE2XYZ*> obs;
+    for (int k = 0; k < E; ++k) {
+        g2o::Matrix2D info;
+        info(0, 0) = e_info3[3 * k]; info(0, 1) = info(1, 0) = e_info3[3 * k + 1]; info(1, 1) = e_info3[3 * k + 2];
+        obs.push_back(addEdgeSE2XYZ(opt, g2o::Vector2D(e_uv[2 * k], e_uv[2 * k + 1]), e_kf[k], P + e_lm[k], cam, Tbc, info, huber));
+    }
+    double total = 0;
+    for (int k = 0; k < O; ++k) { odo[k]->computeError(); chi_o[k] = odo[k]->chi2(); total += chi_o[k]; }
+    for (int k = 0; k < E; ++k) {
+        obs[k]->computeError();
+        chi_e[k] = obs[k]->chi2();
+        total += obs[k]->robustKernel()->rho(chi_e[k]);
+    }
+    int nfixed = 0, nmarg = 0;
+    for (int i = 0; i < P; ++i) nfixed += static_cast<g2o::VertexSE2*>(opt.vertex(i))->fixed();
+    for (int l = 0; l < L; ++l) nmarg += static_cast<g2o::VertexSBAPointXYZ*>(opt.vertex(P + l))->marginalized();
+    counts3[0] = (int32_t)opt.edges().size(); counts3[1] = nfixed; counts3[2] = nmarg;
+    return total;
 }
 
 }  // extern "C"

@@ -326,10 +326,23 @@ def addPriorSE3Expmap(opt: SlamOptimizer, vId: int, meas, info):
                                                   capi.pd(np.ascontiguousarray(info, np.float64).reshape(-1))))
 
 
-def addEdgeSE3Expmap(opt: SlamOptimizer, measure, id0: int, id1: int, info):
-    """optimizer.h:94"""
+def _add_edge_se3(opt: SlamOptimizer, measure, id0: int, id1: int, info):
     capi.check(capi.lib().se2gpu_ba_add_edge_se3(opt._h, int(id0), int(id1), capi.pd(_pose12(measure)),
                                                  capi.pd(np.ascontiguousarray(info, np.float64).reshape(-1))))
+
+
+def swapInfoBlocks(info) -> np.ndarray:
+    """(translation, rotation) <-> (rotation, translation) order of a 6x6 information matrix (optimizer.cpp:492-497)"""
+    w = np.asarray(info, np.float64).reshape(6, 6)
+    n = np.empty((6, 6))
+    n[:3, :3] = w[3:, 3:]; n[3:, :3] = w[:3, 3:]; n[:3, 3:] = w[3:, :3]; n[3:, 3:] = w[:3, :3]
+    return n
+
+
+def addEdgeSE3Expmap(opt: SlamOptimizer, measure, id0: int, id1: int, info):
+    """optimizer.h:94 / optimizer.cpp:482-500: "The input info is [trans rot] order, but EdgeSE3Expmap requires [rot trans]" -
+    the blocks are swapped here as the reference swaps them; the C ABI takes g2o's order."""
+    _add_edge_se3(opt, measure, id0, id1, swapInfoBlocks(info))
 
 
 def addEdgeXYZ2UV(opt: SlamOptimizer, measure, idMP: int, idKF: int, paraId: int, info, thHuber: float):
@@ -363,7 +376,7 @@ def load_se3_graph(opt: SlamOptimizer, g, K=None):
         if g.has_prior[a]:
             addPriorSE3Expmap(opt, a, g.prior_meas[a], g.prior_info[a])
     for k in range(g.O):
-        addEdgeSE3Expmap(opt, g.o_meas[k], int(g.o_i[k]), int(g.o_j[k]), g.o_info[k])
+        addEdgeSE3Expmap(opt, g.o_meas[k], int(g.o_i[k]), int(g.o_j[k]), swapInfoBlocks(g.o_info[k]))   # the graph holds g2o's order
     maxKFid = g.P + 1
     for l in range(g.L):
         addVertexSBAXYZ(opt, g.lms[l], maxKFid + l)
@@ -394,8 +407,8 @@ def addVertexSE3PlaneMotion(opt: SlamOptimizer, Twc, id: int, extPara, paraSE3Of
 
 
 def addEdgeSE3(opt: SlamOptimizer, measure, id0: int, id1: int, info):
-    """optimizer.h:129"""
-    addEdgeSE3Expmap(opt, measure, id0, id1, info)
+    """optimizer.h:129: EdgeSE3 takes (translation, rotation) as it is"""
+    _add_edge_se3(opt, measure, id0, id1, info)
 
 
 estimateVertexSE3 = estimateVertexSE3Expmap     # optimizer.h:135 (the pose type follows the graph)
