@@ -316,7 +316,8 @@ def addPlaneMotionSE3Expmap(opt: SlamOptimizer, Tcw, vId: int, extPara, xrot_inf
     """optimizer.h:82 / optimizer.cpp:236-314: the EdgeSE3ExpmapPrior that keeps key frame vId on the plane (extPara = Config::bTc)."""
     meas = np.zeros(12)
     info = np.zeros(36)
-    capi.check(capi.lib().se2gpu_plane_motion_prior(_pose12(Tcw).ctypes.data, _pose12(extPara).ctypes.data, float(xrot_info),
+    a, b = _pose12(Tcw), _pose12(extPara)      # named: a temporary's buffer is gone before the call
+    capi.check(capi.lib().se2gpu_plane_motion_prior(a.ctypes.data, b.ctypes.data, float(xrot_info),
                                                     float(yrot_info), float(z_info), meas.ctypes.data, info.ctypes.data))
     capi.check(capi.lib().se2gpu_ba_add_prior_se3(opt._h, int(vId), capi.pd(meas), capi.pd(info)))
 
@@ -399,7 +400,8 @@ def addVertexSE3PlaneMotion(opt: SlamOptimizer, Twc, id: int, extPara, paraSE3Of
     addVertexSE3(opt, Twc, id, fixed)
     meas = np.zeros(12)
     info = np.zeros(36)
-    capi.check(capi.lib().se2gpu_plane_motion_prior_iso3(_pose12(Twc).ctypes.data, _pose12(extPara).ctypes.data,
+    a, b = _pose12(Twc), _pose12(extPara)      # named: a temporary's buffer is gone before the call
+    capi.check(capi.lib().se2gpu_plane_motion_prior_iso3(a.ctypes.data, b.ctypes.data,
                                                          float(xrot_info), float(yrot_info), float(z_info), meas.ctypes.data,
                                                          info.ctypes.data))
     capi.check(capi.lib().se2gpu_ba_add_prior_se3(opt._h, int(id), capi.pd(meas), capi.pd(info)))

@@ -44,7 +44,8 @@ class ORBextractor:
             image = np.ascontiguousarray(image, np.uint8)
             assert image.ndim == 2
             img_ptr, (rows, cols), step = image.ctypes.data, image.shape, image.strides[0]
-        mask_ptr = None if mask is None else np.ascontiguousarray(mask, np.uint8).ctypes.data
+        mask = None if mask is None else np.ascontiguousarray(mask, np.uint8)   # kept in a name until the call returns
+        mask_ptr = None if mask is None else mask.ctypes.data
         capi.check(capi.lib().se2gpu_orb_extract(self._h, img_ptr, rows, cols, step, mask_ptr, kps.ctypes.data,
                                                  desc.ctypes.data, cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
