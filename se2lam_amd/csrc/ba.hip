@@ -3100,7 +3100,7 @@ struct se2gpu_ba {
     int solve_depth = 0;          // block columns on the longest dependency chain of the plan (debug)
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc][kSlabs] epochs
     DevBuf<unsigned long long> chol_vfy;   // SE2GPU_BA_CHOL_VERIFY=1: mismatch records + half-slab checksums (d_chol_tiles<true>)
-    DevBuf<int> plan_place;       // k_plan_pack2 -> k_plan_expand: (workgroup << 8) | first group of every block
+    DevBuf<int> plan_place;       // k_plan_tab -> k_plan_tabscan -> k_plan_place: the 256 runs' transfer tables, then their start states
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
     DevBuf<unsigned long long> l0_acc;   // k_lambda0: {max |diag H| as bits, workgroups arrived}; left at zero by every run
     int chol_ntask = 0;
@@ -3377,58 +3377,55 @@ __global__ __launch_bounds__(256) void k_plan_pack(int nblk, const int* __restri
         if (used == gpw) { used = 0; ++wg; }
     }
 }
-// The same packing for graphs whose block count fits the LDS (nblk <= kPackMaxBlk, i.e. up to ~440 key frames; the kernel
-// above stays for the rest), laid out for the machine instead of for one thread per run:
-//   0  groups per block ng (0 = diagonal block, skipped) into LDS bytes, coalesced;
-//   1  the 256 runs' transfer functions with LANE = START STATE (two runs per wave, 16 waves: the 28-fold work of the
-//      tabulation is spread over the lanes and four waves per SIMD hide each other's issue latency);
-//   2  the composition of the 256 tables as a parallel (Hillis-Steele) scan, 8 steps;
-//   3  one thread per run walks it from its now known start state and leaves (workgroup, first group) per block;
-// k_plan_expand then writes the group descriptors with one thread per block.
-constexpr int kPackMaxBlk = 96 * 1024;
-__global__ __launch_bounds__(1024) void k_plan_pack2(int nblk, const int* __restrict__ blk_a, const int* __restrict__ blk_b,
-                                                      const int* __restrict__ blk_ptr, int* __restrict__ place,
-                                                      int* __restrict__ out_n, int gpw) {
-    extern __shared__ unsigned char pack_lds[];
-    int* tab0 = reinterpret_cast<int*>(pack_lds);                 // [256][28]: used | workgroups closed << 8
-    int* tab1 = tab0 + 256 * kGrpPerWG;
-    unsigned char* ng8 = reinterpret_cast<unsigned char*>(tab1 + 256 * kGrpPerWG);
+// The same packing for graphs of up to kPackMaxBlk blocks (~440 key frames; the kernel above stays for the rest), spread
+// over the machine - as ONE workgroup (k_plan_pack2, rounds 3-4) it was the longest kernel of `initialize`: 100 us at 200
+// key frames, most of it twenty dependent rounds of global loads and 632 table steps per lane:
+//   k_plan_tab     one workgroup per run of `per` blocks (256 runs): groups per block into LDS (coalesced loads), then
+//                  the run's transfer function with LANE = START STATE - {used -> (used', workgroups closed)};
+//   k_plan_tabscan one workgroup: the composition of the 256 tables as a parallel (Hillis-Steele) scan in LDS, 8 steps
+//                  -> every run's start state, and the number of workgroups;
+//   k_plan_place   one workgroup per run: one lane walks the run from its start state (workgroup, first group of every
+//                  block, in LDS), then all lanes write the group descriptors.
+constexpr int kPackMaxBlk = 96 * 1024, kPackRuns = 256, kPackPerMax = kPackMaxBlk / kPackRuns;
+__device__ inline int pack_groups_of(int cnt, int gpw) {
+    int ng = max(1, (cnt + kChunk - 1) / kChunk);
+    if (ng > gpw) { const int chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
+    return ng;
+}
+__global__ __launch_bounds__(128) void k_plan_tab(int nblk, const int* __restrict__ blk_a, const int* __restrict__ blk_b,
+                                                   const int* __restrict__ blk_ptr, int* __restrict__ tab, int gpw) {
+    __shared__ unsigned char ng8[kPackPerMax];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int per = (nblk + kPackRuns - 1) / kPackRuns;
+    const int b0 = min(r * per, nblk), b1 = min(b0 + per, nblk);
+    for (int x = t; x < b1 - b0; x += 128) {
+        const int kb = b0 + x;
+        ng8[x] = (unsigned char)(blk_a[kb] != blk_b[kb] ? pack_groups_of(blk_ptr[kb + 1] - blk_ptr[kb], gpw) : 0);   // 0 = diagonal block, skipped
+    }
+    __syncthreads();
+    if (t >= 32) return;
+    int used = t, wgs = 0;
+    for (int x = 0; x < b1 - b0; ++x) {
+        const int ng = ng8[x];
+        if (ng == 0) continue;   // (uniform over the lanes)
+        const bool fl = used + ng > gpw;
+        used = (fl ? 0 : used) + ng;
+        wgs += fl;
+        const bool ex = used == gpw;
+        used = ex ? 0 : used;
+        wgs += ex;
+    }
+    if (t < kGrpPerWG) tab[r * kGrpPerWG + t] = used | (wgs << 8);
+}
+__global__ __launch_bounds__(1024) void k_plan_tabscan(const int* __restrict__ tab, int* __restrict__ start, int* __restrict__ out_n) {
+    __shared__ int tab0[kPackRuns * kGrpPerWG], tab1[kPackRuns * kGrpPerWG];
     const int t = threadIdx.x;
-    for (int kb = t; kb < nblk; kb += 1024) {
-        int ng = 0;
-        if (blk_a[kb] != blk_b[kb]) {
-            const int cnt = blk_ptr[kb + 1] - blk_ptr[kb];
-            ng = max(1, (cnt + kChunk - 1) / kChunk);
-            if (ng > gpw) { const int chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
-        }
-        ng8[kb] = (unsigned char)ng;
-    }
+    for (int e = t; e < kPackRuns * kGrpPerWG; e += 1024) tab0[e] = tab[e];
     __syncthreads();
-    const int per = (nblk + 255) / 256;
-    {   // 1: lane = start state
-        const int half = (t >> 5) & 1, u = t & 31, wave = t >> 6;
-        for (int r = 2 * wave + half; r < 256; r += 32) {
-            const int b0 = min(r * per, nblk), b1 = min(b0 + per, nblk);
-            int used = u, wgs = 0;
-            for (int kb = b0; kb < b1; ++kb) {
-                const int ng = ng8[kb];
-                if (ng == 0) continue;   // (uniform over the half wave)
-                const bool fl = used + ng > gpw;
-                used = (fl ? 0 : used) + ng;
-                wgs += fl;
-                const bool ex = used == gpw;
-                used = ex ? 0 : used;
-                wgs += ex;
-            }
-            if (u < kGrpPerWG) tab0[r * kGrpPerWG + u] = used | (wgs << 8);
-        }
-    }
-    __syncthreads();
-    // 2: inclusive scan of the tables under composition (earlier run first)
     int* src = tab0;
     int* dst = tab1;
-    for (int d = 1; d < 256; d <<= 1) {
-        for (int e = t; e < 256 * kGrpPerWG; e += 1024) {
+    for (int d = 1; d < kPackRuns; d <<= 1) {   // inclusive scan of the tables under composition (earlier run first)
+        for (int e = t; e < kPackRuns * kGrpPerWG; e += 1024) {
             const int r = e / kGrpPerWG, u = e - r * kGrpPerWG;
             int v = src[e];
             if (r >= d) {
@@ -3441,38 +3438,53 @@ __global__ __launch_bounds__(1024) void k_plan_pack2(int nblk, const int* __rest
         __syncthreads();
         int* tmp = src; src = dst; dst = tmp;
     }
-    // 3: walk the runs
-    if (t < 256) {
-        int used = 0, wg = 0;
-        if (t > 0) { const int v = src[(t - 1) * kGrpPerWG]; used = v & 0xff; wg = v >> 8; }
-        const int b0 = min(t * per, nblk), b1 = min(b0 + per, nblk);
-        for (int kb = b0; kb < b1; ++kb) {
-            const int ng = ng8[kb];
-            if (ng == 0) { place[kb] = -1; continue; }
+    if (t < kPackRuns) start[t] = t ? src[(t - 1) * kGrpPerWG] : 0;   // used | workgroup << 8 in front of run t (from state 0)
+    if (t == 0) {
+        const int v = src[(kPackRuns - 1) * kGrpPerWG];
+        out_n[0] = (v >> 8) + ((v & 0xff) ? 1 : 0);
+    }
+}
+__global__ __launch_bounds__(128) void k_plan_place(int nblk, const int* __restrict__ blk_a, const int* __restrict__ blk_b,
+                                                     const int* __restrict__ blk_ptr, const int* __restrict__ start,
+                                                     int4* __restrict__ grp, int grp_cap_wg, int gpw) {
+    __shared__ unsigned char ng8[kPackPerMax];
+    __shared__ int place[kPackPerMax];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int per = (nblk + kPackRuns - 1) / kPackRuns;
+    const int b0 = min(r * per, nblk), b1 = min(b0 + per, nblk);
+    for (int x = t; x < b1 - b0; x += 128) {
+        const int kb = b0 + x;
+        ng8[x] = (unsigned char)(blk_a[kb] != blk_b[kb] ? pack_groups_of(blk_ptr[kb + 1] - blk_ptr[kb], gpw) : 0);
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int v = start[r];
+        int used = v & 0xff, wg = v >> 8;
+        for (int x = 0; x < b1 - b0; ++x) {
+            const int ng = ng8[x];
+            if (ng == 0) { place[x] = -1; continue; }
             if (used + ng > gpw) { ++wg; used = 0; }
-            place[kb] = (wg << 8) | used;
+            place[x] = (wg << 8) | used;
             used += ng;
             if (used == gpw) { used = 0; ++wg; }
         }
-        if (t == 255) out_n[0] = wg + (used ? 1 : 0);
     }
-}
-__global__ void k_plan_expand(int nblk, const int* __restrict__ blk_ptr, const int* __restrict__ place,
-                              int4* __restrict__ grp, int grp_cap_wg, int gpw) {
-    const int kb = blockIdx.x * blockDim.x + threadIdx.x;
-    if (kb >= nblk) return;
-    const int pl = place[kb];
-    if (pl < 0) return;
-    const int wg = pl >> 8, first = pl & 0xff;
-    if (wg >= grp_cap_wg) return;
-    const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
-    const int cnt = q1 - q0;
-    int chunk = kChunk;
-    int ng = max(1, (cnt + chunk - 1) / chunk);
-    if (ng > gpw) { chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
-    for (int g = 0; g < ng; ++g) {
-        const int a0 = q0 + g * chunk, a1 = min(q1, a0 + chunk);
-        grp[(size_t)wg * gpw + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
+    __syncthreads();
+    for (int x = t; x < b1 - b0; x += 128) {
+        const int pl = place[x];
+        if (pl < 0) continue;
+        const int wg = pl >> 8, first = pl & 0xff;
+        if (wg >= grp_cap_wg) continue;
+        const int kb = b0 + x;
+        const int q0 = blk_ptr[kb], q1 = blk_ptr[kb + 1];
+        const int cnt = q1 - q0;
+        int chunk = kChunk;
+        int ng = max(1, (cnt + chunk - 1) / chunk);
+        if (ng > gpw) { chunk = (cnt + gpw - 1) / gpw; ng = (cnt + chunk - 1) / chunk; }
+        for (int g = 0; g < ng; ++g) {
+            const int a0 = q0 + g * chunk, a1 = min(q1, a0 + chunk);
+            grp[(size_t)wg * gpw + first + g] = make_int4(kb, a0, max(a0, a1), first | (ng << 8));
+        }
     }
 }
 // Independent steps of the plan as ONE launch each (a launch boundary costs about as much as these kernels run: 26 launches
@@ -3712,7 +3724,8 @@ struct SolvePlan {
     std::vector<int> deps;
 };
 
-// parts: the poses of every partition in order; pad: partitions (and therefore the rhs row) start on tile boundaries
+// parts: the poses of every partition in order; pad: partitions (and therefore the rhs row) start on tile boundaries;
+// pat: nullptr (dense) or a SYMMETRIC P x P byte pattern
 void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::vector<int>>& parts, bool pad, SolvePlan& sp) {
     sp.pose_off.assign(P, 0);
     int c = 0;
@@ -3734,16 +3747,37 @@ void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::v
     std::vector<uint8_t> Lt((size_t)nt * nbc, 0);
     auto L = [&](int i, int j) -> uint8_t& { return Lt[(size_t)i * nbc + j]; };
     for (int j = 0; j < nbc; ++j) L(j, j) = 1;
+    // pose a touches tile rows t0[a] .. t1[a]; the tiles its neighbours touch as one 64-bit mask per pose (nt <= 64 is what
+    // the dataflow solve takes, larger systems go to k_chol_step and need no tile pattern): P^2 branch-free ORs instead of
+    // P^2 / 2 tests with up to four stores each - this loop was most of the 0.18 ms the plan cost at 200 key frames
     std::vector<int> t0(P), t1(P);
     for (int p = 0; p < P; ++p) { t0[p] = sp.pose_off[p] / kNB; t1[p] = (sp.pose_off[p] + D - 1) / kNB; }
-    for (int a = 0; a < P; ++a)
-        for (int b = 0; b <= a; ++b) {
-            if (pat && !pat[(size_t)a * P + b] && !pat[(size_t)b * P + a]) continue;
-            for (int ta = t0[a]; ta <= t1[a]; ++ta)
-                for (int tb = t0[b]; tb <= t1[b]; ++tb) {
-                    if (ta >= tb) L(ta, tb) = 1; else L(tb, ta) = 1;
-                }
+    if (nt <= 64) {
+        std::vector<unsigned long long> tm(P), rowmask(nt, 0ull);
+        for (int p = 0; p < P; ++p) tm[p] = (t1[p] >= 63 ? ~0ull : (1ull << (t1[p] + 1)) - 1) & ~((1ull << t0[p]) - 1);
+        for (int a = 0; a < P; ++a) {
+            unsigned long long m = tm[a];
+            if (pat) {
+                const uint8_t* row = pat + (size_t)a * P;
+                for (int b = 0; b < P; ++b) m |= tm[b] & (0ull - (unsigned long long)(row[b] != 0));   // (pat is symmetric: solve_plan_choose)
+            } else {
+                m = ~0ull;
+            }
+            for (int ta = t0[a]; ta <= t1[a]; ++ta) rowmask[ta] |= m;
         }
+        for (int i = 0; i < nbc; ++i)
+            for (int j = 0; j <= i; ++j)
+                if (((rowmask[i] >> j) | (rowmask[j] >> i)) & 1ull) L(i, j) = 1;
+    } else {
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b <= a; ++b) {
+                if (pat && !pat[(size_t)a * P + b]) continue;
+                for (int ta = t0[a]; ta <= t1[a]; ++ta)
+                    for (int tb = t0[b]; tb <= t1[b]; ++tb) {
+                        if (ta >= tb) L(ta, tb) = 1; else L(tb, ta) = 1;
+                    }
+            }
+    }
     for (int j = 0; j < nbc; ++j) L(it, j) = 1;        // y = L^-1 b
     for (int j = 0; j < nbc; ++j)                      // symbolic factorisation: fill between the rows of a column
         for (int i = j + 1; i < nt; ++i) {
@@ -3797,18 +3831,32 @@ void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::v
 
 // candidate orders for a pattern whose natural order is a band - open or closed to a ring (key frames in sequence, a loop
 // closure at most between the ends) - and the choice by chain length
-void solve_plan_choose(int P, int D, const uint8_t* pat, bool allow_nd, SolvePlan& best) {
+void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, SolvePlan& best, bool symmetric = false) {
     std::vector<int> all(P);
     for (int p = 0; p < P; ++p) all[p] = p;
+    std::vector<uint8_t> sym;
+    const uint8_t* pat = pat_in;
+    if (pat_in && !symmetric) {   // a caller's pattern may be one-sided (the debug entry point); initialize hands over a symmetric one
+        sym.assign((size_t)P * P, 0);
+        for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) sym[(size_t)a * P + b] = (uint8_t)((pat_in[(size_t)a * P + b] | pat_in[(size_t)b * P + a]) != 0);
+        pat = sym.data();
+    }
     solve_plan_build(P, D, pat, {all}, false, best);
     if (!allow_nd || !pat || D * P < 4 * kNB) return;
+    // widths of the band: which distances |a - b| occur at all (one OR per entry, no branch), then the largest linear and
+    // cyclic distance among them
     int w_lin = 0, w_cyc = 0;
-    for (int a = 0; a < P; ++a)
-        for (int b = 0; b < a; ++b)
-            if (pat[(size_t)a * P + b] || pat[(size_t)b * P + a]) {
-                w_lin = std::max(w_lin, a - b);
-                w_cyc = std::max(w_cyc, std::min(a - b, P - (a - b)));
-            }
+    {
+        std::vector<uint8_t> dist(P, 0);
+        for (int a = 1; a < P; ++a) {
+            const uint8_t* row = pat + (size_t)a * P;
+            uint8_t* dd = dist.data() + a;       // dd[-b] = distance a - b
+            for (int b = 0; b < a; ++b) dd[-b] |= row[b];
+        }
+        for (int d = 1; d < P; ++d)
+            if (dist[d]) { w_lin = std::max(w_lin, d); w_cyc = std::max(w_cyc, std::min(d, P - d)); }
+    }
     const int min_interior = (kNB + D - 1) / D;       // an interior below one tile of poses is not worth a partition
     std::function<void(int, int, int, int, std::vector<std::vector<int>>&)> linear = [&](int lo, int hi, int w, int levels,
                                                                                          std::vector<std::vector<int>>& out) {
@@ -3827,7 +3875,13 @@ void solve_plan_choose(int P, int D, const uint8_t* pat, bool allow_nd, SolvePla
         for (int p = s0; p < s1; ++p) sep.push_back(p);
         out.push_back(sep);
     };
+    // the levels of a dissection that cannot split any further give the same partitions again: every distinct candidate is
+    // built once
+    std::vector<std::vector<std::vector<int>>> seen;
     auto consider = [&](const std::vector<std::vector<int>>& parts) {
+        for (const auto& sd : seen)
+            if (sd == parts) return;
+        seen.push_back(parts);
         SolvePlan cand;
         solve_plan_build(P, D, pat, parts, true, cand);
         // a shorter chain of block columns wins; the natural order keeps ties (no padding, fewer tiles)
@@ -3921,12 +3975,28 @@ int ba_upload_graph(se2gpu_ba* h) {
         int unsorted = 0;
         for (int k = 1; k < E; ++k) unsorted |= e_lm[k] < e_lm[k - 1];
         sorted = !unsorted;
-        if (sorted) {   // pairs = sum over the edges of their position inside their landmark's run
-            int run_start = 0;
-            for (int k = 1; k < E; ++k) {
-                run_start = e_lm[k] != e_lm[k - 1] ? k : run_start;
-                npairs_max += (size_t)(k - run_start);
+        if (sorted) {   // pairs = sum over the edges of their position inside their landmark's run.  The running start of the
+            // run is a one-cycle dependency per edge (40 us at 120,000 edges), so the edges are cut into four pieces that
+            // begin on run boundaries and the four chains advance side by side
+            int cut[5] = {0, E / 4, E / 2, E - E / 4, E};
+            for (int c = 1; c < 4; ++c) {
+                cut[c] = std::max(cut[c], cut[c - 1]);
+                while (cut[c] > 0 && cut[c] < E && e_lm[cut[c]] == e_lm[cut[c] - 1]) ++cut[c];
             }
+            int rs[4] = {cut[0], cut[1], cut[2], cut[3]};
+            size_t acc[4] = {0, 0, 0, 0};
+            int len = 0;
+            for (int c = 0; c < 4; ++c) len = std::max(len, cut[c + 1] - cut[c]);
+            for (int t = 1; t < len; ++t) {
+                for (int c = 0; c < 4; ++c) {
+                    const int k = cut[c] + t;
+                    if (k < cut[c + 1]) {
+                        rs[c] = e_lm[k] != e_lm[k - 1] ? k : rs[c];
+                        acc[c] += (size_t)(k - rs[c]);
+                    }
+                }
+            }
+            npairs_max = acc[0] + acc[1] + acc[2] + acc[3];
         }
     }
     SE2_REQUIRE(in_range, SE2GPU_ERR_INVALID, "an edge references a vertex out of range");
@@ -4160,19 +4230,23 @@ int ba_upload_graph(se2gpu_ba* h) {
     lap("reserve");
     SE2_CHECK(h->h_stage.reserve(staged_bytes));
     SE2_CHECK(h->garena.reserve(staged_bytes));
-    {   // the copy into the pinned arena runs ahead of the DMA in pieces of about 1 MB: the engine starts on the first
-        // piece while the host is still copying the rest (5.7 MB at 200 key frames: 130 us of memcpy beside 230 us of DMA)
-        constexpr size_t kPiece = (size_t)1 << 20;
-        size_t sent = 0;   // bytes of the arena already handed to the copy engine
-        hipStream_t copy_stream = nullptr;
-        SE2_CHECK(ba_copy_stream(h->device, &copy_stream));
-        if (!h->ev_copy0) {
-            SE2_HIP(hipEventCreateWithFlags(&h->ev_copy0, hipEventDisableTiming));
-            SE2_HIP(hipEventCreateWithFlags(&h->ev_copy1, hipEventDisableTiming));
-        }
-        SE2_HIP(hipEventRecord(h->ev_copy0, st));                      // (the arena may still be read by earlier work)
-        SE2_HIP(hipStreamWaitEvent(copy_stream, h->ev_copy0, 0));
-        hipStream_t cur = st;
+    // The copy into the pinned arena runs ahead of the DMA in pieces of about 1 MB: the engine starts on the first piece
+    // while the host is still copying the rest (5.7 MB at 200 key frames: 130 us of memcpy beside the DMA).  The graph's
+    // index arrays and estimates go first, on the handle's stream, and the plan kernels are enqueued right behind them; the
+    // measurements and information matrices - four fifths of the bytes, needed by nothing before the first linearisation -
+    // are copied afterwards on the copy stream, while the device already builds the plan (round 4: the plan chain used to
+    // start only when the host had staged everything, 0.11 ms later).
+    constexpr size_t kPiece = (size_t)1 << 20;
+    size_t sent = 0;   // bytes of the arena already handed to the copy engine
+    hipStream_t copy_stream = nullptr;
+    SE2_CHECK(ba_copy_stream(h->device, &copy_stream));
+    if (!h->ev_copy0) {
+        SE2_HIP(hipEventCreateWithFlags(&h->ev_copy0, hipEventDisableTiming));
+        SE2_HIP(hipEventCreateWithFlags(&h->ev_copy1, hipEventDisableTiming));
+    }
+    SE2_HIP(hipEventRecord(h->ev_copy0, st));                      // (the arena may still be read by earlier work)
+    SE2_HIP(hipStreamWaitEvent(copy_stream, h->ev_copy0, 0));
+    auto stage_range = [&](size_t lo, size_t hi, hipStream_t cur) -> int {   // the staged arrays with lo <= offset < hi
         auto flush_on = [&](size_t upto) -> int {
             if (upto > sent) {
                 SE2_HIP(hipMemcpyAsync(h->garena.p + sent, h->h_stage.p + sent, upto - sent, hipMemcpyHostToDevice, cur));
@@ -4181,12 +4255,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             return SE2GPU_OK;
         };
         for (const Staged& sg : staged) {
-            sg.bind(h->garena.p + sg.off);
-            if (sg.off >= big_end) continue;                           // evaluated on the device: nothing to copy
-            if (sg.off == big_off) {                                   // everything before goes out on the main stream now
-                SE2_CHECK(flush_on(big_off));
-                cur = copy_stream;
-            }
+            if (sg.off < lo || sg.off >= hi) continue;
             for (size_t done = 0; done < sg.bytes;) {
                 const size_t nb = std::min(sg.bytes - done, kPiece);
                 std::memcpy(h->h_stage.p + sg.off + done, (const uint8_t*)sg.src + done, nb);
@@ -4194,10 +4263,11 @@ int ba_upload_graph(se2gpu_ba* h) {
                 if (sg.off + done - sent >= kPiece) SE2_CHECK(flush_on(sg.off + done));
             }
         }
-        SE2_CHECK(flush_on(std::min(big_end, staged_bytes)));
-        SE2_HIP(hipEventRecord(h->ev_copy1, copy_stream));
-    }
-    lap("staging + enqueue");
+        return flush_on(std::min(hi, staged_bytes));
+    };
+    for (const Staged& sg : staged) sg.bind(h->garena.p + sg.off);
+    SE2_CHECK(stage_range(0, big_off, st));
+    lap("indices staged");
     if (h->lg_active && E)
         hipLaunchKernelGGL(k_edge_information, grid1(E, 256), dim3(256), 0, st, E, h->d_lg_lc.p, h->d_lg_lw.p, h->e_kf.p,
                            h->d_lg_sigma2.p, h->d_lg_Rcw.p, h->d_lg_twb.p, h->lg_fx, h->lg_srot, h->lg_sz, h->e_info.p, 1);
@@ -4285,16 +4355,12 @@ int ba_upload_graph(se2gpu_ba* h) {
                                h->plan_st0.p, h->pair_i.p, h->pair_j.p, g1);
         }
         if (nblk <= kPackMaxBlk) {
-            static const bool lds_ok = [] {
-                return hipFuncSetAttribute((const void*)k_plan_pack2, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           2 * 256 * kGrpPerWG * (int)sizeof(int) + kPackMaxBlk) == hipSuccess;
-            }();
-            SE2_REQUIRE(lds_ok, SE2GPU_ERR_HIP, "k_plan_pack2: cannot reserve its LDS");
-            SE2_CHECK(h->plan_place.reserve((size_t)nblk + 1));
-            const size_t lds = 2 * 256 * kGrpPerWG * sizeof(int) + (((size_t)nblk + 15) & ~(size_t)15);
-            hipLaunchKernelGGL(k_plan_pack2, dim3(1), dim3(1024), lds, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p,
-                               h->plan_place.p, h->plan_out.p, gpw);
-            hipLaunchKernelGGL(k_plan_expand, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->blk_ptr.p, h->plan_place.p,
+            SE2_CHECK(h->plan_place.reserve((size_t)kPackRuns * (kGrpPerWG + 1)));   // the runs' tables, then their start states
+            int* tab = h->plan_place.p;
+            int* start = tab + kPackRuns * kGrpPerWG;
+            hipLaunchKernelGGL(k_plan_tab, dim3(kPackRuns), dim3(128), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, tab, gpw);
+            hipLaunchKernelGGL(k_plan_tabscan, dim3(1), dim3(1024), 0, st, tab, start, h->plan_out.p);
+            hipLaunchKernelGGL(k_plan_place, dim3(kPackRuns), dim3(128), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, start,
                                h->grp.p, cap_wg, gpw);
         } else {
             hipLaunchKernelGGL(k_plan_pack, dim3(1), dim3(256), 0, st, nblk, h->blk_a.p, h->blk_b.p, h->blk_ptr.p, h->grp.p,
@@ -4319,7 +4385,13 @@ int ba_upload_graph(se2gpu_ba* h) {
         }
         lap("plan kernels enqueued");
     }
-    SE2_HIP(hipStreamWaitEvent(st, h->ev_copy1, 0));   // measurements / information are in place before anything later runs
+    // measurements and information matrices (with a local graph the information is evaluated on the device: big_end stops in
+    // front of it); the handle's stream waits for them before anything later runs
+    sent = big_off;
+    SE2_CHECK(stage_range(big_off, big_end, copy_stream));
+    SE2_HIP(hipEventRecord(h->ev_copy1, copy_stream));
+    lap("measurements staged");
+    SE2_HIP(hipStreamWaitEvent(st, h->ev_copy1, 0));
     SE2_CHECK(h->fin_counter.reserve(1));
     SE2_HIP(hipMemsetAsync(h->fin_counter.p, 0, sizeof(unsigned), st));
     SE2_CHECK(h->l0_acc.reserve(2));
@@ -4363,7 +4435,7 @@ int ba_upload_graph(se2gpu_ba* h) {
             }
         }
         SolvePlan sp;
-        solve_plan_choose(P, D, pat.empty() ? nullptr : pat.data(), !pat.empty(), sp);
+        solve_plan_choose(P, D, pat.empty() ? nullptr : pat.data(), !pat.empty(), sp, true);
         h->nsys = sp.nsys;
         h->solve_depth = sp.depth;
         h->chol_ntask = (int)sp.tasks.size();

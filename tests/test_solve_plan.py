@@ -166,3 +166,22 @@ def test_nested_dissection_shortens_the_chain_of_block_columns():
         pat[fx, :] = 0; pat[:, fx] = 0
         np.fill_diagonal(pat, 1)
         assert _plan(P, 3, pat, True)["depth"] <= dmax < _plan(P, 3, pat, False)["depth"]
+
+
+def test_one_sided_pattern_gives_the_plan_of_its_symmetric_closure():
+    """The chooser works on pattern | pattern' (initialize hands over a symmetric one; the debug entry point need not)."""
+    rng = np.random.default_rng(3)
+    P = 90
+    full = np.zeros((P, P), np.uint8)
+    for a in range(P):
+        for d in range(1, 14):
+            full[a, (a + d) % P] = full[(a + d) % P, a] = 1
+    upper = np.triu(full)
+    lower = np.tril(full)
+    mixed = np.where(rng.random((P, P)) < 0.5, upper, lower).astype(np.uint8)
+    mixed = np.maximum(mixed, np.where((mixed + mixed.T) == 0, full, 0)).astype(np.uint8)   # every edge on at least one side
+    want = _plan(P, 3, full)
+    for pat in (upper, lower, mixed):
+        got = _plan(P, 3, pat)
+        assert got["nsys"] == want["nsys"] and got["depth"] == want["depth"]
+        assert np.array_equal(got["tasks"], want["tasks"]) and np.array_equal(got["deps"], want["deps"])
