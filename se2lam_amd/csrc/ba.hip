@@ -3092,7 +3092,7 @@ struct se2gpu_ba {
     DevBuf<int> pose_off;         // fill-reducing order of the pose solve: first system column of pose p (nullptr = 3 p)
     DevBuf<int> col_src;          // system column -> 3 * pose + component, -1 = padding (nullptr = identity)
     std::vector<int> h_pose_off;  // host copy (debug_reduced_system gathers S back into pose order)
-    DevBuf<uint8_t> plan_nz;      // per block of the upper triangle: structurally non-zero (k_plan_pattern)
+    DevBuf<uint8_t> plan_nz;      // per block of the upper triangle: structurally non-zero (k_plan_odo, k_plan_pairs2)
     DevBuf<double> plan_nzd;      // the same as doubles: what a sharded run's all-reduce can merge
     PinBuf<uint8_t> h_plan_nz;
     DevBuf<uint8_t> solver_arena; // chol_tasks | chol_deps | pose_off | col_src
@@ -3146,6 +3146,7 @@ struct se2gpu_ba {
     int root = 1, rank = 0, world = 1;
     int device = 0;                // device the buffers live on (handles are pooled per device, see se2gpu_ba_destroy)
     PinBuf<uint8_t> h_stage;       // pinned arena the graph arrays pass through on their way to the device
+    PinBuf<uint8_t> h_stage_solver;   // the solve plan's lists (built while the arena above may still be read by the copy engine)
     // host copy of the estimates: Map::optimizeLocalGraph asks for every vertex separately (Map.cpp:754-783), one
     // download serves all of those calls until the estimates change again
     PinBuf<double> est;            // [poses 3P | landmarks 3L]
@@ -3154,11 +3155,12 @@ struct se2gpu_ba {
     // the two big edge arrays (measurements, information: 40 of the 48 bytes of an edge) travel on a copy stream beside
     // the plan kernels, which only need the indices.  The stream is shared by all handles of a device (ba_copy_stream): a
     // stream per handle would take hardware queues away from the handles' own streams when many windows run at once
-    hipEvent_t ev_copy0 = nullptr, ev_copy1 = nullptr;
+    hipEvent_t ev_copy0 = nullptr, ev_copy1 = nullptr, ev_pat = nullptr;
 
     ~se2gpu_ba() {
         if (ev_copy0) (void)hipEventDestroy(ev_copy0);
         if (ev_copy1) (void)hipEventDestroy(ev_copy1);
+        if (ev_pat) (void)hipEventDestroy(ev_pat);
         drop_graphs();
         if (own_stream) (void)hipStreamDestroy(own_stream);
         if (h_mail) (void)hipHostFree(h_mail);
@@ -3303,11 +3305,14 @@ __global__ void k_lower_bounds(const int* __restrict__ key, int n, int nq, int* 
 
 // PreEdgeSE2 pose-pose blocks: at most one per (a, b) block goes through the plan (the host checked: no self loops, no
 // duplicates; otherwise the edges take the k_odometry / k_reduce_odo fallback and this kernel is not launched)
-__global__ void k_plan_odo(int P, int O, const int* __restrict__ o_i, const int* __restrict__ o_j, int* __restrict__ blk_odo) {
+__global__ void k_plan_odo(int P, int O, const int* __restrict__ o_i, const int* __restrict__ o_j, int* __restrict__ blk_odo,
+                           uint8_t* __restrict__ nz) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= O) return;
     const int i = o_i[k], j = o_j[k];
-    blk_odo[blk_index_of(P, min(i, j), max(i, j))] = 2 * k + (i > j ? 1 : 0);
+    const int q = blk_index_of(P, min(i, j), max(i, j));
+    blk_odo[q] = 2 * k + (i > j ? 1 : 0);
+    if (nz) nz[q] = 1;
 }
 
 // Packing of the off-diagonal blocks' 16-pair chunks ("groups") into workgroups of kGrpPerWG groups, exactly as the
@@ -3497,7 +3502,7 @@ __global__ __launch_bounds__(256) void k_plan_init(int L, int E, int P, const in
                                                     const uint8_t* __restrict__ fixed, int* __restrict__ lm_ptr,
                                                     int* __restrict__ npair, int* __restrict__ idx, int* __restrict__ blk_a,
                                                     int* __restrict__ blk_b, int* __restrict__ blk_odo, size_t ngrp,
-                                                    int4* __restrict__ grp, int b1, int b2, int b3) {
+                                                    int4* __restrict__ grp, int b1, int b2, int b3, uint8_t* __restrict__ nz) {
     const int bx = blockIdx.x;
     if (bx < b1) {   // landmark CSR + pairs per landmark
         const int l = bx * 256 + threadIdx.x;
@@ -3532,6 +3537,7 @@ __global__ __launch_bounds__(256) void k_plan_init(int L, int E, int P, const in
         blk_a[q] = a;
         blk_b[q] = b;
         blk_odo[q] = -1;
+        if (nz) nz[q] = 0;   // the block pattern for the solver's order: set by k_plan_odo and k_plan_pairs2
     } else {   // empty group descriptors
         const size_t i = (size_t)(bx - b3) * 256 + threadIdx.x;
         if (i < ngrp) grp[i] = make_int4(-1, 0, 0, 0);
@@ -3539,7 +3545,8 @@ __global__ __launch_bounds__(256) void k_plan_init(int L, int E, int P, const in
 }
 __global__ __launch_bounds__(256) void k_plan_pairs2(int L, int P, const int* __restrict__ lm_ptr, const int* __restrict__ e_kf,
                                                       const uint8_t* __restrict__ fixed, const int* __restrict__ pair_base,
-                                                      int* __restrict__ key, int2* __restrict__ st, int cap, int big, int b1) {
+                                                      int* __restrict__ key, int2* __restrict__ st, int cap, int big, int b1,
+                                                      uint8_t* __restrict__ nz) {
     if ((int)blockIdx.x < b1) {
         const int l = blockIdx.x * 256 + threadIdx.x;
         if (l >= L) return;
@@ -3551,8 +3558,10 @@ __global__ __launch_bounds__(256) void k_plan_pairs2(int L, int P, const int* __
             for (int t = s + 1; t < end; ++t) {
                 const int b = e_kf[t];
                 if (fixed[b] || a == b) continue;
-                key[o] = a < b ? blk_index_of(P, a, b) : blk_index_of(P, b, a);
+                const int q = a < b ? blk_index_of(P, a, b) : blk_index_of(P, b, a);
+                key[o] = q;
                 st[o] = a < b ? make_int2(s, t) : make_int2(t, s);
+                if (nz) nz[q] = 1;   // (the same byte from many lanes: any of them may win)
                 ++o;
             }
         }
@@ -3580,12 +3589,9 @@ __global__ __launch_bounds__(256) void k_plan_bounds(const int* __restrict__ key
 }
 inline dim3 grid1(size_t n, int block) { return dim3((unsigned)std::max<size_t>((n + block - 1) / block, 1)); }
 
-// which blocks of the reduced system are structurally non-zero (a contributor pair or an odometry edge): what the solver's
-// fill-reducing order is chosen from (solve_plan_choose)
-__global__ void k_plan_pattern(int nblk, const int* __restrict__ blk_ptr, const int* __restrict__ blk_odo, uint8_t* __restrict__ nz) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nblk) nz[q] = (blk_ptr[q + 1] > blk_ptr[q] || blk_odo[q] >= 0) ? 1 : 0;
-}
+// (Which blocks of the reduced system are structurally non-zero - a contributor pair or an odometry edge - is what the
+// solver's fill-reducing order is chosen from, solve_plan_choose: k_plan_odo and k_plan_pairs2 mark them on the way, so that
+// the pattern can travel to the host while the pairs are still being sorted.)
 // identity on the diagonal of the padding columns of a permuted system (set once: neither k_reduce2 nor the in-place
 // factorisation ever writes anything but zero into padding rows / columns)
 // block pattern <-> doubles (dir 0: widen, 1: narrow "any rank has it")
@@ -3968,36 +3974,14 @@ int ba_upload_graph(se2gpu_ba* h) {
     bool sorted = true, in_range = true;
     size_t npairs_max = 0;   // pairs of observations per landmark (an upper bound of the plan's pairs: fixed poses drop out)
     {   // index range (borrowed bulk arrays are validated here), order, pairs per landmark: three branch-free loops (the
-        // first two vectorise; the third carries only the start of the current run)
+        // first two vectorise; the third carries only the start of the current run.  Measured and dropped in round 4: one
+        // fused pass over both arrays, and the third loop as four independent chains - both slower with clang's code)
         unsigned bad = 0;
         for (int k = 0; k < E; ++k) bad |= (unsigned)((unsigned)e_kf[k] >= (unsigned)P) | (unsigned)((unsigned)e_lm[k] >= (unsigned)L);
         in_range = !bad;
         int unsorted = 0;
         for (int k = 1; k < E; ++k) unsorted |= e_lm[k] < e_lm[k - 1];
         sorted = !unsorted;
-        if (sorted) {   // pairs = sum over the edges of their position inside their landmark's run.  The running start of the
-            // run is a one-cycle dependency per edge (40 us at 120,000 edges), so the edges are cut into four pieces that
-            // begin on run boundaries and the four chains advance side by side
-            int cut[5] = {0, E / 4, E / 2, E - E / 4, E};
-            for (int c = 1; c < 4; ++c) {
-                cut[c] = std::max(cut[c], cut[c - 1]);
-                while (cut[c] > 0 && cut[c] < E && e_lm[cut[c]] == e_lm[cut[c] - 1]) ++cut[c];
-            }
-            int rs[4] = {cut[0], cut[1], cut[2], cut[3]};
-            size_t acc[4] = {0, 0, 0, 0};
-            int len = 0;
-            for (int c = 0; c < 4; ++c) len = std::max(len, cut[c + 1] - cut[c]);
-            for (int t = 1; t < len; ++t) {
-                for (int c = 0; c < 4; ++c) {
-                    const int k = cut[c] + t;
-                    if (k < cut[c + 1]) {
-                        rs[c] = e_lm[k] != e_lm[k - 1] ? k : rs[c];
-                        acc[c] += (size_t)(k - rs[c]);
-                    }
-                }
-            }
-            npairs_max = acc[0] + acc[1] + acc[2] + acc[3];
-        }
     }
     SE2_REQUIRE(in_range, SE2GPU_ERR_INVALID, "an edge references a vertex out of range");
     h->edge_perm.clear();
@@ -4016,16 +4000,16 @@ int ba_upload_graph(se2gpu_ba* h) {
         }
         e_kf = s_kf.data(); e_lm = s_lm.data(); e_uv = s_uv.data(); e_info = s_info.data();
     }
-    if (!sorted) {   // recount on the sorted order
-        npairs_max = 0;
-        for (int k = 0; k < E;) {
-            int t = k + 1;
-            while (t < E && e_lm[t] == e_lm[k]) ++t;
-            const size_t d = (size_t)(t - k);
-            npairs_max += d * (d - 1) / 2;
-            k = t;
+    auto count_pairs = [&]() {   // pairs = sum over the edges (sorted by landmark) of their position inside their landmark's run
+        size_t np = 0;
+        int run_start = 0;
+        for (int k = 1; k < E; ++k) {
+            run_start = e_lm[k] != e_lm[k - 1] ? k : run_start;
+            np += (size_t)(k - run_start);
         }
-    }
+        return np;
+    };
+    npairs_max = count_pairs();   // (on the sorted order in either case)
     SE2_REQUIRE(npairs_max < (size_t)1 << 30, SE2GPU_ERR_CAPACITY, "the contributor plan would hold %zu pairs", npairs_max);
     // --- odometry (tiny: host)
     // pose graph: the EdgeSE3 edges of one unordered key-frame pair form a slot (a < b); the "odometry" arrays of the
@@ -4243,6 +4227,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     if (!h->ev_copy0) {
         SE2_HIP(hipEventCreateWithFlags(&h->ev_copy0, hipEventDisableTiming));
         SE2_HIP(hipEventCreateWithFlags(&h->ev_copy1, hipEventDisableTiming));
+        SE2_HIP(hipEventCreateWithFlags(&h->ev_pat, hipEventDisableTiming));
     }
     SE2_HIP(hipEventRecord(h->ev_copy0, st));                      // (the arena may still be read by earlier work)
     SE2_HIP(hipStreamWaitEvent(copy_stream, h->ev_copy0, 0));
@@ -4268,6 +4253,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     for (const Staged& sg : staged) sg.bind(h->garena.p + sg.off);
     SE2_CHECK(stage_range(0, big_off, st));
     lap("indices staged");
+    bool pattern_early = false;
     if (h->lg_active && E)
         hipLaunchKernelGGL(k_edge_information, grid1(E, 256), dim3(256), 0, st, E, h->d_lg_lc.p, h->d_lg_lw.p, h->e_kf.p,
                            h->d_lg_sigma2.p, h->d_lg_Rcw.p, h->d_lg_twb.p, h->lg_fx, h->lg_srot, h->lg_sz, h->e_info.p, 1);
@@ -4324,6 +4310,12 @@ int ba_upload_graph(se2gpu_ba* h) {
                                (int)cnt, shift, bins, nb, h->plan_offs.p, kout, vout);
             return SE2GPU_OK;
         };
+        uint8_t* nzp = nullptr;   // the block pattern for the solver's order, marked on the way (k_plan_odo, k_plan_pairs2)
+        if (nd_possible) {
+            SE2_CHECK(h->plan_nz.reserve((size_t)nblk));
+            SE2_CHECK(h->h_plan_nz.reserve((size_t)nblk));
+            nzp = h->plan_nz.p;
+        }
         // landmark CSR + pairs per landmark | edge indices | block table | empty group descriptors
         {
             const int g1 = (int)grid1((size_t)L + 1, 256).x, g2 = (int)grid1(E, 256).x, g3 = (int)grid1((size_t)P * P, 256).x;
@@ -4331,11 +4323,11 @@ int ba_upload_graph(se2gpu_ba* h) {
             const int g4 = (int)grid1(ngrp, 256).x;
             hipLaunchKernelGGL(k_plan_init, dim3(g1 + g2 + g3 + g4), dim3(256), 0, st, L, E, P, h->e_lm.p, h->e_kf.p, h->fixed.p,
                                h->lm_ptr.p, h->plan_np.p, h->plan_idx.p, h->blk_a.p, h->blk_b.p, h->blk_odo.p, ngrp, h->grp.p,
-                               g1, g1 + g2, g1 + g2 + g3);
+                               g1, g1 + g2, g1 + g2 + g3, nzp);
         }
         hipLaunchKernelGGL(k_scan_i32, dim3(1), dim3(1024), 0, st, h->plan_np.p, h->plan_base.p, L);   // 20 per thread
         if (O && !h->odo_fallback)
-            hipLaunchKernelGGL(k_plan_odo, grid1(O, 64), dim3(64), 0, st, P, O, h->o_i.p, h->o_j.p, h->blk_odo.p);
+            hipLaunchKernelGGL(k_plan_odo, grid1(O, 64), dim3(64), 0, st, P, O, h->o_i.p, h->o_j.p, h->blk_odo.p, nzp);
         // pose -> edges CSR: edge indices stably sorted by key frame (one pass)
         if (E) SE2_CHECK(radix(h->e_kf.p, h->plan_key0.p, h->plan_idx.p, h->pose_edges.p, (size_t)E, 0, Pb));
         hipLaunchKernelGGL(k_lower_bounds, grid1((size_t)P + 1, 256), dim3(256), 0, st, h->plan_key0.p, E, P, h->pose_ptr.p);
@@ -4345,7 +4337,19 @@ int ba_upload_graph(se2gpu_ba* h) {
         {
             const int g1 = (int)grid1(L, 256).x, g2 = (int)grid1(NP, 256).x;
             hipLaunchKernelGGL(k_plan_pairs2, dim3(g1 + g2), dim3(256), 0, st, L, P, h->lm_ptr.p, h->e_kf.p, h->fixed.p,
-                               h->plan_base.p, h->plan_key0.p, h->plan_st0.p, (int)NP, nblk, g1);
+                               h->plan_base.p, h->plan_key0.p, h->plan_st0.p, (int)NP, nblk, g1, nzp);
+        }
+        if (nd_possible) {   // the pattern goes home now: the host chooses the solver's order while the device sorts the pairs
+            if (nd_sharded) {   // the union of the ranks' patterns: widen to doubles, the run's all-reduce, narrow again
+                SE2_CHECK(h->plan_nzd.reserve((size_t)nblk));
+                hipLaunchKernelGGL(k_pattern_widen, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->plan_nz.p, h->plan_nzd.p, 0);
+                SE2_HIP(hipGetLastError());
+                SE2_CHECK(ba_allreduce(h, h->plan_nzd.p, (size_t)nblk));
+                hipLaunchKernelGGL(k_pattern_widen, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->plan_nz.p, h->plan_nzd.p, 1);
+            }
+            SE2_HIP(hipMemcpyAsync(h->h_plan_nz.p, h->plan_nz.p, (size_t)nblk, hipMemcpyDeviceToHost, st));
+            SE2_HIP(hipEventRecord(h->ev_pat, st));
+            pattern_early = true;
         }
         SE2_CHECK(radix(h->plan_key0.p, h->plan_key1.p, h->plan_st0.p, h->plan_st1.p, NP, 0, qlo));
         SE2_CHECK(radix(h->plan_key1.p, h->plan_key0.p, h->plan_st1.p, h->plan_st0.p, NP, qlo, std::max(qhi, 1)));
@@ -4369,20 +4373,6 @@ int ba_upload_graph(se2gpu_ba* h) {
         SE2_HIP(hipGetLastError());
         SE2_CHECK(h->h_scal.reserve(8 + (size_t)h->world));
         SE2_HIP(hipMemcpyAsync(h->h_scal.p, h->plan_out.p, sizeof(int), hipMemcpyDeviceToHost, st));
-        if (nd_possible) {   // the block pattern for the solver's order comes back with the same synchronisation
-            SE2_CHECK(h->plan_nz.reserve((size_t)nblk));
-            SE2_CHECK(h->h_plan_nz.reserve((size_t)nblk));
-            hipLaunchKernelGGL(k_plan_pattern, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->blk_ptr.p, h->blk_odo.p,
-                               h->plan_nz.p);
-            if (nd_sharded) {   // the union of the ranks' patterns: widen to doubles, the run's all-reduce, narrow again
-                SE2_CHECK(h->plan_nzd.reserve((size_t)nblk));
-                hipLaunchKernelGGL(k_pattern_widen, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->plan_nz.p, h->plan_nzd.p, 0);
-                SE2_HIP(hipGetLastError());
-                SE2_CHECK(ba_allreduce(h, h->plan_nzd.p, (size_t)nblk));
-                hipLaunchKernelGGL(k_pattern_widen, grid1((size_t)nblk, 256), dim3(256), 0, st, nblk, h->plan_nz.p, h->plan_nzd.p, 1);
-            }
-            SE2_HIP(hipMemcpyAsync(h->h_plan_nz.p, h->plan_nz.p, (size_t)nblk, hipMemcpyDeviceToHost, st));
-        }
         lap("plan kernels enqueued");
     }
     // measurements and information matrices (with a local graph the information is evaluated on the device: big_end stops in
@@ -4414,14 +4404,11 @@ int ba_upload_graph(se2gpu_ba* h) {
     h->lms = h->lms_a.p; h->lms_t = h->lms_b.p;
     SE2_HIP(hipMemcpyAsync(h->poses, h->poses0.p, (size_t)ps * P * 8, hipMemcpyDeviceToDevice, st));
     if (L) SE2_HIP(hipMemcpyAsync(h->lms, h->lms0.p, 3 * (size_t)L * 8, hipMemcpyDeviceToDevice, st));
-    SE2_HIP(hipStreamSynchronize(st));
-    if (device_plan) {
-        int nwg = 0;
-        std::memcpy(&nwg, h->h_scal.p, sizeof(int));
-        SE2_REQUIRE(nwg <= h->grp_cap_wg, SE2GPU_ERR_CAPACITY, "device plan: %d workgroups exceed the bound %d", nwg, h->grp_cap_wg);
-        h->nwg_off = std::max(nwg, 1);
-    }
-    lap("synchronise");
+    // the host waits for the block pattern only (it left the device in front of the pair sorts) and plans the solve while the
+    // device finishes the plan and the copy engine the measurements; everything is waited for at the end
+    if (pattern_early) SE2_HIP(hipEventSynchronize(h->ev_pat));
+    else SE2_HIP(hipStreamSynchronize(st));
+    lap(pattern_early ? "pattern" : "synchronise");
     // ---- the dense pose solve: order of the poses, tile tasks, dependency lists (solve_plan_choose), then its buffers
     {
         std::vector<uint8_t> pat;
@@ -4439,13 +4426,15 @@ int ba_upload_graph(se2gpu_ba* h) {
         h->nsys = sp.nsys;
         h->solve_depth = sp.depth;
         h->chol_ntask = (int)sp.tasks.size();
-        {   // tasks | dependency lists | pose_off | col_src: through the (now idle) pinned arena, one copy
+        {   // tasks | dependency lists | pose_off | col_src: one copy, through a pinned buffer of their own
             auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
             const size_t b0 = up(sp.tasks.size() * sizeof(int4)), b1 = up(std::max<size_t>(sp.deps.size(), 1) * 4);
             const size_t b2 = sp.permuted ? up(sp.pose_off.size() * 4) : 0, b3 = sp.permuted ? up(sp.col_src.size() * 4) : 0;
-            SE2_CHECK(h->h_stage.reserve(b0 + b1 + b2 + b3));
-            SE2_CHECK(h->solver_arena.reserve(b0 + b1 + b2 + b3));
-            uint8_t* hp = h->h_stage.p;
+            // (at least 1 MB each: the lists of the next window differ in length, and growing a pinned or a device buffer
+            // costs more than a whole initialize - seen as +0.25 ms on the first window after se2gpu_ba_reserve)
+            SE2_CHECK(h->h_stage_solver.reserve(std::max<size_t>(b0 + b1 + b2 + b3, (size_t)1 << 20)));
+            SE2_CHECK(h->solver_arena.reserve(std::max<size_t>(b0 + b1 + b2 + b3, (size_t)1 << 20)));
+            uint8_t* hp = h->h_stage_solver.p;
             std::memcpy(hp, sp.tasks.data(), sp.tasks.size() * sizeof(int4));
             std::memcpy(hp + b0, sp.deps.data(), sp.deps.size() * 4);
             if (sp.permuted) {
@@ -4496,6 +4485,14 @@ int ba_upload_graph(se2gpu_ba* h) {
         }
         lap("solve plan");
     }
+    SE2_HIP(hipStreamSynchronize(st));
+    if (device_plan) {
+        int nwg = 0;
+        std::memcpy(&nwg, h->h_scal.p, sizeof(int));
+        SE2_REQUIRE(nwg <= h->grp_cap_wg, SE2GPU_ERR_CAPACITY, "device plan: %d workgroups exceed the bound %d", nwg, h->grp_cap_wg);
+        h->nwg_off = std::max(nwg, 1);
+    }
+    lap("synchronise");
     // the borrow of se2gpu_ba_load ends here: everything has been copied into the pinned arena and uploaded
     h->bulk_E = 0;
     h->bulk_kf = h->bulk_lm = nullptr;
