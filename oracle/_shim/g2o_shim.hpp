@@ -1,7 +1,7 @@
 // ORACLE - TEST INFRASTRUCTURE ONLY (oracle/_ref).  Never compiled into, linked with or loaded by the product path.
 //
 // A stand-in for the Eigen 3 and g2o (tag 20160424_git) headers that /root/reference/src/EdgeSE2XYZ.cpp, src/optimizer.cpp,
-// src/converter.cpp and include/se2lam/{EdgeSE2XYZ,optimizer,converter}.h include, just large enough for those files to compile
+// src/converter.cpp, src/sparsifier.cpp and include/se2lam/{EdgeSE2XYZ,optimizer,converter,sparsifier}.h include, just large enough for those files to compile
 // UNMODIFIED (oracle/Makefile, target `ref`): fixed-size matrices with comma initialisers, blocks, transposes and products;
 // AngleAxis / Quaternion / Rotation2D / Isometry3d; g2o's SE2, SE3Quat (product, inverse, map, log, adj), CameraParameters::cam_map,
 // internal::toEuler / toSE3Quat / fromSE3Quat, skew, Huber's rho, and a RECORDING graph - vertices with id / fixed /
@@ -10,15 +10,19 @@
 // pins with it is what se2lam WROTE - the residual and the analytic Jacobians of EdgeSE2XYZ (src/EdgeSE2XYZ.cpp:61-106),
 // SE2ToSE3 / SE3ToSE2 / d_inv_d_se2 (:16-39), PreEdgeSE2 (include/se2lam/EdgeSE2XYZ.h:62-102), and all of src/optimizer.cpp:
 // what each add* call puts into the graph, the plane-motion priors, EdgeSE3ExpmapPrior, the information reordering of
-// addEdgeSE3Expmap, Jl / invJl / invJJl - evaluated through the reference's own statements.  The library formulas
+// addEdgeSE3Expmap, Jl / invJl / invJJl - and all of src/sparsifier.cpp (numeric Jacobians, marginalisation, InfoSE3 with its
+// SVD clamp; MatrixXd, LDL', inverse() and JacobiSVD below are plain exact solvers, not Eigen's algorithms) - evaluated
+// through the reference's own statements.  The library formulas
 // underneath (quaternion from angle-axis / matrix, q * v, SE3Quat's product / inverse / map / log / adj, cam_map, toEuler) are
 // written here from the published Eigen / g2o sources; g2o's own edge types (EdgeSE3Expmap, EdgeProjectXYZ2UV, EdgeSE3,
 // EdgeSE3Prior, EdgeSE3PointXYZ) are recorded, not evaluated; the block solver, Levenberg-Marquardt and CHOLMOD are empty
 // types: nothing is ever optimised here.
 #pragma once
 #include <cmath>
+#include <algorithm>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <vector>
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -43,13 +47,21 @@ public:
     Matrix<T, BR, BC> operator-() const { return -Matrix<T, BR, BC>(*this); }   // (Matrix has the converting constructor)
 };
 
+class MatrixXd;
+template <typename T> using aligned_allocator = std::allocator<T>;
+enum { ComputeFullU = 1, ComputeFullV = 2 };
+
 // view of a run-time sized block (m.block(r, c, nr, nc)); M may be const
 template <typename M> class DynBlock {
     M& m;
     int r0, c0, nr, nc;
 public:
     DynBlock(M& m_, int r, int c, int nr_, int nc_) : m(m_), r0(r), c0(c), nr(nr_), nc(nc_) {}
+    int rows() const { return nr; }
+    int cols() const { return nc; }
     double operator()(int r, int c) const { return m(r0 + r, c0 + c); }
+    template <typename Src> DynBlock& operator+=(const Src& s) { for (int r = 0; r < nr; ++r) for (int c = 0; c < nc; ++c) m(r0 + r, c0 + c) += s(r, c); return *this; }
+    DynBlock& operator=(const MatrixXd& o);      // below
     template <typename Src> DynBlock& assign(const Src& s) { for (int r = 0; r < nr; ++r) for (int c = 0; c < nc; ++c) m(r0 + r, c0 + c) = s(r, c); return *this; }
     template <typename T, int R, int C> DynBlock& operator=(const Matrix<T, R, C>& v) { return assign(v); }
     template <typename M2> DynBlock& operator=(const DynBlock<M2>& o) { return assign(o); }
@@ -82,6 +94,28 @@ public:
     CommaInit<T, R, C> operator<<(T first) { return CommaInit<T, R, C>(*this, first); }
     void setZero() { for (T& v : d) v = T(0); }
     void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = T(1); }
+    Matrix(const MatrixXd& o);                   // below (sizes must agree)
+    int rows() const { return R; }
+    int cols() const { return C; }
+    DynBlock<Matrix> col(int c) { return DynBlock<Matrix>(*this, 0, c, R, 1); }
+    Matrix inverse() const {                     // Gauss-Jordan with partial pivoting (Eigen: PartialPivLU; both exact solvers)
+        static_assert(R == C, "square");
+        Matrix a(*this), b = Identity();
+        for (int k = 0; k < R; ++k) {
+            int p = k;
+            for (int r = k + 1; r < R; ++r) if (std::fabs(a(r, k)) > std::fabs(a(p, k))) p = r;
+            if (p != k) for (int c = 0; c < C; ++c) { std::swap(a(k, c), a(p, c)); std::swap(b(k, c), b(p, c)); }
+            const T inv = T(1) / a(k, k);
+            for (int c = 0; c < C; ++c) { a(k, c) *= inv; b(k, c) *= inv; }
+            for (int r = 0; r < R; ++r) {
+                if (r == k) continue;
+                const T f = a(r, k);
+                if (f == T(0)) continue;
+                for (int c = 0; c < C; ++c) { a(r, c) -= f * a(k, c); b(r, c) -= f * b(k, c); }
+            }
+        }
+        return b;
+    }
     static Matrix Zero() { return Matrix(); }
     static Matrix Zero(int, int) { return Matrix(); }
     DynBlock<Matrix> block(int r, int c, int nr, int nc) { return DynBlock<Matrix>(*this, r, c, nr, nc); }
@@ -117,12 +151,125 @@ template <typename T, int R, int K, int C> Matrix<T, R, C> operator*(const Matri
 }
 template <typename T, int R, int C> Matrix<T, R, C> operator*(const Matrix<T, R, C>& a, T s) { Matrix<T, R, C> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = a(r, c) * s; return m; }
 template <typename T, int R, int C> Matrix<T, R, C> operator*(T s, const Matrix<T, R, C>& a) { return a * s; }
+template <typename T, int R, int C> Matrix<T, R, C> operator/(const Matrix<T, R, C>& a, T s) { Matrix<T, R, C> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = a(r, c) / s; return m; }
+template <typename T, int R, int C> Matrix<T, R, C> operator/(const Matrix<T, R, C>& a, int s) { return a / T(s); }
 
 typedef Matrix<double, 2, 1> Vector2d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 2, 2> Matrix2d;
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<double, 4, 4> Matrix4d;
+
+// Eigen::MatrixXd: what src/sparsifier.cpp does with it - Zero / Identity, blocks, products, differences, ldlt().solve()
+class LDLTXd;
+class MatrixXd {
+    int nr = 0, nc = 0;
+    std::vector<double> d;
+public:
+    MatrixXd() {}
+    MatrixXd(int r, int c) : nr(r), nc(c), d((size_t)r * c, 0.0) {}
+    template <typename M> MatrixXd(const DynBlock<M>& b) : nr(b.rows()), nc(b.cols()), d((size_t)nr * nc) { for (int r = 0; r < nr; ++r) for (int c = 0; c < nc; ++c) (*this)(r, c) = b(r, c); }
+    template <typename T, int R, int C> MatrixXd(const Matrix<T, R, C>& m) : nr(R), nc(C), d((size_t)R * C) { for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) (*this)(r, c) = m(r, c); }
+    int rows() const { return nr; }
+    int cols() const { return nc; }
+    double& operator()(int r, int c) { return d[(size_t)r * nc + c]; }
+    double operator()(int r, int c) const { return d[(size_t)r * nc + c]; }
+    static MatrixXd Zero(int r, int c) { return MatrixXd(r, c); }
+    static MatrixXd Identity(int r, int c) { MatrixXd m(r, c); for (int i = 0; i < std::min(r, c); ++i) m(i, i) = 1.0; return m; }
+    DynBlock<MatrixXd> block(int r, int c, int br, int bc) { return DynBlock<MatrixXd>(*this, r, c, br, bc); }
+    DynBlock<const MatrixXd> block(int r, int c, int br, int bc) const { return DynBlock<const MatrixXd>(*this, r, c, br, bc); }
+    MatrixXd operator*(double s) const { MatrixXd m(*this); for (double& v : m.d) v *= s; return m; }
+    MatrixXd operator*(const MatrixXd& o) const {
+        MatrixXd m(nr, o.nc);
+        for (int r = 0; r < nr; ++r) for (int c = 0; c < o.nc; ++c) { double s = 0; for (int k = 0; k < nc; ++k) s += (*this)(r, k) * o(k, c); m(r, c) = s; }
+        return m;
+    }
+    MatrixXd operator-(const MatrixXd& o) const { MatrixXd m(*this); for (size_t i = 0; i < d.size(); ++i) m.d[i] -= o.d[i]; return m; }
+    LDLTXd ldlt() const;
+};
+template <typename M> DynBlock<M>& DynBlock<M>::operator=(const MatrixXd& o) { return assign(o); }
+template <typename T, int R, int C> Matrix<T, R, C>::Matrix(const MatrixXd& o) { for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) d[r * C + c] = o(r, c); }
+
+// H22.ldlt().solve(H21): an exact solver of a symmetric positive definite system.  Eigen's LDLT pivots on the diagonal;
+// this one is the plain Cholesky LDL' without pivoting - the two agree to round-off on the matrices the reference solves
+// (block diagonal 3x3 sums of J' info J with a positive definite information)
+class LDLTXd {
+    MatrixXd L;
+    std::vector<double> D;
+public:
+    explicit LDLTXd(const MatrixXd& A) : L(A.rows(), A.cols()), D(A.rows(), 0.0) {
+        const int n = A.rows();
+        for (int j = 0; j < n; ++j) {
+            double dj = A(j, j);
+            for (int k = 0; k < j; ++k) dj -= L(j, k) * L(j, k) * D[k];
+            D[j] = dj;
+            L(j, j) = 1.0;
+            for (int i = j + 1; i < n; ++i) {
+                double v = A(i, j);
+                for (int k = 0; k < j; ++k) v -= L(i, k) * L(j, k) * D[k];
+                L(i, j) = v / dj;
+            }
+        }
+    }
+    MatrixXd solve(const MatrixXd& B) const {
+        const int n = L.rows(), m = B.cols();
+        MatrixXd X(B);
+        for (int c = 0; c < m; ++c) {
+            for (int i = 0; i < n; ++i) { double v = X(i, c); for (int k = 0; k < i; ++k) v -= L(i, k) * X(k, c); X(i, c) = v; }
+            for (int i = 0; i < n; ++i) X(i, c) /= D[i];
+            for (int i = n - 1; i >= 0; --i) { double v = X(i, c); for (int k = i + 1; k < n; ++k) v -= L(k, i) * X(k, c); X(i, c) = v; }
+        }
+        return X;
+    }
+};
+inline LDLTXd MatrixXd::ldlt() const { return LDLTXd(*this); }
+
+// Eigen::JacobiSVD<MatrixXd>(A, ComputeFullU | ComputeFullV) of a square matrix: one-sided Jacobi (Hestenes) on the columns -
+// A V = U S with orthogonal V, singular values sorted in decreasing order like Eigen's.  (Eigen's is two-sided; an SVD is
+// unique up to the joint sign of a pair (u_i, v_i) and the basis inside a repeated singular value, neither of which the
+// reference's use - sign of u_i . v_i, U S V' - can see.)
+template <typename MatType> class JacobiSVD {
+    MatrixXd U_, V_, S_;
+public:
+    template <typename M> JacobiSVD(const M& A, unsigned = 0) {
+        const int n = A.rows();
+        MatrixXd W(n, n), V = MatrixXd::Identity(n, n);
+        for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) W(r, c) = A(r, c);
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0;
+            for (int p = 0; p < n; ++p)
+                for (int q = p + 1; q < n; ++q) {
+                    double a = 0, b = 0, g = 0;
+                    for (int r = 0; r < n; ++r) { a += W(r, p) * W(r, p); b += W(r, q) * W(r, q); g += W(r, p) * W(r, q); }
+                    if (g == 0 || std::fabs(g) <= 1e-300) continue;
+                    off = std::max(off, std::fabs(g) / std::sqrt(a * b));
+                    const double zeta = (b - a) / (2 * g);
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+                    const double cs = 1 / std::sqrt(1 + t * t), sn = cs * t;
+                    for (int r = 0; r < n; ++r) {
+                        const double wp = W(r, p), wq = W(r, q);
+                        W(r, p) = cs * wp - sn * wq; W(r, q) = sn * wp + cs * wq;
+                        const double vp = V(r, p), vq = V(r, q);
+                        V(r, p) = cs * vp - sn * vq; V(r, q) = sn * vp + cs * vq;
+                    }
+                }
+            if (off < 1e-15) break;
+        }
+        std::vector<double> sv(n);
+        std::vector<int> order(n);
+        for (int c = 0; c < n; ++c) { double a = 0; for (int r = 0; r < n; ++r) a += W(r, c) * W(r, c); sv[c] = std::sqrt(a); order[c] = c; }
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sv[x] > sv[y]; });
+        U_ = MatrixXd(n, n); V_ = MatrixXd(n, n); S_ = MatrixXd(n, 1);
+        for (int k = 0; k < n; ++k) {
+            const int c = order[k];
+            S_(k, 0) = sv[c];
+            for (int r = 0; r < n; ++r) { U_(r, k) = sv[c] > 0 ? W(r, c) / sv[c] : (r == k ? 1.0 : 0.0); V_(r, k) = V(r, c); }
+        }
+    }
+    const MatrixXd& singularValues() const { return S_; }
+    const MatrixXd& matrixU() const { return U_; }
+    const MatrixXd& matrixV() const { return V_; }
+};
 
 class Quaterniond;
 class AngleAxisd {
@@ -317,6 +464,19 @@ public:
         return ret;
     }
     Vector3D map(const Vector3D& xyz) const { return _r * xyz + _t; }
+    Vector3D operator*(const Vector3D& v) const { return _t + _r * v; }
+    Vector6d toMinimalVector() const {            // (translation, q_x, q_y, q_z)
+        Vector6d v;
+        v[0] = _t(0); v[1] = _t(1); v[2] = _t(2);
+        v[3] = _r.x(); v[4] = _r.y(); v[5] = _r.z();
+        return v;
+    }
+    void fromMinimalVector(const Vector6d& v) {
+        const double w = 1. - v[3] * v[3] - v[4] * v[4] - v[5] * v[5];
+        if (w > 0) _r = Eigen::Quaterniond(std::sqrt(w), v[3], v[4], v[5]);
+        else _r = Eigen::Quaterniond(0, -v[3], -v[4], -v[5]);
+        _t = Vector3D(v[0], v[1], v[2]);
+    }
     Vector6d log() const {   // (rotation, translation)
         Vector6d res;
         const Matrix3D _R = _r.toRotationMatrix();

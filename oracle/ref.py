@@ -344,3 +344,39 @@ def window_chi2(g, K=None):
               e_uv.ctypes.data, e_info.ctypes.data, g.O, o_i.ctypes.data, o_j.ctypes.data, o_meas.ctypes.data, o_info.ctypes.data,
               K.ctypes.data, tb.ctypes.data, float(g.huber), chi_e.ctypes.data, chi_o.ctypes.data, counts.ctypes.data)
     return float(total), chi_e[:g.E], chi_o[:g.O], tuple(int(c) for c in counts)
+
+
+# ---- src/sparsifier.cpp (whole file)
+def sparsify(kf, mp, m_kf, m_mp, m_info):
+    """Sparsifier::DoMarginalizeSE3XYZ -> (z_out 4x4 = KF0^-1 KF1, info_out 6x6); same arguments as oracle.sparsify"""
+    k = np.ascontiguousarray(np.concatenate([_pose12(kf[0]), _pose12(kf[1])]))
+    mp = np.ascontiguousarray(mp, np.float64); mk = np.ascontiguousarray(m_kf, np.int32); mm = np.ascontiguousarray(m_mp, np.int32)
+    mi = np.ascontiguousarray(m_info, np.float64).reshape(-1, 9)
+    z = np.zeros(12); info = np.zeros(36)
+    f = lib().ref_sparsify
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(k.ctypes.data, len(mp), mp.ctypes.data, len(mk), mk.ctypes.data, mm.ctypes.data, mi.ctypes.data, z.ctypes.data, info.ctypes.data)
+    return _mat44(z), info.reshape(6, 6)
+
+
+def sparsify_hessian(kf, mp, info):
+    """Sparsifier::JacobianSE3XYZ / HessianSE3XYZ of one measurement -> (J 3x9, H 9x9)"""
+    k = _pose12(kf); p = np.ascontiguousarray(mp, np.float64); w = np.ascontiguousarray(info, np.float64).reshape(-1)
+    J = np.zeros(27); H = np.zeros(81)
+    f = lib().ref_sparsify_hessian
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 5
+    f(k.ctypes.data, p.ctypes.data, w.ctypes.data, J.ctypes.data, H.ctypes.data)
+    return J.reshape(3, 9), H.reshape(9, 9)
+
+
+def sparsify_info_se3(kf, H):
+    """Sparsifier::InfoSE3 on a given 12x12 marginal Hessian -> 6x6"""
+    k = np.ascontiguousarray(np.concatenate([_pose12(kf[0]), _pose12(kf[1])]))
+    Hm = np.ascontiguousarray(H, np.float64).reshape(-1); out = np.zeros(36)
+    f = lib().ref_sparsify_info_se3
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(k.ctypes.data, Hm.ctypes.data, out.ctypes.data)
+    return out.reshape(6, 6)

@@ -13,6 +13,7 @@
 //   se2lam::addCamPara / addVertexSE2 / addVertexSBAXYZ / addEdgeSE2 / addEdgeSE2XYZ / addVertexSE3Expmap / addEdgeSE3Expmap /
 //   addPlaneMotionSE3Expmap / addVertexSE3PlaneMotion / EdgeSE3ExpmapPrior / Jl / invJl / invJJl / verifyInfo and
 //   toSE3Quat / toIsometry3D / toCvMat                         src/optimizer.cpp, src/converter.cpp (whole files)
+//   Sparsifier::DoMarginalizeSE3XYZ / HessianSE3XYZ / JacobianSE3XYZ / InfoSE3 / JacobianSE3      src/sparsifier.cpp (whole file)
 // against oracle/_shim (a stand-in for the OpenCV / ROS headers, and stubs of KeyFrame / MapPoint with the members the
 // matcher reads).  What this library pins is the se2lam-owned logic; the OpenCV arithmetic underneath is the shim's.
 // The signatures mirror oracle/orb_ref.cpp and oracle/match_ref.cpp so that tests call either through the same wrapper.
@@ -28,6 +29,7 @@
 #include "converter.h"
 #include "cvutil.h"
 #include "optimizer.h"
+#include "sparsifier.h"
 
 using namespace se2lam;
 
@@ -436,4 +438,48 @@ double ref_window_chi2(int P, const double* poses, const uint8_t* fixed, int L, 
     return total;
 }
 
+}  // extern "C"
+
+// ---- src/sparsifier.cpp
+extern "C" {
+// Sparsifier::DoMarginalizeSE3XYZ (src/sparsifier.cpp:105-177): kf = two poses T_w_c as (R row-major, t), N map points, M
+// measurements (key frame 0 / 1 - others are ignored by the reference -, map point id, 3x3 information) -> z_out (R, t), info_out 6x6
+void ref_sparsify(const double* kf24, int N, const double* mp, int M, const int32_t* m_kf, const int32_t* m_mp, const double* m_info9,
+                  double* z12, double* info36) {
+    std::vector<g2o::SE3Quat, Eigen::aligned_allocator<g2o::SE3Quat>> vKF{quat12(kf24), quat12(kf24 + 12)};
+    std::vector<g2o::Vector3D, Eigen::aligned_allocator<g2o::Vector3D>> vMP;
+    for (int i = 0; i < N; ++i) vMP.push_back(g2o::Vector3D(mp[3 * i], mp[3 * i + 1], mp[3 * i + 2]));
+    std::vector<MeasSE3XYZ, Eigen::aligned_allocator<MeasSE3XYZ>> vMeas((size_t)M);
+    for (int k = 0; k < M; ++k) {
+        vMeas[k].idKF = m_kf[k];
+        vMeas[k].idMP = m_mp[k];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) vMeas[k].info(r, c) = m_info9[9 * k + 3 * r + c];
+    }
+    g2o::SE3Quat z;
+    g2o::Matrix6d info;
+    Sparsifier::DoMarginalizeSE3XYZ(vKF, vMP, vMeas, z, info);
+    put12(z.rotation().toRotationMatrix(), z.translation(), z12);
+    put36(info, info36);
+}
+// Sparsifier::HessianSE3XYZ (:95-102) with its forward-difference Jacobian (:59-93): J 3x9, H 9x9
+void ref_sparsify_hessian(const double* kf12, const double* mp3, const double* info9, double* J27, double* H81) {
+    const g2o::SE3Quat KF = quat12(kf12);
+    const g2o::Vector3D MP(mp3[0], mp3[1], mp3[2]);
+    g2o::Matrix3D info;
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) info(r, c) = info9[3 * r + c];
+    Eigen::Matrix<double, 3, 9> J;
+    Eigen::Matrix<double, 9, 9> H;
+    Sparsifier::JacobianSE3XYZ(KF, MP, J);
+    Sparsifier::HessianSE3XYZ(KF, MP, info, H);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 9; ++c) J27[9 * r + c] = J(r, c);
+    for (int r = 0; r < 9; ++r) for (int c = 0; c < 9; ++c) H81[9 * r + c] = H(r, c);
+}
+// Sparsifier::InfoSE3 (:219-275) on a given 12x12 marginal Hessian
+void ref_sparsify_info_se3(const double* kf24, const double* H144, double* I36) {
+    Eigen::Matrix<double, 12, 12> H;
+    for (int r = 0; r < 12; ++r) for (int c = 0; c < 12; ++c) H(r, c) = H144[12 * r + c];
+    Eigen::Matrix<double, 6, 6> I;
+    Sparsifier::InfoSE3(quat12(kf24), quat12(kf24 + 12), H, I);
+    put36(I, I36);
+}
 }  // extern "C"

@@ -1,5 +1,8 @@
-// ORACLE - TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED (g2o / Eigen absent): a restatement, checked
-// against an analytic numpy model in tests/test_sparsify.py.
+// ORACLE - TEST INFRASTRUCTURE ONLY.  PARITY: pinned against the reference's own src/sparsifier.cpp, compiled unmodified in
+// oracle/_ref against a stand-in for the Eigen / g2o headers (tests/test_ref_compiled.py: relative pose bit-identical, InfoSE3
+// on the same marginal Hessian to 1e-12, the marginal Hessian from the reference's per-measurement Hessians to 1e-12, end to
+// end to 1e-5 - the construction's condition number is 1e15); also checked against an analytic numpy model
+// (tests/test_sparsify.py).  The Eigen solvers underneath (LDLT, inverse, JacobiSVD) are the stand-in's, not the library's.
 //
 // Sparsifier::DoMarginalizeSE3XYZ (/root/reference/src/sparsifier.cpp:105-177) - SURVEY.md section 8(f).4: the feature
 // constraint between two key frames.  Two key frames KF (T_w_c as g2o::SE3Quat), the N map points both observe, and
