@@ -110,6 +110,13 @@ typedef Point3_<float> Point3f;
 typedef Point3_<double> Point3d;
 template <typename T> inline Point3_<T> operator+(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
 template <typename T> inline Point3_<T> operator-(const Point3_<T>& a, const Point3_<T>& b) { return Point3_<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+// (OpenCV: saturate_cast<T> of the product in the scalar's precision; for float points saturate_cast is a plain conversion)
+template <typename T> inline Point3_<T> operator*(const Point3_<T>& a, float s) { return Point3_<T>((T)(a.x * s), (T)(a.y * s), (T)(a.z * s)); }
+template <typename T> inline Point3_<T> operator*(const Point3_<T>& a, double s) { return Point3_<T>((T)(a.x * s), (T)(a.y * s), (T)(a.z * s)); }
+template <typename T> inline Point3_<T> operator*(const Point3_<T>& a, int s) { return Point3_<T>((T)(a.x * s), (T)(a.y * s), (T)(a.z * s)); }
+template <typename T> inline Point3_<T> operator*(float s, const Point3_<T>& a) { return a * s; }
+template <typename T> inline Point3_<T> operator*(double s, const Point3_<T>& a) { return a * s; }
+class SparseMat {};   // Map.h holds two of them; nothing on the compiled path touches them
 
 template <typename T> struct Rect_ {
     T x, y, width, height;

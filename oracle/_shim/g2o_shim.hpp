@@ -23,6 +23,7 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <type_traits>
 #include <vector>
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -95,6 +96,7 @@ public:
     void setZero() { for (T& v : d) v = T(0); }
     void setIdentity() { setZero(); for (int i = 0; i < (R < C ? R : C); ++i) (*this)(i, i) = T(1); }
     Matrix(const MatrixXd& o);                   // below (sizes must agree)
+    explicit Matrix(const T* p) { for (int i = 0; i < R * C; ++i) d[i] = p[i]; }   // (vectors: Vector3D(meas.meas))
     int rows() const { return R; }
     int cols() const { return C; }
     DynBlock<Matrix> col(int c) { return DynBlock<Matrix>(*this, 0, c, R, 1); }
@@ -151,6 +153,11 @@ template <typename T, int R, int K, int C> Matrix<T, R, C> operator*(const Matri
 }
 template <typename T, int R, int C> Matrix<T, R, C> operator*(const Matrix<T, R, C>& a, T s) { Matrix<T, R, C> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = a(r, c) * s; return m; }
 template <typename T, int R, int C> Matrix<T, R, C> operator*(T s, const Matrix<T, R, C>& a) { return a * s; }
+// a scalar of another arithmetic type (float, int): converted to the matrix's scalar first, as Eigen's scalar promotion does
+template <typename T, int R, int C, typename S, typename std::enable_if<std::is_arithmetic<S>::value && !std::is_same<S, T>::value, int>::type = 0>
+Matrix<T, R, C> operator*(const Matrix<T, R, C>& a, S s) { return a * T(s); }
+template <typename T, int R, int C, typename S, typename std::enable_if<std::is_arithmetic<S>::value && !std::is_same<S, T>::value, int>::type = 0>
+Matrix<T, R, C> operator*(S s, const Matrix<T, R, C>& a) { return a * T(s); }
 template <typename T, int R, int C> Matrix<T, R, C> operator/(const Matrix<T, R, C>& a, T s) { Matrix<T, R, C> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = a(r, c) / s; return m; }
 template <typename T, int R, int C> Matrix<T, R, C> operator/(const Matrix<T, R, C>& a, int s) { return a / T(s); }
 
@@ -159,6 +166,18 @@ typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 2, 2> Matrix2d;
 typedef Matrix<double, 3, 3> Matrix3d;
 typedef Matrix<double, 4, 4> Matrix4d;
+
+// Eigen::Map<Matrix3d, Options>(ptr): the second template argument of Eigen::Map is the ALIGNMENT option, not a storage
+// order - Map<Matrix3d, RowMajor> (src/Map.cpp:951) therefore views the array in Matrix3d's own column-major order
+enum { ColMajor = 0, RowMajor = 1 };
+template <typename M, int Options = 0> class Map {
+    const double* p;
+public:
+    explicit Map(const double* p_) : p(p_) {}
+    M eval() const { M m; for (int r = 0; r < M::RowsAtCompileTime; ++r) for (int c = 0; c < M::ColsAtCompileTime; ++c) m(r, c) = p[c * M::RowsAtCompileTime + r]; return m; }
+    M inverse() const { return eval().inverse(); }
+    double operator()(int r, int c) const { return p[c * M::RowsAtCompileTime + r]; }
+};
 
 // Eigen::MatrixXd: what src/sparsifier.cpp does with it - Zero / Identity, blocks, products, differences, ldlt().solve()
 class LDLTXd;
@@ -739,6 +758,7 @@ public:
     bool verbose() const { return _verbose; }
     bool hasAlgorithm() const { return _algorithm != nullptr; }
     const std::vector<OptimizableGraph::Edge*>& edges() const { return _edges; }
+    const std::map<int, OptimizableGraph::Vertex*>& vertices() const { return _vertices; }
     const std::vector<Parameter*>& parameters() const { return _parameters; }
 };
 

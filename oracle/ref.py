@@ -380,3 +380,109 @@ def sparsify_info_se3(kf, H):
     f.argtypes = [C.c_void_p] * 3
     f(k.ctypes.data, Hm.ctypes.data, out.ctypes.data)
     return out.reshape(6, 6)
+
+
+# ---- the MAP build (libse2lam_ref_map.so): src/Map.cpp, src/KeyFrame.cpp, src/MapPoint.cpp with the reference's own headers
+LIB_MAP = os.path.join(HERE, "_ref", "libse2lam_ref_map.so")
+_map_lib = None
+
+
+def lib_map() -> C.CDLL:
+    global _map_lib
+    if _map_lib is None:
+        build()
+        _map_lib = C.CDLL(LIB_MAP)
+    return _map_lib
+
+
+class RefMap:
+    """A se2lam::Map filled through the reference's own KeyFrame / MapPoint / Map calls (oracle/ref_map_driver.cpp)."""
+
+    def __init__(self, K, bTc, huber, xrot_info=1e6, yrot_info=1e6, z_info=1.0, max_level=8, scale_factor=1.2):
+        l = lib_map()
+        l.ref_map_create.restype = C.c_void_p
+        l.ref_map_create.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_int, C.c_float]
+        k = np.ascontiguousarray(K, np.float32).reshape(-1); t = np.ascontiguousarray(bTc, np.float32).reshape(-1)
+        self._h = C.c_void_p(l.ref_map_create(k.ctypes.data, t.ctypes.data, huber, xrot_info, yrot_info, z_info, max_level, scale_factor))
+        self._l = l
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.ref_map_destroy.argtypes = [C.c_void_p]
+            self._l.ref_map_destroy(self._h)
+            self._h = None
+
+    def add_kf(self, id_kf, frame_id, twb, kp_xy=None, kp_octave=None, view_lc=None) -> int:
+        xy = np.ascontiguousarray(np.zeros((0, 2)) if kp_xy is None else kp_xy, np.float32).reshape(-1, 2)
+        n = len(xy)
+        octv = np.ascontiguousarray(np.zeros(n) if kp_octave is None else kp_octave, np.int32)
+        lc = np.ascontiguousarray(np.tile([0.0, 0.0, 1000.0], (n, 1)) if view_lc is None else view_lc, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(twb, np.float32)
+        f = self._l.ref_map_add_kf
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        return f(self._h, int(id_kf), int(frame_id), t.ctypes.data, n, xy.ctypes.data, octv.ctypes.data, lc.ctypes.data)
+
+    def add_mp(self, id_mp, pos) -> int:
+        p = np.ascontiguousarray(pos, np.float32)
+        f = self._l.ref_map_add_mp
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        return f(self._h, int(id_mp), p.ctypes.data)
+
+    def observe(self, kf, mp, ftr):
+        f = self._l.ref_map_observe
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        f(self._h, int(kf), int(mp), int(ftr))
+
+    def covisible(self, a, b):
+        f = self._l.ref_map_covisible
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f(self._h, int(a), int(b))
+
+    def set_odo(self, kf_from, kf_to, meas, cov):
+        m = np.ascontiguousarray(meas, np.float64); c = np.ascontiguousarray(cov, np.float64).reshape(-1)
+        f = self._l.ref_map_set_odo
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        f(self._h, int(kf_from), int(kf_to), m.ctypes.data, c.ctypes.data)
+
+    def kf_pose(self, kf) -> np.ndarray:
+        out = np.zeros(16, np.float32)
+        f = self._l.ref_map_kf_pose
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        f(self._h, int(kf), out.ctypes.data)
+        return out.reshape(4, 4)
+
+    def update_local_graph(self, current_kf, cap_kf=4096, cap_mp=1 << 18):
+        """Map::setCurrentKF + Map::updateLocalGraph -> (mIdKF of the local key frames, of the reference key frames, mId of the local map points)"""
+        lk = np.zeros(cap_kf, np.int32); rk = np.zeros(cap_kf, np.int32); lm = np.zeros(cap_mp, np.int32); cnt = np.zeros(3, np.int32)
+        f = self._l.ref_map_update_local_graph
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        rc = f(self._h, int(current_kf), lk.ctypes.data, rk.ctypes.data, lm.ctypes.data, cap_kf, cap_mp, cnt.ctypes.data)
+        assert rc == 0, cnt
+        return lk[:cnt[0]].copy(), rk[:cnt[1]].copy(), lm[:cnt[2]].copy()
+
+    def load_local_graph(self, cap_v=1 << 18, cap_o=4096, cap_e=1 << 20):
+        """Map::loadLocalGraph(SlamOptimizer&) on the last local graph -> what the recording optimizer holds"""
+        v_id = np.zeros(cap_v, np.int32); v_kind = np.zeros(cap_v, np.int32); v_est = np.zeros((cap_v, 3)); v_flags = np.zeros(cap_v, np.uint8)
+        o_ids = np.zeros((cap_o, 2), np.int32); o_meas = np.zeros((cap_o, 3)); o_info = np.zeros((cap_o, 9)); o_chi2 = np.zeros(cap_o)
+        e_ids = np.zeros((cap_e, 2), np.int32); e_uv = np.zeros((cap_e, 2)); e_info = np.zeros((cap_e, 4)); e_delta = np.zeros(cap_e); e_chi2 = np.zeros(cap_e)
+        cnt = np.zeros(3, np.int32)
+        f = self._l.ref_map_load_local_graph
+        f.restype = C.c_double
+        VP = C.c_void_p
+        f.argtypes = [VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP]
+        total = f(self._h, cap_v, v_id.ctypes.data, v_kind.ctypes.data, v_est.ctypes.data, v_flags.ctypes.data, cap_o, o_ids.ctypes.data,
+                  o_meas.ctypes.data, o_info.ctypes.data, o_chi2.ctypes.data, cap_e, e_ids.ctypes.data, e_uv.ctypes.data, e_info.ctypes.data,
+                  e_delta.ctypes.data, e_chi2.ctypes.data, cnt.ctypes.data)
+        assert total >= 0, cnt
+        nv, no, ne = (int(c) for c in cnt)
+        return dict(chi2=float(total), v_id=v_id[:nv], v_kind=v_kind[:nv], v_est=v_est[:nv], v_fixed=(v_flags[:nv] & 1).astype(bool),
+                    v_marginalized=(v_flags[:nv] & 2).astype(bool), o_ids=o_ids[:no], o_meas=o_meas[:no], o_info=o_info[:no].reshape(-1, 3, 3),
+                    o_chi2=o_chi2[:no], e_ids=e_ids[:ne], e_uv=e_uv[:ne], e_info=e_info[:ne].reshape(-1, 2, 2), e_delta=e_delta[:ne],
+                    e_chi2=e_chi2[:ne])

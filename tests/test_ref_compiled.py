@@ -524,6 +524,130 @@ def test_sparsifier_ignores_a_third_key_frame_like_the_restatement(oracle, synth
     assert np.array_equal(z0, z1) and np.array_equal(i0, i1)
 
 
+# ---- src/Map.cpp + src/KeyFrame.cpp + src/MapPoint.cpp, compiled with their own headers (libse2lam_ref_map.so)
+def _random_ref_map(rng, K, M, reach):
+    """tests/test_mapview.py's random map, filled into a se2lam::Map through the reference's own calls"""
+    from test_mapview import _random_map
+    kf_id, covisible, kf_obs, mp_id, mp_obs = _random_map(rng, K, M, reach)
+    m = ref.RefMap(np.eye(3), np.eye(4), 2.0)
+    for a in range(K):
+        m.add_kf(int(kf_id[a]), a, [0.0, 0.0, 0.0], np.zeros((len(kf_obs[a]), 2)))
+    for j in range(M):
+        m.add_mp(int(mp_id[j]), [0.0, 0.0, 1000.0])
+    for a in range(K):
+        for f, j in enumerate(kf_obs[a]):
+            m.observe(a, j, f)
+    for a in range(K):
+        for b in covisible[a]:
+            m.covisible(a, b)
+    return m, (kf_id, covisible, kf_obs, mp_id, mp_obs)
+
+
+def test_update_local_graph_of_the_compiled_reference_equals_the_map_view():
+    """Map::updateLocalGraph (src/Map.cpp:285-331) running on real KeyFrame / MapPoint objects - three covisibility hops
+    from the current key frame, getAllObsMPs(false) of the local key frames, every other observer as a reference key frame,
+    the three vectors ordered by mIdKF / mId - against se2gpu_map_update_local_graph on the CSR view of the same map."""
+    from se2lam_amd.mapview import updateLocalGraph
+    rng = np.random.default_rng(17)
+    for K, M, reach in ((6, 40, 2), (40, 500, 3), (90, 1200, 4)):
+        m, view = _random_ref_map(rng, K, M, reach)
+        kf_id, mp_id = view[0], view[3]
+        for cur in (0, K // 2, K - 1):
+            lk_r, rk_r, lm_r = m.update_local_graph(cur)
+            lk, rk, lm = updateLocalGraph(*view, cur, 3)
+            assert kf_id[lk].tolist() == lk_r.tolist() and kf_id[rk].tolist() == rk_r.tolist() and mp_id[lm].tolist() == lm_r.tolist(), (K, cur)
+            assert len(lk_r) >= 1 and not set(lk_r.tolist()) & set(rk_r.tolist())
+
+
+def _reference_window(synth, n_ref):
+    """A 12-key-frame window (tests/test_ba_oracle.py::_info_inputs) as a se2lam::Map: key frames with their key points,
+    octaves and camera-frame points, map points, observations both ways, the odometry chain, a star of covisibility around
+    key frame 0 that leaves the last n_ref key frames outside - they observe local map points and become reference key frames."""
+    from test_ba_oracle import _info_inputs
+    inp, g, level = _info_inputs(synth, 12, 200)
+    K = np.array([[g.fx, 0, g.cx], [0, g.fx, g.cy], [0, 0, 1]], np.float32)
+    bTc = np.eye(4); bTc[:3, :3] = g.Rbc; bTc[:3, 3] = g.tbc
+    huber = np.float32(g.huber)
+    m = ref.RefMap(K, bTc, huber)
+    P, nL = g.P, g.P - n_ref
+    twb = np.c_[inp["twb_xy"], g.poses[:, 2].astype(np.float32)].astype(np.float32)
+    uv32 = g.e_uv.astype(np.float32)
+    frame_id = np.arange(100, 100 + P); frame_id[4] = 50          # Frame::id: the smallest one is local key frame 4
+    ftr = np.zeros(g.E, int); cnt = np.zeros(P, int)
+    for k in range(g.E):
+        ftr[k] = cnt[g.e_kf[k]]; cnt[g.e_kf[k]] += 1
+    for a in range(P):
+        sel = np.nonzero(g.e_kf == a)[0]
+        m.add_kf(10 + a, int(frame_id[a]), twb[a], uv32[sel], level[sel], inp["lc"][sel])
+    for l in range(g.L):
+        m.add_mp(1000 + l, g.lms[l].astype(np.float32))
+    for k in range(g.E):
+        m.observe(int(g.e_kf[k]), int(g.e_lm[k]), int(ftr[k]))
+    for a in range(1, nL):
+        m.covisible(0, a); m.covisible(a, 0)
+    cov = {}
+    for k in range(g.O):
+        i, j = int(g.o_i[k]), int(g.o_j[k])
+        cov[i] = (j, g.o_meas[k], np.linalg.inv(g.o_info[k].reshape(3, 3)))
+        m.set_odo(i, j, *cov[i][1:])
+    return m, dict(g=g, inp=inp, level=level, K=K, huber=huber, twb=twb, uv32=uv32, frame_id=frame_id, nL=nL, odo=cov)
+
+
+@pytest.mark.parametrize("n_ref", [0, 3])
+def test_load_local_graph_of_the_compiled_reference(oracle, synth, n_ref):
+    """Map::loadLocalGraph(SlamOptimizer&) (src/Map.cpp:891-1053), compiled, on a map built with the reference's own calls:
+    the vertex numbering (local key frames, reference key frames, map points from nLocal + nRef + 1), the fixed rule
+    (:900-913, 927, 969), cov^-1 of the pre-integrated odometry (:943-953), and per observation the information
+    Sigma_all^-1 of :1024-1049 - against the restatement (oracle.ba_edge_information, which the device kernel
+    k_edge_information is held to) and, for the whole graph, the restatement's robust cost."""
+    m, w = _reference_window(synth, n_ref)
+    g, inp, nL = w["g"], w["inp"], w["nL"]
+    lk, rk, lm = m.update_local_graph(0)
+    assert lk.tolist() == [10 + a for a in range(nL)] and rk.tolist() == [10 + a for a in range(nL, g.P)]
+    local_mp = sorted(set(int(l) for k, l in zip(g.e_kf, g.e_lm) if k < nL))
+    assert lm.tolist() == [1000 + l for l in local_mp]
+    out = m.load_local_graph()
+    P, maxKFid = g.P, g.P + 1
+    # vertices
+    assert out["v_id"].tolist() == list(range(P)) + [maxKFid + i for i in range(len(local_mp))]
+    assert np.array_equal(out["v_est"][:P], w["twb"].astype(np.float64)) and not out["v_kind"][:P].any() and out["v_kind"][P:].all()
+    assert np.array_equal(out["v_est"][P:], g.lms[local_mp].astype(np.float32).astype(np.float64))
+    fixed = np.zeros(P, bool)
+    if n_ref == 0:
+        fixed[4] = True                                   # the key frame with the smallest Frame::id (:900-913)
+    else:
+        fixed[nL:] = True                                 # reference key frames (:969); no local one is fixed then
+    assert np.array_equal(out["v_fixed"][:P], fixed) and not out["v_fixed"][P:].any()
+    assert out["v_marginalized"][P:].all() and not out["v_marginalized"][:P].any()
+    # odometry edges: local pairs only, information = cov^-1
+    want_odo = [(i, j) for i, (j, _, _) in sorted(w["odo"].items()) if i < nL and j < nL]
+    assert [tuple(x) for x in out["o_ids"].tolist()] == want_odo
+    for (i, j), meas, info in zip(want_odo, out["o_meas"], out["o_info"]):
+        assert np.array_equal(meas, w["odo"][i][1]) and np.allclose(info, np.linalg.inv(w["odo"][i][2]), rtol=1e-11, atol=0)
+    # observation edges: every (key frame, local map point) pair once, measurement, Huber delta, information
+    Rcw = np.stack([m.kf_pose(a)[:3, :3] for a in range(P)]).reshape(P, 9)         # the reference's own float Tcw = cTb * Twb^-1
+    info = oracle.ba_edge_information(**dict(inp, Rcw=Rcw))
+    pos_of = {1000 + l: i for i, l in enumerate(local_mp)}
+    edge_of = {(int(k), maxKFid + pos_of[1000 + int(l)]): e for e, (k, l) in enumerate(zip(g.e_kf, g.e_lm)) if int(l) in set(local_mp)}
+    assert len(out["e_ids"]) == len(edge_of) and len(set(map(tuple, out["e_ids"].tolist()))) == len(edge_of)
+    for ids, uv, W, delta in zip(out["e_ids"].tolist(), out["e_uv"], out["e_info"], out["e_delta"]):
+        e = edge_of[tuple(ids)]
+        assert np.array_equal(uv, w["uv32"][e].astype(np.float64)) and delta == float(w["huber"])
+        assert np.allclose(W, info[e], rtol=1e-10, atol=0), e
+    # the whole graph's robust cost, through the restatement on the same numbers
+    import dataclasses
+    keep = np.array([int(l) in set(local_mp) for l in g.e_lm])
+    remap = np.full(g.L, -1); remap[local_mp] = np.arange(len(local_mp))
+    oi = np.array([i for i, _ in want_odo], np.int32); oj = np.array([j for _, j in want_odo], np.int32)
+    g2 = dataclasses.replace(
+        g, poses=w["twb"].astype(np.float64), fixed=fixed.astype(np.uint8), lms=g.lms[local_mp].astype(np.float32).astype(np.float64),
+        e_kf=g.e_kf[keep].astype(np.int32), e_lm=remap[g.e_lm[keep]].astype(np.int32), e_uv=w["uv32"][keep].astype(np.float64),
+        e_info=np.stack([info[keep][:, 0, 0], info[keep][:, 0, 1], info[keep][:, 1, 1]], axis=1), o_i=oi, o_j=oj,
+        o_meas=np.stack([w["odo"][i][1] for i, _ in want_odo]), o_info=np.stack([np.linalg.inv(w["odo"][i][2]).reshape(-1) for i, _ in want_odo]),
+        huber=float(w["huber"]), poses_true=None, lms_true=None)
+    assert np.isclose(out["chi2"], oracle.ba_chi2(g2), rtol=1e-10, atol=0)
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
@@ -599,3 +723,38 @@ def test_hip_sparsifier_equals_the_compiled_reference(synth):
         assert np.allclose(z, zr, atol=1e-12)
         tol = 1e-4 if case == _SPARSIFY_HARD else 1e-5      # BASELINE's BA tolerance; the hard pair: cond(H_marginal) 5.6e15
         assert np.abs(info - ir).max() <= tol * np.abs(ir).max(), case
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_ref", [0, 3])
+def test_hip_pod_loader_equals_the_compiled_load_local_graph(synth, n_ref):
+    """se2gpu_ba_load_local_graph (vertex numbering, fixed rule, cov^-1, k_edge_information on the device) fed with the flat
+    arrays of the map the compiled reference holds: the robust cost of the loaded graph equals that of the graph
+    Map::loadLocalGraph put into the recording optimizer; the fixed key frames do not move."""
+    from se2lam_amd import optimizer as op
+    m, w = _reference_window(synth, n_ref)
+    g, inp, nL = w["g"], w["inp"], w["nL"]
+    m.update_local_graph(0)
+    out = m.load_local_graph()
+    P = g.P
+    local_mp = sorted(set(int(l) for k, l in zip(g.e_kf, g.e_lm) if k < nL))
+    remap = np.full(g.L, -1); remap[local_mp] = np.arange(len(local_mp))
+    keep = remap[g.e_lm] >= 0
+    order = np.argsort(remap[g.e_lm[keep]], kind="stable")                        # observations grouped by map point
+    Rcw = np.stack([m.kf_pose(a)[:3, :3] for a in range(P)]).reshape(P, 9)
+    odo_to = np.full(nL, -1, np.int32); odo_meas = np.zeros((nL, 3)); odo_cov = np.tile(np.eye(3).reshape(-1), (nL, 1))
+    for i, (j, meas, cov) in w["odo"].items():
+        if i < nL and j < nL:
+            odo_to[i] = j; odo_meas[i] = meas; odo_cov[i] = cov.reshape(-1)
+    pod = op.SlamOptimizer()
+    op.loadLocalGraph(pod, kf_id=w["frame_id"].astype(np.int32), kf_Twb=w["twb"], kf_Rcw=Rcw, n_local=nL, odo_to=odo_to, odo_meas=odo_meas,
+                      odo_cov=odo_cov, mp_pos=g.lms[local_mp].astype(np.float32), obs_mp=remap[g.e_lm[keep]][order], obs_kf=g.e_kf[keep][order],
+                      obs_uv=w["uv32"][keep][order], obs_lc=inp["lc"][keep][order], obs_sigma2=inp["sigma2"][keep][order], K=w["K"], Rbc=g.Rbc,
+                      tbc=g.tbc, huber=w["huber"])
+    pod.initializeOptimization(0)
+    assert np.isclose(pod.activeRobustChi2(), out["chi2"], rtol=1e-9, atol=0)
+    pod.optimize(3)
+    for a in np.nonzero(out["v_fixed"][:P])[0]:
+        assert np.array_equal(op.estimateVertexSE2(pod, int(a)), w["twb"][a].astype(np.float64))
+    moved = [a for a in range(P) if not out["v_fixed"][a] and not np.array_equal(op.estimateVertexSE2(pod, a), w["twb"][a].astype(np.float64))]
+    assert len(moved) == P - int(out["v_fixed"][:P].sum())
