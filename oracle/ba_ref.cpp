@@ -7,7 +7,9 @@
 // their headers unmodified against a stand-in for the Eigen / g2o headers (oracle/_shim/g2o_shim.hpp), and
 // tests/test_ref_compiled.py holds edge_se2xyz / edge_pre_se2 below to their computeError() / linearizeOplus() (1e-11
 // relative), the reduced system assembled from the reference's Jacobians to schur() below (1e-10), robust_chi2() to the cost
-// of a window built with the reference's add* calls (1e-13), and ba_ref_plane_motion_prior to addPlaneMotionSE3Expmap (1e-9).
+// of a window built with the reference's add* calls (1e-13), ba_ref_plane_motion_prior to addPlaneMotionSE3Expmap (1e-9),
+// and ba_ref_edge_information to the information matrices Map::loadLocalGraph (src/Map.cpp, compiled with KeyFrame.cpp and
+// MapPoint.cpp in oracle/_ref/libse2lam_ref_map.so) puts on its edges (1e-10).
 // The SOLVER stays UNPINNED: /root/reference holds no golden vectors, known-answer tests or fixtures
 // for this path, and g2o / Eigen / CHOLMOD are not available in this image, so the Levenberg-Marquardt histories could
 // not be checked against a run of the real reference; they are pinned against scipy instead.
