@@ -23,6 +23,7 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <set>
 #include <type_traits>
 #include <vector>
 
@@ -639,7 +640,14 @@ class Edge : public HyperGraph::Edge {
     RobustKernel* _rk = nullptr;
     int _level = 0;
     std::vector<int> _parameterIds;
+    const std::vector<Parameter*>* _graphParameters = nullptr;   // set by SparseOptimizer::addEdge (g2o: resolveParameters)
 public:
+    void setGraphParameters(const std::vector<Parameter*>* p) { _graphParameters = p; }
+    const Parameter* parameterOf(int argNum) const {
+        if (!_graphParameters) return nullptr;
+        for (const Parameter* p : *_graphParameters) if (p->id() == parameterId(argNum)) return p;
+        return nullptr;
+    }
     explicit Edge(int n) : HyperGraph::Edge(n) {}
     ~Edge() override { delete _rk; }
     void setRobustKernel(RobustKernel* rk) { delete _rk; _rk = rk; }
@@ -708,15 +716,41 @@ public:
     const Eigen::Matrix<double, D, VertexXj::Dimension>& jacobianOplusXj() const { return _jacobianOplusXj; }
 };
 
-// g2o's own edge types that src/optimizer.cpp only constructs and fills in: recorded, not evaluated (their residuals belong to
-// g2o, not to se2lam; the oracle restates them from the published sources)
+// g2o's own edge types that src/optimizer.cpp constructs and fills in.  The two of the SE3-expmap local graph are evaluated
+// too - EdgeProjectXYZ2UV::computeError (types_six_dof_expmap.h: obs - cam_map(T.map(X)) with the camera parameter of id
+// parameterId(0)) and EdgeSE3Expmap::computeError (log(T_1^-1 * measurement * T_0)), from the published g2o sources - so
+// that the cost of a graph Map::loadLocalGraph built can be compared as a whole; the pose-graph types are recorded only.
 #define SE2_SHIM_RECORD_ONLY                                               \
     void computeError() override {}                                        \
     void linearizeOplus() override {}                                      \
     bool read(std::istream&) override { return false; }                    \
     bool write(std::ostream&) const override { return false; }
-class EdgeSE3Expmap : public BaseBinaryEdge<6, SE3Quat, VertexSE3Expmap, VertexSE3Expmap> { public: SE2_SHIM_RECORD_ONLY };
-class EdgeProjectXYZ2UV : public BaseBinaryEdge<2, Vector2D, VertexSBAPointXYZ, VertexSE3Expmap> { public: SE2_SHIM_RECORD_ONLY };
+class EdgeSE3Expmap : public BaseBinaryEdge<6, SE3Quat, VertexSE3Expmap, VertexSE3Expmap> {
+public:
+    void computeError() override {
+        const VertexSE3Expmap* v1 = static_cast<const VertexSE3Expmap*>(_vertices[0]);
+        const VertexSE3Expmap* v2 = static_cast<const VertexSE3Expmap*>(_vertices[1]);
+        const SE3Quat C(_measurement);
+        const SE3Quat error_ = v2->estimate().inverse() * C * v1->estimate();
+        _error = error_.log();
+    }
+    void linearizeOplus() override {}
+    bool read(std::istream&) override { return false; }
+    bool write(std::ostream&) const override { return false; }
+};
+class EdgeProjectXYZ2UV : public BaseBinaryEdge<2, Vector2D, VertexSBAPointXYZ, VertexSE3Expmap> {
+public:
+    void computeError() override {
+        const VertexSE3Expmap* v1 = static_cast<const VertexSE3Expmap*>(_vertices[1]);
+        const VertexSBAPointXYZ* v2 = static_cast<const VertexSBAPointXYZ*>(_vertices[0]);
+        const CameraParameters* cam = dynamic_cast<const CameraParameters*>(parameterOf(0));
+        const Vector2D obs(_measurement);
+        _error = obs - cam->cam_map(v1->estimate().map(v2->estimate()));
+    }
+    void linearizeOplus() override {}
+    bool read(std::istream&) override { return false; }
+    bool write(std::ostream&) const override { return false; }
+};
 class EdgeSE3 : public BaseBinaryEdge<6, Isometry3D, VertexSE3, VertexSE3> { public: SE2_SHIM_RECORD_ONLY };
 class EdgeSE3Prior : public BaseUnaryEdge<6, Isometry3D, VertexSE3> { public: SE2_SHIM_RECORD_ONLY };
 class EdgeSE3PointXYZ : public BaseBinaryEdge<3, Vector3D, VertexSE3, VertexPointXYZ> { public: SE2_SHIM_RECORD_ONLY };
@@ -737,6 +771,7 @@ public:
 class SparseOptimizer {
     std::map<int, OptimizableGraph::Vertex*> _vertices;
     std::vector<OptimizableGraph::Edge*> _edges;
+    std::set<OptimizableGraph::Edge*> _edgeSet;
     std::vector<Parameter*> _parameters;
     OptimizationAlgorithmLevenberg* _algorithm = nullptr;
     bool _verbose = false;
@@ -750,7 +785,12 @@ public:
         delete _algorithm;
     }
     bool addVertex(OptimizableGraph::Vertex* v) { return _vertices.emplace(v->id(), v).second; }
-    bool addEdge(OptimizableGraph::Edge* e) { _edges.push_back(e); return true; }
+    bool addEdge(OptimizableGraph::Edge* e) {       // HyperGraph::addEdge: an edge that is already in the graph is refused
+        if (!_edgeSet.insert(e).second) return false;             // (Map.cpp:551-553 adds every projection edge a second time)
+        e->setGraphParameters(&_parameters);
+        _edges.push_back(e);
+        return true;
+    }
     bool addParameter(Parameter* p) { _parameters.push_back(p); return true; }
     OptimizableGraph::Vertex* vertex(int id) { auto it = _vertices.find(id); return it == _vertices.end() ? nullptr : it->second; }
     void setAlgorithm(OptimizationAlgorithmLevenberg* a) { delete _algorithm; _algorithm = a; }

@@ -486,3 +486,46 @@ class RefMap:
                     v_marginalized=(v_flags[:nv] & 2).astype(bool), o_ids=o_ids[:no], o_meas=o_meas[:no], o_info=o_info[:no].reshape(-1, 3, 3),
                     o_chi2=o_chi2[:no], e_ids=e_ids[:ne], e_uv=e_uv[:ne], e_info=e_info[:ne].reshape(-1, 2, 2), e_delta=e_delta[:ne],
                     e_chi2=e_chi2[:ne])
+
+
+def _refmap_set_odo_se3(self, kf, to, measure, info):
+    """KeyFrame::setOdoMeasureFrom(to, measure 4x4, info 6x6 in (translation, rotation) order) - both CV_32F in the reference"""
+    m = np.ascontiguousarray(measure, np.float32).reshape(-1); w = np.ascontiguousarray(info, np.float32).reshape(-1)
+    f = self._l.ref_map_set_odo_se3
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    f(self._h, int(kf), int(to), m.ctypes.data, w.ctypes.data)
+
+
+def _refmap_load_local_graph_se3(self, cap_v=1 << 18, cap_p=4096, cap_o=4096, cap_e=1 << 20):
+    """Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx) (the SE3-expmap local graph) -> what the recording optimizer holds"""
+    v_id = np.zeros(cap_v, np.int32); v_kind = np.zeros(cap_v, np.int32); v_est = np.zeros((cap_v, 12)); v_flags = np.zeros(cap_v, np.uint8)
+    p_id = np.zeros(cap_p, np.int32); p_meas = np.zeros((cap_p, 12)); p_info = np.zeros((cap_p, 36)); p_chi2 = np.zeros(cap_p)
+    o_ids = np.zeros((cap_o, 2), np.int32); o_meas = np.zeros((cap_o, 12)); o_info = np.zeros((cap_o, 36)); o_chi2 = np.zeros(cap_o)
+    e_ids = np.zeros((cap_e, 2), np.int32); e_uv = np.zeros((cap_e, 2)); e_info = np.zeros((cap_e, 4)); e_delta = np.zeros(cap_e)
+    e_level = np.zeros(cap_e, np.int32); e_chi2 = np.zeros(cap_e)
+    cnt = np.zeros(5, np.int32)
+    f = self._l.ref_map_load_local_graph_se3
+    f.restype = C.c_double
+    VP = C.c_void_p
+    f.argtypes = [VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP]
+    total = f(self._h, cap_v, v_id.ctypes.data, v_kind.ctypes.data, v_est.ctypes.data, v_flags.ctypes.data, cap_p, p_id.ctypes.data,
+              p_meas.ctypes.data, p_info.ctypes.data, p_chi2.ctypes.data, cap_o, o_ids.ctypes.data, o_meas.ctypes.data, o_info.ctypes.data,
+              o_chi2.ctypes.data, cap_e, e_ids.ctypes.data, e_uv.ctypes.data, e_info.ctypes.data, e_delta.ctypes.data, e_level.ctypes.data,
+              e_chi2.ctypes.data, cnt.ctypes.data)
+    assert total >= 0, cnt
+    nv, npri, no, ne, nall = (int(c) for c in cnt)
+
+    def T(a):
+        out = np.tile(np.eye(4), (len(a), 1, 1))
+        out[:, :3, :3] = a[:, :9].reshape(-1, 3, 3); out[:, :3, 3] = a[:, 9:]
+        return out
+    return dict(chi2=float(total), v_id=v_id[:nv], v_kind=v_kind[:nv], v_est=v_est[:nv], v_fixed=(v_flags[:nv] & 1).astype(bool),
+                v_marginalized=(v_flags[:nv] & 2).astype(bool), p_id=p_id[:npri], p_meas=T(p_meas[:npri]), p_info=p_info[:npri].reshape(-1, 6, 6),
+                p_chi2=p_chi2[:npri], o_ids=o_ids[:no], o_meas=T(o_meas[:no]), o_info=o_info[:no].reshape(-1, 6, 6), o_chi2=o_chi2[:no],
+                e_ids=e_ids[:ne], e_uv=e_uv[:ne], e_info=e_info[:ne].reshape(-1, 2, 2), e_delta=e_delta[:ne], e_level=e_level[:ne],
+                e_chi2=e_chi2[:ne], edges_returned=nall)
+
+
+RefMap.set_odo_se3 = _refmap_set_odo_se3
+RefMap.load_local_graph_se3 = _refmap_load_local_graph_se3

@@ -3,6 +3,7 @@
 // C entry points over the REFERENCE's own map data model, compiled from /root/reference where the sources lie (oracle/Makefile,
 // target `ref`; nothing of the reference is copied into this repository):
 //   se2lam::Map::insertKF / insertMP / setCurrentKF / updateLocalGraph / loadLocalGraph(SlamOptimizer&)      src/Map.cpp:35-139, 285-331, 891-1053
+//   se2lam::Map::loadLocalGraph(SlamOptimizer&, vpEdgesAll, vnAllIdx) - the SE3-expmap local graph          src/Map.cpp:414-566
 //   se2lam::KeyFrame (constructor from a Frame, setPose(Se2), setViewMP, addObservation, addCovisibleKF,
 //                     getAllObsMPs, getAllCovisibleKFs, preOdomFromSelf)                                     src/KeyFrame.cpp
 //   se2lam::MapPoint (constructor, addObservation with updateMainKFandDescriptor, getObservations, getOctave,
@@ -219,4 +220,92 @@ double ref_map_load_local_graph(void* h, int cap_v, int32_t* v_id, int32_t* v_ki
     return total;
 }
 
+}  // extern "C"
+
+// ---- the SE3-expmap variant
+namespace {
+void put12(const g2o::SE3Quat& T, double* o) {
+    const Eigen::Matrix3d R = T.rotation().toRotationMatrix();
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) o[3 * r + c] = R(r, c); o[9 + r] = T.translation()[r]; }
+}
+}  // namespace
+extern "C" {
+// KeyFrame::setOdoMeasureFrom (src/KeyFrame.cpp:231-233): the odometry constraint FROM key frame `kf` to `to` as Track leaves it
+// (measure: 4x4 CV_32F, info: 6x6 CV_32F in (translation, rotation) order)
+void ref_map_set_odo_se3(void* h, int kf, int to, const float* measure16, const float* info36) {
+    RefMap* m = static_cast<RefMap*>(h);
+    m->kfs[kf]->setOdoMeasureFrom(m->kfs[to], mat_of(measure16, 4, 4), mat_of(info36, 6, 6));
+}
+// Map::loadLocalGraph(optimizer, vpEdgesAll, vnAllIdx) (src/Map.cpp:414-566) on the local graph of the last updateLocalGraph:
+//   vertices (id order): id, kind (2 = VertexSE3Expmap with estimate (R, t) in v_est12, 1 = VertexSBAPointXYZ in its first 3), flags
+//   EdgeSE3ExpmapPrior: vertex id, measurement (R, t), information (36), chi2          [se2lam's own edge]
+//   EdgeSE3Expmap: the two vertex ids, measurement, information as the edge holds it, chi2
+//   EdgeProjectXYZ2UV: map-point vertex, key-frame vertex, uv, information (4), Huber delta, level, chi2
+// counts5 = {vertices, priors, odometry edges, projection edges, sum of vpEdgesAll[i].size()}; returns sum rho(chi2).
+double ref_map_load_local_graph_se3(void* h, int cap_v, int32_t* v_id, int32_t* v_kind, double* v_est12, uint8_t* v_flags, int cap_p, int32_t* p_id,
+                                    double* p_meas12, double* p_info36, double* p_chi2, int cap_o, int32_t* o_ids, double* o_meas12, double* o_info36,
+                                    double* o_chi2, int cap_e, int32_t* e_ids, double* e_uv, double* e_info4, double* e_delta, int32_t* e_level,
+                                    double* e_chi2, int32_t* counts5) {
+    RefMap* m = static_cast<RefMap*>(h);
+    SlamOptimizer opt;
+    initOptimizer(opt);
+    std::vector<std::vector<g2o::EdgeProjectXYZ2UV*>> vpEdgesAll;
+    std::vector<std::vector<int>> vnAllIdx;
+    m->map.loadLocalGraph(opt, vpEdgesAll, vnAllIdx);
+    int nv = 0, np = 0, no = 0, ne = 0, nall = 0;
+    for (const auto& v : vpEdgesAll) nall += (int)v.size();
+    for (const auto& kv : opt.vertices()) {
+        if (nv < cap_v) {
+            v_id[nv] = kv.first;
+            for (int i = 0; i < 12; ++i) v_est12[12 * nv + i] = 0;
+            if (const g2o::VertexSE3Expmap* v = dynamic_cast<const g2o::VertexSE3Expmap*>(kv.second)) {
+                v_kind[nv] = 2;
+                put12(v->estimate(), v_est12 + 12 * nv);
+            } else if (const g2o::VertexSBAPointXYZ* p = dynamic_cast<const g2o::VertexSBAPointXYZ*>(kv.second)) {
+                v_kind[nv] = 1;
+                for (int i = 0; i < 3; ++i) v_est12[12 * nv + i] = p->estimate()[i];
+            } else {
+                v_kind[nv] = -1;
+            }
+            v_flags[nv] = (uint8_t)((kv.second->fixed() ? 1 : 0) | (kv.second->marginalized() ? 2 : 0));
+        }
+        ++nv;
+    }
+    double total = 0;
+    for (g2o::OptimizableGraph::Edge* e : opt.edges()) {
+        e->computeError();
+        const double c = e->chi2();
+        total += e->robustKernel() ? e->robustKernel()->rho(c) : c;
+        if (EdgeSE3ExpmapPrior* x = dynamic_cast<EdgeSE3ExpmapPrior*>(e)) {
+            if (np < cap_p) {
+                p_id[np] = x->vertices()[0]->id();
+                put12(x->measurement(), p_meas12 + 12 * np);
+                for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) p_info36[36 * np + 6 * r + cc] = x->information()(r, cc);
+                p_chi2[np] = c;
+            }
+            ++np;
+        } else if (g2o::EdgeSE3Expmap* x = dynamic_cast<g2o::EdgeSE3Expmap*>(e)) {
+            if (no < cap_o) {
+                o_ids[2 * no] = x->vertices()[0]->id(); o_ids[2 * no + 1] = x->vertices()[1]->id();
+                put12(x->measurement(), o_meas12 + 12 * no);
+                for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) o_info36[36 * no + 6 * r + cc] = x->information()(r, cc);
+                o_chi2[no] = c;
+            }
+            ++no;
+        } else if (g2o::EdgeProjectXYZ2UV* x = dynamic_cast<g2o::EdgeProjectXYZ2UV*>(e)) {
+            if (ne < cap_e) {
+                e_ids[2 * ne] = x->vertices()[0]->id(); e_ids[2 * ne + 1] = x->vertices()[1]->id();
+                e_uv[2 * ne] = x->measurement()[0]; e_uv[2 * ne + 1] = x->measurement()[1];
+                for (int r = 0; r < 2; ++r) for (int cc = 0; cc < 2; ++cc) e_info4[4 * ne + 2 * r + cc] = x->information()(r, cc);
+                e_delta[ne] = x->robustKernel() ? x->robustKernel()->delta() : 0.0;
+                e_level[ne] = x->level();
+                e_chi2[ne] = c;
+            }
+            ++ne;
+        }
+    }
+    counts5[0] = nv; counts5[1] = np; counts5[2] = no; counts5[3] = ne; counts5[4] = nall;
+    if (nv > cap_v || np > cap_p || no > cap_o || ne > cap_e) return -1.0;
+    return total;
+}
 }  // extern "C"
