@@ -691,11 +691,7 @@ void ba_ref_plane_motion_prior(const double* Tcw12, const double* Tbc12, double 
                                double* meas12, double* info36) {
     const Se3 Tcw = se3_from(Tcw12), Tbc = se3_from(Tbc12);
     Se3 Tbw = se3_mul(Tbc, Tcw);
-    double lg[6];
-    Se3 Ronly = Tbw;
-    Ronly.t[0] = Ronly.t[1] = Ronly.t[2] = 0;
-    se3_log(Ronly, lg);                       // rotation vector of Rbw (Eigen::AngleAxisd angle * axis)
-    const double yaw = lg[2];
+    const double yaw = rotation_vector_z(Tbw.R);   // z of the rotation vector of Rbw, Eigen::AngleAxisd(quaternion): angle * axis
     const double c = std::cos(yaw), sn = std::sin(yaw);
     const double Rz[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
     std::memcpy(Tbw.R, Rz, sizeof(Rz));

@@ -22,10 +22,8 @@ inline void se3_to(const Se3& T, double* p) {
     std::memcpy(p, T.R, 9 * sizeof(double));
     std::memcpy(p + 9, T.t, 3 * sizeof(double));
 }
-inline void normalize_rotation(double R[9]) {
-    // SE3Quat keeps a unit quaternion and renormalises it after every product / construction (normalizeRotation):
-    // matrix -> quaternion (Eigen's conversion) -> normalise -> matrix
-    double q[4];   // x, y, z, w
+// Eigen::Quaterniond(R) as (x, y, z, w), then SE3Quat::normalizeRotation: w >= 0, unit norm
+inline void quat_of_rotation(const double R[9], double q[4]) {
     double t = R[0] + R[4] + R[8];
     if (t > 0) {
         t = std::sqrt(t + 1.0);
@@ -60,6 +58,21 @@ inline void normalize_rotation(double R[9]) {
         for (int a = 0; a < 4; ++a) q[a] = -q[a];
     const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     for (int a = 0; a < 4; ++a) q[a] /= nrm;
+}
+// z component of Eigen::AngleAxisd(q): angle = 2 atan2(|q_xyz|, w), axis = q_xyz / |q_xyz| - the rotation vector of a rotation
+// THROUGH ITS QUATERNION, as src/optimizer.cpp:271-274 takes it; well conditioned near angle pi, where the logarithm of the
+// rotation matrix (se3_log) loses ten digits (found by tools/fuzz_ref_backend.py against the compiled reference)
+inline double rotation_vector_z(const double R[9]) {
+    double q[4];
+    quat_of_rotation(R, q);
+    const double nv = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    return nv > 0 ? 2 * std::atan2(nv, q[3]) * q[2] / nv : 0.0;
+}
+inline void normalize_rotation(double R[9]) {
+    // SE3Quat keeps a unit quaternion and renormalises it after every product / construction (normalizeRotation):
+    // matrix -> quaternion (Eigen's conversion) -> normalise -> matrix
+    double q[4];   // x, y, z, w
+    quat_of_rotation(R, q);
     const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
     const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
     const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];

@@ -277,12 +277,15 @@ extern "C" int se2gpu_plane_motion_prior(const double* Tcw12, const double* Tbc1
     SE2_REQUIRE(Tcw12 && Tbc12 && meas12 && info36, SE2GPU_ERR_INVALID, "plane_motion_prior: NULL argument");
     const Se3 Tcw = se3_from(Tcw12), Tbc = se3_from(Tbc12);
     Se3 Tbw = se3_mul(Tbc, Tcw);
-    // Log_Rbw = angle * axis of Rbw; only its z component survives (:271-274), and the height is dropped (:276-278)
-    Se3 Ronly = Tbw;
-    Ronly.t[0] = Ronly.t[1] = Ronly.t[2] = 0;
-    double lg[6];
-    se3_log(Ronly, lg);
-    const double c = std::cos(lg[2]), sn = std::sin(lg[2]);
+    // Log_Rbw = angle * axis of Rbw as Eigen::AngleAxisd takes it from the QUATERNION (angle = 2 atan2(|q_xyz|, w)); only its
+    // z component survives (:271-274), and the height is dropped (:276-278).  (Until round 4 this went through the logarithm
+    // of the rotation matrix, which loses ten digits near a yaw of pi: 6e-7 mm in the measurement against the compiled
+    // reference, found by tools/fuzz_ref_backend.py.)
+    double q[4];
+    quat_of(Tbw.R, q);
+    const double nv = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double yaw = nv > 0 ? 2 * std::atan2(nv, q[0]) * q[3] / nv : 0.0;
+    const double c = std::cos(yaw), sn = std::sin(yaw);
     const double Rz[9] = {c, -sn, 0, sn, c, 0, 0, 0, 1};
     std::memcpy(Tbw.R, Rz, sizeof(Rz));
     Tbw.t[2] = 0;
