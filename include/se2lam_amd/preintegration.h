@@ -45,8 +45,10 @@ inline Se2f se2Minus(const Se2f& a, const Se2f& b) {
     return Se2f{c * dx + s * dy, -s * dx + c * dy, dth};
 }
 
-// One odometry message: odok = odom_now - odom_last; noise = Config::ODO_{X,Y,T}_NOISE (standard deviations)
-inline void updatePreSE2(PreSE2& p, const Se2f& odok, double noise_x, double noise_y, double noise_t) {
+// One odometry message: odok = odom_now - odom_last; noise = Config::ODO_{X,Y,T}_NOISE (standard deviations; floats in the
+// reference, and their squares are FLOAT products there - Track.cpp:183-185 - which is what the compiled reference showed:
+// 0.002f * 0.002f = 4.00000044e-06, not 4.00000038e-06)
+inline void updatePreSE2(PreSE2& p, const Se2f& odok, float noise_x, float noise_y, float noise_t) {
     const double ox = odok.x, oy = odok.y;
     const double c = std::cos(p.meas[2]), s = std::sin(p.meas[2]);   // Phi_ik = Rotation2D(meas[2])
     const double px = c * ox - s * oy, py = s * ox + c * oy;          // Phi_ik * odork
@@ -57,7 +59,8 @@ inline void updatePreSE2(PreSE2& p, const Se2f& odok, double noise_x, double noi
     p.meas[2] += odok.theta;
     const double A[9] = {1, 0, a02, 0, 1, a12, 0, 0, 1};
     const double B[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
-    const double Sv[3] = {noise_x * noise_x, noise_y * noise_y, noise_t * noise_t};
+    const float sx = noise_x * noise_x, sy = noise_y * noise_y, st = noise_t * noise_t;
+    const double Sv[3] = {sx, sy, st};
     double AS[9], out[9];
     for (int r = 0; r < 3; ++r)
         for (int q = 0; q < 3; ++q) {

@@ -74,11 +74,42 @@ Mat& Mat::setTo(const Scalar& s) {
     for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) setd(r, c, s.val[0]);
     return *this;
 }
+static void need_float_fwd(const Mat& a) {
+    if (a.channels() != 1 || (a.depth() != CV_32F && a.depth() != CV_64F)) throw std::runtime_error("cv shim: matrix arithmetic needs 32F / 64F");
+}
 MatExpr Mat::t() const {
     Mat out(cols, rows, flags);
     const size_t esz = elemSize();
     for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) std::memcpy(out.ptr(c) + r * esz, ptr(r) + c * esz, esz);
     return MatExpr(out);
+}
+MatExpr Mat::inv() const {
+    need_float_fwd(*this);
+    if (rows != cols) throw std::runtime_error("cv shim: inv() of a non-square matrix");
+    const int n = rows;
+    std::vector<double> a((size_t)n * n), b((size_t)n * n, 0.0);
+    for (int r = 0; r < n; ++r) { for (int c = 0; c < n; ++c) a[(size_t)r * n + c] = getd(r, c); b[(size_t)r * n + r] = 1.0; }
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int r = k + 1; r < n; ++r) if (std::fabs(a[(size_t)r * n + k]) > std::fabs(a[(size_t)p * n + k])) p = r;
+        if (p != k) for (int c = 0; c < n; ++c) { std::swap(a[(size_t)k * n + c], a[(size_t)p * n + c]); std::swap(b[(size_t)k * n + c], b[(size_t)p * n + c]); }
+        const double inv = 1.0 / a[(size_t)k * n + k];
+        for (int c = 0; c < n; ++c) { a[(size_t)k * n + c] *= inv; b[(size_t)k * n + c] *= inv; }
+        for (int r = 0; r < n; ++r) {
+            if (r == k) continue;
+            const double f = a[(size_t)r * n + k];
+            if (f == 0) continue;
+            for (int c = 0; c < n; ++c) { a[(size_t)r * n + c] -= f * a[(size_t)k * n + c]; b[(size_t)r * n + c] -= f * b[(size_t)k * n + c]; }
+        }
+    }
+    Mat out(n, n, flags);
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) out.setd(r, c, b[(size_t)r * n + c]);
+    return MatExpr(out);
+}
+double norm(const Mat& m) {
+    double s = 0;
+    for (int r = 0; r < m.rows; ++r) for (int c = 0; c < m.cols; ++c) { const double v = m.getd(r, c); s += v * v; }
+    return std::sqrt(s);
 }
 MatExpr Mat::zeros(int r, int c, int type) {
     Mat out(r, c, type);

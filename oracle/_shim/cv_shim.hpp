@@ -105,6 +105,7 @@ template <typename T> struct Point3_ {
     Point3_() : x(0), y(0), z(0) {}
     Point3_(T x_, T y_, T z_) : x(x_), y(y_), z(z_) {}
     T dot(const Point3_& p) const { return (T)(x * p.x + y * p.y + z * p.z); }
+    Point3_ cross(const Point3_& p) const { return Point3_((T)(y * p.z - z * p.y), (T)(z * p.x - x * p.z), (T)(x * p.y - y * p.x)); }
 };
 typedef Point3_<float> Point3f;
 typedef Point3_<double> Point3d;
@@ -144,6 +145,10 @@ public:
     KeyPoint() : pt(0, 0), size(0), angle(-1), response(0), octave(0), class_id(-1) {}
     KeyPoint(Point2f p, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(p), size(s), angle(a), response(r), octave(o), class_id(c) {}
     KeyPoint(float x, float y, float s, float a = -1, float r = 0, int o = 0, int c = -1) : pt(x, y), size(s), angle(a), response(r), octave(o), class_id(c) {}
+    static void convert(const std::vector<KeyPoint>& keypoints, std::vector<Point2f>& points2f) {
+        points2f.resize(keypoints.size());
+        for (size_t i = 0; i < keypoints.size(); ++i) points2f[i] = keypoints[i].pt;
+    }
 };
 
 template <typename T> struct DataType;
@@ -234,6 +239,7 @@ public:
     Mat& setTo(const Scalar& s);
     Mat& operator=(const Scalar& s) { return setTo(s); }
     MatExpr t() const;
+    MatExpr inv() const;                  // square 32F / 64F matrix, Gauss-Jordan with partial pivoting in double (cv::DECOMP_LU)
     static MatExpr zeros(int r, int c, int type);
     static MatExpr eye(int r, int c, int type);
 
@@ -277,6 +283,8 @@ inline MatExpr operator*(double s, const Mat& a) { return s * MatExpr(a); }
 inline MatExpr operator*(const Mat& a, double s) { return MatExpr(a) * s; }
 inline MatExpr operator/(const Mat& a, double s) { return MatExpr(a) / s; }
 inline MatExpr operator+(const Mat& a, const Mat& b) { return MatExpr(a) + MatExpr(b); }
+inline MatExpr operator+(const MatExpr& a, const Mat& b) { return a + MatExpr(b); }
+inline MatExpr operator+(const Mat& a, const MatExpr& b) { return MatExpr(a) + b; }
 inline MatExpr operator-(const Mat& a, const Mat& b) { return MatExpr(a) - MatExpr(b); }
 inline MatExpr operator-(const MatExpr& a, const Mat& b) { return a - MatExpr(b); }
 inline MatExpr operator-(const Mat& a, const MatExpr& b) { return MatExpr(a) - b; }
@@ -355,6 +363,7 @@ inline int64 getTickCount() { return 0; }
 inline double getTickFrequency() { return 1e9; }
 float fastAtan2(float y, float x);
 inline double norm(double v) { return std::fabs(v); }
+double norm(const Mat& m);   // NORM_L2 of a 32F / 64F matrix
 template <typename T> inline double norm(const Point3_<T>& p) { return std::sqrt((double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z); }
 
 enum { INTER_NEAREST = 0, INTER_LINEAR = 1 };
@@ -369,6 +378,24 @@ void GaussianBlur(InputArray src, OutputArray dst, Size ksize, double sigmaX, do
 void undistort(InputArray src, OutputArray dst, InputArray K, InputArray D, InputArray newK = _InputArray());
 void undistortPoints(InputArray src, OutputArray dst, InputArray K, InputArray D, InputArray R = _InputArray(), InputArray P = _InputArray());
 void Rodrigues(InputArray src, OutputArray dst);
+
+// What the threads' debug views call (Localizer / GlobalMapper ::DrawImg*): accepted, nothing drawn.
+enum { CV_GRAY2BGR = 8, FM_RANSAC = 8 };
+inline void cvtColor(const Mat& src, Mat& dst, int) { if (&src != &dst) dst = src; }
+inline void circle(Mat&, Point2f, int, const Scalar&, int = 1) {}
+inline void line(Mat&, Point2f, Point2f, const Scalar&, int = 1) {}
+inline void vconcat(const Mat& a, const Mat&, Mat& dst) { dst = a; }
+inline void hconcat(const Mat& a, const Mat&, Mat& dst) { dst = a; }
+// cv::findFundamentalMat(FM_RANSAC) is OpenCV's own algorithm (calib3d), not se2lam's: the stand-in keeps every
+// correspondence, so nothing that depends on the RANSAC outcome is pinned through oracle/_ref
+template <typename P> inline Mat findFundamentalMat(const std::vector<P>& a, const std::vector<P>&, int, double, double, std::vector<unsigned char>& mask) {
+    mask.assign(a.size(), 1);
+    return Mat();
+}
+template <typename P> inline Mat findFundamentalMat(const std::vector<P>& a, const std::vector<P>& b, std::vector<unsigned char>& mask, int method = FM_RANSAC,
+                                                    double param1 = 3., double param2 = 0.99) {
+    return findFundamentalMat(a, b, method, param1, param2, mask);
+}
 
 class KeyPointsFilter {
 public:

@@ -20,6 +20,8 @@
 #pragma once
 #include <cmath>
 #include <algorithm>
+#include <deque>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <memory>
@@ -46,6 +48,7 @@ public:
     BlockRef& operator=(const BlockRef& o) { return *this = Matrix<T, BR, BC>(o); }
     template <typename M2> BlockRef& operator=(const BlockRef<M2, T, BR, BC>& o) { return *this = Matrix<T, BR, BC>(o); }
     void setZero() { for (int r = 0; r < BR; ++r) for (int c = 0; c < BC; ++c) m(r0 + r, c0 + c) = T(0); }
+    BlockRef& operator+=(const Matrix<T, BR, BC>& v) { for (int r = 0; r < BR; ++r) for (int c = 0; c < BC; ++c) m(r0 + r, c0 + c) += v(r, c); return *this; }
     Matrix<T, BR, BC> operator-() const { return -Matrix<T, BR, BC>(*this); }   // (Matrix has the converting constructor)
 };
 
@@ -162,6 +165,10 @@ Matrix<T, R, C> operator*(S s, const Matrix<T, R, C>& a) { return a * T(s); }
 template <typename T, int R, int C> Matrix<T, R, C> operator/(const Matrix<T, R, C>& a, T s) { Matrix<T, R, C> m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = a(r, c) / s; return m; }
 template <typename T, int R, int C> Matrix<T, R, C> operator/(const Matrix<T, R, C>& a, int s) { return a / T(s); }
 
+template <typename T, int R, int C> std::ostream& operator<<(std::ostream& os, const Matrix<T, R, C>& m) {
+    for (int r = 0; r < R; ++r) { for (int c = 0; c < C; ++c) os << (c ? " " : "") << m(r, c); os << "\n"; }
+    return os;
+}
 typedef Matrix<double, 2, 1> Vector2d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 2, 2> Matrix2d;
@@ -172,13 +179,23 @@ typedef Matrix<double, 4, 4> Matrix4d;
 // order - Map<Matrix3d, RowMajor> (src/Map.cpp:951) therefore views the array in Matrix3d's own column-major order
 enum { ColMajor = 0, RowMajor = 1 };
 template <typename M, int Options = 0> class Map {
-    const double* p;
+    double* p;
+    enum { R = M::RowsAtCompileTime, C = M::ColsAtCompileTime };
 public:
-    explicit Map(const double* p_) : p(p_) {}
-    M eval() const { M m; for (int r = 0; r < M::RowsAtCompileTime; ++r) for (int c = 0; c < M::ColsAtCompileTime; ++c) m(r, c) = p[c * M::RowsAtCompileTime + r]; return m; }
+    explicit Map(double* p_) : p(p_) {}
+    explicit Map(const double* p_) : p(const_cast<double*>(p_)) {}
+    double& operator()(int r, int c) { return p[c * R + r]; }
+    double operator()(int r, int c) const { return p[c * R + r]; }
+    double& operator[](int i) { return p[i]; }
+    double operator[](int i) const { return p[i]; }
+    M eval() const { M m; for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) m(r, c) = (*this)(r, c); return m; }
+    operator M() const { return eval(); }
     M inverse() const { return eval().inverse(); }
-    double operator()(int r, int c) const { return p[c * M::RowsAtCompileTime + r]; }
+    Map& operator=(const M& m) { for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) (*this)(r, c) = m(r, c); return *this; }
+    template <int N> BlockRef<Map, double, N, 1> head() { return BlockRef<Map, double, N, 1>(*this, 0, 0); }
 };
+template <typename T, int R, int K, typename M, int O> auto operator*(const Matrix<T, R, K>& a, const Map<M, O>& b) -> decltype(a * b.eval()) { return a * b.eval(); }
+template <typename T, int K, int C, typename M, int O> auto operator*(const Map<M, O>& a, const Matrix<T, K, C>& b) -> decltype(a.eval() * b) { return a.eval() * b; }
 
 // Eigen::MatrixXd: what src/sparsifier.cpp does with it - Zero / Identity, blocks, products, differences, ldlt().solve()
 class LDLTXd;
@@ -379,6 +396,7 @@ class Isometry3d {
     Vector3d t_;
 public:
     Isometry3d() { R_.setIdentity(); }
+    static Isometry3d Identity() { return Isometry3d(); }
     explicit Isometry3d(const Quaterniond& q) : R_(q.toRotationMatrix()) {}
     Isometry3d& operator=(const Quaterniond& q) { R_ = q.toRotationMatrix(); t_.setZero(); return *this; }
     Vector3d& translation() { return t_; }
@@ -751,8 +769,42 @@ public:
     bool read(std::istream&) override { return false; }
     bool write(std::ostream&) const override { return false; }
 };
-class EdgeSE3 : public BaseBinaryEdge<6, Isometry3D, VertexSE3, VertexSE3> { public: SE2_SHIM_RECORD_ONLY };
-class EdgeSE3Prior : public BaseUnaryEdge<6, Isometry3D, VertexSE3> { public: SE2_SHIM_RECORD_ONLY };
+namespace internal {
+inline Vector6d toVectorMQT(const Isometry3D& t) {   // g2o/types/slam3d/isometry3d_mappings.cpp: (translation, q_xyz of the unit quaternion with w >= 0)
+    Eigen::Quaterniond q(t.linear());
+    q.normalize();
+    Vector6d v;
+    const double s = q.w() < 0 ? -1.0 : 1.0;
+    v[3] = s * q.x(); v[4] = s * q.y(); v[5] = s * q.z();
+    v[0] = t.translation()[0]; v[1] = t.translation()[1]; v[2] = t.translation()[2];
+    return v;
+}
+}  // namespace internal
+// EdgeSE3 / EdgeSE3Prior (g2o/types/slam3d): error = toVectorMQT(Z^-1 * X_i^-1 * X_j) resp. toVectorMQT(Z^-1 * X * offset) - evaluated
+// so that the cost of GlobalMapper::GlobalBA's graph can be compared as a whole (from the published g2o sources)
+class EdgeSE3 : public BaseBinaryEdge<6, Isometry3D, VertexSE3, VertexSE3> {
+public:
+    void computeError() override {
+        const VertexSE3* from = static_cast<const VertexSE3*>(_vertices[0]);
+        const VertexSE3* to = static_cast<const VertexSE3*>(_vertices[1]);
+        _error = internal::toVectorMQT(_measurement.inverse() * from->estimate().inverse() * to->estimate());
+    }
+    void linearizeOplus() override {}
+    bool read(std::istream&) override { return false; }
+    bool write(std::ostream&) const override { return false; }
+};
+class EdgeSE3Prior : public BaseUnaryEdge<6, Isometry3D, VertexSE3> {
+public:
+    void computeError() override {
+        const VertexSE3* v = static_cast<const VertexSE3*>(_vertices[0]);
+        const ParameterSE3Offset* off = dynamic_cast<const ParameterSE3Offset*>(parameterOf(0));
+        const Isometry3D n2w = off ? v->estimate() * off->offset() : v->estimate();
+        _error = internal::toVectorMQT(_measurement.inverse() * n2w);
+    }
+    void linearizeOplus() override {}
+    bool read(std::istream&) override { return false; }
+    bool write(std::ostream&) const override { return false; }
+};
 class EdgeSE3PointXYZ : public BaseBinaryEdge<3, Vector3D, VertexSE3, VertexPointXYZ> { public: SE2_SHIM_RECORD_ONLY };
 #undef SE2_SHIM_RECORD_ONLY
 
@@ -775,6 +827,8 @@ class SparseOptimizer {
     std::vector<Parameter*> _parameters;
     OptimizationAlgorithmLevenberg* _algorithm = nullptr;
     bool _verbose = false;
+    bool* _stop = nullptr;
+    int _level = 0;
 public:
     SparseOptimizer() {}
     SparseOptimizer(const SparseOptimizer&) = delete;
@@ -795,6 +849,13 @@ public:
     OptimizableGraph::Vertex* vertex(int id) { auto it = _vertices.find(id); return it == _vertices.end() ? nullptr : it->second; }
     void setAlgorithm(OptimizationAlgorithmLevenberg* a) { delete _algorithm; _algorithm = a; }
     void setVerbose(bool v) { _verbose = v; }
+    // Nothing is optimised in oracle/_ref: initializeOptimization / optimize hand the graph, as the reference built it, to
+    // whoever registered a hook (the drivers: cost at the start, the recorded vertices and edges), and return.
+    static std::function<void(SparseOptimizer&, int)>& optimizeHook() { static std::function<void(SparseOptimizer&, int)> h; return h; }
+    bool initializeOptimization(int level = 0) { _level = level; return true; }
+    int optimize(int iterations) { if (optimizeHook()) optimizeHook()(*this, iterations); return 0; }
+    void setForceStopFlag(bool* f) { _stop = f; }
+    int level() const { return _level; }
     bool verbose() const { return _verbose; }
     bool hasAlgorithm() const { return _algorithm != nullptr; }
     const std::vector<OptimizableGraph::Edge*>& edges() const { return _edges; }

@@ -6,3 +6,14 @@
 #define ROS_INFO(...) do { } while (0)
 #define ROS_WARN(...) do { } while (0)
 #define ROS_ERROR(...) do { } while (0)
+
+// the threads' run() loops (Track, LocalMapper, GlobalMapper, Localizer): never entered in oracle/_ref
+namespace ros {
+inline bool ok() { return false; }
+inline void shutdown() {}
+class Rate {
+public:
+    explicit Rate(double) {}
+    void sleep() {}
+};
+}  // namespace ros

@@ -529,3 +529,61 @@ def _refmap_load_local_graph_se3(self, cap_v=1 << 18, cap_p=4096, cap_o=4096, ca
 
 RefMap.set_odo_se3 = _refmap_set_odo_se3
 RefMap.load_local_graph_se3 = _refmap_load_local_graph_se3
+
+
+# ---- the threads (src/Track.cpp, src/Localizer.cpp ...; oracle/ref_threads_driver.cpp)
+def track_triangulate(K, kps_ref, kps_cur, match_idx, has_obs, view_mp, Tcr, lower, upper, frame_gap=10):
+    """Track::doTriangulate -> (pos (n,3) f32 = mLocalMPs (untouched entries stay (-1,-1,-1)), good (n,) u8, match_idx updated, n_good, n_tracked_old)"""
+    l = lib_map()
+    k = np.ascontiguousarray(K, np.float32).reshape(-1)
+    k1 = np.ascontiguousarray(kps_ref); k2 = np.ascontiguousarray(kps_cur)
+    n = len(k1)
+    m = np.ascontiguousarray(match_idx, np.int32).copy()
+    ho = np.ascontiguousarray(np.zeros(n) if has_obs is None else has_obs, np.uint8)
+    vm = np.ascontiguousarray(np.zeros((n, 3)) if view_mp is None else view_mp, np.float32)
+    T = np.ascontiguousarray(Tcr, np.float32).reshape(-1)
+    pos = np.zeros((max(n, 1), 3), np.float32); good = np.zeros(max(n, 1), np.uint8); ng = np.zeros(1, np.int32)
+    f = l.ref_track_triangulate
+    f.restype = C.c_int
+    VP = C.c_void_p
+    f.argtypes = [VP, C.c_float, C.c_float, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP]
+    nold = f(k.ctypes.data, lower, upper, n, k1.ctypes.data, ho.ctypes.data, vm.ctypes.data, len(k2), k2.ctypes.data, m.ctypes.data, T.ctypes.data,
+             int(frame_gap), pos.ctypes.data, good.ctypes.data, ng.ctypes.data)
+    return pos[:n], good[:n], m, int(ng[0]), int(nold)
+
+
+def track_update_frame_pose(bTc, noise, kf_odom, kf_twb, last_odom, odom, meas, cov):
+    """Track::updateFramePose -> dict(meas (3,), cov (9,) as the array holds it, Trb, Twb (3,) f32, Tcr, Tcw (4,4) f32)"""
+    l = lib_map()
+    b = np.ascontiguousarray(bTc, np.float32).reshape(-1); nz = np.ascontiguousarray(noise, np.float32)
+    a = [np.ascontiguousarray(x, np.float32) for x in (kf_odom, kf_twb, last_odom, odom)]
+    m = np.ascontiguousarray(meas, np.float64).copy(); c = np.ascontiguousarray(cov, np.float64).reshape(-1).copy()
+    trb = np.zeros(3, np.float32); twb = np.zeros(3, np.float32); Tcr = np.zeros(16, np.float32); Tcw = np.zeros(16, np.float32)
+    f = l.ref_track_update_frame_pose
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 12
+    f(b.ctypes.data, nz.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, m.ctypes.data, c.ctypes.data,
+      trb.ctypes.data, twb.ctypes.data, Tcr.ctypes.data, Tcw.ctypes.data)
+    return dict(meas=m, cov=c, Trb=trb, Twb=twb, Tcr=Tcr.reshape(4, 4), Tcw=Tcw.reshape(4, 4))
+
+
+def localizer_do_local_ba(K, bTc, huber, Tcw, kps, mp_pos, mp_good, id_kf=7, xrot_info=1e6, yrot_info=1e6, z_info=1.0):
+    """Localizer::DoLocalBA up to optimizer.optimize(30): the graph the reference built and its cost at the start"""
+    l = lib_map()
+    k = np.ascontiguousarray(K, np.float32).reshape(-1); b = np.ascontiguousarray(bTc, np.float32).reshape(-1)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)
+    kp = np.ascontiguousarray(kps); n = len(kp)
+    pos = np.ascontiguousarray(mp_pos, np.float32).reshape(-1, 3); gd = np.ascontiguousarray(mp_good, np.uint8)
+    out5 = np.zeros(5, np.int32); pm = np.zeros(12); pi = np.zeros(36)
+    e_point = np.zeros(max(n, 1), np.int32); e_uv = np.zeros((max(n, 1), 2)); e_w = np.zeros(max(n, 1)); e_chi2 = np.zeros(max(n, 1)); e_delta = np.zeros(max(n, 1))
+    f = l.ref_localizer_do_local_ba
+    f.restype = C.c_double
+    VP = C.c_void_p
+    f.argtypes = [VP, VP] + [C.c_float] * 4 + [C.c_int, VP, C.c_int, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP]
+    total = f(k.ctypes.data, b.ctypes.data, huber, xrot_info, yrot_info, z_info, int(id_kf), T.ctypes.data, n, kp.ctypes.data, pos.ctypes.data,
+              gd.ctypes.data, out5.ctypes.data, pm.ctypes.data, pi.ctypes.data, e_point.ctypes.data, e_uv.ctypes.data, e_w.ctypes.data,
+              e_chi2.ctypes.data, e_delta.ctypes.data)
+    ne = int(out5[2])
+    return dict(chi2=float(total), n_vertices=int(out5[0]), n_fixed=int(out5[1]), n_edges=ne, n_priors=int(out5[3]), iterations=int(out5[4]),
+                prior_meas=_mat44(pm), prior_info=pi.reshape(6, 6), e_point=e_point[:ne], e_uv=e_uv[:ne], e_w=e_w[:ne], e_chi2=e_chi2[:ne],
+                e_delta=e_delta[:ne])

@@ -26,19 +26,6 @@
 #include "cvutil.h"
 #include "optimizer.h"
 
-namespace se2lam {
-// the four static functions of the threads that Map.cpp / MapPoint.cpp name (pruneRedundantKF, UpdateFeatGraph,
-// updateParallax of a point without parallax): not on the pinned path - loud if ever reached
-void Track::calcOdoConstraintCam(const Se2&, cv::Mat&, g2o::Matrix6d&) { throw std::logic_error("Track::calcOdoConstraintCam is outside oracle/_ref"); }
-void Track::calcSE3toXYZInfo(cv::Point3f, const cv::Mat&, const cv::Mat&, Eigen::Matrix3d&, Eigen::Matrix3d&) {
-    throw std::logic_error("Track::calcSE3toXYZInfo is outside oracle/_ref");
-}
-int GlobalMapper::CreateFeatEdge(std::shared_ptr<KeyFrame>, std::shared_ptr<KeyFrame>, SE3Constraint&) { throw std::logic_error("GlobalMapper::CreateFeatEdge is outside oracle/_ref"); }
-std::set<std::shared_ptr<KeyFrame>> GlobalMapper::GetAllConnectedKFs_nLayers(const std::shared_ptr<KeyFrame>, int, std::set<std::shared_ptr<KeyFrame>>) {
-    throw std::logic_error("GlobalMapper::GetAllConnectedKFs_nLayers is outside oracle/_ref");
-}
-}  // namespace se2lam
-
 using namespace se2lam;
 
 namespace {

@@ -721,6 +721,116 @@ def test_se3_local_graph_of_the_compiled_reference(oracle, synth, n_ref):
         assert np.array_equal(back, back.astype(np.float32).astype(np.float64)) and back[0, 0] < 10 < back[3, 3]
 
 
+# ---- the threads, compiled (src/Track.cpp, src/Localizer.cpp ... in libse2lam_ref_map.so)
+def _triangulation_scene(n, seed):
+    from test_triangulate import scene
+    k1, k2, match, has_obs, P1, P2, Ocam, X = scene(n, seed)
+    K = np.array([[400.0, 0, 320.0], [0, 400.0, 240.0], [0, 0, 1]], np.float32)
+    th = 0.03
+    Tcr = np.eye(4, dtype=np.float32)
+    Tcr[:3, :3] = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], np.float32)
+    Tcr[:3, 3] = np.array([-150.0, 5.0, 20.0], np.float32)
+    return K, Tcr, k1, k2, match, has_obs, P1, P2, Ocam, X.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed,n", [(7, 600), (11, 1000), (3, 1)])
+def test_do_triangulate_of_the_compiled_reference_equals_the_restatement(oracle, seed, n):
+    """Track::doTriangulate (src/Track.cpp:373-415) on a Track object filled with the scene: which matches are triangulated
+    (not the ones the key frame already observes: their position is mViewMPs[i], counted as tracked), the depth gate that
+    drops a match, the 2-degree parallax flag, the counters - identical; positions to the accuracy two SVD routines share."""
+    K, Tcr, k1, k2, match, has_obs, P1, P2, Ocam, X = _triangulation_scene(n, seed)
+    pos, good, m, ng, nold = ref.track_triangulate(K, k1, k2, match, has_obs, X, Tcr, 500.0, 8000.0)
+    po, go, mo, ngo, noldo = oracle.triangulate(k1, k2, match, has_obs, P1, P2, Ocam, 500.0, 8000.0, 2)
+    assert (nold, ng) == (noldo, ngo) and np.array_equal(m, mo) and np.array_equal(good, go)
+    seen = (match >= 0) & (has_obs == 1)
+    assert np.array_equal(pos[seen], X[seen])                                     # Track.cpp:389-393
+    acc = (match >= 0) & (has_obs == 0) & (m >= 0)
+    if acc.any():
+        assert np.abs(pos[acc] - po[acc]).max() <= 1e-5 * np.abs(po[acc]).max()
+    untouched = ~(seen | acc)
+    assert (pos[untouched] == -1).all() and not po[untouched].any()               # mLocalMPs keeps its initial (-1, -1, -1) there
+    # a frame closer than nMinFrames = 8 to the key frame is not triangulated at all (:374-376)
+    assert ref.track_triangulate(K, k1, k2, match, has_obs, X, Tcr, 500.0, 8000.0, frame_gap=7)[3:] == (0, 0)
+
+
+def test_update_frame_pose_of_the_compiled_reference(synth):
+    """Track::updateFramePose (src/Track.cpp:162-188): Trb / Tcr / Tcw / Twb of the frame from the odometry, and one step of the
+    SE(2) pre-integration - measurement and covariance - against the generator's restatement of the same recursion
+    (se2lam_amd.synth._preintegrate, which include/se2lam_amd/preintegration.h mirrors in C++).  The covariance array is
+    written through Eigen::Map<Matrix3d, RowMajor>, i.e. in Matrix3d's own column-major order (the second template argument
+    of Eigen::Map is an alignment option): symmetric, so either reading gives the same matrix."""
+    rng = np.random.default_rng(9)
+    bTc = np.eye(4); bTc[:3, :3] = synth.RBC; bTc[:3, 3] = synth.TBC
+    noise = np.array([2.0, 2.0, 0.002], np.float32)
+    kf_odom = np.array([1200.0, -300.0, 0.4], np.float32)
+    kf_twb = np.array([5000.0, 800.0, 1.1], np.float32)
+    meas = np.zeros(3); cov = np.zeros(9)
+    last = kf_odom.copy()
+    want_m = np.zeros(3); want_c = np.zeros((3, 3))
+    Sv = np.diag((noise * noise).astype(np.float64))          # float products (Track.cpp:183-185)
+    for step in range(12):
+        odom = (last + np.array([rng.uniform(5, 40), rng.uniform(-4, 4), rng.uniform(-0.03, 0.03)])).astype(np.float32)
+        out = ref.track_update_frame_pose(bTc, noise, kf_odom, kf_twb, last, odom, meas, cov)
+        # Se2 odok = mFrame.odom - lastOdom (float arithmetic of Se2::operator-, src/Config.cpp:214-223)
+        odok = ref.se2_compose(odom, last, minus=True).astype(np.float64)
+        Phi = synth._rot2(want_m[2])
+        A = np.eye(3); B = np.eye(3)
+        A[:2, 2] = Phi @ np.array([-odok[1], odok[0]]); B[:2, :2] = Phi
+        want_m[:2] += Phi @ odok[:2]; want_m[2] += odok[2]
+        want_c = A @ want_c @ A.T + B @ Sv @ B.T
+        assert np.allclose(out["meas"], want_m, rtol=1e-13, atol=1e-13)
+        got_c = out["cov"].reshape(3, 3)
+        assert np.allclose(got_c, want_c, rtol=1e-12, atol=1e-15) and np.allclose(got_c, got_c.T, rtol=1e-14, atol=1e-18)
+        # the frame's poses: Trb = odom - kfodom, Twb = kfTwb + Trb, Tcr = cTb * (kfodom - odom) * bTc, Tcw = Tcr * kfTcw
+        trb = ref.se2_compose(odom, kf_odom, minus=True)
+        assert np.array_equal(out["Trb"], trb) and np.array_equal(out["Twb"], ref.se2_compose(kf_twb, trb))
+        th = float(out["Twb"][2])
+        Twb = np.eye(4); Twb[:2, :2] = synth._rot2(th); Twb[:2, 3] = out["Twb"][:2]
+        assert np.allclose(out["Tcw"], np.linalg.inv(Twb @ bTc), rtol=0, atol=2e-3)     # float products of 4x4 matrices with mm translations
+        meas, cov, last = out["meas"], out["cov"], odom
+
+
+def _pose_only_case(seed, n):
+    from test_pose_ba import _case, TBC, F, CX, CY, DELTA
+    Tcw_true, Tcw0, Xw, uv, w, pose = _case(seed, n, 0.1)
+    kps = np.zeros(n, KP_DTYPE_REF)
+    lv = np.round(np.log(1.0 / w) / (2 * np.log(1.2))).astype(np.int32)
+    kps["x"], kps["y"], kps["octave"] = uv[:, 0], uv[:, 1], lv
+    return Tcw0.astype(np.float32), Xw.astype(np.float32), kps, TBC, F, CX, CY, DELTA
+
+
+KP_DTYPE_REF = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+@pytest.mark.parametrize("seed,n", [(0, 400), (2, 37), (4, 6)])
+def test_do_local_ba_of_the_compiled_reference(oracle, seed, n):
+    """Localizer::DoLocalBA (src/Localizer.cpp:233-302) as compiled, stopped where it calls optimize(30): one free pose vertex
+    with its plane-motion prior, every observed map point with good parallax as a FIXED, non-marginalised vertex with id
+    mIdKF + mId, one EdgeProjectXYZ2UV each (invSigma2 I of the key point's octave, Huber TH_HUBER) - and the cost of that
+    graph at the start against the restatement of the pose-only bundle adjustment."""
+    Tcw0, Xw, kps, TBC, F, CX, CY, DELTA = _pose_only_case(seed, n)
+    K = np.array([[F, 0, CX], [0, F, CY], [0, 0, 1]], np.float32)
+    good = np.ones(n, np.uint8); good[::9] = 0                                  # points without parallax are skipped (:262)
+    out = ref.localizer_do_local_ba(K, TBC, np.float32(DELTA), Tcw0, kps, Xw, good)
+    ng = int(good.sum())
+    assert (out["n_vertices"], out["n_fixed"], out["n_edges"], out["n_priors"], out["iterations"]) == (1 + ng, ng, ng, 1, 30)
+    assert sorted(out["e_point"].tolist()) == np.nonzero(good)[0].tolist()
+    sf = np.ones(8, np.float32)
+    for i in range(1, 8):
+        sf[i] = sf[i - 1] * np.float32(1.2)
+    inv_sigma2 = (np.float32(1.0) / (sf * sf)).astype(np.float64)
+    sel = out["e_point"]
+    assert np.array_equal(out["e_w"], inv_sigma2[kps["octave"][sel]]) and (out["e_delta"] == float(np.float32(DELTA))).all()
+    assert np.array_equal(out["e_uv"], np.stack([kps["x"][sel], kps["y"][sel]], axis=1).astype(np.float64))
+    # the restatement on the same numbers: pose = toSE3Quat(float Tcw), prior from that pose
+    T0 = _requat(Tcw0.astype(np.float64))
+    meas, info = oracle.plane_motion_prior(T0, _requat(np.asarray(TBC, np.float64)))
+    assert np.allclose(out["prior_meas"], meas, rtol=0, atol=1e-9) and np.allclose(out["prior_info"], info, rtol=1e-9, atol=1e-9 * np.abs(info).max())
+    _, st = oracle.pose_only_ba(T0, meas, info, Xw[sel].astype(np.float64), out["e_uv"], out["e_w"], float(K[0, 0]), float(K[0, 2]), float(K[1, 2]),
+                                float(np.float32(DELTA)), 30)
+    assert np.isclose(out["chi2"], st["chi2_init"], rtol=1e-9, atol=0)
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
@@ -846,3 +956,32 @@ def test_hip_se3_local_graph_cost_equals_the_compiled_reference(synth, n_ref):
     assert np.isclose(o.activeRobustChi2(), out["chi2"], rtol=1e-9, atol=0)
     chi = op.edgeChi2(o, g3.E)
     assert np.allclose(chi, out["e_chi2"], rtol=1e-8, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", [(7, 600), (11, 1000)])
+def test_hip_triangulate_equals_the_compiled_do_triangulate(seed, n):
+    from se2lam_amd.matcher import doTriangulate
+    K, Tcr, k1, k2, match, has_obs, P1, P2, Ocam, X = _triangulation_scene(n, seed)
+    pos, good, m, ng, nold = ref.track_triangulate(K, k1, k2, match, has_obs, X, Tcr, 500.0, 8000.0)
+    got = doTriangulate(k1, k2, match, has_obs, P1, P2, Ocam, 500.0, 8000.0, 2)
+    assert got[3:] == (ng, nold) and np.array_equal(got[1], good) and np.array_equal(got[2], m)
+    acc = (match >= 0) & (has_obs == 0) & (m >= 0)
+    assert np.abs(got[0][acc] - pos[acc]).max() <= 1e-5 * np.abs(pos[acc]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n", [(0, 400), (2, 37)])
+def test_hip_pose_only_ba_starts_from_the_compiled_graph(seed, n):
+    """se2gpu_track_pose_ba on the numbers of the graph the compiled Localizer::DoLocalBA built: same cost at the start."""
+    from se2lam_amd.localizer import Localizer, addPlaneMotionSE3Expmap
+    Tcw0, Xw, kps, TBC, F, CX, CY, DELTA = _pose_only_case(seed, n)
+    K = np.array([[F, 0, CX], [0, F, CY], [0, 0, 1]], np.float32)
+    good = np.ones(n, np.uint8); good[::9] = 0
+    out = ref.localizer_do_local_ba(K, TBC, np.float32(DELTA), Tcw0, kps, Xw, good)
+    sel = out["e_point"]
+    T0 = _requat(Tcw0.astype(np.float64))
+    loc = Localizer()
+    loc.DoLocalBA(T0, _requat(np.asarray(TBC, np.float64)), Xw[sel].astype(np.float64), out["e_uv"], out["e_w"], float(K[0, 0]), float(K[0, 2]),
+                  float(K[1, 2]), float(np.float32(DELTA)), 30)
+    assert np.isclose(loc.stats["chi2_init"], out["chi2"], rtol=1e-9, atol=0)
