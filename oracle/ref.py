@@ -587,3 +587,51 @@ def localizer_do_local_ba(K, bTc, huber, Tcw, kps, mp_pos, mp_good, id_kf=7, xro
     return dict(chi2=float(total), n_vertices=int(out5[0]), n_fixed=int(out5[1]), n_edges=ne, n_priors=int(out5[3]), iterations=int(out5[4]),
                 prior_meas=_mat44(pm), prior_info=pi.reshape(6, 6), e_point=e_point[:ne], e_uv=e_uv[:ne], e_w=e_w[:ne], e_chi2=e_chi2[:ne],
                 e_delta=e_delta[:ne])
+
+
+def _refmap_add_ftr_measure(self, kf_from, kf_to, measure, info):
+    """KeyFrame::addFtrMeasureFrom / To: the feature constraint (4x4 T, 6x6 information in (translation, rotation) order, CV_32F)"""
+    m = np.ascontiguousarray(measure, np.float32).reshape(-1); w = np.ascontiguousarray(info, np.float32).reshape(-1)
+    f = self._l.ref_map_add_ftr_measure
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    f(self._h, int(kf_from), int(kf_to), m.ctypes.data, w.ctypes.data)
+
+
+def _refmap_mp_pos(self, mp):
+    out = np.zeros(3, np.float32)
+    f = self._l.ref_map_mp_pos
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    f(self._h, int(mp), out.ctypes.data)
+    return out
+
+
+def _refmap_global_ba(self, global_iter=15, cap_v=4096, cap_e=1 << 16):
+    """GlobalMapper::GlobalBA (GlobalMapper.cpp:328-535) up to optimize(): the pose graph the reference built and its cost at the start"""
+    v_id = np.zeros(cap_v, np.int32); v_est = np.zeros((cap_v, 12)); v_fixed = np.zeros(cap_v, np.uint8)
+    p_id = np.zeros(cap_v, np.int32); p_meas = np.zeros((cap_v, 12)); p_info = np.zeros((cap_v, 36)); p_chi2 = np.zeros(cap_v)
+    e_ids = np.zeros((cap_e, 2), np.int32); e_meas = np.zeros((cap_e, 12)); e_info = np.zeros((cap_e, 36)); e_chi2 = np.zeros(cap_e)
+    cnt = np.zeros(4, np.int32)
+    f = self._l.ref_global_ba
+    f.restype = C.c_double
+    VP = C.c_void_p
+    f.argtypes = [VP, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, VP, VP, C.c_int, VP, VP, VP, VP, VP]
+    total = f(self._h, int(global_iter), cap_v, v_id.ctypes.data, v_est.ctypes.data, v_fixed.ctypes.data, cap_v, p_id.ctypes.data, p_meas.ctypes.data,
+              p_info.ctypes.data, p_chi2.ctypes.data, cap_e, e_ids.ctypes.data, e_meas.ctypes.data, e_info.ctypes.data, e_chi2.ctypes.data,
+              cnt.ctypes.data)
+    assert total >= 0, cnt
+    nv, npri, ne, it = (int(c) for c in cnt)
+
+    def T(a):
+        out = np.tile(np.eye(4), (len(a), 1, 1))
+        out[:, :3, :3] = a[:, :9].reshape(-1, 3, 3); out[:, :3, 3] = a[:, 9:]
+        return out
+    return dict(chi2=float(total), iterations=it, v_id=v_id[:nv], v_est=T(v_est[:nv]), v_fixed=v_fixed[:nv].astype(bool), p_id=p_id[:npri],
+                p_meas=T(p_meas[:npri]), p_info=p_info[:npri].reshape(-1, 6, 6), p_chi2=p_chi2[:npri], e_ids=e_ids[:ne], e_meas=T(e_meas[:ne]),
+                e_info=e_info[:ne].reshape(-1, 6, 6), e_chi2=e_chi2[:ne])
+
+
+RefMap.add_ftr_measure = _refmap_add_ftr_measure
+RefMap.mp_pos = _refmap_mp_pos
+RefMap.global_ba = _refmap_global_ba

@@ -28,12 +28,9 @@
 
 using namespace se2lam;
 
+#include "ref_map_state.h"
+
 namespace {
-struct RefMap {
-    Map map;
-    std::vector<PtrKeyFrame> kfs;
-    std::vector<PtrMapPoint> mps;
-};
 cv::Mat mat_of(const float* v, int rows, int cols) {
     cv::Mat m(rows, cols, CV_32FC1);
     for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) m.at<float>(r, c) = v[r * cols + c];
@@ -122,6 +119,16 @@ void ref_map_set_odo(void* h, int from, int to, const double* meas3, const doubl
     std::memcpy(p.meas, meas3, sizeof(p.meas));
     std::memcpy(p.cov, cov9, sizeof(p.cov));
     m->kfs[from]->preOdomFromSelf = std::make_pair(m->kfs[to], p);
+}
+// KeyFrame::addFtrMeasureFrom / addFtrMeasureTo (src/KeyFrame.cpp:215-229): the feature constraint GlobalMapper::CreateFeatEdge leaves
+void ref_map_add_ftr_measure(void* h, int from, int to, const float* measure16, const float* info36) {
+    RefMap* m = static_cast<RefMap*>(h);
+    m->kfs[from]->addFtrMeasureFrom(m->kfs[to], mat_of(measure16, 4, 4), mat_of(info36, 6, 6));
+    m->kfs[to]->addFtrMeasureTo(m->kfs[from], mat_of(measure16, 4, 4), mat_of(info36, 6, 6));
+}
+void ref_map_mp_pos(void* h, int mp, float* pos3) {
+    const cv::Point3f p = static_cast<RefMap*>(h)->mps[mp]->getPos();
+    pos3[0] = p.x; pos3[1] = p.y; pos3[2] = p.z;
 }
 // the camera pose the reference derived from the body pose (CV_32F, row-major 4x4)
 void ref_map_kf_pose(void* h, int kf, float* Tcw16) {

@@ -5,6 +5,8 @@
 //   se2lam::Track::doTriangulate                 src/Track.cpp:373-415     (with cvu::triangulate / checkParallax, Config::acceptDepth)
 //   se2lam::Track::updateFramePose               src/Track.cpp:162-188     (frame pose from the odometry, the SE(2) pre-integration)
 //   se2lam::Localizer::DoLocalBA                 src/Localizer.cpp:233-302 (the pose-only graph, handed over at optimize())
+//   se2lam::GlobalMapper::GlobalBA               src/GlobalMapper.cpp:328-535 (the pose graph of all key frames, handed over at optimize();
+//                                                then the write-back of key-frame poses and map-point positions)
 // The members these functions work on are private in the reference's headers; this translation unit - and only this one -
 // reads the headers with `private` / `protected` spelled `public` (access specifiers do not change the object layout with
 // this compiler, and no reference source is touched).  g2o's optimize() is the stand-in's: it hands the graph, as the
@@ -32,11 +34,14 @@
 #include "Map.h"
 #include "Track.h"
 #include "Localizer.h"
+#include "LocalMapper.h"
+#include "GlobalMapper.h"
 #undef private
 #undef protected
 #include "converter.h"
 #include "cvutil.h"
 #include "optimizer.h"
+#include "ref_map_state.h"
 
 using namespace se2lam;
 
@@ -231,4 +236,63 @@ double ref_localizer_do_local_ba(const float* K9, const float* bTc16, float th_h
     return total;
 }
 
+}  // extern "C"
+
+extern "C" {
+// GlobalMapper::GlobalBA on the map of ref_map_* (key frame poses, mOdoMeasureFrom, mFtrMeasureFrom).  At optimize(GLOBAL_ITER):
+//   vertices (id order): id = mIdKF, estimate T_w_c (R, t), fixed
+//   EdgeSE3Prior (insertion order): vertex id, measurement, information (translation, rotation), chi2
+//   EdgeSE3 (insertion order: odometry edges, then feature edges): the two vertex ids, measurement, information, chi2
+// counts4 = {vertices, priors, edges, iterations asked}; returns sum chi2 at the start (no robust kernels in this graph).
+// Afterwards the reference has written the (unchanged) estimates back into the key frames and re-anchored the map points.
+double ref_global_ba(void* h, int global_iter, int cap_v, int32_t* v_id, double* v_est12, uint8_t* v_fixed, int cap_p, int32_t* p_id, double* p_meas12,
+                     double* p_info36, double* p_chi2, int cap_e, int32_t* e_ids, double* e_meas12, double* e_info36, double* e_chi2, int32_t* counts4) {
+    RefMap* m = static_cast<RefMap*>(h);
+    Config::GLOBAL_ITER = global_iter;
+    Config::GLOBAL_VERBOSE = false;
+    LocalMapper lm;
+    GlobalMapper gm;
+    gm.mpMap = &m->map;
+    gm.mpLocalMapper = &lm;
+    double total = -1;
+    std::memset(counts4, 0, 4 * sizeof(int32_t));
+    auto put_iso = [](const g2o::Isometry3D& T, double* o) {
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) o[3 * r + c] = T.linear()(r, c); o[9 + r] = T.translation()[r]; }
+    };
+    g2o::SparseOptimizer::optimizeHook() = [&](g2o::SparseOptimizer& opt, int iterations) {
+        total = 0;
+        counts4[3] = iterations;
+        for (const auto& kv : opt.vertices()) {
+            const int k = counts4[0]++;
+            if (k >= cap_v) continue;
+            v_id[k] = kv.first;
+            put_iso(static_cast<const g2o::VertexSE3*>(kv.second)->estimate(), v_est12 + 12 * k);
+            v_fixed[k] = kv.second->fixed() ? 1 : 0;
+        }
+        for (g2o::OptimizableGraph::Edge* e : opt.edges()) {
+            e->computeError();
+            const double c = e->chi2();
+            total += c;
+            if (g2o::EdgeSE3Prior* p = dynamic_cast<g2o::EdgeSE3Prior*>(e)) {
+                const int k = counts4[1]++;
+                if (k >= cap_p) continue;
+                p_id[k] = p->vertices()[0]->id();
+                put_iso(p->measurement(), p_meas12 + 12 * k);
+                for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) p_info36[36 * k + 6 * r + cc] = p->information()(r, cc);
+                p_chi2[k] = c;
+            } else if (g2o::EdgeSE3* x = dynamic_cast<g2o::EdgeSE3*>(e)) {
+                const int k = counts4[2]++;
+                if (k >= cap_e) continue;
+                e_ids[2 * k] = x->vertices()[0]->id(); e_ids[2 * k + 1] = x->vertices()[1]->id();
+                put_iso(x->measurement(), e_meas12 + 12 * k);
+                for (int r = 0; r < 6; ++r) for (int cc = 0; cc < 6; ++cc) e_info36[36 * k + 6 * r + cc] = x->information()(r, cc);
+                e_chi2[k] = c;
+            }
+        }
+    };
+    gm.GlobalBA();
+    g2o::SparseOptimizer::optimizeHook() = nullptr;
+    if (counts4[0] > cap_v || counts4[1] > cap_p || counts4[2] > cap_e) return -1.0;
+    return total;
+}
 }  // extern "C"

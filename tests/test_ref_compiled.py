@@ -831,6 +831,87 @@ def test_do_local_ba_of_the_compiled_reference(oracle, seed, n):
     assert np.isclose(out["chi2"], st["chi2_init"], rtol=1e-9, atol=0)
 
 
+def _global_map(synth, P=14, seed=3):
+    """All key frames of a small map for GlobalMapper::GlobalBA: mIdKF 0 .. P-1 on the generator's circle, each with the
+    odometry constraint to its predecessor (mOdoMeasureFrom) and feature constraints to key frames ahead (mFtrMeasureFrom);
+    measurements and informations as the CV_32F matrices the reference stores.  One map point per key frame, seen at key point 0."""
+    rng = np.random.default_rng(seed)
+    g = synth.ba_graph(P, 40, seed=seed)
+    K = np.array([[g.fx, 0, g.cx], [0, g.fx, g.cy], [0, 0, 1]], np.float32)
+    bTc = np.eye(4); bTc[:3, :3] = g.Rbc; bTc[:3, 3] = g.tbc
+    m = ref.RefMap(K, bTc, np.float32(g.huber))
+    twb = g.poses.astype(np.float32)
+    lc = np.array([[10.0, -20.0, 2500.0]], np.float32)
+    for a in range(P):
+        m.add_kf(a, 100 + a, twb[a], np.array([[320.0, 240.0]]), np.array([1]), lc)
+    Tcw = np.stack([m.kf_pose(a) for a in range(P)]).astype(np.float64)
+    Twc = np.linalg.inv(Tcw)
+    for a in range(P):                                       # a map point exactly where key frame a sees it: re-anchoring leaves it in place
+        pw = (Twc[a] @ np.r_[lc[0].astype(np.float64), 1.0])[:3]
+        m.add_mp(500 + a, pw.astype(np.float32))
+        m.observe(a, a, 0)
+
+    def constraint(i, j, sig_t, sig_r):
+        Z = (np.linalg.inv(Twc[i]) @ Twc[j] @ synth.from_mqt_np(rng.normal(0, 1.0, 6) * np.array([sig_t] * 3 + [sig_r] * 3))).astype(np.float32)
+        A = np.diag([1 / sig_t ** 2] * 3 + [1 / sig_r ** 2] * 3)
+        B = rng.normal(0, 1, (6, 6)) * 0.05
+        S = np.diag(np.sqrt(np.diag(A)))
+        W = (A + S @ (B + B.T) @ S).astype(np.float32)
+        return Z, 0.5 * (W + W.T)
+    odo, ftr = [], []
+    for a in range(1, P):
+        Z, W = constraint(a, a - 1, 3.0, 1e-3)
+        m.set_odo_se3(a, a - 1, Z, W); odo.append((a, a - 1, Z, W))
+    for a in range(P):
+        for d in (2, 3):
+            if a + d < P and (a + d) % 2 == 0:
+                Z, W = constraint(a, a + d, 8.0, 2e-3)
+                m.add_ftr_measure(a, a + d, Z, W); ftr.append((a, a + d, Z, W))
+    return m, dict(P=P, Twc=Twc, Tcw=Tcw, odo=odo, ftr=ftr, bTc=bTc, lc=lc)
+
+
+def test_global_ba_graph_of_the_compiled_reference(oracle, synth):
+    """GlobalMapper::GlobalBA (src/GlobalMapper.cpp:328-535) as compiled, on a map built through the reference's calls and
+    stopped at optimize(GLOBAL_ITER): a VertexSE3 (T_w_c) per key frame, key frame 0 fixed, the plane-motion prior of
+    addVertexSE3PlaneMotion on every one, EdgeSE3 odometry edges (this key frame -> mOdoMeasureFrom.first) and feature edges
+    (mFtrMeasureFrom), informations as stored; the cost of that graph - EdgeSE3 / EdgeSE3Prior evaluated by g2o's definition
+    in the stand-in - against the restatement of the pose-graph optimisation.  (The feature-edge rejection loop of
+    :421-483 sits behind PRE_REJECT_FTR_OUTLIER, which nothing in the reference defines: it is not part of the compiled code.)
+    Afterwards the reference writes the estimates back and re-anchors every map point on its main key frame (:497-531)."""
+    m, w = _global_map(synth)
+    P = w["P"]
+    before = np.stack([m.mp_pos(a) for a in range(P)])
+    out = m.global_ba(global_iter=15)
+    assert out["iterations"] == 15 and out["v_id"].tolist() == list(range(P)) and out["v_fixed"].tolist() == [True] + [False] * (P - 1)
+    assert out["p_id"].tolist() == list(range(P))
+    # T_w_c = cvu::inv(Tcw) in float, through toIsometry3D's quaternion
+    for a in range(P):
+        assert np.allclose(out["v_est"][a], np.linalg.inv(w["Tcw"][a]), rtol=0, atol=2e-3)
+    want = [(i, j) for i, j, _, _ in w["odo"]] + sorted((i, j) for i, j, _, _ in w["ftr"])
+    got = [tuple(x) for x in out["e_ids"].tolist()]
+    assert got[:P - 1] == want[:P - 1] and sorted(got[P - 1:]) == want[P - 1:]
+    by_pair = {(i, j): (Z, W) for i, j, Z, W in w["odo"] + w["ftr"]}
+    for (i, j), Z, W in zip(got, out["e_meas"], out["e_info"]):
+        assert np.array_equal(W, by_pair[(i, j)][1].astype(np.float64))             # toMatrix6d: the float matrix as it is
+        # toIsometry3D(cv::Mat) (converter.cpp:20-29): the rotation of the quaternion of the float matrix, NOT normalised - equal to the
+        # float matrix to its own rounding
+        assert np.allclose(Z, by_pair[(i, j)][0].astype(np.float64), rtol=0, atol=1e-6)
+    # the same graph through the restatement
+    Tq = _requat(w["bTc"].astype(np.float32).astype(np.float64))
+    pm = [oracle.pg_plane_motion_prior(_requat(out["v_est"][a]), Tq) for a in range(P)]     # toSE3Quat(pose) normalises (optimizer.cpp:430)
+    for a in range(P):
+        assert np.allclose(out["p_meas"][a], pm[a][0], rtol=0, atol=1e-9) and np.allclose(out["p_info"][a], pm[a][1], rtol=1e-9, atol=1e-9 * np.abs(pm[a][1]).max())
+    pg = synth.PoseGraph(poses=out["v_est"], fixed=out["v_fixed"].astype(np.uint8), has_prior=np.ones(P, np.uint8), prior_meas=out["p_meas"],
+                         prior_info=out["p_info"], o_i=out["e_ids"][:, 0].astype(np.int32), o_j=out["e_ids"][:, 1].astype(np.int32),
+                         o_meas=out["e_meas"], o_info=out["e_info"])
+    total, chi = oracle.pg_chi2(pg)
+    assert np.isclose(out["chi2"], total, rtol=1e-9, atol=0) and np.allclose(out["e_chi2"], chi, rtol=1e-8, atol=1e-12)
+    # write-back: poses unchanged (nothing was optimised) up to float conversions; every map point sits where its main key frame sees it
+    for a in range(P):
+        assert np.allclose(m.kf_pose(a), w["Tcw"][a], rtol=0, atol=5e-3)
+        assert np.allclose(m.mp_pos(a), before[a], rtol=0, atol=5e-3)
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
@@ -985,3 +1066,21 @@ def test_hip_pose_only_ba_starts_from_the_compiled_graph(seed, n):
     loc.DoLocalBA(T0, _requat(np.asarray(TBC, np.float64)), Xw[sel].astype(np.float64), out["e_uv"], out["e_w"], float(K[0, 0]), float(K[0, 2]),
                   float(K[1, 2]), float(np.float32(DELTA)), 30)
     assert np.isclose(loc.stats["chi2_init"], out["chi2"], rtol=1e-9, atol=0)
+
+
+@pytest.mark.gpu
+def test_hip_pose_graph_cost_equals_the_compiled_global_ba(synth):
+    """The pose graph the compiled GlobalMapper::GlobalBA built, loaded through the optimizer.h call surface: same cost."""
+    from se2lam_amd import optimizer as op
+    m, w = _global_map(synth)
+    out = m.global_ba()
+    P = w["P"]
+    pg = synth.PoseGraph(poses=out["v_est"], fixed=out["v_fixed"].astype(np.uint8), has_prior=np.ones(P, np.uint8), prior_meas=out["p_meas"],
+                         prior_info=out["p_info"], o_i=out["e_ids"][:, 0].astype(np.int32), o_j=out["e_ids"][:, 1].astype(np.int32),
+                         o_meas=out["e_meas"], o_info=out["e_info"])
+    o = op.SlamOptimizer()
+    op.load_pose_graph(o, pg)
+    o.initializeOptimization(0)
+    assert np.isclose(o.activeRobustChi2(), out["chi2"], rtol=1e-9, atol=0)
+    chi = op.edgeChi2(o, pg.O)
+    assert np.allclose(chi, out["e_chi2"], rtol=1e-8, atol=1e-12)
