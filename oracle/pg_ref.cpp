@@ -1,7 +1,8 @@
 // ORACLE - TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline leg).  PARITY UNPINNED for g2o's part (its
 // EdgeSE3 / EdgeSE3Prior / solver cannot be built here): a restatement, checked against a numpy / scipy
 // model (tests/test_pg_oracle.py).  What se2lam wrote of it - pg_ref_plane_motion_prior = addVertexSE3PlaneMotion - is held to
-// the reference's own src/optimizer.cpp compiled in oracle/_ref (tests/test_ref_compiled.py, 1e-9).
+// the reference's own src/optimizer.cpp compiled in oracle/_ref (tests/test_ref_compiled.py, 1e-9), and pg_ref_chi2 to the cost of
+// the pose graph the compiled GlobalMapper::GlobalBA builds (EdgeSE3 / EdgeSE3Prior by g2o's definition in the stand-in, 1e-9).
 //
 // pg_ref: the pose graph of GlobalMapper::GlobalBA - SURVEY.md section 8(f).4:
 //   /root/reference/src/GlobalMapper.cpp:328-535: one g2o::VertexSE3 per key frame (T_w_c; KF 0 fixed), one EdgeSE3Prior per

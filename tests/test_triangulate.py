@@ -2,7 +2,8 @@
 
 CPU: the oracle recovers synthetic 3-D points from their two projections and applies the depth / parallax gates.
 GPU: the HIP path (se2gpu_triangulate) equals the oracle bit for bit (same FP64 Jacobi sequence, no contraction).
-Parity with OpenCV's FP32 cv::SVD iteration is unpinned (OpenCV is not installed)."""
+Parity with OpenCV's FP32 cv::SVD iteration is unpinned (OpenCV is not installed); Track::doTriangulate itself runs as compiled in
+tests/test_ref_compiled.py (which matches, gates and counters: identical; positions to 1e-5)."""
 import numpy as np
 import pytest
 
