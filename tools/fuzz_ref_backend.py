@@ -5,6 +5,8 @@ MapPoint.cpp) against the restatement and the host-side product code, on random 
            extrinsic, random plane-motion informations)              vs oracle.ba_edge_information / ba_chi2
   prior    addPlaneMotionSE3Expmap / addVertexSE3PlaneMotion          vs oracle.plane_motion_prior / pg_plane_motion_prior
   sparsify Sparsifier::DoMarginalizeSE3XYZ                            vs oracle.sparsify (relative pose exact, InfoSE3 on the same H)
+  tri      Track::doTriangulate on random two-view scenes             vs oracle.triangulate (matches, flags, counters exact)
+  poseba   Localizer::DoLocalBA's graph at optimize()                 vs oracle.pose_only_ba (cost at the start)
 usage: python tools/fuzz_ref_backend.py [seconds]"""
 import dataclasses
 import os
@@ -187,13 +189,73 @@ def fuzz_sparsify(rng):
     return rel
 
 
+KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+def fuzz_tri(rng):
+    n = int(rng.integers(1, 400))
+    K = np.array([[400.0, 0, 320.0], [0, 400.0, 240.0], [0, 0, 1]], np.float32)
+    Tcr = synth.se3_exp_np(np.concatenate([rng.normal(0, 0.03, 3), rng.normal(0, 120.0, 3)])).astype(np.float32)
+    P1 = (K @ np.eye(3, 4, dtype=np.float32)).astype(np.float32); P2 = (K @ Tcr[:3]).astype(np.float32)
+    X = np.stack([rng.uniform(-1500, 1500, n), rng.uniform(-800, 800, n), rng.uniform(200, 14000, n)], 1).astype(np.float32)
+    Xh = np.concatenate([X, np.ones((n, 1), np.float32)], 1)
+    u1 = (P1 @ Xh.T).T; u1 = u1[:, :2] / u1[:, 2:]
+    u2 = (P2 @ Xh.T).T; u2 = u2[:, :2] / u2[:, 2:]
+    k1 = np.zeros(n, KP); k2 = np.zeros(n, KP)
+    k1["x"], k1["y"] = u1[:, 0], u1[:, 1]
+    perm = rng.permutation(n)
+    k2["x"][perm], k2["y"][perm] = u2[:, 0] + rng.normal(0, 0.3, n), u2[:, 1] + rng.normal(0, 0.3, n)
+    match = perm.astype(np.int32); match[rng.random(n) < 0.1] = -1
+    has_obs = (rng.random(n) < 0.15).astype(np.uint8)
+    Ocam = np.linalg.inv(Tcr.astype(np.float64))[:3, 3].astype(np.float32)
+    lower, upper = float(rng.uniform(200, 800)), float(rng.uniform(4000, 12000))
+    pos, good, m, ng, nold = ref.track_triangulate(K, k1, k2, match, has_obs, X, Tcr, lower, upper)
+    po, go, mo, ngo, noldo = oracle.triangulate(k1, k2, match, has_obs, P1, P2, Ocam, lower, upper, 2)
+    # a point whose depth or parallax sits on a gate may fall either way between two SVD routines: compare away from the gates
+    acc = (match >= 0) & (has_obs == 0) & (m >= 0) & (mo >= 0)
+    diff = (m != mo) | (good != go)
+    if diff.any():
+        z = np.where(mo >= 0, po[:, 2], pos[:, 2])
+        p1 = np.where((mo >= 0)[:, None], po, pos).astype(np.float64); p2 = p1 - Ocam
+        cosp = np.abs((p1 * p2).sum(1)) / (np.linalg.norm(p1, axis=1) * np.linalg.norm(p2, axis=1) + 1e-30)
+        near = (np.abs(z - lower) < 1e-3 * lower) | (np.abs(z - upper) < 1e-3 * upper) | (np.abs(cosp - np.cos(np.deg2rad(2.0))) < 1e-6)
+        assert near[diff].all(), ("tri", n, np.nonzero(diff & ~near)[0][:5])
+    assert nold == noldo
+    if acc.any():
+        assert np.abs(pos[acc] - po[acc]).max() <= 1e-4 * np.abs(po[acc]).max(), "tri positions"
+
+
+def fuzz_poseba(rng):
+    n = int(rng.integers(4, 300))
+    F_, CX_, CY_ = 400.0, 320.0, 240.0
+    K = np.array([[F_, 0, CX_], [0, F_, CY_], [0, 0, 1]], np.float32)
+    TBC = np.eye(4); TBC[:3, :3] = synth.RBC; TBC[:3, 3] = synth.TBC
+    pose = np.array([rng.uniform(-4000, 4000), rng.uniform(-4000, 4000), rng.uniform(-3.14, 3.14)])
+    Tcw = (synth.se3_exp_np(np.concatenate([rng.normal(0, 0.01, 3), rng.normal(0, 5.0, 3)])) @ synth.se2_to_Tcw(pose)).astype(np.float32)
+    Xc = np.stack([rng.uniform(-2000, 2000, n), rng.uniform(-1500, 1500, n), rng.uniform(1500, 8000, n)], 1)
+    Xw = ((np.linalg.inv(Tcw.astype(np.float64)) @ np.c_[Xc, np.ones(n)].T).T[:, :3]).astype(np.float32)
+    kps = np.zeros(n, KP)
+    uv = F_ * Xc[:, :2] / Xc[:, 2:] + [CX_, CY_] + rng.normal(0, 2.0, (n, 2))
+    kps["x"], kps["y"], kps["octave"] = uv[:, 0], uv[:, 1], rng.integers(0, 8, n)
+    good = (rng.random(n) < 0.85).astype(np.uint8)
+    delta = np.float32(rng.uniform(1.5, 4.0))
+    out = ref.localizer_do_local_ba(K, TBC, delta, Tcw, kps, Xw, good)
+    sel = out["e_point"]
+    assert sorted(sel.tolist()) == np.nonzero(good)[0].tolist(), "poseba points"
+    T0 = Tcw.astype(np.float64).copy(); T0[:3, :3] = _requat_rot(T0[:3, :3])
+    Tq = TBC.copy(); Tq[:3, :3] = _requat_rot(TBC[:3, :3])
+    meas, info = oracle.plane_motion_prior(T0, Tq)
+    _, st = oracle.pose_only_ba(T0, meas, info, Xw[sel].astype(np.float64), out["e_uv"], out["e_w"], F_, CX_, CY_, float(delta), 1)
+    assert np.isclose(out["chi2"], st["chi2_init"], rtol=1e-8, atol=0), ("poseba", out["chi2"], st["chi2_init"])
+
+
 def main(budget):
     rng = np.random.default_rng(int(os.environ.get("SEED", "20260926")))
     t0 = time.time()
-    n = dict(map=0, graph=0, prior=0, sparsify=0)
+    n = dict(map=0, graph=0, prior=0, sparsify=0, tri=0, poseba=0)
     worst = 0.0
     while time.time() - t0 < budget:
-        kind = ("map", "graph", "prior", "sparsify")[int(rng.integers(0, 4))]
+        kind = ("map", "graph", "prior", "sparsify", "tri", "poseba")[int(rng.integers(0, 6))]
         if kind == "map":
             fuzz_map(rng)
         elif kind == "graph":
@@ -201,6 +263,10 @@ def main(budget):
         elif kind == "prior":
             for _ in range(20):
                 fuzz_prior(rng)
+        elif kind == "tri":
+            fuzz_tri(rng)
+        elif kind == "poseba":
+            fuzz_poseba(rng)
         else:
             worst = max(worst, fuzz_sparsify(rng))
         n[kind] += 1
