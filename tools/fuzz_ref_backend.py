@@ -218,8 +218,11 @@ def fuzz_tri(rng):
         z = np.where(mo >= 0, po[:, 2], pos[:, 2])
         p1 = np.where((mo >= 0)[:, None], po, pos).astype(np.float64); p2 = p1 - Ocam
         cosp = np.abs((p1 * p2).sum(1)) / (np.linalg.norm(p1, axis=1) * np.linalg.norm(p2, axis=1) + 1e-30)
-        near = (np.abs(z - lower) < 1e-3 * lower) | (np.abs(z - upper) < 1e-3 * upper) | (np.abs(cosp - np.cos(np.deg2rad(2.0))) < 1e-6)
-        assert near[diff].all(), ("tri", n, np.nonzero(diff & ~near)[0][:5])
+        near = (np.abs(z - lower) < 1e-3 * lower) | (np.abs(z - upper) < 1e-3 * upper) | (np.abs(cosp - 0.9994) < 1e-6)      # cvu::checkParallax: cos < 0.9994 for 2 degrees
+        if not near[diff].all():
+            i = int(np.nonzero(diff & ~near)[0][0])
+            raise AssertionError(("tri", n, i, "ref", pos[i].tolist(), int(m[i]), int(good[i]), "oracle", po[i].tolist(), int(mo[i]), int(go[i]),
+                                  "depth gates", lower, upper, "cos parallax", float(cosp[i]), "true", X[i].tolist(), "has_obs", int(has_obs[i])))
     assert nold == noldo
     if acc.any():
         assert np.abs(pos[acc] - po[acc]).max() <= 1e-4 * np.abs(po[acc]).max(), "tri positions"
