@@ -917,10 +917,6 @@ __device__ inline double fast_rcp(double d) {  // v_rcp_f64 + 2 Newton steps (fu
     r = fma(fma(-d, r, 1.0), r, r);
     return r;
 }
-__device__ inline double fast_rcp1(double d) {  // v_rcp_f64 + 1 Newton step: relative error ~2e-15
-    double r = __builtin_amdgcn_rcp(d);
-    return fma(fma(-d, r, 1.0), r, r);
-}
 __device__ inline double fast_rsqrt(double d) {  // v_rsq_f64 + 2 Newton steps
     double y = __builtin_amdgcn_rsq(d);
     y = y * fma(-0.5 * d * y, y, 1.5);
@@ -1126,9 +1122,6 @@ __device__ inline d2_t load_agent(const double* p) {
 // express-copy experiment in DESIGN.md 4.1.1.)
 __device__ inline void store_agent(double* p, d2_t v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ inline void store_agent1(double* p, double v) {
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
 }
 #define SE2_WAIT_VM6(a, b, c, d, e, f) \
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
@@ -4738,7 +4731,6 @@ int ba_wait_mail(se2gpu_ba* h, double seq, const volatile uint8_t* stop_flag = n
     h->h_scal.p[0] = mb[0]; h->h_scal.p[1] = mb[1]; h->h_scal.p[2] = mb[2];
     return SE2GPU_OK;
 }
-inline bool ba_mail_ready(se2gpu_ba* h, double seq) { return ((volatile double*)h->h_mail)[3] == seq; }
 
 // multi-GPU: the all-reduced scalars go to the host mailbox too (instead of a stream synchronise + D2H copy per trial)
 __global__ void k_post_mail(const double* __restrict__ scal, volatile double* __restrict__ mail, double seq) {

@@ -279,12 +279,6 @@ __device__ __forceinline__ short2v fast_score_pk(const short2v p[16], short2v v)
     return __builtin_elementwise_max(zero, __builtin_elementwise_max(v - bmx, bmn - v));
 }
 
-// byte `i` (0..11) of the 12-byte window {w0, w1, w2}
-__device__ __forceinline__ int win_byte(uint32_t w0, uint32_t w1, uint32_t w2, int i) {
-    const uint32_t w = i < 4 ? w0 : (i < 8 ? w1 : w2);
-    return (int)((w >> (8 * (i & 3))) & 0xffu);
-}
-
 // One thread = 4 horizontally adjacent pixels of a vertical strip of kScoreRows rows.  A 7-row sliding window lives
 // in registers; every input byte is loaded once per thread with 32-bit loads (three aligned dwords per row: pixels
 // x0-4 .. x0+7) and EXPANDED once, when its row enters the window, into the nine byte pairs {b, b+1}, b = 1..9, as
@@ -334,11 +328,6 @@ __device__ __forceinline__ short2v keep_greater(short2v a, short2v b) {
     return a & m;
 }
 #undef SE2_WP
-
-// bytes x0-1 .. x0+4 of a score row: own word plus the edge bytes of the neighbouring lanes' words
-__device__ __forceinline__ unsigned long long ext_row(uint32_t own, uint32_t left, uint32_t right) {
-    return (unsigned long long)(left >> 24) | ((unsigned long long)own << 8) | ((unsigned long long)(right & 0xffu) << 40);
-}
 
 constexpr int kStripCap = kScoreGroups * kScoreRows;   // 4-pixel groups of one strip
 
