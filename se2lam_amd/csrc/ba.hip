@@ -6195,6 +6195,16 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
     // and reduction (bandwidth / issue bound) run beside them.  SE2GPU_BA_BATCH_GROUPS overrides (1 = one stream).
     static const int env_groups = [] { const char* e = getenv("SE2GPU_BA_BATCH_GROUPS"); return e ? atoi(e) : 0; }();
     int G = env_groups > 0 ? env_groups : (count >= 4 ? 2 : 1);   // (two groups pay from four windows on: 4 / 8 / 12 windows +4 / +12 / +9 %)
+    if (env_groups <= 0 && count >= 6) {
+        // windows of different sizes: a third group.  In lock step a slot lasts as long as its group's slowest window, and
+        // a window that rejects trials holds its whole group for the extra slots; with three groups fewer windows wait for
+        // any one of them.  Measured on the 64 distinct windows of the bench (30-60 key frames, six starts that reject):
+        // 85.1 k -> 102.4 k LM it/s with three groups, 64.7 k with four; uniform batches lose with three (105.8 k -> 99.4 k
+        // at 64 windows) and keep two.
+        int pmin = hs[0]->P, pmax = hs[0]->P;
+        for (int i = 1; i < count; ++i) { pmin = std::min(pmin, hs[i]->P); pmax = std::max(pmax, hs[i]->P); }
+        if (4 * (pmax - pmin) > pmax) G = 3;
+    }
     G = std::max(1, std::min(G, std::min(count, 4)));
     // the plans of the last batches are kept: a mapper (or the bench) that optimises the same windows again re-uses the
     // argument packs on the device (plain pointers, replaced on a miss; leased from the process-wide pool for this call)
