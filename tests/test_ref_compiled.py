@@ -790,6 +790,31 @@ def test_update_frame_pose_of_the_compiled_reference(synth):
         meas, cov, last = out["meas"], out["cov"], odom
 
 
+def test_cpp_preintegration_mirror_equals_the_compiled_update_frame_pose(tmp_path, synth):
+    """include/se2lam_amd/preintegration.h run by tests/cpp_adapters_compile.cpp over its twelve odometry readings, against the
+    reference's own compiled Track::updateFramePose on the same readings: measurement and covariance to 1e-12 (the numpy
+    test of tests/test_capi.py holds them to 1e-5 only, float libm differences aside)."""
+    import subprocess
+    from test_capi import _build_adapter_binary
+    exe = _build_adapter_binary(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("PRESE2")][0]
+    v = np.array(line.split()[1:], dtype=np.float64)
+    meas_c, cov_c = v[:3], v[3:12].reshape(3, 3)
+    f32 = np.float32
+    bTc = np.eye(4); bTc[:3, :3] = synth.RBC; bTc[:3, 3] = synth.TBC
+    noise = np.array([2.0, 2.0, 0.002], f32)
+    last = np.array([100, -20, 0.3], f32)
+    meas, cov = np.zeros(3), np.zeros(9)
+    for k in range(1, 13):
+        now = np.array([f32(100) + f32(35) * f32(k) + f32(3) * f32(k % 3), f32(-20) + f32(4) * f32(k) - f32(2) * f32(k % 2),
+                        f32(0.3) + f32(0.021) * f32(k)], f32)
+        out = ref.track_update_frame_pose(bTc, noise, last, [0.0, 0.0, 0.0], last, now, meas, cov)
+        meas, cov, last = out["meas"], out["cov"], now
+    assert np.allclose(meas_c, meas, rtol=1e-12, atol=1e-12)
+    assert np.allclose(cov_c, cov.reshape(3, 3), rtol=1e-12, atol=1e-18)
+
+
 def _pose_only_case(seed, n):
     from test_pose_ba import _case, TBC, F, CX, CY, DELTA
     Tcw_true, Tcw0, Xw, uv, w, pose = _case(seed, n, 0.1)
