@@ -27,7 +27,9 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -411,23 +413,31 @@ public:
     static void compute(InputArray src, OutputArray w, OutputArray u, OutputArray vt, int flags = 0);
 };
 
-// cv::FileStorage: only Config::readConfig() (never called by the oracle) touches it - declared so that Config.cpp compiles
+// cv::FileStorage: Config::readConfig() and the YAML save / load members of DBoW2's TemplatedVocabulary name it; nothing in
+// oracle/_ref calls them (the vocabulary is read with loadFromBinaryFile) - declared so that those sources compile, loud if used
 class FileNode {
+    [[noreturn]] static void no() { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
 public:
     bool empty() const { return true; }
-    operator int() const { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
-    operator float() const { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
-    operator double() const { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
+    size_t size() const { return 0; }
+    FileNode operator[](const char*) const { return FileNode(); }
+    FileNode operator[](const std::string&) const { return FileNode(); }
+    FileNode operator[](int) const { return FileNode(); }
+    FileNode operator[](unsigned) const { return FileNode(); }
+    template <typename T, typename = typename std::enable_if<std::is_arithmetic<T>::value>::type> operator T() const { no(); }
+    operator std::string() const { no(); }
 };
 template <typename T> inline void operator>>(const FileNode&, T&) { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
 class FileStorage {
 public:
     enum { READ = 0, WRITE = 1 };
+    FileStorage() {}
     FileStorage(const std::string&, int) {}
     bool isOpened() const { return false; }
     FileNode operator[](const char*) const { return FileNode(); }
     FileNode operator[](const std::string&) const { return FileNode(); }
     void release() {}
 };
+template <typename T> inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
 
 }  // namespace cv

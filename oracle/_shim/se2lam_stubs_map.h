@@ -1,9 +1,8 @@
 // ORACLE - TEST INFRASTRUCTURE ONLY (oracle/_ref, second library: libse2lam_ref_map.so).  Pre-included (-include) in front of
 // every reference source file of the MAP build, where src/Map.cpp, src/KeyFrame.cpp and src/MapPoint.cpp are compiled with
 // their own headers, and with them the threads - src/Track.cpp, src/LocalMapper.cpp, src/GlobalMapper.cpp, src/Localizer.cpp,
-// src/Sensors.cpp - and src/sparsifier.cpp.  What is cut off: the DBoW2 vocabulary template (KeyFrame::ComputeBoW calls
-// transform(), the loop detectors score()), ROS (ros::Rate / ros::ok in the run() loops, never entered), the publishers and
-// OdoSLAM's main().
+// src/Sensors.cpp -, src/sparsifier.cpp and the vendored DBoW2 (Thirdparty/DBoW2: the vocabulary template, FORB, the scoring
+// objects).  What is cut off: ROS (ros::Rate / ros::ok in the run() loops, never entered), the publishers and OdoSLAM's main().
 #pragma once
 #include <climits>
 #include <deque>
@@ -20,16 +19,4 @@
 #include "Thirdparty/DBoW2/DBoW2/BowVector.h"
 #include "Thirdparty/DBoW2/DBoW2/FeatureVector.h"
 
-using namespace std;   // Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:34 does this at global scope, and KeyFrame.h relies on it
-
-#define ORBVOCABULARY_H
-
-namespace se2lam {
-
-class ORBVocabulary {   // include/se2lam/ORBVocabulary.h: DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>
-public:
-    void transform(const std::vector<cv::Mat>&, DBoW2::BowVector&, DBoW2::FeatureVector&, int) const {}
-    double score(const DBoW2::BowVector&, const DBoW2::BowVector&) const { return 0; }
-};
-
-}  // namespace se2lam
+using namespace std;   // Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:38 does this at global scope, and KeyFrame.h relies on it

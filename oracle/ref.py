@@ -635,3 +635,50 @@ def _refmap_global_ba(self, global_iter=15, cap_v=4096, cap_e=1 << 16):
 RefMap.add_ftr_measure = _refmap_add_ftr_measure
 RefMap.mp_pos = _refmap_mp_pos
 RefMap.global_ba = _refmap_global_ba
+
+
+# ---- the vendored DBoW2 vocabulary (Thirdparty/DBoW2, compiled from the reference's tree; oracle/ref_voc_driver.cpp)
+class RefVocabulary:
+    """se2lam::ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, loaded with loadFromBinaryFile"""
+
+    def __init__(self, path):
+        self._l = lib_map()
+        info = np.zeros(6, np.int32)
+        f = self._l.ref_voc_load
+        f.restype = C.c_void_p
+        f.argtypes = [C.c_char_p, C.c_void_p]
+        self._h = C.c_void_p(f(str(path).encode(), info.ctypes.data))
+        self.k, self.L, self.words, self.scoring, self.weighting = (int(x) for x in info[:5])
+        self.loaded = bool(info[5])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.ref_voc_free.argtypes = [C.c_void_p]
+            self._l.ref_voc_free(self._h)
+            self._h = None
+
+    def transform(self, desc, levelsup):
+        """-> (word ids, word values, {node id: [feature indices]})"""
+        d = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(d)
+        bid = np.zeros(max(n, 1), np.uint32); bval = np.zeros(max(n, 1)); nb = np.zeros(1, np.int32)
+        node = np.zeros(max(n, 1), np.int32); ptr = np.zeros(max(n, 1) + 1, np.int32); idx = np.zeros(max(n, 1), np.int32); nn = np.zeros(1, np.int32)
+        f = self._l.ref_voc_transform
+        f.restype = C.c_int
+        VP = C.c_void_p
+        f.argtypes = [VP, VP, C.c_int, C.c_int, C.c_int, VP, VP, VP, C.c_int, VP, VP, C.c_int, VP, VP]
+        rc = f(self._h, d.ctypes.data, n, int(levelsup), len(bid), bid.ctypes.data, bval.ctypes.data, nb.ctypes.data, len(node), node.ctypes.data,
+               ptr.ctypes.data, len(idx), idx.ctypes.data, nn.ctypes.data)
+        assert rc == 0
+        k, m = int(nb[0]), int(nn[0])
+        fv = {int(node[i]): idx[ptr[i]:ptr[i + 1]].tolist() for i in range(m)}
+        return bid[:k].tolist(), bval[:k].copy(), fv
+
+    def score(self, a, b):
+        ia = np.ascontiguousarray(a[0], np.uint32); va = np.ascontiguousarray(a[1], np.float64)
+        ib = np.ascontiguousarray(b[0], np.uint32); vb = np.ascontiguousarray(b[1], np.float64)
+        f = self._l.ref_voc_score
+        f.restype = C.c_double
+        VP = C.c_void_p
+        f.argtypes = [VP, C.c_int, VP, VP, C.c_int, VP, VP]
+        return float(f(self._h, len(ia), ia.ctypes.data, va.ctypes.data, len(ib), ib.ctypes.data, vb.ctypes.data))
