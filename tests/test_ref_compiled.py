@@ -986,6 +986,22 @@ def test_vocabulary_mirror_equals_the_compiled_dbow2(tmp_path, k, L, scoring, we
     assert scores[1] == pytest.approx(v.score(got[0][:2], got[0][:2]), rel=1e-14, abs=1e-16)
 
 
+def test_back_end_sweep_smoke(capfd):
+    """A few rounds of every kind of tools/fuzz_ref_backend.py (the long runs are kept under profiles/): random maps, windows,
+    priors, key-frame pairs, two-view scenes and pose-only problems through the compiled reference and the restatement."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_ref_backend", os.path.join(ROOT, "tools", "fuzz_ref_backend.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(20260926)
+    for _ in range(3):
+        fz.fuzz_map(rng); fz.fuzz_graph(rng); fz.fuzz_tri(rng); fz.fuzz_poseba(rng)
+        for _ in range(5):
+            fz.fuzz_prior(rng)
+        assert fz.fuzz_sparsify(rng) >= 0.0
+    capfd.readouterr()          # (Localizer::DoLocalBA prints its timing to stderr)
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
