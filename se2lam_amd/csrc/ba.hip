@@ -6239,10 +6239,19 @@ int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const v
         *slot_out = victim;
         return SE2GPU_OK;
     };
+    // windows of unequal size are dealt to the groups by size (largest first): a group's slot then waits for windows of
+    // its own size class only
+    std::vector<se2gpu_ba*> by_size;
+    se2gpu_ba** ghs_all = hs;
+    if (G == 3 && env_groups <= 0) {
+        by_size.assign(hs, hs + count);
+        std::stable_sort(by_size.begin(), by_size.end(), [](const se2gpu_ba* a, const se2gpu_ba* b) { return a->P > b->P; });
+        ghs_all = by_size.data();
+    }
     for (int g = 0; g < G; ++g) {
         const int b0 = (int)((long long)count * g / G), b1 = (int)((long long)count * (g + 1) / G);
-        groups[g] = Group{nullptr, hs + b0, b1 - b0, false, -1};
-        SE2_CHECK(acquire(hs + b0, b1 - b0, &groups[g].bp, &groups[g].slot, groups));
+        groups[g] = Group{nullptr, ghs_all + b0, b1 - b0, false, -1};
+        SE2_CHECK(acquire(ghs_all + b0, b1 - b0, &groups[g].bp, &groups[g].slot, groups));
     }
     // ---- prologue of every window (ba_run_begin) and the order behind whatever was enqueued for it before
     for (Group& g : groups) {
