@@ -7,6 +7,7 @@ MapPoint.cpp) against the restatement and the host-side product code, on random 
   sparsify Sparsifier::DoMarginalizeSE3XYZ                            vs oracle.sparsify (relative pose exact, InfoSE3 on the same H)
   tri      Track::doTriangulate on random two-view scenes             vs oracle.triangulate (matches, flags, counters exact)
   poseba   Localizer::DoLocalBA's graph at optimize()                 vs oracle.pose_only_ba (cost at the start)
+  pg       GlobalMapper::GlobalBA's graph at optimize()               vs oracle.pg_chi2 (cost and per-edge chi2)
 usage: python tools/fuzz_ref_backend.py [seconds]"""
 import dataclasses
 import os
@@ -256,13 +257,27 @@ def fuzz_poseba(rng):
     assert np.isclose(out["chi2"], st["chi2_init"], rtol=1e-8, atol=0), ("poseba", out["chi2"], st["chi2_init"])
 
 
+def fuzz_pg(rng):
+    import test_ref_compiled as T
+    P = int(rng.integers(3, 30))
+    m, w = T._global_map(synth, P, int(rng.integers(0, 1 << 30)))
+    out = m.global_ba(global_iter=int(rng.integers(1, 40)))
+    assert out["v_id"].tolist() == list(range(P)) and out["v_fixed"].tolist() == [True] + [False] * (P - 1), "pg vertices"
+    assert len(out["e_ids"]) == len(w["odo"]) + len(w["ftr"]), "pg edges"
+    pg = synth.PoseGraph(poses=out["v_est"], fixed=out["v_fixed"].astype(np.uint8), has_prior=np.ones(P, np.uint8), prior_meas=out["p_meas"],
+                         prior_info=out["p_info"], o_i=out["e_ids"][:, 0].astype(np.int32), o_j=out["e_ids"][:, 1].astype(np.int32),
+                         o_meas=out["e_meas"], o_info=out["e_info"])
+    total, chi = oracle.pg_chi2(pg)
+    assert np.isclose(out["chi2"], total, rtol=1e-8, atol=0) and np.allclose(out["e_chi2"], chi, rtol=1e-7, atol=1e-10), ("pg", out["chi2"], total)
+
+
 def main(budget):
     rng = np.random.default_rng(int(os.environ.get("SEED", "20260926")))
     t0 = time.time()
-    n = dict(map=0, graph=0, prior=0, sparsify=0, tri=0, poseba=0)
+    n = dict(map=0, graph=0, prior=0, sparsify=0, tri=0, poseba=0, pg=0)
     worst = 0.0
     while time.time() - t0 < budget:
-        kind = ("map", "graph", "prior", "sparsify", "tri", "poseba")[int(rng.integers(0, 6))]
+        kind = ("map", "graph", "prior", "sparsify", "tri", "poseba", "pg")[int(rng.integers(0, 7))]
         if kind == "map":
             fuzz_map(rng)
         elif kind == "graph":
@@ -274,6 +289,8 @@ def main(budget):
             fuzz_tri(rng)
         elif kind == "poseba":
             fuzz_poseba(rng)
+        elif kind == "pg":
+            fuzz_pg(rng)
         else:
             worst = max(worst, fuzz_sparsify(rng))
         n[kind] += 1
