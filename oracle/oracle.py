@@ -291,6 +291,15 @@ def orb_extract(img, params=None, cap=4096):
     return kps[:n.value].copy(), desc[:n.value].copy()
 
 
+def orb_trig_libm(on: bool):
+    """descriptor steering angle through libm's cosf / sinf (what the reference's C++ resolves to) instead of the rounded double
+    cosine / sine - see Extractor::descriptor in orb_ref.cpp"""
+    f = lib().orb_ref_set_trig_libm
+    f.restype = None
+    f.argtypes = [C.c_int]
+    f(1 if on else 0)
+
+
 def orb_tables(params=None):
     params = params or orb_params()
     L = params.nlevels

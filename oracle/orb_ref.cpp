@@ -10,7 +10,10 @@
 // That pins the constructor's tables, the pyramid loop, the cell grid / quota redistribution / 20-7 threshold rule, the
 // level cut, IC_Angle, computeOrbDescriptor, HarrisResponses and operator().  The OpenCV functions those call (FAST, resize,
 // copyMakeBorder, GaussianBlur, retainBest, fastAtan2, cvRound) are restated here and, independently, in
-// oracle/_shim/cv_shim.cpp; the two agree bit for bit, the real library could not be run.  Pinned
+// oracle/_shim/cv_shim.cpp; the two agree bit for bit, the real library could not be run.
+// One known, understood difference: the descriptor's steering cosine / sine - the reference's expression resolves to libm's
+// cosf / sinf, this restatement rounds the double values (see Extractor::descriptor; orb_ref_set_trig_libm switches): about
+// one descriptor in two million differs by one or two bits under glibc 2.35, none in libm mode.  Pinned
 // from the tree itself in tests/test_orb_oracle.py: the 256x4 pattern table (sha256), umax, per-level quotas / sizes / cell
 // grids, EDGE_THRESHOLD / PATCH_SIZE, the Gaussian taps.
 //
@@ -61,6 +64,7 @@ const int kPattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
+static int g_trig_libm = 0;   // see Extractor::descriptor
 inline int cv_round(double v) { return (int)std::nearbyint(v); }  // default rounding mode: half to even
 inline int cv_round(float v) { return (int)std::nearbyintf(v); }
 inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
@@ -506,7 +510,16 @@ struct Extractor {
     void descriptor(const Level& L, const orb_ref_keypoint& kpt, uint8_t* desc) const {
         const float factorPI = (float)(3.14159265358979323846 / 180.f);
         const float angle = (float)kpt.angle * factorPI;
-        const float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+        // The reference writes `(float)cos(angle)` with a float argument under `using namespace std` (src/ORBextractor.cpp:166): C++
+        // picks the FLOAT overloads, i.e. libm's cosf / sinf - which are not correctly rounded (glibc 2.35: sinf(0.509999156f) is one
+        // ulp below the rounded double sine), so what the reference computes depends on the libm it is linked with.  The restatement
+        // (and the HIP path) round the DOUBLE cosine / sine to float - libm-independent; one descriptor in about two million
+        // differs in two bits from the reference compiled here, where a sampling coordinate sits on a .5 tie (found by
+        // tools/fuzz_ref.py).  g_trig_libm = 1 switches this restatement to cosf / sinf so that the comparison with oracle/_ref is
+        // exact on the machine at hand.
+        float a, b;
+        if (g_trig_libm) { a = cosf(angle); b = sinf(angle); }
+        else { a = (float)std::cos((double)angle); b = (float)std::sin((double)angle); }
         const uint8_t* center = &L.blur[(size_t)(cv_round(kpt.y) + EDGE_THRESHOLD) * L.stride + cv_round(kpt.x) + EDGE_THRESHOLD];
         const int step = L.stride;
         const int* pat = kPattern;
@@ -619,6 +632,7 @@ void orb_ref_pattern(int32_t* out1024) { for (int i = 0; i < 1024; ++i) out1024[
 void orb_ref_gaussian_taps(int32_t* out7) { int t[7]; Extractor::gaussian_taps(t); for (int i = 0; i < 7; ++i) out7[i] = t[i]; }
 float orb_ref_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 int orb_ref_cv_round(float v) { return cv_round(v); }
+void orb_ref_set_trig_libm(int on) { g_trig_libm = on; }
 int orb_ref_fast_score(const uint8_t* center, int stride) { return Extractor::fast_score(center, stride); }
 
 }  // extern "C"

@@ -97,6 +97,28 @@ def test_extractor_odd_sizes_noise_and_flat_images(oracle, synth):
     assert len(ref.orb_extract(cases[5])[0]) == 0
 
 
+def test_descriptor_steering_goes_through_libm_float_trig_in_the_reference(oracle):
+    """src/ORBextractor.cpp:166 writes `(float)cos(angle)` / `(float)sin(angle)` with a FLOAT angle under `using namespace std`:
+    that resolves to the float overloads, i.e. libm's cosf / sinf, which glibc does not round correctly (sinf(0.509999156f) is
+    one ulp below the rounded double sine).  The restatement - like the HIP kernel - rounds the DOUBLE cosine / sine; a steered
+    sampling coordinate that lands exactly on a .5 tie under one of the two then rounds to the other pixel.  Found by
+    tools/fuzz_ref.py (about one descriptor in two million, one or two bits).  With the restatement switched to libm's float
+    trig it equals the compiled reference exactly on such a frame; in its default mode the key points are identical and the
+    descriptors differ in at most a few bits (none where this machine's libm happens to round these arguments correctly)."""
+    img = np.random.default_rng(151).integers(0, 256, (200, 240)).astype(np.uint8)
+    p = oracle.orb_params(3000, 1.2, 4, 20, 0)
+    kr, dr = _canon(*ref.orb_extract(img, p))
+    ka, da = _canon(*oracle.orb_extract(img, p, cap=16384))
+    oracle.orb_trig_libm(True)
+    try:
+        kc, dc = _canon(*oracle.orb_extract(img, p, cap=16384))
+    finally:
+        oracle.orb_trig_libm(False)
+    assert len(kr) == 3000 and np.array_equal(kc, kr) and np.array_equal(dc, dr)
+    assert np.array_equal(ka, kr)
+    assert (da != dr).any(1).sum() <= 1 and np.unpackbits(da ^ dr).sum() <= 2
+
+
 def test_retain_best_as_the_library_text_differs_only_in_ties(oracle, synth):
     """SE2_REF_RETAIN=std runs KeyPointsFilter::retainBest as OpenCV writes it (std::nth_element + std::partition, whatever
     this libstdc++ does with equal responses).  Against the canonical tie rule: the same number of key points per level, the

@@ -19,7 +19,7 @@ def canon(k, d):
 def main(budget):
     rng = np.random.default_rng(int(os.environ.get("SEED", "20260926")))
     t0 = time.time()
-    n_ex = n_mw = n_raise = 0
+    n_ex = n_mw = n_raise = n_trig = 0
     feats = []
     while time.time() - t0 < budget:
         kind = rng.integers(0, 4)
@@ -56,7 +56,20 @@ def main(budget):
             print("reference raises:", img.shape, p.nfeatures, round(p.scale_factor, 2), p.nlevels, "oracle key points:", len(a[0]))
             continue
         ka, da = canon(*a); kb, db = canon(*b)
-        assert len(ka) == len(kb) and np.array_equal(ka, kb) and np.array_equal(da, db), ("extract", img.shape, p.nfeatures, p.scale_factor, p.nlevels, p.fast_th, p.score_type)
+        assert len(ka) == len(kb) and np.array_equal(ka, kb), ("extract", img.shape, p.nfeatures, p.scale_factor, p.nlevels, p.fast_th, p.score_type)
+        if not np.array_equal(da, db):
+            # the reference's cos(angle) / sin(angle) are libm's cosf / sinf (float overloads), not correctly rounded: with the
+            # restatement switched to them the descriptors must be identical; the default (rounded double trig) may differ in a
+            # few bits of one descriptor where a sampling coordinate sits on a .5 tie
+            oracle.orb_trig_libm(True)
+            try:
+                kc, dc = canon(*oracle.orb_extract(img, p, cap=16384))
+            finally:
+                oracle.orb_trig_libm(False)
+            assert np.array_equal(kc, kb) and np.array_equal(dc, db), ("extract (libm trig)", img.shape, p.nfeatures, p.scale_factor, p.nlevels, p.fast_th, p.score_type)
+            rows = int((da != db).any(1).sum()); bits = int(np.unpackbits(da ^ db).sum())
+            n_trig += 1
+            print("libm-dependent descriptor:", img.shape, p.nfeatures, round(p.scale_factor, 2), p.nlevels, "-", rows, "descriptor(s),", bits, "bit(s) of", len(da))
         n_ex += 1
         if len(b[0]) > 20:
             feats.append(b)
@@ -71,7 +84,8 @@ def main(budget):
             assert r[1] == o[1] and np.array_equal(r[0], o[0]) and np.array_equal(r[2], o[2]), ("window", win, lo, mn, mx, ratio)
             n_mw += 1
     print(f"fuzz_ref: {n_ex} extractor cases, {n_mw} MatchByWindow cases in {time.time() - t0:.0f} s - compiled reference == restatement"
-          f" ({n_raise} inputs on which the reference itself raises)")
+          f" ({n_raise} inputs on which the reference itself raises; {n_trig} frames with a descriptor that depends on libm's cosf / sinf,"
+          f" identical with the restatement in its libm mode)")
 
 
 if __name__ == "__main__":
