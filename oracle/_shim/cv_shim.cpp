@@ -10,6 +10,8 @@
 #include "cv_shim.hpp"
 
 #include <cfloat>
+#include <cstdio>
+#include <map>
 #include <cstdlib>
 
 namespace cv {
@@ -585,4 +587,144 @@ void SVD::compute(InputArray _src, OutputArray _w, OutputArray _u, OutputArray _
     U.copyTo(_u.getMatRef());
 }
 
+}  // namespace cv
+
+// ------------------------------------------------------------------------------------------------ FileStorage (structure only)
+namespace cv {
+namespace {
+std::map<std::string, std::vector<FsNodePtr>>& fs_files() {
+    static std::map<std::string, std::vector<FsNodePtr>> files;
+    return files;
+}
+char fs_dt(int depth) {
+    switch (depth) {
+        case CV_8U: return 'u';
+        case CV_8S: return 'c';
+        case CV_16U: return 'w';
+        case CV_16S: return 's';
+        case CV_32S: return 'i';
+        case CV_32F: return 'f';
+        case CV_64F: return 'd';
+    }
+    throw std::runtime_error("cv shim: FileStorage: matrix depth");
+}
+int fs_depth(char dt) {
+    switch (dt) {
+        case 'u': return CV_8U;
+        case 'c': return CV_8S;
+        case 'w': return CV_16U;
+        case 's': return CV_16S;
+        case 'i': return CV_32S;
+        case 'f': return CV_32F;
+        case 'd': return CV_64F;
+    }
+    throw std::runtime_error("cv shim: FileStorage: matrix dt");
+}
+void fs_dump_node(const FsNode& n, std::ostringstream& os) {
+    char buf[32];
+    switch (n.kind) {
+        case FsNode::INT: os << "I " << n.i << "\n"; break;
+        case FsNode::REAL: {
+            uint64_t b;
+            std::memcpy(&b, &n.r, 8);
+            std::snprintf(buf, sizeof buf, "%016llx", (unsigned long long)b);
+            os << "R " << buf << "\n";
+            break;
+        }
+        case FsNode::STR: os << "S " << n.s << "\n"; break;
+        case FsNode::SEQ:
+        case FsNode::MAP: {
+            const bool map = n.kind == FsNode::MAP;
+            os << (map ? "{" : "[") << (n.flow ? ":" : "") << "\n";
+            for (const auto& kv : n.kids) {
+                if (map) os << "K " << kv.first << "\n";
+                fs_dump_node(*kv.second, os);
+            }
+            os << (map ? "}" : "]") << "\n";
+            break;
+        }
+        case FsNode::MAT: {
+            os << "M " << n.m.rows << " " << n.m.cols << " " << fs_dt(n.m.depth()) << " ";
+            const size_t rb = (size_t)n.m.cols * n.m.elemSize();
+            for (int r = 0; r < n.m.rows; ++r)
+                for (size_t k = 0; k < rb; ++k) { std::snprintf(buf, sizeof buf, "%02x", n.m.ptr(r)[k]); os << buf; }
+            os << "\n";
+            break;
+        }
+        default: throw std::runtime_error("cv shim: FileStorage: empty node in a file");
+    }
+}
+}  // namespace
+
+std::vector<FsNodePtr>& shim_fs_file(const std::string& path) { return fs_files()[path]; }
+bool shim_fs_exists(const std::string& path) { return fs_files().count(path) != 0; }
+void shim_fs_erase(const std::string& path) { fs_files().erase(path); }
+
+FsNodePtr shim_fs_node(const Mat& m) {      // cvWrite of a CvMat: !!opencv-matrix {rows, cols, dt, data}; an empty Mat is 0 x 0 of 'u'
+    if (m.channels() != 1 && !m.empty()) throw std::runtime_error("cv shim: FileStorage: multi-channel matrix");
+    FsNodePtr p = std::make_shared<FsNode>();
+    p->kind = FsNode::MAT;
+    if (m.empty()) p->m = Mat();
+    else p->m = m.clone();
+    return p;
+}
+void shim_fs_read(const FileNode& n, Mat& v) {
+    if (n.empty()) { v.release(); return; }     // read(node, mat, default_mat): the default is an empty matrix
+    if (n.kind() != FsNode::MAT) throw std::runtime_error("cv shim: FileNode is not a matrix");
+    v = n.n->m.clone();
+}
+
+std::string shim_fs_dump(const std::string& path) {
+    if (!shim_fs_exists(path)) throw std::runtime_error("cv shim: no such file: " + path);
+    std::ostringstream os;
+    for (const FsNodePtr& d : shim_fs_file(path)) {
+        os << "D\n";
+        for (const auto& kv : d->kids) { os << "K " << kv.first << "\n"; fs_dump_node(*kv.second, os); }
+    }
+    return os.str();
+}
+
+void shim_fs_inject(const std::string& path, const std::string& events) {
+    shim_fs_erase(path);
+    std::vector<FsNodePtr>& docs = shim_fs_file(path);
+    std::vector<FsNodePtr> open;      // open containers; open[0] = the current document
+    std::string key;
+    std::istringstream is(events);
+    std::string line;
+    auto add = [&](const FsNodePtr& v) {
+        if (open.empty()) throw std::runtime_error("cv shim: inject: value before the first D");
+        FsNode& t = *open.back();
+        if (t.kind == FsNode::MAP && key.empty()) throw std::runtime_error("cv shim: inject: value without a key inside a map");
+        t.kids.emplace_back(t.kind == FsNode::MAP ? key : std::string(), v);
+        key.clear();
+    };
+    while (std::getline(is, line)) {
+        if (line.empty()) continue;
+        const char c = line[0];
+        const std::string rest = line.size() > 2 ? line.substr(2) : std::string();
+        FsNodePtr p = std::make_shared<FsNode>();
+        if (c == 'D') { p->kind = FsNode::MAP; docs.push_back(p); open.assign(1, p); }
+        else if (c == 'K') key = rest;
+        else if (c == 'I') { p->kind = FsNode::INT; p->i = std::stoi(rest); add(p); }
+        else if (c == 'R') { p->kind = FsNode::REAL; const uint64_t b = std::stoull(rest, nullptr, 16); std::memcpy(&p->r, &b, 8); add(p); }
+        else if (c == 'S') { p->kind = FsNode::STR; p->s = rest; add(p); }
+        else if (c == '[' || c == '{') { p->kind = c == '[' ? FsNode::SEQ : FsNode::MAP; p->flow = line.size() > 1 && line[1] == ':'; add(p); open.push_back(p); }
+        else if (c == ']' || c == '}') {
+            if (open.size() < 2 || open.back()->kind != (c == ']' ? FsNode::SEQ : FsNode::MAP)) throw std::runtime_error("cv shim: inject: unbalanced " + line);
+            open.pop_back();
+        } else if (c == 'M') {
+            std::istringstream ms(rest);
+            int rows, cols; char dt; std::string hex;
+            ms >> rows >> cols >> dt >> hex;
+            p->kind = FsNode::MAT;
+            if (rows > 0 && cols > 0) {
+                p->m.create(rows, cols, fs_depth(dt));
+                const size_t bytes = (size_t)rows * cols * p->m.elemSize();
+                if (hex.size() != 2 * bytes) throw std::runtime_error("cv shim: inject: matrix data length");
+                for (size_t k = 0; k < bytes; ++k) p->m.data[k] = (uchar)std::stoi(hex.substr(2 * k, 2), nullptr, 16);
+            }
+            add(p);
+        } else throw std::runtime_error("cv shim: inject: unknown line " + line);
+    }
+}
 }  // namespace cv

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <cctype>
 #include <sstream>
 #include <stdexcept>
 #include <type_traits>
@@ -413,31 +414,203 @@ public:
     static void compute(InputArray src, OutputArray w, OutputArray u, OutputArray vt, int flags = 0);
 };
 
-// cv::FileStorage: Config::readConfig() and the YAML save / load members of DBoW2's TemplatedVocabulary name it; nothing in
-// oracle/_ref calls them (the vocabulary is read with loadFromBinaryFile) - declared so that those sources compile, loud if used
-class FileNode {
-    [[noreturn]] static void no() { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
-public:
-    bool empty() const { return true; }
-    size_t size() const { return 0; }
-    FileNode operator[](const char*) const { return FileNode(); }
-    FileNode operator[](const std::string&) const { return FileNode(); }
-    FileNode operator[](int) const { return FileNode(); }
-    FileNode operator[](unsigned) const { return FileNode(); }
-    template <typename T, typename = typename std::enable_if<std::is_arithmetic<T>::value>::type> operator T() const { no(); }
-    operator std::string() const { no(); }
+// cv::FileStorage, STRUCTURE ONLY: a file is a list of documents (one per WRITE / APPEND session) of nested maps,
+// sequences, integers, reals, strings and matrices, kept in memory under its path - no YAML text is produced or parsed (the
+// emitter and the parser are OpenCV's `persistence.cpp`, not se2lam's).  What is a reading of OpenCV 3.2 here is the small
+// state machine behind `fs << "name" << value << "[" ... "]"` (operator<<(FileStorage&, const String&) in persistence.cpp),
+// how points and matrices become nodes, and how FileNode converts on the way back.  It lets the reference's
+// MapStorage::saveMap / loadMap (and Config::readConfig, DBoW2's YAML save / load) run as compiled: the test compares the
+// node structure they write / expect with the one include/se2lam_amd/MapStorage.h writes / expects.  shim_fs_dump /
+// shim_fs_inject move a file in and out as one line per node:
+//     D | K name | I int | R <16 hex digits of the double> | S string | [ [: ] { {: } | M rows cols dt <hex bytes>
+struct FsNode {
+    enum { NONE = 0, INT = 1, REAL = 2, STR = 3, SEQ = 5, MAP = 6, MAT = 7 };
+    int kind = NONE;
+    bool flow = false;
+    int i = 0;
+    double r = 0;
+    std::string s;
+    Mat m;
+    std::vector<std::pair<std::string, std::shared_ptr<FsNode>>> kids;   // (names are empty inside a sequence)
 };
-template <typename T> inline void operator>>(const FileNode&, T&) { throw std::runtime_error("cv shim: FileStorage is not implemented"); }
+typedef std::shared_ptr<FsNode> FsNodePtr;
+std::vector<FsNodePtr>& shim_fs_file(const std::string& path);     // the documents of a file (created empty if unknown)
+bool shim_fs_exists(const std::string& path);
+void shim_fs_erase(const std::string& path);
+std::string shim_fs_dump(const std::string& path);
+void shim_fs_inject(const std::string& path, const std::string& events);
+
+class FileNodeIterator;
+class FileNode {
+public:
+    FsNodePtr n;
+    FileNode() {}
+    explicit FileNode(const FsNodePtr& p) : n(p) {}
+    int kind() const { return n ? n->kind : (int)FsNode::NONE; }
+    bool empty() const { return kind() == FsNode::NONE; }
+    bool isNone() const { return empty(); }
+    bool isSeq() const { return kind() == FsNode::SEQ; }
+    bool isMap() const { return kind() == FsNode::MAP; }
+    size_t size() const { const int k = kind(); return k == FsNode::SEQ || k == FsNode::MAP ? n->kids.size() : (k == FsNode::NONE ? 0 : 1); }
+    FileNode operator[](const std::string& name) const {
+        if (kind() == FsNode::MAP)
+            for (const auto& kv : n->kids) if (kv.first == name) return FileNode(kv.second);
+        return FileNode();
+    }
+    FileNode operator[](const char* name) const { return (*this)[std::string(name)]; }
+    FileNode operator[](int i) const {
+        if (kind() != FsNode::SEQ || i < 0 || i >= (int)n->kids.size()) throw std::runtime_error("cv shim: FileNode[i] outside a sequence");
+        return FileNode(n->kids[i].second);
+    }
+    FileNode operator[](unsigned i) const { return (*this)[(int)i]; }
+    // (OpenCV: a missing node reads as 0 / "", a real read as an integer goes through cvRound)
+    template <typename T, typename = typename std::enable_if<std::is_arithmetic<T>::value>::type> operator T() const {
+        const int k = kind();
+        if (k == FsNode::INT) return (T)n->i;
+        if (k == FsNode::REAL) return std::is_integral<T>::value ? (T)cvRound(n->r) : (T)n->r;
+        if (k == FsNode::NONE) return T(0);
+        throw std::runtime_error("cv shim: FileNode is not a number");
+    }
+    operator std::string() const {
+        if (kind() == FsNode::STR) return n->s;
+        if (kind() == FsNode::NONE) return std::string();
+        throw std::runtime_error("cv shim: FileNode is not a string");
+    }
+    FileNodeIterator begin() const;
+    FileNodeIterator end() const;
+};
+class FileNodeIterator {
+    FileNode node;
+    size_t i;
+public:
+    FileNodeIterator() : i(0) {}
+    FileNodeIterator(const FileNode& n, size_t at) : node(n), i(at) {}
+    FileNode operator*() const {
+        const int k = node.kind();
+        if (k == FsNode::SEQ || k == FsNode::MAP) return FileNode(node.n->kids.at(i).second);
+        return node;   // a scalar iterates as a collection of itself
+    }
+    FileNodeIterator& operator++() { ++i; return *this; }
+    FileNodeIterator operator++(int) { FileNodeIterator t = *this; ++i; return t; }
+    bool operator==(const FileNodeIterator& o) const { return node.n == o.node.n && i == o.i; }
+    bool operator!=(const FileNodeIterator& o) const { return !(*this == o); }
+};
+inline FileNodeIterator FileNode::begin() const { return FileNodeIterator(*this, 0); }
+inline FileNodeIterator FileNode::end() const { return FileNodeIterator(*this, size()); }
+
+template <typename T> inline typename std::enable_if<std::is_arithmetic<T>::value>::type shim_fs_read(const FileNode& n, T& v) { v = (T)n; }
+inline void shim_fs_read(const FileNode& n, std::string& v) { v = (std::string)n; }
+void shim_fs_read(const FileNode& n, Mat& v);
+// read(FileNode, Point_): the node's elements as a vector; anything but two of them gives the default (0, 0)
+template <typename T> inline void shim_fs_read(const FileNode& n, Point_<T>& v) {
+    v = n.size() == 2 && n.isSeq() ? Point_<T>((T)n[0], (T)n[1]) : Point_<T>();
+}
+template <typename T> inline void shim_fs_read(const FileNode& n, Point3_<T>& v) {
+    v = n.size() == 3 && n.isSeq() ? Point3_<T>((T)n[0], (T)n[1], (T)n[2]) : Point3_<T>();
+}
+template <typename T> inline void operator>>(const FileNode& n, T& v) { shim_fs_read(n, v); }
+
+template <typename T> inline typename std::enable_if<std::is_integral<T>::value || std::is_enum<T>::value, FsNodePtr>::type shim_fs_node(T v) {
+    FsNodePtr p = std::make_shared<FsNode>(); p->kind = FsNode::INT; p->i = (int)v; return p;
+}
+template <typename T> inline typename std::enable_if<std::is_floating_point<T>::value, FsNodePtr>::type shim_fs_node(T v) {
+    FsNodePtr p = std::make_shared<FsNode>(); p->kind = FsNode::REAL; p->r = (double)v; return p;   // write(fs, name, float) is cvWriteReal too
+}
+template <typename T> inline FsNodePtr shim_fs_node(const Point_<T>& v) {       // a flow sequence of the coordinates
+    FsNodePtr p = std::make_shared<FsNode>(); p->kind = FsNode::SEQ; p->flow = true;
+    p->kids.emplace_back(std::string(), shim_fs_node(v.x)); p->kids.emplace_back(std::string(), shim_fs_node(v.y));
+    return p;
+}
+template <typename T> inline FsNodePtr shim_fs_node(const Point3_<T>& v) {
+    FsNodePtr p = std::make_shared<FsNode>(); p->kind = FsNode::SEQ; p->flow = true;
+    p->kids.emplace_back(std::string(), shim_fs_node(v.x)); p->kids.emplace_back(std::string(), shim_fs_node(v.y));
+    p->kids.emplace_back(std::string(), shim_fs_node(v.z));
+    return p;
+}
+FsNodePtr shim_fs_node(const Mat& m);
+inline FsNodePtr shim_fs_node(const MatExpr& e) { return shim_fs_node(e.m); }
+
 class FileStorage {
 public:
-    enum { READ = 0, WRITE = 1 };
+    enum { READ = 0, WRITE = 1, APPEND = 2 };
+    enum { NAME_EXPECTED = 1, VALUE_EXPECTED = 2, INSIDE_MAP = 4 };
+    std::string path, elname;
+    int mode = READ, state = 0;
+    bool opened = false;
+    FsNodePtr doc;                      // the document this session writes
+    std::vector<FsNodePtr> structs;     // the containers that are open inside it
+
     FileStorage() {}
-    FileStorage(const std::string&, int) {}
-    bool isOpened() const { return false; }
-    FileNode operator[](const char*) const { return FileNode(); }
-    FileNode operator[](const std::string&) const { return FileNode(); }
-    void release() {}
+    FileStorage(const std::string& p, int m) { open(p, m); }
+    bool open(const std::string& p, int m) {
+        path = p; mode = m; elname.clear(); structs.clear();
+        if (m == READ) { opened = shim_fs_exists(p); return opened; }
+        if (m == WRITE) shim_fs_erase(p);
+        doc = std::make_shared<FsNode>();
+        doc->kind = FsNode::MAP;
+        shim_fs_file(p).push_back(doc);
+        state = NAME_EXPECTED + INSIDE_MAP;
+        opened = true;
+        return true;
+    }
+    bool isOpened() const { return opened; }
+    void release() { opened = false; structs.clear(); doc.reset(); }
+    FileNode operator[](const std::string& name) const {      // the first document that has the key
+        if (!shim_fs_exists(path)) return FileNode();
+        for (const FsNodePtr& d : shim_fs_file(path)) {
+            FileNode f = FileNode(d)[name];
+            if (!f.empty()) return f;
+        }
+        return FileNode();
+    }
+    FileNode operator[](const char* name) const { return (*this)[std::string(name)]; }
+
+    FsNode& top() { return structs.empty() ? *doc : *structs.back(); }
+    void after_value() { elname.clear(); state = top().kind == FsNode::MAP ? NAME_EXPECTED + INSIDE_MAP : VALUE_EXPECTED; }
+    void put(const FsNodePtr& v) {
+        if (!opened || mode == READ) throw std::runtime_error("cv shim: FileStorage is not open for writing");
+        if (state == NAME_EXPECTED + INSIDE_MAP) throw std::runtime_error("cv shim: FileStorage: no element name has been given");
+        top().kids.emplace_back(top().kind == FsNode::MAP ? elname : std::string(), v);
+    }
+    void put_string(const std::string& str) {
+        if (!opened) return;
+        const char c = str.empty() ? 0 : str[0];
+        if (c == '}' || c == ']') {
+            if (structs.empty() || structs.back()->kind != (c == ']' ? FsNode::SEQ : FsNode::MAP)) throw std::runtime_error("cv shim: FileStorage: unbalanced " + str);
+            structs.pop_back();
+            after_value();
+        } else if (state == NAME_EXPECTED + INSIDE_MAP) {
+            if (!(std::isalpha((unsigned char)c) || c == '_')) throw std::runtime_error("cv shim: FileStorage: a key must start with a letter or '_': " + str);
+            elname = str;
+            state = VALUE_EXPECTED + INSIDE_MAP;
+        } else if (c == '{' || c == '[') {
+            FsNodePtr p = std::make_shared<FsNode>();
+            p->kind = c == '{' ? FsNode::MAP : FsNode::SEQ;
+            p->flow = str.size() > 1 && str[1] == ':';
+            put(p);
+            structs.push_back(p);
+            after_value();
+        } else {
+            FsNodePtr p = std::make_shared<FsNode>();
+            p->kind = FsNode::STR;
+            p->s = (str.size() > 1 && c == '\\' && (str[1] == '{' || str[1] == '}' || str[1] == '[' || str[1] == ']')) ? str.substr(1) : str;
+            put(p);
+            after_value();
+        }
+    }
 };
-template <typename T> inline FileStorage& operator<<(FileStorage& fs, const T&) { return fs; }
+inline FileStorage& operator<<(FileStorage& fs, const char* s) { fs.put_string(s); return fs; }
+inline FileStorage& operator<<(FileStorage& fs, char* s) { fs.put_string(s); return fs; }
+inline FileStorage& operator<<(FileStorage& fs, const std::string& s) { fs.put_string(s); return fs; }
+template <typename T> inline FileStorage& operator<<(FileStorage& fs, const T& v) {
+    if (!fs.isOpened()) return fs;
+    fs.put(shim_fs_node(v));
+    fs.after_value();
+    return fs;
+}
+// cv::imwrite / cv::imread are OpenCV's codecs: nothing is written, nothing comes back
+enum { CV_LOAD_IMAGE_GRAYSCALE = 0, IMREAD_GRAYSCALE = 0 };
+inline bool imwrite(const std::string&, const Mat&) { return true; }
+inline Mat imread(const std::string&, int = 1) { return Mat(); }
 
 }  // namespace cv

@@ -412,6 +412,61 @@ class RefMap:
             self._l.ref_map_destroy(self._h)
             self._h = None
 
+    # ---- MapStorage.cpp (oracle/ref_storage_driver.cpp): files travel as node lines, see oracle/_shim/cv_shim.hpp
+    def _storage_check(self, r):
+        if r < 0:
+            self._l.ref_storage_error.restype = C.c_char_p
+            raise RuntimeError("reference MapStorage: " + self._l.ref_storage_error().decode())
+        return r
+
+    def storage_load(self, events: str) -> int:
+        """MapStorage::loadMap() of the file given as node lines, into this map; returns the number of key frames."""
+        f = self._l.ref_storage_load
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_char_p]
+        return self._storage_check(f(self._h, events.encode()))
+
+    def storage_save(self) -> str:
+        """MapStorage::saveMap() of this map; the file it wrote as node lines."""
+        f = self._l.ref_storage_save
+        f.restype = C.c_long
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+        n = self._storage_check(f(self._h, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        self._storage_check(f(self._h, buf, n + 1))
+        return buf.value.decode()
+
+    def storage_counts(self):
+        out = np.zeros(2, np.int32)
+        self._l.ref_storage_counts.argtypes = [C.c_void_p, C.c_void_p]
+        self._l.ref_storage_counts(self._h, out.ctypes.data)
+        return int(out[0]), int(out[1])
+
+    def storage_kf_state(self, kf):
+        out = np.zeros(12, np.int32)
+        self._l.ref_storage_kf_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._l.ref_storage_kf_state(self._h, int(kf), out.ctypes.data)
+        names = ("kps", "kps_un", "desc_rows", "view_mps", "view_infos", "obs", "covisible", "odo_from", "odo_to", "ftr_from", "ftr_to", "img_rows")
+        return dict(zip(names, (int(v) for v in out)))
+
+    def storage_mp_state(self, mp):
+        out = np.zeros(4, np.int32)
+        self._l.ref_storage_mp_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._l.ref_storage_mp_state(self._h, int(mp), out.ctypes.data)
+        return dict(obs=int(out[0]), good_prl=bool(out[1]), null=bool(out[2]), id=int(out[3]))
+
+    def storage_mp_ftr_idx(self, mp, kf) -> int:
+        f = self._l.ref_storage_mp_ftr_idx
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        return f(self._h, int(mp), int(kf))
+
+    def storage_mp_set_good_prl(self, mp, good: bool):
+        f = self._l.ref_storage_mp_set_good_prl
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        f(self._h, int(mp), 1 if good else 0)
+
     def add_kf(self, id_kf, frame_id, twb, kp_xy=None, kp_octave=None, view_lc=None) -> int:
         xy = np.ascontiguousarray(np.zeros((0, 2)) if kp_xy is None else kp_xy, np.float32).reshape(-1, 2)
         n = len(xy)

@@ -1024,6 +1024,145 @@ def test_back_end_sweep_smoke(capfd):
     capfd.readouterr()          # (Localizer::DoLocalBA prints its timing to stderr)
 
 
+# ---- src/MapStorage.cpp, compiled: the map file as a node structure (on-disk map)
+_FS_DT = {"u": np.uint8, "c": np.int8, "w": np.uint16, "s": np.int16, "i": np.int32, "f": np.float32, "d": np.float64}
+
+
+def _fs_events(docs):
+    """A parsed OpenCV-YAML file as the node lines of oracle/_shim/cv_shim.hpp (shim_fs_dump): exact - reals by their bits."""
+    from test_mapstorage import _Matrix
+    out = []
+
+    def val(v):
+        if isinstance(v, _Matrix):
+            a = np.array(v.data if v.data is not None else [], np.float64).astype(_FS_DT[v.dt])
+            assert a.size == v.rows * v.cols
+            out.append(f"M {v.rows} {v.cols} {v.dt} {a.tobytes().hex()}" if a.size else "M 0 0 u ")
+        elif isinstance(v, bool):
+            raise AssertionError("boolean in a map file")
+        elif isinstance(v, int):
+            out.append(f"I {v}")
+        elif isinstance(v, float):
+            out.append("R " + np.float64(v).tobytes()[::-1].hex())
+        elif isinstance(v, str):
+            out.append("S " + v)
+        elif isinstance(v, list) or v is None:
+            out.append("[")
+            for x in v or []:
+                val(x)
+            out.append("]")
+        elif isinstance(v, dict):
+            out.append("{")
+            for k, x in v.items():
+                out.append("K " + k); val(x)
+            out.append("}")
+        else:
+            raise AssertionError(type(v))
+    for d in docs:
+        out.append("D")
+        for k, x in d.items():
+            out.append("K " + k); val(x)
+    return out
+
+
+def _fs_canonical(lines):
+    """Layout-free, order-free where the reference's own containers are: flow marks dropped; the entries of FtrGraphPairs (walked
+    out of a std::map keyed by shared_ptr, i.e. in address order) sorted, duplicates of one (from, to) pair reduced to the first."""
+    lines = [l[0] if l[:2] in ("[:", "{:") else l for l in lines if l]
+    at = lines.index("K FtrGraphPairs")
+    assert lines[at + 1] == "["
+    entries, depth, cur, k = [], 0, [], at + 2
+    while not (depth == 0 and lines[k] == "]"):
+        cur.append(lines[k])
+        depth += lines[k] in ("[", "{")
+        depth -= lines[k] in ("]", "}")
+        if depth == 0:
+            entries.append(tuple(cur)); cur = []
+        k += 1
+    seen, keep = set(), []
+    for e in entries:
+        assert e[1] == "K PairId"
+        pair = (e[3], e[4])
+        if pair not in seen:
+            seen.add(pair); keep.append(e)
+    return lines[:at + 2] + [l for e in sorted(keep, key=lambda e: (int(e[3][2:]), int(e[4][2:]))) for l in e] + lines[k:], len(entries) - len(keep)
+
+
+@pytest.fixture(scope="module")
+def mapstorage_exe(tmp_path_factory):
+    pytest.importorskip("yaml")
+    out = tmp_path_factory.mktemp("msref") / "cpp_mapstorage"
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp_mapstorage.cpp"), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return str(out)
+
+
+@pytest.mark.parametrize("seed,nkf,nmp", [(1, 6, 12), (2, 11, 30), (3, 23, 60)])
+def test_map_file_through_the_compiled_map_storage(mapstorage_exe, tmp_path, capfd, seed, nkf, nmp):
+    """The mirror (include/se2lam_amd/MapStorage.h) writes a map file; the REFERENCE'S MapStorage::loadMap - src/MapStorage.cpp
+    compiled unmodified, over its own Map / KeyFrame / MapPoint - reads its node structure, and the reference's saveMap writes
+    the map back: the same documents, keys in the same order, the same node types, every number and every matrix bit for bit.
+    So the reference accepts what the mirror writes, and for that map it writes what the mirror wrote.  In between, the state
+    loadMap builds in the reference's data model (observations on both sides, covisibility both ways, the odometry chain from /
+    to, the feature constraints) is the one the mirror's loadMap reports.  What this does not cover is text: the YAML emitter /
+    parser and the bitmaps are OpenCV's, restated in the mirror and held to PyYAML and an independent emitter in
+    tests/test_mapstorage.py."""
+    from test_mapstorage import _parse
+    a, b = (str(tmp_path / n) + "/" for n in "ab")
+    os.makedirs(a); os.makedirs(b)
+    subprocess.run([mapstorage_exe, "gen", a, str(seed), str(nkf), str(nmp)], check=True, capture_output=True)
+    docs, top = _parse(open(a + "se2lam.map").read())
+    ev_mirror = _fs_events(docs)
+    m = ref.RefMap(np.eye(3), np.eye(4), 2.0)
+    nk = m.storage_load("\n".join(ev_mirror) + "\n")
+    assert nk == len(top["KeyFrames"]) and m.storage_counts() == (nk, len(top["MapPoints"] or []))
+    ev_ref = m.storage_save().split("\n")
+    capfd.readouterr()
+    want, dups = _fs_canonical(ev_mirror)
+    got, none = _fs_canonical(ev_ref)
+    assert none == 0 and got == want, next((i, g, w) for i, (g, w) in enumerate(zip(got + [None], want + [None])) if g != w)
+    # ---- the reference's map after loadMap against the file and against what the mirror's loadMap reports
+    nm = len(top["MapPoints"] or [])
+    O = np.array(top["Observations"].data or [], np.int64).reshape(nk, nm)
+    I = np.array(top["ObservationIndex"].data or [], np.int64).reshape(nk, nm)
+    Cv = np.array(top["CovisibilityGraph"].data, np.int64).reshape(nk, nk)
+    nxt = [e["NextId"] for e in top["OdoGraphNextKF"]]
+    pairs = {tuple(e["PairId"]) for e in top["FtrGraphPairs"] or []}
+    r = subprocess.run([mapstorage_exe, "copy", a, b], check=True, capture_output=True, text=True).stdout
+    mirror = {int(l.split()[1]): l.split() for l in r.splitlines() if l.startswith("KF ")}
+    for i in range(nk):
+        st = m.storage_kf_state(i)
+        kps = len(top["KeyFrames"][i]["KeyPoints"] or [])
+        assert (st["kps"], st["kps_un"], st["desc_rows"], st["view_mps"], st["view_infos"]) == (kps,) * 5
+        assert st["obs"] == int(O[i].sum()) and st["covisible"] == int(((Cv[i] + Cv[:, i]) > 0).sum())
+        assert st["odo_from"] == nxt[i] and st["odo_to"] == (nxt.index(i) if i in nxt else -1)
+        assert st["ftr_from"] == sum(1 for p in pairs if p[0] == i) and st["ftr_to"] == sum(1 for p in pairs if p[1] == i)
+        mk = mirror[i]      # KF i kps n obs n covis n next d ftr n img RxC
+        assert (int(mk[3]), int(mk[5]), int(mk[7]), int(mk[9])) == (st["kps"], st["obs"], st["covisible"], st["odo_from"])
+        assert int(mk[11]) >= st["ftr_from"]          # (the mirror's vector keeps a repeated pair, the reference's std::map the first)
+    for j in range(nm):
+        st = m.storage_mp_state(j)
+        assert st == dict(obs=int(O[:, j].sum()), good_prl=True, null=False, id=j)
+        for i in np.nonzero(O[:, j])[0]:
+            assert m.storage_mp_ftr_idx(j, int(i)) == int(I[i, j])
+    # ---- sortMapPoints (MapStorage.cpp:98-118): points without good parallax leave the file, ids and matrix columns close up
+    drop = list(range(0, nm, 4))
+    for j in drop:
+        m.storage_mp_set_good_prl(j, False)
+    _, top2 = None, None
+    ev2 = m.storage_save().split("\n")
+    capfd.readouterr()
+    keep = [j for j in range(nm) if j not in drop]
+    O2, I2 = O[:, keep], I[:, keep]
+    line = {l.split()[1]: ev2[k + 1] for k, l in enumerate(ev2) if l in ("K Observations", "K ObservationIndex")}
+    assert line["Observations"] == f"M {nk} {len(keep)} i {O2.astype(np.int32).tobytes().hex()}" if keep and nk else True
+    assert line["ObservationIndex"] == f"M {nk} {len(keep)} i {I2.astype(np.int32).tobytes().hex()}" if keep and nk else True
+    at = ev2.index("K MapPoints")
+    ids = [int(l[2:]) for k, l in enumerate(ev2[at:ev2.index("K Observations")]) if ev2[at + k - 1] == "K Id"]
+    assert ids == list(range(len(keep)))
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_hip_extractor_equals_the_compiled_reference(synth, ref_feats):
