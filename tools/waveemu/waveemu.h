@@ -1,0 +1,156 @@
+// waveemu: runs ONE workgroup of a wave-level HIP kernel on the CPU, for checking a wave protocol (LDS hand-offs, progress
+// counters, readlane broadcasts, barriers) on a machine without a GPU.  NOT part of the product and not a portability
+// layer: nothing under se2lam_amd/ or include/ knows it; the probes under tools/ that include it (-DWAVEEMU) are
+// experiments that are timed on the GPU with hipcc and only have their LOGIC checked here.
+//
+// Model: every work-item is a fibre (ucontext) on one OS thread; a fibre runs until it yields (s_sleep, a barrier, a wave
+// collective), the scheduler then picks the next wave at random (seeded) and inside it the next lane round-robin, so that
+// many interleavings of the waves are exercised; plain loads / stores need no atomics.  Wave collectives (readlane,
+// readfirstlane, shuffles) go through a per-wave exchange buffer with a wave barrier on both sides, so the lanes of a wave
+// must call them in wave-uniform control flow - as on the hardware.  A watchdog on the number of switches reports a
+// deadlock instead of hanging.  Not modelled: timing, memory ordering between waves (stores are visible at once), the
+// register file, bank conflicts.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <vector>
+
+namespace waveemu {
+struct Dim3 { unsigned x = 1, y = 1, z = 1; };
+struct Fibre {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    bool done = false;
+};
+struct Wave {
+    double slot[64];
+    int arrived = 0;
+    unsigned gen = 0;
+};
+struct Group {
+    int nthreads = 0, cur = 0;
+    std::vector<Fibre> fibres;
+    std::vector<Wave> waves;
+    ucontext_t sched;
+    int bar_arrived = 0;
+    unsigned bar_gen = 0;
+    unsigned long long switches = 0, limit = 0;
+    std::function<void()> body;
+    Dim3 block_idx, block_dim, grid_dim;
+};
+inline Group*& g() { static Group* p = nullptr; return p; }
+inline void yield() {
+    Group* G = g();
+    if (++G->switches > G->limit) {
+        std::fprintf(stderr, "waveemu: %llu switches without finishing - deadlock? (thread %d was running)\n", G->switches, G->cur);
+        std::abort();
+    }
+    swapcontext(&G->fibres[G->cur].ctx, &G->sched);
+}
+inline void trampoline() {
+    Group* G = g();
+    G->body();
+    G->fibres[G->cur].done = true;
+    swapcontext(&G->fibres[G->cur].ctx, &G->sched);
+}
+// runs one workgroup of `nthreads` work-items; `seed` picks the interleaving
+inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks, unsigned seed, std::function<void()> body,
+                                    unsigned long long limit = 4000000000ull) {
+    Group G;
+    g() = &G;
+    G.nthreads = nthreads;
+    G.fibres.resize(nthreads);
+    G.waves.resize((nthreads + 63) / 64);
+    G.body = body;
+    G.limit = limit;
+    G.block_idx.x = bx; G.block_dim.x = nthreads; G.grid_dim.x = nblocks;
+    for (int t = 0; t < nthreads; ++t) {
+        Fibre& f = G.fibres[t];
+        f.stack.resize(256 * 1024);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    std::mt19937 rng(seed);
+    const int nw = (int)G.waves.size();
+    std::vector<int> next_lane(nw, 0);
+    int live = nthreads;
+    while (live > 0) {
+        // a random wave, then up to 64 of its lanes in turn (a burst keeps the lanes of a wave close together, as they are)
+        const int w = seed == 0 ? (int)(G.switches % nw) : (int)(rng() % nw);
+        const int burst = seed == 0 ? 64 : 1 + (int)(rng() % 64);
+        for (int k = 0; k < burst && live > 0; ++k) {
+            const int lane = next_lane[w];
+            next_lane[w] = (lane + 1) % 64;
+            const int t = w * 64 + lane;
+            if (t >= nthreads || G.fibres[t].done) continue;
+            G.cur = t;
+            swapcontext(&G.sched, &G.fibres[t].ctx);
+            if (G.fibres[t].done) --live;
+        }
+        if (++G.switches > G.limit) { std::fprintf(stderr, "waveemu: scheduler limit reached - deadlock?\n"); std::abort(); }
+    }
+    g() = nullptr;
+    return G.switches;
+}
+
+inline void block_barrier() {
+    Group* G = g();
+    const unsigned gen = G->bar_gen;
+    if (++G->bar_arrived == G->nthreads) { G->bar_arrived = 0; ++G->bar_gen; return; }
+    while (G->bar_gen == gen) yield();
+}
+inline void wave_barrier() {
+    Group* G = g();
+    Wave& W = G->waves[G->cur / 64];
+    const int width = std::min(64, G->nthreads - (G->cur / 64) * 64);
+    const unsigned gen = W.gen;
+    if (++W.arrived == width) { W.arrived = 0; ++W.gen; return; }
+    while (W.gen == gen) yield();
+}
+// every lane hands in v; afterwards every lane can read any lane's value
+inline double wave_read(double v, int lane) {
+    Group* G = g();
+    Wave& W = G->waves[G->cur / 64];
+    W.slot[G->cur % 64] = v;
+    wave_barrier();
+    const double r = W.slot[lane];
+    wave_barrier();
+    return r;
+}
+}  // namespace waveemu
+
+// ---- the spellings a kernel uses -------------------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+#define __forceinline__ inline
+#define threadIdx (waveemu::Dim3{(unsigned)waveemu::g()->cur, 0, 0})
+#define blockIdx (waveemu::g()->block_idx)
+#define blockDim (waveemu::g()->block_dim)
+#define gridDim (waveemu::g()->grid_dim)
+#define __ATOMIC_SCOPE_IGNORED 0
+#define __HIP_MEMORY_SCOPE_WORKGROUP 0
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (void)(*(p) = (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) ((*(p) += (v)) - (v))
+inline void __syncthreads() { waveemu::block_barrier(); }
+inline void __builtin_amdgcn_s_sleep(int) { waveemu::yield(); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline double __builtin_amdgcn_rcp(double x) { return (double)(float)(1.0 / x); }   // v_rcp_f64 is a ~single-precision seed: the kernels refine it
+inline int __builtin_amdgcn_readfirstlane(int v) { return (int)waveemu::wave_read((double)v, 0); }
+inline double waveemu_readlane(double v, int lane) { return waveemu::wave_read(v, lane); }
+inline long long wall_clock64() { return (long long)waveemu::g()->switches; }
+inline long long clock64() { return (long long)waveemu::g()->switches; }
