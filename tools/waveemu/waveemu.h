@@ -30,7 +30,7 @@ struct Fibre {
     bool done = false;
 };
 struct Wave {
-    double slot[64];
+    double slot[64], slot2[64];
     int arrived = 0;
     unsigned gen = 0;
 };
@@ -62,7 +62,7 @@ inline void trampoline() {
 }
 // runs one workgroup of `nthreads` work-items; `seed` picks the interleaving
 inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks, unsigned seed, std::function<void()> body,
-                                    unsigned long long limit = 4000000000ull) {
+                                    unsigned long long limit = 200000000ull) {
     Group G;
     g() = &G;
     G.nthreads = nthreads;
@@ -152,5 +152,27 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 inline double __builtin_amdgcn_rcp(double x) { return (double)(float)(1.0 / x); }   // v_rcp_f64 is a ~single-precision seed: the kernels refine it
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)waveemu::wave_read((double)v, 0); }
 inline double waveemu_readlane(double v, int lane) { return waveemu::wave_read(v, lane); }
+inline double __shfl_xor(double v, int mask) { return waveemu::wave_read(v, (waveemu::g()->cur % 64) ^ mask); }
+typedef double d2_t __attribute__((vector_size(16)));
+typedef double d4_t __attribute__((vector_size(32)));
+struct int4 { int x, y, z, w; };
+// v_mfma_f64_16x16x4_f64 in the layout tools/mfma_probe.hip found on gfx950: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k,
+// D[i][j] in lane j + 16 (i % 4), register i / 4
+inline d4_t __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, d4_t c, int, int, int) {
+    waveemu::Group* G = waveemu::g();
+    waveemu::Wave& W = G->waves[G->cur / 64];
+    const int lane = G->cur % 64;
+    W.slot[lane] = a; W.slot2[lane] = b;
+    waveemu::wave_barrier();
+    const int j = lane & 15, ib = lane >> 4;
+    for (int v = 0; v < 4; ++v) {
+        const int i = ib + 4 * v;
+        double acc = c[v];
+        for (int k = 0; k < 4; ++k) acc = std::fma(W.slot[i + 16 * k], W.slot2[j + 16 * k], acc);
+        c[v] = acc;
+    }
+    waveemu::wave_barrier();
+    return c;
+}
 inline long long wall_clock64() { return (long long)waveemu::g()->switches; }
 inline long long clock64() { return (long long)waveemu::g()->switches; }
