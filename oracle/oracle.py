@@ -291,13 +291,20 @@ def orb_extract(img, params=None, cap=4096):
     return kps[:n.value].copy(), desc[:n.value].copy()
 
 
-def orb_trig_libm(on: bool):
-    """descriptor steering angle through libm's cosf / sinf (what the reference's C++ resolves to) instead of the rounded double
-    cosine / sine - see Extractor::descriptor in orb_ref.cpp"""
+def orb_trig_libm(mode):
+    """descriptor steering angle: 0 / False = the rounded double cosine / sine (default), 1 / True = libm's cosf / sinf (what the
+    reference's C++ resolves to), 2 = glibc's sinf / cosf algorithm written out in double arithmetic - see orb_ref.cpp"""
     f = lib().orb_ref_set_trig_libm
     f.restype = None
     f.argtypes = [C.c_int]
-    f(1 if on else 0)
+    f(int(mode))
+
+
+def glibc_sincosf(y, cosine: bool) -> float:
+    f = lib().orb_ref_glibc_sincosf
+    f.restype = C.c_float
+    f.argtypes = [C.c_float, C.c_int]
+    return f(float(y), 1 if cosine else 0)
 
 
 def orb_tables(params=None):

@@ -64,7 +64,42 @@ const int kPattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
-static int g_trig_libm = 0;   // see Extractor::descriptor
+static int g_trig_libm = 0;   // see Extractor::descriptor: 0 rounded double cosine / sine, 1 libm's cosf / sinf, 2 glibc's algorithm restated
+
+// glibc's sinf / cosf (2.28 and later: sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c - the routines ARM
+// contributed) for the arguments a key-point angle can take, 0 <= y < 120: a range reduction by one multiply with 2/pi and one
+// multiply-subtract with pi/2, then a degree-7 sine or degree-8 cosine polynomial, all in double, rounded to float once.  Plain
+// IEEE double arithmetic - so it is the same on every machine, which libm's result is not obliged to be - and on this glibc
+// (2.35) it IS libm: tools/glibc_sincosf_check.c compares it with sinf / cosf on all 1,086,918,621 floats of [0, 2 pi], compiled
+// both without and with FMA contraction: no difference (profiles/r04_glibc_sincosf_check.txt).
+namespace glibc_flt32 {
+const double hpi_inv = 0x1.45F306DC9C883p+23;   // 2 / pi * 2^24: the quadrant ends up in bits 24..31 of the truncated product
+const double hpi = 0x1.921FB54442D18p0;
+const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+inline uint32_t abstop12(float x) { uint32_t u; std::memcpy(&u, &x, 4); return (u >> 20) & 0x7ff; }
+// sine polynomial in quadrant n even, cosine polynomial (negated in quadrants 2, 3) in n odd
+inline float poly(double x, double x2, int n, double csign) {
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, t1 = s2 + x2 * s3, x7 = x3 * x2, s = x + x3 * s1;
+        return (float)(s + x7 * t1);
+    }
+    const double x4 = x2 * x2, k2 = csign * c3 + x2 * (csign * c4), k1 = csign * c0 + x2 * (csign * c1), x6 = x4 * x2, c = k1 + x4 * (csign * c2);
+    return (float)(c + x6 * k2);
+}
+inline float sincos(float y, int cosine) {
+    double x = y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {            // |y| < pi / 4
+        if (abstop12(y) < abstop12(0x1p-12f)) return cosine ? 1.0f : y;
+        return poly(x, x * x, cosine, 1.0);
+    }
+    const double r = x * hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    x = x - n * hpi;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return poly(x * sgn, x * x, n ^ cosine, (n & 2) ? -1.0 : 1.0);
+}
+}  // namespace glibc_flt32
 inline int cv_round(double v) { return (int)std::nearbyint(v); }  // default rounding mode: half to even
 inline int cv_round(float v) { return (int)std::nearbyintf(v); }
 inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
@@ -516,9 +551,11 @@ struct Extractor {
         // (and the HIP path) round the DOUBLE cosine / sine to float - libm-independent; one descriptor in about two million
         // differs in two bits from the reference compiled here, where a sampling coordinate sits on a .5 tie (found by
         // tools/fuzz_ref.py).  g_trig_libm = 1 switches this restatement to cosf / sinf so that the comparison with oracle/_ref is
-        // exact on the machine at hand.
+        // exact on the machine at hand; 2 to glibc's algorithm written out (above): the same bits as 1 on a glibc machine, and the
+        // form a GPU kernel can compute.
         float a, b;
-        if (g_trig_libm) { a = cosf(angle); b = sinf(angle); }
+        if (g_trig_libm == 2) { a = glibc_flt32::sincos(angle, 1); b = glibc_flt32::sincos(angle, 0); }
+        else if (g_trig_libm) { a = cosf(angle); b = sinf(angle); }
         else { a = (float)std::cos((double)angle); b = (float)std::sin((double)angle); }
         const uint8_t* center = &L.blur[(size_t)(cv_round(kpt.y) + EDGE_THRESHOLD) * L.stride + cv_round(kpt.x) + EDGE_THRESHOLD];
         const int step = L.stride;
@@ -632,7 +669,8 @@ void orb_ref_pattern(int32_t* out1024) { for (int i = 0; i < 1024; ++i) out1024[
 void orb_ref_gaussian_taps(int32_t* out7) { int t[7]; Extractor::gaussian_taps(t); for (int i = 0; i < 7; ++i) out7[i] = t[i]; }
 float orb_ref_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 int orb_ref_cv_round(float v) { return cv_round(v); }
-void orb_ref_set_trig_libm(int on) { g_trig_libm = on; }
+void orb_ref_set_trig_libm(int mode) { g_trig_libm = mode; }
+float orb_ref_glibc_sincosf(float y, int cosine) { return glibc_flt32::sincos(y, cosine); }
 int orb_ref_fast_score(const uint8_t* center, int stride) { return Extractor::fast_score(center, stride); }
 
 }  // extern "C"

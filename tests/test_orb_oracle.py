@@ -130,3 +130,35 @@ def test_flat_and_empty_images(oracle):
     assert len(k) == 0
     k, d = oracle.orb_extract(np.zeros((0, 0), np.uint8))
     assert len(k) == 0
+
+
+def test_written_out_glibc_sincosf_is_this_machines_libm(oracle, tmp_path):
+    """oracle/orb_ref.cpp, namespace glibc_flt32: glibc's sinf / cosf (2.28 and later) written out in double arithmetic - what the
+    reference's `(float)cos(angle)` / `(float)sin(angle)` with a float angle compute when linked with glibc.  Held to THIS
+    machine's libm on every float of [0, 2 pi] (1.09e9 arguments, a few seconds with OpenMP); skipped where libm is not glibc."""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    try:
+        get_version = ctypes.CDLL("libc.so.6").gnu_get_libc_version
+        get_version.restype = ctypes.c_char_p
+        ver = tuple(int(v) for v in get_version().decode().split(".")[:2])
+    except (OSError, AttributeError, ValueError):
+        pytest.skip("libc is not glibc")
+    if ver < (2, 28):
+        pytest.skip("glibc before 2.28 has another sinf")
+    oracle.lib()
+    here = os.path.dirname(os.path.abspath(__file__))
+    build = os.path.join(os.path.dirname(here), "oracle", "_build")
+    exe = str(tmp_path / "chk")
+    r = subprocess.run(["gcc", "-O2", "-fopenmp", "-fno-builtin", os.path.join(here, "c_glibc_sincosf_check.c"), "-o", exe, "-L", build, "-loracle",
+                        "-Wl,-rpath," + build, "-lm"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "sinf != libm on 0, cosf on 0" in r.stdout, r.stdout + r.stderr
+    # spot values through the Python wrapper: the argument the fuzz found, the small-angle branch, a quadrant boundary
+    import numpy as np
+    assert np.float32(oracle.glibc_sincosf(np.float32(0.509999156), False)).tobytes() == np.float32(float.fromhex("0x1.f3e48ap-2")).tobytes()
+    assert oracle.glibc_sincosf(1e-5, False) == np.float32(1e-5) and oracle.glibc_sincosf(1e-5, True) == 1.0

@@ -109,12 +109,13 @@ def test_descriptor_steering_goes_through_libm_float_trig_in_the_reference(oracl
     p = oracle.orb_params(3000, 1.2, 4, 20, 0)
     kr, dr = _canon(*ref.orb_extract(img, p))
     ka, da = _canon(*oracle.orb_extract(img, p, cap=16384))
-    oracle.orb_trig_libm(True)
-    try:
-        kc, dc = _canon(*oracle.orb_extract(img, p, cap=16384))
-    finally:
-        oracle.orb_trig_libm(False)
-    assert len(kr) == 3000 and np.array_equal(kc, kr) and np.array_equal(dc, dr)
+    for mode in (1, 2):      # libm's cosf / sinf; glibc's algorithm written out (libm-free: what a kernel can compute)
+        oracle.orb_trig_libm(mode)
+        try:
+            kc, dc = _canon(*oracle.orb_extract(img, p, cap=16384))
+        finally:
+            oracle.orb_trig_libm(0)
+        assert len(kr) == 3000 and np.array_equal(kc, kr) and np.array_equal(dc, dr), mode
     assert np.array_equal(ka, kr)
     assert (da != dr).any(1).sum() <= 1 and np.unpackbits(da ^ dr).sum() <= 2
 

@@ -61,12 +61,13 @@ def main(budget):
             # the reference's cos(angle) / sin(angle) are libm's cosf / sinf (float overloads), not correctly rounded: with the
             # restatement switched to them the descriptors must be identical; the default (rounded double trig) may differ in a
             # few bits of one descriptor where a sampling coordinate sits on a .5 tie
-            oracle.orb_trig_libm(True)
-            try:
-                kc, dc = canon(*oracle.orb_extract(img, p, cap=16384))
-            finally:
-                oracle.orb_trig_libm(False)
-            assert np.array_equal(kc, kb) and np.array_equal(dc, db), ("extract (libm trig)", img.shape, p.nfeatures, p.scale_factor, p.nlevels, p.fast_th, p.score_type)
+            for mode in (1, 2):          # libm's cosf / sinf; glibc's algorithm written out in double arithmetic
+                oracle.orb_trig_libm(mode)
+                try:
+                    kc, dc = canon(*oracle.orb_extract(img, p, cap=16384))
+                finally:
+                    oracle.orb_trig_libm(0)
+                assert np.array_equal(kc, kb) and np.array_equal(dc, db), ("extract (libm trig)", mode, img.shape, p.nfeatures, p.scale_factor, p.nlevels, p.fast_th, p.score_type)
             rows = int((da != db).any(1).sum()); bits = int(np.unpackbits(da ^ db).sum())
             n_trig += 1
             print("libm-dependent descriptor:", img.shape, p.nfeatures, round(p.scale_factor, 2), p.nlevels, "-", rows, "descriptor(s),", bits, "bit(s) of", len(da))
