@@ -8,6 +8,7 @@ sixteen waves on one LDS - needs the GPU."""
 import os
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -41,3 +42,24 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
     r = subprocess.run([exe, *n, "1", "2"], capture_output=True, text=True, timeout=600)       # 1 repetition, 2 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("(ok)") == 2 and "MISMATCH" not in r.stdout
+
+
+def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
+    """The product's own d_chol_tiles (se2lam_amd/csrc/ba.hip) - cut out of the source at test time by
+    tools/waveemu/extract_chol_tiles.py, which fails if one of its anchors has moved - solves dense and arcs + separator systems
+    on the CPU with its four waves interleaved adversarially (seeded weights starve a wave while the others run ahead).  A logic
+    race inside a workgroup - slab counters against the staging tiles, the multiplier columns overlaid on Tc / Ta, `ready_s` against
+    COLV / MRC - shows as a wrong solution or a hang.  (Removing the kernel's `loaded_s` wait is caught in 4 of 100 interleavings:
+    profiles/r04_chol32_emulated.txt; the long campaign is there too.)"""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    inc = tmp_path / "chol32_body.inc"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = str(tmp_path / "chol32_emu")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path), os.path.join(ROOT, "tools", "chol32_emu.cpp"),
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for args, n in ((("100", "4"), 4), (("63", "2"), 2), (("nd", "1", "2", "1", "3"), 3)):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.count("(ok)") == n and "MISMATCH" not in r.stdout, r.stdout + r.stderr

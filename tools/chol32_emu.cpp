@@ -1,0 +1,61 @@
+// The SHIPPED dense pose solve - d_chol_tiles of se2lam_amd/csrc/ba.hip, its own lines (tools/waveemu/extract_chol_tiles.py cuts them
+// out at build time and lists its few substitutions) - run on the CPU by tools/waveemu: one task after the other in launch order, the
+// four waves of a task interleaved at random from a seed.  What this looks for is a LOGIC race inside a workgroup that a
+// hardware soak only meets once in hundreds of runs: the slab counters against the staging tiles, the multiplier columns that are
+// overlaid on Tc / Ta (`loaded_s`), `ready_s` against COLV / MRC, the x tasks.  What it cannot see: the memory ordering between
+// workgroups (the emulator's stores are visible at once) - that is what tools/soak_fresh.sh checks on the GPU.  Test harness only.
+//   python tools/waveemu/extract_chol_tiles.py /tmp/chol32_body.inc
+//   g++ -O2 -std=c++17 -I tools/waveemu -I /tmp tools/chol32_emu.cpp -o /tmp/chol32_emu && /tmp/chol32_emu nd 3 5 1 20
+#include "waveemu.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+using std::min;
+#define __host__
+#define WAVE_LOCKSTEP() waveemu::wave_barrier()
+#define SE2_WAIT_VM6(a, b, c, d, e, f)
+struct BaCtl { int done; };
+static inline double bcast_lane(double v, int lane) { return waveemu_readlane(v, lane); }
+static inline d2_t load_agent(const double* p) { return d2_t{p[0], p[1]}; }
+static inline void store_agent(double* p, d2_t v) { p[0] = v.x; p[1] = v.y; }
+static inline unsigned poll_agent(const unsigned* p) { return *p; }
+
+#include "chol32_body.inc"
+#include "chol_host.h"
+
+int main(int argc, char** argv) {
+    // chol32_emu n [interleavings [first seed]]   |   chol32_emu nd <arc tiles> <separator tiles> [first seed [interleavings]]
+    const bool nd = argc > 1 && std::string(argv[1]) == "nd";
+    const int arc = nd ? (argc > 2 ? std::atoi(argv[2]) : 3) : 0, sep = nd ? (argc > 3 ? std::atoi(argv[3]) : 5) : 0;
+    const int n = nd ? 0 : (argc > 1 ? std::atoi(argv[1]) : 100);
+    const unsigned seed0 = nd ? (argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u) : (argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u);
+    const unsigned nseeds = nd ? (argc > 5 ? (unsigned)std::atoi(argv[5]) : 3u) : (argc > 2 ? (unsigned)std::atoi(argv[2]) : 3u);
+    const CholSystem S = chol_system(kNB, n, arc, sep);
+    const int ntask = (int)S.plan.tasks.size();
+    std::printf("n = %d%s: ld %d, %d tile rows, %d block columns (%d on the longest chain), %d tasks of 256 threads\n", S.n, nd ? " (two arcs + separator)" : "", S.ld,
+                S.nt, S.nbc, S.chain, ntask);
+    std::vector<double> PUB(2 * (size_t)S.nt * S.nbc * kSlabs * kSlabDoubles + S.ld, 0.0), x(S.n, 0.0);
+    std::vector<unsigned> flagA((size_t)S.nt * S.nbc * kSlabs, 0u), flagR((size_t)S.nt * S.nbc * kSlabs, 0u);
+    double fail = 0.0;
+    int rc = 0;
+    for (unsigned seed = seed0; seed < seed0 + nseeds; ++seed) {
+        std::fill(PUB.begin(), PUB.end(), 0.0);
+        std::fill(x.begin(), x.end(), 0.0);
+        double* YU = PUB.data() + 2 * (size_t)S.nt * S.nbc * kSlabs * kSlabDoubles;
+        unsigned epoch = seed;
+        unsigned long long sw = 0;
+        for (int t = 0; t < ntask; ++t)
+            sw += waveemu::run_group(256, t, ntask, seed * 7919u + t, [&]() {
+                d_chol_tiles<false>(blockIdx.x, S.A.data(), PUB.data(), YU, S.ld, S.n, S.nbc, S.plan.tasks.data(), S.plan.deps.data(), nullptr, flagA.data(), flagR.data(),
+                                    &epoch, &fail, nullptr, nullptr, x.data(), nullptr);
+            });
+        const double res = chol_residual(S, x);
+        std::printf("interleaving %u: %llu switches, |A x - b|_inf / |b|_inf = %.3e %s, failure flag %g\n", seed, sw, res, res < 1e-11 ? "(ok)" : "(MISMATCH)", fail);
+        if (!(res < 1e-11) || fail != 0.0) rc = 1;
+    }
+    return rc;
+}

@@ -38,8 +38,10 @@ static inline double bcast_lane(double v, int lane) { return waveemu_readlane(v,
 // instruction, and a counter stored after a write is behind the writes of all 64 lanes.  The emulator's lanes are separate
 // fibres, so the places that rely on this say so.
 #define WAVE_LOCKSTEP() waveemu::wave_barrier()
+#define WAVE_ONE_LANE(lane) ((lane) == 0)      // a store every lane of a wave executes in one instruction: a lagging fibre would bring the value back
 #else
 #define WAVE_LOCKSTEP()
+#define WAVE_ONE_LANE(lane) true
 __device__ inline double bcast_lane(double v, int lane) {  // lane: wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(1024) void k_elim64(const double* __restrict__ Din,
                 colv[q * NB] = m[q];
                 asm volatile("" ::: "memory");
                 WAVE_LOCKSTEP();
-                __hip_atomic_store(&readyD, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (WAVE_ONE_LANE(lane)) __hip_atomic_store(&readyD, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (all lanes store the same value in one instruction; the emulator lets one fibre do it)
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int q2 = q + 2; q2 < CW; ++q2) rvb[q & 1][q2] = COLV[jj][cb + q2];
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_elim64(const double* __restrict__ Din,
             }
             asm volatile("" ::: "memory");
             WAVE_LOCKSTEP();
-            __hip_atomic_store(&readyT, cb + CW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (WAVE_ONE_LANE(lane)) __hip_atomic_store(&readyT, cb + CW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (all lanes store the same value in one instruction; the emulator lets one fibre do it)
         }
         long long t_end = wall_clock64();
         if (rep == reps - 1) {

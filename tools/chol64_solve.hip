@@ -12,7 +12,7 @@
 // The plan is built on the host from a tile pattern (symbolic fill on tiles): dense, or `nd` = two uncoupled arcs and a separator,
 // the nested-dissection shape the product's plan gives the 200 key-frame window (3 + 3 + 5 tiles of 64: eight block columns on the
 // chain instead of fourteen of 32).
-//   hipcc --offload-arch=gfx950 -O3 tools/chol64_solve.hip -o tools/bin/chol64_solve && tools/bin/chol64_solve nd 3 5 20   (or: n [repetitions])
+//   hipcc --offload-arch=gfx950 -O3 -I tools/waveemu tools/chol64_solve.hip -o tools/bin/chol64_solve && tools/bin/chol64_solve nd 3 5 20   (or: n [repetitions])
 // NOT YET RUN ON A GPU (written when round 4's GPU minutes were spent).  Its logic - plan, flags, staging counters, MFMA operand
 // mapping, elimination protocol, publish layout, x tasks - runs on the CPU under tools/waveemu (tasks in launch order, the waves of
 // a task interleaved at random):
@@ -43,7 +43,8 @@ __host__ __device__ inline size_t pub_tile(int kind, int i, int j, int nt, int n
 
 #ifdef WAVEEMU
 static inline double bcast_lane(double v, int lane) { return waveemu_readlane(v, lane); }
-#define WAVE_LOCKSTEP() waveemu::wave_barrier()      // see tools/chol64_probe.hip
+#define WAVE_LOCKSTEP() waveemu::wave_barrier()
+#define WAVE_ONE_LANE(lane) ((lane) == 0)      // a store every lane of a wave executes in one instruction: a lagging fibre would bring the value back      // see tools/chol64_probe.hip
 using std::min;
 #define LOAD_AGENT(v, p) v = d2_t{(p)[0], (p)[1]}
 #define WAIT_VM4(a, b, c, d)
@@ -53,6 +54,7 @@ static inline unsigned poll_agent(const unsigned* p) { return *p; }
 static inline void wait_vm() {}
 #else
 #define WAVE_LOCKSTEP()
+#define WAVE_ONE_LANE(lane) true
 typedef double d2_t __attribute__((ext_vector_type(2)));
 typedef double d4_t __attribute__((ext_vector_type(4)));
 __device__ inline double bcast_lane(double v, int lane) {  // lane: wave-uniform
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_chol64(const double* __restrict__ A, d
             if (lane == yrow) YUS[jj] = mm[q];      // (diagonal task of the rhs row's tile row: its T wave publishes y_un)
             asm volatile("" ::: "memory");
             WAVE_LOCKSTEP();
-            __hip_atomic_store(&readyD, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (WAVE_ONE_LANE(lane)) __hip_atomic_store(&readyD, jj + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (all lanes store the same value in one instruction; the emulator lets one fibre do it)
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int q2 = q + 2; q2 < CW; ++q2) rvb[q & 1][q2] = COLV[jj][cb + q2];
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(1024) void k_chol64(const double* __restrict__ A, d
     }
     asm volatile("" ::: "memory");
     WAVE_LOCKSTEP();
-    __hip_atomic_store(&readyT, cb + CW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (WAVE_ONE_LANE(lane)) __hip_atomic_store(&readyT, cb + CW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (all lanes store the same value in one instruction; the emulator lets one fibre do it)
     {
         double* pb = PUB + pub_tile(isR || isDiag ? 1 : 0, i, j, nt, nbc) + w * kSlabDoubles + lane * 2;
 #pragma unroll
@@ -394,64 +396,7 @@ __global__ __launch_bounds__(1024) void k_chol64(const double* __restrict__ A, d
     if (stamp && lane == 0 && w == ND - 1) stamp[3] = wall_clock64();
 }
 
-// ---- host: the dense plan, a random SPD system, the check ------------------------------------------------------------
-struct Plan {
-    std::vector<int4> tasks;
-    std::vector<int> deps;
-};
-// The plan over a tile pattern.  P[i][j] (i >= j; i < nt tile rows, j < nbc block columns): tile (i, j) of the lower triangle is
-// non-zero; the tile row of the rhs row is non-zero everywhere.  Symbolic fill on tiles, then the tasks by block column -
-// dependencies point to earlier tasks only - and the x tasks last.
-static Plan plan_from_pattern(std::vector<std::vector<char>> P, int nt, int nbc, int* chain_len) {
-    for (int m = 0; m < nbc; ++m)                 // fill: L(i, j) when L(i, m) and L(j, m) for some m < j
-        for (int j = m + 1; j < nbc; ++j)
-            if (P[j][m])
-                for (int i = j; i < nt; ++i)
-                    if (P[i][m]) P[i][j] = 1;
-    // R = L^-T by tile rows: R(r, r) always; R(r, j), j > r, when R(r, m) and L(j, m) for some r <= m < j
-    std::vector<std::vector<char>> R(nbc, std::vector<char>(nbc, 0));
-    for (int r = 0; r < nbc; ++r) {
-        R[r][r] = 1;
-        for (int j = r + 1; j < nbc; ++j)
-            for (int m = r; m < j; ++m)
-                if (R[r][m] && P[j][m]) { R[r][j] = 1; break; }
-    }
-    Plan p;
-    auto add = [&](int kind, int i, int j, const std::vector<int>& d) {
-        int4 t;
-        t.x = i | (kind << 16); t.y = j; t.z = (int)p.deps.size();
-        p.deps.insert(p.deps.end(), d.begin(), d.end());
-        t.w = (int)p.deps.size();
-        p.tasks.push_back(t);
-    };
-    std::vector<int> depth(nbc, 1);               // block columns on the longest dependency chain ending in column j
-    for (int j = 0; j < nbc; ++j) {
-        for (int m = 0; m < j; ++m)
-            if (P[j][m]) depth[j] = std::max(depth[j], depth[m] + 1);
-        for (int i = j; i < nt; ++i) {            // the diagonal task, then the L tiles of the column
-            if (i > j && !P[i][j]) continue;
-            std::vector<int> d;
-            for (int m = 0; m < j; ++m)
-                if (P[j][m]) d.push_back(m | (P[i][m] ? 1 << 15 : 0));
-            add(0, i, j, d);
-        }
-        for (int r = 0; r < j; ++r) {
-            if (!R[r][j]) continue;
-            std::vector<int> d;
-            for (int m = 0; m < j; ++m)
-                if (P[j][m]) d.push_back(m | (m >= r && R[r][m] ? 1 << 15 : 0));
-            add(1, r, j, d);
-        }
-    }
-    for (int r = 0; r < nbc; ++r) {
-        std::vector<int> d;
-        for (int j = r; j < nbc; ++j)
-            if (R[r][j]) d.push_back(j);
-        add(2, r, 0, d);
-    }
-    *chain_len = *std::max_element(depth.begin(), depth.end());
-    return p;
-}
+#include "chol_host.h"
 
 int main(int argc, char** argv) {
     // chol64_solve [n [repetitions [interleavings]]]: dense;  chol64_solve nd [arc tiles [separator tiles [repetitions ...]]]: two
@@ -461,38 +406,10 @@ int main(int argc, char** argv) {
     const int n = nd ? NB * (2 * arc + sep) : (argc > 1 ? std::atoi(argv[1]) : 600);
     const int reps = nd ? (argc > 4 ? std::atoi(argv[4]) : 1) : (argc > 2 ? std::atoi(argv[2]) : 1);
     const int seeds_arg = nd ? 5 : 3;
-    const int ld = ((n + 1 + NB - 1) / NB) * NB, nt = ld / NB, nbc = (n + NB - 1) / NB;
-    std::vector<std::vector<char>> P(nt, std::vector<char>(nbc, 1));
-    if (nd)
-        for (int i = 0; i < nbc; ++i)
-            for (int j = 0; j < nbc; ++j) {
-                const int gi = i < arc ? 0 : i < 2 * arc ? 1 : 2, gj = j < arc ? 0 : j < 2 * arc ? 1 : 2;
-                P[i][j] = gi == gj || gi == 2 || gj == 2;
-            }
-    // A: (n + 1) x (n + 1) augmented, row n = the right-hand side; SPD = G G^T + a diagonal, G with the pattern's block structure
-    // (group 0 / 1 rows use their own factor columns only, separator rows all of them: A(arc 0, arc 1) = 0 exactly)
-    std::vector<double> A((size_t)ld * ld, 0.0), G((size_t)n * n, 0.0), b(n);
-    unsigned long long s = 88172645463325252ull;
-    auto unit = [&]() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return (double)((s * 2685821657736338717ull) >> 11) * (1.0 / 9007199254740992.0); };
-    auto group = [&](int r) { return !nd ? 2 : r < NB * arc ? 0 : r < 2 * NB * arc ? 1 : 2; };
-    for (int r = 0; r < n; ++r)
-        for (int k = 0; k < n; ++k)
-            if (group(r) == 2 || group(k) == group(r)) G[(size_t)r * n + k] = unit() - 0.5;
-    for (int r = 0; r < n; ++r) {
-        for (int c = 0; c <= r; ++c) {
-            double a = r == c ? 0.5 * n : 0.0;
-            for (int k = 0; k < n; ++k) a += G[(size_t)r * n + k] * G[(size_t)c * n + k];
-            A[(size_t)r * ld + c] = a; A[(size_t)c * ld + r] = a;
-        }
-        b[r] = 10.0 * (unit() - 0.5);
-        A[(size_t)n * ld + r] = b[r];
-    }
-    if (nd)
-        for (int r = NB * arc; r < 2 * NB * arc; ++r)
-            for (int c = 0; c < NB * arc; ++c)
-                if (A[(size_t)r * ld + c] != 0.0) { std::printf("the arcs are coupled?\n"); return 1; }
-    int chain = 0;
-    const Plan p2 = plan_from_pattern(P, nt, nbc, &chain);
+    const CholSystem S = chol_system(NB, n, arc, sep);
+    const int ld = S.ld, nt = S.nt, nbc = S.nbc, chain = S.chain;
+    const std::vector<double>& A = S.A;
+    const Plan& p2 = S.plan;
     // (tile rows: nt of them - the rhs row may open one of its own; block columns: nbc)
     std::vector<double> PUB(2 * (size_t)nt * nbc * kTileDoubles, 0.0), YU(ld, 0.0), x(n, 0.0);
     std::vector<unsigned> flagA((size_t)nt * nbc * kSlabs, 0u), flagR((size_t)nt * nbc * kSlabs, 0u);
@@ -540,16 +457,9 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dbg.data(), dG, dbg.size() * 8, hipMemcpyDeviceToHost));
     {
 #endif
-        // residual of the solve in the original system
-        double worst = 0.0, scale = 0.0;
-        for (int r = 0; r < n; ++r) {
-            double a = -b[r];
-            for (int c = 0; c < n; ++c) a += A[(size_t)r * ld + c] * x[c];
-            if (!(std::fabs(a) <= worst)) worst = std::fabs(a);
-            scale = std::fmax(scale, std::fabs(b[r]));
-        }
-        std::printf("  |A x - b|_inf / |b|_inf = %.3e %s, failure flag %g\n", worst / scale, worst / scale < 1e-11 ? "(ok)" : "(MISMATCH)", fail);
-        if (!(worst / scale < 1e-11) || fail != 0.0) rc = 1;
+        const double res = chol_residual(S, x);
+        std::printf("  |A x - b|_inf / |b|_inf = %.3e %s, failure flag %g\n", res, res < 1e-11 ? "(ok)" : "(MISMATCH)", fail);
+        if (!(res < 1e-11) || fail != 0.0) rc = 1;
     }
 #ifndef WAVEEMU
     // the chain: per block column the diagonal task's stamps {start, update done, D wave 7 done, last slab flagged} in 100 MHz ticks

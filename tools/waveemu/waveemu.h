@@ -28,6 +28,7 @@ struct Fibre {
     ucontext_t ctx;
     std::vector<char> stack;
     bool done = false;
+    int where = 0;      // what the fibre last yielded in: 1 __syncthreads, 2 a wave collective, 100 + n s_sleep(n)
 };
 struct Wave {
     double slot[64], slot2[64];
@@ -49,7 +50,21 @@ inline Group*& g() { static Group* p = nullptr; return p; }
 inline void yield() {
     Group* G = g();
     if (++G->switches > G->limit) {
-        std::fprintf(stderr, "waveemu: %llu switches without finishing - deadlock? (thread %d was running)\n", G->switches, G->cur);
+        std::fprintf(stderr, "waveemu: %llu switches without finishing - deadlock? (workgroup %u, thread %d was running)\n", G->switches, G->block_idx.x, G->cur);
+        for (size_t w = 0; w < G->waves.size(); ++w) {       // where every wave's lanes are waiting
+            std::fprintf(stderr, "  wave %zu:", w);
+            int last = -1, run = 0;
+            for (int l = 0; l <= 64; ++l) {
+                const size_t t = w * 64 + l;
+                const int wh = l < 64 && t < G->fibres.size() ? (G->fibres[t].done ? -2 : G->fibres[t].where) : -3;
+                if (wh != last) {
+                    if (run) std::fprintf(stderr, " %dx%s%d", run, last == -2 ? "done" : last == 1 ? "syncthreads" : last == 2 ? "collective" : last >= 100 ? "sleep" : "?", last >= 100 ? last - 100 : 0);
+                    last = wh; run = 0;
+                }
+                ++run;
+            }
+            std::fprintf(stderr, "\n");
+        }
         std::abort();
     }
     swapcontext(&G->fibres[G->cur].ctx, &G->sched);
@@ -83,10 +98,17 @@ inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks,
     std::mt19937 rng(seed);
     const int nw = (int)G.waves.size();
     std::vector<int> next_lane(nw, 0);
+    // every wave gets a weight from the seed - 1, 4, 16 or 64 - and is picked in proportion to it: some interleavings starve a wave
+    // for a long time while the others run ahead, which is what finds a missing wait
+    std::vector<int> ticket;
+    for (int w = 0; w < nw; ++w) {
+        const int weight = seed == 0 ? 1 : 1 << (2 * (int)(rng() % 4));
+        for (int k = 0; k < weight; ++k) ticket.push_back(w);
+    }
     int live = nthreads;
     while (live > 0) {
-        // a random wave, then up to 64 of its lanes in turn (a burst keeps the lanes of a wave close together, as they are)
-        const int w = seed == 0 ? (int)(G.switches % nw) : (int)(rng() % nw);
+        // a wave by its weight, then up to 64 of its lanes in turn (a burst keeps the lanes of a wave close together, as they are)
+        const int w = seed == 0 ? (int)(G.switches % nw) : ticket[rng() % ticket.size()];
         const int burst = seed == 0 ? 64 : 1 + (int)(rng() % 64);
         for (int k = 0; k < burst && live > 0; ++k) {
             const int lane = next_lane[w];
@@ -107,6 +129,7 @@ inline void block_barrier() {
     Group* G = g();
     const unsigned gen = G->bar_gen;
     if (++G->bar_arrived == G->nthreads) { G->bar_arrived = 0; ++G->bar_gen; return; }
+    G->fibres[G->cur].where = 1;
     while (G->bar_gen == gen) yield();
 }
 inline void wave_barrier() {
@@ -115,6 +138,7 @@ inline void wave_barrier() {
     const int width = std::min(64, G->nthreads - (G->cur / 64) * 64);
     const unsigned gen = W.gen;
     if (++W.arrived == width) { W.arrived = 0; ++W.gen; return; }
+    G->fibres[G->cur].where = 2;
     while (W.gen == gen) yield();
 }
 // every lane hands in v; afterwards every lane can read any lane's value
@@ -147,15 +171,33 @@ inline double wave_read(double v, int lane) {
 #define __hip_atomic_store(p, v, order, scope) (void)(*(p) = (v))
 #define __hip_atomic_fetch_add(p, v, order, scope) ((*(p) += (v)) - (v))
 inline void __syncthreads() { waveemu::block_barrier(); }
-inline void __builtin_amdgcn_s_sleep(int) { waveemu::yield(); }
+inline void __builtin_amdgcn_s_sleep(int n) { waveemu::g()->fibres[waveemu::g()->cur].where = 100 + n; waveemu::yield(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline double __builtin_amdgcn_rcp(double x) { return (double)(float)(1.0 / x); }   // v_rcp_f64 is a ~single-precision seed: the kernels refine it
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)waveemu::wave_read((double)v, 0); }
 inline double waveemu_readlane(double v, int lane) { return waveemu::wave_read(v, lane); }
 inline double __shfl_xor(double v, int mask) { return waveemu::wave_read(v, (waveemu::g()->cur % 64) ^ mask); }
-typedef double d2_t __attribute__((vector_size(16)));
-typedef double d4_t __attribute__((vector_size(32)));
+// clang's ext_vector_type(2 / 4) of double as far as the kernels use them: brace initialisation, .x / .y, [i]
+struct d2_t {
+    double x, y;
+    double& operator[](int i) { return i ? y : x; }
+    const double& operator[](int i) const { return i ? y : x; }
+};
+struct d4_t {
+    double v[4];
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+};
 struct int4 { int x, y, z, w; };
+struct double2 { double x, y; };
+inline long long __shfl_xor(long long v, int mask) {
+    double d; std::memcpy(&d, &v, 8);
+    d = waveemu::wave_read(d, (waveemu::g()->cur % 64) ^ mask);
+    std::memcpy(&v, &d, 8);
+    return v;
+}
+inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 // v_mfma_f64_16x16x4_f64 in the layout tools/mfma_probe.hip found on gfx950: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k,
 // D[i][j] in lane j + 16 (i % 4), register i / 4
 inline d4_t __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, d4_t c, int, int, int) {
