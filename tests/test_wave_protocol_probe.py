@@ -23,9 +23,9 @@ def test_sixteen_wave_block_column_under_the_wave_emulator(tmp_path, catch):
     r = subprocess.run(["g++", "-O2", "-std=c++17", "-DWAVEEMU", f"-DCATCH={catch}", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
                         os.path.join(ROOT, "tools", "chol64_probe.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([exe, "2", "2", "5"], capture_output=True, text=True, timeout=300)       # 2 blocks, 2 repetitions, 5 interleavings
+    r = subprocess.run([exe, "2", "2", "6"], capture_output=True, text=True, timeout=300)       # 2 blocks, 2 repetitions, 6 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("(ok)") == 5 and "MISMATCH" not in r.stdout
+    assert r.stdout.count("(ok)") == 6 and "MISMATCH" not in r.stdout
 
 
 @pytest.mark.parametrize("n", [("63",), ("128",), ("130",), ("nd", "1", "2")])
@@ -39,9 +39,9 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
     r = subprocess.run(["g++", "-O2", "-std=c++17", "-DWAVEEMU", "-Wno-psabi", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
                         os.path.join(ROOT, "tools", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([exe, *n, "1", "2"], capture_output=True, text=True, timeout=600)       # 1 repetition, 2 interleavings
+    r = subprocess.run([exe, *n, "1", "3"], capture_output=True, text=True, timeout=600)       # 1 repetition, 3 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("(ok)") == 2 and "MISMATCH" not in r.stdout
+    assert r.stdout.count("(ok)") == 3 and "MISMATCH" not in r.stdout
 
 
 def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
@@ -60,6 +60,6 @@ def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
     r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path), os.path.join(ROOT, "tools", "chol32_emu.cpp"),
                         "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    for args, n in ((("100", "4"), 4), (("63", "2"), 2), (("nd", "1", "2", "1", "3"), 3)):
+    for args, n in ((("100", "12"), 12), (("63", "4"), 4), (("nd", "1", "2", "1", "4"), 4)):
         r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.count("(ok)") == n and "MISMATCH" not in r.stdout, r.stdout + r.stderr

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 mkdir -p gpurun_out tools/bin
 hipcc --offload-arch=gfx950 -O3 tools/chol64_probe.hip -o tools/bin/chol64_probe || exit 1
 hipcc --offload-arch=gfx950 -O3 -DCATCH=4 tools/chol64_probe.hip -o tools/bin/chol64_probe4 || exit 1
-hipcc --offload-arch=gfx950 -O3 tools/chol64_solve.hip -o tools/bin/chol64_solve || exit 1
+hipcc --offload-arch=gfx950 -O3 -I tools/waveemu tools/chol64_solve.hip -o tools/bin/chol64_solve || exit 1
 {
     echo "== elimination alone, catch-up 2 columns per poll"; timeout 60 tools/bin/chol64_probe 1 20
     echo "== elimination alone, catch-up 4 columns per poll (6 VGPRs spilled)"; timeout 60 tools/bin/chol64_probe4 1 20

@@ -11,6 +11,10 @@
 // deadlock instead of hanging.  Not modelled: timing, memory ordering between waves (stores are visible at once), the
 // register file, bank conflicts.
 #pragma once
+// (fibres are switched with _setjmp / _longjmp - swapcontext makes a system call per switch - and a fortified longjmp refuses to
+// jump between stacks: this header has to be the first include)
+#undef _FORTIFY_SOURCE
+#include <setjmp.h>
 #include <ucontext.h>
 
 #include <cmath>
@@ -19,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <random>
 #include <vector>
 
@@ -26,7 +31,9 @@ namespace waveemu {
 struct Dim3 { unsigned x = 1, y = 1, z = 1; };
 struct Fibre {
     ucontext_t ctx;
-    std::vector<char> stack;
+    jmp_buf jb;
+    bool started = false;
+    std::unique_ptr<char[]> stack;      // (not zero-filled: only the pages a fibre touches are ever mapped)
     bool done = false;
     int where = 0;      // what the fibre last yielded in: 1 __syncthreads, 2 a wave collective, 100 + n s_sleep(n)
 };
@@ -40,6 +47,7 @@ struct Group {
     std::vector<Fibre> fibres;
     std::vector<Wave> waves;
     ucontext_t sched;
+    jmp_buf sched_jb;
     int bar_arrived = 0;
     unsigned bar_gen = 0;
     unsigned long long switches = 0, limit = 0;
@@ -67,13 +75,13 @@ inline void yield() {
         }
         std::abort();
     }
-    swapcontext(&G->fibres[G->cur].ctx, &G->sched);
+    if (_setjmp(G->fibres[G->cur].jb) == 0) _longjmp(G->sched_jb, 1);
 }
 inline void trampoline() {
     Group* G = g();
     G->body();
     G->fibres[G->cur].done = true;
-    swapcontext(&G->fibres[G->cur].ctx, &G->sched);
+    _longjmp(G->sched_jb, 1);
 }
 // runs one workgroup of `nthreads` work-items; `seed` picks the interleaving
 inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks, unsigned seed, std::function<void()> body,
@@ -88,10 +96,11 @@ inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks,
     G.block_idx.x = bx; G.block_dim.x = nthreads; G.grid_dim.x = nblocks;
     for (int t = 0; t < nthreads; ++t) {
         Fibre& f = G.fibres[t];
-        f.stack.resize(256 * 1024);
+        constexpr size_t kStack = 256 * 1024;
+        f.stack.reset(new char[kStack]);
         getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
-        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_stack.ss_sp = f.stack.get();
+        f.ctx.uc_stack.ss_size = kStack;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())trampoline, 0);
     }
@@ -116,7 +125,11 @@ inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks,
             const int t = w * 64 + lane;
             if (t >= nthreads || G.fibres[t].done) continue;
             G.cur = t;
-            swapcontext(&G.sched, &G.fibres[t].ctx);
+            if (_setjmp(G.sched_jb) == 0) {
+                if (G.fibres[t].started) _longjmp(G.fibres[t].jb, 1);
+                G.fibres[t].started = true;
+                setcontext(&G.fibres[t].ctx);
+            }
             if (G.fibres[t].done) --live;
         }
         if (++G.switches > G.limit) { std::fprintf(stderr, "waveemu: scheduler limit reached - deadlock?\n"); std::abort(); }
