@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 constexpr int NB = 64;     // columns of the block column = D rows = T rows
@@ -30,10 +31,15 @@ constexpr int ND = NB / CW;   // D waves (and as many T waves)
 #ifndef CATCH
 #define CATCH 2     // 4 (what k_chol_tiles does with its four waves) needs 6 VGPRs more than the 128 a wave of a 1024-thread workgroup has: it spills
 #endif
+#ifndef PIVCHK
+#define PIVCHK 0      // 1: the pivot test on the high dword of the pivot in scalar registers (s_min_i32 / s_max_i32) instead of v_max_f64 + v_min_f64
+#endif
 constexpr int CU = CATCH;      // published columns taken per poll in the catch-up phase
 
 #ifdef WAVEEMU
 static inline double bcast_lane(double v, int lane) { return waveemu_readlane(v, lane); }
+static inline int hi_word(double v) { long long b; memcpy(&b, &v, 8); return (int)(b >> 32); }
+using std::min; using std::max;
 // The lanes of a wave execute an LDS instruction together: what one lane wrote, every lane of the SAME wave reads back in the next
 // instruction, and a counter stored after a write is behind the writes of all 64 lanes.  The emulator's lanes are separate
 // fibres, so the places that rely on this say so.
@@ -47,6 +53,7 @@ __device__ inline double bcast_lane(double v, int lane) {  // lane: wave-uniform
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+__device__ inline int hi_word(double v) { return __double2hiint(v); }
 #endif
 
 // out: MD | MRD | MT | MRT, each NB x NB row-major;  stamps[wave]: 100 MHz ticks {start of own columns, end}
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(1024) void k_elim64(const double* __restrict__ Din,
         }
         long long t_own = wall_clock64();
         double pmin = 1e300;
+        int hmin = 0x7fffffff, hmax = 0;      // PIVCHK: a pivot is positive and finite iff 0 < its high dword < 0x7ff00000 (denormal pivots count as failures)
         if (!isT) {
             // ---- D wave: the pivot chain of its eight columns (the q loop of k_chol_tiles with 64 D rows in the wave)
             double* mrc = &MRD[cb][lane];
@@ -102,7 +110,11 @@ __global__ __launch_bounds__(1024) void k_elim64(const double* __restrict__ Din,
 #pragma unroll
             for (int q = 0; q < CW; ++q) {
                 const int jj = cb + q;
+#if PIVCHK
+                { const int h = hi_word(piv); hmin = min(hmin, h); hmax = max(hmax, h); }
+#else
                 pmin = fmin(pmin, piv);
+#endif
                 const double mr0 = m[q] * x0;
                 const double mr = fma(mr0, e, mr0);
                 mrs[q] = mr;
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_elim64(const double* __restrict__ Din,
                 stamps[(size_t)blockIdx.x * 48 + 3 * wv + 1] = t_end - t_begin;
                 stamps[(size_t)blockIdx.x * 48 + 3 * wv + 2] = t_end - t_own;
             }
-            if (!isT && !(pmin > 0.0) && lane == 0) fail[0] = 1.0;
+            if (!isT && (PIVCHK ? (hmin <= 0 || hmax >= 0x7ff00000) : !(pmin > 0.0)) && lane == 0) fail[0] = 1.0;
         }
         __syncthreads();   // the LDS arrays are rewritten by the next repetition
     }
