@@ -41,7 +41,7 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, *n, "1", "3"], capture_output=True, text=True, timeout=600)       # 1 repetition, 3 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("(ok)") == 3 and "MISMATCH" not in r.stdout
+    assert r.stdout.count("(ok)") == 3 and "MISMATCH" not in r.stdout and "2 of 2 bit-identical to the first" in r.stdout
 
 
 def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):

@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -419,7 +420,8 @@ int main(int argc, char** argv) {
     std::printf("n = %d%s: ld %d, %d tile rows, %d block columns (%d on the longest chain), %d tasks of 1024 threads\n", n, nd ? " (two arcs + separator)" : "", ld, nt, nbc, chain, ntask);
 #ifdef WAVEEMU
     const unsigned nseeds = argc > seeds_arg ? (unsigned)std::atoi(argv[seeds_arg]) : 2;
-    int rc = 0;
+    int rc = 0, same = 0;
+    std::vector<double> x_first;
     for (unsigned seed = 1; seed <= nseeds; ++seed) {
         std::fill(PUB.begin(), PUB.end(), 0.0); std::fill(YU.begin(), YU.end(), 0.0); std::fill(x.begin(), x.end(), 0.0);
         unsigned long long sw = 0;
@@ -460,7 +462,16 @@ int main(int argc, char** argv) {
         const double res = chol_residual(S, x);
         std::printf("  |A x - b|_inf / |b|_inf = %.3e %s, failure flag %g\n", res, res < 1e-11 ? "(ok)" : "(MISMATCH)", fail);
         if (!(res < 1e-11) || fail != 0.0) rc = 1;
+#ifdef WAVEEMU
+        // the order in which a task takes its slabs and columns is fixed by the plan, not by the schedule: the same BITS every time
+        if (x_first.empty()) x_first = x;
+        else if (std::memcmp(x_first.data(), x.data(), x.size() * sizeof(double)) != 0) { std::printf("  the solution differs in its bits from the first interleaving's\n"); rc = 1; }
+        else ++same;
+#endif
     }
+#ifdef WAVEEMU
+    std::printf("%u interleavings, %d of %u bit-identical to the first\n", nseeds, same, nseeds - 1);
+#endif
 #ifndef WAVEEMU
     // the chain: per block column the diagonal task's stamps {start, update done, D wave 7 done, last slab flagged} in 100 MHz ticks
     for (int t = 0; t < ntask; ++t)
