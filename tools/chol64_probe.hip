@@ -241,6 +241,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(dF, 0, 8));
     for (int pass = 0; pass < 2; ++pass) {      // the second launch is the warm one
         hipLaunchKernelGGL(k_elim64, dim3(nblk), dim3(1024), 0, 0, dD, dT, dO, dS, dF, reps);
+        CK(hipGetLastError());
         CK(hipDeviceSynchronize());
     }
     CK(hipMemcpy(out.data(), dO, out.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(stamps.data(), dS, stamps.size() * 8, hipMemcpyDeviceToHost));

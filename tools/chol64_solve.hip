@@ -441,6 +441,11 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice)); CK(hipMemset(dP, 0, PUB.size() * 8)); CK(hipMemset(dY, 0, YU.size() * 8));
     CK(hipMemset(dF, 0, 8)); CK(hipMemset(dfa, 0, flagA.size() * 4)); CK(hipMemset(dfr, 0, flagR.size() * 4)); CK(hipMemset(dG, 0, dbg.size() * 8));
     CK(hipMemcpy(dT, p2.tasks.data(), p2.tasks.size() * sizeof(int4), hipMemcpyHostToDevice)); CK(hipMemcpy(dD, p2.deps.data(), p2.deps.size() * 4, hipMemcpyHostToDevice));
+    {
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        std::printf("%s: %zu bytes of LDS per workgroup allowed, %d CUs\n", prop.name, (size_t)prop.sharedMemPerBlock, prop.multiProcessorCount);
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
@@ -448,6 +453,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < std::max(reps, 3); ++rep) {
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k_chol64, dim3(ntask), dim3(1024), 0, 0, dA, dP, dY, ld, n, nbc, dT, dD, dfa, dfr, (unsigned)(rep + 1), dF, dX, dG);
+        CK(hipGetLastError());      // (135 KB of static LDS: a launch the device refuses shows here, not as a wrong answer)
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms;
