@@ -20,7 +20,7 @@ def test_sixteen_wave_block_column_under_the_wave_emulator(tmp_path, catch):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "chol64_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-DWAVEEMU", f"-DCATCH={catch}", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", f"-DCATCH={catch}", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
                         os.path.join(ROOT, "tools", "chol64_probe.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, "2", "2", "6"], capture_output=True, text=True, timeout=300)       # 2 blocks, 2 repetitions, 6 interleavings
@@ -36,7 +36,7 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "chol64_solve_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-DWAVEEMU", "-Wno-psabi", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", "-Wno-psabi", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
                         os.path.join(ROOT, "tools", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, *n, "1", "3"], capture_output=True, text=True, timeout=600)       # 1 repetition, 3 interleavings
@@ -57,10 +57,14 @@ def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     exe = str(tmp_path / "chol32_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path), os.path.join(ROOT, "tools", "chol32_emu.cpp"),
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tools", "waveemu"), "-pthread", "-I", str(tmp_path), os.path.join(ROOT, "tools", "chol32_emu.cpp"),
                         "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for args, n in ((("100", "12"), 12), (("63", "4"), 4), (("nd", "1", "2", "1", "4"), 4)):
         r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and r.stdout.count("(ok)") == n and "MISMATCH" not in r.stdout, r.stdout + r.stderr
         assert f"{n - 1} of {n - 1} bit-identical to the first" in r.stdout      # the result does not depend on the schedule
+    # the whole launch side by side: three workgroups in flight on OS threads, dispatched in index order, polling each other's flags
+    # (with the flag test of the staging step removed this mode fails at once, the one-after-the-other mode above cannot see it)
+    r = subprocess.run([exe, "100", "6"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SE2_EMU_RESIDENT="3"))
+    assert r.returncode == 0 and r.stdout.count("(ok)") == 6 and "5 of 5 bit-identical to the first" in r.stdout, r.stdout + r.stderr

@@ -5,7 +5,8 @@
 // overlaid on Tc / Ta (`loaded_s`), `ready_s` against COLV / MRC, the x tasks.  What it cannot see: the memory ordering between
 // workgroups (the emulator's stores are visible at once) - that is what tools/soak_fresh.sh checks on the GPU.  Test harness only.
 //   python tools/waveemu/extract_chol_tiles.py /tmp/chol32_body.inc
-//   g++ -O2 -std=c++17 -I tools/waveemu -I /tmp tools/chol32_emu.cpp -o /tmp/chol32_emu && /tmp/chol32_emu nd 3 5 1 20
+//   g++ -O2 -std=c++17 -pthread -I tools/waveemu -I /tmp tools/chol32_emu.cpp -o /tmp/chol32_emu && /tmp/chol32_emu nd 3 5 1 20
+//   SE2_EMU_RESIDENT=4 /tmp/chol32_emu 100 50     (the tasks of a launch side by side, four in flight, dispatched in index order)
 #include "waveemu.h"
 
 #include <cmath>
@@ -23,7 +24,7 @@ struct BaCtl { int done; };
 static inline double bcast_lane(double v, int lane) { return waveemu_readlane(v, lane); }
 static inline d2_t load_agent(const double* p) { return d2_t{p[0], p[1]}; }
 static inline void store_agent(double* p, d2_t v) { p[0] = v.x; p[1] = v.y; }
-static inline unsigned poll_agent(const unsigned* p) { return *p; }
+static inline unsigned poll_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 
 #include "chol32_body.inc"
 #include "chol_host.h"
@@ -35,6 +36,8 @@ int main(int argc, char** argv) {
     const int n = nd ? 0 : (argc > 1 ? std::atoi(argv[1]) : 100);
     const unsigned seed0 = nd ? (argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u) : (argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u);
     const unsigned nseeds = nd ? (argc > 5 ? (unsigned)std::atoi(argv[5]) : 3u) : (argc > 2 ? (unsigned)std::atoi(argv[2]) : 3u);
+    // SE2_EMU_RESIDENT=k: the tasks of a launch run side by side, k at a time (default: one after the other)
+    const unsigned resident = std::getenv("SE2_EMU_RESIDENT") ? (unsigned)std::atoi(std::getenv("SE2_EMU_RESIDENT")) : 0u;
     const CholSystem S = chol_system(kNB, n, arc, sep);
     const int ntask = (int)S.plan.tasks.size();
     std::printf("n = %d%s: ld %d, %d tile rows, %d block columns (%d on the longest chain), %d tasks of 256 threads\n", S.n, nd ? " (two arcs + separator)" : "", S.ld,
@@ -50,11 +53,14 @@ int main(int argc, char** argv) {
         double* YU = PUB.data() + 2 * (size_t)S.nt * S.nbc * kSlabs * kSlabDoubles;
         unsigned epoch = seed;
         unsigned long long sw = 0;
-        for (int t = 0; t < ntask; ++t)
-            sw += waveemu::run_group(256, t, ntask, seed * 7919u + t, [&]() {
-                d_chol_tiles<false>(blockIdx.x, S.A.data(), PUB.data(), YU, S.ld, S.n, S.nbc, S.plan.tasks.data(), S.plan.deps.data(), nullptr, flagA.data(), flagR.data(),
-                                    &epoch, &fail, nullptr, nullptr, x.data(), nullptr);
-            });
+        auto task = [&]() {
+            d_chol_tiles<false>(blockIdx.x, S.A.data(), PUB.data(), YU, S.ld, S.n, S.nbc, S.plan.tasks.data(), S.plan.deps.data(), nullptr, flagA.data(), flagR.data(),
+                                &epoch, &fail, nullptr, nullptr, x.data(), nullptr);
+        };
+        if (resident > 0)       // the whole launch side by side: `resident` workgroups in flight on OS threads, dispatched in index order
+            waveemu::run_grid(256, ntask, resident, seed, task);
+        else
+            for (int t = 0; t < ntask; ++t) sw += waveemu::run_group(256, t, ntask, seed * 7919u + t, task);
         const double res = chol_residual(S, x);
         std::printf("interleaving %u: %llu switches, |A x - b|_inf / |b|_inf = %.3e %s, failure flag %g\n", seed, sw, res, res < 1e-11 ? "(ok)" : "(MISMATCH)", fail);
         if (!(res < 1e-11) || fail != 0.0) rc = 1;

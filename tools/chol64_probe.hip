@@ -13,7 +13,7 @@
 // (gfx950, -O3, CATCH=2: 104 VGPRs, no scratch, 98,312 bytes of LDS = one workgroup per CU; not yet run on a GPU - written at the end
 // of round 4 when the round's GPU minutes were spent.)
 // The LOGIC (progress counters, who reads what when, the result) is checked without a GPU by tools/waveemu:
-//   g++ -O2 -std=c++17 -DWAVEEMU -I tools/waveemu -x c++ tools/chol64_probe.hip -o /tmp/chol64_emu && /tmp/chol64_emu
+//   g++ -O2 -std=c++17 -pthread -DWAVEEMU -I tools/waveemu -x c++ tools/chol64_probe.hip -o /tmp/chol64_emu && /tmp/chol64_emu
 #ifdef WAVEEMU
 #include "waveemu.h"
 #else

@@ -16,7 +16,7 @@
 // NOT YET RUN ON A GPU (written when round 4's GPU minutes were spent).  Its logic - plan, flags, staging counters, MFMA operand
 // mapping, elimination protocol, publish layout, x tasks - runs on the CPU under tools/waveemu (tasks in launch order, the waves of
 // a task interleaved at random):
-//   g++ -O2 -std=c++17 -DWAVEEMU -I tools/waveemu -x c++ tools/chol64_solve.hip -o /tmp/chol64_solve_emu && /tmp/chol64_solve_emu 150
+//   g++ -O2 -std=c++17 -pthread -DWAVEEMU -I tools/waveemu -x c++ tools/chol64_solve.hip -o /tmp/chol64_solve_emu && /tmp/chol64_solve_emu 150
 #ifdef WAVEEMU
 #include "waveemu.h"
 #else

@@ -22,7 +22,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <functional>
+#include <thread>
 #include <memory>
 #include <random>
 #include <vector>
@@ -54,7 +56,7 @@ struct Group {
     std::function<void()> body;
     Dim3 block_idx, block_dim, grid_dim;
 };
-inline Group*& g() { static Group* p = nullptr; return p; }
+inline Group*& g() { static thread_local Group* p = nullptr; return p; }      // (one workgroup per OS thread: run_grid)
 inline void yield() {
     Group* G = g();
     if (++G->switches > G->limit) {
@@ -138,6 +140,24 @@ inline unsigned long long run_group(int nthreads, unsigned bx, unsigned nblocks,
     return G.switches;
 }
 
+// A launch of `nblocks` workgroups with at most `resident` of them in flight, each on an OS thread of its own and dispatched in
+// order of their index as the hardware does: what a dataflow kernel relies on when its grid exceeds what is resident (a task
+// may wait only for tasks with a lower index).  The workgroups really run side by side - global memory is shared as it is.
+inline void run_grid(int nthreads, unsigned nblocks, unsigned resident, unsigned seed, std::function<void()> body,
+                     unsigned long long limit = 4000000000ull) {
+    std::atomic<unsigned> next{0};
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < resident; ++k)
+        pool.emplace_back([&]() {
+            for (;;) {
+                const unsigned b = next.fetch_add(1);
+                if (b >= nblocks) return;
+                run_group(nthreads, b, nblocks, seed * 7919u + b, body, limit);
+            }
+        });
+    for (std::thread& t : pool) t.join();
+}
+
 inline void block_barrier() {
     Group* G = g();
     const unsigned gen = G->bar_gen;
@@ -169,7 +189,7 @@ inline double wave_read(double v, int lane) {
 // ---- the spellings a kernel uses -------------------------------------------------------------------------------------
 #define __global__
 #define __device__
-#define __shared__ static
+#define __shared__ static thread_local      // one copy per OS thread = per workgroup in flight
 #define __launch_bounds__(...)
 #define __restrict__
 #define __forceinline__ inline
@@ -180,9 +200,11 @@ inline double wave_read(double v, int lane) {
 #define __ATOMIC_SCOPE_IGNORED 0
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 #define __HIP_MEMORY_SCOPE_AGENT 0
-#define __hip_atomic_load(p, order, scope) (*(p))
-#define __hip_atomic_store(p, v, order, scope) (void)(*(p) = (v))
-#define __hip_atomic_fetch_add(p, v, order, scope) ((*(p) += (v)) - (v))
+// (acquire / release whatever the kernel asks for: on the host they cost nothing and keep the compiler from moving a payload
+// access across a flag when workgroups run on several OS threads)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL)
 inline void __syncthreads() { waveemu::block_barrier(); }
 inline void __builtin_amdgcn_s_sleep(int n) { waveemu::g()->fibres[waveemu::g()->cur].where = 100 + n; waveemu::yield(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
