@@ -42,6 +42,9 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
     r = subprocess.run([exe, *n, "1", "3"], capture_output=True, text=True, timeout=600)       # 1 repetition, 3 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("(ok)") == 3 and "MISMATCH" not in r.stdout and "2 of 2 bit-identical to the first" in r.stdout
+    if n == ("130",):       # the launch side by side: three workgroups in flight on OS threads, polling each other's flags
+        r = subprocess.run([exe, *n, "1", "3"], capture_output=True, text=True, timeout=600, env=dict(os.environ, SE2_EMU_RESIDENT="3"))
+        assert r.returncode == 0 and r.stdout.count("(ok)") == 3 and "2 of 2 bit-identical to the first" in r.stdout, r.stdout + r.stderr
 
 
 def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):

@@ -51,7 +51,7 @@ using std::min;
 #define WAIT_VM4(a, b, c, d)
 #define WAIT_VM8(a, b, c, d, e, f, g, h)
 static inline void store_agent(double* p, d2_t v) { p[0] = v[0]; p[1] = v[1]; }
-static inline unsigned poll_agent(const unsigned* p) { return *p; }
+static inline unsigned poll_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 static inline void wait_vm() {}
 #else
 #define WAVE_LOCKSTEP()
@@ -425,12 +425,18 @@ int main(int argc, char** argv) {
     for (unsigned seed = 1; seed <= nseeds; ++seed) {
         std::fill(PUB.begin(), PUB.end(), 0.0); std::fill(YU.begin(), YU.end(), 0.0); std::fill(x.begin(), x.end(), 0.0);
         unsigned long long sw = 0;
-        for (int rep = 0; rep < reps; ++rep)
-            for (int t = 0; t < ntask; ++t)      // launch order = dependency order: every flag a task polls is already up
-                sw += waveemu::run_group(1024, t, ntask, seed * 7919u + t, [&]() {
-                    k_chol64(A.data(), PUB.data(), YU.data(), ld, n, nbc, p2.tasks.data(), p2.deps.data(), flagA.data(), flagR.data(), seed * 100u + rep + 1u,
-                             &fail, x.data(), dbg.data());
-                });
+        // SE2_EMU_RESIDENT=k: the tasks of a launch side by side on OS threads, k in flight, dispatched in index order; default: one after
+        // the other (launch order = dependency order: every flag a task polls is already up)
+        const unsigned resident = std::getenv("SE2_EMU_RESIDENT") ? (unsigned)std::atoi(std::getenv("SE2_EMU_RESIDENT")) : 0u;
+        for (int rep = 0; rep < reps; ++rep) {
+            auto task = [&]() {
+                k_chol64(A.data(), PUB.data(), YU.data(), ld, n, nbc, p2.tasks.data(), p2.deps.data(), flagA.data(), flagR.data(), seed * 100u + rep + 1u, &fail,
+                         x.data(), dbg.data());
+            };
+            if (resident > 0) waveemu::run_grid(1024, ntask, resident, seed, task);
+            else
+                for (int t = 0; t < ntask; ++t) sw += waveemu::run_group(1024, t, ntask, seed * 7919u + t, task);
+        }
         std::printf("interleaving %u: %llu switches\n", seed, sw);
 #else
 #define CK(x_) do { hipError_t e_ = (x_); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x_, hipGetErrorString(e_)); return 1; } } while (0)
