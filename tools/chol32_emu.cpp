@@ -19,11 +19,23 @@
 using std::min;
 #define __host__
 #define WAVE_LOCKSTEP() waveemu::wave_barrier()
-#define SE2_WAIT_VM6(a, b, c, d, e, f)
+#define SE2_WAIT_VM6(a, b, c, d, e, f) WAIT_VM()
+static inline void WAIT_VM();
 struct BaCtl { int done; };
 static inline double bcast_lane(double v, int lane) { return waveemu_readlane(v, lane); }
 static inline d2_t load_agent(const double* p) { return d2_t{p[0], p[1]}; }
-static inline void store_agent(double* p, d2_t v) { p[0] = v.x; p[1] = v.y; }
+// The hand-off's producer side, modelled at its weakest: a write-through store is not visible to anybody until the wave waits for
+// it (`s_waitcnt vmcnt(0)` = WAIT_VM()) - the latest moment the hardware may complete it.  A flag raised before that wait reaches a
+// consumer ahead of the payload, and the consumer's solution is wrong: `SE2_EMU_RESIDENT` > 0 (tasks side by side) then shows it.
+struct PendingStore { double* p; d2_t v; };
+static thread_local std::vector<PendingStore> g_pending[256];
+static inline void store_agent(double* p, d2_t v) { g_pending[waveemu::g()->cur].push_back(PendingStore{p, v}); }
+static inline void WAIT_VM() {
+    std::vector<PendingStore>& q = g_pending[waveemu::g()->cur];
+    for (const PendingStore& s : q) { s.p[0] = s.v.x; s.p[1] = s.v.y; }
+    q.clear();
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+}
 static inline unsigned poll_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 
 #include "chol32_body.inc"
@@ -56,6 +68,7 @@ int main(int argc, char** argv) {
         auto task = [&]() {
             d_chol_tiles<false>(blockIdx.x, S.A.data(), PUB.data(), YU, S.ld, S.n, S.nbc, S.plan.tasks.data(), S.plan.deps.data(), nullptr, flagA.data(), flagR.data(),
                                 &epoch, &fail, nullptr, nullptr, x.data(), nullptr);
+            WAIT_VM();      // (the end of a wave completes what it has in flight)
         };
         if (resident > 0)       // the whole launch side by side: `resident` workgroups in flight on OS threads, dispatched in index order
             waveemu::run_grid(256, ntask, resident, seed, task);
