@@ -50,9 +50,18 @@ using std::min;
 #define LOAD_AGENT(v, p) v = d2_t{(p)[0], (p)[1]}
 #define WAIT_VM4(a, b, c, d)
 #define WAIT_VM8(a, b, c, d, e, f, g, h)
-static inline void store_agent(double* p, d2_t v) { p[0] = v[0]; p[1] = v[1]; }
+// (the hand-off's producer side at its weakest, as in tools/chol32_emu.cpp: a write-through store is visible to nobody until the wave
+// waits for it; a flag raised before that wait overtakes its payload and SE2_EMU_RESIDENT > 0 shows it)
+struct PendingStore { double* p; d2_t v; };
+static thread_local std::vector<PendingStore> g_pending[1024];
+static inline void store_agent(double* p, d2_t v) { g_pending[waveemu::g()->cur].push_back(PendingStore{p, v}); }
 static inline unsigned poll_agent(const unsigned* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
-static inline void wait_vm() {}
+static inline void wait_vm() {
+    std::vector<PendingStore>& q = g_pending[waveemu::g()->cur];
+    for (const PendingStore& st : q) { st.p[0] = st.v[0]; st.p[1] = st.v[1]; }
+    q.clear();
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+}
 #else
 #define WAVE_LOCKSTEP()
 #define WAVE_ONE_LANE(lane) true
@@ -432,6 +441,7 @@ int main(int argc, char** argv) {
             auto task = [&]() {
                 k_chol64(A.data(), PUB.data(), YU.data(), ld, n, nbc, p2.tasks.data(), p2.deps.data(), flagA.data(), flagR.data(), seed * 100u + rep + 1u, &fail,
                          x.data(), dbg.data());
+                wait_vm();      // (the end of a wave completes what it has in flight)
             };
             if (resident > 0) waveemu::run_grid(1024, ntask, resident, seed, task);
             else
