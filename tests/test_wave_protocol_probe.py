@@ -69,5 +69,7 @@ def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
         assert f"{n - 1} of {n - 1} bit-identical to the first" in r.stdout      # the result does not depend on the schedule
     # the whole launch side by side: three workgroups in flight on OS threads, dispatched in index order, polling each other's flags
     # (with the flag test of the staging step removed this mode fails at once, the one-after-the-other mode above cannot see it)
+    r = subprocess.run([exe, "100", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SE2_EMU_INDEFINITE="1"))
+    assert r.returncode == 0 and "the failure flag is raised" in r.stdout, r.stdout + r.stderr       # a negated diagonal entry is reported
     r = subprocess.run([exe, "100", "6"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SE2_EMU_RESIDENT="3"))
     assert r.returncode == 0 and r.stdout.count("(ok)") == 6 and "5 of 5 bit-identical to the first" in r.stdout, r.stdout + r.stderr

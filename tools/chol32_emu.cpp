@@ -17,6 +17,7 @@
 #include <vector>
 
 using std::min;
+using std::max;
 #define __host__
 #define WAVE_LOCKSTEP() waveemu::wave_barrier()
 #define SE2_WAIT_VM6(a, b, c, d, e, f) WAIT_VM()
@@ -50,7 +51,10 @@ int main(int argc, char** argv) {
     const unsigned nseeds = nd ? (argc > 5 ? (unsigned)std::atoi(argv[5]) : 3u) : (argc > 2 ? (unsigned)std::atoi(argv[2]) : 3u);
     // SE2_EMU_RESIDENT=k: the tasks of a launch run side by side, k at a time (default: one after the other)
     const unsigned resident = std::getenv("SE2_EMU_RESIDENT") ? (unsigned)std::atoi(std::getenv("SE2_EMU_RESIDENT")) : 0u;
-    const CholSystem S = chol_system(kNB, n, arc, sep);
+    CholSystem S = chol_system(kNB, n, arc, sep);
+    // SE2_EMU_INDEFINITE=1: one diagonal entry negated - the diagonal task of that block column must raise the failure flag
+    const bool indefinite = std::getenv("SE2_EMU_INDEFINITE") != nullptr;
+    if (indefinite) { const int k = S.n / 2; S.A[(size_t)k * S.ld + k] = -S.A[(size_t)k * S.ld + k]; }
     const int ntask = (int)S.plan.tasks.size();
     std::printf("n = %d%s: ld %d, %d tile rows, %d block columns (%d on the longest chain), %d tasks of 256 threads\n", S.n, nd ? " (two arcs + separator)" : "", S.ld,
                 S.nt, S.nbc, S.chain, ntask);
@@ -76,6 +80,10 @@ int main(int argc, char** argv) {
             for (int t = 0; t < ntask; ++t) sw += waveemu::run_group(256, t, ntask, seed * 7919u + t, task);
         const double res = chol_residual(S, x);
         std::printf("interleaving %u: %llu switches, |A x - b|_inf / |b|_inf = %.3e %s, failure flag %g\n", seed, sw, res, res < 1e-11 ? "(ok)" : "(MISMATCH)", fail);
+        if (indefinite) {
+            std::printf("  (indefinite system: the failure flag is %s)\n", fail == 1.0 ? "raised, as it must be" : "NOT raised");
+            return fail == 1.0 ? 0 : 1;
+        }
         if (!(res < 1e-11) || fail != 0.0) rc = 1;
         // the order in which a task takes its slabs and columns is fixed by the plan, not by the schedule: every interleaving must give
         // the same BITS

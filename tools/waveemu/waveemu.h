@@ -231,6 +231,7 @@ inline long long __shfl_xor(long long v, int mask) {
     std::memcpy(&v, &d, 8);
     return v;
 }
+inline int __double2hiint(double d) { long long v; std::memcpy(&v, &d, 8); return (int)(v >> 32); }
 inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }
 // v_mfma_f64_16x16x4_f64 in the layout tools/mfma_probe.hip found on gfx950: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k,
