@@ -73,3 +73,16 @@ def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
     assert r.returncode == 0 and "the failure flag is raised" in r.stdout, r.stdout + r.stderr       # a negated diagonal entry is reported
     r = subprocess.run([exe, "100", "6"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SE2_EMU_RESIDENT="3"))
     assert r.returncode == 0 and r.stdout.count("(ok)") == 6 and "5 of 5 bit-identical to the first" in r.stdout, r.stdout + r.stderr
+
+
+def test_staged_patches_still_apply():
+    """tools/patches holds changes to the product that were written and checked as far as a machine without a GPU allows; they must
+    keep applying to the tree they were written against (a change of the kernel underneath is noticed here, not next round)."""
+    if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout")
+    pdir = os.path.join(ROOT, "tools", "patches")
+    patches = sorted(f for f in os.listdir(pdir) if f.endswith(".patch"))
+    assert patches
+    for f in patches:
+        r = subprocess.run(["git", "apply", "--check", os.path.join(pdir, f)], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, f + ": " + r.stderr
