@@ -86,3 +86,26 @@ def test_staged_patches_still_apply():
     for f in patches:
         r = subprocess.run(["git", "apply", "--check", os.path.join(pdir, f)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, f + ": " + r.stderr
+
+
+@pytest.mark.parametrize("P", [21, 33, 64])
+def test_experiments_plan_equals_the_products_plan(tmp_path, P):
+    """tools/waveemu/chol_host.h builds the task plan the experiments run on (dense, arcs + separator); the product's is
+    solve_plan_build in csrc/ba.hip.  On a dense system of P poses the two must be the same lists - the emulated kernel then runs on
+    exactly what the device kernel is given."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    import numpy as np
+    from test_solve_plan import _plan
+    inc = tmp_path / "chol32_body.inc"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = str(tmp_path / "chol32_emu")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path),
+                        os.path.join(ROOT, "tools", "chol32_emu.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe, str(3 * P)], capture_output=True, text=True, env=dict(os.environ, SE2_EMU_PRINT_PLAN="1")).stdout.split("\n")
+    tasks = np.array([[int(v) for v in l.split()[1:]] for l in out if l.startswith("T ")], np.int32)
+    deps = np.array([int(l.split()[1]) for l in out if l.startswith("D ")], np.int32)
+    want = _plan(P, 3, None, allow_nd=False)
+    assert np.array_equal(tasks, want["tasks"]) and np.array_equal(deps, want["deps"])

@@ -56,6 +56,11 @@ int main(int argc, char** argv) {
     const bool indefinite = std::getenv("SE2_EMU_INDEFINITE") != nullptr;
     if (indefinite) { const int k = S.n / 2; S.A[(size_t)k * S.ld + k] = -S.A[(size_t)k * S.ld + k]; }
     const int ntask = (int)S.plan.tasks.size();
+    if (std::getenv("SE2_EMU_PRINT_PLAN")) {      // the plan only: tests compare it with the product's solve_plan_build
+        for (const int4& t : S.plan.tasks) std::printf("T %d %d %d %d\n", t.x, t.y, t.z, t.w);
+        for (int d : S.plan.deps) std::printf("D %d\n", d);
+        return 0;
+    }
     std::printf("n = %d%s: ld %d, %d tile rows, %d block columns (%d on the longest chain), %d tasks of 256 threads\n", S.n, nd ? " (two arcs + separator)" : "", S.ld,
                 S.nt, S.nbc, S.chain, ntask);
     std::vector<double> PUB(2 * (size_t)S.nt * S.nbc * kSlabs * kSlabDoubles + S.ld, 0.0), x(S.n, 0.0);
