@@ -355,6 +355,9 @@ int se2gpu_ba_debug_chol_verify(se2gpu_ba* h, unsigned long long* counts2, unsig
  * /root/reference/include/se2lam/optimizer.h:31.  Test introspection (tests/test_solve_plan.py). */
 int se2gpu_ba_debug_solve_plan(int P, int D, const uint8_t* pattern, int allow_nd, int* nsys, int* nbc, int* depth, int* ntask,
                                int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap);
+/* the same with the tile size of the dense solve as an argument (32 or 64) */
+int se2gpu_ba_debug_solve_plan_tile(int P, int D, const uint8_t* pattern, int allow_nd, int tile, int* nsys, int* nbc, int* depth, int* ntask,
+                                    int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap);
 
 /* Track::doTriangulate (/root/reference/src/Track.cpp:378-419) for every match of a frame pair in one device pass -
  * SURVEY section 8(f).3.  Per feature i of the reference key frame with match_idx[i] >= 0 and no map point yet:

@@ -151,6 +151,7 @@ SYMBOLS = {
     "se2gpu_ba_debug_chol_verify": (_I, [_VP, _VP, _VP, _I]),
     "se2gpu_ba_debug_pool_sizes": (_I, [_VP]),
     "se2gpu_ba_debug_solve_plan": (_I, [_I, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I]),
+    "se2gpu_ba_debug_solve_plan_tile": (_I, [_I, _I, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I]),
     "se2gpu_triangulate": (_I, [_I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, C.c_float, C.c_float, _I, _VP, _VP,
                            C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "se2gpu_track_create": (_I, [C.POINTER(_VP)]),

@@ -3746,21 +3746,21 @@ struct SolvePlan {
 
 // parts: the poses of every partition in order; pad: partitions (and therefore the rhs row) start on tile boundaries;
 // pat: nullptr (dense) or a SYMMETRIC P x P byte pattern
-void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::vector<int>>& parts, bool pad, SolvePlan& sp) {
+void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::vector<int>>& parts, bool pad, SolvePlan& sp, int nb = kNB) {
     sp.pose_off.assign(P, 0);
     int c = 0;
     for (const auto& part : parts) {
         for (int p : part) { sp.pose_off[p] = c; c += D; }
-        if (pad) c = (c + kNB - 1) / kNB * kNB;
+        if (pad) c = (c + nb - 1) / nb * nb;
     }
     sp.nsys = c;
     sp.permuted = pad;
     sp.col_src.assign(sp.nsys, -1);
     for (int p = 0; p < P; ++p)
         for (int k = 0; k < D; ++k) sp.col_src[sp.pose_off[p] + k] = D * p + k;
-    const int nbc = (sp.nsys + kNB - 1) / kNB;
-    const int ld = ((sp.nsys + 1 + kNB - 1) / kNB) * kNB, nt = ld / kNB;
-    const int it = sp.nsys / kNB;                     // tile row of the rhs row (== nbc when the system is padded)
+    const int nbc = (sp.nsys + nb - 1) / nb;
+    const int ld = ((sp.nsys + 1 + nb - 1) / nb) * nb, nt = ld / nb;
+    const int it = sp.nsys / nb;                     // tile row of the rhs row (== nbc when the system is padded)
     sp.nbc = nbc;
     sp.nt = nt;
     // tile pattern of the lower triangle (rows 0 .. nt-1: the rhs tile row is dense)
@@ -3771,7 +3771,7 @@ void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::v
     // the dataflow solve takes, larger systems go to k_chol_step and need no tile pattern): P^2 branch-free ORs instead of
     // P^2 / 2 tests with up to four stores each - this loop was most of the 0.18 ms the plan cost at 200 key frames
     std::vector<int> t0(P), t1(P);
-    for (int p = 0; p < P; ++p) { t0[p] = sp.pose_off[p] / kNB; t1[p] = (sp.pose_off[p] + D - 1) / kNB; }
+    for (int p = 0; p < P; ++p) { t0[p] = sp.pose_off[p] / nb; t1[p] = (sp.pose_off[p] + D - 1) / nb; }
     if (nt <= 64) {
         std::vector<unsigned long long> tm(P), rowmask(nt, 0ull);
         for (int p = 0; p < P; ++p) tm[p] = (t1[p] >= 63 ? ~0ull : (1ull << (t1[p] + 1)) - 1) & ~((1ull << t0[p]) - 1);
@@ -3851,7 +3851,7 @@ void solve_plan_build(int P, int D, const uint8_t* pat, const std::vector<std::v
 
 // candidate orders for a pattern whose natural order is a band - open or closed to a ring (key frames in sequence, a loop
 // closure at most between the ends) - and the choice by chain length
-void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, SolvePlan& best, bool symmetric = false) {
+void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, SolvePlan& best, bool symmetric = false, int nb = kNB) {
     std::vector<int> all(P);
     for (int p = 0; p < P; ++p) all[p] = p;
     std::vector<uint8_t> sym;
@@ -3862,8 +3862,8 @@ void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, Solve
             for (int b = 0; b < P; ++b) sym[(size_t)a * P + b] = (uint8_t)((pat_in[(size_t)a * P + b] | pat_in[(size_t)b * P + a]) != 0);
         pat = sym.data();
     }
-    solve_plan_build(P, D, pat, {all}, false, best);
-    if (!allow_nd || !pat || D * P < 4 * kNB) return;
+    solve_plan_build(P, D, pat, {all}, false, best, nb);
+    if (!allow_nd || !pat || D * P < 4 * nb) return;
     // widths of the band: which distances |a - b| occur at all (one OR per entry, no branch), then the largest linear and
     // cyclic distance among them
     int w_lin = 0, w_cyc = 0;
@@ -3877,7 +3877,7 @@ void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, Solve
         for (int d = 1; d < P; ++d)
             if (dist[d]) { w_lin = std::max(w_lin, d); w_cyc = std::max(w_cyc, std::min(d, P - d)); }
     }
-    const int min_interior = (kNB + D - 1) / D;       // an interior below one tile of poses is not worth a partition
+    const int min_interior = (nb + D - 1) / D;       // an interior below one tile of poses is not worth a partition
     std::function<void(int, int, int, int, std::vector<std::vector<int>>&)> linear = [&](int lo, int hi, int w, int levels,
                                                                                          std::vector<std::vector<int>>& out) {
         const int n = hi - lo;
@@ -3903,7 +3903,7 @@ void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, Solve
             if (sd == parts) return;
         seen.push_back(parts);
         SolvePlan cand;
-        solve_plan_build(P, D, pat, parts, true, cand);
+        solve_plan_build(P, D, pat, parts, true, cand, nb);
         // a shorter chain of block columns wins; the natural order keeps ties (no padding, fewer tiles)
         if (cand.depth < best.depth && cand.nt <= 64) best = std::move(cand);
     };
@@ -3930,9 +3930,9 @@ void solve_plan_choose(int P, int D, const uint8_t* pat_in, bool allow_nd, Solve
         // partitions are padded to tile boundaries, so the chain is ceil(arc / tile) + ceil(separators / tile) block columns: a few
         // poses moved from the arcs into the separators can take a tile off the arcs without adding one to the separators
         // (200 key frames, band 43: arcs 57 -> 52 poses = 6 -> 5 tiles, separators 86 -> 96 poses = 9 tiles either way)
-        auto tiles = [&](int poses) { return (D * poses + kNB - 1) / kNB; };
+        auto tiles = [&](int poses) { return (D * poses + nb - 1) / nb; };
         int sw_best = w, est_best = tiles(std::max(h - w, P - h - w)) + tiles(2 * w);
-        for (int sw = w + 1; sw <= w + kNB && 2 * sw + 2 * min_interior <= P; ++sw) {
+        for (int sw = w + 1; sw <= w + nb && 2 * sw + 2 * min_interior <= P; ++sw) {
             const int est = tiles(std::max(h - sw, P - h - sw)) + tiles(2 * sw);
             if (est < est_best) { est_best = est; sw_best = sw; }
         }
@@ -5921,6 +5921,25 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
 // The plan of the dense pose solve for a P x P block pattern (row-major bytes, != 0 where two poses share a landmark or an
 // odometry edge; NULL = dense), without a device: tests/test_solve_plan.py runs the tile algorithm of k_chol_tiles in numpy
 // from these lists.  Arrays may be NULL (sizes only); tasks: {tile row | kind << 16, block column, first dep, end dep}.
+// (the same with the tile size as an argument: 32 = what k_chol_tiles runs on, 64 = the wide block column of DESIGN.md 8.1)
+int se2gpu_ba_debug_solve_plan_tile(int P, int D, const uint8_t* pattern, int allow_nd, int tile, int* nsys, int* nbc, int* depth, int* ntask,
+                                    int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap) {
+    SE2_REQUIRE(P > 0 && (D == 3 || D == 6) && (tile == 32 || tile == 64) && nsys && nbc && depth && ntask && ndep, SE2GPU_ERR_INVALID, "debug_solve_plan_tile: bad argument");
+    SolvePlan sp;
+    solve_plan_choose(P, D, pattern, allow_nd != 0, sp, false, tile);
+    *nsys = sp.nsys; *nbc = sp.nbc; *depth = sp.depth; *ntask = (int)sp.tasks.size(); *ndep = (int)sp.deps.size();
+    if (pose_off) std::memcpy(pose_off, sp.pose_off.data(), (size_t)P * 4);
+    if (tasks4) {
+        SE2_REQUIRE(task_cap >= (int)sp.tasks.size(), SE2GPU_ERR_CAPACITY, "debug_solve_plan_tile: %zu tasks", sp.tasks.size());
+        std::memcpy(tasks4, sp.tasks.data(), sp.tasks.size() * sizeof(int4));
+    }
+    if (deps) {
+        SE2_REQUIRE(dep_cap >= (int)sp.deps.size(), SE2GPU_ERR_CAPACITY, "debug_solve_plan_tile: %zu dependency entries", sp.deps.size());
+        std::memcpy(deps, sp.deps.data(), sp.deps.size() * 4);
+    }
+    return SE2GPU_OK;
+}
+
 int se2gpu_ba_debug_solve_plan(int P, int D, const uint8_t* pattern, int allow_nd, int* nsys, int* nbc, int* depth, int* ntask,
                                int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap) {
     SE2_REQUIRE(P > 0 && (D == 3 || D == 6) && nsys && nbc && depth && ntask && ndep, SE2GPU_ERR_INVALID, "debug_solve_plan: bad argument");

@@ -10,21 +10,21 @@ import ctypes as C
 import numpy as np
 import pytest
 
-NB = 32
+NB = 32      # module default; the tests below also run at 64 (the wide block column) through se2gpu_ba_debug_solve_plan_tile
 
 
-def _plan(P, D, pattern, allow_nd=True):
+def _plan(P, D, pattern, allow_nd=True, tile=32):
     from se2lam_amd import capi
     lib = capi.lib()
     out = [C.c_int() for _ in range(5)]
     pat = None if pattern is None else np.ascontiguousarray(pattern, np.uint8)
     pp = None if pat is None else pat.ctypes.data
-    capi.check(lib.se2gpu_ba_debug_solve_plan(P, D, pp, int(allow_nd), *[C.byref(o) for o in out], None, None, 0, None, 0))
+    capi.check(lib.se2gpu_ba_debug_solve_plan_tile(P, D, pp, int(allow_nd), tile, *[C.byref(o) for o in out], None, None, 0, None, 0))
     nsys, nbc, depth, ntask, ndep = [o.value for o in out]
     off = np.zeros(P, np.int32)
     tasks = np.zeros((ntask, 4), np.int32)
     deps = np.zeros(max(ndep, 1), np.int32)
-    capi.check(lib.se2gpu_ba_debug_solve_plan(P, D, pp, int(allow_nd), *[C.byref(o) for o in out], off.ctypes.data,
+    capi.check(lib.se2gpu_ba_debug_solve_plan_tile(P, D, pp, int(allow_nd), tile, *[C.byref(o) for o in out], off.ctypes.data,
                                               tasks.ctypes.data, ntask, deps.ctypes.data, len(deps)))
     return dict(nsys=nsys, nbc=nbc, depth=depth, off=off, tasks=tasks, deps=deps[:ndep])
 
@@ -185,3 +185,36 @@ def test_one_sided_pattern_gives_the_plan_of_its_symmetric_closure():
         got = _plan(P, 3, pat)
         assert got["nsys"] == want["nsys"] and got["depth"] == want["depth"]
         assert np.array_equal(got["tasks"], want["tasks"]) and np.array_equal(got["deps"], want["deps"])
+
+
+@pytest.mark.parametrize("name,P,pattern", [
+    ("dense 40", 40, None),
+    ("dense 21 (one tile + rhs inside it)", 21, None),
+    ("ring 200 / 41", 200, _band(200, 41, True)),
+    ("ring 200 / 43", 200, _band(200, 43, True)),
+    ("open band 120 / 12", 120, _band(120, 12, False)),
+    ("open band 64 / 30 (too wide to cut)", 64, _band(64, 30, False)),
+])
+def test_tile_tasks_solve_the_system_at_tile_64(monkeypatch, name, P, pattern):
+    """the plan for the wide block column: the same numpy executor, 64 x 64 tiles"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "NB", 64)
+    rng = np.random.default_rng(P)
+    D = 3
+    if pattern is not None:
+        pattern = pattern.copy()
+        for p in (3, P // 2):
+            pattern[p, :] = 0; pattern[:, p] = 0; pattern[p, p] = 1
+    S = _random_spd(rng, P, D, pattern)
+    b = rng.normal(size=D * P)
+    want = np.linalg.solve(S, b)
+    for nd in (False, True):
+        plan = _plan(P, D, pattern, nd, tile=64)
+        got = _solve_by_tasks(plan, P, D, S, b)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-11), (name, nd, np.abs(got - want).max())
+        assert plan["nsys"] % 64 == 0 or plan["nsys"] == D * P
+
+
+def test_nested_dissection_at_tile_64_puts_eight_block_columns_on_the_chain():
+    nat, nd = _plan(200, 3, _band(200, 43, True), False, tile=64), _plan(200, 3, _band(200, 43, True), True, tile=64)
+    assert nat["depth"] == nat["nbc"] == 10 and nd["depth"] <= 8 and nd["nsys"] % 64 == 0
