@@ -917,6 +917,11 @@ private:
             if (pid.seq.size() != 2) throw std::runtime_error("MapStorage: PairId needs two ids");
             const int a = pid.seq[0].integer(), b = pid.seq[1].integer();
             if (a < 0 || b < 0 || a >= (int)m.kfs.size() || b >= (int)m.kfs.size()) throw std::runtime_error("MapStorage: FtrGraphPairs names a key frame that does not exist");
+            // KeyFrame::addFtrMeasureFrom is std::map::insert (KeyFrame.cpp:221-223): a second constraint between the same pair of key
+            // frames is ignored, the first stays - seen running in the compiled reference (tests/test_ref_compiled.py)
+            bool known = false;
+            for (const StoredFtrEdge& have : m.kfs[a].ftrFrom) known = known || have.to == b;
+            if (known) continue;
             StoredFtrEdge e;
             e.to = b;
             e.measure = matNode(n.at("Measure"));

@@ -1141,12 +1141,39 @@ def test_map_file_through_the_compiled_map_storage(mapstorage_exe, tmp_path, cap
         assert st["ftr_from"] == sum(1 for p in pairs if p[0] == i) and st["ftr_to"] == sum(1 for p in pairs if p[1] == i)
         mk = mirror[i]      # KF i kps n obs n covis n next d ftr n img RxC
         assert (int(mk[3]), int(mk[5]), int(mk[7]), int(mk[9])) == (st["kps"], st["obs"], st["covisible"], st["odo_from"])
-        assert int(mk[11]) >= st["ftr_from"]          # (the mirror's vector keeps a repeated pair, the reference's std::map the first)
+        assert int(mk[11]) == st["ftr_from"]
     for j in range(nm):
         st = m.storage_mp_state(j)
         assert st == dict(obs=int(O[:, j].sum()), good_prl=True, null=False, id=j)
         for i in np.nonzero(O[:, j])[0]:
             assert m.storage_mp_ftr_idx(j, int(i)) == int(I[i, j])
+    # ---- a file that names one pair of key frames twice: KeyFrame::addFtrMeasureFrom is std::map::insert, the first constraint stays.
+    # The first entry of FtrGraphPairs is repeated behind itself with another measurement; reference and mirror both load the file
+    # and save it again - the copy is gone from both, the first entry's measurement is the one that is kept
+    text = open(a + "se2lam.map").read()
+    head, _, tail = text.partition("FtrGraphPairs:\n")
+    entries = tail.split("\n   -\n")
+    if len(entries) > 1 and tail.startswith("   -\n"):
+        first = entries[0][len("   -\n"):] if entries[0].startswith("   -\n") else entries[0]
+        import re
+        twin = re.sub(r"data: \[ [^,\]]*", "data: [ 1.2500000000000000e+02", first, count=1)
+        assert twin != first
+        c = str(tmp_path / "c") + "/"; d = str(tmp_path / "d") + "/"
+        os.makedirs(c); os.makedirs(d)
+        for f in os.listdir(a):
+            if f.endswith(".bmp") or f.endswith(".txt"):
+                open(c + f, "wb").write(open(a + f, "rb").read())
+        open(c + "se2lam.map", "w").write(head + "FtrGraphPairs:\n   -\n" + first + "\n   -\n" + twin + "\n   -\n" + "\n   -\n".join(entries[1:]))
+        docs_c, top_c = _parse(open(c + "se2lam.map").read())
+        assert len(top_c["FtrGraphPairs"]) == len(top["FtrGraphPairs"]) + 1
+        m2 = ref.RefMap(np.eye(3), np.eye(4), 2.0)
+        m2.storage_load("\n".join(_fs_events(docs_c)) + "\n")
+        got2, _ = _fs_canonical(m2.storage_save().split("\n"))
+        capfd.readouterr()
+        subprocess.run([mapstorage_exe, "copy", c, d], check=True, capture_output=True)
+        docs_d, top_d = _parse(open(d + "se2lam.map").read())
+        want2, dup2 = _fs_canonical(_fs_events(docs_d))
+        assert dup2 == 0 and len(top_d["FtrGraphPairs"]) == len(pairs) and got2 == want2 == want
     # ---- sortMapPoints (MapStorage.cpp:98-118): points without good parallax leave the file, ids and matrix columns close up
     drop = list(range(0, nm, 4))
     for j in drop:
