@@ -612,5 +612,6 @@ template <typename T> inline FileStorage& operator<<(FileStorage& fs, const T& v
 enum { CV_LOAD_IMAGE_GRAYSCALE = 0, IMREAD_GRAYSCALE = 0 };
 inline bool imwrite(const std::string&, const Mat&) { return true; }
 inline Mat imread(const std::string&, int = 1) { return Mat(); }
+inline int waitKey(int = 0) { return -1; }      // OdoSLAM::wait's key poll
 
 }  // namespace cv

@@ -11,6 +11,8 @@
 namespace ros {
 inline bool ok() { return false; }
 inline void shutdown() {}
+class NodeHandle {};      // members of MapPublish (the publisher itself is cut off)
+class Publisher {};
 class Rate {
 public:
     explicit Rate(double) {}

@@ -2,7 +2,8 @@
 // every reference source file of the MAP build, where src/Map.cpp, src/KeyFrame.cpp and src/MapPoint.cpp are compiled with
 // their own headers, and with them the threads - src/Track.cpp, src/LocalMapper.cpp, src/GlobalMapper.cpp, src/Localizer.cpp,
 // src/Sensors.cpp -, src/sparsifier.cpp and the vendored DBoW2 (Thirdparty/DBoW2: the vocabulary template, FORB, the scoring
-// objects).  What is cut off: ROS (ros::Rate / ros::ok in the run() loops, never entered), the publishers and OdoSLAM's main().
+// objects), src/MapStorage.cpp and src/OdoSLAM.cpp.  What is cut off: ROS (ros::Rate / ros::ok in the run() loops, never entered) and the two
+// publishers (FramePublish.cpp, MapPublish.cpp: their members that OdoSLAM.cpp names are empty functions in ref_system_driver.cpp).
 #pragma once
 #include <climits>
 #include <deque>

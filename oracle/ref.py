@@ -436,6 +436,23 @@ class RefMap:
         self._storage_check(f(self._h, buf, n + 1))
         return buf.value.decode()
 
+    def save_trajectory(self, bTc, directory: str, frame_ids=None) -> str:
+        """OdoSLAM::saveMap()'s key-frame trajectory (src/OdoSLAM.cpp:198-212, compiled) of this map; returns the text it wrote.
+        frame_ids: KeyFrame::id per key frame (the number each line starts with; the map file does not store it)."""
+        if frame_ids is not None:
+            f = self._l.ref_system_kf_set_id
+            f.restype = None
+            f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            for k, i in enumerate(frame_ids):
+                f(self._h, k, int(i))
+        t = np.ascontiguousarray(bTc, np.float32).reshape(-1)
+        g = self._l.ref_system_save_trajectory
+        g.restype = C.c_int
+        g.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p]
+        if g(self._h, t.ctypes.data, directory.encode()) != 0:
+            raise RuntimeError("reference OdoSLAM::saveMap raised")
+        return open(os.path.join(directory, "se2lam_kf_trajectory.txt")).read()
+
     def storage_counts(self):
         out = np.zeros(2, np.int32)
         self._l.ref_storage_counts.argtypes = [C.c_void_p, C.c_void_p]

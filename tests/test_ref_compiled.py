@@ -1147,6 +1147,15 @@ def test_map_file_through_the_compiled_map_storage(mapstorage_exe, tmp_path, cap
         assert st == dict(obs=int(O[:, j].sum()), good_prl=True, null=False, id=j)
         for i in np.nonzero(O[:, j])[0]:
             assert m.storage_mp_ftr_idx(j, int(i)) == int(I[i, j])
+    # ---- the key-frame trajectory text: OdoSLAM::saveMap (src/OdoSLAM.cpp:198-212, compiled) on the map the reference has just loaded
+    # against the file the mirror's saveKeyFrameTrajectory wrote for the same map - byte for byte (stream formatting of the floats,
+    # cvu::inv(bTc Tcw), the yaw through g2o's toEuler)
+    bTc = np.eye(4, dtype=np.float32); bTc[:3, :3] = [[0, 0, 1], [-1, 0, 0], [0, -1, 0]]; bTc[0, 3] = 100; bTc[2, 3] = 300
+    alive = [i for i in range(nkf) if i % 5 != 3]                         # the generator's key frames that are not null ...
+    tdir = str(tmp_path / "traj"); os.makedirs(tdir)
+    got_txt = m.save_trajectory(bTc, tdir, frame_ids=[7 * i + 3 for i in alive])      # ... and their frame ids
+    capfd.readouterr()
+    assert got_txt == open(a + "se2lam_kf_trajectory.txt").read() and got_txt.count("\n") == nk
     # ---- a file that names one pair of key frames twice: KeyFrame::addFtrMeasureFrom is std::map::insert, the first constraint stays.
     # The first entry of FtrGraphPairs is repeated behind itself with another measurement; reference and mirror both load the file
     # and save it again - the copy is gone from both, the first entry's measurement is the one that is kept
