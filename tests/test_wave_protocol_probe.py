@@ -109,3 +109,42 @@ def test_experiments_plan_equals_the_products_plan(tmp_path, P):
     deps = np.array([int(l.split()[1]) for l in out if l.startswith("D ")], np.int32)
     want = _plan(P, 3, None, allow_nd=False)
     assert np.array_equal(tasks, want["tasks"]) and np.array_equal(deps, want["deps"])
+
+
+def test_64_wide_prototype_on_the_products_own_tile_64_plan(tmp_path):
+    """The product's plan code at tile 64 (se2gpu_ba_debug_solve_plan_tile: nested dissection of an open band of 120 key frames, the
+    partitions padded to tile boundaries in the middle of the system) handed to the prototype kernel as it is - task list, dependency
+    lists, the padded system - under the emulator, one task after the other and three in flight.  (The ring of 200 key frames, 704
+    columns and 121 tasks, takes a minute per interleaving: by hand, `chol64_solve_emu file <path>`.)"""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    import numpy as np
+    import test_solve_plan as T
+    P, D, tile = 120, 3, 64
+    pattern = T._band(P, 12, False)
+    rng = np.random.default_rng(5)
+    S = T._random_spd(rng, P, D, pattern)
+    b = rng.normal(size=D * P)
+    plan = T._plan(P, D, pattern, True, tile=tile)
+    assert plan["nsys"] % tile == 0 and plan["depth"] < plan["nbc"]          # re-ordered and padded
+    nsys, off = plan["nsys"], plan["off"]
+    ld = -(-(nsys + 1) // tile) * tile
+    A = np.zeros((ld, ld))
+    cols = np.concatenate([off[p] + np.arange(D) for p in range(P)])
+    A[np.ix_(cols, cols)] = S
+    pad = np.setdiff1d(np.arange(nsys), cols)
+    A[pad, pad] = 1.0
+    A[nsys, cols] = b
+    path = str(tmp_path / "system.bin")
+    with open(path, "wb") as f:
+        f.write(np.array([nsys, ld, len(plan["tasks"]), len(plan["deps"])], np.int32).tobytes())
+        f.write(np.ascontiguousarray(plan["tasks"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(plan["deps"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(A, np.float64).tobytes())
+    exe = str(tmp_path / "chol64_solve_emu")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
+                        os.path.join(ROOT, "tools", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for env in ({}, {"SE2_EMU_RESIDENT": "3"}):
+        r = subprocess.run([exe, "file", path, "1", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.count("(ok)") == 1 and "MISMATCH" not in r.stdout, r.stdout + r.stderr

@@ -413,11 +413,32 @@ int main(int argc, char** argv) {
     // uncoupled arcs and a separator that couples to both (the nested-dissection shape of the 200 key-frame window: 3 + 3 + 5 tiles)
     const bool nd = argc > 1 && std::string(argv[1]) == "nd";
     const int arc = nd ? (argc > 2 ? std::atoi(argv[2]) : 3) : 0, sep = nd ? (argc > 3 ? std::atoi(argv[3]) : 5) : 0;
-    const int n = nd ? NB * (2 * arc + sep) : (argc > 1 ? std::atoi(argv[1]) : 600);
-    const int reps = nd ? (argc > 4 ? std::atoi(argv[4]) : 1) : (argc > 2 ? std::atoi(argv[2]) : 1);
-    const int seeds_arg = nd ? 5 : 3;
-    const CholSystem S = chol_system(NB, n, arc, sep);
+    const bool file_mode = argc > 2 && std::string(argv[1]) == "file";
+    int n = nd ? NB * (2 * arc + sep) : (argc > 1 && !file_mode ? std::atoi(argv[1]) : 600);
+    const int reps = file_mode ? (argc > 3 ? std::atoi(argv[3]) : 1) : nd ? (argc > 4 ? std::atoi(argv[4]) : 1) : (argc > 2 ? std::atoi(argv[2]) : 1);
+    const int seeds_arg = file_mode ? 4 : nd ? 5 : 3;
+    // chol64_solve file <path> [repetitions [interleavings]]: a system and ITS PLAN from a file - int32 {n, ld, tasks, dependency entries},
+    // the tasks (4 int32 each), the dependency entries, A (ld x ld doubles, the rhs in row n), as tests/test_wave_protocol_probe.py
+    // writes it from the product's own se2gpu_ba_debug_solve_plan_tile(..., 64, ...)
+    const bool from_file = argc > 2 && std::string(argv[1]) == "file";
+    CholSystem S;
+    if (from_file) {
+        FILE* f = std::fopen(argv[2], "rb");
+        int hdr[4];
+        if (!f || std::fread(hdr, 4, 4, f) != 4) { std::printf("cannot read %s\n", argv[2]); return 2; }
+        S.n = hdr[0]; S.ld = hdr[1]; S.nt = S.ld / NB; S.nbc = (S.n + NB - 1) / NB; S.chain = 0;
+        S.plan.tasks.resize(hdr[2]); S.plan.deps.resize(hdr[3]); S.A.resize((size_t)S.ld * S.ld); S.b.resize(S.n);
+        bool ok = std::fread(S.plan.tasks.data(), sizeof(int4), hdr[2], f) == (size_t)hdr[2];
+        ok = ok && std::fread(S.plan.deps.data(), 4, hdr[3], f) == (size_t)hdr[3];
+        ok = ok && std::fread(S.A.data(), 8, S.A.size(), f) == S.A.size();
+        std::fclose(f);
+        if (!ok) { std::printf("short file %s\n", argv[2]); return 2; }
+        for (int c = 0; c < S.n; ++c) S.b[c] = S.A[(size_t)S.n * S.ld + c];
+    } else {
+        S = chol_system(NB, n, arc, sep);
+    }
     const int ld = S.ld, nt = S.nt, nbc = S.nbc, chain = S.chain;
+    n = S.n;
     const std::vector<double>& A = S.A;
     const Plan& p2 = S.plan;
     // (tile rows: nt of them - the rhs row may open one of its own; block columns: nbc)
