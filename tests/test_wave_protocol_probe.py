@@ -148,3 +148,49 @@ def test_64_wide_prototype_on_the_products_own_tile_64_plan(tmp_path):
     for env in ({}, {"SE2_EMU_RESIDENT": "3"}):
         r = subprocess.run([exe, "file", path, "1", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and r.stdout.count("(ok)") == 1 and "MISMATCH" not in r.stdout, r.stdout + r.stderr
+
+
+def _write_system(path, P, pattern, tile, seed=5, D=3):
+    """a random SPD system with the given pose pattern, laid out by the PRODUCT'S plan (nested dissection, padded partitions), and that plan"""
+    import numpy as np
+    import test_solve_plan as T
+    rng = np.random.default_rng(seed)
+    S = T._random_spd(rng, P, D, pattern)
+    b = rng.normal(size=D * P)
+    plan = T._plan(P, D, pattern, True, tile=tile)
+    nsys, off = plan["nsys"], plan["off"]
+    ld = -(-(nsys + 1) // tile) * tile
+    A = np.zeros((ld, ld))
+    cols = np.concatenate([off[p] + np.arange(D) for p in range(P)])
+    A[np.ix_(cols, cols)] = S
+    pad = np.setdiff1d(np.arange(nsys), cols)
+    A[pad, pad] = 1.0
+    A[nsys, cols] = b
+    with open(path, "wb") as f:
+        f.write(np.array([nsys, ld, len(plan["tasks"]), len(plan["deps"])], np.int32).tobytes())
+        f.write(np.ascontiguousarray(plan["tasks"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(plan["deps"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(A, np.float64).tobytes())
+    return plan
+
+
+def test_shipped_kernel_on_the_products_own_plan(tmp_path):
+    """The shipped d_chol_tiles on what the product hands it for an open band of 120 key frames - nested dissection, partitions padded in
+    the middle of the system, 125 tasks - under the emulator, one task after the other and four in flight; the 200 key-frame ring of
+    the bench (608 columns, 333 tasks) by hand: profiles/r04_chol32_emulated.txt."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    import test_solve_plan as T
+    path = str(tmp_path / "system.bin")
+    plan = _write_system(path, 120, T._band(120, 12, False), 32)
+    assert plan["nsys"] % 32 == 0 and plan["depth"] < plan["nbc"]
+    inc = tmp_path / "chol32_body.inc"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = str(tmp_path / "chol32_emu")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path),
+                        os.path.join(ROOT, "tools", "chol32_emu.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for env in ({}, {"SE2_EMU_RESIDENT": "4"}):
+        r = subprocess.run([exe, "file", path, "1", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and r.stdout.count("(ok)") == 2 and "1 of 1 bit-identical to the first" in r.stdout, r.stdout + r.stderr

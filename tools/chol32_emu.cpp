@@ -46,12 +46,20 @@ int main(int argc, char** argv) {
     // chol32_emu n [interleavings [first seed]]   |   chol32_emu nd <arc tiles> <separator tiles> [first seed [interleavings]]
     const bool nd = argc > 1 && std::string(argv[1]) == "nd";
     const int arc = nd ? (argc > 2 ? std::atoi(argv[2]) : 3) : 0, sep = nd ? (argc > 3 ? std::atoi(argv[3]) : 5) : 0;
-    const int n = nd ? 0 : (argc > 1 ? std::atoi(argv[1]) : 100);
-    const unsigned seed0 = nd ? (argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u) : (argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u);
-    const unsigned nseeds = nd ? (argc > 5 ? (unsigned)std::atoi(argv[5]) : 3u) : (argc > 2 ? (unsigned)std::atoi(argv[2]) : 3u);
+    const bool file_mode = argc > 2 && std::string(argv[1]) == "file";
+    const int n = nd || file_mode ? 0 : (argc > 1 ? std::atoi(argv[1]) : 100);
+    const unsigned seed0 = file_mode ? (argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u) : nd ? (argc > 4 ? (unsigned)std::atoi(argv[4]) : 1u) : (argc > 3 ? (unsigned)std::atoi(argv[3]) : 1u);
+    const unsigned nseeds = file_mode ? (argc > 4 ? (unsigned)std::atoi(argv[4]) : 2u) : nd ? (argc > 5 ? (unsigned)std::atoi(argv[5]) : 3u) : (argc > 2 ? (unsigned)std::atoi(argv[2]) : 3u);
     // SE2_EMU_RESIDENT=k: the tasks of a launch run side by side, k at a time (default: one after the other)
     const unsigned resident = std::getenv("SE2_EMU_RESIDENT") ? (unsigned)std::atoi(std::getenv("SE2_EMU_RESIDENT")) : 0u;
-    CholSystem S = chol_system(kNB, n, arc, sep);
+    // chol32_emu file <path> [first seed [interleavings]]: a system and its plan from a file (chol_host.h)
+    const bool from_file = argc > 2 && std::string(argv[1]) == "file";
+    CholSystem S;
+    if (from_file) {
+        if (!chol_system_from_file(kNB, argv[2], S)) { std::printf("cannot read %s\n", argv[2]); return 2; }
+    } else {
+        S = chol_system(kNB, n, arc, sep);
+    }
     // SE2_EMU_INDEFINITE=1: one diagonal entry negated - the diagonal task of that block column must raise the failure flag
     const bool indefinite = std::getenv("SE2_EMU_INDEFINITE") != nullptr;
     if (indefinite) { const int k = S.n / 2; S.A[(size_t)k * S.ld + k] = -S.A[(size_t)k * S.ld + k]; }

@@ -423,17 +423,7 @@ int main(int argc, char** argv) {
     const bool from_file = argc > 2 && std::string(argv[1]) == "file";
     CholSystem S;
     if (from_file) {
-        FILE* f = std::fopen(argv[2], "rb");
-        int hdr[4];
-        if (!f || std::fread(hdr, 4, 4, f) != 4) { std::printf("cannot read %s\n", argv[2]); return 2; }
-        S.n = hdr[0]; S.ld = hdr[1]; S.nt = S.ld / NB; S.nbc = (S.n + NB - 1) / NB; S.chain = 0;
-        S.plan.tasks.resize(hdr[2]); S.plan.deps.resize(hdr[3]); S.A.resize((size_t)S.ld * S.ld); S.b.resize(S.n);
-        bool ok = std::fread(S.plan.tasks.data(), sizeof(int4), hdr[2], f) == (size_t)hdr[2];
-        ok = ok && std::fread(S.plan.deps.data(), 4, hdr[3], f) == (size_t)hdr[3];
-        ok = ok && std::fread(S.A.data(), 8, S.A.size(), f) == S.A.size();
-        std::fclose(f);
-        if (!ok) { std::printf("short file %s\n", argv[2]); return 2; }
-        for (int c = 0; c < S.n; ++c) S.b[c] = S.A[(size_t)S.n * S.ld + c];
+        if (!chol_system_from_file(NB, argv[2], S)) { std::printf("cannot read %s\n", argv[2]); return 2; }
     } else {
         S = chol_system(NB, n, arc, sep);
     }

@@ -110,6 +110,21 @@ inline CholSystem chol_system(int NB, int n_dense, int arc, int sep) {
     S.plan = plan_from_pattern(P, nt, nbc, &S.chain);
     return S;
 }
+// a system and ITS PLAN from a file: int32 {n, ld, tasks, dependency entries}, the tasks (4 int32 each), the dependency entries, A (ld x ld
+// doubles, the right-hand side in row n) - what tests/test_wave_protocol_probe.py writes from the product's own plan code
+inline bool chol_system_from_file(int NB, const char* path, CholSystem& S) {
+    FILE* f = std::fopen(path, "rb");
+    int hdr[4];
+    if (!f || std::fread(hdr, 4, 4, f) != 4) return false;
+    S.n = hdr[0]; S.ld = hdr[1]; S.nt = S.ld / NB; S.nbc = (S.n + NB - 1) / NB; S.chain = 0;
+    S.plan.tasks.resize(hdr[2]); S.plan.deps.resize(hdr[3]); S.A.resize((size_t)S.ld * S.ld); S.b.resize(S.n);
+    bool ok = std::fread(S.plan.tasks.data(), sizeof(int4), hdr[2], f) == (size_t)hdr[2];
+    ok = ok && std::fread(S.plan.deps.data(), 4, hdr[3], f) == (size_t)hdr[3];
+    ok = ok && std::fread(S.A.data(), 8, S.A.size(), f) == S.A.size();
+    std::fclose(f);
+    for (int c = 0; ok && c < S.n; ++c) S.b[c] = S.A[(size_t)S.n * S.ld + c];
+    return ok;
+}
 // |A x - b|_inf / |b|_inf
 inline double chol_residual(const CholSystem& S, const std::vector<double>& x) {
     double worst = 0.0, scale = 0.0;
