@@ -83,6 +83,12 @@ int se2gpu_orb_debug_level(se2gpu_orb* h, int frame, int level, int blurred, uin
                            int* rows, int* cols);
 /* FAST score map S of a level of the last call, same geometry as the level. */
 int se2gpu_orb_debug_score(se2gpu_orb* h, int frame, int level, uint8_t* out, size_t out_cap, int* rows, int* cols);
+/* The device routine behind both retainBest cuts (/root/reference/src/ORBextractor.cpp:692-694, 708-709 = cv::KeyPointsFilter::
+ * retainBest + resize = std::nth_element by response, first n kept), run on caller data for the parity tests: `entries` (host,
+ * in / out) are n values whose HIGH 32 bits are the comparison key (larger = better response) and whose low 32 bits travel
+ * along; on return they are permuted exactly as libstdc++'s std::nth_element(first, first + nth, last, key greater) leaves
+ * them.  force_global != 0 runs the in-place global-memory path that cells beyond the LDS capacity take. */
+int se2gpu_orb_debug_nth_element(uint64_t* entries, int n, int nth, int force_global);
 
 /* ------------------------------------------------------------------------------------------
  * ORB matcher  -  replaces se2lam::ORBmatcher

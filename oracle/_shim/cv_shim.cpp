@@ -484,26 +484,27 @@ void FAST(InputArray _img, std::vector<KeyPoint>& keypoints, int threshold, bool
     }
 }
 
-// keypoint.cpp KeyPointsFilter::retainBest: nth_element by response, then keep everything that ties with the n-th response.
-// Which of the tied points end up where is libstdc++'s nth_element / partition - implementation-defined, and the reference
-// cuts the list to n right afterwards (ORBextractor.cpp:693-694, 708-709), so WHICH ties survive is not a property of the
-// algorithm.  SE2_REF_RETAIN=std runs the library text verbatim (whatever this machine's libstdc++ does); the default is the
-// canonical choice the oracle and the HIP path document: the n best by (response descending, position in
-// the list ascending), a stable sort - one of the outcomes the library text allows.
+// keypoint.cpp KeyPointsFilter::retainBest, as OpenCV 3.2 writes it: std::nth_element by response, then std::partition keeps
+// everything that ties with the n-th response.  The reference cuts the list to n right afterwards (ORBextractor.cpp:693-694,
+// 708-709), so which of the tied points survive, and in what order they enter the level's list, is what THIS toolchain's
+// std::nth_element leaves in the first n places: libstdc++'s introselect, the library a GCC build of the reference links.  That
+// is the default since round 5 (it is what a real build does; the restatement and the HIP path compute the same permutation,
+// oracle/stl_nth.h).  SE2_REF_RETAIN=stable is the order rounds 1-4 defined instead - the n best by (response descending,
+// position in the list ascending) - kept as a labelled alternative.
 void KeyPointsFilter::retainBest(std::vector<KeyPoint>& keypoints, int n_points) {
     if (n_points < 0 || keypoints.size() <= (size_t)n_points) return;
     if (n_points == 0) { keypoints.clear(); return; }
-    static const bool verbatim = [] { const char* e = std::getenv("SE2_REF_RETAIN"); return e && std::string(e) == "std"; }();
-    if (verbatim) {
-        std::nth_element(keypoints.begin(), keypoints.begin() + n_points, keypoints.end(),
-                         [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; });
-        const float ambiguous = keypoints[n_points - 1].response;
-        auto new_end = std::partition(keypoints.begin() + n_points, keypoints.end(), [&](const KeyPoint& k) { return k.response >= ambiguous; });
-        keypoints.resize(new_end - keypoints.begin());
+    static const bool stable = [] { const char* e = std::getenv("SE2_REF_RETAIN"); return e && std::string(e) == "stable"; }();
+    if (stable) {
+        std::stable_sort(keypoints.begin(), keypoints.end(), [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; });
+        keypoints.resize(n_points);
         return;
     }
-    std::stable_sort(keypoints.begin(), keypoints.end(), [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; });
-    keypoints.resize(n_points);
+    std::nth_element(keypoints.begin(), keypoints.begin() + n_points, keypoints.end(),
+                     [](const KeyPoint& a, const KeyPoint& b) { return a.response > b.response; });
+    const float ambiguous = keypoints[n_points - 1].response;
+    auto new_end = std::partition(keypoints.begin() + n_points, keypoints.end(), [&](const KeyPoint& k) { return k.response >= ambiguous; });
+    keypoints.resize(new_end - keypoints.begin());
 }
 
 // ------------------------------------------------------------------------------------------------ SVD

@@ -300,6 +300,42 @@ def orb_trig_libm(mode):
     f(int(mode))
 
 
+def orb_retain_stable(on):
+    """retainBest order: False (default) = libstdc++'s nth_element restated (stl_nth.h) = what a GCC build of the reference keeps;
+    True = the order rounds 1-4 defined (best n by response, ties by list position, list order kept)"""
+    f = lib().orb_ref_set_retain_stable
+    f.restype = None
+    f.argtypes = [C.c_int]
+    f(int(bool(on)))
+
+
+def nth_element(entries, nth, std=False):
+    """entries: uint64, high 32 bits = key (larger is better).  The permutation libstdc++'s std::nth_element leaves, by the
+    restatement in stl_nth.h (std=True: by this machine's std::nth_element itself)"""
+    e = np.ascontiguousarray(entries, np.uint64).copy()
+    f = lib().orb_ref_std_nth_element if std else lib().orb_ref_nth_element
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    f(e.ctypes.data, len(e), int(nth))
+    return e
+
+
+def nth_heap_selects():
+    f = lib().orb_ref_nth_heap_selects
+    f.restype = C.c_long
+    return f()
+
+
+def nth_killer(n, nth):
+    """keys (uint32, larger is better) on which libstdc++'s introselect runs out of its depth limit (median-of-three killer)"""
+    k = np.zeros(n, np.uint32)
+    f = lib().orb_ref_nth_killer
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    f(int(n), int(nth), k.ctypes.data)
+    return k
+
+
 def glibc_sincosf(y, cosine: bool) -> float:
     f = lib().orb_ref_glibc_sincosf
     f.restype = C.c_float

@@ -27,12 +27,12 @@
 //   cv::resize INTER_LINEAR 8UC1: 11-bit fixed-point coefficients, src = (dst+0.5)*scale-0.5,
 //                                 vertical pass (((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2
 //   cv::GaussianBlur 7x7 sigma 2 on 8U: separable, taps round(k*256) = {18,34,49,55,49,34,18}, (v + 2^15) >> 16
-//   cv::KeyPointsFilter::retainBest: keeps the n best responses; its tie order comes from
-//       std::nth_element and is implementation-defined, so this oracle DEFINES the canonical order
-//       (SURVEY.md §7 hard part 2): inside a cell (response desc, y asc, x asc); level-wide overflow
-//       keeps the `quota` best by (response desc, list position asc) and preserves list order.
+//   cv::KeyPointsFilter::retainBest: std::nth_element by response + the reference's resize(n) = the first n entries of the
+//       permutation libstdc++'s introselect leaves (stl_nth.h: restated, held to this machine's std::nth_element) - which of
+//       the tied key points stay and in what order they enter the level's list is what a GCC build of the reference does
+//       (round 5; rounds 1-4 defined an order of their own: orb_ref_set_retain_stable).
 //   cv::fastAtan2 (degree-7 odd polynomial), cvRound = round-half-to-even, cvFloor, cvCeil.
-//   cos/sin of the keypoint angle: computed in double and rounded once to float (hard part 3).
+//   cos/sin of the keypoint angle: the float overloads = libm's cosf / sinf; glibc's algorithm restated (glibc_flt32, mode 2).
 //
 // Build: g++ -O2 -ffp-contract=off (oracle/Makefile): x*b + y*a must be mul, mul, add (no FMA).
 #include <algorithm>
@@ -41,6 +41,8 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+
+#include "stl_nth.h"
 
 extern "C" {
 struct orb_ref_params {
@@ -64,7 +66,8 @@ const int kPattern[256 * 4] = {
 #include "orb_pattern_31.inc"
 };
 
-static int g_trig_libm = 0;   // see Extractor::descriptor: 0 rounded double cosine / sine, 1 libm's cosf / sinf, 2 glibc's algorithm restated
+static int g_retain_stable = 0;   // see Extractor::retain_best
+static int g_trig_libm = 2;   // see Extractor::descriptor: 0 rounded double cosine / sine, 1 libm's cosf / sinf, 2 glibc's algorithm restated
 
 // glibc's sinf / cosf (2.28 and later: sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, s_sincosf_data.c - the routines ARM
 // contributed) for the arguments a key-point angle can take, 0 <= y < 120: a range reduction by one multiply with 2/pi and one
@@ -368,6 +371,25 @@ struct Extractor {
         return g;
     }
 
+    // cv::KeyPointsFilter::retainBest(v, n) followed by the reference's v.resize(n): see stl_nth.h.  g_retain_stable = 1 is the
+    // order rounds 1-4 defined instead (the n best by response, ties by position in the list, list order kept) - one of the
+    // outcomes the C++ standard allows, not the one a GCC build of the reference produces; kept as a labelled alternative.
+    static void retain_best(std::vector<KP>& v, int n) {
+        if (n < 0 || (int)v.size() <= n) return;
+        if (n == 0) { v.clear(); return; }
+        if (g_retain_stable) {
+            std::vector<int> idx(v.size());
+            for (size_t q = 0; q < idx.size(); ++q) idx[q] = (int)q;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return v[a].resp > v[b].resp; });
+            std::vector<KP> kept;
+            for (int q = 0; q < n; ++q) kept.push_back(v[idx[q]]);
+            v.swap(kept);
+            return;
+        }
+        stl_nth::nth_element(v.data(), v.data() + n, v.data() + v.size(), [](const KP& a, const KP& b) { return a.resp > b.resp; });
+        v.resize(n);
+    }
+
     void compute_keypoints(std::vector<std::vector<orb_ref_keypoint>>& all) {
         all.assign(nlevels, {});
         for (int level = 0; level < nlevels; ++level) {
@@ -446,28 +468,12 @@ struct Extractor {
             for (int i = 0; i < levelRows; i++)
                 for (int j = 0; j < levelCols; j++) {
                     std::vector<KP>& kc = cellKP[i][j];
-                    // canonical retainBest + resize: best n by (response desc, y asc, x asc)
-                    std::sort(kc.begin(), kc.end(), [](const KP& a, const KP& b) {
-                        if (a.resp != b.resp) return a.resp > b.resp;
-                        if (a.y != b.y) return a.y < b.y;
-                        return a.x < b.x;
-                    });
-                    if ((int)kc.size() > nToRetain[i][j]) kc.resize(nToRetain[i][j]);
+                    // KeyPointsFilter::retainBest(keysCell, nToRetain) + resize (ORBextractor.cpp:692-694): the first nToRetain
+                    // entries of what libstdc++'s nth_element leaves of FAST's row-major list (stl_nth.h)
+                    retain_best(kc, nToRetain[i][j]);
                     for (const KP& k : kc) list.push_back(k);
                 }
-            if ((int)list.size() > nDesired) {
-                // canonical level-wide retainBest: keep the nDesired best by (response desc, position asc),
-                // preserving list order
-                std::vector<int> idx(list.size());
-                for (size_t q = 0; q < idx.size(); ++q) idx[q] = (int)q;
-                std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return list[a].resp > list[b].resp; });
-                std::vector<char> keep(list.size(), 0);
-                for (int q = 0; q < nDesired; ++q) keep[idx[q]] = 1;
-                std::vector<KP> kept;
-                for (size_t q = 0; q < list.size(); ++q)
-                    if (keep[q]) kept.push_back(list[q]);
-                list.swap(kept);
-            }
+            if ((int)list.size() > nDesired) retain_best(list, nDesired);   // :706-710
             for (const KP& k : list) {
                 orb_ref_keypoint kp;
                 kp.x = (float)k.x;
@@ -670,6 +676,32 @@ void orb_ref_gaussian_taps(int32_t* out7) { int t[7]; Extractor::gaussian_taps(t
 float orb_ref_fast_atan2(float y, float x) { return fast_atan2(y, x); }
 int orb_ref_cv_round(float v) { return cv_round(v); }
 void orb_ref_set_trig_libm(int mode) { g_trig_libm = mode; }
+void orb_ref_set_retain_stable(int on) { g_retain_stable = on; }
+// stl_nth.h on caller data (entries: high 32 bits = key, larger is better; low 32 bits travel along), this machine's
+// std::nth_element on the same, and a median-of-three killer for it (McIlroy's adversary run against std::nth_element).
+void orb_ref_nth_element(uint64_t* e, int n, int nth) {
+    stl_nth::nth_element(e, e + nth, e + n, [](uint64_t a, uint64_t b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); });
+}
+void orb_ref_std_nth_element(uint64_t* e, int n, int nth) {
+    std::nth_element(e, e + nth, e + n, [](uint64_t a, uint64_t b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); });
+}
+long orb_ref_nth_heap_selects() { return stl_nth::heap_selects(); }
+void orb_ref_nth_killer(int n, int nth, uint32_t* keys) {
+    std::vector<int> val(n, n), idx(n);
+    int nsolid = 0, candidate = 0;
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    auto less = [&](int x, int y) {
+        if (val[x] == n && val[y] == n) {
+            if (x == candidate) val[x] = nsolid++;
+            else val[y] = nsolid++;
+        }
+        if (val[x] == n) candidate = x;
+        else if (val[y] == n) candidate = y;
+        return val[x] < val[y];
+    };
+    std::nth_element(idx.begin(), idx.begin() + nth, idx.end(), less);
+    for (int i = 0; i < n; ++i) keys[i] = (uint32_t)(n - val[i]);   // "less" on val = "greater" on n - val
+}
 float orb_ref_glibc_sincosf(float y, int cosine) { return glibc_flt32::sincos(y, cosine); }
 int orb_ref_fast_score(const uint8_t* center, int stride) { return Extractor::fast_score(center, stride); }
 

@@ -89,6 +89,7 @@ SYMBOLS = {
     "se2gpu_orb_set_stream": (_I, [_VP, _VP]),
     "se2gpu_orb_debug_level": (_I, [_VP, _I, _I, _I, _VP, _SZ, C.POINTER(_I), C.POINTER(_I)]),
     "se2gpu_orb_debug_score": (_I, [_VP, _I, _I, _VP, _SZ, C.POINTER(_I), C.POINTER(_I)]),
+    "se2gpu_orb_debug_nth_element": (_I, [_VP, _I, _I, _I]),
     "se2gpu_orb_stream": (_VP, [_VP]),
     "se2gpu_orb_score_kernel": (_I, [_VP, _VP]),
     "se2gpu_orb_profile": (_I, [_VP, _I]),

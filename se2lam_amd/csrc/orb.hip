@@ -5,18 +5,19 @@
 //   GaussianBlur call :769, computeOrbDescriptor :161-200, operator() :727-788.
 // The OpenCV primitives it calls are restated with the semantics DESIGN.md defines
 // (FAST-9/16 + cornerScore + in-cell NMS, 11-bit fixed-point bilinear resize, reflect-101 border, 8-bit
-// fixed-point 7x7 Gaussian, canonical retain-best order, fastAtan2, round-half-even).
+// fixed-point 7x7 Gaussian, retainBest as libstdc++'s nth_element leaves it, fastAtan2, round-half-even).
 //
 // Pipeline (every kernel covers the whole batch; all stages stay in HBM, no host round trip):
 //   k_level0 / k_resize   pyramid level k from level k-1, border filled in the same pass; resize coefficients from host
 //                         tables over the bordered row, the taps of a thread from one 64-bit load per source row
 //   k_fast_score[_sparse] S(x,y) = FAST-9/16 score for every level in one launch, in-cell non-max suppression fused:
 //                         writes a sparse plane (S where S > 7 and a strict in-cell maximum, else 0)
-//   k_cell_detect         one workgroup per (frame, level, cell): collects the non-zero scores, threshold 20 /
-//                         fallback 7, rank sort by (response desc, y, x) -> per-cell sorted candidate list
-//                         (<true>: HARRIS_SCORE, responses re-scored with the 7x7 Harris measure)
-//   k_level_select        one workgroup per (frame, level): quota redistribution (wave-parallel), per-cell top-n gather,
-//                         level-wide retain-best by rank, keypoint list in level order
+//   k_cell_collect        one workgroup per (frame, level, cell): what cv::FAST returns for the cell (threshold 20 /
+//                         fallback 7) in row-major order -> the cell's list (<true>: HARRIS_SCORE, responses re-scored)
+//   k_cell_retain         one wave per cell: quota redistribution replayed, then retainBest + resize = libstdc++'s
+//                         nth_element (introselect) step for step, the partition spread over the lanes
+//   k_level_select        one workgroup per (frame, level): the cells' retained corners in cell order, the level-wide
+//                         retainBest + resize by the same introselect, key points out in the reference's order
 //   k_orientation         one wave per keypoint: integer intensity-centroid moments, fastAtan2
 //   k_blur                blurred pyramid: the 16 px frame keeps the un-blurred reflect copies (as in the reference's
 //                         in-place ROI blur), the interior gets the 7x7 fixed-point Gaussian (register window, packed
@@ -66,7 +67,11 @@ struct Geom {
     // k_fast_score or a tile of k_fast_score_sparse): list (column tc, row tr) of level l = lst_base[l] + tr * tiles_x + tc
     int lst_tw, lst_th, lst_cap;
     int lst_base[kMaxLevels + 1];
-    int cell_cap;                        // entries kept per cell in the global candidate lists
+    // per-cell lists of k_cell_collect: a cell of level l owns lcap[l] entries (no cell can hold more corners: in-cell maxima
+    // are never adjacent) at lcell_off[l] + cell * lcap[l] of its frame's block (lcell_off[nlevels] entries); levels whose
+    // cells can exceed the LDS paths also own 2 * lcap[l] uint32 of scratch per cell, at lscr_off[l] (sort / position lists)
+    int lcap[kMaxLevels];
+    unsigned lcell_off[kMaxLevels + 1], lscr_off[kMaxLevels + 1];
     int umax[16];
     int nfeatures;
     int fast_th;
@@ -293,7 +298,7 @@ __device__ __forceinline__ short2v fast_score_pk(const short2v p[16], short2v v)
 // [16, w-16) x [16, h-16) in steps of cellW x cellH), else 0 - and keeps only the non-zero results: every wave appends
 // the 4-pixel groups that hold a survivor to the candidate list of its strip, {(y << 12) | x of the group, its four S'
 // bytes}, at a slot from a wave ballot (no atomics, no score plane: a strip writes some hundred bytes instead of 4.7 KB
-// and k_cell_detect reads those instead of scanning the plane).  A strip has 62 x 19 groups, which is the capacity of
+// and k_cell_collect reads those instead of scanning the plane).  A strip has 62 x 19 groups, which is the capacity of
 // its list: it cannot overflow.
 constexpr int kScoreRows = 19;
 constexpr int kScoreGroups = 62;  // useful column groups per wave
@@ -632,10 +637,20 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-cell detection: NMS + threshold selection + sort.
-// Cell (i, j) of level l scans x in [16 + j*cellW, min(16 + (j+1)*cellW, w-16)), same for y: the cells tile the
-// scan area exactly (cell window = cell +- 3 px, cv::FAST skips a 3 px rim, ORBextractor.cpp:569-608).
-// key = (255 - S) << 24 | y << 12 | x  (ascending = response desc, y asc, x asc)
+// Key-point retention (ORBextractor.cpp:616-710).  cv::FAST hands every cell its corners in row-major order; the reference
+// then cuts each cell, and afterwards the level's concatenated list, with KeyPointsFilter::retainBest(v, n) + v.resize(n):
+// std::nth_element by response and the first n entries of the permutation it leaves.  Which of several equal-response
+// corners survive, and the order in which the survivors reach the output (MatchByWindow is order-dependent), are therefore
+// properties of libstdc++'s introselect - a fixed function of the input - and the kernels below compute exactly that
+// permutation (rounds 1-4 sorted by (response, y, x) instead, which keeps the same points only up to ties):
+//   k_cell_collect  one workgroup per cell: the cell's FAST output (threshold 20, or 7 if that gave <= 3 corners) in row-major
+//                   order -> the cell's list, + its size
+//   k_cell_retain   one wave per cell: the level's quota redistribution (:631-679) replayed, then introselect on the list
+//   k_level_select  one workgroup per (frame, level): the cells' first nToRetain entries in cell order, introselect with the
+//                   level's quota, key points out in that order
+// A list entry: FAST_SCORE  uint32  S << 24 | y << 12 | x         (response = S - 1 = cornerScore)
+//               HARRIS      uint64  ordered(response) << 32 | y << 12 | x
+// and the comparator of retainBest, a.response > b.response, is key(a) > key(b) on the high part.
 // ---------------------------------------------------------------------------------------------
 // HarrisResponses(cellImage, pts, 7, 0.04f) of ORBextractor.cpp:85-126 for one key point (x, y) of the un-blurred level:
 // 7x7 block of 3x3 Sobel windows, integer sums, then the reference's float expression (compiled without contraction).
@@ -678,14 +693,202 @@ __global__ __launch_bounds__(256) void k_scatter_lists(Geom g, int f, int l, con
     }
 }
 
+// ---- list entries
+template <bool HARRIS> struct Ent;
+template <> struct Ent<false> {
+    using T = uint32_t;
+    static __device__ __forceinline__ uint32_t key(T e) { return e >> 24; }
+    static __device__ __forceinline__ uint32_t pos(T e) { return e & 0x00ffffffu; }
+    static __device__ __forceinline__ float resp(T e) { return (float)((int)(e >> 24) - 1); }   // cornerScore = S - 1
+};
+template <> struct Ent<true> {
+    using T = unsigned long long;
+    static __device__ __forceinline__ uint32_t key(T e) { return (uint32_t)(e >> 32); }
+    static __device__ __forceinline__ uint32_t pos(T e) { return (uint32_t)e & 0x00ffffffu; }
+    static __device__ __forceinline__ float resp(T e) {
+        uint32_t b = (uint32_t)(e >> 32);
+        b ^= (b >> 31) ? 0x80000000u : 0xffffffffu;
+        return __uint_as_float(b);
+    }
+    static __device__ __forceinline__ T make(float r, uint32_t pos) {   // float order -> unsigned order (-0 counts as +0)
+        uint32_t b = __float_as_uint(r);
+        if (b == 0x80000000u) b = 0;
+        b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+        return ((T)b << 32) | pos;
+    }
+};
+
+// memory written by some lanes of a wave and read by others afterwards (LDS or global): order it
+__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+// ---- libstdc++'s heap select (bits/stl_heap.h + __heap_select), the branch introselect takes when its depth limit runs out.
+// Executed by ONE lane: it is reached on adversarial inputs only (median-of-three killers), never on image data.
+template <bool H>
+__device__ void seq_adjust_heap(typename Ent<H>::T* first, int hole, int len, typename Ent<H>::T value) {
+    using E = Ent<H>;
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (E::key(first[child]) > E::key(first[child - 1])) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;                     // __push_heap
+    while (hole > top && E::key(first[parent]) > E::key(value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+template <bool H>
+__device__ void seq_heap_select(typename Ent<H>::T* first, int middle, int last) {   // offsets relative to first
+    using E = Ent<H>;
+    const int len = middle;
+    if (len >= 2)
+        for (int parent = (len - 2) / 2;; --parent) {   // __make_heap
+            seq_adjust_heap<H>(first, parent, len, first[parent]);
+            if (parent == 0) break;
+        }
+    for (int i = middle; i < last; ++i)
+        if (E::key(first[i]) > E::key(first[0])) {      // __pop_heap(first, middle, i)
+            const typename E::T v = first[i];
+            first[i] = first[0];
+            seq_adjust_heap<H>(first, 0, len, v);
+        }
+}
+
+// ---- std::nth_element(a, a + nth, a + n, response greater) of libstdc++ (bits/stl_algo.h __introselect), by one wave.
+// The control flow is the library's, step for step: depth limit 2 lg n, median of (first + 1, mid, last - 1) moved to first,
+// the unguarded Hoare partition of [first + 1, last) around it, the side that holds nth kept, insertion sort below four
+// elements.  Only the partition is spread over the lanes, and it is the same partition: the sequential loop swaps the k-th
+// element from the left that is not greater than the pivot with the k-th element from the right that is not smaller, for
+// k = 1, 2, ... while the former lies left of the latter (the elements it passes over never move, so "k-th" can be counted
+// in the array as it stood), and returns where the left scan stops next: the (K+1)-th such element from the left, or the
+// place the K-th swap put one if that comes first.  lp / rp: scratch for the two position lists (n entries each).
+template <bool H, class PosT>
+__device__ void introselect_wave(typename Ent<H>::T* a, PosT* lp, PosT* rp, int n, int nth) {
+    using E = Ent<H>;
+    using T = typename E::T;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int first = 0, last = n;
+    int depth = 2 * (31 - __clz(n));
+    while (last - first > 3) {
+        if (depth == 0) {
+            if (lane == 0) {
+                seq_heap_select<H>(a + first, nth + 1 - first, last - first);
+                const T t = a[first];
+                a[first] = a[nth];
+                a[nth] = t;
+            }
+            wave_fence();
+            return;
+        }
+        --depth;
+        if (lane == 0) {   // __move_median_to_first(first, first + 1, mid, last - 1)
+            const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+            const T ea = a[ia], eb = a[ib], ec = a[ic], er = a[first];
+            const uint32_t ka = E::key(ea), kb = E::key(eb), kc = E::key(ec);
+            int src;
+            if (ka > kb) src = (kb > kc) ? ib : (ka > kc) ? ic : ia;
+            else src = (ka > kc) ? ia : (kb > kc) ? ic : ib;
+            a[first] = src == ia ? ea : src == ib ? eb : ec;
+            a[src] = er;
+        }
+        wave_fence();
+        const uint32_t pk = E::key(a[first]);
+        const int lo = first + 1, hi = last;
+        int cL = 0, cR = 0;
+        for (int b = lo; b < hi; b += 64) {
+            const int p = b + lane;
+            bool isL = false, isR = false;
+            if (p < hi) {
+                const uint32_t k = E::key(a[p]);
+                isL = !(k > pk);     // the left scan `while (comp(*first, *pivot)) ++first` stops here
+                isR = !(pk > k);     // the right scan `while (comp(*pivot, *last)) --last` stops here
+            }
+            const unsigned long long mL = __builtin_amdgcn_ballot_w64(isL), mR = __builtin_amdgcn_ballot_w64(isR);
+            if (isL) lp[cL + __popcll(mL & lt)] = (PosT)p;
+            if (isR) rp[cR + __popcll(mR & lt)] = (PosT)p;   // counted from the left; the k-th from the right is rp[cR - 1 - k]
+            cL += __popcll(mL);
+            cR += __popcll(mR);
+        }
+        wave_fence();
+        const int m = min(cL, cR);
+        int K = 0;                                            // swaps the sequential loop performs
+        for (int b = 0; b < m; b += 64) {
+            const int k = b + lane;
+            const bool ok = k < m && (int)lp[k] < (int)rp[cR - 1 - k];
+            const int c = __popcll(__builtin_amdgcn_ballot_w64(ok));   // (true on a prefix: lp ascends, rp[cR-1-k] descends)
+            K += c;
+            if (c < 64) break;
+        }
+        for (int b = 0; b < K; b += 64) {
+            const int k = b + lane;
+            if (k < K) {
+                const int i = (int)lp[k], j = (int)rp[cR - 1 - k];
+                const T ei = a[i], ej = a[j];
+                a[i] = ej;
+                a[j] = ei;
+            }
+        }
+        int cut = K > 0 ? (int)rp[cR - K] : hi;
+        if (K < cL) cut = min(cut, (int)lp[K]);
+        wave_fence();
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0)                                            // __insertion_sort on at most three elements
+        for (int i = first + 1; i < last; ++i) {
+            const T v = a[i];
+            int hole = i;
+            while (hole > first && E::key(v) > E::key(a[hole - 1])) {
+                a[hole] = a[hole - 1];
+                --hole;
+            }
+            a[hole] = v;
+        }
+    wave_fence();
+}
+
+// bitonic sort of npad (a power of two) uint32 keys by the 256 threads of a workgroup; LDS or global memory
+__device__ __forceinline__ void bitonic_sort_u32(uint32_t* keys, int npad) {
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npad; i += 256) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cell_collect: what cv::FAST returns for the cell, in the order it returns it.
+// Cell (i, j) of level l scans x in [16 + j*cellW, min(16 + (j+1)*cellW, w-16)), same for y: the cells tile the
+// scan area exactly (cell window = cell +- 3 px, cv::FAST skips a 3 px rim, ORBextractor.cpp:569-608).
+// sort key = (y << 12 | x) << 8 | S: ascending = row-major, the order of cv::FAST's output vector
+// ---------------------------------------------------------------------------------------------
 constexpr int kMaxListsPerCell = 64;
+constexpr int kRankMax = 768;      // up to here a rank sort (no barriers) beats the bitonic network
 template <bool HARRIS>
-__global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __restrict__ lst_ent, const int* __restrict__ lst_cnt,
-                                                      const uint8_t* __restrict__ pyr,
-                                                      uint32_t* __restrict__ cell_keys, float* __restrict__ cell_resp,
-                                                      int* __restrict__ cell_total, int* __restrict__ overflow) {
+__global__ __launch_bounds__(256) void k_cell_collect(Geom g, const uint2* __restrict__ lst_ent, const int* __restrict__ lst_cnt,
+                                                       const uint8_t* __restrict__ pyr,
+                                                       typename Ent<HARRIS>::T* __restrict__ cell_ent, uint32_t* __restrict__ cell_scr,
+                                                       int* __restrict__ cell_total, int* __restrict__ overflow) {
+    using E = Ent<HARRIS>;
     __shared__ uint32_t keys[kSortCap];
-    __shared__ unsigned long long keys64[HARRIS ? kSortCap : 1];   // (~ordered(response) << 32) | (y << 12) | x
     __shared__ int s_nw, s_n20;   // candidates with 7 < S <= fast_th (stored from the back of keys[]) / with S > fast_th (front)
     __shared__ int s_off[kMaxListsPerCell + 1];                    // exclusive prefix of the entry counts of the cell's lists
     __shared__ unsigned s_lst[kMaxListsPerCell];
@@ -699,6 +902,8 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
     if (threadIdx.x == 0) { s_nw = 0; s_n20 = 0; }
     const int cw = xb - xa, ch = yb - ya;
     const int stride = g.stride[l];
+    const int lcap = g.lcap[l];
+    typename E::T* out = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + g.lcell_off[l] + (size_t)(cell - g.cell_base[l]) * lcap;
     // the candidate lists whose tiles meet the cell: columns tc0..tc1 x rows tr0..tr1 of the level's list grid
     const int ltx = (g.w[l] - 2 * kEdge + g.lst_tw - 1) / g.lst_tw;
     const int tc0 = (xa - kEdge) / g.lst_tw, tc1 = (xb - 1 - kEdge) / g.lst_tw;
@@ -742,7 +947,7 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
                     const int sc = (int)((en.y >> (8 * q)) & 0xffu);
                     const int x = x0 + q;
                     if (sc == 0 || x < xa || x >= xb) continue;
-                    visit(sc, ((uint32_t)(255 - sc) << 24) | ((uint32_t)y << 12) | (uint32_t)x);
+                    visit(sc, ((((uint32_t)y << 12) | (uint32_t)x) << 8) | (uint32_t)sc);
                 }
             }
         }
@@ -757,138 +962,41 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
         }
     });
     __syncthreads();
-    // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 keypoints, FAST(7).  The thr-20 corners
-    // sort before all others (key = 255 - S first), so when they are taken the others never need sorting at all.
+    // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 keypoints, FAST(7) - the corners at 7 are
+    // the strict in-cell maxima of all scores above 7, those at 20 the ones among them that score above 20
     const int n20 = s_n20, nw = s_nw;
-    int n = n20;
-    int total = n20 > 3 ? n20 : n20 + nw;   // what cv::FAST returns for the cell: the quota logic needs the true count
-    const bool too_many = n20 + nw > kSortCap;   // front and back ran into each other (a huge cell full of corners)
-    if (too_many) {
-        // Only the min(total, cell_cap) best by score can be retained, so everything below the score that bounds them
-        // drops out before the sort: histogram of the scores, cut, second collection.  (Harris retains by another
-        // response: a streaming selection, below.)
-        __shared__ int hist[256];
-        __shared__ int s_cut, s_cnt;
-        if (HARRIS) {
-            // HARRIS_SCORE retains by another response than the one the lists are ordered by, so no score cut can thin
-            // the cell out beforehand.  Streaming selection instead: the cell's corners are taken in bands of rows that
-            // fit the sort buffer beside the K best so far (K = what the cell may retain), every band is scored with the
-            // Harris measure, merged by a sort, and the best K stay.  Exact; a cell full of corners costs a few rounds.
-            __shared__ int s_y1, s_band, s_slot, s_bad;
-            const int lo = n20 > 3 ? g.fast_th : 7;                 // the corners cv::FAST returns for the cell: S > lo
-            const int K = min(total, g.cell_cap);
-            const int budget = kSortCap - K;
-            const uint8_t* lvl = pyr + pix(g, f, l, 0, 0);
-            for (int i = threadIdx.x; i < ch; i += 256) keys[i] = 0;   // corners per row (keys[] is free in this path)
-            walk([&](int sc, uint32_t key) {
-                if (sc > lo) atomicAdd(&keys[(int)((key >> 12) & 0xfffu) - ya], 1u);
-            });
-            __syncthreads();
-            int have = 0;
-            for (int y0 = 0; y0 < ch;) {
-                if (threadIdx.x == 0) {
-                    int y1 = y0, cnt = 0;
-                    while (y1 < ch && cnt + (int)keys[y1] <= budget) cnt += (int)keys[y1++];
-                    s_y1 = y1; s_band = cnt; s_slot = 0;
-                    s_bad = (y1 == y0) ? 1 : 0;                     // one row beyond the buffer (K > 2048 and a row of > 2000 corners)
-                }
-                __syncthreads();
-                if (s_bad) {
-                    if (threadIdx.x == 0) atomicOr(overflow, 1);
-                    if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
-                    return;
-                }
-                const int y1 = s_y1, band = s_band;
-                walk([&](int sc, uint32_t key) {
-                    const int yy = (int)((key >> 12) & 0xfffu) - ya;
-                    if (sc > lo && yy >= y0 && yy < y1) {
-                        const uint32_t pos = key & 0x00ffffffu;
-                        const float rsp = harris_response(lvl, stride, (int)(pos & 0xfff), (int)(pos >> 12));
-                        uint32_t bits = __float_as_uint(rsp);
-                        bits ^= (bits >> 31) ? 0xffffffffu : 0x80000000u;   // monotone map float -> uint32
-                        keys64[have + atomicAdd(&s_slot, 1)] = ((unsigned long long)(~bits) << 32) | pos;
-                    }
-                });
-                __syncthreads();
-                const int m = have + band;
-                int np2 = 1;
-                while (np2 < m) np2 <<= 1;
-                for (int i = m + threadIdx.x; i < np2; i += 256) keys64[i] = ~0ull;
-                __syncthreads();
-                for (int k = 2; k <= np2; k <<= 1)
-                    for (int j = k >> 1; j > 0; j >>= 1) {
-                        for (int i = threadIdx.x; i < np2; i += 256) {
-                            const int ixj = i ^ j;
-                            if (ixj > i) {
-                                const unsigned long long a = keys64[i], b = keys64[ixj];
-                                const bool up = (i & k) == 0;
-                                if ((a > b) == up) { keys64[i] = b; keys64[ixj] = a; }
-                            }
-                        }
-                        __syncthreads();
-                    }
-                have = min(K, m);
-                y0 = y1;
-            }
-            uint32_t* outh = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-            float* outhr = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-            if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = total;
-            for (int i = threadIdx.x; i < have; i += 256) {
-                const unsigned long long k = keys64[i];
-                uint32_t bits = ~(uint32_t)(k >> 32);
-                bits ^= (bits >> 31) ? 0x80000000u : 0xffffffffu;       // inverse of the map above
-                outh[i] = (uint32_t)k;
-                outhr[i] = __uint_as_float(bits);
-            }
-            return;
-        }
-        hist[threadIdx.x] = 0;
-        walk([&](int sc, uint32_t) { atomicAdd(&hist[sc], 1); });
+    const int total = n20 > 3 ? n20 : n20 + nw;
+    const uint8_t* lvl = pyr + pix(g, f, l, 0, 0);
+    auto emit = [&](int i, uint32_t key) {   // sorted place i of the cell's list
+        const uint32_t pos = key >> 8;
+        if constexpr (HARRIS) out[i] = E::make(harris_response(lvl, stride, (int)(pos & 0xfff), (int)(pos >> 12)), pos);
+        else out[i] = (key << 24) | pos;
+    };
+    if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = total <= lcap ? total : 0;
+    if (total > lcap) {   // (in-cell maxima are never adjacent, so a cell holds at most ceil(w/2) ceil(h/2) of them = lcap)
+        if (threadIdx.x == 0) atomicOr(overflow, 1);
+        return;
+    }
+    if (n20 + nw > kSortCap) {
+        // a huge cell full of corners (front and back ran into each other): collect what FAST returns once more, straight into
+        // the cell's scratch list in global memory, and sort it there.  lcap is a power of two on such levels.
+        uint32_t* scr = cell_scr + (size_t)f * g.lscr_off[g.nlevels] + g.lscr_off[l] + (size_t)(cell - g.cell_base[l]) * 2 * lcap;
+        const int lo = n20 > 3 ? g.fast_th : 7;
         __syncthreads();
-        __shared__ int s_need_ties, s_yc;
-        if (threadIdx.x == 0) {
-            const int lo = n20 > 3 ? g.fast_th + 1 : 8, need = min(total, g.cell_cap);
-            int cut = 255, above = 0;                 // above = candidates with a score > cut
-            while (cut > lo && above + hist[cut] < need) above += hist[cut--];
-            s_cut = cut;
-            s_cnt = above + hist[cut];
-            s_need_ties = need - above;
-            s_yc = 0x7fffffff;
-            s_n20 = 0;
-        }
-        __syncthreads();
-        const int cut = s_cut;
-        if (s_cnt > kSortCap) {
-            // flat imagery: thousands of corners share the bounding score.  Of those only the first few in key order
-            // (row, then column) can be retained: a histogram over the rows of the cell (in keys[], free at this point)
-            // gives the last row that is needed.
-            for (int i = threadIdx.x; i < ch; i += 256) keys[i] = 0;
-            walk([&](int sc, uint32_t key) {
-                if (sc == cut) atomicAdd(&keys[(int)((key >> 12) & 0xfffu) - ya], 1u);
-            });
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int cum = 0, r = 0;
-                while (r < ch && cum + (int)keys[r] < s_need_ties) cum += (int)keys[r++];
-                cum += r < ch ? (int)keys[r] : 0;
-                s_yc = ya + r;
-                s_cnt = s_cnt - hist[cut] + cum;
-            }
-            __syncthreads();
-        }
-        n = s_cnt;
-        const int yc = s_yc;
-        if (n > kSortCap) {   // (a single row of one score beyond the buffer: cannot happen below 8192 columns)
-            if (threadIdx.x == 0) atomicOr(overflow, 1);
-            if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = 0;
-            return;
-        }
-        __syncthreads();
+        if (threadIdx.x == 0) s_n20 = 0;
         walk([&](int sc, uint32_t key) {
-            if (sc > cut || (sc == cut && (int)((key >> 12) & 0xfffu) <= yc)) keys[atomicAdd(&s_n20, 1)] = key;
+            if (sc > lo) scr[atomicAdd(&s_n20, 1)] = key;
         });
+        int npad = 1;
+        while (npad < total) npad <<= 1;
+        for (int i = total + threadIdx.x; i < npad; i += 256) scr[i] = 0xffffffffu;
         __syncthreads();
-    } else if (n20 <= 3) {
+        bitonic_sort_u32(scr, npad);
+        for (int i = threadIdx.x; i < total; i += 256) emit(i, scr[i]);
+        return;
+    }
+    int n = n20;
+    if (n20 <= 3) {
         uint32_t mv[kSortCap / 256];   // source and destination ranges may overlap: through registers
 #pragma unroll
         for (int u = 0; u < kSortCap / 256; ++u) {
@@ -904,24 +1012,14 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
         __syncthreads();
         n = n20 + nw;
     }
-    // FAST_SCORE with a cell of ordinary size (~100 candidates): rank sort.  A key's rank = the number of smaller keys
-    // (keys are unique: they contain the position); every thread reads the same keys[j] (LDS broadcast), no barriers -
-    // the bitonic network below costs ~30 barrier-separated stages for the same job.
-    constexpr int kRankMax = 768;
-    if (!HARRIS && n <= kRankMax) {
-        const int totalr = total;
-        const int keepr = min(totalr, g.cell_cap);
-        uint32_t* outk = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-        float* outf = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-        if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = totalr;
+    if (n <= kRankMax) {
+        // a cell of ordinary size (~100 corners): rank sort.  A key's rank = the number of smaller keys (keys are unique: they
+        // contain the position); every thread reads the same keys[j] (LDS broadcast), no barriers
         for (int i = threadIdx.x; i < n; i += 256) {
             const uint32_t ki = keys[i];
             int rank = 0;
             for (int j = 0; j < n; ++j) rank += keys[j] < ki;
-            if (rank < keepr) {
-                outk[rank] = ki & 0x00ffffffu;
-                outf[rank] = (float)(254 - (int)(ki >> 24));   // cornerScore = S - 1
-            }
+            emit(rank, ki);
         }
         return;
     }
@@ -929,79 +1027,16 @@ __global__ __launch_bounds__(256) void k_cell_detect(Geom g, const uint2* __rest
     while (npad < n) npad <<= 1;
     for (int i = n + threadIdx.x; i < npad; i += 256) keys[i] = 0xffffffffu;
     __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < npad; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    const int keep = min(total, g.cell_cap);
-    uint32_t* out = cell_keys + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-    float* outr = cell_resp + ((size_t)f * g.cell_base[g.nlevels] + cell) * g.cell_cap;
-    if (threadIdx.x == 0) cell_total[(size_t)f * g.cell_base[g.nlevels] + cell] = total;
-    if (!HARRIS) {
-        for (int i = threadIdx.x; i < keep; i += 256) {
-            out[i] = keys[i] & 0x00ffffffu;
-            outr[i] = (float)(254 - (int)(keys[i] >> 24));   // cornerScore = S - 1
-        }
-        return;
-    }
-    // HARRIS_SCORE (ORBextractor.cpp:625-629): the key points FAST selected get the Harris response of the level
-    // image and are retained by it: order (response desc, y asc, x asc)
-    const uint8_t* lvl = pyr + pix(g, f, l, 0, 0);
-    int np2 = 1;
-    while (np2 < total) np2 <<= 1;
-    for (int i = threadIdx.x; i < np2; i += 256) {
-        unsigned long long k = ~0ull;
-        if (i < total) {
-            const uint32_t pos = keys[i] & 0x00ffffffu;
-            const float rsp = harris_response(lvl, stride, (int)(pos & 0xfff), (int)(pos >> 12));
-            uint32_t bits = __float_as_uint(rsp);
-            bits ^= (bits >> 31) ? 0xffffffffu : 0x80000000u;   // monotone map float -> uint32
-            k = ((unsigned long long)(~bits) << 32) | pos;
-        }
-        keys64[i] = k;
-    }
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys64[i], b = keys64[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys64[i] = b; keys64[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; i < keep; i += 256) {
-        const unsigned long long k = keys64[i];
-        uint32_t bits = ~(uint32_t)(k >> 32);
-        bits ^= (bits >> 31) ? 0x80000000u : 0xffffffffu;       // inverse of the map above
-        out[i] = (uint32_t)k;
-        outr[i] = __uint_as_float(bits);
-    }
+    bitonic_sort_u32(keys, npad);
+    for (int i = threadIdx.x; i < n; i += 256) emit(i, keys[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-(frame, level) selection: quota redistribution (ORBextractor.cpp:631-679), per-cell retain (:687-705), level-wide
-// retain (:706-710).  Output: kp_list[f][i] = {level, x, y, response} in final order; counts[f].
-// A level's place in the output is the number of key points the lower levels keep, which follows from their cell
-// totals alone - every workgroup replays the (cheap, wave-parallel) quota logic of the levels below it instead of
-// waiting for them.
-// ---------------------------------------------------------------------------------------------
 // Quota replay of one level by one wave: lane c + 64 k owns cell c + 64 k (<= 256 cells).  The reference's loop
 // (:640-679) is a fixed-point over passes whose body does not depend on the cell order, so a pass is one wave step.
-// n_ret / c_off (nullable) receive the per-cell retain counts and their exclusive prefix; returns their sum.
-__device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, int cell_cap, int* n_ret, int* c_off,
-                                           int* __restrict__ overflow) {
+// n_ret / c_off receive the per-cell retain counts and their exclusive prefix; returns their sum.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, int* n_ret, int* c_off) {
     const int lane = threadIdx.x & 63;
     int t[4], r[4];
     bool nm[4];
@@ -1035,99 +1070,147 @@ __device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = lane + 64 * k;
-        if (r[k] > cell_cap) { atomicOr(overflow, 2); r[k] = cell_cap; }
         int incl = r[k];
         for (int d = 1; d < 64; d <<= 1) {
             const int v = __shfl_up(incl, d);
             if (lane >= d) incl += v;
         }
-        if (n_ret && c < nCells) { n_ret[c] = r[k]; c_off[c] = base + incl - r[k]; }
+        if (c < nCells) { n_ret[c] = r[k]; c_off[c] = base + incl - r[k]; }
         base += __shfl(incl, 63);
     }
     return base;
 }
 
-__global__ __launch_bounds__(256) void k_level_select(Geom g, const uint32_t* __restrict__ cell_keys,
-                                                       const float* __restrict__ cell_resp,
-                                                       const int* __restrict__ cell_total, int4* __restrict__ kp_list,
+// ---------------------------------------------------------------------------------------------
+// k_quota: nToRetain of every cell (ORBextractor.cpp:631-679), one wave per (frame, level); cell_plan[cell] = {nToRetain,
+// place of the cell's first retained corner in the level's list}
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_quota(Geom g, const int* __restrict__ cell_total, int2* __restrict__ cell_plan) {
+    __shared__ int n_ret[256], c_off[256];
+    SE2_FRAME_GRID(f, l);
+    const int ncells_frame = g.cell_base[g.nlevels];
+    const int nc = g.gcols[l] * g.grows[l];
+    level_quota(cell_total + (size_t)f * ncells_frame + g.cell_base[l], nc, g.nfc[l], n_ret, c_off);
+    wave_fence();
+    int2* out = cell_plan + (size_t)f * ncells_frame + g.cell_base[l];
+    for (int c = threadIdx.x; c < nc; c += 64) out[c] = make_int2(n_ret[c], c_off[c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_cell_retain: KeyPointsFilter::retainBest(keysCell, nToRetain) + resize (ORBextractor.cpp:692-694), one wave per cell.
+// A cell that keeps everything (most cells of sparse imagery) is done - its list is already in the reference's order.  Otherwise introselect over the list: in LDS up to
+// kSelCap corners, in place in global memory (with the cell's scratch lists) beyond.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelCap = 512;      // corners a cell can hold for the LDS path of k_cell_retain (more: in place in global memory)
+template <bool HARRIS>
+__global__ __launch_bounds__(256) void k_cell_retain(Geom g, typename Ent<HARRIS>::T* __restrict__ cell_ent,
+                                                      uint32_t* __restrict__ cell_scr, const int* __restrict__ cell_total,
+                                                      const int2* __restrict__ cell_plan, int* __restrict__ overflow) {
+    using E = Ent<HARRIS>;
+    using T = typename E::T;
+    __shared__ T s_a[4][kSelCap];
+    __shared__ uint16_t s_lp[4][kSelCap], s_rp[4][kSelCap];
+    const int f = (int)blockIdx.x;
+    if (f >= g.nframes) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int cell = (int)blockIdx.y * 4 + wave;
+    const int ncells_frame = g.cell_base[g.nlevels];
+    if (cell >= ncells_frame) return;
+    int l = 0;
+    while (l + 1 < g.nlevels && cell >= g.cell_base[l + 1]) ++l;
+    const int c = cell - g.cell_base[l];
+    const int total = cell_total[(size_t)f * ncells_frame + cell];
+    const int nret = cell_plan[(size_t)f * ncells_frame + cell].x;
+    if (total <= nret) return;
+    const int lcap = g.lcap[l];
+    T* list = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + g.lcell_off[l] + (size_t)c * lcap;
+    if (total <= kSelCap) {
+        T* a = s_a[wave];
+        for (int i = lane; i < total; i += 64) a[i] = list[i];
+        wave_fence();
+        introselect_wave<HARRIS, uint16_t>(a, s_lp[wave], s_rp[wave], total, nret);
+        for (int i = lane; i < nret; i += 64) list[i] = a[i];
+    } else {
+        if (lcap <= kSelCap) {   // (cannot happen: total <= lcap)
+            if (lane == 0) atomicOr(overflow, 2);
+            return;
+        }
+        uint32_t* scr = cell_scr + (size_t)f * g.lscr_off[g.nlevels] + g.lscr_off[l] + (size_t)c * 2 * lcap;
+        introselect_wave<HARRIS, uint32_t>(list, scr, scr + lcap, total, nret);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-(frame, level) selection: the cells' retained corners in cell row-major order (ORBextractor.cpp:687-705), the
+// level-wide retainBest + resize (:706-710).  Output: kp_list[f][i] = {level, x, y, response} in the reference's order;
+// counts[f].  A level's place in the output is the number of key points the lower levels keep, which follows from k_quota's
+// plan alone - no workgroup waits for another.
+// ---------------------------------------------------------------------------------------------
+template <bool HARRIS>
+__global__ __launch_bounds__(256) void k_level_select(Geom g, const typename Ent<HARRIS>::T* __restrict__ cell_ent,
+                                                       const int2* __restrict__ cell_plan, int4* __restrict__ kp_list,
                                                        int* __restrict__ counts, int cap, int* __restrict__ overflow) {
-    __shared__ uint32_t lst[kLevelCap];
-    __shared__ float lrsp[kLevelCap];
-    __shared__ int keepflag[kLevelCap];
-    __shared__ int n_retain[64 * 4];   // per cell (<= 256 cells per level)
-    __shared__ int cell_off[64 * 4 + 1];
-    __shared__ int s_kept[kMaxLevels], s_scan[256];
+    using E = Ent<HARRIS>;
+    using T = typename E::T;
+    __shared__ T lst[kLevelCap];
+    __shared__ uint16_t s_lp[kLevelCap], s_rp[kLevelCap];
+    __shared__ int s_kept[kMaxLevels];
     SE2_FRAME_GRID(f, l);
     const int ncells_frame = g.cell_base[g.nlevels];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int* tot_f = cell_total + (size_t)f * ncells_frame;
-    for (int lv = wave; lv <= l; lv += 4) {
-        const int nc = g.gcols[lv] * g.grows[lv];
-        int o = level_quota(tot_f + g.cell_base[lv], nc, g.nfc[lv], g.cell_cap, lv == l ? n_retain : nullptr, cell_off,
-                            overflow);
+    const int2* plan_f = cell_plan + (size_t)f * ncells_frame;
+    if (threadIdx.x <= (unsigned)l) {                      // entries of a level before its level-wide retain: last cell's place + count
+        const int2 last = plan_f[g.cell_base[threadIdx.x + 1] - 1];
+        int o = last.x + last.y;
         if (o > kLevelCap) { atomicOr(overflow, 4); o = kLevelCap; }
-        if ((threadIdx.x & 63) == 0) s_kept[lv] = o;      // entries before the level-wide retain
+        s_kept[threadIdx.x] = o;
     }
     __syncthreads();
     const int nCells = g.gcols[l] * g.grows[l];
     const int n = s_kept[l];
     int out_n = 0;                                         // key points of the lower levels
     for (int lv = 0; lv < l; ++lv) out_n += min(s_kept[lv], g.quota[lv]);
-    // gather the per-cell prefixes in cell row-major order
-    for (int c = 0; c < nCells; ++c) {
-        const uint32_t* src = cell_keys + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
-        const float* srcr = cell_resp + ((size_t)f * ncells_frame + g.cell_base[l] + c) * g.cell_cap;
-        const int o = cell_off[c];
-        for (int i = threadIdx.x; i < n_retain[c]; i += 256)
-            if (o + i < kLevelCap) {
-                lst[o + i] = src[i];
-                lrsp[o + i] = srcr[i];
-            }
+    // the cells' lists one after the other: a wave takes every fourth cell
+    const T* lbase = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + g.lcell_off[l];
+    for (int c = wave; c < nCells; c += 4) {
+        const T* src = lbase + (size_t)c * g.lcap[l];
+        const int2 pl = plan_f[g.cell_base[l] + c];
+        for (int i = (int)(threadIdx.x & 63); i < pl.x; i += 64)
+            if (pl.y + i < kLevelCap) lst[pl.y + i] = src[i];
     }
     __syncthreads();
     const int quota = g.quota[l];
     if (n > quota) {
-        // keep the `quota` best by (response desc, list position asc), preserving list order
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const float ri = lrsp[i];
-            int rank = 0;
-            for (int j = 0; j < n; ++j) {
-                const float rj = lrsp[j];
-                rank += (rj > ri) || (rj == ri && j < i);
-            }
-            keepflag[i] = rank < quota;
+        if (wave == 0) introselect_wave<HARRIS, uint16_t>(lst, s_lp, s_rp, n, quota);
+        __syncthreads();
+    }
+    const int keep = min(n, quota);
+    for (int i = threadIdx.x; i < keep; i += 256) {
+        const int pos = out_n + i;
+        if (pos < cap) {
+            const T e = lst[i];
+            const uint32_t p = E::pos(e);
+            kp_list[(size_t)f * cap + pos] = make_int4(l, (int)(p & 0xfff), (int)(p >> 12), __float_as_int(E::resp(e)));
+        } else {
+            atomicOr(overflow, 8);
         }
+    }
+    if (l == g.nlevels - 1 && threadIdx.x == 0) counts[f] = min(out_n + keep, cap);
+}
+
+// se2gpu_orb_debug_nth_element: introselect_wave on caller data (tests): LDS path up to kSelCap entries, global path beyond
+__global__ __launch_bounds__(64) void k_debug_nth(unsigned long long* a, uint32_t* scr, int n, int nth, int force_global) {
+    __shared__ unsigned long long s_a[kSelCap];
+    __shared__ uint16_t s_lp[kSelCap], s_rp[kSelCap];
+    if (n <= kSelCap && !force_global) {
+        for (int i = threadIdx.x; i < n; i += 64) s_a[i] = a[i];
+        wave_fence();
+        introselect_wave<true, uint16_t>(s_a, s_lp, s_rp, n, nth);
+        for (int i = threadIdx.x; i < n; i += 64) a[i] = s_a[i];
     } else {
-        for (int i = threadIdx.x; i < n; i += 256) keepflag[i] = 1;
+        introselect_wave<true, uint32_t>(a, scr, scr + n, n, nth);
     }
-    __syncthreads();
-    // ordered compaction: chunks of 256 with a block scan
-    int base = 0;
-    for (int c0 = 0; c0 < n; c0 += 256) {
-        const int i = c0 + threadIdx.x;
-        const int kf = (i < n) ? keepflag[i] : 0;
-        s_scan[threadIdx.x] = kf;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            const int v = (threadIdx.x >= (unsigned)d) ? s_scan[threadIdx.x - d] : 0;
-            __syncthreads();
-            s_scan[threadIdx.x] += v;
-            __syncthreads();
-        }
-        const int pos = out_n + base + s_scan[threadIdx.x] - kf;
-        if (kf) {
-            if (pos < cap) {
-                const uint32_t key = lst[i];
-                kp_list[(size_t)f * cap + pos] = make_int4(l, (int)(key & 0xfff), (int)((key >> 12) & 0xfff),
-                                                           __float_as_int(lrsp[i]));
-            } else {
-                atomicOr(overflow, 8);
-            }
-        }
-        base += s_scan[255];
-        __syncthreads();
-    }
-    if (l == g.nlevels - 1 && threadIdx.x == 0) counts[f] = min(out_n + base, cap);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1299,6 +1382,36 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
 // cos / sin of the key-point angle, in double and rounded once to float as computeOrbDescriptor does
 // (ORBextractor.cpp:166-167).  One THREAD per key point: inside k_describe (one wave per key point) the double-precision
 // sin and cos would be executed once per wave, i.e. 64 times more often.
+// The reference's `(float)cos(angle)` / `(float)sin(angle)` take a FLOAT angle under `using namespace std`: the float overloads,
+// i.e. libm's cosf / sinf - glibc's are one ulp off the rounded double value on 0.1 % of the arguments, and one descriptor in two
+// million then samples a neighbouring pixel.  glibc's routine (flt-32, 2.28 and later) is plain double arithmetic: one multiply
+// with 2/pi (scaled by 2^24, so that the quadrant is bits 24..31 of the truncated product), one multiply-subtract with pi/2, a
+// degree-7 sine or degree-8 cosine polynomial, one rounding to float.  Written out here it gives the bits the reference gets on a
+// glibc host (the CPU checker holds the same lines to libm on every float of [0, 2 pi]: tests/c_glibc_sincosf_check.c); contraction is off in
+// this translation unit, which is one of the two forms checked.
+__device__ __forceinline__ float glibc_sincosf_poly(double x, double x2, int n, double csign) {
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, t1 = 0x1.1107605230bc4p-7 + x2 * -0x1.994eb3774cf24p-13, x7 = x3 * x2, s = x + x3 * -0x1.555545995a603p-3;
+        return (float)(s + x7 * t1);
+    }
+    const double c0 = csign * 0x1p0, c1 = csign * -0x1.ffffffd0c621cp-2, c2 = csign * 0x1.55553e1068f19p-5, c3 = csign * -0x1.6c087e89a359dp-10,
+                 c4 = csign * 0x1.99343027bf8c3p-16;
+    const double x4 = x2 * x2, k2 = c3 + x2 * c4, k1 = c0 + x2 * c1, x6 = x4 * x2, c = k1 + x4 * c2;
+    return (float)(c + x6 * k2);
+}
+__device__ __forceinline__ float glibc_sincosf(float y, int cosine) {   // 0 <= y < 120
+    double x = y;
+    const unsigned top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    if (top < ((__float_as_uint(0x1.921FB6p-1f) >> 20) & 0x7ffu)) {       // |y| < pi / 4
+        if (top < ((__float_as_uint(0x1p-12f) >> 20) & 0x7ffu)) return cosine ? 1.0f : y;
+        return glibc_sincosf_poly(x, x * x, cosine, 1.0);
+    }
+    const double r = x * 0x1.45F306DC9C883p+23;
+    const int n = ((int)r + 0x800000) >> 24;
+    x = x - n * 0x1.921FB54442D18p0;
+    const double sgn = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    return glibc_sincosf_poly(x * sgn, x * x, n ^ cosine, (n & 2) ? -1.0 : 1.0);
+}
 __global__ __launch_bounds__(256) void k_angle_trig(const int* __restrict__ counts, int cap,
                                                      const float* __restrict__ angles, float2* __restrict__ cs) {
     const int f = blockIdx.y;
@@ -1306,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_angle_trig(const int* __restrict__ coun
     if (k >= min(counts[f], cap)) return;
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     const float angle = angles[(size_t)f * cap + k] * factorPI;
-    cs[(size_t)f * cap + k] = make_float2((float)cos((double)angle), (float)sin((double)angle));
+    cs[(size_t)f * cap + k] = make_float2(glibc_sincosf(angle, 1), glibc_sincosf(angle, 0));
 }
 
 __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restrict__ blur,
@@ -1433,8 +1546,10 @@ struct se2gpu_orb {
     int dense_lst_base[kMaxLevels + 1], sparse_lst_base[kMaxLevels + 1];
     DevBuf<uint32_t> cell_keys;
     DevBuf<int> cell_total, counts, overflow;
+    DevBuf<int2> cell_plan;                  // k_quota: {nToRetain, place in the level's list} per cell
     DevBuf<int4> kp_list, tabs;
-    DevBuf<float> angles, cell_resp;
+    DevBuf<float> angles;
+    DevBuf<uint32_t> cell_scr;               // scratch of the huge-cell paths (Geom::lscr_off)
     DevBuf<float2> angle_cs;
     DevBuf<se2gpu_keypoint> kps;
     DevBuf<uint8_t> desc;
@@ -1486,7 +1601,6 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     unsigned off = 0;
     const float imageRatio = (float)cols / rows;
     g.cell_base[0] = 0;
-    int maxq = 0;
     for (int l = 0; l < L; ++l) {
         const float scale = h->mvInvScale[l];
         g.w[l] = cv_round_f((float)cols * scale);
@@ -1497,7 +1611,6 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         g.off[l] = off;
         off += (unsigned)g.stride[l] * (g.h[l] + 2 * kEdge);
         g.quota[l] = h->quota[l];
-        maxq = std::max(maxq, g.quota[l]);
         g.gcols[l] = (int)std::sqrt((float)g.quota[l] / (5 * imageRatio));
         g.grows[l] = (int)(imageRatio * g.gcols[l]);
         SE2_REQUIRE(g.gcols[l] >= 1 && g.grows[l] >= 1 && g.gcols[l] * g.grows[l] <= 256, SE2GPU_ERR_INVALID,
@@ -1514,7 +1627,20 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
                     "level %d: degenerate cell grid", l);
     }
     g.frame_bytes = (off + 255u) & ~255u;
-    g.cell_cap = std::min(kSortCap, ((2 * maxq + 64 + 63) / 64) * 64);
+    // per-cell list capacity: in-cell maxima are never adjacent, so ceil(cellW / 2) * ceil(cellH / 2) bounds a cell's corners
+    g.lcell_off[0] = 0;
+    g.lscr_off[0] = 0;
+    for (int l = 0; l < L; ++l) {
+        const long long bound = (long long)((g.cellW[l] + 1) / 2) * ((g.cellH[l] + 1) / 2);
+        long long lc = ((bound + 63) / 64) * 64;
+        if (bound > kSortCap) { lc = 1; while (lc < bound) lc <<= 1; }   // sorted in global memory by a bitonic network
+        const long long nc = (long long)g.gcols[l] * g.grows[l];
+        SE2_REQUIRE(lc <= (1 << 24) && g.lcell_off[l] + nc * lc < (1ll << 31) && g.lscr_off[l] + 2 * nc * lc < (1ll << 31), SE2GPU_ERR_INVALID,
+                    "level %d: cells of %dx%d pixels are too large", l, g.cellW[l], g.cellH[l]);
+        g.lcap[l] = (int)lc;
+        g.lcell_off[l + 1] = g.lcell_off[l] + (unsigned)(nc * lc);
+        g.lscr_off[l + 1] = g.lscr_off[l] + (lc > kSelCap ? (unsigned)(2 * nc * lc) : 0u);
+    }
     // tiles
     h->score_tile_base[0] = 0;
     h->sparse_tile_base[0] = 0;
@@ -1607,9 +1733,10 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     SE2_CHECK(h->blur.reserve(B * g.frame_bytes));
     SE2_CHECK(h->lst_cnt.reserve(B * (size_t)std::max(h->dense_lst_base[L], h->sparse_lst_base[L])));
     SE2_CHECK(h->lst_ent.reserve(B * std::max((size_t)h->dense_lst_base[L] * kStripCap, (size_t)h->sparse_lst_base[L] * kFsListCap)));
-    SE2_CHECK(h->cell_keys.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
+    SE2_CHECK(h->cell_keys.reserve(B * (size_t)g.lcell_off[L] * (g.harris ? 2 : 1)));   // uint32 entries, uint64 with HARRIS_SCORE
+    SE2_CHECK(h->cell_scr.reserve(std::max<size_t>(1, B * (size_t)g.lscr_off[L])));
     SE2_CHECK(h->cell_total.reserve(B * g.cell_base[L]));
-    SE2_CHECK(h->cell_resp.reserve(B * g.cell_base[L] * (size_t)g.cell_cap));
+    SE2_CHECK(h->cell_plan.reserve(B * g.cell_base[L]));
     SE2_CHECK(h->overflow.reserve(1));
     SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
     SE2_HIP(hipStreamSynchronize(h->stream));
@@ -1726,14 +1853,26 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         h->fs_frames = nframes;
     }
     h->last_lists = g;
-    if (g.harris)
-        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<true>, dim3(F8, g.cell_base[L]), dim3(256), 0, g,
-                   h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
-    else
-        SE2_LAUNCH(h->prof, st, "k_cell_detect", k_cell_detect<false>, dim3(F8, g.cell_base[L]), dim3(256), 0, g,
-                   h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_resp.p, h->cell_total.p, h->overflow.p);
-    SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
-               h->cell_resp.p, h->cell_total.p, h->kp_list.p, d_counts, cap, h->overflow.p);
+    const unsigned ncell = (unsigned)g.cell_base[L];
+    if (g.harris) {
+        using T = Ent<true>::T;
+        T* ent = reinterpret_cast<T*>(h->cell_keys.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect<true>, dim3(F8, ncell), dim3(256), 0, g, h->lst_ent.p,
+                   h->lst_cnt.p, h->pyr.p, ent, h->cell_scr.p, h->cell_total.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, ent,
+                   h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<true>, dim3(F8, L), dim3(256), 0, g, ent, h->cell_plan.p,
+                   h->kp_list.p, d_counts, cap, h->overflow.p);
+    } else {
+        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect<false>, dim3(F8, ncell), dim3(256), 0, g, h->lst_ent.p,
+                   h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g,
+                   h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<false>, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
+                   h->cell_plan.p, h->kp_list.p, d_counts, cap, h->overflow.p);
+    }
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 3) / 4), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p, h->tabs.p + h->orient_off);
     SE2_LAUNCH(h->prof, st, "k_angle_trig", k_angle_trig, dim3((cap + 255) / 256, nframes), dim3(256), 0, d_counts, cap,
@@ -1960,6 +2099,21 @@ int se2gpu_orb_profile(se2gpu_orb* h, int enable) {
     SE2_REQUIRE(h, SE2GPU_ERR_INVALID, "orb handle is NULL");
     h->prof.enabled = enable != 0;
     h->prof.reset();
+    return SE2GPU_OK;
+}
+
+int se2gpu_orb_debug_nth_element(uint64_t* entries, int n, int nth, int force_global) {
+    SE2_REQUIRE(entries && n > 0 && nth >= 0 && nth < n && n <= (1 << 24), SE2GPU_ERR_INVALID, "nth_element: bad arguments");
+    SE2_REQUIRE(have_device(), SE2GPU_ERR_NO_DEVICE, "no HIP device");
+    DevBuf<unsigned long long> a;
+    DevBuf<uint32_t> scr;
+    SE2_CHECK(a.reserve((size_t)n));
+    SE2_CHECK(scr.reserve(2 * (size_t)n));
+    SE2_HIP(hipMemcpy(a.p, entries, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_nth, dim3(1), dim3(64), 0, nullptr, a.p, scr.p, n, nth, force_global);
+    SE2_HIP(hipGetLastError());
+    SE2_HIP(hipDeviceSynchronize());
+    SE2_HIP(hipMemcpy(entries, a.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SE2GPU_OK;
 }
 

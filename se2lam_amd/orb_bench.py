@@ -111,7 +111,7 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
         # one launch of an extractor kernel processes the B frames of the batch; its algorithmic bytes are its stage's
         # share of SURVEY.md section 8(d)'s pass-per-stage accounting (sum over the 8 pyramid levels = 950,532 px)
         stage = {"k_level0": 307_200 + 307_200, "k_resize": (926_546 + 643_332 - 307_200) / 7.0,
-                 "k_fast_score": 950_532, "k_cell_detect": 950_532, "k_blur": 1_901_064,
+                 "k_fast_score": 950_532, "k_cell_collect": 60_000, "k_cell_retain": 60_000, "k_blur": 1_901_064,
                  "k_orientation": 749_000, "k_describe": 512_000 + 60_000, "k_level_select": 60_000}
         b_launch = stage.get(dom, B_ORB) * B
         ach = b_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9

@@ -162,3 +162,39 @@ def test_written_out_glibc_sincosf_is_this_machines_libm(oracle, tmp_path):
     import numpy as np
     assert np.float32(oracle.glibc_sincosf(np.float32(0.509999156), False)).tobytes() == np.float32(float.fromhex("0x1.f3e48ap-2")).tobytes()
     assert oracle.glibc_sincosf(1e-5, False) == np.float32(1e-5) and oracle.glibc_sincosf(1e-5, True) == 1.0
+
+
+def test_restated_nth_element_equals_libstdcxx(tmp_path):
+    """oracle/stl_nth.h - libstdc++'s introselect written out, the order KeyPointsFilter::retainBest + resize keeps key points in
+    (ORBextractor.cpp:692-694, 708-709) - against this machine's std::nth_element: the WHOLE permutation, on every input over a
+    three-letter alphabet up to length 9, 60,000 random inputs from all-tied to tie-free, and median-of-three killers that run
+    into the depth limit (heap-select branch)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "cpp_stl_nth")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(here, "cpp_stl_nth.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout + r.stderr
+
+
+def test_restatement_keeps_key_points_in_the_order_of_libstdcxx_nth_element(oracle, synth):
+    """the restatement's two cuts go through stl_nth.h; its labelled alternative (the order of rounds 1-4) keeps the same number
+    of points per level with the same responses, but not the same points in the same places"""
+    k, d = oracle.orb_extract(synth.frame(3))
+    oracle.orb_retain_stable(True)
+    try:
+        k4, d4 = oracle.orb_extract(synth.frame(3))
+    finally:
+        oracle.orb_retain_stable(False)
+    assert len(k) == len(k4) == 1000 and not np.array_equal(k, k4)
+    for lv in range(8):
+        assert np.array_equal(np.sort(k["response"][k["octave"] == lv]), np.sort(k4["response"][k4["octave"] == lv]))
+    # nth_element wrapper = std::nth_element on this machine
+    rng = np.random.default_rng(2)
+    for n in (4, 17, 240, 3000):
+        e = (rng.integers(8, 70, n).astype(np.uint64) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        for nth in (0, n // 2, n - 1):
+            assert np.array_equal(oracle.nth_element(e, nth), oracle.nth_element(e, nth, std=True))

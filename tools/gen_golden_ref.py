@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/ref_r04.json and tests/golden/ref_r04.npz: outputs of THE REFERENCE ITSELF - its own source files compiled
+"""Writes tests/golden/ref_r05.json and tests/golden/ref_r05.npz: outputs of THE REFERENCE ITSELF - its own source files compiled
 unmodified in oracle/_ref (oracle/Makefile, target `ref`) - on the seeded synthetic inputs of se2lam_amd.synth.  They travel
 with the repository, so that the restatement (CPU) and the HIP path (GPU) can be held to reference-derived numbers on a
 machine where /root/reference and oracle/_ref are absent.  tests/test_golden_ref.py reads them; where oracle/_ref is
@@ -22,8 +22,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle, ref  # noqa: E402
 from se2lam_amd import synth  # noqa: E402
 
-OUT_JSON = os.path.join(ROOT, "tests", "golden", "ref_r04.json")
-OUT_NPZ = os.path.join(ROOT, "tests", "golden", "ref_r04.npz")
+OUT_JSON = os.path.join(ROOT, "tests", "golden", "ref_r05.json")
+OUT_NPZ = os.path.join(ROOT, "tests", "golden", "ref_r05.npz")
 
 
 def digest(*arrays):
@@ -31,11 +31,6 @@ def digest(*arrays):
     for a in arrays:
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
-
-
-def canon(k, d):
-    o = np.lexsort((k["x"], k["y"], k["octave"]))
-    return k[o], d[o]
 
 
 def inputs():
@@ -62,10 +57,10 @@ def build():
     # ---- front end (exact)
     feats = {}
     for t in (0, 1):
-        k, d = canon(*ref.orb_extract(synth.frame(t)))
+        k, d = ref.orb_extract(synth.frame(t))   # in the reference's own order (round 5: no sorting before the digest)
         feats[t] = (k, d)
         js[f"orb_frame{t}"] = {"n": int(len(k)), "sha256": digest(k, d)}
-    k, d = canon(*ref.orb_extract(synth.frame(0), oracle.orb_params(score_type=oracle.HARRIS_SCORE)))
+    k, d = ref.orb_extract(synth.frame(0), oracle.orb_params(score_type=oracle.HARRIS_SCORE))
     js["orb_frame0_harris"] = {"n": int(len(k)), "sha256": digest(k, d)}
     (k0, d0), (k1, d1) = feats[0], feats[1]
     m, n, prev = ref.match_window(k0, d0, k1, d1)
