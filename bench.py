@@ -325,10 +325,10 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             # HBM bytes per launch of that kernel from rocprofv3 PMC passes (profiles/pmc_traffic.json, collected with
             # tools/pmc_summarize.py on this workload; FETCH_SIZE x2 correction) - null when the file has no entry
-            "traffic": (traffic.get(dom, {}).get("traffic_bytes") if world == 1 else None),
+            "traffic": (_traffic_of(traffic, dom)[0] if world == 1 else None),
             "traffic_commit": traffic.get("_meta", {}).get("commit"),
-            "traffic_source_sha": traffic.get("_meta", {}).get("source_sha"),
-            "traffic_stale": bool(traffic.get("_meta", {}).get("stale", False)),
+            "traffic_code_sha": traffic.get(dom, {}).get("code_sha"),
+            "traffic_stale": _traffic_of(traffic, dom)[1],
             "algorithmic_bytes_per_launch": B_dom, "avg_launch_us": kern[dom]["avg_us"],
             "note": ("the dominant kernel is the dense pose solve: a 600-column dependency chain, bound by FP64 / LDS "
                      "latency and inter-workgroup hand-offs, not by bandwidth (DESIGN.md 4.1.1)"
@@ -540,6 +540,7 @@ def _orb_cpu_baseline(synth, nframes, seconds=10.0):
               "sample": f"{nfr} frames of the same synthetic sequence: oracle/orb_ref.cpp extract + "
                         f"oracle/match_ref.cpp MatchByWindow, 1 thread"}
     out = dict(single)
+    out["reference"] = _orb_reference_baseline(imgs, 0.3 * seconds)
     multi = _in_subprocess("orb", {"nframes": len(imgs), "seconds": 0.4 * seconds}, timeout=max(60.0, 6 * seconds))
     if "value" in multi and multi["value"] > single["value"]:
         out = dict(multi)
@@ -547,6 +548,32 @@ def _orb_cpu_baseline(synth, nframes, seconds=10.0):
     out["single_thread"] = single
     out["host"] = _host_desc()
     return out
+
+
+def _orb_reference_baseline(imgs, seconds):
+    """The reference ITSELF where it compiles: oracle/_ref = /root/reference/src/ORBextractor.cpp +
+    ORBmatcher.cpp + Frame.cpp, unmodified (ORBextractor::operator() :727-788, MatchByWindow :278-381), one thread, the same
+    frames.  The OpenCV calls underneath (FAST, resize, GaussianBlur, retainBest) are the stand-in's scalar code, not OpenCV's
+    SIMD builds - hence the kind."""
+    try:
+        from oracle import ref
+        if not ref.available():
+            return {"error": "oracle/_ref is not built here"}
+        ref.lib()
+        t1 = time.perf_counter()
+        nfr = 0
+        prev = ref.orb_extract(imgs[0])
+        while time.perf_counter() - t1 < seconds and nfr < len(imgs) - 1:
+            cur = ref.orb_extract(imgs[nfr + 1])
+            ref.match_window(prev[0], prev[1], cur[0], cur[1])
+            prev = cur
+            nfr += 1
+        cdt = time.perf_counter() - t1
+        return {"value": nfr / cdt, "unit": "frames/s", "cores": 1, "kind": "reference sources, 3P = stand-in",
+                "sample": f"{nfr} frames: the reference's own ORBextractor::operator() + ORBmatcher::MatchByWindow (oracle/_ref, "
+                          f"compiled from /root/reference unmodified, OpenCV stand-in underneath), 1 thread"}
+    except Exception as exc:   # test infrastructure: never take the bench line down
+        return {"error": repr(exc)}
 
 
 def _in_subprocess(which, cfg, timeout):
@@ -652,17 +679,41 @@ def source_sha():
 
 
 def _pmc_traffic():
-    """profiles/pmc_traffic.json (tools/pmc_summarize.py) - only if it was captured from THESE kernel sources; a capture
-    of older kernels is a stale constant and is dropped (roofline.traffic = null, traffic_stale = its stamp)."""
+    """profiles/pmc_traffic.json (tools/pmc_summarize.py), kernel by kernel: an entry counts only if the DEVICE CODE it was
+    measured on is the device code this library carries - every entry is stamped with the hash of its kernel's gfx950 code
+    object (se2lam_amd/devcode.py), read back from libse2gpu.so here.  A host-only edit of a source file, or a change in
+    another translation unit, leaves a kernel's entry valid; a change of its own code object drops it (roofline.traffic =
+    null, traffic_stale = true for that kernel).  (Rounds 2-4 stamped the whole csrc/ directory: any edit staled everything.)"""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return {}
-    meta = t.get("_meta", {})
-    if meta.get("source_sha") != source_sha():
-        return {"_meta": dict(meta, stale=True)}
-    return t
+    meta = dict(t.get("_meta", {}))
+    try:
+        from se2lam_amd import devcode
+        now = devcode.kernel_code_hashes()
+    except Exception as exc:   # unreadable library: nothing can be vouched for
+        return {"_meta": dict(meta, stale=True, stale_reason=repr(exc))}
+    out, stale = {}, []
+    for k, v in t.items():
+        if k == "_meta":
+            continue
+        if isinstance(v, dict) and v.get("code_sha") and (k not in now or v["code_sha"] == now[k]):
+            out[k] = v          # (k not in now: a runtime kernel such as __amd_rocclr_copyBuffer - not ours to hash)
+        else:
+            stale.append(k)
+    out["_meta"] = dict(meta, stale_kernels=stale)
+    return out
+
+
+def _traffic_of(traffic, kernel):
+    """(bytes per launch or None, is the capture stale for this kernel?)"""
+    e = traffic.get(kernel)
+    meta = traffic.get("_meta", {})
+    if e:
+        return e.get("traffic_bytes"), False
+    return None, bool(meta.get("stale")) or kernel in meta.get("stale_kernels", [])
 
 
 def _host_desc():

@@ -61,7 +61,8 @@ int se2gpu_orb_levels(const se2gpu_orb* h);            /* GetLevels()      ORBex
 float se2gpu_orb_scale_factor(const se2gpu_orb* h);    /* GetScaleFactor() ORBextractor.h:56 */
 
 /* operator()(image, mask, keypoints, descriptors): `img` is a rows x cols CV_8UC1 host image with
- * row pitch `step`; `mask` must be NULL (the reference always passes an empty mask, Frame.cpp:25).
+ * row pitch `step`; `mask` is accepted and ignored, as in the reference (its cellMask never reaches cv::FAST,
+ * ORBextractor.cpp:610-622; its only caller passes an empty mask, Frame.cpp:25).
  * Writes up to `cap` keypoints / cap*32 descriptor bytes, *n_out = number of keypoints.
  * An empty image (rows==0 || cols==0) returns OK with *n_out = 0 (ORBextractor.cpp:730-731). */
 int se2gpu_orb_extract(se2gpu_orb* h, const uint8_t* img, int rows, int cols, size_t step, const uint8_t* mask,
@@ -314,7 +315,9 @@ int se2gpu_ba_initialize(se2gpu_ba* h);
 /* g2o::OptimizableGraph::Edge::setLevel(level) of the `edge`-th EdgeSE3 added to a pose graph (the index
  * se2gpu_ba_edge_chi2 reports it under); takes effect at the next se2gpu_ba_initialize. */
 int se2gpu_ba_set_edge_level(se2gpu_ba* h, int edge, int level);
-/* restores every vertex estimate to the value it was added with (device-to-device) */
+/* restores every vertex estimate to the value the device graph was built with (device-to-device): the value it was added with -
+ * or, on a pose graph that was initialised a second time, the estimates that second se2gpu_ba_initialize started from (g2o has
+ * no such reset; a re-initialise moves the reset point) */
 int se2gpu_ba_reset_estimates(se2gpu_ba* h);
 /* ... of `count` windows with one launch (the companion of se2gpu_ba_optimize_batch for a mapper that re-optimises the same
  * windows): ordered before any later operation on each of the windows */

@@ -41,6 +41,7 @@ struct EdgeHandle {
     SlamOptimizer* opt = nullptr;
     int index = -1;      // position among the edges whose chi2 the library reports; -1: an edge without per-edge chi2
     int level_ = 0;
+    int pushed_level_ = 0;   // the level the library was last told (edges start at 0 there)
     void computeError() {}
     double chi2() const;
     void setLevel(int l);
@@ -108,9 +109,12 @@ public:
         if (level != 0) throw std::runtime_error("initializeOptimization: only level 0 can be optimised");
         for (const EdgeHandle& e : plain_edges_) if (e.level_ != 0) throw std::runtime_error("initializeOptimization: an edge without a library index has been moved to another level (setLevel)");
         if (levels_touched_)
-            for (const EdgeHandle& e : edges_)
-                if (se2gpu_ba_set_edge_level(h_, e.index, e.level_) != SE2GPU_OK && e.level_ != 0)
+            for (EdgeHandle& e : edges_) {
+                if (e.level_ == e.pushed_level_) continue;   // nothing to tell the library (setLevel(1) ... setLevel(0) on a landmark graph: no call at all)
+                if (se2gpu_ba_set_edge_level(h_, e.index, e.level_) != SE2GPU_OK)
                     throw std::runtime_error("initializeOptimization: an edge has been moved to another level (setLevel); only the pose graph's EdgeSE3 have levels on the device");
+                e.pushed_level_ = e.level_;
+            }
         check(se2gpu_ba_initialize(h_), "initializeOptimization");
         edge_chi2_.clear();
         return true;

@@ -4245,6 +4245,16 @@ int ba_upload_graph(se2gpu_ba* h) {
     }
     SE2_HIP(hipEventRecord(h->ev_copy0, st));                      // (the arena may still be read by earlier work)
     SE2_HIP(hipStreamWaitEvent(copy_stream, h->ev_copy0, 0));
+    // From here on DMA out of the pinned arena is in flight on two streams.  The success path waits for all of it at the end;
+    // an error return in between must not leave it running (the next load / initialize on the handle writes into the arena
+    // without waiting): wait on the way out.
+    struct DrainOnError {
+        hipStream_t a, b;
+        bool armed = true;
+        ~DrainOnError() {
+            if (armed) { (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(a); }
+        }
+    } drain{st, copy_stream};
     auto stage_range = [&](size_t lo, size_t hi, hipStream_t cur) -> int {   // the staged arrays with lo <= offset < hi
         auto flush_on = [&](size_t upto) -> int {
             if (upto > sent) {
@@ -4515,6 +4525,7 @@ int ba_upload_graph(se2gpu_ba* h) {
     h->est_valid = false;
     static std::atomic<unsigned long> serial{0};
     h->init_serial = ++serial;
+    drain.armed = false;   // (everything was waited for above)
     return SE2GPU_OK;
 }
 
@@ -5038,6 +5049,13 @@ struct BatchKernel<Body, BS> {
     }
     void launch_xcd(const BatchArena& ar, hipStream_t st) const {   // every window on one XCD (k_batched_xcd)
         if (packs.empty() || maxblk <= 0) return;
+        // k_batched_xcd's mapping is written for 8 XCDs dealt round-robin (MI355X in SPX mode).  Any other device or
+        // partition mode would get correct results from it but windows serialised in groups of eight for nothing: ask.
+        static const bool eight = [] {
+            int dev = 0, n = 0;
+            return hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && n == 8;
+        }();
+        if (!eight) { launch(ar, st); return; }
         hipLaunchKernelGGL((k_batched_xcd<Body, BS, std::remove_cv_t<A>...>), dim3((unsigned)((maxblk + 7) & ~7), (unsigned)packs.size()),
                            dim3(BS), 0, st, reinterpret_cast<const P*>(ar.dev.p + off));
     }

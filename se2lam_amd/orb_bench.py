@@ -117,6 +117,7 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
         ach = b_launch / (kern[dom]["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": (traffic or {}).get(dom, {}).get("traffic_bytes"),
+                "traffic_stale": dom in (traffic or {}).get("_meta", {}).get("stale_kernels", []),
                 "algorithmic_bytes_per_launch": b_launch,
                 "avg_launch_us": kern[dom]["avg_us"],
                 "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,

@@ -37,14 +37,18 @@ def main():
                      "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes"}}
     # what the capture is valid for: the kernel sources it ran (bench.py nulls `traffic` when they have changed since) and
     # the commit the caller says it is at (the GPU box has no .git: pass GRAFT_COMMIT=$(git rev-parse --short HEAD))
+    # what the capture is valid for: every kernel's entry carries the hash of the gfx950 code object it was measured on
+    # (se2lam_amd/devcode.py reads it out of libse2gpu.so; bench.py drops an entry whose kernel has changed since - and only that)
     import bench
+    from se2lam_amd import devcode
+    code = devcode.kernel_code_hashes()
     out["_meta"]["source_sha"] = bench.source_sha()
     out["_meta"]["commit"] = os.environ.get("GRAFT_COMMIT") or None
     for k in sorted(F, key=lambda k: -sum(F[k])):
         f = sum(F[k]) / len(F[k])
         w = sum(W.get(k, [0.0])) / max(len(W.get(k, [0.0])), 1)
         out[k] = {"launches": len(F[k]), "fetch_size_kib_avg": f, "write_size_kib_avg": w,
-                  "traffic_bytes": (2 * f + w) * 1024}
+                  "traffic_bytes": (2 * f + w) * 1024, "code_sha": code.get(k)}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if k != "_meta":
