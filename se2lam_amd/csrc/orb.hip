@@ -764,6 +764,80 @@ __device__ void seq_heap_select(typename Ent<H>::T* first, int middle, int last)
         }
 }
 
+// ---- the rounds of introselect once its range fits the wave: one element per lane in a register (lane p holds a[base + p]),
+// the same steps as introselect_wave below with lane shuffles instead of LDS traffic - a third of the instructions, and most
+// cells (~100 corners) spend all but their first round here.  Returns false when the depth limit ran out (the range is
+// written back, the caller takes the heap-select branch); true when the selection is finished.
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+__device__ __forceinline__ unsigned long long lane_read(unsigned long long v, int i) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), i) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, i);
+}
+template <bool H, class PosT>
+__device__ bool introselect_tail(typename Ent<H>::T* a, PosT* lp, PosT* rp, int& first, int& last, const int nth, int& depth) {
+    using E = Ent<H>;
+    using T = typename E::T;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long lt = (1ull << lane) - 1ull, gt = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    const int base = first, len0 = last - first;
+    T v = lane < len0 ? a[base + lane] : (T)0;
+    bool done = true;
+    while (last - first > 3) {
+        if (depth == 0) { done = false; break; }
+        --depth;
+        const int i0 = __builtin_amdgcn_readfirstlane(first - base), hi = __builtin_amdgcn_readfirstlane(last - base);
+        const int ia = i0 + 1, ib = i0 + (hi - i0) / 2, ic = hi - 1;
+        const T ea = lane_read(v, ia), eb = lane_read(v, ib), ec = lane_read(v, ic), er = lane_read(v, i0);
+        const uint32_t ka = E::key(ea), kb = E::key(eb), kc = E::key(ec);
+        int src;                                              // __move_median_to_first(first, first + 1, mid, last - 1)
+        if (ka > kb) src = (kb > kc) ? ib : (ka > kc) ? ic : ia;
+        else src = (ka > kc) ? ia : (kb > kc) ? ic : ib;
+        const T es = src == ia ? ea : src == ib ? eb : ec;
+        if (lane == src) v = er;
+        if (lane == i0) v = es;
+        const uint32_t pk = E::key(es);
+        const bool inr = lane > i0 && lane < hi;
+        const uint32_t k = E::key(v);
+        const bool isL = inr && !(k > pk), isR = inr && !(pk > k);
+        const unsigned long long mL = __builtin_amdgcn_ballot_w64(isL), mR = __builtin_amdgcn_ballot_w64(isR);
+        const int cL = __popcll(mL), cR = __popcll(mR);
+        const int rL = __popcll(mL & lt), rR = __popcll(mR & gt);     // rank from the left / from the right
+        if (isL) lp[rL] = (PosT)lane;
+        if (isR) rp[rR] = (PosT)lane;
+        wave_fence();
+        const int m = min(cL, cR);
+        const bool ok = lane < m && (int)lp[lane] < (int)rp[lane];
+        const int K = __popcll(__builtin_amdgcn_ballot_w64(ok));
+        int from = lane;                                      // the K swaps as one permutation
+        if (isL && rL < K) from = (int)rp[rL];
+        else if (isR && rR < K) from = (int)lp[rR];
+        v = __shfl(v, from);
+        int cut = K > 0 ? (int)rp[K - 1] : hi;
+        if (K < cL) cut = min(cut, (int)lp[K]);
+        cut = __builtin_amdgcn_readfirstlane(cut) + base;
+        wave_fence();
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (done) {                                               // __insertion_sort on at most three elements
+        const int i0 = __builtin_amdgcn_readfirstlane(first - base), cnt = __builtin_amdgcn_readfirstlane(last - first);
+        T e[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) e[q] = lane_read(v, min(i0 + q, 63));
+        if (cnt >= 2 && E::key(e[1]) > E::key(e[0])) { const T t = e[0]; e[0] = e[1]; e[1] = t; }
+        if (cnt >= 3) {
+            if (E::key(e[2]) > E::key(e[0])) { const T t = e[2]; e[2] = e[1]; e[1] = e[0]; e[0] = t; }
+            else if (E::key(e[2]) > E::key(e[1])) { const T t = e[2]; e[2] = e[1]; e[1] = t; }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < cnt && lane == i0 + q) v = e[q];
+    }
+    if (lane < len0) a[base + lane] = v;
+    wave_fence();
+    return done;
+}
+
 // ---- std::nth_element(a, a + nth, a + n, response greater) of libstdc++ (bits/stl_algo.h __introselect), by one wave.
 // The control flow is the library's, step for step: depth limit 2 lg n, median of (first + 1, mid, last - 1) moved to first,
 // the unguarded Hoare partition of [first + 1, last) around it, the side that holds nth kept, insertion sort below four
@@ -781,6 +855,7 @@ __device__ void introselect_wave(typename Ent<H>::T* a, PosT* lp, PosT* rp, int 
     int first = 0, last = n;
     int depth = 2 * (31 - __clz(n));
     while (last - first > 3) {
+        if (last - first <= 64 && depth > 0 && introselect_tail<H, PosT>(a, lp, rp, first, last, nth, depth)) return;
         if (depth == 0) {
             if (lane == 0) {
                 seq_heap_select<H>(a + first, nth + 1 - first, last - first);
@@ -875,24 +950,206 @@ __device__ __forceinline__ void bitonic_sort_u32(uint32_t* keys, int npad) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_cell_collect: what cv::FAST returns for the cell, in the order it returns it.
+// k_cell_collect_w: what cv::FAST returns for the cell, in the order it returns it - one WAVE per cell (four cells per
+// workgroup, no barriers).  The kernel is bound by the instructions a wave issues per cell (33 k cells per batch), so:
+//   * the cell's rectangle, its candidate lists and its list in HBM come from a table built with the geometry (CellGeo: the
+//     dozen integer divisions they take cost more than the rest of the preamble);
+//   * all in-cell candidates (S > 7) go into ONE array, one ballot per pixel column; the FAST(20) / FAST(7) choice
+//     (ORBextractor.cpp:616-623) is a count taken on the way and a filter afterwards;
+//   * row-major order by a counting sort over the cell's rows (an ordinary cell: ~100 corners on ~75 rows), then a rank
+//     inside each row's few entries - a tenth of the comparisons of a full rank sort.
+// A cell with more than kWCap candidates, more than 64 lists or more than kWRows rows is left to the workgroup kernel below
+// (cell_total = kCellDeferred + an entry in the deferred queue).  Same lists, same sort key, same output as there.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCellDeferred = -1;
+constexpr int kWCap = 512, kWRows = 128;
+constexpr int kMaxListsPerCell = 64;
+// per cell and list layout (dense strips / sparse tiles), two int4:
+//   a = {xa | ya << 16, xb | yb << 16, id of the first list, ntc | min(nl, 255) << 8 | lists per row << 16 | level << 28}
+//   b = {list offset in the frame's block (entries), scratch offset (uint32), lcap, bits of 1.0f / ntc}
+struct CellGeoRec { int4 a, b; };
+template <bool HARRIS>
+__global__ __launch_bounds__(256) void k_cell_collect_w(Geom g, const CellGeoRec* __restrict__ geo, const uint2* __restrict__ lst_ent,
+                                                         const int* __restrict__ lst_cnt, const uint8_t* __restrict__ pyr,
+                                                         typename Ent<HARRIS>::T* __restrict__ cell_ent, int* __restrict__ cell_total,
+                                                         int* __restrict__ defer_q) {
+    using E = Ent<HARRIS>;
+    __shared__ uint32_t s_keys[4][kWCap], s_tmp[4][kWCap];
+    __shared__ int s_cnt[4][kWRows], s_rs[4][kWRows];
+    __shared__ int s_offs[4][kMaxListsPerCell + 1];
+    __shared__ unsigned s_lsts[4][kMaxListsPerCell];
+    const int f = (int)blockIdx.x;
+    if (f >= g.nframes) return;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = (int)(threadIdx.x & 63);
+    const int cell = (int)blockIdx.y * 4 + wave;
+    const int ncells_frame = g.cell_base[g.nlevels];
+    if (cell >= ncells_frame) return;
+    uint32_t* keys = s_keys[wave];
+    uint32_t* tmp = s_tmp[wave];
+    int* cnt = s_cnt[wave];
+    int* rs = s_rs[wave];
+    int* s_off = s_offs[wave];
+    unsigned* s_lst = s_lsts[wave];
+    const int4 ga = geo[cell].a, gb = geo[cell].b;
+    const int xa = ga.x & 0xffff, ya = (int)((unsigned)ga.x >> 16), xb = ga.y & 0xffff, yb = (int)((unsigned)ga.y >> 16);
+    const int ntc = ga.w & 0xff, nl = (ga.w >> 8) & 0xff, ltx = (ga.w >> 16) & 0xfff, l = (int)((unsigned)ga.w >> 28);
+    int* tot_out = cell_total + (size_t)f * ncells_frame + cell;
+    auto defer = [&]() {
+        if (lane == 0) {
+            *tot_out = kCellDeferred;
+            defer_q[1 + atomicAdd(&defer_q[0], 1)] = (f << 12) | cell;
+        }
+    };
+    if (nl == 0) {
+        if (lane == 0) *tot_out = 0;
+        return;
+    }
+    const int ch = yb - ya;
+    if (nl > kMaxListsPerCell || ch > kWRows) { defer(); return; }
+    {   // the cell's lists: counts -> exclusive prefix
+        int c = 0;
+        if (lane < nl) {
+            const int row = (int)(((float)lane + 0.5f) * __int_as_float(gb.w));   // lane / ntc (exact: see orb_configure)
+            const unsigned id = (unsigned)(ga.z + row * ltx + (lane - row * ntc));
+            s_lst[lane] = id;
+            c = lst_cnt[(size_t)f * g.lst_base[g.nlevels] + id];
+        }
+        int incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        s_off[lane + 1] = incl;
+        if (lane == 0) s_off[0] = 0;
+        cnt[lane] = 0;
+        cnt[lane + 64] = 0;
+    }
+    wave_fence();
+    const int nent = s_off[nl];
+    const uint2* ebase = lst_ent + (size_t)f * g.lst_base[g.nlevels] * g.lst_cap;
+    int n_all = 0, n20 = 0;   // in-cell candidates (S > 7) / those above fast_th
+    const int step0 = nl > 1 ? 1 << (31 - __clz(nl - 1)) : 0;   // first step of the binary search over the nl list starts
+    bool odd = false;         // an entry with three in-cell maxima among its four pixels (impossible: they are never adjacent)
+    for (int e0 = 0; e0 < nent; e0 += 64) {
+        const int e = e0 + lane;
+        uint2 en = make_uint2(0u, 0u);
+        unsigned mask = 0;    // which of the entry's four pixels are in-cell candidates
+        if (e < nent) {
+            int k = 0;        // the list that holds entry e
+            for (int step = step0; step > 0; step >>= 1)
+                if (k + step < nl && s_off[k + step] <= e) k += step;
+            en = ebase[(size_t)s_lst[k] * g.lst_cap + (e - s_off[k])];
+            const int y = (int)(en.x >> 12), x0 = (int)(en.x & 0xfffu);
+            // non-zero bytes of en.y -> bits 0..3; columns of the cell -> bits [xa - x0, xb - x0) of the four
+            unsigned t = en.y | (en.y >> 4);
+            t |= t >> 2;
+            t |= t >> 1;
+            const unsigned nz = ((t & 0x01010101u) * 0x01020408u) >> 24;
+            const int qlo = min(max(xa - x0, 0), 4), qhi = min(max(xb - x0, 0), 4);
+            const unsigned cols = ((1u << qhi) - 1u) & ~((1u << qlo) - 1u);
+            mask = (y >= ya && y < yb) ? (nz & cols) : 0u;
+        }
+        // slots (the order inside keys[] does not matter: it is sorted below): an entry holds at most two candidates
+        const unsigned m2 = mask & (mask - 1u);
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(mask != 0), b2 = __builtin_amdgcn_ballot_w64(m2 != 0);
+        odd |= (m2 & (m2 - 1u)) != 0;
+        const int slot = n_all + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0u)) +
+                         (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0u));
+        const uint32_t ybits = (en.x >> 12) << 20;
+        const int x0 = (int)(en.x & 0xfffu);
+        if (mask && slot < kWCap) {
+            const int q = __ffs(mask) - 1;
+            keys[slot] = ybits | ((uint32_t)(x0 + q) << 8) | ((en.y >> (8 * q)) & 0xffu);
+        }
+        if (m2 && slot + 1 < kWCap) {
+            const int q = __ffs(m2) - 1;
+            keys[slot + 1] = ybits | ((uint32_t)(x0 + q) << 8) | ((en.y >> (8 * q)) & 0xffu);
+        }
+        n_all += __popcll(b1) + __popcll(b2);
+    }
+    if (n_all > kWCap || __builtin_amdgcn_ballot_w64(odd) != 0) { defer(); return; }
+    wave_fence();
+    for (int i0 = 0; i0 < n_all; i0 += 64) {
+        const int i = i0 + lane;
+        n20 += __popcll(__builtin_amdgcn_ballot_w64(i < n_all && (int)(keys[i] & 0xffu) > g.fast_th));
+    }
+    // threshold choice of ORBextractor.cpp:616-623: FAST(20); if it yields <= 3 key points, FAST(7) - the corners at 7 are the
+    // strict in-cell maxima of all scores above 7, those at 20 the ones among them that score above 20
+    const int lo = n20 > 3 ? g.fast_th : 7;
+    const int n = n20 > 3 ? n20 : n_all;
+    const int lcap = gb.z;
+    if (n > lcap) { defer(); return; }   // (cannot happen: in-cell maxima are never adjacent)
+    wave_fence();
+    // counting sort by row: slot inside the row (arrival order), row starts, placement, then the rank inside the row by x
+    int slotv[kWCap / 64];
+#pragma unroll
+    for (int u = 0; u < kWCap / 64; ++u) {
+        const int i = lane + 64 * u;
+        slotv[u] = -1;
+        if (64 * u >= n_all) continue;   // (uniform)
+        if (i < n_all) {
+            const uint32_t key = keys[i];
+            if ((int)(key & 0xffu) > lo) slotv[u] = atomicAdd(&cnt[(int)(key >> 20) - ya], 1);
+        }
+    }
+    wave_fence();
+    {
+        const int c0 = cnt[lane], c1 = cnt[lane + 64];
+        int i0 = c0, i1 = c1;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v0 = __shfl_up(i0, d), v1 = __shfl_up(i1, d);
+            if (lane >= d) { i0 += v0; i1 += v1; }
+        }
+        const int t0 = __shfl(i0, 63);
+        rs[lane] = i0 - c0;
+        rs[lane + 64] = t0 + i1 - c1;
+    }
+    wave_fence();
+#pragma unroll
+    for (int u = 0; u < kWCap / 64; ++u) {
+        const int i = lane + 64 * u;
+        if (64 * u >= n_all) continue;   // (uniform)
+        if (i < n_all && slotv[u] >= 0) {
+            const uint32_t key = keys[i];
+            tmp[rs[(int)(key >> 20) - ya] + slotv[u]] = key;
+        }
+    }
+    wave_fence();
+    typename E::T* out = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + (unsigned)gb.x;
+    const uint8_t* lvl = pyr + pix(g, f, l, 0, 0);
+    const int stride = g.stride[l];
+    for (int p = lane; p < n; p += 64) {
+        const uint32_t key = tmp[p];
+        const int r = (int)(key >> 20) - ya;
+        const int b0 = rs[r], b1 = b0 + cnt[r];
+        int rank = b0;
+        for (int j = b0; j < b1; ++j) rank += tmp[j] < key;
+        const uint32_t pos = key >> 8;
+        if constexpr (HARRIS) out[rank] = E::make(harris_response(lvl, stride, (int)(pos & 0xfff), (int)(pos >> 12)), pos);
+        else out[rank] = (key << 24) | pos;
+    }
+    if (lane == 0) *tot_out = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cell_collect_wg / k_cell_collect_big: the same for the cells k_cell_collect_w left (huge cells, cells full of corners):
+// one WORKGROUP per cell.
 // Cell (i, j) of level l scans x in [16 + j*cellW, min(16 + (j+1)*cellW, w-16)), same for y: the cells tile the
 // scan area exactly (cell window = cell +- 3 px, cv::FAST skips a 3 px rim, ORBextractor.cpp:569-608).
 // sort key = (y << 12 | x) << 8 | S: ascending = row-major, the order of cv::FAST's output vector
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxListsPerCell = 64;
 constexpr int kRankMax = 768;      // up to here a rank sort (no barriers) beats the bitonic network
 template <bool HARRIS>
-__global__ __launch_bounds__(256) void k_cell_collect(Geom g, const uint2* __restrict__ lst_ent, const int* __restrict__ lst_cnt,
-                                                       const uint8_t* __restrict__ pyr,
-                                                       typename Ent<HARRIS>::T* __restrict__ cell_ent, uint32_t* __restrict__ cell_scr,
-                                                       int* __restrict__ cell_total, int* __restrict__ overflow) {
+__device__ void cell_collect_wg(const Geom& g, const int f, const int cell, const uint2* __restrict__ lst_ent,
+                                const int* __restrict__ lst_cnt, const uint8_t* __restrict__ pyr,
+                                typename Ent<HARRIS>::T* __restrict__ cell_ent, uint32_t* __restrict__ cell_scr,
+                                int* __restrict__ cell_total, int* __restrict__ overflow) {
     using E = Ent<HARRIS>;
     __shared__ uint32_t keys[kSortCap];
     __shared__ int s_nw, s_n20;   // candidates with 7 < S <= fast_th (stored from the back of keys[]) / with S > fast_th (front)
     __shared__ int s_off[kMaxListsPerCell + 1];                    // exclusive prefix of the entry counts of the cell's lists
     __shared__ unsigned s_lst[kMaxListsPerCell];
-    SE2_FRAME_GRID(f, cell);
     int l = 0;
     while (l + 1 < g.nlevels && cell >= g.cell_base[l + 1]) ++l;
     const int ci = (cell - g.cell_base[l]) / g.gcols[l], cj = (cell - g.cell_base[l]) % g.gcols[l];
@@ -1031,6 +1288,20 @@ __global__ __launch_bounds__(256) void k_cell_collect(Geom g, const uint2* __res
     for (int i = threadIdx.x; i < n; i += 256) emit(i, keys[i]);
 }
 
+// the deferred cells of a batch (defer_q = {count, (frame << 12 | cell) ...}, filled by k_cell_collect_w), a fixed small grid
+template <bool HARRIS>
+__global__ __launch_bounds__(256) void k_cell_collect_big(Geom g, const int* __restrict__ defer_q, const uint2* __restrict__ lst_ent,
+                                                           const int* __restrict__ lst_cnt, const uint8_t* __restrict__ pyr,
+                                                           typename Ent<HARRIS>::T* __restrict__ cell_ent, uint32_t* __restrict__ cell_scr,
+                                                           int* __restrict__ cell_total, int* __restrict__ overflow) {
+    const int nq = defer_q[0];
+    for (int it = (int)blockIdx.x; it < nq; it += (int)gridDim.x) {
+        const int v = defer_q[1 + it];
+        cell_collect_wg<HARRIS>(g, v >> 12, v & 0xfff, lst_ent, lst_cnt, pyr, cell_ent, cell_scr, cell_total, overflow);
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Quota replay of one level by one wave: lane c + 64 k owns cell c + 64 k (<= 256 cells).  The reference's loop
 // (:640-679) is a fixed-point over passes whose body does not depend on the cell order, so a pass is one wave step.
@@ -1085,8 +1356,10 @@ __device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, 
 // k_quota: nToRetain of every cell (ORBextractor.cpp:631-679), one wave per (frame, level); cell_plan[cell] = {nToRetain,
 // place of the cell's first retained corner in the level's list}
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_quota(Geom g, const int* __restrict__ cell_total, int2* __restrict__ cell_plan) {
+__global__ __launch_bounds__(64) void k_quota(Geom g, const int* __restrict__ cell_total, int2* __restrict__ cell_plan,
+                                              int* __restrict__ defer_q) {
     __shared__ int n_ret[256], c_off[256];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) defer_q[0] = 0;   // (k_cell_collect_big is done: next batch)
     SE2_FRAME_GRID(f, l);
     const int ncells_frame = g.cell_base[g.nlevels];
     const int nc = g.gcols[l] * g.grows[l];
@@ -1103,7 +1376,7 @@ __global__ __launch_bounds__(64) void k_quota(Geom g, const int* __restrict__ ce
 // ---------------------------------------------------------------------------------------------
 constexpr int kSelCap = 512;      // corners a cell can hold for the LDS path of k_cell_retain (more: in place in global memory)
 template <bool HARRIS>
-__global__ __launch_bounds__(256) void k_cell_retain(Geom g, typename Ent<HARRIS>::T* __restrict__ cell_ent,
+__global__ __launch_bounds__(256) void k_cell_retain(Geom g, const CellGeoRec* __restrict__ geo, typename Ent<HARRIS>::T* __restrict__ cell_ent,
                                                       uint32_t* __restrict__ cell_scr, const int* __restrict__ cell_total,
                                                       const int2* __restrict__ cell_plan, int* __restrict__ overflow) {
     using E = Ent<HARRIS>;
@@ -1117,14 +1390,12 @@ __global__ __launch_bounds__(256) void k_cell_retain(Geom g, typename Ent<HARRIS
     const int cell = (int)blockIdx.y * 4 + wave;
     const int ncells_frame = g.cell_base[g.nlevels];
     if (cell >= ncells_frame) return;
-    int l = 0;
-    while (l + 1 < g.nlevels && cell >= g.cell_base[l + 1]) ++l;
-    const int c = cell - g.cell_base[l];
     const int total = cell_total[(size_t)f * ncells_frame + cell];
     const int nret = cell_plan[(size_t)f * ncells_frame + cell].x;
     if (total <= nret) return;
-    const int lcap = g.lcap[l];
-    T* list = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + g.lcell_off[l] + (size_t)c * lcap;
+    const int4 gb = geo[cell].b;
+    const int lcap = gb.z;
+    T* list = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + (unsigned)gb.x;
     if (total <= kSelCap) {
         T* a = s_a[wave];
         for (int i = lane; i < total; i += 64) a[i] = list[i];
@@ -1136,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_cell_retain(Geom g, typename Ent<HARRIS
             if (lane == 0) atomicOr(overflow, 2);
             return;
         }
-        uint32_t* scr = cell_scr + (size_t)f * g.lscr_off[g.nlevels] + g.lscr_off[l] + (size_t)c * 2 * lcap;
+        uint32_t* scr = cell_scr + (size_t)f * g.lscr_off[g.nlevels] + (unsigned)gb.y;
         introselect_wave<HARRIS, uint32_t>(list, scr, scr + lcap, total, nret);
     }
 }
@@ -1547,6 +1818,8 @@ struct se2gpu_orb {
     DevBuf<uint32_t> cell_keys;
     DevBuf<int> cell_total, counts, overflow;
     DevBuf<int2> cell_plan;                  // k_quota: {nToRetain, place in the level's list} per cell
+    DevBuf<int4> cell_geo;                   // CellGeoRec per cell: [0, ncell) for the dense score kernel's lists, [ncell, 2 ncell) sparse
+    DevBuf<int> defer_q;                     // cells k_cell_collect_w left to k_cell_collect_big: {count, entries ...}
     DevBuf<int4> kp_list, tabs;
     DevBuf<float> angles;
     DevBuf<uint32_t> cell_scr;               // scratch of the huge-cell paths (Geom::lscr_off)
@@ -1727,6 +2000,40 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         tabs.push_back(make_int4((int)w[0], (int)w[1], (int)w[2], (int)w[3]));
     }
     SE2_CHECK(h->tabs.upload(tabs, h->stream));
+    {   // CellGeoRec tables (k_cell_collect_w, k_cell_retain): rectangle, candidate lists and list place of every cell
+        const int ncell = g.cell_base[L];
+        std::vector<int4> geo(4 * (size_t)ncell);
+        for (int layout = 0; layout < 2; ++layout) {
+            const int tw = layout == 0 ? 4 * kScoreGroups : kFsTW, th = layout == 0 ? kScoreRows : kFsTH;
+            const int* lbase = layout == 0 ? h->dense_lst_base : h->sparse_lst_base;
+            for (int l = 0; l < L; ++l)
+                for (int c = 0; c < g.gcols[l] * g.grows[l]; ++c) {
+                    const int ci = c / g.gcols[l], cj = c % g.gcols[l];
+                    const int xa = kEdge + cj * g.cellW[l], ya = kEdge + ci * g.cellH[l];
+                    const int xb = (cj == g.gcols[l] - 1) ? g.w[l] - kEdge : xa + g.cellW[l];
+                    const int yb = (ci == g.grows[l] - 1) ? g.h[l] - kEdge : ya + g.cellH[l];
+                    const int ltx = (g.w[l] - 2 * kEdge + tw - 1) / tw;
+                    const int tc0 = (xa - kEdge) / tw, tc1 = (xb - 1 - kEdge) / tw, tr0 = (ya - kEdge) / th, tr1 = (yb - 1 - kEdge) / th;
+                    const int ntc = tc1 - tc0 + 1;
+                    const int nl = (xb > xa && yb > ya) ? ntc * (tr1 - tr0 + 1) : 0;
+                    // (lane + 0.5f) * (1.0f / ntc) truncates to lane / ntc for lane < 64: lane + 0.5 is never a multiple of ntc
+                    // and stays 0.5 / ntc >= 1 / 128 away from one, the float error is ~1e-5
+                    const float rcp = 1.0f / (float)std::max(ntc, 1);
+                    int rb;
+                    std::memcpy(&rb, &rcp, 4);
+                    SE2_REQUIRE(ltx < 4096 && std::min(ntc, 255) == (ntc & 0xff), SE2GPU_ERR_INVALID, "level %d: cell / list geometry out of range", l);
+                    int4 a = make_int4(xa | (ya << 16), xb | (yb << 16), lbase[l] + tr0 * ltx + tc0,
+                                       (ntc & 0xff) | (std::min(nl, 255) << 8) | (ltx << 16) | (int)((unsigned)l << 28));
+                    if (nl > 255 || ntc > 255) a.w = (a.w & ~0xffff) | 1 | (255 << 8);   // (deferred to the workgroup kernel, which derives its own lists)
+                    const int4 b = make_int4((int)(g.lcell_off[l] + (unsigned)c * (unsigned)g.lcap[l]),
+                                             g.lcap[l] > kSelCap ? (int)(g.lscr_off[l] + 2u * (unsigned)c * (unsigned)g.lcap[l]) : 0, g.lcap[l], rb);
+                    const size_t at = 2 * ((size_t)layout * ncell + g.cell_base[l] + c);
+                    geo[at] = a;
+                    geo[at + 1] = b;
+                }
+        }
+        SE2_CHECK(h->cell_geo.upload(geo, h->stream));
+    }
     // buffers
     const size_t B = (size_t)h->max_batch;
     SE2_CHECK(h->pyr.reserve(B * g.frame_bytes));
@@ -1737,6 +2044,8 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     SE2_CHECK(h->cell_scr.reserve(std::max<size_t>(1, B * (size_t)g.lscr_off[L])));
     SE2_CHECK(h->cell_total.reserve(B * g.cell_base[L]));
     SE2_CHECK(h->cell_plan.reserve(B * g.cell_base[L]));
+    SE2_CHECK(h->defer_q.reserve(1 + B * g.cell_base[L]));
+    SE2_HIP(hipMemsetAsync(h->defer_q.p, 0, sizeof(int), h->stream));
     SE2_CHECK(h->overflow.reserve(1));
     SE2_HIP(hipMemsetAsync(h->overflow.p, 0, sizeof(int), h->stream));
     SE2_HIP(hipStreamSynchronize(h->stream));
@@ -1854,21 +2163,27 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     }
     h->last_lists = g;
     const unsigned ncell = (unsigned)g.cell_base[L];
+    const CellGeoRec* geo = reinterpret_cast<const CellGeoRec*>(h->cell_geo.p) + (run_sparse ? ncell : 0u);
+    constexpr unsigned kBigGrid = 512;   // workgroups that share the deferred cells of a batch (normally none)
     if (g.harris) {
         using T = Ent<true>::T;
         T* ent = reinterpret_cast<T*>(h->cell_keys.p);
-        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect<true>, dim3(F8, ncell), dim3(256), 0, g, h->lst_ent.p,
-                   h->lst_cnt.p, h->pyr.p, ent, h->cell_scr.p, h->cell_total.p, h->overflow.p);
-        SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p);
-        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, ent,
+        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect_w<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, h->lst_ent.p,
+                   h->lst_cnt.p, h->pyr.p, ent, h->cell_total.p, h->defer_q.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_collect_big", k_cell_collect_big<true>, dim3(kBigGrid), dim3(256), 0, g, h->defer_q.p,
+                   h->lst_ent.p, h->lst_cnt.p, h->pyr.p, ent, h->cell_scr.p, h->cell_total.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p, h->defer_q.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, ent,
                    h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
         SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<true>, dim3(F8, L), dim3(256), 0, g, ent, h->cell_plan.p,
                    h->kp_list.p, d_counts, cap, h->overflow.p);
     } else {
-        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect<false>, dim3(F8, ncell), dim3(256), 0, g, h->lst_ent.p,
-                   h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->overflow.p);
-        SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p);
-        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g,
+        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect_w<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, h->lst_ent.p,
+                   h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_total.p, h->defer_q.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_collect_big", k_cell_collect_big<false>, dim3(kBigGrid), dim3(256), 0, g, h->defer_q.p,
+                   h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p, h->defer_q.p);
+        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo,
                    h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
         SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<false>, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
                    h->cell_plan.p, h->kp_list.p, d_counts, cap, h->overflow.p);

@@ -82,7 +82,8 @@ def test_staged_patches_still_apply():
         pytest.skip("not a git checkout")
     pdir = os.path.join(ROOT, "tools", "patches")
     patches = sorted(f for f in os.listdir(pdir) if f.endswith(".patch"))
-    assert patches
+    if not patches:
+        pytest.skip("nothing is staged (round 5 applied one of round 4's two patches and dropped the other: tools/patches/README.md)")
     for f in patches:
         r = subprocess.run(["git", "apply", "--check", os.path.join(pdir, f)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, f + ": " + r.stderr
