@@ -45,7 +45,6 @@ constexpr int kEdge = 16;          // EDGE_THRESHOLD
 constexpr int kPatch = 31;         // PATCH_SIZE
 constexpr int kHalfPatch = 15;     // HALF_PATCH_SIZE
 constexpr int kSortCap = 4096;     // candidates (S > 7, local maxima) one cell can hold in LDS
-constexpr int kLevelCap = 2048;    // keypoints one level can hold before the level-wide retain
 
 __constant__ signed char c_pattern[1024] = {
 #include "orb_pattern_31.inc"
@@ -59,6 +58,14 @@ struct Geom {
     unsigned frame_bytes;
     int quota[kMaxLevels], gcols[kMaxLevels], grows[kMaxLevels], cellW[kMaxLevels], cellH[kMaxLevels];
     int nfc[kMaxLevels];                 // nfeaturesCell
+    // The scan area of a level is the union of its cells' FAST windows: x in [16, sx1), y in [16, sy1).  Normally sx1 = w - 16;
+    // when the cells are so wide that the last column starts at or beyond w - 16 ((gcols - 1) * cellW >= w - 32: its window is
+    // empty, ORBextractor.cpp:598-603) the column before it still spans its full cellW and scans up to 13 px of the reflect
+    // frame - the reference does exactly that (beyond 13 px its cv::Mat::colRange raises).  Same for rows.  skip: bit 0 /
+    // bit 1 = the last cell column / row is not even visited by the reference's loops (hX <= 0 / hY <= 0: `continue`), which
+    // leaves those cells open in the quota redistribution instead of closing them with zero key points.
+    int sx1[kMaxLevels], sy1[kMaxLevels], skip[kMaxLevels];
+    int level_cap;                       // entries of k_level_select's list: max over the levels of quota + 2 * cells (rounded up)
     int cell_base[kMaxLevels + 1];       // prefix sum of cells per level
     float scale[kMaxLevels];             // mvScaleFactor
     float patch[kMaxLevels];             // (float)(int)(PATCH_SIZE * mvScaleFactor[level])
@@ -342,8 +349,9 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     int l = 0;
     while (l + 1 < g.nlevels && bx >= g.tile_base[l + 1]) ++l;
     const int t = bx - g.tile_base[l];
-    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
-    const int sw = W - 2 * kEdge;
+    const int H = g.h[l], stride = g.stride[l];
+    const int X1 = g.sx1[l], Y1 = g.sy1[l];   // end of the scan area (w - 16, h - 16, or up to 13 px beyond: Geom::sx1)
+    const int sw = X1 - kEdge;
     const int tiles_x = (sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups);
     const int lane = threadIdx.x & 63;
     const int x0 = kEdge + (t % tiles_x) * (4 * kScoreGroups) + (lane - 1) * 4;  // lane 0 / 63 = halo groups
@@ -351,14 +359,14 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     // kernel is bound by VALU issue, and every address computed per lane is VALU work)
     const int strip = __builtin_amdgcn_readfirstlane((t / tiles_x) * 4 + (int)(threadIdx.x >> 6));
     const int y0 = kEdge + strip * kScoreRows;
-    if (y0 >= H - kEdge) return;  // wave-uniform
-    const bool xin = x0 >= kEdge && x0 < W - kEdge;            // this lane's group starts inside the scan area
+    if (y0 >= Y1) return;  // wave-uniform
+    const bool xin = x0 >= kEdge && x0 < X1;            // this lane's group starts inside the scan area
     const uint8_t* base = pyr + pix(g, f, l, 0, 0);
     // candidate list of this strip
     const size_t lst = (size_t)f * g.lst_base[g.nlevels] + g.lst_base[l] + strip * tiles_x + (t % tiles_x);
     uint2* ent = lst_ent + lst * kStripCap;
     int nent = 0;                                              // wave-uniform
-    const int xc = min(max(x0, kEdge), W - kEdge - 1) & ~3;    // clamped (aligned) load position for halo lanes outside
+    const int xc = min(max(x0, kEdge), X1 - 1) & ~3;    // clamped (aligned) load position for halo lanes outside
     uint32_t E[7][9];
     const int ymax = H + kEdge - 1;   // last row of the bordered plane (strips at the bottom clamp their look-ahead)
     // window rows y0-4 .. y0+1 (slots 0..5) so that the first computed score row is y0-1
@@ -367,8 +375,8 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         const uint32_t* p = (const uint32_t*)(base + (ptrdiff_t)min(y0 - 4 + r, ymax) * stride + xc - 4);
         expand_row(p[0], p[1], p[2], E[r]);
     }
-    const int yend = min(y0 + kScoreRows, H - kEdge);
-    const int nvalid = xin ? min(4, W - kEdge - x0) : 0;
+    const int yend = min(y0 + kScoreRows, Y1);
+    const int nvalid = xin ? min(4, X1 - x0) : 0;
     // cell-edge flags of the 4 pixels (horizontal): bit q of eL / eR
     const int cellW = g.cellW[l], cellH = g.cellH[l];
     unsigned eL = 0, eR = 0;
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
     for (int q = 0; q < 4; ++q) {
         const int xr = x0 + q - kEdge;
         if (xr >= 0 && xr % cellW == 0) eL |= 1u << q;
-        if (xr >= 0 && (xr % cellW == cellW - 1 || x0 + q == W - kEdge - 1)) eR |= 1u << q;
+        if (xr >= 0 && (xr % cellW == cellW - 1 || x0 + q == X1 - 1)) eR |= 1u << q;
     }
     // Non-max suppression state, all in packed int16 pairs A = pixels {0,1}, B = pixels {2,3} of this thread:
     //   c   scores with S <= 7 already zeroed (a score <= 7 can neither win nor beat a winner, so this changes nothing)
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
             expand_row(p[0], p[1], p[2], E[(PH + 6) % 7]);
         }
         uint32_t cA = 0, cB = 0;
-        if (y >= kEdge && y < H - kEdge) {   // rows outside the scan area score 0
+        if (y >= kEdge && y < Y1) {   // rows outside the scan area score 0
             cA = __builtin_bit_cast(uint32_t, keep_greater(score_pair<PH, 4>(E), seven)) & vA;
             cB = __builtin_bit_cast(uint32_t, keep_greater(score_pair<PH, 6>(E), seven)) & vB;
         }
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256) void k_fast_score(Geom g, const uint8_t* __res
         uint32_t o4 = 0;   // the four S' bytes of this thread's group in row yo
         if (yo >= y0 && yo < yend && lane >= 1 && lane <= kScoreGroups && nvalid > 0) {
             const uint32_t tT = (ymod == 0) ? 0u : 0xffffffffu;                                            // row above in the cell?
-            const uint32_t tB = ((ymod == cellH - 1) || yo == H - kEdge - 1) ? 0u : 0xffffffffu;          // row below?
+            const uint32_t tB = ((ymod == cellH - 1) || yo == Y1 - 1) ? 0u : 0xffffffffu;          // row below?
             const short2v mA = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_bit_cast(short2v, HcpA),
                                                                                      __builtin_bit_cast(short2v, H3ppA & tT)),
                                                          __builtin_bit_cast(short2v, H3A & tB));
@@ -501,8 +509,9 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
     int l = 0;
     while (l + 1 < g.nlevels && tlin >= g.tile_base[l + 1]) ++l;
     const int t = tlin - g.tile_base[l];
-    const int W = g.w[l], H = g.h[l], stride = g.stride[l];
-    const int tiles_x = (W - 2 * kEdge + kFsTW - 1) / kFsTW;
+    const int H = g.h[l], stride = g.stride[l];
+    const int X1 = g.sx1[l], Y1 = g.sy1[l];   // end of the scan area (Geom::sx1)
+    const int tiles_x = (X1 - kEdge + kFsTW - 1) / kFsTW;
     const int x0 = kEdge + (t % tiles_x) * kFsTW, y0 = kEdge + (t / tiles_x) * kFsTH;
     const int tid = threadIdx.x;
     const uint8_t* plane = pyr + (size_t)f * g.frame_bytes + g.off[l];   // bordered plane: pixel (x, y) at (y+16)*stride + x+16
@@ -522,7 +531,7 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
     if (tid == 0) { s_n = 0; s_nout = 0; }
     __syncthreads();
     // 1. compass test.  Thread = (column group gx = tid & 31, row phase tid >> 5): the 128 tile columns, rows -1 .. TH.
-    const int xlo = max(kEdge, x0 - 1), xhi = min(W - kEdge, x0 + kFsTW + 1);   // columns that need a score
+    const int xlo = max(kEdge, x0 - 1), xhi = min(X1, x0 + kFsTW + 1);   // columns that need a score
     {
         const int gx = (tid & 31) + 1;                                   // score-tile group: pixels x0 + 4 (gx - 1) ..
         const int xg = x0 - 4 + 4 * gx;
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
             if (xg + q >= xlo && xg + q < xhi) colmask |= 1u << q;
         for (int gy = tid >> 5; gy < kFsSH; gy += 8) {
             const int y = y0 + gy - 1;
-            if (y < kEdge || y >= H - kEdge || !colmask) continue;
+            if (y < kEdge || y >= Y1 || !colmask) continue;
             const uint32_t* row = s_img + (gy + 3) * LWd + gx;           // row y, columns xg-4 .. xg+7
             const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
             const uint32_t n1 = row[1 - 3 * LWd], s1 = row[1 + 3 * LWd];  // rows y-3 / y+3, columns xg .. xg+3
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
         const int side = tid >= kFsSH, gy = tid - side * kFsSH;
         const int sx = side ? kFsTW + 4 : 3;
         const int x = x0 - 4 + sx, y = y0 + gy - 1;
-        if (y >= kEdge && y < H - kEdge && x >= xlo && x < xhi) {
+        if (y >= kEdge && y < Y1 && x >= xlo && x < xhi) {
             const int c = (gy + 3) * kFsLW + sx + 4;
             const int v = img8[c];
             const int dn = img8[c - 3 * kFsLW] - v, ds = img8[c + 3 * kFsLW] - v, de = img8[c + 3] - v, dw = img8[c - 3] - v;
@@ -609,8 +618,8 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
         int xm = xr0 + lx, ym = yr0 + ly;                                  // position inside the cell
         while (xm >= cellW) xm -= cellW;
         while (ym >= cellH) ym -= cellH;
-        const bool L = xm != 0, R = !(xm == cellW - 1 || x0 + lx == W - kEdge - 1);
-        const bool T = ym != 0, B = !(ym == cellH - 1 || y0 + ly == H - kEdge - 1);
+        const bool L = xm != 0, R = !(xm == cellW - 1 || x0 + lx == X1 - 1);
+        const bool T = ym != 0, B = !(ym == cellH - 1 || y0 + ly == Y1 - 1);
         int m = 0;
         if (L) m = max(m, (int)sc8[i - 1]);
         if (R) m = max(m, (int)sc8[i + 1]);
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(256) void k_fast_score_sparse(Geom g, const uint8_t
             if (L) m = max(m, (int)sc8[i + kFsSW - 1]);
             if (R) m = max(m, (int)sc8[i + kFsSW + 1]);
         }
-        if (c > m && x0 + lx < W - kEdge && y0 + ly < H - kEdge) {
+        if (c > m && x0 + lx < X1 && y0 + ly < Y1) {
             const int slot = atomicAdd(&s_nout, 1);
             if (slot < kFsListCap) ent[slot] = make_uint2(((uint32_t)(y0 + ly) << 12) | (uint32_t)(x0 + lx), (uint32_t)c);
         }
@@ -998,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_cell_collect_w(Geom g, const CellGeoRec
     auto defer = [&]() {
         if (lane == 0) {
             *tot_out = kCellDeferred;
-            defer_q[1 + atomicAdd(&defer_q[0], 1)] = (f << 12) | cell;
+            defer_q[1 + atomicAdd(&defer_q[0], 1)] = (f << 16) | cell;
         }
     };
     if (nl == 0) {
@@ -1162,7 +1171,7 @@ __device__ void cell_collect_wg(const Geom& g, const int f, const int cell, cons
     const int lcap = g.lcap[l];
     typename E::T* out = cell_ent + (size_t)f * g.lcell_off[g.nlevels] + g.lcell_off[l] + (size_t)(cell - g.cell_base[l]) * lcap;
     // the candidate lists whose tiles meet the cell: columns tc0..tc1 x rows tr0..tr1 of the level's list grid
-    const int ltx = (g.w[l] - 2 * kEdge + g.lst_tw - 1) / g.lst_tw;
+    const int ltx = (g.sx1[l] - kEdge + g.lst_tw - 1) / g.lst_tw;
     const int tc0 = (xa - kEdge) / g.lst_tw, tc1 = (xb - 1 - kEdge) / g.lst_tw;
     const int tr0 = (ya - kEdge) / g.lst_th, tr1 = (yb - 1 - kEdge) / g.lst_th;
     const int ntc = tc1 - tc0 + 1;
@@ -1288,7 +1297,7 @@ __device__ void cell_collect_wg(const Geom& g, const int f, const int cell, cons
     for (int i = threadIdx.x; i < n; i += 256) emit(i, keys[i]);
 }
 
-// the deferred cells of a batch (defer_q = {count, (frame << 12 | cell) ...}, filled by k_cell_collect_w), a fixed small grid
+// the deferred cells of a batch (defer_q = {count, (frame << 16 | cell) ...}, filled by k_cell_collect_w), a fixed small grid
 template <bool HARRIS>
 __global__ __launch_bounds__(256) void k_cell_collect_big(Geom g, const int* __restrict__ defer_q, const uint2* __restrict__ lst_ent,
                                                            const int* __restrict__ lst_cnt, const uint8_t* __restrict__ pyr,
@@ -1297,29 +1306,34 @@ __global__ __launch_bounds__(256) void k_cell_collect_big(Geom g, const int* __r
     const int nq = defer_q[0];
     for (int it = (int)blockIdx.x; it < nq; it += (int)gridDim.x) {
         const int v = defer_q[1 + it];
-        cell_collect_wg<HARRIS>(g, v >> 12, v & 0xfff, lst_ent, lst_cnt, pyr, cell_ent, cell_scr, cell_total, overflow);
+        cell_collect_wg<HARRIS>(g, v >> 16, v & 0xffff, lst_ent, lst_cnt, pyr, cell_ent, cell_scr, cell_total, overflow);
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Quota replay of one level by one wave: lane c + 64 k owns cell c + 64 k (<= 256 cells).  The reference's loop
+// Quota replay of one level by one wave: lane c + 64 k owns cell c + 64 k (<= kQuotaCells = 1024 cells).  The reference's loop
 // (:640-679) is a fixed-point over passes whose body does not depend on the cell order, so a pass is one wave step.
 // n_ret / c_off receive the per-cell retain counts and their exclusive prefix; returns their sum.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, int* n_ret, int* c_off) {
+// skip / gcols: cells of the last column (bit 0) / row (bit 1) that the reference's loops never visit (Geom::skip) keep
+// nTotal = nToRetain = 0 and bNoMore = false - the redistribution passes close them, not the first pass.
+constexpr int kQuotaPerLane = 16, kQuotaCells = 64 * kQuotaPerLane;
+__device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, int* n_ret, int* c_off, int skip, int gcols) {
     const int lane = threadIdx.x & 63;
-    int t[4], r[4];
-    bool nm[4];
+    int t[kQuotaPerLane], r[kQuotaPerLane];
+    bool nm[kQuotaPerLane];
     int dist = 0, cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kQuotaPerLane; ++k) {
         const int c = lane + 64 * k;
         t[k] = c < nCells ? tot[c] : 0;
         r[k] = 0;
         nm[k] = true;
         if (c < nCells) {
-            if (t[k] > nfc) { r[k] = nfc; nm[k] = false; }
+            const bool skipped = skip && (((skip & 1) && c % gcols == gcols - 1) || ((skip & 2) && c >= nCells - gcols));
+            if (skipped) { t[k] = 0; nm[k] = false; }
+            else if (t[k] > nfc) { r[k] = nfc; nm[k] = false; }
             else { r[k] = t[k]; dist += nfc - t[k]; ++cnt; }
         }
     }
@@ -1328,7 +1342,7 @@ __device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, 
         const int nNew = nfc + (int)ceilf((float)dist / (float)(nCells - cnt));
         int d2 = 0, c2 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < kQuotaPerLane; ++k)
             if (!nm[k]) {
                 if (t[k] > nNew) { r[k] = nNew; }
                 else { r[k] = t[k]; d2 += nNew - t[k]; nm[k] = true; ++c2; }
@@ -1339,7 +1353,8 @@ __device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, 
     }
     int base = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < kQuotaPerLane; ++k) {
+        if (64 * k >= nCells) break;   // (uniform: most levels have fewer than 64 cells)
         const int c = lane + 64 * k;
         int incl = r[k];
         for (int d = 1; d < 64; d <<= 1) {
@@ -1358,12 +1373,12 @@ __device__ __forceinline__ int level_quota(const int* tot, int nCells, int nfc, 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_quota(Geom g, const int* __restrict__ cell_total, int2* __restrict__ cell_plan,
                                               int* __restrict__ defer_q) {
-    __shared__ int n_ret[256], c_off[256];
+    __shared__ int n_ret[kQuotaCells], c_off[kQuotaCells];
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) defer_q[0] = 0;   // (k_cell_collect_big is done: next batch)
     SE2_FRAME_GRID(f, l);
     const int ncells_frame = g.cell_base[g.nlevels];
     const int nc = g.gcols[l] * g.grows[l];
-    level_quota(cell_total + (size_t)f * ncells_frame + g.cell_base[l], nc, g.nfc[l], n_ret, c_off);
+    level_quota(cell_total + (size_t)f * ncells_frame + g.cell_base[l], nc, g.nfc[l], n_ret, c_off, g.skip[l], g.gcols[l]);
     wave_fence();
     int2* out = cell_plan + (size_t)f * ncells_frame + g.cell_base[l];
     for (int c = threadIdx.x; c < nc; c += 64) out[c] = make_int2(n_ret[c], c_off[c]);
@@ -1424,15 +1439,21 @@ __global__ __launch_bounds__(256) void k_level_select(Geom g, const typename Ent
                                                        int* __restrict__ counts, int cap, int* __restrict__ overflow) {
     using E = Ent<HARRIS>;
     using T = typename E::T;
-    __shared__ T lst[kLevelCap];
-    __shared__ uint16_t s_lp[kLevelCap], s_rp[kLevelCap];
+    // dynamic LDS: the level's list and the two position lists of its introselect, g.level_cap entries each (the largest
+    // quota + 2 cells of any level bounds what the cells can hand over; a few hundred entries with the usual parameters)
+    extern __shared__ __attribute__((aligned(16))) unsigned char level_lds[];
+    const int kLevelCap = g.level_cap;
+    T* lst = reinterpret_cast<T*>(level_lds);
+    uint16_t* s_lp = reinterpret_cast<uint16_t*>(lst + kLevelCap);
+    uint16_t* s_rp = s_lp + kLevelCap;
     __shared__ int s_kept[kMaxLevels];
     SE2_FRAME_GRID(f, l);
     const int ncells_frame = g.cell_base[g.nlevels];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int2* plan_f = cell_plan + (size_t)f * ncells_frame;
     if (threadIdx.x <= (unsigned)l) {                      // entries of a level before its level-wide retain: last cell's place + count
-        const int2 last = plan_f[g.cell_base[threadIdx.x + 1] - 1];
+        const bool cells = g.cell_base[threadIdx.x + 1] > g.cell_base[threadIdx.x];   // (a level can have none: orb_configure)
+        const int2 last = cells ? plan_f[g.cell_base[threadIdx.x + 1] - 1] : make_int2(0, 0);
         int o = last.x + last.y;
         if (o > kLevelCap) { atomicOr(overflow, 4); o = kLevelCap; }
         s_kept[threadIdx.x] = o;
@@ -1886,20 +1907,48 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         g.quota[l] = h->quota[l];
         g.gcols[l] = (int)std::sqrt((float)g.quota[l] / (5 * imageRatio));
         g.grows[l] = (int)(imageRatio * g.gcols[l]);
-        SE2_REQUIRE(g.gcols[l] >= 1 && g.grows[l] >= 1 && g.gcols[l] * g.grows[l] <= 256, SE2GPU_ERR_INVALID,
-                    "level %d: unsupported cell grid %dx%d", l, g.gcols[l], g.grows[l]);
+        g.scale[l] = h->mvScale[l];
+        g.patch[l] = (float)(int)(kPatch * h->mvScale[l]);
+        if (g.gcols[l] < 1 || g.grows[l] < 1) {
+            // A level whose quota is too small for one cell (levelCols = sqrt(quota / (5 ratio)) = 0, or levelRows = ratio *
+            // levelCols = 0 on a portrait image): the reference's loops over levelRows x levelCols then visit nothing and the
+            // level contributes no key point (ORBextractor.cpp:541-716; e.g. the top level of 150 features over 8 levels).
+            // Here: no cells, an empty scan area (so no score tiles and no candidate lists either).
+            g.gcols[l] = g.grows[l] = 0;
+            g.cellW[l] = g.cellH[l] = 1;
+            g.nfc[l] = 0;
+            g.cell_base[l + 1] = g.cell_base[l];
+            g.sx1[l] = g.sy1[l] = kEdge;
+            g.skip[l] = 0;
+            continue;
+        }
+        SE2_REQUIRE(g.gcols[l] * g.grows[l] <= kQuotaCells, SE2GPU_ERR_INVALID, "level %d: unsupported cell grid %dx%d (more than 1024 cells)", l,
+                    g.gcols[l], g.grows[l]);
         const int W = g.w[l] - 2 * kEdge, H = g.h[l] - 2 * kEdge;
         g.cellW[l] = (int)std::ceil((float)W / g.gcols[l]);
         g.cellH[l] = (int)std::ceil((float)H / g.grows[l]);
         g.nfc[l] = (int)std::ceil((float)g.quota[l] / (g.gcols[l] * g.grows[l]));
         g.cell_base[l + 1] = g.cell_base[l] + g.gcols[l] * g.grows[l];
-        g.scale[l] = h->mvScale[l];
-        g.patch[l] = (float)(int)(kPatch * h->mvScale[l]);
-        // the cells must tile the scan area the way the reference's windows do (no empty last row / column)
-        SE2_REQUIRE(g.cellW[l] * (g.gcols[l] - 1) < W && g.cellH[l] * (g.grows[l] - 1) < H, SE2GPU_ERR_INVALID,
-                    "level %d: degenerate cell grid", l);
+        // Where the last cell column / row starts: inside the scan area (the usual case); at or up to 13 px beyond its end
+        // (its own window is empty or not visited, the one before it scans into the reflect frame: Geom::sx1, skip); further
+        // out the reference itself raises (cv::Mat::colRange / rowRange of a cell window outside the level, ORBextractor.cpp:608)
+        const int ex = g.cellW[l] * (g.gcols[l] - 1), ey = g.cellH[l] * (g.grows[l] - 1);
+        SE2_REQUIRE(ex <= W + 13 && ey <= H + 13, SE2GPU_ERR_INVALID,
+                    "level %d: a cell window of the %dx%d grid lies outside the %dx%d level (the reference raises on this geometry)",
+                    l, g.gcols[l], g.grows[l], g.w[l], g.h[l]);
+        g.sx1[l] = kEdge + std::max(W, ex);
+        g.sy1[l] = kEdge + std::max(H, ey);
+        g.skip[l] = (ex >= W + 6 ? 1 : 0) | (ey >= H + 6 ? 2 : 0);
     }
     g.frame_bytes = (off + 255u) & ~255u;
+    {   // k_level_select's list: every redistribution pass hands the cells at most quota + cells entries in total
+        int lc = 64;
+        for (int l = 0; l < L; ++l) lc = std::max(lc, g.quota[l] + 2 * g.gcols[l] * g.grows[l]);
+        lc = (lc + 63) & ~63;
+        SE2_REQUIRE((size_t)lc * ((g.harris ? 8 : 4) + 4) <= 64 * 1024 && lc < 65536, SE2GPU_ERR_INVALID,
+                    "%d features on one pyramid level exceed the level list (at most %d)", lc, g.harris ? 5440 : 8128);
+        g.level_cap = lc;
+    }
     // per-cell list capacity: in-cell maxima are never adjacent, so ceil(cellW / 2) * ceil(cellH / 2) bounds a cell's corners
     g.lcell_off[0] = 0;
     g.lscr_off[0] = 0;
@@ -1919,7 +1968,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     h->sparse_tile_base[0] = 0;
     h->blur_tile_base[0] = 0;
     for (int l = 0; l < L; ++l) {
-        const int sw = g.w[l] - 2 * kEdge, sh = g.h[l] - 2 * kEdge;
+        const int sw = g.sx1[l] - kEdge, sh = g.sy1[l] - kEdge;   // the scan area (Geom::sx1)
         h->score_tile_base[l + 1] = h->score_tile_base[l] + ((sw + 4 * kScoreGroups - 1) / (4 * kScoreGroups)) * ((sh + 4 * kScoreRows - 1) / (4 * kScoreRows));
         h->sparse_tile_base[l + 1] = h->sparse_tile_base[l] + ((sw + kFsTW - 1) / kFsTW) * ((sh + kFsTH - 1) / kFsTH);
         if (l == 0) h->scan_pixels = 0;
@@ -2012,7 +2061,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
                     const int xa = kEdge + cj * g.cellW[l], ya = kEdge + ci * g.cellH[l];
                     const int xb = (cj == g.gcols[l] - 1) ? g.w[l] - kEdge : xa + g.cellW[l];
                     const int yb = (ci == g.grows[l] - 1) ? g.h[l] - kEdge : ya + g.cellH[l];
-                    const int ltx = (g.w[l] - 2 * kEdge + tw - 1) / tw;
+                    const int ltx = (g.sx1[l] - kEdge + tw - 1) / tw;
                     const int tc0 = (xa - kEdge) / tw, tc1 = (xb - 1 - kEdge) / tw, tr0 = (ya - kEdge) / th, tr1 = (yb - 1 - kEdge) / th;
                     const int ntc = tc1 - tc0 + 1;
                     const int nl = (xb > xa && yb > ya) ? ntc * (tr1 - tr0 + 1) : 0;
@@ -2032,18 +2081,19 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
                     geo[at + 1] = b;
                 }
         }
+        if (geo.empty()) geo.resize(4);   // (no level has a cell)
         SE2_CHECK(h->cell_geo.upload(geo, h->stream));
     }
     // buffers
     const size_t B = (size_t)h->max_batch;
-    SE2_CHECK(h->pyr.reserve(B * g.frame_bytes));
-    SE2_CHECK(h->blur.reserve(B * g.frame_bytes));
-    SE2_CHECK(h->lst_cnt.reserve(B * (size_t)std::max(h->dense_lst_base[L], h->sparse_lst_base[L])));
-    SE2_CHECK(h->lst_ent.reserve(B * std::max((size_t)h->dense_lst_base[L] * kStripCap, (size_t)h->sparse_lst_base[L] * kFsListCap)));
-    SE2_CHECK(h->cell_keys.reserve(B * (size_t)g.lcell_off[L] * (g.harris ? 2 : 1)));   // uint32 entries, uint64 with HARRIS_SCORE
+    SE2_CHECK(h->pyr.reserve(B * g.frame_bytes + 256));    // (+ slack: a patch copy of a key point in the reflect frame may read a few bytes past a row)
+    SE2_CHECK(h->blur.reserve(B * g.frame_bytes + 256));
+    SE2_CHECK(h->lst_cnt.reserve(std::max<size_t>(1, B * (size_t)std::max(h->dense_lst_base[L], h->sparse_lst_base[L]))));
+    SE2_CHECK(h->lst_ent.reserve(std::max<size_t>(1, B * std::max((size_t)h->dense_lst_base[L] * kStripCap, (size_t)h->sparse_lst_base[L] * kFsListCap))));
+    SE2_CHECK(h->cell_keys.reserve(std::max<size_t>(64, B * (size_t)g.lcell_off[L] * (g.harris ? 2 : 1))));   // uint32 entries, uint64 with HARRIS_SCORE
     SE2_CHECK(h->cell_scr.reserve(std::max<size_t>(1, B * (size_t)g.lscr_off[L])));
-    SE2_CHECK(h->cell_total.reserve(B * g.cell_base[L]));
-    SE2_CHECK(h->cell_plan.reserve(B * g.cell_base[L]));
+    SE2_CHECK(h->cell_total.reserve(std::max<size_t>(1, B * g.cell_base[L])));
+    SE2_CHECK(h->cell_plan.reserve(std::max<size_t>(1, B * g.cell_base[L])));
     SE2_CHECK(h->defer_q.reserve(1 + B * g.cell_base[L]));
     SE2_HIP(hipMemsetAsync(h->defer_q.p, 0, sizeof(int), h->stream));
     SE2_CHECK(h->overflow.reserve(1));
@@ -2168,24 +2218,28 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
     if (g.harris) {
         using T = Ent<true>::T;
         T* ent = reinterpret_cast<T*>(h->cell_keys.p);
-        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect_w<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, h->lst_ent.p,
-                   h->lst_cnt.p, h->pyr.p, ent, h->cell_total.p, h->defer_q.p);
+        if (ncell)
+            SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect_w<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, h->lst_ent.p,
+                       h->lst_cnt.p, h->pyr.p, ent, h->cell_total.p, h->defer_q.p);
         SE2_LAUNCH(h->prof, st, "k_cell_collect_big", k_cell_collect_big<true>, dim3(kBigGrid), dim3(256), 0, g, h->defer_q.p,
                    h->lst_ent.p, h->lst_cnt.p, h->pyr.p, ent, h->cell_scr.p, h->cell_total.p, h->overflow.p);
         SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p, h->defer_q.p);
-        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, ent,
-                   h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
-        SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<true>, dim3(F8, L), dim3(256), 0, g, ent, h->cell_plan.p,
+        if (ncell)
+            SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, ent,
+                       h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<true>, dim3(F8, L), dim3(256), (size_t)g.level_cap * 12, g, ent, h->cell_plan.p,
                    h->kp_list.p, d_counts, cap, h->overflow.p);
     } else {
-        SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect_w<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, h->lst_ent.p,
-                   h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_total.p, h->defer_q.p);
+        if (ncell)   // (no level may have a cell: a handful of features over many levels, orb_configure)
+            SE2_LAUNCH(h->prof, st, "k_cell_collect", k_cell_collect_w<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, h->lst_ent.p,
+                       h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_total.p, h->defer_q.p);
         SE2_LAUNCH(h->prof, st, "k_cell_collect_big", k_cell_collect_big<false>, dim3(kBigGrid), dim3(256), 0, g, h->defer_q.p,
                    h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->overflow.p);
         SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p, h->defer_q.p);
-        SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo,
-                   h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
-        SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<false>, dim3(F8, L), dim3(256), 0, g, h->cell_keys.p,
+        if (ncell)
+            SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo,
+                       h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
+        SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<false>, dim3(F8, L), dim3(256), (size_t)g.level_cap * 8, g, h->cell_keys.p,
                    h->cell_plan.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     }
     SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 3) / 4), dim3(256), 0, g, h->pyr.p,
@@ -2227,6 +2281,7 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
     se2gpu_orb* h = new se2gpu_orb;
     h->params = *params;
     if (h->params.max_rows <= 0 || h->params.max_cols <= 0) { h->params.max_rows = 480; h->params.max_cols = 640; }
+    SE2_REQUIRE(params->max_batch < 32768, SE2GPU_ERR_INVALID, "max_batch %d: at most 32767 frames per batch", params->max_batch);
     h->max_batch = std::max(1, params->max_batch);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;

@@ -331,3 +331,70 @@ def test_device_nth_element_equals_libstdcxx(oracle):
             for glob in ((0, 1) if n <= 1024 else (1,)):
                 assert np.array_equal(dev(e, nth, glob), want), ("killer", n, nth, fold, glob)
     assert oracle.nth_heap_selects() - h0 >= 4 and ncase > 1000
+
+
+@pytest.mark.parametrize("rows,cols,nf,nl", [(142, 229, 1327, 3), (395, 182, 2135, 3), (506, 174, 1606, 5), (201, 423, 2170, 2),
+                                             (143, 678, 878, 2), (679, 162, 400, 1), (198, 193, 2549, 2), (161, 188, 2148, 2),
+                                             (137, 184, 2162, 2), (176, 671, 1623, 5)])
+def test_cell_grids_whose_last_column_or_row_starts_beyond_the_scan_area(oracle, synth, rows, cols, nf, nl):
+    """cellW = ceil(W / levelCols) can put the last cell column at or beyond the end of the scan area: its own window is then
+    empty (no key points, ORBextractor.cpp:598-603) or not even visited (hX <= 0: `continue`, which also changes the quota
+    redistribution), and the column before it scans up to 13 px into the level's reflect frame - key points with x > w - 16.
+    Same for rows.  About one random (size, nfeatures, levels) combination in five is like that; rounds 1-4 refused them
+    ("degenerate cell grid") although the reference runs them.  Both score kernels, FAST and Harris responses, batches."""
+    from se2lam_amd.orb import ORBextractor
+    tex = synth.texture()
+    img = np.ascontiguousarray(tex[33:33 + rows, 61:61 + cols])
+    noise = np.random.default_rng(rows * cols).integers(0, 256, (rows, cols)).astype(np.uint8)
+    for st in (1, 0):
+        p = oracle.orb_params(nfeatures=nf, nlevels=nl, score_type=st)
+        ex = ORBextractor(nfeatures=nf, nlevels=nl, scoreType=st, max_rows=rows, max_cols=cols, max_batch=2)
+        for im in (img, noise):
+            ko, do = oracle.orb_extract(im, p, cap=4 * nf + 64)
+            k, d = ex(im)
+            assert len(ko) > 0 and np.array_equal(k, ko) and np.array_equal(d, do), (st, len(k), len(ko))
+        out = ex.extract_batch(np.stack([img, noise]))
+        ko, do = oracle.orb_extract(noise, p, cap=4 * nf + 64)
+        assert np.array_equal(out[1][0], ko) and np.array_equal(out[1][1], do)
+
+
+def test_both_score_kernels_on_a_grid_with_an_empty_last_column(oracle, synth, monkeypatch):
+    rows, cols, nf, nl = 395, 182, 2135, 3
+    img = np.ascontiguousarray(synth.texture()[100:100 + rows, 200:200 + cols])
+    ko, do = oracle.orb_extract(img, oracle.orb_params(nfeatures=nf, nlevels=nl), cap=4 * nf + 64)
+    sc = 1.2 ** ko["octave"].astype(np.float64)
+    assert (ko["x"] / sc > np.round(cols / sc) - 16 + 0.5).any()               # key points inside the reflect frame
+    from se2lam_amd.orb import ORBextractor
+    for mode in ("dense", "sparse"):
+        monkeypatch.setenv("SE2GPU_ORB_SCORE", mode)
+        ex = ORBextractor(nfeatures=nf, nlevels=nl, max_rows=rows, max_cols=cols)
+        k, d = ex(img)
+        assert ex.score_kernel()[0] == mode and np.array_equal(k, ko) and np.array_equal(d, do), mode
+
+
+@pytest.mark.parametrize("rows,cols,nf,nl", [(136, 899, 150, 7), (396, 882, 150, 7), (480, 640, 150, 8), (500, 300, 100, 6), (480, 640, 20, 8)])
+def test_levels_whose_quota_is_too_small_for_one_cell(oracle, synth, rows, cols, nf, nl):
+    """levelCols = (int)sqrt(quota / (5 ratio)) is 0 for the top levels of a small feature budget (150 features over 8 levels:
+    the reference's loops over levelRows x levelCols visit nothing, ORBextractor.cpp:541-716) - such a level contributes no key
+    point, the others are unaffected.  Rounds 1-4 refused the whole extractor ("unsupported cell grid 0x0")."""
+    from se2lam_amd.orb import ORBextractor
+    img = np.ascontiguousarray(synth.texture()[10:10 + rows, 20:20 + cols])
+    p = oracle.orb_params(nfeatures=nf, nlevels=nl)
+    ko, do = oracle.orb_extract(img, p)
+    ex = ORBextractor(nfeatures=nf, nlevels=nl, max_rows=rows, max_cols=cols, max_batch=3)
+    k, d = ex(img)
+    assert np.array_equal(k, ko) and np.array_equal(d, do), (len(k), len(ko))
+    assert (np.bincount(ko["octave"], minlength=nl) == 0).any() or nf == 150 and (rows, cols) == (480, 640)
+    out = ex.extract_batch(np.stack([img, img[::-1].copy(), img]))
+    assert np.array_equal(out[2][0], ko) and np.array_equal(out[2][1], do)
+
+
+@pytest.mark.parametrize("rows,cols,nf,nl", [(653, 1005, 5135, 1), (501, 715, 2786, 2), (884, 253, 3225, 1)])
+def test_cell_grids_of_more_than_256_cells(oracle, synth, rows, cols, nf, nl):
+    """many features on few levels: 950, 266 and 611 cells at level 0 (rounds 1-4: "unsupported cell grid", limit 256; now 1024)"""
+    from se2lam_amd.orb import ORBextractor
+    img = np.ascontiguousarray(synth.texture()[0:rows, 0:cols])
+    p = oracle.orb_params(nfeatures=nf, nlevels=nl)
+    ko, do = oracle.orb_extract(img, p, cap=16384)
+    k, d = ORBextractor(nfeatures=nf, nlevels=nl, max_rows=rows, max_cols=cols)(img)
+    assert len(ko) > 1000 and np.array_equal(k, ko) and np.array_equal(d, do)
