@@ -1285,6 +1285,45 @@ def test_hip_images_to_matches_equal_the_compiled_reference(synth, ref_feats):
 
 
 @pytest.mark.gpu
+def test_hip_extractor_refuses_exactly_the_geometries_on_which_the_reference_raises(synth):
+    """A cell window outside its pyramid level makes the reference raise (cv::Mat::colRange / rowRange, ORBextractor.cpp:608):
+    with many features on a wide, low image the last-but-one cell column ends more than 13 px beyond the scan area.  The library
+    refuses those geometries (SE2GPU_ERR_INVALID at the first call) and runs every other one: 120 random (size, features,
+    levels, scale) combinations, the two sides must fail on the same ones (rounds 1-4: the library refused 16 % the reference
+    runs, and returned key points on the 3 % where it raises)."""
+    from se2lam_amd import capi, orb
+    from oracle import oracle
+    rng = np.random.default_rng(2026)
+    tex = synth.texture()
+    n_raise = n_run = 0
+    for _ in range(120):
+        h, w = int(rng.integers(120, 700)), int(rng.integers(160, 900))
+        nl = int(rng.integers(1, 9)); scale = float(rng.choice([1.1, 1.2, 1.3, 1.5]))
+        nf = int(rng.integers(50, 3000))
+        if rng.random() < 0.5:          # wide and low with many features: where the reference's rectangles leave the level
+            h, nf = int(rng.integers(120, 220)), int(rng.integers(1500, 3000))
+        while min(h, w) / scale ** (nl - 1) < 64:
+            nl -= 1
+        img = np.ascontiguousarray(tex[:h, :w])
+        try:
+            kr, dr = ref.orb_extract(img, oracle.orb_params(nf, scale, nl, 20, 1), cap=16384)
+            raised = False
+        except ValueError:
+            raised = True
+        try:
+            k, d = orb.ORBextractor(nf, scale, nl, 1, 20, max_rows=h, max_cols=w)(img)
+            refused = False
+        except capi.Se2GpuError as e:
+            assert "the reference raises" in str(e), e
+            refused = True
+        assert raised == refused, (h, w, nf, scale, nl, raised, refused)
+        if not raised:
+            assert np.array_equal(k, kr) and np.array_equal(d, dr), (h, w, nf, scale, nl)
+        n_raise += raised; n_run += not raised
+    assert n_raise >= 5 and n_run >= 60, (n_raise, n_run)
+
+
+@pytest.mark.gpu
 def test_hip_matchers_equal_the_compiled_reference(ref_feats):
     from se2lam_amd.matcher import ORBmatcher
     mt = ORBmatcher(0.9)
