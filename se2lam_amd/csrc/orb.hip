@@ -1529,44 +1529,85 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fast
     return a;
 }
 
+constexpr int kOriPerWave = 4;   // key points per wave of k_orientation
 __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __restrict__ pyr,
                                                       const int4* __restrict__ kp_list, const int* __restrict__ counts,
                                                       int cap, float* __restrict__ angles, const int4* __restrict__ wtab) {
-    // one wave per key point: lane = (row offset v = 0..15, column octet c = 0..3); a lane reads 8 bytes of row +v and
-    // of row -v with two (unaligned) 32-bit loads each - 749 disc pixels in 4 load instructions instead of 47 byte
-    // loads per lane.  Integer moments: the summation order is irrelevant.
+    // lane = (row offset v = 0..15, column octet c = 0..3), c fastest; a lane reads 8 bytes of row +v and of row -v with two
+    // (unaligned) 32-bit loads each - the 749 disc pixels of a key point in 4 load instructions instead of 47 byte loads per
+    // lane.  Integer moments: the summation order is irrelevant.
+    // A wave takes FOUR key points (round 5): the kernel is bound by the latency of its dependent loads (record -> level
+    // geometry -> pixels; SQ counters: a wave is parked 77 % of its life) at 32 waves per CU, so one key point per wave meant
+    // 32 rounds of one latency chain each.  Four records and sixteen pixel loads per lane are in flight together, and the
+    // eight moments of the four key points are summed over the lanes by a transposing butterfly (11 shuffles instead of 48).
     SE2_FRAME_GRID(f, bx);
-    const int k = __builtin_amdgcn_readfirstlane(bx * 4 + (int)(threadIdx.x / 64));   // the wave's key point: its record is a scalar load
+    const int kbase = __builtin_amdgcn_readfirstlane((bx * 4 + (int)(threadIdx.x / 64)) * kOriPerWave);
     const int lane = threadIdx.x & 63;
-    const int v = lane & 15, c = lane >> 4;
+    // (column octet fastest: the four lanes of a disc row are neighbours and their 8-byte pieces one 32-byte run - the texture
+    // path then sees 16 rows per load instruction instead of 64 scattered dwords)
+    const int v = lane >> 2, c = lane & 3;
     const int n = counts[f];
-    int m01 = 0, m10 = 0;
-    if (k < n) {
-        const int4 kp = kp_list[(size_t)f * cap + k];
-        const int stride = g.stride[kp.x];
-        const uint8_t* center = pyr + pix(g, f, kp.x, kp.z, kp.y);
-        const int u0 = -16 + 8 * c;
-        const uint8_t* pp = center + u0 + v * stride;
-        const uint8_t* pm = center + u0 - v * stride;
-        const uint32_t p0 = *reinterpret_cast<const uint32_t*>(pp), p1 = *reinterpret_cast<const uint32_t*>(pp + 4);
-        uint32_t q0 = *reinterpret_cast<const uint32_t*>(pm), q1 = *reinterpret_cast<const uint32_t*>(pm + 4);
-        if (v == 0) q0 = q1 = 0;   // the centre row counts once
+    if (kbase >= n) return;
+    const int4 w = wtab[lane];
+    uint32_t P0[kOriPerWave], P1[kOriPerWave], Q0[kOriPerWave], Q1[kOriPerWave];
+#pragma unroll
+    for (int i = 0; i < kOriPerWave; ++i) {
+        P0[i] = P1[i] = Q0[i] = Q1[i] = 0;
+        if (kbase + i < n) {   // (uniform; the records are scalar loads)
+            const int4 kp = kp_list[(size_t)f * cap + kbase + i];
+            const int stride = g.stride[kp.x];
+            const uint8_t* center = pyr + pix(g, f, kp.x, kp.z, kp.y);
+            const int u0 = -16 + 8 * c;
+            const uint8_t* pp = center + u0 + v * stride;
+            const uint8_t* pm = center + u0 - v * stride;
+            P0[i] = *reinterpret_cast<const uint32_t*>(pp);
+            P1[i] = *reinterpret_cast<const uint32_t*>(pp + 4);
+            Q0[i] = *reinterpret_cast<const uint32_t*>(pm);
+            Q1[i] = *reinterpret_cast<const uint32_t*>(pm + 4);
+        }
+    }
+    int val[2 * kOriPerWave];   // {m10, m01} of the four key points: this lane's share
+#pragma unroll
+    for (int i = 0; i < kOriPerWave; ++i) {
+        const uint32_t p0 = P0[i], p1 = P1[i];
+        const uint32_t q0 = v == 0 ? 0u : Q0[i], q1 = v == 0 ? 0u : Q1[i];   // the centre row counts once
         // m10 = sum u (I(u, v) + I(u, -v)), m01 = v sum (I(u, v) - I(u, -v)) over the disc row: with the byte weights
         // {u + 16} and {1} of the lane's eight columns (zero outside the disc) these are eight v_dot4_u32_u8
-        const int4 w = wtab[lane];
         const uint32_t su = __builtin_amdgcn_udot4(p0, (uint32_t)w.x, __builtin_amdgcn_udot4(p1, (uint32_t)w.y,
                             __builtin_amdgcn_udot4(q0, (uint32_t)w.x, __builtin_amdgcn_udot4(q1, (uint32_t)w.y, 0u, false), false), false), false);
         const uint32_t sp = __builtin_amdgcn_udot4(p0, (uint32_t)w.z, __builtin_amdgcn_udot4(p1, (uint32_t)w.w, 0u, false), false);
         const uint32_t sm = __builtin_amdgcn_udot4(q0, (uint32_t)w.z, __builtin_amdgcn_udot4(q1, (uint32_t)w.w, 0u, false), false);
-        m10 = (int)su - 16 * (int)(sp + sm);
-        m01 = v * ((int)sp - (int)sm);
+        val[2 * i] = (int)su - 16 * (int)(sp + sm);
+        val[2 * i + 1] = v * ((int)sp - (int)sm);
+    }
+    // transposing butterfly: a step with lane mask M halves the values a lane carries - the lane keeps the half its bit of M
+    // selects, sends the other half to its partner and adds what the partner sends.  After M = 32, 16, 8 a lane holds the sum
+    // over 8 lanes of value number 4 b32 + 2 b16 + b8; three plain steps finish the sum over the remaining lanes.
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool hi = lane & 32;
+        const int keep = hi ? val[j + 4] : val[j], send = hi ? val[j] : val[j + 4];
+        val[j] = keep + __shfl_xor(send, 32);
     }
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        m01 += __shfl_xor(m01, m);
-        m10 += __shfl_xor(m10, m);
+    for (int j = 0; j < 2; ++j) {
+        const bool hi = lane & 16;
+        const int keep = hi ? val[j + 2] : val[j], send = hi ? val[j] : val[j + 2];
+        val[j] = keep + __shfl_xor(send, 16);
     }
-    if (k < n && lane == 0) angles[(size_t)f * cap + k] = fast_atan2_deg((float)m01, (float)m10);
+    {
+        const bool hi = lane & 8;
+        const int keep = hi ? val[1] : val[0], send = hi ? val[0] : val[1];
+        val[0] = keep + __shfl_xor(send, 8);
+    }
+    int tot = val[0];
+    tot += __shfl_xor(tot, 4);
+    tot += __shfl_xor(tot, 2);
+    tot += __shfl_xor(tot, 1);
+    // lanes with bit 8 clear hold m10 of key point i = 2 b32 + b16, their partners (bit 8 set) its m01
+    const int other = __shfl_xor(tot, 8);
+    const int i = ((lane >> 5) & 1) * 2 + ((lane >> 4) & 1);
+    if ((lane & 15) == 0 && kbase + i < n) angles[(size_t)f * cap + kbase + i] = fast_atan2_deg((float)other, (float)tot);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2038,7 +2079,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     // bytes {u + 16 | 0} (x, y) and {1 | 0} (z, w), zero outside the disc row (|u| > umax[v])
     h->orient_off = tabs.size();
     for (int lane = 0; lane < 64; ++lane) {
-        const int v = lane & 15, c = lane >> 4, d = h->umax[v], u0 = -16 + 8 * c;
+        const int v = lane >> 2, c = lane & 3, d = h->umax[v], u0 = -16 + 8 * c;
         uint32_t w[4] = {0, 0, 0, 0};
         for (int i = 0; i < 8; ++i) {
             const int u = u0 + i;
@@ -2242,7 +2283,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, st, "k_level_select", k_level_select<false>, dim3(F8, L), dim3(256), (size_t)g.level_cap * 8, g, h->cell_keys.p,
                    h->cell_plan.p, h->kp_list.p, d_counts, cap, h->overflow.p);
     }
-    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 3) / 4), dim3(256), 0, g, h->pyr.p,
+    SE2_LAUNCH(h->prof, st, "k_orientation", k_orientation, dim3(F8, (cap + 4 * kOriPerWave - 1) / (4 * kOriPerWave)), dim3(256), 0, g, h->pyr.p,
                h->kp_list.p, d_counts, cap, h->angles.p, h->tabs.p + h->orient_off);
     SE2_LAUNCH(h->prof, st, "k_angle_trig", k_angle_trig, dim3((cap + 255) / 256, nframes), dim3(256), 0, d_counts, cap,
                h->angles.p, h->angle_cs.p);
