@@ -334,10 +334,14 @@ struct SpillTarget {
     const uint8_t* desc;             // target descriptors
     const uint8_t* excl;             // features to skip (KeyFrame::hasObservation), or nullptr
 };
+// rec (nullable): the (feature, distance) pairs are written there in enumeration order, rec_cap entries at most - the scan of
+// the first sweep feeds the replay of the later ones (query_replay_spill)
 __device__ inline LaneBest query_scan_spill(const SpillTarget& tg, float x, float y, float r, int minLevel, int maxLevel,
                                             const uint8_t* __restrict__ d1, int q, const int* vMatchesDistance,
-                                            const int* head, const int* next, const int* accD) {
+                                            const int* head, const int* next, const int* accD, uint2* __restrict__ rec = nullptr,
+                                            int rec_cap = 0, int* rec_count = nullptr) {
     LaneBest b{INT_MAX, -1, INT_MAX, -1, -1, -1};
+    if (rec_count) *rec_count = 0;
     const Bounds& bd = tg.bd;
     int nMinCellX = (int)floorf((x - bd.min_x - r) * bd.wInv);
     nMinCellX = max(0, nMinCellX);
@@ -364,13 +368,53 @@ __device__ inline LaneBest query_scan_spill(const SpillTarget& tg, float x, floa
                         !(fabsf(kp.y - y) > r) && !(tg.excl && tg.excl[idx]);
         if (!ok) continue;
         const int dist = hamming256(d1, tg.desc + 32 * (size_t)idx);
+        if (rec && t < rec_cap) rec[t] = make_uint2((uint32_t)idx, (uint32_t)dist);
         int eff = vMatchesDistance ? vMatchesDistance[idx] : INT_MAX;
         for (int a = head[idx]; a >= 0; a = next[a])
             if (a < q) eff = min(eff, accD[a]);
         if (!(eff <= dist)) lane_best_push(b, dist, t, idx);
         ++t;
     }
+    if (rec_count) *rec_count = t;
     return b;
+}
+// The later sweeps of a spilled query: its candidates do not change between sweeps (the grid, the window and the distances are
+// fixed), only the tentative acceptances they are weighed against do - so the list recorded by the first sweep is replayed
+// instead of walking the grid and recomputing every Hamming distance again (the re-scan per sweep).
+__device__ inline LaneBest query_replay_spill(const uint2* __restrict__ rec, int cnt, int q, const int* vMatchesDistance,
+                                              const int* head, const int* next, const int* accD) {
+    LaneBest b{INT_MAX, -1, INT_MAX, -1, -1, -1};
+    for (int t = 0; t < cnt; ++t) {
+        const uint2 e = rec[t];
+        const int idx = (int)e.x, dist = (int)e.y;
+        int eff = vMatchesDistance ? vMatchesDistance[idx] : INT_MAX;
+        for (int a = head[idx]; a >= 0; a = next[a])
+            if (a < q) eff = min(eff, accD[a]);
+        if (!(eff <= dist)) lane_best_push(b, dist, t, idx);
+    }
+    return b;
+}
+// A spilled query's place in its workgroup's spill arena: taken once, in the first sweep (an LDS bump allocator; ncand is the
+// exact number of candidates the scan will enumerate); {-1, 0} when the arena is full - the query then re-scans every sweep
+__device__ inline LaneBest query_spill(const SpillTarget& tg, float x, float y, float r, int minLevel, int maxLevel,
+                                       const uint8_t* __restrict__ d1, int q, const int* vMatchesDistance, const int* head,
+                                       const int* next, const int* accD, int sweep, int need, uint2* __restrict__ arena, int arena_cap,
+                                       int* used, int2* __restrict__ place) {
+    if (sweep == 0) {
+        int pos = -1;
+        if (arena) {
+            pos = atomicAdd(used, need);
+            if (pos + need > arena_cap) pos = -1;
+        }
+        int cnt = 0;
+        const LaneBest b = query_scan_spill(tg, x, y, r, minLevel, maxLevel, d1, q, vMatchesDistance, head, next, accD,
+                                            pos >= 0 ? arena + pos : nullptr, need, &cnt);
+        *place = (pos >= 0 && cnt <= need) ? make_int2(pos, cnt) : make_int2(-1, 0);
+        return b;
+    }
+    const int2 pl = *place;
+    if (pl.x >= 0) return query_replay_spill(arena + pl.x, pl.y, q, vMatchesDistance, head, next, accD);
+    return query_scan_spill(tg, x, y, r, minLevel, maxLevel, d1, q, vMatchesDistance, head, next, accD);
 }
 
 // MatchByWindow greedy pass (ORBmatcher.cpp:292-377), one workgroup per pair, parallel over ALL queries.
@@ -392,8 +436,11 @@ __global__ __launch_bounds__(1024) void k_resolve_window(const se2gpu_keypoint* 
                                                           int* __restrict__ overflow, Bounds bd,
                                                           const uint8_t* __restrict__ desc, const uint32_t* __restrict__ sorted,
                                                           const int* __restrict__ n_grid, int win, int level_offset,
-                                                          int min_level, int max_level) {
+                                                          int min_level, int max_level, uint2* __restrict__ spill, int spill_cap,
+                                                          int2* __restrict__ spill_place) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
+    __shared__ int s_spill_used;
+    if (threadIdx.x == 0) s_spill_used = 0;
     const int p = blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fa = pair_a[p], fb = pair_b[p];
@@ -435,8 +482,10 @@ __global__ __launch_bounds__(1024) void k_resolve_window(const se2gpu_keypoint* 
                 const int level1 = k1[q].octave;
                 const int minLevel2 = level1 - level_offset > 0 ? level1 - level_offset : 0;
                 const SpillTarget tg{bd, sorted + (size_t)fb * cap, n_grid + (size_t)fb * kGridRec, k2, desc + (size_t)fb * cap * 32, nullptr};
-                b = query_scan_spill(tg, prev_xy[((size_t)p * cap + q) * 2], prev_xy[((size_t)p * cap + q) * 2 + 1], (float)win,
-                                     minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + q) * 32, q, nullptr, head, next, accD);
+                b = query_spill(tg, prev_xy[((size_t)p * cap + q) * 2], prev_xy[((size_t)p * cap + q) * 2 + 1], (float)win,
+                                minLevel2, level1 + level_offset, desc + ((size_t)fa * cap + q) * 32, q, nullptr, head, next, accD, sweep,
+                                ncand[(size_t)p * cap + q], spill ? spill + (size_t)p * spill_cap : nullptr, spill_cap, &s_spill_used,
+                                spill_place + (size_t)p * cap + q);
             } else {
                 b = query_scan(cl, n, q, nullptr, head, next, accD);
             }
@@ -564,9 +613,10 @@ __global__ __launch_bounds__(1024) void k_resolve_projection(const se2gpu_keypoi
                                                               const uint32_t* __restrict__ sorted,
                                                               const int* __restrict__ n_grid, const float* __restrict__ proj_xy,
                                                               const uint8_t* __restrict__ mp_desc,
-                                                              const int* __restrict__ mp_octave, int win, int level_offset) {
+                                                              const int* __restrict__ mp_octave, int win, int level_offset,
+                                                              uint2* __restrict__ spill, int spill_cap, int2* __restrict__ spill_place) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
-    __shared__ int s_cnt;
+    __shared__ int s_cnt, s_spill_used;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int nE = (n + 3) & ~3;
     int* head = lds;
@@ -587,6 +637,7 @@ __global__ __launch_bounds__(1024) void k_resolve_projection(const se2gpu_keypoi
         const uint32_t* cand_c = cand + (size_t)i0 * kMaxCand;
         stage_candidates(cand_c, ncand + i0, mq, off, ce, cand_lds, overflow);
         for (int q = tid; q < mq; q += nthr) { accT[q] = -1; accD[q] = 0; }
+        if (tid == 0) s_spill_used = 0;   // (the arena is the chunk's; a barrier follows before the first use)
         for (int sweep = 0; sweep <= mq + 1; ++sweep) {
             for (int t = tid; t < n; t += nthr) head[t] = -1;
             __syncthreads();
@@ -602,9 +653,10 @@ __global__ __launch_bounds__(1024) void k_resolve_projection(const se2gpu_keypoi
                     const int predictLevel = mp_octave[i0 + q];
                     const int minLevel = predictLevel > level_offset ? predictLevel - level_offset : 0;
                     const SpillTarget tg{bd, sorted, n_grid, kps, desc, kf_observed};
-                    b = query_scan_spill(tg, proj_xy[2 * (size_t)(i0 + q)], proj_xy[2 * (size_t)(i0 + q) + 1],
-                                         (float)(predictLevel * win), minLevel, predictLevel + level_offset,
-                                         mp_desc + 32 * (size_t)(i0 + q), q, vMatchesDistance, head, next, accD);
+                    b = query_spill(tg, proj_xy[2 * (size_t)(i0 + q)], proj_xy[2 * (size_t)(i0 + q) + 1],
+                                    (float)(predictLevel * win), minLevel, predictLevel + level_offset,
+                                    mp_desc + 32 * (size_t)(i0 + q), q, vMatchesDistance, head, next, accD, sweep, ncand[i0 + q], spill,
+                                    spill_cap, &s_spill_used, spill_place + i0 + q);
                 } else {
                     b = query_scan(cl, nc, q, vMatchesDistance, head, next, accD);
                 }
@@ -744,6 +796,8 @@ struct se2gpu_matcher {
     int max_features = 0, max_batch = 1, device = 0;
     // scratch for frame sets of up to `nframes_cap` frames with stride `cap_cur`
     DevBuf<uint32_t> sorted, cand;
+    DevBuf<uint2> spill;          // (feature, distance) lists of the queries with more than kMaxCand candidates (query_spill)
+    DevBuf<int2> spill_place;
     DevBuf<int> n_grid, ncand, overflow, pair_a, pair_b, counts, matches, nmatches, mp_octave;
     DevBuf<float> prev, mp_pos, proj_xy;
     DevBuf<se2gpu_keypoint> kps;
@@ -823,9 +877,14 @@ int window_batch(se2gpu_matcher* h, const Bounds& bd, const se2gpu_keypoint* d_k
     const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));  // staged candidate entries
     const size_t lds = fixed_lds + (size_t)cand_lds * sizeof(int);
     const int resolve_threads = std::min(1024, std::max(64, (cap + 63) & ~63));
+    // spill arena: 8 x cap (feature, distance) entries per pair - e.g. sixteen queries that see half of the other frame each
+    const int spill_cap = 8 * cap;
+    SE2_CHECK(h->spill.reserve((size_t)npairs * spill_cap));
+    SE2_CHECK(h->spill_place.reserve((size_t)npairs * cap));
     hipLaunchKernelGGL(k_resolve_window, dim3(npairs), dim3(resolve_threads), lds, st, d_kps, d_counts, cap, d_pair_a,
                        d_pair_b, h->cand.p, h->ncand.p, nnratio, cand_lds, d_matches12, d_prev, d_nmatches, d_overflow, bd, d_desc,
-                       (const uint32_t*)h->sorted.p, (const int*)h->n_grid.p, win, level_offset, min_level, max_level);
+                       (const uint32_t*)h->sorted.p, (const int*)h->n_grid.p, win, level_offset, min_level, max_level, h->spill.p,
+                       spill_cap, h->spill_place.p);
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
 }
@@ -917,7 +976,8 @@ int se2gpu_matcher_set_stream(se2gpu_matcher* h, void* s) {
 }
 
 // Calls of this handle so far in which at least one query had more than 128 candidates in its search window and was
-// resolved by the exact - and much slower: one wave re-scans the grid per sweep of the fixed point - spill scan.  A caller on
+// resolved by the exact spill scan (one thread walks the grid in the first sweep of the fixed point and records the list; the
+// later sweeps replay it).  A caller on
 // the tracking thread can watch the counter: a frame pair that moves it pays a latency the usual pair does not.
 int se2gpu_matcher_spill_calls(const se2gpu_matcher* h, long long* calls) {
     SE2_REQUIRE(h && calls, SE2GPU_ERR_INVALID, "matcher_spill_calls: NULL argument");
@@ -1057,11 +1117,14 @@ int se2gpu_match_projection(se2gpu_matcher* h, const se2gpu_frame_bounds* bounds
         SE2_REQUIRE(fixed_lds + 4096 <= kLdsBudget, SE2GPU_ERR_CAPACITY, "%d key-frame features need %zu B of LDS", n, fixed_lds);
         SE2_CHECK(lds_attributes());
         const int cand_lds = (int)((kLdsBudget - 1024 - fixed_lds) / sizeof(int));
+        const int spill_cap = 16 * std::max(n, 1024);   // per chunk of 1024 map points
+        SE2_CHECK(h->spill.reserve((size_t)spill_cap));
+        SE2_CHECK(h->spill_place.reserve((size_t)std::max(m, 1)));
         hipLaunchKernelGGL(k_resolve_projection, dim3(1), dim3(1024), fixed_lds + (size_t)cand_lds * sizeof(int), st, d_kps,
                            n, m, h->cand.p, h->ncand.p, nnratio, chunk, cand_lds, (int*)(ds + o_m), d_sc, d_sc + 1, bd,
                            (const uint8_t*)(ds + o_desc), (const uint8_t*)(ds + o_obs), (const uint32_t*)h->sorted.p,
                            (const int*)h->n_grid.p, (const float*)h->proj_xy.p, (const uint8_t*)(ds + o_mdesc),
-                           (const int*)(ds + o_oct), win_size, level_offset);
+                           (const int*)(ds + o_oct), win_size, level_offset, h->spill.p, spill_cap, h->spill_place.p);
     }
     SE2_HIP(hipGetLastError());
     SE2_HIP(hipMemcpyAsync(hs, ds, o_kps, hipMemcpyDeviceToHost, st));
