@@ -2021,7 +2021,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         h->sparse_lst_base[l + 1] = h->sparse_tile_base[l + 1];
     }
     // resize tables
-    std::vector<int4> tabs;
+    std::vector<int4> tabs, geo;   // (host sources of asynchronous uploads: alive until the synchronisation at the end)
     h->xtab_off.assign(L, 0);
     h->ytab_off.assign(L, 0);
     for (int l = 1; l < L; ++l) {
@@ -2092,7 +2092,7 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
     SE2_CHECK(h->tabs.upload(tabs, h->stream));
     {   // CellGeoRec tables (k_cell_collect_w, k_cell_retain): rectangle, candidate lists and list place of every cell
         const int ncell = g.cell_base[L];
-        std::vector<int4> geo(4 * (size_t)ncell);
+        geo.assign(4 * (size_t)ncell, make_int4(0, 0, 0, 0));
         for (int layout = 0; layout < 2; ++layout) {
             const int tw = layout == 0 ? 4 * kScoreGroups : kFsTW, th = layout == 0 ? kScoreRows : kFsTH;
             const int* lbase = layout == 0 ? h->dense_lst_base : h->sparse_lst_base;
