@@ -148,3 +148,35 @@ def test_cpp_adapters_run_on_gpu(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "localBA adapters" in r.stdout and "ORBextractor adapter" in r.stdout and "ORBmatcher adapter" in r.stdout
+
+
+def test_pmc_traffic_is_stamped_per_kernel_on_the_device_code(tmp_path, monkeypatch):
+    """se2lam_amd/devcode.py reads, out of libse2gpu.so itself, which gfx950 code object every kernel lives in and hashes its
+    loadable sections; bench.py keeps a counter capture (profiles/pmc_traffic.json) kernel by kernel as long as that hash is
+    the one it was measured on - a host-only edit or a change in another translation unit must not stale it, a change of the
+    kernel's own code object must (VERDICT r04 next #4: the r04 driver line had `traffic: null` after a host-only edit)."""
+    import json
+    import sys
+    from se2lam_amd import devcode
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    h = devcode.kernel_code_hashes()
+    for k in ("k_chol_tiles", "k_reduce2", "k_fast_score", "k_cell_retain", "k_cand_window"):
+        assert k in h and len(h[k]) == 16, k
+    assert h["k_chol_tiles"] == h["k_reduce2"] and h["k_fast_score"] == h["k_cell_retain"]      # same translation unit
+    assert len({h["k_chol_tiles"], h["k_fast_score"], h["k_cand_window"]}) == 3                  # three different ones
+    assert devcode.kernel_code_hashes() == h
+    fake = {"_meta": {"commit": "abc"},
+            "k_chol_tiles": {"traffic_bytes": 1.0, "code_sha": h["k_chol_tiles"]},
+            "k_fast_score": {"traffic_bytes": 2.0, "code_sha": "0" * 16},                      # measured on other device code
+            "k_blur": {"traffic_bytes": 3.0},                                                   # an old capture without stamps
+            "__amd_rocclr_copyBuffer": {"traffic_bytes": 4.0, "code_sha": None}}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "pmc_traffic.json").write_text(json.dumps(fake))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t = bench._pmc_traffic()
+    assert bench._traffic_of(t, "k_chol_tiles") == (1.0, False)
+    assert bench._traffic_of(t, "k_fast_score") == (None, True)
+    assert bench._traffic_of(t, "k_blur") == (None, True)
+    assert bench._traffic_of(t, "k_never_measured") == (None, False)
