@@ -87,8 +87,10 @@ def parse():
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--orb-batch", type=int, default=256)
     ap.add_argument("--orb-steps", type=int, default=10)
-    ap.add_argument("--orb-inflight", type=int, default=2,
-                    help="ORB batches in flight (extractor handles on their own streams, alternating); 1 = one handle")
+    ap.add_argument("--orb-inflight", type=int, default=3,
+                    help="ORB batches in flight on the resident leg (extractor handles on their own streams, taking turns); 1 = one "
+                         "handle.  Three since round 5: 201-203 k frames/s against 193-194 k with two (the third batch fills what the "
+                         "latency-bound tail of a batch leaves idle); the PCIe-inclusive leg keeps two (its copies need the other queues)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--ba-windows", type=int, default=-1,
                     help="independent 50-KF local windows optimised concurrently per GPU (se2gpu_ba_optimize_batch); "
@@ -353,8 +355,14 @@ def main():
     if not args.no_orb:
         try:
             from se2lam_amd import orb_bench
+            own_process = world == 1 and args.orb_inflight > 2    # the PCIe-inclusive leg with the two handles of a streaming caller
             orb_obj = orb_bench.run(rank, world, args.orb_batch, args.orb_steps, sync_all, dist, torch,
-                                    traffic=traffic if args.orb_batch == 256 else {}, inflight=args.orb_inflight)
+                                    traffic=traffic if args.orb_batch == 256 else {}, inflight=args.orb_inflight,
+                                    streaming_leg=not own_process)
+            if own_process and orb_obj is not None:
+                log("ORB streaming leg (own process)")
+                orb_obj["streaming"] = _in_subprocess("orb_streaming", {"batch": args.orb_batch, "steps": 40},
+                                                      timeout=180.0)
         except ImportError:
             orb_obj = None
         log("ORB leg done; CPU baselines")
@@ -582,6 +590,11 @@ def _in_subprocess(which, cfg, timeout):
     box whose cgroup grants fewer cores can take minutes, and a C call cannot be interrupted from Python."""
     import subprocess
     env = dict(os.environ, OMP_WAIT_POLICY="passive", OMP_PROC_BIND="false")
+    if which == "orb_streaming":
+        # a streaming process gives every stream a hardware queue of its own (the default of four is dealt in creation order and
+        # puts the upload stream behind an extractor's: 100 k frames/s in a fresh process, 155 k with 32 queues); the resident
+        # leg is the other way round (202 k with four queues, 185 k with eight or more) and keeps the default in this process
+        env.setdefault("GPU_MAX_HW_QUEUES", "32")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-child", which, json.dumps(cfg)]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env)
@@ -594,6 +607,12 @@ def _in_subprocess(which, cfg, timeout):
 
 
 def _cpu_child(which, cfg):
+    if which == "orb_streaming":   # (a GPU leg: the ORB pipeline with the transfers in the loop, in a process of its own)
+        from se2lam_amd import orb_bench
+        with _stdout_to_stderr():
+            out = orb_bench.streaming_child(int(cfg["batch"]), int(cfg["steps"]))
+        print(json.dumps(out), flush=True)
+        return
     from oracle import oracle
     from se2lam_amd import synth
     oracle.lib()
