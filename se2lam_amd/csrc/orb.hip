@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(256) void k_orientation(Geom g, const uint8_t* __re
 // 7x7 Gaussian, sigma 2, 8-bit fixed point: taps {18,34,49,55,49,34,18} per pass, (v + 2^15) >> 16, saturate.
 // Tile = 64 x 16 outputs per workgroup; reads the un-blurred pyramid (whose frame holds reflect-101 copies).
 // ---------------------------------------------------------------------------------------------
-constexpr int kBlurRows = 35;
+constexpr int kBlurRows = 36;
 // One thread = 4 adjacent output pixels of a vertical strip of kBlurRows rows; the horizontal 7-tap sums of the last
 // 7 rows stay in registers (sliding window), inputs come in as three aligned dwords per row.  No LDS.
 // The blurred pyramid keeps the UN-blurred 16 px reflect frame of every level (the descriptor pattern of a key point
@@ -1651,11 +1651,28 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
         const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)y * stride + x0 - 4);
         hrow_w(p[0], p[1], p[2], h);
     };
-    // The window of the last seven rows is a circular buffer with static slots: the row loop is unrolled by 7
-    // (kBlurRows is a multiple of 7).
-    int hw[7][4];
+    // The vertical pass takes the seven horizontal sums h[y-3 .. y+3] of a pixel two at a time: the window holds PAIRS of
+    // consecutive rows, P[r] = h[r] | h[r+1] << 16 (a sum fits 16 bits), and
+    //     18 h[y-3] + 34 h[y-2] | 49 h[y-1] + 55 h[y] | 49 h[y+1] + 34 h[y+2] | 18 h[y+3]
+    // is three v_dot2_u32_u16 on P[y-3], P[y-1], P[y+1] and one multiply-add - with the v_lshl_or that forms the new pair five
+    // instructions per pixel instead of seven (three adds of the symmetric rows + four multiply-adds; round 5).  The window of
+    // six pairs P[y-3 .. y+2] is a circular buffer with static slots: the row loop is unrolled by 6 (kBlurRows is a multiple of 6).
+    typedef unsigned short ushort2b __attribute__((ext_vector_type(2)));
+    const ushort2b K01 = {18, 34}, K23 = {49, 55}, K45 = {49, 34};
+    uint32_t pw[6][4];      // pw[(PH + i) % 6] = P[y - 3 + i] at the step of row y (i = 0..4), P[y + 2] is formed there
+    int hprev[4];           // h[y + 2]
+    {
+        int h0[4], h1[4];
+        hrow(y0 - 3, h0);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) hrow(y0 - 3 + r, hw[r]);
+        for (int r = 0; r < 5; ++r) {   // pairs P[y0-3 .. y0+1] from the rows y0-3 .. y0+2
+            hrow(y0 - 2 + r, h1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pw[r][q] = (uint32_t)h0[q] | ((uint32_t)h1[q] << 16); h0[q] = h1[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hprev[q] = h0[q];
+    }
     const int yend = min(y0 + kBlurRows, H);
     const int nvalid = min(4, W - x0);
     // the row entering the window is fetched two steps ahead, so that its latency hides behind the steps' arithmetic
@@ -1668,7 +1685,7 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
         m0 = q[0]; m1 = q[1]; m2 = q[2];
     }
     auto step = [&](auto phc, int y) {
-        constexpr int PH = decltype(phc)::value;   // window row r of this iteration lives in slot (PH + r) % 7
+        constexpr int PH = decltype(phc)::value;   // pair i of this iteration lives in slot (PH + i) % 6
         if (y >= yend) return;                     // uniform
         const uint32_t c0 = n0, c1 = n1, c2 = n2;
         n0 = m0; n1 = m1; n2 = m2;
@@ -1676,12 +1693,19 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
             const uint32_t* p = (const uint32_t*)(src + (ptrdiff_t)min(y + 5, ylast) * stride + x0 - 4);
             m0 = p[0]; m1 = p[1]; m2 = p[2];
         }
-        hrow_w(c0, c1, c2, hw[(PH + 6) % 7]);
+        int hn[4];                                 // h[y + 3]
+        hrow_w(c0, c1, c2, hn);
         int sacc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            sacc[q] = 18 * (hw[PH % 7][q] + hw[(PH + 6) % 7][q]) + 34 * (hw[(PH + 1) % 7][q] + hw[(PH + 5) % 7][q]) +
-                      49 * (hw[(PH + 2) % 7][q] + hw[(PH + 4) % 7][q]) + 55 * hw[(PH + 3) % 7][q] + (1 << 15);
+        for (int q = 0; q < 4; ++q) {
+            pw[(PH + 5) % 6][q] = (uint32_t)hprev[q] | ((uint32_t)hn[q] << 16);   // P[y + 2]
+            hprev[q] = hn[q];
+            uint32_t acc = 18u * (uint32_t)hn[q] + (1u << 15);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2b, pw[PH % 6][q]), K01, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2b, pw[(PH + 2) % 6][q]), K23, acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2b, pw[(PH + 4) % 6][q]), K45, acc, false);
+            sacc[q] = (int)acc;
+        }
         // (v + 2^15) >> 16, saturated to a byte, two pixels per instruction (gfx950's v_ashr_pk_u8_i32: the low half of the
         // result holds the two bytes, the upper half is NOT cleared - v_perm_b32 takes only the low halves).  Written with
         // the builtin on purpose: the plain form min(max(x >> 16, 0), 255) is matched to the same instruction by ROCm 7.2's
@@ -1698,14 +1722,13 @@ __global__ __launch_bounds__(256) void k_blur(Geom g, const uint8_t* __restrict_
             *o = (*o & keep) | (out & ~keep);
         }
     };
-    for (int y = y0; y < yend; y += 7) {
+    for (int y = y0; y < yend; y += 6) {
         step(std::integral_constant<int, 0>{}, y);
         step(std::integral_constant<int, 1>{}, y + 1);
         step(std::integral_constant<int, 2>{}, y + 2);
         step(std::integral_constant<int, 3>{}, y + 3);
         step(std::integral_constant<int, 4>{}, y + 4);
         step(std::integral_constant<int, 5>{}, y + 5);
-        step(std::integral_constant<int, 6>{}, y + 6);
     }
 }
 
