@@ -1825,18 +1825,23 @@ __global__ __launch_bounds__(256) void k_describe(Geom g, const uint8_t* __restr
 #pragma unroll
         for (int i = 0; i < (kPD + 63) / 64; ++i)
             if (lane + 64 * i < kPD) patch[2 * wv + u][lane + 64 * i] = pv[u][i];
+    // The rotation of a test pair (x0, y0), (x1, y1) is two packed multiplies and a packed add / subtract per coordinate
+    // (v_pk_mul_f32 / v_pk_add_f32: IEEE per lane, the products and the sum rounded separately as in the reference's scalar
+    // x*b + y*a - contraction is off in this translation unit); the pattern bytes are unpacked once for both key points.
+    typedef float float2p __attribute__((ext_vector_type(2)));
     int t0[2][4], t1[2][4];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const float a = ab[u].x, b = ab[u].y;
-        const uint8_t* pc = reinterpret_cast<const uint8_t*>(patch[2 * wv + u]) + kPR * kPW + kPW / 2;   // the key point
+    for (int q = 0; q < 4; ++q) {
+        const int pw = reinterpret_cast<const int*>(c_pattern)[64 * q + lane];   // the 4 pattern bytes in one load
+        const float2p X = {(float)(signed char)(pw & 0xff), (float)(signed char)((pw >> 16) & 0xff)};
+        const float2p Y = {(float)(signed char)((pw >> 8) & 0xff), (float)(signed char)((pw >> 24) & 0xff)};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int pw = reinterpret_cast<const int*>(c_pattern)[64 * q + lane];   // the 4 pattern bytes in one load
-            const float x0 = (float)(signed char)(pw & 0xff), y0 = (float)(signed char)((pw >> 8) & 0xff);
-            const float x1 = (float)(signed char)((pw >> 16) & 0xff), y1 = (float)(signed char)((pw >> 24) & 0xff);
-            const int r0 = (int)rintf(x0 * b + y0 * a), c0 = (int)rintf(x0 * a - y0 * b);
-            const int r1 = (int)rintf(x1 * b + y1 * a), c1 = (int)rintf(x1 * a - y1 * b);
+        for (int u = 0; u < 2; ++u) {
+            const float2p A = {ab[u].x, ab[u].x}, Bv = {ab[u].y, ab[u].y};
+            const uint8_t* pc = reinterpret_cast<const uint8_t*>(patch[2 * wv + u]) + kPR * kPW + kPW / 2;   // the key point
+            const float2p R = X * Bv + Y * A, Cc = X * A - Y * Bv;
+            const int r0 = (int)rintf(R.x), c0 = (int)rintf(Cc.x);
+            const int r1 = (int)rintf(R.y), c1 = (int)rintf(Cc.y);
             t0[u][q] = pc[r0 * kPW + c0];
             t1[u][q] = pc[r1 * kPW + c1];
         }
