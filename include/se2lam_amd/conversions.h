@@ -16,7 +16,8 @@ inline Mat8U view8U(const cv::Mat& m) {          // non-owning view of a CV_8UC1
     Mat8U o;
     if (m.empty()) return o;
     CV_Assert(m.type() == CV_8UC1);
-    o.rows = m.rows; o.cols = m.cols; o.step = m.step[0]; o.data = m.ptr<uint8_t>(0);
+    o.rows = m.rows; o.cols = m.cols; o.step = static_cast<size_t>(m.step);   // cv::MatStep converts to size_t; a stand-in's plain size_t passes through
+    o.data = m.ptr<uint8_t>(0);
     return o;
 }
 inline MatF toMatF(const cv::Mat& m) {

@@ -251,6 +251,7 @@ void copyMakeBorder(InputArray _src, OutputArray _dst, int top, int bottom, int 
 // dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;  INTER_NEAREST for the mask pyramid
 static inline short sat_short(float v) { const int i = cvRound(v); return (short)std::min(std::max(i, -32768), 32767); }
 void resize(InputArray _src, OutputArray _dst, Size dsize, double inv_scale_x, double inv_scale_y, int interpolation) {
+    ++shim_call_counts()[1];
     Mat src = _src.getMat();
     if (src.type() != CV_8UC1) throw std::runtime_error("cv shim: resize is 8UC1 only");
     const Size ssize = src.size();
@@ -318,6 +319,7 @@ void resize(InputArray _src, OutputArray _dst, Size dsize, double inv_scale_x, d
 // returns (sum + 2^15) >> 16, saturated).  A view without BORDER_ISOLATED reads the pixels around it in its parent
 // matrix (FilterEngine::apply with the located ROI); only beyond the parent is the border extrapolated.
 void GaussianBlur(InputArray _src, OutputArray _dst, Size ksize, double sigma1, double sigma2, int borderType) {
+    ++shim_call_counts()[2];
     Mat src = _src.getMat();
     if (src.type() != CV_8UC1) throw std::runtime_error("cv shim: GaussianBlur is 8UC1 only");
     _dst.create(src.size(), src.type());
@@ -383,7 +385,42 @@ void undistort(InputArray _src, OutputArray _dst, InputArray, InputArray _D, Inp
 void undistortPoints(InputArray, OutputArray, InputArray, InputArray, InputArray, InputArray) {
     throw std::runtime_error("cv shim: undistortPoints is not implemented (the oracle's cameras have no distortion)");
 }
-void Rodrigues(InputArray, OutputArray) { throw std::runtime_error("cv shim: Rodrigues is not implemented (Config::readConfig is never run)"); }
+// calib3d/src/calibration.cpp cvRodrigues2, rotation VECTOR -> matrix (the direction Track::calcSE3toXYZInfo uses, src/Track.cpp:298-299):
+// computed in double, theta = |r|; below DBL_EPSILON the identity, otherwise c I + (1 - c) r r^T + s [r]x over the unit axis;
+// the result has the depth of the input
+void Rodrigues(InputArray _src, OutputArray _dst) {
+    Mat src = _src.getMat();
+    if (!((src.rows == 3 && src.cols == 1) || (src.rows == 1 && src.cols == 3)) || src.channels() != 1 || (src.depth() != CV_32F && src.depth() != CV_64F))
+        throw std::runtime_error("cv shim: Rodrigues takes a 3x1 / 1x3 rotation vector of floats or doubles (the matrix -> vector direction is not implemented)");
+    double r[3];
+    for (int i = 0; i < 3; ++i) {
+        const int rr = src.rows == 3 ? i : 0, cc = src.rows == 3 ? 0 : i;
+        r[i] = src.depth() == CV_32F ? (double)src.at<float>(rr, cc) : src.at<double>(rr, cc);
+    }
+    const double theta = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (!(theta < DBL_EPSILON)) {
+        const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+        const double x = r[0] * itheta, y = r[1] * itheta, z = r[2] * itheta;
+        const double rrt[9] = {x * x, x * y, x * z, x * y, y * y, y * z, x * z, y * z, z * z};
+        const double rx[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int k = 0; k < 9; ++k) R[k] = c * I[k] + c1 * rrt[k] + s * rx[k];
+    }
+    Mat out(3, 3, src.depth() == CV_32F ? CV_32FC1 : CV_64FC1);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        if (src.depth() == CV_32F) out.at<float>(i, j) = (float)R[3 * i + j]; else out.at<double>(i, j) = R[3 * i + j];
+    }
+    out.copyTo(_dst.getMatRef());
+}
+
+// how often the stand-in's image functions ran: the drop-in build (tests/dropin), where ORBextractor.cpp is the binding over libse2gpu,
+// must never reach FAST / resize / GaussianBlur (oracle/ref_pipeline_driver.cpp reports the counts)
+long long* shim_call_counts() { static long long c[4] = {0, 0, 0, 0}; return c; }
+std::function<int(const float*, const float*, int, unsigned char*)>& shim_fundamental_hook() {
+    static std::function<int(const float*, const float*, int, unsigned char*)> h;
+    return h;
+}
 
 // ------------------------------------------------------------------------------------------------ features2d
 // fast.cpp FAST_t<16> + fast_score.cpp cornerScore<16>: a pixel is a corner when more than 8 contiguous pixels of the
@@ -426,6 +463,7 @@ static int corner_score16(const uchar* ptr, const int pixel[25], int threshold) 
     return -b0 - 1;
 }
 void FAST(InputArray _img, std::vector<KeyPoint>& keypoints, int threshold, bool nonmax_suppression) {
+    ++shim_call_counts()[0];
     Mat img = _img.getMat();
     if (img.type() != CV_8UC1) throw std::runtime_error("cv shim: FAST is 8UC1 only");
     const int K = 8, N = 16 + K + 1;

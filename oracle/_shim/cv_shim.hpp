@@ -32,6 +32,7 @@
 #include <stdexcept>
 #include <type_traits>
 #include <string>
+#include <functional>
 #include <vector>
 
 #ifndef M_PI
@@ -389,10 +390,21 @@ inline void circle(Mat&, Point2f, int, const Scalar&, int = 1) {}
 inline void line(Mat&, Point2f, Point2f, const Scalar&, int = 1) {}
 inline void vconcat(const Mat& a, const Mat&, Mat& dst) { dst = a; }
 inline void hconcat(const Mat& a, const Mat&, Mat& dst) { dst = a; }
-// cv::findFundamentalMat(FM_RANSAC) is OpenCV's own algorithm (calib3d), not se2lam's: the stand-in keeps every
-// correspondence, so nothing that depends on the RANSAC outcome is pinned through oracle/_ref
-template <typename P> inline Mat findFundamentalMat(const std::vector<P>& a, const std::vector<P>&, int, double, double, std::vector<unsigned char>& mask) {
+// cv::findFundamentalMat(FM_RANSAC) is OpenCV's own algorithm (calib3d), not se2lam's: without a hook the stand-in keeps every
+// correspondence, so nothing that depends on the RANSAC outcome is pinned through oracle/_ref.  The pipeline builds
+// (oracle/ref_pipeline_driver.cpp) register a hook (points as n x 2 floats -> mask, returns the inlier count): the oracle's restatement of
+// OpenCV 3.2's FM_RANSAC (oracle/match_ref.cpp) in the CPU build, se2gpu_track_fundamental_mask in the drop-in build.
+std::function<int(const float*, const float*, int, unsigned char*)>& shim_fundamental_hook();
+long long* shim_call_counts();   // {FAST, resize, GaussianBlur, findFundamentalMat} calls so far
+template <typename P> inline Mat findFundamentalMat(const std::vector<P>& a, const std::vector<P>& b, int method, double param1, double param2, std::vector<unsigned char>& mask) {
+    ++shim_call_counts()[3];
     mask.assign(a.size(), 1);
+    if (shim_fundamental_hook()) {
+        if (method != FM_RANSAC || param1 != 3. || param2 != 0.99 || a.size() != b.size())
+            throw std::runtime_error("cv shim: findFundamentalMat is hooked for (FM_RANSAC, 3, 0.99) only");
+        static_assert(sizeof(P) == 2 * sizeof(float), "Point2f");
+        shim_fundamental_hook()(reinterpret_cast<const float*>(a.data()), reinterpret_cast<const float*>(b.data()), (int)a.size(), mask.data());
+    }
     return Mat();
 }
 template <typename P> inline Mat findFundamentalMat(const std::vector<P>& a, const std::vector<P>& b, std::vector<unsigned char>& mask, int method = FM_RANSAC,

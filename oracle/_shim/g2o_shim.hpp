@@ -855,6 +855,7 @@ public:
     bool initializeOptimization(int level = 0) { _level = level; return true; }
     int optimize(int iterations) { if (optimizeHook()) optimizeHook()(*this, iterations); return 0; }
     void setForceStopFlag(bool* f) { _stop = f; }
+    bool* forceStopFlag() const { return _stop; }
     int level() const { return _level; }
     bool verbose() const { return _verbose; }
     bool hasAlgorithm() const { return _algorithm != nullptr; }
