@@ -374,6 +374,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("BA CPU baseline")
         cpu = _ba_cpu_baseline(g_full, args.cpu_seconds)
+        log("pipeline (configs[0]) CPU baseline")
+        cpu["pipeline"] = _pipeline_baseline()
         log("done")
 
     if rank == 0:
@@ -613,6 +615,11 @@ def _cpu_child(which, cfg):
             out = orb_bench.streaming_child(int(cfg["batch"]), int(cfg["steps"]))
         print(json.dumps(out), flush=True)
         return
+    if which == "pipeline":
+        with _stdout_to_stderr():
+            out = _pipeline_child(cfg["kind"], int(cfg["frames"]), int(cfg["fps"]))
+        print(json.dumps(out), flush=True)
+        return
     from oracle import oracle
     from se2lam_amd import synth
     oracle.lib()
@@ -666,6 +673,48 @@ def _cpu_child(which, cfg):
         print(json.dumps({"value": done / cdt, "unit": "frames/s", "cores": thr, "kind": "port",
                           "sample": f"{done} frames: oracle extract of every frame, then MatchByWindow t -> t+1, both "
                                     f"frame-parallel over {thr} threads (= usable cores)"}), flush=True)
+
+
+def _pipeline_child(kind, nframes, fps):
+    """BASELINE.json configs[0], timed: the reference's own Track -> LocalMapper -> optimizer (compiled from /root/reference where the
+    sources lie, oracle/_ref; fed frame by frame by oracle/ref_pipeline_driver.cpp) over `nframes` synthetic frames + odometry.
+    kind "cpu": every source the reference's, one thread (its Track and LocalMapper are one thread each); kind "dropin": the same
+    sources with ORBextractor.cpp / ORBmatcher.cpp replaced by the bindings over libse2gpu and optimize() forwarded to it."""
+    from oracle import pipeline
+    from se2lam_amd import synth
+    if not pipeline.available(kind):
+        return {"error": "oracle/_ref/libse2lam_pipeline_%s.so is not built here" % kind}
+    frames, odo = synth.frames(nframes), pipeline.odometry(nframes)
+    cfg = pipeline.default_config()
+    cfg.fps = fps
+    if kind == "dropin":    # first-use costs (code objects, arenas) stay out of the sample, as they do for every other GPU leg
+        pipeline.run(kind, frames[:12], odo[:12], cfg, raw_matches=False)
+    res = pipeline.run(kind, frames, odo, cfg, raw_matches=False)
+    ms = res["ms_track"] + res["ms_mapper"]
+    bas = [r for r in res["frames"] if r["local_ba"]]
+    return {"value": 1e3 * nframes / ms, "unit": "frames/s", "cores": 1,
+            "kind": "reference sources, 3P = stand-in" if kind == "cpu" else "reference sources over libse2gpu",
+            "ms_per_frame_track": res["ms_track"] / nframes,
+            "ms_per_local_ba": (sum(r["ms_mapper"] for r in bas) / len(bas)) if bas else None,
+            "key_frames_inserted": int(sum(r["new_kf"] for r in res["frames"])), "local_bas": len(bas),
+            "map_points": int(res["frames"][-1]["n_mps"]),
+            "sample": f"{nframes} synthetic 640x480 frames + SE(2) odometry through the reference's Track::mTrack -> LocalMapper::addNewKF / "
+                      f"localBA -> optimizer (key frame at most every {fps + 1} frames), one thread; "
+                      + ("ORBextractor / ORBmatcher / g2o optimize() / findFundamentalMat = the reference's sources and the OpenCV / g2o stand-ins"
+                         if kind == "cpu" else
+                         "ORBextractor / ORBmatcher = tests/dropin bindings over libse2gpu, optimize() and findFundamentalMat forwarded to it; "
+                         "host buffers in and out every call (PCIe-inclusive)")}
+
+
+def _pipeline_baseline(nframes=60, fps=10):
+    """cpu_baseline.pipeline: configs[0]'s CPU run timed beside the same run over libse2gpu (both in child processes)"""
+    cpu = _in_subprocess("pipeline", {"kind": "cpu", "frames": nframes, "fps": fps}, timeout=240.0)
+    gpu = _in_subprocess("pipeline", {"kind": "dropin", "frames": nframes, "fps": fps}, timeout=240.0)
+    out = dict(cpu)
+    out["over_libse2gpu"] = gpu
+    if "value" in cpu and "value" in gpu:
+        out["speedup_end_to_end"] = gpu["value"] / cpu["value"]
+    return out
 
 
 class _stdout_to_stderr:
