@@ -34,107 +34,14 @@
 
 #include "common.h"
 #include "se3_math.h"
+#include "ba_device.h"
+#include "ba_window.h"
 
 using namespace se2gpu;
+using namespace se2gpu::badev;
 
 namespace {
 
-constexpr int kGroup = 8;       // lanes cooperating on one landmark
-constexpr int kBlock = 256;
-constexpr double kPi = 3.14159265358979323846;
-
-struct CamDev {
-    double fx, cx, cy;
-    double Rcb[9];
-    double tcb[3];
-    double huber;
-};
-
-// Levenberg-Marquardt controller state, resident on the device: every kernel of an LM trial reads it (which buffer holds
-// the estimate, the damping, whether this trial is a retry on the same linearisation, whether the run is over) and the
-// last kernel of the trial (k_finalize / k_lm_decide) advances it with g2o's policy.  The host only enqueues trial
-// "slots" and reads the block back once per optimize() call - no host round trip between trials.
-constexpr int kMailSeq = 4;   // mailbox word of the device-side slot counter (BaCtl::seq)
-struct BaCtl {
-    double lambda, ni, current_chi, rho;
-    double chi2_init, chi2_final;
-    int it, qmax, trials, iters;
-    int done, terminated, stopped, retry;
-    int sel;          // 0: the estimate lives in the "a" buffers (trial state in "b"), 1: the other way round
-    int mode, error, pad;
-    double chi2_hist[64], lambda_hist[64];
-    int trials_hist[64];
-    // survive k_ctl_init (and, like sel, say something about the handle rather than about one run):
-    double seq;       // trial slots finished so far; posted next to the block (mail[kMailSeq]) - the host mirrors the count
-    unsigned epoch;   // dense solves so far = the value the tile flags of k_chol_tiles are compared with
-    unsigned pad2;
-};
-
-__host__ __device__ inline double normalize_theta(double theta) {
-    if (theta >= -kPi && theta < kPi) return theta;
-    double multiplier = floor(theta / (2 * kPi));
-    theta = theta - multiplier * 2 * kPi;
-    if (theta >= kPi) theta -= 2 * kPi;
-    if (theta < -kPi) theta += 2 * kPi;
-    return theta;
-}
-
-// Residual (and optionally the 2x3 pose / 2x3 landmark Jacobians) of one EdgeSE2XYZ.
-// lc = Rcb Rz(-theta) (lw - [x,y,0]) + tcb ; e = f (X/Z, Y/Z) + c - z     (EdgeSE2XYZ.cpp:61-106)
-template <bool JAC>
-__device__ inline void se2xyz(const CamDev& cam, double px, double py, double pth, double lx, double ly, double lz,
-                              double u, double v, double& e0, double& e1, double* Jp, double* Jl) {
-    double s, c;
-    sincos(pth, &s, &c);
-    const double dx = lx - px, dy = ly - py;
-    double R[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        R[i * 3 + 0] = cam.Rcb[i * 3 + 0] * c - cam.Rcb[i * 3 + 1] * s;
-        R[i * 3 + 1] = cam.Rcb[i * 3 + 0] * s + cam.Rcb[i * 3 + 1] * c;
-        R[i * 3 + 2] = cam.Rcb[i * 3 + 2];
-    }
-    const double X = R[0] * dx + R[1] * dy + R[2] * lz + cam.tcb[0];
-    const double Y = R[3] * dx + R[4] * dy + R[5] * lz + cam.tcb[1];
-    const double Z = R[6] * dx + R[7] * dy + R[8] * lz + cam.tcb[2];
-    const double zi = 1.0 / Z;
-    e0 = cam.fx * X * zi + cam.cx - u;
-    e1 = cam.fx * Y * zi + cam.cy - v;
-    if (JAC) {
-        const double zi2 = zi * zi;
-        const double j00 = cam.fx * zi, j02 = -cam.fx * X * zi2, j12 = -cam.fx * Y * zi2;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            Jl[k] = j00 * R[k] + j02 * R[6 + k];
-            Jl[3 + k] = j00 * R[3 + k] + j12 * R[6 + k];
-        }
-        Jp[0] = -Jl[0]; Jp[1] = -Jl[1]; Jp[2] = Jl[0] * dy - Jl[1] * dx;
-        Jp[3] = -Jl[3]; Jp[4] = -Jl[4]; Jp[5] = Jl[3] * dy - Jl[4] * dx;
-    }
-}
-
-__device__ inline void huber(double e2, double delta, double& rho0, double& rho1) {  // RobustKernelHuber
-    const double dsqr = delta * delta;
-    if (e2 <= dsqr) {
-        rho0 = e2; rho1 = 1.0;
-    } else {
-        const double sq = sqrt(e2);
-        rho0 = 2 * sq * delta - dsqr;
-        rho1 = delta / sq;
-    }
-}
-
-__device__ inline double group_sum(double v) {  // sum over an aligned group of kGroup lanes
-#pragma unroll
-    for (int m = 1; m < kGroup; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-}
-
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_linearize: per landmark group (8 lanes per landmark, a lane takes every 8th edge of the landmark).
@@ -154,23 +61,6 @@ __device__ inline double wave_sum(double v) {
 // <FUSED = false> is the opening pass of an optimize() call only: lambda_0 = 1e-5 max diag H needs the diagonals first, so
 // it writes Hll, bl and the un-reduced pose terms Hpp_e (6 sym), bp_e (3) for k_lambda0 / k_pose_reduce and no records.
 // ---------------------------------------------------------------------------------------------
-// A = G^-1 for M = h + lambda I = G G^T
-__device__ inline void chol_inv3(const double h[6], double lambda, double a[6]) {
-    const double m00 = h[0] + lambda, m10 = h[1], m20 = h[2], m11 = h[3] + lambda, m21 = h[4], m22 = h[5] + lambda;
-    // M is positive definite whenever lambda > 0; in Gauss-Newton mode (lambda = 0) a landmark without parallax makes it
-    // singular to rounding, and a pivot that comes out at -1e-17 must give a huge finite step (as a cofactor inverse, and
-    // g2o's, would), not a NaN: pivots are floored 30 orders of magnitude below the block's trace
-    const double floor_ = 1e-30 * (m00 + m11 + m22);
-    const double a00 = 1.0 / sqrt(fmax(m00, floor_));
-    const double g10 = m10 * a00, g20 = m20 * a00;
-    const double a11 = 1.0 / sqrt(fmax(m11 - g10 * g10, floor_));
-    const double g21 = (m21 - g20 * g10) * a11;
-    const double a22 = 1.0 / sqrt(fmax(m22 - g20 * g20 - g21 * g21, floor_));
-    const double a10 = -(a11 * g10) * a00;             // rows of A G = I
-    const double a21 = -(a22 * g21) * a11;
-    const double a20 = -(a21 * g10 + a22 * g20) * a00;
-    a[0] = a00; a[1] = a10; a[2] = a11; a[3] = a20; a[4] = a21; a[5] = a22;
-}
 
 // one edge's whitened record from its un-reduced blocks: hh = Hpl_e (9), hp = Hpp_e (6 sym), bpe = bp_e (3)
 __device__ inline void write_edge_record(double* __restrict__ w_out, double* __restrict__ dg, const double* __restrict__ hh,
@@ -355,23 +245,6 @@ __global__ __launch_bounds__(kBlock) void k_linearize(CamDev cam, int L, const i
 // k_odometry: one thread per PreEdgeSE2 (EdgeSE2XYZ.h:62-102, no robust kernel): blocks Oii, Ojj, Oij (3x3
 // row-major) and gradients obi, obj.  Fixed vertices get zero blocks (constructQuadraticForm skips them).
 // ---------------------------------------------------------------------------------------------
-__device__ inline void pre_se2(const double* pi, const double* pj, const double* z, double e[3], double A[9],
-                               double B[9]) {
-    double s, c;
-    sincos(pi[2], &s, &c);
-    const double rx = pj[0] - pi[0], ry = pj[1] - pi[1];
-    e[0] = c * rx + s * ry - z[0];
-    e[1] = -s * rx + c * ry - z[1];
-    e[2] = pj[2] - pi[2] - z[2];
-    const double qx = -ry, qy = rx;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { A[i] = 0; B[i] = 0; }
-    A[0] = -c; A[1] = -s; A[3] = s; A[4] = -c;
-    A[2] = -(c * qx + s * qy);
-    A[5] = -(-s * qx + c * qy);
-    A[8] = -1;
-    B[0] = c; B[1] = s; B[3] = -s; B[4] = c; B[8] = 1;
-}
 
 __device__ __forceinline__ void d_odometry(const unsigned bx, int O, const int* __restrict__ o_i, const int* __restrict__ o_j,
                            const double* __restrict__ o_meas, const double* __restrict__ o_info,
@@ -1765,57 +1638,6 @@ __global__ __launch_bounds__(kBlock) void k_update(CamDev cam, int L, double lam
     d_update(blockIdx.x, cam, L, lambda, lm_ptr, e_kf, e_uv, e_info, poses, fixed, lms, xp, zeta, W, bl, lms_trial, part, ctl, poses_b, fin, Ainv);
 }
 
-// One step of g2o's OptimizationAlgorithmLevenberg::solve / OptimizationAlgorithmGaussNewton on the controller block, run
-// by ONE thread after the (all-reduced) scalars of a trial are known:  sc = {chi2 of the trial state, computeScale()
-// denominator, factorisation flag}.  Mirrors, statement for statement, the host loop this replaces
-// (rho = (chi - chi_trial) / (scale + 1e-3); accept: lambda *= max(1/3, min(1 - (2 rho - 1)^3, 2/3)), ni = 2, the trial
-// state becomes the estimate (sel flips = discardTop); reject: lambda *= ni, ni *= 2 (pop); at most 10 trials per
-// iteration; Terminate when all 10 failed or rho == 0).  `stop` is the caller's force-stop flag, mirrored by the host
-// into mapped memory (SparseOptimizer::setForceStopFlag).
-__device__ inline void lm_advance(BaCtl* c, const double* sc, bool stopped) {
-    double tempChi = sc[0];
-    const double scale_in = sc[1], fail = sc[2];
-    if (fail >= 1e5) { c->error = 1; c->done = 1; return; }   // a dataflow spin of k_chol_tiles timed out
-    if (fail > 0.0) tempChi = 1.7976931348623157e308;          // factorisation failed: the step is rejected
-    c->trials += 1;
-    const int qmax = c->qmax + 1;
-    c->qmax = qmax;
-    double rho;
-    if (c->mode == SE2GPU_BA_GN) {
-        c->sel ^= 1;
-        c->current_chi = tempChi;
-        rho = 1;
-    } else {
-        rho = (c->current_chi - tempChi) / (scale_in + 1e-3);
-        if (rho > 0 && tempChi < 1.7976931348623157e308 && tempChi == tempChi) {
-            const double t = 2 * rho - 1;
-            double alpha = 1. - t * t * t;
-            alpha = fmin(alpha, 2. / 3.);
-            c->lambda *= fmax(1. / 3., alpha);
-            c->ni = 2;
-            c->current_chi = tempChi;
-            c->sel ^= 1;
-        } else {
-            c->lambda *= c->ni;
-            c->ni *= 2;
-        }
-        if (rho < 0 && qmax < 10 && !stopped) {   // do { ... } while (rho < 0 && qmax < 10 && !terminate())
-            c->rho = rho;
-            c->retry = 1;
-            return;
-        }
-    }
-    c->rho = rho;
-    const int it = c->it;
-    if (it < 64) { c->chi2_hist[it] = c->current_chi; c->lambda_hist[it] = c->lambda; c->trials_hist[it] = qmax; }
-    c->it = it + 1;
-    c->chi2_final = c->current_chi;
-    c->qmax = 0;
-    c->retry = 0;
-    if (c->mode == SE2GPU_BA_LM && (qmax == 10 || rho == 0)) { c->terminated = 1; c->done = 1; }
-    if (stopped) { c->stopped = 1; c->done = 1; }
-    if (c->it >= c->iters) c->done = 1;
-}
 
 // a dataflow solve timed out and the host switched the handle to the per-column launches: the trial is simply redone
 __global__ void k_ctl_clear_error(BaCtl* __restrict__ ctl) {
@@ -6211,6 +6033,146 @@ int ba_run_finish(se2gpu_ba* h, se2gpu_ba_stats* stats) {
     return SE2GPU_OK;
 }
 
+// ---- optimize() of `count` windows, ONE WORKGROUP PER WINDOW (csrc/ba_window.hip): every window lives in one compute unit's
+// LDS for its whole optimize(iters) - no per-edge records, no launches per trial.  Taken for batches of SE2GPU_BA_RESIDENT_MIN
+// windows or more (default 12: below that the multi-launch paths, which spread a window over the chip, finish a batch sooner)
+// whose windows all fit (SE(2) model, one GPU, at most ~60 free key frames, no landmark with more than 64 observations).
+// SE2GPU_BA_RESIDENT=0 switches the path off, =1 takes it for any batch.  *handled = 0: the caller goes on to the other paths.
+struct ResidentScratch {
+    PinBuf<WindowArgs> host;
+    DevBuf<WindowArgs> dev;
+    DevBuf<long long> stamps;
+};
+int ba_resident_threads(const se2gpu_ba* h, size_t* lds) {
+    int nfree = 0;
+    for (int p = 0; p < h->P; ++p) nfree += h->h_fixed[p] ? 0 : 1;
+    for (int t : {512, 256, 128}) {
+        const size_t b = ba_window_lds_bytes(h->P, nfree, t);
+        if (b) { *lds = b; return t; }
+    }
+    return 0;
+}
+bool ba_resident_ok(const se2gpu_ba* h) {
+    return h->initialized && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->prof.enabled && h->d_mail &&
+           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P;
+}
+int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
+                         se2gpu_ba_stats* stats, int* handled) {
+    *handled = 0;
+    // (read per call, not once: a test - or a mapper - can switch the path between two batches)
+    const char* e_on = getenv("SE2GPU_BA_RESIDENT");
+    const char* e_min = getenv("SE2GPU_BA_RESIDENT_MIN");
+    const int env_on = e_on ? atoi(e_on) : -1, env_min = e_min ? atoi(e_min) : 12;
+    if (env_on == 0 || count < 1 || (env_on != 1 && count < env_min) || ba_env_sync() || iters < 0) return SE2GPU_OK;
+    if (mode != SE2GPU_BA_LM && mode != SE2GPU_BA_GN) return SE2GPU_OK;
+    int threads = 512;
+    size_t lds = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!ba_resident_ok(hs[i]) || hs[i]->device != hs[0]->device) return SE2GPU_OK;
+        size_t b = 0;
+        const int t = ba_resident_threads(hs[i], &b);
+        if (!t) return SE2GPU_OK;
+        threads = std::min(threads, t);
+    }
+    for (int i = 0; i < count; ++i) {   // (all windows of a launch share the workgroup size: the widest window's)
+        int nfree = 0;
+        for (int p = 0; p < hs[i]->P; ++p) nfree += hs[i]->h_fixed[p] ? 0 : 1;
+        const size_t b = ba_window_lds_bytes(hs[i]->P, nfree, threads);
+        if (!b) return SE2GPU_OK;
+        lds = std::max(lds, b);
+    }
+    for (int i = 0; i < count; ++i)
+        for (int j = 0; j < i; ++j)
+            if (hs[i] == hs[j]) return SE2GPU_OK;
+    static std::mutex launch_mu;   // (hipFuncSetAttribute inside the launcher)
+    Lease<ResidentScratch> lease;
+    ResidentScratch& rs = *lease.obj;
+    SE2_CHECK(rs.host.reserve((size_t)count));
+    SE2_CHECK(rs.dev.reserve((size_t)count));
+    static const bool trace = [] { const char* e = getenv("SE2GPU_BA_RESIDENT_TRACE"); return e && e[0] == '1'; }();
+    if (trace) SE2_CHECK(rs.stamps.reserve(16 * (size_t)count));
+    hipStream_t st = hs[0]->stream;
+    for (int i = 0; i < count; ++i) {
+        se2gpu_ba* h = hs[i];
+        h->est_valid = false;
+        h->run_mode = mode;
+        h->run_iters = iters;
+        h->run_enqueued = 1;
+        h->run_sync = false;
+        h->run_active = true;
+        *h->h_stop = (stop_flag && *stop_flag) ? 1 : 0;
+        if (h->join_event) {   // a batched reset on another stream ...
+            if (h->join_stream != st) SE2_HIP(hipStreamWaitEvent(st, h->join_event, 0));
+            h->join_event = nullptr;
+            h->join_stream = nullptr;
+        }
+        if (h->stream != st) SE2_HIP(hipStreamSynchronize(h->stream));   // ... or anything still enqueued on the window's own stream
+        h->own_pending = false;
+        WindowArgs& a = rs.host.p[i];
+        a.cam = h->cam;
+        a.P = h->P; a.L = h->L; a.E = h->E; a.O = h->O; a.iters = iters; a.mode = mode;
+        a.lm_ptr = h->lm_ptr.p; a.e_kf = h->e_kf.p; a.e_uv = h->e_uv.p; a.e_info = h->e_info.p;
+        a.poses_a = h->poses_a.p; a.poses_b = h->poses_b.p; a.lms_a = h->lms_a.p; a.lms_b = h->lms_b.p;
+        a.fixed = h->fixed.p;
+        a.o_i = h->o_i.p; a.o_j = h->o_j.p; a.o_meas = h->o_meas.p; a.o_info = h->o_info.p;
+        a.ctl = h->ctl.p;
+        a.mail = h->d_mail;
+        a.stop = h->d_stop;
+        a.stamps = trace ? rs.stamps.p + 16 * (size_t)i : nullptr;
+    }
+    SE2_HIP(hipMemcpyAsync(rs.dev.p, rs.host.p, (size_t)count * sizeof(WindowArgs), hipMemcpyHostToDevice, st));
+    {
+        std::lock_guard<std::mutex> lk(launch_mu);
+        SE2_CHECK(ba_window_launch(rs.dev.p, count, threads, lds, st));
+    }
+    for (int i = 0; i < count; ++i) {
+        hs[i]->dev_seq += 1;
+        hs[i]->run_seq = hs[i]->dev_seq;
+    }
+    bool refused = false;
+    for (int i = 0; i < count; ++i) {
+        se2gpu_ba* h = hs[i];
+        volatile double* mb = h->h_mail;
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (mb[kMailSeq] != h->run_seq) {
+            __builtin_ia32_pause();
+            if (stop_flag && *stop_flag)
+                for (int j = 0; j < count; ++j) *hs[j]->h_stop = 1;
+            if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                SE2_HIP(hipStreamSynchronize(st));
+                SE2_REQUIRE(mb[kMailSeq] == h->run_seq, SE2GPU_ERR_HIP, "window %d of the resident batch never reported back", i);
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        refused |= ba_posted(h)->error == 2;
+    }
+    SE2_HIP(hipStreamSynchronize(st));   // (the argument packs are leased: nothing of this call may be in flight when they go back)
+    if (trace) {
+        std::vector<long long> hst(16 * (size_t)count);
+        SE2_HIP(hipMemcpy(hst.data(), rs.stamps.p, hst.size() * 8, hipMemcpyDeviceToHost));
+        const long long* s0 = hst.data();
+        std::fprintf(stderr, "se2gpu_ba resident: window 0, last trial: build %.1f us, factorise %.1f us, back-substitute %.1f us, update %.1f us (%d threads, %zu B LDS)\n",
+                     (s0[1] - s0[0]) * 0.01, (s0[2] - s0[1]) * 0.01, (s0[3] - s0[2]) * 0.01, (s0[4] - s0[3]) * 0.01, threads, lds);
+    }
+    if (refused) {
+        // a window holds a landmark the kernel does not take (more than 64 observations, or more wide landmarks than it lists):
+        // the refused windows have not been touched; the batch is finished by the other paths, window by window
+        for (int i = 0; i < count; ++i) {
+            se2gpu_ba* h = hs[i];
+            if (ba_posted(h)->error != 2) { SE2_CHECK(ba_run_finish(h, stats ? stats + i : nullptr)); continue; }
+            hipLaunchKernelGGL(k_ctl_clear_error, dim3(1), dim3(1), 0, h->stream, h->ctl.p);
+            SE2_HIP(hipGetLastError());
+            SE2_CHECK(se2gpu_ba_optimize(h, iters, mode, stop_flag, 0, stats ? stats + i : nullptr));
+        }
+        *handled = 1;
+        return SE2GPU_OK;
+    }
+    for (int i = 0; i < count; ++i) SE2_CHECK(ba_run_finish(hs[i], stats ? stats + i : nullptr));
+    *handled = 1;
+    return SE2GPU_OK;
+}
+
 // optimize() of `count` windows in lock step.  *handled = 0 when the windows are not all eligible (the caller falls back
 // to one stream per window).
 int ba_optimize_lockstep(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
@@ -6418,6 +6380,11 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
     // A local window is a dozen launches per LM iteration; one host thread enqueues ~0.3 M launches per second, which is
     // what bounds many small windows in flight.  The windows are therefore dealt to a few enqueue threads (each window
     // stays on one thread: a handle is not thread-safe, its stream is its own).  SE2GPU_BA_BATCH_THREADS overrides.
+    {   // one workgroup per window for its whole optimize(), when the batch is large enough to fill compute units that way
+        int handled = 0;
+        const int rc = ba_optimize_resident(hs, count, iters, mode, stop_flag, stats, &handled);
+        if (handled || rc != SE2GPU_OK) return rc;
+    }
     {   // one launch per stage for all windows, when every window qualifies (model 0, one GPU, dataflow solve)
         int handled = 0;
         const int rc = ba_optimize_lockstep(hs, count, iters, mode, stop_flag, stats, &handled);
