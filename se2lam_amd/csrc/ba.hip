@@ -2834,6 +2834,11 @@ struct IdTable {
 constexpr int kMailDoubles = 256, kMailStop = 250;
 static_assert(8 + sizeof(BaCtl) / 8 <= kMailStop, "controller block does not fit the mailbox");
 
+// how many handle streams have been destroyed so far: an event that was last recorded on a stream which no longer exists must not be
+// handed to hipEventSynchronize any more (the runtime looks at the stream: "operation not permitted on an event last recorded in a
+// capturing stream", or worse) - se2gpu_ba_reset_estimates_batch keeps such events across calls and compares this count
+inline std::atomic<unsigned long>& streams_destroyed() { static std::atomic<unsigned long> n{0}; return n; }
+
 struct se2gpu_ba {
     hipStream_t own_stream = nullptr, stream = nullptr;
     LaunchProfile prof;
@@ -2977,7 +2982,10 @@ struct se2gpu_ba {
         if (ev_copy1) (void)hipEventDestroy(ev_copy1);
         if (ev_pat) (void)hipEventDestroy(ev_pat);
         drop_graphs();
-        if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (own_stream) {
+            (void)hipStreamDestroy(own_stream);
+            streams_destroyed().fetch_add(1, std::memory_order_relaxed);
+        }
         if (h_mail) (void)hipHostFree(h_mail);
     }
 };
@@ -4953,6 +4961,7 @@ struct ResetScratch {
     DevBuf<ResetItem> dev;
     hipEvent_t ring[64] = {};
     unsigned next = 0;
+    unsigned long deaths = 0;   // streams_destroyed() when the ring's last event was recorded
 };
 
 // a window the lock-step path can take: SE(2) model, one GPU, device controller, dataflow solve, no per-kernel profile
@@ -5627,7 +5636,12 @@ int se2gpu_ba_reset_estimates_batch(se2gpu_ba** hs, int count) {
     hipStream_t st = hs[0]->stream;
     SE2_CHECK(ba_join(hs[0]));
     // the staging buffer of the previous call may still be read by its copy: the ring's event of that call says when not
-    if (sc->next) SE2_HIP(hipEventSynchronize(sc->ring[(sc->next - 1) % 64]));
+    if (sc->next) {
+        // (that event sits on the stream of the previous call's first window; if any handle stream has been destroyed since, it
+        // may be that one - then the whole device is waited for instead: rare, a batch of windows has just been torn down)
+        if (sc->deaths == streams_destroyed().load(std::memory_order_relaxed)) SE2_HIP(hipEventSynchronize(sc->ring[(sc->next - 1) % 64]));
+        else SE2_HIP(hipDeviceSynchronize());
+    }
     SE2_CHECK(sc->host.reserve((size_t)count));
     SE2_CHECK(sc->dev.reserve((size_t)count));
     unsigned most = 1;
@@ -5655,6 +5669,7 @@ int se2gpu_ba_reset_estimates_batch(se2gpu_ba** hs, int count) {
     hipEvent_t& e = sc->ring[sc->next++ % 64];
     if (!e) SE2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     SE2_HIP(hipEventRecord(e, st));
+    sc->deaths = streams_destroyed().load(std::memory_order_relaxed);
     for (int i = 0; i < count; ++i) {
         hs[i]->join_event = e;
         hs[i]->join_stream = st;
@@ -6035,7 +6050,7 @@ int ba_run_finish(se2gpu_ba* h, se2gpu_ba_stats* stats) {
 
 // ---- optimize() of `count` windows, ONE WORKGROUP PER WINDOW (csrc/ba_window.hip): every window lives in one compute unit's
 // LDS for its whole optimize(iters) - no per-edge records, no launches per trial.  Taken for batches of SE2GPU_BA_RESIDENT_MIN
-// windows or more (default 12: below that the multi-launch paths, which spread a window over the chip, finish a batch sooner)
+// windows or more (default 96: below that the multi-launch paths, which spread a window over the chip, finish a batch sooner)
 // whose windows all fit (SE(2) model, one GPU, at most ~60 free key frames, no landmark with more than 64 observations).
 // SE2GPU_BA_RESIDENT=0 switches the path off, =1 takes it for any batch.  *handled = 0: the caller goes on to the other paths.
 struct ResidentScratch {
@@ -6054,7 +6069,7 @@ int ba_resident_threads(const se2gpu_ba* h, size_t* lds) {
 }
 bool ba_resident_ok(const se2gpu_ba* h) {
     return h->initialized && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->prof.enabled && h->d_mail &&
-           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P;
+           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P && h->Hpl.p && h->Hpl.cap * 8 >= (size_t)h->L * 16;
 }
 int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
                          se2gpu_ba_stats* stats, int* handled) {
@@ -6062,7 +6077,7 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
     // (read per call, not once: a test - or a mapper - can switch the path between two batches)
     const char* e_on = getenv("SE2GPU_BA_RESIDENT");
     const char* e_min = getenv("SE2GPU_BA_RESIDENT_MIN");
-    const int env_on = e_on ? atoi(e_on) : -1, env_min = e_min ? atoi(e_min) : 12;
+    const int env_on = e_on ? atoi(e_on) : -1, env_min = e_min ? atoi(e_min) : 96;
     if (env_on == 0 || count < 1 || (env_on != 1 && count < env_min) || ba_env_sync() || iters < 0) return SE2GPU_OK;
     if (mode != SE2GPU_BA_LM && mode != SE2GPU_BA_GN) return SE2GPU_OK;
     int threads = 512;
@@ -6118,6 +6133,8 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         a.ctl = h->ctl.p;
         a.mail = h->d_mail;
         a.stop = h->d_stop;
+        a.desc = reinterpret_cast<int4*>(h->Hpl.p);   // (the multi-launch path's W records: 72 B per edge, idle on this path)
+        { const char* e = getenv("SE2GPU_BA_RESIDENT_DEBUG"); a.debug = e ? atoi(e) : 0; }
         a.stamps = trace ? rs.stamps.p + 16 * (size_t)i : nullptr;
     }
     SE2_HIP(hipMemcpyAsync(rs.dev.p, rs.host.p, (size_t)count * sizeof(WindowArgs), hipMemcpyHostToDevice, st));
@@ -6156,7 +6173,7 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
                      (s0[1] - s0[0]) * 0.01, (s0[2] - s0[1]) * 0.01, (s0[3] - s0[2]) * 0.01, (s0[4] - s0[3]) * 0.01, threads, lds);
     }
     if (refused) {
-        // a window holds a landmark the kernel does not take (more than 64 observations, or more wide landmarks than it lists):
+        // a window holds a landmark the kernel does not take (more than 64 observations):
         // the refused windows have not been touched; the batch is finished by the other paths, window by window
         for (int i = 0; i < count; ++i) {
             se2gpu_ba* h = hs[i];

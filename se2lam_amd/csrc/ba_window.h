@@ -25,11 +25,12 @@ struct WindowArgs {
     badev::BaCtl* ctl;        // the window's controller block (device)
     double* mail;             // device address of the window's mapped mailbox, or NULL
     const int* stop;          // device address of the mapped force-stop word, or NULL
+    int4* desc;               // L x 16 B of scratch: the kernel lists the landmarks by their observation counts here
+    int debug;
     long long* stamps;        // debug: 16 phase time stamps (100 MHz wall clock) of the LAST trial, or NULL
 };
 
 constexpr int kWindowMaxDegree = 64;     // observations of one landmark the kernel takes (a wave per landmark beyond 16)
-constexpr int kWindowBigCap = 1024;      // landmarks with more than 8 observations it lists per window
 
 // dynamic LDS a window of P poses, nfree of them free, needs with `threads` threads per workgroup (0: does not fit 160 KiB)
 size_t ba_window_lds_bytes(int P, int nfree, int threads);

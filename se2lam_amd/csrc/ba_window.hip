@@ -27,8 +27,7 @@
 // 26 MB.  Sums into S are atomic, hence in no fixed order: results agree with the multi-launch path and the oracle to
 // rounding (1e-12 relative on the cost), not bit for bit - the parity bar of this path is north_star's 1e-5.
 //
-// Landmarks with more than 8 observations take 16 lanes, with more than 16 a whole wave; more than 64 is refused
-// (BaCtl::error = 2: the caller runs the window on the multi-launch path).
+// A landmark with more than 64 observations is refused (BaCtl::error = 2: the caller runs the window on the multi-launch path).
 #include "ba_window.h"
 
 using namespace se2gpu;
@@ -54,17 +53,15 @@ constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
 constexpr int kDppHalfMirror = 0x141;   // lane i <-> 7 - i inside every 8 lanes
 constexpr int kDppMirror = 0x140;       // lane i <-> 15 - i inside every 16 lanes
 
-// the sum over an aligned group of G lanes, in every lane of the group
+// the sum over an aligned group of G lanes (4, 8, 16, 32 or 64), in every lane of the group
 template <int G>
 __device__ __forceinline__ double gsum(double v) {
     v += dpp_move<kDppXor1>(v);
     v += dpp_move<kDppXor2>(v);
-    v += dpp_move<kDppHalfMirror>(v);
+    if (G >= 8) v += dpp_move<kDppHalfMirror>(v);
     if (G >= 16) v += dpp_move<kDppMirror>(v);
-    if (G >= 64) {
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-    }
+    if (G >= 32) v += __shfl_xor(v, 16);
+    if (G >= 64) v += __shfl_xor(v, 32);
     return v;
 }
 __device__ __forceinline__ double wsum(double v) { return gsum<64>(v); }
@@ -76,8 +73,41 @@ __device__ __forceinline__ double wmax(double v) {
 
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }   // packed lower triangle, r >= c
 
+__shared__ int g_dbg;
 __device__ __forceinline__ void lds_add(double* p, double v) {
+    if (g_dbg & 2) { *p += v; return; }
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// 1 / x and 1 / sqrt(x) from the hardware's seeds (v_rcp_f64 / v_rsq_f64: ~26 good bits) and two Newton steps: within an ulp or two of
+// the correctly rounded value at 5 / 9 instructions, where the compiler's IEEE division and square root take 12 / 25
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// A = G^-1 for M = h + lambda I = G G^T (badev::chol_inv3 with the reciprocal square roots above; the same pivot floor)
+__device__ __forceinline__ void chol3(const double h[6], double lambda, double a[6]) {
+    const double m00 = h[0] + lambda, m10 = h[1], m20 = h[2], m11 = h[3] + lambda, m21 = h[4], m22 = h[5] + lambda;
+    const double floor_ = fmax(1e-30 * (m00 + m11 + m22), 1e-300);
+    const double a00 = fast_rsqrt(fmax(m00, floor_));
+    const double g10 = m10 * a00, g20 = m20 * a00;
+    const double a11 = fast_rsqrt(fmax(m11 - g10 * g10, floor_));
+    const double g21 = (m21 - g20 * g10) * a11;
+    const double a22 = fast_rsqrt(fmax(m22 - g20 * g20 - g21 * g21, floor_));
+    const double a10 = -(a11 * g10) * a00;
+    const double a21 = -(a22 * g21) * a11;
+    const double a20 = -(a21 * g10 + a22 * g20) * a00;
+    a[0] = a00; a[1] = a10; a[2] = a11; a[3] = a20; a[4] = a21; a[5] = a22;
 }
 
 // EdgeSE2XYZ (EdgeSE2XYZ.cpp:61-106) with the pose's sine / cosine at hand
@@ -95,7 +125,7 @@ __device__ __forceinline__ void edge_se2xyz(const CamDev& cam, double px, double
     const double X = R[0] * dx + R[1] * dy + R[2] * lz + cam.tcb[0];
     const double Y = R[3] * dx + R[4] * dy + R[5] * lz + cam.tcb[1];
     const double Z = R[6] * dx + R[7] * dy + R[8] * lz + cam.tcb[2];
-    const double zi = 1.0 / Z;
+    const double zi = fast_rcp(Z);
     e0 = cam.fx * X * zi + cam.cx - u;
     e1 = cam.fx * Y * zi + cam.cy - v;
     if (JAC) {
@@ -111,9 +141,9 @@ __device__ __forceinline__ void edge_se2xyz(const CamDev& cam, double px, double
     }
 }
 
-enum { kEval = 0, kDiag = 1, kBuild = 2, kUpdate = 3 };
+enum { kEval = 0, kDiag = 1, kUpdate = 3 };
 
-// what a pass needs of the window, all in LDS except the edge arrays and the landmarks
+// what a pass needs of the window, all in LDS except the edge arrays, the landmarks and the landmark order
 struct Ctx {
     const WindowArgs* a;
     double* S;          // packed lower triangle of the augmented system, rows 0 .. n-1 = S, row n = b_s
@@ -126,42 +156,76 @@ struct Ctx {
     double* stage;      // this wave's staging strip: 64 lanes x kStageDoubles
     const double* lms;  // L x 3: the estimate's landmarks
     double* lms_trial;  // L x 3: the other buffer
+    const int4* desc;   // L: {landmark, first edge, observations, -} by ascending number of observations (made by the prologue)
     int n;
     double lambda;
 };
 
-// One landmark by an aligned group of G lanes (a lane per observation).  Returns through chi / scale / dmax the lane's
-// contributions (to be summed / maximised over the workgroup by the caller).
+struct EdgeIn {   // one observation as it comes from memory
+    int kf;
+    double u, v, w0, w1, w2;
+};
+__device__ __forceinline__ EdgeIn load_edge(const WindowArgs& a, int e) {
+    EdgeIn r;
+    r.kf = a.e_kf[e];
+    const double2 uv = reinterpret_cast<const double2*>(a.e_uv)[e];
+    r.u = uv.x; r.v = uv.y;
+    r.w0 = a.e_info[3 * (size_t)e]; r.w1 = a.e_info[3 * (size_t)e + 1]; r.w2 = a.e_info[3 * (size_t)e + 2];
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// All passes: one lane per OBSERVATION, an aligned group of G lanes per landmark (G = 4, 8, 16 or 64 by the landmark's count; the
+// landmarks are visited in ascending order of their counts, so a wave's groups are of a kind and consecutive lanes read consecutive
+// edges).
+// ------------------------------------------------------------------------------------------------------------------
+struct GroupIn {
+    int l, beg, k;
+    double lx, ly, lz;
+    EdgeIn ed;
+    bool has;
+};
+// a landmark's descriptor {landmark, first edge, observations, -} from the list the prologue made; zero beyond the class's end
+__device__ __forceinline__ int4 load_desc(const Ctx& c, int idx, int end) {
+    return idx < end ? c.desc[idx] : make_int4(0, 0, 0, 0);
+}
+template <int G>
+__device__ __forceinline__ GroupIn load_group(const Ctx& c, const int4 d, int lane) {
+    const WindowArgs& a = *c.a;
+    GroupIn g;
+    g.l = d.x; g.beg = d.y; g.k = d.z; g.lx = 0; g.ly = 0; g.lz = 1; g.has = false;
+    g.ed = EdgeIn{0, 0, 0, 0, 0, 0};
+    if (g.k > 0) {
+        g.lx = c.lms[3 * (size_t)g.l]; g.ly = c.lms[3 * (size_t)g.l + 1]; g.lz = c.lms[3 * (size_t)g.l + 2];
+        const int sub = lane & (G - 1);
+        g.has = sub < g.k;
+        if (g.has) g.ed = load_edge(a, g.beg + sub);
+    }
+    return g;
+}
+
+// EVAL / DIAG / UPDATE of one landmark.  Nothing but sums crosses lanes: Hll, bl and - for the back-substitution -
+// q = sum_e Hlp_e dp_e, and then   x_l = (Hll + lambda I)^-1 (bl - q)   needs neither W_e nor a second look at the Jacobians
+// (sum_e W_e^T dp_e = A q: the factor A comes out of the sum).
 template <int MODE, int G>
-__device__ __forceinline__ void landmark(const Ctx& c, int l, bool valid, int lane, double& chi, double& scale, double& dmax) {
+__device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int lane, double& chi, double& scale, double& dmax) {
     const WindowArgs& a = *c.a;
     const int sub = lane & (G - 1);
-    int beg = 0, k = 0;
-    if (valid) {
-        beg = a.lm_ptr[l];
-        k = a.lm_ptr[l + 1] - beg;
-    }
-    const bool has = sub < k;
-    const int e = has ? beg + sub : 0;
-    int kf = 0;
-    double u = 0, v = 0, w0 = 0, w1 = 0, w2 = 0, lx = 0, ly = 0, lz = 1;
-    if (has) {
-        kf = a.e_kf[e];
-        u = a.e_uv[2 * (size_t)e]; v = a.e_uv[2 * (size_t)e + 1];
-        w0 = a.e_info[3 * (size_t)e]; w1 = a.e_info[3 * (size_t)e + 1]; w2 = a.e_info[3 * (size_t)e + 2];
-    }
-    if (valid) { lx = c.lms[3 * (size_t)l]; ly = c.lms[3 * (size_t)l + 1]; lz = c.lms[3 * (size_t)l + 2]; }
+    const bool has = g.has;
+    const int kf = g.ed.kf;
+    const double w0 = g.ed.w0, w1 = g.ed.w1, w2 = g.ed.w2;
     const double px = c.cur[3 * kf], py = c.cur[3 * kf + 1], ps = c.scur[2 * kf], pc = c.scur[2 * kf + 1];
-    const int c0 = has ? c.col[kf] : -1;
-    double e0, e1, Jp[6], Jl[6];
+    double e0, e1;
     if (MODE == kEval) {
-        edge_se2xyz<false>(a.cam, px, py, ps, pc, lx, ly, lz, u, v, e0, e1, nullptr, nullptr);
+        edge_se2xyz<false>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, nullptr, nullptr);
         double r0, r1;
         huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, r0, r1);
         if (has) chi += r0;
         return;
     }
-    edge_se2xyz<true>(a.cam, px, py, ps, pc, lx, ly, lz, u, v, e0, e1, Jp, Jl);
+    const int c0 = has ? c.col[kf] : -1;
+    double Jp[6], Jl[6];
+    edge_se2xyz<true>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, Jp, Jl);
     const double we0 = w0 * e0 + w1 * e1, we1 = w1 * e0 + w2 * e1;
     double r0, r1;
     huber(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
@@ -169,9 +233,120 @@ __device__ __forceinline__ void landmark(const Ctx& c, int l, bool valid, int la
     const double or0 = -r1 * we0, or1 = -r1 * we1;            // omega_r
     double WJl[6];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        WJl[q] = W0 * Jl[q] + W1 * Jl[3 + q];
-        WJl[3 + q] = W1 * Jl[q] + W2 * Jl[3 + q];
+    for (int m = 0; m < 3; ++m) {
+        WJl[m] = W0 * Jl[m] + W1 * Jl[3 + m];
+        WJl[3 + m] = W1 * Jl[m] + W2 * Jl[3 + m];
+    }
+    double acc[12];   // hll (6) | bl (3) | q (3)
+    acc[0] = Jl[0] * WJl[0] + Jl[3] * WJl[3];
+    acc[1] = Jl[0] * WJl[1] + Jl[3] * WJl[4];
+    acc[2] = Jl[0] * WJl[2] + Jl[3] * WJl[5];
+    acc[3] = Jl[1] * WJl[1] + Jl[4] * WJl[4];
+    acc[4] = Jl[1] * WJl[2] + Jl[4] * WJl[5];
+    acc[5] = Jl[2] * WJl[2] + Jl[5] * WJl[5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[6 + r] = Jl[r] * or0 + Jl[3 + r] * or1;
+    acc[9] = acc[10] = acc[11] = 0.0;
+    if (c0 >= 0) {
+        if (MODE == kDiag) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double wj0 = W0 * Jp[r] + W1 * Jp[3 + r], wj1 = W1 * Jp[r] + W2 * Jp[3 + r];
+                lds_add(c.x + c0 + r, Jp[r] * wj0 + Jp[3 + r] * wj1);
+            }
+        } else {
+            const double d0 = c.x[c0], d1 = c.x[c0 + 1], d2 = c.x[c0 + 2];
+            const double v0 = Jp[0] * d0 + Jp[1] * d1 + Jp[2] * d2, v1 = Jp[3] * d0 + Jp[4] * d1 + Jp[5] * d2;   // Jp dp
+#pragma unroll
+            for (int m = 0; m < 3; ++m) acc[9 + m] = WJl[m] * v0 + WJl[3 + m] * v1;    // Hlp_e dp_e = Jl^T Omega' (Jp dp)
+            scale += v0 * or0 + v1 * or1;                                              // dp . b_e, the edge's share of dp . b_p
+        }
+    }
+    if (!has) {   // (its arithmetic ran on a made-up edge and may hold infinities: nothing of it may reach the group's sums)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) acc[i] = 0.0;
+    }
+    if (MODE == kDiag) {   // lambda_0 = 1e-5 max diag H (computeLambdaInit): the landmark blocks' diagonals
+        const double h0 = gsum<G>(acc[0]), h3 = gsum<G>(acc[3]), h5 = gsum<G>(acc[5]);
+        if (g.k > 0) dmax = fmax(dmax, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = gsum<G>(acc[i]);
+    double xl[3] = {0, 0, 0};
+    if (g.k > 0) {
+        double A[6];
+        chol3(acc, c.lambda, A);
+        const double g0 = acc[6] - acc[9], g1 = acc[7] - acc[10], g2 = acc[8] - acc[11];
+        const double t0 = A[0] * g0, t1 = A[1] * g0 + A[2] * g1, t2 = A[3] * g0 + A[4] * g1 + A[5] * g2;    // A (bl - q)
+        xl[0] = A[0] * t0 + A[1] * t1 + A[3] * t2;                                                           // A^T (...)
+        xl[1] = A[2] * t1 + A[4] * t2;
+        xl[2] = A[5] * t2;
+    }
+    const double nxl = g.lx + xl[0], nyl = g.ly + xl[1], nzl = g.lz + xl[2];
+    if (g.k > 0 && sub == 0) {
+        c.lms_trial[3 * (size_t)g.l] = nxl; c.lms_trial[3 * (size_t)g.l + 1] = nyl; c.lms_trial[3 * (size_t)g.l + 2] = nzl;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) scale += xl[m] * (c.lambda * xl[m] + acc[6 + m]);
+    }
+    if (has) {   // robust chi^2 of the observation at the trial state
+        edge_se2xyz<false>(a.cam, c.trl[3 * kf], c.trl[3 * kf + 1], c.strl[2 * kf], c.strl[2 * kf + 1], nxl, nyl, nzl, g.ed.u, g.ed.v, e0, e1, nullptr, nullptr);
+        double q0, q1;
+        huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, q0, q1);
+        chi += q0;
+    }
+}
+
+// the landmarks [begin, end) of the order, G lanes each; the next group's operands are in flight while this one is worked on
+template <int MODE, int G, int NT>
+__device__ __forceinline__ void eval_class(const Ctx& c, int begin, int end, double& chi, double& scale, double& dmax) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (begin >= end) return;
+    constexpr int kStep = NT / G;
+    GroupIn nx = load_group<G>(c, load_desc(c, begin + tid / G, end), lane);
+    int4 d2 = load_desc(c, begin + kStep + tid / G, end);
+    for (int i0 = begin; i0 < end; i0 += kStep) {
+        const GroupIn g = nx;
+        nx = load_group<G>(c, d2, lane);
+        d2 = load_desc(c, i0 + 2 * kStep + tid / G, end);
+        eval_group<MODE, G>(c, g, lane, chi, scale, dmax);
+    }
+}
+// landmarks without an observation keep their place: their trial position is their position
+template <int NT>
+__device__ __forceinline__ void copy_unobserved(const Ctx& c, int end) {
+    for (int i = threadIdx.x; i < end; i += NT) {
+        const int l = c.desc[i].x;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) c.lms_trial[3 * (size_t)l + m] = c.lms[3 * (size_t)l + m];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BUILD of one landmark
+// ------------------------------------------------------------------------------------------------------------------
+template <int G>
+__device__ __forceinline__ void build_group(const Ctx& c, const GroupIn& g, int lane) {
+    const WindowArgs& a = *c.a;
+    const int sub = lane & (G - 1);
+    const int k = g.k;
+    const bool has = g.has;
+    const int kf = g.ed.kf;
+    const double w0 = g.ed.w0, w1 = g.ed.w1, w2 = g.ed.w2;
+    const double px = c.cur[3 * kf], py = c.cur[3 * kf + 1], ps = c.scur[2 * kf], pc = c.scur[2 * kf + 1];
+    const int c0 = has ? c.col[kf] : -1;
+    double e0, e1, Jp[6], Jl[6];
+    edge_se2xyz<true>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, Jp, Jl);
+    const double we0 = w0 * e0 + w1 * e1, we1 = w1 * e0 + w2 * e1;
+    double r0, r1;
+    huber(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
+    const double W0 = r1 * w0, W1 = r1 * w1, W2 = r1 * w2;    // weightedOmega
+    const double or0 = -r1 * we0, or1 = -r1 * we1;            // omega_r
+    double WJl[6];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        WJl[m] = W0 * Jl[m] + W1 * Jl[3 + m];
+        WJl[3 + m] = W1 * Jl[m] + W2 * Jl[3 + m];
     }
     double hll[6], b[3];
     hll[0] = Jl[0] * WJl[0] + Jl[3] * WJl[3];
@@ -188,29 +363,16 @@ __device__ __forceinline__ void landmark(const Ctx& c, int l, bool valid, int la
 #pragma unroll
         for (int i = 0; i < 3; ++i) b[i] = 0.0;
     }
-    const bool fr = c0 >= 0;
-    if (MODE == kDiag) {
-        // lambda_0 = 1e-5 max diag H (computeLambdaInit): the landmark blocks' diagonals here, the free poses' by atomics
-        const double h0 = gsum<G>(hll[0]), h3 = gsum<G>(hll[3]), h5 = gsum<G>(hll[5]);
-        if (valid) dmax = fmax(dmax, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
-        if (fr) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const double wj0 = W0 * Jp[r] + W1 * Jp[3 + r], wj1 = W1 * Jp[r] + W2 * Jp[3 + r];
-                lds_add(c.x + c0 + r, Jp[r] * wj0 + Jp[3 + r] * wj1);
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int i = 0; i < 6; ++i) hll[i] = gsum<G>(hll[i]);
 #pragma unroll
     for (int i = 0; i < 3; ++i) b[i] = gsum<G>(b[i]);
     double A[6], zt[3];
-    chol_inv3(hll, c.lambda, A);
+    chol3(hll, c.lambda, A);
     zt[0] = A[0] * b[0];
     zt[1] = A[1] * b[0] + A[2] * b[1];
     zt[2] = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
+    const bool fr = c0 >= 0;
     // W_e = Hpl_e A^T, Hpl_e = Jp^T (Omega' Jl)  (zero for a fixed pose: constructQuadraticForm skips it)
     double Wm[9];
 #pragma unroll
@@ -222,129 +384,95 @@ __device__ __forceinline__ void landmark(const Ctx& c, int l, bool valid, int la
         Wm[r * 3 + 1] = h0 * A[1] + h1 * A[2];
         Wm[r * 3 + 2] = h0 * A[3] + h1 * A[4] + h2 * A[5];
     }
-    double bpe[3];
+    if (fr) {
+        double WJp[6];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) bpe[r] = fr ? Jp[r] * or0 + Jp[3 + r] * or1 : 0.0;
-
-    if (MODE == kBuild) {
-        if (fr) {
-            double WJp[6];
+        for (int m = 0; m < 3; ++m) {
+            WJp[m] = W0 * Jp[m] + W1 * Jp[3 + m];
+            WJp[3 + m] = W1 * Jp[m] + W2 * Jp[3 + m];
+        }
+        // the pose's own block: Hpp_e - W_e W_e^T (lower triangle) and its right-hand side b_e - W_e zeta
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                WJp[q] = W0 * Jp[q] + W1 * Jp[3 + q];
-                WJp[3 + q] = W1 * Jp[q] + W2 * Jp[3 + q];
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int m = 0; m <= r; ++m) {
+                const double hpp = Jp[r] * WJp[m] + Jp[3 + r] * WJp[3 + m];
+                const double ww = Wm[r * 3] * Wm[m * 3] + Wm[r * 3 + 1] * Wm[m * 3 + 1] + Wm[r * 3 + 2] * Wm[m * 3 + 2];
+                lds_add(c.S + tri(c0 + r, c0 + m), hpp - ww);
             }
-            // the pose's own block: Hpp_e - W_e W_e^T (lower triangle) and its right-hand side b_e - W_e zeta
+            const double bpe = Jp[r] * or0 + Jp[3 + r] * or1;
+            lds_add(c.S + tri(c.n, c0 + r), bpe - (Wm[r * 3] * zt[0] + Wm[r * 3 + 1] * zt[1] + Wm[r * 3 + 2] * zt[2]));
+        }
+    }
+    // the pair products of the landmark's observations: every lane puts W_e and its column into the wave's strip, lane i then takes
+    // the partners (i + s) mod k, s = 1 .. k / 2 (the pairs at distance k / 2 of an even k only from the lower half)
+    double* mine = c.stage + (size_t)lane * kStageDoubles;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+    for (int i = 0; i < 9; ++i) mine[i] = Wm[i];
+    mine[9] = (double)c0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int half = k >> 1;
+    int smax = half;
 #pragma unroll
-                for (int q = 0; q <= r; ++q) {
-                    const double hpp = Jp[r] * WJp[q] + Jp[3 + r] * WJp[3 + q];
-                    const double ww = Wm[r * 3] * Wm[q * 3] + Wm[r * 3 + 1] * Wm[q * 3 + 1] + Wm[r * 3 + 2] * Wm[q * 3 + 2];
-                    lds_add(c.S + tri(c0 + r, c0 + q), hpp - ww);
+    for (int m = G; m < 64; m <<= 1) smax = max(smax, __shfl_xor(smax, m));   // the wave's longest landmark sets the trip count
+    const int gbase = lane & ~(G - 1);
+    if (g_dbg & 1) smax = 0;
+    for (int s = 1; s <= smax; ++s) {
+        const bool act = has && s <= half && !(2 * s == k && sub >= half);
+        int j = sub + s;
+        if (j >= k) j -= k;
+        const double* his = c.stage + (size_t)(gbase + (act ? j : sub)) * kStageDoubles;
+        double Wp[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Wp[i] = his[i];
+        const int cp = (int)his[9];
+        if (act && fr && cp >= 0) {
+            // block (mine, his) of S loses W_mine W_his^T; it is stored where row > column.  (Two observations of one landmark by
+            // the SAME key frame - the reference never builds that - land in the pose's own block: P + P^T, lower triangle.)
+            const bool lower = c0 > cp, same = c0 == cp;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    double pr = Wm[r * 3] * Wp[m * 3] + Wm[r * 3 + 1] * Wp[m * 3 + 1] + Wm[r * 3 + 2] * Wp[m * 3 + 2];
+                    int at = lower ? tri(c0 + r, cp + m) : tri(cp + m, c0 + r);
+                    if (same) { at = tri(c0 + max(r, m), c0 + min(r, m)); if (r == m) pr *= 2.0; }
+                    lds_add(c.S + at, -pr);
                 }
-                lds_add(c.S + tri(c.n, c0 + r), bpe[r] - (Wm[r * 3] * zt[0] + Wm[r * 3 + 1] * zt[1] + Wm[r * 3 + 2] * zt[2]));
-            }
         }
-        // the pair products of the landmark's observations: every lane puts W_e and its column into the wave's strip, lane i then
-        // takes the partners (i + s) mod k, s = 1 .. k / 2 (the pairs at distance k / 2 of an even k only from the lower half)
-        double* mine = c.stage + (size_t)lane * kStageDoubles;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) mine[i] = Wm[i];
-        mine[9] = (double)c0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int half = k >> 1;
-        int smax = half;
-#pragma unroll
-        for (int m = G; m < 64; m <<= 1) smax = max(smax, __shfl_xor(smax, m));   // the wave's longest landmark sets the trip count
-        const int gbase = lane & ~(G - 1);
-        for (int s = 1; s <= smax; ++s) {
-            const bool act = has && s <= half && !(2 * s == k && sub >= half);
-            int j = sub + s;
-            if (j >= k) j -= k;
-            const double* his = c.stage + (size_t)(gbase + (act ? j : sub)) * kStageDoubles;
-            double Wp[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Wp[i] = his[i];
-            const int cp = (int)his[9];
-            if (act && fr && cp >= 0) {
-                // block (mine, his) of S loses W_mine W_his^T; it is stored where row > column
-                const bool lower = c0 > cp;
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const double pr = Wm[r * 3] * Wp[q * 3] + Wm[r * 3 + 1] * Wp[q * 3 + 1] + Wm[r * 3 + 2] * Wp[q * 3 + 2];
-                        lds_add(c.S + (lower ? tri(c0 + r, cp + q) : tri(cp + q, c0 + r)), -pr);
-                    }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        return;
     }
-
-    // ---- kUpdate: back-substitution, trial landmark, robust chi^2 at the trial state, the gain denominator
-    double dp[3] = {0, 0, 0};
-    if (fr) { dp[0] = c.x[c0]; dp[1] = c.x[c0 + 1]; dp[2] = c.x[c0 + 2]; }
-    double t[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) t[q] = gsum<G>(Wm[q] * dp[0] + Wm[3 + q] * dp[1] + Wm[6 + q] * dp[2]);   // sum_e W_e^T dp_e
-    const double t0 = zt[0] - t[0], t1 = zt[1] - t[1], t2 = zt[2] - t[2];
-    double xl[3];
-    xl[0] = A[0] * t0 + A[1] * t1 + A[3] * t2;                 // x_l = A^T (zeta - sum_e W_e^T dp_e)
-    xl[1] = A[2] * t1 + A[4] * t2;
-    xl[2] = A[5] * t2;
-    const double nx = lx + xl[0], ny = ly + xl[1], nz = lz + xl[2];
-    if (valid && sub == 0) {
-        c.lms_trial[3 * (size_t)l] = nx; c.lms_trial[3 * (size_t)l + 1] = ny; c.lms_trial[3 * (size_t)l + 2] = nz;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) scale += xl[q] * (c.lambda * xl[q] + b[q]);
-    }
-    if (has) {
-        scale += dp[0] * bpe[0] + dp[1] * bpe[1] + dp[2] * bpe[2];   // the landmark edges' share of dp . b_p
-        edge_se2xyz<false>(a.cam, c.trl[3 * kf], c.trl[3 * kf + 1], c.strl[2 * kf], c.strl[2 * kf + 1], nx, ny, nz, u, v, e0, e1, nullptr, nullptr);
-        double q0, q1;
-        huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, q0, q1);
-        chi += q0;
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-// all landmarks of the window: 8 lanes each; those with more observations from the list the prologue made, 16 lanes or a wave each
-template <int MODE, int NT>
-__device__ __forceinline__ void landmark_pass(const Ctx& c, const int* big, int nbig, double& chi, double& scale, double& dmax) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L = c.a->L;
-    for (int l0 = 0; l0 < L; l0 += NT / 8) {
-        const int l = l0 + tid / 8;
-        bool valid = l < L;
-        if (valid) valid = c.a->lm_ptr[l + 1] - c.a->lm_ptr[l] <= 8;
-        landmark<MODE, 8>(c, l, valid, lane, chi, scale, dmax);
-    }
-    for (int i0 = 0; i0 < nbig; i0 += NT / 16) {
-        const int i = i0 + tid / 16;
-        bool valid = i < nbig;
-        const int l = valid ? big[i] : 0;
-        if (valid) valid = c.a->lm_ptr[l + 1] - c.a->lm_ptr[l] <= 16;
-        landmark<MODE, 16>(c, l, valid, lane, chi, scale, dmax);
-    }
-    for (int i = wave; i < nbig; i += NT / 64) {
-        const int l = big[i];
-        if (c.a->lm_ptr[l + 1] - c.a->lm_ptr[l] <= 16) continue;   // (uniform over the wave)
-        landmark<MODE, 64>(c, l, true, lane, chi, scale, dmax);
+// the landmarks [begin, end) of the list, G lanes each; the next group's operands and the descriptor after that are in flight while
+// this one is worked on
+template <int G, int NT>
+__device__ __forceinline__ void build_class(const Ctx& c, int begin, int end) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (begin >= end) return;
+    constexpr int kStep = NT / G;
+    GroupIn nx = load_group<G>(c, load_desc(c, begin + tid / G, end), lane);
+    int4 d2 = load_desc(c, begin + kStep + tid / G, end);
+    for (int i0 = begin; i0 < end; i0 += kStep) {
+        const GroupIn g = nx;
+        nx = load_group<G>(c, d2, lane);
+        d2 = load_desc(c, i0 + 2 * kStep + tid / G, end);
+        build_group<G>(c, g, lane);
     }
 }
 
 // PreEdgeSE2 (EdgeSE2XYZ.h:62-102), one thread per edge
+enum { kOdoEval = 0, kOdoDiag = 1, kOdoBuild = 2, kOdoUpdate = 3 };
 template <int MODE>
 __device__ __forceinline__ void odometry_edge(const Ctx& c, int k, double& chi, double& scale) {
     const WindowArgs& a = *c.a;
     const int i = a.o_i[k], j = a.o_j[k];
     const double* W = a.o_info + 9 * (size_t)k;
     double e[3], A[9], B[9];
-    if (MODE == kUpdate) {   // the gain denominator's share at the estimate's linearisation, chi^2 at the trial state
+    if (MODE == kOdoUpdate) {   // the gain denominator's share at the estimate's linearisation, chi^2 at the trial state
         pre_se2(c.cur + 3 * i, c.cur + 3 * j, a.o_meas + 3 * (size_t)k, e, A, B);
         const int ci = c.col[i], cj = c.col[j];
         double omr[3];
@@ -358,7 +486,7 @@ __device__ __forceinline__ void odometry_edge(const Ctx& c, int k, double& chi, 
         return;
     }
     pre_se2(c.cur + 3 * i, c.cur + 3 * j, a.o_meas + 3 * (size_t)k, e, A, B);
-    if (MODE == kEval) {
+    if (MODE == kOdoEval) {
         for (int r = 0; r < 3; ++r) chi += e[r] * (W[r * 3] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
         return;
     }
@@ -376,7 +504,7 @@ __device__ __forceinline__ void odometry_edge(const Ctx& c, int k, double& chi, 
             const double aa = A[r] * WA[q] + A[3 + r] * WA[3 + q] + A[6 + r] * WA[6 + q];
             const double ab = A[r] * WB[q] + A[3 + r] * WB[3 + q] + A[6 + r] * WB[6 + q];
             const double bb = B[r] * WB[q] + B[3 + r] * WB[3 + q] + B[6 + r] * WB[6 + q];
-            if (MODE == kDiag) {
+            if (MODE == kOdoDiag) {
                 if (q == r) {
                     if (ci >= 0) lds_add(c.x + ci + r, aa);
                     if (cj >= 0) lds_add(c.x + cj + r, bb);
@@ -387,7 +515,7 @@ __device__ __forceinline__ void odometry_edge(const Ctx& c, int k, double& chi, 
             if (cj >= 0 && q <= r) lds_add(c.S + tri(cj + r, cj + q), bb);
             if (ci >= 0 && cj >= 0) lds_add(c.S + (ci > cj ? tri(ci + r, cj + q) : tri(cj + q, ci + r)), ab);   // H(i r, j q)
         }
-        if (MODE == kBuild) {
+        if (MODE == kOdoBuild) {
             if (ci >= 0) lds_add(c.S + tri(c.n, ci + r), A[r] * omr[0] + A[3 + r] * omr[1] + A[6 + r] * omr[2]);
             if (cj >= 0) lds_add(c.S + tri(c.n, cj + r), B[r] * omr[0] + B[3 + r] * omr[1] + B[6 + r] * omr[2]);
         }
@@ -410,80 +538,100 @@ __device__ __forceinline__ void wg_reduce(double* red, double& s0, double& s1, d
     s0 = a; s1 = b; m = mm;
 }
 
-// LL^T of the augmented system in place (left-looking, 3x3 blocks, the right-hand side as row n): the off-diagonal blocks of
-// L overwrite S, the diagonal blocks go to dl (6 per block: l00 l10 l11 l20 l21 l22) with their reciprocals in invd.
-// *fail is set when a pivot is not positive (the step is then rejected, as g2o rejects a failed Cholesky).
-template <int NT>
-__device__ __forceinline__ void factorize(double* S, double* dl, double* invd, int nf, int* fail) {
-    const int tid = threadIdx.x, sub = tid & 7, grp = tid >> 3;
-    const int n = 3 * nf;
-    for (int J = 0; J < nf; ++J) {
-        // ---- T(I, J) = S(I, J) - sum_{K < J} L(I, K) L(J, K)^T for every block row I >= J (the last "block" is the row of b_s)
-        for (int I = J + grp; I <= nf; I += NT / 8) {
-            const int rows = I < nf ? 3 : 1;
-            double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            for (int K = sub; K < J; K += 8) {
-                double lj[9], li[9];
+// ------------------------------------------------------------------------------------------------------------------
+// LL^T of the augmented system in place (left-looking, 3x3 blocks, the right-hand side as row n): the off-diagonal blocks of L
+// overwrite S, the diagonal blocks go to dl (6 per block: l00 l10 l11 l20 l21 l22) with their reciprocals in invd.  *fail is set
+// when a pivot is not positive (the step is then rejected, as g2o rejects a failed Cholesky).
+// Block column J: T(I, J) = S(I, J) - sum_{K < J} L(I, K) L(J, K)^T for the block rows I >= J, LPB lanes sharing a block's sum over
+// K (8 while the column is long, up to 64 near the end, where few rows are left and the sum is longest); then every block's first
+// lane factorises T(J, J) for itself (six multiplies: cheaper than a hand-off) and solves its own L(I, J) = T(I, J) L(J, J)^-T.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int LPB>
+__device__ __forceinline__ void factor_column(double* S, double* dl, double* invd, double* tjj, int nf, int J, int* fail) {
+    const int tid = threadIdx.x, sub = tid & (LPB - 1), grp = tid / LPB;
+    // (the right-hand side is block row nf: row n and two rows of zeros, so every block row is 3 x 3 and the loops unroll)
+    for (int I0 = J; I0 <= nf; I0 += NT / LPB) {
+        const int I = I0 + grp;
+        const bool live = I <= nf;
+        const int Ic = live ? I : J;
+        const double* rowI[3] = {S + tri(3 * Ic, 0), S + tri(3 * Ic + 1, 0), S + tri(3 * Ic + 2, 0)};
+        const double* rowJ[3] = {S + tri(3 * J, 0), S + tri(3 * J + 1, 0), S + tri(3 * J + 2, 0)};
+        double t[9];   // S(I, J), requested before the sum it will be reduced by
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) lj[q * 3 + m] = S[tri(3 * J + q, 3 * K + m)];
+            for (int q = 0; q < 3; ++q) t[r * 3 + q] = (sub == 0 && (Ic > J || q <= r)) ? rowI[r][3 * J + q] : 0.0;
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int K = sub; K < J; K += LPB) {
+            double lj[9], li[9];
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) li[r * 3 + m] = r < rows ? S[tri(3 * I + r, 3 * K + m)] : 0.0;
+                for (int m = 0; m < 3; ++m) lj[q * 3 + m] = rowJ[q][3 * K + m];
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) acc[r * 3 + q] += li[r * 3] * lj[q * 3] + li[r * 3 + 1] * lj[q * 3 + 1] + li[r * 3 + 2] * lj[q * 3 + 2];
-            }
+                for (int m = 0; m < 3; ++m) li[r * 3 + m] = rowI[r][3 * K + m];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) acc[i] = gsum<8>(acc[i]);
-            if (sub == 0) {
-                for (int r = 0; r < rows; ++r)
-                    for (int q = 0; q < 3; ++q)
-                        if (I > J || q <= r) S[tri(3 * I + r, 3 * J + q)] -= acc[r * 3 + q];
-            }
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) acc[r * 3 + q] += li[r * 3] * lj[q * 3] + li[r * 3 + 1] * lj[q * 3 + 1] + li[r * 3 + 2] * lj[q * 3 + 2];
         }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t[i] -= gsum<LPB>(acc[i]);
+        // T(J, J) goes to everybody through a six-word strip; the other blocks keep their T in registers across the barrier
+        if (sub == 0 && live && I == J) { tjj[0] = t[0]; tjj[1] = t[3]; tjj[2] = t[4]; tjj[3] = t[6]; tjj[4] = t[7]; tjj[5] = t[8]; }
         __syncthreads();
-        // ---- L(J, J) from T(J, J) by every group's first lane (6 multiplies: cheaper than a hand-off), L(I, J) = T(I, J) L(J, J)^-T
-        if (sub == 0) {
-            const double t00 = S[tri(3 * J, 3 * J)], t10 = S[tri(3 * J + 1, 3 * J)], t11 = S[tri(3 * J + 1, 3 * J + 1)];
-            const double t20 = S[tri(3 * J + 2, 3 * J)], t21 = S[tri(3 * J + 2, 3 * J + 1)], t22 = S[tri(3 * J + 2, 3 * J + 2)];
+        if (sub == 0 && live) {
+            const double t00 = tjj[0], t10 = tjj[1], t11 = tjj[2], t20 = tjj[3], t21 = tjj[4], t22 = tjj[5];
             bool bad = !(t00 > 0.0);
-            const double l00 = sqrt(bad ? 1.0 : t00), i00 = 1.0 / l00;
+            const double i00 = fast_rsqrt(bad ? 1.0 : t00), l00 = t00 * i00;
             const double l10 = t10 * i00, l20 = t20 * i00;
             const double d1 = t11 - l10 * l10;
             bad |= !(d1 > 0.0);
-            const double l11 = sqrt(d1 > 0.0 ? d1 : 1.0), i11 = 1.0 / l11;
+            const double i11 = fast_rsqrt(d1 > 0.0 ? d1 : 1.0), l11 = d1 * i11;
             const double l21 = (t21 - l20 * l10) * i11;
             const double d2 = t22 - l20 * l20 - l21 * l21;
             bad |= !(d2 > 0.0);
-            const double l22 = sqrt(d2 > 0.0 ? d2 : 1.0), i22 = 1.0 / l22;
-            for (int I = J + grp; I <= nf; I += NT / 8) {
-                if (I == J) {
-                    if (bad) *fail = 1;
-                    dl[6 * J] = l00; dl[6 * J + 1] = l10; dl[6 * J + 2] = l11; dl[6 * J + 3] = l20; dl[6 * J + 4] = l21; dl[6 * J + 5] = l22;
-                    invd[3 * J] = i00; invd[3 * J + 1] = i11; invd[3 * J + 2] = i22;
-                    continue;
-                }
-                const int rows = I < nf ? 3 : 1;
-                for (int r = 0; r < rows; ++r) {
-                    double* t = S + tri(3 * I + r, 3 * J);
-                    const double x0 = t[0] * i00;
-                    const double x1 = (t[1] - x0 * l10) * i11;
-                    const double x2 = (t[2] - x0 * l20 - x1 * l21) * i22;
-                    t[0] = x0; t[1] = x1; t[2] = x2;
+            const double i22 = fast_rsqrt(d2 > 0.0 ? d2 : 1.0), l22 = d2 * i22;
+            if (I == J) {
+                if (bad) *fail = 1;
+                dl[6 * J] = l00; dl[6 * J + 1] = l10; dl[6 * J + 2] = l11; dl[6 * J + 3] = l20; dl[6 * J + 4] = l21; dl[6 * J + 5] = l22;
+                invd[3 * J] = i00; invd[3 * J + 1] = i11; invd[3 * J + 2] = i22;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    double* o = S + tri(3 * I + r, 3 * J);
+                    const double x0 = t[r * 3] * i00;
+                    const double x1 = (t[r * 3 + 1] - x0 * l10) * i11;
+                    const double x2 = (t[r * 3 + 2] - x0 * l20 - x1 * l21) * i22;
+                    o[0] = x0; o[1] = x1; o[2] = x2;
                 }
             }
         }
         __syncthreads();
     }
-    (void)n;
+}
+template <int NT>
+__device__ __forceinline__ void factorize(double* S, double* dl, double* invd, double* tjj, int nf, int* fail) {
+    for (int J = 0; J < nf; ++J) {
+        const int blocks = nf - J + 1;
+        if (blocks * 64 <= NT) factor_column<NT, 64>(S, dl, invd, tjj, nf, J, fail);
+        else if (blocks * 32 <= NT) factor_column<NT, 32>(S, dl, invd, tjj, nf, J, fail);
+        else if (blocks * 16 <= NT) factor_column<NT, 16>(S, dl, invd, tjj, nf, J, fail);
+        else factor_column<NT, 8>(S, dl, invd, tjj, nf, J, fail);
+    }
 }
 
-// x = L^-T y by ONE wave: y (row n of the factor) in registers, three unknowns per lane; row j of L is read once, x_j leaves by a
-// scalar broadcast.  n <= 192.
+// x = L^-T y by ONE wave: y (row n of the factor) in registers, three unknowns per lane, a pose block per step from the last to the
+// first: the block's three unknowns by scalar broadcasts (readlane) and its own 3x3 triangle, then its three rows of L - requested a
+// step ahead - leave every earlier unknown's y.  n <= 192.
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ void back_substitute(const double* S, const double* dl, const double* invd, int nf, double* x) {
     const int lane = threadIdx.x & 63;
     const int n = 3 * nf;
@@ -493,24 +641,45 @@ __device__ __forceinline__ void back_substitute(const double* S, const double* d
         const int i = lane + 64 * s;
         y[s] = i < n ? S[tri(n, i)] : 0.0;
     }
-    for (int j = n - 1; j >= 0; --j) {
-        const int J = j / 3, r = j - 3 * J;
-        const double ys = j >= 128 ? y[2] : (j >= 64 ? y[1] : y[0]);
-        const long long bits = __double_as_longlong(ys);
-        const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), j & 63);
-        const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), j & 63);
-        const double xj = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo) * invd[j];
-        if (lane == 0) x[j] = xj;
+    auto load_rows = [&](int J, double (&rw)[3][3], double (&d)[6], double (&iv)[3]) {
+        if (J < 0) return;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int i = lane + 64 * s;
-            if (i < j) {
-                double lji;
-                if (i >= 3 * J) lji = dl[6 * J + (r == 1 ? 1 : 3 + (i - 3 * J))];   // inside the diagonal block: l10 (r = 1) or l20 / l21 (r = 2)
-                else lji = S[tri(j, i)];
-                y[s] -= lji * xj;
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int i = lane + 64 * s;
+                rw[r][s] = i < 3 * J ? S[tri(3 * J + r, i)] : 0.0;
             }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = dl[6 * J + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) iv[i] = invd[3 * J + i];
+    };
+    double rw[3][3], d[6], iv[3], nrw[3][3] = {}, nd[6] = {}, niv[3] = {};
+    load_rows(nf - 1, rw, d, iv);
+    for (int J = nf - 1; J >= 0; --J) {
+        load_rows(J - 1, nrw, nd, niv);
+        double yb[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int j = 3 * J + r;
+            const double ys = j >= 128 ? y[2] : (j >= 64 ? y[1] : y[0]);
+            yb[r] = lane_value(ys, j & 63);
         }
+        const double x2 = yb[2] * iv[2];
+        const double x1 = (yb[1] - d[4] * x2) * iv[1];
+        const double x0 = (yb[0] - d[1] * x1 - d[3] * x2) * iv[0];
+        if (lane == 0) { x[3 * J] = x0; x[3 * J + 1] = x1; x[3 * J + 2] = x2; }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) y[s] -= rw[0][s] * x0 + rw[1][s] * x1 + rw[2][s] * x2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) rw[r][s] = nrw[r][s];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = nd[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) iv[i] = niv[i];
     }
 }
 
@@ -519,13 +688,13 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     const WindowArgs& a = all[blockIdx.x];
     extern __shared__ double lds[];
     __shared__ BaCtl ctl;
-    __shared__ int s_nf, s_nbig, s_fail, s_err, s_stop;
-    __shared__ int big[kWindowBigCap];
-    __shared__ double red[24];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.P;
+    __shared__ int s_nf, s_fail, s_err, s_stop;
+    __shared__ int hist[kWindowMaxDegree + 2], cursor[kWindowMaxDegree + 2];
+    __shared__ double red[24], tjj[6];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int P = a.P, L = a.L;
 
-    // ---- prologue: the controller block (k_ctl_init's rules), columns of the free poses, the list of wide landmarks
+    // ---- prologue: the controller block (k_ctl_init's rules), columns of the free poses, the landmarks ordered by their counts
     if (tid == 0) {
         const BaCtl* g = a.ctl;
         const int sel = g->sel;
@@ -539,9 +708,11 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         ctl.mode = a.mode;
         ctl.seq = seq;
         ctl.epoch = epoch;
-        s_nbig = 0; s_fail = 0; s_err = 0;
+        s_fail = 0; s_err = 0;
+        g_dbg = a.debug;
         s_stop = (a.stop && *(const volatile int*)a.stop) ? 1 : 0;
     }
+    for (int i = tid; i < kWindowMaxDegree + 2; i += NT) hist[i] = 0;
     // LDS map (doubles): cur 3P | trl 3P | scur 2P | strl 2P | x n | invd n | dl 2n | stage NT x kStageDoubles | S (n+1)(n+2)/2 ; col P ints first
     int* col = reinterpret_cast<int*>(lds);
     double* base = lds + (P + 1) / 2;
@@ -559,29 +730,35 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         const double* src = ctl.sel ? a.poses_b : a.poses_a;
         for (int i = tid; i < 3 * P; i += NT) bufA[i] = src[i];
     }
-    for (int l = tid; l < a.L; l += NT) {
+    for (int l = tid; l < L; l += NT) {
         const int k = a.lm_ptr[l + 1] - a.lm_ptr[l];
         if (k > kWindowMaxDegree) s_err = 2;
-        else if (k > 8) {
-            const int at = atomicAdd(&s_nbig, 1);
-            if (at < kWindowBigCap) big[at] = l;
-            else s_err = 2;
-        }
+        else atomicAdd(&hist[k], 1);
     }
     __syncthreads();
+    if (tid == 0) {   // hist[k] -> first position of the landmarks with k observations
+        int at = 0;
+        for (int k = 0; k <= kWindowMaxDegree + 1; ++k) { const int h = hist[k]; hist[k] = at; cursor[k] = at; at += h; }
+    }
+    __syncthreads();
+    const bool refused = s_err != 0;   // a landmark this kernel does not take: nothing is touched, the caller runs the window elsewhere
+    if (!refused)
+        for (int l = tid; l < L; l += NT) {
+            const int beg = a.lm_ptr[l], k = a.lm_ptr[l + 1] - beg;
+            a.desc[atomicAdd(&cursor[k], 1)] = make_int4(l, beg, k, 0);
+        }
     const int nf = s_nf, n = 3 * nf;
     double* xs = scB + 2 * P;
     double* invd = xs + n;
     double* dl = invd + n;
     double* stage_all = dl + 2 * n;
     double* S = stage_all + (size_t)NT * kStageDoubles;
-    const int ntri = (n + 1) * (n + 2) / 2;
+    const int ntri = (n + 3) * (n + 4) / 2;   // rows 0 .. n-1 = S, row n = b_s, two rows of zeros (the factorisation's last block row)
     for (int p = tid; p < P; p += NT) sincos(bufA[3 * p + 2], &scA[2 * p], &scA[2 * p + 1]);
-    const int nbig = min(s_nbig, kWindowBigCap);
-    const bool refused = s_err != 0;   // a landmark this kernel does not take: nothing is touched, the caller runs the window elsewhere
-    __syncthreads();
     if (refused && tid == 0) { ctl.error = 2; ctl.done = 1; }
     __syncthreads();
+    // classes of the build pass: landmarks with 1-4 observations take 4 lanes, 5-8 take 8, 9-16 take 16, the rest a wave
+    const int b1 = hist[1], b5 = hist[5], b9 = hist[9], b17 = hist[17];
 
     Ctx c;
     c.a = &a;
@@ -592,6 +769,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     c.stage = stage_all + (size_t)wave * 64 * kStageDoubles;
     c.lms = ctl.sel ? a.lms_b : a.lms_a;
     c.lms_trial = ctl.sel ? a.lms_a : a.lms_b;
+    c.desc = a.desc;
     c.n = n;
     c.lambda = 0.0;
     double* cur = bufA;
@@ -602,8 +780,11 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     // ---- chi^2 of the starting state (computeActiveErrors + activeRobustChi2 in front of the first iteration)
     if (!refused) {
         double chi = 0, sc = 0, dm = 0;
-        landmark_pass<kEval, NT>(c, big, nbig, chi, sc, dm);
-        for (int k = tid; k < a.O; k += NT) odometry_edge<kEval>(c, k, chi, sc);
+        eval_class<kEval, 4, NT>(c, b1, b5, chi, sc, dm);
+        eval_class<kEval, 8, NT>(c, b5, b9, chi, sc, dm);
+        eval_class<kEval, 16, NT>(c, b9, b17, chi, sc, dm);
+        eval_class<kEval, 64, NT>(c, b17, L, chi, sc, dm);
+        for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoEval>(c, k, chi, sc);
         wg_reduce<NT>(red, chi, sc, dm);
         if (tid == 0) {
             ctl.current_chi = ctl.chi2_init = ctl.chi2_final = chi;
@@ -617,8 +798,11 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         for (int i = tid; i < n; i += NT) xs[i] = 0.0;
         __syncthreads();
         double chi = 0, sc = 0, dm = 0;
-        landmark_pass<kDiag, NT>(c, big, nbig, chi, sc, dm);
-        for (int k = tid; k < a.O; k += NT) odometry_edge<kDiag>(c, k, chi, sc);
+        eval_class<kDiag, 4, NT>(c, b1, b5, chi, sc, dm);
+        eval_class<kDiag, 8, NT>(c, b5, b9, chi, sc, dm);
+        eval_class<kDiag, 16, NT>(c, b9, b17, chi, sc, dm);
+        eval_class<kDiag, 64, NT>(c, b17, L, chi, sc, dm);
+        for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoDiag>(c, k, chi, sc);
         __syncthreads();
         for (int i = tid; i < n; i += NT) dm = fmax(dm, fabs(xs[i]));
         wg_reduce<NT>(red, chi, sc, dm);
@@ -636,15 +820,18 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         if (tid == 0) s_fail = 0;
         __syncthreads();
         {
-            double chi = 0, sc = 0, dm = 0;
-            landmark_pass<kBuild, NT>(c, big, nbig, chi, sc, dm);
-            for (int k = tid; k < a.O; k += NT) odometry_edge<kBuild>(c, k, chi, sc);
+            double chi = 0, sc = 0;
+            build_class<4, NT>(c, b1, b5);
+            build_class<8, NT>(c, b5, b9);
+            build_class<16, NT>(c, b9, b17);
+            build_class<64, NT>(c, b17, L);
+            for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoBuild>(c, k, chi, sc);
         }
         __syncthreads();
         for (int i = tid; i < n; i += NT) S[tri(i, i)] += lambda;      // setLambda: the damping on the pose diagonal (the landmarks' went into A)
         __syncthreads();
         if (stamps && tid == 0) stamps[1] = wall_clock64();
-        factorize<NT>(S, dl, invd, nf, &s_fail);
+        factorize<NT>(S, dl, invd, tjj, nf, &s_fail);
         if (stamps && tid == 0) stamps[2] = wall_clock64();
         if (wave == 0) back_substitute(S, dl, invd, nf, xs);
         __syncthreads();
@@ -663,8 +850,12 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
             sincos(th, &strl[2 * p], &strl[2 * p + 1]);
         }
         __syncthreads();
-        landmark_pass<kUpdate, NT>(c, big, nbig, chi, sc, dm);
-        for (int k = tid; k < a.O; k += NT) odometry_edge<kUpdate>(c, k, chi, sc);
+        copy_unobserved<NT>(c, b1);
+        eval_class<kUpdate, 4, NT>(c, b1, b5, chi, sc, dm);
+        eval_class<kUpdate, 8, NT>(c, b5, b9, chi, sc, dm);
+        eval_class<kUpdate, 16, NT>(c, b9, b17, chi, sc, dm);
+        eval_class<kUpdate, 64, NT>(c, b17, L, chi, sc, dm);
+        for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoUpdate>(c, k, chi, sc);
         wg_reduce<NT>(red, chi, sc, dm);
         if (stamps && tid == 0) stamps[4] = wall_clock64();
         if (tid == 0) {
@@ -713,10 +904,10 @@ namespace se2gpu {
 
 size_t ba_window_lds_bytes(int P, int nfree, int threads) {
     const size_t n = 3 * (size_t)nfree;
-    size_t doubles = (size_t)(P + 1) / 2 + 10 * (size_t)P + 4 * n + (size_t)threads * kStageDoubles + (n + 1) * (n + 2) / 2;
+    size_t doubles = (size_t)(P + 1) / 2 + 10 * (size_t)P + 4 * n + (size_t)threads * kStageDoubles + (n + 3) * (n + 4) / 2;
     const size_t bytes = doubles * 8;
     // static LDS of the kernel: the controller block, the list of wide landmarks, the reduction scratch
-    const size_t fixed = sizeof(BaCtl) + kWindowBigCap * sizeof(int) + 24 * 8 + 128;
+    const size_t fixed = sizeof(BaCtl) + 2 * (kWindowMaxDegree + 2) * sizeof(int) + 30 * 8 + 128;
     if (n > 192 || bytes + fixed > 160 * 1024) return 0;
     return bytes;
 }
