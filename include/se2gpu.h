@@ -335,6 +335,11 @@ int se2gpu_ba_optimize(se2gpu_ba* h, int iters, int mode, const volatile uint8_t
  * identical to calling se2gpu_ba_optimize on every handle in turn.  stats: NULL or `count` entries. */
 int se2gpu_ba_optimize_batch(se2gpu_ba** handles, int count, int iters, int mode, const volatile uint8_t* stop_flag,
                              se2gpu_ba_stats* stats);
+/* Which of its three paths the calling thread's last se2gpu_ba_optimize_batch took (-1: none yet): 0 = one stream per window,
+ * 1 = lock step (one launch per stage for all windows), 2 = resident (one workgroup per window for its whole optimize():
+ * batches of SE2GPU_BA_RESIDENT_MIN = 96 windows or more whose windows fit a compute unit's LDS, csrc/ba_window.hip; its sums
+ * are atomic, so its results equal the other paths' to rounding, not to the bit).  SE2GPU_BA_RESIDENT=0 / 1 forces the choice. */
+int se2gpu_ba_last_batch_path(void);
 int se2gpu_ba_get_se2(se2gpu_ba* h, int id, double xyt[3]);   /* estimateVertexSE2   */
 int se2gpu_ba_get_xyz(se2gpu_ba* h, int id, double xyz[3]);   /* estimateVertexSBAXYZ */
 int se2gpu_ba_get_all(se2gpu_ba* h, double* poses /*P*3, in pose-add order*/, double* lms /*L*3*/);

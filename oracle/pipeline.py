@@ -104,6 +104,10 @@ def lib(kind: str) -> C.CDLL:
         L.ref_pipe_mappoints.restype = C.c_int
         L.ref_pipe_mappoints.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.ref_pipe_shim_calls.argtypes = [C.c_void_p]
+        L.ref_pipe_keyframe_addresses.restype = C.c_int
+        L.ref_pipe_keyframe_addresses.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_pipe_observations.restype = C.c_int
+        L.ref_pipe_observations.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _libs[kind] = L
     return _libs[kind]
 
@@ -163,6 +167,21 @@ class Pipeline:
         n = self.L.ref_pipe_mappoints(self.h, cap, ids.ctypes.data, pos.ctypes.data, nobs.ctypes.data, good.ctypes.data)
         assert n <= cap
         return dict(id=ids[:n], pos=pos[:n], n_obs=nobs[:n], good_prl=good[:n])
+
+    def keyframe_address_rank(self, cap: int = 4096) -> np.ndarray:
+        """rank of every key frame's heap address among the key frames (what std::map<PtrKeyFrame, int> orders a map point's
+        observations by - see ref_pipe_keyframe_addresses)"""
+        a = np.zeros(cap, np.uint64)
+        n = self.L.ref_pipe_keyframe_addresses(self.h, cap, a.ctypes.data)
+        assert 0 <= n <= cap
+        return np.argsort(np.argsort(a[:n])).astype(np.int32)
+
+    def observations(self, kf_pos: int, cap: int = 4096):
+        """(feature indices, map-point ids) of the key frame at position kf_pos of keyframes()"""
+        ftr, mp = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        n = self.L.ref_pipe_observations(self.h, kf_pos, cap, ftr.ctypes.data, mp.ctypes.data)
+        assert 0 <= n <= cap
+        return ftr[:n].copy(), mp[:n].copy()
 
     def shim_calls(self) -> dict:
         c = (C.c_longlong * 4)()

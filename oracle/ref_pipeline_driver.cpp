@@ -16,8 +16,11 @@
 // (MatchByProjection), Map::updateLocalGraph / pruneRedundantKF / loadLocalGraph / optimizeLocalGraph, LocalMapper::localBA.
 // The members these functions work on are private in the reference's headers; this translation unit reads the headers with
 // `private` / `protected` spelled `public` (no reference source is touched).
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
+#include <new>
 #include <cstring>
 #include <deque>
 #include <fstream>
@@ -48,6 +51,64 @@
 #include "cvutil.h"
 
 using namespace se2lam;
+
+// ---- creation order = address order for the map's objects.  The reference orders a map point's observations by the ADDRESS of the
+// key frame (std::map<PtrKeyFrame, int>, include/se2lam/MapPoint.h:86; likewise std::map<PtrMapPoint, int> in KeyFrame.h and the
+// std::set<PtrMapPoint> / std::set<PtrKeyFrame> its functions return), and MapPoint::updateMainKFandDescriptor
+// (src/MapPoint.cpp:228-292) breaks the ties of its least-median rule by that order - with two observations, always.  Which key
+// frame lies lower in memory is the allocator's business: the CPU build, which allocates image pyramids in between, and the drop-in
+// build, which does not, get different orders from malloc and would then disagree about main key frames, main descriptors and, a few
+// frames later, map points (observed: key-frame address ranks [0 2 1] against [0 1 2], the first difference in the map at the third
+// key frame).  Both builds therefore take the storage of key frames and map points (std::make_shared: the object plus a control
+// block) from a bump arena that is never reused: a younger object always lies higher, in every run.  This pins an
+// implementation-defined behaviour of the reference for the comparison, as oracle/stl_nth.h pins std::nth_element; nothing of the
+// library under test is involved.
+namespace {
+struct BumpArena {
+    char* cur = nullptr;
+    char* end = nullptr;
+    std::vector<std::pair<char*, char*>> chunks;
+    std::mutex mu;
+    void* take(std::size_t n) {
+        std::lock_guard<std::mutex> lk(mu);
+        n = (n + 63) & ~std::size_t(63);
+        if (!cur || cur + n > end) {
+            const std::size_t sz = std::max<std::size_t>(n, std::size_t(32) << 20);
+            cur = static_cast<char*>(std::malloc(sz));
+            if (!cur) throw std::bad_alloc();
+            end = cur + sz;
+            // (chunks come from malloc in ascending order or not - objects of one run stay ordered as long as they share a chunk; a
+            // chunk holds ~400 key frames, far more than any run here creates)
+            chunks.emplace_back(cur, end);
+        }
+        void* p = cur;
+        cur += n;
+        return p;
+    }
+    bool owns(const void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const auto& c : chunks)
+            if (p >= c.first && p < c.second) return true;
+        return false;
+    }
+};
+BumpArena& arena() { static BumpArena* a = new (std::malloc(sizeof(BumpArena))) BumpArena; return *a; }
+inline bool map_object_size(std::size_t n) {
+    return (n >= sizeof(KeyFrame) && n <= sizeof(KeyFrame) + 64) || (n >= sizeof(MapPoint) && n <= sizeof(MapPoint) + 64);
+}
+}  // namespace
+void* operator new(std::size_t n) {
+    if (map_object_size(n)) return arena().take(n);
+    void* p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void operator delete(void* p) noexcept {
+    if (p && !arena().owns(p)) std::free(p);
+}
+void operator delete(void* p, std::size_t) noexcept {
+    if (p && !arena().owns(p)) std::free(p);
+}
 
 extern "C" {
 const char* pipeline_kind(void);          // oracle/pipeline_cpu_solver.cpp or tests/dropin/g2o_forward.cpp
@@ -270,6 +331,35 @@ int ref_pipe_mappoints(void* h, int cap, int32_t* id, float* pos3, int32_t* n_ob
             n_obs[n] = (int)m->countObservation();
             good_prl[n] = m->isGoodPrl() ? 1 : 0;
         }
+        ++n;
+    }
+    return n;
+}
+
+// the heap addresses of the key-frame objects (ref_pipe_keyframes' order).  The reference keeps a map point's observations in a
+// std::map<PtrKeyFrame, int> (include/se2lam/MapPoint.h:86), i.e. ordered by ADDRESS, and MapPoint::updateMainKFandDescriptor
+// (src/MapPoint.cpp:228-292) breaks the ties of its least-median rule by that order: with two observations both medians are 0 and the
+// key frame at the lower address becomes the main one.  Two runs agree on such ties only if their allocators place the key frames in
+// the same relative order - the test compares this order before it compares anything that depends on it.
+int ref_pipe_keyframe_addresses(void* h, int cap, uint64_t* addr) {
+    Pipe* p = static_cast<Pipe*>(h);
+    const std::vector<PtrKeyFrame> kfs = p->map.getAllKF();
+    int n = 0;
+    for (const PtrKeyFrame& k : kfs) {
+        if (n < cap) addr[n] = (uint64_t)(uintptr_t)k.get();
+        ++n;
+    }
+    return n;
+}
+
+// the observations of one key frame (position in ref_pipe_keyframes' order): feature index -> map-point id, ascending feature index
+int ref_pipe_observations(void* h, int kf_pos, int cap, int32_t* ftr, int32_t* mp_id) {
+    Pipe* p = static_cast<Pipe*>(h);
+    const std::vector<PtrKeyFrame> kfs = p->map.getAllKF();
+    if (kf_pos < 0 || kf_pos >= (int)kfs.size()) return -1;
+    int n = 0;
+    for (const auto& kv : kfs[kf_pos]->mDualObservations) {
+        if (n < cap) { ftr[n] = kv.first; mp_id[n] = kv.second ? kv.second->mId : -1; }
         ++n;
     }
     return n;

@@ -142,6 +142,7 @@ SYMBOLS = {
     "se2gpu_ba_reset_estimates_batch": (_I, [_VP, _I]),
     "se2gpu_ba_optimize": (_I, [_VP, _I, _I, _PU8, _I, C.POINTER(BaStats)]),
     "se2gpu_ba_optimize_batch": (_I, [C.POINTER(_VP), _I, _I, _I, _PU8, C.POINTER(BaStats)]),
+    "se2gpu_ba_last_batch_path": (_I, []),
     "se2gpu_ba_get_se2": (_I, [_VP, _I, _PD]),
     "se2gpu_ba_get_xyz": (_I, [_VP, _I, _PD]),
     "se2gpu_ba_get_all": (_I, [_VP, _PD, _PD]),

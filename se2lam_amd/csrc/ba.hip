@@ -6390,9 +6390,13 @@ static int ba_optimize_group(se2gpu_ba** hs, int count, int iters, int mode, con
     return SE2GPU_OK;
 }
 
+static thread_local int t_last_batch_path = -1;
+int se2gpu_ba_last_batch_path(void) { return t_last_batch_path; }
+
 int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
                              se2gpu_ba_stats* stats) {
     SE2_REQUIRE(hs && count >= 0, SE2GPU_ERR_INVALID, "optimize_batch: bad argument");
+    t_last_batch_path = 0;
     for (int i = 0; i < count; ++i) SE2_REQUIRE(hs[i] && hs[i]->initialized, SE2GPU_ERR_STATE, "optimize_batch: handle %d is not initialised", i);
     // A local window is a dozen launches per LM iteration; one host thread enqueues ~0.3 M launches per second, which is
     // what bounds many small windows in flight.  The windows are therefore dealt to a few enqueue threads (each window
@@ -6400,11 +6404,13 @@ int se2gpu_ba_optimize_batch(se2gpu_ba** hs, int count, int iters, int mode, con
     {   // one workgroup per window for its whole optimize(), when the batch is large enough to fill compute units that way
         int handled = 0;
         const int rc = ba_optimize_resident(hs, count, iters, mode, stop_flag, stats, &handled);
+        if (handled) t_last_batch_path = 2;
         if (handled || rc != SE2GPU_OK) return rc;
     }
     {   // one launch per stage for all windows, when every window qualifies (model 0, one GPU, dataflow solve)
         int handled = 0;
         const int rc = ba_optimize_lockstep(hs, count, iters, mode, stop_flag, stats, &handled);
+        if (handled) t_last_batch_path = 1;
         if (handled || rc != SE2GPU_OK) return rc;
     }
     // Cross-stream orderings left by se2gpu_ba_reset_estimates_batch are resolved HERE, by the calling thread, before any

@@ -4,7 +4,7 @@
 //   /root/reference/src/LocalMapper.cpp:259-260      optimizer.initializeOptimization(0); optimizer.optimize(Config::LOCAL_ITER)
 //   /root/reference/src/EdgeSE2XYZ.cpp:61-106         per-edge residual + 2x3 / 2x3 Jacobians
 //   /root/reference/include/se2lam/EdgeSE2XYZ.h:62-102 PreEdgeSE2
-//   [3P g2o 20160424]  Huber, Schur complement of the landmarks, dense pose solve, Levenberg policy (restated: oracle/ba_ref.cpp)
+//   [3P g2o 20160424]  Huber, Schur complement of the landmarks, dense pose solve, Levenberg policy (as the multi-launch path restates them)
 //
 // Why.  The multi-launch path (csrc/ba.hip) spreads ONE window over the chip: four launches per LM trial, per-edge records
 // (W_e, Dg_e: 168 B) written by k_linearize and read back 2.2x over by k_reduce2, tile hand-offs of the dense solve through

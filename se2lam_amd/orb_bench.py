@@ -19,7 +19,7 @@ B_ORB = 5_742_474      # algorithmic bytes per frame, SURVEY.md §8(d)
 B_MATCH = 132_000      # algorithmic bytes per frame pair
 
 
-MIN_TIMED_S = 0.1      # floor of the timed region (as bench.py's BA leg)
+MIN_TIMED_S = 2.0      # floor of the timed region (as bench.py's BA leg)
 
 
 def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, traffic=None, inflight=2, streaming_leg=True):
@@ -136,11 +136,18 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
             streaming = {"error": repr(exc)}
     return {"metric": "ORB extract+match frames/s @640x480", "value": fps, "unit": "frames/s", "n_gpus": world,
             "batch": B, "steps": steps, "steps_requested": steps_requested, "timed_s": dt, "ms_per_batch": 1e3 * dt / steps,
-            "scaling": "weak", "batches_in_flight": nex,
+            "scaling": "weak", "batches_in_flight": nex, "gpu_max_hw_queues": _hw_queues(),
             "config": {"workload": "640x480 u8, 8-level pyramid, 1000 features/frame, MatchByWindow(win 20, ratio 0.9), "
                                    "frames t vs t+1", "features_per_frame": float(cnt.mean()),
                        "matches_per_pair": float(nm.mean())},
             "roofline": roof, "cpu_baseline": None, "streaming": streaming}
+
+
+def _hw_queues():
+    """GPU_MAX_HW_QUEUES of this process (the HIP runtime's default is 4): the resident and the streaming leg run with different
+    settings, and a reader of the bench line should see which"""
+    import os
+    return os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")
 
 
 def streaming_child(B, steps, cap=1024):
@@ -167,6 +174,7 @@ def streaming_child(B, steps, cap=1024):
 
     out = run_streaming(0, 1, B, steps, sync_all, None, exs, mt, cap, warmup=8)
     out["process"] = "own process, two extractor handles"
+    out["gpu_max_hw_queues"] = _hw_queues()
     return out
 
 

@@ -7,6 +7,8 @@
 // them.  Also: cv::findFundamentalMat of Track::removeOutliers (src/Track.cpp:326) -> se2gpu_track_fundamental_mask.
 // Nothing of oracle/ is compiled into, linked to or called from this file.
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -92,6 +94,18 @@ void pipeline_install_hooks(void) {
     cv::shim_fundamental_hook() = [](const float* a, const float* b, int n, unsigned char* mask) {
         int inl = 0;
         se2lam_amd::check(se2gpu_track_fundamental_mask(g_track, a, b, n, mask, &inl), "se2gpu_track_fundamental_mask");
+        if (const char* dump = std::getenv("SE2_DROPIN_DUMP")) {   // debugging aid: the call, for a replay through the other implementation
+            static int call = 0;
+            char name[512];
+            std::snprintf(name, sizeof(name), "%s/fundamental_%d.bin", dump, call++);
+            if (FILE* f = std::fopen(name, "wb")) {
+                std::fwrite(&n, 4, 1, f);
+                std::fwrite(a, 4, (size_t)2 * n, f);
+                std::fwrite(b, 4, (size_t)2 * n, f);
+                std::fwrite(mask, 1, (size_t)n, f);
+                std::fclose(f);
+            }
+        }
         return inl;
     };
 }
