@@ -6080,25 +6080,25 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
     const int env_on = e_on ? atoi(e_on) : -1, env_min = e_min ? atoi(e_min) : 96;
     if (env_on == 0 || count < 1 || (env_on != 1 && count < env_min) || ba_env_sync() || iters < 0) return SE2GPU_OK;
     if (mode != SE2GPU_BA_LM && mode != SE2GPU_BA_GN) return SE2GPU_OK;
-    int threads = 512;
-    size_t lds = 0;
+    // Windows are dealt to (at most) three launches by the widest workgroup their reduced system leaves room for in LDS (512, 256 or
+    // 128 threads; a 50-key-frame window takes 512, one of 60 only 128), each launch on the stream of its first window, the heaviest
+    // windows first (workgroups start in index order: the long ones must not be the tail).
+    struct Item { int i, threads; size_t lds; };
+    std::vector<Item> items((size_t)count);
     for (int i = 0; i < count; ++i) {
         if (!ba_resident_ok(hs[i]) || hs[i]->device != hs[0]->device) return SE2GPU_OK;
         size_t b = 0;
         const int t = ba_resident_threads(hs[i], &b);
         if (!t) return SE2GPU_OK;
-        threads = std::min(threads, t);
-    }
-    for (int i = 0; i < count; ++i) {   // (all windows of a launch share the workgroup size: the widest window's)
-        int nfree = 0;
-        for (int p = 0; p < hs[i]->P; ++p) nfree += hs[i]->h_fixed[p] ? 0 : 1;
-        const size_t b = ba_window_lds_bytes(hs[i]->P, nfree, threads);
-        if (!b) return SE2GPU_OK;
-        lds = std::max(lds, b);
+        items[(size_t)i] = Item{i, t, b};
     }
     for (int i = 0; i < count; ++i)
         for (int j = 0; j < i; ++j)
             if (hs[i] == hs[j]) return SE2GPU_OK;
+    std::stable_sort(items.begin(), items.end(), [&](const Item& a, const Item& b) {
+        if (a.threads != b.threads) return a.threads > b.threads;
+        return hs[a.i]->E > hs[b.i]->E;
+    });
     static std::mutex launch_mu;   // (hipFuncSetAttribute inside the launcher)
     Lease<ResidentScratch> lease;
     ResidentScratch& rs = *lease.obj;
@@ -6106,9 +6106,15 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
     SE2_CHECK(rs.dev.reserve((size_t)count));
     static const bool trace = [] { const char* e = getenv("SE2GPU_BA_RESIDENT_TRACE"); return e && e[0] == '1'; }();
     if (trace) SE2_CHECK(rs.stamps.reserve(16 * (size_t)count));
-    hipStream_t st = hs[0]->stream;
-    for (int i = 0; i < count; ++i) {
+    const char* e_dbg = getenv("SE2GPU_BA_RESIDENT_DEBUG");
+    std::vector<hipStream_t> class_streams;
+    int threads = 0;
+    size_t lds = 0;
+    for (int k = 0; k < count; ++k) {
+        const int i = items[(size_t)k].i;
         se2gpu_ba* h = hs[i];
+        if (k == 0 || items[(size_t)k].threads != items[(size_t)k - 1].threads) class_streams.push_back(h->stream);
+        hipStream_t st = class_streams.back();
         h->est_valid = false;
         h->run_mode = mode;
         h->run_iters = iters;
@@ -6121,9 +6127,9 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
             h->join_event = nullptr;
             h->join_stream = nullptr;
         }
-        if (h->stream != st) SE2_HIP(hipStreamSynchronize(h->stream));   // ... or anything still enqueued on the window's own stream
+        if (h->stream != st && h->own_pending) SE2_HIP(hipStreamSynchronize(h->stream));   // ... or a reset still enqueued on the window's own stream
         h->own_pending = false;
-        WindowArgs& a = rs.host.p[i];
+        WindowArgs& a = rs.host.p[k];
         a.cam = h->cam;
         a.P = h->P; a.L = h->L; a.E = h->E; a.O = h->O; a.iters = iters; a.mode = mode;
         a.lm_ptr = h->lm_ptr.p; a.e_kf = h->e_kf.p; a.e_uv = h->e_uv.p; a.e_info = h->e_info.p;
@@ -6134,13 +6140,22 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         a.mail = h->d_mail;
         a.stop = h->d_stop;
         a.desc = reinterpret_cast<int4*>(h->Hpl.p);   // (the multi-launch path's W records: 72 B per edge, idle on this path)
-        { const char* e = getenv("SE2GPU_BA_RESIDENT_DEBUG"); a.debug = e ? atoi(e) : 0; }
-        a.stamps = trace ? rs.stamps.p + 16 * (size_t)i : nullptr;
+        a.debug = e_dbg ? atoi(e_dbg) : 0;
+        a.stamps = trace ? rs.stamps.p + 16 * (size_t)k : nullptr;
     }
-    SE2_HIP(hipMemcpyAsync(rs.dev.p, rs.host.p, (size_t)count * sizeof(WindowArgs), hipMemcpyHostToDevice, st));
     {
         std::lock_guard<std::mutex> lk(launch_mu);
-        SE2_CHECK(ba_window_launch(rs.dev.p, count, threads, lds, st));
+        size_t cs = 0;
+        for (int k0 = 0; k0 < count;) {
+            int k1 = k0;
+            size_t need = 0;
+            while (k1 < count && items[(size_t)k1].threads == items[(size_t)k0].threads) { need = std::max(need, items[(size_t)k1].lds); ++k1; }
+            hipStream_t st = class_streams[cs++];
+            SE2_HIP(hipMemcpyAsync(rs.dev.p + k0, rs.host.p + k0, (size_t)(k1 - k0) * sizeof(WindowArgs), hipMemcpyHostToDevice, st));
+            SE2_CHECK(ba_window_launch(rs.dev.p + k0, k1 - k0, items[(size_t)k0].threads, need, st));
+            if (k0 == 0) { threads = items[0].threads; lds = need; }
+            k0 = k1;
+        }
     }
     for (int i = 0; i < count; ++i) {
         hs[i]->dev_seq += 1;
@@ -6157,14 +6172,14 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
             if (stop_flag && *stop_flag)
                 for (int j = 0; j < count; ++j) *hs[j]->h_stop = 1;
             if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
-                SE2_HIP(hipStreamSynchronize(st));
+                for (hipStream_t st : class_streams) SE2_HIP(hipStreamSynchronize(st));
                 SE2_REQUIRE(mb[kMailSeq] == h->run_seq, SE2GPU_ERR_HIP, "window %d of the resident batch never reported back", i);
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         refused |= ba_posted(h)->error == 2;
     }
-    SE2_HIP(hipStreamSynchronize(st));   // (the argument packs are leased: nothing of this call may be in flight when they go back)
+    for (hipStream_t st : class_streams) SE2_HIP(hipStreamSynchronize(st));   // (the argument packs are leased: nothing of this call may be in flight when they go back)
     if (trace) {
         std::vector<long long> hst(16 * (size_t)count);
         SE2_HIP(hipMemcpy(hst.data(), rs.stamps.p, hst.size() * 8, hipMemcpyDeviceToHost));
