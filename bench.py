@@ -464,9 +464,12 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
                 reps += 1
             sync_all()
             dt = time.perf_counter() - t0
-            if dist is not None:
+            if dist is not None:   # weak form: every rank ran its own windows, no collective; the job's rate = all ranks' iterations / slowest rank's time
                 dt = dist.allreduce_max(dt)
-            rate = world * done / dt
+                done = int(dist.allreduce_sum(float(done)))
+                rate = done / dt
+            else:
+                rate = done / dt
             return {"windows_per_gpu": n, "iters_per_s": rate, "ms_per_optimize10": 1e3 * dt / reps, "timed_s": dt,
                     "path": _batch_path_name(),
                     "whole_step_achieved_gbs": B * rate / world / 1e9,
@@ -510,7 +513,9 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
         dt = time.perf_counter() - t0
         if dist is not None:
             dt = dist.allreduce_max(dt)
-        mixed = {"windows_per_gpu": nmix, "iters_per_s": world * done / dt, "lm_trials_per_iter": trials / max(done, 1),
+            done = int(dist.allreduce_sum(float(done)))
+            byts = dist.allreduce_sum(float(byts)) / world
+        mixed = {"windows_per_gpu": nmix, "iters_per_s": (done if dist is not None else world * done) / dt, "lm_trials_per_iter": trials / max(done, 1),
                  "ms_per_optimize10": 1e3 * dt / reps, "whole_step_achieved_gbs": byts / dt / 1e9,
                  "whole_step_frac": byts / dt / 1e9 / HBM_PEAK_GBS, "path": _batch_path_name(),
                  "key_frames": [min(gm.P for gm in gs), max(gm.P for gm in gs)], "landmarks": [min(gm.L for gm in gs), max(gm.L for gm in gs)],

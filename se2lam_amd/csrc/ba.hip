@@ -971,9 +971,10 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
 //      block column m = 0..j-1 as soon as that column is published (left-looking; only m = j-1 is on the critical path),
 //   2. eliminates the stacked [D; T] exactly like k_chol_step (wave 0, lane = row),
 //   3. publishes its result and raises flag(i,j) (agent-scope release; consumers poll with a bounded spin).
-// Tasks are ordered by block column, dependencies point to lower workgroup ids only, so the dataflow cannot deadlock
-// even when the grid exceeds what is resident (in-order dispatch); a spin that exceeds 2 s reports a failure instead
-// of hanging.  The factorisation is kept in LDL^T form, which takes the 32 reciprocal square roots off the critical
+// Tasks are ordered by block column, dependencies point to lower task numbers only, and a workgroup DRAWS its task number
+// from a counter when it starts (not its block index): whatever it waits for is already running, whatever order the
+// workgroups of the grid are dispatched in.  A spin that exceeds 2 s would report a failure instead of hanging (reached
+// only by the fault-injection test).  The factorisation is kept in LDL^T form, which takes the 32 reciprocal square roots off the critical
 // path: with M = the unnormalised elimination result and MR = M * diag(1/pivot),
 //      L L^T = MR M^T,    x = R y = MR_R y_un      (no square root anywhere)
 // both M (in place in A / R) and MR (in AM / RM) are published.  Flags carry the solve's epoch: no clearing needed.
@@ -1039,15 +1040,26 @@ __device__ inline unsigned long long bits4(d2_t a, d2_t b) {
            (unsigned long long)__double_as_longlong(b.x) ^ (unsigned long long)__double_as_longlong(b.y);
 }
 template <bool VERIFY>
-__device__ __forceinline__ void d_chol_tiles(const unsigned bx, const double* __restrict__ A, double* __restrict__ PUB,
+__device__ __forceinline__ void d_chol_tiles(const unsigned bx_dispatch, const double* __restrict__ A, double* __restrict__ PUB,
                                                      double* __restrict__ YU, int ld, int n,
                                                      int nbc, const int4* __restrict__ tasks, const int* __restrict__ deps,
                                                      const int* __restrict__ col_src,
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
-                                                     double* __restrict__ xout, unsigned long long* __restrict__ vfy) {
+                                                     double* __restrict__ xout, unsigned long long* __restrict__ vfy,
+                                                     unsigned long long* __restrict__ head, int ntask) {
+    (void)bx_dispatch;
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
+    // Which task a workgroup runs is not its block index but the next number of a counter it draws when it STARTS (round 6): the
+    // tasks are listed in topological order, so whatever a task waits for has been drawn by a workgroup that is already running -
+    // no assumption about the order in which the hardware dispatches the workgroups of a grid is left (HIP promises none), and the
+    // spin time-out below is unreachable by construction (it stays as the guard of the fault-injection test).  Every launch of a
+    // handle draws exactly `ntask` numbers (all workgroups pass here or none does), the counter is 64 bits wide and never reset.
+    __shared__ unsigned task_s;
+    if (threadIdx.x == 0) task_s = (unsigned)(atomicAdd(head, 1ull) % (unsigned long long)ntask);
+    __syncthreads();
+    const unsigned bx = task_s;
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     const int nt = ld / kNB;
     // LDS: 36 KB per task (was 59), so that more tasks share a CU when a batch of windows is solved side by side
@@ -1419,8 +1431,9 @@ __global__ __launch_bounds__(256) void k_chol_tiles(const double* __restrict__ A
                                                      unsigned* __restrict__ flagA, unsigned* __restrict__ flagR,
                                                      const unsigned* __restrict__ epoch_ptr, double* __restrict__ fail,
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
-                                                     double* __restrict__ xout, unsigned long long* __restrict__ vfy) {
-    d_chol_tiles<VERIFY>(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout, vfy);
+                                                     double* __restrict__ xout, unsigned long long* __restrict__ vfy,
+                                                     unsigned long long* __restrict__ head, int ntask) {
+    d_chol_tiles<VERIFY>(blockIdx.x, A, PUB, YU, ld, n, nbc, tasks, deps, col_src, flagA, flagR, epoch_ptr, fail, dbg, ctl, xout, vfy, head, ntask);
 }
 
 // x = R y  (R = L^-T upper triangular, y = augmented row n of A).  One wave per row.
@@ -2919,6 +2932,7 @@ struct se2gpu_ba {
     int nsys = 0;                 // order of the (padded) system the solver factorises; D * P in natural order
     int solve_depth = 0;          // block columns on the longest dependency chain of the plan (debug)
     DevBuf<unsigned> chol_flags;  // [2][nt][nbc][kSlabs] epochs
+    DevBuf<unsigned long long> chol_head;   // k_chol_tiles: task numbers drawn so far (a workgroup's task = this count mod the task count)
     DevBuf<unsigned long long> chol_vfy;   // SE2GPU_BA_CHOL_VERIFY=1: mismatch records + half-slab checksums (d_chol_tiles<true>)
     DevBuf<int> plan_place;       // k_plan_tab -> k_plan_tabscan -> k_plan_place: the 256 runs' transfer tables, then their start states
     DevBuf<unsigned> fin_counter; // k_update: landmark workgroups that have published their partials (FinArgs)
@@ -4322,6 +4336,8 @@ int ba_upload_graph(se2gpu_ba* h) {
         const int nt2 = h->ld / kNB, nbc2 = (h->nsys + kNB - 1) / kNB;
         SE2_CHECK(h->chol_flags.reserve(2 * kSlabs * (size_t)nt2 * nbc2));
         SE2_HIP(hipMemsetAsync(h->chol_flags.p, 0, 2 * kSlabs * (size_t)nt2 * nbc2 * sizeof(unsigned), st));   // flags = 0 = "no epoch yet"
+        SE2_CHECK(h->chol_head.reserve(1));
+        SE2_HIP(hipMemsetAsync(h->chol_head.p, 0, sizeof(unsigned long long), st));
         static const bool verify = [] { const char* e = getenv("SE2GPU_BA_CHOL_VERIFY"); return e && e[0] == '1'; }();
         if (verify) {
             const size_t words = kVfyChk + 2 * 2 * kSlabs * (size_t)nt2 * nbc2;
@@ -4664,11 +4680,11 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         if (h->chol_vfy.p)
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                       fail, h->chol_trace.p, c, h->xp.p, h->chol_vfy.p);
+                       fail, h->chol_trace.p, c, h->xp.p, h->chol_vfy.p, h->chol_head.p, h->chol_ntask - skip);
         else
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                       fail, h->chol_trace.p, c, h->xp.p, (unsigned long long*)nullptr);
+                       fail, h->chol_trace.p, c, h->xp.p, (unsigned long long*)nullptr, h->chol_head.p, h->chol_ntask - skip);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;
@@ -5023,11 +5039,11 @@ int ba_build_batch_plan(BatchPlan& bp, se2gpu_ba** hs, int count, int iters, int
             if (bp.verify)
                 bp.chol_v.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, n, nbc, h->chol_tasks.p, (const int*)h->chol_deps.p,
                               (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                              fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p, h->chol_vfy.p);
+                              fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p, h->chol_vfy.p, h->chol_head.p, h->chol_ntask);
             else
                 bp.chol.add(h->chol_ntask, (const double*)h->red, Rm, YU, ld, n, nbc, h->chol_tasks.p, (const int*)h->chol_deps.p,
                             (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                            fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p, (unsigned long long*)nullptr);
+                            fail, h->chol_trace.p, (const BaCtl*)h->ctl.p, h->xp.p, (unsigned long long*)nullptr, h->chol_head.p, h->chol_ntask);
         }
     }
     bp.ctl_init.commit(bp.arena); bp.eval0.commit(bp.arena); bp.step.commit(bp.arena); bp.step_notify.commit(bp.arena);
@@ -5990,9 +6006,9 @@ int ba_run_step(se2gpu_ba* h, bool wait, const volatile uint8_t* stop_flag, int 
     BaCtl c;
     std::memcpy(&c, (const void*)(h->h_mail + 8), sizeof(BaCtl));
     if (c.error && !h->chol_steps) {
-        // The dataflow of k_chol_tiles relies on workgroups being dispatched in task order once the grid exceeds what is
-        // resident; should a runtime ever break that, a dependency spin times out (2 s) instead of hanging - and the handle
-        // falls back to one launch per block column (k_chol_step) for the rest of its life.  The failed trial changed
+        // A dependency spin of k_chol_tiles timed out (2 s).  Since round 6 the tasks are drawn from a counter in topological
+        // order, so this cannot follow from the order of dispatch any more; it is what SE2GPU_BA_CHOL_FAULT=1 injects (a launch
+        // without its first task).  The handle then falls back to one launch per block column (k_chol_step) for the rest of its life.  The failed trial changed
         // nothing (lm_advance returns before touching the state), so it is simply redone.
         std::fprintf(stderr, "se2gpu_ba: k_chol_tiles timed out; continuing with k_chol_step\n");
         h->chol_steps = h->chol_fallback = true;

@@ -85,6 +85,20 @@ class Rendezvous:
         self.sock.sendall(struct.pack("<d", value))
         return struct.unpack("<d", _recv_exact(self.sock, 8))[0]
 
+    def allreduce_sum(self, value: float) -> float:
+        """the sum over ranks, added in rank order on rank 0 (every rank gets the same bits)"""
+        if self.world == 1:
+            return value
+        if self.rank == 0:
+            total = value
+            for p in self.peers:
+                total += struct.unpack("<d", _recv_exact(p, 8))[0]
+            for p in self.peers:
+                p.sendall(struct.pack("<d", total))
+            return total
+        self.sock.sendall(struct.pack("<d", value))
+        return struct.unpack("<d", _recv_exact(self.sock, 8))[0]
+
     def barrier(self):
         self.allreduce_max(0.0)
 
