@@ -33,8 +33,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 ITERS_PER_CALL = 10    # Config::LOCAL_ITER of the synthetic setup
-MIN_TIMED_S = 2.0      # floor of the timed region of the headline leg (long enough for a 5 s SMI sampler to see the device busy)
-MIN_WINDOWS_S = 0.4    # ... of every row of the window sweep (its best row is then timed again for MIN_TIMED_S)
+MIN_TIMED_S = float(os.environ.get("SE2_BENCH_MIN_TIMED_S", "2.0"))   # (the profiling captures of tools/capture.sh shorten it) floor of the timed region of the headline leg (long enough for a 5 s SMI sampler to see the device busy)
+MIN_WINDOWS_S = min(0.4, MIN_TIMED_S)    # ... of every row of the window sweep (its best row is then timed again for MIN_TIMED_S)
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector = matrix peak (MI355X_MICROARCH.md)
 
 
@@ -94,6 +94,7 @@ def parse():
                          "handle.  Three since round 5: 201-203 k frames/s against 193-194 k with two (the third batch fills what the "
                          "latency-bound tail of a batch leaves idle); the PCIe-inclusive leg keeps two (its copies need the other queues)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--ba-mixed", type=int, default=1, help="0: skip the batch of distinct windows of the window leg")
     ap.add_argument("--ba-windows", type=int, default=-1,
                     help="independent 50-KF local windows optimised concurrently per GPU (se2gpu_ba_optimize_batch); "
                          "-1 = sweep 1, 8, 32, 64; 0 = skip")
@@ -485,7 +486,7 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
             best = timed(MIN_TIMED_S)
             log(f"BA windows x{nb}, {best['timed_s']:.1f} s: {best['iters_per_s']:.0f} it/s aggregate ({best['path']})")
     mixed = None
-    if args.ba_windows <= 0 or args.ba_windows >= 16:
+    if args.ba_mixed and (args.ba_windows <= 0 or args.ba_windows >= 16):
         # the same batch size with DISTINCT windows (30-60 key frames, 3-6 k landmarks, different seeds, a few starts that
         # reject trials): sizes, solve plans and accept / reject patterns differ per window - the honest form of the number above
         nmix = args.ba_windows if args.ba_windows > 0 else 128
@@ -522,6 +523,14 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
                  "edges_total": int(sum(gm.E for gm in gs)), "windows_with_rejected_trials": int(sum(1 for o in mopts if max(o.stats["trials_hist"]) > 1))}
         log(f"BA windows x{nmix} (distinct windows): {mixed['iters_per_s']:.0f} it/s aggregate, {mixed['lm_trials_per_iter']:.2f} trials per iteration")
         del mopts
+    traffic = _pmc_traffic()
+    tw = traffic.get("k_window_lm")
+    if tw and tw.get("windows_per_launch"):
+        # HBM bytes of ONE LM iteration of one window on the resident path, from the PMC capture of tools/capture.sh (its launches hold
+        # `windows_per_launch` uniform windows, ITERS_PER_CALL iterations each, plus the two opening passes of an optimize())
+        per_it = tw["traffic_bytes"] / (tw["windows_per_launch"] * ITERS_PER_CALL)
+        best["resident_traffic"] = {"bytes_per_window_iteration": per_it, "algorithmic_bytes_per_iter": B, "ratio": per_it / B,
+                                    "code_sha": tw.get("code_sha")}
     return {"metric": "BA LM-iters/s, independent 50-KF windows in flight", "value": best["iters_per_s"],
             "unit": "iters/s", "n_gpus": world, "scaling": "weak",
             "config": {"workload": f"localBA window {g.P} KF / {g.L} landmarks / {g.E} EdgeSE2XYZ + {g.O} PreEdgeSE2, "

@@ -1055,9 +1055,14 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx_dispatch, const d
     // tasks are listed in topological order, so whatever a task waits for has been drawn by a workgroup that is already running -
     // no assumption about the order in which the hardware dispatches the workgroups of a grid is left (HIP promises none), and the
     // spin time-out below is unreachable by construction (it stays as the guard of the fault-injection test).  Every launch of a
-    // handle draws exactly `ntask` numbers (all workgroups pass here or none does), the counter is 64 bits wide and never reset.
+    // handle draws exactly `ntask` numbers (all workgroups pass here or none does); whoever draws the last one puts the counter
+    // back to zero for the next launch, which cannot start before this one has ended.
     __shared__ unsigned task_s;
-    if (threadIdx.x == 0) task_s = (unsigned)(atomicAdd(head, 1ull) % (unsigned long long)ntask);
+    if (threadIdx.x == 0) {
+        const unsigned c = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(head), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == (unsigned)ntask - 1u) __hip_atomic_store(reinterpret_cast<unsigned*>(head), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        task_s = c;
+    }
     __syncthreads();
     const unsigned bx = task_s;
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)

@@ -1910,6 +1910,7 @@ struct se2gpu_orb {
     DevBuf<int2> cell_plan;                  // k_quota: {nToRetain, place in the level's list} per cell
     DevBuf<int4> cell_geo;                   // CellGeoRec per cell: [0, ncell) for the dense score kernel's lists, [ncell, 2 ncell) sparse
     DevBuf<int> defer_q;                     // cells k_cell_collect_w left to k_cell_collect_big: {count, entries ...}
+    bool defer_dirty = false;                // a run was cut short between k_cell_collect_w and k_quota: defer_q[0] may not be zero
     DevBuf<int4> kp_list, tabs;
     DevBuf<float> angles;
     DevBuf<uint32_t> cell_scr;               // scratch of the huge-cell paths (Geom::lscr_off)
@@ -2014,7 +2015,8 @@ int orb_configure(se2gpu_orb* h, int rows, int cols) {
         int lc = 64;
         for (int l = 0; l < L; ++l) lc = std::max(lc, g.quota[l] + 2 * g.gcols[l] * g.grows[l]);
         lc = (lc + 63) & ~63;
-        SE2_REQUIRE((size_t)lc * ((g.harris ? 8 : 4) + 4) <= 64 * 1024 && lc < 65536, SE2GPU_ERR_INVALID,
+        // (64 bytes of the 64 KiB are k_level_select's static LDS: the launch at the exact limit would be refused by the runtime)
+        SE2_REQUIRE((size_t)lc * ((g.harris ? 8 : 4) + 4) <= 64 * 1024 - 64 && lc < 65536, SE2GPU_ERR_INVALID,
                     "%d features on one pyramid level exceed the level list (at most %d)", lc, g.harris ? 5440 : 8128);
         g.level_cap = lc;
     }
@@ -2281,6 +2283,11 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         h->fs_frames = nframes;
     }
     h->last_lists = g;
+    // Only k_quota puts the deferred-cell count back to zero.  Should a run ever leave between k_cell_collect_w and k_quota (a launch
+    // error), the count would carry into the next batch and k_cell_collect_w would append beyond the queue: a run that
+    // did not get past k_quota leaves the flag set, and the next one clears the word first.
+    if (h->defer_dirty) SE2_HIP(hipMemsetAsync(h->defer_q.p, 0, sizeof(int), st));
+    h->defer_dirty = true;
     const unsigned ncell = (unsigned)g.cell_base[L];
     const CellGeoRec* geo = reinterpret_cast<const CellGeoRec*>(h->cell_geo.p) + (run_sparse ? ncell : 0u);
     constexpr unsigned kBigGrid = 512;   // workgroups that share the deferred cells of a batch (normally none)
@@ -2293,6 +2300,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, st, "k_cell_collect_big", k_cell_collect_big<true>, dim3(kBigGrid), dim3(256), 0, g, h->defer_q.p,
                    h->lst_ent.p, h->lst_cnt.p, h->pyr.p, ent, h->cell_scr.p, h->cell_total.p, h->overflow.p);
         SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p, h->defer_q.p);
+        h->defer_dirty = false;
         if (ncell)
             SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<true>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo, ent,
                        h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
@@ -2305,6 +2313,7 @@ int orb_run(se2gpu_orb* h, const uint8_t* d_imgs, int pitch, int nframes, se2gpu
         SE2_LAUNCH(h->prof, st, "k_cell_collect_big", k_cell_collect_big<false>, dim3(kBigGrid), dim3(256), 0, g, h->defer_q.p,
                    h->lst_ent.p, h->lst_cnt.p, h->pyr.p, h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->overflow.p);
         SE2_LAUNCH(h->prof, st, "k_quota", k_quota, dim3(F8, L), dim3(64), 0, g, h->cell_total.p, h->cell_plan.p, h->defer_q.p);
+        h->defer_dirty = false;
         if (ncell)
             SE2_LAUNCH(h->prof, st, "k_cell_retain", k_cell_retain<false>, dim3(F8, (ncell + 3) / 4), dim3(256), 0, g, geo,
                        h->cell_keys.p, h->cell_scr.p, h->cell_total.p, h->cell_plan.p, h->overflow.p);
@@ -2347,10 +2356,10 @@ int se2gpu_orb_create(const se2gpu_orb_params* params, se2gpu_orb** out) {
     SE2_REQUIRE(params->nlevels >= 1 && params->nlevels <= kMaxLevels && params->nfeatures > 0 &&
                     params->scale_factor > 1.0f && params->fast_th >= 7 && params->fast_th < 255,
                 SE2GPU_ERR_INVALID, "orb_create: parameter out of range");
+    SE2_REQUIRE(params->max_batch < 32768, SE2GPU_ERR_INVALID, "max_batch %d: at most 32767 frames per batch", params->max_batch);   // (before the handle exists: nothing to free on this path)
     se2gpu_orb* h = new se2gpu_orb;
     h->params = *params;
     if (h->params.max_rows <= 0 || h->params.max_cols <= 0) { h->params.max_rows = 480; h->params.max_cols = 640; }
-    SE2_REQUIRE(params->max_batch < 32768, SE2GPU_ERR_INVALID, "max_batch %d: at most 32767 frames per batch", params->max_batch);
     h->max_batch = std::max(1, params->max_batch);
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;

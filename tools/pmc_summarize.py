@@ -49,6 +49,8 @@ def main():
         w = sum(W.get(k, [0.0])) / max(len(W.get(k, [0.0])), 1)
         out[k] = {"launches": len(F[k]), "fetch_size_kib_avg": f, "write_size_kib_avg": w,
                   "traffic_bytes": (2 * f + w) * 1024, "code_sha": code.get(k)}
+        if k == "k_window_lm" and os.environ.get("SE2_PMC_WINDOWS"):   # the resident BA kernel: one launch = this many windows' optimize(10)
+            out[k]["windows_per_launch"] = int(os.environ["SE2_PMC_WINDOWS"])
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in out.items():
         if k != "_meta":
