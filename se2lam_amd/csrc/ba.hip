@@ -973,7 +973,8 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ A, doubl
 //   3. publishes its result and raises flag(i,j) (agent-scope release; consumers poll with a bounded spin).
 // Tasks are ordered by block column, dependencies point to lower task numbers only, and a workgroup DRAWS its task number
 // from a counter when it starts (not its block index): whatever it waits for is already running, whatever order the
-// workgroups of the grid are dispatched in.  A spin that exceeds 2 s would report a failure instead of hanging (reached
+// workgroups of the grid are dispatched in.  (A grid of at most half the device's resident workgroups - one window's solve -
+// skips the counter: all of it is dispatched in any case.)  A spin that exceeds 2 s would report a failure instead of hanging (reached
 // only by the fault-injection test).  The factorisation is kept in LDL^T form, which takes the 32 reciprocal square roots off the critical
 // path: with M = the unnormalised elimination result and MR = M * diag(1/pivot),
 //      L L^T = MR M^T,    x = R y = MR_R y_un      (no square root anywhere)
@@ -1049,7 +1050,6 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx_dispatch, const d
                                                      long long* __restrict__ dbg, const BaCtl* __restrict__ ctl,
                                                      double* __restrict__ xout, unsigned long long* __restrict__ vfy,
                                                      unsigned long long* __restrict__ head, int ntask) {
-    (void)bx_dispatch;
     if (ctl && ctl->done) return;   // uniform over the grid: nobody waits for a tile that will not be published
     // Which task a workgroup runs is not its block index but the next number of a counter it draws when it STARTS (round 6): the
     // tasks are listed in topological order, so whatever a task waits for has been drawn by a workgroup that is already running -
@@ -1057,14 +1057,19 @@ __device__ __forceinline__ void d_chol_tiles(const unsigned bx_dispatch, const d
     // spin time-out below is unreachable by construction (it stays as the guard of the fault-injection test).  Every launch of a
     // handle draws exactly `ntask` numbers (all workgroups pass here or none does); whoever draws the last one puts the counter
     // back to zero for the next launch, which cannot start before this one has ended.
+    // head == nullptr: the host has checked that the WHOLE grid fits the device at once (ba_chol_grid_fits) - then every workgroup
+    // is dispatched whatever the others wait for, the block index can be the task number, and the first task of the chain does not
+    // pay the counter's round trip (2-3 us of a 96 us solve).
     __shared__ unsigned task_s;
-    if (threadIdx.x == 0) {
-        const unsigned c = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(head), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c == (unsigned)ntask - 1u) __hip_atomic_store(reinterpret_cast<unsigned*>(head), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        task_s = c;
+    if (head) {
+        if (threadIdx.x == 0) {
+            const unsigned c = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(head), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == (unsigned)ntask - 1u) __hip_atomic_store(reinterpret_cast<unsigned*>(head), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            task_s = c;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const unsigned bx = task_s;
+    const unsigned bx = head ? task_s : bx_dispatch;
     const unsigned epoch = *epoch_ptr;   // moved on by the kernel that built this system (k_reduce2 / k3_reduce2)
     const int nt = ld / kNB;
     // LDS: 36 KB per task (was 59), so that more tasks share a CU when a batch of windows is solved side by side
@@ -4668,6 +4673,16 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
     const int nt = ld / kNB;                 // tile rows of A (incl. the rhs / padding tile row)
     const int nbc = (n + kNB - 1) / kNB;     // block columns to factor
     double* Rm = h->Rinv.p;
+    // A grid that fits the device at once - with a factor two to spare - needs no task counter: all of its workgroups get a slot
+    // in any order of dispatch (waiting ones hold at most half the slots; whatever else runs on the device ends by itself).
+    static const int capacity = [] {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t pr{};
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_chol_tiles<false>), 256, 0) != hipSuccess) return 0;
+        return per_cu * pr.multiProcessorCount;
+    }();
+    unsigned long long* const head = (2 * h->chol_ntask <= capacity) ? nullptr : h->chol_head.p;
     if (h->chol_steps) {
         for (int k = 0; k < nbc; ++k)  // update with panel k-1 fused with the elimination of panel k
             SE2_LAUNCH(h->prof, st, "k_chol_step", k_chol_step, dim3(nbc - k, nt), dim3(256), 0, A, Rm, ld, n, nt, k, fail, c);
@@ -4685,11 +4700,11 @@ int ba_solve(se2gpu_ba* h, bool ctl = false) {
         if (h->chol_vfy.p)
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<true>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                       fail, h->chol_trace.p, c, h->xp.p, h->chol_vfy.p, h->chol_head.p, h->chol_ntask - skip);
+                       fail, h->chol_trace.p, c, h->xp.p, h->chol_vfy.p, head, h->chol_ntask - skip);
         else
             SE2_LAUNCH(h->prof, st, "k_chol_tiles", k_chol_tiles<false>, dim3(h->chol_ntask - skip), dim3(256), 0, A, Rm, YU, ld, n, nbc,
                        h->chol_tasks.p + skip, (const int*)h->chol_deps.p, (const int*)h->col_src.p, flagA, flagR, &h->ctl.p->epoch,
-                       fail, h->chol_trace.p, c, h->xp.p, (unsigned long long*)nullptr, h->chol_head.p, h->chol_ntask - skip);
+                       fail, h->chol_trace.p, c, h->xp.p, (unsigned long long*)nullptr, head, h->chol_ntask - skip);
     }
     SE2_HIP(hipGetLastError());
     return SE2GPU_OK;

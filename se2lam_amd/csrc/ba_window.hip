@@ -689,7 +689,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     extern __shared__ double lds[];
     __shared__ BaCtl ctl;
     __shared__ int s_nf, s_fail, s_err, s_stop;
-    __shared__ int hist[kWindowMaxDegree + 2], wtot[5][8];
+    __shared__ int hist[kWindowMaxDegree + 2], wtot[18][8];
     __shared__ double red[24], tjj[6];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int P = a.P, L = a.L;
@@ -743,11 +743,15 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     __syncthreads();
     const bool refused = s_err != 0;   // a landmark this kernel does not take: nothing is touched, the caller runs the window elsewhere
     if (!refused) {
-        // the list: a STABLE partition of the landmarks into the five classes (no observation | 1-4 | 5-8 | 9-16 | 17-64), so that
-        // inside a class consecutive groups read ascending addresses of the edge arrays (a list in arbitrary order fetched every
-        // cache line of the edges about twice: PMC, profiles/r06h).  Rounds of NT landmarks; a landmark's place = its class's start
-        // + the class members before it (ballot ranks inside the wave, wave totals through LDS, the rounds' totals in registers).
-        int next[5] = {0, hist[1], hist[5], hist[9], hist[17]};
+        // the list: the landmarks by their number of observations (0, 1, ... 16, more), STABLE inside a count, so that the groups of
+        // a wave are alike (the longest landmark of a wave sets the trip count of its pair loop) and consecutive groups read
+        // ascending addresses of the edge arrays (a list in arbitrary order inside a count fetched every cache line of the edges
+        // about twice: PMC, profiles/r06h).  Rounds of NT landmarks; a landmark's place = its count's start + the members before
+        // it (ballot ranks inside the wave, wave totals through LDS, the rounds' totals in registers).
+        constexpr int kBuckets = 18;
+        int next[kBuckets];
+#pragma unroll
+        for (int b = 0; b < kBuckets; ++b) next[b] = hist[b];
         const int lane = tid & 63;
         const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
         for (int l0 = 0; l0 < L; l0 += NT) {
@@ -756,23 +760,26 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
             if (l < L) {
                 beg = a.lm_ptr[l];
                 k = a.lm_ptr[l + 1] - beg;
-                cls = k == 0 ? 0 : k <= 4 ? 1 : k <= 8 ? 2 : k <= 16 ? 3 : 4;
+                cls = min(k, kBuckets - 1);
             }
             int rank = 0;
 #pragma unroll
-            for (int b = 0; b < 5; ++b) {
+            for (int b = 0; b < kBuckets; ++b) {
                 const unsigned long long m = __ballot(cls == b);
                 if (cls == b) rank = __popcll(m & below);
                 if (lane == 0) wtot[b][wave] = __popcll(m);
             }
             __syncthreads();
             if (cls >= 0) {
-                int at = next[cls] + rank;
+                int at = rank;
+#pragma unroll
+                for (int b = 0; b < kBuckets; ++b)
+                    if (cls == b) at += next[b];
                 for (int w = 0; w < wave; ++w) at += wtot[cls][w];
                 a.desc[at] = make_int4(l, beg, k, 0);
             }
 #pragma unroll
-            for (int b = 0; b < 5; ++b)
+            for (int b = 0; b < kBuckets; ++b)
                 for (int w = 0; w < NT / 64; ++w) next[b] += wtot[b][w];
             __syncthreads();
         }
@@ -937,7 +944,7 @@ size_t ba_window_lds_bytes(int P, int nfree, int threads) {
     size_t doubles = (size_t)(P + 1) / 2 + 10 * (size_t)P + 4 * n + (size_t)threads * kStageDoubles + (n + 3) * (n + 4) / 2;
     const size_t bytes = doubles * 8;
     // static LDS of the kernel: the controller block, the list of wide landmarks, the reduction scratch
-    const size_t fixed = sizeof(BaCtl) + (kWindowMaxDegree + 2 + 40) * sizeof(int) + 30 * 8 + 128;
+    const size_t fixed = sizeof(BaCtl) + (kWindowMaxDegree + 2 + 18 * 8) * sizeof(int) + 30 * 8 + 128;
     if (n > 192 || bytes + fixed > 160 * 1024) return 0;
     return bytes;
 }
