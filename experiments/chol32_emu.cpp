@@ -1,11 +1,11 @@
-// The SHIPPED dense pose solve - d_chol_tiles of se2lam_amd/csrc/ba.hip, its own lines (tools/waveemu/extract_chol_tiles.py cuts them
-// out at build time and lists its few substitutions) - run on the CPU by tools/waveemu: one task after the other in launch order, the
+// The SHIPPED dense pose solve - d_chol_tiles of se2lam_amd/csrc/ba.hip, its own lines (experiments/waveemu/extract_chol_tiles.py cuts them
+// out at build time and lists its few substitutions) - run on the CPU by experiments/waveemu: one task after the other in launch order, the
 // four waves of a task interleaved at random from a seed.  What this looks for is a LOGIC race inside a workgroup that a
 // hardware soak only meets once in hundreds of runs: the slab counters against the staging tiles, the multiplier columns that are
 // overlaid on Tc / Ta (`loaded_s`), `ready_s` against COLV / MRC, the x tasks.  What it cannot see: the memory ordering between
 // workgroups (the emulator's stores are visible at once) - that is what tools/soak_fresh.sh checks on the GPU.  Test harness only.
-//   python tools/waveemu/extract_chol_tiles.py /tmp/chol32_body.inc
-//   g++ -O2 -std=c++17 -pthread -I tools/waveemu -I /tmp tools/chol32_emu.cpp -o /tmp/chol32_emu && /tmp/chol32_emu nd 3 5 1 20
+//   python experiments/waveemu/extract_chol_tiles.py /tmp/chol32_body.inc
+//   g++ -O2 -std=c++17 -pthread -I experiments/waveemu -I /tmp experiments/chol32_emu.cpp -o /tmp/chol32_emu && /tmp/chol32_emu nd 3 5 1 20
 //   SE2_EMU_RESIDENT=4 /tmp/chol32_emu 100 50     (the tasks of a launch side by side, four in flight, dispatched in index order)
 #include "waveemu.h"
 
@@ -82,9 +82,10 @@ int main(int argc, char** argv) {
         double* YU = PUB.data() + 2 * (size_t)S.nt * S.nbc * kSlabs * kSlabDoubles;
         unsigned epoch = seed;
         unsigned long long sw = 0;
+        static unsigned long long head = 0;   // the launch's task counter (round 6): a workgroup's task is the number it draws, not its block index
         auto task = [&]() {
             d_chol_tiles<false>(blockIdx.x, S.A.data(), PUB.data(), YU, S.ld, S.n, S.nbc, S.plan.tasks.data(), S.plan.deps.data(), nullptr, flagA.data(), flagR.data(),
-                                &epoch, &fail, nullptr, nullptr, x.data(), nullptr);
+                                &epoch, &fail, nullptr, nullptr, x.data(), nullptr, &head, ntask);
             WAIT_VM();      // (the end of a wave completes what it has in flight)
         };
         if (resident > 0)       // the whole launch side by side: `resident` workgroups in flight on OS threads, dispatched in index order

@@ -1,4 +1,4 @@
-// The 64-wide block column of DESIGN.md 8.1 (ii) as a standalone experiment: the elimination of the stacked [D; T] - a 64 x 64
+// The 64-wide block column of docs/history/DESIGN_rounds_1-5.md 8.1 (ii) as a standalone experiment: the elimination of the stacked [D; T] - a 64 x 64
 // diagonal copy D and a 64 x 64 tile T - by SIXTEEN waves, in the LDL^T form of k_chol_tiles (csrc/ba.hip):
 //      M = the unnormalised elimination result, MR = M diag(1 / pivot);   [D; T] = [MR_D; MR_T] diag(pivot) MR_D^T
 //   waves 0..7  own columns 8 w .. 8 w + 7 over the 64 D rows (lane = row): the pivot chain, as wave w of k_chol_tiles today -

@@ -1,5 +1,5 @@
 // The dense pose solve of csrc/ba.hip (k_chol_tiles: LDL^T of the augmented system as one dataflow launch over tiles, x = R y)
-// with 64-WIDE block columns and SIXTEEN waves per task - DESIGN.md 8.1 (ii) built as a standalone prototype, so that it can be
+// with 64-WIDE block columns and SIXTEEN waves per task - docs/history/DESIGN_rounds_1-5.md 8.1 (ii) built as a standalone prototype, so that it can be
 // measured against k_chol_tiles before any of the product is touched:
 //   * update phase: the 64 x 64 x 64 tile products on the matrix cores, wave (a, b) of the 4 x 4 grid owns the 16 x 16 quadrant
 //     (a, b) of T and of the private copy of D; the operand tiles travel in eight 8-column slabs - waves 0..7 fetch and stage the

@@ -1,5 +1,5 @@
 #!/bin/bash
-# The two 64-wide block column experiments of DESIGN.md 8.1 on the GPU box (each run under its own timeout; the kernels give up on a
+# The two 64-wide block column experiments of docs/history/DESIGN_rounds_1-5.md 8.1 on the GPU box (each run under its own timeout; the kernels give up on a
 # flag after 2 s by themselves):   gpurun --timeout 300 -- 'bash tools/gpu_chol64.sh'
 cd "${GRAFT_REPO_ROOT:-.}" || exit 1
 mkdir -p gpurun_out tools/bin

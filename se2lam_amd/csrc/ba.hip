@@ -5812,7 +5812,7 @@ int se2gpu_ba_debug_reduced_system(se2gpu_ba* h, double lambda, double* S, doubl
 // The plan of the dense pose solve for a P x P block pattern (row-major bytes, != 0 where two poses share a landmark or an
 // odometry edge; NULL = dense), without a device: tests/test_solve_plan.py runs the tile algorithm of k_chol_tiles in numpy
 // from these lists.  Arrays may be NULL (sizes only); tasks: {tile row | kind << 16, block column, first dep, end dep}.
-// (the same with the tile size as an argument: 32 = what k_chol_tiles runs on, 64 = the wide block column of DESIGN.md 8.1)
+// (the same with the tile size as an argument: 32 = what k_chol_tiles runs on, 64 = the wide block column of docs/history/DESIGN_rounds_1-5.md 8.1)
 int se2gpu_ba_debug_solve_plan_tile(int P, int D, const uint8_t* pattern, int allow_nd, int tile, int* nsys, int* nbc, int* depth, int* ntask,
                                     int* ndep, int32_t* pose_off, int32_t* tasks4, int task_cap, int32_t* deps, int dep_cap) {
     SE2_REQUIRE(P > 0 && (D == 3 || D == 6) && (tile == 32 || tile == 64) && nsys && nbc && depth && ntask && ndep, SE2GPU_ERR_INVALID, "debug_solve_plan_tile: bad argument");

@@ -196,7 +196,7 @@ def test_one_sided_pattern_gives_the_plan_of_its_symmetric_closure():
     ("open band 64 / 30 (too wide to cut)", 64, _band(64, 30, False)),
 ])
 def test_tile_tasks_solve_the_system_at_tile_64(monkeypatch, name, P, pattern):
-    """the plan for the wide block column: the same numpy executor, 64 x 64 tiles"""
+    """the plan for the wide block column (docs/history/DESIGN_rounds_1-5.md 8.1): the same numpy executor, 64 x 64 tiles"""
     import sys
     monkeypatch.setattr(sys.modules[__name__], "NB", 64)
     rng = np.random.default_rng(P)

@@ -1,6 +1,6 @@
-"""tools/chol64_probe.hip and tools/chol64_solve.hip - the sixteen-wave, 64-wide block column of DESIGN.md 8.1 (ii): the elimination
+"""experiments/chol64_probe.hip and experiments/chol64_solve.hip - the sixteen-wave, 64-wide block column of docs/history/DESIGN_rounds_1-5.md 8.1 (ii): the elimination
 alone, and the whole dense pose solve as a standalone prototype of k_chol_tiles at that tile size - are experiments for the next
-round, written without a GPU.  Their LOGIC runs here on the CPU under tools/waveemu (every work-item a fibre, the waves of a
+round, written without a GPU.  Their LOGIC runs here on the CPU under experiments/waveemu (every work-item a fibre, the waves of a
 task interleaved at random from a seed, wave collectives and the MFMA through an exchange buffer): LDS progress counters, who
 reads which pivot row when, the T waves one hop behind the D waves, the plan, the flags, the staging counters, the MFMA operand
 mapping, the publish layout, the x tasks.  What the experiments are for - the cost of a pivot and of a block column with
@@ -20,8 +20,8 @@ def test_sixteen_wave_block_column_under_the_wave_emulator(tmp_path, catch):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "chol64_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", f"-DCATCH={catch}", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
-                        os.path.join(ROOT, "tools", "chol64_probe.hip"), "-o", exe], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", f"-DCATCH={catch}", "-I", os.path.join(ROOT, "experiments", "waveemu"), "-x", "c++",
+                        os.path.join(ROOT, "experiments", "chol64_probe.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, "2", "2", "6"], capture_output=True, text=True, timeout=300)       # 2 blocks, 2 repetitions, 6 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
@@ -36,8 +36,8 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     exe = str(tmp_path / "chol64_solve_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", "-Wno-psabi", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
-                        os.path.join(ROOT, "tools", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", "-Wno-psabi", "-I", os.path.join(ROOT, "experiments", "waveemu"), "-x", "c++",
+                        os.path.join(ROOT, "experiments", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, *n, "1", "3"], capture_output=True, text=True, timeout=600)       # 1 repetition, 3 interleavings
     assert r.returncode == 0, r.stdout + r.stderr
@@ -49,7 +49,7 @@ def test_64_wide_solve_prototype_under_the_wave_emulator(tmp_path, n):
 
 def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
     """The product's own d_chol_tiles (se2lam_amd/csrc/ba.hip) - cut out of the source at test time by
-    tools/waveemu/extract_chol_tiles.py, which fails if one of its anchors has moved - solves dense and arcs + separator systems
+    experiments/waveemu/extract_chol_tiles.py, which fails if one of its anchors has moved - solves dense and arcs + separator systems
     on the CPU with its four waves interleaved adversarially (seeded weights starve a wave while the others run ahead).  A logic
     race inside a workgroup - slab counters against the staging tiles, the multiplier columns overlaid on Tc / Ta, `ready_s` against
     COLV / MRC - shows as a wrong solution or a hang.  (Removing the kernel's `loaded_s` wait is caught in 4 of 100 interleavings:
@@ -57,10 +57,10 @@ def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
     if shutil.which("g++") is None:
         pytest.skip("no g++")
     inc = tmp_path / "chol32_body.inc"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     exe = str(tmp_path / "chol32_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tools", "waveemu"), "-pthread", "-I", str(tmp_path), os.path.join(ROOT, "tools", "chol32_emu.cpp"),
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "experiments", "waveemu"), "-pthread", "-I", str(tmp_path), os.path.join(ROOT, "experiments", "chol32_emu.cpp"),
                         "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for args, n in ((("100", "12"), 12), (("63", "4"), 4), (("nd", "1", "2", "1", "4"), 4)):
@@ -76,14 +76,14 @@ def test_shipped_dense_solve_kernel_under_the_wave_emulator(tmp_path):
 
 
 def test_staged_patches_still_apply():
-    """tools/patches holds changes to the product that were written and checked as far as a machine without a GPU allows; they must
+    """experiments/patches holds changes to the product that were written and checked as far as a machine without a GPU allows; they must
     keep applying to the tree they were written against (a change of the kernel underneath is noticed here, not next round)."""
     if shutil.which("git") is None or not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("not a git checkout")
-    pdir = os.path.join(ROOT, "tools", "patches")
+    pdir = os.path.join(ROOT, "experiments", "patches")
     patches = sorted(f for f in os.listdir(pdir) if f.endswith(".patch"))
     if not patches:
-        pytest.skip("nothing is staged (round 5 applied one of round 4's two patches and dropped the other: tools/patches/README.md)")
+        pytest.skip("nothing is staged (round 5 applied one of round 4's two patches and dropped the other: experiments/patches/README.md)")
     for f in patches:
         r = subprocess.run(["git", "apply", "--check", os.path.join(pdir, f)], cwd=ROOT, capture_output=True, text=True)
         assert r.returncode == 0, f + ": " + r.stderr
@@ -91,7 +91,7 @@ def test_staged_patches_still_apply():
 
 @pytest.mark.parametrize("P", [21, 33, 64])
 def test_experiments_plan_equals_the_products_plan(tmp_path, P):
-    """tools/waveemu/chol_host.h builds the task plan the experiments run on (dense, arcs + separator); the product's is
+    """experiments/waveemu/chol_host.h builds the task plan the experiments run on (dense, arcs + separator); the product's is
     solve_plan_build in csrc/ba.hip.  On a dense system of P poses the two must be the same lists - the emulated kernel then runs on
     exactly what the device kernel is given."""
     if shutil.which("g++") is None:
@@ -99,11 +99,11 @@ def test_experiments_plan_equals_the_products_plan(tmp_path, P):
     import numpy as np
     from test_solve_plan import _plan
     inc = tmp_path / "chol32_body.inc"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     exe = str(tmp_path / "chol32_emu")
-    r = subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path),
-                        os.path.join(ROOT, "tools", "chol32_emu.cpp"), "-o", exe], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "experiments", "waveemu"), "-I", str(tmp_path),
+                        os.path.join(ROOT, "experiments", "chol32_emu.cpp"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe, str(3 * P)], capture_output=True, text=True, env=dict(os.environ, SE2_EMU_PRINT_PLAN="1")).stdout.split("\n")
     tasks = np.array([[int(v) for v in l.split()[1:]] for l in out if l.startswith("T ")], np.int32)
@@ -143,8 +143,8 @@ def test_64_wide_prototype_on_the_products_own_tile_64_plan(tmp_path):
         f.write(np.ascontiguousarray(plan["deps"], np.int32).tobytes())
         f.write(np.ascontiguousarray(A, np.float64).tobytes())
     exe = str(tmp_path / "chol64_solve_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", "-I", os.path.join(ROOT, "tools", "waveemu"), "-x", "c++",
-                        os.path.join(ROOT, "tools", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-DWAVEEMU", "-I", os.path.join(ROOT, "experiments", "waveemu"), "-x", "c++",
+                        os.path.join(ROOT, "experiments", "chol64_solve.hip"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for env in ({}, {"SE2_EMU_RESIDENT": "3"}):
         r = subprocess.run([exe, "file", path, "1", "1"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
@@ -186,11 +186,11 @@ def test_shipped_kernel_on_the_products_own_plan(tmp_path):
     plan = _write_system(path, 120, T._band(120, 12, False), 32)
     assert plan["nsys"] % 32 == 0 and plan["depth"] < plan["nbc"]
     inc = tmp_path / "chol32_body.inc"
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "experiments", "waveemu", "extract_chol_tiles.py"), str(inc)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     exe = str(tmp_path / "chol32_emu")
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "tools", "waveemu"), "-I", str(tmp_path),
-                        os.path.join(ROOT, "tools", "chol32_emu.cpp"), "-o", exe], capture_output=True, text=True)
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "experiments", "waveemu"), "-I", str(tmp_path),
+                        os.path.join(ROOT, "experiments", "chol32_emu.cpp"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for env in ({}, {"SE2_EMU_RESIDENT": "4"}):
         r = subprocess.run([exe, "file", path, "1", "2"], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))

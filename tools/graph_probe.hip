@@ -1,5 +1,5 @@
 // Is a hipGraph launch of a kernel chain cheaper than the same chain launched kernel by kernel?  (window batches of the BA
-// are bound by the launch rate)
+// are bound by the launch rate, docs/history/DESIGN_rounds_1-5.md 4.1.2)
 //   hipcc --offload-arch=gfx950 -O3 tools/graph_probe.hip -o tools/bin/graph_probe && tools/bin/graph_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
