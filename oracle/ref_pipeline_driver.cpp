@@ -6,7 +6,7 @@
 //   libse2lam_pipeline_cpu.so     every reference source, its own ORBextractor.cpp / ORBmatcher.cpp included; g2o's optimize() and
 //                                 cv::findFundamentalMat - third-party libraries the image lacks - from oracle/pipeline_cpu_solver.cpp
 //   libse2lam_pipeline_dropin.so  the same reference sources EXCEPT ORBextractor.cpp / ORBmatcher.cpp, whose place the bindings over
-//                                 libse2gpu take (tests/dropin/ORBextractor.cpp, ORBmatcher.cpp); optimize() and findFundamentalMat go
+//                                 libse2gpu take (tests/dropin/ORBextractor_binding.cpp, ORBmatcher_binding.cpp); optimize() and findFundamentalMat go
 //                                 to libse2gpu too (tests/dropin/g2o_forward.cpp).  No oracle restatement is linked into it.
 // The reference's threads are loops around a few member calls (Track::run, src/Track.cpp:56-103; LocalMapper::run,
 // src/LocalMapper.cpp:304-364) that poll ros::ok() and a mailbox; here the two loop bodies are called in turn for every frame,

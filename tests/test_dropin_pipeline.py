@@ -3,7 +3,7 @@ REFERENCE's own Track / LocalMapper / Map / KeyFrame / MapPoint / Frame sources 
 target `pipeline`), twice:
 
   * the CPU build: the reference's own ORBextractor.cpp / ORBmatcher.cpp, g2o's optimize() and cv::findFundamentalMat from the oracle;
-  * the drop-in build: ORBextractor.cpp / ORBmatcher.cpp REPLACED by tests/dropin/ORBextractor.cpp / ORBmatcher.cpp (the bindings of
+  * the drop-in build: ORBextractor.cpp / ORBmatcher.cpp REPLACED by tests/dropin/ORBextractor_binding.cpp / ORBmatcher_binding.cpp (the bindings of
     INTEGRATION.md sections 1-2 as real files, through include/se2lam_amd/{ORBextractor,ORBmatcher,conversions}.h), optimize() and
     findFundamentalMat forwarded to libse2gpu (tests/dropin/g2o_forward.cpp, through include/se2lam_amd/optimizer.h).
 
