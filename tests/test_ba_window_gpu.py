@@ -174,3 +174,36 @@ def test_default_threshold_keeps_small_batches_on_the_multi_launch_paths(synth):
     optimize_batch(large, 8)
     for o in large:
         _same(o, st, est, "100 windows")
+
+
+def test_resident_edge_cases(synth, resident):
+    """windows at the edges of what the kernel meets: two key frames (configs[0]'s first local BA), no odometry edge, a single free
+    pose, every pose fixed (only the landmarks move), landmarks with a single observation"""
+    import copy
+    from se2lam_amd.optimizer import optimize_batch
+    base = synth.ba_graph(8, 60)
+    two = synth.ba_graph(2, 40)
+    no_odo = copy.copy(base)
+    no_odo.o_i, no_odo.o_j = base.o_i[:0], base.o_j[:0]
+    no_odo.o_meas, no_odo.o_info = base.o_meas[:0], base.o_info[:0]
+    one_free = copy.copy(base)
+    one_free.fixed = np.ones_like(base.fixed)
+    one_free.fixed[3] = 0
+    all_fixed = copy.copy(base)
+    all_fixed.fixed = np.ones_like(base.fixed)
+    single = copy.copy(synth.ba_graph(12, 120))
+    keep = np.ones(single.E, bool)
+    e_lm = np.asarray(single.e_lm)
+    for l in range(0, single.L, 7):                       # every seventh landmark keeps only its first observation
+        idx = np.nonzero(e_lm == l)[0]
+        keep[idx[1:]] = False
+    single.e_kf, single.e_lm = np.asarray(single.e_kf)[keep], e_lm[keep]
+    single.e_uv, single.e_info = np.asarray(single.e_uv)[keep], np.asarray(single.e_info)[keep]
+    graphs = [two, no_odo, one_free, all_fixed, single]
+    ref = [_multi_launch(g, 6) for g in graphs]
+    opts = [_opt(g) for g in graphs]
+    optimize_batch(opts, 6)
+    from se2lam_amd import capi
+    assert int(capi.lib().se2gpu_ba_last_batch_path()) == 2
+    for g, o, (st, est) in zip(graphs, opts, ref):
+        _same(o, st, est, (g.P, g.L, g.E, int(np.asarray(g.fixed).sum())))
