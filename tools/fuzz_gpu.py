@@ -17,7 +17,7 @@ from se2lam_amd.optimizer import SlamOptimizer  # noqa: E402
 from se2lam_amd.orb import ORBextractor  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-KINDS = [int(k) for k in sys.argv[3].split(',')] if len(sys.argv) > 3 else list(range(11))   # e.g. 0,4,5: the three BA models only
+KINDS = [int(k) for k in sys.argv[3].split(',')] if len(sys.argv) > 3 else list(range(12))   # e.g. 0,4,5: the three BA models only; 11 = the one-workgroup-per-window batch path
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t_end = time.time() + budget
 tex = synth.texture()
@@ -241,6 +241,43 @@ while time.time() < t_end:
         print(f"bow  frames {a},{b} bits {nbits} mpOnly {mp_only} ori {ori} ratio {ratio}: {nm} matches {'ok' if ok else ''}")
         if not ok:
             fail("bow")
+        continue
+    if kind == 11:   # a batch of random windows through the one-workgroup-per-window kernel (csrc/ba_window.hip), each against the oracle
+        nb = int(rng.integers(1, 7))
+        gs, its = [], int(rng.integers(1, 11))
+        for _ in range(nb):
+            P = int(rng.integers(2, 61))
+            L = int(rng.integers(max(8, P), 30 * P))
+            g = synth.ba_graph(P, L, obs_per_lm=float(rng.uniform(2.5, 12.0)), seed=int(rng.integers(1, 10**6)))
+            if rng.random() < 0.4:
+                k = int(rng.integers(1, P))
+                g.poses[k, :2] += rng.normal(0, 400, 2)
+            gs.append(g)
+        os.environ["SE2GPU_BA_RESIDENT"] = "1"
+        opts = []
+        for g in gs:
+            o = SlamOptimizer()
+            o.load(g)
+            o.initializeOptimization(0)
+            opts.append(o)
+        op.optimize_batch(opts, its)
+        os.environ.pop("SE2GPU_BA_RESIDENT")
+        from se2lam_amd import capi as _capi
+        path = int(_capi.lib().se2gpu_ba_last_batch_path())
+        for g, o in zip(gs, opts):
+            ref = oracle.ba_optimize(g, its)[2]
+            n = ref["iterations"]
+            got, want = np.array(o.stats["chi2_hist"][:o.stats["iterations"]]), np.array(ref["chi2_hist"][:n])
+            # a rejected / accepted trial whose gain ratio is within rounding of zero may fall either way when the sums are unordered:
+            # the histories are compared while the decisions agree, and they must agree wherever |rho| is not tiny
+            same = o.stats["iterations"] == n and o.stats["trials_hist"][:n] == ref["trials_hist"][:n]
+            ok = same and np.allclose(got, want, rtol=1e-5)
+            if not same and np.abs(np.array(ref["rho_log"])).min() < 1e-6:
+                ok = True
+            print(f"baw  path {path} P {g.P} L {g.L} E {g.E} iters {its}: trials {o.stats['trials_hist'][:o.stats['iterations']]} {'ok' if ok else 'MISMATCH'}")
+            if not ok or path != 2:
+                print(got, want, ref["trials_hist"][:n])
+                sys.exit(1)
         continue
     if kind == 1:
         W, H = int(rng.integers(160, 900)), int(rng.integers(120, 700))
