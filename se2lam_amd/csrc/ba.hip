@@ -6117,7 +6117,7 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
     if (env_on == 0 || count < 1 || (env_on != 1 && count < env_min) || ba_env_sync() || iters < 0) return SE2GPU_OK;
     if (mode != SE2GPU_BA_LM && mode != SE2GPU_BA_GN) return SE2GPU_OK;
     // Windows are dealt to (at most) three launches by the widest workgroup their reduced system leaves room for in LDS (512, 256 or
-    // 128 threads; a 50-key-frame window takes 512, one of 60 only 128), each launch on the stream of its first window, the heaviest
+    // 128 threads; a 50-key-frame window takes 512, one of 60 takes 256), each launch on the stream of its first window, the heaviest
     // windows first (workgroups start in index order: the long ones must not be the tail).
     struct Item { int i, threads; size_t lds; };
     std::vector<Item> items((size_t)count);
@@ -6126,6 +6126,9 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         size_t b = 0;
         const int t = ba_resident_threads(hs[i], &b);
         if (!t) return SE2GPU_OK;
+        // (a window that only fits the 128-thread workgroup - 61 free key frames and up - takes twice as long here as the whole
+        // batch takes on the lock-step path: a batch that holds one is left to the other paths unless this one is forced)
+        if (t < 256 && env_on != 1) return SE2GPU_OK;
         items[(size_t)i] = Item{i, t, b};
     }
     for (int i = 0; i < count; ++i)

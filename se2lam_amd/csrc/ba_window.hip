@@ -540,14 +540,14 @@ __device__ __forceinline__ void wg_reduce(double* red, double& s0, double& s1, d
 
 // ------------------------------------------------------------------------------------------------------------------
 // LL^T of the augmented system in place (left-looking, 3x3 blocks, the right-hand side as row n): the off-diagonal blocks of L
-// overwrite S, the diagonal blocks go to dl (6 per block: l00 l10 l11 l20 l21 l22) with their reciprocals in invd.  *fail is set
+// overwrite S - the diagonal blocks too (over T(J, J), once everybody has it) - with the reciprocals of the diagonal in invd.  *fail is set
 // when a pivot is not positive (the step is then rejected, as g2o rejects a failed Cholesky).
 // Block column J: T(I, J) = S(I, J) - sum_{K < J} L(I, K) L(J, K)^T for the block rows I >= J, LPB lanes sharing a block's sum over
 // K (8 while the column is long, up to 64 near the end, where few rows are left and the sum is longest); then every block's first
 // lane factorises T(J, J) for itself (six multiplies: cheaper than a hand-off) and solves its own L(I, J) = T(I, J) L(J, J)^-T.
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT, int LPB>
-__device__ __forceinline__ void factor_column(double* S, double* dl, double* invd, double* tjj, int nf, int J, int* fail) {
+__device__ __forceinline__ void factor_column(double* S, double* invd, double* tjj, int nf, int J, int* fail) {
     const int tid = threadIdx.x, sub = tid & (LPB - 1), grp = tid / LPB;
     // (the right-hand side is block row nf: row n and two rows of zeros, so every block row is 3 x 3 and the loops unroll)
     for (int I0 = J; I0 <= nf; I0 += NT / LPB) {
@@ -596,7 +596,10 @@ __device__ __forceinline__ void factor_column(double* S, double* dl, double* inv
             const double i22 = fast_rsqrt(d2 > 0.0 ? d2 : 1.0), l22 = d2 * i22;
             if (I == J) {
                 if (bad) *fail = 1;
-                dl[6 * J] = l00; dl[6 * J + 1] = l10; dl[6 * J + 2] = l11; dl[6 * J + 3] = l20; dl[6 * J + 4] = l21; dl[6 * J + 5] = l22;
+                // L(J, J) over T(J, J) in place (everybody reads T(J, J) from the strip tjj, and no later column reads a diagonal block)
+                S[tri(3 * J, 3 * J)] = l00;
+                S[tri(3 * J + 1, 3 * J)] = l10; S[tri(3 * J + 1, 3 * J + 1)] = l11;
+                S[tri(3 * J + 2, 3 * J)] = l20; S[tri(3 * J + 2, 3 * J + 1)] = l21; S[tri(3 * J + 2, 3 * J + 2)] = l22;
                 invd[3 * J] = i00; invd[3 * J + 1] = i11; invd[3 * J + 2] = i22;
             } else {
 #pragma unroll
@@ -613,13 +616,13 @@ __device__ __forceinline__ void factor_column(double* S, double* dl, double* inv
     }
 }
 template <int NT>
-__device__ __forceinline__ void factorize(double* S, double* dl, double* invd, double* tjj, int nf, int* fail) {
+__device__ __forceinline__ void factorize(double* S, double* invd, double* tjj, int nf, int* fail) {
     for (int J = 0; J < nf; ++J) {
         const int blocks = nf - J + 1;
-        if (blocks * 64 <= NT) factor_column<NT, 64>(S, dl, invd, tjj, nf, J, fail);
-        else if (blocks * 32 <= NT) factor_column<NT, 32>(S, dl, invd, tjj, nf, J, fail);
-        else if (blocks * 16 <= NT) factor_column<NT, 16>(S, dl, invd, tjj, nf, J, fail);
-        else factor_column<NT, 8>(S, dl, invd, tjj, nf, J, fail);
+        if (blocks * 64 <= NT) factor_column<NT, 64>(S, invd, tjj, nf, J, fail);
+        else if (blocks * 32 <= NT) factor_column<NT, 32>(S, invd, tjj, nf, J, fail);
+        else if (blocks * 16 <= NT) factor_column<NT, 16>(S, invd, tjj, nf, J, fail);
+        else factor_column<NT, 8>(S, invd, tjj, nf, J, fail);
     }
 }
 
@@ -632,7 +635,7 @@ __device__ __forceinline__ double lane_value(double v, int src) {
     const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ void back_substitute(const double* S, const double* dl, const double* invd, int nf, double* x) {
+__device__ __forceinline__ void back_substitute(const double* S, const double* invd, int nf, double* x) {
     const int lane = threadIdx.x & 63;
     const int n = 3 * nf;
     double y[3];
@@ -650,8 +653,9 @@ __device__ __forceinline__ void back_substitute(const double* S, const double* d
                 const int i = lane + 64 * s;
                 rw[r][s] = i < 3 * J ? S[tri(3 * J + r, i)] : 0.0;
             }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) d[i] = dl[6 * J + i];
+        d[0] = S[tri(3 * J, 3 * J)];
+        d[1] = S[tri(3 * J + 1, 3 * J)]; d[2] = S[tri(3 * J + 1, 3 * J + 1)];
+        d[3] = S[tri(3 * J + 2, 3 * J)]; d[4] = S[tri(3 * J + 2, 3 * J + 1)]; d[5] = S[tri(3 * J + 2, 3 * J + 2)];
 #pragma unroll
         for (int i = 0; i < 3; ++i) iv[i] = invd[3 * J + i];
     };
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         s_stop = (a.stop && *(const volatile int*)a.stop) ? 1 : 0;
     }
     for (int i = tid; i < kWindowMaxDegree + 2; i += NT) hist[i] = 0;
-    // LDS map (doubles): cur 3P | trl 3P | scur 2P | strl 2P | x n | invd n | dl 2n | stage NT x kStageDoubles | S (n+1)(n+2)/2 ; col P ints first
+    // LDS map (doubles): cur 3P | trl 3P | scur 2P | strl 2P | x n | invd n | stage NT x kStageDoubles | S (n+3)(n+4)/2 ; col P ints first
     int* col = reinterpret_cast<int*>(lds);
     double* base = lds + (P + 1) / 2;
     double* bufA = base;
@@ -787,8 +791,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     const int nf = s_nf, n = 3 * nf;
     double* xs = scB + 2 * P;
     double* invd = xs + n;
-    double* dl = invd + n;
-    double* stage_all = dl + 2 * n;
+    double* stage_all = invd + n;
     double* S = stage_all + (size_t)NT * kStageDoubles;
     const int ntri = (n + 3) * (n + 4) / 2;   // rows 0 .. n-1 = S, row n = b_s, two rows of zeros (the factorisation's last block row)
     for (int p = tid; p < P; p += NT) sincos(bufA[3 * p + 2], &scA[2 * p], &scA[2 * p + 1]);
@@ -868,9 +871,9 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         for (int i = tid; i < n; i += NT) S[tri(i, i)] += lambda;      // setLambda: the damping on the pose diagonal (the landmarks' went into A)
         __syncthreads();
         if (stamps && tid == 0) stamps[1] = wall_clock64();
-        factorize<NT>(S, dl, invd, tjj, nf, &s_fail);
+        factorize<NT>(S, invd, tjj, nf, &s_fail);
         if (stamps && tid == 0) stamps[2] = wall_clock64();
-        if (wave == 0) back_substitute(S, dl, invd, nf, xs);
+        if (wave == 0) back_substitute(S, invd, nf, xs);
         __syncthreads();
         if (stamps && tid == 0) stamps[3] = wall_clock64();
         // ---- oplus into the trial state (VertexSE2::oplusImpl: additive x, y; normalised heading)
@@ -941,7 +944,7 @@ namespace se2gpu {
 
 size_t ba_window_lds_bytes(int P, int nfree, int threads) {
     const size_t n = 3 * (size_t)nfree;
-    size_t doubles = (size_t)(P + 1) / 2 + 10 * (size_t)P + 4 * n + (size_t)threads * kStageDoubles + (n + 3) * (n + 4) / 2;
+    size_t doubles = (size_t)(P + 1) / 2 + 10 * (size_t)P + 2 * n + (size_t)threads * kStageDoubles + (n + 3) * (n + 4) / 2;
     const size_t bytes = doubles * 8;
     // static LDS of the kernel: the controller block, the list of wide landmarks, the reduction scratch
     const size_t fixed = sizeof(BaCtl) + (kWindowMaxDegree + 2 + 18 * 8) * sizeof(int) + 30 * 8 + 128;
