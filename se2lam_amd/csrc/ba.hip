@@ -6105,7 +6105,7 @@ int ba_resident_threads(const se2gpu_ba* h, size_t* lds) {
 }
 bool ba_resident_ok(const se2gpu_ba* h) {
     return h->initialized && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->prof.enabled && h->d_mail &&
-           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P && h->Hpl.p && h->Hpl.cap * 8 >= (size_t)h->L * 16;
+           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P && h->Hpl.p && h->Hpl.cap * 8 >= (size_t)h->L * 16 + (size_t)h->E * 44 + 16;
 }
 int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
                          se2gpu_ba_stats* stats, int* handled) {
@@ -6178,7 +6178,7 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         a.ctl = h->ctl.p;
         a.mail = h->d_mail;
         a.stop = h->d_stop;
-        a.desc = reinterpret_cast<int4*>(h->Hpl.p);   // (the multi-launch path's W records: 72 B per edge, idle on this path)
+        a.desc = reinterpret_cast<int4*>(h->Hpl.p);   // (the multi-launch path's W records: 72 B per edge, idle on this path; the list + the records by class)
         a.debug = e_dbg ? atoi(e_dbg) : 0;
         a.stamps = trace ? rs.stamps.p + 16 * (size_t)k : nullptr;
     }

@@ -23,8 +23,9 @@
 //   UPDATE  the edges stream in a second time: the linearisation is RECOMPUTED (flops are free here, bytes are not) for the
 //           back-substitution x_l = A^T (zeta - sum_e W_e^T dp_e), the trial landmark goes to the other estimate buffer,
 //           robust chi^2 at the trial state, the gain denominator; then g2o's accept / reject on the controller block
-// Per LM trial a window reads its edge arrays twice and writes its landmarks once: 2.6 MB where the multi-launch path moves
-// 26 MB.  Sums into S are atomic, hence in no fixed order: results agree with the multi-launch path and the oracle to
+// Per LM trial a window reads its observations twice and writes its landmarks once; the prologue copies the observations into the
+// order the passes visit them in (class by class, see k_window_lm), so that every pass reads whole cache lines.  Measured (PMC,
+// tools/resident_pmc.sh): 4.4 MB per window and LM iteration = 2.6x the algorithmic 1.66 MB, where the multi-launch path moves 26 MB.  Sums into S are atomic, hence in no fixed order: results agree with the multi-launch path and the oracle to
 // rounding (1e-12 relative on the cost), not bit for bit - the parity bar of this path is north_star's 1e-5.
 //
 // A landmark with more than 64 observations is refused (BaCtl::error = 2: the caller runs the window on the multi-launch path).
@@ -156,7 +157,12 @@ struct Ctx {
     double* stage;      // this wave's staging strip: 64 lanes x kStageDoubles
     const double* lms;  // L x 3: the estimate's landmarks
     double* lms_trial;  // L x 3: the other buffer
-    const int4* desc;   // L: {landmark, first edge, observations, -}: the landmarks class by class (made by the prologue)
+    const int4* desc;   // L: {landmark, first record, observations, first edge}: the landmarks class by class (made by the prologue)
+    // the observations of the landmarks with at most 16 of them, copied by the prologue in the ORDER OF THAT LIST (one array per field)
+    const double2* r_uv;
+    const double2* r_w01;
+    const double* r_w2;
+    const int* r_kf;
     int n;
     double lambda;
 };
@@ -185,7 +191,7 @@ struct GroupIn {
     EdgeIn ed;
     bool has;
 };
-// a landmark's descriptor {landmark, first edge, observations, -} from the list the prologue made; zero beyond the class's end
+// a landmark's descriptor {landmark, first record, observations, first edge} from the list the prologue made; zero beyond the class's end
 __device__ __forceinline__ int4 load_desc(const Ctx& c, int idx, int end) {
     return idx < end ? c.desc[idx] : make_int4(0, 0, 0, 0);
 }
@@ -199,9 +205,36 @@ __device__ __forceinline__ GroupIn load_group(const Ctx& c, const int4 d, int la
         g.lx = c.lms[3 * (size_t)g.l]; g.ly = c.lms[3 * (size_t)g.l + 1]; g.lz = c.lms[3 * (size_t)g.l + 2];
         const int sub = lane & (G - 1);
         g.has = sub < g.k;
-        if (g.has) g.ed = load_edge(a, g.beg + sub);
+        if (g.has) {
+            if (G == 64) {
+                g.ed = load_edge(a, g.beg + sub);   // (a wave per landmark: its observations lie together in the caller's arrays as they are)
+            } else {
+                const int e = g.beg + sub;
+                const double2 uv = c.r_uv[e], w01 = c.r_w01[e];
+                g.ed.kf = c.r_kf[e];
+                g.ed.u = uv.x; g.ed.v = uv.y;
+                g.ed.w0 = w01.x; g.ed.w1 = w01.y; g.ed.w2 = c.r_w2[e];
+            }
+        }
     }
     return g;
+}
+// prologue: the observations of the landmarks [begin, end) of the list go to the record arrays, G lanes per landmark
+template <int G, int NT>
+__device__ __forceinline__ void copy_class(const Ctx& c, int begin, int end) {
+    const WindowArgs& a = *c.a;
+    const int tid = threadIdx.x, sub = tid & (G - 1);
+    for (int i = begin + tid / G; i < end; i += NT / G) {
+        const int4 d = c.desc[i];
+        if (sub < d.z) {
+            const EdgeIn ed = load_edge(a, d.w + sub);
+            const int e = d.y + sub;
+            const_cast<double2*>(c.r_uv)[e] = double2{ed.u, ed.v};
+            const_cast<double2*>(c.r_w01)[e] = double2{ed.w0, ed.w1};
+            const_cast<double*>(c.r_w2)[e] = ed.w2;
+            const_cast<int*>(c.r_kf)[e] = ed.kf;
+        }
+    }
 }
 
 // EVAL / DIAG / UPDATE of one landmark.  Nothing but sums crosses lanes: Hll, bl and - for the back-substitution -
@@ -693,7 +726,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     extern __shared__ double lds[];
     __shared__ BaCtl ctl;
     __shared__ int s_nf, s_fail, s_err, s_stop;
-    __shared__ int hist[kWindowMaxDegree + 2], wtot[18][8];
+    __shared__ int hist[kWindowMaxDegree + 2], wtot[18][8], rstart[18];
     __shared__ double red[24], tjj[6];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int P = a.P, L = a.L;
@@ -740,9 +773,15 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         else atomicAdd(&hist[k], 1);
     }
     __syncthreads();
-    if (tid == 0) {   // hist[k] -> first position of the landmarks with k observations
-        int at = 0;
-        for (int k = 0; k <= kWindowMaxDegree + 1; ++k) { const int h = hist[k]; hist[k] = at; at += h; }
+    if (tid == 0) {   // hist[k] -> first position of the landmarks with k observations, rstart[k] -> their first record
+        int at = 0, rat = 0;
+        for (int k = 0; k <= kWindowMaxDegree + 1; ++k) {
+            const int h = hist[k];
+            hist[k] = at;
+            if (k < 18) rstart[k] = rat;
+            at += h;
+            rat += h * k;
+        }
     }
     __syncthreads();
     const bool refused = s_err != 0;   // a landmark this kernel does not take: nothing is touched, the caller runs the window elsewhere
@@ -780,7 +819,8 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
                 for (int b = 0; b < kBuckets; ++b)
                     if (cls == b) at += next[b];
                 for (int w = 0; w < wave; ++w) at += wtot[cls][w];
-                a.desc[at] = make_int4(l, beg, k, 0);
+                // (all landmarks of a count below 17 have that many records: the place of a landmark's first one follows from its own)
+                a.desc[at] = make_int4(l, cls < kBuckets - 1 ? rstart[cls] + (at - hist[cls]) * k : beg, k, beg);
             }
 #pragma unroll
             for (int b = 0; b < kBuckets; ++b)
@@ -810,6 +850,13 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     c.lms = ctl.sel ? a.lms_b : a.lms_a;
     c.lms_trial = ctl.sel ? a.lms_a : a.lms_b;
     c.desc = a.desc;
+    {   // the record arrays lie behind the list: 16 + 16 + 8 + 4 bytes per observation (the caller has checked the room: ba_resident_ok)
+        const size_t E = (size_t)a.E;
+        c.r_uv = reinterpret_cast<const double2*>(a.desc + L);
+        c.r_w01 = c.r_uv + E;
+        c.r_w2 = reinterpret_cast<const double*>(c.r_w01 + E);
+        c.r_kf = reinterpret_cast<const int*>(c.r_w2 + E);
+    }
     c.n = n;
     c.lambda = 0.0;
     double* cur = bufA;
@@ -817,6 +864,16 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     double* scur = scA;
     double* strl = scB;
 
+    // ---- the observations in the order of the list.  The passes below visit the landmarks class by class; in the caller's arrays a
+    // class's landmarks alternate with the others', and every cache line of the edge arrays came in once PER CLASS that has a
+    // landmark in it (PMC, profiles/r06k: 6.6 MB per window and iteration for 3.0 MB of operands).  One gapped read here, and every
+    // pass of every trial reads whole lines.
+    if (!refused) {
+        copy_class<4, NT>(c, b1, b5);
+        copy_class<8, NT>(c, b5, b9);
+        copy_class<16, NT>(c, b9, b17);
+        __syncthreads();
+    }
     // ---- chi^2 of the starting state (computeActiveErrors + activeRobustChi2 in front of the first iteration)
     if (!refused) {
         double chi = 0, sc = 0, dm = 0;
