@@ -111,6 +111,15 @@ __device__ __forceinline__ void chol3(const double h[6], double lambda, double a
     a[0] = a00; a[1] = a10; a[2] = a11; a[3] = a20; a[4] = a21; a[5] = a22;
 }
 
+// RobustKernelHuber (badev::huber) without the branch and with the reciprocal square root above: sqrt(e2) = e2 rsqrt(e2)
+__device__ __forceinline__ void huber_w(double e2, double delta, double& rho0, double& rho1) {
+    const double dsqr = delta * delta;
+    const double rs = fast_rsqrt(fmax(e2, 1e-300));
+    const bool in = e2 <= dsqr;
+    rho0 = in ? e2 : 2.0 * (e2 * rs) * delta - dsqr;
+    rho1 = in ? 1.0 : delta * rs;
+}
+
 // EdgeSE2XYZ (EdgeSE2XYZ.cpp:61-106) with the pose's sine / cosine at hand
 template <bool JAC>
 __device__ __forceinline__ void edge_se2xyz(const CamDev& cam, double px, double py, double s, double c, double lx, double ly, double lz,
@@ -252,7 +261,7 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
     if (MODE == kEval) {
         edge_se2xyz<false>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, nullptr, nullptr);
         double r0, r1;
-        huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, r0, r1);
+        huber_w(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, r0, r1);
         if (has) chi += r0;
         return;
     }
@@ -261,7 +270,7 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
     edge_se2xyz<true>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, Jp, Jl);
     const double we0 = w0 * e0 + w1 * e1, we1 = w1 * e0 + w2 * e1;
     double r0, r1;
-    huber(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
+    huber_w(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
     const double W0 = r1 * w0, W1 = r1 * w1, W2 = r1 * w2;    // weightedOmega
     const double or0 = -r1 * we0, or1 = -r1 * we1;            // omega_r
     double WJl[6];
@@ -270,7 +279,7 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
         WJl[m] = W0 * Jl[m] + W1 * Jl[3 + m];
         WJl[3 + m] = W1 * Jl[m] + W2 * Jl[3 + m];
     }
-    double acc[12];   // hll (6) | bl (3) | q (3)
+    double acc[12];   // hll (6) | bl (3) | q (3); the update pass sums bl - q as one vector (slots 6..8)
     acc[0] = Jl[0] * WJl[0] + Jl[3] * WJl[3];
     acc[1] = Jl[0] * WJl[1] + Jl[3] * WJl[4];
     acc[2] = Jl[0] * WJl[2] + Jl[3] * WJl[5];
@@ -304,28 +313,31 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
         if (g.k > 0) dmax = fmax(dmax, fmax(fabs(h0), fmax(fabs(h3), fabs(h5))));
         return;
     }
+    const double ble[3] = {acc[6], acc[7], acc[8]};   // this observation's own b_l share: x_l . b_l is summed observation by observation
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = gsum<G>(acc[i]);
+    for (int i = 0; i < 6; ++i) acc[i] = gsum<G>(acc[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) acc[6 + i] = gsum<G>(acc[6 + i] - acc[9 + i]);
     double xl[3] = {0, 0, 0};
     if (g.k > 0) {
         double A[6];
         chol3(acc, c.lambda, A);
-        const double g0 = acc[6] - acc[9], g1 = acc[7] - acc[10], g2 = acc[8] - acc[11];
+        const double g0 = acc[6], g1 = acc[7], g2 = acc[8];
         const double t0 = A[0] * g0, t1 = A[1] * g0 + A[2] * g1, t2 = A[3] * g0 + A[4] * g1 + A[5] * g2;    // A (bl - q)
         xl[0] = A[0] * t0 + A[1] * t1 + A[3] * t2;                                                           // A^T (...)
         xl[1] = A[2] * t1 + A[4] * t2;
         xl[2] = A[5] * t2;
     }
     const double nxl = g.lx + xl[0], nyl = g.ly + xl[1], nzl = g.lz + xl[2];
+    scale += xl[0] * ble[0] + xl[1] * ble[1] + xl[2] * ble[2];   // (zero without an observation)
     if (g.k > 0 && sub == 0) {
         c.lms_trial[3 * (size_t)g.l] = nxl; c.lms_trial[3 * (size_t)g.l + 1] = nyl; c.lms_trial[3 * (size_t)g.l + 2] = nzl;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) scale += xl[m] * (c.lambda * xl[m] + acc[6 + m]);
+        scale += c.lambda * (xl[0] * xl[0] + xl[1] * xl[1] + xl[2] * xl[2]);
     }
     if (has) {   // robust chi^2 of the observation at the trial state
         edge_se2xyz<false>(a.cam, c.trl[3 * kf], c.trl[3 * kf + 1], c.strl[2 * kf], c.strl[2 * kf + 1], nxl, nyl, nzl, g.ed.u, g.ed.v, e0, e1, nullptr, nullptr);
         double q0, q1;
-        huber(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, q0, q1);
+        huber_w(e0 * (w0 * e0 + w1 * e1) + e1 * (w1 * e0 + w2 * e1), a.cam.huber, q0, q1);
         chi += q0;
     }
 }
@@ -372,7 +384,7 @@ __device__ __forceinline__ void build_group(const Ctx& c, const GroupIn& g, int 
     edge_se2xyz<true>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, Jp, Jl);
     const double we0 = w0 * e0 + w1 * e1, we1 = w1 * e0 + w2 * e1;
     double r0, r1;
-    huber(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
+    huber_w(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
     const double W0 = r1 * w0, W1 = r1 * w1, W2 = r1 * w2;    // weightedOmega
     const double or0 = -r1 * we0, or1 = -r1 * we1;            // omega_r
     double WJl[6];
