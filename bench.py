@@ -489,7 +489,7 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
     if args.ba_mixed and (args.ba_windows <= 0 or args.ba_windows >= 16):
         # the same batch size with DISTINCT windows (30-60 key frames, 3-6 k landmarks, different seeds, a few starts that
         # reject trials): sizes, solve plans and accept / reject patterns differ per window - the honest form of the number above
-        nmix = args.ba_windows if args.ba_windows > 0 else 128
+        nmix = args.ba_windows if args.ba_windows > 0 else int(best["windows_per_gpu"])   # (the sweep's best count)
         gs = synth.mixed_windows(nmix)
         mopts = []
         for gm in gs:
