@@ -123,6 +123,16 @@ def run(rank, world, batch, steps, sync_all, dist, torch, warmup=2, cap=1024, tr
                 "whole_step_achieved": (B_ORB + B_MATCH) * fps / world / 1e9,
                 "whole_step_frac": (B_ORB + B_MATCH) * fps / world / 1e9 / HBM_PEAK_GBS,
                 "kernels_us": {k: round(v["avg_us"], 2) for k, v in kern.items()}}
+        if dom == "k_fast_score":
+            # The kernel is not bound by bytes but by VALU issue: its instruction count per frame from the SQ counters
+            # of profiles/r05c_orb_sq_counters.json (63,488 waves x 4,438.6 VALU instructions per 256 frames; the dense kernel's
+            # count does not depend on the image), 4 clk per wave64 instruction on a 16-lane SIMD, 1,024 SIMDs at the 2.4 GHz peak
+            insts = 63_488 * 4_438.6 / 256.0 * B
+            min_us = insts * 4.0 / 1024.0 / 2.4e3
+            roof["valu"] = {"wave_instructions_per_launch": insts, "clk_per_instruction": 4, "simds": 1024, "clock_ghz_assumed": 2.4,
+                            "min_launch_us": min_us, "frac": min_us / kern[dom]["avg_us"],
+                            "source": "profiles/r05c_orb_sq_counters.json (SQ_INSTS_VALU per wave x waves)"}
+            roof["bound_by"] = {"what": "VALU issue", "frac_of_valu_issue": min_us / kern[dom]["avg_us"]}
     import sys
     print(f"[orb_bench] resident {fps:.0f} frames/s with {nex} batches in flight", file=sys.stderr, flush=True)
     streaming = None
