@@ -176,6 +176,32 @@ def test_default_threshold_keeps_small_batches_on_the_multi_launch_paths(synth):
         _same(o, st, est, "100 windows")
 
 
+def test_a_window_of_the_128_thread_class_keeps_the_batch_off_the_resident_path_unless_forced(synth):
+    """a window with 61+ free key frames only fits the 128-thread workgroup and would take twice as long there as the whole batch
+    takes in lock step: by default such a batch is left to the multi-launch paths (bit-identical to one-by-one runs); forced, the
+    kernel takes it (same decisions, costs to 1e-9)"""
+    from se2lam_amd import capi
+    from se2lam_amd.optimizer import optimize_batch
+    small, big = synth.ba_graph(8, 60), synth.ba_graph(62, 400)
+    refs = [_multi_launch(small, 5), _multi_launch(big, 5)]
+    os.environ.pop("SE2GPU_BA_RESIDENT", None)
+    opts = [_opt(small) for _ in range(99)] + [_opt(big)]
+    optimize_batch(opts, 5)
+    assert capi.lib().se2gpu_ba_last_batch_path() != 2
+    for o in opts[:3]:
+        assert o.stats == refs[0][0] and np.array_equal(o.estimates()[0], refs[0][1][0])
+    assert opts[-1].stats == refs[1][0] and np.array_equal(opts[-1].estimates()[0], refs[1][1][0])
+    os.environ["SE2GPU_BA_RESIDENT"] = "1"
+    try:
+        forced = [_opt(small), _opt(big)]
+        optimize_batch(forced, 5)
+        assert capi.lib().se2gpu_ba_last_batch_path() == 2
+        _same(forced[0], *refs[0], "small window, forced")
+        _same(forced[1], *refs[1], "62 key frames, forced")
+    finally:
+        os.environ.pop("SE2GPU_BA_RESIDENT", None)
+
+
 def test_resident_edge_cases(synth, resident):
     """windows at the edges of what the kernel meets: two key frames (configs[0]'s first local BA), no odometry edge, a single free
     pose, every pose fixed (only the landmarks move), landmarks with a single observation"""
