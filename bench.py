@@ -501,7 +501,7 @@ def _ba_windows(args, rank, world, sync_all, dist, P=50, L=5000, calls=6):
         def run_mixed():
             reset_estimates_batch(mopts)
             its = optimize_batch(mopts, ITERS_PER_CALL)
-            return sum(its), sum(i * gm.algorithmic_bytes_per_iter() for i, gm in zip(its, gs)), sum(o.stats["trials"] for o in mopts)
+            return sum(its), sum(i * gm.algorithmic_bytes_per_iter() for i, gm in zip(its, gs)), sum(o.stat("trials") for o in mopts)
 
         run_mixed()
         sync_all()

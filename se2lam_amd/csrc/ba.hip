@@ -6105,7 +6105,8 @@ int ba_resident_threads(const se2gpu_ba* h, size_t* lds) {
 }
 bool ba_resident_ok(const se2gpu_ba* h) {
     return h->initialized && h->model == 0 && !h->allreduce && !h->comm && !h->host_solve && !h->prof.enabled && h->d_mail &&
-           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P && h->Hpl.p && h->Hpl.cap * 8 >= (size_t)h->L * 16 + (size_t)h->E * 44 + 16;
+           h->L > 0 && h->P > 0 && (int)h->h_fixed.size() == h->P && h->Hpl.p && h->Hpl.cap * 8 >= (size_t)h->L * 16 + (size_t)h->E * 44 + 16 &&
+           h->Dinv.p && h->Dinv.cap >= 6 * (size_t)h->L;
 }
 int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const volatile uint8_t* stop_flag,
                          se2gpu_ba_stats* stats, int* handled) {
@@ -6179,6 +6180,7 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         a.mail = h->d_mail;
         a.stop = h->d_stop;
         a.desc = reinterpret_cast<int4*>(h->Hpl.p);   // (the multi-launch path's W records: 72 B per edge, idle on this path; the list + the records by class)
+        a.ainv = h->Dinv.p;   // (the multi-launch path's A_l: 6 L + 1 doubles, idle on this path)
         a.debug = e_dbg ? atoi(e_dbg) : 0;
         a.stamps = trace ? rs.stamps.p + 16 * (size_t)k : nullptr;
     }
@@ -6225,6 +6227,8 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         const long long* s0 = hst.data();
         std::fprintf(stderr, "se2gpu_ba resident: window 0, last trial: build %.1f us, factorise %.1f us, back-substitute %.1f us, update %.1f us (%d threads, %zu B LDS)\n",
                      (s0[1] - s0[0]) * 0.01, (s0[2] - s0[1]) * 0.01, (s0[3] - s0[2]) * 0.01, (s0[4] - s0[3]) * 0.01, threads, lds);
+        std::fprintf(stderr, "se2gpu_ba resident: window 0, prologue: list %.1f us, opening pass (records, chi2, lambda_0) %.1f us\n",
+                     (s0[6] - s0[5]) * 0.01, (s0[7] - s0[6]) * 0.01);
     }
     if (refused) {
         // a window holds a landmark the kernel does not take (more than 64 observations):

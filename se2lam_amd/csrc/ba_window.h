@@ -25,7 +25,9 @@ struct WindowArgs {
     badev::BaCtl* ctl;        // the window's controller block (device)
     double* mail;             // device address of the window's mapped mailbox, or NULL
     const int* stop;          // device address of the mapped force-stop word, or NULL
-    int4* desc;               // L x 16 B of scratch: the kernel lists the landmarks by their observation counts here
+    int4* desc;               // scratch: the kernel lists the landmarks by their observation counts here (L x 16 B) and copies the
+                              // observations into that order behind the list (E x 44 B)
+    double* ainv;             // L x 6 of scratch: the build pass leaves every landmark's factor A here (list order) for the update pass
     int debug;
     long long* stamps;        // debug: 16 phase time stamps (100 MHz wall clock) of the LAST trial, or NULL
 };

@@ -195,7 +195,7 @@ __device__ __forceinline__ EdgeIn load_edge(const WindowArgs& a, int e) {
 // edges).
 // ------------------------------------------------------------------------------------------------------------------
 struct GroupIn {
-    int l, beg, k;
+    int l, beg, k, at;   // landmark, first record, observations, place in the list
     double lx, ly, lz;
     EdgeIn ed;
     bool has;
@@ -204,11 +204,13 @@ struct GroupIn {
 __device__ __forceinline__ int4 load_desc(const Ctx& c, int idx, int end) {
     return idx < end ? c.desc[idx] : make_int4(0, 0, 0, 0);
 }
-template <int G>
-__device__ __forceinline__ GroupIn load_group(const Ctx& c, const int4 d, int lane) {
+// FIRST: the opening pass of an optimize() - the observations still come from the caller's arrays (d.w) and go to the record arrays
+// on the way, so that every later pass reads them in the order of the list
+template <int G, bool FIRST = false>
+__device__ __forceinline__ GroupIn load_group(const Ctx& c, const int4 d, int lane, int at) {
     const WindowArgs& a = *c.a;
     GroupIn g;
-    g.l = d.x; g.beg = d.y; g.k = d.z; g.lx = 0; g.ly = 0; g.lz = 1; g.has = false;
+    g.l = d.x; g.beg = d.y; g.k = d.z; g.at = at; g.lx = 0; g.ly = 0; g.lz = 1; g.has = false;
     g.ed = EdgeIn{0, 0, 0, 0, 0, 0};
     if (g.k > 0) {
         g.lx = c.lms[3 * (size_t)g.l]; g.ly = c.lms[3 * (size_t)g.l + 1]; g.lz = c.lms[3 * (size_t)g.l + 2];
@@ -217,6 +219,13 @@ __device__ __forceinline__ GroupIn load_group(const Ctx& c, const int4 d, int la
         if (g.has) {
             if (G == 64) {
                 g.ed = load_edge(a, g.beg + sub);   // (a wave per landmark: its observations lie together in the caller's arrays as they are)
+            } else if (FIRST) {
+                g.ed = load_edge(a, d.w + sub);
+                const int e = g.beg + sub;
+                const_cast<double2*>(c.r_uv)[e] = double2{g.ed.u, g.ed.v};
+                const_cast<double2*>(c.r_w01)[e] = double2{g.ed.w0, g.ed.w1};
+                const_cast<double*>(c.r_w2)[e] = g.ed.w2;
+                const_cast<int*>(c.r_kf)[e] = g.ed.kf;
             } else {
                 const int e = g.beg + sub;
                 const double2 uv = c.r_uv[e], w01 = c.r_w01[e];
@@ -228,27 +237,11 @@ __device__ __forceinline__ GroupIn load_group(const Ctx& c, const int4 d, int la
     }
     return g;
 }
-// prologue: the observations of the landmarks [begin, end) of the list go to the record arrays, G lanes per landmark
-template <int G, int NT>
-__device__ __forceinline__ void copy_class(const Ctx& c, int begin, int end) {
-    const WindowArgs& a = *c.a;
-    const int tid = threadIdx.x, sub = tid & (G - 1);
-    for (int i = begin + tid / G; i < end; i += NT / G) {
-        const int4 d = c.desc[i];
-        if (sub < d.z) {
-            const EdgeIn ed = load_edge(a, d.w + sub);
-            const int e = d.y + sub;
-            const_cast<double2*>(c.r_uv)[e] = double2{ed.u, ed.v};
-            const_cast<double2*>(c.r_w01)[e] = double2{ed.w0, ed.w1};
-            const_cast<double*>(c.r_w2)[e] = ed.w2;
-            const_cast<int*>(c.r_kf)[e] = ed.kf;
-        }
-    }
-}
-
-// EVAL / DIAG / UPDATE of one landmark.  Nothing but sums crosses lanes: Hll, bl and - for the back-substitution -
-// q = sum_e Hlp_e dp_e, and then   x_l = (Hll + lambda I)^-1 (bl - q)   needs neither W_e nor a second look at the Jacobians
-// (sum_e W_e^T dp_e = A q: the factor A comes out of the sum).
+// EVAL / DIAG / UPDATE of one landmark.  Nothing but sums crosses lanes: for the back-substitution bl - q with
+// q = sum_e Hlp_e dp_e, and then   x_l = (Hll + lambda I)^-1 (bl - q) = A^T A (bl - q)   needs neither W_e nor a second look at the
+// Jacobians (sum_e W_e^T dp_e = A q: the factor A comes out of the sum).  A itself - 48 bytes per landmark - is what the build pass of
+// the same trial computed: it travels through memory (WindowArgs::ainv, list order), which spares this pass the six sums of Hll and
+// its factorisation, a third of its instructions.
 template <int MODE, int G>
 __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int lane, double& chi, double& scale, double& dmax) {
     const WindowArgs& a = *c.a;
@@ -266,11 +259,18 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
         return;
     }
     const int c0 = has ? c.col[kf] : -1;
+    // the update pass: A = G^-1 of Hll + lambda I as this trial's build pass left it (requested here, needed after the sums)
+    double2 A01 = {1, 0}, A23 = {1, 0}, A45 = {0, 1};
+    if (MODE == kUpdate && g.k > 0) {
+        const double2* src = reinterpret_cast<const double2*>(a.ainv + 6 * (size_t)g.at);
+        A01 = src[0]; A23 = src[1]; A45 = src[2];
+    }
     double Jp[6], Jl[6];
     edge_se2xyz<true>(a.cam, px, py, ps, pc, g.lx, g.ly, g.lz, g.ed.u, g.ed.v, e0, e1, Jp, Jl);
     const double we0 = w0 * e0 + w1 * e1, we1 = w1 * e0 + w2 * e1;
     double r0, r1;
     huber_w(e0 * we0 + e1 * we1, a.cam.huber, r0, r1);
+    if (MODE == kDiag && has) chi += r0;                       // (the lambda_0 pass is the chi^2 of the starting state as well)
     const double W0 = r1 * w0, W1 = r1 * w1, W2 = r1 * w2;    // weightedOmega
     const double or0 = -r1 * we0, or1 = -r1 * we1;            // omega_r
     double WJl[6];
@@ -279,13 +279,14 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
         WJl[m] = W0 * Jl[m] + W1 * Jl[3 + m];
         WJl[3 + m] = W1 * Jl[m] + W2 * Jl[3 + m];
     }
-    double acc[12];   // hll (6) | bl (3) | q (3); the update pass sums bl - q as one vector (slots 6..8)
-    acc[0] = Jl[0] * WJl[0] + Jl[3] * WJl[3];
-    acc[1] = Jl[0] * WJl[1] + Jl[3] * WJl[4];
-    acc[2] = Jl[0] * WJl[2] + Jl[3] * WJl[5];
-    acc[3] = Jl[1] * WJl[1] + Jl[4] * WJl[4];
-    acc[4] = Jl[1] * WJl[2] + Jl[4] * WJl[5];
-    acc[5] = Jl[2] * WJl[2] + Jl[5] * WJl[5];
+    double acc[12];   // hll (6: the lambda_0 pass only) | bl (3) | q (3); the update pass sums bl - q as one vector (slots 6..8)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[i] = 0.0;
+    if (MODE == kDiag) {
+        acc[0] = Jl[0] * WJl[0] + Jl[3] * WJl[3];
+        acc[3] = Jl[1] * WJl[1] + Jl[4] * WJl[4];
+        acc[5] = Jl[2] * WJl[2] + Jl[5] * WJl[5];
+    }
 #pragma unroll
     for (int r = 0; r < 3; ++r) acc[6 + r] = Jl[r] * or0 + Jl[3 + r] * or1;
     acc[9] = acc[10] = acc[11] = 0.0;
@@ -315,13 +316,10 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
     }
     const double ble[3] = {acc[6], acc[7], acc[8]};   // this observation's own b_l share: x_l . b_l is summed observation by observation
 #pragma unroll
-    for (int i = 0; i < 6; ++i) acc[i] = gsum<G>(acc[i]);
-#pragma unroll
     for (int i = 0; i < 3; ++i) acc[6 + i] = gsum<G>(acc[6 + i] - acc[9 + i]);
     double xl[3] = {0, 0, 0};
     if (g.k > 0) {
-        double A[6];
-        chol3(acc, c.lambda, A);
+        const double A[6] = {A01.x, A01.y, A23.x, A23.y, A45.x, A45.y};
         const double g0 = acc[6], g1 = acc[7], g2 = acc[8];
         const double t0 = A[0] * g0, t1 = A[1] * g0 + A[2] * g1, t2 = A[3] * g0 + A[4] * g1 + A[5] * g2;    // A (bl - q)
         xl[0] = A[0] * t0 + A[1] * t1 + A[3] * t2;                                                           // A^T (...)
@@ -343,16 +341,16 @@ __device__ __forceinline__ void eval_group(const Ctx& c, const GroupIn& g, int l
 }
 
 // the landmarks [begin, end) of the order, G lanes each; the next group's operands are in flight while this one is worked on
-template <int MODE, int G, int NT>
+template <int MODE, int G, int NT, bool FIRST = false>
 __device__ __forceinline__ void eval_class(const Ctx& c, int begin, int end, double& chi, double& scale, double& dmax) {
     const int tid = threadIdx.x, lane = tid & 63;
     if (begin >= end) return;
     constexpr int kStep = NT / G;
-    GroupIn nx = load_group<G>(c, load_desc(c, begin + tid / G, end), lane);
+    GroupIn nx = load_group<G, FIRST>(c, load_desc(c, begin + tid / G, end), lane, begin + tid / G);
     int4 d2 = load_desc(c, begin + kStep + tid / G, end);
     for (int i0 = begin; i0 < end; i0 += kStep) {
         const GroupIn g = nx;
-        nx = load_group<G>(c, d2, lane);
+        nx = load_group<G, FIRST>(c, d2, lane, i0 + kStep + tid / G);
         d2 = load_desc(c, i0 + 2 * kStep + tid / G, end);
         eval_group<MODE, G>(c, g, lane, chi, scale, dmax);
     }
@@ -414,6 +412,10 @@ __device__ __forceinline__ void build_group(const Ctx& c, const GroupIn& g, int 
     for (int i = 0; i < 3; ++i) b[i] = gsum<G>(b[i]);
     double A[6], zt[3];
     chol3(hll, c.lambda, A);
+    if (k > 0 && sub == 0) {   // the update pass of this trial takes the factor from here instead of summing Hll and factorising it again
+        double2* dst = reinterpret_cast<double2*>(a.ainv + 6 * (size_t)g.at);
+        dst[0] = double2{A[0], A[1]}; dst[1] = double2{A[2], A[3]}; dst[2] = double2{A[4], A[5]};
+    }
     zt[0] = A[0] * b[0];
     zt[1] = A[1] * b[0] + A[2] * b[1];
     zt[2] = A[3] * b[0] + A[4] * b[1] + A[5] * b[2];
@@ -499,11 +501,11 @@ __device__ __forceinline__ void build_class(const Ctx& c, int begin, int end) {
     const int tid = threadIdx.x, lane = tid & 63;
     if (begin >= end) return;
     constexpr int kStep = NT / G;
-    GroupIn nx = load_group<G>(c, load_desc(c, begin + tid / G, end), lane);
+    GroupIn nx = load_group<G>(c, load_desc(c, begin + tid / G, end), lane, begin + tid / G);
     int4 d2 = load_desc(c, begin + kStep + tid / G, end);
     for (int i0 = begin; i0 < end; i0 += kStep) {
         const GroupIn g = nx;
-        nx = load_group<G>(c, d2, lane);
+        nx = load_group<G>(c, d2, lane, i0 + kStep + tid / G);
         d2 = load_desc(c, i0 + 2 * kStep + tid / G, end);
         build_group<G>(c, g, lane);
     }
@@ -742,6 +744,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     __shared__ double red[24], tjj[6];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int P = a.P, L = a.L;
+    if (a.stamps && tid == 0) a.stamps[5] = wall_clock64();
 
     // ---- prologue: the controller block (k_ctl_init's rules), columns of the free poses, the landmarks ordered by their counts
     if (tid == 0) {
@@ -840,6 +843,7 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
             __syncthreads();
         }
     }
+    if (a.stamps && tid == 0) a.stamps[6] = wall_clock64();   // (the list is made)
     const int nf = s_nf, n = 3 * nf;
     double* xs = scB + 2 * P;
     double* invd = xs + n;
@@ -876,50 +880,44 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
     double* scur = scA;
     double* strl = scB;
 
-    // ---- the observations in the order of the list.  The passes below visit the landmarks class by class; in the caller's arrays a
-    // class's landmarks alternate with the others', and every cache line of the edge arrays came in once PER CLASS that has a
-    // landmark in it (PMC, profiles/r06k: 6.6 MB per window and iteration for 3.0 MB of operands).  One gapped read here, and every
-    // pass of every trial reads whole lines.
+    // ---- the opening pass: chi^2 of the starting state (computeActiveErrors + activeRobustChi2 in front of the first iteration),
+    // for Levenberg-Marquardt together with the diagonal of the first linearisation (lambda_0 = 1e-5 max diag H, computeLambdaInit;
+    // Gauss-Newton keeps lambda = 0) - and on the way the observations go into the ORDER OF THE LIST.  The passes visit the landmarks
+    // class by class; in the caller's arrays a class's landmarks alternate with the others', and every cache line of the edge arrays
+    // came in once PER CLASS that has a landmark in it (PMC, profiles/r06k: 6.6 MB per window and iteration for 3.0 MB of operands).
+    // One gapped read here, and every pass of every trial reads whole lines.
     if (!refused) {
-        copy_class<4, NT>(c, b1, b5);
-        copy_class<8, NT>(c, b5, b9);
-        copy_class<16, NT>(c, b9, b17);
+        const bool lm = a.mode == SE2GPU_BA_LM;
+        for (int i = tid; i < n; i += NT) xs[i] = 0.0;
         __syncthreads();
-    }
-    // ---- chi^2 of the starting state (computeActiveErrors + activeRobustChi2 in front of the first iteration)
-    if (!refused) {
         double chi = 0, sc = 0, dm = 0;
-        eval_class<kEval, 4, NT>(c, b1, b5, chi, sc, dm);
-        eval_class<kEval, 8, NT>(c, b5, b9, chi, sc, dm);
-        eval_class<kEval, 16, NT>(c, b9, b17, chi, sc, dm);
-        eval_class<kEval, 64, NT>(c, b17, L, chi, sc, dm);
-        for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoEval>(c, k, chi, sc);
+        if (lm) {
+            eval_class<kDiag, 4, NT, true>(c, b1, b5, chi, sc, dm);
+            eval_class<kDiag, 8, NT, true>(c, b5, b9, chi, sc, dm);
+            eval_class<kDiag, 16, NT, true>(c, b9, b17, chi, sc, dm);
+            eval_class<kDiag, 64, NT, true>(c, b17, L, chi, sc, dm);
+            for (int k = tid; k < a.O; k += NT) { odometry_edge<kOdoEval>(c, k, chi, sc); odometry_edge<kOdoDiag>(c, k, chi, sc); }
+        } else {
+            eval_class<kEval, 4, NT, true>(c, b1, b5, chi, sc, dm);
+            eval_class<kEval, 8, NT, true>(c, b5, b9, chi, sc, dm);
+            eval_class<kEval, 16, NT, true>(c, b9, b17, chi, sc, dm);
+            eval_class<kEval, 64, NT, true>(c, b17, L, chi, sc, dm);
+            for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoEval>(c, k, chi, sc);
+        }
+        __syncthreads();   // (the diagonal's atomics have landed; the records are written)
+        if (lm)
+            for (int i = tid; i < n; i += NT) dm = fmax(dm, fabs(xs[i]));
         wg_reduce<NT>(red, chi, sc, dm);
         if (tid == 0) {
             ctl.current_chi = ctl.chi2_init = ctl.chi2_final = chi;
             if (s_stop) { ctl.stopped = 1; ctl.done = 1; }
             if (ctl.iters <= 0) ctl.done = 1;
+            if (lm && !ctl.done) { ctl.lambda = 1e-5 * dm; ctl.ni = 2; }
         }
         __syncthreads();
     }
-    // ---- lambda_0 = 1e-5 max diag H of the first linearisation (computeLambdaInit); Gauss-Newton keeps lambda = 0
-    if (!ctl.done && a.mode == SE2GPU_BA_LM) {
-        for (int i = tid; i < n; i += NT) xs[i] = 0.0;
-        __syncthreads();
-        double chi = 0, sc = 0, dm = 0;
-        eval_class<kDiag, 4, NT>(c, b1, b5, chi, sc, dm);
-        eval_class<kDiag, 8, NT>(c, b5, b9, chi, sc, dm);
-        eval_class<kDiag, 16, NT>(c, b9, b17, chi, sc, dm);
-        eval_class<kDiag, 64, NT>(c, b17, L, chi, sc, dm);
-        for (int k = tid; k < a.O; k += NT) odometry_edge<kOdoDiag>(c, k, chi, sc);
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) dm = fmax(dm, fabs(xs[i]));
-        wg_reduce<NT>(red, chi, sc, dm);
-        if (tid == 0) { ctl.lambda = 1e-5 * dm; ctl.ni = 2; }
-        __syncthreads();
-    }
-
     long long* stamps = a.stamps;
+    if (stamps && tid == 0) stamps[7] = wall_clock64();       // (the opening pass)
     // ---- the trials
     while (!ctl.done) {
         const double lambda = ctl.lambda;
