@@ -74,9 +74,9 @@ __device__ __forceinline__ double wmax(double v) {
 
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }   // packed lower triangle, r >= c
 
-__shared__ int g_dbg;
+// (a run-time debug switch lived here until r06q - plain read-modify-write instead of the atomic, the pair loop skipped: it put a
+// branch around every one of the kernel's atomics and cut the schedule into as many pieces; the two timings it gave are in DESIGN.md)
 __device__ __forceinline__ void lds_add(double* p, double v) {
-    if (g_dbg & 2) { *p += v; return; }
     (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -465,7 +465,6 @@ __device__ __forceinline__ void build_group(const Ctx& c, const GroupIn& g, int 
 #pragma unroll
     for (int m = G; m < 64; m <<= 1) smax = max(smax, __shfl_xor(smax, m));   // the wave's longest landmark sets the trip count
     const int gbase = lane & ~(G - 1);
-    if (g_dbg & 1) smax = 0;
     for (int s = 1; s <= smax; ++s) {
         const bool act = has && s <= half && !(2 * s == k && sub >= half);
         int j = sub + s;
@@ -761,7 +760,6 @@ __global__ __launch_bounds__(NT) void k_window_lm(const WindowArgs* __restrict__
         ctl.seq = seq;
         ctl.epoch = epoch;
         s_fail = 0; s_err = 0;
-        g_dbg = a.debug;
         s_stop = (a.stop && *(const volatile int*)a.stop) ? 1 : 0;
     }
     for (int i = tid; i < kWindowMaxDegree + 2; i += NT) hist[i] = 0;
