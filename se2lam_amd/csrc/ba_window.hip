@@ -45,8 +45,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     const long long b = __double_as_longlong(v);
     int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // (no "old" operand: every lane reads a lane of its own row, so nothing of the destination survives - with one, the compiler
+    // copies the source first and a butterfly step costs five instructions instead of three)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
