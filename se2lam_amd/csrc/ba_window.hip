@@ -441,58 +441,82 @@ __device__ __forceinline__ void build_group(const Ctx& c, const GroupIn& g, int 
             WJp[3 + m] = W1 * Jp[m] + W2 * Jp[3 + m];
         }
         // the pose's own block: Hpp_e - W_e W_e^T (lower triangle) and its right-hand side b_e - W_e zeta
+        int ob[3];   // the block's three rows at its first column: one multiplication, two additions
+        ob[0] = tri(c0, c0); ob[1] = ob[0] + c0 + 1; ob[2] = ob[1] + c0 + 2;
+        const int nrow = tri(c.n, 0) + c0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll
             for (int m = 0; m <= r; ++m) {
                 const double hpp = Jp[r] * WJp[m] + Jp[3 + r] * WJp[3 + m];
                 const double ww = Wm[r * 3] * Wm[m * 3] + Wm[r * 3 + 1] * Wm[m * 3 + 1] + Wm[r * 3 + 2] * Wm[m * 3 + 2];
-                lds_add(c.S + tri(c0 + r, c0 + m), hpp - ww);
+                lds_add(c.S + ob[r] + m, hpp - ww);
             }
             const double bpe = Jp[r] * or0 + Jp[3 + r] * or1;
-            lds_add(c.S + tri(c.n, c0 + r), bpe - (Wm[r * 3] * zt[0] + Wm[r * 3 + 1] * zt[1] + Wm[r * 3 + 2] * zt[2]));
+            lds_add(c.S + nrow + r, bpe - (Wm[r * 3] * zt[0] + Wm[r * 3 + 1] * zt[1] + Wm[r * 3 + 2] * zt[2]));
         }
     }
     // the pair products of the landmark's observations: every lane puts W_e and its column into the wave's strip, lane i then takes
     // the partners (i + s) mod k, s = 1 .. k / 2 (the pairs at distance k / 2 of an even k only from the lower half)
-    double* mine = c.stage + (size_t)lane * kStageDoubles;
+    double* mine = c.stage + lane * kStageDoubles;   // (32-bit index arithmetic: LDS)
 #pragma unroll
     for (int i = 0; i < 9; ++i) mine[i] = Wm[i];
     mine[9] = (double)c0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // (the strip is this wave's alone and a wave's LDS operations execute in the order they were issued: what the other lanes wrote
+    // is there when the reads below arrive - only the compiler has to keep the order)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    asm volatile("" ::: "memory");
     const int half = k >> 1;
     int smax = half;
 #pragma unroll
     for (int m = G; m < 64; m <<= 1) smax = max(smax, __shfl_xor(smax, m));   // the wave's longest landmark sets the trip count
     const int gbase = lane & ~(G - 1);
-    for (int s = 1; s <= smax; ++s) {
-        const bool act = has && s <= half && !(2 * s == k && sub >= half);
+    // the partner of step s + 1 is requested BEFORE the atomics of step s go out: its products then run while those drain (the LDS
+    // serves a wave's operations in order - a read issued behind nine atomics waits for all of them)
+    double Wn[10];
+    auto partner = [&](int s, bool& act) {
+        act = has && s <= half && !(2 * s == k && sub >= half);
         int j = sub + s;
         if (j >= k) j -= k;
-        const double* his = c.stage + (size_t)(gbase + (act ? j : sub)) * kStageDoubles;
+        const double* his = c.stage + (gbase + (act ? j : sub)) * kStageDoubles;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) Wn[i] = his[i];
+    };
+    bool act_n = false;
+    if (smax >= 1) partner(1, act_n);
+    for (int s = 1; s <= smax; ++s) {
+        const bool act = act_n;
         double Wp[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Wp[i] = his[i];
-        const int cp = (int)his[9];
+        for (int i = 0; i < 9; ++i) Wp[i] = Wn[i];
+        const int cp = (int)Wn[9];
+        if (s < smax) partner(s + 1, act_n);
         if (act && fr && cp >= 0) {
             // block (mine, his) of S loses W_mine W_his^T; it is stored where row > column.  (Two observations of one landmark by
             // the SAME key frame - the reference never builds that - land in the pose's own block: P + P^T, lower triangle.)
+            // One multiplication for the block's place - the first of its three rows, the others follow by additions - and one
+            // select per entry between "my rows, his columns" and the transposed place.
             const bool lower = c0 > cp, same = c0 == cp;
+            const int hi = lower ? c0 : cp, lo = lower ? cp : c0;
+            int rb[3];
+            rb[0] = tri(hi, lo); rb[1] = rb[0] + hi + 1; rb[2] = rb[1] + hi + 2;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     double pr = Wm[r * 3] * Wp[m * 3] + Wm[r * 3 + 1] * Wp[m * 3 + 1] + Wm[r * 3 + 2] * Wp[m * 3 + 2];
-                    int at = lower ? tri(c0 + r, cp + m) : tri(cp + m, c0 + r);
-                    if (same) { at = tri(c0 + max(r, m), c0 + min(r, m)); if (r == m) pr *= 2.0; }
+                    int at = rb[r] + m;                                   // r == m: the same place either way
+                    if (r > m) at = (lower || same) ? rb[r] + m : rb[m] + r;
+                    if (r < m) at = lower ? rb[r] + m : rb[m] + r;        // (same: not lower, row m = max(r, m))
+                    if (r == m && same) pr *= 2.0;
                     lds_add(c.S + at, -pr);
                 }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();   // (the next landmark's strip writes stay behind these reads)
+    asm volatile("" ::: "memory");
 }
 
 // the landmarks [begin, end) of the list, G lanes each; the next group's operands and the descriptor after that are in flight while
