@@ -97,15 +97,32 @@ __device__ inline void huber(double e2, double delta, double& rho0, double& rho1
     }
 }
 
-__device__ inline double group_sum(double v) {  // sum over an aligned group of kGroup lanes
-#pragma unroll
-    for (int m = 1; m < kGroup; m <<= 1) v += __shfl_xor(v, m);
+// Butterfly sums on DPP moves (no trip through the LDS crossbar, no wait): the partner of the first two steps is lane ^ 1, lane ^ 2;
+// from then on every lane of a quad (of eight, of sixteen) holds the same partial sum, so ANY lane of the other half is the partner
+// of lane ^ 4 (lane ^ 8) - the mirrors 7 - lane and 15 - lane are such lanes.  Bit for bit what the shuffles by xor gave.
+template <int CTRL>
+__device__ __forceinline__ double dpp_partner(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ inline double group_sum(double v) {  // sum over an aligned group of kGroup = 8 lanes
+    static_assert(kGroup == 8, "three butterfly steps");
+    v += dpp_partner<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_partner<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_partner<0x141>(v);   // row_half_mirror
     return v;
 }
 
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    v += dpp_partner<0xB1>(v);
+    v += dpp_partner<0x4E>(v);
+    v += dpp_partner<0x141>(v);
+    v += dpp_partner<0x140>(v);   // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
     return v;
 }
 
