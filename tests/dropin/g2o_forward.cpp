@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <chrono>
 
 #include <opencv2/core/core.hpp>
 #include <g2o_shim.hpp>
@@ -28,6 +29,8 @@
 namespace {
 struct LastBA { double v[10]; };
 LastBA g_last{};
+double g_ms[4] = {0, 0, 0, 0};   // the last forward(): replay in, initialize, optimize, write back (ms) - a probe's aid (SE2_DROPIN_TIMES)
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 se2gpu_track* g_track = nullptr;
 
 // returns false when the graph is not the SE(2)-XYZ local window (other optimisations of the reference are not driven here)
@@ -35,6 +38,7 @@ bool forward(g2o::SparseOptimizer& opt, int iterations) {
     namespace amd = se2lam_amd;
     for (const auto& kv : opt.vertices())
         if (!dynamic_cast<const g2o::VertexSE2*>(kv.second) && !dynamic_cast<const g2o::VertexSBAPointXYZ*>(kv.second)) return false;
+    const double t0 = now_ms();
     amd::SlamOptimizer dev;   // se2gpu_ba_create: the handle comes from the library's pool (LocalMapper.cpp:239 builds one per localBA)
     dev.setVerbose(opt.verbose());
     dev.setForceStopFlag(opt.forceStopFlag());
@@ -71,13 +75,20 @@ bool forward(g2o::SparseOptimizer& opt, int iterations) {
             return false;
         }
     }
+    const double t1 = now_ms();
     dev.initializeOptimization(0);
+    const double t2 = now_ms();
     const int done = dev.optimize(iterations);
+    const double t3 = now_ms();
     for (const auto& kv : opt.vertices()) {
         if (kv.second->fixed()) continue;
         if (g2o::VertexSE2* v = dynamic_cast<g2o::VertexSE2*>(kv.second)) v->setEstimate(amd::toG2o(amd::estimateVertexSE2(dev, kv.first)));
         else static_cast<g2o::VertexSBAPointXYZ*>(kv.second)->setEstimate(amd::toEigen(amd::estimateVertexSBAXYZ(dev, kv.first)));
     }
+    g_ms[0] = t1 - t0; g_ms[1] = t2 - t1; g_ms[2] = t3 - t2; g_ms[3] = now_ms() - t3;
+    if (std::getenv("SE2_DROPIN_TIMES"))
+        std::fprintf(stderr, "drop-in optimize(%d): replay in %.3f ms, initialize %.3f ms, optimize %.3f ms, write back %.3f ms (P %d L %d E %d)\n",
+                     iterations, g_ms[0], g_ms[1], g_ms[2], g_ms[3], P, L, E);
     const se2gpu_ba_stats& s = dev.stats();
     const double rec[10] = {(double)P, (double)L, (double)E, (double)O, s.chi2_init, s.chi2_final, (double)done, (double)s.trials,
                             s.lambda_final, (double)s.stopped};
