@@ -233,3 +233,40 @@ def test_resident_edge_cases(synth, resident):
     assert int(capi.lib().se2gpu_ba_last_batch_path()) == 2
     for g, o, (st, est) in zip(graphs, opts, ref):
         _same(o, st, est, (g.P, g.L, g.E, int(np.asarray(g.fixed).sum())))
+
+
+def test_a_batch_of_distinct_windows_over_both_workgroup_widths(synth, resident):
+    """24 windows of 30-60 key frames (distinct sizes and seeds, some starts that reject trials): the batch is dealt to the 512- and
+    the 256-thread launches, every window decides like its multi-launch run, costs and poses to 1e-9"""
+    from se2lam_amd import capi
+    from se2lam_amd.optimizer import optimize_batch
+    graphs = synth.mixed_windows(24, p_range=(30, 60), l_range=(300, 900), kidnapped_every=5)
+    assert min(g.P for g in graphs) < 40 and max(g.P for g in graphs) >= 58          # both widths are in the batch
+    ref = [_multi_launch(g, 8) for g in graphs]
+    opts = [_opt(g) for g in graphs]
+    optimize_batch(opts, 8)
+    assert int(capi.lib().se2gpu_ba_last_batch_path()) == 2
+    for g, o, (st, est) in zip(graphs, opts, ref):
+        _same(o, st, est, (g.P, g.L, g.E))
+
+
+def test_a_window_without_room_for_the_record_copy_is_left_to_the_other_paths(synth, resident):
+    """the kernel keeps its list of landmarks and its copy of the observations in the idle W buffer of the multi-launch path (72 B per
+    observation): a window with far more landmarks than observations has no room there - the call runs it elsewhere, bit for bit
+    (unless the handle comes out of the library's pool with a buffer that grew on an earlier, larger window)"""
+    import copy
+    from se2lam_amd import capi
+    from se2lam_amd.optimizer import optimize_batch
+    g = copy.copy(synth.ba_graph(10, 400))
+    e_lm = np.asarray(g.e_lm)
+    keep = e_lm % 8 == 0                                   # seven landmarks in eight lose all their observations
+    g.e_kf, g.e_lm = np.asarray(g.e_kf)[keep], e_lm[keep]
+    g.e_uv, g.e_info = np.asarray(g.e_uv)[keep], np.asarray(g.e_info)[keep]
+    assert 16 * g.L + 44 * int(keep.sum()) > 72 * int(keep.sum())
+    st, est = _multi_launch(g, 6)
+    o = _opt(g)
+    optimize_batch([o], 6)
+    if int(capi.lib().se2gpu_ba_last_batch_path()) == 2:
+        _same(o, st, est, "a handle from the pool whose buffer had grown on a larger window before: room after all")
+    else:
+        assert o.stats == st and np.array_equal(o.estimates()[0], est[0])
