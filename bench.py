@@ -336,7 +336,7 @@ def main():
             "traffic_stale": _traffic_of(traffic, dom)[1],
             "algorithmic_bytes_per_launch": B_dom, "avg_launch_us": kern[dom]["avg_us"],
             "note": ("the dominant kernel is the dense pose solve: a 600-column dependency chain, bound by FP64 / LDS "
-                     "latency and inter-workgroup hand-offs, not by bandwidth (DESIGN.md 4.1.1)"
+                     "latency and inter-workgroup hand-offs, not by bandwidth (DESIGN.md 4.1, 7)"
                      if dom.startswith("k_chol") else None),
             "whole_step_achieved": B_ba * iters_per_s / 1e9,
             "whole_step_frac": B_ba * iters_per_s / 1e9 / HBM_PEAK_GBS,
@@ -409,6 +409,7 @@ def main():
                        # the other two legs' headline figures, where a reader of `parsed` finds them (their full objects follow below)
                        "orb_frames_per_s": (orb_obj or {}).get("value"),
                        "orb_roofline_frac": ((orb_obj or {}).get("roofline") or {}).get("frac"),
+                       "orb_valu_issue_frac": (((orb_obj or {}).get("roofline") or {}).get("valu") or {}).get("frac"),
                        "orb_whole_step_frac": ((orb_obj or {}).get("roofline") or {}).get("whole_step_frac"),
                        "ba_windows_iters_per_s": (windows_obj or {}).get("value"),
                        "ba_windows_in_flight": ((windows_obj or {}).get("best") or {}).get("windows_per_gpu"),

@@ -994,7 +994,7 @@ __device__ inline d2_t load_agent(const double* p) {
 // (s_nop: a VMEM store of more than 64 bits reads its data a few cycles after issue, and a VALU write to those VGPRs in
 // the next instruction would change what is stored.  The compiler's hazard recogniser does not see through inline asm, so
 // the wait states are part of the instruction here - found with a temporary in the upper half of the operand, see the
-// express-copy experiment in DESIGN.md 4.1.1.)
+// express-copy experiment in docs/history/DESIGN_rounds_1-5.md 4.1.1.)
 __device__ inline void store_agent(double* p, d2_t v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
