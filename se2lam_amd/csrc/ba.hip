@@ -6146,7 +6146,6 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
     SE2_CHECK(rs.dev.reserve((size_t)count));
     static const bool trace = [] { const char* e = getenv("SE2GPU_BA_RESIDENT_TRACE"); return e && e[0] == '1'; }();
     if (trace) SE2_CHECK(rs.stamps.reserve(16 * (size_t)count));
-    const char* e_dbg = getenv("SE2GPU_BA_RESIDENT_DEBUG");
     std::vector<hipStream_t> class_streams;
     int threads = 0;
     size_t lds = 0;
@@ -6181,7 +6180,7 @@ int ba_optimize_resident(se2gpu_ba** hs, int count, int iters, int mode, const v
         a.stop = h->d_stop;
         a.desc = reinterpret_cast<int4*>(h->Hpl.p);   // (the multi-launch path's W records: 72 B per edge, idle on this path; the list + the records by class)
         a.ainv = h->Dinv.p;   // (the multi-launch path's A_l: 6 L + 1 doubles, idle on this path)
-        a.debug = e_dbg ? atoi(e_dbg) : 0;
+        a.debug = 0;
         a.stamps = trace ? rs.stamps.p + 16 * (size_t)k : nullptr;
     }
     {

@@ -28,7 +28,7 @@ struct WindowArgs {
     int4* desc;               // scratch: the kernel lists the landmarks by their observation counts here (L x 16 B) and copies the
                               // observations into that order behind the list (E x 44 B)
     double* ainv;             // L x 6 of scratch: the build pass leaves every landmark's factor A here (list order) for the update pass
-    int debug;
+    int debug;                // (unused: the run-time debug switch is gone, the field keeps the pack's layout)
     long long* stamps;        // debug: 16 phase time stamps (100 MHz wall clock) of the LAST trial, or NULL
 };
 
