@@ -12,20 +12,22 @@
 // iterations/s.  A 50-key-frame window is small enough to LIVE in one compute unit: the lower triangle of the
 // reduced system S (147 unknowns: 87 KB) fits the 160 KiB of LDS.  So here a workgroup owns a window for its whole
 // optimize(iters): the poses, S, the right-hand sides and the solution never leave LDS, the LM controller runs in the
-// workgroup, and nothing per edge is ever written to memory:
-//   BUILD   the edges stream in once (44 B each), 8 lanes per landmark: residual, Jacobians, Huber weight, Hll / bl by a
-//           DPP butterfly inside the group, the 3x3 factor A = G^-1 of Hll + lambda I, W_e = Hpl_e A^T in registers; the
-//           pose blocks Hpp_e - W_e W_e^T and b_e - W_e zeta go to S / b_s by LDS atomics (ds_add_f64), the pair products
-//           W_i W_j^T of a landmark's observations through a per-wave staging strip (each pair once: lane i takes the
-//           partners i + 1 .. i + k/2 cyclically)
+// workgroup, and nothing per edge and trial is written to memory:
+//   OPEN    (once per optimize) the landmarks are listed by observation count, and one pass gives chi^2 of the starting state,
+//           the diagonal for lambda_0 and a copy of the observations in the order of that list (whole cache lines from then on)
+//   BUILD   the observations stream in once (44 B each), one lane each, 4 / 8 / 16 / 64 lanes per landmark by its count: residual,
+//           Jacobians, Huber weight, Hll / bl by a DPP butterfly inside the group, the 3x3 factor A = G^-1 of Hll + lambda I,
+//           W_e = Hpl_e A^T in registers; the pose blocks Hpp_e - W_e W_e^T and b_e - W_e zeta go to S / b_s by LDS atomics
+//           (ds_add_f64), the pair products W_i W_j^T of a landmark's observations through a per-wave staging strip (each pair
+//           once: lane i takes the partners i + 1 .. i + k/2 cyclically); A (48 B per landmark) is left in memory for UPDATE
 //   SOLVE   left-looking LL^T on 3x3 blocks in LDS with the right-hand side as an extra row (the forward substitution comes
-//           with the factorisation), 8 lanes share a block's dot product; x = L^-T y by one wave, y in registers
-//   UPDATE  the edges stream in a second time: the linearisation is RECOMPUTED (flops are free here, bytes are not) for the
-//           back-substitution x_l = A^T (zeta - sum_e W_e^T dp_e), the trial landmark goes to the other estimate buffer,
+//           with the factorisation), 8-64 lanes share a block's dot product; x = L^-T y by one wave, y in registers
+//   UPDATE  the observations stream in a second time: the Jacobians are RECOMPUTED (nothing per edge is kept) for the
+//           back-substitution x_l = A^T (A (bl - sum_e Hlp_e dp_e)), the trial landmark goes to the other estimate buffer,
 //           robust chi^2 at the trial state, the gain denominator; then g2o's accept / reject on the controller block
-// Per LM trial a window reads its observations twice and writes its landmarks once; the prologue copies the observations into the
-// order the passes visit them in (class by class, see k_window_lm), so that every pass reads whole cache lines.  Measured (PMC,
-// tools/resident_pmc.sh): 4.4 MB per window and LM iteration = 2.6x the algorithmic 1.66 MB, where the multi-launch path moves 26 MB.  Sums into S are atomic, hence in no fixed order: results agree with the multi-launch path and the oracle to
+// Per LM trial a window reads its observations twice, writes and reads A once and writes its landmarks once.  Measured (PMC,
+// tools/resident_pmc.sh): 4.6 MB per window and LM iteration = 2.8x the algorithmic 1.66 MB, where the multi-launch path moves 26 MB.
+// Sums into S are atomic, hence in no fixed order: results agree with the multi-launch path and the oracle to
 // rounding (1e-12 relative on the cost), not bit for bit - the parity bar of this path is north_star's 1e-5.
 //
 // A landmark with more than 64 observations is refused (BaCtl::error = 2: the caller runs the window on the multi-launch path).
